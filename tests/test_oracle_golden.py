@@ -1,0 +1,190 @@
+"""CPU: pin the oracle (oracle/) against outputs of the reference itself (tests/golden/*.npz, produced by
+tests/golden/make_golden.py from the imported reference).  Runs anywhere, no GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from oracle import detr as O
+from oracle import loss as OL
+from oracle import msda as OM
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+@pytest.mark.parametrize("tag,dt,tol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 2e-5)])
+def test_msda_forward_backward_vs_reference(golden_dir, case, tag, dt, tol):
+    g = _load(golden_dir, "msda.npz")
+    c = json.loads(str(g[f"{case}_case"]))
+    x = W.make_msda_inputs(c["seed"], c["B"], c["Lq"], c["M"], c["D"], [tuple(s) for s in c["shapes"]], c["P"], dtype=dt)
+    out = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert (out - _t(g[f"{case}_{tag}_out"])).abs().max() < tol
+    out_gs = OM.msda_forward_grid_sample(x["value"], x["shapes"], x["loc"], x["attn"])
+    assert (out_gs - _t(g[f"{case}_{tag}_out"])).abs().max() < tol
+    gv, gl, ga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"])
+    assert (gv - _t(g[f"{case}_{tag}_grad_value"])).abs().max() < tol * 10
+    assert (ga - _t(g[f"{case}_{tag}_grad_attn"])).abs().max() < tol * 10
+    # grad_loc carries a factor W/H: scale tolerance
+    assert (gl - _t(g[f"{case}_{tag}_grad_loc"])).abs().max() < tol * 200
+
+
+def test_msda_scalar_loops_agree(golden_dir):
+    g = _load(golden_dir, "msda.npz")
+    c = json.loads(str(g["b_case"]))
+    x = W.make_msda_inputs(c["seed"], c["B"], c["Lq"], c["M"], c["D"], [tuple(s) for s in c["shapes"]], c["P"], dtype=torch.float64)
+    out = OM.msda_forward_scalar(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert (out - _t(g["b_f64_out"])).abs().max() < 1e-12
+
+
+def test_msda_edge_cases():
+    # every sample out of range -> zeros; exact pixel centres reproduce the pixel value
+    shapes = [(4, 5), (2, 3)]
+    x = W.make_msda_inputs(3, 1, 6, 2, 8, shapes, 2, dtype=torch.float64)
+    loc = torch.full_like(x["loc"], 3.0)
+    out = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc, x["attn"])
+    assert out.abs().max() == 0
+    gv, gl, ga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], loc, x["attn"], x["grad_out"])
+    assert gv.abs().max() == 0 and gl.abs().max() == 0 and ga.abs().max() == 0
+    loc = torch.zeros_like(x["loc"])
+    loc[..., 0, :, 0] = (2 + 0.5) / 5
+    loc[..., 0, :, 1] = (1 + 0.5) / 4
+    loc[..., 1, :, 0] = (1 + 0.5) / 3
+    loc[..., 1, :, 1] = (0 + 0.5) / 2
+    attn = torch.full_like(x["attn"], 0.25)
+    out = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc, attn).reshape(1, 6, 2, 8)
+    expect = 0.5 * x["value"][0, 1 * 5 + 2] + 0.5 * x["value"][0, 20 + 0 * 3 + 1]
+    assert (out[0, 0] - expect).abs().max() < 1e-12
+
+
+def test_decoder_self_attention_vs_reference(golden_dir):
+    g = _load(golden_dir, "mha.npz")
+    shapes = json.loads(str(g["shapes"]))
+    sd = {"attn." + k: v for k, v in W.fill_state_dict(shapes, seed=int(g["seed"])).items()}
+    out, q, k = O.decoder_self_attention(sd, "attn", _t(g["x"]), _t(g["pos"]))
+    assert (out - _t(g["out"])).abs().max() < 2e-5
+    assert (q - _t(g["q"])).abs().max() < 1e-5
+    assert (k - _t(g["k"])).abs().max() < 1e-5
+
+
+def _small(golden_dir):
+    g = _load(golden_dir, "sgg_small.npz")
+    cfg = json.loads(str(g["cfg"]))
+    shapes = json.loads(str(g["shapes"]))
+    sd = W.fill_state_dict(shapes, seed=int(g["seed"]))
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg["num_labels"], cfg["num_rel_labels"]), cfg["freq_bias_eps"])
+    rng = W.rng_inputs(int(g["input_seed"]))
+    B, H, Wd = 2, int(g["H"]), int(g["W"])
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    vh, vw = [int(v) for v in g["valid1"]]
+    pm[1, vh:, :] = 0
+    pm[1, :, vw:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    cfg = O_cfg(cfg)
+    targets = W.make_targets(int(g["target_seed"]), B, cfg["num_queries"], cfg["num_labels"], cfg["num_rel_labels"])
+    return g, cfg, sd, pv, pm, targets
+
+
+def O_cfg(cfg):
+    c = dict(d_model=256, num_feature_levels=4, encoder_attention_heads=8, bbox_cost=5, giou_cost=2,
+             bbox_loss_coefficient=5, giou_loss_coefficient=2, focal_alpha=0.25)
+    c.update(cfg)
+    return c
+
+
+def test_full_model_forward_vs_reference(golden_dir):
+    g, cfg, sd, pv, pm, _ = _small(golden_dir)
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+    tol = 2e-4
+    assert (out["encoder_last_hidden_state"] - _t(g["enc"])).abs().max() < tol
+    assert (out["intermediate_hidden_states"] - _t(g["inter"])).abs().max() < tol
+    assert (out["init_reference_points"] - _t(g["init_ref"])).abs().max() < 1e-6
+    assert (torch.stack(out["decoder_attention_queries"]) - _t(g["q"])).abs().max() < tol
+    assert (torch.stack(out["decoder_attention_keys"]) - _t(g["k"])).abs().max() < tol
+    assert (out["logits"] - _t(g["logits"])).abs().max() < tol
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < tol
+    assert (out["conn_logits"] - _t(g["conn_logits"])).abs().max() < tol
+    assert (out["pred_rel"] - _t(g["pred_rel"])).abs().max() < tol
+    assert (out["pred_connectivity"] - _t(g["pred_connectivity"])).abs().max() < tol
+    # pre-sigmoid relation logits = MLP output + freq bias gathered at argmax classes (egtr:405-413)
+    node = out["logits"].argmax(-1)
+    bias = torch.stack([sd["triplet_dist"][node[i]][:, node[i]] for i in range(2)], 0)
+    assert (out["rel_logits"] - bias - _t(g["rel_mlp"])).abs().max() < tol
+
+
+def test_matcher_indices_bit_exact(golden_dir):
+    g, cfg, sd, pv, pm, targets = _small(golden_dir)
+    idx, costs = OL.hungarian_match(_t(g["logits"]), _t(g["pred_boxes"]), targets, cfg["ce_loss_coefficient"],
+                                    cfg["bbox_cost"], cfg["giou_cost"], cfg["smoothing"])
+    for i, ((a, b), c) in enumerate(zip(idx, costs)):
+        assert np.array_equal(a.numpy(), g[f"match_pred_{i}"])
+        assert np.array_equal(b.numpy(), g[f"match_tgt_{i}"])
+        assert np.abs(c.numpy() - g[f"match_cost_{i}"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_loss_vs_reference(golden_dir, training):
+    g, cfg, sd, pv, pm, targets = _small(golden_dir)
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+    total, ld, _, _ = OL.sgg_loss(out, targets, cfg, training=training)
+    key = "train" if training else "eval"
+    ref = json.loads(str(g[f"{key}_loss_dict"]))
+    assert set(ref) == set(ld), (sorted(ref), sorted(ld))
+    for k, v in ref.items():
+        assert abs(float(ld[k]) - v) < 2e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
+    assert abs(float(total) - float(g[f"{key}_loss"])) < 2e-4 * abs(float(g[f"{key}_loss"]))
+
+
+def test_aux_loss_vs_reference(golden_dir):
+    g, cfg, sd, pv, pm, targets = _small(golden_dir)
+    ga = _load(golden_dir, "sgg_small_aux.npz")
+    cfg = O_cfg(json.loads(str(ga["cfg"])))
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+    total, ld, _, _ = OL.sgg_loss(out, targets, cfg, training=True)
+    ref = json.loads(str(ga["train_loss_dict"]))
+    assert set(ref) == set(ld), (sorted(set(ref) ^ set(ld)))
+    for k, v in ref.items():
+        assert abs(float(ld[k]) - v) < 2e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
+    assert abs(float(total) - float(ga["train_loss"])) < 2e-4 * abs(float(ga["train_loss"]))
+
+
+def full_case(golden_dir):
+    g = _load(golden_dir, "sgg_full.npz")
+    cfg = O_cfg(json.loads(str(g["cfg"])))
+    shapes = json.loads(str(g["shapes"]))
+    sd = W.fill_state_dict(shapes, seed=int(g["seed"]))
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg["num_labels"], cfg["num_rel_labels"]), cfg["freq_bias_eps"])
+    rng = W.rng_inputs(int(g["input_seed"]))
+    pv = torch.from_numpy(rng.standard_normal((1, 3, 600, 1000))).float()
+    pm = torch.ones(1, 600, 1000, dtype=torch.long)
+    return g, cfg, sd, pv, pm
+
+
+def test_full_size_600x1000_vs_reference(golden_dir):
+    """BASELINE config 2 shape (N=200, 6 enc / 6 dec, C=150, R=50) with the stub backbone."""
+    g, cfg, sd, pv, pm = full_case(golden_dir)
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+    tol = 5e-4
+    assert (out["logits"] - _t(g["logits"])).abs().max() < tol
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < tol
+    assert (out["last_hidden_state"] - _t(g["last_hidden"])).abs().max() < tol
+    assert (out["encoder_last_hidden_state"][:, ::37] - _t(g["enc_strided"])).abs().max() < tol
+    node = out["logits"].argmax(-1)
+    bias = sd["triplet_dist"][node[0]][:, node[0]][None]
+    assert ((out["rel_logits"] - bias)[:, ::5, ::7] - _t(g["rel_mlp_strided"])).abs().max() < tol
+    assert (out["conn_logits"][..., 0] - _t(g["conn_logits"])).abs().max() < tol
+    assert abs(out["pred_rel"].double().sum().item() - float(g["pred_rel_sum"])) < 1.0
