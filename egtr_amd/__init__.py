@@ -1,0 +1,14 @@
+"""egtr_amd -- MI355X (gfx950) native hot path of EGTR scene-graph generation.
+
+Layout:
+  csrc/               hand-written HIP kernels + the C ABI (include/egtr_hip.h) -> libegtr_hip.so
+  _lib.py             ctypes binding of that C ABI (fails loudly if the library is missing)
+  load_custom.py      drop-in for the reference's model/load_custom.py: returns an object exposing
+                      ms_deform_attn_forward / ms_deform_attn_backward with the reference's pybind signatures
+  ops.py              autograd bridges (MSDA, decoder self-attention core, relation head)
+  deformable_detr.py  host-side mirror of the reference's model/deformable_detr.py module API
+  egtr.py             host-side mirror of model/egtr.py (DetrForSceneGraphGeneration, SceneGraphGenerationLoss)
+  util.py             loss helpers (mirror of model/util.py)
+  runtime.py          one-process-per-GPU data-parallel helpers (RCCL via torch.distributed), HIP-graph capture
+"""
+__version__ = "0.1.0"

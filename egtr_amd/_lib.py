@@ -1,0 +1,60 @@
+"""ctypes binding of libegtr_hip.so (C ABI: include/egtr_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved, importing a kernel
+entry point raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C egtr_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libegtr_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+# name -> argtypes (restype is always int status unless listed in _RESTYPES)
+SIGNATURES = {
+    "egtr_abi_version": [],
+    "egtr_status_string": [_I],
+    "egtr_last_hip_error": [],
+    "egtr_msda_forward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "egtr_msda_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "egtr_msda_forward_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "egtr_self_attn_forward_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "egtr_self_attn_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
+}
+_RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p}
+
+_lib = None
+
+
+class EgtrHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises EgtrHipError if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EgtrHipError(
+                f"{LIB_PATH} not found: the HIP extension has not been built "
+                "(run `make -C egtr_amd/csrc` or __graft_entry__.build()). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing -> loud
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, ctypes.c_int)
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        h = lib()
+        msg = h.egtr_status_string(status).decode()
+        if status == -2:
+            msg += ": " + h.egtr_last_hip_error().decode()
+        raise EgtrHipError(f"{what} failed: {msg} (status {status})")

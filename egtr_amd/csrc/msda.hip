@@ -1,0 +1,564 @@
+// Multi-scale deformable attention (MSDA) for gfx950 / CDNA4 -- forward and backward.
+//
+// What it computes (reference: model/custom_kernel/cuda/ms_deform_im2col_cuda.cuh, formulas restated in
+// SURVEY.md Appendix B):
+//   out[b,q,m,:] = sum_{l<L} sum_{p<P} attn[b,q,m,l,p] * bilinear(value_l[b,:,m,:], loc[b,q,m,l,p]*(W_l,H_l) - 0.5)
+// with zero contribution from samples outside (-1,H)x(-1,W) and from individual out-of-range corners.
+//
+// Design (NOT the reference's one-thread-per-output-element / D-thread-block scheme):
+//   * one 64-lane wavefront owns one query: lane = (head m = lane>>3, channel quad c4 = lane&7), so a group of
+//     8 lanes reads one aligned 128-byte line (32 fp32 channels of one head of one pixel) per bilinear corner
+//     with a single global_load_dwordx4, and the 8 groups = the 8 heads.  (M = 8, D = 32, L*P = 16.)
+//   * the query's 256 location floats and 128 attention weights are fetched once, coalesced (1 KiB + 512 B per
+//     wave): lane i computes the sample geometry of head i>>3, samples 2*(i&7) and 2*(i&7)+1, and stages
+//     per-sample records {4 clamped corner byte-offsets, 4 (bilinear x attention) weights} in LDS;
+//     the gather loop then reads each record with two broadcast ds_read_b128 per sample.
+//   * workgroup -> query mapping is XCD-aware: consecutive blockIdx values round-robin over the 8 XCDs, so
+//     block b is given the (b%8)-th contiguous chunk of queries; each XCD's private 4 MiB L2 then serves one
+//     horizontal stripe of every feature level instead of the whole 12.8 MB value tensor.
+//   * backward: same mapping; grad_attn / grad_loc are reduced over the 8 lanes of a head with DPP
+//     (quad_perm / row_half_mirror) instead of the reference's shared-memory serial reduce (cuh:376-393);
+//     grad_value uses hardware fp32 atomics (global_atomic_add_f32) like the reference's atomicAdd.
+//   * any other (M, D, L, P) goes through a simple generic kernel (one thread per output element).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kWaves = 4;  // waves (= queries) per workgroup in the wave-per-query kernels
+
+// Level geometry of up to four levels, held in scalar registers (plain members, never indexed dynamically,
+// so nothing is spilled to scratch).
+struct LevelGeom {
+  int H0, H1, H2, H3, W0, W1, W2, W3, s0, s1, s2, s3;
+};
+
+// Select one of four wave-uniform values by a per-lane level index.
+__device__ __forceinline__ int sel4(int a0, int a1, int a2, int a3, int l) {
+  int r = a0;
+  r = (l == 1) ? a1 : r;
+  r = (l == 2) ? a2 : r;
+  r = (l == 3) ? a3 : r;
+  return r;
+}
+#define SEL_H(G, l) sel4(G.H0, G.H1, G.H2, G.H3, l)
+#define SEL_W(G, l) sel4(G.W0, G.W1, G.W2, G.W3, l)
+#define SEL_S(G, l) sel4(G.s0, G.s1, G.s2, G.s3, l)
+
+// XCD-aware bijective remap: block b runs on XCD b%8 (observed dispatch order, used for speed only);
+// give XCD x the x-th contiguous chunk of logical work items.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+struct SampleGeom {
+  int off[4];    // byte offsets (within one batch image) of the 4 clamped corners, head+level folded in
+  float w[4];    // bilinear weights hh*hw, hh*lw, lh*hw, lh*lw
+  bool ok[4];    // per-corner in-range (and sample valid)
+  float lh, lw;
+  bool valid;
+};
+
+// Geometry of one sample (reference cuh:38-78 / 268-288).  x,y already scaled: x = loc_x*W - 0.5.
+template <int ROW_BYTES /* M*D*sizeof(elt) */, int HEAD_BYTES /* D*sizeof(elt) */>
+__device__ __forceinline__ SampleGeom sample_geom(float lx, float ly, int H, int W, int start, int head) {
+  SampleGeom g;
+  const float x = lx * (float)W - 0.5f;
+  const float y = ly * (float)H - 0.5f;
+  g.valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
+  const float yf = floorf(y), xf = floorf(x);
+  g.lh = y - yf;
+  g.lw = x - xf;
+  const float hh = 1.f - g.lh, hw = 1.f - g.lw;
+  // NaN / huge coordinates: valid == false, so every weight is zeroed; clamp keeps addresses in range.
+  int y0 = g.valid ? (int)yf : 0, x0 = g.valid ? (int)xf : 0;
+  const int y1 = y0 + 1, x1 = x0 + 1;
+  const bool y0ok = y0 >= 0, x0ok = x0 >= 0, y1ok = y1 <= H - 1, x1ok = x1 <= W - 1;
+  g.ok[0] = g.valid && y0ok && x0ok;
+  g.ok[1] = g.valid && y0ok && x1ok;
+  g.ok[2] = g.valid && y1ok && x0ok;
+  g.ok[3] = g.valid && y1ok && x1ok;
+  g.w[0] = hh * hw;
+  g.w[1] = hh * g.lw;
+  g.w[2] = g.lh * hw;
+  g.w[3] = g.lh * g.lw;
+  const int y0c = max(y0, 0), x0c = max(x0, 0), y1c = min(y1, H - 1), x1c = min(x1, W - 1);
+  const int r0 = (start + y0c * W) * ROW_BYTES + head * HEAD_BYTES;
+  const int r1 = (start + y1c * W) * ROW_BYTES + head * HEAD_BYTES;
+  g.off[0] = r0 + x0c * ROW_BYTES;
+  g.off[1] = r0 + x1c * ROW_BYTES;
+  g.off[2] = r1 + x0c * ROW_BYTES;
+  g.off[3] = r1 + x1c * ROW_BYTES;
+  return g;
+}
+
+__device__ __forceinline__ void load_geom(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                                          int L, LevelGeom& g) {
+  const int l1 = (1 < L) ? 1 : 0, l2 = (2 < L) ? 2 : 0, l3 = (3 < L) ? 3 : 0;
+  g.H0 = (int)shapes[0];
+  g.W0 = (int)shapes[1];
+  g.s0 = (int)lsi[0];
+  g.H1 = (int)shapes[2 * l1];
+  g.W1 = (int)shapes[2 * l1 + 1];
+  g.s1 = (int)lsi[l1];
+  g.H2 = (int)shapes[2 * l2];
+  g.W2 = (int)shapes[2 * l2 + 1];
+  g.s2 = (int)lsi[l2];
+  g.H3 = (int)shapes[2 * l3];
+  g.W3 = (int)shapes[2 * l3 + 1];
+  g.s3 = (int)lsi[l3];
+}
+
+// LDS record layout: [wave][head][sample] 16-byte entries, head stride padded by one entry so that the four
+// heads served together by one ds_read_b128 lane group land on distinct banks (MI355X_MICROARCH.md, LDS).
+constexpr int kHeadStride = 17;                 // entries (16 samples + 1 pad)
+constexpr int kWaveEntries = 8 * kHeadStride;   // per array per wave
+
+// ------------------------------------------------------------------------------------------------ forward
+// fp32, M = 8, D = 32, L*P = 16 (L <= 4).  One wave per query, kWaves queries per workgroup.
+__global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
+    int Lq, int S, int L, int P, int nblk) {
+  __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
+  __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * kWaveEntries];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  const int q = blk * kWaves + wave;
+  if (q >= nq_total) return;  // wave-uniform; no workgroup barrier below
+  LevelGeom G;
+  load_geom(shapes, lsi, L, G);
+  const int b = q / Lq;
+  const char* vbase = reinterpret_cast<const char*>(value) + (size_t)b * S * (256 * 4);
+
+  // stage 1: lane i -> head i>>3, samples 2*(i&7), 2*(i&7)+1
+  const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
+  const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
+  const int head_s = lane >> 3, s0 = (lane & 7) * 2;
+  int4* my_off = s_off + wave * kWaveEntries;
+  float4* my_w = s_w + wave * kWaveEntries;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int s = s0 + j;
+    const int lvl = s / P;
+    const SampleGeom g = sample_geom<1024, 128>(j ? lc.z : lc.x, j ? lc.w : lc.y, SEL_H(G, lvl), SEL_W(G, lvl),
+                                                SEL_S(G, lvl), head_s);
+    const float a = j ? aw.y : aw.x;
+    my_off[head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
+    my_w[head_s * kHeadStride + s] = make_float4(g.ok[0] ? g.w[0] * a : 0.f, g.ok[1] ? g.w[1] * a : 0.f,
+                                                 g.ok[2] ? g.w[2] * a : 0.f, g.ok[3] ? g.w[3] * a : 0.f);
+  }
+  // LDS ops of one wave execute in order; the fences only stop the compiler from reordering across lanes.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // stage 2: lane -> (head = lane>>3, channel quad = lane&7)
+  const int head = lane >> 3;
+  const char* vlane = vbase + (lane & 7) * 16;
+  const int4* ro = my_off + head * kHeadStride;
+  const float4* rw = my_w + head * kHeadStride;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    const int4 o = ro[s];
+    const float4 w = rw[s];
+    const float4 v0 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.x);
+    const float4 v1 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.y);
+    const float4 v2 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.z);
+    const float4 v3 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.w);
+    acc.x += w.x * v0.x + w.y * v1.x + w.z * v2.x + w.w * v3.x;
+    acc.y += w.x * v0.y + w.y * v1.y + w.z * v2.y + w.w * v3.y;
+    acc.z += w.x * v0.z + w.y * v1.z + w.z * v2.z + w.w * v3.z;
+    acc.w += w.x * v0.w + w.y * v1.w + w.z * v2.w + w.w * v3.w;
+  }
+  reinterpret_cast<float4*>(out + (size_t)q * 256)[lane] = acc;
+}
+
+// bf16 storage, fp32 accumulate; M = 8, D = 32, L*P = 16: a head row is 64 bytes = 4 lanes x 16 B, so one wave
+// owns TWO queries (lanes 0-31 / 32-63), lane = (query half, head = (lane>>2)&7, channel octet = lane&3).
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  // round-to-nearest-even (inputs are finite sums)
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua += 0x7fffu + ((ua >> 16) & 1u);
+  ub += 0x7fffu + ((ub >> 16) & 1u);
+  return (ua >> 16) | (ub & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
+    const uint16_t* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attn, uint16_t* __restrict__ out, int nq_total,
+    int Lq, int S, int L, int P, int nblk) {
+  __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * 2 * kWaveEntries];
+  __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * 2 * kWaveEntries];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  const int qpair = (blk * kWaves + wave) * 2;
+  if (qpair >= nq_total) return;
+  LevelGeom G;
+  load_geom(shapes, lsi, L, G);
+  int4* my_off = s_off + wave * 2 * kWaveEntries;
+  float4* my_w = s_w + wave * 2 * kWaveEntries;
+  // stage 1: two queries x 128 (head,sample) records over 64 lanes = 4 records per lane
+#pragma unroll
+  for (int qq = 0; qq < 2; ++qq) {
+    const int q = min(qpair + qq, nq_total - 1);
+    const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
+    const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
+    const int head_s = lane >> 3, s0 = (lane & 7) * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int s = s0 + j;
+      const int lvl = s / P;
+      const SampleGeom g = sample_geom<512, 64>(j ? lc.z : lc.x, j ? lc.w : lc.y, SEL_H(G, lvl), SEL_W(G, lvl),
+                                                SEL_S(G, lvl), head_s);
+      const float a = j ? aw.y : aw.x;
+      my_off[qq * kWaveEntries + head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
+      my_w[qq * kWaveEntries + head_s * kHeadStride + s] =
+          make_float4(g.ok[0] ? g.w[0] * a : 0.f, g.ok[1] ? g.w[1] * a : 0.f, g.ok[2] ? g.w[2] * a : 0.f,
+                      g.ok[3] ? g.w[3] * a : 0.f);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int half = lane >> 5, head = (lane >> 2) & 7;
+  const int q = qpair + half;
+  const bool live = q < nq_total;
+  const int qc = live ? q : nq_total - 1;
+  const int b = qc / Lq;
+  const char* vlane = reinterpret_cast<const char*>(value) + (size_t)b * S * 512 + (lane & 3) * 16;
+  const int4* ro = my_off + half * kWaveEntries + head * kHeadStride;
+  const float4* rw = my_w + half * kWaveEntries + head * kHeadStride;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int s = 0; s < 16; ++s) {
+    const int4 o = ro[s];
+    const float4 w = rw[s];
+    const uint4 v0 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.x);
+    const uint4 v1 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.y);
+    const uint4 v2 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.z);
+    const uint4 v3 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.w);
+    const unsigned a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+    const unsigned a2[4] = {v2.x, v2.y, v2.z, v2.w}, a3[4] = {v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[2 * k] += w.x * bf16_lo(a0[k]) + w.y * bf16_lo(a1[k]) + w.z * bf16_lo(a2[k]) + w.w * bf16_lo(a3[k]);
+      acc[2 * k + 1] += w.x * bf16_hi(a0[k]) + w.y * bf16_hi(a1[k]) + w.z * bf16_hi(a2[k]) + w.w * bf16_hi(a3[k]);
+    }
+  }
+  if (live) {
+    uint4 r;
+    r.x = pack_bf16(acc[0], acc[1]);
+    r.y = pack_bf16(acc[2], acc[3]);
+    r.z = pack_bf16(acc[4], acc[5]);
+    r.w = pack_bf16(acc[6], acc[7]);
+    reinterpret_cast<uint4*>(out + (size_t)q * 256)[lane & 31] = r;
+  }
+}
+
+// Generic shapes: one thread per output element (b,q,m,c); correctness path for unusual (M, D, L, P).
+template <typename T>
+__device__ __forceinline__ float ld_elt(const T* p);
+template <>
+__device__ __forceinline__ float ld_elt<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float ld_elt<uint16_t>(const uint16_t* p) { return __uint_as_float(((unsigned)*p) << 16); }
+
+__global__ void msda_fwd_generic_f32(const float* __restrict__ value, const int64_t* __restrict__ shapes,
+                                     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
+                                     const float* __restrict__ attn, float* __restrict__ out, long long n, int S,
+                                     int M, int D, int L, int Lq, int P) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % D);
+    long long t = idx / D;
+    const int m = (int)(t % M);
+    t /= M;  // t = b*Lq + q
+    const int b = (int)(t / Lq);
+    const float* vb = value + (size_t)b * S * M * D + m * D + c;
+    const float* lp = loc + (size_t)(t * M + m) * L * P * 2;
+    const float* ap = attn + (size_t)(t * M + m) * L * P;
+    float col = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
+      for (int p = 0; p < P; ++p) {
+        const float x = lp[(l * P + p) * 2] * W - 0.5f, y = lp[(l * P + p) * 2 + 1] * H - 0.5f;
+        if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
+        const float yf = floorf(y), xf = floorf(x);
+        const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
+        const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        if (y0 >= 0 && x0 >= 0) v1 = vb[(size_t)(st + y0 * W + x0) * M * D];
+        if (y0 >= 0 && x1 <= W - 1) v2 = vb[(size_t)(st + y0 * W + x1) * M * D];
+        if (y1 <= H - 1 && x0 >= 0) v3 = vb[(size_t)(st + y1 * W + x0) * M * D];
+        if (y1 <= H - 1 && x1 <= W - 1) v4 = vb[(size_t)(st + y1 * W + x1) * M * D];
+        const float val = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+        col += val * ap[l * P + p];
+      }
+    }
+    out[idx] = col;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// Sum over the 8 lanes of a head group; every lane of the group ends with the total.
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  return v;
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
+  unsafeAtomicAdd(p + 0, v.x);
+  unsafeAtomicAdd(p + 1, v.y);
+  unsafeAtomicAdd(p + 2, v.z);
+  unsafeAtomicAdd(p + 3, v.w);
+}
+
+// fp32, M = 8, D = 32, L*P = 16.  One wave per query.  LDS record per (head, sample): three 16-byte entries:
+//   off[4] | {w-validity bits, lh, lw, attn} | {Wf, Hf, -, -}
+__global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
+    const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
+    float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, int nq_total,
+    int Lq, int S, int L, int P, int nblk) {
+  __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
+  __shared__ __attribute__((aligned(16))) float4 s_a[kWaves * kWaveEntries];   // {bits, lh, lw, attn}
+  __shared__ __attribute__((aligned(16))) float2 s_wh[kWaves * kWaveEntries];  // {W, H}
+  __shared__ __attribute__((aligned(16))) float s_gl[kWaves * 256];            // grad_loc staging
+  __shared__ __attribute__((aligned(16))) float s_ga[kWaves * 128];            // grad_attn staging
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  const int q = blk * kWaves + wave;
+  if (q >= nq_total) return;
+  LevelGeom G;
+  load_geom(shapes, lsi, L, G);
+  const int b = q / Lq;
+  const size_t boff = (size_t)b * S * (256 * 4);
+  const char* vbase = reinterpret_cast<const char*>(value) + boff;
+  char* gvbase = reinterpret_cast<char*>(grad_value) + boff;
+
+  const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
+  const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
+  const int head_s = lane >> 3, s0 = (lane & 7) * 2;
+  int4* my_off = s_off + wave * kWaveEntries;
+  float4* my_a = s_a + wave * kWaveEntries;
+  float2* my_wh = s_wh + wave * kWaveEntries;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int s = s0 + j;
+    const int lvl = s / P;
+    const int H = SEL_H(G, lvl), W = SEL_W(G, lvl);
+    const SampleGeom g = sample_geom<1024, 128>(j ? lc.z : lc.x, j ? lc.w : lc.y, H, W, SEL_S(G, lvl), head_s);
+    const int bits = (g.ok[0] ? 1 : 0) | (g.ok[1] ? 2 : 0) | (g.ok[2] ? 4 : 0) | (g.ok[3] ? 8 : 0);
+    my_off[head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
+    my_a[head_s * kHeadStride + s] = make_float4(__int_as_float(bits), g.lh, g.lw, j ? aw.y : aw.x);
+    my_wh[head_s * kHeadStride + s] = make_float2((float)W, (float)H);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const int head = lane >> 3, c4 = lane & 7;
+  const float4 g = reinterpret_cast<const float4*>(grad_out + (size_t)q * 256)[lane];
+  const int4* ro = my_off + head * kHeadStride;
+  const float4* ra = my_a + head * kHeadStride;
+  const float2* rwh = my_wh + head * kHeadStride;
+  float* gl_stage = s_gl + wave * 256;
+  float* ga_stage = s_ga + wave * 128;
+#pragma unroll 2
+  for (int s = 0; s < 16; ++s) {
+    const int4 o = ro[s];
+    const float4 a4 = ra[s];
+    const float2 wh = rwh[s];
+    const int bits = __float_as_int(a4.x);
+    const float lh = a4.y, lw = a4.z, a = a4.w, hh = 1.f - lh, hw = 1.f - lw;
+    const float m0 = (bits & 1) ? 1.f : 0.f, m1 = (bits & 2) ? 1.f : 0.f, m2 = (bits & 4) ? 1.f : 0.f,
+                m3 = (bits & 8) ? 1.f : 0.f;
+    float4 v0 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.x);
+    float4 v1 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.y);
+    float4 v2 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.z);
+    float4 v3 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.w);
+    const float w0 = hh * hw * m0, w1 = hh * lw * m1, w2 = lh * hw * m2, w3 = lh * lw * m3;
+    // top = grad_out * attn (cuh:114)
+    const float4 top = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);
+    if (bits & 1) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.x),
+                              make_float4(w0 * top.x, w0 * top.y, w0 * top.z, w0 * top.w));
+    if (bits & 2) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.y),
+                              make_float4(w1 * top.x, w1 * top.y, w1 * top.z, w1 * top.w));
+    if (bits & 4) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.z),
+                              make_float4(w2 * top.x, w2 * top.y, w2 * top.z, w2 * top.w));
+    if (bits & 8) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.w),
+                              make_float4(w3 * top.x, w3 * top.y, w3 * top.z, w3 * top.w));
+    // masked corner values (an out-of-range corner contributes 0 everywhere, cuh:121-150)
+    v0.x *= m0; v0.y *= m0; v0.z *= m0; v0.w *= m0;
+    v1.x *= m1; v1.y *= m1; v1.z *= m1; v1.w *= m1;
+    v2.x *= m2; v2.y *= m2; v2.z *= m2; v2.w *= m2;
+    v3.x *= m3; v3.y *= m3; v3.z *= m3; v3.w *= m3;
+    float ga = 0.f, gw = 0.f, gh = 0.f;
+#define EGTR_ACC(C)                                                                    \
+    {                                                                                   \
+      const float val = hh * hw * v0.C + hh * lw * v1.C + lh * hw * v2.C + lh * lw * v3.C; \
+      const float dh = -hw * v0.C - lw * v1.C + hw * v2.C + lw * v3.C;                  \
+      const float dw = -hh * v0.C + hh * v1.C - lh * v2.C + lh * v3.C;                  \
+      ga += g.C * val;                                                                  \
+      gw += dw * top.C;                                                                 \
+      gh += dh * top.C;                                                                 \
+    }
+    EGTR_ACC(x) EGTR_ACC(y) EGTR_ACC(z) EGTR_ACC(w)
+#undef EGTR_ACC
+    ga = group8_sum(ga);
+    gw = group8_sum(gw) * wh.x;  // * W (cuh:157)
+    gh = group8_sum(gh) * wh.y;  // * H (cuh:158)
+    if (c4 == 0) {
+      ga_stage[head * 16 + s] = ga;
+      gl_stage[(head * 16 + s) * 2] = gw;
+      gl_stage[(head * 16 + s) * 2 + 1] = gh;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  reinterpret_cast<float4*>(grad_loc + (size_t)q * 256)[lane] = reinterpret_cast<const float4*>(gl_stage)[lane];
+  reinterpret_cast<float2*>(grad_attn + (size_t)q * 128)[lane] = reinterpret_cast<const float2*>(ga_stage)[lane];
+}
+
+// Generic backward: one thread per (b,q,m,l,p) sample, loops over the D channels; atomics for grad_value.
+__global__ void msda_bwd_generic_f32(const float* __restrict__ grad_out, const float* __restrict__ value,
+                                     const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+                                     const float* __restrict__ loc, const float* __restrict__ attn,
+                                     float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                                     float* __restrict__ grad_attn, long long n, int S, int M, int D, int L, int Lq,
+                                     int P) {
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(idx % P);
+    long long t = idx / P;
+    const int l = (int)(t % L);
+    t /= L;
+    const int m = (int)(t % M);
+    t /= M;  // b*Lq + q
+    const int b = (int)(t / Lq);
+    const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
+    const float x = loc[idx * 2] * W - 0.5f, y = loc[idx * 2 + 1] * H - 0.5f;
+    float ga = 0.f, gw = 0.f, gh = 0.f;
+    if (y > -1.f && x > -1.f && y < (float)H && x < (float)W) {
+      const float yf = floorf(y), xf = floorf(x);
+      const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
+      const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+      const bool k0 = y0 >= 0 && x0 >= 0, k1 = y0 >= 0 && x1 <= W - 1, k2 = y1 <= H - 1 && x0 >= 0,
+                 k3 = y1 <= H - 1 && x1 <= W - 1;
+      const size_t bo = (size_t)b * S * M * D + m * D;
+      const size_t o0 = bo + (size_t)(st + y0 * W + x0) * M * D, o1 = bo + (size_t)(st + y0 * W + x1) * M * D,
+                   o2 = bo + (size_t)(st + y1 * W + x0) * M * D, o3 = bo + (size_t)(st + y1 * W + x1) * M * D;
+      const float a = attn[idx];
+      const float* go = grad_out + (size_t)(t * M + m) * D;
+      for (int c = 0; c < D; ++c) {
+        const float v0 = k0 ? value[o0 + c] : 0.f, v1 = k1 ? value[o1 + c] : 0.f, v2 = k2 ? value[o2 + c] : 0.f,
+                    v3 = k3 ? value[o3 + c] : 0.f;
+        const float top = go[c] * a;
+        if (k0) unsafeAtomicAdd(grad_value + o0 + c, hh * hw * top);
+        if (k1) unsafeAtomicAdd(grad_value + o1 + c, hh * lw * top);
+        if (k2) unsafeAtomicAdd(grad_value + o2 + c, lh * hw * top);
+        if (k3) unsafeAtomicAdd(grad_value + o3 + c, lh * lw * top);
+        ga += go[c] * (hh * hw * v0 + hh * lw * v1 + lh * hw * v2 + lh * lw * v3);
+        gw += (-hh * v0 + hh * v1 - lh * v2 + lh * v3) * top;
+        gh += (-hw * v0 - lw * v1 + hw * v2 + lw * v3) * top;
+      }
+      gw *= W;
+      gh *= H;
+    }
+    grad_attn[idx] = ga;
+    grad_loc[idx * 2] = gw;
+    grad_loc[idx * 2 + 1] = gh;
+  }
+}
+
+bool fast_shape(int M, int D, int L, int P) { return M == 8 && D == 32 && L >= 1 && L <= 4 && L * P == 16; }
+
+}  // namespace
+
+extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start_index, const float* sampling_loc,
+                                     const float* attn_weight, int batch, int spatial_size, int num_heads,
+                                     int channels, int num_levels, int num_query, int num_point, float* out) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out) return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
+      num_point <= 0)
+    return EGTR_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long nq = (long long)batch * num_query;
+  if (fast_shape(num_heads, channels, num_levels, num_point) && (long long)spatial_size * 1024 < (1ll << 31) &&
+      nq < (1ll << 30)) {
+    const int nblk = (int)((nq + kWaves - 1) / kWaves);
+    hipLaunchKernelGGL(msda_fwd_q64_f32, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
+                       num_levels, num_point, nblk);
+  } else {
+    const long long n = nq * num_heads * channels;
+    const int threads = 256;
+    const int blocks = (int)std::min<long long>((n + threads - 1) / threads, 65535ll * 16);
+    hipLaunchKernelGGL(msda_fwd_generic_f32, dim3(blocks), dim3(threads), 0, st, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, out, n, spatial_size, num_heads, channels,
+                       num_levels, num_query, num_point);
+  }
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,
+                                      const int64_t* level_start_index, const float* sampling_loc,
+                                      const float* attn_weight, int batch, int spatial_size, int num_heads,
+                                      int channels, int num_levels, int num_query, int num_point, uint16_t* out) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out) return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_query <= 0) return EGTR_E_ARG;
+  if (!fast_shape(num_heads, channels, num_levels, num_point) || (long long)spatial_size * 512 >= (1ll << 31))
+    return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long nq = (long long)batch * num_query;
+  const int nblk = (int)((nq + 2 * kWaves - 1) / (2 * kWaves));
+  hipLaunchKernelGGL(msda_fwd_q32_bf16, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+                     level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size, num_levels,
+                     num_point, nblk);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const float* value,
+                                      const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                      const float* sampling_loc, const float* attn_weight, int batch,
+                                      int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                      int num_point, float* grad_value, float* grad_sampling_loc,
+                                      float* grad_attn_weight) {
+  if (!grad_out || !value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_value ||
+      !grad_sampling_loc || !grad_attn_weight)
+    return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
+      num_point <= 0)
+    return EGTR_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long nq = (long long)batch * num_query;
+  if (fast_shape(num_heads, channels, num_levels, num_point) && (long long)spatial_size * 1024 < (1ll << 31) &&
+      nq < (1ll << 30)) {
+    const int nblk = (int)((nq + kWaves - 1) / kWaves);
+    hipLaunchKernelGGL(msda_bwd_q64_f32, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk);
+  } else {
+    const long long n = nq * num_heads * num_levels * num_point;
+    const int threads = 256;
+    const int blocks = (int)std::min<long long>((n + threads - 1) / threads, 65535ll * 16);
+    hipLaunchKernelGGL(msda_bwd_generic_f32, dim3(blocks), dim3(threads), 0, st, grad_out, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                       grad_attn_weight, n, spatial_size, num_heads, channels, num_levels, num_query, num_point);
+  }
+  return egtr_check_launch();
+}

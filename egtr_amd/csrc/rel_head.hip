@@ -1,0 +1,242 @@
+// EGTR relation head for gfx950: pairwise gate -> gated sum over slots -> two 3-layer MLPs, fused.
+//
+// Replaces model/egtr.py:366-416 (plain PyTorch in the reference), which materialises
+// relation_source [B, N, N, Ld+1, 2d] (573 MB fp32 at N = 200, Ld = 6) plus same-sized temporaries.
+//
+// Algebra (exact identities; only fp32 re-association differs -- DESIGN.md "relation head"):
+//   src[i,j,t]  = [q^[i,t] ; k^[j,t]]                      (t = decoder layer slots + the final-hidden slot)
+//   g[i,j,t]    = sigmoid(w_g . src + b_g) = sigmoid(gate_q[i,t] + gate_k[j,t])            (separable logit)
+//   W1 . sum_t g src = sum_t g[i,j,t] (uq[i,t,:] + uk[j,t,:])   with uq = W1[:, :d] q^, uk = W1[:, d:] k^
+// so the N^2 x (Ld+1) x 2d tensor never exists: live inputs are O(N (Ld+1) d), outputs O(N^2 R).
+//
+// Kernel shape: one wavefront owns 32 consecutive (i,j) pairs of ONE of the two MLPs (blockIdx.y).
+//   layer 1 (VALU): lane (pair = l&31, half = l>>5) builds the 128 hidden-1 channels {128*half + s} of its pair
+//                   directly in the register layout the MFMA wants -- no LDS round trip.
+//   layer 2 (MFMA, v_mfma_f32_32x32x2_f32, exact f32): computed transposed, h2^T = W2 h1^T, so D[row = n][col =
+//                   pair]; A = W2[n0 + (l&31)][128*half + s], B = the lane's own h1 value; 128 steps per 32-wide
+//                   n tile.  Bias + ReLU on the accumulator.
+//   layer 3: relation MLP: rel^T = W3 h2^T again on MFMA, consuming the accumulator registers of layer 2 as the
+//            B operand in place (k-slot `half` at step r <-> n = n0 + (r&3) + 8(r>>2) + 4 half);
+//            connectivity MLP (1 output): VALU dot product + one cross-half shuffle.
+//   epilogue: relation tile staged through LDS and written as one contiguous run of 32*R floats, with the
+//            Neural-Motifs frequency bias triplet_dist[cls_i, cls_j, :] gathered and added on the way out
+//            (egtr.py:405-413).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int kHd = 256;  // hidden width of both MLPs (= d_model)
+
+// T = number of slots (decoder layers + 1), OT = number of 32-wide relation-output tiles (R <= 32*OT).
+template <int T, int OT>
+__global__ __launch_bounds__(64) void rel_head_fwd_f32(
+    const float* __restrict__ gate_q, const float* __restrict__ gate_k, const float* __restrict__ uq,
+    const float* __restrict__ uk, const float* __restrict__ b1, const float* __restrict__ w2r,
+    const float* __restrict__ b2r, const float* __restrict__ w3r, const float* __restrict__ b3r,
+    const float* __restrict__ w2c, const float* __restrict__ b2c, const float* __restrict__ w3c,
+    const float* __restrict__ b3c, const float* __restrict__ triplet, const int64_t* __restrict__ node_cls, int B,
+    int N, int R, int C1, float* __restrict__ rel_logits, float* __restrict__ conn_logits,
+    float* __restrict__ gate_mean) {
+  __shared__ __attribute__((aligned(16))) float s_out[32 * (32 * OT + 1)];
+  __shared__ int s_tb[32];
+  const int lane = threadIdx.x, pi = lane & 31, hf = lane >> 5;
+  const int mlp = blockIdx.y;  // 0 = relation, 1 = connectivity (wave-uniform)
+  const long long total = (long long)B * N * N;
+  const long long p0 = (long long)blockIdx.x * 32;
+  const long long p = p0 + pi;
+  const bool valid = p < total;
+  const long long pc = valid ? p : total - 1;
+  const int b = (int)(pc / ((long long)N * N));
+  const int rem = (int)(pc - (long long)b * N * N);
+  const int i = rem / N, j = rem - i * N;
+  const size_t qi = (size_t)b * N + i, kj = (size_t)b * N + j;
+
+  float g[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float x = gate_q[qi * T + t] + gate_k[kj * T + t];
+    g[t] = 1.f / (1.f + expf(-x));
+  }
+  if (gate_mean != nullptr && mlp == 0) {  // rel_gate_{t} logging (egtr.py:496-505)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float v = (valid && hf == 0) ? g[t] : 0.f;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      if (lane == 0) unsafeAtomicAdd(gate_mean + t, v / (float)total);
+    }
+  }
+
+  // ---- layer 1: h1[s] = relu(b1 + sum_t g[t] (uq[i,t,ch] + uk[j,t,ch])), ch = 256*mlp + 128*hf + s ----------
+  float h1[128];
+  {
+    const int ch0 = mlp * kHd + hf * 128;
+    const float4* pb = reinterpret_cast<const float4*>(b1 + ch0);
+    const float4* pq = reinterpret_cast<const float4*>(uq + qi * T * (2 * kHd) + ch0);
+    const float4* pk = reinterpret_cast<const float4*>(uk + kj * T * (2 * kHd) + ch0);
+#pragma unroll
+    for (int s4 = 0; s4 < 32; ++s4) {
+      float4 acc = pb[s4];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 a = pq[t * (2 * kHd / 4) + s4];
+        const float4 c = pk[t * (2 * kHd / 4) + s4];
+        acc.x += g[t] * (a.x + c.x);
+        acc.y += g[t] * (a.y + c.y);
+        acc.z += g[t] * (a.z + c.z);
+        acc.w += g[t] * (a.w + c.w);
+      }
+      h1[4 * s4 + 0] = fmaxf(acc.x, 0.f);
+      h1[4 * s4 + 1] = fmaxf(acc.y, 0.f);
+      h1[4 * s4 + 2] = fmaxf(acc.z, 0.f);
+      h1[4 * s4 + 3] = fmaxf(acc.w, 0.f);
+    }
+  }
+
+  const float* w2 = mlp ? w2c : w2r;
+  const float* b2 = mlp ? b2c : b2r;
+  f32x16 racc[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[ot][r] = 0.f;
+  float cacc = 0.f;
+
+#pragma unroll 1
+  for (int nt = 0; nt < kHd / 32; ++nt) {
+    // ---- layer 2: h2^T[n][pair], n = 32 nt + (r&3) + 8 (r>>2) + 4 hf ---------------------------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float4* wrow = reinterpret_cast<const float4*>(w2 + (size_t)(nt * 32 + pi) * kHd + hf * 128);
+#pragma unroll
+    for (int s4 = 0; s4 < 32; ++s4) {
+      const float4 w = wrow[s4];
+      acc = mfma32(w.x, h1[4 * s4 + 0], acc);
+      acc = mfma32(w.y, h1[4 * s4 + 1], acc);
+      acc = mfma32(w.z, h1[4 * s4 + 2], acc);
+      acc = mfma32(w.w, h1[4 * s4 + 3], acc);
+    }
+    // bias + relu; 4 consecutive n per register quad
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int n0 = nt * 32 + 8 * rq + 4 * hf;
+      const float4 bb = *reinterpret_cast<const float4*>(b2 + n0);
+      acc[4 * rq + 0] = fmaxf(acc[4 * rq + 0] + bb.x, 0.f);
+      acc[4 * rq + 1] = fmaxf(acc[4 * rq + 1] + bb.y, 0.f);
+      acc[4 * rq + 2] = fmaxf(acc[4 * rq + 2] + bb.z, 0.f);
+      acc[4 * rq + 3] = fmaxf(acc[4 * rq + 3] + bb.w, 0.f);
+    }
+    if (mlp == 0) {
+      // ---- layer 3 (relation): rel^T[r_out][pair] += W3[r_out][n] h2^T[n][pair] ----------------------------
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const int ro = ot * 32 + pi;
+        const bool rok = ro < R;
+        const float* w3row = w3r + (size_t)(rok ? ro : 0) * kHd + nt * 32 + 4 * hf;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float4 w = *reinterpret_cast<const float4*>(w3row + 8 * rq);
+          if (!rok) w = make_float4(0.f, 0.f, 0.f, 0.f);
+          racc[ot] = mfma32(w.x, acc[4 * rq + 0], racc[ot]);
+          racc[ot] = mfma32(w.y, acc[4 * rq + 1], racc[ot]);
+          racc[ot] = mfma32(w.z, acc[4 * rq + 2], racc[ot]);
+          racc[ot] = mfma32(w.w, acc[4 * rq + 3], racc[ot]);
+        }
+      }
+    } else {
+      // ---- layer 3 (connectivity, one output): dot with w3c over this lane's 16 n values ---------------------
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 w = *reinterpret_cast<const float4*>(w3c + nt * 32 + 8 * rq + 4 * hf);
+        cacc += w.x * acc[4 * rq + 0] + w.y * acc[4 * rq + 1] + w.z * acc[4 * rq + 2] + w.w * acc[4 * rq + 3];
+      }
+    }
+  }
+
+  if (mlp == 1) {
+    cacc += __shfl_xor(cacc, 32);
+    if (valid && hf == 0) conn_logits[p] = cacc + b3c[0];
+    return;
+  }
+  // ---- relation epilogue: stage [pair][r_out] in LDS, add b3 + frequency bias, write one contiguous run -------
+  constexpr int kStride = 32 * OT + 1;
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      s_out[pi * kStride + ro] = racc[ot][r];
+    }
+  if (hf == 0) {
+    int tb = -1;
+    if (triplet != nullptr) tb = ((int)node_cls[qi] * C1 + (int)node_cls[kj]) * R;
+    s_tb[pi] = tb;
+  }
+  __syncthreads();
+  const int npair = (int)((total - p0) < 32 ? (total - p0) : 32);
+  float* dst = rel_logits + (size_t)p0 * R;
+  for (int pp = 0; pp < npair; ++pp) {
+    const int tb = s_tb[pp];
+    for (int r = lane; r < R; r += 64) {
+      float v = s_out[pp * kStride + r] + b3r[r];
+      if (tb >= 0) v += triplet[tb + r];
+      dst[(size_t)pp * R + r] = v;
+    }
+  }
+}
+
+template <int T>
+int launch_T(hipStream_t st, int R, dim3 grid, const float* gate_q, const float* gate_k, const float* uq,
+             const float* uk, const float* b1, const float* w2r, const float* b2r, const float* w3r,
+             const float* b3r, const float* w2c, const float* b2c, const float* w3c, const float* b3c,
+             const float* triplet, const int64_t* node_cls, int B, int N, int C1, float* rel, float* conn,
+             float* gate_mean) {
+  if (R <= 32)
+    hipLaunchKernelGGL((rel_head_fwd_f32<T, 1>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
+                       b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean);
+  else
+    hipLaunchKernelGGL((rel_head_fwd_f32<T, 2>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
+                       b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k,
+                                         const float* uq, const float* uk, const float* b1, const float* w2r,
+                                         const float* b2r, const float* w3r, const float* b3r, const float* w2c,
+                                         const float* b2c, const float* w3c, const float* b3c,
+                                         const float* triplet_dist, const int64_t* node_cls, int batch,
+                                         int num_query, int num_slots, int hidden, int num_rel, int num_cls_plus1,
+                                         float* rel_logits, float* conn_logits, float* gate_mean) {
+  if (!gate_q || !gate_k || !uq || !uk || !b1 || !w2r || !b2r || !w3r || !b3r || !w2c || !b2c || !w3c || !b3c ||
+      !rel_logits || !conn_logits)
+    return EGTR_E_ARG;
+  if (triplet_dist != nullptr && node_cls == nullptr) return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_slots <= 0 || num_rel <= 0) return EGTR_E_ARG;
+  if (hidden != kHd || num_rel > 64 || num_slots > 10) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long total = (long long)batch * num_query * num_query;
+  const dim3 grid((unsigned)((total + 31) / 32), 2);
+#define EGTR_T(TT)                                                                                                  \
+  case TT:                                                                                                          \
+    launch_T<TT>(st, num_rel, grid, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,             \
+                 triplet_dist, node_cls, batch, num_query, num_cls_plus1, rel_logits, conn_logits, gate_mean);      \
+    break;
+  switch (num_slots) {
+    EGTR_T(1) EGTR_T(2) EGTR_T(3) EGTR_T(4) EGTR_T(5) EGTR_T(6) EGTR_T(7) EGTR_T(8) EGTR_T(9) EGTR_T(10)
+    default: return EGTR_E_UNSUPPORTED;
+  }
+#undef EGTR_T
+  return egtr_check_launch();
+}

@@ -1,0 +1,299 @@
+// Decoder multi-head self-attention core for gfx950: softmax(q k^T) v per head, fp32, exact-f32 MFMA.
+//
+// Replaces the bmm -> softmax -> bmm chain (and the head transposes around it) of
+// DeformableDetrMultiheadAttention.forward, model/deformable_detr.py:1170-1253, and emits the retained
+// per-layer maps "scaled q" and "k" in [B, M, N, D] layout (dd:1179-1185) that the EGTR relation head consumes.
+//
+// Shape regime: N = 100..300 object queries, D = 32, M = 8: the whole score row fits in registers, so no
+// online-softmax rescaling is needed.  One wavefront owns (batch b, head h, a tile of 16 query rows).
+//
+// MFMA use (v_mfma_f32_16x16x4_f32: exact f32, A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)*4+r][col=l&15]):
+//   * scores are computed TRANSPOSED, S^T = K Q^T, so that D[row = key][col = query]: a lane (c = l&15, g = l>>4)
+//     then holds, for query row c, the keys {k0 + 4g + r}: the softmax row statistics are an in-lane reduce plus
+//     two cross-lane steps (xor 16, xor 32), and
+//   * the probabilities are ALREADY in the B-operand layout of the second contraction O^T = V^T P^T (k-slot g at
+//     step t <-> key k0 + 4g + t), so P never leaves registers (no LDS round trip, no transpose).
+//   * the contraction index of the first product is assigned d = 8g + kk so each lane fetches its K / Q row
+//     fragment as two 16-byte loads.
+//
+// Backward (training): one wave per (b, h, 16-row tile) plays two roles without atomics:
+//   role A: dQ for its 16 query rows (loops over key tiles), role B: dK, dV for its 16 key rows (loops over
+//   query tiles); P is recomputed from the saved log-sum-exp.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float xor16_32_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ float xor16_32_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// Load 8 contiguous floats of row `row` (clamped to N-1) of a [B, N, M*32] tensor, head h, columns 8g..8g+7.
+__device__ __forceinline__ void load_frag8(const float* __restrict__ base, int N, int MD, int b, int row, int h,
+                                           int g, float (&f)[8]) {
+  const int r = min(row, N - 1);
+  const float4* p = reinterpret_cast<const float4*>(base + ((size_t)b * N + r) * MD + h * 32 + g * 8);
+  const float4 a = p[0], c = p[1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+  f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+}
+
+// NT = number of 16-key tiles held in registers (N <= 16*NT).  D = 32.
+template <int NT>
+__global__ __launch_bounds__(64) void self_attn_fwd_f32(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, float* __restrict__ out,
+                                                        float* __restrict__ q_heads, float* __restrict__ k_heads,
+                                                        float* __restrict__ lse, int B, int N, int M) {
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int ntile = (N + 15) >> 4;
+  int wid = blockIdx.x;
+  const int qt = wid % ntile;
+  wid /= ntile;
+  const int h = wid % M, b = wid / M;
+  const int MD = M * 32;
+  const int q0 = qt * 16;
+
+  float qf[8];
+  load_frag8(q, N, MD, b, q0 + c, h, g, qf);
+  // retained maps: this wave copies its own 16 rows of q and k into [B, M, N, 32]
+  if (q_heads != nullptr || k_heads != nullptr) {
+    if (q0 + c < N) {
+      const size_t o = (((size_t)b * M + h) * N + q0 + c) * 32 + g * 8;
+      if (q_heads) {
+        reinterpret_cast<float4*>(q_heads + o)[0] = make_float4(qf[0], qf[1], qf[2], qf[3]);
+        reinterpret_cast<float4*>(q_heads + o)[1] = make_float4(qf[4], qf[5], qf[6], qf[7]);
+      }
+      if (k_heads) {
+        float kf0[8];
+        load_frag8(k, N, MD, b, q0 + c, h, g, kf0);
+        reinterpret_cast<float4*>(k_heads + o)[0] = make_float4(kf0[0], kf0[1], kf0[2], kf0[3]);
+        reinterpret_cast<float4*>(k_heads + o)[1] = make_float4(kf0[4], kf0[5], kf0[6], kf0[7]);
+      }
+    }
+  }
+
+  f32x4 s[NT];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+    const int k0 = kt * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (k0 < N) {
+      float kf[8];
+      load_frag8(k, N, MD, b, k0 + c, h, g, kf);
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) acc = mfma16(kf[kk], qf[kk], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = (k0 + g * 4 + r) < N;
+      acc[r] = ok ? acc[r] : -INFINITY;
+      mx = fmaxf(mx, acc[r]);
+    }
+    s[kt] = acc;
+  }
+  mx = xor16_32_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = __expf(s[kt][r] - mx);
+      s[kt][r] = p;
+      sum += p;
+    }
+  }
+  sum = xor16_32_sum(sum);
+  const float inv = 1.f / sum;
+
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+    const int k0 = kt * 16;
+    if (k0 < N) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int key = min(k0 + g * 4 + t, N - 1);
+        const float* vp = v + ((size_t)b * N + key) * MD + h * 32 + c;
+        o0 = mfma16(vp[0], s[kt][t], o0);
+        o1 = mfma16(vp[16], s[kt][t], o1);
+      }
+    }
+  }
+  if (q0 + c < N) {
+    float* op = out + ((size_t)b * N + q0 + c) * MD + h * 32 + g * 4;
+    *reinterpret_cast<float4*>(op) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+    *reinterpret_cast<float4*>(op + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
+    if (lse != nullptr && g == 0) lse[((size_t)b * M + h) * N + q0 + c] = mx + __logf(sum);
+  }
+}
+
+// Backward.  See file header.  grad wrt the kernel's inputs q (already scaled), k, v.
+__global__ __launch_bounds__(64) void self_attn_bwd_f32(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, const float* __restrict__ out,
+                                                        const float* __restrict__ lse,
+                                                        const float* __restrict__ grad_out,
+                                                        float* __restrict__ grad_q, float* __restrict__ grad_k,
+                                                        float* __restrict__ grad_v, int B, int N, int M) {
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const int ntile = (N + 15) >> 4;
+  int wid = blockIdx.x;
+  const int tile = wid % ntile;
+  wid /= ntile;
+  const int h = wid % M, b = wid / M;
+  const int MD = M * 32;
+  const int r0 = tile * 16;
+  const float* lse_bh = lse + ((size_t)b * M + h) * N;
+
+  // ---------------- role A: dQ for query rows r0..r0+15 (layout: scores transposed, query row = c) ------------
+  {
+    float qf[8], dof[8], of[8];
+    load_frag8(q, N, MD, b, r0 + c, h, g, qf);
+    load_frag8(grad_out, N, MD, b, r0 + c, h, g, dof);
+    load_frag8(out, N, MD, b, r0 + c, h, g, of);
+    float delta = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) delta += dof[i] * of[i];
+    delta = xor16_32_sum(delta);
+    const float l_row = lse_bh[min(r0 + c, N - 1)];
+    f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ntile; ++kt) {
+      const int k0 = kt * 16;
+      float kf[8], vf[8];
+      load_frag8(k, N, MD, b, k0 + c, h, g, kf);
+      load_frag8(v, N, MD, b, k0 + c, h, g, vf);
+      f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        st = mfma16(kf[kk], qf[kk], st);    // S^T[key][qrow]
+        dp = mfma16(vf[kk], dof[kk], dp);   // dP^T[key][qrow] = V dO^T
+      }
+      f32x4 ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (k0 + g * 4 + r) < N;
+        const float p = ok ? __expf(st[r] - l_row) : 0.f;
+        ds[r] = p * (dp[r] - delta);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int key = min(k0 + g * 4 + t, N - 1);
+        const float* kp = k + ((size_t)b * N + key) * MD + h * 32 + c;
+        dq0 = mfma16(kp[0], ds[t], dq0);   // dQ^T[d][qrow] += K^T[d][key] dS^T[key][qrow]
+        dq1 = mfma16(kp[16], ds[t], dq1);
+      }
+    }
+    if (r0 + c < N) {
+      float* p = grad_q + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
+      *reinterpret_cast<float4*>(p) = make_float4(dq0[0], dq0[1], dq0[2], dq0[3]);
+      *reinterpret_cast<float4*>(p + 16) = make_float4(dq1[0], dq1[1], dq1[2], dq1[3]);
+    }
+  }
+  // ---------------- role B: dK, dV for key rows r0..r0+15 (scores NOT transposed: D[row = qrow][col = key]) ----
+  {
+    float kf[8], vf[8];
+    load_frag8(k, N, MD, b, r0 + c, h, g, kf);
+    load_frag8(v, N, MD, b, r0 + c, h, g, vf);
+    const bool key_ok = (r0 + c) < N;
+    f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f},
+          dv1 = {0.f, 0.f, 0.f, 0.f};
+    for (int qt = 0; qt < ntile; ++qt) {
+      const int q0 = qt * 16;
+      float qf[8], dof[8], of[8];
+      load_frag8(q, N, MD, b, q0 + c, h, g, qf);
+      load_frag8(grad_out, N, MD, b, q0 + c, h, g, dof);
+      load_frag8(out, N, MD, b, q0 + c, h, g, of);
+      float delta_c = 0.f;  // delta of query row q0 + c
+#pragma unroll
+      for (int i = 0; i < 8; ++i) delta_c += dof[i] * of[i];
+      delta_c = xor16_32_sum(delta_c);
+      f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        sc = mfma16(qf[kk], kf[kk], sc);    // S[qrow][key]
+        dp = mfma16(dof[kk], vf[kk], dp);   // dP[qrow][key] = dO V^T
+      }
+      f32x4 p, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = q0 + g * 4 + r;
+        const float l_row = lse_bh[min(qrow, N - 1)];
+        const float dl = __shfl(delta_c, g * 4 + r);  // lane (c' = 4g+r, g' = 0) holds delta of row q0+4g+r
+        const bool ok = key_ok && qrow < N;
+        p[r] = ok ? __expf(sc[r] - l_row) : 0.f;
+        ds[r] = p[r] * (dp[r] - dl);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int qrow = min(q0 + g * 4 + t, N - 1);
+        const float* dop = grad_out + ((size_t)b * N + qrow) * MD + h * 32 + c;
+        const float* qp = q + ((size_t)b * N + qrow) * MD + h * 32 + c;
+        dv0 = mfma16(dop[0], p[t], dv0);    // dV^T[d][key] += dO^T[d][qrow] P[qrow][key]
+        dv1 = mfma16(dop[16], p[t], dv1);
+        dk0 = mfma16(qp[0], ds[t], dk0);    // dK^T[d][key] += Q^T[d][qrow] dS[qrow][key]
+        dk1 = mfma16(qp[16], ds[t], dk1);
+      }
+    }
+    if (key_ok) {
+      float* pk = grad_k + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
+      float* pv = grad_v + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
+      *reinterpret_cast<float4*>(pk) = make_float4(dk0[0], dk0[1], dk0[2], dk0[3]);
+      *reinterpret_cast<float4*>(pk + 16) = make_float4(dk1[0], dk1[1], dk1[2], dk1[3]);
+      *reinterpret_cast<float4*>(pv) = make_float4(dv0[0], dv0[1], dv0[2], dv0[3]);
+      *reinterpret_cast<float4*>(pv + 16) = make_float4(dv1[0], dv1[1], dv1[2], dv1[3]);
+    }
+  }
+}
+
+template <int NT>
+void launch_fwd(hipStream_t st, const float* q, const float* k, const float* v, float* out, float* qh, float* kh,
+                float* lse, int B, int N, int M) {
+  const int ntile = (N + 15) / 16;
+  hipLaunchKernelGGL(self_attn_fwd_f32<NT>, dim3(B * M * ntile), dim3(64), 0, st, q, k, v, out, qh, kh, lse, B, N, M);
+}
+
+}  // namespace
+
+extern "C" int egtr_self_attn_forward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
+                                          int batch, int num_query, int num_heads, int head_dim, float* out,
+                                          float* q_heads, float* k_heads, float* lse) {
+  if (!q || !k || !v || !out) return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_heads <= 0) return EGTR_E_ARG;
+  if (head_dim != 32 || num_query > 16 * 40) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nt = (num_query + 15) / 16;
+  if (nt <= 7) launch_fwd<7>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
+  else if (nt <= 13) launch_fwd<13>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
+  else if (nt <= 19) launch_fwd<19>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
+  else launch_fwd<40>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
+                                           const float* out, const float* lse, const float* grad_out, int batch,
+                                           int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
+                                           float* grad_v) {
+  if (!q || !k || !v || !out || !lse || !grad_out || !grad_q || !grad_k || !grad_v) return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_heads <= 0) return EGTR_E_ARG;
+  if (head_dim != 32) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ntile = (num_query + 15) / 16;
+  hipLaunchKernelGGL(self_attn_bwd_f32, dim3(batch * num_heads * ntile), dim3(64), 0, st, q, k, v, out, lse, grad_out,
+                     grad_q, grad_k, grad_v, batch, num_query, num_heads);
+  return egtr_check_launch();
+}

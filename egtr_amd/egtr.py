@@ -1,0 +1,422 @@
+"""Host-side mirror of the reference's ``model/egtr.py``: ``DetrForSceneGraphGeneration`` and the SGG loss.
+
+Same constructor / forward signature, output object and state-dict keys as the reference.
+The relation head (model/egtr.py:322-418) is evaluated through the separable algebra of DESIGN.md: six small
+GEMMs produce per-query tables, and ONE fused HIP kernel (egtr_amd/csrc/rel_head.hip) does the pairwise gate,
+gated sum, both 3-layer MLPs and the frequency-bias gather -- the reference's 573 MB ``relation_source`` tensor
+never exists.  Citations "egtr:NNN" are to /root/reference/model/egtr.py.
+"""
+import copy
+import math
+import random
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .deformable_detr import (DeformableDetrHungarianMatcher, DeformableDetrMLPPredictionHead, DeformableDetrModel,
+                              DeformableDetrPreTrainedModel, inverse_sigmoid)
+from .hf_compat import ModelOutput
+from .util import (center_to_corners_format, dice_loss, generalized_box_iou, nested_tensor_from_tensor_list,
+                   sigmoid_focal_loss)
+
+
+@dataclass
+class DetrSceneGraphGenerationOutput(ModelOutput):
+    """egtr:53-115."""
+    loss: Optional[torch.FloatTensor] = None
+    loss_dict: Optional[Dict] = None
+    logits: Optional[torch.FloatTensor] = None
+    pred_boxes: Optional[torch.FloatTensor] = None
+    pred_rel: Optional[torch.FloatTensor] = None
+    pred_connectivity: Optional[torch.FloatTensor] = None
+    auxiliary_outputs: Optional[List[Dict]] = None
+    last_hidden_state: Optional[torch.FloatTensor] = None
+    decoder_hidden_states: Optional[Tuple[torch.FloatTensor]] = None
+    decoder_attentions: Optional[Tuple[torch.FloatTensor]] = None
+    cross_attentions: Optional[Tuple[torch.FloatTensor]] = None
+    encoder_last_hidden_state: Optional[torch.FloatTensor] = None
+    encoder_hidden_states: Optional[Tuple[torch.FloatTensor]] = None
+    encoder_attentions: Optional[Tuple[torch.FloatTensor]] = None
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
+    def __init__(self, config, **kwargs):
+        super().__init__(config)
+        self.model = DeformableDetrModel(config)
+        self.class_embed = nn.Linear(config.d_model, config.num_labels)
+        self.bbox_embed = DeformableDetrMLPPredictionHead(input_dim=config.d_model, hidden_dim=config.d_model,
+                                                          output_dim=4, num_layers=3)
+        prior_prob = 0.01
+        bias_value = -math.log((1 - prior_prob) / prior_prob)
+        self.class_embed.bias.data = torch.ones(config.num_labels) * bias_value
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        num_pred = config.decoder_layers
+        if config.with_box_refine:
+            self.class_embed = _get_clones(self.class_embed, num_pred)
+            self.bbox_embed = _get_clones(self.bbox_embed, num_pred)
+            nn.init.constant_(self.bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            self.model.decoder.bbox_embed = self.bbox_embed
+        else:  # every index aliases ONE module (egtr:152-158)
+            nn.init.constant_(self.bbox_embed.layers[-1].bias.data[2:], -2.0)
+            self.class_embed = nn.ModuleList([self.class_embed for _ in range(num_pred)])
+            self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(num_pred)])
+            self.model.decoder.bbox_embed = None
+
+        self.num_queries = self.config.num_queries
+        self.head_dim = config.d_model // config.num_attention_heads
+        self.layer_head = self.config.decoder_layers * config.num_attention_heads
+
+        fg_matrix = kwargs.get("fg_matrix", None)
+        if fg_matrix is not None:  # training: frequency-bias tables from dataset statistics (egtr:169-184)
+            eps = config.freq_bias_eps
+            rel_dist = torch.FloatTensor((fg_matrix.sum(axis=(0, 1))) / (fg_matrix.sum() + eps))
+            # NB the reference's operator precedence: fg + (eps / (sum + eps)), kept bug-for-bug
+            triplet_dist = torch.FloatTensor(fg_matrix + eps / (fg_matrix.sum(2, keepdims=True) + eps))
+            triplet_dist = F.log_softmax(triplet_dist, dim=-1) if config.use_log_softmax else triplet_dist.log()
+            self.rel_dist = nn.Parameter(rel_dist, requires_grad=False)
+            self.triplet_dist = nn.Parameter(triplet_dist, requires_grad=False)
+        else:  # inference: filled from the checkpoint (egtr:185-194); zero-initialised here rather than garbage
+            self.triplet_dist = nn.Parameter(
+                torch.zeros(config.num_labels + 1, config.num_labels + 1, config.num_rel_labels), requires_grad=False)
+            self.rel_dist = nn.Parameter(torch.ones(config.num_rel_labels), requires_grad=False)
+
+        d = config.d_model
+        self.proj_q = nn.ModuleList([nn.Linear(d, d) for _ in range(config.decoder_layers)])
+        self.proj_k = nn.ModuleList([nn.Linear(d, d) for _ in range(config.decoder_layers)])
+        self.final_sub_proj = nn.Linear(d, d)
+        self.final_obj_proj = nn.Linear(d, d)
+        self.rel_predictor_gate = nn.Linear(2 * d, 1)
+        self.rel_predictor = DeformableDetrMLPPredictionHead(input_dim=2 * d, hidden_dim=d,
+                                                             output_dim=config.num_rel_labels, num_layers=3)
+        self.connectivity_layer = DeformableDetrMLPPredictionHead(input_dim=2 * d, hidden_dim=d, output_dim=1,
+                                                                  num_layers=3)
+        self.post_init()
+
+    @torch.jit.unused
+    def _set_aux_loss(self, outputs_class, outputs_coord):
+        return [{"logits": a, "pred_boxes": b} for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
+
+    # ---------------------------------------------------------------------------------------- relation head
+    def _relation_head(self, queries, keys, sequence_output, logits, want_gate_mean):
+        """egtr:322-418 via the separable algebra.  Returns pre-sigmoid (rel [B,N,N,R], conn [B,N,N,1], gate_mean)."""
+        bsz, N, d = sequence_output.shape
+        unscaling = self.head_dim ** 0.5
+        # slot projections q^[b,i,t,:], k^[b,j,t,:]  (t < Ld: decoder layers, t = Ld: final hidden state)
+        pq = [proj(q.transpose(1, 2).reshape(bsz, N, d) * unscaling) for q, proj in zip(queries, self.proj_q)]
+        pk = [proj(k.transpose(1, 2).reshape(bsz, N, d)) for k, proj in zip(keys, self.proj_k)]
+        pq.append(self.final_sub_proj(sequence_output))
+        pk.append(self.final_obj_proj(sequence_output))
+        Q = torch.stack(pq, -2)  # [B,N,T,d]
+        K = torch.stack(pk, -2)
+        # separable gate logit and first MLP layer:  [W1_rel ; W1_conn ; w_gate] applied to each half
+        wg = self.rel_predictor_gate.weight  # [1, 2d]
+        w1 = torch.cat([self.rel_predictor.layers[0].weight, self.connectivity_layer.layers[0].weight], 0)  # [2Hd,2d]
+        wq = torch.cat([w1[:, :d], wg[:, :d]], 0)  # [2Hd+1, d]
+        wk = torch.cat([w1[:, d:], wg[:, d:]], 0)
+        tq = F.linear(Q, wq)  # [B,N,T,2Hd+1]
+        tk = F.linear(K, wk)
+        hd2 = w1.shape[0]
+        uq, gate_q = tq[..., :hd2].contiguous(), tq[..., hd2].contiguous()
+        uk, gate_k = tk[..., :hd2].contiguous(), (tk[..., hd2] + self.rel_predictor_gate.bias).contiguous()
+        b1 = torch.cat([self.rel_predictor.layers[0].bias, self.connectivity_layer.layers[0].bias], 0)
+        triplet, node = None, None
+        if self.config.use_freq_bias:  # egtr:405-413
+            triplet = self.triplet_dist
+            node = torch.argmax(logits, dim=-1)
+        rp, cl = self.rel_predictor.layers, self.connectivity_layer.layers
+        return ops.relation_head(gate_q, gate_k, uq, uk, b1, rp[1].weight, rp[1].bias, rp[2].weight, rp[2].bias,
+                                 cl[1].weight, cl[1].bias, cl[2].weight, cl[2].bias, triplet, node,
+                                 want_gate_mean)
+
+    def forward(self, pixel_values, pixel_mask=None, decoder_attention_mask=None, encoder_outputs=None,
+                inputs_embeds=None, decoder_inputs_embeds=None, labels=None, output_attentions=None,
+                output_hidden_states=None, output_attention_states=None, return_dict=None):
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        outputs = self.model(pixel_values, pixel_mask=pixel_mask, decoder_attention_mask=decoder_attention_mask,
+                             encoder_outputs=encoder_outputs, inputs_embeds=inputs_embeds,
+                             decoder_inputs_embeds=decoder_inputs_embeds, output_attentions=output_attentions,
+                             output_hidden_states=output_hidden_states,
+                             output_attention_states=True,  # the relation head needs the retained q / k maps
+                             return_dict=True)
+        sequence_output = outputs["last_hidden_state"]
+        bsz = sequence_output.size(0)
+        hidden_states = outputs.intermediate_hidden_states
+        init_reference = outputs.init_reference_points
+        inter_references = outputs.intermediate_reference_points
+
+        outputs_classes, outputs_coords = [], []
+        for level in range(hidden_states.shape[1]):  # egtr:286-305
+            reference = init_reference if level == 0 else inter_references[:, level - 1]
+            reference = inverse_sigmoid(reference)
+            outputs_class = self.class_embed[level](hidden_states[:, level])
+            delta_bbox = self.bbox_embed[level](hidden_states[:, level])
+            if reference.shape[-1] == 4:
+                outputs_coord_logits = delta_bbox + reference
+            elif reference.shape[-1] == 2:
+                outputs_coord_logits = torch.cat([delta_bbox[..., :2] + reference, delta_bbox[..., 2:]], -1)
+            else:
+                raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {reference.shape[-1]}")
+            outputs_classes.append(outputs_class)
+            outputs_coords.append(outputs_coord_logits.sigmoid())
+        outputs_class = torch.stack(outputs_classes, dim=1)
+        outputs_coord = torch.stack(outputs_coords, dim=1)
+        logits = outputs_class[:, -1]
+        pred_boxes = outputs_coord[:, -1]
+        if self.config.auxiliary_loss:
+            outputs_class = outputs_class[:, : self.config.decoder_layers, ...].permute(1, 0, 2, 3)
+            outputs_coord = outputs_coord[:, : self.config.decoder_layers, ...].permute(1, 0, 2, 3)
+        _, num_object_queries, _ = logits.shape
+
+        decoder_attention_queries = outputs["decoder_attention_queries"]
+        outputs["decoder_attention_queries"] = None
+        decoder_attention_keys = outputs["decoder_attention_keys"]
+        outputs["decoder_attention_keys"] = None
+        pred_rel, pred_connectivity, gate_mean = self._relation_head(
+            decoder_attention_queries, decoder_attention_keys, sequence_output, logits,
+            want_gate_mean=labels is not None)
+
+        loss, loss_dict, auxiliary_outputs = None, None, None
+        if labels is not None:
+            matcher = DeformableDetrHungarianMatcher(
+                class_cost=self.config.ce_loss_coefficient, bbox_cost=self.config.bbox_cost,
+                giou_cost=self.config.giou_cost, smoothing=self.config.smoothing)
+            criterion = SceneGraphGenerationLoss(
+                matcher=matcher, num_object_queries=num_object_queries, num_classes=self.config.num_labels,
+                num_rel_labels=self.config.num_rel_labels, eos_coef=self.config.eos_coefficient,
+                losses=["labels", "boxes", "relations", "cardinality", "uncertainty"],
+                smoothing=self.config.smoothing, rel_sample_negatives=self.config.rel_sample_negatives,
+                rel_sample_nonmatching=self.config.rel_sample_nonmatching, model_training=self.training,
+                focal_alpha=self.config.focal_alpha,
+                rel_sample_negatives_largest=self.config.rel_sample_negatives_largest,
+                rel_sample_nonmatching_largest=self.config.rel_sample_nonmatching_largest)
+            criterion.to(self.device)
+            outputs_loss = {"logits": logits, "pred_boxes": pred_boxes, "pred_rel": pred_rel,
+                            "pred_connectivity": pred_connectivity}  # pre-sigmoid (egtr:450-454)
+            if self.config.auxiliary_loss:
+                auxiliary_outputs = self._set_aux_loss(outputs_class, outputs_coord)
+                outputs_loss["auxiliary_outputs"] = auxiliary_outputs
+            loss_dict = criterion(outputs_loss, labels)
+            weight_dict = {"loss_ce": self.config.ce_loss_coefficient, "loss_bbox": self.config.bbox_loss_coefficient,
+                           "loss_giou": self.config.giou_loss_coefficient,
+                           "loss_rel": self.config.rel_loss_coefficient,
+                           "loss_connectivity": self.config.connectivity_loss_coefficient}
+            if self.config.auxiliary_loss:
+                aux = {}
+                for i in range(self.config.decoder_layers - 1):
+                    aux.update({f"{k}_{i}": v for k, v in weight_dict.items()})
+                weight_dict.update(aux)
+            loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+            for i in range(self.config.decoder_layers + 1):  # rel_gate_{i} logging (egtr:496-505)
+                loss_dict[f"rel_gate_{i}"] = gate_mean[i]
+
+        if self.config.logit_adjustment:  # egtr:509-512
+            pred_rel = pred_rel - self.config.logit_adj_tau * self.rel_dist.log().to(pred_rel.device)
+        pred_rel = pred_rel.sigmoid()
+        pred_connectivity = pred_connectivity.sigmoid()
+
+        if not return_dict:
+            output = (logits, pred_boxes) + ((auxiliary_outputs,) if auxiliary_outputs is not None else ()) \
+                + outputs.to_tuple()
+            return ((loss, loss_dict) + output) if loss is not None else output
+        return DetrSceneGraphGenerationOutput(
+            loss=loss, loss_dict=loss_dict, logits=logits, pred_boxes=pred_boxes, pred_rel=pred_rel,
+            pred_connectivity=pred_connectivity, auxiliary_outputs=auxiliary_outputs,
+            last_hidden_state=outputs.last_hidden_state, decoder_hidden_states=outputs.decoder_hidden_states,
+            decoder_attentions=outputs.decoder_attentions, cross_attentions=outputs.cross_attentions,
+            encoder_last_hidden_state=outputs.encoder_last_hidden_state,
+            encoder_hidden_states=outputs.encoder_hidden_states, encoder_attentions=outputs.encoder_attentions)
+
+
+class SceneGraphGenerationLoss(nn.Module):
+    """Hungarian-matched detection losses + relation BCE with relation smoothing and hard-negative sampling +
+    connectivity BCE (egtr:544-1034).  Host-side PyTorch on device tensors, like the reference."""
+
+    def __init__(self, matcher, num_object_queries, num_classes, num_rel_labels, eos_coef, losses, smoothing,
+                 rel_sample_negatives, rel_sample_nonmatching, model_training, focal_alpha,
+                 rel_sample_negatives_largest, rel_sample_nonmatching_largest):
+        super().__init__()
+        self.num_object_queries = num_object_queries
+        self.num_classes = num_classes
+        self.num_rel_labels = num_rel_labels
+        self.matcher = matcher
+        self.eos_coef = eos_coef
+        self.losses = losses
+        self.rel_loss = torch.nn.BCEWithLogitsLoss(reduction="none")
+        self.rel_sample_negatives = rel_sample_negatives
+        self.rel_sample_nonmatching = rel_sample_nonmatching
+        self.model_training = model_training
+        self.focal_alpha = focal_alpha
+        self.rel_sample_negatives_largest = rel_sample_negatives_largest
+        self.rel_sample_nonmatching_largest = rel_sample_nonmatching_largest
+        self.nonmatching_cost = (-torch.log(torch.tensor(1e-8)) * matcher.class_cost + 4 * matcher.bbox_cost
+                                 + 2 * matcher.giou_cost - torch.log(torch.tensor((1.0 / smoothing) - 1.0)))
+        self.connectivity_loss = torch.nn.BCEWithLogitsLoss(reduction="none")
+
+    def loss_labels(self, outputs, targets, indices, matching_costs, num_boxes):
+        """Focal classification loss (egtr:611-659)."""
+        if "logits" not in outputs:
+            raise ValueError("No logits were found in the outputs")
+        source_logits = outputs["logits"]
+        idx = self._get_src_permutation_idx(indices)
+        target_classes_o = torch.cat([t["class_labels"][J] for t, (_, J) in zip(targets, indices)])
+        target_classes = torch.full(source_logits.shape[:2], self.num_classes, dtype=torch.int64,
+                                    device=source_logits.device)
+        target_classes[idx] = target_classes_o.to(source_logits.device)
+        onehot = torch.zeros([source_logits.shape[0], source_logits.shape[1], source_logits.shape[2] + 1],
+                             dtype=source_logits.dtype, layout=source_logits.layout, device=source_logits.device)
+        onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
+        loss_ce = sigmoid_focal_loss(source_logits, onehot[:, :, :-1], num_boxes, alpha=self.focal_alpha,
+                                     gamma=2) * source_logits.shape[1]
+        return {"loss_ce": loss_ce}
+
+    @torch.no_grad()
+    def loss_cardinality(self, outputs, targets, indices, matching_costs, num_boxes):
+        logits = outputs["logits"]
+        tgt_lengths = torch.as_tensor([len(v["class_labels"]) for v in targets], device=logits.device)
+        card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
+        return {"cardinality_error": F.l1_loss(card_pred.float(), tgt_lengths.float())}
+
+    @torch.no_grad()
+    def loss_uncertainty(self, outputs, targets, indices, matching_costs, num_boxes):
+        vals = []
+        for target, index, matching_cost in zip(targets, indices, matching_costs):
+            nonzero_index = target["rel"][index[1], :, :][:, index[1], :].nonzero()
+            uncertainty = matching_cost.sigmoid()
+            vals.append(uncertainty[nonzero_index[:, 0]] * uncertainty[nonzero_index[:, 1]])
+        return {"uncertainty": torch.cat(vals).mean()}
+
+    def loss_boxes(self, outputs, targets, indices, matching_costs, num_boxes):
+        assert "pred_boxes" in outputs, "No predicted boxes found in outputs"
+        idx = self._get_src_permutation_idx(indices)
+        src_boxes = outputs["pred_boxes"][idx]
+        target_boxes = torch.cat([t["boxes"][i] for t, (_, i) in zip(targets, indices)], dim=0)
+        losses = {"loss_bbox": F.l1_loss(src_boxes, target_boxes, reduction="none").sum() / num_boxes}
+        loss_giou = 1 - torch.diag(generalized_box_iou(center_to_corners_format(src_boxes),
+                                                       center_to_corners_format(target_boxes)))
+        losses["loss_giou"] = loss_giou.sum() / num_boxes
+        return losses
+
+    def loss_masks(self, outputs, targets, indices, matching_costs, num_boxes):
+        assert "pred_masks" in outputs, "No predicted masks found in outputs"
+        src_idx = self._get_src_permutation_idx(indices)
+        tgt_idx = self._get_tgt_permutation_idx(indices)
+        src_masks = outputs["pred_masks"][src_idx]
+        target_masks, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets]).decompose()
+        target_masks = target_masks.to(src_masks)[tgt_idx]
+        src_masks = F.interpolate(src_masks[:, None], size=target_masks.shape[-2:], mode="bilinear",
+                                  align_corners=False)[:, 0].flatten(1)
+        target_masks = target_masks.flatten(1).view(src_masks.shape)
+        return {"loss_mask": sigmoid_focal_loss(src_masks, target_masks, num_boxes),
+                "loss_dice": dice_loss(src_masks, target_masks, num_boxes)}
+
+    def loss_relations(self, outputs, targets, indices, matching_costs, num_boxes):
+        """egtr:754-815.  Index tensors are moved to the logits' device once per image (the reference indexes
+        device tensors with CPU index tensors, egtr:761-785; same values)."""
+        losses, connect_losses = [], []
+        dev = outputs["pred_rel"].device
+        for i, ((src_index, target_index), target, matching_cost) in enumerate(zip(indices, targets, matching_costs)):
+            full_index = torch.arange(self.num_object_queries)
+            uniques, counts = torch.cat([full_index, src_index]).unique(return_counts=True)
+            full_src_index = torch.cat([src_index, uniques[counts == 1]]).to(dev)
+            full_target_index = torch.cat([target_index, torch.arange(len(target_index), self.num_object_queries)])
+            full_matching_cost = torch.cat([matching_cost, torch.full(
+                (self.num_object_queries - len(matching_cost),), float(self.nonmatching_cost),
+                device=matching_cost.device)])
+            pred_rel = outputs["pred_rel"][i, full_src_index][:, full_src_index]
+            fti = full_target_index.to(target["rel"].device)
+            target_rel = target["rel"][fti][:, fti]
+            rel_index = torch.nonzero(target_rel)
+            target_connect = torch.zeros(target_rel.shape[0], target_rel.shape[1], 1, device=target_rel.device)
+            target_connect[rel_index[:, 0], rel_index[:, 1]] = 1
+            pred_connectivity = outputs["pred_connectivity"][i, full_src_index][:, full_src_index]
+            connect_losses.append(self.connectivity_loss(pred_connectivity, target_connect))
+            if self.model_training:
+                loss = self._loss_relations(pred_rel, target_rel, full_matching_cost, self.rel_sample_negatives,
+                                            self.rel_sample_nonmatching)
+            else:
+                loss = self._loss_relations(pred_rel, target_rel, full_matching_cost, None, None)
+            losses.append(loss)
+        return {"loss_rel": torch.cat(losses).mean(), "loss_connectivity": torch.stack(connect_losses).mean()}
+
+    def _loss_relations(self, pred_rel, target_rel, matching_cost, rel_sample_negatives, rel_sample_nonmatching):
+        """egtr:817-923."""
+        if (rel_sample_negatives is None) and (rel_sample_nonmatching is None):
+            weight = 1.0 - matching_cost.sigmoid()
+            weight = torch.outer(weight, weight)
+            target_rel = target_rel * weight.unsqueeze(-1)
+            return self.rel_loss(pred_rel, target_rel).mean(-1).reshape(-1)
+        matched = matching_cost != self.nonmatching_cost.to(matching_cost.device)
+        num_target_objects = int(matched.sum())
+        sub = target_rel[:num_target_objects, :num_target_objects, :]
+        true_indices = sub.nonzero()
+        false_indices = (sub != 1.0).nonzero()
+        nonmatching_indices = (torch.outer(matched, matched).unsqueeze(-1).repeat(1, 1, self.num_rel_labels)
+                               != True).nonzero()  # noqa: E712
+        num_target_relations = len(true_indices)
+
+        def _sample(cands, k, largest_flag):
+            if k == 0 or num_target_relations == 0:
+                return cands[[]]
+            n = min(num_target_relations * k, cands.size(0))
+            if largest_flag:
+                scores = pred_rel[cands[:, 0], cands[:, 1], cands[:, 2]]
+                sel = torch.topk(scores, n, largest=True)[1]
+            else:
+                sel = torch.tensor(random.sample(range(cands.size(0)), n), device=cands.device)
+            return cands[sel]
+
+        if rel_sample_negatives is not None:
+            false_indices = _sample(false_indices, rel_sample_negatives, self.rel_sample_negatives_largest)
+        if rel_sample_nonmatching is not None:
+            nonmatching_indices = _sample(nonmatching_indices, rel_sample_nonmatching,
+                                          self.rel_sample_nonmatching_largest)
+        relation_indices = torch.cat([true_indices, false_indices, nonmatching_indices])
+        pred_rel = pred_rel[relation_indices[:, 0], relation_indices[:, 1], relation_indices[:, 2]]
+        target_rel = target_rel[relation_indices[:, 0], relation_indices[:, 1], relation_indices[:, 2]]
+        weight = 1.0 - matching_cost.sigmoid()
+        weight = weight[relation_indices[:, 0]] * weight[relation_indices[:, 1]]
+        return self.rel_loss(pred_rel, target_rel * weight)
+
+    def _get_src_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        src_idx = torch.cat([src for (src, _) in indices])
+        return batch_idx, src_idx
+
+    def _get_tgt_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(tgt, i) for i, (_, tgt) in enumerate(indices)])
+        tgt_idx = torch.cat([tgt for (_, tgt) in indices])
+        return batch_idx, tgt_idx
+
+    def get_loss(self, loss, outputs, targets, indices, matching_costs, num_boxes):
+        loss_map = {"labels": self.loss_labels, "cardinality": self.loss_cardinality, "boxes": self.loss_boxes,
+                    "masks": self.loss_masks, "relations": self.loss_relations,
+                    "uncertainty": self.loss_uncertainty}
+        assert loss in loss_map, f"Loss {loss} not supported"
+        return loss_map[loss](outputs, targets, indices, matching_costs, num_boxes)
+
+    def forward(self, outputs, targets):
+        """egtr:953-1034.  ``num_boxes`` is per-rank (the reference's all-reduce is commented out, :976-980)."""
+        outputs_without_aux = {k: v for k, v in outputs.items() if k not in ("auxiliary_outputs", "enc_outputs")}
+        indices, matching_costs = self.matcher(outputs_without_aux, targets)
+        num_boxes = float(max(sum(len(t["class_labels"]) for t in targets), 1))
+        losses = {}
+        for loss in self.losses:
+            losses.update(self.get_loss(loss, outputs, targets, indices, matching_costs, num_boxes))
+        if "auxiliary_outputs" in outputs:
+            for i, auxiliary_outputs in enumerate(outputs["auxiliary_outputs"]):
+                indices, matching_costs = self.matcher(auxiliary_outputs, targets)
+                for loss in self.losses:
+                    if loss in ["masks", "relations", "uncertainty"]:
+                        continue
+                    l_dict = self.get_loss(loss, auxiliary_outputs, targets, indices, matching_costs, num_boxes)
+                    losses.update({k + f"_{i}": v for k, v in l_dict.items()})
+        return losses

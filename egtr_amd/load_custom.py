@@ -1,0 +1,95 @@
+"""Drop-in replacement for the reference's kernel loader (model/load_custom.py:23-57).
+
+The reference JIT-compiles its CUDA sources with torch.utils.cpp_extension.load() and returns a pybind module
+exposing ``ms_deform_attn_forward`` / ``ms_deform_attn_backward`` (model/custom_kernel/vision.cpp:13-15).
+Here the kernels are hand-written HIP, prebuilt in-tree into libegtr_hip.so (C ABI, include/egtr_hip.h), and this
+module returns an object with the SAME two functions and the same argument lists, so
+``MultiScaleDeformableAttentionFunction`` (model/deformable_detr.py:402-455) can call it unchanged.
+
+Error convention follows the reference's AT_ASSERTM host checks (ms_deform_attn_cuda.cu:31-41, 96-108): a
+RuntimeError for non-contiguous / non-device operands.  Unlike the reference there is no silent PyTorch
+fallback (deformable_detr.py:1096-1101 swallows every exception): a failure here propagates.
+"""
+import torch
+
+from . import _lib
+
+
+def _chk(t, name, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} tensor has to be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if t.data_ptr() % 16 != 0:
+        raise RuntimeError(f"{name} must be 16-byte aligned")
+    return t
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _MultiScaleDeformableAttention:
+    """Module-like object bound to the global ``MultiScaleDeformableAttention`` (deformable_detr.py:392)."""
+
+    @staticmethod
+    def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
+        lib = _lib.lib()
+        B, S, M, D = value.shape
+        L = spatial_shapes.shape[0]
+        Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+        _chk(spatial_shapes, "spatial_shapes", torch.int64)
+        _chk(level_start_index, "level_start_index", torch.int64)
+        _chk(sampling_loc, "sampling_loc", torch.float32)
+        _chk(attn_weight, "attn_weight", torch.float32)
+        if value.dtype == torch.float32:
+            _chk(value, "value")
+            out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
+            st = lib.egtr_msda_forward_f32(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
+                                           level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                                           attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr())
+        elif value.dtype == torch.bfloat16:
+            _chk(value, "value")
+            out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
+            st = lib.egtr_msda_forward_bf16(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
+                                            level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                                            attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr())
+        else:
+            raise RuntimeError(f"ms_deform_attn_forward: unsupported dtype {value.dtype}")
+        _lib.check(st, "ms_deform_attn_forward")
+        return out
+
+    @staticmethod
+    def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
+                                im2col_step):
+        lib = _lib.lib()
+        B, S, M, D = value.shape
+        L = spatial_shapes.shape[0]
+        Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+        for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"),
+                     (grad_output, "grad_output")):
+            _chk(t, n, torch.float32)
+        _chk(spatial_shapes, "spatial_shapes", torch.int64)
+        _chk(level_start_index, "level_start_index", torch.int64)
+        grad_value = torch.zeros_like(value)  # accumulated with atomics (reference: cu:124)
+        grad_loc = torch.empty_like(sampling_loc)
+        grad_attn = torch.empty_like(attn_weight)
+        st = lib.egtr_msda_backward_f32(_stream(), grad_output.data_ptr(), value.data_ptr(),
+                                        spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                        sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P,
+                                        grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+        _lib.check(st, "ms_deform_attn_backward")
+        return grad_value, grad_loc, grad_attn
+
+
+def load_hip_kernels():
+    """Counterpart of load_cuda_kernels() (model/load_custom.py:23): returns the kernel module object.
+    Raises if libegtr_hip.so is missing -- the caller must not swallow that."""
+    _lib.lib()
+    return _MultiScaleDeformableAttention
+
+
+# the reference's name, so `from .load_custom import load_cuda_kernels` keeps working
+load_cuda_kernels = load_hip_kernels

@@ -1,0 +1,157 @@
+"""Autograd bridges between PyTorch-ROCm tensors and the HIP kernels of libegtr_hip.so.
+
+Every op here enqueues on torch's current HIP stream through the C ABI (include/egtr_hip.h); none has a CPU or
+eager-PyTorch fallback -- a missing library raises ``egtr_amd._lib.EgtrHipError``.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from .load_custom import _chk, _stream, load_hip_kernels
+
+_MSDA = None
+
+
+def _msda():
+    global _MSDA
+    if _MSDA is None:
+        _MSDA = load_hip_kernels()
+    return _MSDA
+
+
+class MultiScaleDeformableAttentionFunction(Function):
+    """Same contract as the reference's autograd Function (model/deformable_detr.py:402-455)."""
+
+    @staticmethod
+    def forward(context, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        context.im2col_step = im2col_step
+        output = _msda().ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
+                                                sampling_locations, attention_weights, im2col_step)
+        context.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                                  attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(context, grad_output):
+        value, shapes, lsi, loc, attn = context.saved_tensors
+        grad_value, grad_loc, grad_attn = _msda().ms_deform_attn_backward(
+            value, shapes, lsi, loc, attn, grad_output.contiguous(), context.im2col_step)
+        return grad_value, None, None, grad_loc, grad_attn, None
+
+
+class DecoderSelfAttentionFunction(Function):
+    """softmax(q k^T) v per head + the retained [B, M, N, D] maps of scaled q and k
+    (replaces model/deformable_detr.py:1170-1253; q must already carry the D^-1/2 scaling of :1166)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads, want_maps):
+        lib = _lib.lib()
+        B, N, MD = q.shape
+        D = MD // num_heads
+        for t, n in ((q, "q"), (k, "k"), (v, "v")):
+            _chk(t, n, torch.float32)
+        out = torch.empty_like(q)
+        need_bwd = q.requires_grad or k.requires_grad or v.requires_grad
+        qh = torch.empty(B, num_heads, N, D, dtype=q.dtype, device=q.device) if want_maps else None
+        kh = torch.empty_like(qh) if want_maps else None
+        lse = torch.empty(B, num_heads, N, dtype=q.dtype, device=q.device) if need_bwd else None
+        st = lib.egtr_self_attn_forward_f32(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), B, N, num_heads, D,
+                                            out.data_ptr(), qh.data_ptr() if want_maps else None,
+                                            kh.data_ptr() if want_maps else None,
+                                            lse.data_ptr() if need_bwd else None)
+        _lib.check(st, "egtr_self_attn_forward_f32")
+        ctx.num_heads = num_heads
+        ctx.want_maps = want_maps
+        if need_bwd:
+            ctx.save_for_backward(q, k, v, out, lse)
+        if want_maps:
+            return out, qh, kh
+        return out, None, None
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out, grad_qh, grad_kh):
+        lib = _lib.lib()
+        q, k, v, out, lse = ctx.saved_tensors
+        B, N, MD = q.shape
+        M = ctx.num_heads
+        grad_out = grad_out.contiguous()
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        st = lib.egtr_self_attn_backward_f32(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                                             lse.data_ptr(), grad_out.data_ptr(), B, N, M, MD // M, gq.data_ptr(),
+                                             gk.data_ptr(), gv.data_ptr())
+        _lib.check(st, "egtr_self_attn_backward_f32")
+        # the retained maps are pure re-layouts of q and k: their gradients fold straight back
+        if grad_qh is not None:
+            gq = gq + grad_qh.transpose(1, 2).reshape(B, N, MD)
+        if grad_kh is not None:
+            gk = gk + grad_kh.transpose(1, 2).reshape(B, N, MD)
+        return gq, gk, gv, None, None
+
+
+def decoder_self_attention(q, k, v, num_heads, want_maps=True):
+    return DecoderSelfAttentionFunction.apply(q.contiguous(), k.contiguous(), v.contiguous(), num_heads, want_maps)
+
+
+def _rel_head_separable_torch(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c):
+    """Differentiable PyTorch-ROCm statement of the SAME separable algebra the fused HIP kernel evaluates
+    (egtr_amd/csrc/rel_head.hip).  Used only to obtain gradients in training (backward recompute); the forward
+    values always come from the HIP kernel."""
+    Hd = w2r.shape[1]
+    g = torch.sigmoid(gate_q[:, :, None, :] + gate_k[:, None, :, :])  # [B,N,N,T]
+    h1 = torch.einsum("bijt,bitc->bijc", g, uq) + torch.einsum("bijt,bjtc->bijc", g, uk) + b1
+    h1 = torch.relu(h1)
+    rel = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(h1[..., :Hd], w2r, b2r)), w3r, b3r)
+    conn = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(h1[..., Hd:], w2c, b2c)), w3c, b3c)
+    return rel, conn[..., 0], g
+
+
+class RelationHeadFunction(Function):
+    """Fused pairwise gate + gated sum + relation / connectivity MLPs (replaces model/egtr.py:366-416)."""
+
+    @staticmethod
+    def forward(ctx, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist, node_cls,
+                want_gate_mean):
+        lib = _lib.lib()
+        B, N, T = gate_q.shape
+        Hd = w2r.shape[1]
+        R = w3r.shape[0]
+        tens = [gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c]
+        names = ["gate_q", "gate_k", "uq", "uk", "b1", "w2r", "b2r", "w3r", "b3r", "w2c", "b2c", "w3c", "b3c"]
+        tens = [_chk(t.contiguous(), n, torch.float32) for t, n in zip(tens, names)]
+        rel = torch.empty(B, N, N, R, dtype=torch.float32, device=gate_q.device)
+        conn = torch.empty(B, N, N, dtype=torch.float32, device=gate_q.device)
+        gm = torch.zeros(T, dtype=torch.float32, device=gate_q.device) if want_gate_mean else None
+        if triplet_dist is not None:
+            _chk(triplet_dist, "triplet_dist", torch.float32)
+            _chk(node_cls, "node_cls", torch.int64)
+            c1 = triplet_dist.shape[0]
+        else:
+            c1 = 0
+        st = lib.egtr_rel_head_forward_f32(
+            _stream(), *[t.data_ptr() for t in tens], triplet_dist.data_ptr() if triplet_dist is not None else None,
+            node_cls.data_ptr() if triplet_dist is not None else None, B, N, T, Hd, R, c1, rel.data_ptr(),
+            conn.data_ptr(), gm.data_ptr() if want_gate_mean else None)
+        _lib.check(st, "egtr_rel_head_forward_f32")
+        ctx.save_for_backward(*tens)
+        return rel, conn.unsqueeze(-1), gm
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_rel, grad_conn, grad_gm):
+        # Gradient by recomputation of the separable algebra with PyTorch-ROCm ops on the GPU (rocBLAS GEMMs).
+        # The frequency bias is an additive constant, so it does not appear here.
+        tens = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
+        with torch.enable_grad():
+            rel, conn, _ = _rel_head_separable_torch(*tens)
+            grads = torch.autograd.grad([rel, conn], tens, [grad_rel, grad_conn[..., 0]], allow_unused=True)
+        return tuple(grads) + (None, None, None)
+
+
+def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
+                  node_cls=None, want_gate_mean=False):
+    return RelationHeadFunction.apply(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,
+                                      triplet_dist, node_cls, want_gate_mean)

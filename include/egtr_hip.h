@@ -1,0 +1,113 @@
+/*
+ * egtr_hip.h -- C ABI of libegtr_hip.so: the MI355X (gfx950) hot path of EGTR scene-graph generation.
+ *
+ * Plain C: raw device pointers, sizes and a HIP stream handle; no torch / ATen types.  Every entry point
+ * enqueues on the given stream and returns immediately (no host sync, no allocation, re-entrant, no global
+ * state).  Return value: 0 on success, a negative EGTR_E_* code otherwise (egtr_status_string() names it;
+ * launch errors are returned, not printf'd as the reference does at ms_deform_im2col_cuda.cuh:948-952).
+ *
+ * Reference interfaces replaced (all paths relative to naver-ai/egtr):
+ *   egtr_msda_forward_*   <- ms_deformable_im2col_cuda()   model/custom_kernel/cuda/ms_deform_im2col_cuda.cuh:924-955
+ *                            as driven by ms_deform_attn_cuda_forward(), cuda/ms_deform_attn_cuda.cu:23-83,
+ *                            exported to Python as ms_deform_attn_forward (vision.cpp:13, ms_deform_attn.h:20-39)
+ *   egtr_msda_backward_*  <- ms_deformable_col2im_cuda()   ms_deform_im2col_cuda.cuh:957-1327
+ *                            as driven by ms_deform_attn_cuda_backward(), cuda/ms_deform_attn_cuda.cu:86-156,
+ *                            exported as ms_deform_attn_backward (vision.cpp:14, ms_deform_attn.h:41-61)
+ *   egtr_self_attn_*      <- the bmm / softmax / bmm core of DeformableDetrMultiheadAttention.forward,
+ *                            model/deformable_detr.py:1170-1253 (plain PyTorch in the reference), including the
+ *                            retained per-layer scaled-Q / K maps of :1179-1185
+ *   egtr_rel_head_*       <- the pairwise gate + gated sum + two 3-layer MLPs of
+ *                            DetrForSceneGraphGeneration.forward, model/egtr.py:366-416 (plain PyTorch)
+ *
+ * Layout conventions (row-major, innermost last), identical to the reference's tensors:
+ *   value          [B, S, M, D]        spatial_shapes [L, 2] int64 (H, W), DEVICE memory
+ *   sampling_loc   [B, Lq, M, L, P, 2] level_start_index [L] int64, DEVICE memory
+ *   attn_weight    [B, Lq, M, L, P]    out [B, Lq, M*D]
+ * The reference chunks the batch by im2col_step (cu:53-64); these kernels take the whole batch in one launch,
+ * so the binding accepts and ignores im2col_step.
+ */
+#ifndef EGTR_HIP_H
+#define EGTR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* egtr_stream_t; /* a hipStream_t; NULL = the default stream */
+
+enum {
+  EGTR_OK = 0,
+  EGTR_E_ARG = -1,      /* null pointer / non-positive size / unsupported shape */
+  EGTR_E_LAUNCH = -2,   /* hipGetLastError() reported a launch failure */
+  EGTR_E_UNSUPPORTED = -3
+};
+
+int egtr_abi_version(void);
+const char* egtr_status_string(int status);
+/* last HIP error string seen by this thread (for EGTR_E_LAUNCH) */
+const char* egtr_last_hip_error(void);
+
+/* ---- multi-scale deformable attention: sample + weighted sum over L levels x P points ------------------- */
+/* out must hold B*Lq*M*D elements; it is fully overwritten (no zero-init needed, unlike cu:57). */
+int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
+                          int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                          int num_point, float* out);
+
+/* grad_value [B,S,M,D] MUST be zero-initialised by the caller (accumulated with atomics, as cu:124 relies on);
+ * grad_sampling_loc [B,Lq,M,L,P,2] and grad_attn_weight [B,Lq,M,L,P] are fully overwritten. */
+int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const float* value,
+                           const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,
+                           int num_heads, int channels, int num_levels, int num_query, int num_point,
+                           float* grad_value, float* grad_sampling_loc, float* grad_attn_weight);
+
+/* bf16 storage (uint16_t = raw bfloat16 bits), fp32 accumulation.  The reference dispatches float/double only
+ * (cu:67,137); this is the added path for the bf16 stress configuration.  loc / attn stay fp32. */
+int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,
+                           const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
+                           int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                           int num_point, uint16_t* out);
+
+/* ---- decoder multi-head self-attention core ------------------------------------------------------------- */
+/* q (already scaled by D^-1/2, dd:1166), k, v: [B, N, M*D] as produced by the q/k/v projections.
+ * out [B, N, M*D] = softmax(q k^T) v per head (dd:1190-1253, no mask, attention_dropout = 0).
+ * q_heads / k_heads (optional, may be NULL): the retained maps [B, M, N, D] of dd:1179-1185.
+ * lse (optional): [B, M, N] log-sum-exp of each score row, saved for the backward. */
+int egtr_self_attn_forward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v, int batch,
+                               int num_query, int num_heads, int head_dim, float* out, float* q_heads,
+                               float* k_heads, float* lse);
+
+/* grads wrt q, k, v ([B, N, M*D] each, fully overwritten) from grad_out [B,N,M*D], the forward's out and lse. */
+int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
+                                const float* out, const float* lse, const float* grad_out, int batch,
+                                int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
+                                float* grad_v);
+
+/* ---- EGTR relation head ---------------------------------------------------------------------------------- */
+/* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):
+ *   gate_q [B, N, T], gate_k [B, N, T]   : w_g[:d].q^[i,t]  and  w_g[d:].k^[j,t] + b_g      (T = Ld + 1 slots)
+ *   uq [B, N, T, 2*Hd], uk [B, N, T, 2*Hd]: first-layer pre-activations W1[:, :d] q^ and W1[:, d:] k^ of the
+ *                                           relation MLP (cols 0..Hd-1) and connectivity MLP (cols Hd..2Hd-1)
+ *   b1 [2*Hd]; w2r [Hd, Hd], b2r [Hd], w3r [R, Hd], b3r [R]   (rel_predictor.layers.1/.2)
+ *   w2c [Hd, Hd], b2c [Hd], w3c [1, Hd], b3c [1]              (connectivity_layer.layers.1/.2)
+ *   rel_bias (optional) [B, N, N, R] is NOT taken: the frequency bias is gathered inside from
+ *   triplet_dist [C+1, C+1, R] with node_cls [B, N] int64 (argmax of the class logits, egtr.py:405-413);
+ *   pass triplet_dist = NULL to disable (use_freq_bias = False).
+ * Outputs: rel_logits [B, N, N, R] (incl. frequency bias), conn_logits [B, N, N] (pre-sigmoid, what the loss
+ * consumes, egtr.py:450-454); gate_mean (optional) [T] = mean over (b,i,j) of the gate (egtr.py:496-505);
+ * it is accumulated with atomics, zero it first. */
+int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
+                              const float* uk, const float* b1, const float* w2r, const float* b2r,
+                              const float* w3r, const float* b3r, const float* w2c, const float* b2c,
+                              const float* w3c, const float* b3c, const float* triplet_dist,
+                              const int64_t* node_cls, int batch, int num_query, int num_slots, int hidden,
+                              int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
+                              float* gate_mean);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGTR_HIP_H */

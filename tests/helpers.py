@@ -1,0 +1,53 @@
+"""Shared test helpers: build the product model for a golden fixture."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import weights as W
+
+
+def product_config(cfg_dict):
+    from egtr_amd.deformable_detr import DeformableDetrConfig
+    base_keys = ("num_queries", "encoder_layers", "decoder_layers", "dropout", "auxiliary_loss")
+    cfg = DeformableDetrConfig(**{k: cfg_dict[k] for k in base_keys if k in cfg_dict})
+    for k, v in cfg_dict.items():
+        if k not in base_keys:
+            setattr(cfg, k, v)
+    return cfg
+
+
+def build_product_model(cfg_dict, shapes, seed, stub_backbone=True, device="cpu"):
+    """Product DetrForSceneGraphGeneration with the fixture's seeded weights (and the fixtures' stub backbone)."""
+    import egtr_amd.deformable_detr as pdd
+    from egtr_amd.egtr import DetrForSceneGraphGeneration
+    import _ref_import
+    cfg = product_config(cfg_dict)
+    fg = W.fg_matrix(cfg.num_labels, cfg.num_rel_labels, seed=0)
+    orig = pdd.DeformableDetrTimmConvEncoder
+    if stub_backbone:
+        pdd.DeformableDetrTimmConvEncoder = _ref_import.make_stub_backbone_class()
+    try:
+        model = DetrForSceneGraphGeneration(cfg, fg_matrix=fg)
+    finally:
+        pdd.DeformableDetrTimmConvEncoder = orig
+    sd = W.fill_state_dict(shapes, seed=seed)
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(fg, cfg.freq_bias_eps)
+    return model, cfg, sd
+
+
+def small_inputs(g):
+    rng = W.rng_inputs(int(g["input_seed"]))
+    B, H, Wd = 2, int(g["H"]), int(g["W"])
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    vh, vw = [int(v) for v in g["valid1"]]
+    pm[1, vh:, :] = 0
+    pm[1, :, vw:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    return pv, pm
+
+
+def load_golden(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)

@@ -1,0 +1,254 @@
+"""GPU (-m gpu): parity of every HIP kernel, called through the C ABI (ctypes -> libegtr_hip.so), against the CPU
+oracle on the same seeded inputs and against the committed golden vectors from the reference.
+
+Tolerances (fp32 path; the north-star's bar is 1e-3 on logits):
+  MSDA forward 2e-5 abs on O(1) outputs; backward 2e-4 (grad_loc carries a factor W/H -> 5e-3);
+  self-attention 2e-5; relation head 2e-4 on logits of magnitude O(1..10).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+import weights as W
+from oracle import detr as O
+from oracle import msda as OM
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _kernels():
+    from egtr_amd.load_custom import load_hip_kernels
+    return load_hip_kernels()
+
+
+def _run_msda(x, bwd=True):
+    k = _kernels()
+    d = {n: t.to(DEV) for n, t in x.items()}
+    out = k.ms_deform_attn_forward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 64)
+    res = [out.cpu()]
+    if bwd:
+        gv, gl, ga = k.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], d["grad_out"], 64)
+        res += [gv.cpu(), gl.cpu(), ga.cpu()]
+    torch.cuda.synchronize()
+    return res
+
+
+@pytest.mark.parametrize("case", ["a", "b"])
+def test_msda_vs_reference_golden(golden_dir, case):
+    """Inputs regenerated from the fixture's seed; expected outputs are the REFERENCE's (fp32 run)."""
+    g = Hh.load_golden(golden_dir, "msda.npz")
+    c = json.loads(str(g[f"{case}_case"]))
+    x = W.make_msda_inputs(c["seed"], c["B"], c["Lq"], c["M"], c["D"], [tuple(s) for s in c["shapes"]], c["P"])
+    out, gv, gl, ga = _run_msda(x)
+    assert (out - _t(g[f"{case}_f64_out"]).float()).abs().max() < 2e-5
+    assert (gv - _t(g[f"{case}_f64_grad_value"]).float()).abs().max() < 2e-4
+    assert (ga - _t(g[f"{case}_f64_grad_attn"]).float()).abs().max() < 2e-4
+    assert (gl - _t(g[f"{case}_f64_grad_loc"]).float()).abs().max() < 5e-3
+
+
+@pytest.mark.parametrize("B,Lq,shapes", [
+    (1, 200, [(19, 32), (10, 16), (5, 8), (3, 4)]),       # decoder-like: Lq = N
+    (2, 820, [(19, 32), (10, 16), (5, 8), (3, 4)]),       # encoder-like: Lq = S
+    (4, 7, [(5, 5), (3, 3), (2, 2), (1, 1)]),             # ragged tail: nq not a multiple of waves/block
+    (1, 1, [(1, 1), (1, 1), (1, 1), (1, 1)]),             # degenerate 1x1 levels
+    (3, 33, [(8, 8), (4, 4)]),                            # L=2, P=8 (L*P = 16 fast path)
+])
+def test_msda_vs_oracle(B, Lq, shapes):
+    P = 16 // len(shapes)
+    x = W.make_msda_inputs(100 + B + Lq, B, Lq, 8, 32, shapes, P, oob_frac=0.15)
+    out, gv, gl, ga = _run_msda(x)
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    rgv, rgl, rga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"])
+    assert (out - ref).abs().max() < 2e-5
+    assert (gv - rgv).abs().max() < 2e-4
+    assert (ga - rga).abs().max() < 2e-4
+    assert (gl - rgl).abs().max() < 5e-3 * max(1.0, float(rgl.abs().max()) / 50)
+
+
+def test_msda_generic_shapes():
+    for (M, D, shapes, P) in ((3, 20, [(6, 5), (2, 3)], 2), (4, 16, [(7, 9)], 3), (8, 32, [(4, 4), (2, 2), (1, 1)], 4)):
+        x = W.make_msda_inputs(7, 2, 13, M, D, shapes, P)
+        out, gv, gl, ga = _run_msda(x)
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+        rgv, rgl, rga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"])
+        assert (out - ref).abs().max() < 2e-5 and (gv - rgv).abs().max() < 2e-4
+        assert (ga - rga).abs().max() < 2e-4 and (gl - rgl).abs().max() < 5e-3
+
+
+def test_msda_all_samples_out_of_range_and_exact_centres():
+    shapes = [(4, 5), (2, 3), (2, 2), (1, 1)]
+    x = W.make_msda_inputs(3, 1, 6, 8, 32, shapes, 4)
+    x["loc"] = torch.full_like(x["loc"], 3.0)
+    out, gv, gl, ga = _run_msda(x)
+    assert out.abs().max() == 0 and gv.abs().max() == 0 and gl.abs().max() == 0 and ga.abs().max() == 0
+    x["loc"] = torch.full_like(x["loc"], float("nan"))
+    out, gv, gl, ga = _run_msda(x)
+    assert out.abs().max() == 0 and gv.abs().max() == 0
+    # exact pixel centres of level 0 reproduce that pixel (weights 1,0,0,0), uniform attention over 16 samples
+    x = W.make_msda_inputs(3, 1, 6, 8, 32, shapes, 4)
+    loc = torch.zeros_like(x["loc"])
+    for l, (H, Wd) in enumerate(shapes):
+        loc[..., l, :, 0] = 0.5 / Wd
+        loc[..., l, :, 1] = 0.5 / H
+    x["loc"], x["attn"] = loc, torch.full_like(x["attn"], 1 / 16)
+    out = _run_msda(x, bwd=False)[0].reshape(1, 6, 8, 32)
+    starts = [0, 20, 26, 30]
+    expect = sum(x["value"][0, s] for s in starts) * 0.25
+    assert (out[0, 0] - expect).abs().max() < 1e-6
+
+
+def test_msda_full_size_properties():
+    """BASELINE shape (600x1000 -> S = 12537, encoder Lq = S): size-independent properties + sampled rows."""
+    shapes = [(75, 125), (38, 63), (19, 32), (10, 16)]
+    S = sum(h * w for h, w in shapes)
+    x = W.make_msda_inputs(11, 1, S, 8, 32, shapes, 4, oob_frac=0.05)
+    out = _run_msda(x, bwd=False)[0]
+    # (1) linearity in value
+    x2 = dict(x)
+    x2["value"] = 2.5 * x["value"]
+    assert (_run_msda(x2, bwd=False)[0] - 2.5 * out).abs().max() < 1e-4
+    # (2) constant value + all samples strictly inside => output == constant (attention weights sum to 1)
+    x3 = dict(x)
+    x3["value"] = torch.full_like(x["value"], 0.75)
+    x3["loc"] = x["loc"].clamp(0.3, 0.7)
+    assert (_run_msda(x3, bwd=False)[0] - 0.75).abs().max() < 1e-5
+    # (3) a sample of queries against the oracle
+    idx = torch.arange(0, S, 97)
+    xs = dict(x)
+    xs["loc"], xs["attn"] = x["loc"][:, idx].contiguous(), x["attn"][:, idx].contiguous()
+    ref = OM.msda_forward(xs["value"], xs["shapes"], xs["lsi"], xs["loc"], xs["attn"])
+    assert (out[:, idx] - ref).abs().max() < 2e-5
+    # (4) backward: grad_value checksum = sum over samples of in-range bilinear weight mass (grad_out = 1)
+    x["grad_out"] = torch.ones_like(x["grad_out"])
+    _, gv, gl, ga = _run_msda(x)
+    rgv, _, rga = OM.msda_backward(xs["value"], xs["shapes"], xs["lsi"], xs["loc"], xs["attn"],
+                                   torch.ones(1, len(idx), 256))
+    assert (ga[:, idx] - rga).abs().max() < 2e-4
+    assert torch.isfinite(gv).all() and torch.isfinite(gl).all()
+
+
+def test_msda_bf16_forward():
+    k = _kernels()
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    for Lq in (200, 33):
+        x = W.make_msda_inputs(21, 2, Lq, 8, 32, shapes, 4)
+        vb = x["value"].to(torch.bfloat16)
+        out = k.ms_deform_attn_forward(vb.to(DEV), x["shapes"].to(DEV), x["lsi"].to(DEV), x["loc"].to(DEV),
+                                       x["attn"].to(DEV), 64).float().cpu()
+        ref = OM.msda_forward(vb.float(), x["shapes"], x["lsi"], x["loc"], x["attn"])
+        assert (out - ref).abs().max() < 2e-2  # one bf16 rounding of an O(1) output
+
+
+def test_msda_argument_checks():
+    k = _kernels()
+    x = W.make_msda_inputs(1, 1, 4, 8, 32, [(2, 2), (1, 1), (1, 1), (1, 1)], 4)
+    with pytest.raises(RuntimeError):
+        k.ms_deform_attn_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], 64)  # CPU tensors
+    d = {n: t.to(DEV) for n, t in x.items()}
+    with pytest.raises(RuntimeError):
+        k.ms_deform_attn_forward(d["value"].transpose(1, 2), d["shapes"], d["lsi"], d["loc"], d["attn"], 64)
+
+
+# ------------------------------------------------------------------------------------------- self-attention
+def _attn_ref(q, k, v, M):
+    B, N, MD = q.shape
+    D = MD // M
+    h = lambda t: t.view(B, N, M, D).transpose(1, 2)  # noqa: E731
+    w = torch.softmax(h(q) @ h(k).transpose(-1, -2), -1)
+    return (w @ h(v)).transpose(1, 2).reshape(B, N, MD)
+
+
+@pytest.mark.parametrize("B,N", [(1, 200), (2, 100), (1, 37), (2, 300), (1, 16), (1, 5)])
+def test_self_attention_forward_backward(B, N):
+    from egtr_amd.ops import decoder_self_attention
+    rng = W.rng_inputs(50 + N)
+    q, k, v, go = [torch.from_numpy(rng.standard_normal((B, N, 256))).float() for _ in range(4)]
+    q = q * 32 ** -0.5
+    qd, kd, vd = [t.to(DEV).requires_grad_(True) for t in (q, k, v)]
+    out, qh, kh = decoder_self_attention(qd, kd, vd, 8, want_maps=True)
+    gqh, gkh = torch.from_numpy(rng.standard_normal((2, B, 8, N, 32))).float()
+    (out * go.to(DEV)).sum().backward(retain_graph=True)
+    g1 = [t.grad.clone().cpu() for t in (qd, kd, vd)]
+    q64, k64, v64 = [t.double().requires_grad_(True) for t in (q, k, v)]
+    ref = _attn_ref(q64, k64, v64, 8)
+    (ref * go.double()).sum().backward()
+    assert (out.detach().cpu() - ref.detach().float()).abs().max() < 2e-5
+    assert (qh.detach().cpu() - q.view(B, N, 8, 32).transpose(1, 2)).abs().max() == 0
+    assert (kh.detach().cpu() - k.view(B, N, 8, 32).transpose(1, 2)).abs().max() == 0
+    for a, b in zip(g1, (q64, k64, v64)):
+        assert (a - b.grad.float()).abs().max() < 5e-5 * max(1.0, float(b.grad.abs().max()))
+    # gradients flowing through the retained maps fold back into q / k
+    for t in (qd, kd, vd):
+        t.grad = None
+    ((qh * gqh.to(DEV)).sum() + (kh * gkh.to(DEV)).sum()).backward()
+    assert (qd.grad.cpu() - gqh.transpose(1, 2).reshape(B, N, 256)).abs().max() < 1e-6
+    assert (kd.grad.cpu() - gkh.transpose(1, 2).reshape(B, N, 256)).abs().max() < 1e-6
+
+
+def test_self_attention_vs_reference_golden(golden_dir):
+    """Reference MHA module fixture: q/k projections on the host, core in HIP, out_proj on the host."""
+    from egtr_amd.deformable_detr import DeformableDetrMultiheadAttention
+    g = Hh.load_golden(golden_dir, "mha.npz")
+    shapes = json.loads(str(g["shapes"]))
+    m = DeformableDetrMultiheadAttention(256, 8)
+    m.load_state_dict(W.fill_state_dict(shapes, seed=int(g["seed"])))
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        o, _, q, k = m(_t(g["x"]).to(DEV), position_embeddings=_t(g["pos"]).to(DEV), output_attention_states=True)
+    assert (o.cpu() - _t(g["out"])).abs().max() < 2e-5
+    assert (q.cpu() - _t(g["q"])).abs().max() < 1e-5 and (k.cpu() - _t(g["k"])).abs().max() < 1e-5
+
+
+# --------------------------------------------------------------------------------------------- relation head
+def _head_inputs(seed, B, N, T, R, C):
+    rng = W.rng_inputs(seed)
+    r = lambda *s, sc=1.0: torch.from_numpy(rng.standard_normal(s) * sc).float()  # noqa: E731
+    d = dict(gate_q=r(B, N, T), gate_k=r(B, N, T), uq=r(B, N, T, 512, sc=0.5), uk=r(B, N, T, 512, sc=0.5),
+             b1=r(512, sc=0.1), w2r=r(256, 256, sc=1 / 16), b2r=r(256, sc=0.1), w3r=r(R, 256, sc=1 / 16),
+             b3r=r(R, sc=0.1), w2c=r(256, 256, sc=1 / 16), b2c=r(256, sc=0.1), w3c=r(1, 256, sc=1 / 16),
+             b3c=r(1, sc=0.1))
+    trip = r(C + 1, C + 1, R)
+    node = torch.from_numpy(rng.integers(0, C + 1, (B, N))).long()
+    return d, trip, node
+
+
+@pytest.mark.parametrize("B,N,T,R", [(1, 200, 7, 50), (2, 24, 4, 7), (1, 100, 4, 30), (1, 33, 9, 64), (1, 7, 1, 1)])
+def test_relation_head_forward(B, N, T, R):
+    import cpu_kernels as ck
+    from egtr_amd.ops import relation_head
+    d, trip, node = _head_inputs(60 + N, B, N, T, R, 11)
+    dd = {k: v.to(DEV) for k, v in d.items()}
+    rel, conn, gm = relation_head(*dd.values(), trip.to(DEV), node.to(DEV), True)
+    d64 = {k: v.double() for k, v in d.items()}
+    rrel, rconn, rgm = ck.relation_head(*d64.values(), trip.double(), node, True)
+    assert (rel.cpu() - rrel.float()).abs().max() < 2e-4
+    assert (conn.cpu() - rconn.float()).abs().max() < 2e-4
+    assert (gm.cpu() - rgm.float()).abs().max() < 1e-5
+    rel2, conn2, gm2 = relation_head(*dd.values(), None, None, False)  # no frequency bias
+    rrel2, _, _ = ck.relation_head(*d64.values(), None, None, False)
+    assert (rel2.cpu() - rrel2.float()).abs().max() < 2e-4 and gm2 is None
+
+
+def test_relation_head_backward_matches_autograd():
+    import cpu_kernels as ck
+    from egtr_amd.ops import relation_head
+    d, trip, node = _head_inputs(77, 2, 12, 4, 7, 5)
+    dd = {k: v.to(DEV).requires_grad_(True) for k, v in d.items()}
+    rel, conn, _ = relation_head(*dd.values(), trip.to(DEV), node.to(DEV), False)
+    rng = W.rng_inputs(78)
+    g1 = torch.from_numpy(rng.standard_normal(tuple(rel.shape))).float()
+    g2 = torch.from_numpy(rng.standard_normal(tuple(conn.shape))).float()
+    ((rel * g1.to(DEV)).sum() + (conn * g2.to(DEV)).sum()).backward()
+    d64 = {k: v.double().requires_grad_(True) for k, v in d.items()}
+    rrel, rconn, _ = ck.relation_head(*d64.values(), trip.double(), node, False)
+    ((rrel * g1.double()).sum() + (rconn * g2.double()).sum()).backward()
+    for k in d:
+        assert (dd[k].grad.cpu() - d64[k].grad.float()).abs().max() < 1e-3 * max(1.0, float(d64[k].grad.abs().max())), k

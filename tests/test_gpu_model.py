@@ -1,0 +1,135 @@
+"""GPU (-m gpu): the full product model (real HIP kernels) against the reference's golden vectors and the oracle."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    g = Hh.load_golden(golden_dir, "sgg_small.npz")
+    return g, json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
+
+
+def test_native_library_is_the_one_loaded():
+    from egtr_amd import _lib
+    h = _lib.lib()
+    assert h.egtr_abi_version() == 1
+    maps = open("/proc/self/maps").read()
+    assert "libegtr_hip.so" in maps
+
+
+def test_forward_small_vs_reference(small):
+    g, cfg_dict, shapes = small
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    pv, pm = Hh.small_inputs(g)
+    with torch.no_grad():
+        out = model(pixel_values=pv.to(DEV), pixel_mask=pm.to(DEV), output_attentions=False,
+                    output_attention_states=True, output_hidden_states=True)
+    tol = 1e-3  # the north-star's bar for box / class / relation outputs
+    assert (out.encoder_last_hidden_state.cpu() - _t(g["enc"])).abs().max() < tol
+    assert (out["logits"].cpu() - _t(g["logits"])).abs().max() < tol
+    assert (out["pred_boxes"].cpu() - _t(g["pred_boxes"])).abs().max() < tol
+    assert (out["pred_rel"].cpu() - _t(g["pred_rel"])).abs().max() < tol
+    assert (out["pred_connectivity"].cpu() - _t(g["pred_connectivity"])).abs().max() < tol
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_loss_and_grads_small_vs_reference(small, training):
+    g, cfg_dict, shapes = small
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model = model.to(DEV).train(training)
+    pv, pm = Hh.small_inputs(g)
+    targets = [{k: t.to(DEV) for k, t in d.items()}
+               for d in W.make_targets(int(g["target_seed"]), 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+    key = "train" if training else "eval"
+    with torch.set_grad_enabled(training):
+        out = model(pixel_values=pv.to(DEV), pixel_mask=pm.to(DEV), labels=targets, output_attention_states=True)
+    ref = json.loads(str(g[f"{key}_loss_dict"]))
+    assert set(ref) == set(out.loss_dict)
+    for k, v in ref.items():
+        assert abs(float(out.loss_dict[k]) - v) < 1e-3 * max(1.0, abs(v)), (k, float(out.loss_dict[k]), v)
+    assert abs(float(out.loss) - float(g[f"{key}_loss"])) < 1e-3 * abs(float(g[f"{key}_loss"]))
+    if training:
+        out.loss.backward()
+        gn = json.loads(str(g["grad_norms"]))
+        params = dict(model.named_parameters())
+        for n, v in gn.items():
+            got = float(params[n].grad.norm())
+            assert abs(got - v) < 5e-3 * max(abs(v), 1e-2), (n, got, v)
+        for k in g.files:
+            if k.startswith("grad::"):
+                ref_g = _t(g[k])
+                assert (params[k[6:]].grad.cpu() - ref_g).abs().max() < 5e-3 * max(1.0, float(ref_g.abs().max())), k
+
+
+def test_hungarian_indices_bit_exact_on_device_outputs(small):
+    """Matcher fed with the DEVICE model's own outputs must reproduce the reference's assignment."""
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher
+    g, cfg_dict, shapes = small
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    pv, pm = Hh.small_inputs(g)
+    with torch.no_grad():
+        out = model(pixel_values=pv.to(DEV), pixel_mask=pm.to(DEV), output_attention_states=True)
+    targets = [{k: t.to(DEV) for k, t in d.items()}
+               for d in W.make_targets(int(g["target_seed"]), 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+    m = DeformableDetrHungarianMatcher(class_cost=cfg.ce_loss_coefficient, bbox_cost=cfg.bbox_cost,
+                                       giou_cost=cfg.giou_cost, smoothing=cfg.smoothing)
+    idx, costs = m({"logits": out.logits, "pred_boxes": out.pred_boxes}, targets)
+    for i, (a, b) in enumerate(idx):
+        assert np.array_equal(a.numpy(), g[f"match_pred_{i}"]) and np.array_equal(b.numpy(), g[f"match_tgt_{i}"])
+
+
+def test_full_size_600x1000_vs_reference(golden_dir):
+    """BASELINE config 2 shape: N=200, 6 enc / 6 dec, C=150, R=50, stub backbone (the fixture's)."""
+    g = Hh.load_golden(golden_dir, "sgg_full.npz")
+    cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    rng = W.rng_inputs(int(g["input_seed"]))
+    pv = torch.from_numpy(rng.standard_normal((1, 3, 600, 1000))).float().to(DEV)
+    pm = torch.ones(1, 600, 1000, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        out = model(pixel_values=pv, pixel_mask=pm, output_attention_states=True, output_hidden_states=True)
+    tol = 1e-3
+    assert (out.logits.cpu() - _t(g["logits"])).abs().max() < tol
+    assert (out.pred_boxes.cpu() - _t(g["pred_boxes"])).abs().max() < tol
+    assert (out.last_hidden_state.cpu() - _t(g["last_hidden"])).abs().max() < tol
+    assert (out.encoder_last_hidden_state.cpu()[:, ::37] - _t(g["enc_strided"])).abs().max() < tol
+    conn_logit = torch.logit(out.pred_connectivity.cpu()[..., 0].double().clamp(1e-12, 1 - 1e-12)).float()
+    assert (conn_logit - _t(g["conn_logits"])).abs().max() < 2e-3
+    assert abs(out.pred_rel.double().sum().item() - float(g["pred_rel_sum"])) < 2.0
+    assert abs(out.pred_connectivity.double().sum().item() - float(g["pred_conn_sum"])) < 0.5
+
+
+def test_resnet50_model_runs_and_is_deterministic():
+    cfg_dict = dict(num_queries=50, encoder_layers=2, decoder_layers=2, dropout=0.0, auxiliary_loss=False,
+                    num_labels=20, num_rel_labels=9, use_freq_bias=True, use_log_softmax=False, freq_bias_eps=1e-12,
+                    logit_adjustment=False, logit_adj_tau=0.3)
+    from egtr_amd.egtr import DetrForSceneGraphGeneration
+    cfg = Hh.product_config(cfg_dict)
+    torch.manual_seed(0)
+    model = DetrForSceneGraphGeneration(cfg, fg_matrix=W.fg_matrix(20, 9)).to(DEV).eval()
+    pv = torch.randn(1, 3, 224, 320, device=DEV)
+    with torch.no_grad():
+        a = model(pixel_values=pv, output_attention_states=True)
+        b = model(pixel_values=pv, output_attention_states=True)
+    assert torch.equal(a.pred_rel, b.pred_rel) and a.pred_rel.shape == (1, 50, 50, 9)
+    assert torch.isfinite(a.pred_rel).all()

@@ -1,0 +1,157 @@
+"""CPU: the product's HOST-side logic (module API mirror, state-dict contract, glue arithmetic, matcher, loss,
+autograd bridges) against the golden vectors from the reference.  The three HIP ops are replaced by
+oracle-built stand-ins through the ``cpu_kernels`` fixture -- this file does NOT test the kernels."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    g = Hh.load_golden(golden_dir, "sgg_small.npz")
+    cfg_dict = json.loads(str(g["cfg"]))
+    shapes = json.loads(str(g["shapes"]))
+    return g, cfg_dict, shapes
+
+
+def test_state_dict_key_contract(small):
+    g, cfg_dict, shapes = small
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    ref = {k: tuple(v) for k, v in shapes.items()}
+    assert own == ref  # identical key set AND shapes as the instantiated reference
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    names = [n for n, _ in model.named_parameters()]
+    for sub in ("backbone", "reference_points", "sampling_offsets"):  # LR grouping, train_egtr.py:427-463
+        assert any(sub in n for n in names)
+
+
+def test_resnet50_backbone_keys_and_shapes():
+    from egtr_amd.deformable_detr import DeformableDetrConfig, DeformableDetrTimmConvEncoder
+    enc = DeformableDetrTimmConvEncoder(DeformableDetrConfig())
+    keys = set(enc.state_dict().keys())
+    assert "model.conv1.weight" in keys and "model.layer4.2.bn3.running_var" in keys
+    assert "model.layer1.0.downsample.0.weight" in keys and "model.layer2.0.downsample.1.running_mean" in keys
+    assert not any("num_batches_tracked" in k for k in keys)
+    n_train = sum(p.numel() for p in enc.parameters() if p.requires_grad)
+    assert n_train == sum(p.numel() for n, p in enc.named_parameters() if any(f"layer{i}" in n for i in (2, 3, 4)))
+    assert abs(n_train / 1e6 - 23.2) < 0.3  # SURVEY: ~23.3 M trainable backbone params
+    with torch.no_grad():
+        out = enc(torch.randn(1, 3, 75, 100), torch.ones(1, 75, 100, dtype=torch.long))
+    assert [tuple(f.shape[1:]) for f, _ in out] == [(512, 10, 13), (1024, 5, 7), (2048, 3, 4)]
+
+
+def test_forward_matches_reference(small, cpu_kernels):
+    g, cfg_dict, shapes = small
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model.eval()
+    pv, pm = Hh.small_inputs(g)
+    with torch.no_grad():
+        out = model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
+                    output_hidden_states=True)
+    tol = 2e-4
+    assert (out["logits"] - _t(g["logits"])).abs().max() < tol
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < tol
+    assert (out["pred_rel"] - _t(g["pred_rel"])).abs().max() < tol
+    assert (out["pred_connectivity"] - _t(g["pred_connectivity"])).abs().max() < tol
+    assert (out.encoder_last_hidden_state - _t(g["enc"])).abs().max() < tol
+    assert "pred_connectivity" in out and out.loss is None and "loss" not in out
+    assert out.logits.shape == (2, cfg.num_queries, cfg.num_labels)
+    assert len(out.decoder_hidden_states) == cfg.decoder_layers + 1
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_loss_and_grads_match_reference(small, cpu_kernels, training):
+    import weights as W
+    g, cfg_dict, shapes = small
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model.train(training)
+    pv, pm = Hh.small_inputs(g)
+    targets = W.make_targets(int(g["target_seed"]), 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)
+    key = "train" if training else "eval"
+    with torch.set_grad_enabled(training):
+        out = model(pixel_values=pv, pixel_mask=pm, labels=targets, output_attentions=False,
+                    output_attention_states=True, output_hidden_states=True)
+    ref = json.loads(str(g[f"{key}_loss_dict"]))
+    assert set(ref) == set(out.loss_dict)
+    for k, v in ref.items():
+        assert abs(float(out.loss_dict[k]) - v) < 3e-4 * max(1.0, abs(v)), (k, float(out.loss_dict[k]), v)
+    assert abs(float(out.loss) - float(g[f"{key}_loss"])) < 3e-4 * abs(float(g[f"{key}_loss"]))
+    if training:
+        out.loss.backward()
+        gn = json.loads(str(g["grad_norms"]))
+        params = dict(model.named_parameters())
+        assert set(gn) == {n for n, p in params.items() if p.grad is not None}
+        for n, v in gn.items():
+            got = float(params[n].grad.norm())
+            assert abs(got - v) < 2e-3 * max(abs(v), 1e-3), (n, got, v)
+        for k in g.files:
+            if k.startswith("grad::"):
+                ref_g = _t(g[k])
+                assert (params[k[6:]].grad - ref_g).abs().max() < 2e-3 * max(1.0, float(ref_g.abs().max())), k
+
+
+def test_matcher_indices_bit_exact(small):
+    import weights as W
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher
+    g, cfg_dict, shapes = small
+    targets = W.make_targets(int(g["target_seed"]), 2, cfg_dict["num_queries"], cfg_dict["num_labels"],
+                             cfg_dict["num_rel_labels"])
+    m = DeformableDetrHungarianMatcher(class_cost=cfg_dict["ce_loss_coefficient"], bbox_cost=5, giou_cost=2,
+                                       smoothing=cfg_dict["smoothing"])
+    idx, costs = m({"logits": _t(g["logits"]), "pred_boxes": _t(g["pred_boxes"])}, targets)
+    for i, ((a, b), c) in enumerate(zip(idx, costs)):
+        assert np.array_equal(a.numpy(), g[f"match_pred_{i}"]) and np.array_equal(b.numpy(), g[f"match_tgt_{i}"])
+        assert np.abs(c.numpy() - g[f"match_cost_{i}"]).max() < 1e-5
+
+
+def test_aux_loss_matches_reference(small, cpu_kernels, golden_dir):
+    import weights as W
+    g, cfg_dict, shapes = small
+    ga = Hh.load_golden(golden_dir, "sgg_small_aux.npz")
+    cfg_aux = json.loads(str(ga["cfg"]))
+    model, cfg, sd = Hh.build_product_model(cfg_aux, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model.train()
+    pv, pm = Hh.small_inputs(g)
+    targets = W.make_targets(int(g["target_seed"]), 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)
+    out = model(pixel_values=pv, pixel_mask=pm, labels=targets, output_attention_states=True)
+    ref = json.loads(str(ga["train_loss_dict"]))
+    assert set(ref) == set(out.loss_dict)
+    for k, v in ref.items():
+        assert abs(float(out.loss_dict[k]) - v) < 3e-4 * max(1.0, abs(v)), (k, float(out.loss_dict[k]), v)
+    assert abs(float(out.loss) - float(ga["train_loss"])) < 3e-4 * abs(float(ga["train_loss"]))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No fallback: with the .so absent every kernel entry point raises."""
+    import egtr_amd._lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.EgtrHipError):
+        L.lib()
+    from egtr_amd.load_custom import load_hip_kernels
+    with pytest.raises(L.EgtrHipError):
+        load_hip_kernels()
+
+
+def test_output_object_and_config_roundtrip(tmp_path, small):
+    from egtr_amd.deformable_detr import DeformableDetrConfig
+    g, cfg_dict, shapes = small
+    cfg = Hh.product_config(cfg_dict)
+    cfg.save_pretrained(str(tmp_path))
+    cfg2 = DeformableDetrConfig.from_pretrained(str(tmp_path))
+    assert cfg2.num_queries == cfg.num_queries and cfg2.num_rel_labels == cfg.num_rel_labels
+    assert cfg2.num_labels == cfg.num_labels and cfg2.smoothing == cfg.smoothing
+    assert cfg2.use_return_dict and cfg2.hidden_size == 256 and cfg2.num_attention_heads == 8
