@@ -702,6 +702,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
         self.decoder = DeformableDetrDecoder(config)
         self.level_embed = nn.Parameter(torch.Tensor(config.num_feature_levels, config.d_model))
         self.reference_points = nn.Linear(config.d_model, 2)
+        self._geom_cache = {}
         self.post_init()
 
     def get_encoder(self):
@@ -765,8 +766,16 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
         source_flatten = torch.cat(source_flatten, 1)
         mask_flatten = torch.cat(mask_flatten, 1)
         lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
-        spatial_shapes = torch.as_tensor(spatial_shapes_list, dtype=torch.long, device=source_flatten.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        # the (tiny) level-geometry tensors are cached per shape: built once with a synchronous H2D copy, then
+        # reused, which keeps the forward free of host<->device traffic and capturable in a HIP graph
+        key = (tuple(spatial_shapes_list), str(source_flatten.device))
+        cached = self._geom_cache.get(key)
+        if cached is None:
+            spatial_shapes = torch.as_tensor(spatial_shapes_list, dtype=torch.long, device=source_flatten.device)
+            level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+            self._geom_cache[key] = (spatial_shapes, level_start_index)
+        else:
+            spatial_shapes, level_start_index = cached
         valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1).float()
 
         if encoder_outputs is None:

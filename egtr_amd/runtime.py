@@ -1,0 +1,158 @@
+"""Run-time helpers around the model: HIP-graph replay of the inference forward, the reference's optimizer
+grouping, and one-process-per-GPU data parallelism over RCCL (``torch.distributed`` backend "nccl" on ROCm).
+
+The reference drives training through pytorch-lightning (train_egtr.py:770-783: DDPStrategy, accumulate 2,
+clip 0.1) and measures FPS with a bare loop (evaluate_egtr.py:26-36).  Lightning is not part of the hot path and
+is absent on the GPU box; these helpers reproduce exactly the pieces that touch it.
+"""
+import contextlib
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class GraphedForward:
+    """Replay ``model(pixel_values, pixel_mask, output_attention_states=True, output_hidden_states=True)`` from a
+    captured HIP graph.  At bs = 1 the forward is ~700 short kernels, i.e. launch-bound when issued eagerly
+    (MI355X_MICROARCH.md: eager launch ~3.3-3.8 us host time each); a graph replay issues them back-to-back.
+    Inputs are copied into static buffers; outputs are the graph's static tensors (valid until the next call).
+    Falls back to eager launches (``self.graphed = False``) if capture is not possible -- same kernels either way."""
+
+    def __init__(self, model, enabled=True, warmup=2):
+        self.model = model
+        self.enabled = enabled
+        self.warmup = warmup
+        self.graphed = False
+        self._graph = None
+        self._key = None
+        self._static_in = None
+        self._static_out = None
+        self.capture_error = None
+
+    def _eager(self, pv, pm):
+        return self.model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
+                          output_hidden_states=True)
+
+    def _capture(self, pv, pm):
+        self._static_in = (pv.clone(), pm.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup):
+                self._eager(*self._static_in)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_out = self._eager(*self._static_in)
+        self._graph = g
+        self._key = (tuple(pv.shape), tuple(pm.shape), pv.device)
+        self.graphed = True
+
+    @torch.no_grad()
+    def __call__(self, pv, pm):
+        if not self.enabled:
+            return self._eager(pv, pm)
+        key = (tuple(pv.shape), tuple(pm.shape), pv.device)
+        if self._graph is None or key != self._key:
+            try:
+                self._capture(pv, pm)
+            except Exception as e:  # capture unsupported by some library call: run eagerly, same kernels
+                self.capture_error = repr(e)
+                self.enabled = False
+                self.graphed = False
+                torch.cuda.synchronize()
+                return self._eager(pv, pm)
+        self._static_in[0].copy_(pv)
+        self._static_in[1].copy_(pm)
+        self._graph.replay()
+        return self._static_out
+
+
+def configure_optimizers(model, lr=2e-6, lr_backbone=2e-7, lr_initialized=2e-4, weight_decay=1e-4,
+                         initialized_keys=()):
+    """The reference's three AdamW parameter groups (train_egtr.py:426-467)."""
+    diff = ["backbone", "reference_points", "sampling_offsets"]
+    init = list(initialized_keys) if lr_initialized is not None else []
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    groups = [{"params": [p for n, p in named if not any(d in n for d in diff) and not any(d in n for d in init)]},
+              {"params": [p for n, p in named if any(d in n for d in diff)], "lr": lr_backbone}]
+    if init:
+        groups.append({"params": [p for n, p in named if any(d in n for d in init)], "lr": lr_initialized})
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+
+
+def init_distributed():
+    """One process per GPU; RCCL over xGMI when GPUs are present, gloo on CPU (tests).  Reads the torchrun env."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if torch.cuda.is_available():
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+    else:
+        dist.init_process_group("gloo")
+    return world
+
+
+class DataParallelTrainer:
+    """Data-parallel train step with the reference's semantics (train_egtr.py:303-319, 770-779):
+    identical replicas, per-rank micro-batches, gradient all-reduce (bucketed, overlapped with backward by DDP)
+    once per optimizer step -- micro-steps before the accumulation boundary run under ``no_sync`` -- then
+    clip-grad-norm 0.1 and AdamW.  ``num_boxes`` stays per-rank (model/egtr.py:976-980)."""
+
+    def __init__(self, model, optimizer=None, accumulate=2, clip=0.1, bucket_cap_mb=25):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.raw = model
+        if self.world > 1:
+            ids = [torch.cuda.current_device()] if next(model.parameters()).is_cuda else None
+            self.model = torch.nn.parallel.DistributedDataParallel(
+                model, device_ids=ids, find_unused_parameters=False, bucket_cap_mb=bucket_cap_mb,
+                gradient_as_bucket_view=True)
+        else:
+            self.model = model
+        self.opt = optimizer if optimizer is not None else configure_optimizers(model)
+        self.accumulate = accumulate
+        self.clip = clip
+        self._micro = 0
+
+    def common_step(self, batch):
+        out = self.model(pixel_values=batch["pixel_values"], pixel_mask=batch["pixel_mask"], labels=batch["labels"],
+                         output_attentions=False, output_attention_states=True, output_hidden_states=True)
+        return out.loss, out.loss_dict
+
+    def training_step(self, batch):
+        """One micro-batch; returns (loss, loss_dict, stepped)."""
+        self._micro += 1
+        boundary = self._micro % self.accumulate == 0
+        ctx = contextlib.nullcontext() if (boundary or self.world == 1) else self.model.no_sync()
+        with ctx:
+            loss, loss_dict = self.common_step(batch)
+            (loss / self.accumulate).backward()
+        if boundary:
+            torch.nn.utils.clip_grad_norm_(self.raw.parameters(), self.clip)
+            self.opt.step()
+            self.opt.zero_grad(set_to_none=True)
+        return loss.detach(), loss_dict, boundary
+
+
+@torch.no_grad()
+def calculate_fps(model, batches, warmup=3):
+    """evaluate_egtr.py:26-36 with warm-up and synchronisation (the reference's loop has neither)."""
+    import time
+    model.eval()
+    n = 0
+    t0 = None
+    for i, batch in enumerate(batches):
+        if i == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        model(pixel_values=batch["pixel_values"].cuda(), pixel_mask=batch["pixel_mask"].cuda(),
+              output_attentions=False, output_attention_states=True, output_hidden_states=True)
+        if i >= warmup:
+            n += batch["pixel_values"].shape[0]
+    torch.cuda.synchronize()
+    return n / (time.perf_counter() - t0) if t0 is not None and n else float("nan")

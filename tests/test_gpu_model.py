@@ -40,7 +40,18 @@ def test_forward_small_vs_reference(small):
         out = model(pixel_values=pv.to(DEV), pixel_mask=pm.to(DEV), output_attentions=False,
                     output_attention_states=True, output_hidden_states=True)
     tol = 1e-3  # the north-star's bar for box / class / relation outputs
-    assert (out.encoder_last_hidden_state.cpu() - _t(g["enc"])).abs().max() < tol
+    # Encoder states are compared on REAL (unpadded) tokens only: at padded tokens the sine position embedding
+    # evaluates sin/cos of ~1e6-sized arguments ((y - 0.5) / (0 + 1e-6) * 2 pi, dd:857-858), which is ill-conditioned
+    # (a 1-ulp difference between CPU and GPU division moves the result by O(1)); those tokens are masked out of
+    # every value tensor (dd:1052) and never reach the decoder.
+    valid = model.model(pv.to(DEV), pm.to(DEV), output_attention_states=True).encoder_last_hidden_state  # noqa: F841
+    import torch.nn.functional as F
+    masks = []
+    for (h, w) in ((12, 16), (6, 8), (3, 4), (2, 2)):
+        masks.append(F.interpolate(pm[None].float(), size=(h, w)).to(torch.bool)[0].flatten(1))
+    mflat = torch.cat(masks, 1)
+    diff = (out.encoder_last_hidden_state.cpu() - _t(g["enc"])).abs()
+    assert diff[mflat].max() < tol
     assert (out["logits"].cpu() - _t(g["logits"])).abs().max() < tol
     assert (out["pred_boxes"].cpu() - _t(g["pred_boxes"])).abs().max() < tol
     assert (out["pred_rel"].cpu() - _t(g["pred_rel"])).abs().max() < tol
@@ -131,5 +142,47 @@ def test_resnet50_model_runs_and_is_deterministic():
     with torch.no_grad():
         a = model(pixel_values=pv, output_attention_states=True)
         b = model(pixel_values=pv, output_attention_states=True)
-    assert torch.equal(a.pred_rel, b.pred_rel) and a.pred_rel.shape == (1, 50, 50, 9)
+    # MIOpen's convolutions are not bit-reproducible run to run (measured: 1e-7 differences in the backbone output
+    # with identical inputs); the hand-written kernels are (test_kernels_are_bitwise_deterministic)
+    assert (a.pred_rel - b.pred_rel).abs().max() < 1e-5 and a.pred_rel.shape == (1, 50, 50, 9)
     assert torch.isfinite(a.pred_rel).all()
+
+
+def test_kernels_are_bitwise_deterministic():
+    from egtr_amd.load_custom import load_hip_kernels
+    from egtr_amd.ops import decoder_self_attention, relation_head
+    import test_gpu_kernels as T
+    k = load_hip_kernels()
+    x = W.make_msda_inputs(1, 2, 820, 8, 32, [(19, 32), (10, 16), (5, 8), (3, 4)], 4)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    outs = [k.ms_deform_attn_forward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 64) for _ in range(4)]
+    assert all(torch.equal(outs[0], o) for o in outs)
+    q, kk, v = [torch.randn(2, 200, 256, device=DEV) for _ in range(3)]
+    o = [decoder_self_attention(q, kk, v, 8, True)[0] for _ in range(4)]
+    assert all(torch.equal(o[0], t) for t in o)
+    dd, trip, node = T._head_inputs(60, 1, 100, 7, 50, 11)
+    dd = {a: b.to(DEV) for a, b in dd.items()}
+    r = [relation_head(*dd.values(), trip.to(DEV), node.to(DEV), False)[0] for _ in range(4)]
+    assert all(torch.equal(r[0], t) for t in r)
+
+
+def test_graph_replay_matches_eager():
+    """The bench's HIP-graph replay runs the same kernels as eager launches: identical outputs."""
+    from egtr_amd.egtr import DetrForSceneGraphGeneration
+    from egtr_amd.runtime import GraphedForward
+    cfg_dict = dict(num_queries=40, encoder_layers=1, decoder_layers=2, dropout=0.0, auxiliary_loss=False,
+                    num_labels=20, num_rel_labels=9, use_freq_bias=True, use_log_softmax=False, freq_bias_eps=1e-12,
+                    logit_adjustment=False, logit_adj_tau=0.3)
+    cfg = Hh.product_config(cfg_dict)
+    torch.manual_seed(0)
+    model = DetrForSceneGraphGeneration(cfg, fg_matrix=W.fg_matrix(20, 9)).to(DEV).eval()
+    g = GraphedForward(model, enabled=True)
+    for seed in (1, 2):
+        torch.manual_seed(seed)
+        pv = torch.randn(1, 3, 160, 224, device=DEV)
+        pm = torch.ones(1, 160, 224, dtype=torch.long, device=DEV)
+        with torch.no_grad():
+            e = model(pixel_values=pv, pixel_mask=pm, output_attention_states=True)
+        r = g(pv, pm)
+        assert g.graphed, g.capture_error
+        assert (r.pred_rel - e.pred_rel).abs().max() < 1e-5 and (r.pred_boxes - e.pred_boxes).abs().max() < 1e-5
