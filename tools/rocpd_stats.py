@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd SQLite result (ROCm 7.2 default output) into a per-kernel stats table
+(the same columns as `rocprofv3 --stats`' kernel_stats.csv): calls, total / average / min / max duration, %.
+
+    python tools/rocpd_stats.py gpurun_out/prof/x_results.db [--top 40] [--csv out.csv]
+"""
+import argparse
+import csv
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\[clone .*?\]", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name if len(name) <= 110 else name[:107] + "..."
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--csv", default=None)
+    a = ap.parse_args()
+    c = sqlite3.connect(a.db)
+    rows = c.execute("select name, start, end from kernels").fetchall()
+    agg = {}
+    for name, s, e in rows:
+        d = agg.setdefault(name, [0, 0, 1 << 62, 0])
+        dur = e - s
+        d[0] += 1
+        d[1] += dur
+        d[2] = min(d[2], dur)
+        d[3] = max(d[3], dur)
+    total = sum(v[1] for v in agg.values()) or 1
+    table = sorted(((n, v[0], v[1], v[1] / v[0], v[2], v[3], 100.0 * v[1] / total) for n, v in agg.items()),
+                   key=lambda r: -r[2])
+    out = [("Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage")]
+    out += [(short(n), c_, t, round(avg, 1), mn, mx, round(pc, 3)) for n, c_, t, avg, mn, mx, pc in table]
+    if a.csv:
+        with open(a.csv, "w", newline="") as f:
+            csv.writer(f).writerows(out)
+    print(f"{len(rows)} dispatches, {len(agg)} distinct kernels, total kernel time {total / 1e6:.3f} ms")
+    for r in out[: a.top + 1]:
+        print("%-112s %7s %14s %11s %9s %9s %8s" % r)
+
+
+if __name__ == "__main__":
+    sys.exit(main())
