@@ -25,95 +25,11 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "msda_common.h"
 
 namespace {
 
-constexpr int kWaves = 4;  // waves (= queries) per workgroup in the wave-per-query kernels
-
-// Level geometry of up to four levels, held in scalar registers (plain members, never indexed dynamically,
-// so nothing is spilled to scratch).
-struct LevelGeom {
-  int H0, H1, H2, H3, W0, W1, W2, W3, s0, s1, s2, s3;
-};
-
-// Select one of four wave-uniform values by a per-lane level index.
-__device__ __forceinline__ int sel4(int a0, int a1, int a2, int a3, int l) {
-  int r = a0;
-  r = (l == 1) ? a1 : r;
-  r = (l == 2) ? a2 : r;
-  r = (l == 3) ? a3 : r;
-  return r;
-}
-#define SEL_H(G, l) sel4(G.H0, G.H1, G.H2, G.H3, l)
-#define SEL_W(G, l) sel4(G.W0, G.W1, G.W2, G.W3, l)
-#define SEL_S(G, l) sel4(G.s0, G.s1, G.s2, G.s3, l)
-
-// XCD-aware bijective remap: block b runs on XCD b%8 (observed dispatch order, used for speed only);
-// give XCD x the x-th contiguous chunk of logical work items.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int q = nblk >> 3, r = nblk & 7;
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
-
-struct SampleGeom {
-  int off[4];    // byte offsets (within one batch image) of the 4 clamped corners, head+level folded in
-  float w[4];    // bilinear weights hh*hw, hh*lw, lh*hw, lh*lw
-  bool ok[4];    // per-corner in-range (and sample valid)
-  float lh, lw;
-  bool valid;
-};
-
-// Geometry of one sample (reference cuh:38-78 / 268-288).  x,y already scaled: x = loc_x*W - 0.5.
-template <int ROW_BYTES /* M*D*sizeof(elt) */, int HEAD_BYTES /* D*sizeof(elt) */>
-__device__ __forceinline__ SampleGeom sample_geom(float lx, float ly, int H, int W, int start, int head) {
-  SampleGeom g;
-  const float x = lx * (float)W - 0.5f;
-  const float y = ly * (float)H - 0.5f;
-  g.valid = (y > -1.f) && (x > -1.f) && (y < (float)H) && (x < (float)W);
-  const float yf = floorf(y), xf = floorf(x);
-  g.lh = y - yf;
-  g.lw = x - xf;
-  const float hh = 1.f - g.lh, hw = 1.f - g.lw;
-  // NaN / huge coordinates: valid == false, so every weight is zeroed; clamp keeps addresses in range.
-  int y0 = g.valid ? (int)yf : 0, x0 = g.valid ? (int)xf : 0;
-  const int y1 = y0 + 1, x1 = x0 + 1;
-  const bool y0ok = y0 >= 0, x0ok = x0 >= 0, y1ok = y1 <= H - 1, x1ok = x1 <= W - 1;
-  g.ok[0] = g.valid && y0ok && x0ok;
-  g.ok[1] = g.valid && y0ok && x1ok;
-  g.ok[2] = g.valid && y1ok && x0ok;
-  g.ok[3] = g.valid && y1ok && x1ok;
-  g.w[0] = hh * hw;
-  g.w[1] = hh * g.lw;
-  g.w[2] = g.lh * hw;
-  g.w[3] = g.lh * g.lw;
-  const int y0c = max(y0, 0), x0c = max(x0, 0), y1c = min(y1, H - 1), x1c = min(x1, W - 1);
-  const int r0 = (start + y0c * W) * ROW_BYTES + head * HEAD_BYTES;
-  const int r1 = (start + y1c * W) * ROW_BYTES + head * HEAD_BYTES;
-  g.off[0] = r0 + x0c * ROW_BYTES;
-  g.off[1] = r0 + x1c * ROW_BYTES;
-  g.off[2] = r1 + x0c * ROW_BYTES;
-  g.off[3] = r1 + x1c * ROW_BYTES;
-  return g;
-}
-
-__device__ __forceinline__ void load_geom(const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-                                          int L, LevelGeom& g) {
-  const int l1 = (1 < L) ? 1 : 0, l2 = (2 < L) ? 2 : 0, l3 = (3 < L) ? 3 : 0;
-  g.H0 = (int)shapes[0];
-  g.W0 = (int)shapes[1];
-  g.s0 = (int)lsi[0];
-  g.H1 = (int)shapes[2 * l1];
-  g.W1 = (int)shapes[2 * l1 + 1];
-  g.s1 = (int)lsi[l1];
-  g.H2 = (int)shapes[2 * l2];
-  g.W2 = (int)shapes[2 * l2 + 1];
-  g.s2 = (int)lsi[l2];
-  g.H3 = (int)shapes[2 * l3];
-  g.W3 = (int)shapes[2 * l3 + 1];
-  g.s3 = (int)lsi[l3];
-}
+using namespace egtr_msda;
 
 // LDS record layout: [wave][head][sample] 16-byte entries, head stride padded by one entry so that the four
 // heads served together by one ds_read_b128 lane group land on distinct banks (MI355X_MICROARCH.md, LDS).
@@ -488,18 +404,31 @@ bool fast_shape(int M, int D, int L, int P) { return M == 8 && D == 32 && L >= 1
 
 }  // namespace
 
-extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                     const int64_t* level_start_index, const float* sampling_loc,
-                                     const float* attn_weight, int batch, int spatial_size, int num_heads,
-                                     int channels, int num_levels, int num_query, int num_point, float* out) {
+int egtr_launch_msda_fwd_tile_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
+                                  const float* loc, const float* attn, float* out, int B, int Lq, int S, int L,
+                                  int P);
+
+// variant: 0 = automatic (tile kernel for encoder-shaped calls Lq == S, wave-per-query otherwise),
+//          1 = wave-per-query, 2 = tile x head with LDS windows, 3 = generic one-thread-per-element.
+extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value,
+                                             const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                             const float* sampling_loc, const float* attn_weight, int batch,
+                                             int spatial_size, int num_heads, int channels, int num_levels,
+                                             int num_query, int num_point, float* out, int variant) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out) return EGTR_E_ARG;
   if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
       num_point <= 0)
     return EGTR_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long nq = (long long)batch * num_query;
-  if (fast_shape(num_heads, channels, num_levels, num_point) && (long long)spatial_size * 1024 < (1ll << 31) &&
-      nq < (1ll << 30)) {
+  const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
+                    (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
+  if (variant == 0) variant = fast ? ((num_query == spatial_size && num_query >= 1024) ? 2 : 1) : 3;
+  if ((variant == 1 || variant == 2) && !fast) return EGTR_E_UNSUPPORTED;
+  if (variant == 2)
+    return egtr_launch_msda_fwd_tile_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                         out, batch, num_query, spatial_size, num_levels, num_point);
+  if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(msda_fwd_q64_f32, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
@@ -513,6 +442,15 @@ extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, c
                        num_levels, num_query, num_point);
   }
   return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start_index, const float* sampling_loc,
+                                     const float* attn_weight, int batch, int spatial_size, int num_heads,
+                                     int channels, int num_levels, int num_query, int num_point, float* out) {
+  return egtr_msda_forward_f32_variant(stream, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                       batch, spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                       out, 0);
 }
 
 extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,

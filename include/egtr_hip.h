@@ -56,6 +56,22 @@ int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_
                           int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                           int num_point, float* out);
 
+/* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
+ * 1 = wave-per-query, 2 = query-tile x head with LDS-staged windows, 3 = generic one-thread-per-element.
+ * Every variant computes the same function; EGTR_E_UNSUPPORTED if the shape rules out the requested variant. */
+int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const float* sampling_loc,
+                                  const float* attn_weight, int batch, int spatial_size, int num_heads, int channels,
+                                  int num_levels, int num_query, int num_point, float* out, int variant);
+
+/* Profiling hook for variant 2 (M = 8, D = 32): runs the tile kernel with per-phase accounting.  cycles (device,
+ * 4 x uint64, zero it first) receives the shader-clock cycles summed over work items of phase A (geometry + bounding
+ * boxes), phase B (records + window staging), phase C (gather) and the number of work items. */
+int egtr_msda_tile_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, const float* sampling_loc,
+                                const float* attn_weight, int batch, int spatial_size, int num_levels, int num_query,
+                                int num_point, float* out, unsigned long long* cycles);
+
 /* grad_value [B,S,M,D] MUST be zero-initialised by the caller (accumulated with atomics, as cu:124 relies on);
  * grad_sampling_loc [B,Lq,M,L,P,2] and grad_attn_weight [B,Lq,M,L,P] are fully overwritten. */
 int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const float* value,

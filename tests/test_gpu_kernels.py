@@ -73,6 +73,76 @@ def test_msda_vs_oracle(B, Lq, shapes):
     assert (gl - rgl).abs().max() < 5e-3 * max(1.0, float(rgl.abs().max()) / 50)
 
 
+def _grid_inputs(seed, B, shapes, jitter, dtype=torch.float32):
+    """Encoder-like operands: queries = the pixels of the levels, samples = reference + ring offsets + jitter."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    M, L, P = 8, len(shapes), 16 // len(shapes)
+    S = sum(h * w for h, w in shapes)
+    refs = []
+    for (h, w) in shapes:
+        ys, xs = torch.meshgrid(torch.linspace(0.5, h - 0.5, h) / h, torch.linspace(0.5, w - 0.5, w) / w, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1), ys.reshape(-1)], -1))
+    ref = torch.cat(refs, 0)
+    th = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+    grid = torch.stack([th.cos(), th.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(M, 1, 1, 2).repeat(1, L, P, 1)
+    for i in range(P):
+        grid[:, :, i, :] *= i + 1
+    off = grid[None, None] + jitter * torch.randn(B, S, M, L, P, 2, generator=g)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32)
+    loc = ref[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
+    attn = torch.softmax(torch.randn(B, S, M, L * P, generator=g), -1).view(B, S, M, L, P)
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    return dict(value=torch.randn(B, S, M, 32, generator=g), shapes=shp, lsi=lsi, loc=loc.contiguous(),
+                attn=attn.contiguous(), grad_out=torch.randn(B, S, 256, generator=g))
+
+
+@pytest.mark.parametrize("shapes,B,jitter", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),     # windows fit: LDS path
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 1, 8.0),     # scattered offsets: windows overflow -> mixed LDS/global
+    ([(38, 63), (19, 32), (10, 16), (5, 8)], 1, 1.0),   # ragged 8x8 tiles on every level
+    ([(9, 13), (5, 7)], 3, 0.5),                        # L = 2, P = 8
+    ([(16, 16)], 1, 0.5),                               # L = 1, P = 16
+])
+def test_msda_tile_variant_matches_oracle_and_wave_variant(shapes, B, jitter):
+    """Variant 2 (query tile x head, LDS-staged windows) on encoder-shaped calls (queries = pixels)."""
+    k = _kernels()
+    x = _grid_inputs(5, B, shapes, jitter)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    o2 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 2).cpu()
+    o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert (o2 - ref).abs().max() < 2e-5
+    assert (o2 - o1).abs().max() < 2e-5
+
+
+def test_msda_tile_variant_arbitrary_queries():
+    """Variant 2 when the queries are NOT the pixel grid (Lq != S or random locations): linear tiles, windows
+    rarely fit, results must still be exact; plus all-out-of-range and NaN locations."""
+    k = _kernels()
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    for Lq in (200, 820, 65):
+        x = W.make_msda_inputs(31 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
+        d = {n: t.to(DEV) for n, t in x.items()}
+        o2 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 2).cpu()
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+        assert (o2 - ref).abs().max() < 2e-5
+    x = _grid_inputs(6, 1, shapes, 0.3)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    for bad in (3.0, float("nan")):
+        loc = torch.full_like(d["loc"], bad)
+        o2 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], 2)
+        assert o2.abs().max().item() == 0
+    # half the queries far outside, half inside
+    loc = d["loc"].clone()
+    loc[:, ::2] = 5.0
+    o2 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], 2).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc.cpu(), x["attn"])
+    assert (o2 - ref).abs().max() < 2e-5
+
+
 def test_msda_generic_shapes():
     for (M, D, shapes, P) in ((3, 20, [(6, 5), (2, 3)], 2), (4, 16, [(7, 9)], 3), (8, 32, [(4, 4), (2, 2), (1, 1)], 4)):
         x = W.make_msda_inputs(7, 2, 13, M, D, shapes, P)

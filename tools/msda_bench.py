@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="800x1333 shapes")
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="print per-phase cycles of the tile kernel")
+    ap.add_argument("--variant", type=int, default=0, help="forward kernel variant (include/egtr_hip.h)")
     a = ap.parse_args()
     from egtr_amd.load_custom import load_hip_kernels
     k = load_hip_kernels()
@@ -65,7 +67,23 @@ def main():
                                              dtype=torch.bfloat16 if a.bf16 else torch.float32)
     go = torch.randn(a.batch, loc.shape[1], 256, device=dev)
     fn = (lambda: k.ms_deform_attn_backward(value, shp, lsi, loc, attn, go, 64)) if a.bwd else \
-        (lambda: k.ms_deform_attn_forward(value, shp, lsi, loc, attn, 64))
+        ((lambda: k.ms_deform_attn_forward_variant(value, shp, lsi, loc, attn, a.variant))
+         if (a.variant and not a.bf16) else (lambda: k.ms_deform_attn_forward(value, shp, lsi, loc, attn, 64)))
+    if a.phases:
+        from egtr_amd import _lib
+        cyc = torch.zeros(4, dtype=torch.int64, device=dev)
+        out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
+        for _ in range(3):
+            cyc.zero_()
+            st = _lib.lib().egtr_msda_tile_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
+                                                        shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
+                                                        attn.data_ptr(), a.batch, value.shape[1], shp.shape[0],
+                                                        loc.shape[1], 4, out.data_ptr(), cyc.data_ptr())
+            _lib.check(st, "phase cycles")
+            torch.cuda.synchronize()
+        c = cyc.tolist()
+        print(f"tile kernel phases per work item (s_memtime ticks): A={c[0]/c[3]:.0f} B={c[1]/c[3]:.0f} "
+              f"C={c[2]/c[3]:.0f} items={c[3]}")
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
@@ -82,7 +100,7 @@ def main():
     alg = B * (min(S * 256 * e, Lq * 8 * 16 * 4 * 32 * e) + Lq * 256 * 4 + Lq * 128 * 4 + Lq * 256 * e)
     if a.bwd:
         alg += B * (Lq * 256 * 4 + 2 * S * 256 * 4 + Lq * 256 * 4 + Lq * 128 * 4)
-    print(f"msda {'bwd' if a.bwd else 'fwd'} lq={a.lq} B={B} S={S} Lq={Lq} {'bf16' if a.bf16 else 'f32'}: "
+    print(f"msda {'bwd' if a.bwd else 'fwd'} variant={a.variant} jitter={a.jitter} lq={a.lq} B={B} S={S} Lq={Lq} {'bf16' if a.bf16 else 'f32'}: "
           f"{us:.2f} us/launch (incl. the zero-fill of grad_value for bwd), algorithmic {alg / 1e6:.2f} MB -> "
           f"{alg / us / 1e3:.1f} GB/s = {alg / us / 1e3 / 8000 * 100:.1f}% of 8 TB/s")
 

@@ -1,18 +1,20 @@
 #!/bin/bash
 # Collect PMC counters for a command in separate rocprofv3 passes (counters never combined with tracing other
-# than --kernel-trace).  Usage: tools/pmc_passes.sh <outdir> <tag> -- <program> [args...]
+# than --kernel-trace).  Usage: tools/pmc_passes.sh <outdir> <tag> <pass-set> -- <program> [args...]
+#   pass-set: "mem" (FETCH/WRITE/L2/L1), "sq" (wave/instruction/LDS counters), "all"
+# Each pass runs under its own `timeout 150` (TA_* counters were seen to abort rocprofv3 on this pool: not used).
 set -u
-out=$1; tag=$2; shift 3
+out=$1; tag=$2; set_=$3; shift 4
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
+MEM=("FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum")
+SQ=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+    "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD" \
+    "SQ_WAIT_INST_LDS SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_IFETCH SQ_LDS_DATA_FIFO_FULL")
+case "$set_" in mem) P=("${MEM[@]}");; sq) P=("${SQ[@]}");; *) P=("${MEM[@]}" "${SQ[@]}");; esac
 i=0
-for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
-            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
-            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
-            "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" \
-            "GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD" \
-            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_READ_sum"; do
+for ctrs in "${P[@]}"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs -d "$out/${tag}_p$i" -o pmc -- "$@" > "$out/${tag}_p$i.log" 2>&1
-  echo "pass $i ($ctrs): rc=$?"
+  timeout 150 rocprofv3 --kernel-trace --pmc $ctrs -d "$out/${tag}_${set_}$i" -o pmc -- "$@" > "$out/${tag}_${set_}$i.log" 2>&1
+  echo "pass $set_$i ($ctrs): rc=$?"
 done
