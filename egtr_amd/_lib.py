@@ -22,9 +22,11 @@ SIGNATURES = {
     "egtr_msda_forward_f32_variant": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I],
     "egtr_msda_tile_phase_cycles": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "egtr_msda_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
+    "egtr_msda_backward_f32_variant": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I],
     "egtr_msda_forward_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "egtr_self_attn_forward_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "egtr_self_attn_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "egtr_linear_f32": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I],
     "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
 }
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p}

@@ -1,0 +1,87 @@
+// Skinny fp32 linear layer for gfx950: Y[M,N] = act((X[M,K] . W[N,K]^T + b[N]) * alpha), M small (object queries).
+//
+// Why: the decoder, the detection heads and the relation-head projections apply ~60 nn.Linear layers per image to
+// M = 200 query rows.  hipBLASLt serves those from a 256x208 macro-tile kernel -- ONE workgroup, 54 us per call
+// (rocprofv3, profiles/r01_bench_kernel_stats.txt: 62 calls = 3.3 ms of a 12 ms forward).  Here a workgroup owns a
+// 16 x 32 output tile; its 4 waves split K four ways (and the 4 lane groups of a wave split it again), so a K = 256
+// product is 32 exact-f32 MFMAs (v_mfma_f32_16x16x4_f32) per wave, followed by an LDS reduction and a fused
+// bias / scale / ReLU epilogue.  104 workgroups for a 200 x 256 output.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// SPAN = K / 16 floats handled by one (wave, lane-group); compile-time for full unrolling: 16 (K=256), 64 (K=1024),
+// 32 (K=512); generic runtime variant below for other K % 64 == 0.
+template <int SPAN>
+__global__ __launch_bounds__(256) void linear_skinny_f32(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         int M, int K, int N, float alpha, int relu, int span_rt) {
+  __shared__ float s_red[4 * 2 * 64 * 4];
+  const int span = SPAN > 0 ? SPAN : span_rt;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
+  const int kb = (wave * 4 + g) * span;
+  const int row = min(m0 + c, M - 1);
+  const int wr0 = min(n0 + c, N - 1), wr1 = min(n0 + 16 + c, N - 1);
+  const float4* xp = reinterpret_cast<const float4*>(x + (size_t)row * K + kb);
+  const float4* w0 = reinterpret_cast<const float4*>(w + (size_t)wr0 * K + kb);
+  const float4* w1 = reinterpret_cast<const float4*>(w + (size_t)wr1 * K + kb);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int t4 = 0; t4 < span / 4; ++t4) {
+    const float4 a = xp[t4], b0 = w0[t4], b1 = w1[t4];
+    // D[row i = X row][col j = W row]: A[i][kk] = X[m0+i][k], B[kk][j] = W[n0+j][k]
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+  }
+  // cross-wave reduction through LDS: s_red[wave][sub][lane][r]
+  reinterpret_cast<f32x4*>(s_red)[(wave * 2 + 0) * 64 + lane] = acc0;
+  reinterpret_cast<f32x4*>(s_red)[(wave * 2 + 1) * 64 + lane] = acc1;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + 256 * j;  // element of the 16 x 32 tile in accumulator order
+    const int sub = e >> 8, ln = (e >> 2) & 63, r = e & 3;
+    float v = s_red[((0 * 2 + sub) * 64 + ln) * 4 + r] + s_red[((1 * 2 + sub) * 64 + ln) * 4 + r] +
+              s_red[((2 * 2 + sub) * 64 + ln) * 4 + r] + s_red[((3 * 2 + sub) * 64 + ln) * 4 + r];
+    const int orow = m0 + (ln >> 4) * 4 + r, ocol = n0 + sub * 16 + (ln & 15);
+    if (orow < M && ocol < N) {
+      if (bias != nullptr) v += bias[ocol];
+      v *= alpha;
+      if (relu) v = fmaxf(v, 0.f);
+      y[(size_t)orow * N + ocol] = v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const float* bias, float* y,
+                               int M, int K, int N, float alpha, int relu) {
+  if (!x || !w || !y) return EGTR_E_ARG;
+  if (M <= 0 || K <= 0 || N <= 0) return EGTR_E_ARG;
+  if (K % 64 != 0) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((N + 31) / 32, (M + 15) / 16);
+  const int span = K / 16;
+  if (span == 16)
+    hipLaunchKernelGGL(linear_skinny_f32<16>, grid, dim3(256), 0, st, x, w, bias, y, M, K, N, alpha, relu, span);
+  else if (span == 32)
+    hipLaunchKernelGGL(linear_skinny_f32<32>, grid, dim3(256), 0, st, x, w, bias, y, M, K, N, alpha, relu, span);
+  else if (span == 64)
+    hipLaunchKernelGGL(linear_skinny_f32<64>, grid, dim3(256), 0, st, x, w, bias, y, M, K, N, alpha, relu, span);
+  else
+    hipLaunchKernelGGL(linear_skinny_f32<0>, grid, dim3(256), 0, st, x, w, bias, y, M, K, N, alpha, relu, span);
+  return egtr_check_launch();
+}

@@ -408,7 +408,7 @@ int egtr_launch_msda_fwd_tile_f32(hipStream_t st, const float* value, const int6
                                   const float* loc, const float* attn, float* out, int B, int Lq, int S, int L,
                                   int P);
 
-// variant: 0 = automatic (tile kernel for encoder-shaped calls Lq == S, wave-per-query otherwise),
+// variant: 0 = automatic (wave-per-query when M = 8, D = 32, L*P = 16, else generic),
 //          1 = wave-per-query, 2 = tile x head with LDS windows, 3 = generic one-thread-per-element.
 extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value,
                                              const int64_t* spatial_shapes, const int64_t* level_start_index,
@@ -423,7 +423,7 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   const long long nq = (long long)batch * num_query;
   const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
-  if (variant == 0) variant = fast ? ((num_query == spatial_size && num_query >= 1024) ? 2 : 1) : 3;
+  if (variant == 0) variant = fast ? 1 : 3;  // variant 2 is opt-in until it beats variant 1
   if ((variant == 1 || variant == 2) && !fast) return EGTR_E_UNSUPPORTED;
   if (variant == 2)
     return egtr_launch_msda_fwd_tile_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
@@ -470,12 +470,18 @@ extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* valu
   return egtr_check_launch();
 }
 
-extern "C" int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const float* value,
-                                      const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                      const float* sampling_loc, const float* attn_weight, int batch,
-                                      int spatial_size, int num_heads, int channels, int num_levels, int num_query,
-                                      int num_point, float* grad_value, float* grad_sampling_loc,
-                                      float* grad_attn_weight) {
+int egtr_launch_msda_bwd_tile_f32(hipStream_t st, const float* grad_out, const float* value, const int64_t* shapes,
+                                  const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
+                                  float* grad_loc, float* grad_attn, int B, int Lq, int S, int L, int P);
+
+// variant: 0 = automatic (tile x head with LDS-accumulated grad_value windows when M = 8, D = 32, L*P = 16 and
+// Lq >= 1024; wave-per-query for short query lists; generic otherwise), 1 = wave-per-query, 2 = tile, 3 = generic.
+extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
+                                              const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                              const float* sampling_loc, const float* attn_weight, int batch,
+                                              int spatial_size, int num_heads, int channels, int num_levels,
+                                              int num_query, int num_point, float* grad_value,
+                                              float* grad_sampling_loc, float* grad_attn_weight, int variant) {
   if (!grad_out || !value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_value ||
       !grad_sampling_loc || !grad_attn_weight)
     return EGTR_E_ARG;
@@ -484,8 +490,15 @@ extern "C" int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_ou
     return EGTR_E_ARG;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long nq = (long long)batch * num_query;
-  if (fast_shape(num_heads, channels, num_levels, num_point) && (long long)spatial_size * 1024 < (1ll << 31) &&
-      nq < (1ll << 30)) {
+  const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
+                    (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
+  if (variant == 0) variant = fast ? (num_query >= 1024 ? 2 : 1) : 3;
+  if ((variant == 1 || variant == 2) && !fast) return EGTR_E_UNSUPPORTED;
+  if (variant == 2)
+    return egtr_launch_msda_bwd_tile_f32(st, grad_out, value, spatial_shapes, level_start_index, sampling_loc,
+                                         attn_weight, grad_value, grad_sampling_loc, grad_attn_weight, batch,
+                                         num_query, spatial_size, num_levels, num_point);
+  if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(msda_bwd_q64_f32, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
@@ -499,4 +512,15 @@ extern "C" int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_ou
                        grad_attn_weight, n, spatial_size, num_heads, channels, num_levels, num_query, num_point);
   }
   return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const float* value,
+                                      const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                      const float* sampling_loc, const float* attn_weight, int batch,
+                                      int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                      int num_point, float* grad_value, float* grad_sampling_loc,
+                                      float* grad_attn_weight) {
+  return egtr_msda_backward_f32_variant(stream, grad_out, value, spatial_shapes, level_start_index, sampling_loc,
+                                        attn_weight, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                        num_point, grad_value, grad_sampling_loc, grad_attn_weight, 0);
 }

@@ -333,13 +333,13 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         if total != sequence_length:
             raise ValueError("Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
 
-        value = self.value_proj(encoder_hidden_states)
+        value = ops.module_linear(self.value_proj, encoder_hidden_states)
         if attention_mask is not None:
             value = value.masked_fill(~attention_mask[..., None], float(0))  # dd:1052
         value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = self.sampling_offsets(hidden_states).view(
+        sampling_offsets = ops.module_linear(self.sampling_offsets, hidden_states).view(
             batch_size, num_queries, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = self.attention_weights(hidden_states).view(
+        attention_weights = ops.module_linear(self.attention_weights, hidden_states).view(
             batch_size, num_queries, self.n_heads, self.n_levels * self.n_points)
         attention_weights = F.softmax(attention_weights, -1).view(
             batch_size, num_queries, self.n_heads, self.n_levels, self.n_points)
@@ -356,7 +356,7 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         output = MultiScaleDeformableAttentionFunction.apply(
             value.contiguous(), spatial_shapes, level_start_index, sampling_locations.contiguous(),
             attention_weights.contiguous(), self.im2col_step)
-        output = self.output_proj(output)
+        output = ops.module_linear(self.output_proj, output)
         return output, attention_weights
 
 
@@ -398,12 +398,12 @@ class DeformableDetrMultiheadAttention(nn.Module):
         hidden_states_original = hidden_states
         if position_embeddings is not None:
             hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
-        query_states = self.q_proj(hidden_states) * self.scaling  # dd:1166
-        key_states = self.k_proj(hidden_states)
-        value_states = self.v_proj(hidden_states_original)
+        query_states = ops.module_linear(self.q_proj, hidden_states, alpha=self.scaling)  # dd:1166, scale fused
+        key_states = ops.module_linear(self.k_proj, hidden_states)
+        value_states = ops.module_linear(self.v_proj, hidden_states_original)
         attn_output, q_maps, k_maps = ops.decoder_self_attention(
             query_states, key_states, value_states, self.num_heads, want_maps=output_attention_states)
-        attn_output = self.out_proj(attn_output)
+        attn_output = ops.module_linear(self.out_proj, attn_output)
         return attn_output, None, q_maps, k_maps
 
 
@@ -436,9 +436,12 @@ class DeformableDetrEncoderLayer(nn.Module):
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         hidden_states = self.self_attn_layer_norm(residual + hidden_states)
         residual = hidden_states
-        hidden_states = self.activation_fn(self.fc1(hidden_states))
+        if self.activation_fn is F.relu:
+            hidden_states = ops.module_linear(self.fc1, hidden_states, relu=True)
+        else:
+            hidden_states = self.activation_fn(ops.module_linear(self.fc1, hidden_states))
         hidden_states = F.dropout(hidden_states, p=self.activation_dropout, training=self.training)
-        hidden_states = self.fc2(hidden_states)
+        hidden_states = ops.module_linear(self.fc2, hidden_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         hidden_states = self.final_layer_norm(residual + hidden_states)
         if self.training:  # dd:1346-1351 (data-dependent host sync, kept for parity)
@@ -491,9 +494,12 @@ class DeformableDetrDecoderLayer(nn.Module):
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         hidden_states = self.encoder_attn_layer_norm(second_residual + hidden_states)
         residual = hidden_states
-        hidden_states = self.activation_fn(self.fc1(hidden_states))
+        if self.activation_fn is F.relu:
+            hidden_states = ops.module_linear(self.fc1, hidden_states, relu=True)
+        else:
+            hidden_states = self.activation_fn(ops.module_linear(self.fc1, hidden_states))
         hidden_states = F.dropout(hidden_states, p=self.activation_dropout, training=self.training)
-        hidden_states = self.fc2(hidden_states)
+        hidden_states = ops.module_linear(self.fc2, hidden_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         hidden_states = self.final_layer_norm(residual + hidden_states)
         outputs = (hidden_states,)
@@ -795,7 +801,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
         query_embed, target = torch.split(query_embeds, num_channels, dim=1)  # dd:2339
         query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)
         target = target.unsqueeze(0).expand(batch_size, -1, -1)
-        reference_points = self.reference_points(query_embed).sigmoid()
+        reference_points = ops.module_linear(self.reference_points, query_embed).sigmoid()
         init_reference_points = reference_points
 
         decoder_outputs = self.decoder(
@@ -830,7 +836,7 @@ class DeformableDetrMLPPredictionHead(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+            x = ops.module_linear(layer, x, relu=i < self.num_layers - 1)
         return x
 
 

@@ -111,10 +111,11 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         bsz, N, d = sequence_output.shape
         unscaling = self.head_dim ** 0.5
         # slot projections q^[b,i,t,:], k^[b,j,t,:]  (t < Ld: decoder layers, t = Ld: final hidden state)
-        pq = [proj(q.transpose(1, 2).reshape(bsz, N, d) * unscaling) for q, proj in zip(queries, self.proj_q)]
-        pk = [proj(k.transpose(1, 2).reshape(bsz, N, d)) for k, proj in zip(keys, self.proj_k)]
-        pq.append(self.final_sub_proj(sequence_output))
-        pk.append(self.final_obj_proj(sequence_output))
+        pq = [ops.module_linear(proj, q.transpose(1, 2).reshape(bsz, N, d) * unscaling)
+              for q, proj in zip(queries, self.proj_q)]
+        pk = [ops.module_linear(proj, k.transpose(1, 2).reshape(bsz, N, d)) for k, proj in zip(keys, self.proj_k)]
+        pq.append(ops.module_linear(self.final_sub_proj, sequence_output))
+        pk.append(ops.module_linear(self.final_obj_proj, sequence_output))
         Q = torch.stack(pq, -2)  # [B,N,T,d]
         K = torch.stack(pk, -2)
         # separable gate logit and first MLP layer:  [W1_rel ; W1_conn ; w_gate] applied to each half
@@ -122,8 +123,8 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         w1 = torch.cat([self.rel_predictor.layers[0].weight, self.connectivity_layer.layers[0].weight], 0)  # [2Hd,2d]
         wq = torch.cat([w1[:, :d], wg[:, :d]], 0)  # [2Hd+1, d]
         wk = torch.cat([w1[:, d:], wg[:, d:]], 0)
-        tq = F.linear(Q, wq)  # [B,N,T,2Hd+1]
-        tk = F.linear(K, wk)
+        tq = ops.linear(Q, wq)  # [B,N,T,2Hd+1]
+        tk = ops.linear(K, wk)
         hd2 = w1.shape[0]
         uq, gate_q = tq[..., :hd2].contiguous(), tq[..., hd2].contiguous()
         uk, gate_k = tk[..., :hd2].contiguous(), (tk[..., hd2] + self.rel_predictor_gate.bias).contiguous()
@@ -157,7 +158,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         for level in range(hidden_states.shape[1]):  # egtr:286-305
             reference = init_reference if level == 0 else inter_references[:, level - 1]
             reference = inverse_sigmoid(reference)
-            outputs_class = self.class_embed[level](hidden_states[:, level])
+            outputs_class = ops.module_linear(self.class_embed[level], hidden_states[:, level])
             delta_bbox = self.bbox_embed[level](hidden_states[:, level])
             if reference.shape[-1] == 4:
                 outputs_coord_logits = delta_bbox + reference

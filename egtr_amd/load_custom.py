@@ -79,7 +79,7 @@ class _MultiScaleDeformableAttention:
 
     @staticmethod
     def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                                im2col_step):
+                                im2col_step, variant=0):
         lib = _lib.lib()
         B, S, M, D = value.shape
         L = spatial_shapes.shape[0]
@@ -92,10 +92,11 @@ class _MultiScaleDeformableAttention:
         grad_value = torch.zeros_like(value)  # accumulated with atomics (reference: cu:124)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
-        st = lib.egtr_msda_backward_f32(_stream(), grad_output.data_ptr(), value.data_ptr(),
-                                        spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                                        sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P,
-                                        grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+        st = lib.egtr_msda_backward_f32_variant(_stream(), grad_output.data_ptr(), value.data_ptr(),
+                                                spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                                sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq,
+                                                P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                                                variant)
         _lib.check(st, "ms_deform_attn_backward")
         return grad_value, grad_loc, grad_attn
 

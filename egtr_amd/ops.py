@@ -96,6 +96,61 @@ def decoder_self_attention(q, k, v, num_heads, want_maps=True):
     return DecoderSelfAttentionFunction.apply(q.contiguous(), k.contiguous(), v.contiguous(), num_heads, want_maps)
 
 
+SKINNY_MAX_ROWS = 4096  # above this the vendor GEMM (rocBLAS / hipBLASLt) fills the chip and is the right tool
+
+
+class SkinnyLinearFunction(Function):
+    """act((x W^T + b) * alpha) through egtr_linear_f32 (csrc/linear.hip).  Backward: plain GEMMs (PyTorch-ROCm)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, alpha, relu):
+        lib = _lib.lib()
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = _chk(x.reshape(-1, K).contiguous(), "x", torch.float32)
+        w = _chk(weight.contiguous(), "weight", torch.float32)
+        b = _chk(bias.contiguous(), "bias", torch.float32) if bias is not None else None
+        y = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device)
+        st = lib.egtr_linear_f32(_stream(), x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                 y.data_ptr(), x2.shape[0], K, N, float(alpha), 1 if relu else 0)
+        _lib.check(st, "egtr_linear_f32")
+        ctx.alpha, ctx.relu, ctx.has_bias = float(alpha), bool(relu), bias is not None
+        if x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad):
+            ctx.save_for_backward(x2, w, y if relu else None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y):
+        x2, w, y = ctx.saved_tensors
+        g = grad_y.reshape(-1, grad_y.shape[-1])
+        if ctx.relu:
+            g = g * (y > 0).to(g.dtype)
+        if ctx.alpha != 1.0:
+            g = g * ctx.alpha
+        gx = (g @ w).view(*grad_y.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
+        gw = g.t() @ x2 if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None
+
+
+def linear(x, weight, bias=None, alpha=1.0, relu=False):
+    """nn.Linear (+ optional scale and ReLU).  Object-query-sized inputs on the GPU (rows <= SKINNY_MAX_ROWS,
+    K % 64 == 0, fp32) run the hand-written skinny MFMA kernel; token-sized inputs (encoder, S ~ 12.5k rows) go to
+    the vendor GEMM, which is the right tool there.  (On CPU tensors -- host-logic tests -- this is F.linear.)"""
+    rows = x.numel() // x.shape[-1]
+    if x.is_cuda and x.dtype == torch.float32 and rows <= SKINNY_MAX_ROWS and x.shape[-1] % 64 == 0:
+        return SkinnyLinearFunction.apply(x, weight, bias, alpha, relu)
+    y = torch.nn.functional.linear(x, weight, bias)
+    if alpha != 1.0:
+        y = y * alpha
+    return torch.relu(y) if relu else y
+
+
+def module_linear(mod, x, alpha=1.0, relu=False):
+    return linear(x, mod.weight, mod.bias, alpha, relu)
+
+
 def _rel_head_separable_torch(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c):
     """Differentiable PyTorch-ROCm statement of the SAME separable algebra the fused HIP kernel evaluates
     (egtr_amd/csrc/rel_head.hip).  Used only to obtain gradients in training (backward recompute); the forward

@@ -80,6 +80,14 @@ int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const fl
                            int num_heads, int channels, int num_levels, int num_query, int num_point,
                            float* grad_value, float* grad_sampling_loc, float* grad_attn_weight);
 
+/* Same with an explicit kernel choice: 0 = automatic, 1 = wave-per-query (global atomics per sample), 2 = query-tile
+ * x head with grad_value accumulated in LDS windows and flushed once per element, 3 = generic. */
+int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
+                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                   const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,
+                                   int num_heads, int channels, int num_levels, int num_query, int num_point,
+                                   float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int variant);
+
 /* bf16 storage (uint16_t = raw bfloat16 bits), fp32 accumulation.  The reference dispatches float/double only
  * (cu:67,137); this is the added path for the bf16 stress configuration.  loc / attn stay fp32. */
 int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,
@@ -101,6 +109,15 @@ int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const floa
                                 const float* out, const float* lse, const float* grad_out, int batch,
                                 int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
                                 float* grad_v);
+
+/* ---- skinny linear layer (object-query rows) --------------------------------------------------------------- */
+/* y[M,N] = act((x[M,K] . w[N,K]^T + bias[N]) * alpha); bias may be NULL; relu != 0 applies max(.,0) last.
+ * Replaces the nn.Linear calls of the decoder layers (model/deformable_detr.py:1132-1135, 990-995, 1386-1387),
+ * the detection heads (model/egtr.py:128-134) and the relation-head projections (model/egtr.py:196-209) for the
+ * M = num_queries regime, where the vendor GEMM is latency-bound on one workgroup.  Requires K % 64 == 0
+ * (EGTR_E_UNSUPPORTED otherwise); exact-f32 MFMA. */
+int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const float* bias, float* y, int M, int K,
+                    int N, float alpha, int relu);
 
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):

@@ -143,6 +143,45 @@ def test_msda_tile_variant_arbitrary_queries():
     assert (o2 - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("shapes,B,jitter", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 1, 8.0),
+    ([(38, 63), (19, 32), (10, 16), (5, 8)], 1, 1.0),
+    ([(9, 13), (5, 7)], 3, 0.5),
+])
+def test_msda_backward_tile_variant(shapes, B, jitter):
+    """Backward variant 2 (grad_value accumulated in LDS windows) vs the oracle and vs variant 1."""
+    k = _kernels()
+    x = _grid_inputs(9, B, shapes, jitter)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    rgv, rgl, rga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"])
+    for variant in (2, 1):
+        gv, gl, ga = k.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"],
+                                               d["grad_out"], 64, variant)
+        assert (gv.cpu() - rgv).abs().max() < 3e-4 * max(1.0, float(rgv.abs().max())), variant
+        assert (ga.cpu() - rga).abs().max() < 2e-4, variant
+        assert (gl.cpu() - rgl).abs().max() < 5e-3 * max(1.0, float(rgl.abs().max()) / 50), variant
+
+
+def test_msda_backward_tile_variant_arbitrary_queries():
+    k = _kernels()
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    for Lq in (1100, 65):
+        x = W.make_msda_inputs(41 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
+        d = {n: t.to(DEV) for n, t in x.items()}
+        gv, gl, ga = k.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"],
+                                               d["grad_out"], 64, 2)
+        rgv, rgl, rga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"])
+        assert (gv.cpu() - rgv).abs().max() < 3e-4 * max(1.0, float(rgv.abs().max()))
+        assert (ga.cpu() - rga).abs().max() < 2e-4
+        assert (gl.cpu() - rgl).abs().max() < 5e-3 * max(1.0, float(rgl.abs().max()) / 50)
+    x = _grid_inputs(6, 1, shapes, 0.3)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    gv, gl, ga = k.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], torch.full_like(d["loc"], 3.0),
+                                           d["attn"], d["grad_out"], 64, 2)
+    assert gv.abs().max().item() == 0 and gl.abs().max().item() == 0 and ga.abs().max().item() == 0
+
+
 def test_msda_generic_shapes():
     for (M, D, shapes, P) in ((3, 20, [(6, 5), (2, 3)], 2), (4, 16, [(7, 9)], 3), (8, 32, [(4, 4), (2, 2), (1, 1)], 4)):
         x = W.make_msda_inputs(7, 2, 13, M, D, shapes, P)
@@ -322,3 +361,39 @@ def test_relation_head_backward_matches_autograd():
     ((rrel * g1.double()).sum() + (rconn * g2.double()).sum()).backward()
     for k in d:
         assert (dd[k].grad.cpu() - d64[k].grad.float()).abs().max() < 1e-3 * max(1.0, float(d64[k].grad.abs().max())), k
+
+
+# ---------------------------------------------------------------------------------------------- skinny linear
+@pytest.mark.parametrize("M,K,N", [(200, 256, 256), (200, 256, 1024), (200, 1024, 256), (400, 256, 150),
+                                   (1400, 256, 513), (7, 64, 2), (300, 512, 50), (33, 320, 4), (1, 256, 1)])
+def test_skinny_linear(M, K, N):
+    from egtr_amd.ops import linear
+    rng = W.rng_inputs(K + N + M)
+    x = torch.from_numpy(rng.standard_normal((M, K))).float()
+    w = torch.from_numpy(rng.standard_normal((N, K)) / K ** 0.5).float()
+    b = torch.from_numpy(rng.standard_normal((N,))).float()
+    for (alpha, relu, bias) in ((1.0, False, True), (0.1767767, False, True), (1.0, True, True), (1.0, False, False)):
+        xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        bd = b.to(DEV).requires_grad_(True) if bias else None
+        y = linear(xd, wd, bd, alpha=alpha, relu=relu)
+        x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+        b64 = b.double().requires_grad_(True) if bias else None
+        r = torch.nn.functional.linear(x64, w64, b64) * alpha
+        r = torch.relu(r) if relu else r
+        assert (y.detach().cpu() - r.detach().float()).abs().max() < 2e-5 * max(1.0, float(r.abs().max()))
+        go = torch.from_numpy(rng.standard_normal((M, N))).float()
+        (y * go.to(DEV)).sum().backward()
+        (r * go.double()).sum().backward()
+        assert (xd.grad.cpu() - x64.grad.float()).abs().max() < 1e-4 * max(1.0, float(x64.grad.abs().max()))
+        assert (wd.grad.cpu() - w64.grad.float()).abs().max() < 1e-4 * max(1.0, float(w64.grad.abs().max()))
+        if bias:
+            assert (bd.grad.cpu() - b64.grad.float()).abs().max() < 1e-4 * max(1.0, float(b64.grad.abs().max()))
+
+
+def test_skinny_linear_batched_input_and_determinism():
+    from egtr_amd.ops import linear
+    x = torch.randn(2, 200, 7, 256, device=DEV)
+    w = torch.randn(513, 256, device=DEV) / 16
+    y1, y2 = linear(x, w), linear(x, w)
+    assert y1.shape == (2, 200, 7, 513) and torch.equal(y1, y2)
+    assert (y1 - torch.nn.functional.linear(x.double(), w.double()).float()).abs().max() < 2e-5 * float(y1.abs().max())

@@ -66,7 +66,7 @@ def main():
     value, shp, lsi, loc, attn = make_inputs(a.batch, a.lq, a.jitter, dev, shapes,
                                              dtype=torch.bfloat16 if a.bf16 else torch.float32)
     go = torch.randn(a.batch, loc.shape[1], 256, device=dev)
-    fn = (lambda: k.ms_deform_attn_backward(value, shp, lsi, loc, attn, go, 64)) if a.bwd else \
+    fn = (lambda: k.ms_deform_attn_backward(value, shp, lsi, loc, attn, go, 64, a.variant)) if a.bwd else \
         ((lambda: k.ms_deform_attn_forward_variant(value, shp, lsi, loc, attn, a.variant))
          if (a.variant and not a.bf16) else (lambda: k.ms_deform_attn_forward(value, shp, lsi, loc, attn, 64)))
     if a.phases:
