@@ -8,7 +8,16 @@ architecture is defined directly with timm's parameter names (``conv1``, ``bn1``
 north-star ("host code stays Python on PyTorch-ROCm for the ResNet-50 backbone").
 """
 import torch
+import torch.nn.functional as F
 from torch import nn
+
+
+def _fold(conv, bn):
+    """Fold a frozen BN into the preceding conv: y = conv(x, w * scale) + shift (exact algebra; fp32 rounding differs
+    from scale-after-conv by ~1e-7 relative)."""
+    scale = bn.weight * (bn.running_var + 1e-5).rsqrt()
+    shift = bn.bias - bn.running_mean * scale
+    return (conv.weight * scale.reshape(-1, 1, 1, 1)).contiguous(), shift.contiguous()
 
 
 class DeformableDetrFrozenBatchNorm2d(nn.Module):
@@ -58,6 +67,21 @@ class Bottleneck(nn.Module):
         y = self.bn3(self.conv3(y))
         return torch.relu(y + idt)
 
+    def folded_params(self):
+        p = [_fold(self.conv1, self.bn1), _fold(self.conv2, self.bn2), _fold(self.conv3, self.bn3)]
+        if self.downsample is not None:
+            p.append(_fold(self.downsample[0], self.downsample[1]))
+        return p
+
+    def forward_folded(self, x, p):
+        """Inference path: frozen BN folded into the conv weights, bias + ReLU (+ residual add) fused into the MIOpen
+        convolution call (miopenFusion): 3-4 kernels per block instead of ~20."""
+        s = self.conv2.stride
+        idt = x if self.downsample is None else F.conv2d(x, p[3][0], p[3][1], stride=self.downsample[0].stride)
+        y = torch.miopen_convolution_relu(x, p[0][0], p[0][1], (1, 1), (0, 0), (1, 1), 1)
+        y = torch.miopen_convolution_relu(y, p[1][0], p[1][1], s, (1, 1), (1, 1), 1)
+        return torch.miopen_convolution_add_relu(y, p[2][0], idt, 1.0, p[2][1], (1, 1), (0, 0), (1, 1), 1)
+
 
 class ResNet50Features(nn.Module):
     """Returns the C3, C4, C5 maps (strides 8, 16, 32; 512, 1024, 2048 channels)."""
@@ -79,7 +103,32 @@ class ResNet50Features(nn.Module):
                 inplanes = planes * 4
             setattr(self, f"layer{li}", nn.Sequential(*layers))
 
+        self._folded = None
+        self._folded_key = None
+
+    def _fold_key(self):
+        return tuple(p._version for p in self.parameters()) + (str(self.conv1.weight.device),)
+
     def forward(self, x):
+        # Inference (no grad, eval, GPU): folded-BN + fused conv/bias/ReLU path; the folded weights are cached and
+        # rebuilt if any parameter was modified in place (optimizer step, load_state_dict).
+        if x.is_cuda and not torch.is_grad_enabled() and not self.training:
+            key = self._fold_key()
+            if self._folded is None or key != self._folded_key:
+                with torch.no_grad():
+                    self._folded = {"stem": _fold(self.conv1, self.bn1)}
+                    for li in range(1, 5):
+                        self._folded[li] = [blk.folded_params() for blk in getattr(self, f"layer{li}")]
+                self._folded_key = key
+            w, b = self._folded["stem"]
+            x = self.maxpool(torch.miopen_convolution_relu(x, w, b, (2, 2), (3, 3), (1, 1), 1))
+            feats = []
+            for li in range(1, 5):
+                for blk, p in zip(getattr(self, f"layer{li}"), self._folded[li]):
+                    x = blk.forward_folded(x, p)
+                if li in self.out_indices:
+                    feats.append(x)
+            return feats
         x = self.maxpool(torch.relu(self.bn1(self.conv1(x))))
         feats = []
         for li in range(1, 5):

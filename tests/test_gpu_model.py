@@ -186,3 +186,33 @@ def test_graph_replay_matches_eager():
         r = g(pv, pm)
         assert g.graphed, g.capture_error
         assert (r.pred_rel - e.pred_rel).abs().max() < 1e-5 and (r.pred_boxes - e.pred_boxes).abs().max() < 1e-5
+
+
+def test_backbone_folded_inference_path_matches_unfolded():
+    """Frozen-BN folding + MIOpen fused conv/bias/ReLU (inference path) vs the plain module path."""
+    from egtr_amd.backbone import ResNet50Features
+    torch.manual_seed(0)
+    net = ResNet50Features().to(DEV).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "running_var"):
+                m.running_var.uniform_(0.5, 1.5)
+                m.running_mean.normal_(0, 0.1)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.1)
+    x = torch.randn(1, 3, 224, 320, device=DEV)
+    with torch.no_grad():
+        fast = net(x)
+    with torch.enable_grad():  # grad mode selects the unfolded path
+        slow = [f.detach() for f in net(x)]
+    for a, b in zip(fast, slow):
+        assert a.shape == b.shape
+        assert (a - b).abs().max() < 2e-3 * max(1.0, float(b.abs().max()))
+    # cache invalidation when a parameter changes in place
+    with torch.no_grad():
+        net.layer2[0].conv1.weight.mul_(0.5)
+        fast2 = net(x)
+    with torch.enable_grad():
+        slow2 = [f.detach() for f in net(x)]
+    assert (fast2[0] - slow2[0]).abs().max() < 2e-3 * max(1.0, float(slow2[0].abs().max()))
+    assert (fast2[0] - fast[0]).abs().max() > 1e-3
