@@ -27,6 +27,8 @@ SIGNATURES = {
     "egtr_self_attn_forward_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "egtr_self_attn_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "egtr_linear_f32": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I],
+    "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "egtr_add_layernorm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
     "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
 }
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p}

@@ -74,13 +74,17 @@ class Bottleneck(nn.Module):
         return p
 
     def forward_folded(self, x, p):
-        """Inference path: frozen BN folded into the conv weights, bias + ReLU (+ residual add) fused into the MIOpen
-        convolution call (miopenFusion): 3-4 kernels per block instead of ~20."""
+        """Inference path: frozen BN folded into the conv weights; the per-channel shift, the residual add and the ReLU
+        are ONE fused HIP pass after each convolution (csrc/elementwise.hip).  (torch.miopen_convolution_relu was
+        tried first: for fp32 it still runs separate broadcast-add and clamp kernels -- rocprofv3, round 1.)"""
+        from . import ops
         s = self.conv2.stride
-        idt = x if self.downsample is None else F.conv2d(x, p[3][0], p[3][1], stride=self.downsample[0].stride)
-        y = torch.miopen_convolution_relu(x, p[0][0], p[0][1], (1, 1), (0, 0), (1, 1), 1)
-        y = torch.miopen_convolution_relu(y, p[1][0], p[1][1], s, (1, 1), (1, 1), 1)
-        return torch.miopen_convolution_add_relu(y, p[2][0], idt, 1.0, p[2][1], (1, 1), (0, 0), (1, 1), 1)
+        idt = x
+        if self.downsample is not None:
+            idt = ops.bias_act_(F.conv2d(x, p[3][0], None, stride=self.downsample[0].stride), p[3][1], None, relu=False)
+        y = ops.bias_act_(F.conv2d(x, p[0][0]), p[0][1])
+        y = ops.bias_act_(F.conv2d(y, p[1][0], None, stride=s, padding=1), p[1][1])
+        return ops.bias_act_(F.conv2d(y, p[2][0]), p[2][1], idt)
 
 
 class ResNet50Features(nn.Module):
@@ -120,8 +124,9 @@ class ResNet50Features(nn.Module):
                     for li in range(1, 5):
                         self._folded[li] = [blk.folded_params() for blk in getattr(self, f"layer{li}")]
                 self._folded_key = key
+            from . import ops
             w, b = self._folded["stem"]
-            x = self.maxpool(torch.miopen_convolution_relu(x, w, b, (2, 2), (3, 3), (1, 1), 1))
+            x = self.maxpool(ops.bias_act_(F.conv2d(x, w, None, stride=2, padding=3), b))
             feats = []
             for li in range(1, 5):
                 for blk, p in zip(getattr(self, f"layer{li}"), self._folded[li]):

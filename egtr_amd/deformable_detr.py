@@ -434,7 +434,7 @@ class DeformableDetrEncoderLayer(nn.Module):
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = self.self_attn_layer_norm(residual + hidden_states)
+        hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
         residual = hidden_states
         if self.activation_fn is F.relu:
             hidden_states = ops.module_linear(self.fc1, hidden_states, relu=True)
@@ -443,7 +443,7 @@ class DeformableDetrEncoderLayer(nn.Module):
         hidden_states = F.dropout(hidden_states, p=self.activation_dropout, training=self.training)
         hidden_states = ops.module_linear(self.fc2, hidden_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = self.final_layer_norm(residual + hidden_states)
+        hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
         if self.training:  # dd:1346-1351 (data-dependent host sync, kept for parity)
             if torch.isinf(hidden_states).any() or torch.isnan(hidden_states).any():
                 clamp_value = torch.finfo(hidden_states.dtype).max - 1000
@@ -483,7 +483,7 @@ class DeformableDetrDecoderLayer(nn.Module):
             hidden_states=hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
             output_attentions=output_attentions, output_attention_states=output_attention_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = self.self_attn_layer_norm(residual + hidden_states)
+        hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
         second_residual = hidden_states
         hidden_states, cross_attn_weights = self.encoder_attn(
             hidden_states=hidden_states, attention_mask=encoder_attention_mask,
@@ -492,7 +492,7 @@ class DeformableDetrDecoderLayer(nn.Module):
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = self.encoder_attn_layer_norm(second_residual + hidden_states)
+        hidden_states = ops.add_layer_norm(hidden_states, second_residual, self.encoder_attn_layer_norm)
         residual = hidden_states
         if self.activation_fn is F.relu:
             hidden_states = ops.module_linear(self.fc1, hidden_states, relu=True)
@@ -501,7 +501,7 @@ class DeformableDetrDecoderLayer(nn.Module):
         hidden_states = F.dropout(hidden_states, p=self.activation_dropout, training=self.training)
         hidden_states = ops.module_linear(self.fc2, hidden_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = self.final_layer_norm(residual + hidden_states)
+        hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
         outputs = (hidden_states,)
         if output_attentions:
             outputs += (self_attn_weights, cross_attn_weights)

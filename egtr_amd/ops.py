@@ -151,6 +151,57 @@ def module_linear(mod, x, alpha=1.0, relu=False):
     return linear(x, mod.weight, mod.bias, alpha, relu)
 
 
+def bias_act_(x, bias, residual=None, relu=True):
+    """In-place y = act(x + bias[c] (+ residual)) on an NCHW activation (inference only, no autograd)."""
+    lib = _lib.lib()
+    N, C, H, W_ = x.shape
+    _chk(x, "x", torch.float32)
+    _chk(bias, "bias", torch.float32)
+    if residual is not None:
+        _chk(residual, "residual", torch.float32)
+    st = lib.egtr_bias_act_nchw_f32(_stream(), x.data_ptr(), bias.data_ptr(),
+                                    residual.data_ptr() if residual is not None else None, x.data_ptr(), N, C, H * W_,
+                                    1 if relu else 0)
+    _lib.check(st, "egtr_bias_act_nchw_f32")
+    return x
+
+
+class AddLayerNormFunction(Function):
+    """LayerNorm(x + residual) over 256 channels in one pass (csrc/elementwise.hip).  Backward: recomputation with
+    PyTorch-ROCm ops (training only)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps):
+        lib = _lib.lib()
+        x2 = _chk(x.contiguous(), "x", torch.float32)
+        r2 = _chk(residual.contiguous(), "residual", torch.float32)
+        y = torch.empty_like(x2)
+        st = lib.egtr_add_layernorm_f32(_stream(), x2.data_ptr(), r2.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                        y.data_ptr(), x2.numel() // x2.shape[-1], x2.shape[-1], float(eps))
+        _lib.check(st, "egtr_add_layernorm_f32")
+        ctx.eps = eps
+        ctx.save_for_backward(x2, r2, weight, bias)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, r, w, b = ctx.saved_tensors
+        with torch.enable_grad():
+            s = (x + r).detach().requires_grad_(True)
+            wd, bd = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
+            y = torch.nn.functional.layer_norm(s, (s.shape[-1],), wd, bd, ctx.eps)
+            gs, gw, gb = torch.autograd.grad(y, (s, wd, bd), gy)
+        return gs, gs, gw, gb, None
+
+
+def add_layer_norm(x, residual, ln):
+    """ln(residual + x) for an nn.LayerNorm over d_model = 256."""
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256:
+        return AddLayerNormFunction.apply(x, residual, ln.weight, ln.bias, ln.eps)
+    return ln(residual + x)
+
+
 def _rel_head_separable_torch(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c):
     """Differentiable PyTorch-ROCm statement of the SAME separable algebra the fused HIP kernel evaluates
     (egtr_amd/csrc/rel_head.hip).  Used only to obtain gradients in training (backward recompute); the forward

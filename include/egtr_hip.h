@@ -119,6 +119,16 @@ int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const floa
 int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const float* bias, float* y, int M, int K,
                     int N, float alpha, int relu);
 
+/* ---- fused memory-bound epilogues --------------------------------------------------------------------------- */
+/* y = act(x + bias[c] (+ residual)) on an NCHW fp32 activation [N, C, HW]; residual may be NULL; y may alias x.
+ * (Folded frozen-BN shift + bottleneck residual + ReLU of the ResNet-50 backbone in one pass.) */
+int egtr_bias_act_nchw_f32(egtr_stream_t stream, const float* x, const float* bias, const float* residual, float* y,
+                           int N, int C, int HW, int relu);
+/* y = LayerNorm(x (+ residual)) * gamma + beta over rows of `dim` (= 256) channels, biased variance, eps inside the
+ * sqrt: the residual + LayerNorm of every encoder / decoder sub-layer (model/deformable_detr.py:1329-1330 etc.). */
+int egtr_add_layernorm_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,
+                           const float* beta, float* y, int rows, int dim, float eps);
+
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):
  *   gate_q [B, N, T], gate_k [B, N, T]   : w_g[:d].q^[i,t]  and  w_g[d:].k^[j,t] + b_g      (T = Ld + 1 slots)

@@ -397,3 +397,36 @@ def test_skinny_linear_batched_input_and_determinism():
     y1, y2 = linear(x, w), linear(x, w)
     assert y1.shape == (2, 200, 7, 513) and torch.equal(y1, y2)
     assert (y1 - torch.nn.functional.linear(x.double(), w.double()).float()).abs().max() < 2e-5 * float(y1.abs().max())
+
+
+def test_add_layernorm_and_bias_act():
+    from egtr_amd import ops
+    rng = W.rng_inputs(3)
+    x = torch.from_numpy(rng.standard_normal((3, 77, 256))).float()
+    r = torch.from_numpy(rng.standard_normal((3, 77, 256))).float()
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(torch.from_numpy(1 + 0.1 * rng.standard_normal(256)).float())
+        ln.bias.copy_(torch.from_numpy(0.1 * rng.standard_normal(256)).float())
+    ref = torch.nn.functional.layer_norm((x + r).double(), (256,), ln.weight.double(), ln.bias.double(), ln.eps)
+    lnd = ln.to(DEV)
+    xd, rd = x.to(DEV).requires_grad_(True), r.to(DEV).requires_grad_(True)
+    y = ops.add_layer_norm(xd, rd, lnd)
+    assert (y.detach().cpu() - ref.float()).abs().max() < 2e-5
+    go = torch.from_numpy(rng.standard_normal((3, 77, 256))).float()
+    (y * go.to(DEV)).sum().backward()
+    x64 = (x + r).double().requires_grad_(True)
+    w64, b64 = ln.weight.detach().cpu().double().requires_grad_(True), ln.bias.detach().cpu().double().requires_grad_(True)
+    (torch.nn.functional.layer_norm(x64, (256,), w64, b64, ln.eps) * go.double()).sum().backward()
+    assert (xd.grad.cpu() - x64.grad.float()).abs().max() < 1e-4 and torch.equal(xd.grad, rd.grad)
+    assert (lnd.weight.grad.cpu() - w64.grad.float()).abs().max() < 1e-3
+    # bias + residual + relu on NCHW, aligned (HW % 4 == 0) and unaligned shapes
+    for (n, c, h, w_) in ((2, 64, 10, 12), (1, 7, 5, 9), (1, 256, 75, 125)):
+        a = torch.from_numpy(rng.standard_normal((n, c, h, w_))).float()
+        res = torch.from_numpy(rng.standard_normal((n, c, h, w_))).float()
+        b = torch.from_numpy(rng.standard_normal((c,))).float()
+        for use_res, relu in ((True, True), (False, True), (False, False)):
+            got = ops.bias_act_(a.to(DEV).clone(), b.to(DEV), res.to(DEV) if use_res else None, relu=relu).cpu()
+            exp = a + b.view(1, -1, 1, 1) + (res if use_res else 0)
+            exp = torch.relu(exp) if relu else exp
+            assert torch.equal(got, exp) or (got - exp).abs().max() < 1e-6

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Split ONE graph-replayed forward of bench.py (taken from a rocprofv3 rocpd trace) into stages and list the top
+kernels of each.  Stage boundaries: first MSDA launch (encoder start), first self-attention launch (decoder
+start), relation-head launch (end)."""
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+db = sys.argv[1]
+c = sqlite3.connect(db)
+rows = c.execute("select name, start, end from kernels order by start").fetchall()
+idx = [i for i, r in enumerate(rows) if "rel_head_fwd" in r[0]]
+k = len(idx) - 1
+seg = rows[idx[k - 1] + 1: idx[k] + 1]
+names = [r[0] for r in seg]
+print(f"one forward: {len(seg)} kernels, span {(seg[-1][2] - seg[0][1]) / 1e6:.3f} ms, busy {sum(r[2] - r[1] for r in seg) / 1e6:.3f} ms")
+
+
+def first(pat):
+    for i, nm in enumerate(names):
+        if pat in nm:
+            return i
+    return None
+
+
+i_enc, i_dec = first("msda_fwd"), first("self_attn_fwd")
+cuts = [("backbone+input_proj", 0, i_enc - 6), ("encoder", i_enc - 6, i_dec - 6), ("decoder+heads", i_dec - 6, len(seg))]
+for label, a, b in cuts:
+    s = seg[a:b]
+    print(f"\n{label}: {len(s)} kernels, span {(s[-1][2] - s[0][1]) / 1e6:.3f} ms, busy {sum(r[2] - r[1] for r in s) / 1e6:.3f} ms")
+    d = defaultdict(lambda: [0, 0])
+    for r in s:
+        n = re.sub(r"\[clone.*", "", r[0])
+        n = re.sub(r"^void ", "", n)[:100]
+        d[n][0] += 1
+        d[n][1] += r[2] - r[1]
+    for n, (cnt, t) in sorted(d.items(), key=lambda kv: -kv[1][1])[:12]:
+        print(f"   {t / 1e3:8.1f} us {cnt:4d}x  {n}")
