@@ -401,8 +401,16 @@ class DeformableDetrMultiheadAttention(nn.Module):
         query_states = ops.module_linear(self.q_proj, hidden_states, alpha=self.scaling)  # dd:1166, scale fused
         key_states = ops.module_linear(self.k_proj, hidden_states)
         value_states = ops.module_linear(self.v_proj, hidden_states_original)
-        attn_output, q_maps, k_maps = ops.decoder_self_attention(
-            query_states, key_states, value_states, self.num_heads, want_maps=output_attention_states)
+        attn_output, _, _ = ops.decoder_self_attention(query_states, key_states, value_states, self.num_heads,
+                                                       want_maps=False)
+        q_maps = k_maps = None
+        if output_attention_states:
+            # the retained maps [B, M, N, D] (dd:1179-1185) are pure re-layouts of the projections: hand them out
+            # as transposed VIEWS -- same shape and values as the reference's tensors, no copy, and gradients flow
+            # back through ordinary autograd (the relation head reshapes them straight back to [B, N, M*D])
+            b_, n_, _ = query_states.shape
+            q_maps = query_states.view(b_, n_, self.num_heads, self.head_dim).transpose(1, 2)
+            k_maps = key_states.view(b_, n_, self.num_heads, self.head_dim).transpose(1, 2)
         attn_output = ops.module_linear(self.out_proj, attn_output)
         return attn_output, None, q_maps, k_maps
 

@@ -141,6 +141,11 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
     rows = x.numel() // x.shape[-1]
     if x.is_cuda and x.dtype == torch.float32 and rows <= SKINNY_MAX_ROWS and x.shape[-1] % 64 == 0:
         return SkinnyLinearFunction.apply(x, weight, bias, alpha, relu)
+    if (relu and alpha == 1.0 and bias is not None and x.is_cuda and not torch.is_grad_enabled()
+            and hasattr(torch, "_addmm_activation")):
+        # token-sized GEMM with the ReLU in the hipBLASLt epilogue (saves one pass over the [S, 1024] activation)
+        y = torch._addmm_activation(bias, x.reshape(-1, x.shape[-1]), weight.t(), use_gelu=False)
+        return y.view(*x.shape[:-1], weight.shape[0])
     y = torch.nn.functional.linear(x, weight, bias)
     if alpha != 1.0:
         y = y * alpha
