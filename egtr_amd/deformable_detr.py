@@ -234,6 +234,8 @@ class DeformableDetrSinePositionEmbedding(nn.Module):
     def forward(self, pixel_values, pixel_mask):
         if pixel_mask is None:
             raise ValueError("No pixel mask provided")
+        if pixel_mask.is_cuda and self.normalize:  # fused HIP kernel after the two cumulative sums
+            return ops.sine_position_embedding(pixel_mask, self.embedding_dim, self.temperature, self.scale)
         y_embed = pixel_mask.cumsum(1, dtype=torch.float32)
         x_embed = pixel_mask.cumsum(2, dtype=torch.float32)
         if self.normalize:

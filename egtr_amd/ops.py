@@ -171,6 +171,22 @@ def bias_act_(x, bias, residual=None, relu=True):
     return x
 
 
+def sine_position_embedding(pixel_mask, embedding_dim, temperature, scale, eps=1e-6):
+    """DeformableDetrSinePositionEmbedding(normalize=True) (dd:850-876) with the ~20 elementwise kernels after the two
+    cumulative sums fused into one HIP kernel.  pixel_mask [B,H,W] bool/int -> [B, 2*embedding_dim, H, W] fp32."""
+    lib = _lib.lib()
+    y_embed = pixel_mask.cumsum(1, dtype=torch.float32).contiguous()
+    x_embed = pixel_mask.cumsum(2, dtype=torch.float32).contiguous()
+    dim_t = torch.arange(embedding_dim, dtype=torch.float32, device=pixel_mask.device)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / embedding_dim)
+    B, H, W_ = pixel_mask.shape
+    out = torch.empty(B, 2 * embedding_dim, H, W_, dtype=torch.float32, device=pixel_mask.device)
+    st = lib.egtr_sine_pos_embed_f32(_stream(), y_embed.data_ptr(), x_embed.data_ptr(), dim_t.data_ptr(),
+                                     out.data_ptr(), B, H, W_, embedding_dim, float(scale), float(eps))
+    _lib.check(st, "egtr_sine_pos_embed_f32")
+    return out
+
+
 class AddLayerNormFunction(Function):
     """LayerNorm(x + residual) over 256 channels in one pass (csrc/elementwise.hip).  Backward: recomputation with
     PyTorch-ROCm ops (training only)."""

@@ -129,6 +129,12 @@ int egtr_bias_act_nchw_f32(egtr_stream_t stream, const float* x, const float* bi
 int egtr_add_layernorm_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,
                            const float* beta, float* y, int rows, int dim, float eps);
 
+/* Sine position embedding of DeformableDetrSinePositionEmbedding(normalize=True) (model/deformable_detr.py:850-876)
+ * from y_embed / x_embed = cumsum of the mask along H / W ([B,H,W] fp32) and dim_t [E] (the reference's
+ * temperature ** (2*(i//2)/E) table); out [B, 2E, H, W]. */
+int egtr_sine_pos_embed_f32(egtr_stream_t stream, const float* y_embed, const float* x_embed, const float* dim_t,
+                            float* out, int B, int H, int W, int E, float scale, float eps);
+
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):
  *   gate_q [B, N, T], gate_k [B, N, T]   : w_g[:d].q^[i,t]  and  w_g[d:].k^[j,t] + b_g      (T = Ld + 1 slots)

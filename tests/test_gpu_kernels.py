@@ -430,3 +430,19 @@ def test_add_layernorm_and_bias_act():
             exp = a + b.view(1, -1, 1, 1) + (res if use_res else 0)
             exp = torch.relu(exp) if relu else exp
             assert torch.equal(got, exp) or (got - exp).abs().max() < 1e-6
+
+
+def test_sine_position_embedding_matches_reference_formula():
+    from egtr_amd.deformable_detr import DeformableDetrSinePositionEmbedding
+    pe = DeformableDetrSinePositionEmbedding(128, normalize=True)
+    for (B, H, Wd) in ((1, 75, 125), (2, 19, 32), (1, 10, 16)):
+        mask = torch.ones(B, H, Wd, dtype=torch.bool)
+        if B > 1:
+            mask[1, H - 5:, :] = False
+            mask[1, :, Wd - 7:] = False
+        ref = pe(torch.zeros(B, 3, H, Wd), mask)          # CPU: the reference's elementwise formula
+        got = pe(torch.zeros(B, 3, H, Wd, device=DEV), mask.to(DEV)).cpu()
+        assert got.shape == ref.shape == (B, 256, H, Wd)
+        valid = mask[:, None].expand_as(ref)
+        # padded positions evaluate sin/cos of ~1e6-sized arguments (ill-conditioned, never used): compare valid ones
+        assert (got - ref)[valid].abs().max() < 2e-5
