@@ -243,6 +243,7 @@ __device__ __forceinline__ void atomic_add4(float* p, float4 v) {
 
 // fp32, M = 8, D = 32, L*P = 16.  One wave per query.  LDS record per (head, sample): three 16-byte entries:
 //   off[4] | {w-validity bits, lh, lw, attn} | {Wf, Hf, -, -}
+template <bool VALUE_ATOMICS>
 __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
@@ -308,13 +309,13 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     const float w0 = hh * hw * m0, w1 = hh * lw * m1, w2 = lh * hw * m2, w3 = lh * lw * m3;
     // top = grad_out * attn (cuh:114)
     const float4 top = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);
-    if (bits & 1) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.x),
+    if (VALUE_ATOMICS && (bits & 1)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.x),
                               make_float4(w0 * top.x, w0 * top.y, w0 * top.z, w0 * top.w));
-    if (bits & 2) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.y),
+    if (VALUE_ATOMICS && (bits & 2)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.y),
                               make_float4(w1 * top.x, w1 * top.y, w1 * top.z, w1 * top.w));
-    if (bits & 4) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.z),
+    if (VALUE_ATOMICS && (bits & 4)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.z),
                               make_float4(w2 * top.x, w2 * top.y, w2 * top.z, w2 * top.w));
-    if (bits & 8) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.w),
+    if (VALUE_ATOMICS && (bits & 8)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.w),
                               make_float4(w3 * top.x, w3 * top.y, w3 * top.z, w3 * top.w));
     // masked corner values (an out-of-range corner contributes 0 everywhere, cuh:121-150)
     v0.x *= m0; v0.y *= m0; v0.z *= m0; v0.w *= m0;
@@ -470,12 +471,14 @@ extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* valu
   return egtr_check_launch();
 }
 
-int egtr_launch_msda_bwd_tile_f32(hipStream_t st, const float* grad_out, const float* value, const int64_t* shapes,
-                                  const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
-                                  float* grad_loc, float* grad_attn, int B, int Lq, int S, int L, int P);
+int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
+                                        const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
+                                        int B, int Lq, int S, int L, int P);
 
-// variant: 0 = automatic (tile x head with LDS-accumulated grad_value windows when M = 8, D = 32, L*P = 16 and
-// Lq >= 1024; wave-per-query for short query lists; generic otherwise), 1 = wave-per-query, 2 = tile, 3 = generic.
+// variant: 0 = automatic, 1 = wave-per-query with per-sample global atomics (reference scheme), 2 = two kernels:
+// wave-per-query for grad_attn / grad_loc (no atomics) + query-tile x head MFMA accumulation of grad_value
+// (msda_tile.hip), 3 = generic.  Automatic = 2 for encoder-shaped calls (Lq == S: queries are the pixels, so tiles
+// have compact windows), 1 for short / arbitrary query lists, 3 for shapes other than M = 8, D = 32, L*P = 16.
 extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
                                               const int64_t* spatial_shapes, const int64_t* level_start_index,
                                               const float* sampling_loc, const float* attn_weight, int batch,
@@ -492,15 +495,22 @@ extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float*
   const long long nq = (long long)batch * num_query;
   const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
-  if (variant == 0) variant = fast ? (num_query >= 1024 ? 2 : 1) : 3;
+  if (variant == 0) variant = fast ? ((num_query == spatial_size && num_query >= 256) ? 2 : 1) : 3;
   if ((variant == 1 || variant == 2) && !fast) return EGTR_E_UNSUPPORTED;
-  if (variant == 2)
-    return egtr_launch_msda_bwd_tile_f32(st, grad_out, value, spatial_shapes, level_start_index, sampling_loc,
-                                         attn_weight, grad_value, grad_sampling_loc, grad_attn_weight, batch,
-                                         num_query, spatial_size, num_levels, num_point);
+  if (variant == 2) {
+    const int nblk = (int)((nq + kWaves - 1) / kWaves);
+    hipLaunchKernelGGL(msda_bwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk);
+    const int st1 = egtr_check_launch();
+    if (st1 != EGTR_OK) return st1;
+    return egtr_launch_msda_bwd_value_tile_f32(st, grad_out, spatial_shapes, level_start_index, sampling_loc,
+                                               attn_weight, grad_value, batch, num_query, spatial_size, num_levels,
+                                               num_point);
+  }
   if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
-    hipLaunchKernelGGL(msda_bwd_q64_f32, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
+    hipLaunchKernelGGL(msda_bwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
                        grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk);
   } else {

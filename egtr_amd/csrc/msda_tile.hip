@@ -311,32 +311,32 @@ __global__ __launch_bounds__(kThreads, 4) void msda_fwd_tile_f32(
 
 
 // ------------------------------------------------------------------------------------------------ backward
-// Same work decomposition.  grad_value is accumulated into an LDS image of each staged window with ds_add_f32 and
-// flushed ONCE per window element with a global atomic: for an 8x8 query tile that is ~23x fewer global atomics than
-// one per (sample, corner, channel) -- the reference's scheme (cuh:125-152), which the wave-per-query backward
-// (msda.hip) also uses and which measured 2.4 ms per encoder launch.  Levels whose window does not fit fall back to
-// direct global reads + global atomics.  One workgroup per CU (LDS: value windows + grad windows + records).
-constexpr int kBwdWinPx = 440;  // pixels per window image (value and grad each); pixel 0 = zeros / scratch
+// grad_value only (grad_attn / grad_loc come from the wave-per-query kernel in msda.hip, run without its atomics).
+// The scatter  grad_value[pixel, c] += sum_{q, sample, corner} w * attn * grad_out[q, c]  is turned into a small dense
+// matrix product per work item (query tile of 64, head):  G[pixel, c] = A^T[pixel, q] . T[q, c]  with
+//   A[q, pixel] (64 x Np fp32, LDS) = bilinear x attention weight mass query q puts on window pixel `pixel`
+//                                     (built without atomics: row q is written by the threads of query q only and the
+//                                     levels occupy disjoint column ranges),
+//   T[q, c]     (64 x 32)           = grad_out of the tile for this head,
+// evaluated on the matrix cores with v_mfma_f32_32x32x2_f32 (exact f32); G is then added to global memory with ONE
+// coalesced atomic per window element (32 lanes = 128 contiguous bytes).  The windows of the L levels are concatenated
+// into one virtual pixel range that is processed in chunks of kChunk columns, so any window size is handled (more
+// chunks, never a different code path).  History: per-(sample, corner, channel) global atomics as in
+// the reference (cuh:125-152) = 2.4 ms per encoder launch; LDS ds_add_f32 accumulation = 1.2 ms (LDS float atomics
+// are serialised per lane, ~130 cycles per instruction).
+constexpr int kChunk = 448;  // columns of A per pass (multiple of 32)
 
-// Sum over the 8 lanes of a (query, head) group; every lane ends with the total (DPP, no LDS).
-__device__ __forceinline__ float grp8_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-  return v;
-}
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(kThreads, 2) void msda_bwd_tile_f32(
-    const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
-    const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
-    float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, int B, int Lq, int S,
-    int L, int P) {
-  __shared__ __attribute__((aligned(16))) float4 s_val[kBwdWinPx * 8];
-  // grad window: 33 floats per pixel (not 32): with a 128-B pixel stride every query of a wave would hit the SAME 8
-  // of the 32 LDS banks with its ds_add_f32 (measured: 133 cycles per instruction); the odd stride spreads them.
-  __shared__ float s_grd[kBwdWinPx * 33];
-  __shared__ __attribute__((aligned(16))) int4 s_off[kTQ * kRecStride];
-  __shared__ __attribute__((aligned(16))) float4 s_geo[kTQ * kRecStride];  // {corner-valid bits, lh, lw, attn}
+__global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
+    const float* __restrict__ grad_out, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ grad_value, int B, int Lq,
+    int S, int L, int P) {
+  __shared__ __attribute__((aligned(16))) float s_A[kTQ * kChunk];         // A[q][column]
+  __shared__ __attribute__((aligned(16))) float4 s_T[kTQ * 8];             // T[q][32 channels]
+  __shared__ __attribute__((aligned(16))) float4 s_w[kTQ * kRecStride];    // per sample: 4 weights (x attention)
+  __shared__ __attribute__((aligned(8))) int2 s_vp[kTQ * kRecStride];      // per sample: 4 virtual pixel ids (16 bit)
+  __shared__ int s_pix[kChunk];                                            // global byte offset of a chunk column
   __shared__ int s_bbox[16];
 
   const int tid = threadIdx.x, ql = tid >> 3, c4 = tid & 7;
@@ -344,7 +344,6 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_tile_f32(
   load_geom(shapes, lsi, L, G);
   const TileMap tm = make_tile_map(G, L, Lq);
   const int nwork = B * tm.ntiles * 8;
-  if (tid < 8) s_val[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
     const int wlog = xcd_remap(work, nwork);
@@ -352,39 +351,39 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_tile_f32(
     const int t = wlog >> 3;
     const int b = t / tm.ntiles, tile = t - b * tm.ntiles;
     const int q = tile_query(tm, G, tile, ql, Lq);
-    const size_t boff = (size_t)b * S * 1024;
-    const char* vbase = reinterpret_cast<const char*>(value) + boff;
-    char* gvbase = reinterpret_cast<char*>(grad_value) + boff;
+    char* gvbase = reinterpret_cast<char*>(grad_value) + (size_t)b * S * 1024;
 
     if (tid < 16) s_bbox[tid] = (tid & 1) ? INT_MIN : INT_MAX;
     __syncthreads();
 
-    // ---- A: geometry + per-level bounding boxes -----------------------------------------------------------------
+    // ---- A: geometry of samples 2*c4, 2*c4+1 + per-level bounding boxes ------------------------------------------
     const int lvl = (2 * c4) / P;
     const int H = SEL_H(G, lvl), W = SEL_W(G, lvl), st = SEL_S(G, lvl);
-    int y0[2], x0[2], bits[2];
-    float glh[2], glw[2], ga_w[2];
+    int y0[2], x0[2];
+    float wgt[2][4];
+    bool any[2];
     int ymin = INT_MAX, ymax = INT_MIN, xmin = INT_MAX, xmax = INT_MIN;
-    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
     {
       float4 lc = make_float4(9.f, 9.f, 9.f, 9.f);
       float2 aw = make_float2(0.f, 0.f);
+      float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
       if (q >= 0) {
         const size_t qh = ((size_t)b * Lq + q) * 8 + head;
         lc = reinterpret_cast<const float4*>(loc + qh * 32)[c4];
         aw = reinterpret_cast<const float2*>(attn + qh * 16)[c4];
         go = reinterpret_cast<const float4*>(grad_out + qh * 32)[c4];
       }
+      s_T[ql * 8 + c4] = go;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const SampleGeom g = sample_geom<1024, 128>(j ? lc.z : lc.x, j ? lc.w : lc.y, H, W, st, head);
+        const float a = j ? aw.y : aw.x;
         y0[j] = g.y0;
         x0[j] = g.x0;
-        bits[j] = (g.ok[0] ? 1 : 0) | (g.ok[1] ? 2 : 0) | (g.ok[2] ? 4 : 0) | (g.ok[3] ? 8 : 0);
-        glh[j] = g.lh;
-        glw[j] = g.lw;
-        ga_w[j] = j ? aw.y : aw.x;
-        if (bits[j]) {
+        any[j] = g.ok[0] || g.ok[1] || g.ok[2] || g.ok[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wgt[j][k] = g.ok[k] ? g.w[k] * a : 0.f;
+        if (any[j]) {
           ymin = min(ymin, max(y0[j], 0));
           ymax = max(ymax, min(y0[j] + 1, H - 1));
           xmin = min(xmin, max(x0[j], 0));
@@ -407,190 +406,96 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_tile_f32(
     }
     __syncthreads();
 
-    // ---- B: windows, records, stage value windows, zero grad windows ---------------------------------------------
-    int wy0[4], wx0[4], wy1[4], wx1[4], ww[4], base[4], npx[4];
-    unsigned staged = 0;
-    {
-      int off = 1;
+    // ---- B: concatenate the level windows into one virtual pixel range; per-sample records ------------------------
+    int wy0[4], wx0[4], ww[4], vb[5];
+    vb[0] = 0;
 #pragma unroll
-      for (int l = 0; l < 4; ++l) {
-        wy0[l] = s_bbox[l * 4 + 0];
-        wy1[l] = s_bbox[l * 4 + 1];
-        wx0[l] = s_bbox[l * 4 + 2];
-        wx1[l] = s_bbox[l * 4 + 3];
-        const bool empty = (l >= L) || (wy0[l] > wy1[l]);
-        ww[l] = empty ? 0 : (wx1[l] - wx0[l] + 1);
-        npx[l] = empty ? 0 : ww[l] * (wy1[l] - wy0[l] + 1);
-        base[l] = off;
-        if (off + npx[l] <= kBwdWinPx) {
-          staged |= 1u << l;
-          off += npx[l];
-        } else {
-          npx[l] = 0;
-        }
-      }
+    for (int l = 0; l < 4; ++l) {
+      wy0[l] = s_bbox[l * 4 + 0];
+      const int wy1 = s_bbox[l * 4 + 1];
+      wx0[l] = s_bbox[l * 4 + 2];
+      const int wx1 = s_bbox[l * 4 + 3];
+      const bool empty = (l >= L) || (wy0[l] > wy1);
+      ww[l] = empty ? 0 : (wx1 - wx0[l] + 1);
+      vb[l + 1] = vb[l] + (empty ? 0 : ww[l] * (wy1 - wy0[l] + 1));
     }
-    const int total = base[3] + npx[3];
+    const int ntot = vb[4];
     {
-      const bool st_l = (staged >> lvl) & 1u;
-      const int by0 = sel4(wy0[0], wy0[1], wy0[2], wy0[3], lvl), by1 = sel4(wy1[0], wy1[1], wy1[2], wy1[3], lvl);
-      const int bx0 = sel4(wx0[0], wx0[1], wx0[2], wx0[3], lvl), bx1 = sel4(wx1[0], wx1[1], wx1[2], wx1[3], lvl);
-      const int bww = sel4(ww[0], ww[1], ww[2], ww[3], lvl), bbase = sel4(base[0], base[1], base[2], base[3], lvl);
+      const int by0 = sel4(wy0[0], wy0[1], wy0[2], wy0[3], lvl), bx0 = sel4(wx0[0], wx0[1], wx0[2], wx0[3], lvl);
+      const int bww = sel4(ww[0], ww[1], ww[2], ww[3], lvl), bvb = sel4(vb[0], vb[1], vb[2], vb[3], lvl);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int s = 2 * c4 + j;
-        int4 o;
-        if (!bits[j]) {
-          o = st_l ? make_int4(0, 0, 0, 0) : make_int4(head * 128, head * 128, head * 128, head * 128);
-        } else if (st_l) {
-          const int ya = min(max(y0[j], by0), by1), yb = min(max(y0[j] + 1, by0), by1);
-          const int xa = min(max(x0[j], bx0), bx1), xb = min(max(x0[j] + 1, bx0), bx1);
-          const int r0 = bbase + (ya - by0) * bww - bx0, r1 = bbase + (yb - by0) * bww - bx0;
-          o = make_int4((r0 + xa) * 128, (r0 + xb) * 128, (r1 + xa) * 128, (r1 + xb) * 128);
-        } else {
+        int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (any[j]) {  // clamped corners lie inside the level's bounding box by construction
           const int ya = max(y0[j], 0), yb = min(y0[j] + 1, H - 1), xa = max(x0[j], 0), xb = min(x0[j] + 1, W - 1);
-          const int r0 = (st + ya * W) * 1024 + head * 128, r1 = (st + yb * W) * 1024 + head * 128;
-          o = make_int4(r0 + xa * 1024, r0 + xb * 1024, r1 + xa * 1024, r1 + xb * 1024);
+          const int r0 = bvb + (ya - by0) * bww - bx0, r1 = bvb + (yb - by0) * bww - bx0;
+          v0 = r0 + xa; v1 = r0 + xb; v2 = r1 + xa; v3 = r1 + xb;
         }
-        s_off[ql * kRecStride + s] = o;
-        s_geo[ql * kRecStride + s] = make_float4(__int_as_float(bits[j]), glh[j], glw[j], ga_w[j]);
+        s_vp[ql * kRecStride + s] = make_int2(v0 | (v1 << 16), v2 | (v3 << 16));
+        s_w[ql * kRecStride + s] = make_float4(wgt[j][0], wgt[j][1], wgt[j][2], wgt[j][3]);
       }
     }
-    {
-      float4 tmp[7];
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int p = 1 + ql + kTQ * i;
-        tmp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < total) {
-          const int l = (p >= base[1] ? 1 : 0) + (p >= base[2] ? 1 : 0) + (p >= base[3] ? 1 : 0);
-          const int rel = p - sel4(base[0], base[1], base[2], base[3], l);
+
+    // ---- C: chunks of kChunk virtual pixels: zero A, build A, MFMA, one atomic per element ----------------------
+    for (int k0 = 0; k0 < ntot; k0 += kChunk) {
+      const int ncols = min(kChunk, ntot - k0);
+      const int mtiles = (ncols + 31) >> 5;
+      __syncthreads();  // records visible (first chunk) / previous chunk's MFMA reads of A and s_pix finished
+      {
+        const int ncol4 = mtiles * 8;
+        for (int e = tid; e < kTQ * ncol4; e += kThreads) {
+          const int r = e / ncol4, c = e - r * ncol4;
+          reinterpret_cast<float4*>(s_A + r * kChunk)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < ncols) {  // global byte offset of chunk column `tid`
+          const int p = k0 + tid;
+          const int l = (p >= vb[1] ? 1 : 0) + (p >= vb[2] ? 1 : 0) + (p >= vb[3] ? 1 : 0);
+          const int rel = p - sel4(vb[0], vb[1], vb[2], vb[3], l);
           const int wwl = sel4(ww[0], ww[1], ww[2], ww[3], l);
           const int r = (int)(((float)rel + 0.5f) * __frcp_rn((float)wwl));
           const int c = rel - r * wwl;
           const int Wl = sel4(G.W0, G.W1, G.W2, G.W3, l), stl = sel4(G.s0, G.s1, G.s2, G.s3, l);
           const int yy = sel4(wy0[0], wy0[1], wy0[2], wy0[3], l) + r, xx = sel4(wx0[0], wx0[1], wx0[2], wx0[3], l) + c;
-          tmp[i] = *reinterpret_cast<const float4*>(vbase + ((size_t)(stl + yy * Wl + xx) * 1024 + head * 128 + c4 * 16));
+          s_pix[tid] = (stl + yy * Wl + xx) * 1024 + head * 128;
         }
       }
-#pragma unroll
-      for (int i = 0; i < 7; ++i) {
-        const int p = 1 + ql + kTQ * i;
-        if (p < total) {
-          s_val[p * 8 + c4] = tmp[i];
-          float* gz = s_grd + p * 33 + c4 * 4;
-          gz[0] = 0.f; gz[1] = 0.f; gz[2] = 0.f; gz[3] = 0.f;
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- C: per sample: corner values -> grad_attn / grad_loc partials; grad_value -> LDS or global atomics ------
-    float keep_a[2] = {0.f, 0.f}, keep_x[2] = {0.f, 0.f}, keep_y[2] = {0.f, 0.f};
-    {
-      const int4* ro = s_off + ql * kRecStride;
-      const float4* rg = s_geo + ql * kRecStride;
-      for (int l = 0; l < L; ++l) {
-        const float Wf = (float)sel4(G.W0, G.W1, G.W2, G.W3, l), Hf = (float)sel4(G.H0, G.H1, G.H2, G.H3, l);
-        const bool st_l = (staged >> l) & 1u;
+      __syncthreads();
+      // build A: thread (q, level l = c4) owns the samples of level l of query q -> no cross-thread conflicts
+      if (c4 < L) {
+        float* arow = s_A + ql * kChunk;
         for (int pp = 0; pp < P; ++pp) {
-          const int s = l * P + pp;
-          const int4 o = ro[s];
-          const float4 ge = rg[s];
-          const int bt = __float_as_int(ge.x);
-          const float lh = ge.y, lw = ge.z, a = ge.w, hh = 1.f - lh, hw = 1.f - lw;
-          const float m0 = (bt & 1) ? 1.f : 0.f, m1 = (bt & 2) ? 1.f : 0.f, m2 = (bt & 4) ? 1.f : 0.f,
-                      m3 = (bt & 8) ? 1.f : 0.f;
-          const float w0 = hh * hw * m0, w1 = hh * lw * m1, w2 = lh * hw * m2, w3 = lh * lw * m3;
-          const float4 top = make_float4(go.x * a, go.y * a, go.z * a, go.w * a);
-          float4 v0, v1, v2, v3;
-          if (st_l) {
-            v0 = s_val[(o.x >> 4) + c4];
-            v1 = s_val[(o.y >> 4) + c4];
-            v2 = s_val[(o.z >> 4) + c4];
-            v3 = s_val[(o.w >> 4) + c4];
-#define EGTR_LADD(OFF, WT)                                     \
-            {                                                  \
-              float* p_ = s_grd + ((OFF) >> 7) * 33 + c4 * 4;  \
-              atomicAdd(p_ + 0, (WT) * top.x);                 \
-              atomicAdd(p_ + 1, (WT) * top.y);                 \
-              atomicAdd(p_ + 2, (WT) * top.z);                 \
-              atomicAdd(p_ + 3, (WT) * top.w);                 \
-            }
-            if (bt & 1) EGTR_LADD(o.x, w0)
-            if (bt & 2) EGTR_LADD(o.y, w1)
-            if (bt & 4) EGTR_LADD(o.z, w2)
-            if (bt & 8) EGTR_LADD(o.w, w3)
-#undef EGTR_LADD
-          } else {
-            v0 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.x);
-            v1 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.y);
-            v2 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.z);
-            v3 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.w);
-#define EGTR_GADD(OFF, WT)                                                                   \
-            {                                                                                \
-              float* p_ = reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)(OFF));      \
-              unsafeAtomicAdd(p_ + 0, (WT) * top.x);                                         \
-              unsafeAtomicAdd(p_ + 1, (WT) * top.y);                                         \
-              unsafeAtomicAdd(p_ + 2, (WT) * top.z);                                         \
-              unsafeAtomicAdd(p_ + 3, (WT) * top.w);                                         \
-            }
-            if (bt & 1) EGTR_GADD(o.x, w0)
-            if (bt & 2) EGTR_GADD(o.y, w1)
-            if (bt & 4) EGTR_GADD(o.z, w2)
-            if (bt & 8) EGTR_GADD(o.w, w3)
-#undef EGTR_GADD
-          }
-          float ga = 0.f, gw = 0.f, gh = 0.f;
-#define EGTR_ACC(C)                                                                               \
-          {                                                                                       \
-            const float a0 = v0.C * m0, a1 = v1.C * m1, a2 = v2.C * m2, a3 = v3.C * m3;           \
-            ga += go.C * (hh * hw * a0 + hh * lw * a1 + lh * hw * a2 + lh * lw * a3);             \
-            gw += (-hh * a0 + hh * a1 - lh * a2 + lh * a3) * top.C;                               \
-            gh += (-hw * a0 - lw * a1 + hw * a2 + lw * a3) * top.C;                               \
-          }
-          EGTR_ACC(x) EGTR_ACC(y) EGTR_ACC(z) EGTR_ACC(w)
-#undef EGTR_ACC
-          ga = grp8_sum(ga);
-          gw = grp8_sum(gw) * Wf;
-          gh = grp8_sum(gh) * Hf;
-          // lane c4 keeps samples 2*c4 and 2*c4+1 so the 8 lanes can write 64 B + 128 B coalesced at the end
-          const bool mine = (s >> 1) == c4;
-          const int jj = s & 1;
-          if (mine) {
-            if (jj) { keep_a[1] = ga; keep_x[1] = gw; keep_y[1] = gh; }
-            else    { keep_a[0] = ga; keep_x[0] = gw; keep_y[0] = gh; }
-          }
+          const int2 v = s_vp[ql * kRecStride + c4 * P + pp];
+          const float4 w = s_w[ql * kRecStride + c4 * P + pp];
+          const unsigned c0 = (unsigned)((v.x & 0xffff) - k0), c1 = (unsigned)(((unsigned)v.x >> 16) - k0);
+          const unsigned c2 = (unsigned)((v.y & 0xffff) - k0), c3 = (unsigned)(((unsigned)v.y >> 16) - k0);
+          if (w.x != 0.f && c0 < (unsigned)ncols) arow[c0] += w.x;
+          if (w.y != 0.f && c1 < (unsigned)ncols) arow[c1] += w.y;
+          if (w.z != 0.f && c2 < (unsigned)ncols) arow[c2] += w.z;
+          if (w.w != 0.f && c3 < (unsigned)ncols) arow[c3] += w.w;
         }
       }
-    }
-    if (q >= 0) {
-      const size_t qh = ((size_t)b * Lq + q) * 8 + head;
-      reinterpret_cast<float4*>(grad_loc + qh * 32)[c4] = make_float4(keep_x[0], keep_y[0], keep_x[1], keep_y[1]);
-      reinterpret_cast<float2*>(grad_attn + qh * 16)[c4] = make_float2(keep_a[0], keep_a[1]);
-    }
-    __syncthreads();
-
-    // ---- D: flush the grad windows: one global atomic per touched element -----------------------------------------
+      __syncthreads();
+      {
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 31, hf = lane >> 5;
+        const float* tmat = reinterpret_cast<const float*>(s_T);
+        for (int mt = wave; mt < mtiles; mt += kThreads / 64) {
+          f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const int p = 1 + ql + kTQ * i;
-      if (p < total) {
-        const float* gr = s_grd + p * 33 + c4 * 4;
-        const float4 gsum = make_float4(gr[0], gr[1], gr[2], gr[3]);
-        if (gsum.x != 0.f || gsum.y != 0.f || gsum.z != 0.f || gsum.w != 0.f) {
-          const int l = (p >= base[1] ? 1 : 0) + (p >= base[2] ? 1 : 0) + (p >= base[3] ? 1 : 0);
-          const int rel = p - sel4(base[0], base[1], base[2], base[3], l);
-          const int wwl = sel4(ww[0], ww[1], ww[2], ww[3], l);
-          const int r = (int)(((float)rel + 0.5f) * __frcp_rn((float)wwl));
-          const int c = rel - r * wwl;
-          const int Wl = sel4(G.W0, G.W1, G.W2, G.W3, l), stl = sel4(G.s0, G.s1, G.s2, G.s3, l);
-          const int yy = sel4(wy0[0], wy0[1], wy0[2], wy0[3], l) + r, xx = sel4(wx0[0], wx0[1], wx0[2], wx0[3], l) + c;
-          float* dst = reinterpret_cast<float*>(gvbase + ((size_t)(stl + yy * Wl + xx) * 1024 + head * 128 + c4 * 16));
-          unsafeAtomicAdd(dst + 0, gsum.x);
-          unsafeAtomicAdd(dst + 1, gsum.y);
-          unsafeAtomicAdd(dst + 2, gsum.z);
-          unsafeAtomicAdd(dst + 3, gsum.w);
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const float* acol = s_A + mt * 32 + li;
+#pragma unroll 8
+          for (int s2 = 0; s2 < kTQ / 2; ++s2) {
+            const int qq = 2 * s2 + hf;
+            // D[i = pixel][j = channel] += A_op[i][k = qq] * B_op[k = qq][j]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acol[qq * kChunk], tmat[qq * 32 + li], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int col = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+            if (col < ncols && acc[r] != 0.f)
+              unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)s_pix[col]) + li, acc[r]);
+          }
         }
       }
     }
@@ -622,11 +527,11 @@ extern "C" int egtr_msda_tile_phase_cycles(egtr_stream_t stream, const float* va
   return egtr_check_launch();
 }
 
-// Launcher used by egtr_msda_backward_f32 (msda.hip) when M = 8, D = 32, L*P = 16 and Lq >= 1024.
-int egtr_launch_msda_bwd_tile_f32(hipStream_t st, const float* grad_out, const float* value, const int64_t* shapes,
-                                  const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
-                                  float* grad_loc, float* grad_attn, int B, int Lq, int S, int L, int P) {
-  hipLaunchKernelGGL(msda_bwd_tile_f32, dim3(256), dim3(kThreads), 0, st, grad_out, value, shapes, lsi, loc, attn,
-                     grad_value, grad_loc, grad_attn, B, Lq, S, L, P);
+// Launcher used by egtr_msda_backward_f32 (msda.hip): grad_value of encoder-shaped calls (M = 8, D = 32, L*P = 16).
+int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
+                                        const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
+                                        int B, int Lq, int S, int L, int P) {
+  hipLaunchKernelGGL(msda_bwd_value_tile_f32, dim3(256), dim3(kThreads), 0, st, grad_out, shapes, lsi, loc, attn,
+                     grad_value, B, Lq, S, L, P);
   return egtr_check_launch();
 }
