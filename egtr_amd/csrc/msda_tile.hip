@@ -46,28 +46,30 @@ struct TileMap {
   int tw0, tw1, tw2, tw3;   // tiles per row of each level
 };
 
+template <int TH = 8, int TW = 8>
 __device__ __forceinline__ TileMap make_tile_map(const LevelGeom& G, int L, int Lq) {
   TileMap m;
   const int s0 = G.H0 * G.W0, s1 = (L > 1) ? G.H1 * G.W1 : 0, s2 = (L > 2) ? G.H2 * G.W2 : 0,
             s3 = (L > 3) ? G.H3 * G.W3 : 0;
   m.grid2d = (s0 + s1 + s2 + s3 == Lq) && (G.s0 == 0) && (L < 2 || G.s1 == s0) && (L < 3 || G.s2 == s0 + s1) &&
              (L < 4 || G.s3 == s0 + s1 + s2);
-  m.tw0 = (G.W0 + 7) >> 3;
-  m.tw1 = (G.W1 + 7) >> 3;
-  m.tw2 = (G.W2 + 7) >> 3;
-  m.tw3 = (G.W3 + 7) >> 3;
-  m.nt0 = m.tw0 * ((G.H0 + 7) >> 3);
-  m.nt1 = (L > 1) ? m.tw1 * ((G.H1 + 7) >> 3) : 0;
-  m.nt2 = (L > 2) ? m.tw2 * ((G.H2 + 7) >> 3) : 0;
-  m.nt3 = (L > 3) ? m.tw3 * ((G.H3 + 7) >> 3) : 0;
-  m.ntiles = m.grid2d ? (m.nt0 + m.nt1 + m.nt2 + m.nt3) : ((Lq + kTQ - 1) / kTQ);
+  m.tw0 = (G.W0 + TW - 1) / TW;
+  m.tw1 = (G.W1 + TW - 1) / TW;
+  m.tw2 = (G.W2 + TW - 1) / TW;
+  m.tw3 = (G.W3 + TW - 1) / TW;
+  m.nt0 = m.tw0 * ((G.H0 + TH - 1) / TH);
+  m.nt1 = (L > 1) ? m.tw1 * ((G.H1 + TH - 1) / TH) : 0;
+  m.nt2 = (L > 2) ? m.tw2 * ((G.H2 + TH - 1) / TH) : 0;
+  m.nt3 = (L > 3) ? m.tw3 * ((G.H3 + TH - 1) / TH) : 0;
+  m.ntiles = m.grid2d ? (m.nt0 + m.nt1 + m.nt2 + m.nt3) : ((Lq + TH * TW - 1) / (TH * TW));
   return m;
 }
 
 // Query index (within the batch image) of slot `ql` (0..63) of tile `tile`; -1 if the slot is padding.
+template <int TH = 8, int TW = 8>
 __device__ __forceinline__ int tile_query(const TileMap& m, const LevelGeom& G, int tile, int ql, int Lq) {
   if (!m.grid2d) {
-    const int q = tile * kTQ + ql;
+    const int q = tile * (TH * TW) + ql;
     return q < Lq ? q : -1;
   }
   int lvl = 0, t = tile;
@@ -77,25 +79,31 @@ __device__ __forceinline__ int tile_query(const TileMap& m, const LevelGeom& G, 
   const int tw = sel4(m.tw0, m.tw1, m.tw2, m.tw3, lvl);
   const int H = SEL_H(G, lvl), W = SEL_W(G, lvl), st = SEL_S(G, lvl);
   const int ty = t / tw, tx = t - ty * tw;
-  const int qy = ty * 8 + (ql >> 3), qx = tx * 8 + (ql & 7);
+  const int qy = ty * TH + ql / TW, qx = tx * TW + ql % TW;
   return (qy < H && qx < W) ? st + qy * W + qx : -1;
 }
 
 // PROF: accumulate per-phase shader-clock cycles of thread 0 of every workgroup into prof[0..3] (A, B, C, count).
-template <bool PROF>
-__global__ __launch_bounds__(kThreads, 4) void msda_fwd_tile_f32(
+//   TH x TW  query tile (encoder mode), WINPX = LDS window budget in pixels, WPS = min waves per SIMD for the register
+//   allocator (blocks per CU x waves per block / 4).  <8,8,360,4>: 64-query tiles, 80 KB LDS, 2 blocks per CU;
+//   <4,4,160,3>: 16-query tiles (2 waves), 29 KB LDS, 5 blocks per CU -- more independent work items in flight per CU
+//   to overlap the global round trips (loc/attn, then the windows) that a work item makes back to back.
+template <bool PROF, int TH, int TW, int WINPX, int WPS>
+__global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_tile_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int S,
     int L, int P, unsigned long long* __restrict__ prof) {
-  __shared__ __attribute__((aligned(16))) float4 s_win[kWinPx * 8];
-  __shared__ __attribute__((aligned(16))) int4 s_off[kTQ * kRecStride];
-  __shared__ __attribute__((aligned(16))) float4 s_wt[kTQ * kRecStride];
+  constexpr int TQ = TH * TW;
+  constexpr int NPASS = (WINPX + TQ - 1) / TQ;
+  __shared__ __attribute__((aligned(16))) float4 s_win[WINPX * 8];
+  __shared__ __attribute__((aligned(16))) int4 s_off[TQ * kRecStride];
+  __shared__ __attribute__((aligned(16))) float4 s_wt[TQ * kRecStride];
   __shared__ int s_bbox[16];  // [level][ymin, ymax, xmin, xmax]
 
   const int tid = threadIdx.x, ql = tid >> 3, c4 = tid & 7;
   LevelGeom G;
   load_geom(shapes, lsi, L, G);
-  const TileMap tm = make_tile_map(G, L, Lq);
+  const TileMap tm = make_tile_map<TH, TW>(G, L, Lq);
   const int nwork = B * tm.ntiles * 8;
   if (tid < 8) s_win[tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the all-zero pixel
 
@@ -109,7 +117,7 @@ __global__ __launch_bounds__(kThreads, 4) void msda_fwd_tile_f32(
       const int wl = xcd_remap(w, nwork);
       const int hd = wl & 7, tt = wl >> 3;
       const int bb = tt / tm.ntiles, tl = tt - bb * tm.ntiles;
-      const int qq = tile_query(tm, G, tl, ql, Lq);
+      const int qq = tile_query<TH, TW>(tm, G, tl, ql, Lq);
       if (qq >= 0) {
         const size_t qh = ((size_t)bb * Lq + qq) * 8 + hd;
         lc_next = reinterpret_cast<const float4*>(loc + qh * 32)[c4];
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(kThreads, 4) void msda_fwd_tile_f32(
     const int head = wlog & 7;
     const int t = wlog >> 3;
     const int b = t / tm.ntiles, tile = t - b * tm.ntiles;
-    const int q = tile_query(tm, G, tile, ql, Lq);
+    const int q = tile_query<TH, TW>(tm, G, tile, ql, Lq);
     const char* vbase = reinterpret_cast<const char*>(value) + (size_t)b * S * 1024;
     const float4 lc = lc_next;
     const float2 aw = aw_next;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(kThreads, 4) void msda_fwd_tile_f32(
         ww[l] = empty ? 0 : (wx1[l] - wx0[l] + 1);
         npx[l] = empty ? 0 : ww[l] * (wy1[l] - wy0[l] + 1);
         base[l] = off;
-        if (off + npx[l] <= kWinPx) {
+        if (off + npx[l] <= WINPX) {
           staged |= 1u << l;
           off += npx[l];
         } else {
@@ -233,10 +241,10 @@ __global__ __launch_bounds__(kThreads, 4) void msda_fwd_tile_f32(
       // Copy the staged windows global -> LDS.  Flattened over all levels so that every thread first ISSUES all of
       // its (up to 6) 16-byte loads and only then stores them (one global round trip per work item, not per pass).
       const int total = base[3] + npx[3];  // one past the last staged pixel
-      float4 tmp[6];
+      float4 tmp[NPASS];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int p = 1 + ql + kTQ * i;
+      for (int i = 0; i < NPASS; ++i) {
+        const int p = 1 + ql + TQ * i;
         tmp[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < total) {
           const int l = (p >= base[1] ? 1 : 0) + (p >= base[2] ? 1 : 0) + (p >= base[3] ? 1 : 0);
@@ -250,8 +258,8 @@ __global__ __launch_bounds__(kThreads, 4) void msda_fwd_tile_f32(
         }
       }
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int p = 1 + ql + kTQ * i;
+      for (int i = 0; i < NPASS; ++i) {
+        const int p = 1 + ql + TQ * i;
         if (p < total) s_win[p * 8 + c4] = tmp[i];
       }
     }
@@ -508,8 +516,17 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
 int egtr_launch_msda_fwd_tile_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
                                   const float* loc, const float* attn, float* out, int B, int Lq, int S, int L,
                                   int P) {
-  hipLaunchKernelGGL(msda_fwd_tile_f32<false>, dim3(512), dim3(kThreads), 0, st, value, shapes, lsi, loc, attn, out,
-                     B, Lq, S, L, P, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL((msda_fwd_tile_f32<false, 8, 8, 360, 4>), dim3(512), dim3(512), 0, st, value, shapes, lsi, loc,
+                     attn, out, B, Lq, S, L, P, (unsigned long long*)nullptr);
+  return egtr_check_launch();
+}
+
+// variant 4: 16-query (4 x 4) tiles, 2 waves per workgroup, 5 workgroups per CU
+int egtr_launch_msda_fwd_tile16_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
+                                    const float* loc, const float* attn, float* out, int B, int Lq, int S, int L,
+                                    int P) {
+  hipLaunchKernelGGL((msda_fwd_tile_f32<false, 4, 4, 160, 3>), dim3(1280), dim3(128), 0, st, value, shapes, lsi, loc,
+                     attn, out, B, Lq, S, L, P, (unsigned long long*)nullptr);
   return egtr_check_launch();
 }
 
@@ -521,9 +538,9 @@ extern "C" int egtr_msda_tile_phase_cycles(egtr_stream_t stream, const float* va
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out || !cycles)
     return EGTR_E_ARG;
   if (num_levels < 1 || num_levels > 4 || num_levels * num_point != 16) return EGTR_E_UNSUPPORTED;
-  hipLaunchKernelGGL(msda_fwd_tile_f32<true>, dim3(512), dim3(kThreads), 0, static_cast<hipStream_t>(stream), value,
-                     spatial_shapes, level_start_index, sampling_loc, attn_weight, out, batch, num_query,
-                     spatial_size, num_levels, num_point, cycles);
+  hipLaunchKernelGGL((msda_fwd_tile_f32<true, 8, 8, 360, 4>), dim3(512), dim3(512), 0,
+                     static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index, sampling_loc,
+                     attn_weight, out, batch, num_query, spatial_size, num_levels, num_point, cycles);
   return egtr_check_launch();
 }
 

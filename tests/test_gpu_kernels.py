@@ -112,9 +112,10 @@ def test_msda_tile_variant_matches_oracle_and_wave_variant(shapes, B, jitter):
     x = _grid_inputs(5, B, shapes, jitter)
     d = {n: t.to(DEV) for n, t in x.items()}
     o2 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 2).cpu()
+    o4 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 4).cpu()
     o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
     ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-    assert (o2 - ref).abs().max() < 2e-5
+    assert (o2 - ref).abs().max() < 2e-5 and (o4 - ref).abs().max() < 2e-5
     assert (o2 - o1).abs().max() < 2e-5
 
 
@@ -126,9 +127,10 @@ def test_msda_tile_variant_arbitrary_queries():
     for Lq in (200, 820, 65):
         x = W.make_msda_inputs(31 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
         d = {n: t.to(DEV) for n, t in x.items()}
-        o2 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 2).cpu()
         ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
-        assert (o2 - ref).abs().max() < 2e-5
+        for variant in (2, 4):
+            o2 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+            assert (o2 - ref).abs().max() < 2e-5, variant
     x = _grid_inputs(6, 1, shapes, 0.3)
     d = {n: t.to(DEV) for n, t in x.items()}
     for bad in (3.0, float("nan")):
