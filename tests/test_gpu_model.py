@@ -216,3 +216,47 @@ def test_backbone_folded_inference_path_matches_unfolded():
         slow2 = [f.detach() for f in net(x)]
     assert (fast2[0] - slow2[0]).abs().max() < 2e-3 * max(1.0, float(slow2[0].abs().max()))
     assert (fast2[0] - fast[0]).abs().max() > 1e-3
+
+
+@pytest.mark.parametrize("name,over,img", [
+    ("open_images_v6", dict(num_queries=200, encoder_layers=1, decoder_layers=2, num_labels=601, num_rel_labels=30), (160, 224)),
+    ("stress_heads", dict(num_queries=300, encoder_layers=1, decoder_layers=8, num_labels=150, num_rel_labels=50), (128, 160)),
+])
+def test_other_baseline_configs_vs_oracle(name, over, img):
+    """BASELINE configs[3] (Open Images V6 heads: 601 classes / 30 predicates) and the stress shape's N = 300 / 8 decoder
+    layers (T = 9 relation slots): product on the GPU vs the CPU oracle with identical seeded weights (fp32)."""
+    from oracle import detr as O
+    cfg_dict = dict(num_queries=24, encoder_layers=2, decoder_layers=3, dropout=0.0, auxiliary_loss=False,
+                    num_labels=12, num_rel_labels=7, use_freq_bias=True, use_log_softmax=False, freq_bias_eps=1e-12,
+                    logit_adjustment=False, logit_adj_tau=0.3)
+    cfg_dict.update(over)
+    import egtr_amd.deformable_detr as pdd
+    from egtr_amd.egtr import DetrForSceneGraphGeneration
+    import _ref_import
+    cfg = Hh.product_config(cfg_dict)
+    fg = W.fg_matrix(cfg.num_labels, cfg.num_rel_labels, seed=0)
+    orig = pdd.DeformableDetrTimmConvEncoder
+    pdd.DeformableDetrTimmConvEncoder = _ref_import.make_stub_backbone_class()
+    try:
+        model = DetrForSceneGraphGeneration(cfg, fg_matrix=fg)
+    finally:
+        pdd.DeformableDetrTimmConvEncoder = orig
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = W.fill_state_dict(shapes, seed=77)
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(fg, cfg.freq_bias_eps)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    rng = W.rng_inputs(5)
+    pv = torch.from_numpy(rng.standard_normal((2, 3) + img)).float()
+    pm = torch.ones((2,) + img, dtype=torch.long)
+    pm[1, img[0] - 32:, :] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    with torch.no_grad():
+        got = model(pixel_values=pv.to(DEV), pixel_mask=pm.to(DEV), output_attention_states=True)
+        ocfg = dict(d_model=256, num_feature_levels=4, encoder_attention_heads=8)
+        ocfg.update(cfg_dict)
+        ref = O.sgg_forward(sd, ocfg, pv, pm)
+    assert (got.logits.cpu() - ref["logits"]).abs().max() < 1e-3
+    assert (got.pred_boxes.cpu() - ref["pred_boxes"]).abs().max() < 1e-3
+    assert (got.pred_rel.cpu() - ref["pred_rel"]).abs().max() < 1e-3
+    assert (got.pred_connectivity.cpu() - ref["pred_connectivity"]).abs().max() < 1e-3

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the fused relation-head kernel at the VG shape (N=200, T=7, R=50)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+
+
+def main():
+    import test_gpu_kernels as T
+    from egtr_amd.ops import relation_head
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    d, trip, node = T._head_inputs(60, B, 200, 7, 50, 150)
+    dd = {k: v.cuda() for k, v in d.items()}
+    trip, node = trip.cuda(), node.cuda()
+    for _ in range(5):
+        relation_head(*dd.values(), trip, node, False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        relation_head(*dd.values(), trip, node, False)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    fl = 2.0 * B * 200 * 200 * (2 * 256 * 256 + 256 * 64)
+    print(f"rel_head fwd B={B}: {us:.1f} us/launch, {fl / us / 1e6:.1f} TFLOP/s (f32 MFMA peak 157)")
+
+
+if __name__ == "__main__":
+    main()
