@@ -412,6 +412,10 @@ int egtr_launch_msda_fwd_tile16_f32(hipStream_t st, const float* value, const in
                                     const float* loc, const float* attn, float* out, int B, int Lq, int S, int L,
                                     int P);
 
+int egtr_launch_msda_fwd_lane_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
+                                  const float* loc, const float* attn, float* out, int B, int Lq, int S, int kind,
+                                  unsigned long long* prof);
+
 // variant: 0 = automatic (wave-per-query when M = 8, D = 32, L*P = 16, else generic),
 //          1 = wave-per-query, 2 = tile x head with LDS windows, 3 = generic one-thread-per-element.
 extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value,
@@ -428,7 +432,13 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
   if (variant == 0) variant = fast ? 1 : 3;  // variant 2 is opt-in until it beats variant 1
-  if ((variant == 1 || variant == 2 || variant == 4) && !fast) return EGTR_E_UNSUPPORTED;
+  if ((variant == 1 || variant == 2 || variant == 4 || variant == 5 || variant == 6) && !fast)
+    return EGTR_E_UNSUPPORTED;
+  if (variant == 5 || variant == 6) {
+    if (num_levels != 4 || num_point != 4) return EGTR_E_UNSUPPORTED;
+    return egtr_launch_msda_fwd_lane_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
+                                         batch, num_query, spatial_size, variant - 5, nullptr);
+  }
   if (variant == 4)
     return egtr_launch_msda_fwd_tile16_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                                            out, batch, num_query, spatial_size, num_levels, num_point);
@@ -449,6 +459,19 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
                        num_levels, num_query, num_point);
   }
   return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                           const int64_t* level_start_index, const float* sampling_loc,
+                                           const float* attn_weight, int batch, int spatial_size, int num_query,
+                                           int kind, float* out, unsigned long long* cycles) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out || !cycles)
+    return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_query <= 0 || kind < 0 || kind > 1) return EGTR_E_ARG;
+  if ((long long)spatial_size * 1024 >= (1ll << 31) || (long long)batch * num_query >= (1ll << 27))
+    return EGTR_E_UNSUPPORTED;
+  return egtr_launch_msda_fwd_lane_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
+                                       sampling_loc, attn_weight, out, batch, num_query, spatial_size, kind, cycles);
 }
 
 extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,

@@ -39,50 +39,6 @@ constexpr int kThreads = 512;   // kTQ x 8 lanes
 constexpr int kWinPx = 360;     // LDS window budget in pixels (128 B each); pixel 0 is an all-zero pixel
 constexpr int kRecStride = 17;  // record entries per query (16 samples + 1 pad: conflict-free ds_read_b128)
 
-struct TileMap {
-  bool grid2d;
-  int ntiles;               // tiles per batch image
-  int nt0, nt1, nt2, nt3;   // tiles per level (2-D mode)
-  int tw0, tw1, tw2, tw3;   // tiles per row of each level
-};
-
-template <int TH = 8, int TW = 8>
-__device__ __forceinline__ TileMap make_tile_map(const LevelGeom& G, int L, int Lq) {
-  TileMap m;
-  const int s0 = G.H0 * G.W0, s1 = (L > 1) ? G.H1 * G.W1 : 0, s2 = (L > 2) ? G.H2 * G.W2 : 0,
-            s3 = (L > 3) ? G.H3 * G.W3 : 0;
-  m.grid2d = (s0 + s1 + s2 + s3 == Lq) && (G.s0 == 0) && (L < 2 || G.s1 == s0) && (L < 3 || G.s2 == s0 + s1) &&
-             (L < 4 || G.s3 == s0 + s1 + s2);
-  m.tw0 = (G.W0 + TW - 1) / TW;
-  m.tw1 = (G.W1 + TW - 1) / TW;
-  m.tw2 = (G.W2 + TW - 1) / TW;
-  m.tw3 = (G.W3 + TW - 1) / TW;
-  m.nt0 = m.tw0 * ((G.H0 + TH - 1) / TH);
-  m.nt1 = (L > 1) ? m.tw1 * ((G.H1 + TH - 1) / TH) : 0;
-  m.nt2 = (L > 2) ? m.tw2 * ((G.H2 + TH - 1) / TH) : 0;
-  m.nt3 = (L > 3) ? m.tw3 * ((G.H3 + TH - 1) / TH) : 0;
-  m.ntiles = m.grid2d ? (m.nt0 + m.nt1 + m.nt2 + m.nt3) : ((Lq + TH * TW - 1) / (TH * TW));
-  return m;
-}
-
-// Query index (within the batch image) of slot `ql` (0..63) of tile `tile`; -1 if the slot is padding.
-template <int TH = 8, int TW = 8>
-__device__ __forceinline__ int tile_query(const TileMap& m, const LevelGeom& G, int tile, int ql, int Lq) {
-  if (!m.grid2d) {
-    const int q = tile * (TH * TW) + ql;
-    return q < Lq ? q : -1;
-  }
-  int lvl = 0, t = tile;
-  if (t >= m.nt0) { t -= m.nt0; lvl = 1;
-    if (t >= m.nt1) { t -= m.nt1; lvl = 2;
-      if (t >= m.nt2) { t -= m.nt2; lvl = 3; } } }
-  const int tw = sel4(m.tw0, m.tw1, m.tw2, m.tw3, lvl);
-  const int H = SEL_H(G, lvl), W = SEL_W(G, lvl), st = SEL_S(G, lvl);
-  const int ty = t / tw, tx = t - ty * tw;
-  const int qy = ty * TH + ql / TW, qx = tx * TW + ql % TW;
-  return (qy < H && qx < W) ? st + qy * W + qx : -1;
-}
-
 // PROF: accumulate per-phase shader-clock cycles of thread 0 of every workgroup into prof[0..3] (A, B, C, count).
 //   TH x TW  query tile (encoder mode), WINPX = LDS window budget in pixels, WPS = min waves per SIMD for the register
 //   allocator (blocks per CU x waves per block / 4).  <8,8,360,4>: 64-query tiles, 80 KB LDS, 2 blocks per CU;

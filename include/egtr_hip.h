@@ -57,7 +57,9 @@ int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_
                           int num_point, float* out);
 
 /* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
- * 1 = wave-per-query, 2 = query-tile x head with LDS-staged windows, 3 = generic one-thread-per-element.
+ * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
+ * 3 = generic one-thread-per-element, 5 / 6 = lane-per-query with LDS windows in [channel quad][pixel] planes
+ * (2 waves / 1 wave per workgroup; needs num_levels = num_point = 4).
  * Every variant computes the same function; EGTR_E_UNSUPPORTED if the shape rules out the requested variant. */
 int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                   const int64_t* level_start_index, const float* sampling_loc,
@@ -71,6 +73,14 @@ int egtr_msda_tile_phase_cycles(egtr_stream_t stream, const float* value, const 
                                 const int64_t* level_start_index, const float* sampling_loc,
                                 const float* attn_weight, int batch, int spatial_size, int num_levels, int num_query,
                                 int num_point, float* out, unsigned long long* cycles);
+
+/* Same for variants 5 (kind 0) and 6 (kind 1).  cycles: 8 x uint64 (zero it first): loc/attn + bounding boxes,
+ * window staging, gather, output, number of work items; then, for the work items whose four windows were all staged:
+ * their number, their gather cycles, their total cycles. */
+int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, const float* sampling_loc,
+                                const float* attn_weight, int batch, int spatial_size, int num_query, int kind,
+                                float* out, unsigned long long* cycles);
 
 /* grad_value [B,S,M,D] MUST be zero-initialised by the caller (accumulated with atomics, as cu:124 relies on);
  * grad_sampling_loc [B,Lq,M,L,P,2] and grad_attn_weight [B,Lq,M,L,P] are fully overwritten. */

@@ -119,6 +119,57 @@ def test_msda_tile_variant_matches_oracle_and_wave_variant(shapes, B, jitter):
     assert (o2 - o1).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("variant", [5, 6])
+@pytest.mark.parametrize("shapes,B,jitter", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # windows fit: LDS path
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 1, 8.0),       # scattered offsets: windows overflow -> mixed LDS/global
+    ([(38, 63), (19, 32), (10, 16), (5, 8)], 1, 1.0),     # ragged 16x4 / 16x8 tiles on every level
+    ([(75, 125), (38, 63), (19, 32), (10, 16)], 1, 0.2),  # the 600x1000 pyramid
+])
+def test_msda_lane_variant_matches_oracle_and_wave_variant(variant, shapes, B, jitter):
+    """Variants 5 / 6 (lane per query, LDS windows in [channel quad][pixel] planes) on encoder-shaped calls."""
+    k = _kernels()
+    x = _grid_inputs(7, B, shapes, jitter)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    o5 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+    o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert (o5 - ref).abs().max() < 2e-5
+    assert (o5 - o1).abs().max() < 2e-5
+    # repeated launches on the same buffers give the same bits (no stale-LDS dependence)
+    o5b = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+    assert torch.equal(o5, o5b)
+
+
+@pytest.mark.parametrize("variant", [5, 6])
+def test_msda_lane_variant_arbitrary_queries(variant):
+    """Variants 5 / 6 when the queries are NOT the pixel grid: linear tiles, windows rarely fit, results must still be
+    exact; plus all-out-of-range and NaN locations, and L*P = 16 with L != 4 is refused."""
+    k = _kernels()
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    for Lq in (200, 820, 65):
+        x = W.make_msda_inputs(31 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
+        d = {n: t.to(DEV) for n, t in x.items()}
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+        assert (o - ref).abs().max() < 2e-5, Lq
+    x = _grid_inputs(6, 1, shapes, 0.3)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    for bad in (3.0, float("nan")):
+        loc = torch.full_like(d["loc"], bad)
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant)
+        assert o.abs().max().item() == 0
+    loc = d["loc"].clone()
+    loc[:, ::2] = 5.0
+    o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc.cpu(), x["attn"])
+    assert (o - ref).abs().max() < 2e-5
+    x = _grid_inputs(8, 1, [(9, 13), (5, 7)], 0.5)  # L = 2, P = 8
+    d = {n: t.to(DEV) for n, t in x.items()}
+    with pytest.raises(Exception):
+        k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant)
+
+
 def test_msda_tile_variant_arbitrary_queries():
     """Variant 2 when the queries are NOT the pixel grid (Lq != S or random locations): linear tiles, windows
     rarely fit, results must still be exact; plus all-out-of-range and NaN locations."""

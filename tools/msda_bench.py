@@ -69,7 +69,23 @@ def main():
     fn = (lambda: k.ms_deform_attn_backward(value, shp, lsi, loc, attn, go, 64, a.variant)) if a.bwd else \
         ((lambda: k.ms_deform_attn_forward_variant(value, shp, lsi, loc, attn, a.variant))
          if (a.variant and not a.bf16) else (lambda: k.ms_deform_attn_forward(value, shp, lsi, loc, attn, 64)))
-    if a.phases:
+    if a.phases and a.variant in (5, 6):
+        from egtr_amd import _lib
+        cyc = torch.zeros(8, dtype=torch.int64, device=dev)
+        out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
+        for _ in range(3):
+            cyc.zero_()
+            st = _lib.lib().egtr_msda_lane_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
+                                                        shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
+                                                        attn.data_ptr(), a.batch, value.shape[1], loc.shape[1],
+                                                        a.variant - 5, out.data_ptr(), cyc.data_ptr())
+            _lib.check(st, "phase cycles")
+            torch.cuda.synchronize()
+        c = cyc.tolist()
+        print(f"lane kernel phases per work item (s_memtime ticks): load+geom+bbox={c[0]/c[4]:.0f} "
+              f"stage={c[1]/c[4]:.0f} gather={c[2]/c[4]:.0f} out={c[3]/c[4]:.0f} items={c[4]}; "
+              f"all-staged items={c[5]} gather={c[6]/max(c[5],1):.0f} total={c[7]/max(c[5],1):.0f}")
+    elif a.phases:
         from egtr_amd import _lib
         cyc = torch.zeros(4, dtype=torch.int64, device=dev)
         out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
