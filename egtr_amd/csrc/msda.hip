@@ -416,6 +416,9 @@ int egtr_launch_msda_fwd_lane_f32(hipStream_t st, const float* value, const int6
                                   const float* loc, const float* attn, float* out, int B, int Lq, int S, int kind,
                                   unsigned long long* prof);
 
+int egtr_launch_msda_fwd_res_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
+                                 const float* loc, const float* attn, float* out, int B, int Lq, int S, int L, int P);
+
 // variant: 0 = automatic (wave-per-query when M = 8, D = 32, L*P = 16, else generic),
 //          1 = wave-per-query, 2 = tile x head with LDS windows, 3 = generic one-thread-per-element.
 extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value,
@@ -432,8 +435,10 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
   if (variant == 0) variant = fast ? 1 : 3;  // variant 2 is opt-in until it beats variant 1
-  if ((variant == 1 || variant == 2 || variant == 4 || variant == 5 || variant == 6) && !fast)
-    return EGTR_E_UNSUPPORTED;
+  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 7)) && !fast) return EGTR_E_UNSUPPORTED;
+  if (variant == 7)
+    return egtr_launch_msda_fwd_res_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
+                                        batch, num_query, spatial_size, num_levels, num_point);
   if (variant == 5 || variant == 6) {
     if (num_levels != 4 || num_point != 4) return EGTR_E_UNSUPPORTED;
     return egtr_launch_msda_fwd_lane_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,

@@ -59,7 +59,8 @@ int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_
 /* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
  * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
  * 3 = generic one-thread-per-element, 5 / 6 = lane-per-query with LDS windows in [channel quad][pixel] planes
- * (2 waves / 1 wave per workgroup; needs num_levels = num_point = 4).
+ * (2 waves / 1 wave per workgroup; needs num_levels = num_point = 4), 7 = one head per workgroup with that head's
+ * coarsest levels resident in LDS.
  * Every variant computes the same function; EGTR_E_UNSUPPORTED if the shape rules out the requested variant. */
 int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                   const int64_t* level_start_index, const float* sampling_loc,

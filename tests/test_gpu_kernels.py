@@ -119,6 +119,52 @@ def test_msda_tile_variant_matches_oracle_and_wave_variant(shapes, B, jitter):
     assert (o2 - o1).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("shapes,B,jitter", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # every level resident
+    ([(38, 63), (19, 32), (10, 16), (5, 8)], 3, 1.0),     # levels 1-3 resident, level 0 from global memory
+    ([(75, 125), (38, 63), (19, 32), (10, 16)], 1, 0.5),  # the 600x1000 pyramid: levels 2-3 resident
+    ([(100, 167), (50, 84), (25, 42), (13, 21)], 1, 0.5), # 800x1333: only level 3 fits
+    ([(9, 13), (5, 7)], 3, 0.5),                          # L = 2, P = 8
+    ([(16, 16)], 1, 0.5),                                 # L = 1, P = 16
+    ([(40, 40)], 1, 0.5),                                 # L = 1 too large to be resident
+])
+def test_msda_resident_variant_matches_oracle(shapes, B, jitter):
+    """Variant 7 (one head per workgroup, coarsest levels resident in LDS) on encoder-shaped calls."""
+    k = _kernels()
+    x = _grid_inputs(9, B, shapes, jitter)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    o7 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 7).cpu()
+    o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert (o7 - ref).abs().max() < 2e-5
+    assert (o7 - o1).abs().max() < 2e-5
+    o7b = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 7).cpu()
+    assert torch.equal(o7, o7b)
+
+
+def test_msda_resident_variant_arbitrary_queries():
+    """Variant 7 with decoder-style query sets (Lq != S, ragged tails), out-of-range and NaN locations."""
+    k = _kernels()
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    for Lq in (200, 820, 65, 3):
+        x = W.make_msda_inputs(41 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
+        d = {n: t.to(DEV) for n, t in x.items()}
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 7).cpu()
+        assert (o - ref).abs().max() < 2e-5, Lq
+    x = _grid_inputs(6, 1, shapes, 0.3)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    for bad in (3.0, float("nan")):
+        loc = torch.full_like(d["loc"], bad)
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], 7)
+        assert o.abs().max().item() == 0
+    loc = d["loc"].clone()
+    loc[:, ::2] = 5.0
+    o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], 7).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc.cpu(), x["attn"])
+    assert (o - ref).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("variant", [5, 6])
 @pytest.mark.parametrize("shapes,B,jitter", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # windows fit: LDS path

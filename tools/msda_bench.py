@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--big", action="store_true", help="800x1333 shapes")
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--phases", action="store_true", help="print per-phase cycles of the tile kernel")
+    ap.add_argument("--graph", action="store_true", help="replay 20 launches per HIP graph (no CPU launch floor)")
     ap.add_argument("--variant", type=int, default=0, help="forward kernel variant (include/egtr_hip.h)")
     a = ap.parse_args()
     from egtr_amd.load_custom import load_hip_kernels
@@ -103,13 +104,31 @@ def main():
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
+    per = 1
+    if a.graph:
+        per = 20
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                for _ in range(per):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        launch = gr.replay
+        launch()
+        torch.cuda.synchronize()
+        fn_ = launch
+    else:
+        fn_ = fn
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.iters):
-        fn()
+        fn_()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / a.iters
+    us = e0.elapsed_time(e1) * 1e3 / a.iters / per
     B, S = value.shape[:2]
     Lq = loc.shape[1]
     e = value.element_size()

@@ -22,9 +22,17 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--top", type=int, default=40)
     ap.add_argument("--csv", default=None)
+    ap.add_argument("--last-ms", type=float, default=0.0,
+                    help="only dispatches that start in the last X ms of the trace (steady state after warm-up)")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     rows = c.execute("select name, start, end from kernels").fetchall()
+    if a.last_ms > 0 and rows:
+        t_end = max(r[2] for r in rows)
+        rows = [r for r in rows if r[1] >= t_end - a.last_ms * 1e6]
+        busy = sum(r[2] - r[1] for r in rows)
+        print(f"window: last {a.last_ms:.0f} ms, GPU busy {100.0 * busy / (a.last_ms * 1e6):.1f} % "
+              f"(sum of kernel durations / window)")
     agg = {}
     for name, s, e in rows:
         d = agg.setdefault(name, [0, 0, 1 << 62, 0])
