@@ -213,10 +213,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (bounded sample)")
     ap.add_argument("--graph", type=int, default=1, help="replay the forward from a HIP graph (0 = eager launches)")
+    ap.add_argument("--miopen-find", type=int, default=0,
+                    help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find for the backbone convolutions)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = BASELINE configs[1] (default, the headline metric); train = configs[2]-style train "
                          "step (forward + SGG loss + backward + DDP all-reduce + AdamW), batch 4/GPU unless --batch")
     args = ap.parse_args()
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
