@@ -57,43 +57,54 @@ def build_model(device, cfg_over=None):
 
 
 class MsdaProbe:
-    """Remembers the operands of the most recent encoder-shaped (Lq == S) MSDA forward launch."""
+    """Remembers the operands of the most recent encoder-shaped (Lq == S) MSDA forward launch: the inference path calls
+    the fused entry (softmax + sampling locations inside the kernel), the training path the plain one."""
 
     def __init__(self):
         self.args = None
+        self.fused = False
         from egtr_amd import ops
         self._ops = ops
         self._orig = ops.MultiScaleDeformableAttentionFunction.forward
+        self._orig_fused = ops.msda_forward_fused
 
     def __enter__(self):
         probe = self
-        orig = self._orig
+        orig, orig_fused = self._orig, self._orig_fused
 
         def fwd(ctx, value, shapes, lsi, loc, attn, step):
             if loc.shape[1] == value.shape[1]:
-                probe.args = (value, shapes, lsi, loc, attn, step)
+                probe.args, probe.fused = (value, shapes, lsi, loc, attn, step), False
             return orig(ctx, value, shapes, lsi, loc, attn, step)
 
+        def fwd_fused(value, shapes, lsi, off, logits, ref, want_weights=False):
+            if off.shape[1] == value.shape[1]:
+                probe.args, probe.fused = (value, shapes, lsi, off.contiguous(), logits.contiguous(), ref), True
+            return orig_fused(value, shapes, lsi, off, logits, ref, want_weights)
+
         self._ops.MultiScaleDeformableAttentionFunction.forward = staticmethod(fwd)
+        self._ops.msda_forward_fused = fwd_fused
         return self
 
     def __exit__(self, *a):
         self._ops.MultiScaleDeformableAttentionFunction.forward = staticmethod(self._orig)
+        self._ops.msda_forward_fused = self._orig_fused
 
 
-def time_msda_kernel(args, iters=200):
+def time_msda_kernel(args, fused, iters=200):
     """Average duration of the encoder MSDA kernel: `iters` back-to-back launches through the C ABI on torch's
     current stream, bracketed by HIP events recorded on that same stream."""
     from egtr_amd.load_custom import load_hip_kernels
     k = load_hip_kernels()
-    value, shapes, lsi, loc, attn, step = args
+    value, loc = args[0], args[3]
+    fn = (lambda: k.ms_deform_attn_forward_fused(*args)) if fused else (lambda: k.ms_deform_attn_forward(*args))
     for _ in range(10):
-        k.ms_deform_attn_forward(value, shapes, lsi, loc, attn, step)
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        k.ms_deform_attn_forward(value, shapes, lsi, loc, attn, step)
+        fn()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
@@ -101,6 +112,8 @@ def time_msda_kernel(args, iters=200):
     Lq = loc.shape[1]
     e = value.element_size()
     # value S*256*e (capped by the gathered bytes) + loc Lq*256*4 + attn Lq*128*4 + out Lq*256*e
+    # (the fused entry reads raw offsets / logits of exactly the loc / attn sizes; its reference points, Lq*L*8 B,
+    # are not counted)
     alg = B * (min(S * M * D * e, Lq * M * 16 * 4 * D * e) + Lq * M * 32 * 4 + Lq * M * 16 * 4 + Lq * M * D * e)
     return us, alg
 
@@ -272,7 +285,7 @@ def main():
     if rank == 0 and args.graph and not fwd.graphed:
         print(f"[bench] HIP-graph capture unavailable, ran eager launches: {fwd.capture_error}", file=sys.stderr)
 
-    msda_us, alg_bytes = time_msda_kernel(msda_args)
+    msda_us, alg_bytes = time_msda_kernel(msda_args, probe.fused)
     achieved = alg_bytes / (msda_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "msda_traffic.json")
@@ -290,7 +303,7 @@ def main():
                                f"600x1000, bs={args.batch}/GPU fp32 (BASELINE configs[1])",
                    "images_per_step_per_gpu": args.batch, "hip_graph": bool(args.graph) and fwd.graphed,
                    "parallelism": f"replicas x{world} (independent images, no collective)"},
-        "roofline": {"bound": "hbm", "kernel": "msda_fwd_q64_f32 (encoder layer, Lq = S = 12537)",
+        "roofline": {"bound": "hbm", "kernel": "msda_fwd_q64_f32%s (encoder layer, Lq = S = 12537)" % ("<fused softmax + sampling locations>" if probe.fused else ""),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(msda_us, 3)},

@@ -38,10 +38,17 @@ constexpr int kWaveEntries = 8 * kHeadStride;   // per array per wave
 
 // ------------------------------------------------------------------------------------------------ forward
 // fp32, M = 8, D = 32, L*P = 16 (L <= 4).  One wave per query, kWaves queries per workgroup.
+//
+// FUSED: `loc` holds the raw sampling offsets (output of the sampling_offsets Linear, same [.., M, L, P, 2] layout) and
+// `attn` the raw attention logits; the kernel itself forms  loc = ref[q, l, :] + offset / (W_l, H_l)  and the softmax
+// over the L*P logits of a head (deformable_detr.py:1055-1073) -- the 16 logits of a head live in 8 adjacent lanes,
+// reduced with DPP -- instead of four elementwise launches and a 19 MB round trip per encoder layer.  `attn_out`
+// (optional) receives the softmaxed weights.
+template <bool FUSED>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
-    int Lq, int S, int L, int P, int nblk) {
+    int Lq, int S, int L, int P, int nblk, const float* __restrict__ ref, float* __restrict__ attn_out) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * kWaveEntries];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -54,9 +61,27 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
   const char* vbase = reinterpret_cast<const char*>(value) + (size_t)b * S * (256 * 4);
 
   // stage 1: lane i -> head i>>3, samples 2*(i&7), 2*(i&7)+1
-  const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
-  const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
+  float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
+  float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
   const int head_s = lane >> 3, s0 = (lane & 7) * 2;
+  if (FUSED) {
+    const int lvl = s0 / P;  // both samples of the lane lie in one level (P is even)
+    const float2 r = *reinterpret_cast<const float2*>(ref + ((size_t)q * L + lvl) * 2);
+    const float fw = (float)SEL_W(G, lvl), fh = (float)SEL_H(G, lvl);
+    lc = make_float4(r.x + lc.x / fw, r.y + lc.y / fh, r.x + lc.z / fw, r.y + lc.w / fh);
+    // softmax over the 16 logits of the head: 8 lanes x 2
+    float m = fmaxf(aw.x, aw.y);
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
+    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, false)));
+    const float e0 = expf(aw.x - m), e1 = expf(aw.y - m);
+    float sum = e0 + e1;
+    sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
+    sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
+    sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
+    aw = make_float2(e0 / sum, e1 / sum);
+    if (attn_out != nullptr) reinterpret_cast<float2*>(attn_out + (size_t)q * 128)[lane] = aw;
+  }
   int4* my_off = s_off + wave * kWaveEntries;
   float4* my_w = s_w + wave * kWaveEntries;
 #pragma unroll
@@ -452,9 +477,9 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
                                          out, batch, num_query, spatial_size, num_levels, num_point);
   if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
-    hipLaunchKernelGGL(msda_fwd_q64_f32, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+    hipLaunchKernelGGL(msda_fwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
-                       num_levels, num_point, nblk);
+                       num_levels, num_point, nblk, (const float*)nullptr, (float*)nullptr);
   } else {
     const long long n = nq * num_heads * channels;
     const int threads = 256;
@@ -477,6 +502,26 @@ extern "C" int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* va
     return EGTR_E_UNSUPPORTED;
   return egtr_launch_msda_fwd_lane_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
                                        sampling_loc, attn_weight, out, batch, num_query, spatial_size, kind, cycles);
+}
+
+extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                           const int64_t* level_start_index, const float* sampling_offsets,
+                                           const float* attn_logits, const float* reference_points, int batch,
+                                           int spatial_size, int num_heads, int channels, int num_levels,
+                                           int num_query, int num_point, float* out, float* attn_weight_out) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
+      !out)
+    return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_query <= 0) return EGTR_E_ARG;
+  const long long nq = (long long)batch * num_query;
+  if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
+      (long long)spatial_size * 1024 >= (1ll << 31) || nq >= (1ll << 27))
+    return EGTR_E_UNSUPPORTED;
+  const int nblk = (int)((nq + kWaves - 1) / kWaves);
+  hipLaunchKernelGGL(msda_fwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
+                     spatial_shapes, level_start_index, sampling_offsets, attn_logits, out, (int)nq, num_query,
+                     spatial_size, num_levels, num_point, nblk, reference_points, attn_weight_out);
+  return egtr_check_launch();
 }
 
 extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,

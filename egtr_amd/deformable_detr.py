@@ -337,27 +337,37 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
 
         value = ops.module_linear(self.value_proj, encoder_hidden_states)
         if attention_mask is not None:
-            value = value.masked_fill(~attention_mask[..., None], float(0))  # dd:1052
+            # dd:1052 `value.masked_fill(~mask[..., None], 0)` as one select (no mask inversion, no clone)
+            value = torch.where(attention_mask[..., None], value, value.new_zeros(()))
         value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
         sampling_offsets = ops.module_linear(self.sampling_offsets, hidden_states).view(
             batch_size, num_queries, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = ops.module_linear(self.attention_weights, hidden_states).view(
             batch_size, num_queries, self.n_heads, self.n_levels * self.n_points)
-        attention_weights = F.softmax(attention_weights, -1).view(
-            batch_size, num_queries, self.n_heads, self.n_levels, self.n_points)
-        if reference_points.shape[-1] == 2:
-            offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)  # (W, H)
-            sampling_locations = (reference_points[:, :, None, :, None, :]
-                                  + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = (reference_points[:, :, None, :, None, :2]
-                                  + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5)
-        else:
+        if reference_points.shape[-1] not in (2, 4):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but got {reference_points.shape[-1]}")
-        # HIP kernel; NO try/except fallback (the reference swallows every exception here, dd:1096-1101)
-        output = MultiScaleDeformableAttentionFunction.apply(
-            value.contiguous(), spatial_shapes, level_start_index, sampling_locations.contiguous(),
-            attention_weights.contiguous(), self.im2col_step)
+        needs_grad = torch.is_grad_enabled() and (value.requires_grad or sampling_offsets.requires_grad
+                                                  or attention_weights.requires_grad or reference_points.requires_grad)
+        if (not needs_grad and value.is_cuda and reference_points.shape[-1] == 2 and value.dtype == torch.float32
+                and ops.msda_fused_supported(self.n_heads, self.d_model // self.n_heads, self.n_levels, self.n_points)):
+            # inference: softmax + sampling locations (dd:1055-1073) are formed inside the HIP kernel
+            output, attention_weights = ops.msda_forward_fused(
+                value.contiguous(), spatial_shapes, level_start_index, sampling_offsets, attention_weights,
+                reference_points.contiguous(), want_weights=output_attentions)
+        else:
+            attention_weights = F.softmax(attention_weights, -1).view(
+                batch_size, num_queries, self.n_heads, self.n_levels, self.n_points)
+            if reference_points.shape[-1] == 2:
+                offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)  # (W, H)
+                sampling_locations = (reference_points[:, :, None, :, None, :]
+                                      + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
+            else:
+                sampling_locations = (reference_points[:, :, None, :, None, :2]
+                                      + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5)
+            # HIP kernel; NO try/except fallback (the reference swallows every exception here, dd:1096-1101)
+            output = MultiScaleDeformableAttentionFunction.apply(
+                value.contiguous(), spatial_shapes, level_start_index, sampling_locations.contiguous(),
+                attention_weights.contiguous(), self.im2col_step)
         output = ops.module_linear(self.output_proj, output)
         return output, attention_weights
 

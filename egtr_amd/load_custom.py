@@ -62,6 +62,33 @@ class _MultiScaleDeformableAttention:
         return out
 
     @staticmethod
+    def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                     reference_points, want_weights=False):
+        """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` computed in the kernel
+        (deformable_detr.py:1055-1073, 2-d reference points).  fp32, M = 8, D = 32, L*P = 16; no autograd.
+        Returns (out [B,Lq,M*D], attention weights [B,Lq,M,L,P] or None)."""
+        lib = _lib.lib()
+        B, S, M, D = value.shape
+        L = spatial_shapes.shape[0]
+        Lq, P = sampling_offsets.shape[1], sampling_offsets.shape[4]
+        for t, n in ((value, "value"), (sampling_offsets, "sampling_offsets"), (attn_logits, "attn_logits"),
+                     (reference_points, "reference_points")):
+            _chk(t, n, torch.float32)
+        _chk(spatial_shapes, "spatial_shapes", torch.int64)
+        _chk(level_start_index, "level_start_index", torch.int64)
+        if tuple(reference_points.shape) != (B, Lq, L, 2):
+            raise RuntimeError(f"ms_deform_attn_forward_fused: reference_points must be [B, Lq, L, 2], "
+                               f"got {tuple(reference_points.shape)}")
+        out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
+        wts = torch.empty(B, Lq, M, L, P, dtype=value.dtype, device=value.device) if want_weights else None
+        st = lib.egtr_msda_forward_fused_f32(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
+                                             level_start_index.data_ptr(), sampling_offsets.data_ptr(),
+                                             attn_logits.data_ptr(), reference_points.data_ptr(), B, S, M, D, L, Lq, P,
+                                             out.data_ptr(), wts.data_ptr() if want_weights else None)
+        _lib.check(st, "ms_deform_attn_forward_fused")
+        return out, wts
+
+    @staticmethod
     def ms_deform_attn_forward_variant(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, variant):
         """fp32 forward with an explicit kernel variant (include/egtr_hip.h); benchmarks and A/B parity tests."""
         lib = _lib.lib()

@@ -42,6 +42,22 @@ class MultiScaleDeformableAttentionFunction(Function):
         return grad_value, None, None, grad_loc, grad_attn, None
 
 
+def msda_fused_supported(num_heads, channels, num_levels, num_points):
+    """Shapes served by egtr_msda_forward_fused_f32 (the wave-per-query kernel)."""
+    return num_heads == 8 and channels == 32 and num_levels * num_points == 16 and num_levels <= 4 \
+        and num_points % 2 == 0
+
+
+def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
+                       want_weights=False):
+    """MSDA forward with its softmax / sampling-location prologue fused in (no autograd: inference path)."""
+    from .load_custom import load_hip_kernels
+    k = load_hip_kernels()
+    B, Lq, M, LP = attn_logits.shape
+    return k.ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets.contiguous(),
+                                          attn_logits.contiguous(), reference_points, want_weights)
+
+
 class DecoderSelfAttentionFunction(Function):
     """softmax(q k^T) v per head + the retained [B, M, N, D] maps of scaled q and k
     (replaces model/deformable_detr.py:1170-1253; q must already carry the D^-1/2 scaling of :1166)."""

@@ -56,6 +56,18 @@ int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_
                           int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                           int num_point, float* out);
 
+/* Forward with the prologue of DeformableDetrMultiscaleDeformableAttention.forward fused in
+ * (model/deformable_detr.py:1055-1073, 2-d reference points): sampling_offsets [B,Lq,M,L,P,2] and attn_logits
+ * [B,Lq,M,L*P] are the raw outputs of the two Linear layers, reference_points is [B,Lq,L,2]; the kernel forms
+ * loc = ref + offset / (W_l, H_l) and softmax(logits) itself.  attn_weight_out (optional, [B,Lq,M,L*P]) receives the
+ * softmaxed weights.  Only M = 8, D = 32, L*P = 16, P even; EGTR_E_UNSUPPORTED otherwise (compose the prologue on the
+ * host and call egtr_msda_forward_f32). */
+int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                const int64_t* level_start_index, const float* sampling_offsets,
+                                const float* attn_logits, const float* reference_points, int batch, int spatial_size,
+                                int num_heads, int channels, int num_levels, int num_query, int num_point, float* out,
+                                float* attn_weight_out);
+
 /* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
  * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
  * 3 = generic one-thread-per-element, 5 / 6 = lane-per-query with LDS windows in [channel quad][pixel] planes

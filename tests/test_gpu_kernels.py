@@ -119,6 +119,40 @@ def test_msda_tile_variant_matches_oracle_and_wave_variant(shapes, B, jitter):
     assert (o2 - o1).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("shapes,B,Lq", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, None),   # encoder-shaped (Lq = S)
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 3, 50),     # decoder-shaped
+    ([(9, 13), (5, 7)], 2, 33),                        # L = 2, P = 8
+])
+def test_msda_fused_prologue_matches_composition(shapes, B, Lq):
+    """egtr_msda_forward_fused_f32 (softmax + loc = ref + off / (W, H) inside the kernel, dd:1055-1073) against the
+    host-side composition of the same arithmetic followed by the plain kernel, and against the oracle."""
+    k = _kernels()
+    g = torch.Generator().manual_seed(11)
+    L = len(shapes)
+    P = 16 // L
+    S = sum(h * w for h, w in shapes)
+    Lq = Lq or S
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(B, S, 8, 32, generator=g)
+    off = 3.0 * torch.randn(B, Lq, 8, L, P, 2, generator=g)
+    logits = 2.0 * torch.randn(B, Lq, 8, L * P, generator=g)
+    ref = torch.rand(B, Lq, L, 2, generator=g) * 1.2 - 0.1      # some reference points outside [0, 1]
+    norm = torch.stack([shp[:, 1], shp[:, 0]], -1)
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    attn = torch.softmax(logits, -1).view(B, Lq, 8, L, P)
+    want = OM.msda_forward(value, shp, lsi, loc.contiguous(), attn.contiguous())
+    d = [t.to(DEV) for t in (value, shp, lsi, off, logits, ref)]
+    out, w = k.ms_deform_attn_forward_fused(*d, want_weights=True)
+    assert (out.cpu() - want).abs().max() < 2e-5
+    assert (w.cpu() - attn).abs().max() < 1e-6
+    plain = k.ms_deform_attn_forward(d[0], d[1], d[2], loc.to(DEV).contiguous(), attn.to(DEV).contiguous(), 64)
+    assert (out - plain).abs().max().item() < 2e-5
+    out2, w2 = k.ms_deform_attn_forward_fused(*d, want_weights=False)
+    assert w2 is None and torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("shapes,B,jitter", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # every level resident
     ([(38, 63), (19, 32), (10, 16), (5, 8)], 3, 1.0),     # levels 1-3 resident, level 0 from global memory

@@ -8,6 +8,8 @@ import sys
 from collections import defaultdict
 
 db = sys.argv[1]
+TOP = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+SEQ = len(sys.argv) > 3  # also print the kernel sequence of each stage
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if "rel_head_fwd" in r[0]]
@@ -35,5 +37,8 @@ for label, a, b in cuts:
         n = re.sub(r"^void ", "", n)[:100]
         d[n][0] += 1
         d[n][1] += r[2] - r[1]
-    for n, (cnt, t) in sorted(d.items(), key=lambda kv: -kv[1][1])[:12]:
+    for n, (cnt, t) in sorted(d.items(), key=lambda kv: -kv[1][1])[:TOP]:
         print(f"   {t / 1e3:8.1f} us {cnt:4d}x  {n}")
+    if SEQ:
+        for r in s:
+            print(f"      {(r[2] - r[1]) / 1e3:7.1f}  {re.sub(r'^void ', '', r[0])[:120]}")
