@@ -132,6 +132,128 @@ __global__ __launch_bounds__(256) void sine_pos_embed(const float* __restrict__ 
   }
 }
 
+
+// ---- level geometry: everything DeformableDetrModel.forward derives from pixel_mask alone ----------------------------
+// (model/deformable_detr.py:2195-2278 + 1616-1648 + 850-876).  For every feature level l (H_l x W_l) and pixel (y, x):
+//   mask_l[y, x]  = nearest-neighbour resize of pixel_mask (F.interpolate(mask.float(), size).bool(): source index
+//                   min(floor(dst * in/out), in - 1) with a float scale)                                     -> mask_flat
+//   y_embed, x_embed = cumulative sums of mask_l along y / x; normalised sine embedding of 2E channels
+//                   (+ level_embed[l])                                                                        -> pos_flat
+//   valid_ratios[b, l] = (sum_x mask_l[0, x] / W_l, sum_y mask_l[y, 0] / H_l)
+//   reference_points[b, s, l', :] = ((x + 0.5) / (vr[b,l,0] W_l), (y + 0.5) / (vr[b,l,1] H_l)) * vr[b, l', :]
+// replacing ~100 tiny PyTorch kernels per forward.  One workgroup = 32 consecutive pixels of the flattened level list
+// of one image; 8 threads count the mask column / row of a pixel, then thread c writes channel c of the 32 pixels.
+struct LevelDims {
+  int H[4], W[4], start[4];
+};
+
+template <typename MaskT>
+__global__ __launch_bounds__(256) void level_geometry(const MaskT* __restrict__ pixel_mask, const float* __restrict__ dim_t,
+                                                      const float* __restrict__ level_embed, LevelDims ld, int L, int S,
+                                                      int Hin, int Win, int E, float scale, float eps,
+                                                      unsigned char* __restrict__ mask_flat, float* __restrict__ pos_flat,
+                                                      float* __restrict__ valid_ratios, float* __restrict__ ref_points) {
+  constexpr int TP = 32;
+  __shared__ int s_cnt[8];          // [level][row-0 count, column-0 count]
+  __shared__ float s_vr[8];         // valid ratios of this image [level][x, y]
+  __shared__ int s_pix[TP][6];      // level, cy, toty, cx, totx, mask
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int s0 = blockIdx.x * TP;
+  const MaskT* pm = pixel_mask + (size_t)b * Hin * Win;
+  auto mask_at = [&](int l, int y, int x) -> int {
+    const float sh = (float)Hin / (float)ld.H[l], sw = (float)Win / (float)ld.W[l];
+    const int sy = min((int)floorf((float)y * sh), Hin - 1), sx = min((int)floorf((float)x * sw), Win - 1);
+    return pm[(size_t)sy * Win + sx] != 0 ? 1 : 0;
+  };
+  if (tid < 8) s_cnt[tid] = 0;
+  __syncthreads();
+  // valid ratios: row 0 and column 0 of every level
+  for (int l = 0; l < L; ++l) {
+    int cw = 0, ch = 0;
+    for (int x = tid; x < ld.W[l]; x += 256) cw += mask_at(l, 0, x);
+    for (int y = tid; y < ld.H[l]; y += 256) ch += mask_at(l, y, 0);
+    if (cw) atomicAdd(&s_cnt[2 * l], cw);
+    if (ch) atomicAdd(&s_cnt[2 * l + 1], ch);
+  }
+  // per-pixel column / row counts: 8 threads per pixel
+  {
+    const int p = tid >> 3, part = tid & 7;
+    const int s = s0 + p;
+    int l = 0, cy = 0, toty = 0, cx = 0, totx = 0, m = 0;
+    if (s < S) {
+      while (l + 1 < L && s >= ld.start[l + 1]) ++l;
+      const int rel = s - ld.start[l];
+      const int y = rel / ld.W[l], x = rel - y * ld.W[l];
+      for (int yy = part; yy < ld.H[l]; yy += 8) {
+        const int v = mask_at(l, yy, x);
+        toty += v;
+        cy += (yy <= y) ? v : 0;
+      }
+      for (int xx = part; xx < ld.W[l]; xx += 8) {
+        const int v = mask_at(l, y, xx);
+        totx += v;
+        cx += (xx <= x) ? v : 0;
+      }
+      if (part == 0) m = mask_at(l, y, x);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      cy += __shfl_xor(cy, o);
+      toty += __shfl_xor(toty, o);
+      cx += __shfl_xor(cx, o);
+      totx += __shfl_xor(totx, o);
+    }
+    if (part == 0) {
+      s_pix[p][0] = l;
+      s_pix[p][1] = cy;
+      s_pix[p][2] = toty;
+      s_pix[p][3] = cx;
+      s_pix[p][4] = totx;
+      s_pix[p][5] = m;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * L) {
+    const int l = tid >> 1;
+    const float vr = (float)s_cnt[tid] / (float)((tid & 1) ? ld.H[l] : ld.W[l]);
+    s_vr[tid] = vr;
+    if (blockIdx.x == 0) valid_ratios[(size_t)b * L * 2 + tid] = vr;
+  }
+  __syncthreads();
+  // mask + reference points: thread t -> pixel t / 8, (target level, xy) = t % 8
+  {
+    const int p = tid >> 3, k = tid & 7, s = s0 + p;
+    if (s < S) {
+      const int l = s_pix[p][0];
+      if (k == 0) mask_flat[(size_t)b * S + s] = (unsigned char)s_pix[p][5];
+      if (k < 2 * L) {
+        const int rel = s - ld.start[l];
+        const int y = rel / ld.W[l], x = rel - y * ld.W[l];
+        const int lt = k >> 1, ax = k & 1;  // ax 0: x, 1: y
+        const float base = ax ? ((float)y + 0.5f) / (s_vr[2 * l + 1] * (float)ld.H[l])
+                              : ((float)x + 0.5f) / (s_vr[2 * l] * (float)ld.W[l]);
+        ref_points[(((size_t)b * S + s) * L + lt) * 2 + ax] = base * s_vr[2 * lt + ax];
+      }
+    }
+  }
+  // position embedding: thread c -> channel c (c < E: y half, else x half; even index -> sin, odd -> cos)
+  for (int c = tid; c < 2 * E; c += 256) {
+    const int axis = c >= E, i = axis ? c - E : c;
+    const float dt = dim_t[i];
+    for (int p = 0; p < TP; ++p) {
+      const int s = s0 + p;
+      if (s >= S) break;
+      const int l = s_pix[p][0];
+      const float e = (float)(axis ? s_pix[p][3] : s_pix[p][1]), last = (float)(axis ? s_pix[p][4] : s_pix[p][2]);
+      const float v = (e - 0.5f) / (last + eps) * scale;
+      const float a = v / dt;
+      const float r = (i & 1) ? cosf(a) : sinf(a);
+      pos_flat[((size_t)b * S + s) * (2 * E) + c] = r + level_embed[l * 2 * E + c];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int egtr_sine_pos_embed_f32(egtr_stream_t stream, const float* y_embed, const float* x_embed,
@@ -143,6 +265,41 @@ extern "C" int egtr_sine_pos_embed_f32(egtr_stream_t stream, const float* y_embe
   const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(sine_pos_embed, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), y_embed, x_embed,
                      dim_t, out, B, H, W, E, scale, eps);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size,
+                                       const float* dim_t, const float* level_embed, const int* level_hw,
+                                       int num_levels, int batch, int height, int width, int embed_dim, float scale,
+                                       float eps, unsigned char* mask_flat, float* pos_flat, float* valid_ratios,
+                                       float* ref_points) {
+  if (!pixel_mask || !dim_t || !level_embed || !level_hw || !mask_flat || !pos_flat || !valid_ratios || !ref_points)
+    return EGTR_E_ARG;
+  if (num_levels < 1 || num_levels > 4 || batch <= 0 || height <= 0 || width <= 0 || embed_dim <= 0)
+    return EGTR_E_ARG;
+  if (mask_elem_size != 1 && mask_elem_size != 8) return EGTR_E_UNSUPPORTED;
+  LevelDims ld;
+  int S = 0;
+  for (int l = 0; l < 4; ++l) {
+    const bool on = l < num_levels;
+    ld.H[l] = on ? level_hw[2 * l] : 1;
+    ld.W[l] = on ? level_hw[2 * l + 1] : 1;
+    ld.start[l] = S;
+    if (on) {
+      if (ld.H[l] <= 0 || ld.W[l] <= 0) return EGTR_E_ARG;
+      S += ld.H[l] * ld.W[l];
+    }
+  }
+  const dim3 grid((unsigned)((S + 31) / 32), (unsigned)batch);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mask_elem_size == 8)
+    hipLaunchKernelGGL(level_geometry<long long>, grid, dim3(256), 0, st, static_cast<const long long*>(pixel_mask),
+                       dim_t, level_embed, ld, num_levels, S, height, width, embed_dim, scale, eps, mask_flat, pos_flat,
+                       valid_ratios, ref_points);
+  else
+    hipLaunchKernelGGL(level_geometry<unsigned char>, grid, dim3(256), 0, st,
+                       static_cast<const unsigned char*>(pixel_mask), dim_t, level_embed, ld, num_levels, S, height,
+                       width, embed_dim, scale, eps, mask_flat, pos_flat, valid_ratios, ref_points);
   return egtr_check_launch();
 }
 

@@ -584,15 +584,16 @@ class DeformableDetrEncoder(DeformableDetrPreTrainedModel):
 
     def forward(self, inputs_embeds=None, attention_mask=None, position_embeddings=None, spatial_shapes=None,
                 level_start_index=None, valid_ratios=None, output_attentions=None, output_hidden_states=None,
-                return_dict=None, spatial_shapes_list=None):
+                return_dict=None, spatial_shapes_list=None, reference_points=None):
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else self.config.output_hidden_states)
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
         hidden_states = F.dropout(inputs_embeds, p=self.dropout, training=self.training)
-        reference_points = self.get_reference_points(
-            spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes, valid_ratios,
-            device=inputs_embeds.device)
+        if reference_points is None:  # (the fused level-geometry kernel hands them in precomputed)
+            reference_points = self.get_reference_points(
+                spatial_shapes_list if spatial_shapes_list is not None else spatial_shapes, valid_ratios,
+                device=inputs_embeds.device)
         encoder_states = () if output_hidden_states else None
         all_attentions = () if output_attentions else None
         for encoder_layer in self.layers:
@@ -764,34 +765,54 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
         if pixel_mask is None:
             pixel_mask = torch.ones((batch_size, height, width), dtype=torch.long, device=device)
 
-        features, position_embeddings_list = self.backbone(pixel_values, pixel_mask)
-        sources, masks = [], []
-        for level, (source, mask) in enumerate(features):
-            sources.append(self.input_proj[level](source))
-            masks.append(mask)
-            if mask is None:
-                raise ValueError("No attention mask was provided")
-        if self.config.num_feature_levels > len(sources):  # dd:2228-2241
-            _len_sources = len(sources)
-            for level in range(_len_sources, self.config.num_feature_levels):
-                source = self.input_proj[level](features[-1][0] if level == _len_sources else sources[-1])
-                mask = F.interpolate(pixel_mask[None].float(), size=source.shape[-2:]).to(torch.bool)[0]
-                pos_l = self.backbone.position_embedding(source, mask).to(source.dtype)
-                sources.append(source)
-                masks.append(mask)
-                position_embeddings_list.append(pos_l)
-
+        pos_mod = self.backbone.position_embedding
+        fused_geometry = (pixel_mask.is_cuda and isinstance(pos_mod, DeformableDetrSinePositionEmbedding)
+                          and pos_mod.normalize and self.config.num_feature_levels <= 4
+                          and not (torch.is_grad_enabled() and self.level_embed.requires_grad))
         query_embeds = self.query_position_embeddings.weight
-        source_flatten, mask_flatten, lvl_pos_embed_flatten, spatial_shapes_list = [], [], [], []
-        for level, (source, mask, pos_embed) in enumerate(zip(sources, masks, position_embeddings_list)):
-            batch_size, num_channels, height, width = source.shape
-            spatial_shapes_list.append((height, width))
-            source_flatten.append(source.flatten(2).transpose(1, 2))
-            mask_flatten.append(mask.flatten(1))
-            lvl_pos_embed_flatten.append(pos_embed.flatten(2).transpose(1, 2) + self.level_embed[level].view(1, 1, -1))
-        source_flatten = torch.cat(source_flatten, 1)
-        mask_flatten = torch.cat(mask_flatten, 1)
-        lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+        encoder_reference_points = None
+        if fused_geometry:
+            # inference: masks, position embeddings (+ level_embed), valid ratios and the encoder reference points of
+            # all levels come from ONE HIP kernel instead of ~100 tiny launches (dd:2195-2278, 1616-1648, 850-876)
+            feature_maps = self.backbone.conv_encoder.model(pixel_values)
+            sources = [self.input_proj[level](fm) for level, fm in enumerate(feature_maps)]
+            for level in range(len(sources), self.config.num_feature_levels):  # dd:2228-2241
+                sources.append(self.input_proj[level](feature_maps[-1] if level == len(feature_maps) else sources[-1]))
+            spatial_shapes_list = [tuple(src.shape[-2:]) for src in sources]
+            source_flatten = torch.cat([src.flatten(2).transpose(1, 2) for src in sources], 1)
+            mask_flatten, lvl_pos_embed_flatten, valid_ratios, encoder_reference_points = ops.level_geometry(
+                pixel_mask, spatial_shapes_list, self.level_embed, pos_mod.embedding_dim, pos_mod.temperature,
+                pos_mod.scale)
+        else:
+            features, position_embeddings_list = self.backbone(pixel_values, pixel_mask)
+            sources, masks = [], []
+            for level, (source, mask) in enumerate(features):
+                sources.append(self.input_proj[level](source))
+                masks.append(mask)
+                if mask is None:
+                    raise ValueError("No attention mask was provided")
+            if self.config.num_feature_levels > len(sources):  # dd:2228-2241
+                _len_sources = len(sources)
+                for level in range(_len_sources, self.config.num_feature_levels):
+                    source = self.input_proj[level](features[-1][0] if level == _len_sources else sources[-1])
+                    mask = F.interpolate(pixel_mask[None].float(), size=source.shape[-2:]).to(torch.bool)[0]
+                    pos_l = self.backbone.position_embedding(source, mask).to(source.dtype)
+                    sources.append(source)
+                    masks.append(mask)
+                    position_embeddings_list.append(pos_l)
+
+            source_flatten, mask_flatten, lvl_pos_embed_flatten, spatial_shapes_list = [], [], [], []
+            for level, (source, mask, pos_embed) in enumerate(zip(sources, masks, position_embeddings_list)):
+                batch_size, num_channels, height, width = source.shape
+                spatial_shapes_list.append((height, width))
+                source_flatten.append(source.flatten(2).transpose(1, 2))
+                mask_flatten.append(mask.flatten(1))
+                lvl_pos_embed_flatten.append(pos_embed.flatten(2).transpose(1, 2)
+                                             + self.level_embed[level].view(1, 1, -1))
+            source_flatten = torch.cat(source_flatten, 1)
+            mask_flatten = torch.cat(mask_flatten, 1)
+            lvl_pos_embed_flatten = torch.cat(lvl_pos_embed_flatten, 1)
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1).float()
         # the (tiny) level-geometry tensors are cached per shape: built once with a synchronous H2D copy, then
         # reused, which keeps the forward free of host<->device traffic and capturable in a HIP graph
         key = (tuple(spatial_shapes_list), str(source_flatten.device))
@@ -802,7 +823,6 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             self._geom_cache[key] = (spatial_shapes, level_start_index)
         else:
             spatial_shapes, level_start_index = cached
-        valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1).float()
 
         if encoder_outputs is None:
             encoder_outputs = self.encoder(
@@ -810,7 +830,8 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                 position_embeddings=lvl_pos_embed_flatten, spatial_shapes=spatial_shapes,
                 level_start_index=level_start_index, valid_ratios=valid_ratios,
                 output_attentions=output_attentions, output_hidden_states=output_hidden_states,
-                return_dict=return_dict, spatial_shapes_list=spatial_shapes_list)
+                return_dict=return_dict, spatial_shapes_list=spatial_shapes_list,
+                reference_points=encoder_reference_points)
         elif return_dict and not isinstance(encoder_outputs, BaseModelOutput):
             encoder_outputs = BaseModelOutput(
                 last_hidden_state=encoder_outputs[0],

@@ -203,6 +203,42 @@ def sine_position_embedding(pixel_mask, embedding_dim, temperature, scale, eps=1
     return out
 
 
+_DIM_T = {}
+
+
+def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale, eps=1e-6):
+    """Everything DeformableDetrModel.forward derives from ``pixel_mask`` alone, in one HIP kernel
+    (egtr_level_geometry_f32): returns (mask_flatten [B,S] bool, lvl_pos_embed_flatten [B,S,2E] incl. level_embed,
+    valid_ratios [B,L,2], encoder reference_points [B,S,L,2]).  Inference only (no autograd through level_embed)."""
+    import ctypes
+    lib = _lib.lib()
+    dev = pixel_mask.device
+    key = (embedding_dim, float(temperature), str(dev))
+    dim_t = _DIM_T.get(key)
+    if dim_t is None:  # a constant of the module configuration (dd:864-865)
+        dim_t = torch.arange(embedding_dim, dtype=torch.float32, device=dev)
+        dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / embedding_dim)
+        _DIM_T[key] = dim_t
+    if pixel_mask.dtype not in (torch.int64, torch.uint8, torch.bool):
+        pixel_mask = (pixel_mask != 0).to(torch.uint8)
+    pm = pixel_mask.contiguous()
+    _chk(pm, "pixel_mask")
+    le = _chk(level_embed.detach().contiguous(), "level_embed", torch.float32)
+    B, H, W_ = pm.shape
+    L = len(spatial_shapes_list)
+    S = sum(h * w for h, w in spatial_shapes_list)
+    hw = (ctypes.c_int * (2 * L))(*[int(v) for hw_ in spatial_shapes_list for v in hw_])
+    mask_u8 = torch.empty(B, S, dtype=torch.uint8, device=dev)
+    pos = torch.empty(B, S, 2 * embedding_dim, dtype=torch.float32, device=dev)
+    vr = torch.empty(B, L, 2, dtype=torch.float32, device=dev)
+    ref = torch.empty(B, S, L, 2, dtype=torch.float32, device=dev)
+    st = lib.egtr_level_geometry_f32(_stream(), pm.data_ptr(), pm.element_size(), dim_t.data_ptr(), le.data_ptr(), hw,
+                                     L, B, H, W_, embedding_dim, float(scale), float(eps), mask_u8.data_ptr(),
+                                     pos.data_ptr(), vr.data_ptr(), ref.data_ptr())
+    _lib.check(st, "egtr_level_geometry_f32")
+    return mask_u8.view(torch.bool), pos, vr, ref
+
+
 class AddLayerNormFunction(Function):
     """LayerNorm(x + residual) over 256 channels in one pass (csrc/elementwise.hip).  Backward: recomputation with
     PyTorch-ROCm ops (training only)."""

@@ -158,6 +158,17 @@ int egtr_add_layernorm_f32(egtr_stream_t stream, const float* x, const float* re
 int egtr_sine_pos_embed_f32(egtr_stream_t stream, const float* y_embed, const float* x_embed, const float* dim_t,
                             float* out, int B, int H, int W, int E, float scale, float eps);
 
+/* Everything DeformableDetrModel.forward derives from pixel_mask alone (model/deformable_detr.py:2195-2278, 1616-1648,
+ * 850-876), for up to 4 feature levels level_hw = {H_0, W_0, H_1, W_1, ...} (HOST array): nearest-resized masks
+ * flattened over the levels (mask_flat [B,S] bytes, 1 = valid), normalised sine position embeddings + level_embed
+ * (pos_flat [B,S,2*embed_dim]; dim_t [embed_dim] = temperature^(2*(i/2)/embed_dim), level_embed [L,2*embed_dim]),
+ * valid_ratios [B,L,2] and the encoder reference points [B,S,L,2].  pixel_mask is [B,height,width] of int64
+ * (mask_elem_size 8) or bytes (1), non-zero = valid. */
+int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size, const float* dim_t,
+                            const float* level_embed, const int* level_hw, int num_levels, int batch, int height,
+                            int width, int embed_dim, float scale, float eps, unsigned char* mask_flat,
+                            float* pos_flat, float* valid_ratios, float* ref_points);
+
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):
  *   gate_q [B, N, T], gate_k [B, N, T]   : w_g[:d].q^[i,t]  and  w_g[d:].k^[j,t] + b_g      (T = Ld + 1 slots)
