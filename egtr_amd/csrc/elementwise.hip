@@ -80,7 +80,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ __launch_bounds__(256) void add_layernorm_256(const float* __restrict__ x, const float* __restrict__ res,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
-                                                         int rows, float eps) {
+                                                         int rows, float eps, const float* __restrict__ pos,
+                                                         int pos_rows, float* __restrict__ y_pos) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -94,8 +95,30 @@ __global__ __launch_bounds__(256) void add_layernorm_256(const float* __restrict
   const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);  // biased, as nn.LayerNorm
   const float rstd = rsqrtf(var + eps);
   const float4 g = reinterpret_cast<const float4*>(gamma)[lane], b = reinterpret_cast<const float4*>(beta)[lane];
-  reinterpret_cast<float4*>(y + (size_t)row * 256)[lane] =
-      make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
+  const float4 o = make_float4(dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w);
+  reinterpret_cast<float4*>(y + (size_t)row * 256)[lane] = o;
+  if (y_pos != nullptr) {  // the next sub-layer's "with_pos_embed" input: y + pos (pos rows repeat every pos_rows)
+    const float4 pe = reinterpret_cast<const float4*>(pos + (size_t)(row % pos_rows) * 256)[lane];
+    reinterpret_cast<float4*>(y_pos + (size_t)row * 256)[lane] = make_float4(o.x + pe.x, o.y + pe.y, o.z + pe.z, o.w + pe.w);
+  }
+}
+
+// y[g, r, :] = keep[r] ? y[g, r, :] + bias[g, :] : 0   (the value projections of all decoder layers at once: bias add
+// and the padding-mask select of deformable_detr.py:1050-1052 in one pass over G x R x C)
+__global__ __launch_bounds__(256) void bias_mask_rows(float* __restrict__ y, const float* __restrict__ bias,
+                                                      const unsigned char* __restrict__ keep, long long n4, int R,
+                                                      int C4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long long gr = i / C4;
+    const int r = (int)(gr % R);
+    const int g = (int)(gr / R);
+    float4 v = reinterpret_cast<float4*>(y)[i];
+    const float4 b = reinterpret_cast<const float4*>(bias)[(size_t)g * C4 + c4];
+    const bool k = keep == nullptr || keep[r] != 0;
+    v = k ? make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w) : make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
 }
 
 // Sine position embedding (DeformableDetrSinePositionEmbedding, normalize=True; model/deformable_detr.py:850-876) from
@@ -332,6 +355,29 @@ extern "C" int egtr_add_layernorm_f32(egtr_stream_t stream, const float* x, cons
   if (rows <= 0) return EGTR_E_ARG;
   if (dim != 256) return EGTR_E_UNSUPPORTED;
   hipLaunchKernelGGL(add_layernorm_256, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     residual, gamma, beta, y, rows, eps);
+                     residual, gamma, beta, y, rows, eps, (const float*)nullptr, 1, (float*)nullptr);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_add_layernorm_pos_f32(egtr_stream_t stream, const float* x, const float* residual,
+                                          const float* gamma, const float* beta, float* y, int rows, int dim,
+                                          float eps, const float* pos, int pos_rows, float* y_plus_pos) {
+  if (!x || !gamma || !beta || !y || !pos || !y_plus_pos) return EGTR_E_ARG;
+  if (rows <= 0 || pos_rows <= 0) return EGTR_E_ARG;
+  if (dim != 256) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(add_layernorm_256, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     residual, gamma, beta, y, rows, eps, pos, pos_rows, y_plus_pos);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_bias_mask_rows_f32(egtr_stream_t stream, float* y, const float* bias, const unsigned char* keep,
+                                       int groups, int rows, int cols) {
+  if (!y || !bias) return EGTR_E_ARG;
+  if (groups <= 0 || rows <= 0 || cols <= 0) return EGTR_E_ARG;
+  if (cols % 4 != 0) return EGTR_E_UNSUPPORTED;
+  const long long n4 = (long long)groups * rows * (cols / 4);
+  const int blocks = (int)std::min<long long>((n4 + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(bias_mask_rows, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), y, bias, keep, n4,
+                     rows, cols / 4);
   return egtr_check_launch();
 }

@@ -65,7 +65,101 @@ __global__ __launch_bounds__(256) void linear_skinny_f32(const float* __restrict
   }
 }
 
+// Up to 16 independent skinny linears in one launch (blockIdx.z = group): the q / k / v projections of a decoder layer,
+// the sampling_offsets + attention_weights pair, the 14 slot projections of the relation head, ...  Every kernel
+// launch costs ~5 us in a graph-replayed forward, whatever its size; these layers are all launch-bound.
+//   y_g[M_g, N_g] (row stride ldy_g) = act((alpha_x_g * X_g W_g^T + b_g) * alpha_g)
+struct LinGroup {
+  const float* x;
+  const float* w;
+  const float* b;
+  float* y;
+  int M, N, ldy, relu;
+  float alpha_x, alpha;
+};
+struct LinGroups {
+  LinGroup g[16];
+};
+
+template <int SPAN>
+__global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, int K, int span_rt) {
+  __shared__ float s_red[4 * 2 * 64 * 4];
+  const LinGroup& G = P.g[blockIdx.z];
+  const int M = G.M, N = G.N;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 32;
+  if (m0 >= M || n0 >= N) return;  // uniform per workgroup
+  const int span = SPAN > 0 ? SPAN : span_rt;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int kb = (wave * 4 + g) * span;
+  const int row = min(m0 + c, M - 1);
+  const int wr0 = min(n0 + c, N - 1), wr1 = min(n0 + 16 + c, N - 1);
+  const float4* xp = reinterpret_cast<const float4*>(G.x + (size_t)row * K + kb);
+  const float4* w0 = reinterpret_cast<const float4*>(G.w + (size_t)wr0 * K + kb);
+  const float4* w1 = reinterpret_cast<const float4*>(G.w + (size_t)wr1 * K + kb);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int t4 = 0; t4 < span / 4; ++t4) {
+    const float4 a = xp[t4], b0 = w0[t4], b1 = w1[t4];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+  }
+  reinterpret_cast<f32x4*>(s_red)[(wave * 2 + 0) * 64 + lane] = acc0;
+  reinterpret_cast<f32x4*>(s_red)[(wave * 2 + 1) * 64 + lane] = acc1;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + 256 * j;
+    const int sub = e >> 8, ln = (e >> 2) & 63, r = e & 3;
+    float v = s_red[((0 * 2 + sub) * 64 + ln) * 4 + r] + s_red[((1 * 2 + sub) * 64 + ln) * 4 + r] +
+              s_red[((2 * 2 + sub) * 64 + ln) * 4 + r] + s_red[((3 * 2 + sub) * 64 + ln) * 4 + r];
+    const int orow = m0 + (ln >> 4) * 4 + r, ocol = n0 + sub * 16 + (ln & 15);
+    if (orow < M && ocol < N) {
+      if (G.alpha_x != 1.f) v *= G.alpha_x;  // (alpha_x X) W^T: the product is scaled before the bias is added
+      if (G.b != nullptr) v += G.b[ocol];
+      v *= G.alpha;
+      if (G.relu) v = fmaxf(v, 0.f);
+      G.y[(size_t)orow * G.ldy + ocol] = v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* const* x,
+                                       const float* const* w, const float* const* bias, float* const* y, const int* M,
+                                       const int* N, const int* ldy, const float* alpha_x, const float* alpha,
+                                       const int* relu, int K) {
+  if (!x || !w || !bias || !y || !M || !N || !ldy || !alpha_x || !alpha || !relu) return EGTR_E_ARG;
+  if (num_groups <= 0 || num_groups > 16 || K <= 0) return EGTR_E_ARG;
+  if (K % 64 != 0) return EGTR_E_UNSUPPORTED;
+  LinGroups P;
+  int maxM = 0, maxN = 0;
+  for (int i = 0; i < 16; ++i) {
+    const int s = i < num_groups ? i : 0;
+    if (!x[s] || !w[s] || !y[s] || M[s] <= 0 || N[s] <= 0 || ldy[s] < N[s]) return EGTR_E_ARG;
+    P.g[i] = LinGroup{x[s], w[s], bias[s], y[s], M[s], N[s], ldy[s], relu[s], alpha_x[s], alpha[s]};
+    if (i < num_groups) {
+      maxM = M[s] > maxM ? M[s] : maxM;
+      maxN = N[s] > maxN ? N[s] : maxN;
+    }
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((maxN + 31) / 32, (maxM + 15) / 16, num_groups);
+  const int span = K / 16;
+  if (span == 16)
+    hipLaunchKernelGGL(linear_skinny_grouped_f32<16>, grid, dim3(256), 0, st, P, K, span);
+  else if (span == 64)
+    hipLaunchKernelGGL(linear_skinny_grouped_f32<64>, grid, dim3(256), 0, st, P, K, span);
+  else
+    hipLaunchKernelGGL(linear_skinny_grouped_f32<0>, grid, dim3(256), 0, st, P, K, span);
+  return egtr_check_launch();
+}
 
 extern "C" int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const float* bias, float* y,
                                int M, int K, int N, float alpha, int relu) {

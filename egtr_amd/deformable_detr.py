@@ -276,6 +276,27 @@ def build_position_encoding(config):
     raise ValueError(f"Not supported {config.position_embedding_type}")
 
 
+_ZEROS = {}
+
+
+def _zero_scalar(like):
+    """A cached 0-dim zero on ``like``'s device / dtype (torch.where operand; avoids one fill launch per call)."""
+    key = (like.device, like.dtype)
+    z = _ZEROS.get(key)
+    if z is None:
+        z = torch.zeros((), device=like.device, dtype=like.dtype)
+        _ZEROS[key] = z
+    return z
+
+
+def _pos_rows(position_embeddings):
+    """Position embeddings as the [rows, 256] table the LayerNorm + position kernel tiles over the batch."""
+    p = position_embeddings
+    if p.dim() == 3 and p.stride(0) == 0:  # query embeddings expanded over the batch
+        p = p[0]
+    return p.reshape(-1, p.shape[-1])
+
+
 # ---------------------------------------------------------------------------------------- attention modules
 class DeformableDetrMultiscaleDeformableAttention(nn.Module):
     """Multi-scale deformable attention (dd:963-1104); the sample + weighted-sum core runs in HIP."""
@@ -322,8 +343,13 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 encoder_hidden_states=None, encoder_attention_mask=None,
                 position_embeddings: Optional[torch.Tensor] = None, reference_points=None, spatial_shapes=None,
-                level_start_index=None, output_attentions: bool = False, spatial_shapes_list=None):
-        if position_embeddings is not None:
+                level_start_index=None, output_attentions: bool = False, spatial_shapes_list=None,
+                hidden_with_pos=None, precomputed_value=None):
+        # hidden_with_pos / precomputed_value: inference-only hand-ins that save launches (the previous LayerNorm
+        # kernel also wrote hidden + pos; the decoder projects the values of all its layers in one batched GEMM)
+        if hidden_with_pos is not None:
+            hidden_states = hidden_with_pos
+        elif position_embeddings is not None:
             hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
         batch_size, num_queries, _ = hidden_states.shape
         batch_size, sequence_length, _ = encoder_hidden_states.shape
@@ -335,15 +361,24 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         if total != sequence_length:
             raise ValueError("Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
 
-        value = ops.module_linear(self.value_proj, encoder_hidden_states)
-        if attention_mask is not None:
-            # dd:1052 `value.masked_fill(~mask[..., None], 0)` as one select (no mask inversion, no clone)
-            value = torch.where(attention_mask[..., None], value, value.new_zeros(()))
+        if precomputed_value is not None:
+            value = precomputed_value
+        else:
+            value = ops.module_linear(self.value_proj, encoder_hidden_states)
+            if attention_mask is not None:
+                # dd:1052 `value.masked_fill(~mask[..., None], 0)` as one select (no mask inversion, no clone)
+                value = torch.where(attention_mask[..., None], value, _zero_scalar(value))
         value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets = ops.module_linear(self.sampling_offsets, hidden_states).view(
-            batch_size, num_queries, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = ops.module_linear(self.attention_weights, hidden_states).view(
-            batch_size, num_queries, self.n_heads, self.n_levels * self.n_points)
+        if ops.inference_fast_path(hidden_states) and batch_size * num_queries <= ops.SKINNY_MAX_ROWS:
+            sampling_offsets, attention_weights = ops.linear_grouped([
+                dict(x=hidden_states, w=self.sampling_offsets.weight, b=self.sampling_offsets.bias),
+                dict(x=hidden_states, w=self.attention_weights.weight, b=self.attention_weights.bias)])
+        else:
+            sampling_offsets = ops.module_linear(self.sampling_offsets, hidden_states)
+            attention_weights = ops.module_linear(self.attention_weights, hidden_states)
+        sampling_offsets = sampling_offsets.view(batch_size, num_queries, self.n_heads, self.n_levels, self.n_points, 2)
+        attention_weights = attention_weights.view(batch_size, num_queries, self.n_heads,
+                                                   self.n_levels * self.n_points)
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but got {reference_points.shape[-1]}")
         needs_grad = torch.is_grad_enabled() and (value.requires_grad or sampling_offsets.requires_grad
@@ -400,7 +435,7 @@ class DeformableDetrMultiheadAttention(nn.Module):
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_embeddings: Optional[torch.Tensor] = None, output_attentions: bool = False,
-                output_attention_states: bool = False):
+                output_attention_states: bool = False, hidden_with_pos=None):
         if attention_mask is not None:
             raise NotImplementedError("decoder self-attention masks are not supported by the fused kernel")
         if output_attentions:
@@ -408,11 +443,19 @@ class DeformableDetrMultiheadAttention(nn.Module):
         if self.dropout != 0.0 and self.training:
             raise NotImplementedError("attention dropout is not supported by the fused kernel (EGTR uses 0.0)")
         hidden_states_original = hidden_states
-        if position_embeddings is not None:
+        if hidden_with_pos is not None:
+            hidden_states = hidden_with_pos
+        elif position_embeddings is not None:
             hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
-        query_states = ops.module_linear(self.q_proj, hidden_states, alpha=self.scaling)  # dd:1166, scale fused
-        key_states = ops.module_linear(self.k_proj, hidden_states)
-        value_states = ops.module_linear(self.v_proj, hidden_states_original)
+        if ops.inference_fast_path(hidden_states):  # q / k / v projections in one launch
+            query_states, key_states, value_states = ops.linear_grouped([
+                dict(x=hidden_states, w=self.q_proj.weight, b=self.q_proj.bias, alpha=self.scaling),
+                dict(x=hidden_states, w=self.k_proj.weight, b=self.k_proj.bias),
+                dict(x=hidden_states_original, w=self.v_proj.weight, b=self.v_proj.bias)])
+        else:
+            query_states = ops.module_linear(self.q_proj, hidden_states, alpha=self.scaling)  # dd:1166, scale fused
+            key_states = ops.module_linear(self.k_proj, hidden_states)
+            value_states = ops.module_linear(self.v_proj, hidden_states_original)
         attn_output, _, _ = ops.decoder_self_attention(query_states, key_states, value_states, self.num_heads,
                                                        want_maps=False)
         q_maps = k_maps = None
@@ -446,13 +489,16 @@ class DeformableDetrEncoderLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask, position_embeddings=None, reference_points=None,
                 spatial_shapes=None, level_start_index=None, output_attentions: bool = False,
-                spatial_shapes_list=None):
+                spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False):
+        """``hidden_with_pos`` / ``return_with_pos`` (inference plumbing): hidden + position embeddings handed in by
+        the previous layer / appended to the outputs for the next one (written by the final LayerNorm kernel)."""
         residual = hidden_states
         hidden_states, attn_weights = self.self_attn(
             hidden_states=hidden_states, attention_mask=attention_mask, encoder_hidden_states=hidden_states,
             encoder_attention_mask=attention_mask, position_embeddings=position_embeddings,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-            output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list)
+            output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
+            hidden_with_pos=hidden_with_pos)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
         residual = hidden_states
@@ -463,7 +509,12 @@ class DeformableDetrEncoderLayer(nn.Module):
         hidden_states = F.dropout(hidden_states, p=self.activation_dropout, training=self.training)
         hidden_states = ops.module_linear(self.fc2, hidden_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
+        next_with_pos = None
+        if return_with_pos and position_embeddings is not None and ops.inference_fast_path(hidden_states):
+            hidden_states, next_with_pos = ops.add_layer_norm_pos(hidden_states, residual, self.final_layer_norm,
+                                                                  _pos_rows(position_embeddings))
+        else:
+            hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
         if self.training:  # dd:1346-1351 (data-dependent host sync, kept for parity)
             if torch.isinf(hidden_states).any() or torch.isnan(hidden_states).any():
                 clamp_value = torch.finfo(hidden_states.dtype).max - 1000
@@ -471,6 +522,8 @@ class DeformableDetrEncoderLayer(nn.Module):
         outputs = (hidden_states,)
         if output_attentions:
             outputs += (attn_weights,)
+        if return_with_pos:
+            outputs += (next_with_pos,)
         return outputs
 
 
@@ -497,20 +550,30 @@ class DeformableDetrDecoderLayer(nn.Module):
     def forward(self, hidden_states, attention_mask=None, position_embeddings=None, reference_points=None,
                 spatial_shapes=None, level_start_index=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, output_attentions=False, output_attention_states=False,
-                spatial_shapes_list=None):
+                spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False, precomputed_value=None):
+        """``hidden_with_pos`` / ``return_with_pos`` / ``precomputed_value``: inference plumbing, see the encoder layer
+        and DeformableDetrDecoder.forward."""
+        fast = position_embeddings is not None and ops.inference_fast_path(hidden_states)
         residual = hidden_states
         hidden_states, self_attn_weights, self_attn_queries, self_attn_keys = self.self_attn(
             hidden_states=hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
-            output_attentions=output_attentions, output_attention_states=output_attention_states)
+            output_attentions=output_attentions, output_attention_states=output_attention_states,
+            hidden_with_pos=hidden_with_pos)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
+        cross_with_pos = None
+        if fast:
+            hidden_states, cross_with_pos = ops.add_layer_norm_pos(hidden_states, residual, self.self_attn_layer_norm,
+                                                                   _pos_rows(position_embeddings))
+        else:
+            hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
         second_residual = hidden_states
         hidden_states, cross_attn_weights = self.encoder_attn(
             hidden_states=hidden_states, attention_mask=encoder_attention_mask,
             encoder_hidden_states=encoder_hidden_states, encoder_attention_mask=encoder_attention_mask,
             position_embeddings=position_embeddings, reference_points=reference_points,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-            output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list)
+            output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
+            hidden_with_pos=cross_with_pos, precomputed_value=precomputed_value)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         hidden_states = ops.add_layer_norm(hidden_states, second_residual, self.encoder_attn_layer_norm)
         residual = hidden_states
@@ -521,12 +584,19 @@ class DeformableDetrDecoderLayer(nn.Module):
         hidden_states = F.dropout(hidden_states, p=self.activation_dropout, training=self.training)
         hidden_states = ops.module_linear(self.fc2, hidden_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
+        next_with_pos = None
+        if fast and return_with_pos:
+            hidden_states, next_with_pos = ops.add_layer_norm_pos(hidden_states, residual, self.final_layer_norm,
+                                                                  _pos_rows(position_embeddings))
+        else:
+            hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
         outputs = (hidden_states,)
         if output_attentions:
             outputs += (self_attn_weights, cross_attn_weights)
         if output_attention_states:
             outputs += (self_attn_queries, self_attn_keys)
+        if return_with_pos:
+            outputs += (next_with_pos,)
         return outputs
 
 
@@ -596,6 +666,7 @@ class DeformableDetrEncoder(DeformableDetrPreTrainedModel):
                 device=inputs_embeds.device)
         encoder_states = () if output_hidden_states else None
         all_attentions = () if output_attentions else None
+        with_pos = None
         for encoder_layer in self.layers:
             if output_hidden_states:
                 encoder_states = encoder_states + (hidden_states,)
@@ -603,8 +674,9 @@ class DeformableDetrEncoder(DeformableDetrPreTrainedModel):
                 hidden_states, attention_mask, position_embeddings=position_embeddings,
                 reference_points=reference_points, spatial_shapes=spatial_shapes,
                 level_start_index=level_start_index, output_attentions=output_attentions,
-                spatial_shapes_list=spatial_shapes_list)
+                spatial_shapes_list=spatial_shapes_list, hidden_with_pos=with_pos, return_with_pos=True)
             hidden_states = layer_outputs[0]
+            with_pos = layer_outputs[-1]
             if output_attentions:
                 all_attentions = all_attentions + (layer_outputs[1],)
         if output_hidden_states:
@@ -645,8 +717,29 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
         intermediate_reference_points = ()
         all_attention_queries = () if output_attention_states else None
         all_attention_keys = () if output_attention_states else None
+        fast = ops.inference_fast_path(hidden_states) and encoder_hidden_states is not None
+        values = None
+        if fast:
+            # the value projections of ALL layers' cross-attention depend only on the encoder output: one batched
+            # GEMM + one bias / padding-mask pass instead of (GEMM + fill + select) per layer
+            nl = len(self.layers)
+            w_t, b_all = ops.cached_weights(
+                ("decoder_value_proj", id(self)),
+                [l.encoder_attn.value_proj.weight for l in self.layers] + [l.encoder_attn.value_proj.bias for l in self.layers],
+                lambda: (torch.stack([l.encoder_attn.value_proj.weight.t() for l in self.layers]).contiguous(),
+                         torch.stack([l.encoder_attn.value_proj.bias for l in self.layers]).contiguous()))
+            bsz_, seq_, dm_ = encoder_hidden_states.shape
+            x2 = encoder_hidden_states.reshape(1, bsz_ * seq_, dm_).expand(nl, -1, -1)
+            values = ops.bias_mask_rows_(torch.bmm(x2, w_t), b_all, encoder_attention_mask)
+            values = values.view(nl, bsz_, seq_, dm_)
+        hoisted_reference = None
+        if self.bbox_embed is None and reference_points.shape[-1] == 2:  # no refinement: same input for every layer
+            hoisted_reference = reference_points[:, :, None] * valid_ratios[:, None]
+        with_pos = None
         for idx, decoder_layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
+            if hoisted_reference is not None:
+                reference_points_input = hoisted_reference
+            elif reference_points.shape[-1] == 4:
                 reference_points_input = (reference_points[:, :, None]
                                           * torch.cat([valid_ratios, valid_ratios], -1)[:, None])
             else:
@@ -660,8 +753,11 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 encoder_hidden_states=encoder_hidden_states, reference_points=reference_points_input,
                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                 encoder_attention_mask=encoder_attention_mask, output_attentions=output_attentions,
-                output_attention_states=output_attention_states, spatial_shapes_list=spatial_shapes_list)
+                output_attention_states=output_attention_states, spatial_shapes_list=spatial_shapes_list,
+                hidden_with_pos=with_pos, return_with_pos=True,
+                precomputed_value=values[idx] if values is not None else None)
             hidden_states = layer_outputs[0]
+            with_pos = layer_outputs[-1]
             if self.bbox_embed is not None:  # iterative box refinement (dd:1903-1918)
                 tmp = self.bbox_embed[idx](hidden_states)
                 if reference_points.shape[-1] == 4:
@@ -774,7 +870,11 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
         if fused_geometry:
             # inference: masks, position embeddings (+ level_embed), valid ratios and the encoder reference points of
             # all levels come from ONE HIP kernel instead of ~100 tiny launches (dd:2195-2278, 1616-1648, 850-876)
-            feature_maps = self.backbone.conv_encoder.model(pixel_values)
+            conv_encoder = self.backbone.conv_encoder
+            if isinstance(conv_encoder, DeformableDetrTimmConvEncoder):
+                feature_maps = conv_encoder.model(pixel_values)
+            else:  # a user-supplied feature extractor: keep its (feature, mask) interface, drop its masks
+                feature_maps = [fm for fm, _ in conv_encoder(pixel_values, pixel_mask)]
             sources = [self.input_proj[level](fm) for level, fm in enumerate(feature_maps)]
             for level in range(len(sources), self.config.num_feature_levels):  # dd:2228-2241
                 sources.append(self.input_proj[level](feature_maps[-1] if level == len(feature_maps) else sources[-1]))

@@ -110,30 +110,63 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         """egtr:322-418 via the separable algebra.  Returns pre-sigmoid (rel [B,N,N,R], conn [B,N,N,1], gate_mean)."""
         bsz, N, d = sequence_output.shape
         unscaling = self.head_dim ** 0.5
-        # slot projections q^[b,i,t,:], k^[b,j,t,:]  (t < Ld: decoder layers, t = Ld: final hidden state)
-        pq = [ops.module_linear(proj, q.transpose(1, 2).reshape(bsz, N, d) * unscaling)
-              for q, proj in zip(queries, self.proj_q)]
-        pk = [ops.module_linear(proj, k.transpose(1, 2).reshape(bsz, N, d)) for k, proj in zip(keys, self.proj_k)]
-        pq.append(ops.module_linear(self.final_sub_proj, sequence_output))
-        pk.append(ops.module_linear(self.final_obj_proj, sequence_output))
-        Q = torch.stack(pq, -2)  # [B,N,T,d]
-        K = torch.stack(pk, -2)
-        # separable gate logit and first MLP layer:  [W1_rel ; W1_conn ; w_gate] applied to each half
+        rp, cl = self.rel_predictor.layers, self.connectivity_layer.layers
         wg = self.rel_predictor_gate.weight  # [1, 2d]
-        w1 = torch.cat([self.rel_predictor.layers[0].weight, self.connectivity_layer.layers[0].weight], 0)  # [2Hd,2d]
-        wq = torch.cat([w1[:, :d], wg[:, :d]], 0)  # [2Hd+1, d]
-        wk = torch.cat([w1[:, d:], wg[:, d:]], 0)
-        tq = ops.linear(Q, wq)  # [B,N,T,2Hd+1]
-        tk = ops.linear(K, wk)
-        hd2 = w1.shape[0]
-        uq, gate_q = tq[..., :hd2].contiguous(), tq[..., hd2].contiguous()
-        uk, gate_k = tk[..., :hd2].contiguous(), (tk[..., hd2] + self.rel_predictor_gate.bias).contiguous()
-        b1 = torch.cat([self.rel_predictor.layers[0].bias, self.connectivity_layer.layers[0].bias], 0)
+        if ops.inference_fast_path(sequence_output):
+            # Inference: the 2 x (Ld + 1) slot projections run as ONE grouped launch writing straight into the stacked
+            # [B,N,T,d] buffers (the x sqrt(D) unscaling of egtr:343 is the group's input scale), and the four
+            # separable first-layer / gate products as one more; their weight slices are cached derived constants.
+            T = len(queries) + 1
+            Q = torch.empty(bsz, N, T, d, dtype=sequence_output.dtype, device=sequence_output.device)
+            K = torch.empty_like(Q)
+            Qv, Kv = Q.view(bsz * N, T, d), K.view(bsz * N, T, d)
+            items = []
+            for t, (q, proj) in enumerate(zip(queries, self.proj_q)):
+                items.append(dict(x=q.transpose(1, 2).reshape(bsz, N, d), w=proj.weight, b=proj.bias,
+                                  alpha_x=unscaling, out=Qv[:, t, :]))
+            items.append(dict(x=sequence_output, w=self.final_sub_proj.weight, b=self.final_sub_proj.bias,
+                              out=Qv[:, T - 1, :]))
+            for t, (k, proj) in enumerate(zip(keys, self.proj_k)):
+                items.append(dict(x=k.transpose(1, 2).reshape(bsz, N, d), w=proj.weight, b=proj.bias,
+                                  out=Kv[:, t, :]))
+            items.append(dict(x=sequence_output, w=self.final_obj_proj.weight, b=self.final_obj_proj.bias,
+                              out=Kv[:, T - 1, :]))
+            for i0 in range(0, len(items), 16):
+                ops.linear_grouped(items[i0:i0 + 16])
+            w1q, w1k, wgq, wgk, b1 = ops.cached_weights(
+                ("rel_head_first_layer", id(self)),
+                [rp[0].weight, cl[0].weight, wg, rp[0].bias, cl[0].bias],
+                lambda: (torch.cat([rp[0].weight[:, :d], cl[0].weight[:, :d]], 0).contiguous(),
+                         torch.cat([rp[0].weight[:, d:], cl[0].weight[:, d:]], 0).contiguous(),
+                         wg[:, :d].contiguous(), wg[:, d:].contiguous(),
+                         torch.cat([rp[0].bias, cl[0].bias], 0).contiguous()))
+            uq, uk, gate_q, gate_k = ops.linear_grouped([
+                dict(x=Q, w=w1q), dict(x=K, w=w1k), dict(x=Q, w=wgq),
+                dict(x=K, w=wgk, b=self.rel_predictor_gate.bias)])
+            gate_q, gate_k = gate_q[..., 0], gate_k[..., 0]
+        else:
+            # slot projections q^[b,i,t,:], k^[b,j,t,:]  (t < Ld: decoder layers, t = Ld: final hidden state)
+            pq = [ops.module_linear(proj, q.transpose(1, 2).reshape(bsz, N, d) * unscaling)
+                  for q, proj in zip(queries, self.proj_q)]
+            pk = [ops.module_linear(proj, k.transpose(1, 2).reshape(bsz, N, d)) for k, proj in zip(keys, self.proj_k)]
+            pq.append(ops.module_linear(self.final_sub_proj, sequence_output))
+            pk.append(ops.module_linear(self.final_obj_proj, sequence_output))
+            Q = torch.stack(pq, -2)  # [B,N,T,d]
+            K = torch.stack(pk, -2)
+            # separable gate logit and first MLP layer:  [W1_rel ; W1_conn ; w_gate] applied to each half
+            w1 = torch.cat([rp[0].weight, cl[0].weight], 0)  # [2Hd,2d]
+            wq = torch.cat([w1[:, :d], wg[:, :d]], 0)  # [2Hd+1, d]
+            wk = torch.cat([w1[:, d:], wg[:, d:]], 0)
+            tq = ops.linear(Q, wq)  # [B,N,T,2Hd+1]
+            tk = ops.linear(K, wk)
+            hd2 = w1.shape[0]
+            uq, gate_q = tq[..., :hd2].contiguous(), tq[..., hd2].contiguous()
+            uk, gate_k = tk[..., :hd2].contiguous(), (tk[..., hd2] + self.rel_predictor_gate.bias).contiguous()
+            b1 = torch.cat([rp[0].bias, cl[0].bias], 0)
         triplet, node = None, None
         if self.config.use_freq_bias:  # egtr:405-413
             triplet = self.triplet_dist
             node = torch.argmax(logits, dim=-1)
-        rp, cl = self.rel_predictor.layers, self.connectivity_layer.layers
         return ops.relation_head(gate_q, gate_k, uq, uk, b1, rp[1].weight, rp[1].bias, rp[2].weight, rp[2].bias,
                                  cl[1].weight, cl[1].bias, cl[2].weight, cl[2].bias, triplet, node,
                                  want_gate_mean)
@@ -158,8 +191,17 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             # class_embed / bbox_embed alias ONE module for every level (egtr:152-158): apply them once to the stacked
             # [B, Ld, N, d] states instead of Ld times (same arithmetic per row as egtr:286-305)
             refs = torch.cat([init_reference[:, None], inter_references[:, :-1]], 1)
-            outputs_class = ops.module_linear(self.class_embed[0], hidden_states)
-            delta_bbox = self.bbox_embed[0](hidden_states)
+            box_layers = self.bbox_embed[0].layers
+            if ops.inference_fast_path(hidden_states) and hidden_states.numel() // hidden_states.shape[-1] <= ops.SKINNY_MAX_ROWS:
+                # class logits and the first box-MLP layer read the same rows: one grouped launch
+                outputs_class, delta_bbox = ops.linear_grouped([
+                    dict(x=hidden_states, w=self.class_embed[0].weight, b=self.class_embed[0].bias),
+                    dict(x=hidden_states, w=box_layers[0].weight, b=box_layers[0].bias, relu=len(box_layers) > 1)])
+                for i, layer in enumerate(box_layers[1:], 1):
+                    delta_bbox = ops.module_linear(layer, delta_bbox, relu=i < len(box_layers) - 1)
+            else:
+                outputs_class = ops.module_linear(self.class_embed[0], hidden_states)
+                delta_bbox = self.bbox_embed[0](hidden_states)
             if refs.shape[-1] == 4:
                 outputs_coord = (delta_bbox + inverse_sigmoid(refs)).sigmoid()
             elif refs.shape[-1] == 2:

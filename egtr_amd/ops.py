@@ -168,6 +168,105 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
     return torch.relu(y) if relu else y
 
 
+_WCACHE = {}
+
+
+def cached_weights(name, tensors, builder):
+    """Derived constants of module weights (stacks, slices, concatenations) built once and rebuilt when any source
+    tensor is replaced or modified in place (data pointer / version counter)."""
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    hit = _WCACHE.get(name)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, builder())
+        _WCACHE[name] = hit
+    return hit[1]
+
+
+def inference_fast_path(x):
+    """True when the launch-count optimisations (grouped linears, LayerNorm + position output, batched value
+    projections) apply: fp32 tensors on the GPU and no autograd graph being recorded."""
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+
+
+def linear_grouped(items):
+    """Several independent skinny linears in ONE HIP launch (egtr_linear_grouped_f32).  ``items`` is a list of dicts:
+    x [.., K], w [N, K], b [N] or None, optional out (2-D view [rows, N] with unit inner stride: rows of a larger
+    buffer), alpha_x (scale on x), alpha (scale after the bias), relu.  Returns the list of outputs ([.., N], or the
+    given ``out`` views).  Inference only (no autograd)."""
+    import ctypes
+    lib = _lib.lib()
+    G = len(items)
+    if not 0 < G <= 16:
+        raise ValueError("linear_grouped: 1..16 groups")
+    K = items[0]["x"].shape[-1]
+    xs, ws, bs, ys, Ms, Ns, lds, ax, al, rl, outs, keep = [], [], [], [], [], [], [], [], [], [], [], []
+    for it in items:
+        x, w, b = it["x"], it["w"], it.get("b")
+        x2 = _chk(x.reshape(-1, K).contiguous(), "x", torch.float32)
+        w2 = _chk(w.detach().contiguous(), "w", torch.float32)
+        b2 = _chk(b.detach().contiguous(), "b", torch.float32) if b is not None else None
+        if w2.shape[1] != K or x.shape[-1] != K:
+            raise ValueError("linear_grouped: all groups share K")
+        M, N = x2.shape[0], w2.shape[0]
+        out = it.get("out")
+        if out is None:
+            y2 = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            outs.append(y2.view(*x.shape[:-1], N))
+        else:
+            if out.dim() != 2 or out.shape != (M, N) or out.stride(1) != 1:
+                raise ValueError("linear_grouped: out must be a [rows, N] view with unit inner stride")
+            y2 = out
+            outs.append(out)
+        keep += [x2, w2, b2, y2]
+        xs.append(x2.data_ptr()); ws.append(w2.data_ptr()); bs.append(b2.data_ptr() if b2 is not None else None)
+        ys.append(y2.data_ptr()); Ms.append(M); Ns.append(N); lds.append(y2.stride(0))
+        ax.append(float(it.get("alpha_x", 1.0))); al.append(float(it.get("alpha", 1.0)))
+        rl.append(1 if it.get("relu") else 0)
+    PA, IA, FA = ctypes.c_void_p * G, ctypes.c_int * G, ctypes.c_float * G
+    st = lib.egtr_linear_grouped_f32(_stream(), G, PA(*xs), PA(*ws), PA(*bs), PA(*ys), IA(*Ms), IA(*Ns), IA(*lds),
+                                     FA(*ax), FA(*al), IA(*rl), K)
+    _lib.check(st, "egtr_linear_grouped_f32")
+    return outs
+
+
+def bias_mask_rows_(y, bias, keep):
+    """In place: y[g, r, :] = keep[r] ? y[g, r, :] + bias[g, :] : 0  (y [G, R, C]; keep [R] bool or None)."""
+    lib = _lib.lib()
+    G, R, C = y.shape
+    _chk(y, "y", torch.float32)
+    b2 = _chk(bias.detach().contiguous(), "bias", torch.float32)
+    k2 = None
+    if keep is not None:
+        k2 = keep.reshape(-1).contiguous()
+        k2 = k2.view(torch.uint8) if k2.dtype == torch.bool else k2.to(torch.uint8)
+        _chk(k2, "keep")
+    st = lib.egtr_bias_mask_rows_f32(_stream(), y.data_ptr(), b2.data_ptr(), k2.data_ptr() if k2 is not None else None,
+                                     G, R, C)
+    _lib.check(st, "egtr_bias_mask_rows_f32")
+    return y
+
+
+def add_layer_norm_pos(x, residual, ln, pos):
+    """(ln(residual + x), ln(residual + x) + pos) in one HIP launch; pos is [rows_p, 256] with rows % rows_p == 0
+    (broadcast over the batch).  Inference only."""
+    lib = _lib.lib()
+    x2 = _chk(x.contiguous(), "x", torch.float32)
+    r2 = _chk(residual.contiguous(), "residual", torch.float32)
+    p2 = _chk(pos.contiguous(), "pos", torch.float32)
+    rows = x2.numel() // 256
+    prow = p2.numel() // 256
+    if x2.shape[-1] != 256 or rows % prow != 0:
+        raise ValueError("add_layer_norm_pos: d_model must be 256 and pos must tile the rows")
+    y = torch.empty_like(x2)
+    yp = torch.empty_like(x2)
+    st = lib.egtr_add_layernorm_pos_f32(_stream(), x2.data_ptr(), r2.data_ptr(), ln.weight.data_ptr(),
+                                        ln.bias.data_ptr(), y.data_ptr(), rows, 256, float(ln.eps), p2.data_ptr(),
+                                        prow, yp.data_ptr())
+    _lib.check(st, "egtr_add_layernorm_pos_f32")
+    return y, yp
+
+
 def module_linear(mod, x, alpha=1.0, relu=False):
     return linear(x, mod.weight, mod.bias, alpha, relu)
 

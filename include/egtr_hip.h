@@ -142,6 +142,13 @@ int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const floa
 int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const float* bias, float* y, int M, int K,
                     int N, float alpha, int relu);
 
+/* Up to 16 independent skinny linears in ONE launch (every launch costs ~5 us in a graph-replayed forward):
+ *   y_g[M_g, N_g] (row stride ldy_g floats) = act((alpha_x_g * X_g W_g^T + b_g) * alpha_g),  X_g [M_g, K], W_g [N_g, K].
+ * All arrays are HOST arrays of num_groups entries (pointers are device pointers; bias[g] may be NULL); K % 64 == 0. */
+int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* const* x, const float* const* w,
+                            const float* const* bias, float* const* y, const int* M, const int* N, const int* ldy,
+                            const float* alpha_x, const float* alpha, const int* relu, int K);
+
 /* ---- fused memory-bound epilogues --------------------------------------------------------------------------- */
 /* y = act(x + bias[c] (+ residual)) on an NCHW fp32 activation [N, C, HW]; residual may be NULL; y may alias x.
  * (Folded frozen-BN shift + bottleneck residual + ReLU of the ResNet-50 backbone in one pass.) */
@@ -151,6 +158,17 @@ int egtr_bias_act_nchw_f32(egtr_stream_t stream, const float* x, const float* bi
  * sqrt: the residual + LayerNorm of every encoder / decoder sub-layer (model/deformable_detr.py:1329-1330 etc.). */
 int egtr_add_layernorm_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,
                            const float* beta, float* y, int rows, int dim, float eps);
+
+/* Same, and additionally y_plus_pos = y + pos[row % pos_rows] (the "with_pos_embed" input of the next sub-layer,
+ * deformable_detr.py:1023-1024 / 1148-1149), saving one elementwise launch per sub-layer. */
+int egtr_add_layernorm_pos_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,
+                               const float* beta, float* y, int rows, int dim, float eps, const float* pos,
+                               int pos_rows, float* y_plus_pos);
+
+/* In place: y[g, r, :] = keep[r] ? y[g, r, :] + bias[g, :] : 0  (bias add + padding-mask select of
+ * deformable_detr.py:1050-1052 for the value projections of all decoder layers at once; keep may be NULL). */
+int egtr_bias_mask_rows_f32(egtr_stream_t stream, float* y, const float* bias, const unsigned char* keep, int groups,
+                            int rows, int cols);
 
 /* Sine position embedding of DeformableDetrSinePositionEmbedding(normalize=True) (model/deformable_detr.py:850-876)
  * from y_embed / x_embed = cumsum of the mask along H / W ([B,H,W] fp32) and dim_t [E] (the reference's

@@ -617,3 +617,52 @@ def test_level_geometry_matches_reference_composition(mask_dtype):
     # padded tokens: the embedding takes sin / cos of arguments up to ~1e6 (cumsum / eps); compare loosely in the
     # argument domain by checking the values stay in [-1, 1] + level_embed range
     assert (posf.cpu() - level_embed.repeat_interleave(torch.tensor([80, 20, 6, 2]), 0)[None]).abs().max() <= 1.0 + 1e-6
+
+
+def test_linear_grouped_matches_torch():
+    """egtr_linear_grouped_f32: mixed shapes, input scale, output scale, ReLU, strided output rows, no bias."""
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    K = 256
+    specs = [(200, 256, 1.0, 0.17677669, False, True), (200, 256, 1.0, 1.0, False, True),
+             (37, 513, 5.656854, 1.0, False, False), (1400, 1, 1.0, 1.0, False, True), (64, 128, 1.0, 1.0, True, True)]
+    items, want = [], []
+    buf = torch.zeros(200, 3, 256, device=DEV)
+    for i, (M, N, ax, al, relu, has_b) in enumerate(specs):
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / 16
+        b = torch.randn(N, generator=g) if has_b else None
+        r = F.linear(x * ax, w, b) * al
+        want.append(torch.relu(r) if relu else r)
+        it = dict(x=x.to(DEV), w=w.to(DEV), b=b.to(DEV) if has_b else None, alpha_x=ax, alpha=al, relu=relu)
+        if i == 1:
+            it["out"] = buf[:, 1, :]
+        items.append(it)
+    with torch.no_grad():
+        outs = ops.linear_grouped(items)
+    for o, r in zip(outs, want):
+        assert (o.cpu() - r).abs().max() < 2e-5 * max(1.0, float(r.abs().max()))
+    assert torch.equal(outs[1], buf[:, 1, :]) and buf[:, 0].abs().max() == 0 and buf[:, 2].abs().max() == 0
+
+
+def test_add_layer_norm_pos_and_bias_mask_rows():
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x, res, pos = torch.randn(3, 50, 256, generator=g), torch.randn(3, 50, 256, generator=g), torch.randn(50, 256, generator=g)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(256, generator=g))
+        ln.bias.copy_(torch.randn(256, generator=g))
+        want = ln(x + res)
+        y, yp = ops.add_layer_norm_pos(x.to(DEV), res.to(DEV), ln.to(DEV), pos.to(DEV))
+    assert (y.cpu() - want).abs().max() < 2e-5
+    assert (yp.cpu() - (want + pos)).abs().max() < 2e-5
+    v = torch.randn(4, 77, 256, generator=g)
+    b = torch.randn(4, 256, generator=g)
+    keep = torch.rand(77, generator=g) > 0.3
+    want = torch.where(keep[None, :, None], v + b[:, None, :], torch.zeros(()))
+    got = ops.bias_mask_rows_(v.to(DEV).clone(), b.to(DEV), keep.to(DEV))
+    assert torch.equal(got.cpu(), want)
+    got = ops.bias_mask_rows_(v.to(DEV).clone(), b.to(DEV), None)
+    assert torch.equal(got.cpu(), v + b[:, None, :])
