@@ -277,6 +277,70 @@ __global__ __launch_bounds__(256) void level_geometry(const MaskT* __restrict__ 
   }
 }
 
+
+// ---- input projection epilogue: conv bias + GroupNorm(32) + flatten(2).transpose(1, 2) + cat over the levels -----------
+// (model/deformable_detr.py:2209-2262: nn.Sequential(Conv2d, GroupNorm) per level, then source.flatten(2).transpose(1, 2)
+// and torch.cat).  x_l is the bias-free convolution output [B, C, H_l, W_l]; out is [B, S, C].
+struct GnLevels {
+  const float* x[4];
+  const float* conv_bias[4];
+  const float* gamma[4];
+  const float* beta[4];
+  int hw[4], start[4], tile0[4];
+};
+
+// stats[(l * B + b) * G + g] = (mean, rstd) of (x + conv_bias) over the C/G channels x H_l W_l pixels of one group
+__global__ __launch_bounds__(256) void gn_stats_levels(GnLevels P, int C, int G, float eps, float2* __restrict__ stats) {
+  __shared__ float s_red[8];
+  const int g = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
+  const int cpg = C / G, hw = P.hw[l];
+  const long long n = (long long)cpg * hw;
+  const float* x = P.x[l] + ((size_t)b * C + (size_t)g * cpg) * hw;  // the group's channels are contiguous in NCHW
+  const float* cb = P.conv_bias[l] + g * cpg;
+  auto block_sum = [&](float v) -> float {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  };
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) acc += x[i] + cb[i / hw];
+  const float mean = block_sum(acc) / (float)n;
+  acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const float d = x[i] + cb[i / hw] - mean;
+    acc += d * d;
+  }
+  const float var = block_sum(acc) / (float)n;  // biased, as nn.GroupNorm
+  if (threadIdx.x == 0) stats[((size_t)l * gridDim.y + b) * G + g] = make_float2(mean, rsqrtf(var + eps));
+}
+
+// one workgroup = 32 pixels of one level x all C = 256 channels: coalesced NCHW reads (lanes along the pixels), LDS
+// transpose, coalesced [.., C] writes (lanes along the channels)
+__global__ __launch_bounds__(256) void gn_apply_flatten(GnLevels P, int L, int C, int G, int S, const float2* __restrict__ stats,
+                                                        float* __restrict__ out) {
+  __shared__ float s_t[32][257];
+  const int b = blockIdx.y;
+  int l = 0;
+  while (l + 1 < L && (int)blockIdx.x >= P.tile0[l + 1]) ++l;
+  const int p0 = ((int)blockIdx.x - P.tile0[l]) * 32, hw = P.hw[l];
+  const int cpg = C / G;
+  const int px = threadIdx.x & 31, cs = threadIdx.x >> 5;  // 8 channel sub-lanes
+  const float* x = P.x[l] + (size_t)b * C * hw;
+  for (int c = cs; c < C; c += 8) {
+    const float2 st = stats[((size_t)l * gridDim.y + b) * G + c / cpg];
+    float v = 0.f;
+    if (p0 + px < hw) v = (x[(size_t)c * hw + p0 + px] + P.conv_bias[l][c] - st.x) * st.y * P.gamma[l][c] + P.beta[l][c];
+    s_t[px][c] = v;
+  }
+  __syncthreads();
+  for (int p = 0; p < 32; ++p) {
+    if (p0 + p >= hw) break;
+    out[((size_t)b * S + P.start[l] + p0 + p) * C + threadIdx.x] = s_t[p][threadIdx.x];
+  }
+}
+
 }  // namespace
 
 extern "C" int egtr_sine_pos_embed_f32(egtr_stream_t stream, const float* y_embed, const float* x_embed,
@@ -323,6 +387,40 @@ extern "C" int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_m
     hipLaunchKernelGGL(level_geometry<unsigned char>, grid, dim3(256), 0, st,
                        static_cast<const unsigned char*>(pixel_mask), dim_t, level_embed, ld, num_levels, S, height,
                        width, embed_dim, scale, eps, mask_flat, pos_flat, valid_ratios, ref_points);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, const float* const* x,
+                                                     const float* const* conv_bias, const float* const* gamma,
+                                                     const float* const* beta, const int* level_hw, int batch,
+                                                     int channels, int num_groups, float eps, float* stats,
+                                                     float* out) {
+  if (!x || !conv_bias || !gamma || !beta || !level_hw || !stats || !out) return EGTR_E_ARG;
+  if (num_levels < 1 || num_levels > 4 || batch <= 0 || num_groups <= 0) return EGTR_E_ARG;
+  if (channels != 256 || channels % num_groups != 0) return EGTR_E_UNSUPPORTED;
+  GnLevels P;
+  int S = 0, tiles = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int s = l < num_levels ? l : 0;
+    if (!x[s] || !conv_bias[s] || !gamma[s] || !beta[s] || level_hw[2 * s] <= 0 || level_hw[2 * s + 1] <= 0)
+      return EGTR_E_ARG;
+    P.x[l] = x[s];
+    P.conv_bias[l] = conv_bias[s];
+    P.gamma[l] = gamma[s];
+    P.beta[l] = beta[s];
+    P.hw[l] = level_hw[2 * s] * level_hw[2 * s + 1];
+    P.start[l] = S;
+    P.tile0[l] = tiles;
+    if (l < num_levels) {
+      S += P.hw[l];
+      tiles += (P.hw[l] + 31) / 32;
+    }
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_stats_levels, dim3(num_groups, batch, num_levels), dim3(256), 0, st, P, channels, num_groups, eps,
+                     reinterpret_cast<float2*>(stats));
+  hipLaunchKernelGGL(gn_apply_flatten, dim3(tiles, batch), dim3(256), 0, st, P, num_levels, channels, num_groups, S,
+                     reinterpret_cast<const float2*>(stats), out);
   return egtr_check_launch();
 }
 

@@ -48,7 +48,8 @@ template <bool FUSED>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
-    int Lq, int S, int L, int P, int nblk, const float* __restrict__ ref, float* __restrict__ attn_out) {
+    int Lq, int S, int L, int P, int nblk, const float* __restrict__ ref, float* __restrict__ attn_out, int ld_off,
+    int ld_logit, const unsigned char* __restrict__ keep) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * kWaveEntries];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -61,8 +62,9 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
   const char* vbase = reinterpret_cast<const char*>(value) + (size_t)b * S * (256 * 4);
 
   // stage 1: lane i -> head i>>3, samples 2*(i&7), 2*(i&7)+1
-  float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
-  float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
+  // FUSED: offsets / logits may be column blocks of one wider Linear output (row strides ld_off / ld_logit floats)
+  float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * (FUSED ? ld_off : 256))[lane];
+  float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * (FUSED ? ld_logit : 128))[lane];
   const int head_s = lane >> 3, s0 = (lane & 7) * 2;
   if (FUSED) {
     const int lvl = s0 / P;  // both samples of the lane lie in one level (P is even)
@@ -91,9 +93,19 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     const SampleGeom g = sample_geom<1024, 128>(j ? lc.z : lc.x, j ? lc.w : lc.y, SEL_H(G, lvl), SEL_W(G, lvl),
                                                 SEL_S(G, lvl), head_s);
     const float a = j ? aw.y : aw.x;
+    bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
+    if (FUSED && keep != nullptr) {
+      // padded tokens contribute nothing (deformable_detr.py:1050-1052 zeroes their value rows; zeroing their
+      // weights is the same sum and saves a pass over the value tensor)
+      const unsigned char* kp = keep + (size_t)b * S;
+      k0 = k0 && kp[g.off[0] >> 10];
+      k1 = k1 && kp[g.off[1] >> 10];
+      k2 = k2 && kp[g.off[2] >> 10];
+      k3 = k3 && kp[g.off[3] >> 10];
+    }
     my_off[head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
-    my_w[head_s * kHeadStride + s] = make_float4(g.ok[0] ? g.w[0] * a : 0.f, g.ok[1] ? g.w[1] * a : 0.f,
-                                                 g.ok[2] ? g.w[2] * a : 0.f, g.ok[3] ? g.w[3] * a : 0.f);
+    my_w[head_s * kHeadStride + s] = make_float4(k0 ? g.w[0] * a : 0.f, k1 ? g.w[1] * a : 0.f,
+                                                 k2 ? g.w[2] * a : 0.f, k3 ? g.w[3] * a : 0.f);
   }
   // LDS ops of one wave execute in order; the fences only stop the compiler from reordering across lanes.
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -479,7 +491,8 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(msda_fwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
-                       num_levels, num_point, nblk, (const float*)nullptr, (float*)nullptr);
+                       num_levels, num_point, nblk, (const float*)nullptr, (float*)nullptr, 256, 128,
+                       (const unsigned char*)nullptr);
   } else {
     const long long n = nq * num_heads * channels;
     const int threads = 256;
@@ -508,19 +521,22 @@ extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* va
                                            const int64_t* level_start_index, const float* sampling_offsets,
                                            const float* attn_logits, const float* reference_points, int batch,
                                            int spatial_size, int num_heads, int channels, int num_levels,
-                                           int num_query, int num_point, float* out, float* attn_weight_out) {
+                                           int num_query, int num_point, float* out, float* attn_weight_out,
+                                           int ld_offsets, int ld_logits, const unsigned char* keep_mask) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
       !out)
     return EGTR_E_ARG;
   if (batch <= 0 || spatial_size <= 0 || num_query <= 0) return EGTR_E_ARG;
   const long long nq = (long long)batch * num_query;
+  if (ld_offsets < 256 || ld_logits < 128 || (ld_offsets & 3) || (ld_logits & 1)) return EGTR_E_ARG;
   if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
       (long long)spatial_size * 1024 >= (1ll << 31) || nq >= (1ll << 27))
     return EGTR_E_UNSUPPORTED;
   const int nblk = (int)((nq + kWaves - 1) / kWaves);
   hipLaunchKernelGGL(msda_fwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
                      spatial_shapes, level_start_index, sampling_offsets, attn_logits, out, (int)nq, num_query,
-                     spatial_size, num_levels, num_point, nblk, reference_points, attn_weight_out);
+                     spatial_size, num_levels, num_point, nblk, reference_points, attn_weight_out, ld_offsets,
+                     ld_logits, keep_mask);
   return egtr_check_launch();
 }
 

@@ -361,18 +361,29 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         if total != sequence_length:
             raise ValueError("Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
 
+        fast = ops.inference_fast_path(hidden_states)
+        value_is_masked = True
         if precomputed_value is not None:
             value = precomputed_value
         else:
             value = ops.module_linear(self.value_proj, encoder_hidden_states)
-            if attention_mask is not None:
-                # dd:1052 `value.masked_fill(~mask[..., None], 0)` as one select (no mask inversion, no clone)
-                value = torch.where(attention_mask[..., None], value, _zero_scalar(value))
-        value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
-        if ops.inference_fast_path(hidden_states) and batch_size * num_queries <= ops.SKINNY_MAX_ROWS:
+            value_is_masked = attention_mask is None
+        if fast and batch_size * num_queries <= ops.SKINNY_MAX_ROWS:
             sampling_offsets, attention_weights = ops.linear_grouped([
                 dict(x=hidden_states, w=self.sampling_offsets.weight, b=self.sampling_offsets.bias),
                 dict(x=hidden_states, w=self.attention_weights.weight, b=self.attention_weights.bias)])
+        elif fast:
+            # token-sized input: both Linears read the same rows -> one vendor GEMM over the concatenated weights; the
+            # kernel below reads the two column blocks in place (row stride = 3 * M * L * P)
+            w_cat, b_cat = ops.cached_weights(
+                ("msda_offsets_weights", id(self)),
+                [self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
+                 self.attention_weights.bias],
+                lambda: (torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
+                         torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous()))
+            both = F.linear(hidden_states, w_cat, b_cat)
+            n_off = self.sampling_offsets.weight.shape[0]
+            sampling_offsets, attention_weights = both[..., :n_off], both[..., n_off:]
         else:
             sampling_offsets = ops.module_linear(self.sampling_offsets, hidden_states)
             attention_weights = ops.module_linear(self.attention_weights, hidden_states)
@@ -385,11 +396,18 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                                                   or attention_weights.requires_grad or reference_points.requires_grad)
         if (not needs_grad and value.is_cuda and reference_points.shape[-1] == 2 and value.dtype == torch.float32
                 and ops.msda_fused_supported(self.n_heads, self.d_model // self.n_heads, self.n_levels, self.n_points)):
-            # inference: softmax + sampling locations (dd:1055-1073) are formed inside the HIP kernel
+            # inference: softmax + sampling locations (dd:1055-1073) are formed inside the HIP kernel, which also
+            # skips padded tokens (== the zeroed value rows of dd:1052) when the values were not masked above
+            value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
             output, attention_weights = ops.msda_forward_fused(
                 value.contiguous(), spatial_shapes, level_start_index, sampling_offsets, attention_weights,
-                reference_points.contiguous(), want_weights=output_attentions)
+                reference_points.contiguous(), want_weights=output_attentions,
+                keep_mask=None if value_is_masked else attention_mask)
         else:
+            if not value_is_masked:
+                # dd:1052 `value.masked_fill(~mask[..., None], 0)` as one select (no mask inversion, no clone)
+                value = torch.where(attention_mask[..., None], value, _zero_scalar(value))
+            value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
             attention_weights = F.softmax(attention_weights, -1).view(
                 batch_size, num_queries, self.n_heads, self.n_levels, self.n_points)
             if reference_points.shape[-1] == 2:
@@ -875,11 +893,25 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                 feature_maps = conv_encoder.model(pixel_values)
             else:  # a user-supplied feature extractor: keep its (feature, mask) interface, drop its masks
                 feature_maps = [fm for fm, _ in conv_encoder(pixel_values, pixel_mask)]
-            sources = [self.input_proj[level](fm) for level, fm in enumerate(feature_maps)]
-            for level in range(len(sources), self.config.num_feature_levels):  # dd:2228-2241
-                sources.append(self.input_proj[level](feature_maps[-1] if level == len(feature_maps) else sources[-1]))
-            spatial_shapes_list = [tuple(src.shape[-2:]) for src in sources]
-            source_flatten = torch.cat([src.flatten(2).transpose(1, 2) for src in sources], 1)
+            n_extra = self.config.num_feature_levels - len(feature_maps)
+            if (n_extra <= 1 and self.config.d_model == 256 and feature_maps[0].dtype == torch.float32
+                    and all(isinstance(p[1], nn.GroupNorm) and p[0].bias is not None for p in self.input_proj)):
+                # input projections: bias-free convolutions, then conv bias + GroupNorm + flatten + transpose + cat
+                # of all levels in two HIP launches
+                convs = [F.conv2d(fm, self.input_proj[level][0].weight, None, self.input_proj[level][0].stride,
+                                  self.input_proj[level][0].padding) for level, fm in enumerate(feature_maps)]
+                if n_extra == 1:  # dd:2228-2241: the extra level is a strided 3x3 convolution of the last feature map
+                    c = self.input_proj[len(feature_maps)][0]
+                    convs.append(F.conv2d(feature_maps[-1], c.weight, None, c.stride, c.padding))
+                spatial_shapes_list = [tuple(cv.shape[-2:]) for cv in convs]
+                source_flatten = ops.input_proj_groupnorm_flatten(convs, self.input_proj)
+            else:
+                sources = [self.input_proj[level](fm) for level, fm in enumerate(feature_maps)]
+                for level in range(len(sources), self.config.num_feature_levels):  # dd:2228-2241
+                    sources.append(self.input_proj[level](feature_maps[-1] if level == len(feature_maps)
+                                                          else sources[-1]))
+                spatial_shapes_list = [tuple(src.shape[-2:]) for src in sources]
+                source_flatten = torch.cat([src.flatten(2).transpose(1, 2) for src in sources], 1)
             mask_flatten, lvl_pos_embed_flatten, valid_ratios, encoder_reference_points = ops.level_geometry(
                 pixel_mask, spatial_shapes_list, self.level_embed, pos_mod.embedding_dim, pos_mod.temperature,
                 pos_mod.scale)
@@ -940,6 +972,9 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
 
         batch_size, _, num_channels = encoder_outputs[0].shape
         query_embed, target = torch.split(query_embeds, num_channels, dim=1)  # dd:2339
+        if ops.inference_fast_path(query_embeds):
+            # column slices of the [N, 2d] table: made dense once here instead of once per consumer kernel
+            query_embed, target = query_embed.contiguous(), target.contiguous()
         query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)
         target = target.unsqueeze(0).expand(batch_size, -1, -1)
         reference_points = ops.module_linear(self.reference_points, query_embed).sigmoid()

@@ -63,28 +63,46 @@ class _MultiScaleDeformableAttention:
 
     @staticmethod
     def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                     reference_points, want_weights=False):
+                                     reference_points, want_weights=False, keep_mask=None):
         """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` computed in the kernel
         (deformable_detr.py:1055-1073, 2-d reference points).  fp32, M = 8, D = 32, L*P = 16; no autograd.
+        sampling_offsets [B,Lq,M,L,P,2] / attn_logits [B,Lq,M,L*P] may be column blocks of one wider Linear output
+        (any row stride, unit inner strides); keep_mask [B,S] bool: padded tokens are skipped (== zeroed value rows).
         Returns (out [B,Lq,M*D], attention weights [B,Lq,M,L,P] or None)."""
         lib = _lib.lib()
         B, S, M, D = value.shape
         L = spatial_shapes.shape[0]
         Lq, P = sampling_offsets.shape[1], sampling_offsets.shape[4]
-        for t, n in ((value, "value"), (sampling_offsets, "sampling_offsets"), (attn_logits, "attn_logits"),
-                     (reference_points, "reference_points")):
+        for t, n in ((value, "value"), (reference_points, "reference_points")):
             _chk(t, n, torch.float32)
         _chk(spatial_shapes, "spatial_shapes", torch.int64)
         _chk(level_start_index, "level_start_index", torch.int64)
         if tuple(reference_points.shape) != (B, Lq, L, 2):
             raise RuntimeError(f"ms_deform_attn_forward_fused: reference_points must be [B, Lq, L, 2], "
                                f"got {tuple(reference_points.shape)}")
+
+        def rows(t, width, name):  # [B, Lq, width...] -> row stride in floats (dense inner dims, uniform row stride)
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError(f"{name} must be a float32 CUDA/HIP tensor")
+            t2 = t.reshape(B, Lq, width) if t.is_contiguous() else t.flatten(2)
+            if t2.stride(2) != 1 or (B > 1 and t2.stride(0) != Lq * t2.stride(1)):
+                t2 = t2.contiguous()
+            return t2, t2.stride(1)
+
+        off2, ld_off = rows(sampling_offsets, M * L * P * 2, "sampling_offsets")
+        log2, ld_log = rows(attn_logits, M * L * P, "attn_logits")
+        km = None
+        if keep_mask is not None:
+            km = keep_mask.reshape(B, S).contiguous()
+            km = km.view(torch.uint8) if km.dtype == torch.bool else km.to(torch.uint8)
+            _chk(km, "keep_mask")
         out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
         wts = torch.empty(B, Lq, M, L, P, dtype=value.dtype, device=value.device) if want_weights else None
         st = lib.egtr_msda_forward_fused_f32(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
-                                             level_start_index.data_ptr(), sampling_offsets.data_ptr(),
-                                             attn_logits.data_ptr(), reference_points.data_ptr(), B, S, M, D, L, Lq, P,
-                                             out.data_ptr(), wts.data_ptr() if want_weights else None)
+                                             level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
+                                             reference_points.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(),
+                                             wts.data_ptr() if want_weights else None, ld_off, ld_log,
+                                             km.data_ptr() if km is not None else None)
         _lib.check(st, "ms_deform_attn_forward_fused")
         return out, wts
 

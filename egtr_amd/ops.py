@@ -49,13 +49,12 @@ def msda_fused_supported(num_heads, channels, num_levels, num_points):
 
 
 def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
-                       want_weights=False):
+                       want_weights=False, keep_mask=None):
     """MSDA forward with its softmax / sampling-location prologue fused in (no autograd: inference path)."""
     from .load_custom import load_hip_kernels
     k = load_hip_kernels()
-    B, Lq, M, LP = attn_logits.shape
-    return k.ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets.contiguous(),
-                                          attn_logits.contiguous(), reference_points, want_weights)
+    return k.ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                          reference_points, want_weights, keep_mask)
 
 
 class DecoderSelfAttentionFunction(Function):
@@ -299,6 +298,37 @@ def sine_position_embedding(pixel_mask, embedding_dim, temperature, scale, eps=1
     st = lib.egtr_sine_pos_embed_f32(_stream(), y_embed.data_ptr(), x_embed.data_ptr(), dim_t.data_ptr(),
                                      out.data_ptr(), B, H, W_, embedding_dim, float(scale), float(eps))
     _lib.check(st, "egtr_sine_pos_embed_f32")
+    return out
+
+
+def input_proj_groupnorm_flatten(conv_outputs, input_projs):
+    """Conv bias + GroupNorm + flatten(2).transpose(1, 2) + cat over the levels (dd:2209-2262) in two HIP launches.
+    ``conv_outputs[l]``: bias-free output [B,256,H_l,W_l] of ``input_projs[l][0]``; ``input_projs[l]`` = Sequential(
+    Conv2d, GroupNorm).  Returns [B, S, 256].  Inference only."""
+    import ctypes
+    lib = _lib.lib()
+    L = len(conv_outputs)
+    B, C = conv_outputs[0].shape[:2]
+    gn0 = input_projs[0][1]
+    xs = [_chk(x.contiguous(), "conv output", torch.float32) for x in conv_outputs]
+    keep = []
+    for proj in input_projs[:L]:
+        conv, gn = proj[0], proj[1]
+        if gn.num_groups != gn0.num_groups or gn.eps != gn0.eps or conv.bias is None:
+            raise ValueError("input_proj_groupnorm_flatten: levels must share the GroupNorm configuration")
+        keep.append((_chk(conv.bias.detach().contiguous(), "conv bias", torch.float32),
+                     _chk(gn.weight.detach().contiguous(), "gn weight", torch.float32),
+                     _chk(gn.bias.detach().contiguous(), "gn bias", torch.float32)))
+    hw = [int(v) for x in xs for v in x.shape[-2:]]
+    S = sum(h * w for h, w in zip(hw[0::2], hw[1::2]))
+    out = torch.empty(B, S, C, dtype=torch.float32, device=xs[0].device)
+    stats = torch.empty(L * B * gn0.num_groups * 2, dtype=torch.float32, device=xs[0].device)
+    PA, IA = ctypes.c_void_p * L, ctypes.c_int * (2 * L)
+    st = lib.egtr_input_proj_groupnorm_flatten_f32(
+        _stream(), L, PA(*[x.data_ptr() for x in xs]), PA(*[k[0].data_ptr() for k in keep]),
+        PA(*[k[1].data_ptr() for k in keep]), PA(*[k[2].data_ptr() for k in keep]), IA(*hw), B, C, gn0.num_groups,
+        float(gn0.eps), stats.data_ptr(), out.data_ptr())
+    _lib.check(st, "egtr_input_proj_groupnorm_flatten_f32")
     return out
 
 

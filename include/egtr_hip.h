@@ -60,13 +60,17 @@ int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_
  * (model/deformable_detr.py:1055-1073, 2-d reference points): sampling_offsets [B,Lq,M,L,P,2] and attn_logits
  * [B,Lq,M,L*P] are the raw outputs of the two Linear layers, reference_points is [B,Lq,L,2]; the kernel forms
  * loc = ref + offset / (W_l, H_l) and softmax(logits) itself.  attn_weight_out (optional, [B,Lq,M,L*P]) receives the
- * softmaxed weights.  Only M = 8, D = 32, L*P = 16, P even; EGTR_E_UNSUPPORTED otherwise (compose the prologue on the
- * host and call egtr_msda_forward_f32). */
+ * softmaxed weights.  ld_offsets / ld_logits: floats between consecutive queries (256 / 128 when dense; larger when
+ * the two are column blocks of one wider Linear output).  keep_mask (optional, [B,S] bytes, non-zero = valid token):
+ * padded tokens are skipped in the sum, which equals zeroing their value rows (deformable_detr.py:1050-1052).
+ * Only M = 8, D = 32, L*P = 16, P even; EGTR_E_UNSUPPORTED otherwise (compose the prologue on the host and call
+ * egtr_msda_forward_f32). */
 int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                 const int64_t* level_start_index, const float* sampling_offsets,
                                 const float* attn_logits, const float* reference_points, int batch, int spatial_size,
                                 int num_heads, int channels, int num_levels, int num_query, int num_point, float* out,
-                                float* attn_weight_out);
+                                float* attn_weight_out, int ld_offsets, int ld_logits,
+                                const unsigned char* keep_mask);
 
 /* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
  * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
@@ -186,6 +190,16 @@ int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_mask, int ma
                             const float* level_embed, const int* level_hw, int num_levels, int batch, int height,
                             int width, int embed_dim, float scale, float eps, unsigned char* mask_flat,
                             float* pos_flat, float* valid_ratios, float* ref_points);
+
+/* Epilogue of the per-level input projections (model/deformable_detr.py:2209-2262): conv bias + GroupNorm(num_groups)
+ * + flatten(2).transpose(1, 2) + concatenation over the levels, in two launches for all levels.  x[l] is the BIAS-FREE
+ * convolution output [B, 256, H_l, W_l] (NCHW); conv_bias / gamma / beta are per level [256]; level_hw = {H_0, W_0, ...};
+ * the pointer arrays and level_hw are HOST arrays.  stats: device scratch of num_levels*B*num_groups*2 floats;
+ * out: [B, S, 256]. */
+int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, const float* const* x,
+                                          const float* const* conv_bias, const float* const* gamma,
+                                          const float* const* beta, const int* level_hw, int batch, int channels,
+                                          int num_groups, float eps, float* stats, float* out);
 
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):

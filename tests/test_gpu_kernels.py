@@ -666,3 +666,45 @@ def test_add_layer_norm_pos_and_bias_mask_rows():
     assert torch.equal(got.cpu(), want)
     got = ops.bias_mask_rows_(v.to(DEV).clone(), b.to(DEV), None)
     assert torch.equal(got.cpu(), v + b[:, None, :])
+
+
+def test_input_proj_groupnorm_flatten_matches_torch():
+    """Conv bias + GroupNorm(32) + flatten(2).transpose(1, 2) + cat over four levels (dd:2209-2262) in two launches."""
+    import torch.nn as nn
+    from egtr_amd import ops
+    torch.manual_seed(7)
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 3)]
+    projs = nn.ModuleList([nn.Sequential(nn.Conv2d(8, 256, 1), nn.GroupNorm(32, 256)) for _ in shapes])
+    with torch.no_grad():
+        for p in projs:
+            p[0].bias.normal_()
+            p[1].weight.normal_()
+            p[1].bias.normal_()
+    xs = [3.0 * torch.randn(2, 256, h, w) + 1.5 for h, w in shapes]
+    with torch.no_grad():
+        want = torch.cat([p[1](x + p[0].bias.view(1, -1, 1, 1)).flatten(2).transpose(1, 2) for p, x in zip(projs, xs)], 1)
+        got = ops.input_proj_groupnorm_flatten([x.to(DEV) for x in xs], projs.to(DEV))
+    assert got.shape == want.shape
+    assert (got.cpu() - want).abs().max() < 2e-5
+
+
+def test_msda_fused_strided_inputs_and_keep_mask():
+    """Fused entry with offsets / logits as column blocks of one [B, Lq, 384] tensor and an in-kernel padding mask,
+    against masking the value rows on the host."""
+    k = _kernels()
+    g = torch.Generator().manual_seed(12)
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    B, S = 2, sum(h * w for h, w in shapes)
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(B, S, 8, 32, generator=g)
+    both = torch.randn(B, S, 384, generator=g) * 2
+    ref = torch.rand(B, S, 4, 2, generator=g)
+    keep = torch.rand(B, S, generator=g) > 0.25
+    d = [t.to(DEV) for t in (value, shp, lsi, both, ref, keep)]
+    off = d[3][..., :256].view(B, S, 8, 4, 4, 2)
+    logits = d[3][..., 256:].view(B, S, 8, 16)
+    out, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5])
+    vm = torch.where(d[5][..., None, None], d[0], torch.zeros((), device=DEV))
+    want, _ = k.ms_deform_attn_forward_fused(vm, d[1], d[2], off.contiguous(), logits.contiguous(), d[4], False, None)
+    assert (out - want).abs().max().item() < 1e-6
