@@ -289,31 +289,44 @@ struct GnLevels {
   int hw[4], start[4], tile0[4];
 };
 
-// stats[(l * B + b) * G + g] = (mean, rstd) of (x + conv_bias) over the C/G channels x H_l W_l pixels of one group
-__global__ __launch_bounds__(256) void gn_stats_levels(GnLevels P, int C, int G, float eps, float2* __restrict__ stats) {
-  __shared__ float s_red[8];
+// stats[(l * B + b) * G + g] = (mean, rstd) of (x + conv_bias) over the C/G channels x H_l W_l pixels of one group.
+// One pass: per-thread fp32 partial sums of <= ~100 elements, combined in double (E[x^2] - mean^2 in double).
+__global__ __launch_bounds__(1024) void gn_stats_levels(GnLevels P, int C, int G, float eps, float2* __restrict__ stats) {
+  __shared__ double s_red[2][16];
   const int g = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
   const int cpg = C / G, hw = P.hw[l];
-  const long long n = (long long)cpg * hw;
   const float* x = P.x[l] + ((size_t)b * C + (size_t)g * cpg) * hw;  // the group's channels are contiguous in NCHW
-  const float* cb = P.conv_bias[l] + g * cpg;
-  auto block_sum = [&](float v) -> float {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
-  };
-  float acc = 0.f;
-  for (long long i = threadIdx.x; i < n; i += 256) acc += x[i] + cb[i / hw];
-  const float mean = block_sum(acc) / (float)n;
-  acc = 0.f;
-  for (long long i = threadIdx.x; i < n; i += 256) {
-    const float d = x[i] + cb[i / hw] - mean;
-    acc += d * d;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < cpg; ++c) {
+    const float cb = P.conv_bias[l][g * cpg + c];
+    const float* xc = x + (size_t)c * hw;
+    for (int i = threadIdx.x; i < hw; i += 1024) {
+      const float v = xc[i] + cb;
+      s1 += v;
+      s2 += v * v;
+    }
   }
-  const float var = block_sum(acc) / (float)n;  // biased, as nn.GroupNorm
-  if (threadIdx.x == 0) stats[((size_t)l * gridDim.y + b) * G + g] = make_float2(mean, rsqrtf(var + eps));
+  double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    d1 += __shfl_xor(d1, o);
+    d2 += __shfl_xor(d2, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_red[0][threadIdx.x >> 6] = d1;
+    s_red[1][threadIdx.x >> 6] = d2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      t1 += s_red[0][w];
+      t2 += s_red[1][w];
+    }
+    const double n = (double)cpg * hw, mean = t1 / n;
+    const double var = fmax(t2 / n - mean * mean, 0.0);  // biased, as nn.GroupNorm
+    stats[((size_t)l * gridDim.y + b) * G + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+  }
 }
 
 // one workgroup = 32 pixels of one level x all C = 256 channels: coalesced NCHW reads (lanes along the pixels), LDS
@@ -417,7 +430,7 @@ extern "C" int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int n
     }
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_stats_levels, dim3(num_groups, batch, num_levels), dim3(256), 0, st, P, channels, num_groups, eps,
+  hipLaunchKernelGGL(gn_stats_levels, dim3(num_groups, batch, num_levels), dim3(1024), 0, st, P, channels, num_groups, eps,
                      reinterpret_cast<float2*>(stats));
   hipLaunchKernelGGL(gn_apply_flatten, dim3(tiles, batch), dim3(256), 0, st, P, num_levels, channels, num_groups, S,
                      reinterpret_cast<const float2*>(stats), out);
