@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (bounded sample)")
     ap.add_argument("--graph", type=int, default=1, help="replay the forward from a HIP graph (0 = eager launches)")
+    ap.add_argument("--tune-gemm", type=int, default=1,
+                    help="1 = PyTorch TunableOp picks the fastest rocBLAS / hipBLASLt solution per GEMM shape during "
+                         "warm-up (egtr_amd.runtime.enable_gemm_tuning)")
     ap.add_argument("--miopen-find", type=int, default=0,
                     help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find for the backbone convolutions)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
@@ -234,6 +237,9 @@ def main():
     args = ap.parse_args()
     if args.miopen_find:
         torch.backends.cudnn.benchmark = True
+    if args.tune_gemm:
+        from egtr_amd.runtime import enable_gemm_tuning
+        enable_gemm_tuning()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -301,7 +307,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "VG inference: ResNet-50, N=200, 6 enc/6 dec, 150 classes, 50 predicates, "
                                f"600x1000, bs={args.batch}/GPU fp32 (BASELINE configs[1])",
-                   "images_per_step_per_gpu": args.batch, "hip_graph": bool(args.graph) and fwd.graphed,
+                   "images_per_step_per_gpu": args.batch, "hip_graph": bool(args.graph) and fwd.graphed, "gemm_tuning": bool(args.tune_gemm),
                    "parallelism": f"replicas x{world} (independent images, no collective)"},
         "roofline": {"bound": "hbm", "kernel": "msda_fwd_q64_f32%s (encoder layer, Lq = S = 12537)" % ("<fused softmax + sampling locations>" if probe.fused else ""),
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -19,7 +19,7 @@ SIGNATURES = {
     "egtr_status_string": [_I],
     "egtr_last_hip_error": [],
     "egtr_msda_forward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "egtr_msda_forward_fused_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P],
+    "egtr_msda_forward_fused_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "egtr_msda_forward_f32_variant": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I],
     "egtr_msda_tile_phase_cycles": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "egtr_msda_lane_phase_cycles": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
@@ -36,7 +36,7 @@ SIGNATURES = {
     "egtr_add_layernorm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
     "egtr_sine_pos_embed_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float],
     "egtr_level_geometry_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P,
-                                _P],
+                                _P, _P],
     "egtr_input_proj_groupnorm_flatten_f32": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
 }

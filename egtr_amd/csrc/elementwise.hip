@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void level_geometry(const MaskT* __restrict__ 
                                                       const float* __restrict__ level_embed, LevelDims ld, int L, int S,
                                                       int Hin, int Win, int E, float scale, float eps,
                                                       unsigned char* __restrict__ mask_flat, float* __restrict__ pos_flat,
-                                                      float* __restrict__ valid_ratios, float* __restrict__ ref_points) {
+                                                      float* __restrict__ valid_ratios, float* __restrict__ ref_points,
+                                                      unsigned* __restrict__ mask_bits) {
   constexpr int TP = 32;
   __shared__ int s_cnt[8];          // [level][row-0 count, column-0 count]
   __shared__ float s_vr[8];         // valid ratios of this image [level][x, y]
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void level_geometry(const MaskT* __restrict__ 
     if (s < S) {
       const int l = s_pix[p][0];
       if (k == 0) mask_flat[(size_t)b * S + s] = (unsigned char)s_pix[p][5];
+
       if (k < 2 * L) {
         const int rel = s - ld.start[l];
         const int y = rel / ld.W[l], x = rel - y * ld.W[l];
@@ -259,6 +261,11 @@ __global__ __launch_bounds__(256) void level_geometry(const MaskT* __restrict__ 
         ref_points[(((size_t)b * S + s) * L + lt) * 2 + ax] = base * s_vr[2 * lt + ax];
       }
     }
+  }
+  if (tid == 0 && mask_bits != nullptr) {  // the workgroup's 32 tokens are exactly one word of the bit mask
+    unsigned w = 0;
+    for (int p = 0; p < TP && s0 + p < S; ++p) w |= s_pix[p][5] ? (1u << p) : 0u;
+    mask_bits[(size_t)b * ((S + 31) >> 5) + blockIdx.x] = w;
   }
   // position embedding: thread c -> channel c (c < E: y half, else x half; even index -> sin, odd -> cos)
   for (int c = tid; c < 2 * E; c += 256) {
@@ -372,7 +379,7 @@ extern "C" int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_m
                                        const float* dim_t, const float* level_embed, const int* level_hw,
                                        int num_levels, int batch, int height, int width, int embed_dim, float scale,
                                        float eps, unsigned char* mask_flat, float* pos_flat, float* valid_ratios,
-                                       float* ref_points) {
+                                       float* ref_points, unsigned* mask_bits) {
   if (!pixel_mask || !dim_t || !level_embed || !level_hw || !mask_flat || !pos_flat || !valid_ratios || !ref_points)
     return EGTR_E_ARG;
   if (num_levels < 1 || num_levels > 4 || batch <= 0 || height <= 0 || width <= 0 || embed_dim <= 0)
@@ -395,11 +402,11 @@ extern "C" int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_m
   if (mask_elem_size == 8)
     hipLaunchKernelGGL(level_geometry<long long>, grid, dim3(256), 0, st, static_cast<const long long*>(pixel_mask),
                        dim_t, level_embed, ld, num_levels, S, height, width, embed_dim, scale, eps, mask_flat, pos_flat,
-                       valid_ratios, ref_points);
+                       valid_ratios, ref_points, mask_bits);
   else
     hipLaunchKernelGGL(level_geometry<unsigned char>, grid, dim3(256), 0, st,
                        static_cast<const unsigned char*>(pixel_mask), dim_t, level_embed, ld, num_levels, S, height,
-                       width, embed_dim, scale, eps, mask_flat, pos_flat, valid_ratios, ref_points);
+                       width, embed_dim, scale, eps, mask_flat, pos_flat, valid_ratios, ref_points, mask_bits);
   return egtr_check_launch();
 }
 

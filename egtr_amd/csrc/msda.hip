@@ -33,6 +33,7 @@ using namespace egtr_msda;
 
 // LDS record layout: [wave][head][sample] 16-byte entries, head stride padded by one entry so that the four
 // heads served together by one ds_read_b128 lane group land on distinct banks (MI355X_MICROARCH.md, LDS).
+constexpr int kMaxBitWords = 1024;              // padding-mask bits kept in LDS by the fused forward (S <= 32768)
 constexpr int kHeadStride = 17;                 // entries (16 samples + 1 pad)
 constexpr int kWaveEntries = 8 * kHeadStride;   // per array per wave
 
@@ -49,12 +50,22 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
     int Lq, int S, int L, int P, int nblk, const float* __restrict__ ref, float* __restrict__ attn_out, int ld_off,
-    int ld_logit, const unsigned char* __restrict__ keep) {
+    int ld_logit, const unsigned char* __restrict__ keep, const unsigned* __restrict__ keep_bits) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * kWaveEntries];
+  __shared__ unsigned s_bits[FUSED ? kMaxBitWords : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = xcd_remap(blockIdx.x, nblk);
   const int q = blk * kWaves + wave;
+  const int nwords = (S + 31) >> 5;
+  bool bits_in_lds = false;
+  if (FUSED && keep_bits != nullptr && nwords <= kMaxBitWords) {
+    // padding mask of the image of this workgroup's first query, one bit per token (1.5 KB at 600x1000), in LDS
+    const int b0 = min(blk * kWaves, nq_total - 1) / Lq;
+    for (int i = threadIdx.x; i < nwords; i += kWaves * 64) s_bits[i] = keep_bits[(size_t)b0 * nwords + i];
+    __syncthreads();
+    bits_in_lds = q < nq_total && q / Lq == b0;
+  }
   if (q >= nq_total) return;  // wave-uniform; no workgroup barrier below
   LevelGeom G;
   load_geom(shapes, lsi, L, G);
@@ -94,9 +105,23 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
                                                 SEL_S(G, lvl), head_s);
     const float a = j ? aw.y : aw.x;
     bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
-    if (FUSED && keep != nullptr) {
-      // padded tokens contribute nothing (deformable_detr.py:1050-1052 zeroes their value rows; zeroing their
-      // weights is the same sum and saves a pass over the value tensor)
+    // padded tokens contribute nothing (deformable_detr.py:1050-1052 zeroes their value rows; zeroing their weights
+    // is the same sum and saves a pass over the value tensor)
+    if (FUSED && keep_bits != nullptr) {
+      const int p0 = g.off[0] >> 10, p1 = g.off[1] >> 10, p2 = g.off[2] >> 10, p3 = g.off[3] >> 10;
+      if (bits_in_lds) {
+        k0 = k0 && ((s_bits[p0 >> 5] >> (p0 & 31)) & 1u);
+        k1 = k1 && ((s_bits[p1 >> 5] >> (p1 & 31)) & 1u);
+        k2 = k2 && ((s_bits[p2 >> 5] >> (p2 & 31)) & 1u);
+        k3 = k3 && ((s_bits[p3 >> 5] >> (p3 & 31)) & 1u);
+      } else {
+        const unsigned* kb = keep_bits + (size_t)b * nwords;
+        k0 = k0 && ((kb[p0 >> 5] >> (p0 & 31)) & 1u);
+        k1 = k1 && ((kb[p1 >> 5] >> (p1 & 31)) & 1u);
+        k2 = k2 && ((kb[p2 >> 5] >> (p2 & 31)) & 1u);
+        k3 = k3 && ((kb[p3 >> 5] >> (p3 & 31)) & 1u);
+      }
+    } else if (FUSED && keep != nullptr) {
       const unsigned char* kp = keep + (size_t)b * S;
       k0 = k0 && kp[g.off[0] >> 10];
       k1 = k1 && kp[g.off[1] >> 10];
@@ -492,7 +517,7 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
     hipLaunchKernelGGL(msda_fwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
                        num_levels, num_point, nblk, (const float*)nullptr, (float*)nullptr, 256, 128,
-                       (const unsigned char*)nullptr);
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr);
   } else {
     const long long n = nq * num_heads * channels;
     const int threads = 256;
@@ -522,7 +547,8 @@ extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* va
                                            const float* attn_logits, const float* reference_points, int batch,
                                            int spatial_size, int num_heads, int channels, int num_levels,
                                            int num_query, int num_point, float* out, float* attn_weight_out,
-                                           int ld_offsets, int ld_logits, const unsigned char* keep_mask) {
+                                           int ld_offsets, int ld_logits, const unsigned char* keep_mask,
+                                           const unsigned* keep_bits) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
       !out)
     return EGTR_E_ARG;
@@ -536,7 +562,7 @@ extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* va
   hipLaunchKernelGGL(msda_fwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
                      spatial_shapes, level_start_index, sampling_offsets, attn_logits, out, (int)nq, num_query,
                      spatial_size, num_levels, num_point, nblk, reference_points, attn_weight_out, ld_offsets,
-                     ld_logits, keep_mask);
+                     ld_logits, keep_mask, keep_bits);
   return egtr_check_launch();
 }
 

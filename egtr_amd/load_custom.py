@@ -91,18 +91,25 @@ class _MultiScaleDeformableAttention:
 
         off2, ld_off = rows(sampling_offsets, M * L * P * 2, "sampling_offsets")
         log2, ld_log = rows(attn_logits, M * L * P, "attn_logits")
-        km = None
+        km = kbits = None
         if keep_mask is not None:
-            km = keep_mask.reshape(B, S).contiguous()
-            km = km.view(torch.uint8) if km.dtype == torch.bool else km.to(torch.uint8)
-            _chk(km, "keep_mask")
+            # a bit-packed copy written by the level-geometry kernel travels as an attribute of the mask tensor
+            kbits = getattr(keep_mask, "_egtr_bits", None)
+            if kbits is not None and (kbits.dtype != torch.int32 or tuple(kbits.shape) != (B, (S + 31) // 32)
+                                      or not kbits.is_cuda):
+                kbits = None
+            if kbits is None:
+                km = keep_mask.reshape(B, S).contiguous()
+                km = km.view(torch.uint8) if km.dtype == torch.bool else km.to(torch.uint8)
+                _chk(km, "keep_mask")
         out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
         wts = torch.empty(B, Lq, M, L, P, dtype=value.dtype, device=value.device) if want_weights else None
         st = lib.egtr_msda_forward_fused_f32(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
                                              level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
                                              reference_points.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(),
                                              wts.data_ptr() if want_weights else None, ld_off, ld_log,
-                                             km.data_ptr() if km is not None else None)
+                                             km.data_ptr() if km is not None else None,
+                                             kbits.data_ptr() if kbits is not None else None)
         _lib.check(st, "ms_deform_attn_forward_fused")
         return out, wts
 

@@ -358,14 +358,17 @@ def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, 
     S = sum(h * w for h, w in spatial_shapes_list)
     hw = (ctypes.c_int * (2 * L))(*[int(v) for hw_ in spatial_shapes_list for v in hw_])
     mask_u8 = torch.empty(B, S, dtype=torch.uint8, device=dev)
+    bits = torch.empty(B, (S + 31) // 32, dtype=torch.int32, device=dev)
     pos = torch.empty(B, S, 2 * embedding_dim, dtype=torch.float32, device=dev)
     vr = torch.empty(B, L, 2, dtype=torch.float32, device=dev)
     ref = torch.empty(B, S, L, 2, dtype=torch.float32, device=dev)
     st = lib.egtr_level_geometry_f32(_stream(), pm.data_ptr(), pm.element_size(), dim_t.data_ptr(), le.data_ptr(), hw,
                                      L, B, H, W_, embedding_dim, float(scale), float(eps), mask_u8.data_ptr(),
-                                     pos.data_ptr(), vr.data_ptr(), ref.data_ptr())
+                                     pos.data_ptr(), vr.data_ptr(), ref.data_ptr(), bits.data_ptr())
     _lib.check(st, "egtr_level_geometry_f32")
-    return mask_u8.view(torch.bool), pos, vr, ref
+    mask = mask_u8.view(torch.bool)
+    mask._egtr_bits = bits  # one bit per token, consumed by the fused MSDA kernel (kept in LDS there)
+    return mask, pos, vr, ref
 
 
 class AddLayerNormFunction(Function):

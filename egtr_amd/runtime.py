@@ -139,6 +139,25 @@ class DataParallelTrainer:
         return loss.detach(), loss_dict, boundary
 
 
+def enable_gemm_tuning(results_file=None):
+    """Let PyTorch's TunableOp pick, per GEMM shape, the fastest rocBLAS / hipBLASLt solution the first time the shape
+    is seen (the MI355X analogue of the reference's ``torch.backends.cudnn.benchmark``-style autotuning).  The token
+    sized encoder GEMMs (12 537 x 256 x {256, 384, 1024}) gain ~20 % over the libraries' default heuristics.  Call
+    before the first forward; shapes must have been seen eagerly before a HIP-graph capture."""
+    import os
+    import tempfile
+    try:
+        import torch.cuda.tunable as tunable
+    except Exception:  # pragma: no cover - very old torch
+        return False
+    tunable.enable(True)
+    tunable.tuning_enable(True)
+    if results_file is None:
+        results_file = os.path.join(tempfile.gettempdir(), f"egtr_tunableop_{os.getpid()}.csv")
+    tunable.set_filename(results_file, insert_device_ordinal=True)
+    return True
+
+
 @torch.no_grad()
 def calculate_fps(model, batches, warmup=3):
     """evaluate_egtr.py:26-36 with warm-up and synchronisation (the reference's loop has neither)."""

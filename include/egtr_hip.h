@@ -61,8 +61,10 @@ int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_
  * [B,Lq,M,L*P] are the raw outputs of the two Linear layers, reference_points is [B,Lq,L,2]; the kernel forms
  * loc = ref + offset / (W_l, H_l) and softmax(logits) itself.  attn_weight_out (optional, [B,Lq,M,L*P]) receives the
  * softmaxed weights.  ld_offsets / ld_logits: floats between consecutive queries (256 / 128 when dense; larger when
- * the two are column blocks of one wider Linear output).  keep_mask (optional, [B,S] bytes, non-zero = valid token):
- * padded tokens are skipped in the sum, which equals zeroing their value rows (deformable_detr.py:1050-1052).
+ * the two are column blocks of one wider Linear output).  keep_mask (optional, [B,S] bytes, non-zero = valid token)
+ * or keep_bits (optional, [B, ceil(S/32)] words, bit s%32 of word s/32 -- as written by egtr_level_geometry_f32;
+ * takes precedence, kept in LDS): padded tokens are skipped in the sum, which equals zeroing their value rows
+ * (deformable_detr.py:1050-1052).
  * Only M = 8, D = 32, L*P = 16, P even; EGTR_E_UNSUPPORTED otherwise (compose the prologue on the host and call
  * egtr_msda_forward_f32). */
 int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
@@ -70,7 +72,7 @@ int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const 
                                 const float* attn_logits, const float* reference_points, int batch, int spatial_size,
                                 int num_heads, int channels, int num_levels, int num_query, int num_point, float* out,
                                 float* attn_weight_out, int ld_offsets, int ld_logits,
-                                const unsigned char* keep_mask);
+                                const unsigned char* keep_mask, const unsigned* keep_bits);
 
 /* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
  * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
@@ -184,12 +186,13 @@ int egtr_sine_pos_embed_f32(egtr_stream_t stream, const float* y_embed, const fl
  * 850-876), for up to 4 feature levels level_hw = {H_0, W_0, H_1, W_1, ...} (HOST array): nearest-resized masks
  * flattened over the levels (mask_flat [B,S] bytes, 1 = valid), normalised sine position embeddings + level_embed
  * (pos_flat [B,S,2*embed_dim]; dim_t [embed_dim] = temperature^(2*(i/2)/embed_dim), level_embed [L,2*embed_dim]),
- * valid_ratios [B,L,2] and the encoder reference points [B,S,L,2].  pixel_mask is [B,height,width] of int64
+ * valid_ratios [B,L,2] and the encoder reference points [B,S,L,2]; mask_bits (optional, [B, ceil(S/32)] words,
+ * fully overwritten) receives the same mask one bit per token.  pixel_mask is [B,height,width] of int64
  * (mask_elem_size 8) or bytes (1), non-zero = valid. */
 int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size, const float* dim_t,
                             const float* level_embed, const int* level_hw, int num_levels, int batch, int height,
                             int width, int embed_dim, float scale, float eps, unsigned char* mask_flat,
-                            float* pos_flat, float* valid_ratios, float* ref_points);
+                            float* pos_flat, float* valid_ratios, float* ref_points, unsigned* mask_bits);
 
 /* Epilogue of the per-level input projections (model/deformable_detr.py:2209-2262): conv bias + GroupNorm(num_groups)
  * + flatten(2).transpose(1, 2) + concatenation over the levels, in two launches for all levels.  x[l] is the BIAS-FREE

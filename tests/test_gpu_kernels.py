@@ -610,6 +610,10 @@ def test_level_geometry_matches_reference_composition(mask_dtype):
     mask, posf, vrf, ref = ops.level_geometry(pm.to(mask_dtype).to(DEV), shapes, level_embed.to(DEV), 128, 10000,
                                               2 * math.pi)
     assert torch.equal(mask.cpu(), want_mask)
+    bits = mask._egtr_bits.cpu().long() & 0xFFFFFFFF
+    S_ = want_mask.shape[1]
+    unpacked = ((bits[:, torch.arange(S_) // 32] >> (torch.arange(S_) % 32)) & 1).bool()
+    assert torch.equal(unpacked, want_mask)
     assert torch.equal(vrf.cpu(), vr)
     assert (ref.cpu() - want_ref).abs().max() < 1e-6
     valid = want_mask[..., None].expand_as(want_pos)
@@ -708,3 +712,13 @@ def test_msda_fused_strided_inputs_and_keep_mask():
     vm = torch.where(d[5][..., None, None], d[0], torch.zeros((), device=DEV))
     want, _ = k.ms_deform_attn_forward_fused(vm, d[1], d[2], off.contiguous(), logits.contiguous(), d[4], False, None)
     assert (out - want).abs().max().item() < 1e-6
+    # the same mask bit-packed (as the level-geometry kernel hands it over): identical result
+    words = torch.zeros(B, (S + 31) // 32, dtype=torch.int64)
+    idx = torch.arange(S)
+    for bi in range(B):
+        words[bi].index_add_(0, idx // 32, keep[bi].long() << (idx % 32))
+    bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(DEV)
+    km = d[5].clone()
+    km._egtr_bits = bits
+    out_b, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, km)
+    assert torch.equal(out_b, out)
