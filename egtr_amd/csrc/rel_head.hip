@@ -35,6 +35,56 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 
 constexpr int kHd = 256;  // hidden width of both MLPs (= d_model)
+constexpr int kH1Stride = 260;  // LDS row pitch (floats) of the layer-1 transpose: 256 + 4
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int OFF>
+__device__ __forceinline__ f32x4v gload_b128(const float4* p) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait(f32x4v& v) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+// wait for load t of a set whose load 0 has N_T0 newer own loads (one fewer per later t); t is a compile-time constant
+// after unrolling, so the switch folds to a single s_waitcnt
+template <int N_T0>
+__device__ __forceinline__ void vm_wait1(f32x4v& c, int t) {
+#define EGTR_VMW(K) case K: asm volatile("s_waitcnt vmcnt(%1)" : "+v"(c) : "n"(N_T0 - K > 0 ? N_T0 - K : 0)); break;
+  switch (t) {
+    EGTR_VMW(0) EGTR_VMW(1) EGTR_VMW(2) EGTR_VMW(3) EGTR_VMW(4) EGTR_VMW(5) EGTR_VMW(6) EGTR_VMW(7) EGTR_VMW(8)
+    EGTR_VMW(9)
+    default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(c)); break;
+  }
+#undef EGTR_VMW
+}
+
+// Layer-2 inner product of one 32-wide n tile: 32 float4 of the lane's W2 row, each feeding 4 MFMAs, with the row
+// loads running PRE float4 ahead (template recursion = full unroll with compile-time offsets / wait counts).
+template <int PRE>
+struct PrefetchRow {
+  template <int I>
+  static __device__ __forceinline__ void issue(f32x4v (&wq)[PRE], const float4* wrow) {
+    wq[I] = gload_b128<I * 16>(wrow);
+    if constexpr (I + 1 < PRE) issue<I + 1>(wq, wrow);
+  }
+  template <int S4>
+  static __device__ __forceinline__ void run(f32x4v (&wq)[PRE], const float4* wrow, const float (&h1)[128], f32x16& acc) {
+    constexpr int newer = (31 - S4) < (PRE - 1) ? (31 - S4) : (PRE - 1);  // own loads issued after this one
+    vm_wait<newer>(wq[S4 % PRE]);
+    const f32x4v w = wq[S4 % PRE];
+    acc = mfma32(w.x, h1[4 * S4 + 0], acc);
+    acc = mfma32(w.y, h1[4 * S4 + 1], acc);
+    acc = mfma32(w.z, h1[4 * S4 + 2], acc);
+    acc = mfma32(w.w, h1[4 * S4 + 3], acc);
+    if constexpr (S4 + PRE < 32) wq[S4 % PRE] = gload_b128<(S4 + PRE) * 16>(wrow);
+    if constexpr (S4 + 1 < 32) run<S4 + 1>(wq, wrow, h1, acc);
+  }
+};
 
 // T = number of slots (decoder layers + 1), OT = number of 32-wide relation-output tiles (R <= 32*OT).
 template <int T, int OT>
@@ -46,7 +96,11 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
     const float* __restrict__ b3c, const float* __restrict__ triplet, const int64_t* __restrict__ node_cls, int B,
     int N, int R, int C1, float* __restrict__ rel_logits, float* __restrict__ conn_logits,
     float* __restrict__ gate_mean) {
-  __shared__ __attribute__((aligned(16))) float s_out[32 * (32 * OT + 1)];
+  // one buffer, two lives: the layer-1 transpose (read back into registers before layer 2), then the output tile
+  constexpr int kBuf = 16 * kH1Stride > 32 * (32 * OT + 1) ? 16 * kH1Stride : 32 * (32 * OT + 1);
+  __shared__ __attribute__((aligned(16))) float s_buf[kBuf];
+  float* const s_out = s_buf;
+  float* const s_h1 = s_buf;
   __shared__ int s_tb[32];
   const int lane = threadIdx.x, pi = lane & 31, hf = lane >> 5;
   const int mlp = blockIdx.y;  // 0 = relation, 1 = connectivity (wave-uniform)
@@ -76,29 +130,92 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
     }
   }
 
-  // ---- layer 1: h1[s] = relu(b1 + sum_t g[t] (uq[i,t,ch] + uk[j,t,ch])), ch = 256*mlp + 128*hf + s ----------
+  // ---- layer 1: h1[pair][ch] = relu(b1 + sum_t g[pair,t] (uq[i,t,ch] + uk[j,t,ch])), ch in this MLP's 256 ------------
+  // The wave walks its 32 pairs one at a time with lane = channel quad (4 l .. 4 l + 3), so every uq / uk row read is
+  // one contiguous 1 KiB per wave, and the 2T row loads of pair p+1 are in flight while pair p is accumulated (inline
+  // asm: hipcc would sink them back next to their uses).  The result goes through LDS (rows padded to 260 floats:
+  // conflict-free ds_read_b128) into the layout the MFMA wants: lane (pair, half) holds the 128 channels
+  // {128 half + s}.  (First version: lane = pair reading its own rows, 16 B from 64 different lines per instruction,
+  // each used at once -- 45 % of the kernel's time went into waiting for those loads.)
   float h1[128];
   {
-    const int ch0 = mlp * kHd + hf * 128;
-    const float4* pb = reinterpret_cast<const float4*>(b1 + ch0);
-    const float4* pq = reinterpret_cast<const float4*>(uq + qi * T * (2 * kHd) + ch0);
-    const float4* pk = reinterpret_cast<const float4*>(uk + kj * T * (2 * kHd) + ch0);
-#pragma unroll
-    for (int s4 = 0; s4 < 32; ++s4) {
-      float4 acc = pb[s4];
+    const int qrow_l = (int)qi, krow_l = (int)kj;
+    const float4 bias4 = reinterpret_cast<const float4*>(b1 + mlp * kHd)[lane];
+    const float4* uq4 = reinterpret_cast<const float4*>(uq) + mlp * (kHd / 4) + lane;
+    const float4* uk4 = reinterpret_cast<const float4*>(uk) + mlp * (kHd / 4) + lane;
+    constexpr int ROW4 = 2 * kHd / 4;  // float4 per (row, slot)
+    // uq rows change only when the pair index crosses into the next i (at most twice per 32 consecutive pairs): they
+    // are kept in registers and reloaded on change; the uk rows (a new j every pair) are double-buffered.
+    float4 ua[T];
+    f32x4v rc[2][T];
+    int q_cur = -1;
+    auto issue = [&](int set, int pp) {
+      const int kr = __builtin_amdgcn_readlane(krow_l, pp);
+      const float4* pk = uk4 + (size_t)kr * T * ROW4;
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const float4 a = pq[t * (2 * kHd / 4) + s4];
-        const float4 c = pk[t * (2 * kHd / 4) + s4];
-        acc.x += g[t] * (a.x + c.x);
-        acc.y += g[t] * (a.y + c.y);
-        acc.z += g[t] * (a.z + c.z);
-        acc.w += g[t] * (a.w + c.w);
+        if (set == 0) rc[0][t] = gload_b128<0>(pk + t * ROW4);
+        else rc[1][t] = gload_b128<0>(pk + t * ROW4);
       }
-      h1[4 * s4 + 0] = fmaxf(acc.x, 0.f);
-      h1[4 * s4 + 1] = fmaxf(acc.y, 0.f);
-      h1[4 * s4 + 2] = fmaxf(acc.z, 0.f);
-      h1[4 * s4 + 3] = fmaxf(acc.w, 0.f);
+    };
+    auto consume = [&](int set, int pp, int row, bool more) {
+      const int qr = __builtin_amdgcn_readlane(qrow_l, pp);
+      if (qr != q_cur) {  // wave-uniform
+        q_cur = qr;
+        const float4* pq = uq4 + (size_t)qr * T * ROW4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) ua[t] = pq[t * ROW4];
+      }
+      float4 acc = bias4;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        // own loads issued after this one: the rest of this set + (if any) the whole next set
+        if (set == 0) {
+          if (more) { vm_wait1<T + (T - 1)>(rc[0][t], t); } else { vm_wait1<T - 1>(rc[0][t], t); }
+        } else {
+          if (more) { vm_wait1<T + (T - 1)>(rc[1][t], t); } else { vm_wait1<T - 1>(rc[1][t], t); }
+        }
+        const float4 a = ua[t];
+        const f32x4v c = set ? rc[1][t] : rc[0][t];
+        const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[t]), pp));
+        acc.x += gt * (a.x + c.x);
+        acc.y += gt * (a.y + c.y);
+        acc.z += gt * (a.z + c.z);
+        acc.w += gt * (a.w + c.w);
+      }
+      *reinterpret_cast<float4*>(&s_h1[row * kH1Stride + 4 * lane]) =
+          make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+    };
+    // two rounds of 16 pairs: the transpose buffer is 16 rows (16.6 KB), which leaves room for 2 waves per SIMD, so
+    // that one wave's load-bound layer 1 overlaps another wave's MFMA-bound layers 2-3
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int pbase = half * 16;
+      issue(0, pbase);
+#pragma unroll 1
+      for (int pp = 0; pp < 16; pp += 2) {
+        issue(1, pbase + pp + 1);
+        consume(0, pbase + pp, pp, true);
+        if (pp + 2 < 16) issue(0, pbase + pp + 2);
+        consume(1, pbase + pp + 1, pp + 1, pp + 2 < 16);
+      }
+      // LDS ops of one wave execute in order; the fences only stop the compiler from reordering across lanes
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if ((pi >> 4) == half) {
+        const float4* hp = reinterpret_cast<const float4*>(&s_h1[(pi & 15) * kH1Stride + hf * 128]);
+#pragma unroll
+        for (int s4 = 0; s4 < 32; ++s4) {
+          const float4 v = hp[s4];
+          h1[4 * s4 + 0] = v.x;
+          h1[4 * s4 + 1] = v.y;
+          h1[4 * s4 + 2] = v.z;
+          h1[4 * s4 + 3] = v.w;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 
@@ -117,15 +234,15 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // W2 row of this lane, software-pipelined kPre float4 ahead of the MFMAs that consume it: with one wave per SIMD
+    // nothing else hides the L2 latency, and hipcc sinks ordinary loads back to 1-2 in flight (the matrix pipe idled 2/3
+    // of the time).  The loads are inline asm (kept in program order) with hand-counted s_waitcnt; loads return in
+    // order, so compiler-issued loads in between only make these waits more conservative.
     const float4* wrow = reinterpret_cast<const float4*>(w2 + (size_t)(nt * 32 + pi) * kHd + hf * 128);
-#pragma unroll
-    for (int s4 = 0; s4 < 32; ++s4) {
-      const float4 w = wrow[s4];
-      acc = mfma32(w.x, h1[4 * s4 + 0], acc);
-      acc = mfma32(w.y, h1[4 * s4 + 1], acc);
-      acc = mfma32(w.z, h1[4 * s4 + 2], acc);
-      acc = mfma32(w.w, h1[4 * s4 + 3], acc);
-    }
+    constexpr int kPre = 8;
+    f32x4v wq[kPre];
+    PrefetchRow<kPre>::template issue<0>(wq, wrow);
+    PrefetchRow<kPre>::template run<0>(wq, wrow, h1, acc);
     // bias + relu; 4 consecutive n per register quad
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
