@@ -111,12 +111,14 @@ class ResNet50Features(nn.Module):
         self._folded_key = None
 
     def _fold_key(self):
-        return tuple(p._version for p in self.parameters()) + (str(self.conv1.weight.device),)
+        return tuple(p._version for p in self.parameters()) + (str(self.conv1.weight.device), self.conv1.weight.dtype,
+                                                               self.conv1.weight.data_ptr())
 
     def forward(self, x):
         # Inference (no grad, eval, GPU): folded-BN + fused conv/bias/ReLU path; the folded weights are cached and
         # rebuilt if any parameter was modified in place (optimizer step, load_state_dict).
-        if x.is_cuda and not torch.is_grad_enabled() and not self.training:
+        if (x.is_cuda and x.dtype == torch.float32 and self.conv1.weight.dtype == torch.float32
+                and not torch.is_grad_enabled() and not self.training):
             key = self._fold_key()
             if self._folded is None or key != self._folded_key:
                 with torch.no_grad():

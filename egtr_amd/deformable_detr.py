@@ -880,7 +880,9 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             pixel_mask = torch.ones((batch_size, height, width), dtype=torch.long, device=device)
 
         pos_mod = self.backbone.position_embedding
-        fused_geometry = (pixel_mask.is_cuda and isinstance(pos_mod, DeformableDetrSinePositionEmbedding)
+        fused_geometry = (pixel_mask.is_cuda and pixel_values.dtype == torch.float32
+                          and self.level_embed.dtype == torch.float32
+                          and isinstance(pos_mod, DeformableDetrSinePositionEmbedding)
                           and pos_mod.normalize and self.config.num_feature_levels <= 4
                           and not (torch.is_grad_enabled() and self.level_embed.requires_grad))
         query_embeds = self.query_position_embeddings.weight

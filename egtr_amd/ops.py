@@ -27,6 +27,8 @@ class MultiScaleDeformableAttentionFunction(Function):
     def forward(context, value, value_spatial_shapes, value_level_start_index, sampling_locations,
                 attention_weights, im2col_step):
         context.im2col_step = im2col_step
+        if value.dtype == torch.bfloat16:  # bf16 values, fp32 sampling geometry (csrc: msda_fwd_q32_bf16)
+            sampling_locations, attention_weights = sampling_locations.float(), attention_weights.float()
         output = _msda().ms_deform_attn_forward(value, value_spatial_shapes, value_level_start_index,
                                                 sampling_locations, attention_weights, im2col_step)
         context.save_for_backward(value, value_spatial_shapes, value_level_start_index, sampling_locations,
@@ -108,6 +110,10 @@ class DecoderSelfAttentionFunction(Function):
 
 
 def decoder_self_attention(q, k, v, num_heads, want_maps=True):
+    if q.dtype != torch.float32:  # bf16 / fp16 models: the kernel computes in fp32, results go back to the model dtype
+        o, qm, km = DecoderSelfAttentionFunction.apply(q.float().contiguous(), k.float().contiguous(),
+                                                       v.float().contiguous(), num_heads, want_maps)
+        return o.to(q.dtype), (qm.to(q.dtype) if qm is not None else None), (km.to(q.dtype) if km is not None else None)
     return DecoderSelfAttentionFunction.apply(q.contiguous(), k.contiguous(), v.contiguous(), num_heads, want_maps)
 
 
@@ -464,5 +470,11 @@ class RelationHeadFunction(Function):
 
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
                   node_cls=None, want_gate_mean=False):
+    if gate_q.dtype != torch.float32:  # bf16 / fp16 models: fp32 kernel, outputs cast back
+        dt = gate_q.dtype
+        f = [t.float() for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c)]
+        rel, conn, gm = RelationHeadFunction.apply(*f, triplet_dist.float() if triplet_dist is not None else None,
+                                                   node_cls, want_gate_mean)
+        return rel.to(dt), conn.to(dt), gm
     return RelationHeadFunction.apply(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,
                                       triplet_dist, node_cls, want_gate_mean)
