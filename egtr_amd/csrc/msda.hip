@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "msda_common.h"
@@ -481,6 +482,23 @@ int egtr_launch_msda_fwd_lane_f32(hipStream_t st, const float* value, const int6
 int egtr_launch_msda_fwd_res_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
                                  const float* loc, const float* attn, float* out, int B, int Lq, int S, int L, int P);
 
+int egtr_launch_msda_fwd_win_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
+                                 const float* loc, const float* attn, float* out, int B, int Lq, int S, int L, int P,
+                                 int kind, const float* ref, float* attn_out, int ld_off, int ld_logit,
+                                 const unsigned char* keep, const unsigned* keep_bits, unsigned long long* prof);
+
+// A/B switch for benchmarks: EGTR_MSDA_FWD_VARIANT=<n> overrides the automatic choice of the forward kernel
+// (read once; never needed for correctness -- every variant computes the same function).
+constexpr int kAutoEncoderVariant = 1;  // what "automatic" picks for encoder-shaped calls
+
+static int env_fwd_variant() {
+  static const int v = [] {
+    const char* e = getenv("EGTR_MSDA_FWD_VARIANT");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+
 // variant: 0 = automatic (wave-per-query when M = 8, D = 32, L*P = 16, else generic),
 //          1 = wave-per-query, 2 = tile x head with LDS windows, 3 = generic one-thread-per-element.
 extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value,
@@ -496,8 +514,16 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   const long long nq = (long long)batch * num_query;
   const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
-  if (variant == 0) variant = fast ? 1 : 3;  // variant 2 is opt-in until it beats variant 1
-  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 7)) && !fast) return EGTR_E_UNSUPPORTED;
+  if (variant == 0 && fast && env_fwd_variant() > 0) variant = env_fwd_variant();
+  if (variant == 0)
+    variant = !fast ? 3 : ((num_query == spatial_size && num_query >= 1024 && !(num_point & 1)) ? kAutoEncoderVariant : 1);
+  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 10)) && !fast) return EGTR_E_UNSUPPORTED;
+  if (variant >= 8 && variant <= 10) {
+    if (num_point & 1) return EGTR_E_UNSUPPORTED;
+    return egtr_launch_msda_fwd_win_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
+                                        batch, num_query, spatial_size, num_levels, num_point, variant - 8, nullptr,
+                                        nullptr, 256, 128, nullptr, nullptr, nullptr);
+  }
   if (variant == 7)
     return egtr_launch_msda_fwd_res_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
                                         batch, num_query, spatial_size, num_levels, num_point);
@@ -529,6 +555,22 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   return egtr_check_launch();
 }
 
+extern "C" int egtr_msda_win_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                          const int64_t* level_start_index, const float* sampling_loc,
+                                          const float* attn_weight, int batch, int spatial_size, int num_levels,
+                                          int num_query, int num_point, int kind, float* out,
+                                          unsigned long long* cycles) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out || !cycles)
+    return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_query <= 0 || kind < 0 || kind > 2) return EGTR_E_ARG;
+  if (num_levels < 1 || num_levels > 4 || num_levels * num_point != 16 || (num_point & 1) ||
+      (long long)spatial_size * 1024 >= (1ll << 31))
+    return EGTR_E_UNSUPPORTED;
+  return egtr_launch_msda_fwd_win_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
+                                      sampling_loc, attn_weight, out, batch, num_query, spatial_size, num_levels,
+                                      num_point, kind, nullptr, nullptr, 256, 128, nullptr, nullptr, cycles);
+}
+
 extern "C" int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                            const int64_t* level_start_index, const float* sampling_loc,
                                            const float* attn_weight, int batch, int spatial_size, int num_query,
@@ -542,13 +584,14 @@ extern "C" int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* va
                                        sampling_loc, attn_weight, out, batch, num_query, spatial_size, kind, cycles);
 }
 
-extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                           const int64_t* level_start_index, const float* sampling_offsets,
-                                           const float* attn_logits, const float* reference_points, int batch,
-                                           int spatial_size, int num_heads, int channels, int num_levels,
-                                           int num_query, int num_point, float* out, float* attn_weight_out,
-                                           int ld_offsets, int ld_logits, const unsigned char* keep_mask,
-                                           const unsigned* keep_bits) {
+extern "C" int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const float* value,
+                                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                                   const float* sampling_offsets, const float* attn_logits,
+                                                   const float* reference_points, int batch, int spatial_size,
+                                                   int num_heads, int channels, int num_levels, int num_query,
+                                                   int num_point, float* out, float* attn_weight_out, int ld_offsets,
+                                                   int ld_logits, const unsigned char* keep_mask,
+                                                   const unsigned* keep_bits, int variant) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
       !out)
     return EGTR_E_ARG;
@@ -558,12 +601,38 @@ extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* va
   if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
       (long long)spatial_size * 1024 >= (1ll << 31) || nq >= (1ll << 27))
     return EGTR_E_UNSUPPORTED;
+  if (variant != 0 && variant != 1 && (variant < 8 || variant > 10)) return EGTR_E_UNSUPPORTED;
+  if (variant == 0) {
+    // automatic: the LDS-window kernel for encoder-shaped calls (queries = the pixels of the levels), the
+    // wave-per-query kernel for short / arbitrary query lists (decoder)
+    const int e = env_fwd_variant();
+    variant = (e == 1 || (e >= 8 && e <= 10)) ? e : kAutoEncoderVariant;
+    if (!(num_query == spatial_size && num_query >= 1024)) variant = 1;
+  }
+  if (variant >= 8)
+    return egtr_launch_msda_fwd_win_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
+                                        sampling_offsets, attn_logits, out, batch, num_query, spatial_size,
+                                        num_levels, num_point, variant - 8, reference_points, attn_weight_out,
+                                        ld_offsets, ld_logits, keep_mask, keep_bits, nullptr);
   const int nblk = (int)((nq + kWaves - 1) / kWaves);
   hipLaunchKernelGGL(msda_fwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
                      spatial_shapes, level_start_index, sampling_offsets, attn_logits, out, (int)nq, num_query,
                      spatial_size, num_levels, num_point, nblk, reference_points, attn_weight_out, ld_offsets,
                      ld_logits, keep_mask, keep_bits);
   return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                           const int64_t* level_start_index, const float* sampling_offsets,
+                                           const float* attn_logits, const float* reference_points, int batch,
+                                           int spatial_size, int num_heads, int channels, int num_levels,
+                                           int num_query, int num_point, float* out, float* attn_weight_out,
+                                           int ld_offsets, int ld_logits, const unsigned char* keep_mask,
+                                           const unsigned* keep_bits) {
+  return egtr_msda_forward_fused_f32_variant(stream, value, spatial_shapes, level_start_index, sampling_offsets,
+                                             attn_logits, reference_points, batch, spatial_size, num_heads, channels,
+                                             num_levels, num_query, num_point, out, attn_weight_out, ld_offsets,
+                                             ld_logits, keep_mask, keep_bits, 0);
 }
 
 extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,

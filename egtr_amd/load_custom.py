@@ -63,7 +63,7 @@ class _MultiScaleDeformableAttention:
 
     @staticmethod
     def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                     reference_points, want_weights=False, keep_mask=None):
+                                     reference_points, want_weights=False, keep_mask=None, variant=0):
         """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` computed in the kernel
         (deformable_detr.py:1055-1073, 2-d reference points).  fp32, M = 8, D = 32, L*P = 16; no autograd.
         sampling_offsets [B,Lq,M,L,P,2] / attn_logits [B,Lq,M,L*P] may be column blocks of one wider Linear output
@@ -104,12 +104,12 @@ class _MultiScaleDeformableAttention:
                 _chk(km, "keep_mask")
         out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
         wts = torch.empty(B, Lq, M, L, P, dtype=value.dtype, device=value.device) if want_weights else None
-        st = lib.egtr_msda_forward_fused_f32(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
-                                             level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
-                                             reference_points.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(),
-                                             wts.data_ptr() if want_weights else None, ld_off, ld_log,
-                                             km.data_ptr() if km is not None else None,
-                                             kbits.data_ptr() if kbits is not None else None)
+        st = lib.egtr_msda_forward_fused_f32_variant(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
+                                                     level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
+                                                     reference_points.data_ptr(), B, S, M, D, L, Lq, P,
+                                                     out.data_ptr(), wts.data_ptr() if want_weights else None, ld_off,
+                                                     ld_log, km.data_ptr() if km is not None else None,
+                                                     kbits.data_ptr() if kbits is not None else None, variant)
         _lib.check(st, "ms_deform_attn_forward_fused")
         return out, wts
 

@@ -74,11 +74,24 @@ int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const 
                                 float* attn_weight_out, int ld_offsets, int ld_logits,
                                 const unsigned char* keep_mask, const unsigned* keep_bits);
 
+/* Same with an explicit kernel choice: 0 = automatic, 1 = wave-per-query, 8 / 9 / 10 = the LDS-window kernel
+ * (see egtr_msda_forward_f32_variant). */
+int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                        const int64_t* level_start_index, const float* sampling_offsets,
+                                        const float* attn_logits, const float* reference_points, int batch,
+                                        int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                        int num_point, float* out, float* attn_weight_out, int ld_offsets,
+                                        int ld_logits, const unsigned char* keep_mask, const unsigned* keep_bits,
+                                        int variant);
+
 /* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
  * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
  * 3 = generic one-thread-per-element, 5 / 6 = lane-per-query with LDS windows in [channel quad][pixel] planes
  * (2 waves / 1 wave per workgroup; needs num_levels = num_point = 4), 7 = one head per workgroup with that head's
- * coarsest levels resident in LDS.
+ * coarsest levels resident in LDS, 8 / 9 / 10 = query tile x head with one 16-byte record per sample, zero-filled
+ * bounding windows of the unclamped corners, conflict-free gather lanes and non-persistent small workgroups
+ * (4x8 tiles, 4 workgroups per CU / 8x8 tiles, 2 per CU / 4x8 tiles with a larger window, 3 per CU; num_point even).
+ * The environment variable EGTR_MSDA_FWD_VARIANT overrides "automatic" (A/B runs of whole-model benchmarks).
  * Every variant computes the same function; EGTR_E_UNSUPPORTED if the shape rules out the requested variant. */
 int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                   const int64_t* level_start_index, const float* sampling_loc,
@@ -92,6 +105,13 @@ int egtr_msda_tile_phase_cycles(egtr_stream_t stream, const float* value, const 
                                 const int64_t* level_start_index, const float* sampling_loc,
                                 const float* attn_weight, int batch, int spatial_size, int num_levels, int num_query,
                                 int num_point, float* out, unsigned long long* cycles);
+
+/* Same for variants 8 / 9 / 10 (kind 0 / 1 / 2).  cycles: 6 x uint64 (zero it first): loc/attn issue + first barrier,
+ * geometry + bounding boxes, records + window copy, gather + store, number of work items, number of staged levels. */
+int egtr_msda_win_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                               const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
+                               int batch, int spatial_size, int num_levels, int num_query, int num_point, int kind,
+                               float* out, unsigned long long* cycles);
 
 /* Same for variants 5 (kind 0) and 6 (kind 1).  cycles: 8 x uint64 (zero it first): loc/attn + bounding boxes,
  * window staging, gather, output, number of work items; then, for the work items whose four windows were all staged:

@@ -199,6 +199,104 @@ def test_msda_resident_variant_arbitrary_queries():
     assert (o - ref).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("variant", [8, 9, 10])
+@pytest.mark.parametrize("shapes,B,jitter", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # windows fit: LDS path
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 1, 8.0),       # scattered offsets: windows overflow -> mixed LDS/global
+    ([(38, 63), (19, 32), (10, 16), (5, 8)], 1, 1.0),     # ragged tiles on every level
+    ([(75, 125), (38, 63), (19, 32), (10, 16)], 2, 0.2),  # the 600x1000 pyramid, two images
+    ([(9, 13), (5, 7)], 3, 0.5),                          # L = 2, P = 8
+    ([(16, 16)], 1, 0.5),                                 # L = 1, P = 16
+])
+def test_msda_window_variant_matches_oracle_and_wave_variant(variant, shapes, B, jitter):
+    """Variants 8-10 (query tile x head, zero-filled LDS bounding windows, one record per sample) on encoder-shaped
+    calls: vs the oracle (2e-5), vs variant 1, bitwise repeatable."""
+    k = _kernels()
+    x = _grid_inputs(9, B, shapes, jitter)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    o8 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+    o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert (o8 - ref).abs().max() < 2e-5
+    assert (o8 - o1).abs().max() < 2e-5
+    o8b = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+    assert torch.equal(o8, o8b)
+
+
+@pytest.mark.parametrize("variant", [8, 9, 10])
+def test_msda_window_variant_arbitrary_queries(variant):
+    """Variants 8-10 when the queries are NOT the pixel grid: linear tiles, windows rarely fit, results must still be
+    exact; samples straddling every image border; all-out-of-range and NaN locations."""
+    k = _kernels()
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    for Lq in (200, 820, 65):
+        x = W.make_msda_inputs(31 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
+        d = {n: t.to(DEV) for n, t in x.items()}
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+        assert (o - ref).abs().max() < 2e-5, Lq
+    x = _grid_inputs(6, 1, shapes, 0.3)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    for bad in (3.0, float("nan")):
+        loc = torch.full_like(d["loc"], bad)
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant)
+        assert o.abs().max().item() == 0
+    loc = d["loc"].clone()
+    loc[:, ::2] = 5.0
+    o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc.cpu(), x["attn"])
+    assert (o - ref).abs().max() < 2e-5
+    # every sample pushed towards / across a border (corners outside the level are zero-filled in the window)
+    for shift in (-0.04, 0.04):
+        loc = (d["loc"] + shift).contiguous()
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant).cpu()
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc.cpu(), x["attn"])
+        assert (o - ref).abs().max() < 2e-5, shift
+
+
+@pytest.mark.parametrize("variant", [8, 9, 10])
+@pytest.mark.parametrize("shapes,B", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2),
+    ([(75, 125), (38, 63), (19, 32), (10, 16)], 1),
+    ([(9, 13), (5, 7)], 2),
+])
+def test_msda_window_variant_fused_prologue_and_keep_mask(variant, shapes, B):
+    """The fused entry (softmax + sampling locations in the kernel, strided offsets | logits block, padding mask as
+    bytes and bit-packed) served by the LDS-window kernel == the wave-per-query kernel on the same operands."""
+    k = _kernels()
+    g = torch.Generator().manual_seed(13)
+    L = len(shapes)
+    P = 16 // L
+    S = sum(h * w for h, w in shapes)
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(B, S, 8, 32, generator=g)
+    both = torch.randn(B, S, 384, generator=g) * 2
+    gx = _grid_inputs(3, 1, shapes, 0.0)
+    ref = torch.cat([torch.stack([((torch.arange(h * w) % w) + 0.5) / w, ((torch.arange(h * w) // w) + 0.5) / h], -1)
+                     for h, w in shapes], 0)
+    ref = ref[None, :, None, :].expand(B, S, L, 2).contiguous() * (0.9 + 0.2 * torch.rand(B, 1, L, 2, generator=g))
+    keep = torch.rand(B, S, generator=g) > 0.25
+    d = [t.to(DEV) for t in (value, shp, lsi, both, ref, keep)]
+    off = d[3][..., :256].view(B, S, 8, L, P, 2)
+    logits = d[3][..., 256:].view(B, S, 8, 16)
+    for km in (None, d[5]):
+        want, ww = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, km, variant=1)
+        got, gw = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, km, variant=variant)
+        assert (got - want).abs().max().item() < 2e-5
+        assert torch.equal(gw, ww)
+    words = torch.zeros(B, (S + 31) // 32, dtype=torch.int64)
+    idx = torch.arange(S)
+    for bi in range(B):
+        words[bi].index_add_(0, idx // 32, keep[bi].long() << (idx % 32))
+    bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(DEV)
+    kmb = d[5].clone()
+    kmb._egtr_bits = bits
+    want, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5], variant=variant)
+    got, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, kmb, variant=variant)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("variant", [5, 6])
 @pytest.mark.parametrize("shapes,B,jitter", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # windows fit: LDS path

@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--phases", action="store_true", help="print per-phase cycles of the tile kernel")
     ap.add_argument("--graph", action="store_true", help="replay 20 launches per HIP graph (no CPU launch floor)")
     ap.add_argument("--variant", type=int, default=0, help="forward kernel variant (include/egtr_hip.h)")
+    ap.add_argument("--fused", action="store_true", help="fused-prologue entry (offsets | logits block + ref points)")
     a = ap.parse_args()
     from egtr_amd.load_custom import load_hip_kernels
     k = load_hip_kernels()
@@ -70,7 +71,31 @@ def main():
     fn = (lambda: k.ms_deform_attn_backward(value, shp, lsi, loc, attn, go, 64, a.variant)) if a.bwd else \
         ((lambda: k.ms_deform_attn_forward_variant(value, shp, lsi, loc, attn, a.variant))
          if (a.variant and not a.bf16) else (lambda: k.ms_deform_attn_forward(value, shp, lsi, loc, attn, 64)))
-    if a.phases and a.variant in (5, 6):
+    if a.fused:
+        B_, Lq_ = loc.shape[:2]
+        shp_f = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float32, device=dev)
+        refp = loc[:, :, 0, :, 0, :].clone()                               # [B, Lq, L, 2]
+        offs = (loc - refp[:, :, None, :, None, :]) * shp_f[None, None, None, :, None, :]
+        both = torch.cat([offs.reshape(B_, Lq_, 256), torch.log(attn.reshape(B_, Lq_, 128))], -1).contiguous()
+        off_v = both[..., :256].view(B_, Lq_, 8, len(shapes), 4, 2)
+        log_v = both[..., 256:].view(B_, Lq_, 8, 16)
+        fn = lambda: k.ms_deform_attn_forward_fused(value, shp, lsi, off_v, log_v, refp, False, None, variant=a.variant)
+    if a.phases and a.variant in (8, 9, 10):
+        from egtr_amd import _lib
+        cyc = torch.zeros(6, dtype=torch.int64, device=dev)
+        out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
+        for _ in range(3):
+            cyc.zero_()
+            st = _lib.lib().egtr_msda_win_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
+                                                       shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
+                                                       attn.data_ptr(), a.batch, value.shape[1], shp.shape[0],
+                                                       loc.shape[1], 4, a.variant - 8, out.data_ptr(), cyc.data_ptr())
+            _lib.check(st, "phase cycles")
+            torch.cuda.synchronize()
+        c = cyc.tolist()
+        print(f"window kernel phases per work item (s_memtime ticks = 100 MHz?): P0={c[0]/c[4]:.0f} A={c[1]/c[4]:.0f} "
+              f"B={c[2]/c[4]:.0f} C={c[3]/c[4]:.0f} items={c[4]} staged levels/item={c[5]/c[4]:.2f}")
+    elif a.phases and a.variant in (5, 6):
         from egtr_amd import _lib
         cyc = torch.zeros(8, dtype=torch.int64, device=dev)
         out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
