@@ -45,6 +45,17 @@ __device__ __forceinline__ int dpp_xor8_max(int v) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// loads with an explicit address space (LDS / global): they can never be merged into flat loads
+__device__ __forceinline__ float4 lds_ld4(const __attribute__((address_space(3))) char* p) {
+  const f32x4 v = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 glb_ld4(const __attribute__((address_space(1))) char* p) {
+  const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 
 // acc[0..1] += w * v[0..1]: one v_pk_fma_f32 with the scalar weight broadcast by op_sel
 __device__ __forceinline__ f32x2 pk_fma(f32x2 v, float w, f32x2 acc) {
@@ -380,6 +391,511 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_win_f32(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pipelined form (variants 11 / 12): persistent workgroups, every LDS structure double-buffered.  While the workgroup
+// gathers item j from buffer j&1, the window copy (LDS-DMA) of item j+1 lands in the other buffer and the loc / attn
+// rows of item j+2 are in flight into registers, so no global round trip is exposed in steady state:
+//     X: [DMA(j) landed, records(j) visible]                           (workgroup barrier)
+//        geometry + bounding boxes of item j+1 (registers -> LDS atomics); issue loc/attn loads of item j+2
+//     Y: [bounding boxes complete]                                      (workgroup barrier)
+//        pack windows, issue DMA(j+1), write records(j+1)
+//        gather item j from LDS, wait for DMA(j+1), store the outputs
+// Barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() fence would drain the in-flight DMA / output stores.
+// What the counters of the first pipelined build said: the kernel is bound by INSTRUCTION ISSUE (one
+// VALU and one SALU instruction per SIMD per 4 cycles, one instruction per wave per ~5 cycles), not by LDS or memory,
+// so everything around the 8 v_pk_fma_f32 + 5 ds_read_b128 per sample is written for instruction count: the item's
+// coordinates live in scalar registers, the window copy is a scalar row loop around ONE global_load_lds per 8 pixels
+// with loop-invariant lane offsets, bounding boxes are reduced with two DPP steps + LDS atomics, and padding masks are
+// handled per image (an image without padded tokens -- every bs=1 inference -- never looks at the mask again).
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int kItemsPerEpoch = 64;  // work items a workgroup decodes at once into its LDS table
+
+template <bool FUSED, int TH, int TW, int WINPX, int WPS, bool PROF = false>
+__global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
+    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int S,
+    const float* __restrict__ ref, int ld_off, int ld_logit, const unsigned* __restrict__ keep_bits,
+    unsigned long long* __restrict__ prof) {
+  // PROF: wave 0 of every workgroup accumulates shader-clock ticks into prof[0..7]: barrier X, geometry, barrier Y,
+  // pack + copy issue + records, gather, DMA wait, whole workgroup, items
+  unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tk = 0, tstart = 0;
+  auto tick = [&](int slot) {
+    if (PROF) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      pt[slot] += now - tk;
+      tk = now;
+    }
+  };
+  if (PROF) tstart = tk = __builtin_amdgcn_s_memtime();
+  // L = 4 levels x P = 4 points only (the launcher routes every other shape to the wave-per-query kernel)
+  constexpr int TQ = TH * TW;
+  constexpr int NT = TQ * 8;
+  constexpr int NW = TQ / 8;    // waves per workgroup
+  constexpr int RS = TQ + 1;    // record stride per sample (+1: conflict-free record writes)
+  constexpr int WPXB = kZeroPx + WINPX;  // pixels per window buffer
+  static_assert(TW == 8, "a wave gathers one row of 8 x-adjacent queries");
+  static_assert(WPXB * 128 < 65536, "LDS addresses are packed into 16 bits");
+  __shared__ __attribute__((aligned(16))) float4 s_win[2][WPXB * 8];
+  __shared__ __attribute__((aligned(16))) float4 s_w[2][16 * RS];  // [buffer][sample][query] weights
+  __shared__ __attribute__((aligned(16))) uint4 s_a[2][4 * RS];    // [buffer][level][query][point] addresses
+  __shared__ __attribute__((aligned(16))) int4 s_bbox[2][4];       // [parity][level]{ymin, ymax, xmin, xmax}
+  __shared__ __attribute__((aligned(16))) int4 s_item[kItemsPerEpoch][2];  // {b, head, qbase, wq}, {wlim, hlim, -, -}
+  __shared__ unsigned s_padded;                                     // bit b: image b has padded tokens
+
+  const int tid = threadIdx.x, c4 = tid & 7;
+  const int lane = tid & 63, col = lane >> 3;   // geometry / copy phases: lane = (query column, channel quad)
+  const int wave = rfl(tid >> 6);               // = query row of the tile
+  const int ql = wave * 8 + col;
+  int gcol, gc;                                 // gather phase: lane = (query column, channel quad), see header
+  {
+    const int l5 = lane & 31;
+    if (l5 < 4) { gcol = 0; gc = l5; }
+    else if (l5 < 12) { gcol = 2; gc = l5 - 4; }
+    else if (l5 < 16) { gcol = 0; gc = l5 - 8; }
+    else if (l5 < 20) { gcol = 3; gc = l5 - 16; }
+    else if (l5 < 28) { gcol = 1; gc = l5 - 20; }
+    else { gcol = 3; gc = l5 - 24; }
+    gcol += (lane >> 5) * 4;
+  }
+  const int gq = wave * 8 + gcol;
+  LevelGeom G;
+  load_geom(shapes, lsi, 4, G);
+  const int nwords = (S + 31) >> 5;
+  const int kstride = gridDim.x >> 3;
+  const int lvl = c4 >> 1;        // level of this thread's two samples (2*c4, 2*c4+1; P = 4)
+  const int H = SEL_H(G, lvl), W = SEL_W(G, lvl), st = SEL_S(G, lvl);
+  const float fW = (float)W, fH = (float)H;
+  const bool masked = FUSED && keep_bits != nullptr;
+
+  // ---- work-item table: lane t decodes this workgroup's t-th item of the epoch (vector ALU, once) -----------------
+  int nwork;
+  {
+    const TileMap tm = make_tile_map<TH, TW>(G, 4, Lq);
+    const int xcd = blockIdx.x & 7;
+    const int n0 = tm.grid2d ? tm.nt0 : tm.ntiles, n1 = tm.grid2d ? tm.nt1 : 0, n2 = tm.grid2d ? tm.nt2 : 0,
+              n3 = tm.grid2d ? tm.nt3 : 0;
+    const int lo0 = (xcd * n0) >> 3, lo1 = (xcd * n1) >> 3, lo2 = (xcd * n2) >> 3, lo3 = (xcd * n3) >> 3;
+    const int c0 = (((xcd + 1) * n0) >> 3) - lo0, c1 = (((xcd + 1) * n1) >> 3) - lo1,
+              c2 = (((xcd + 1) * n2) >> 3) - lo2, c3 = (((xcd + 1) * n3) >> 3) - lo3;
+    const int per_img = (c0 + c1 + c2 + c3) * 8;
+    nwork = B * per_img;
+    if ((int)(blockIdx.x >> 3) >= nwork) return;
+    // epochs of kItemsPerEpoch items: one epoch unless the batch is large
+    for (int e = tid; e < kItemsPerEpoch; e += NT) {
+      const int k = (int)(blockIdx.x >> 3) + e * kstride;  // epoch 0; later epochs re-run this block (see below)
+      (void)k;
+    }
+    // (table filled per epoch inside the epoch loop below: needs the tile map, which stays in scalar registers only
+    //  for the few instructions of fill_table)
+    auto fill_table = [&](int kfirst) {
+      if (tid < kItemsPerEpoch) {
+        const int k = kfirst + tid * kstride;
+        int4 a = make_int4(0, 0, 0, 8), b4 = make_int4(0, 0, 0, 0);
+        if (k < nwork) {
+          const int b = k / per_img;
+          const int r = k - b * per_img;
+          const int head = r & 7;
+          int t = r >> 3;
+          if (!tm.grid2d) {
+            const int qb = (lo0 + t) * TQ;
+            a = make_int4(b, head, qb, 8);
+            b4 = make_int4(Lq - qb, TH, 1, 0);
+          } else {
+            int lt;
+            if (t < c3) { lt = 3; t += lo3; }
+            else if ((t -= c3) < c2) { lt = 2; t += lo2; }
+            else if ((t -= c2) < c1) { lt = 1; t += lo1; }
+            else { lt = 0; t = t - c1 + lo0; }
+            const int tw = sel4(tm.tw0, tm.tw1, tm.tw2, tm.tw3, lt);
+            const int Ht = SEL_H(G, lt), Wt = SEL_W(G, lt), st_t = SEL_S(G, lt);
+            const int ty = t / tw, tx = t - ty * tw;
+            a = make_int4(b, head, st_t + ty * TH * Wt + tx * 8, Wt);
+            b4 = make_int4(Wt - tx * 8, Ht - ty * TH, 0, 0);
+          }
+        }
+        s_item[tid][0] = a;
+        s_item[tid][1] = b4;
+      }
+    };
+
+    // ---- helpers (all inlined) -----------------------------------------------------------------------------------
+    struct Item { int b, head, qbase, wq, wlim, hlim, linear; };
+    auto get_item = [&](int slot) -> Item {
+      const int4 a = s_item[slot][0];
+      const int4 c = s_item[slot][1];
+      Item it;
+      it.b = rfl(a.x); it.head = rfl(a.y); it.qbase = rfl(a.z); it.wq = rfl(a.w);
+      it.wlim = rfl(c.x); it.hlim = rfl(c.y); it.linear = rfl(c.z);
+      return it;
+    };
+    // query index of tile slot (row = wave, column cl); -1 = padding slot.  Linear mode: wq = 8, hlim = TH.
+    auto slot_query = [&](const Item& it, int cl) -> int {
+      const int o = wave * it.wq + cl;
+      const bool ok = it.linear ? (o < it.wlim) : (wave < it.hlim && cl < it.wlim);
+      return ok ? it.qbase + o : -1;
+    };
+    auto load_la = [&](const Item& it, bool live, float4& lc, float2& aw, float2& rp, int& qv) {
+      lc = make_float4(9.f, 9.f, 9.f, 9.f);  // far outside -> invalid
+      aw = make_float2(0.f, 0.f);
+      rp = make_float2(0.f, 0.f);
+      qv = live ? slot_query(it, col) : -1;
+      if (qv >= 0) {
+        const size_t qg = (size_t)it.b * Lq + qv;
+        if (FUSED) {
+          lc = reinterpret_cast<const float4*>(loc + qg * ld_off)[it.head * 8 + c4];
+          aw = reinterpret_cast<const float2*>(attn + qg * ld_logit)[it.head * 8 + c4];
+          rp = *reinterpret_cast<const float2*>(ref + (qg * 4 + lvl) * 2);
+        } else {
+          lc = reinterpret_cast<const float4*>(loc + (qg * 8 + it.head) * 32)[c4];
+          aw = reinterpret_cast<const float2*>(attn + (qg * 8 + it.head) * 16)[c4];
+        }
+      }
+    };
+
+    int y0[2], x0[2];
+    float wq[2][4];
+    bool val[2];
+    // geometry of this thread's two samples (cuh:38-78 / 268-288) + bounding-box atomics into s_bbox[par]
+    auto geom_bbox = [&](float4 lc, float2 aw, float2 rp, int q, int par) {
+      if (FUSED) {
+        if (q >= 0) lc = make_float4(rp.x + lc.x / fW, rp.y + lc.y / fH, rp.x + lc.z / fW, rp.y + lc.w / fH);
+        float m = fmaxf(aw.x, aw.y);
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
+        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, false)));
+        const float e0 = expf(aw.x - m), e1 = expf(aw.y - m);
+        float sum = e0 + e1;
+        sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
+        sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
+        sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
+        aw = (q >= 0) ? make_float2(e0 / sum, e1 / sum) : make_float2(0.f, 0.f);
+      }
+      int ymin = INT_MAX, ymax = INT_MIN, xmin = INT_MAX, xmax = INT_MIN;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float x = (j ? lc.z : lc.x) * fW - 0.5f, y = (j ? lc.w : lc.y) * fH - 0.5f;
+        val[j] = (y > -1.f) && (x > -1.f) && (y < fH) && (x < fW);
+        // invalid samples (outside, NaN): a harmless in-range position with zero attention -> all weights 0, finite
+        x = val[j] ? x : 0.f;
+        y = val[j] ? y : 0.f;
+        const float a = val[j] ? (j ? aw.y : aw.x) : 0.f;
+        const float yf = floorf(y), xf = floorf(x);
+        const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+        y0[j] = (int)yf;
+        x0[j] = (int)xf;
+        wq[j][0] = hh * hw * a;
+        wq[j][1] = hh * lw * a;
+        wq[j][2] = lh * hw * a;
+        wq[j][3] = lh * lw * a;
+        ymin = min(ymin, val[j] ? y0[j] : INT_MAX);
+        ymax = max(ymax, val[j] ? y0[j] + 1 : INT_MIN);
+        xmin = min(xmin, val[j] ? x0[j] : INT_MAX);
+        xmax = max(xmax, val[j] ? x0[j] + 1 : INT_MIN);
+      }
+      // the 8 queries of the wave sit in lanes l, l^8, l^16, l^32: fold l^8 with DPP, the rest with LDS atomics
+      ymin = dpp_xor8_min(ymin);
+      ymax = dpp_xor8_max(ymax);
+      xmin = dpp_xor8_min(xmin);
+      xmax = dpp_xor8_max(xmax);
+      if ((lane & 8) == 0 && ymin <= ymax) {
+        int* bb = reinterpret_cast<int*>(&s_bbox[par][lvl]);
+        atomicMin(bb + 0, ymin);
+        atomicMax(bb + 1, ymax);
+        atomicMin(bb + 2, xmin);
+        atomicMax(bb + 3, xmax);
+      }
+    };
+
+    // pack windows of the item into buffer `buf`, issue the window copy, write the records; returns the staged mask
+    auto pack_stage = [&](const Item& it, int buf, int par) -> unsigned {
+      const char* vbase = reinterpret_cast<const char*>(value) + (size_t)it.b * S * 1024 + it.head * 128;
+      int wy0[4], wx0[4], ww[4], wh[4], base[4];
+      unsigned staged = 0;
+      // an image with padded tokens is served from global memory with per-corner mask checks (all levels unstaged)
+      const bool allow = !masked || !((s_padded >> min(it.b, 31)) & 1u);
+      {
+        int off = 0;
+#pragma unroll
+        for (int l = 3; l >= 0; --l) {
+          const int4 bb = s_bbox[par][l];
+          wy0[l] = rfl(bb.x);
+          const int wy1 = rfl(bb.y);
+          wx0[l] = rfl(bb.z);
+          const int wx1 = rfl(bb.w);
+          const bool empty = wy0[l] > wy1;
+          ww[l] = empty ? 0 : (wx1 - wx0[l] + 1);
+          wh[l] = empty ? 0 : (wy1 - wy0[l] + 1);
+          base[l] = off;
+          if (!empty && allow && off + ww[l] * wh[l] <= WINPX) {
+            staged |= 1u << l;
+            off += ww[l] * wh[l];
+          } else {
+            wh[l] = 0;
+          }
+        }
+      }
+      float4* winb = s_win[buf];
+#pragma unroll
+      for (int l = 3; l >= 0; --l) {
+        if (wh[l] == 0) continue;
+        const int Hl = sel4(G.H0, G.H1, G.H2, G.H3, l), Wl = sel4(G.W0, G.W1, G.W2, G.W3, l);
+        const int sl = sel4(G.s0, G.s1, G.s2, G.s3, l);
+        // rows of the window inside the level: [r_lo, r_hi); this wave copies r_lo + wave, + NW, ...
+        const int r_lo = max(0, -wy0[l]), r_hi = min(wh[l], Hl - wy0[l]);
+        for (int cb = 0; cb < ww[l]; cb += 8) {
+          const int cc = cb + col, xx = wx0[l] + cc;
+          if (cc < ww[l] && (unsigned)xx < (unsigned)Wl) {
+            const unsigned voff = (unsigned)(xx * 1024 + c4 * 16);
+            const int r0 = r_lo + ((wave + l) & (NW - 1));  // rotate the dealing so no wave always gets the extra row
+            const char* grow = vbase + (size_t)(sl + (wy0[l] + r0) * Wl) * 1024;
+            int lds = (kZeroPx + base[l] + r0 * ww[l] + cb) * 8;
+            for (int rr = r0; rr < r_hi; rr += NW) {
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + voff),
+                                               (__attribute__((address_space(3))) void*)(winb + lds), 16, 0, 0);
+              grow += (size_t)NW * Wl * 1024;
+              lds += NW * ww[l] * 8;
+            }
+          }
+        }
+        // zero apron: window pixels outside the level (only tiles whose samples straddle an image border)
+        if (wy0[l] < 0 || wy0[l] + wh[l] > Hl || wx0[l] < 0 || wx0[l] + ww[l] > Wl) {
+          const int npx = ww[l] * wh[l];
+          const float inv = __frcp_rn((float)ww[l]);
+          for (int p = ql; p < npx; p += TQ) {
+            const int rr = (int)(((float)p + 0.5f) * inv);  // exact for p, ww < 4096
+            const int cc = p - rr * ww[l];
+            if ((unsigned)(wy0[l] + rr) >= (unsigned)Hl || (unsigned)(wx0[l] + cc) >= (unsigned)Wl)
+              winb[(kZeroPx + base[l] + p) * 8 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        }
+      }
+      {
+        const bool st_l = (staged >> lvl) & 1u;
+        unsigned code[2];
+        if (st_l) {
+          // a00 = (kZeroPx + base + (y0 - wy0) * ww + (x0 - wx0)) * 128 = K_l + (y0 * ww + x0) * 128
+          const int bww = sel4(ww[0], ww[1], ww[2], ww[3], lvl);
+          const int K = sel4((kZeroPx + base[0] - wy0[0] * ww[0] - wx0[0]) * 128,
+                             (kZeroPx + base[1] - wy0[1] * ww[1] - wx0[1]) * 128,
+                             (kZeroPx + base[2] - wy0[2] * ww[2] - wx0[2]) * 128,
+                             (kZeroPx + base[3] - wy0[3] * ww[3] - wx0[3]) * 128, lvl);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int a00 = K + (y0[j] * bww + x0[j]) * 128;
+            code[j] = val[j] ? (unsigned)(a00 | ((a00 + bww * 128) << 16)) : 0u;
+          }
+        } else {
+          // global records: clamped top-left pixel << 2 | dx << 1 | dy; out-of-range corners and padded tokens are
+          // folded into the weights
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int ya = max(y0[j], 0), yb = min(y0[j] + 1, H - 1), xa = max(x0[j], 0), xb = min(x0[j] + 1, W - 1);
+            const int p00 = st + ya * W + xa;
+            const int dx = xb - xa, dy = yb - ya;
+            bool k0 = y0[j] >= 0 && x0[j] >= 0, k1 = y0[j] >= 0 && x0[j] + 1 <= W - 1,
+                 k2 = y0[j] + 1 <= H - 1 && x0[j] >= 0, k3 = y0[j] + 1 <= H - 1 && x0[j] + 1 <= W - 1;
+            if (masked && val[j]) {
+              const int p01 = p00 + dx, p10 = p00 + dy * W, p11 = p10 + dx;
+              const unsigned* kb = keep_bits + (size_t)it.b * nwords;
+              k0 = k0 && ((kb[p00 >> 5] >> (p00 & 31)) & 1u);
+              k1 = k1 && ((kb[p01 >> 5] >> (p01 & 31)) & 1u);
+              k2 = k2 && ((kb[p10 >> 5] >> (p10 & 31)) & 1u);
+              k3 = k3 && ((kb[p11 >> 5] >> (p11 & 31)) & 1u);
+            }
+            wq[j][0] = k0 ? wq[j][0] : 0.f;
+            wq[j][1] = k1 ? wq[j][1] : 0.f;
+            wq[j][2] = k2 ? wq[j][2] : 0.f;
+            wq[j][3] = k3 ? wq[j][3] : 0.f;
+            code[j] = val[j] ? (unsigned)((p00 << 2) | (dx << 1) | dy) : 0u;
+          }
+        }
+        s_w[buf][(2 * c4) * RS + ql] = make_float4(wq[0][0], wq[0][1], wq[0][2], wq[0][3]);
+        s_w[buf][(2 * c4 + 1) * RS + ql] = make_float4(wq[1][0], wq[1][1], wq[1][2], wq[1][3]);
+        reinterpret_cast<uint2*>(s_a[buf] + lvl * RS + ql)[c4 & 1] = make_uint2(code[0], code[1]);
+      }
+      return staged;
+    };
+
+    auto gather = [&](const Item& it, int buf, unsigned staged, bool wait_dma) {
+      const int qo = slot_query(it, gcol);
+      // explicit address spaces: the two branches of the generic path must not be merged into flat loads
+      typedef const __attribute__((address_space(3))) char* lds_cp;
+      typedef const __attribute__((address_space(1))) char* glb_cp;
+      const lds_cp win = (lds_cp)(s_win[buf]);
+      const float4* wb = s_w[buf] + gq;
+      const uint4* ab = s_a[buf] + gq;
+      const unsigned coff = gc * 16;
+      const glb_cp glb = (glb_cp)(reinterpret_cast<const char*>(value) + (size_t)it.b * S * 1024 + it.head * 128 + gc * 16);
+      f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#define EGTR_WIN_FMA16()                                            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
+        acc0 = pk_fma(f32x2{v[j][0].x, v[j][0].y}, w[j].x, acc0);   \
+        acc1 = pk_fma(f32x2{v[j][0].z, v[j][0].w}, w[j].x, acc1);   \
+        acc0 = pk_fma(f32x2{v[j][1].x, v[j][1].y}, w[j].y, acc0);   \
+        acc1 = pk_fma(f32x2{v[j][1].z, v[j][1].w}, w[j].y, acc1);   \
+        acc0 = pk_fma(f32x2{v[j][2].x, v[j][2].y}, w[j].z, acc0);   \
+        acc1 = pk_fma(f32x2{v[j][2].z, v[j][2].w}, w[j].z, acc1);   \
+        acc0 = pk_fma(f32x2{v[j][3].x, v[j][3].y}, w[j].w, acc0);   \
+        acc1 = pk_fma(f32x2{v[j][3].z, v[j][3].w}, w[j].w, acc1);   \
+      }
+      if (staged == 0xFu) {
+        // every window is in LDS (the regular case).  Software pipeline over the levels: the 20 ds_read_b128 of
+        // level l+1 are in flight while the 32 v_pk_fma_f32 of level l issue (two register buffers).
+        uint4 A[4];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) A[l] = ab[l * RS];
+        float4 wv[2][4], vv[2][4][4];
+        auto issue = [&](int l, int bf) {
+          const unsigned cd[4] = {A[l].x, A[l].y, A[l].z, A[l].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            wv[bf][j] = wb[(l * 4 + j) * RS];
+            const unsigned a0 = (cd[j] & 0xffffu) | coff, a1 = (cd[j] >> 16) | coff;
+            vv[bf][j][0] = lds_ld4(win + a0);
+            vv[bf][j][1] = lds_ld4(win + a0 + 128);
+            vv[bf][j][2] = lds_ld4(win + a1);
+            vv[bf][j][3] = lds_ld4(win + a1 + 128);
+          }
+        };
+        issue(0, 0);
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          if (l < 3) issue(l + 1, (l + 1) & 1);
+          const int bf = l & 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc0 = pk_fma(f32x2{vv[bf][j][0].x, vv[bf][j][0].y}, wv[bf][j].x, acc0);
+            acc1 = pk_fma(f32x2{vv[bf][j][0].z, vv[bf][j][0].w}, wv[bf][j].x, acc1);
+            acc0 = pk_fma(f32x2{vv[bf][j][1].x, vv[bf][j][1].y}, wv[bf][j].y, acc0);
+            acc1 = pk_fma(f32x2{vv[bf][j][1].z, vv[bf][j][1].w}, wv[bf][j].y, acc1);
+            acc0 = pk_fma(f32x2{vv[bf][j][2].x, vv[bf][j][2].y}, wv[bf][j].z, acc0);
+            acc1 = pk_fma(f32x2{vv[bf][j][2].z, vv[bf][j][2].w}, wv[bf][j].z, acc1);
+            acc0 = pk_fma(f32x2{vv[bf][j][3].x, vv[bf][j][3].y}, wv[bf][j].w, acc0);
+            acc1 = pk_fma(f32x2{vv[bf][j][3].z, vv[bf][j][3].w}, wv[bf][j].w, acc1);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) {
+          const uint4 A = ab[l * RS];
+          const unsigned cd[4] = {A.x, A.y, A.z, A.w};
+          float4 w[4], v[4][4];
+          if ((staged >> l) & 1u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              w[j] = wb[(l * 4 + j) * RS];
+              const unsigned a0 = (cd[j] & 0xffffu) | coff, a1 = (cd[j] >> 16) | coff;
+              v[j][0] = lds_ld4(win + a0);
+              v[j][1] = lds_ld4(win + a0 + 128);
+              v[j][2] = lds_ld4(win + a1);
+              v[j][3] = lds_ld4(win + a1 + 128);
+            }
+          } else {
+            const unsigned Wb = (unsigned)sel4(G.W0, G.W1, G.W2, G.W3, l) * 1024u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              w[j] = wb[(l * 4 + j) * RS];
+              const unsigned o00 = (cd[j] >> 2) << 10;
+              const unsigned dxb = (cd[j] & 2u) ? 1024u : 0u, dyb = (cd[j] & 1u) ? Wb : 0u;
+              v[j][0] = glb_ld4(glb + o00);
+              v[j][1] = glb_ld4(glb + o00 + dxb);
+              v[j][2] = glb_ld4(glb + o00 + dyb);
+              v[j][3] = glb_ld4(glb + o00 + dyb + dxb);
+            }
+          }
+          EGTR_WIN_FMA16()
+        }
+      }
+#undef EGTR_WIN_FMA16
+      if (PROF) {
+        // make the timer see the FMAs (they depend on the last LDS reads)
+        asm volatile("" :: "v"(acc0), "v"(acc1));
+        tick(4);
+      }
+      // the next item's window copy had the whole gather to land; wait for it BEFORE the stores join the queue
+      if (wait_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      tick(5);
+      if (qo >= 0)
+        reinterpret_cast<float4*>(out + (((size_t)it.b * Lq + qo) * 8 + it.head) * 32)[gc] =
+            make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+    };
+
+    // ---- prologue ------------------------------------------------------------------------------------------------
+    if (tid < 8) reinterpret_cast<int4*>(s_bbox)[tid] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);
+    if (tid < kZeroPx * 8) {
+      s_win[0][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      s_win[1][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid == 0) s_padded = 0;
+    fill_table((int)(blockIdx.x >> 3));
+    wg_barrier();
+    if (masked) {
+      // which images have padded tokens at all (one pass over the bit mask per workgroup; bit 31 = images >= 31)
+      for (int b = 0; b < B; ++b) {
+        bool pad = false;
+        for (int i = tid; i < nwords; i += NT) {
+          const unsigned full = (i == nwords - 1 && (S & 31)) ? ((1u << (S & 31)) - 1u) : 0xffffffffu;
+          pad = pad || ((keep_bits[(size_t)b * nwords + i] & full) != full);
+        }
+        if (pad) atomicOr(&s_padded, 1u << min(b, 31));
+      }
+    }
+    // ---- epochs x pipeline -----------------------------------------------------------------------------------------
+    for (int kfirst = (int)(blockIdx.x >> 3); kfirst < nwork; kfirst += kItemsPerEpoch * kstride) {
+      if (kfirst != (int)(blockIdx.x >> 3)) {
+        wg_barrier();  // every wave has finished the previous epoch (its table and buffers are free)
+        fill_table(kfirst);
+        if (tid < 8) reinterpret_cast<int4*>(s_bbox)[tid] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);
+        wg_barrier();
+      }
+      const int nit = min(kItemsPerEpoch, (nwork - kfirst + kstride - 1) / kstride);  // items of this epoch
+      Item cur = get_item(0);
+      float4 lc;
+      float2 aw, rp;
+      int qv;
+      load_la(cur, true, lc, aw, rp, qv);
+      geom_bbox(lc, aw, rp, qv, 0);
+      Item nxt = cur;
+      if (nit > 1) nxt = get_item(1);
+      load_la(nxt, nit > 1, lc, aw, rp, qv);
+      wg_barrier();
+      unsigned staged_cur = pack_stage(cur, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int j = 0;; ++j) {
+        if (PROF) tk = __builtin_amdgcn_s_memtime();
+        wg_barrier();  // X: DMA(j) landed (each wave waited for its own pieces), records(j) visible
+        tick(0);
+        if (tid < 4) s_bbox[j & 1][tid] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);  // next used by item j+2
+        const bool live_next = j + 1 < nit;
+        const Item it_next = nxt;
+        unsigned staged_next = 0;
+        if (live_next) {
+          geom_bbox(lc, aw, rp, qv, (j + 1) & 1);
+          const bool more = j + 2 < nit;
+          if (more) nxt = get_item(j + 2);
+          load_la(nxt, more, lc, aw, rp, qv);
+          tick(1);
+          wg_barrier();  // Y
+          tick(2);
+          staged_next = pack_stage(it_next, (j + 1) & 1, (j + 1) & 1);
+          tick(3);
+        }
+        gather(cur, j & 1, staged_cur, live_next);
+        if (PROF) pt[7] += 1;
+        if (!live_next) break;
+        cur = it_next;
+        staged_cur = staged_next;
+      }
+    }
+    if (PROF && tid == 0) {
+      pt[6] = __builtin_amdgcn_s_memtime() - tstart;
+      for (int i = 0; i < 8; ++i) atomicAdd(prof + i, pt[i]);
+    }
+  }
+}
+
 int pick_grid(int B, int S, int tq) {
   // upper estimate of the number of (tile, head) items (the level shapes live in device memory); the kernel strides
   // over the real count, surplus workgroups exit at once
@@ -402,6 +918,33 @@ int egtr_launch_msda_fwd_win_f32(hipStream_t st, const float* value, const int64
   hipLaunchKernelGGL((msda_fwd_win_f32<F, TH_, 8, WINPX_, WPS_>), dim3(pick_grid(B, S, TH_ * 8)), dim3(TH_ * 64), 0, \
                      st, value, shapes, lsi, loc, attn, out, B, Lq, S, L, P, ref, attn_out, ld_off, ld_logit, keep,  \
                      keep_bits, prof)
+  if (kind == 3 || kind == 4) {
+    // persistent: exactly the resident workgroups (2 per CU at 80 KB LDS / 1 per CU at 160 KB)
+    hipDeviceProp_t prop;
+    int dev = 0;
+    static int ncu = 0;
+    if (ncu == 0) {
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return EGTR_E_LAUNCH;
+      ncu = prop.multiProcessorCount;
+    }
+#define EGTR_WINP_LAUNCH(F, TH_, WINPX_, WPS_, PERCU)                                                                \
+  hipLaunchKernelGGL((msda_fwd_winp_f32<F, TH_, 8, WINPX_, WPS_>), dim3((ncu * PERCU) & ~7), dim3(TH_ * 64), 0, st,   \
+                     value, shapes, lsi, loc, attn, out, B, Lq, S, ref, ld_off, ld_logit, keep_bits,                \
+                     (unsigned long long*)nullptr)
+    if (L != 4 || P != 4 || attn_out != nullptr || (keep != nullptr && keep_bits == nullptr)) return EGTR_E_UNSUPPORTED;
+    if (kind == 3 && prof != nullptr && !fused) {
+      hipLaunchKernelGGL((msda_fwd_winp_f32<false, 4, 8, 224, 2, true>), dim3((ncu * 2) & ~7), dim3(256), 0, st, value,
+                         shapes, lsi, loc, attn, out, B, Lq, S, ref, ld_off, ld_logit, keep_bits, prof);
+      return egtr_check_launch();
+    }
+    if (kind == 3) {
+      if (fused) EGTR_WINP_LAUNCH(true, 4, 224, 2, 2); else EGTR_WINP_LAUNCH(false, 4, 224, 2, 2);
+    } else {
+      if (fused) EGTR_WINP_LAUNCH(true, 8, 456, 2, 1); else EGTR_WINP_LAUNCH(false, 8, 456, 2, 1);
+    }
+#undef EGTR_WINP_LAUNCH
+    return egtr_check_launch();
+  }
   if (kind == 1) {
     if (fused) EGTR_WIN_LAUNCH(true, 8, 464, 4); else EGTR_WIN_LAUNCH(false, 8, 464, 4);
   } else if (kind == 2) {

@@ -106,7 +106,7 @@ int egtr_msda_tile_phase_cycles(egtr_stream_t stream, const float* value, const 
                                 const float* attn_weight, int batch, int spatial_size, int num_levels, int num_query,
                                 int num_point, float* out, unsigned long long* cycles);
 
-/* Same for variants 8 / 9 / 10 (kind 0 / 1 / 2).  cycles: 6 x uint64 (zero it first): loc/attn issue + first barrier,
+/* Same for variants 8 / 9 / 10 (kind 0 / 1 / 2; kind 3 = variant 11: 8 x uint64, see msda_win.hip).  cycles: 6 x uint64 (zero it first): loc/attn issue + first barrier,
  * geometry + bounding boxes, records + window copy, gather + store, number of work items, number of staged levels. */
 int egtr_msda_win_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,

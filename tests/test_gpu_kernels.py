@@ -199,7 +199,7 @@ def test_msda_resident_variant_arbitrary_queries():
     assert (o - ref).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("variant", [8, 9, 10])
+@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12])
 @pytest.mark.parametrize("shapes,B,jitter", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # windows fit: LDS path
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 1, 8.0),       # scattered offsets: windows overflow -> mixed LDS/global
@@ -214,6 +214,10 @@ def test_msda_window_variant_matches_oracle_and_wave_variant(variant, shapes, B,
     k = _kernels()
     x = _grid_inputs(9, B, shapes, jitter)
     d = {n: t.to(DEV) for n, t in x.items()}
+    if variant >= 11 and len(shapes) != 4:   # the pipelined form is specialised for L = P = 4
+        with pytest.raises(Exception):
+            k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant)
+        return
     o8 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
     o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
     ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
@@ -223,7 +227,7 @@ def test_msda_window_variant_matches_oracle_and_wave_variant(variant, shapes, B,
     assert torch.equal(o8, o8b)
 
 
-@pytest.mark.parametrize("variant", [8, 9, 10])
+@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12])
 def test_msda_window_variant_arbitrary_queries(variant):
     """Variants 8-10 when the queries are NOT the pixel grid: linear tiles, windows rarely fit, results must still be
     exact; samples straddling every image border; all-out-of-range and NaN locations."""
@@ -254,7 +258,7 @@ def test_msda_window_variant_arbitrary_queries(variant):
         assert (o - ref).abs().max() < 2e-5, shift
 
 
-@pytest.mark.parametrize("variant", [8, 9, 10])
+@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12])
 @pytest.mark.parametrize("shapes,B", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2),
     ([(75, 125), (38, 63), (19, 32), (10, 16)], 1),
@@ -280,11 +284,21 @@ def test_msda_window_variant_fused_prologue_and_keep_mask(variant, shapes, B):
     d = [t.to(DEV) for t in (value, shp, lsi, both, ref, keep)]
     off = d[3][..., :256].view(B, S, 8, L, P, 2)
     logits = d[3][..., 256:].view(B, S, 8, 16)
-    for km in (None, d[5]):
-        want, ww = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, km, variant=1)
-        got, gw = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, km, variant=variant)
+    if variant >= 11:
+        # the pipelined form: L = P = 4, bit-packed masks only, no attention-weight output
+        with pytest.raises(Exception):
+            k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, None, variant=variant)
+        if L != 4:
+            return
+        want, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, None, variant=1)
+        got, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, None, variant=variant)
         assert (got - want).abs().max().item() < 2e-5
-        assert torch.equal(gw, ww)
+    else:
+        for km in (None, d[5]):
+            want, ww = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, km, variant=1)
+            got, gw = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, km, variant=variant)
+            assert (got - want).abs().max().item() < 2e-5
+            assert torch.equal(gw, ww)
     words = torch.zeros(B, (S + 31) // 32, dtype=torch.int64)
     idx = torch.arange(S)
     for bi in range(B):
@@ -292,9 +306,15 @@ def test_msda_window_variant_fused_prologue_and_keep_mask(variant, shapes, B):
     bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(DEV)
     kmb = d[5].clone()
     kmb._egtr_bits = bits
-    want, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5], variant=variant)
+    want, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5], variant=1)
     got, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, kmb, variant=variant)
-    assert torch.equal(got, want)
+    assert (got - want).abs().max().item() < 2e-5
+    # an all-valid mask takes the LDS path and equals the unmasked result bit for bit
+    ones = torch.ones_like(d[5])
+    ones._egtr_bits = torch.full_like(bits, -1)
+    a, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, ones, variant=variant)
+    b_, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, None, variant=variant)
+    assert torch.equal(a, b_)
 
 
 @pytest.mark.parametrize("variant", [5, 6])
