@@ -95,7 +95,9 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
     const float* __restrict__ w2c, const float* __restrict__ b2c, const float* __restrict__ w3c,
     const float* __restrict__ b3c, const float* __restrict__ triplet, const int64_t* __restrict__ node_cls, int B,
     int N, int R, int C1, float* __restrict__ rel_logits, float* __restrict__ conn_logits,
-    float* __restrict__ gate_mean) {
+    float* __restrict__ gate_mean, float* __restrict__ h1_save, float* __restrict__ h2_save) {
+  // h1_save / h2_save (training only, may be null): post-ReLU hidden activations of both layers, [2 (mlp)][B*N*N][256],
+  // so that the backward needs no recomputation (egtr_rel_head_backward_pairs_f32 + rocBLAS GEMMs, egtr_amd/ops.py)
   // one buffer, two lives: the layer-1 transpose (read back into registers before layer 2), then the output tile
   constexpr int kBuf = 16 * kH1Stride > 32 * (32 * OT + 1) ? 16 * kH1Stride : 32 * (32 * OT + 1);
   __shared__ __attribute__((aligned(16))) float s_buf[kBuf];
@@ -183,8 +185,10 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
         acc.z += gt * (a.z + c.z);
         acc.w += gt * (a.w + c.w);
       }
-      *reinterpret_cast<float4*>(&s_h1[row * kH1Stride + 4 * lane]) =
-          make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+      const float4 hv = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+      *reinterpret_cast<float4*>(&s_h1[row * kH1Stride + 4 * lane]) = hv;
+      if (h1_save != nullptr && p0 + pp < total)  // one contiguous 1 KiB row per wave
+        reinterpret_cast<float4*>(h1_save + ((size_t)mlp * total + (size_t)(p0 + pp)) * kHd)[lane] = hv;
     };
     // two rounds of 16 pairs: the transpose buffer is 16 rows (16.6 KB), which leaves room for 2 waves per SIMD, so
     // that one wave's load-bound layer 1 overlaps another wave's MFMA-bound layers 2-3
@@ -252,6 +256,9 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
       acc[4 * rq + 1] = fmaxf(acc[4 * rq + 1] + bb.y, 0.f);
       acc[4 * rq + 2] = fmaxf(acc[4 * rq + 2] + bb.z, 0.f);
       acc[4 * rq + 3] = fmaxf(acc[4 * rq + 3] + bb.w, 0.f);
+      if (h2_save != nullptr && valid)
+        *reinterpret_cast<float4*>(h2_save + ((size_t)mlp * total + (size_t)p) * kHd + n0) =
+            make_float4(acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
     }
     if (mlp == 0) {
       // ---- layer 3 (relation): rel^T[r_out][pair] += W3[r_out][n] h2^T[n][pair] ----------------------------
@@ -317,25 +324,172 @@ int launch_T(hipStream_t st, int R, dim3 grid, const float* gate_q, const float*
              const float* uk, const float* b1, const float* w2r, const float* b2r, const float* w3r,
              const float* b3r, const float* w2c, const float* b2c, const float* w3c, const float* b3c,
              const float* triplet, const int64_t* node_cls, int B, int N, int C1, float* rel, float* conn,
-             float* gate_mean) {
+             float* gate_mean, float* h1_save, float* h2_save) {
   if (R <= 32)
     hipLaunchKernelGGL((rel_head_fwd_f32<T, 1>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
-                       b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean);
+                       b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean, h1_save,
+                       h2_save);
   else
     hipLaunchKernelGGL((rel_head_fwd_f32<T, 2>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
-                       b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean);
+                       b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean, h1_save,
+                       h2_save);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------ backward
+// The MLP part of the backward is plain GEMMs on [B*N*N, 256] matrices (rocBLAS, driven from egtr_amd/ops.py) using
+// the activations saved by the forward.  What is NOT a GEMM is the pairwise part below: from dh1 = dL/d(pre-ReLU
+// layer-1 output) [2][B*N*N][256] it produces the gradients of the per-query tables,
+//   duq[i,t,:] = sum_j g[i,j,t] dh1[i,j,:]          duk[j,t,:] = sum_i g[i,j,t] dh1[i,j,:]
+//   dg[i,j,t]  = dh1[i,j,:] . (uq[i,t,:] + uk[j,t,:])       dz = dg g (1 - g)
+//   dgate_q[i,t] = sum_j dz[i,j,t]                  dgate_k[j,t] = sum_i dz[i,j,t]
+// in two passes over dh1 (one contiguous 2 x 1 KiB row per wave per pair, each read exactly once per pass):
+//   pass Q: workgroup = (b, i), waves split j: duq, and the uq half of dg -> dz buffer
+//   pass K: workgroup = (b, j), waves split i: duk, the uk half of dg, dz = (.) g (1 - g) -> dz buffer, dgate_k
+//   pass A: dgate_q[i,t] = sum_j dz[i,j,t]
+// Lane l of a wave owns channels {4 l .. 4 l + 3} of the relation half and of the connectivity half (8 channels).
+template <int T, bool KPASS>
+__global__ __launch_bounds__(256) void rel_head_bwd_pairs_f32(
+    const float* __restrict__ dh1, const float* __restrict__ gate_q, const float* __restrict__ gate_k,
+    const float* __restrict__ utab /* uq (Q pass) or uk (K pass): [B,N,T,512] */, int B, int N,
+    float* __restrict__ dutab /* duq or duk [B,N,T,512] */, float* __restrict__ dz /* [B,N,N,T] */,
+    float* __restrict__ dgate_k /* K pass: [B,N,T] */) {
+  __shared__ float s_g[256 * T];                                  // gate of (fixed, m) for m < N in chunks of 256
+  __shared__ __attribute__((aligned(16))) float s_red[4 * T * 512];  // per-wave partial dutab, reduced at the end
+  __shared__ float s_dk[4 * T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / N, f = blockIdx.x - b * N;  // f = the fixed index (i in the Q pass, j in the K pass)
+  const size_t total = (size_t)B * N * N;
+  const float* gfix = (KPASS ? gate_k : gate_q) + ((size_t)b * N + f) * T;
+  const float* gvar = (KPASS ? gate_q : gate_k) + (size_t)b * N * T;
+  float gf[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) gf[t] = gfix[t];
+  // this lane's 8 channels of the fixed row's table, all T slots
+  float4 ur[T], uc[T];
+  {
+    const float4* up = reinterpret_cast<const float4*>(utab + ((size_t)b * N + f) * T * 512);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      ur[t] = up[t * 128 + lane];
+      uc[t] = up[t * 128 + 64 + lane];
+    }
+  }
+  float4 ar[T], ac[T];
+  float dk[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    ar[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ac[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dk[t] = 0.f;
+  }
+  for (int m0 = 0; m0 < N; m0 += 256) {
+    const int mc = min(256, N - m0);
+    __syncthreads();
+    if (tid < mc) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) s_g[tid * T + t] = 1.f / (1.f + expf(-(gf[t] + gvar[(size_t)(m0 + tid) * T + t])));
+    }
+    __syncthreads();
+    for (int mm = wave; mm < mc; mm += 4) {
+      const int m = m0 + mm;
+      const size_t pair = KPASS ? ((size_t)b * N + m) * N + f : ((size_t)b * N + f) * N + m;
+      const float4 dr = reinterpret_cast<const float4*>(dh1 + pair * 256)[lane];
+      const float4 dc = reinterpret_cast<const float4*>(dh1 + (total + pair) * 256)[lane];
+      float dot[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float g = s_g[mm * T + t];
+        ar[t].x += g * dr.x; ar[t].y += g * dr.y; ar[t].z += g * dr.z; ar[t].w += g * dr.w;
+        ac[t].x += g * dc.x; ac[t].y += g * dc.y; ac[t].z += g * dc.z; ac[t].w += g * dc.w;
+        dot[t] = dr.x * ur[t].x + dr.y * ur[t].y + dr.z * ur[t].z + dr.w * ur[t].w + dc.x * uc[t].x +
+                 dc.y * uc[t].y + dc.z * uc[t].z + dc.w * uc[t].w;
+      }
+      // reduce the T dot products over the 64 lanes
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dot[t] += __shfl_xor(dot[t], o);
+      }
+      if (lane < T) {
+        float v = 0.f, g = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          v = (lane == t) ? dot[t] : v;
+          g = (lane == t) ? s_g[mm * T + t] : g;
+        }
+        if (KPASS) {
+          const float z = (dz[pair * T + lane] + v) * g * (1.f - g);
+          dz[pair * T + lane] = z;
+          dk[0] += z;  // lane t accumulates dgate_k[f, t]
+        } else {
+          dz[pair * T + lane] = v;
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the table gradient
+  {
+    float4* mine = reinterpret_cast<float4*>(s_red + wave * T * 512);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      mine[t * 128 + lane] = ar[t];
+      mine[t * 128 + 64 + lane] = ac[t];
+    }
+    if (KPASS && lane < T) s_dk[wave * T + lane] = dk[0];
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(dutab + ((size_t)b * N + f) * T * 512);
+    const float4* r0 = reinterpret_cast<const float4*>(s_red);
+    for (int e = tid; e < T * 128; e += 256) {
+      const float4 a = r0[e], c = r0[T * 128 + e], d = r0[2 * T * 128 + e], g = r0[3 * T * 128 + e];
+      dst[e] = make_float4(a.x + c.x + d.x + g.x, a.y + c.y + d.y + g.y, a.z + c.z + d.z + g.z, a.w + c.w + d.w + g.w);
+    }
+    if (KPASS && tid < T)
+      dgate_k[((size_t)b * N + f) * T + tid] = s_dk[tid] + s_dk[T + tid] + s_dk[2 * T + tid] + s_dk[3 * T + tid];
+  }
+}
+
+// dgate_q[b,i,t] = sum_j dz[b,i,j,t]: one wave per (b, i)
+template <int T>
+__global__ __launch_bounds__(64) void rel_head_bwd_gate_q_f32(const float* __restrict__ dz, int N,
+                                                              float* __restrict__ dgate_q) {
+  const size_t row = blockIdx.x;  // b * N + i
+  const float* src = dz + row * N * T;
+  float acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = 0.f;
+  for (int j = threadIdx.x; j < N; j += 64)
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] += src[(size_t)j * T + t];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc[t] += __shfl_xor(acc[t], o);
+    if (threadIdx.x == 0) dgate_q[row * T + t] = acc[t];
+  }
+}
+
+template <int T>
+int launch_bwd_T(hipStream_t st, const float* dh1, const float* gate_q, const float* gate_k, const float* uq,
+                 const float* uk, int B, int N, float* duq, float* duk, float* dgq, float* dgk, float* dz) {
+  hipLaunchKernelGGL((rel_head_bwd_pairs_f32<T, false>), dim3(B * N), dim3(256), 0, st, dh1, gate_q, gate_k, uq, B, N,
+                     duq, dz, (float*)nullptr);
+  hipLaunchKernelGGL((rel_head_bwd_pairs_f32<T, true>), dim3(B * N), dim3(256), 0, st, dh1, gate_q, gate_k, uk, B, N,
+                     duk, dz, dgk);
+  hipLaunchKernelGGL((rel_head_bwd_gate_q_f32<T>), dim3(B * N), dim3(64), 0, st, dz, N, dgq);
   return 0;
 }
 
 }  // namespace
 
-extern "C" int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k,
-                                         const float* uq, const float* uk, const float* b1, const float* w2r,
-                                         const float* b2r, const float* w3r, const float* b3r, const float* w2c,
-                                         const float* b2c, const float* w3c, const float* b3c,
-                                         const float* triplet_dist, const int64_t* node_cls, int batch,
-                                         int num_query, int num_slots, int hidden, int num_rel, int num_cls_plus1,
-                                         float* rel_logits, float* conn_logits, float* gate_mean) {
+extern "C" int egtr_rel_head_forward_save_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k,
+                                              const float* uq, const float* uk, const float* b1, const float* w2r,
+                                              const float* b2r, const float* w3r, const float* b3r, const float* w2c,
+                                              const float* b2c, const float* w3c, const float* b3c,
+                                              const float* triplet_dist, const int64_t* node_cls, int batch,
+                                              int num_query, int num_slots, int hidden, int num_rel,
+                                              int num_cls_plus1, float* rel_logits, float* conn_logits,
+                                              float* gate_mean, float* h1_save, float* h2_save) {
   if (!gate_q || !gate_k || !uq || !uk || !b1 || !w2r || !b2r || !w3r || !b3r || !w2c || !b2c || !w3c || !b3c ||
       !rel_logits || !conn_logits)
     return EGTR_E_ARG;
@@ -348,7 +502,44 @@ extern "C" int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate
 #define EGTR_T(TT)                                                                                                  \
   case TT:                                                                                                          \
     launch_T<TT>(st, num_rel, grid, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,             \
-                 triplet_dist, node_cls, batch, num_query, num_cls_plus1, rel_logits, conn_logits, gate_mean);      \
+                 triplet_dist, node_cls, batch, num_query, num_cls_plus1, rel_logits, conn_logits, gate_mean,       \
+                 h1_save, h2_save);                                                                                 \
+    break;
+  switch (num_slots) {
+    EGTR_T(1) EGTR_T(2) EGTR_T(3) EGTR_T(4) EGTR_T(5) EGTR_T(6) EGTR_T(7) EGTR_T(8) EGTR_T(9) EGTR_T(10)
+    default: return EGTR_E_UNSUPPORTED;
+  }
+#undef EGTR_T
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k,
+                                         const float* uq, const float* uk, const float* b1, const float* w2r,
+                                         const float* b2r, const float* w3r, const float* b3r, const float* w2c,
+                                         const float* b2c, const float* w3c, const float* b3c,
+                                         const float* triplet_dist, const int64_t* node_cls, int batch,
+                                         int num_query, int num_slots, int hidden, int num_rel, int num_cls_plus1,
+                                         float* rel_logits, float* conn_logits, float* gate_mean) {
+  return egtr_rel_head_forward_save_f32(stream, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,
+                                        triplet_dist, node_cls, batch, num_query, num_slots, hidden, num_rel,
+                                        num_cls_plus1, rel_logits, conn_logits, gate_mean, nullptr, nullptr);
+}
+
+extern "C" int egtr_rel_head_backward_pairs_f32(egtr_stream_t stream, const float* dh1, const float* gate_q,
+                                                const float* gate_k, const float* uq, const float* uk, int batch,
+                                                int num_query, int num_slots, int hidden, float* grad_uq,
+                                                float* grad_uk, float* grad_gate_q, float* grad_gate_k,
+                                                float* dz_workspace) {
+  if (!dh1 || !gate_q || !gate_k || !uq || !uk || !grad_uq || !grad_uk || !grad_gate_q || !grad_gate_k ||
+      !dz_workspace)
+    return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_slots <= 0) return EGTR_E_ARG;
+  if (hidden != kHd || num_slots > 10) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define EGTR_T(TT)                                                                                                  \
+  case TT:                                                                                                          \
+    launch_bwd_T<TT>(st, dh1, gate_q, gate_k, uq, uk, batch, num_query, grad_uq, grad_uk, grad_gate_q, grad_gate_k, \
+                     dz_workspace);                                                                                 \
     break;
   switch (num_slots) {
     EGTR_T(1) EGTR_T(2) EGTR_T(3) EGTR_T(4) EGTR_T(5) EGTR_T(6) EGTR_T(7) EGTR_T(8) EGTR_T(9) EGTR_T(10)

@@ -413,19 +413,6 @@ def add_layer_norm(x, residual, ln):
     return ln(residual + x)
 
 
-def _rel_head_separable_torch(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c):
-    """Differentiable PyTorch-ROCm statement of the SAME separable algebra the fused HIP kernel evaluates
-    (egtr_amd/csrc/rel_head.hip).  Used only to obtain gradients in training (backward recompute); the forward
-    values always come from the HIP kernel."""
-    Hd = w2r.shape[1]
-    g = torch.sigmoid(gate_q[:, :, None, :] + gate_k[:, None, :, :])  # [B,N,N,T]
-    h1 = torch.einsum("bijt,bitc->bijc", g, uq) + torch.einsum("bijt,bjtc->bijc", g, uk) + b1
-    h1 = torch.relu(h1)
-    rel = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(h1[..., :Hd], w2r, b2r)), w3r, b3r)
-    conn = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(h1[..., Hd:], w2c, b2c)), w3c, b3c)
-    return rel, conn[..., 0], g
-
-
 class RelationHeadFunction(Function):
     """Fused pairwise gate + gated sum + relation / connectivity MLPs (replaces model/egtr.py:366-416)."""
 
@@ -448,24 +435,63 @@ class RelationHeadFunction(Function):
             c1 = triplet_dist.shape[0]
         else:
             c1 = 0
-        st = lib.egtr_rel_head_forward_f32(
+        need_grad = any(ctx.needs_input_grad[:13])
+        P_ = B * N * N
+        h1s = torch.empty(2, P_, Hd, dtype=torch.float32, device=gate_q.device) if need_grad else None
+        h2s = torch.empty(2, P_, Hd, dtype=torch.float32, device=gate_q.device) if need_grad else None
+        st = lib.egtr_rel_head_forward_save_f32(
             _stream(), *[t.data_ptr() for t in tens], triplet_dist.data_ptr() if triplet_dist is not None else None,
             node_cls.data_ptr() if triplet_dist is not None else None, B, N, T, Hd, R, c1, rel.data_ptr(),
-            conn.data_ptr(), gm.data_ptr() if want_gate_mean else None)
-        _lib.check(st, "egtr_rel_head_forward_f32")
-        ctx.save_for_backward(*tens)
+            conn.data_ptr(), gm.data_ptr() if want_gate_mean else None,
+            h1s.data_ptr() if need_grad else None, h2s.data_ptr() if need_grad else None)
+        _lib.check(st, "egtr_rel_head_forward_save_f32")
+        if need_grad:
+            ctx.save_for_backward(*tens, h1s, h2s)
         return rel, conn.unsqueeze(-1), gm
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_rel, grad_conn, grad_gm):
-        # Gradient by recomputation of the separable algebra with PyTorch-ROCm ops on the GPU (rocBLAS GEMMs).
-        # The frequency bias is an additive constant, so it does not appear here.
-        tens = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
-        with torch.enable_grad():
-            rel, conn, _ = _rel_head_separable_torch(*tens)
-            grads = torch.autograd.grad([rel, conn], tens, [grad_rel, grad_conn[..., 0]], allow_unused=True)
-        return tuple(grads) + (None, None, None)
+        """MLP part: rocBLAS GEMMs on the [B*N*N, 256] activations the forward kernel saved (no recomputation; the
+        ReLU masks are applied with threshold_backward).  Pairwise part (gradients of the per-query tables and of
+        the gate logits): HIP, egtr_rel_head_backward_pairs_f32.  The frequency bias is an additive constant."""
+        (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, h1s, h2s) = ctx.saved_tensors
+        lib = _lib.lib()
+        B, N, T = gate_q.shape
+        Hd = w2r.shape[1]
+        R = w3r.shape[0]
+        P_ = B * N * N
+        tb = torch.ops.aten.threshold_backward
+        G = grad_rel.reshape(P_, R).contiguous()
+        gc = grad_conn.reshape(P_, 1).contiguous()
+        dh1 = torch.empty(2, P_, Hd, dtype=torch.float32, device=G.device)
+        # relation MLP
+        dh2 = tb(G @ w3r, h2s[0], 0.0)
+        dw3r = G.t() @ h2s[0]
+        db3r = G.sum(0)
+        torch.mm(dh2, w2r, out=dh1[0])
+        dw2r = dh2.t() @ h1s[0]
+        db2r = dh2.sum(0)
+        # connectivity MLP (one output)
+        dh2 = tb(gc * w3c, h2s[1], 0.0)
+        dw3c = gc.t() @ h2s[1]
+        db3c = gc.sum(0)
+        torch.mm(dh2, w2c, out=dh1[1])
+        dw2c = dh2.t() @ h1s[1]
+        db2c = dh2.sum(0)
+        del dh2
+        dh1 = tb(dh1, h1s, 0.0)
+        db1 = dh1.sum(1).reshape(-1)
+        duq = torch.empty_like(uq)
+        duk = torch.empty_like(uk)
+        dgq = torch.empty_like(gate_q)
+        dgk = torch.empty_like(gate_k)
+        dz = torch.empty(P_ * T, dtype=torch.float32, device=G.device)
+        st = lib.egtr_rel_head_backward_pairs_f32(_stream(), dh1.data_ptr(), gate_q.data_ptr(), gate_k.data_ptr(),
+                                                  uq.data_ptr(), uk.data_ptr(), B, N, T, Hd, duq.data_ptr(),
+                                                  duk.data_ptr(), dgq.data_ptr(), dgk.data_ptr(), dz.data_ptr())
+        _lib.check(st, "egtr_rel_head_backward_pairs_f32")
+        return (dgq, dgk, duq, duk, db1, dw2r, db2r, dw3r, db3r, dw2c, db2c, dw3c, db3c, None, None, None)
 
 
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,

@@ -245,6 +245,25 @@ int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate_q, const f
                               int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
                               float* gate_mean);
 
+/* Training variant of the forward: additionally stores the post-ReLU hidden activations of layer 1 and layer 2 of both
+ * MLPs, h1_save / h2_save [2 (0 = relation, 1 = connectivity)][B*N*N][hidden] (either may be NULL), for the backward. */
+int egtr_rel_head_forward_save_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
+                                   const float* uk, const float* b1, const float* w2r, const float* b2r,
+                                   const float* w3r, const float* b3r, const float* w2c, const float* b2c,
+                                   const float* w3c, const float* b3c, const float* triplet_dist,
+                                   const int64_t* node_cls, int batch, int num_query, int num_slots, int hidden,
+                                   int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
+                                   float* gate_mean, float* h1_save, float* h2_save);
+
+/* Pairwise part of the relation-head backward (everything that is not a plain GEMM).  dh1 [2][B*N*N][hidden] is the
+ * gradient wrt the pre-ReLU layer-1 output (relation half, connectivity half), produced by rocBLAS GEMMs from the
+ * saved activations.  Outputs (fully overwritten): grad_uq / grad_uk [B,N,T,2*hidden], grad_gate_q / grad_gate_k
+ * [B,N,T].  dz_workspace: B*N*N*T floats of scratch (receives d loss / d gate logit per pair and slot). */
+int egtr_rel_head_backward_pairs_f32(egtr_stream_t stream, const float* dh1, const float* gate_q, const float* gate_k,
+                                     const float* uq, const float* uk, int batch, int num_query, int num_slots,
+                                     int hidden, float* grad_uq, float* grad_uk, float* grad_gate_q,
+                                     float* grad_gate_k, float* dz_workspace);
+
 #ifdef __cplusplus
 }
 #endif

@@ -597,10 +597,14 @@ def test_relation_head_forward(B, N, T, R):
     assert (rel2.cpu() - rrel2.float()).abs().max() < 2e-4 and gm2 is None
 
 
-def test_relation_head_backward_matches_autograd():
+@pytest.mark.parametrize("B,N,T,R", [(2, 12, 4, 7), (1, 200, 7, 50), (3, 40, 7, 50), (1, 33, 9, 64), (2, 7, 1, 1),
+                                     (1, 300, 9, 50)])
+def test_relation_head_backward_matches_autograd(B, N, T, R):
+    """Forward that saves h1 / h2 + backward = rocBLAS GEMMs on the saved activations + the HIP pairwise kernels
+    (egtr_rel_head_backward_pairs_f32), against fp64 autograd through the reference formulation (tests/cpu_kernels)."""
     import cpu_kernels as ck
     from egtr_amd.ops import relation_head
-    d, trip, node = _head_inputs(77, 2, 12, 4, 7, 5)
+    d, trip, node = _head_inputs(77 + N, B, N, T, R, 5)
     dd = {k: v.to(DEV).requires_grad_(True) for k, v in d.items()}
     rel, conn, _ = relation_head(*dd.values(), trip.to(DEV), node.to(DEV), False)
     rng = W.rng_inputs(78)
@@ -611,7 +615,15 @@ def test_relation_head_backward_matches_autograd():
     rrel, rconn, _ = ck.relation_head(*d64.values(), trip.double(), node, False)
     ((rrel * g1.double()).sum() + (rconn * g2.double()).sum()).backward()
     for k in d:
-        assert (dd[k].grad.cpu() - d64[k].grad.float()).abs().max() < 1e-3 * max(1.0, float(d64[k].grad.abs().max())), k
+        got, want = dd[k].grad.cpu().double(), d64[k].grad
+        if B * N * N <= 4096:
+            assert (got - want).abs().max() < 1e-3 * max(1.0, float(want.abs().max())), k
+        else:
+            # Large problems: of the B*N*N*512 ReLU inputs a handful lie within fp32 rounding of zero, and the fp32
+            # kernel and the fp64 reference then disagree on that mask bit (an O(1) change of ONE term of a sum over
+            # 1e5 pairs).  The relative Frobenius error is insensitive to those few terms; 3e-3 still catches any
+            # systematic error (a wrong term, a missing slot, a transposed weight are all > 1e-1).
+            assert float((got - want).norm() / want.norm().clamp_min(1e-12)) < 3e-3, k
 
 
 # ---------------------------------------------------------------------------------------------- skinny linear

@@ -29,6 +29,36 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / 50
     fl = 2.0 * B * 200 * 200 * (2 * 256 * 256 + 256 * 64)
     print(f"rel_head fwd B={B}: {us:.1f} us/launch, {fl / us / 1e6:.1f} TFLOP/s (f32 MFMA peak 157)")
+    # training: forward (saving h1 / h2) + backward (rocBLAS GEMMs + the HIP pairwise kernels) vs autograd through the
+    # PyTorch statement of the same separable algebra (what round 1 shipped first)
+    dg = {k: v.clone().requires_grad_(True) for k, v in dd.items()}
+
+    def step_hip():
+        rel, conn, _ = relation_head(*dg.values(), trip, node, False)
+        (rel.sum() + conn.sum()).backward()
+
+    def separable(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c):
+        g = torch.sigmoid(gate_q[:, :, None, :] + gate_k[:, None, :, :])
+        h1 = torch.relu(torch.einsum("bijt,bitc->bijc", g, uq) + torch.einsum("bijt,bjtc->bijc", g, uk) + b1)
+        lin = torch.nn.functional.linear
+        rel = lin(torch.relu(lin(h1[..., :256], w2r, b2r)), w3r, b3r)
+        conn = lin(torch.relu(lin(h1[..., 256:], w2c, b2c)), w3c, b3c)
+        return rel, conn
+
+    def step_torch():
+        rel, conn = separable(*dg.values())
+        (rel.sum() + conn.sum()).backward()
+
+    for name, fn in (("HIP fwd+bwd", step_hip), ("PyTorch separable fwd+bwd", step_torch)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print(f"rel_head {name} B={B}: {e0.elapsed_time(e1) / 10:.3f} ms/step")
 
 
 if __name__ == "__main__":
