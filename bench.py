@@ -181,7 +181,7 @@ def train_bench(args, world, rank, dev, dist):
     model, cfg, cfg_dict = build_model(dev, {"dropout": 0.1})
     model.train()
     opt = configure_optimizers(model, lr=2e-6, lr_backbone=2e-7, lr_initialized=None, weight_decay=1e-4)
-    tr = DataParallelTrainer(model, optimizer=opt, accumulate=1, clip=0.1)
+    tr = DataParallelTrainer(model, optimizer=opt, accumulate=1, clip=0.1, graph=bool(args.train_graph))
     torch.manual_seed(100 + rank)
     b = {"pixel_values": torch.randn(batch, 3, H_IMG, W_IMG, device=dev),
          "pixel_mask": torch.ones(batch, H_IMG, W_IMG, dtype=torch.long, device=dev),
@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (bounded sample)")
     ap.add_argument("--graph", type=int, default=1, help="replay the forward from a HIP graph (0 = eager launches)")
+    ap.add_argument("--train-graph", type=int, default=0,
+                    help="--mode train, one GPU: replay forward / backward of the static part of the step from HIP "
+                         "graphs (measured slower than eager launches: the step is GPU-bound, DESIGN.md 4.7)")
     ap.add_argument("--tune-gemm", type=int, default=1,
                     help="1 = PyTorch TunableOp picks the fastest rocBLAS / hipBLASLt solution per GEMM shape during "
                          "warm-up (egtr_amd.runtime.enable_gemm_tuning)")

@@ -533,10 +533,14 @@ class DeformableDetrEncoderLayer(nn.Module):
                                                                   _pos_rows(position_embeddings))
         else:
             hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
-        if self.training:  # dd:1346-1351 (data-dependent host sync, kept for parity)
-            if torch.isinf(hidden_states).any() or torch.isnan(hidden_states).any():
-                clamp_value = torch.finfo(hidden_states.dtype).max - 1000
-                hidden_states = torch.clamp(hidden_states, min=-clamp_value, max=clamp_value)
+        if self.training:
+            # dd:1346-1351 clamps the states iff any element is inf / nan -- a data-dependent branch that costs the
+            # reference two host synchronisations per encoder layer.  Same function without the sync (and therefore
+            # capturable in a HIP graph): the "any non-finite" flag stays on the device and selects the clamped tensor.
+            bad = torch.logical_not(torch.isfinite(hidden_states).all())
+            clamp_value = torch.finfo(hidden_states.dtype).max - 1000
+            hidden_states = torch.where(bad, torch.clamp(hidden_states, min=-clamp_value, max=clamp_value),
+                                        hidden_states)
         outputs = (hidden_states,)
         if output_attentions:
             outputs += (attn_weights,)

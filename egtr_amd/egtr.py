@@ -171,18 +171,11 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
                                  cl[1].weight, cl[1].bias, cl[2].weight, cl[2].bias, triplet, node,
                                  want_gate_mean)
 
-    def forward(self, pixel_values, pixel_mask=None, decoder_attention_mask=None, encoder_outputs=None,
-                inputs_embeds=None, decoder_inputs_embeds=None, labels=None, output_attentions=None,
-                output_hidden_states=None, output_attention_states=None, return_dict=None):
-        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
-        outputs = self.model(pixel_values, pixel_mask=pixel_mask, decoder_attention_mask=decoder_attention_mask,
-                             encoder_outputs=encoder_outputs, inputs_embeds=inputs_embeds,
-                             decoder_inputs_embeds=decoder_inputs_embeds, output_attentions=output_attentions,
-                             output_hidden_states=output_hidden_states,
-                             output_attention_states=True,  # the relation head needs the retained q / k maps
-                             return_dict=True)
+    def _heads(self, outputs, want_gate_mean):
+        """Detection heads + relation head on the base model's outputs (egtr:283-418).  Returns
+        (logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean); the relation /
+        connectivity logits are PRE-sigmoid."""
         sequence_output = outputs["last_hidden_state"]
-        bsz = sequence_output.size(0)
         hidden_states = outputs.intermediate_hidden_states
         init_reference = outputs.init_reference_points
         inter_references = outputs.intermediate_reference_points
@@ -231,7 +224,6 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         if self.config.auxiliary_loss:
             outputs_class = outputs_class[:, : self.config.decoder_layers, ...].permute(1, 0, 2, 3)
             outputs_coord = outputs_coord[:, : self.config.decoder_layers, ...].permute(1, 0, 2, 3)
-        _, num_object_queries, _ = logits.shape
 
         decoder_attention_queries = outputs["decoder_attention_queries"]
         outputs["decoder_attention_queries"] = None
@@ -239,41 +231,83 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         outputs["decoder_attention_keys"] = None
         pred_rel, pred_connectivity, gate_mean = self._relation_head(
             decoder_attention_queries, decoder_attention_keys, sequence_output, logits,
-            want_gate_mean=labels is not None)
+            want_gate_mean=want_gate_mean)
+        return logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean
+
+    def forward_tensors(self, pixel_values, pixel_mask):
+        """The static-shape part of a TRAINING step as a plain tensors -> tensors function (no host synchronisation, no
+        Python objects in or out), so that forward and backward can each be replayed from one HIP graph
+        (egtr_amd.runtime.DataParallelTrainer(graph=True)).  ``loss_from_tensors`` turns the result into the loss."""
+        outputs = self.model(pixel_values, pixel_mask=pixel_mask, output_attentions=False, output_hidden_states=True,
+                             output_attention_states=True, return_dict=True)
+        logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean = \
+            self._heads(outputs, want_gate_mean=True)
+        if self.config.auxiliary_loss:
+            return logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord
+        return logits, pred_boxes, pred_rel, pred_connectivity, gate_mean
+
+    def loss_from_tensors(self, tensors, labels):
+        """Matcher + SGG loss (egtr:420-505) on the tensors ``forward_tensors`` returns."""
+        logits, pred_boxes, pred_rel, pred_connectivity, gate_mean = tensors[:5]
+        outputs_class = tensors[5] if self.config.auxiliary_loss else None
+        outputs_coord = tensors[6] if self.config.auxiliary_loss else None
+        loss, loss_dict, _ = self._loss(logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class,
+                                        outputs_coord, labels)
+        return loss, loss_dict
+
+    def _loss(self, logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord, labels):
+        auxiliary_outputs = None
+        num_object_queries = logits.shape[1]
+        matcher = DeformableDetrHungarianMatcher(
+            class_cost=self.config.ce_loss_coefficient, bbox_cost=self.config.bbox_cost,
+            giou_cost=self.config.giou_cost, smoothing=self.config.smoothing)
+        criterion = SceneGraphGenerationLoss(
+            matcher=matcher, num_object_queries=num_object_queries, num_classes=self.config.num_labels,
+            num_rel_labels=self.config.num_rel_labels, eos_coef=self.config.eos_coefficient,
+            losses=["labels", "boxes", "relations", "cardinality", "uncertainty"],
+            smoothing=self.config.smoothing, rel_sample_negatives=self.config.rel_sample_negatives,
+            rel_sample_nonmatching=self.config.rel_sample_nonmatching, model_training=self.training,
+            focal_alpha=self.config.focal_alpha,
+            rel_sample_negatives_largest=self.config.rel_sample_negatives_largest,
+            rel_sample_nonmatching_largest=self.config.rel_sample_nonmatching_largest)
+        criterion.to(logits.device)
+        outputs_loss = {"logits": logits, "pred_boxes": pred_boxes, "pred_rel": pred_rel,
+                        "pred_connectivity": pred_connectivity}  # pre-sigmoid (egtr:450-454)
+        if self.config.auxiliary_loss:
+            auxiliary_outputs = self._set_aux_loss(outputs_class, outputs_coord)
+            outputs_loss["auxiliary_outputs"] = auxiliary_outputs
+        loss_dict = criterion(outputs_loss, labels)
+        weight_dict = {"loss_ce": self.config.ce_loss_coefficient, "loss_bbox": self.config.bbox_loss_coefficient,
+                       "loss_giou": self.config.giou_loss_coefficient,
+                       "loss_rel": self.config.rel_loss_coefficient,
+                       "loss_connectivity": self.config.connectivity_loss_coefficient}
+        if self.config.auxiliary_loss:
+            aux = {}
+            for i in range(self.config.decoder_layers - 1):
+                aux.update({f"{k}_{i}": v for k, v in weight_dict.items()})
+            weight_dict.update(aux)
+        loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+        for i in range(self.config.decoder_layers + 1):  # rel_gate_{i} logging (egtr:496-505)
+            loss_dict[f"rel_gate_{i}"] = gate_mean[i]
+        return loss, loss_dict, auxiliary_outputs
+
+    def forward(self, pixel_values, pixel_mask=None, decoder_attention_mask=None, encoder_outputs=None,
+                inputs_embeds=None, decoder_inputs_embeds=None, labels=None, output_attentions=None,
+                output_hidden_states=None, output_attention_states=None, return_dict=None):
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        outputs = self.model(pixel_values, pixel_mask=pixel_mask, decoder_attention_mask=decoder_attention_mask,
+                             encoder_outputs=encoder_outputs, inputs_embeds=inputs_embeds,
+                             decoder_inputs_embeds=decoder_inputs_embeds, output_attentions=output_attentions,
+                             output_hidden_states=output_hidden_states,
+                             output_attention_states=True,  # the relation head needs the retained q / k maps
+                             return_dict=True)
+        logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean = \
+            self._heads(outputs, want_gate_mean=labels is not None)
 
         loss, loss_dict, auxiliary_outputs = None, None, None
         if labels is not None:
-            matcher = DeformableDetrHungarianMatcher(
-                class_cost=self.config.ce_loss_coefficient, bbox_cost=self.config.bbox_cost,
-                giou_cost=self.config.giou_cost, smoothing=self.config.smoothing)
-            criterion = SceneGraphGenerationLoss(
-                matcher=matcher, num_object_queries=num_object_queries, num_classes=self.config.num_labels,
-                num_rel_labels=self.config.num_rel_labels, eos_coef=self.config.eos_coefficient,
-                losses=["labels", "boxes", "relations", "cardinality", "uncertainty"],
-                smoothing=self.config.smoothing, rel_sample_negatives=self.config.rel_sample_negatives,
-                rel_sample_nonmatching=self.config.rel_sample_nonmatching, model_training=self.training,
-                focal_alpha=self.config.focal_alpha,
-                rel_sample_negatives_largest=self.config.rel_sample_negatives_largest,
-                rel_sample_nonmatching_largest=self.config.rel_sample_nonmatching_largest)
-            criterion.to(self.device)
-            outputs_loss = {"logits": logits, "pred_boxes": pred_boxes, "pred_rel": pred_rel,
-                            "pred_connectivity": pred_connectivity}  # pre-sigmoid (egtr:450-454)
-            if self.config.auxiliary_loss:
-                auxiliary_outputs = self._set_aux_loss(outputs_class, outputs_coord)
-                outputs_loss["auxiliary_outputs"] = auxiliary_outputs
-            loss_dict = criterion(outputs_loss, labels)
-            weight_dict = {"loss_ce": self.config.ce_loss_coefficient, "loss_bbox": self.config.bbox_loss_coefficient,
-                           "loss_giou": self.config.giou_loss_coefficient,
-                           "loss_rel": self.config.rel_loss_coefficient,
-                           "loss_connectivity": self.config.connectivity_loss_coefficient}
-            if self.config.auxiliary_loss:
-                aux = {}
-                for i in range(self.config.decoder_layers - 1):
-                    aux.update({f"{k}_{i}": v for k, v in weight_dict.items()})
-                weight_dict.update(aux)
-            loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
-            for i in range(self.config.decoder_layers + 1):  # rel_gate_{i} logging (egtr:496-505)
-                loss_dict[f"rel_gate_{i}"] = gate_mean[i]
+            loss, loss_dict, auxiliary_outputs = self._loss(logits, pred_boxes, pred_rel, pred_connectivity,
+                                                            gate_mean, outputs_class, outputs_coord, labels)
 
         if self.config.logit_adjustment:  # egtr:509-512
             pred_rel = pred_rel - self.config.logit_adj_tau * self.rel_dist.log().to(pred_rel.device)

@@ -80,7 +80,10 @@ def configure_optimizers(model, lr=2e-6, lr_backbone=2e-7, lr_initialized=2e-4, 
               {"params": [p for n, p in named if any(d in n for d in diff)], "lr": lr_backbone}]
     if init:
         groups.append({"params": [p for n, p in named if any(d in n for d in init)], "lr": lr_initialized})
-    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+    # same update rule as the reference's torch.optim.AdamW; on the GPU the single-kernel-per-group ("fused")
+    # implementation replaces ~10 multi-tensor launches per group (the step is launch-bound: 42.5 M parameters)
+    on_gpu = bool(named) and all(p.is_cuda for _, p in named)
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, fused=True if on_gpu else None)
 
 
 def init_distributed():
@@ -104,9 +107,17 @@ class DataParallelTrainer:
     once per optimizer step -- micro-steps before the accumulation boundary run under ``no_sync`` -- then
     clip-grad-norm 0.1 and AdamW.  ``num_boxes`` stays per-rank (model/egtr.py:976-980)."""
 
-    def __init__(self, model, optimizer=None, accumulate=2, clip=0.1, bucket_cap_mb=25):
+    def __init__(self, model, optimizer=None, accumulate=2, clip=0.1, bucket_cap_mb=25, graph=False):
+        """graph=True (single process, GPU, fixed image size): the static-shape part of the step -- backbone, encoder,
+        decoder, detection + relation heads, forward AND backward -- is captured once into two HIP graphs
+        (torch.cuda.make_graphed_callables over ``model.forward_tensors``) and replayed; the Hungarian matcher and the
+        loss stay eager in between (they synchronise with the host and have data-dependent shapes).  An eager step
+        issues ~2700 launches and leaves the GPU idle a quarter of the time (rocprofv3)."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.raw = model
+        self._graph_wanted = bool(graph) and self.world == 1
+        self._graphed = None
+        self._graph_key = None
         if self.world > 1:
             ids = [torch.cuda.current_device()] if next(model.parameters()).is_cuda else None
             self.model = torch.nn.parallel.DistributedDataParallel(
@@ -119,8 +130,30 @@ class DataParallelTrainer:
         self.clip = clip
         self._micro = 0
 
+    def _graphed_body(self, pixel_values, pixel_mask):
+        key = (tuple(pixel_values.shape), pixel_values.dtype, tuple(pixel_mask.shape), pixel_mask.dtype)
+        if self._graphed is None or key != self._graph_key:
+            raw = self.raw
+
+            class _Body(torch.nn.Module):  # parameters are found through the wrapped model
+                def __init__(self):
+                    super().__init__()
+                    self.m = raw
+
+                def forward(self, pv, pm):
+                    return self.m.forward_tensors(pv, pm)
+
+            self._graphed = torch.cuda.make_graphed_callables(
+                _Body(), (pixel_values.detach().clone(), pixel_mask.detach().clone()), num_warmup_iters=3)
+            self._graph_key = key
+            self.opt.zero_grad(set_to_none=True)  # the warm-up / capture backward passes left gradients behind
+        return self._graphed(pixel_values, pixel_mask)
+
     def common_step(self, batch):
-        out = self.model(pixel_values=batch["pixel_values"], pixel_mask=batch["pixel_mask"], labels=batch["labels"],
+        pv, pm = batch["pixel_values"], batch["pixel_mask"]
+        if self._graph_wanted and pv.is_cuda and self.raw.training:
+            return self.raw.loss_from_tensors(self._graphed_body(pv, pm), batch["labels"])
+        out = self.model(pixel_values=pv, pixel_mask=pm, labels=batch["labels"],
                          output_attentions=False, output_attention_states=True, output_hidden_states=True)
         return out.loss, out.loss_dict
 

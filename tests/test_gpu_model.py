@@ -188,6 +188,41 @@ def test_graph_replay_matches_eager():
         assert (r.pred_rel - e.pred_rel).abs().max() < 1e-5 and (r.pred_boxes - e.pred_boxes).abs().max() < 1e-5
 
 
+def test_graphed_train_step_matches_eager_train_step(small):
+    """DataParallelTrainer(graph=True) replays forward and backward of the static part of the step from HIP graphs;
+    losses and parameter updates must equal the eager step's (dropout 0 so that both are deterministic)."""
+    import copy
+    from egtr_amd.egtr import DetrForSceneGraphGeneration
+    from egtr_amd.runtime import DataParallelTrainer, configure_optimizers
+    g, cfg_dict, shapes = small
+    cfg_dict = dict(cfg_dict, dropout=0.0)
+    base, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    base.load_state_dict(sd)
+    base = base.to(DEV).train()
+    targets = [{k: t.to(DEV) for k, t in d.items()}
+               for d in W.make_targets(5, 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+    pv, pm = Hh.small_inputs(g)   # the second image is padded: the mask path is part of the captured graph
+    batch = {"pixel_values": pv.to(DEV), "pixel_mask": pm.to(DEV), "labels": targets}
+    results = []
+    for graph in (False, True):
+        model = copy.deepcopy(base)
+        opt = configure_optimizers(model, lr=1e-4, lr_backbone=1e-5, lr_initialized=None, weight_decay=1e-4)
+        tr = DataParallelTrainer(model, optimizer=opt, accumulate=1, clip=0.1, graph=graph)
+        losses = []
+        for _ in range(3):
+            loss, ld, stepped = tr.training_step(batch)
+            assert stepped
+            losses.append(float(loss))
+        if graph:
+            assert tr._graphed is not None
+        results.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < 2e-4 * max(1.0, abs(a)), (l0, l1)
+    for n in p0:
+        assert (p0[n] - p1[n]).abs().max() < 2e-5 * max(1.0, float(p0[n].abs().max())), n
+
+
 def test_backbone_folded_inference_path_matches_unfolded():
     """Frozen-BN folding + MIOpen fused conv/bias/ReLU (inference path) vs the plain module path."""
     from egtr_amd.backbone import ResNet50Features

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Wall-clock split of the training loss (matcher + every loss term) at the BASELINE configs[2] shape, with a device
+synchronisation after each piece.  python tools/loss_phases.py [--batch 4]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    model, cfg, _ = bench.build_model(dev, {"dropout": 0.1})
+    model.train()
+    torch.manual_seed(100)
+    b = {"pixel_values": torch.randn(a.batch, 3, bench.H_IMG, bench.W_IMG, device=dev),
+         "pixel_mask": torch.ones(a.batch, bench.H_IMG, bench.W_IMG, dtype=torch.long, device=dev),
+         "labels": bench.make_targets(a.batch, cfg, dev, 7)}
+    kw = dict(pixel_values=b["pixel_values"], pixel_mask=b["pixel_mask"], output_attentions=False,
+              output_attention_states=True, output_hidden_states=True)
+    crit = None
+    import egtr_amd.egtr as E
+    orig = E.SceneGraphGenerationLoss.forward
+    times = {}
+
+    def timed(name, fn, *args):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn(*args)
+        torch.cuda.synchronize()
+        times[name] = times.get(name, 0.0) + time.perf_counter() - t0
+        return r
+
+    def fwd(self, outputs, targets):
+        outputs_without_aux = {k: v for k, v in outputs.items() if k not in ("auxiliary_outputs", "enc_outputs")}
+        indices, matching_costs = timed("matcher(main)", self.matcher, outputs_without_aux, targets)
+        num_boxes = float(max(sum(len(t["class_labels"]) for t in targets), 1))
+        losses = {}
+        for loss in self.losses:
+            losses.update(timed("loss:" + loss, self.get_loss, loss, outputs, targets, indices, matching_costs, num_boxes))
+        if "auxiliary_outputs" in outputs:
+            for i, aux in enumerate(outputs["auxiliary_outputs"]):
+                indices, matching_costs = timed("matcher(aux)", self.matcher, aux, targets)
+                for loss in self.losses:
+                    if loss in ["masks", "relations", "uncertainty"]:
+                        continue
+                    l_dict = timed("aux loss:" + loss, self.get_loss, loss, aux, targets, indices, matching_costs, num_boxes)
+                    losses.update({k + f"_{i}": v for k, v in l_dict.items()})
+        return losses
+
+    E.SceneGraphGenerationLoss.forward = fwd
+    n = 5
+    for it in range(n + 2):
+        if it == 2:
+            times.clear()
+        out = model(labels=b["labels"], **kw)
+        out.loss.backward()
+    tot = sum(times.values())
+    print("loss phases (ms per step, batch %d): " % a.batch + ", ".join(f"{k} {1e3 * v / n:.2f}" for k, v in times.items())
+          + f"; total {1e3 * tot / n:.2f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--graph", type=int, default=0, help="1 = forward / backward of the static part replayed from HIP graphs")
     a = ap.parse_args()
     from egtr_amd.runtime import configure_optimizers
     dev = torch.device("cuda:0")
@@ -36,6 +37,30 @@ def main():
 
     kw = dict(pixel_values=b["pixel_values"], pixel_mask=b["pixel_mask"], output_attentions=False,
               output_attention_states=True, output_hidden_states=True)
+    if a.graph:
+        from egtr_amd.runtime import DataParallelTrainer
+        tr = DataParallelTrainer(model, optimizer=opt, accumulate=1, clip=0.1, graph=True)
+        acc = [0.0] * 4
+        for it in range(a.steps + 3):
+            t0 = sync()
+            tens = tr._graphed_body(b["pixel_values"], b["pixel_mask"])
+            t1 = sync()
+            loss, _ = model.loss_from_tensors(tens, b["labels"])
+            t2 = sync()
+            loss.backward()
+            t3 = sync()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            t4 = sync()
+            if it >= 3:
+                for k, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                    acc[k] += d
+        print("graphed train step phases (ms, batch %d): " % a.batch +
+              ", ".join(f"{n} {1e3 * v / a.steps:.1f}" for n, v in
+                        zip(["forward graph replay", "matcher + loss", "backward (loss eager + graph replay)",
+                             "clip+step"], acc)) + f"; step = {1e3 * sum(acc) / a.steps:.1f}")
+        return
     for it in range(a.steps + 3):
         t0 = sync()
         out = model(labels=None, **kw)
