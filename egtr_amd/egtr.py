@@ -351,6 +351,7 @@ class SceneGraphGenerationLoss(nn.Module):
         self.nonmatching_cost = (-torch.log(torch.tensor(1e-8)) * matcher.class_cost + 4 * matcher.bbox_cost
                                  + 2 * matcher.giou_cost - torch.log(torch.tensor((1.0 / smoothing) - 1.0)))
         self.connectivity_loss = torch.nn.BCEWithLogitsLoss(reduction="none")
+        self.force_device_relations = False  # tests: take the sync-light relation-loss path on CPU tensors too
 
     def loss_labels(self, outputs, targets, indices, matching_costs, num_boxes):
         """Focal classification loss (egtr:611-659)."""
@@ -378,12 +379,16 @@ class SceneGraphGenerationLoss(nn.Module):
 
     @torch.no_grad()
     def loss_uncertainty(self, outputs, targets, indices, matching_costs, num_boxes):
-        vals = []
+        # egtr:671-690: mean of u[s] * u[o] over the non-zero target triplets of the matched block.  Evaluated as
+        # (sum over pairs of count * u u^T) / (number of triplets): no nonzero() index list, no host synchronisation.
+        num, den = [], []
         for target, index, matching_cost in zip(targets, indices, matching_costs):
-            nonzero_index = target["rel"][index[1], :, :][:, index[1], :].nonzero()
-            uncertainty = matching_cost.sigmoid()
-            vals.append(uncertainty[nonzero_index[:, 0]] * uncertainty[nonzero_index[:, 1]])
-        return {"uncertainty": torch.cat(vals).mean()}
+            tidx = index[1].to(target["rel"].device)
+            cnt = (target["rel"][tidx][:, tidx] != 0).sum(-1).to(matching_cost.dtype)   # [T, T]
+            u = matching_cost.sigmoid()
+            num.append((cnt * torch.outer(u, u)).sum())
+            den.append(cnt.sum())
+        return {"uncertainty": torch.stack(num).sum() / torch.stack(den).sum()}
 
     def loss_boxes(self, outputs, targets, indices, matching_costs, num_boxes):
         assert "pred_boxes" in outputs, "No predicted boxes found in outputs"
@@ -412,6 +417,11 @@ class SceneGraphGenerationLoss(nn.Module):
     def loss_relations(self, outputs, targets, indices, matching_costs, num_boxes):
         """egtr:754-815.  Index tensors are moved to the logits' device once per image (the reference indexes
         device tensors with CPU index tensors, egtr:761-785; same values)."""
+        if (self.model_training and (outputs["pred_rel"].is_cuda or self.force_device_relations)
+                and (self.rel_sample_negatives is not None or self.rel_sample_nonmatching is not None)
+                and (self.rel_sample_negatives is None or self.rel_sample_negatives_largest)
+                and (self.rel_sample_nonmatching is None or self.rel_sample_nonmatching_largest)):
+            return self._loss_relations_device(outputs, targets, indices, matching_costs)
         losses, connect_losses = [], []
         dev = outputs["pred_rel"].device
         for i, ((src_index, target_index), target, matching_cost) in enumerate(zip(indices, targets, matching_costs)):
@@ -437,6 +447,92 @@ class SceneGraphGenerationLoss(nn.Module):
                 loss = self._loss_relations(pred_rel, target_rel, full_matching_cost, None, None)
             losses.append(loss)
         return {"loss_rel": torch.cat(losses).mean(), "loss_connectivity": torch.stack(connect_losses).mean()}
+
+    def _loss_relations_device(self, outputs, targets, indices, matching_costs):
+        """Training-mode relation / connectivity losses (egtr:754-923 with ``*_largest`` sampling) without the
+        reference's per-image ``nonzero()`` index lists (~2 M x 3 int64 per image for the non-matching candidates) and
+        their host synchronisations -- ONE batched synchronisation per step for the candidate counts.  Same value and
+        gradient: both losses are means over a set of elements, so they are evaluated in the un-permuted query order
+        as (sum of selected BCE terms) / (number of selected terms); the hard negatives are the top-k scores of the
+        candidate sets, selected with a masked ``topk`` instead of ``topk`` over gathered index lists (ties have equal
+        logits and zero targets, hence equal loss terms)."""
+        pred_rel_all, pred_conn_all = outputs["pred_rel"], outputs["pred_connectivity"]
+        dev = pred_rel_all.device
+        N, R = self.num_object_queries, self.num_rel_labels
+        nmc = float(self.nonmatching_cost)
+        per_image = []
+        counts = []
+        for (src_index, target_index), target, matching_cost in zip(indices, targets, matching_costs):
+            T = int(len(src_index))
+            sidx, tidx = src_index.to(dev), target_index.to(dev)
+            # target row of every query: matched -> its target, unmatched (ascending) -> rows T, T+1, ... (egtr:761-768)
+            unmatched = torch.ones(N, dtype=torch.bool)
+            unmatched[src_index] = False
+            tq = torch.empty(N, dtype=torch.int64)
+            tq[src_index] = target_index
+            tq[unmatched] = torch.arange(T, N)
+            tq = tq.to(dev)
+            rel_t = target["rel"]
+            block_t = rel_t[tidx][:, tidx]                       # [T, T, R] targets of the matched block
+            counts.append(torch.stack([(block_t != 0).sum(), (block_t != 1.0).sum()]))
+            per_image.append((T, sidx, tidx, tq, block_t, matching_cost))
+        cnt = torch.stack(counts).tolist() if counts else []     # the one host synchronisation
+        rel_sum, rel_cnt, conn_losses = [], 0, []
+        for i, (T, sidx, tidx, tq, block_t, matching_cost) in enumerate(per_image):
+            n_true, n_false = int(cnt[i][0]), int(cnt[i][1])
+            pred = pred_rel_all[i]                               # [N, N, R]
+            cost_q = torch.full((N,), nmc, device=dev, dtype=matching_cost.dtype)
+            cost_q[sidx] = matching_cost
+            wq = 1.0 - cost_q.sigmoid()
+            rel_t = targets[i]["rel"]
+            # connectivity (egtr:786-793): target = any non-zero relation between the two queries' target rows
+            tc = (rel_t != 0).any(-1).to(pred.dtype)             # [N, N] over target rows
+            conn_losses.append(self.connectivity_loss(pred_conn_all[i], tc[tq][:, tq].unsqueeze(-1)))
+            # matched block
+            block_p = pred[sidx][:, sidx]                        # [T, T, R]
+            wb = wq[sidx]
+            wblock = (wb[:, None] * wb[None, :]).unsqueeze(-1)
+            l_block = self.rel_loss(block_p, block_t * wblock)
+            parts = [(l_block * (block_t != 0)).sum()]
+            n_sel = n_true
+            false_mask = block_t != 1.0
+            if self.rel_sample_negatives is None:
+                parts.append((l_block * false_mask).sum())
+                n_sel += n_false
+            else:
+                k1 = min(n_true * self.rel_sample_negatives, n_false) if n_true > 0 else 0
+                if k1 > 0:
+                    sel = torch.topk(block_p.detach().masked_fill(~false_mask, float("-inf")).reshape(-1), k1)[1]
+                    parts.append(self.rel_loss(block_p.reshape(-1)[sel],
+                                               (block_t * wblock).reshape(-1)[sel]).sum())
+                    n_sel += k1
+            # non-matching region: every (a, b, r) with a or b unmatched
+            mq = torch.zeros(N, dtype=torch.bool, device=dev)
+            mq[sidx] = True
+            nm_mask = ~(mq[:, None] & mq[None, :])               # [N, N]
+            n_nm = (N * N - T * T) * R
+            if self.rel_sample_nonmatching is None:
+                tgt_full = rel_t[tq][:, tq] * (wq[:, None] * wq[None, :]).unsqueeze(-1)
+                parts.append((self.rel_loss(pred, tgt_full) * nm_mask.unsqueeze(-1)).sum())
+                n_sel += n_nm
+            else:
+                k2 = min(n_true * self.rel_sample_nonmatching, n_nm) if n_true > 0 else 0
+                if k2 > 0:
+                    sel = torch.topk(pred.detach().masked_fill(~nm_mask.unsqueeze(-1), float("-inf")).reshape(-1),
+                                     k2)[1]
+                    a = torch.div(sel, N * R, rounding_mode="floor")
+                    b = torch.div(sel, R, rounding_mode="floor") % N
+                    r = sel % R
+                    tgt = rel_t[tq[a], tq[b], r] * (wq[a] * wq[b])
+                    parts.append(self.rel_loss(pred.reshape(-1)[sel], tgt).sum())
+                    n_sel += k2
+            rel_sum.append(torch.stack(parts).sum())
+            rel_cnt += n_sel
+        if rel_cnt > 0:
+            loss_rel = torch.stack(rel_sum).sum() / rel_cnt
+        else:  # no relation in the batch: the reference takes the mean of an empty tensor
+            loss_rel = torch.cat([pred_rel_all.new_zeros(0)]).mean()
+        return {"loss_rel": loss_rel, "loss_connectivity": torch.stack(conn_losses).mean()}
 
     def _loss_relations(self, pred_rel, target_rel, matching_cost, rel_sample_negatives, rel_sample_nonmatching):
         """egtr:817-923."""

@@ -116,6 +116,40 @@ def test_matcher_indices_bit_exact(small):
         assert np.abs(c.numpy() - g[f"match_cost_{i}"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("neg,nm", [(80, 80), (2, 3), (None, 5), (4, None), (0, 7)])
+def test_relation_loss_device_path_equals_reference_loop(neg, nm):
+    """The sync-light training path of loss_relations (masked top-k, sums / counts in un-permuted query order) against
+    the line-by-line mirror of egtr:754-923 (index lists via nonzero) on the same inputs: loss_rel, loss_connectivity
+    and the gradients wrt pred_rel / pred_connectivity."""
+    import weights as W
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher
+    from egtr_amd.egtr import SceneGraphGenerationLoss
+    N, C, R, B = 24, 11, 6, 3
+    targets = W.make_targets(21, B, N, C, R, tmin=0, tmax=7)
+    targets[1]["rel"].zero_()  # an image without relations
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(B, N, C, generator=g)
+    boxes = torch.rand(B, N, 4, generator=g) * 0.5 + 0.25
+    matcher = DeformableDetrHungarianMatcher(class_cost=2, bbox_cost=5, giou_cost=2, smoothing=1e-14)
+    indices, costs = matcher({"logits": logits, "pred_boxes": boxes}, targets)
+    res = []
+    for force in (False, True):
+        crit = SceneGraphGenerationLoss(matcher=matcher, num_object_queries=N, num_classes=C, num_rel_labels=R,
+                                        eos_coef=0.1, losses=["relations"], smoothing=1e-14, rel_sample_negatives=neg,
+                                        rel_sample_nonmatching=nm, model_training=True, focal_alpha=0.25,
+                                        rel_sample_negatives_largest=True, rel_sample_nonmatching_largest=True)
+        crit.force_device_relations = force
+        pr = torch.randn(B, N, N, R, generator=torch.Generator().manual_seed(6)).requires_grad_(True)
+        pc = torch.randn(B, N, N, 1, generator=torch.Generator().manual_seed(7)).requires_grad_(True)
+        out = crit.loss_relations({"pred_rel": pr, "pred_connectivity": pc}, targets, indices, costs, 1.0)
+        (out["loss_rel"] * 3.0 + out["loss_connectivity"]).backward()
+        res.append((float(out["loss_rel"]), float(out["loss_connectivity"]), pr.grad.clone(), pc.grad.clone()))
+    (a_rel, a_conn, a_gr, a_gc), (b_rel, b_conn, b_gr, b_gc) = res
+    assert abs(a_rel - b_rel) < 1e-6 * max(1.0, abs(a_rel)) and abs(a_conn - b_conn) < 1e-6
+    assert (a_gr - b_gr).abs().max() < 1e-7 and (a_gc - b_gc).abs().max() < 1e-7
+    assert int((a_gr != 0).sum()) == int((b_gr != 0).sum())  # the same number of selected triplets
+
+
 def test_aux_loss_matches_reference(small, cpu_kernels, golden_dir):
     import weights as W
     g, cfg_dict, shapes = small
