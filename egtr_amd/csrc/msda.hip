@@ -517,8 +517,8 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   if (variant == 0 && fast && env_fwd_variant() > 0) variant = env_fwd_variant();
   if (variant == 0)
     variant = !fast ? 3 : ((num_query == spatial_size && num_query >= 1024 && !(num_point & 1)) ? kAutoEncoderVariant : 1);
-  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 12)) && !fast) return EGTR_E_UNSUPPORTED;
-  if (variant >= 8 && variant <= 12) {
+  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 13)) && !fast) return EGTR_E_UNSUPPORTED;
+  if (variant >= 8 && variant <= 13) {
     if (num_point & 1) return EGTR_E_UNSUPPORTED;
     return egtr_launch_msda_fwd_win_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
                                         batch, num_query, spatial_size, num_levels, num_point, variant - 8, nullptr,
@@ -562,7 +562,7 @@ extern "C" int egtr_msda_win_phase_cycles(egtr_stream_t stream, const float* val
                                           unsigned long long* cycles) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out || !cycles)
     return EGTR_E_ARG;
-  if (batch <= 0 || spatial_size <= 0 || num_query <= 0 || kind < 0 || kind > 3) return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_query <= 0 || kind < 0 || kind > 5) return EGTR_E_ARG;
   if (num_levels < 1 || num_levels > 4 || num_levels * num_point != 16 || (num_point & 1) ||
       (long long)spatial_size * 1024 >= (1ll << 31))
     return EGTR_E_UNSUPPORTED;
@@ -601,12 +601,12 @@ extern "C" int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const f
   if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
       (long long)spatial_size * 1024 >= (1ll << 31) || nq >= (1ll << 27))
     return EGTR_E_UNSUPPORTED;
-  if (variant != 0 && variant != 1 && (variant < 8 || variant > 12)) return EGTR_E_UNSUPPORTED;
+  if (variant != 0 && variant != 1 && (variant < 8 || variant > 13)) return EGTR_E_UNSUPPORTED;
   if (variant == 0) {
     // automatic: the LDS-window kernel for encoder-shaped calls (queries = the pixels of the levels), the
     // wave-per-query kernel for short / arbitrary query lists (decoder)
     const int e = env_fwd_variant();
-    variant = (e == 1 || (e >= 8 && e <= 12)) ? e : kAutoEncoderVariant;
+    variant = (e == 1 || (e >= 8 && e <= 13)) ? e : kAutoEncoderVariant;
     if (!(num_query == spatial_size && num_query >= 1024)) variant = 1;
   }
   if (variant >= 8)

@@ -32,6 +32,10 @@ using namespace egtr_msda;
 
 namespace {
 
+#ifndef EGTR_WIN_ABLATE
+#define EGTR_WIN_ABLATE 0  // timing ablations (wrong results): 1 = no window copy, 2 = no gather
+#endif
+
 constexpr int kZeroPx = 2;  // all-zero pixels at the start of the window buffer (target of invalid samples)
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -409,9 +413,13 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_win_f32(
 // handled per image (an image without padded tokens -- every bs=1 inference -- never looks at the mask again).
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int kItemsPerEpoch = 64;  // work items a workgroup decodes at once into its LDS table
 
-template <bool FUSED, int TH, int TW, int WINPX, int WPS, bool PROF = false>
+// NBUF = 2: the double-buffered pipeline described above (2 workgroups per CU).  NBUF = 1 (variant 13): the same lean
+// code single-buffered -- geometry -> Y -> pack + copy + records -> wait -> X -> gather -- with 4 workgroups per CU, so that
+// the phases of DIFFERENT workgroups overlap (a gathering workgroup keeps the LDS pipe busy while its neighbours run
+// scalar packing code or wait for their window copy); only the loc / attn rows of the next item are prefetched.
+// EPOCH = work items a workgroup decodes at once into its LDS table.
+template <bool FUSED, int TH, int TW, int WINPX, int WPS, bool PROF = false, int NBUF = 2, int EPOCH = 64>
 __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int S,
@@ -437,11 +445,11 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
   constexpr int WPXB = kZeroPx + WINPX;  // pixels per window buffer
   static_assert(TW == 8, "a wave gathers one row of 8 x-adjacent queries");
   static_assert(WPXB * 128 < 65536, "LDS addresses are packed into 16 bits");
-  __shared__ __attribute__((aligned(16))) float4 s_win[2][WPXB * 8];
-  __shared__ __attribute__((aligned(16))) float4 s_w[2][16 * RS];  // [buffer][sample][query] weights
-  __shared__ __attribute__((aligned(16))) uint4 s_a[2][4 * RS];    // [buffer][level][query][point] addresses
+  __shared__ __attribute__((aligned(16))) float4 s_win[NBUF][WPXB * 8];
+  __shared__ __attribute__((aligned(16))) float4 s_w[NBUF][16 * RS];  // [buffer][sample][query] weights
+  __shared__ __attribute__((aligned(16))) uint4 s_a[NBUF][4 * RS];    // [buffer][level][query][point] addresses
   __shared__ __attribute__((aligned(16))) int4 s_bbox[2][4];       // [parity][level]{ymin, ymax, xmin, xmax}
-  __shared__ __attribute__((aligned(16))) int4 s_item[kItemsPerEpoch][2];  // {b, head, qbase, wq}, {wlim, hlim, -, -}
+  __shared__ __attribute__((aligned(16))) int4 s_item[EPOCH][2];  // {b, head, qbase, wq}, {wlim, hlim, -, -}
   __shared__ unsigned s_padded;                                     // bit b: image b has padded tokens
 
   const int tid = threadIdx.x, c4 = tid & 7;
@@ -482,15 +490,15 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
     const int per_img = (c0 + c1 + c2 + c3) * 8;
     nwork = B * per_img;
     if ((int)(blockIdx.x >> 3) >= nwork) return;
-    // epochs of kItemsPerEpoch items: one epoch unless the batch is large
-    for (int e = tid; e < kItemsPerEpoch; e += NT) {
+    // epochs of EPOCH items: one epoch unless the batch is large
+    for (int e = tid; e < EPOCH; e += NT) {
       const int k = (int)(blockIdx.x >> 3) + e * kstride;  // epoch 0; later epochs re-run this block (see below)
       (void)k;
     }
     // (table filled per epoch inside the epoch loop below: needs the tile map, which stays in scalar registers only
     //  for the few instructions of fill_table)
     auto fill_table = [&](int kfirst) {
-      if (tid < kItemsPerEpoch) {
+      if (tid < EPOCH) {
         const int k = kfirst + tid * kstride;
         int4 a = make_int4(0, 0, 0, 8), b4 = make_int4(0, 0, 0, 0);
         if (k < nwork) {
@@ -542,14 +550,19 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
       rp = make_float2(0.f, 0.f);
       qv = live ? slot_query(it, col) : -1;
       if (qv >= 0) {
-        const size_t qg = (size_t)it.b * Lq + qv;
+        // wave-uniform 64-bit bases + 32-bit lane offsets (the launcher guarantees Lq * row pitch < 2^31 bytes)
         if (FUSED) {
-          lc = reinterpret_cast<const float4*>(loc + qg * ld_off)[it.head * 8 + c4];
-          aw = reinterpret_cast<const float2*>(attn + qg * ld_logit)[it.head * 8 + c4];
-          rp = *reinterpret_cast<const float2*>(ref + (qg * 4 + lvl) * 2);
+          const char* lb = reinterpret_cast<const char*>(loc + (size_t)it.b * Lq * ld_off + it.head * 32);
+          const char* ab_ = reinterpret_cast<const char*>(attn + (size_t)it.b * Lq * ld_logit + it.head * 16);
+          const char* rb = reinterpret_cast<const char*>(ref + (size_t)it.b * Lq * 8);
+          lc = *reinterpret_cast<const float4*>(lb + (unsigned)(qv * (ld_off * 4) + c4 * 16));
+          aw = *reinterpret_cast<const float2*>(ab_ + (unsigned)(qv * (ld_logit * 4) + c4 * 8));
+          rp = *reinterpret_cast<const float2*>(rb + (unsigned)(qv * 32 + lvl * 8));
         } else {
-          lc = reinterpret_cast<const float4*>(loc + (qg * 8 + it.head) * 32)[c4];
-          aw = reinterpret_cast<const float2*>(attn + (qg * 8 + it.head) * 16)[c4];
+          const char* lb = reinterpret_cast<const char*>(loc + ((size_t)it.b * Lq * 8 + it.head) * 32);
+          const char* ab_ = reinterpret_cast<const char*>(attn + ((size_t)it.b * Lq * 8 + it.head) * 16);
+          lc = *reinterpret_cast<const float4*>(lb + (unsigned)(qv * 1024 + c4 * 16));
+          aw = *reinterpret_cast<const float2*>(ab_ + (unsigned)(qv * 512 + c4 * 8));
         }
       }
     };
@@ -637,37 +650,46 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
         }
       }
       float4* winb = s_win[buf];
-#pragma unroll
-      for (int l = 3; l >= 0; --l) {
-        if (wh[l] == 0) continue;
-        const int Hl = sel4(G.H0, G.H1, G.H2, G.H3, l), Wl = sel4(G.W0, G.W1, G.W2, G.W3, l);
-        const int sl = sel4(G.s0, G.s1, G.s2, G.s3, l);
-        // rows of the window inside the level: [r_lo, r_hi); this wave copies r_lo + wave, + NW, ...
-        const int r_lo = max(0, -wy0[l]), r_hi = min(wh[l], Hl - wy0[l]);
-        for (int cb = 0; cb < ww[l]; cb += 8) {
-          const int cc = cb + col, xx = wx0[l] + cc;
-          if (cc < ww[l] && (unsigned)xx < (unsigned)Wl) {
-            const unsigned voff = (unsigned)(xx * 1024 + c4 * 16);
-            const int r0 = r_lo + ((wave + l) & (NW - 1));  // rotate the dealing so no wave always gets the extra row
-            const char* grow = vbase + (size_t)(sl + (wy0[l] + r0) * Wl) * 1024;
-            int lds = (kZeroPx + base[l] + r0 * ww[l] + cb) * 8;
-            for (int rr = r0; rr < r_hi; rr += NW) {
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + voff),
-                                               (__attribute__((address_space(3))) void*)(winb + lds), 16, 0, 0);
-              grow += (size_t)NW * Wl * 1024;
-              lds += NW * ww[l] * 8;
+      {
+        // window copy: wave w copies level 3 - (w & 3) (rows dealt over the NW / 4 waves that share the level), so the
+        // scalar set-up below runs once per wave instead of once per level per wave
+        const int l = 3 - (wave & 3), rsub = wave >> 2;
+        constexpr int NSUB = NW / 4 > 0 ? NW / 4 : 1;
+        const int wwl = sel4(ww[0], ww[1], ww[2], ww[3], l), whl = sel4(wh[0], wh[1], wh[2], wh[3], l);
+        if (whl != 0 && (NW >= 4 || true)) {
+          const int wy0l = sel4(wy0[0], wy0[1], wy0[2], wy0[3], l), wx0l = sel4(wx0[0], wx0[1], wx0[2], wx0[3], l);
+          const int basel = sel4(base[0], base[1], base[2], base[3], l);
+          const int Hl = sel4(G.H0, G.H1, G.H2, G.H3, l), Wl = sel4(G.W0, G.W1, G.W2, G.W3, l);
+          const int sl = sel4(G.s0, G.s1, G.s2, G.s3, l);
+          // rows of the window inside the level: [r_lo, r_hi)
+          const int r_lo = max(0, -wy0l), r_hi = min(whl, Hl - wy0l);
+          for (int cb = 0; cb < wwl; cb += 8) {
+            const int cc = cb + col, xx = wx0l + cc;
+            if (cc < wwl && (unsigned)xx < (unsigned)Wl) {
+              const unsigned voff = (unsigned)(xx * 1024 + c4 * 16);
+              const int r0 = r_lo + rsub;
+              const char* grow = vbase + (size_t)(sl + (wy0l + r0) * Wl) * 1024;
+              int lds = (kZeroPx + basel + r0 * wwl + cb) * 8;
+              for (int rr = r0; rr < r_hi; rr += NSUB) {
+#if EGTR_WIN_ABLATE != 1
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + voff),
+                                                 (__attribute__((address_space(3))) void*)(winb + lds), 16, 0, 0);
+#endif
+                grow += (size_t)NSUB * Wl * 1024;
+                lds += NSUB * wwl * 8;
+              }
             }
           }
-        }
-        // zero apron: window pixels outside the level (only tiles whose samples straddle an image border)
-        if (wy0[l] < 0 || wy0[l] + wh[l] > Hl || wx0[l] < 0 || wx0[l] + ww[l] > Wl) {
-          const int npx = ww[l] * wh[l];
-          const float inv = __frcp_rn((float)ww[l]);
-          for (int p = ql; p < npx; p += TQ) {
-            const int rr = (int)(((float)p + 0.5f) * inv);  // exact for p, ww < 4096
-            const int cc = p - rr * ww[l];
-            if ((unsigned)(wy0[l] + rr) >= (unsigned)Hl || (unsigned)(wx0[l] + cc) >= (unsigned)Wl)
-              winb[(kZeroPx + base[l] + p) * 8 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+          // zero apron: window pixels outside the level (only tiles whose samples straddle an image border)
+          if (rsub == 0 && (wy0l < 0 || wy0l + whl > Hl || wx0l < 0 || wx0l + wwl > Wl)) {
+            const int npx = wwl * whl;
+            const float inv = __frcp_rn((float)wwl);
+            for (int p = col; p < npx; p += 8) {
+              const int rr = (int)(((float)p + 0.5f) * inv);  // exact for p, ww < 4096
+              const int cc = p - rr * wwl;
+              if ((unsigned)(wy0l + rr) >= (unsigned)Hl || (unsigned)(wx0l + cc) >= (unsigned)Wl)
+                winb[(kZeroPx + basel + p) * 8 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
           }
         }
       }
@@ -719,6 +741,7 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
     };
 
     auto gather = [&](const Item& it, int buf, unsigned staged, bool wait_dma) {
+      (void)0;
       const int qo = slot_query(it, gcol);
       // explicit address spaces: the two branches of the generic path must not be merged into flat loads
       typedef const __attribute__((address_space(3))) char* lds_cp;
@@ -729,6 +752,9 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
       const unsigned coff = gc * 16;
       const glb_cp glb = (glb_cp)(reinterpret_cast<const char*>(value) + (size_t)it.b * S * 1024 + it.head * 128 + gc * 16);
       f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#if EGTR_WIN_ABLATE == 2
+      staged = 0x10u;  // timing ablation: no gather at all (wrong results)
+#endif
 #define EGTR_WIN_FMA16()                                            \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
         acc0 = pk_fma(f32x2{v[j][0].x, v[j][0].y}, w[j].x, acc0);   \
@@ -740,7 +766,7 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
         acc0 = pk_fma(f32x2{v[j][3].x, v[j][3].y}, w[j].w, acc0);   \
         acc1 = pk_fma(f32x2{v[j][3].z, v[j][3].w}, w[j].w, acc1);   \
       }
-      if (staged == 0xFu) {
+      if (staged == 0xFu && WPS <= 2) {
         // every window is in LDS (the regular case).  Software pipeline over the levels: the 20 ds_read_b128 of
         // level l+1 are in flight while the 32 v_pk_fma_f32 of level l issue (two register buffers).
         uint4 A[4];
@@ -776,36 +802,84 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
             acc1 = pk_fma(f32x2{vv[bf][j][3].z, vv[bf][j][3].w}, wv[bf][j].w, acc1);
           }
         }
-      } else {
-#pragma unroll 1
+      } else if (staged == 0xFu) {
+        // every window is in LDS, 4 waves per SIMD (<= 128 registers): two samples (10 ds_read_b128) at a time; the
+        // other waves of the SIMD cover the LDS latency
+#pragma unroll
         for (int l = 0; l < 4; ++l) {
           const uint4 A = ab[l * RS];
           const unsigned cd[4] = {A.x, A.y, A.z, A.w};
-          float4 w[4], v[4][4];
-          if ((staged >> l) & 1u) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              w[j] = wb[(l * 4 + j) * RS];
-              const unsigned a0 = (cd[j] & 0xffffu) | coff, a1 = (cd[j] >> 16) | coff;
+          for (int h = 0; h < 2; ++h) {
+            float4 w[2], v[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              w[j] = wb[(l * 4 + 2 * h + j) * RS];
+              const unsigned a0 = (cd[2 * h + j] & 0xffffu) | coff, a1 = (cd[2 * h + j] >> 16) | coff;
               v[j][0] = lds_ld4(win + a0);
               v[j][1] = lds_ld4(win + a0 + 128);
               v[j][2] = lds_ld4(win + a1);
               v[j][3] = lds_ld4(win + a1 + 128);
             }
-          } else {
-            const unsigned Wb = (unsigned)sel4(G.W0, G.W1, G.W2, G.W3, l) * 1024u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              w[j] = wb[(l * 4 + j) * RS];
-              const unsigned o00 = (cd[j] >> 2) << 10;
-              const unsigned dxb = (cd[j] & 2u) ? 1024u : 0u, dyb = (cd[j] & 1u) ? Wb : 0u;
-              v[j][0] = glb_ld4(glb + o00);
-              v[j][1] = glb_ld4(glb + o00 + dxb);
-              v[j][2] = glb_ld4(glb + o00 + dyb);
-              v[j][3] = glb_ld4(glb + o00 + dyb + dxb);
+            for (int j = 0; j < 2; ++j) {
+              acc0 = pk_fma(f32x2{v[j][0].x, v[j][0].y}, w[j].x, acc0);
+              acc1 = pk_fma(f32x2{v[j][0].z, v[j][0].w}, w[j].x, acc1);
+              acc0 = pk_fma(f32x2{v[j][1].x, v[j][1].y}, w[j].y, acc0);
+              acc1 = pk_fma(f32x2{v[j][1].z, v[j][1].w}, w[j].y, acc1);
+              acc0 = pk_fma(f32x2{v[j][2].x, v[j][2].y}, w[j].z, acc0);
+              acc1 = pk_fma(f32x2{v[j][2].z, v[j][2].w}, w[j].z, acc1);
+              acc0 = pk_fma(f32x2{v[j][3].x, v[j][3].y}, w[j].w, acc0);
+              acc1 = pk_fma(f32x2{v[j][3].z, v[j][3].w}, w[j].w, acc1);
             }
           }
-          EGTR_WIN_FMA16()
+        }
+      } else {
+#pragma unroll 1
+        for (int l = 0; l < ((staged & 0x10u) ? 0 : 4); ++l) {
+          const uint4 A = ab[l * RS];
+          const unsigned cd[4] = {A.x, A.y, A.z, A.w};
+          const bool in_lds = (staged >> l) & 1u;
+          const unsigned Wb = (unsigned)sel4(G.W0, G.W1, G.W2, G.W3, l) * 1024u;
+#pragma unroll 1
+          for (int h = 0; h < 2; ++h) {
+            float4 w[2], v[2][4];
+            if (in_lds) {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const unsigned c = h ? (j ? cd[3] : cd[2]) : (j ? cd[1] : cd[0]);
+                w[j] = wb[(l * 4 + 2 * h + j) * RS];
+                const unsigned a0 = (c & 0xffffu) | coff, a1 = (c >> 16) | coff;
+                v[j][0] = lds_ld4(win + a0);
+                v[j][1] = lds_ld4(win + a0 + 128);
+                v[j][2] = lds_ld4(win + a1);
+                v[j][3] = lds_ld4(win + a1 + 128);
+              }
+            } else {
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const unsigned c = h ? (j ? cd[3] : cd[2]) : (j ? cd[1] : cd[0]);
+                w[j] = wb[(l * 4 + 2 * h + j) * RS];
+                const unsigned o00 = (c >> 2) << 10;
+                const unsigned dxb = (c & 2u) ? 1024u : 0u, dyb = (c & 1u) ? Wb : 0u;
+                v[j][0] = glb_ld4(glb + o00);
+                v[j][1] = glb_ld4(glb + o00 + dxb);
+                v[j][2] = glb_ld4(glb + o00 + dyb);
+                v[j][3] = glb_ld4(glb + o00 + dyb + dxb);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              acc0 = pk_fma(f32x2{v[j][0].x, v[j][0].y}, w[j].x, acc0);
+              acc1 = pk_fma(f32x2{v[j][0].z, v[j][0].w}, w[j].x, acc1);
+              acc0 = pk_fma(f32x2{v[j][1].x, v[j][1].y}, w[j].y, acc0);
+              acc1 = pk_fma(f32x2{v[j][1].z, v[j][1].w}, w[j].y, acc1);
+              acc0 = pk_fma(f32x2{v[j][2].x, v[j][2].y}, w[j].z, acc0);
+              acc1 = pk_fma(f32x2{v[j][2].z, v[j][2].w}, w[j].z, acc1);
+              acc0 = pk_fma(f32x2{v[j][3].x, v[j][3].y}, w[j].w, acc0);
+              acc1 = pk_fma(f32x2{v[j][3].z, v[j][3].w}, w[j].w, acc1);
+            }
+          }
         }
       }
 #undef EGTR_WIN_FMA16
@@ -817,16 +891,17 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
       // the next item's window copy had the whole gather to land; wait for it BEFORE the stores join the queue
       if (wait_dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tick(5);
-      if (qo >= 0)
-        reinterpret_cast<float4*>(out + (((size_t)it.b * Lq + qo) * 8 + it.head) * 32)[gc] =
-            make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+      if (qo >= 0) {
+        char* ob = reinterpret_cast<char*>(out + ((size_t)it.b * Lq * 8 + it.head) * 32);
+        *reinterpret_cast<float4*>(ob + (unsigned)(qo * 1024 + gc * 16)) = make_float4(acc0.x, acc0.y, acc1.x, acc1.y);
+      }
     };
 
     // ---- prologue ------------------------------------------------------------------------------------------------
     if (tid < 8) reinterpret_cast<int4*>(s_bbox)[tid] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);
     if (tid < kZeroPx * 8) {
       s_win[0][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-      s_win[1][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+      s_win[NBUF - 1][tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (tid == 0) s_padded = 0;
     fill_table((int)(blockIdx.x >> 3));
@@ -843,19 +918,42 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
       }
     }
     // ---- epochs x pipeline -----------------------------------------------------------------------------------------
-    for (int kfirst = (int)(blockIdx.x >> 3); kfirst < nwork; kfirst += kItemsPerEpoch * kstride) {
+    for (int kfirst = (int)(blockIdx.x >> 3); kfirst < nwork; kfirst += EPOCH * kstride) {
       if (kfirst != (int)(blockIdx.x >> 3)) {
         wg_barrier();  // every wave has finished the previous epoch (its table and buffers are free)
         fill_table(kfirst);
         if (tid < 8) reinterpret_cast<int4*>(s_bbox)[tid] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);
         wg_barrier();
       }
-      const int nit = min(kItemsPerEpoch, (nwork - kfirst + kstride - 1) / kstride);  // items of this epoch
+      const int nit = min(EPOCH, (nwork - kfirst + kstride - 1) / kstride);  // items of this epoch
       Item cur = get_item(0);
       float4 lc;
       float2 aw, rp;
       int qv;
       load_la(cur, true, lc, aw, rp, qv);
+      if (NBUF == 1) {
+        for (int j = 0; j < nit; ++j) {
+          if (PROF) tk = __builtin_amdgcn_s_memtime();
+          geom_bbox(lc, aw, rp, qv, j & 1);
+          Item nxt = cur;
+          if (j + 1 < nit) nxt = get_item(j + 1);
+          load_la(nxt, j + 1 < nit, lc, aw, rp, qv);
+          tick(1);
+          wg_barrier();  // Y: bounding boxes complete; every wave has finished the previous item's gather
+          tick(2);
+          const unsigned staged = pack_stage(cur, 0, j & 1);
+          tick(3);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          tick(5);
+          wg_barrier();  // X: window landed, records visible
+          tick(0);
+          if (tid < 4) s_bbox[j & 1][tid] = make_int4(INT_MAX, INT_MIN, INT_MAX, INT_MIN);  // next used by item j+2
+          gather(cur, 0, staged, false);
+          if (PROF) pt[7] += 1;
+          cur = nxt;
+        }
+        continue;
+      }
       geom_bbox(lc, aw, rp, qv, 0);
       Item nxt = cur;
       if (nit > 1) nxt = get_item(1);
@@ -879,10 +977,10 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
           tick(1);
           wg_barrier();  // Y
           tick(2);
-          staged_next = pack_stage(it_next, (j + 1) & 1, (j + 1) & 1);
+          staged_next = pack_stage(it_next, (NBUF - 1) & (j + 1), (j + 1) & 1);
           tick(3);
         }
-        gather(cur, j & 1, staged_cur, live_next);
+        gather(cur, (NBUF - 1) & j, staged_cur, live_next);
         if (PROF) pt[7] += 1;
         if (!live_next) break;
         cur = it_next;
@@ -918,7 +1016,7 @@ int egtr_launch_msda_fwd_win_f32(hipStream_t st, const float* value, const int64
   hipLaunchKernelGGL((msda_fwd_win_f32<F, TH_, 8, WINPX_, WPS_>), dim3(pick_grid(B, S, TH_ * 8)), dim3(TH_ * 64), 0, \
                      st, value, shapes, lsi, loc, attn, out, B, Lq, S, L, P, ref, attn_out, ld_off, ld_logit, keep,  \
                      keep_bits, prof)
-  if (kind == 3 || kind == 4) {
+  if (kind == 3 || kind == 4 || kind == 5) {
     // persistent: exactly the resident workgroups (2 per CU at 80 KB LDS / 1 per CU at 160 KB)
     hipDeviceProp_t prop;
     int dev = 0;
@@ -932,9 +1030,29 @@ int egtr_launch_msda_fwd_win_f32(hipStream_t st, const float* value, const int64
                      value, shapes, lsi, loc, attn, out, B, Lq, S, ref, ld_off, ld_logit, keep_bits,                \
                      (unsigned long long*)nullptr)
     if (L != 4 || P != 4 || attn_out != nullptr || (keep != nullptr && keep_bits == nullptr)) return EGTR_E_UNSUPPORTED;
+    {  // 32-bit lane offsets inside one image
+      const long long pitch = std::max<long long>(1024, 4ll * std::max(ld_off, ld_logit));
+      if ((long long)Lq * pitch >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+    }
     if (kind == 3 && prof != nullptr && !fused) {
       hipLaunchKernelGGL((msda_fwd_winp_f32<false, 4, 8, 224, 2, true>), dim3((ncu * 2) & ~7), dim3(256), 0, st, value,
                          shapes, lsi, loc, attn, out, B, Lq, S, ref, ld_off, ld_logit, keep_bits, prof);
+      return egtr_check_launch();
+    }
+    if (kind == 5 && prof != nullptr && !fused) {
+      hipLaunchKernelGGL((msda_fwd_winp_f32<false, 4, 8, 224, 4, true, 1, 32>), dim3((ncu * 4) & ~7), dim3(256), 0, st,
+                         value, shapes, lsi, loc, attn, out, B, Lq, S, ref, ld_off, ld_logit, keep_bits, prof);
+      return egtr_check_launch();
+    }
+    if (kind == 5) {
+      if (fused)
+        hipLaunchKernelGGL((msda_fwd_winp_f32<true, 4, 8, 224, 4, false, 1, 32>), dim3((ncu * 4) & ~7), dim3(256), 0,
+                           st, value, shapes, lsi, loc, attn, out, B, Lq, S, ref, ld_off, ld_logit, keep_bits,
+                           (unsigned long long*)nullptr);
+      else
+        hipLaunchKernelGGL((msda_fwd_winp_f32<false, 4, 8, 224, 4, false, 1, 32>), dim3((ncu * 4) & ~7), dim3(256), 0,
+                           st, value, shapes, lsi, loc, attn, out, B, Lq, S, ref, ld_off, ld_logit, keep_bits,
+                           (unsigned long long*)nullptr);
       return egtr_check_launch();
     }
     if (kind == 3) {

@@ -199,7 +199,7 @@ def test_msda_resident_variant_arbitrary_queries():
     assert (o - ref).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("shapes,B,jitter", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # windows fit: LDS path
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 1, 8.0),       # scattered offsets: windows overflow -> mixed LDS/global
@@ -227,7 +227,7 @@ def test_msda_window_variant_matches_oracle_and_wave_variant(variant, shapes, B,
     assert torch.equal(o8, o8b)
 
 
-@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12, 13])
 def test_msda_window_variant_arbitrary_queries(variant):
     """Variants 8-10 when the queries are NOT the pixel grid: linear tiles, windows rarely fit, results must still be
     exact; samples straddling every image border; all-out-of-range and NaN locations."""
@@ -258,7 +258,7 @@ def test_msda_window_variant_arbitrary_queries(variant):
         assert (o - ref).abs().max() < 2e-5, shift
 
 
-@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("shapes,B", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2),
     ([(75, 125), (38, 63), (19, 32), (10, 16)], 1),

@@ -80,7 +80,7 @@ def main():
         off_v = both[..., :256].view(B_, Lq_, 8, len(shapes), 4, 2)
         log_v = both[..., 256:].view(B_, Lq_, 8, 16)
         fn = lambda: k.ms_deform_attn_forward_fused(value, shp, lsi, off_v, log_v, refp, False, None, variant=a.variant)
-    if a.phases and a.variant == 11:
+    if a.phases and a.variant in (11, 13):
         from egtr_amd import _lib
         cyc = torch.zeros(8, dtype=torch.int64, device=dev)
         out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
@@ -89,14 +89,14 @@ def main():
             st = _lib.lib().egtr_msda_win_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
                                                        shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
                                                        attn.data_ptr(), a.batch, value.shape[1], shp.shape[0],
-                                                       loc.shape[1], 4, 3, out.data_ptr(), cyc.data_ptr())
+                                                       loc.shape[1], 4, 3 if a.variant == 11 else 5, out.data_ptr(), cyc.data_ptr())
             _lib.check(st, "phase cycles")
             torch.cuda.synchronize()
         c = cyc.tolist()
         n = max(c[7], 1)
         print(f"pipelined window kernel, wave 0, ticks per item: barrierX={c[0]/n:.0f} geometry={c[1]/n:.0f} "
               f"barrierY={c[2]/n:.0f} pack+copy+records={c[3]/n:.0f} gather={c[4]/n:.0f} dma_wait={c[5]/n:.0f}; "
-              f"items={c[7]}; ticks per workgroup={c[6]/512:.0f}")
+              f"items={c[7]}; ticks per workgroup={c[6]/(512 if a.variant == 11 else 1024):.0f}")
     elif a.phases and a.variant in (8, 9, 10):
         from egtr_amd import _lib
         cyc = torch.zeros(6, dtype=torch.int64, device=dev)
