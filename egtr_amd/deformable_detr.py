@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import ops
-from .backbone import DeformableDetrFrozenBatchNorm2d, ResNet50Features
+from .backbone import DeformableDetrFrozenBatchNorm2d, ResNet50Features, conv1x1_as_gemm
 from .hf_compat import ModelOutput, PretrainedConfig, PreTrainedModel
 from .ops import MultiScaleDeformableAttentionFunction
 from .util import center_to_corners_format, generalized_box_iou, sigmoid_focal_loss
@@ -904,8 +904,14 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                     and all(isinstance(p[1], nn.GroupNorm) and p[0].bias is not None for p in self.input_proj)):
                 # input projections: bias-free convolutions, then conv bias + GroupNorm + flatten + transpose + cat
                 # of all levels in two HIP launches
-                convs = [F.conv2d(fm, self.input_proj[level][0].weight, None, self.input_proj[level][0].stride,
-                                  self.input_proj[level][0].padding) for level, fm in enumerate(feature_maps)]
+                convs = []
+                for level, fm in enumerate(feature_maps):
+                    c = self.input_proj[level][0]
+                    if (tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0)
+                            and c.groups == 1):
+                        convs.append(conv1x1_as_gemm(fm, c.weight))  # a tuned GEMM on the NCHW tensor as it lies
+                    else:
+                        convs.append(F.conv2d(fm, c.weight, None, c.stride, c.padding))
                 if n_extra == 1:  # dd:2228-2241: the extra level is a strided 3x3 convolution of the last feature map
                     c = self.input_proj[len(feature_maps)][0]
                     convs.append(F.conv2d(feature_maps[-1], c.weight, None, c.stride, c.padding))

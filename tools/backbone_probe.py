@@ -117,6 +117,39 @@ def main():
         print(f"(b) channels_last, 1x1 as GEMM: {t_b:.3f} ms")
         t_c, fc = graph_time(lambda: fwd(False))
         print(f"(c) channels_last, all MIOpen:  {t_c:.3f} ms")
+        # (d) NCHW throughout (3x3 / 7x7 / strided convs through MIOpen as shipped), stride-1 1x1 convs as W . X GEMMs on
+        #     the [C, H*W] view (tuned by TunableOp instead of MIOpen's own rocBLAS call) + the shipped epilogue kernel
+        from egtr_amd import ops
+
+        def conv1x1_nchw(xin, w2d):
+            B_, C_, H_, W_ = xin.shape
+            return torch.matmul(w2d, xin.reshape(B_, C_, H_ * W_)).view(B_, -1, H_, W_)
+
+        def fwd_d():
+            w, b = P["stem"]
+            y = net.maxpool(ops.bias_act_(F.conv2d(x, w, None, stride=2, padding=3), b))
+            feats = []
+            for li in range(1, 5):
+                for blk, p in zip(getattr(net, f"layer{li}"), P[li]):
+                    s_ = blk.conv2.stride
+                    idt = y
+                    if blk.downsample is not None:
+                        if blk.downsample[0].stride == (1, 1):
+                            idt = ops.bias_act_(conv1x1_nchw(y, p[3][0].flatten(1)), p[3][1], None, relu=False)
+                        else:
+                            idt = ops.bias_act_(F.conv2d(y, p[3][0], None, stride=blk.downsample[0].stride), p[3][1],
+                                                None, relu=False)
+                    z = ops.bias_act_(conv1x1_nchw(y, p[0][0].flatten(1)), p[0][1])
+                    z = ops.bias_act_(F.conv2d(z, p[1][0], None, stride=s_, padding=1), p[1][1])
+                    y = ops.bias_act_(conv1x1_nchw(z, p[2][0].flatten(1)), p[2][1], idt)
+                if li in net.out_indices:
+                    feats.append(y)
+            return feats
+
+        t_d, fd = graph_time(fwd_d)
+        print(f"(d) NCHW, stride-1 1x1 as W.X GEMM:  {t_d:.3f} ms")
+        for i in range(3):
+            print(f"  C{i + 3}: max |d - a| = {(fd[i] - fa[i]).abs().max().item():.3e}")
         for i in range(3):
             print(f"  C{i + 3}: max |b - a| = {(fb[i] - fa[i]).abs().max().item():.3e}  (|a| max {fa[i].abs().max().item():.2f}), "
                   f"max |c - a| = {(fc[i] - fa[i]).abs().max().item():.3e}")
