@@ -24,9 +24,27 @@ def main():
     ap.add_argument("--csv", default=None)
     ap.add_argument("--last-ms", type=float, default=0.0,
                     help="only dispatches that start in the last X ms of the trace (steady state after warm-up)")
+    ap.add_argument("--split-grid", default=None,
+                    help="NAME:THRESHOLD -- report kernels whose name contains NAME separately for launches with at "
+                         "least THRESHOLD workgroups (e.g. msda_fwd_q64:1000 = the encoder-shaped MSDA launches)")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     rows = c.execute("select name, start, end from kernels").fetchall()
+    if a.split_grid:
+        nm, thr = a.split_grid.rsplit(":", 1)
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+        gx = next((x for x in ("grid_x", "grid_size_x", "grid_size") if x in cols), None)
+        wx = next((x for x in ("workgroup_x", "workgroup_size_x", "workgroup_size") if x in cols), None)
+        if gx is None:
+            print(f"--split-grid: no grid column in {cols}")
+        else:
+            q = f"select name, start, end, {gx}, {wx if wx else 1} from kernels"
+            big = [(e - s_) for n, s_, e, g, w in c.execute(q) if nm in n and (g // max(int(w), 1)) >= int(thr)]
+            small = [(e - s_) for n, s_, e, g, w in c.execute(q) if nm in n and (g // max(int(w), 1)) < int(thr)]
+            for lab, v in ((f">= {thr} workgroups", big), (f"< {thr} workgroups", small)):
+                if v:
+                    print(f"{nm} launches with {lab}: n = {len(v)}, average {sum(v) / len(v) / 1e3:.2f} us, "
+                          f"min {min(v) / 1e3:.2f} us, max {max(v) / 1e3:.2f} us")
     if a.last_ms > 0 and rows:
         t_end = max(r[2] for r in rows)
         rows = [r for r in rows if r[1] >= t_end - a.last_ms * 1e6]
