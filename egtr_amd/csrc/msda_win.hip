@@ -490,13 +490,7 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
     const int per_img = (c0 + c1 + c2 + c3) * 8;
     nwork = B * per_img;
     if ((int)(blockIdx.x >> 3) >= nwork) return;
-    // epochs of EPOCH items: one epoch unless the batch is large
-    for (int e = tid; e < EPOCH; e += NT) {
-      const int k = (int)(blockIdx.x >> 3) + e * kstride;  // epoch 0; later epochs re-run this block (see below)
-      (void)k;
-    }
-    // (table filled per epoch inside the epoch loop below: needs the tile map, which stays in scalar registers only
-    //  for the few instructions of fill_table)
+    // work items are decoded EPOCH at a time (one epoch unless the batch is large) into the LDS table
     auto fill_table = [&](int kfirst) {
       if (tid < EPOCH) {
         const int k = kfirst + tid * kstride;
@@ -656,7 +650,7 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
         const int l = 3 - (wave & 3), rsub = wave >> 2;
         constexpr int NSUB = NW / 4 > 0 ? NW / 4 : 1;
         const int wwl = sel4(ww[0], ww[1], ww[2], ww[3], l), whl = sel4(wh[0], wh[1], wh[2], wh[3], l);
-        if (whl != 0 && (NW >= 4 || true)) {
+        if (whl != 0) {
           const int wy0l = sel4(wy0[0], wy0[1], wy0[2], wy0[3], l), wx0l = sel4(wx0[0], wx0[1], wx0[2], wx0[3], l);
           const int basel = sel4(base[0], base[1], base[2], base[3], l);
           const int Hl = sel4(G.H0, G.H1, G.H2, G.H3, l), Wl = sel4(G.W0, G.W1, G.W2, G.W3, l);
@@ -741,7 +735,6 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
     };
 
     auto gather = [&](const Item& it, int buf, unsigned staged, bool wait_dma) {
-      (void)0;
       const int qo = slot_query(it, gcol);
       // explicit address spaces: the two branches of the generic path must not be merged into flat loads
       typedef const __attribute__((address_space(3))) char* lds_cp;
@@ -755,17 +748,6 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
 #if EGTR_WIN_ABLATE == 2
       staged = 0x10u;  // timing ablation: no gather at all (wrong results)
 #endif
-#define EGTR_WIN_FMA16()                                            \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {               \
-        acc0 = pk_fma(f32x2{v[j][0].x, v[j][0].y}, w[j].x, acc0);   \
-        acc1 = pk_fma(f32x2{v[j][0].z, v[j][0].w}, w[j].x, acc1);   \
-        acc0 = pk_fma(f32x2{v[j][1].x, v[j][1].y}, w[j].y, acc0);   \
-        acc1 = pk_fma(f32x2{v[j][1].z, v[j][1].w}, w[j].y, acc1);   \
-        acc0 = pk_fma(f32x2{v[j][2].x, v[j][2].y}, w[j].z, acc0);   \
-        acc1 = pk_fma(f32x2{v[j][2].z, v[j][2].w}, w[j].z, acc1);   \
-        acc0 = pk_fma(f32x2{v[j][3].x, v[j][3].y}, w[j].w, acc0);   \
-        acc1 = pk_fma(f32x2{v[j][3].z, v[j][3].w}, w[j].w, acc1);   \
-      }
       if (staged == 0xFu && WPS <= 2) {
         // every window is in LDS (the regular case).  Software pipeline over the levels: the 20 ds_read_b128 of
         // level l+1 are in flight while the 32 v_pk_fma_f32 of level l issue (two register buffers).
@@ -882,7 +864,6 @@ __global__ __launch_bounds__(TH * TW * 8, WPS) void msda_fwd_winp_f32(
           }
         }
       }
-#undef EGTR_WIN_FMA16
       if (PROF) {
         // make the timer see the FMAs (they depend on the last LDS reads)
         asm volatile("" :: "v"(acc0), "v"(acc1));
