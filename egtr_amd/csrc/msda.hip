@@ -306,7 +306,10 @@ __device__ __forceinline__ void atomic_add4(float* p, float4 v) {
 
 // fp32, M = 8, D = 32, L*P = 16.  One wave per query.  LDS record per (head, sample): three 16-byte entries:
 //   off[4] | {w-validity bits, lh, lw, attn} | {Wf, Hf, -, -}
-template <bool VALUE_ATOMICS>
+// SPLIT > 1 (short query lists, e.g. the decoder's 200 queries per image): SPLIT waves share one query, each taking
+// 16 / SPLIT consecutive samples (= one level for SPLIT = 4), so that a B x 200-query call fills the chip (800 waves of
+// serial atomics -> 3200) -- every wave still builds all 16 records (cheap) but gathers / scatters only its own.
+template <bool VALUE_ATOMICS, int SPLIT = 1>
 __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
@@ -319,7 +322,9 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   __shared__ __attribute__((aligned(16))) float s_ga[kWaves * 128];            // grad_attn staging
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = xcd_remap(blockIdx.x, nblk);
-  const int q = blk * kWaves + wave;
+  const int gw = blk * kWaves + wave;
+  const int q = gw / SPLIT, part = gw % SPLIT;
+  constexpr int NS = 16 / SPLIT;  // samples per wave
   if (q >= nq_total) return;
   LevelGeom G;
   load_geom(shapes, lsi, L, G);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   float* gl_stage = s_gl + wave * 256;
   float* ga_stage = s_ga + wave * 128;
 #pragma unroll 2
-  for (int s = 0; s < 16; ++s) {
+  for (int s = part * NS; s < (part + 1) * NS; ++s) {
     const int4 o = ro[s];
     const float4 a4 = ra[s];
     const float2 wh = rwh[s];
@@ -409,8 +414,20 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  reinterpret_cast<float4*>(grad_loc + (size_t)q * 256)[lane] = reinterpret_cast<const float4*>(gl_stage)[lane];
-  reinterpret_cast<float2*>(grad_attn + (size_t)q * 128)[lane] = reinterpret_cast<const float2*>(ga_stage)[lane];
+  if (SPLIT == 1) {
+    reinterpret_cast<float4*>(grad_loc + (size_t)q * 256)[lane] = reinterpret_cast<const float4*>(gl_stage)[lane];
+    reinterpret_cast<float2*>(grad_attn + (size_t)q * 128)[lane] = reinterpret_cast<const float2*>(ga_stage)[lane];
+  } else {
+    // this wave's samples: per head 2 * NS location gradients and NS attention gradients
+    for (int e = lane; e < 8 * 2 * NS; e += 64) {
+      const int idx = ((e / (2 * NS)) * 16 + part * NS) * 2 + e % (2 * NS);
+      grad_loc[(size_t)q * 256 + idx] = gl_stage[idx];
+    }
+    for (int e = lane; e < 8 * NS; e += 64) {
+      const int idx = (e / NS) * 16 + part * NS + e % NS;
+      grad_attn[(size_t)q * 128 + idx] = ga_stage[idx];
+    }
+  }
 }
 
 // Generic backward: one thread per (b,q,m,l,p) sample, loops over the D channels; atomics for grad_value.
@@ -698,7 +715,13 @@ extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float*
                                                attn_weight, grad_value, batch, num_query, spatial_size, num_levels,
                                                num_point);
   }
-  if (variant == 1) {
+  if (variant == 1 && nq * 4 <= 16384 && (num_point == 4 || num_point == 8 || num_point == 16)) {
+    // short query list: 4 waves per query (one level's samples each for L = P = 4)
+    const int nblk = (int)((nq * 4 + kWaves - 1) / kWaves);
+    hipLaunchKernelGGL((msda_bwd_q64_f32<true, 4>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
+                       spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk);
+  } else if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(msda_bwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
