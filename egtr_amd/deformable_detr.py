@@ -1044,7 +1044,10 @@ class DeformableDetrHungarianMatcher(nn.Module):
         self.bias_epsilon = torch.log(torch.tensor(1e-8))
 
     @torch.no_grad()
-    def forward(self, outputs, targets):
+    def prepare(self, outputs, targets):
+        """First half of ``forward``: the cost matrix on the device and its copy to the host, ENQUEUED only (pinned
+        buffer + event on GPU tensors).  The caller can launch more GPU work (the relation head) before ``finish`` waits
+        for the copy: the assignment then runs on the host while the GPU is busy instead of in a pipeline bubble."""
         bs, num_queries = outputs["logits"].shape[:2]
         out_prob = outputs["logits"].flatten(0, 1).sigmoid()
         out_bbox = outputs["pred_boxes"].flatten(0, 1)
@@ -1057,15 +1060,34 @@ class DeformableDetrHungarianMatcher(nn.Module):
         bbox_cost = torch.cdist(out_bbox, tgt_bbox, p=1)
         giou_cost = -generalized_box_iou(center_to_corners_format(out_bbox), center_to_corners_format(tgt_bbox))
         cost_matrix = self.bbox_cost * bbox_cost + self.class_cost * class_cost + self.giou_cost * giou_cost
-        cost_matrix = cost_matrix.view(bs, num_queries, -1).cpu()  # the one D2H sync of the step (dd:2985)
+        cost_matrix = cost_matrix.view(bs, num_queries, -1)
+        event = None
+        if cost_matrix.is_cuda:
+            host = torch.empty(cost_matrix.shape, dtype=cost_matrix.dtype, pin_memory=True)
+            host.copy_(cost_matrix, non_blocking=True)  # the one D2H transfer of the step (dd:2985)
+            event = torch.cuda.Event()
+            event.record()
+        else:
+            host = cost_matrix
+        return host, event, [len(v["boxes"]) for v in targets], out_prob.device
+
+    @torch.no_grad()
+    def finish(self, pending):
+        cost_matrix, event, sizes, device = pending
+        if event is not None:
+            event.synchronize()
+        alpha = 0.25
         if self.smoothing:
             cost_min = self.class_cost * (1 - alpha) * self.bias_epsilon - self.giou_cost
             inverse_sigmoid_smoothing = -torch.log(torch.tensor((1.0 / self.smoothing) - 1.0))
             cost_matrix = cost_matrix - cost_min + inverse_sigmoid_smoothing
-        sizes = [len(v["boxes"]) for v in targets]
         indices = [linear_sum_assignment(c[i]) for i, c in enumerate(cost_matrix.split(sizes, -1))]
-        matching_costs = [c[i, indices[i][0], indices[i][1]].to(out_prob.device)
+        matching_costs = [c[i, indices[i][0], indices[i][1]].to(device)
                           for i, c in enumerate(cost_matrix.split(sizes, -1))]
         indices = [(torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64))
                    for i, j in indices]
         return indices, matching_costs
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        return self.finish(self.prepare(outputs, targets))

@@ -171,10 +171,17 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
                                  cl[1].weight, cl[1].bias, cl[2].weight, cl[2].bias, triplet, node,
                                  want_gate_mean)
 
-    def _heads(self, outputs, want_gate_mean):
+    def _matcher(self):
+        return DeformableDetrHungarianMatcher(
+            class_cost=self.config.ce_loss_coefficient, bbox_cost=self.config.bbox_cost,
+            giou_cost=self.config.giou_cost, smoothing=self.config.smoothing)
+
+    def _heads(self, outputs, want_gate_mean, labels=None):
         """Detection heads + relation head on the base model's outputs (egtr:283-418).  Returns
-        (logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean); the relation /
-        connectivity logits are PRE-sigmoid."""
+        (logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending_match); the
+        relation / connectivity logits are PRE-sigmoid.  With ``labels`` on the GPU the Hungarian cost matrix and its
+        copy to the host are enqueued BEFORE the relation head is launched (the matcher needs only logits and boxes), so
+        that the host-side assignment overlaps the relation-head kernel instead of idling the GPU."""
         sequence_output = outputs["last_hidden_state"]
         hidden_states = outputs.intermediate_hidden_states
         init_reference = outputs.init_reference_points
@@ -225,6 +232,10 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             outputs_class = outputs_class[:, : self.config.decoder_layers, ...].permute(1, 0, 2, 3)
             outputs_coord = outputs_coord[:, : self.config.decoder_layers, ...].permute(1, 0, 2, 3)
 
+        pending = None
+        if labels is not None and logits.is_cuda:
+            pending = self._matcher().prepare({"logits": logits, "pred_boxes": pred_boxes}, labels)
+
         decoder_attention_queries = outputs["decoder_attention_queries"]
         outputs["decoder_attention_queries"] = None
         decoder_attention_keys = outputs["decoder_attention_keys"]
@@ -232,7 +243,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         pred_rel, pred_connectivity, gate_mean = self._relation_head(
             decoder_attention_queries, decoder_attention_keys, sequence_output, logits,
             want_gate_mean=want_gate_mean)
-        return logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean
+        return logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending
 
     def forward_tensors(self, pixel_values, pixel_mask):
         """The static-shape part of a TRAINING step as a plain tensors -> tensors function (no host synchronisation, no
@@ -240,7 +251,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         (egtr_amd.runtime.DataParallelTrainer(graph=True)).  ``loss_from_tensors`` turns the result into the loss."""
         outputs = self.model(pixel_values, pixel_mask=pixel_mask, output_attentions=False, output_hidden_states=True,
                              output_attention_states=True, return_dict=True)
-        logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean = \
+        logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, _ = \
             self._heads(outputs, want_gate_mean=True)
         if self.config.auxiliary_loss:
             return logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord
@@ -255,12 +266,11 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
                                         outputs_coord, labels)
         return loss, loss_dict
 
-    def _loss(self, logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord, labels):
+    def _loss(self, logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord, labels,
+              pending_match=None):
         auxiliary_outputs = None
         num_object_queries = logits.shape[1]
-        matcher = DeformableDetrHungarianMatcher(
-            class_cost=self.config.ce_loss_coefficient, bbox_cost=self.config.bbox_cost,
-            giou_cost=self.config.giou_cost, smoothing=self.config.smoothing)
+        matcher = self._matcher()
         criterion = SceneGraphGenerationLoss(
             matcher=matcher, num_object_queries=num_object_queries, num_classes=self.config.num_labels,
             num_rel_labels=self.config.num_rel_labels, eos_coef=self.config.eos_coefficient,
@@ -276,7 +286,8 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         if self.config.auxiliary_loss:
             auxiliary_outputs = self._set_aux_loss(outputs_class, outputs_coord)
             outputs_loss["auxiliary_outputs"] = auxiliary_outputs
-        loss_dict = criterion(outputs_loss, labels)
+        loss_dict = criterion(outputs_loss, labels,
+                              matched=matcher.finish(pending_match) if pending_match is not None else None)
         weight_dict = {"loss_ce": self.config.ce_loss_coefficient, "loss_bbox": self.config.bbox_loss_coefficient,
                        "loss_giou": self.config.giou_loss_coefficient,
                        "loss_rel": self.config.rel_loss_coefficient,
@@ -301,13 +312,13 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
                              output_hidden_states=output_hidden_states,
                              output_attention_states=True,  # the relation head needs the retained q / k maps
                              return_dict=True)
-        logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean = \
-            self._heads(outputs, want_gate_mean=labels is not None)
+        logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending = \
+            self._heads(outputs, want_gate_mean=labels is not None, labels=labels)
 
         loss, loss_dict, auxiliary_outputs = None, None, None
         if labels is not None:
             loss, loss_dict, auxiliary_outputs = self._loss(logits, pred_boxes, pred_rel, pred_connectivity,
-                                                            gate_mean, outputs_class, outputs_coord, labels)
+                                                            gate_mean, outputs_class, outputs_coord, labels, pending)
 
         if self.config.logit_adjustment:  # egtr:509-512
             pred_rel = pred_rel - self.config.logit_adj_tau * self.rel_dist.log().to(pred_rel.device)
@@ -590,10 +601,11 @@ class SceneGraphGenerationLoss(nn.Module):
         assert loss in loss_map, f"Loss {loss} not supported"
         return loss_map[loss](outputs, targets, indices, matching_costs, num_boxes)
 
-    def forward(self, outputs, targets):
-        """egtr:953-1034.  ``num_boxes`` is per-rank (the reference's all-reduce is commented out, :976-980)."""
+    def forward(self, outputs, targets, matched=None):
+        """egtr:953-1034.  ``num_boxes`` is per-rank (the reference's all-reduce is commented out, :976-980).
+        ``matched``: the (indices, matching_costs) of the main outputs when the caller already ran the matcher."""
         outputs_without_aux = {k: v for k, v in outputs.items() if k not in ("auxiliary_outputs", "enc_outputs")}
-        indices, matching_costs = self.matcher(outputs_without_aux, targets)
+        indices, matching_costs = matched if matched is not None else self.matcher(outputs_without_aux, targets)
         num_boxes = float(max(sum(len(t["class_labels"]) for t in targets), 1))
         losses = {}
         for loss in self.losses:
