@@ -208,3 +208,41 @@ def calculate_fps(model, batches, warmup=3):
             n += batch["pixel_values"].shape[0]
     torch.cuda.synchronize()
     return n / (time.perf_counter() - t0) if t0 is not None and n else float("nan")
+
+
+@torch.no_grad()
+def triplet_candidates(outputs, num_labels, orig_sizes, max_topk=100):
+    """The evaluator inputs of the reference's ``evaluate_batch`` (train_egtr.py:54-106, multiple-predicate branch)
+    computed where the model outputs live: per image the ``max_topk`` best (subject, object, predicate) triplets by
+    ``pred_rel * pred_connectivity * score_s * score_o`` (self-pairs excluded), their relation scores, object
+    classes / scores and boxes rescaled to the original image size.
+
+    The reference copies ``pred_rel`` [N, N, R] (8 MB at N = 200) to the host and runs a full numpy argsort over its
+    2 M entries per image (lib/pytorch_misc.py:27-34); here it is one batched ``topk`` on the device and only
+    ``max_topk`` rows leave it.  Ties between equal triplet scores may be ordered differently from numpy's argsort
+    (both orders are valid argsorts).  ``orig_sizes``: [B, 2] (h, w).  Returns a list of dicts of tensors on the
+    outputs' device with the reference's ``pred_entry`` keys (+ ``triplet_scores``)."""
+    logits, boxes = outputs["logits"], outputs["pred_boxes"]
+    rel = torch.clamp(outputs["pred_rel"], 0.0, 1.0)
+    if "pred_connectivity" in outputs and outputs["pred_connectivity"] is not None:
+        rel = rel * torch.clamp(outputs["pred_connectivity"], 0.0, 1.0)
+    B, N, _, R = rel.shape
+    obj_scores, pred_classes = torch.max(logits.softmax(-1)[..., :num_labels], -1)         # [B, N]
+    sub_ob = obj_scores[:, :, None] * obj_scores[:, None, :]
+    sub_ob = sub_ob.masked_fill(torch.eye(N, dtype=torch.bool, device=rel.device)[None], 0.0)
+    scores = (rel * sub_ob.unsqueeze(-1)).reshape(B, -1)
+    k = min(max_topk, scores.shape[1])
+    top, flat = torch.topk(scores, k, dim=1)                                                  # sorted descending
+    s_idx = torch.div(flat, N * R, rounding_mode="floor")
+    o_idx = torch.div(flat, R, rounding_mode="floor") % N
+    p_idx = flat % R
+    rel_scores = rel.reshape(B, -1).gather(1, flat)
+    sizes = torch.as_tensor(orig_sizes, dtype=torch.float32, device=rel.device).reshape(B, 2)
+    cx, cy, w, h = boxes.unbind(-1)
+    xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+    scale = torch.stack([sizes[:, 1], sizes[:, 0], sizes[:, 1], sizes[:, 0]], -1)            # (w, h, w, h)
+    xyxy = xyxy * scale[:, None, :]
+    return [{"pred_boxes": xyxy[b], "pred_classes": pred_classes[b], "obj_scores": obj_scores[b],
+             "pred_rel_inds": torch.stack([s_idx[b], o_idx[b], p_idx[b]], -1), "rel_scores": rel_scores[b],
+             "triplet_scores": top[b]} for b in range(B)]
+

@@ -334,3 +334,23 @@ def test_stress_config_bf16_forward_runs():
         assert torch.isfinite(t.float()).all()
     assert (ob.logits.float() - o32.logits).abs().max() < 0.25
     assert (ob.pred_boxes.float() - o32.pred_boxes).abs().max() < 0.05
+
+
+def test_triplet_candidates_on_device_match_reference_postprocessing():
+    """Evaluator inputs computed on the GPU vs the numpy restatement of the reference's evaluate_batch."""
+    from egtr_amd.runtime import triplet_candidates
+    from oracle import postprocess as OP
+    g = torch.Generator().manual_seed(41)
+    B, N, C, R = 2, 200, 150, 50
+    outputs = {"logits": torch.randn(B, N, C + 1, generator=g) * 2, "pred_boxes": torch.rand(B, N, 4, generator=g),
+               "pred_rel": torch.rand(B, N, N, R, generator=g), "pred_connectivity": torch.rand(B, N, N, 1, generator=g)}
+    sizes = torch.tensor([[600, 1000], [480, 640]])
+    got = triplet_candidates({k: v.to(DEV) for k, v in outputs.items()}, C, sizes, max_topk=100)
+    for b in range(B):
+        want = OP.triplet_candidates(outputs["logits"][b], outputs["pred_boxes"][b], outputs["pred_rel"][b],
+                                     outputs["pred_connectivity"][b], C, sizes[b], 100)
+        assert np.abs(got[b]["triplet_scores"].cpu().numpy() - want["triplet_scores"]).max() < 1e-6
+        assert set(map(tuple, got[b]["pred_rel_inds"].cpu().numpy())) == set(map(tuple, want["pred_rel_inds"]))
+        assert np.array_equal(got[b]["pred_classes"].cpu().numpy(), want["pred_classes"])
+        assert np.abs(got[b]["pred_boxes"].cpu().numpy() - want["pred_boxes"]).max() < 1e-3
+

@@ -189,3 +189,42 @@ def test_output_object_and_config_roundtrip(tmp_path, small):
     assert cfg2.num_queries == cfg.num_queries and cfg2.num_rel_labels == cfg.num_rel_labels
     assert cfg2.num_labels == cfg.num_labels and cfg2.smoothing == cfg.smoothing
     assert cfg2.use_return_dict and cfg2.hidden_size == 256 and cfg2.num_attention_heads == 8
+
+
+def test_triplet_candidates_match_reference_postprocessing():
+    """egtr_amd.runtime.triplet_candidates (batched device-side top-k) against the numpy restatement of the reference's
+    evaluate_batch / argsort_desc (oracle/postprocess.py).  Clamped relation scores produce exact ties; tied triplets
+    may come in either order (both are valid argsorts), everything else must agree row by row."""
+    from egtr_amd.runtime import triplet_candidates
+    from oracle import postprocess as OP
+    g = torch.Generator().manual_seed(31)
+    B, N, C, R = 3, 23, 12, 7
+    outputs = {"logits": torch.randn(B, N, C + 1, generator=g) * 2, "pred_boxes": torch.rand(B, N, 4, generator=g),
+               "pred_rel": torch.rand(B, N, N, R, generator=g) * 1.1 - 0.05,          # a few values outside [0, 1]
+               "pred_connectivity": torch.rand(B, N, N, 1, generator=g)}
+    sizes = torch.tensor([[480, 640], [600, 1000], [333, 500]])
+    got = triplet_candidates(outputs, C, sizes, max_topk=100)
+    for b in range(B):
+        want = OP.triplet_candidates(outputs["logits"][b], outputs["pred_boxes"][b], outputs["pred_rel"][b],
+                                     outputs["pred_connectivity"][b], C, sizes[b], 100)
+        gi, wi = got[b]["pred_rel_inds"].numpy(), want["pred_rel_inds"]
+        ts = want["triplet_scores"]
+        assert np.abs(got[b]["triplet_scores"].numpy() - ts).max() < 1e-6
+        uniq = np.ones(len(ts), dtype=bool)
+        uniq[1:] &= ts[1:] != ts[:-1]
+        uniq[:-1] &= ts[:-1] != ts[1:]
+        assert uniq.sum() > 80 and np.array_equal(gi[uniq], wi[uniq])
+        assert set(map(tuple, gi)) == set(map(tuple, wi))
+        assert np.abs(np.sort(got[b]["rel_scores"].numpy()) - np.sort(want["rel_scores"])).max() < 1e-6
+        assert np.array_equal(got[b]["pred_classes"].numpy(), want["pred_classes"])
+        assert np.abs(got[b]["obj_scores"].numpy() - want["obj_scores"]).max() < 1e-6
+        assert np.abs(got[b]["pred_boxes"].numpy() - want["pred_boxes"]).max() < 1e-3
+    # without the connectivity head, and fewer candidates than max_topk
+    small = {k_: v[:, :3, ...] if k_ in ("logits", "pred_boxes") else v[:, :3, :3] for k_, v in outputs.items()}
+    small.pop("pred_connectivity")
+    got = triplet_candidates(small, C, sizes, max_topk=100)
+    want = OP.triplet_candidates(small["logits"][0], small["pred_boxes"][0], small["pred_rel"][0], None, C, sizes[0], 100)
+    assert got[0]["pred_rel_inds"].shape == (3 * 3 * R, 3)
+    nz = want["triplet_scores"] > 0   # the zero-score self pairs tie: compare the strictly positive part
+    assert np.array_equal(got[0]["pred_rel_inds"].numpy()[nz], want["pred_rel_inds"][nz])
+
