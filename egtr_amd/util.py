@@ -89,3 +89,20 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]):
         pad_img[: img.shape[0], : img.shape[1], : img.shape[2]].copy_(img)
         m[: img.shape[1], : img.shape[2]] = False
     return NestedTensor(tensor, mask)
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """IoU matrix [N, K] with the "+1 pixel" box convention of the reference's Cython routine
+    (lib/fpn/box_intersections_cpu/bbox.pyx:21-61, used by lib/evaluation/sg_eval.py:318-322), vectorised so that it
+    runs wherever the boxes live (CPU or GPU); zero where the boxes do not overlap.  Computed in float64 like the
+    reference (``np.float``)."""
+    a = torch.as_tensor(boxes).to(torch.float64)
+    q = torch.as_tensor(query_boxes, device=a.device).to(torch.float64)
+    iw = torch.minimum(a[:, None, 2], q[None, :, 2]) - torch.maximum(a[:, None, 0], q[None, :, 0]) + 1
+    ih = torch.minimum(a[:, None, 3], q[None, :, 3]) - torch.maximum(a[:, None, 1], q[None, :, 1]) + 1
+    area_a = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+    area_q = (q[:, 2] - q[:, 0] + 1) * (q[:, 3] - q[:, 1] + 1)
+    inter = iw * ih
+    ua = area_a[:, None] + area_q[None, :] - inter
+    return torch.where((iw > 0) & (ih > 0), inter / ua, torch.zeros((), dtype=torch.float64, device=a.device))
+

@@ -3,6 +3,7 @@ scene-graph post-processing, the inputs of its evaluators.
 
     triplet_candidates  <- evaluate_batch, train_egtr.py:54-106 (multiple-predicate branch) with argsort_desc,
                            lib/pytorch_misc.py:27-34, and rescale_bboxes, util/box_ops.py:87-91
+    bbox_overlaps       <- lib/fpn/box_intersections_cpu/bbox.pyx:21-61 (Cython in the reference; loops restated)
 """
 import numpy as np
 import torch
@@ -29,3 +30,22 @@ def triplet_candidates(logits, pred_boxes, pred_rel, pred_connectivity, num_labe
     boxes = (xyxy * torch.tensor([w, h, w, h], dtype=torch.float32)).numpy()
     return {"pred_boxes": boxes, "pred_classes": pred_classes.numpy(), "obj_scores": obj_scores.numpy(),
             "pred_rel_inds": inds, "rel_scores": rel_scores, "triplet_scores": scores[inds[:, 0], inds[:, 1], inds[:, 2]]}
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """bbox.pyx:21-61, loop for loop (float64, "+1 pixel" convention)."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+    query = np.ascontiguousarray(query_boxes, dtype=np.float64)
+    n_, k_ = boxes.shape[0], query.shape[0]
+    out = np.zeros((n_, k_), dtype=np.float64)
+    for k in range(k_):
+        box_area = (query[k, 2] - query[k, 0] + 1) * (query[k, 3] - query[k, 1] + 1)
+        for n in range(n_):
+            iw = min(boxes[n, 2], query[k, 2]) - max(boxes[n, 0], query[k, 0]) + 1
+            if iw > 0:
+                ih = min(boxes[n, 3], query[k, 3]) - max(boxes[n, 1], query[k, 1]) + 1
+                if ih > 0:
+                    ua = float((boxes[n, 2] - boxes[n, 0] + 1) * (boxes[n, 3] - boxes[n, 1] + 1) + box_area - iw * ih)
+                    out[n, k] = iw * ih / ua
+    return out
+

@@ -228,3 +228,19 @@ def test_triplet_candidates_match_reference_postprocessing():
     nz = want["triplet_scores"] > 0   # the zero-score self pairs tie: compare the strictly positive part
     assert np.array_equal(got[0]["pred_rel_inds"].numpy()[nz], want["pred_rel_inds"][nz])
 
+
+def test_bbox_overlaps_matches_reference_cython_routine():
+    from egtr_amd.util import bbox_overlaps
+    from oracle import postprocess as OP
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(0, 500, (40, 2))
+    a = np.concatenate([xy, xy + rng.uniform(0, 200, (40, 2))], 1)
+    xy = rng.uniform(0, 500, (17, 2))
+    q = np.concatenate([xy, xy + rng.uniform(0, 200, (17, 2))], 1)
+    q[0] = a[0]                      # identical boxes -> 1
+    q[1] = a[1] + 10000.0            # disjoint -> 0
+    got = bbox_overlaps(torch.from_numpy(a), torch.from_numpy(q)).numpy()
+    want = OP.bbox_overlaps(a, q)
+    assert got.shape == (40, 17) and np.abs(got - want).max() < 1e-12
+    assert got[0, 0] == 1.0 and got[1, 1] == 0.0
+
