@@ -5,7 +5,8 @@
 // per-layer maps "scaled q" and "k" in [B, M, N, D] layout (dd:1179-1185) that the EGTR relation head consumes.
 //
 // Shape regime: N = 100..300 object queries, D = 32, M = 8: the whole score row fits in registers, so no
-// online-softmax rescaling is needed.  One wavefront owns (batch b, head h, a tile of 16 query rows).
+// online-softmax rescaling is needed inside a wave.  One workgroup owns (batch b, head h, a tile of 16 query rows); its
+// four waves split the keys and merge their partial (max, sum, output) through LDS.
 //
 // MFMA use (v_mfma_f32_16x16x4_f32: exact f32, A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=(l>>4)*4+r][col=l&15]):
 //   * scores are computed TRANSPOSED, S^T = K Q^T, so that D[row = key][col = query]: a lane (c = l&15, g = l>>4)
@@ -53,13 +54,18 @@ __device__ __forceinline__ void load_frag8(const float* __restrict__ base, int N
   f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
 }
 
-// NT = number of 16-key tiles held in registers (N <= 16*NT).  D = 32.
-template <int NT>
-__global__ __launch_bounds__(64) void self_attn_fwd_f32(const float* __restrict__ q, const float* __restrict__ k,
-                                                        const float* __restrict__ v, float* __restrict__ out,
-                                                        float* __restrict__ q_heads, float* __restrict__ k_heads,
-                                                        float* __restrict__ lse, int B, int N, int M) {
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+// Forward.  The keys are split over KS waves of one workgroup (wave w takes key tiles w, w + KS, ...; NTW = tiles per
+// wave held in registers): with ONE wave per (b, head, 16-query tile) the kernel was a single dependent chain of
+// 13 x (K-tile load -> 8 MFMAs) + 104 x (V load -> MFMA) -- 15.4 us per launch for 41 MFLOP with only 104 waves on the
+// chip; split four ways 11 us (226.9 vs 225.6 images/s end to end).  Each wave keeps its own running
+// maximum / sum / unnormalised output and the partial results are merged lane by lane through LDS
+// (O = sum_w O_w e^{m_w - M} / sum_w s_w e^{m_w - M}); the softmax is exact as before, only the summation order differs.
+template <int NTW, int KS>
+__global__ __launch_bounds__(64 * KS) void self_attn_fwd_split_f32(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
+    float* __restrict__ q_heads, float* __restrict__ k_heads, float* __restrict__ lse, int B, int N, int M) {
+  __shared__ float s_part[KS][10][64];  // [wave][o0[0..3], o1[0..3], max, sum][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int ntile = (N + 15) >> 4;
   int wid = blockIdx.x;
   const int qt = wid % ntile;
@@ -70,28 +76,25 @@ __global__ __launch_bounds__(64) void self_attn_fwd_f32(const float* __restrict_
 
   float qf[8];
   load_frag8(q, N, MD, b, q0 + c, h, g, qf);
-  // retained maps: this wave copies its own 16 rows of q and k into [B, M, N, 32]
-  if (q_heads != nullptr || k_heads != nullptr) {
-    if (q0 + c < N) {
-      const size_t o = (((size_t)b * M + h) * N + q0 + c) * 32 + g * 8;
-      if (q_heads) {
-        reinterpret_cast<float4*>(q_heads + o)[0] = make_float4(qf[0], qf[1], qf[2], qf[3]);
-        reinterpret_cast<float4*>(q_heads + o)[1] = make_float4(qf[4], qf[5], qf[6], qf[7]);
-      }
-      if (k_heads) {
-        float kf0[8];
-        load_frag8(k, N, MD, b, q0 + c, h, g, kf0);
-        reinterpret_cast<float4*>(k_heads + o)[0] = make_float4(kf0[0], kf0[1], kf0[2], kf0[3]);
-        reinterpret_cast<float4*>(k_heads + o)[1] = make_float4(kf0[4], kf0[5], kf0[6], kf0[7]);
-      }
+  if (wave == 0 && (q_heads != nullptr || k_heads != nullptr) && q0 + c < N) {
+    const size_t o = (((size_t)b * M + h) * N + q0 + c) * 32 + g * 8;
+    if (q_heads) {
+      reinterpret_cast<float4*>(q_heads + o)[0] = make_float4(qf[0], qf[1], qf[2], qf[3]);
+      reinterpret_cast<float4*>(q_heads + o)[1] = make_float4(qf[4], qf[5], qf[6], qf[7]);
+    }
+    if (k_heads) {
+      float kf0[8];
+      load_frag8(k, N, MD, b, q0 + c, h, g, kf0);
+      reinterpret_cast<float4*>(k_heads + o)[0] = make_float4(kf0[0], kf0[1], kf0[2], kf0[3]);
+      reinterpret_cast<float4*>(k_heads + o)[1] = make_float4(kf0[4], kf0[5], kf0[6], kf0[7]);
     }
   }
 
-  f32x4 s[NT];
+  f32x4 s[NTW];
   float mx = -INFINITY;
 #pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-    const int k0 = kt * 16;
+  for (int i = 0; i < NTW; ++i) {
+    const int k0 = (wave + i * KS) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (k0 < N) {
       float kf[8];
@@ -105,42 +108,61 @@ __global__ __launch_bounds__(64) void self_attn_fwd_f32(const float* __restrict_
       acc[r] = ok ? acc[r] : -INFINITY;
       mx = fmaxf(mx, acc[r]);
     }
-    s[kt] = acc;
+    s[i] = acc;
   }
   mx = xor16_32_max(mx);
   float sum = 0.f;
 #pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
+  for (int i = 0; i < NTW; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float p = __expf(s[kt][r] - mx);
-      s[kt][r] = p;
+      const float p = (mx == -INFINITY) ? 0.f : __expf(s[i][r] - mx);  // a wave without keys contributes nothing
+      s[i][r] = p;
       sum += p;
     }
   }
   sum = xor16_32_sum(sum);
-  const float inv = 1.f / sum;
 
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-    const int k0 = kt * 16;
+  for (int i = 0; i < NTW; ++i) {
+    const int k0 = (wave + i * KS) * 16;
     if (k0 < N) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int key = min(k0 + g * 4 + t, N - 1);
         const float* vp = v + ((size_t)b * N + key) * MD + h * 32 + c;
-        o0 = mfma16(vp[0], s[kt][t], o0);
-        o1 = mfma16(vp[16], s[kt][t], o1);
+        o0 = mfma16(vp[0], s[i][t], o0);
+        o1 = mfma16(vp[16], s[i][t], o1);
       }
     }
   }
-  if (q0 + c < N) {
-    float* op = out + ((size_t)b * N + q0 + c) * MD + h * 32 + g * 4;
-    *reinterpret_cast<float4*>(op) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
-    *reinterpret_cast<float4*>(op + 16) = make_float4(o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv);
-    if (lse != nullptr && g == 0) lse[((size_t)b * M + h) * N + q0 + c] = mx + __logf(sum);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    s_part[wave][r][lane] = o0[r];
+    s_part[wave][4 + r][lane] = o1[r];
   }
+  s_part[wave][8][lane] = mx;
+  s_part[wave][9][lane] = sum;
+  __syncthreads();
+  if (wave != 0 || q0 + c >= N) return;
+  float mall = -INFINITY;
+#pragma unroll
+  for (int w = 0; w < KS; ++w) mall = fmaxf(mall, s_part[w][8][lane]);
+  float tot = 0.f, o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < KS; ++w) {
+    const float mw = s_part[w][8][lane];
+    const float f = (mw == -INFINITY) ? 0.f : __expf(mw - mall);
+    tot += s_part[w][9][lane] * f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] += s_part[w][r][lane] * f;
+  }
+  const float inv = 1.f / tot;
+  float* op = out + ((size_t)b * N + q0 + c) * MD + h * 32 + g * 4;
+  *reinterpret_cast<float4*>(op) = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+  *reinterpret_cast<float4*>(op + 16) = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+  if (lse != nullptr && g == 0) lse[((size_t)b * M + h) * N + q0 + c] = mall + __logf(tot);
 }
 
 // Backward.  See file header.  grad wrt the kernel's inputs q (already scaled), k, v.
@@ -260,13 +282,6 @@ __global__ __launch_bounds__(64) void self_attn_bwd_f32(const float* __restrict_
   }
 }
 
-template <int NT>
-void launch_fwd(hipStream_t st, const float* q, const float* k, const float* v, float* out, float* qh, float* kh,
-                float* lse, int B, int N, int M) {
-  const int ntile = (N + 15) / 16;
-  hipLaunchKernelGGL(self_attn_fwd_f32<NT>, dim3(B * M * ntile), dim3(64), 0, st, q, k, v, out, qh, kh, lse, B, N, M);
-}
-
 }  // namespace
 
 extern "C" int egtr_self_attn_forward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
@@ -277,10 +292,14 @@ extern "C" int egtr_self_attn_forward_f32(egtr_stream_t stream, const float* q, 
   if (head_dim != 32 || num_query > 16 * 40) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nt = (num_query + 15) / 16;
-  if (nt <= 7) launch_fwd<7>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
-  else if (nt <= 13) launch_fwd<13>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
-  else if (nt <= 19) launch_fwd<19>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
-  else launch_fwd<40>(st, q, k, v, out, q_heads, k_heads, lse, batch, num_query, num_heads);
+  // keys split over 4 waves per workgroup (shorter dependent chains, 4x the waves on the chip)
+  const dim3 grid(batch * num_heads * nt), block(256);
+  if (nt <= 16)
+    hipLaunchKernelGGL((self_attn_fwd_split_f32<4, 4>), grid, block, 0, st, q, k, v, out, q_heads, k_heads, lse, batch,
+                       num_query, num_heads);
+  else
+    hipLaunchKernelGGL((self_attn_fwd_split_f32<10, 4>), grid, block, 0, st, q, k, v, out, q_heads, k_heads, lse, batch,
+                       num_query, num_heads);
   return egtr_check_launch();
 }
 
