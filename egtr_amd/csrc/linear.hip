@@ -15,6 +15,65 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// hipcc sinks ordinary global loads next to their first use (20 VGPRs, one L2 round trip per K step): the operand loads
+// of a whole batch of K steps are therefore issued up front as inline asm (kept in program order) and consumed behind
+// hand-counted s_waitcnt vmcnt -- loads return in order, so waiting until only the 3 (NB - 1 - i) newer loads are
+// outstanding guarantees the three operands of step i have landed (same technique as rel_head.hip).
+template <int OFF>
+__device__ __forceinline__ f32x4 gload16(const float4* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void vmwait(f32x4& v) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+// one batch of NB K-steps (4 floats each) starting at float4 index T0 of the three operand rows
+template <int NB, int T0>
+struct SkinnyBatch {
+  template <int I>
+  static __device__ __forceinline__ void issue(f32x4 (&a)[NB], f32x4 (&b0)[NB], f32x4 (&b1)[NB], const float4* xp,
+                                               const float4* w0, const float4* w1) {
+    a[I] = gload16<(T0 + I) * 16>(xp);
+    b0[I] = gload16<(T0 + I) * 16>(w0);
+    b1[I] = gload16<(T0 + I) * 16>(w1);
+    if constexpr (I + 1 < NB) issue<I + 1>(a, b0, b1, xp, w0, w1);
+  }
+  template <int I>
+  static __device__ __forceinline__ void consume(f32x4 (&a)[NB], f32x4 (&b0)[NB], f32x4 (&b1)[NB], f32x4& acc0,
+                                                 f32x4& acc1) {
+    vmwait<3 * (NB - 1 - I)>(a[I]);
+    vmwait<3 * (NB - 1 - I)>(b0[I]);
+    vmwait<3 * (NB - 1 - I)>(b1[I]);
+    // D[row i = X row][col j = W row]: A[i][kk] = X[m0+i][k], B[kk][j] = W[n0+j][k]
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].x, b0[I].x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].x, b1[I].x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].y, b0[I].y, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].y, b1[I].y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].z, b0[I].z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].z, b1[I].z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].w, b0[I].w, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[I].w, b1[I].w, acc1, 0, 0, 0);
+    if constexpr (I + 1 < NB) consume<I + 1>(a, b0, b1, acc0, acc1);
+  }
+};
+
+// the K loop of one (wave, lane group): SPAN floats in batches of up to 8 steps
+template <int SPAN>
+__device__ __forceinline__ void skinny_kloop(const float4* xp, const float4* w0, const float4* w1, f32x4& acc0,
+                                             f32x4& acc1) {
+  constexpr int STEPS = SPAN / 4, NB = STEPS < 8 ? STEPS : 8;
+  static_assert(STEPS % NB == 0, "SPAN / 4 must be a multiple of the batch");
+#pragma unroll
+  for (int t0 = 0; t0 < STEPS; t0 += NB) {
+    f32x4 a[NB], b0[NB], b1[NB];
+    SkinnyBatch<NB, 0>::template issue<0>(a, b0, b1, xp + t0, w0 + t0, w1 + t0);
+    SkinnyBatch<NB, 0>::template consume<0>(a, b0, b1, acc0, acc1);
+  }
+}
+
 // SPAN = K / 16 floats handled by one (wave, lane-group); compile-time for full unrolling: 16 (K=256), 64 (K=1024),
 // 32 (K=512); generic runtime variant below for other K % 64 == 0.
 template <int SPAN>
@@ -32,10 +91,12 @@ __global__ __launch_bounds__(256) void linear_skinny_f32(const float* __restrict
   const float4* w0 = reinterpret_cast<const float4*>(w + (size_t)wr0 * K + kb);
   const float4* w1 = reinterpret_cast<const float4*>(w + (size_t)wr1 * K + kb);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (SPAN > 0) {
+    skinny_kloop<SPAN>(xp, w0, w1, acc0, acc1);
+  } else
 #pragma unroll 4
   for (int t4 = 0; t4 < span / 4; ++t4) {
     const float4 a = xp[t4], b0 = w0[t4], b1 = w1[t4];
-    // D[row i = X row][col j = W row]: A[i][kk] = X[m0+i][k], B[kk][j] = W[n0+j][k]
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0);
@@ -97,6 +158,9 @@ __global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, in
   const float4* w0 = reinterpret_cast<const float4*>(G.w + (size_t)wr0 * K + kb);
   const float4* w1 = reinterpret_cast<const float4*>(G.w + (size_t)wr1 * K + kb);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (SPAN > 0) {
+    skinny_kloop<SPAN>(xp, w0, w1, acc0, acc1);
+  } else
 #pragma unroll 4
   for (int t4 = 0; t4 < span / 4; ++t4) {
     const float4 a = xp[t4], b0 = w0[t4], b1 = w1[t4];
