@@ -36,6 +36,8 @@ SIGNATURES = {
     "egtr_add_layernorm_pos_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _I, _P],
     "egtr_bias_mask_rows_f32": [_P, _P, _P, _P, _I, _I, _I],
     "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "egtr_bias_act_nchw_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "egtr_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
     "egtr_add_layernorm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
     "egtr_sine_pos_embed_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float],
     "egtr_level_geometry_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P,

@@ -14,10 +14,12 @@ from torch import nn
 
 def _fold(conv, bn):
     """Fold a frozen BN into the preceding conv: y = conv(x, w * scale) + shift (exact algebra; fp32 rounding differs
-    from scale-after-conv by ~1e-7 relative)."""
-    scale = bn.weight * (bn.running_var + 1e-5).rsqrt()
-    shift = bn.bias - bn.running_mean * scale
-    return (conv.weight * scale.reshape(-1, 1, 1, 1)).contiguous(), shift.contiguous()
+    from scale-after-conv by ~1e-7 relative).  The folding arithmetic is fp32 whatever the model dtype; the folded
+    weight is stored in the model dtype, the shift always in fp32 (it is applied by the fused epilogue kernel)."""
+    scale = bn.weight.float() * (bn.running_var.float() + 1e-5).rsqrt()
+    shift = bn.bias.float() - bn.running_mean.float() * scale
+    return ((conv.weight.float() * scale.reshape(-1, 1, 1, 1)).to(conv.weight.dtype).contiguous(),
+            shift.contiguous())
 
 
 def conv1x1_as_gemm(x, weight):
@@ -132,7 +134,7 @@ class ResNet50Features(nn.Module):
     def forward(self, x):
         # Inference (no grad, eval, GPU): folded-BN + fused conv/bias/ReLU path; the folded weights are cached and
         # rebuilt if any parameter was modified in place (optimizer step, load_state_dict).
-        if (x.is_cuda and x.dtype == torch.float32 and self.conv1.weight.dtype == torch.float32
+        if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and self.conv1.weight.dtype == x.dtype
                 and not torch.is_grad_enabled() and not self.training):
             key = self._fold_key()
             if self._folded is None or key != self._folded_key:

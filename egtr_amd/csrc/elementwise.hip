@@ -103,6 +103,116 @@ __global__ __launch_bounds__(256) void add_layernorm_256(const float* __restrict
   }
 }
 
+// ---- bf16 storage, fp32 arithmetic (the bf16 stress configuration; raw bfloat16 bits as uint16_t) ---------------------
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even; NaN stays NaN
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+struct bf16x8 { uint4 v; };
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// rows x 256 bf16, one wave per row, lanes 0..31 hold 8 channels each (16 B); gamma / beta bf16 (a model cast with
+// .to(bfloat16) carries them in bf16), statistics in fp32
+__global__ __launch_bounds__(256) void add_layernorm_256_bf16(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ res,
+                                                              const unsigned short* __restrict__ gamma,
+                                                              const unsigned short* __restrict__ beta,
+                                                              unsigned short* __restrict__ y, int rows, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bool act = lane < 32;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (act) {
+    unpack8(reinterpret_cast<const uint4*>(x + (size_t)row * 256)[lane], v);
+    if (res != nullptr) {
+      float r[8];
+      unpack8(reinterpret_cast<const uint4*>(res + (size_t)row * 256)[lane], r);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = bf2f(f2bf(v[i] + r[i]));  // the reference rounds the residual sum to bf16
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sum += v[i];
+  const float mean = wave_sum(sum) * (1.f / 256.f);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sq += act ? (v[i] - mean) * (v[i] - mean) : 0.f;
+  const float rstd = rsqrtf(wave_sum(sq) * (1.f / 256.f) + eps);
+  if (act) {
+    float g[8], b[8], o[8];
+    unpack8(reinterpret_cast<const uint4*>(gamma)[lane], g);
+    unpack8(reinterpret_cast<const uint4*>(beta)[lane], b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (v[i] - mean) * rstd * g[i] + b[i];
+    reinterpret_cast<uint4*>(y + (size_t)row * 256)[lane] = pack8(o);
+  }
+}
+
+// y = act(x + bias[c] (+ residual)) on a bf16 NCHW activation, fp32 bias; 8 elements (16 B) per lane over the FLAT
+// tensor, the channel resolved per element (a group of 8 may straddle one plane boundary; HW >= 8)
+__global__ __launch_bounds__(256) void bias_act_nchw_flat8_bf16(const unsigned short* __restrict__ x,
+                                                                const float* __restrict__ bias,
+                                                                const unsigned short* __restrict__ res,
+                                                                unsigned short* __restrict__ y, long long n8, int C,
+                                                                int HW, int relu) {
+  const double inv = 1.0 / (double)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const long long e0 = i * 8;
+    long long p0 = (long long)((double)e0 * inv);
+    while ((p0 + 1) * HW <= e0) ++p0;
+    while (p0 * HW > e0) --p0;
+    const int left = (int)((p0 + 1) * HW - e0);
+    const float b0 = bias[(int)(p0 % C)], b1 = bias[(int)((p0 + 1) % C)];
+    float v[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[i], v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] += (k < left) ? b0 : b1;
+    if (res != nullptr) {
+      float r[8];
+      unpack8(reinterpret_cast<const uint4*>(res)[i], r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
+    reinterpret_cast<uint4*>(y)[i] = pack8(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_act_nchw_scalar_bf16(const unsigned short* __restrict__ x,
+                                                                 const float* __restrict__ bias,
+                                                                 const unsigned short* __restrict__ res,
+                                                                 unsigned short* __restrict__ y, long long n, int C,
+                                                                 int HW, int relu) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)((i / HW) % C);
+    float v = bf2f(x[i]) + bias[c];
+    if (res != nullptr) v += bf2f(res[i]);
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = f2bf(v);
+  }
+}
+
 // y[g, r, :] = keep[r] ? y[g, r, :] + bias[g, :] : 0   (the value projections of all decoder layers at once: bias add
 // and the padding-mask select of deformable_detr.py:1050-1052 in one pass over G x R x C)
 __global__ __launch_bounds__(256) void bias_mask_rows(float* __restrict__ y, const float* __restrict__ bias,
@@ -499,3 +609,34 @@ extern "C" int egtr_bias_mask_rows_f32(egtr_stream_t stream, float* y, const flo
                      rows, cols / 4);
   return egtr_check_launch();
 }
+
+extern "C" int egtr_bias_act_nchw_bf16(egtr_stream_t stream, const uint16_t* x, const float* bias,
+                                       const uint16_t* residual, uint16_t* y, int N, int C, int HW, int relu) {
+  if (!x || !bias || !y) return EGTR_E_ARG;
+  if (N <= 0 || C <= 0 || HW <= 0) return EGTR_E_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long n = (long long)N * C * HW;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                         reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+  if (n % 8 == 0 && aligned && HW >= 8) {
+    const long long n8 = n / 8;
+    const int blocks = (int)std::min<long long>((n8 + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(bias_act_nchw_flat8_bf16, dim3(blocks), dim3(256), 0, st, x, bias, residual, y, n8, C, HW, relu);
+  } else {
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(bias_act_nchw_scalar_bf16, dim3(blocks), dim3(256), 0, st, x, bias, residual, y, n, C, HW, relu);
+  }
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_add_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual,
+                                       const uint16_t* gamma, const uint16_t* beta, uint16_t* y, int rows, int dim,
+                                       float eps) {
+  if (!x || !gamma || !beta || !y) return EGTR_E_ARG;
+  if (rows <= 0) return EGTR_E_ARG;
+  if (dim != 256) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(add_layernorm_256_bf16, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     residual, gamma, beta, y, rows, eps);
+  return egtr_check_launch();
+}
+

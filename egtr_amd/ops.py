@@ -277,9 +277,20 @@ def module_linear(mod, x, alpha=1.0, relu=False):
 
 
 def bias_act_(x, bias, residual=None, relu=True):
-    """In-place y = act(x + bias[c] (+ residual)) on an NCHW activation (inference only, no autograd)."""
+    """In-place y = act(x + bias[c] (+ residual)) on an NCHW activation (inference only, no autograd).  fp32, or bf16
+    activations with an fp32 bias."""
     lib = _lib.lib()
     N, C, H, W_ = x.shape
+    if x.dtype == torch.bfloat16:
+        _chk(x, "x", torch.bfloat16)
+        _chk(bias, "bias", torch.float32)
+        if residual is not None:
+            _chk(residual, "residual", torch.bfloat16)
+        st = lib.egtr_bias_act_nchw_bf16(_stream(), x.data_ptr(), bias.data_ptr(),
+                                         residual.data_ptr() if residual is not None else None, x.data_ptr(), N, C,
+                                         H * W_, 1 if relu else 0)
+        _lib.check(st, "egtr_bias_act_nchw_bf16")
+        return x
     _chk(x, "x", torch.float32)
     _chk(bias, "bias", torch.float32)
     if residual is not None:
@@ -410,6 +421,17 @@ def add_layer_norm(x, residual, ln):
     """ln(residual + x) for an nn.LayerNorm over d_model = 256."""
     if x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 256:
         return AddLayerNormFunction.apply(x, residual, ln.weight, ln.bias, ln.eps)
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] == 256 and not torch.is_grad_enabled()
+            and ln.weight.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16):
+        # bf16 inference (stress configuration): one pass, fp32 statistics
+        lib = _lib.lib()
+        x2 = _chk(x.contiguous(), "x", torch.bfloat16)
+        r2 = _chk(residual.contiguous(), "residual", torch.bfloat16)
+        y = torch.empty_like(x2)
+        st = lib.egtr_add_layernorm_bf16(_stream(), x2.data_ptr(), r2.data_ptr(), ln.weight.data_ptr(),
+                                         ln.bias.data_ptr(), y.data_ptr(), x2.numel() // 256, 256, float(ln.eps))
+        _lib.check(st, "egtr_add_layernorm_bf16")
+        return y
     return ln(residual + x)
 
 

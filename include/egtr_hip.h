@@ -185,6 +185,14 @@ int egtr_bias_act_nchw_f32(egtr_stream_t stream, const float* x, const float* bi
 int egtr_add_layernorm_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,
                            const float* beta, float* y, int rows, int dim, float eps);
 
+/* bf16 storage (raw bfloat16 bits), fp32 arithmetic -- the same two epilogues for the bf16 stress configuration:
+ * y = act(x + bias[c] (+ residual)) on an NCHW activation (bias fp32), and y = LayerNorm(x + residual) over 256 channels
+ * (gamma / beta bf16; the residual sum is rounded to bf16 before the statistics, as the PyTorch composition does). */
+int egtr_bias_act_nchw_bf16(egtr_stream_t stream, const uint16_t* x, const float* bias, const uint16_t* residual,
+                            uint16_t* y, int N, int C, int HW, int relu);
+int egtr_add_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual, const uint16_t* gamma,
+                            const uint16_t* beta, uint16_t* y, int rows, int dim, float eps);
+
 /* Same, and additionally y_plus_pos = y + pos[row % pos_rows] (the "with_pos_embed" input of the next sub-layer,
  * deformable_detr.py:1023-1024 / 1148-1149), saving one elementwise launch per sub-layer. */
 int egtr_add_layernorm_pos_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,

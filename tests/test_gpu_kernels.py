@@ -852,3 +852,39 @@ def test_msda_fused_strided_inputs_and_keep_mask():
     km._egtr_bits = bits
     out_b, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, km)
     assert torch.equal(out_b, out)
+
+
+# ------------------------------------------------------------------------------------------- bf16 epilogues
+@pytest.mark.parametrize("rows", [1, 5, 200, 12537])
+def test_add_layer_norm_bf16(rows):
+    """egtr_add_layernorm_bf16 (bf16 storage, fp32 statistics) vs the fp64 LayerNorm of the bf16-rounded sum."""
+    from egtr_amd.ops import add_layer_norm
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 256, generator=g).bfloat16()
+    r = torch.randn(rows, 256, generator=g).bfloat16()
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(256, generator=g)); ln.bias.copy_(0.2 * torch.randn(256, generator=g))
+    ln = ln.to(DEV).bfloat16()
+    with torch.no_grad():
+        y = add_layer_norm(x.to(DEV), r.to(DEV), ln)
+    assert y.dtype == torch.bfloat16
+    s_ = (x + r).double()   # the reference composition rounds the residual sum to bf16
+    want = torch.nn.functional.layer_norm(s_, (256,), ln.weight.double().cpu(), ln.bias.double().cpu(), ln.eps)
+    assert (y.cpu().double() - want).abs().max() < 2e-2 * max(1.0, float(want.abs().max()) / 4)
+
+
+@pytest.mark.parametrize("N,C,H,Wd", [(2, 64, 25, 42), (1, 256, 100, 167), (3, 8, 3, 3), (1, 5, 1, 7), (2, 16, 50, 84)])
+def test_bias_act_nchw_bf16(N, C, H, Wd):
+    from egtr_amd.ops import bias_act_
+    g = torch.Generator().manual_seed(N * C + H)
+    x = torch.randn(N, C, H, Wd, generator=g).bfloat16()
+    res = torch.randn(N, C, H, Wd, generator=g).bfloat16()
+    b = torch.randn(C, generator=g)
+    for use_res, relu in ((True, True), (False, True), (False, False)):
+        want = x.float() + b.view(1, C, 1, 1) + (res.float() if use_res else 0)
+        want = torch.relu(want) if relu else want
+        y = bias_act_(x.clone().to(DEV), b.to(DEV), res.to(DEV) if use_res else None, relu=relu)
+        assert y.dtype == torch.bfloat16
+        assert torch.equal(y.cpu(), want.bfloat16()), (use_res, relu)
+

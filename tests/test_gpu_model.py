@@ -354,3 +354,26 @@ def test_triplet_candidates_on_device_match_reference_postprocessing():
         assert np.array_equal(got[b]["pred_classes"].cpu().numpy(), want["pred_classes"])
         assert np.abs(got[b]["pred_boxes"].cpu().numpy() - want["pred_boxes"]).max() < 1e-3
 
+
+def test_backbone_folded_path_bf16_matches_unfolded_bf16():
+    """bf16 model: frozen-BN folding (fp32 arithmetic, bf16 weights) + the bf16 bias/residual/ReLU epilogue vs the
+    plain bf16 module path and vs the fp32 backbone (bf16 tolerance)."""
+    from egtr_amd.backbone import ResNet50Features
+    torch.manual_seed(0)
+    net = ResNet50Features().to(DEV).eval()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.1)
+    x = torch.randn(2, 3, 96, 132, device=DEV)
+    with torch.no_grad():
+        f32 = net(x)
+        nb = net.bfloat16()
+        folded = nb(x.bfloat16())
+    assert folded[0].dtype == torch.bfloat16
+    for a, b in zip(folded, f32):
+        ref = float(b.abs().max())
+        assert float((a.float() - b).abs().max()) < 0.06 * max(ref, 1.0)
+
