@@ -172,10 +172,16 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return (ua >> 16) | (ub & 0xffff0000u);
 }
 
+// FUSED: `loc` / `attn` hold the raw bf16 outputs of the sampling_offsets / attention_weights Linears (row strides
+// ld_off / ld_logit elements) and `ref` the bf16 reference points [nq, L, 2]; softmax and loc = ref + off / (W, H) are
+// formed here in fp32 (the PyTorch composition rounds every intermediate to bf16); `keep` (optional, bytes per token):
+// padded tokens are skipped == their value rows zeroed (dd:1052).
+template <bool FUSED>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
     const uint16_t* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-    const float* __restrict__ loc, const float* __restrict__ attn, uint16_t* __restrict__ out, int nq_total,
-    int Lq, int S, int L, int P, int nblk) {
+    const void* __restrict__ loc, const void* __restrict__ attn, uint16_t* __restrict__ out, int nq_total,
+    int Lq, int S, int L, int P, int nblk, const uint16_t* __restrict__ ref, int ld_off, int ld_logit,
+    const unsigned char* __restrict__ keep) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * 2 * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * 2 * kWaveEntries];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -190,9 +196,33 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
 #pragma unroll
   for (int qq = 0; qq < 2; ++qq) {
     const int q = min(qpair + qq, nq_total - 1);
-    const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
-    const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
     const int head_s = lane >> 3, s0 = (lane & 7) * 2;
+    float4 lc;
+    float2 aw;
+    if (FUSED) {
+      const int lvl = s0 / P;
+      const uint2 o = reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(loc) + (size_t)q * ld_off)[lane];
+      const unsigned lg = reinterpret_cast<const unsigned*>(reinterpret_cast<const uint16_t*>(attn) + (size_t)q * ld_logit)[lane];
+      const unsigned rp = reinterpret_cast<const unsigned*>(ref + ((size_t)q * L + lvl) * 2)[0];
+      const float rx = bf16_lo(rp), ry = bf16_hi(rp);
+      const float fw = (float)SEL_W(G, lvl), fh = (float)SEL_H(G, lvl);
+      lc = make_float4(rx + bf16_lo(o.x) / fw, ry + bf16_hi(o.x) / fh, rx + bf16_lo(o.y) / fw, ry + bf16_hi(o.y) / fh);
+      aw = make_float2(bf16_lo(lg), bf16_hi(lg));
+      float m = fmaxf(aw.x, aw.y);
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
+      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, false)));
+      const float e0 = expf(aw.x - m), e1 = expf(aw.y - m);
+      float sum = e0 + e1;
+      sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
+      sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
+      sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
+      aw = make_float2(e0 / sum, e1 / sum);
+    } else {
+      lc = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(loc) + (size_t)q * 256)[lane];
+      aw = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(attn) + (size_t)q * 128)[lane];
+    }
+    const unsigned char* kp = (FUSED && keep != nullptr) ? keep + (size_t)(q / Lq) * S : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int s = s0 + j;
@@ -200,10 +230,16 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
       const SampleGeom g = sample_geom<512, 64>(j ? lc.z : lc.x, j ? lc.w : lc.y, SEL_H(G, lvl), SEL_W(G, lvl),
                                                 SEL_S(G, lvl), head_s);
       const float a = j ? aw.y : aw.x;
+      bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
+      if (kp != nullptr) {
+        k0 = k0 && kp[g.off[0] >> 9];
+        k1 = k1 && kp[g.off[1] >> 9];
+        k2 = k2 && kp[g.off[2] >> 9];
+        k3 = k3 && kp[g.off[3] >> 9];
+      }
       my_off[qq * kWaveEntries + head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
       my_w[qq * kWaveEntries + head_s * kHeadStride + s] =
-          make_float4(g.ok[0] ? g.w[0] * a : 0.f, g.ok[1] ? g.w[1] * a : 0.f, g.ok[2] ? g.w[2] * a : 0.f,
-                      g.ok[3] ? g.w[3] * a : 0.f);
+          make_float4(k0 ? g.w[0] * a : 0.f, k1 ? g.w[1] * a : 0.f, k2 ? g.w[2] * a : 0.f, k3 ? g.w[3] * a : 0.f);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -672,9 +708,33 @@ extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* valu
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long nq = (long long)batch * num_query;
   const int nblk = (int)((nq + 2 * kWaves - 1) / (2 * kWaves));
-  hipLaunchKernelGGL(msda_fwd_q32_bf16, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
-                     level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size, num_levels,
-                     num_point, nblk);
+  hipLaunchKernelGGL(msda_fwd_q32_bf16<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+                     level_start_index, (const void*)sampling_loc, (const void*)attn_weight, out, (int)nq, num_query,
+                     spatial_size, num_levels, num_point, nblk, (const uint16_t*)nullptr, 256, 128,
+                     (const unsigned char*)nullptr);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,
+                                            const int64_t* level_start_index, const uint16_t* sampling_offsets,
+                                            const uint16_t* attn_logits, const uint16_t* reference_points, int batch,
+                                            int spatial_size, int num_heads, int channels, int num_levels,
+                                            int num_query, int num_point, uint16_t* out, int ld_offsets, int ld_logits,
+                                            const unsigned char* keep_mask) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
+      !out)
+    return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_query <= 0) return EGTR_E_ARG;
+  if (ld_offsets < 256 || ld_logits < 128 || (ld_offsets & 3) || (ld_logits & 1)) return EGTR_E_ARG;
+  const long long nq = (long long)batch * num_query;
+  if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
+      (long long)spatial_size * 512 >= (1ll << 31) || nq >= (1ll << 27))
+    return EGTR_E_UNSUPPORTED;
+  const int nblk = (int)((nq + 2 * kWaves - 1) / (2 * kWaves));
+  hipLaunchKernelGGL(msda_fwd_q32_bf16<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
+                     spatial_shapes, level_start_index, (const void*)sampling_offsets, (const void*)attn_logits, out,
+                     (int)nq, num_query, spatial_size, num_levels, num_point, nblk, reference_points, ld_offsets,
+                     ld_logits, keep_mask);
   return egtr_check_launch();
 }
 

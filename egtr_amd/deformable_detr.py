@@ -394,7 +394,10 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but got {reference_points.shape[-1]}")
         needs_grad = torch.is_grad_enabled() and (value.requires_grad or sampling_offsets.requires_grad
                                                   or attention_weights.requires_grad or reference_points.requires_grad)
-        if (not needs_grad and value.is_cuda and reference_points.shape[-1] == 2 and value.dtype == torch.float32
+        if (not needs_grad and value.is_cuda and reference_points.shape[-1] == 2
+                and (value.dtype == torch.float32
+                     or (value.dtype == torch.bfloat16 and not output_attentions
+                         and sampling_offsets.dtype == torch.bfloat16))
                 and ops.msda_fused_supported(self.n_heads, self.d_model // self.n_heads, self.n_levels, self.n_points)):
             # inference: softmax + sampling locations (dd:1055-1073) are formed inside the HIP kernel, which also
             # skips padded tokens (== the zeroed value rows of dd:1052) when the values were not masked above

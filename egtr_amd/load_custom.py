@@ -114,6 +114,45 @@ class _MultiScaleDeformableAttention:
         return out, wts
 
     @staticmethod
+    def ms_deform_attn_forward_fused_bf16(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                          reference_points, keep_mask=None):
+        """bf16 counterpart of ``ms_deform_attn_forward_fused`` (M = 8, D = 32, L*P = 16): every tensor bf16, softmax and
+        sampling locations formed in fp32 inside the kernel.  Returns out [B, Lq, M*D] bf16."""
+        lib = _lib.lib()
+        B, S, M, D = value.shape
+        L = spatial_shapes.shape[0]
+        Lq, P = sampling_offsets.shape[1], sampling_offsets.shape[4]
+        bf = torch.bfloat16
+        _chk(value, "value", bf)
+        _chk(spatial_shapes, "spatial_shapes", torch.int64)
+        _chk(level_start_index, "level_start_index", torch.int64)
+        ref = _chk(reference_points.to(bf).contiguous(), "reference_points", bf)
+        if tuple(ref.shape) != (B, Lq, L, 2):
+            raise RuntimeError(f"reference_points must be [B, Lq, L, 2], got {tuple(ref.shape)}")
+
+        def rows(t, width, name):
+            if not t.is_cuda or t.dtype != bf:
+                raise RuntimeError(f"{name} must be a bfloat16 CUDA/HIP tensor")
+            t2 = t.reshape(B, Lq, width) if t.is_contiguous() else t.flatten(2)
+            if t2.stride(2) != 1 or (B > 1 and t2.stride(0) != Lq * t2.stride(1)) or t2.data_ptr() % 8:
+                t2 = t2.contiguous()
+            return t2, t2.stride(1)
+
+        off2, ld_off = rows(sampling_offsets, M * L * P * 2, "sampling_offsets")
+        log2, ld_log = rows(attn_logits, M * L * P, "attn_logits")
+        km = None
+        if keep_mask is not None:
+            km = keep_mask.reshape(B, S).contiguous()
+            km = km.view(torch.uint8) if km.dtype == torch.bool else km.to(torch.uint8)
+        out = torch.empty(B, Lq, M * D, dtype=bf, device=value.device)
+        st = lib.egtr_msda_forward_fused_bf16(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
+                                              level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
+                                              ref.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(), ld_off, ld_log,
+                                              km.data_ptr() if km is not None else None)
+        _lib.check(st, "ms_deform_attn_forward_fused_bf16")
+        return out
+
+    @staticmethod
     def ms_deform_attn_forward_variant(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, variant):
         """fp32 forward with an explicit kernel variant (include/egtr_hip.h); benchmarks and A/B parity tests."""
         lib = _lib.lib()

@@ -55,6 +55,11 @@ def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offset
     """MSDA forward with its softmax / sampling-location prologue fused in (no autograd: inference path)."""
     from .load_custom import load_hip_kernels
     k = load_hip_kernels()
+    if value.dtype == torch.bfloat16:
+        if want_weights:
+            raise NotImplementedError("the bf16 fused MSDA forward does not return attention weights")
+        return k.ms_deform_attn_forward_fused_bf16(value, spatial_shapes, level_start_index, sampling_offsets,
+                                                   attn_logits, reference_points, keep_mask), None
     return k.ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
                                           reference_points, want_weights, keep_mask)
 

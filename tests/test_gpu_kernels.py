@@ -888,3 +888,34 @@ def test_bias_act_nchw_bf16(N, C, H, Wd):
         assert y.dtype == torch.bfloat16
         assert torch.equal(y.cpu(), want.bfloat16()), (use_res, relu)
 
+
+@pytest.mark.parametrize("shapes,B,Lq", [([(19, 32), (10, 16), (5, 8), (3, 4)], 2, None),
+                                         ([(19, 32), (10, 16), (5, 8), (3, 4)], 3, 50), ([(9, 13), (5, 7)], 2, 33)])
+def test_msda_fused_bf16_matches_fp32_composition(shapes, B, Lq):
+    """egtr_msda_forward_fused_bf16 (bf16 storage, fp32 prologue + accumulation, optional padding mask) against the
+    oracle evaluated on the SAME bf16-rounded operands."""
+    k = _kernels()
+    g = torch.Generator().manual_seed(17)
+    L = len(shapes)
+    P = 16 // L
+    S = sum(h * w for h, w in shapes)
+    Lq = Lq or S
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    bf = torch.bfloat16
+    value = torch.randn(B, S, 8, 32, generator=g).to(bf)
+    off = (3.0 * torch.randn(B, Lq, 8, L, P, 2, generator=g)).to(bf)
+    logits = (2.0 * torch.randn(B, Lq, 8, L * P, generator=g)).to(bf)
+    ref = (torch.rand(B, Lq, L, 2, generator=g) * 1.2 - 0.1).to(bf)
+    keep = torch.rand(B, S, generator=g) > 0.2
+    norm = torch.stack([shp[:, 1], shp[:, 0]], -1).float()
+    loc = ref.float()[:, :, None, :, None, :] + off.float() / norm[None, None, None, :, None, :]
+    attn = torch.softmax(logits.float(), -1).view(B, Lq, 8, L, P)
+    for km in (None, keep):
+        v = value.float() if km is None else value.float() * km[..., None, None]
+        want = OM.msda_forward(v, shp, lsi, loc.contiguous(), attn.contiguous())
+        got = k.ms_deform_attn_forward_fused_bf16(value.to(DEV), shp.to(DEV), lsi.to(DEV), off.to(DEV), logits.to(DEV),
+                                                  ref.to(DEV), None if km is None else km.to(DEV))
+        assert got.dtype == bf
+        assert (got.cpu().float() - want).abs().max() < 2e-2 * max(1.0, float(want.abs().max()))
+
