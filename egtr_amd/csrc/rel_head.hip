@@ -319,6 +319,248 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
   }
 }
 
+// ------------------------------------------------------------------------------------------ bf16 matrix cores
+// Same kernel with layers 2 and 3 on v_mfma_f32_32x32x16_bf16 (the bf16 stress configuration: the weights W2 / W3 are
+// the model's bf16 parameters, h1 / h2 are rounded to bf16 as operands, accumulation in fp32).  Layer 1 (gate, gated
+// sum, ReLU) is unchanged fp32 VALU work.  Operand layout of the 32x32x16 MFMA: lane (i = l & 31, hf = l >> 5) holds
+// A[i][8 hf + 0..7] and B[8 hf + 0..7][i]; D as for 32x32x2 (row = (r & 3) + 8 (r >> 2) + 4 hf, col = l & 31).
+//   layer 2:  h2^T[n][pair] = sum_k W2[n][k] h1[pair][k]: step t covers k = 16 t .. 16 t + 15, so lane (pair, hf) keeps the
+//             h1 channels {16 t + 8 hf + e} as 16 packed operands (64 VGPRs instead of 128 fp32 values);
+//   layer 3:  the 16 accumulators of a 32-wide n tile are rows {0-3, 8-11, 16-19, 24-27} + 4 hf: registers 0..7 / 8..15
+//             are the B operands of two K = 16 steps whose k slot e stands for row (e & 3) + 8 (e >> 2) + 4 hf (+ 16 for
+//             the second step); the W3 operand is gathered in the same order (two 8-byte loads per step).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 pack_bf16x8(const float (&f)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (__bf16)f[i];
+  return v;
+}
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
+
+template <int T, int OT>
+__global__ __launch_bounds__(64) void rel_head_fwd_bf16w(
+    const float* __restrict__ gate_q, const float* __restrict__ gate_k, const float* __restrict__ uq,
+    const float* __restrict__ uk, const float* __restrict__ b1, const unsigned short* __restrict__ w2r,
+    const float* __restrict__ b2r, const unsigned short* __restrict__ w3r, const float* __restrict__ b3r,
+    const unsigned short* __restrict__ w2c, const float* __restrict__ b2c, const unsigned short* __restrict__ w3c,
+    const float* __restrict__ b3c, const float* __restrict__ triplet, const int64_t* __restrict__ node_cls, int B,
+    int N, int R, int C1, float* __restrict__ rel_logits, float* __restrict__ conn_logits,
+    float* __restrict__ gate_mean) {
+  constexpr int kBuf = 16 * kH1Stride > 32 * (32 * OT + 1) ? 16 * kH1Stride : 32 * (32 * OT + 1);
+  __shared__ __attribute__((aligned(16))) float s_buf[kBuf];
+  float* const s_out = s_buf;
+  float* const s_h1 = s_buf;
+  __shared__ int s_tb[32];
+  const int lane = threadIdx.x, pi = lane & 31, hf = lane >> 5;
+  const int mlp = blockIdx.y;
+  const long long total = (long long)B * N * N;
+  const long long p0 = (long long)blockIdx.x * 32;
+  const long long p = p0 + pi;
+  const bool valid = p < total;
+  const long long pc = valid ? p : total - 1;
+  const int b = (int)(pc / ((long long)N * N));
+  const int rem = (int)(pc - (long long)b * N * N);
+  const int i = rem / N, j = rem - i * N;
+  const size_t qi = (size_t)b * N + i, kj = (size_t)b * N + j;
+
+  float g[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float x = gate_q[qi * T + t] + gate_k[kj * T + t];
+    g[t] = 1.f / (1.f + expf(-x));
+  }
+  if (gate_mean != nullptr && mlp == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float v = (valid && hf == 0) ? g[t] : 0.f;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      if (lane == 0) unsafeAtomicAdd(gate_mean + t, v / (float)total);
+    }
+  }
+
+  // ---- layer 1 (fp32, as in rel_head_fwd_f32): pair by pair, lane = channel quad, transposed through LDS ------------
+  bf16x8 h1b[16];
+  {
+    const int qrow_l = (int)qi, krow_l = (int)kj;
+    const float4 bias4 = reinterpret_cast<const float4*>(b1 + mlp * kHd)[lane];
+    const float4* uq4 = reinterpret_cast<const float4*>(uq) + mlp * (kHd / 4) + lane;
+    const float4* uk4 = reinterpret_cast<const float4*>(uk) + mlp * (kHd / 4) + lane;
+    constexpr int ROW4 = 2 * kHd / 4;
+    float4 ua[T];
+    f32x4v rc[2][T];
+    int q_cur = -1;
+    auto issue = [&](int set, int pp) {
+      const int kr = __builtin_amdgcn_readlane(krow_l, pp);
+      const float4* pk = uk4 + (size_t)kr * T * ROW4;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if (set == 0) rc[0][t] = gload_b128<0>(pk + t * ROW4);
+        else rc[1][t] = gload_b128<0>(pk + t * ROW4);
+      }
+    };
+    auto consume = [&](int set, int pp, int row, bool more) {
+      const int qr = __builtin_amdgcn_readlane(qrow_l, pp);
+      if (qr != q_cur) {
+        q_cur = qr;
+        const float4* pq = uq4 + (size_t)qr * T * ROW4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) ua[t] = pq[t * ROW4];
+      }
+      float4 acc = bias4;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if (set == 0) {
+          if (more) { vm_wait1<T + (T - 1)>(rc[0][t], t); } else { vm_wait1<T - 1>(rc[0][t], t); }
+        } else {
+          if (more) { vm_wait1<T + (T - 1)>(rc[1][t], t); } else { vm_wait1<T - 1>(rc[1][t], t); }
+        }
+        const float4 a = ua[t];
+        const f32x4v c = set ? rc[1][t] : rc[0][t];
+        const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[t]), pp));
+        acc.x += gt * (a.x + c.x);
+        acc.y += gt * (a.y + c.y);
+        acc.z += gt * (a.z + c.z);
+        acc.w += gt * (a.w + c.w);
+      }
+      *reinterpret_cast<float4*>(&s_h1[row * kH1Stride + 4 * lane]) =
+          make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+    };
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      const int pbase = half * 16;
+      issue(0, pbase);
+#pragma unroll 1
+      for (int pp = 0; pp < 16; pp += 2) {
+        issue(1, pbase + pp + 1);
+        consume(0, pbase + pp, pp, true);
+        if (pp + 2 < 16) issue(0, pbase + pp + 2);
+        consume(1, pbase + pp + 1, pp + 1, pp + 2 < 16);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if ((pi >> 4) == half) {
+        const float* hp = &s_h1[(pi & 15) * kH1Stride + 8 * hf];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float4 v0 = *reinterpret_cast<const float4*>(hp + 16 * t);
+          const float4 v1 = *reinterpret_cast<const float4*>(hp + 16 * t + 4);
+          const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          h1b[t] = pack_bf16x8(f);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  const unsigned short* w2 = mlp ? w2c : w2r;
+  const float* b2 = mlp ? b2c : b2r;
+  f32x16 racc[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[ot][r] = 0.f;
+  float cacc = 0.f;
+
+#pragma unroll 1
+  for (int nt = 0; nt < kHd / 32; ++nt) {
+    // ---- layer 2: 16 steps of K = 16; the lane's W2 row fragment for step t is 16 contiguous bytes ------------------
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float4* wrow = reinterpret_cast<const float4*>(w2 + (size_t)(nt * 32 + pi) * kHd) + hf;
+    f32x4v wq[16];
+    // all 16 operand loads in flight, consumed in order (inline asm keeps them in program order)
+    wq[0] = gload_b128<0 * 32>(wrow);   wq[1] = gload_b128<1 * 32>(wrow);   wq[2] = gload_b128<2 * 32>(wrow);
+    wq[3] = gload_b128<3 * 32>(wrow);   wq[4] = gload_b128<4 * 32>(wrow);   wq[5] = gload_b128<5 * 32>(wrow);
+    wq[6] = gload_b128<6 * 32>(wrow);   wq[7] = gload_b128<7 * 32>(wrow);   wq[8] = gload_b128<8 * 32>(wrow);
+    wq[9] = gload_b128<9 * 32>(wrow);   wq[10] = gload_b128<10 * 32>(wrow); wq[11] = gload_b128<11 * 32>(wrow);
+    wq[12] = gload_b128<12 * 32>(wrow); wq[13] = gload_b128<13 * 32>(wrow); wq[14] = gload_b128<14 * 32>(wrow);
+    wq[15] = gload_b128<15 * 32>(wrow);
+#define EGTR_L2STEP(TT)                                                       \
+    vm_wait<15 - TT>(wq[TT]);                                                  \
+    acc = mfma_bf16(__builtin_bit_cast(bf16x8, wq[TT]), h1b[TT], acc);
+    EGTR_L2STEP(0) EGTR_L2STEP(1) EGTR_L2STEP(2) EGTR_L2STEP(3) EGTR_L2STEP(4) EGTR_L2STEP(5) EGTR_L2STEP(6)
+    EGTR_L2STEP(7) EGTR_L2STEP(8) EGTR_L2STEP(9) EGTR_L2STEP(10) EGTR_L2STEP(11) EGTR_L2STEP(12) EGTR_L2STEP(13)
+    EGTR_L2STEP(14) EGTR_L2STEP(15)
+#undef EGTR_L2STEP
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int n0 = nt * 32 + 8 * rq + 4 * hf;
+      const float4 bb = *reinterpret_cast<const float4*>(b2 + n0);
+      acc[4 * rq + 0] = fmaxf(acc[4 * rq + 0] + bb.x, 0.f);
+      acc[4 * rq + 1] = fmaxf(acc[4 * rq + 1] + bb.y, 0.f);
+      acc[4 * rq + 2] = fmaxf(acc[4 * rq + 2] + bb.z, 0.f);
+      acc[4 * rq + 3] = fmaxf(acc[4 * rq + 3] + bb.w, 0.f);
+    }
+    if (mlp == 0) {
+      // ---- layer 3 (relation): two K = 16 steps per n tile; k slot e <-> n = nt*32 + 16 kb + (e&3) + 8 (e>>2) + 4 hf ----
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const float hv[8] = {acc[8 * kb + 0], acc[8 * kb + 1], acc[8 * kb + 2], acc[8 * kb + 3],
+                             acc[8 * kb + 4], acc[8 * kb + 5], acc[8 * kb + 6], acc[8 * kb + 7]};
+        const bf16x8 hb = pack_bf16x8(hv);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const int ro = ot * 32 + pi;
+          const bool rok = ro < R;
+          const unsigned short* w3p = w3r + (size_t)(rok ? ro : 0) * kHd + nt * 32 + 16 * kb + 4 * hf;
+          uint2 lo = *reinterpret_cast<const uint2*>(w3p), hi = *reinterpret_cast<const uint2*>(w3p + 8);
+          if (!rok) { lo = make_uint2(0u, 0u); hi = make_uint2(0u, 0u); }
+          const uint4 wv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          racc[ot] = mfma_bf16(__builtin_bit_cast(bf16x8, wv), hb, racc[ot]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const uint2 wv = *reinterpret_cast<const uint2*>(w3c + nt * 32 + 8 * rq + 4 * hf);
+        cacc += bf16_bits_to_f32((unsigned short)(wv.x & 0xffffu)) * acc[4 * rq + 0] +
+                bf16_bits_to_f32((unsigned short)(wv.x >> 16)) * acc[4 * rq + 1] +
+                bf16_bits_to_f32((unsigned short)(wv.y & 0xffffu)) * acc[4 * rq + 2] +
+                bf16_bits_to_f32((unsigned short)(wv.y >> 16)) * acc[4 * rq + 3];
+      }
+    }
+  }
+
+  if (mlp == 1) {
+    cacc += __shfl_xor(cacc, 32);
+    if (valid && hf == 0) conn_logits[p] = cacc + b3c[0];
+    return;
+  }
+  constexpr int kStride = 32 * OT + 1;
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      s_out[pi * kStride + ro] = racc[ot][r];
+    }
+  if (hf == 0) {
+    int tb = -1;
+    if (triplet != nullptr) tb = ((int)node_cls[qi] * C1 + (int)node_cls[kj]) * R;
+    s_tb[pi] = tb;
+  }
+  __syncthreads();
+  const int npair = (int)((total - p0) < 32 ? (total - p0) : 32);
+  float* dst = rel_logits + (size_t)p0 * R;
+  for (int pp = 0; pp < npair; ++pp) {
+    const int tb = s_tb[pp];
+    for (int r = lane; r < R; r += 64) {
+      float v = s_out[pp * kStride + r] + b3r[r];
+      if (tb >= 0) v += triplet[tb + r];
+      dst[(size_t)pp * R + r] = v;
+    }
+  }
+}
+
 template <int T>
 int launch_T(hipStream_t st, int R, dim3 grid, const float* gate_q, const float* gate_k, const float* uq,
              const float* uk, const float* b1, const float* w2r, const float* b2r, const float* w3r,
@@ -548,3 +790,40 @@ extern "C" int egtr_rel_head_backward_pairs_f32(egtr_stream_t stream, const floa
 #undef EGTR_T
   return egtr_check_launch();
 }
+
+extern "C" int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* gate_q, const float* gate_k,
+                                           const float* uq, const float* uk, const float* b1, const uint16_t* w2r,
+                                           const float* b2r, const uint16_t* w3r, const float* b3r,
+                                           const uint16_t* w2c, const float* b2c, const uint16_t* w3c,
+                                           const float* b3c, const float* triplet_dist, const int64_t* node_cls,
+                                           int batch, int num_query, int num_slots, int hidden, int num_rel,
+                                           int num_cls_plus1, float* rel_logits, float* conn_logits,
+                                           float* gate_mean) {
+  if (!gate_q || !gate_k || !uq || !uk || !b1 || !w2r || !b2r || !w3r || !b3r || !w2c || !b2c || !w3c || !b3c ||
+      !rel_logits || !conn_logits)
+    return EGTR_E_ARG;
+  if (triplet_dist != nullptr && node_cls == nullptr) return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_slots <= 0 || num_rel <= 0) return EGTR_E_ARG;
+  if (hidden != kHd || num_rel > 64 || num_slots > 10) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long total = (long long)batch * num_query * num_query;
+  const dim3 grid((unsigned)((total + 31) / 32), 2);
+#define EGTR_TB(TT)                                                                                                  \
+  case TT:                                                                                                           \
+    if (num_rel <= 32)                                                                                               \
+      hipLaunchKernelGGL((rel_head_fwd_bf16w<TT, 1>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, \
+                         b3r, w2c, b2c, w3c, b3c, triplet_dist, node_cls, batch, num_query, num_rel, num_cls_plus1,  \
+                         rel_logits, conn_logits, gate_mean);                                                        \
+    else                                                                                                             \
+      hipLaunchKernelGGL((rel_head_fwd_bf16w<TT, 2>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, \
+                         b3r, w2c, b2c, w3c, b3c, triplet_dist, node_cls, batch, num_query, num_rel, num_cls_plus1,  \
+                         rel_logits, conn_logits, gate_mean);                                                        \
+    break;
+  switch (num_slots) {
+    EGTR_TB(1) EGTR_TB(2) EGTR_TB(3) EGTR_TB(4) EGTR_TB(5) EGTR_TB(6) EGTR_TB(7) EGTR_TB(8) EGTR_TB(9) EGTR_TB(10)
+    default: return EGTR_E_UNSUPPORTED;
+  }
+#undef EGTR_TB
+  return egtr_check_launch();
+}
+

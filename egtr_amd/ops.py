@@ -521,9 +521,49 @@ class RelationHeadFunction(Function):
         return (dgq, dgk, duq, duk, db1, dw2r, db2r, dw3r, db3r, dw2c, db2c, dw3c, db3c, None, None, None)
 
 
+def relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
+                        node_cls=None, want_gate_mean=False):
+    """Inference forward of a bf16 model: layers 2 / 3 on the bf16 matrix cores with the bf16 parameters as they are
+    (egtr_rel_head_forward_bf16w); the per-query tables, gates, biases and the outputs are fp32.  No autograd."""
+    lib = _lib.lib()
+    B, N, T = gate_q.shape
+    Hd = w2r.shape[1]
+    R = w3r.shape[0]
+    dev = gate_q.device
+    f32 = [_chk(t.detach().float().contiguous(), n, torch.float32)
+           for t, n in ((gate_q, "gate_q"), (gate_k, "gate_k"), (uq, "uq"), (uk, "uk"), (b1, "b1"), (b2r, "b2r"),
+                        (b3r, "b3r"), (b2c, "b2c"), (b3c, "b3c"))]
+    gq, gk, uq_, uk_, b1_, b2r_, b3r_, b2c_, b3c_ = f32
+    wts = [_chk(t.detach().contiguous(), n, torch.bfloat16)
+           for t, n in ((w2r, "w2r"), (w3r, "w3r"), (w2c, "w2c"), (w3c, "w3c"))]
+    w2r_, w3r_, w2c_, w3c_ = wts
+    rel = torch.empty(B, N, N, R, dtype=torch.float32, device=dev)
+    conn = torch.empty(B, N, N, dtype=torch.float32, device=dev)
+    gm = torch.zeros(T, dtype=torch.float32, device=dev) if want_gate_mean else None
+    td = None
+    c1 = 0
+    if triplet_dist is not None:
+        td = _chk(triplet_dist.detach().float().contiguous(), "triplet_dist", torch.float32)
+        _chk(node_cls, "node_cls", torch.int64)
+        c1 = td.shape[0]
+    st = lib.egtr_rel_head_forward_bf16w(
+        _stream(), gq.data_ptr(), gk.data_ptr(), uq_.data_ptr(), uk_.data_ptr(), b1_.data_ptr(), w2r_.data_ptr(),
+        b2r_.data_ptr(), w3r_.data_ptr(), b3r_.data_ptr(), w2c_.data_ptr(), b2c_.data_ptr(), w3c_.data_ptr(),
+        b3c_.data_ptr(), td.data_ptr() if td is not None else None,
+        node_cls.data_ptr() if td is not None else None, B, N, T, Hd, R, c1, rel.data_ptr(), conn.data_ptr(),
+        gm.data_ptr() if want_gate_mean else None)
+    _lib.check(st, "egtr_rel_head_forward_bf16w")
+    return rel, conn.unsqueeze(-1), gm
+
+
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
                   node_cls=None, want_gate_mean=False):
-    if gate_q.dtype != torch.float32:  # bf16 / fp16 models: fp32 kernel, outputs cast back
+    if gate_q.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and any(
+            t.requires_grad for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c))):
+        rel, conn, gm = relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,
+                                            triplet_dist, node_cls, want_gate_mean)
+        return rel.to(torch.bfloat16), conn.to(torch.bfloat16), gm
+    if gate_q.dtype != torch.float32:  # fp16 models / bf16 training: fp32 kernel, outputs cast back
         dt = gate_q.dtype
         f = [t.float() for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c)]
         rel, conn, gm = RelationHeadFunction.apply(*f, triplet_dist.float() if triplet_dist is not None else None,

@@ -273,6 +273,17 @@ int egtr_rel_head_forward_save_f32(egtr_stream_t stream, const float* gate_q, co
                                    int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
                                    float* gate_mean, float* h1_save, float* h2_save);
 
+/* Forward with layers 2 and 3 on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16): w2r / w3r / w2c / w3c are the
+ * model's bf16 parameters (raw bfloat16 bits, nn.Linear layout), the hidden activations are rounded to bf16 as matrix
+ * operands, accumulation, layer 1, biases, frequency bias and outputs stay fp32.  For bf16 models (stress configuration). */
+int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
+                                const float* uk, const float* b1, const uint16_t* w2r, const float* b2r,
+                                const uint16_t* w3r, const float* b3r, const uint16_t* w2c, const float* b2c,
+                                const uint16_t* w3c, const float* b3c, const float* triplet_dist,
+                                const int64_t* node_cls, int batch, int num_query, int num_slots, int hidden,
+                                int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
+                                float* gate_mean);
+
 /* Pairwise part of the relation-head backward (everything that is not a plain GEMM).  dh1 [2][B*N*N][hidden] is the
  * gradient wrt the pre-ReLU layer-1 output (relation half, connectivity half), produced by rocBLAS GEMMs from the
  * saved activations.  Outputs (fully overwritten): grad_uq / grad_uk [B,N,T,2*hidden], grad_gate_q / grad_gate_k

@@ -597,6 +597,28 @@ def test_relation_head_forward(B, N, T, R):
     assert (rel2.cpu() - rrel2.float()).abs().max() < 2e-4 and gm2 is None
 
 
+@pytest.mark.parametrize("B,N,T,R", [(1, 200, 7, 50), (2, 24, 4, 7), (1, 33, 9, 64), (1, 7, 1, 1), (2, 300, 9, 50)])
+def test_relation_head_forward_bf16_matrix_cores(B, N, T, R):
+    """bf16-weight forward (layers 2 / 3 on v_mfma_f32_32x32x16_bf16) against the fp64 restatement evaluated with the
+    same bf16-rounded weights.  What differs is the bf16 rounding of the hidden activations as matrix operands:
+    tolerance 3e-2 absolute on logits of magnitude ~1-4 and 5e-3 relative Frobenius (a fragment-layout mistake is O(1))."""
+    import cpu_kernels as ck
+    from egtr_amd.ops import relation_head_bf16w
+    d, trip, node = _head_inputs(160 + N, B, N, T, R, 11)
+    wnames = ("w2r", "w3r", "w2c", "w3c")
+    dd = {k: (v.to(DEV).bfloat16() if k in wnames else v.to(DEV)) for k, v in d.items()}
+    rel, conn, gm = relation_head_bf16w(*dd.values(), trip.to(DEV), node.to(DEV), True)
+    d64 = {k: (v.bfloat16().double() if k in wnames else v.double()) for k, v in d.items()}
+    rrel, rconn, rgm = ck.relation_head(*d64.values(), trip.double(), node, True)
+    for got, ref in ((rel.cpu().double(), rrel), (conn.cpu().double(), rconn)):
+        assert (got - ref).abs().max() < 3e-2
+        assert (got - ref).norm() / ref.norm() < 5e-3
+    assert (gm.cpu() - rgm.float()).abs().max() < 1e-5
+    rel2, _, gm2 = relation_head_bf16w(*dd.values(), None, None, False)
+    rrel2, _, _ = ck.relation_head(*d64.values(), None, None, False)
+    assert (rel2.cpu().double() - rrel2).abs().max() < 3e-2 and gm2 is None
+
+
 @pytest.mark.parametrize("B,N,T,R", [(2, 12, 4, 7), (1, 200, 7, 50), (3, 40, 7, 50), (1, 33, 9, 64), (2, 7, 1, 1),
                                      (1, 300, 9, 50)])
 def test_relation_head_backward_matches_autograd(B, N, T, R):

@@ -29,6 +29,19 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / 50
     fl = 2.0 * B * 200 * 200 * (2 * 256 * 256 + 256 * 64)
     print(f"rel_head fwd B={B}: {us:.1f} us/launch, {fl / us / 1e6:.1f} TFLOP/s (f32 MFMA peak 157)")
+    from egtr_amd.ops import relation_head_bf16w
+    wn = ("w2r", "w3r", "w2c", "w3c")
+    db = {k: (v.bfloat16() if k in wn else v) for k, v in dd.items()}
+    for _ in range(5):
+        relation_head_bf16w(*db.values(), trip, node, False)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        relation_head_bf16w(*db.values(), trip, node, False)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    print(f"rel_head fwd bf16 matrix cores B={B}: {us:.1f} us/launch, {fl / us / 1e6:.1f} TFLOP/s")
     # training: forward (saving h1 / h2) + backward (rocBLAS GEMMs + the HIP pairwise kernels) vs autograd through the
     # PyTorch statement of the same separable algebra (what round 1 shipped first)
     dg = {k: v.clone().requires_grad_(True) for k, v in dd.items()}
