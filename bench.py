@@ -77,10 +77,10 @@ class MsdaProbe:
                 probe.args, probe.fused = (value, shapes, lsi, loc, attn, step), False
             return orig(ctx, value, shapes, lsi, loc, attn, step)
 
-        def fwd_fused(value, shapes, lsi, off, logits, ref, want_weights=False, keep_mask=None):
+        def fwd_fused(value, shapes, lsi, off, logits, ref, want_weights=False, keep_mask=None, **kw):
             if off.shape[1] == value.shape[1]:
                 probe.args, probe.fused = (value, shapes, lsi, off, logits, ref, False, keep_mask), True
-            return orig_fused(value, shapes, lsi, off, logits, ref, want_weights, keep_mask)
+            return orig_fused(value, shapes, lsi, off, logits, ref, want_weights, keep_mask, **kw)
 
         self._ops.MultiScaleDeformableAttentionFunction.forward = staticmethod(fwd)
         self._ops.msda_forward_fused = fwd_fused

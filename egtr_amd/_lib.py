@@ -22,6 +22,8 @@ SIGNATURES = {
     "egtr_msda_forward_fused_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "egtr_msda_forward_fused_f32_variant": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P,
                                             _I],
+    "egtr_msda_forward_fused_vbias_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P,
+                                            _I, _P],
     "egtr_msda_forward_f32_variant": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I],
     "egtr_msda_tile_phase_cycles": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "egtr_msda_win_phase_cycles": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
@@ -36,6 +38,7 @@ SIGNATURES = {
     "egtr_linear_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I],
     "egtr_add_layernorm_pos_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _I, _P],
     "egtr_bias_mask_rows_f32": [_P, _P, _P, _P, _I, _I, _I],
+    "egtr_box_decode_f32": [_P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_bias_act_nchw_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],

@@ -46,23 +46,28 @@ constexpr int kWaveEntries = 8 * kHeadStride;   // per array per wave
 // over the L*P logits of a head (deformable_detr.py:1055-1073) -- the 16 logits of a head live in 8 adjacent lanes,
 // reduced with DPP -- instead of four elementwise launches and a 19 MB round trip per encoder layer.  `attn_out`
 // (optional) receives the softmaxed weights.
-template <bool FUSED>
+// SPLIT: short query lists (decoder: 200 queries = 200 waves on 1024 SIMDs, one dependent chain of 4 x 16 gathers each):
+// one query per workgroup, wave w gathers samples 4w .. 4w+3 (16 loads in flight at once) and the four partial sums
+// are added in sample order through LDS.
+constexpr long long kSplitMaxQueries = 1024;
+template <bool FUSED, bool SPLIT = false>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
     int Lq, int S, int L, int P, int nblk, const float* __restrict__ ref, float* __restrict__ attn_out, int ld_off,
-    int ld_logit, const unsigned char* __restrict__ keep, const unsigned* __restrict__ keep_bits) {
+    int ld_logit, const unsigned char* __restrict__ keep, const unsigned* __restrict__ keep_bits,
+    const float* __restrict__ vbias) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * kWaveEntries];
   __shared__ unsigned s_bits[FUSED ? kMaxBitWords : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = xcd_remap(blockIdx.x, nblk);
-  const int q = blk * kWaves + wave;
+  const int q = SPLIT ? blk : blk * kWaves + wave;
   const int nwords = (S + 31) >> 5;
   bool bits_in_lds = false;
   if (FUSED && keep_bits != nullptr && nwords <= kMaxBitWords) {
     // padding mask of the image of this workgroup's first query, one bit per token (1.5 KB at 600x1000), in LDS
-    const int b0 = min(blk * kWaves, nq_total - 1) / Lq;
+    const int b0 = min(SPLIT ? blk : blk * kWaves, nq_total - 1) / Lq;
     for (int i = threadIdx.x; i < nwords; i += kWaves * 64) s_bits[i] = keep_bits[(size_t)b0 * nwords + i];
     __syncthreads();
     bits_in_lds = q < nq_total && q / Lq == b0;
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
     sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
     aw = make_float2(e0 / sum, e1 / sum);
-    if (attn_out != nullptr) reinterpret_cast<float2*>(attn_out + (size_t)q * 128)[lane] = aw;
+    if (attn_out != nullptr && (!SPLIT || wave == 0)) reinterpret_cast<float2*>(attn_out + (size_t)q * 128)[lane] = aw;
   }
   int4* my_off = s_off + wave * kWaveEntries;
   float4* my_w = s_w + wave * kWaveEntries;
@@ -144,6 +149,49 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
   const int4* ro = my_off + head * kHeadStride;
   const float4* rw = my_w + head * kHeadStride;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // vbias (optional, [256]): `value` is the bias-free projection W x and the bias b of value_proj is applied here:
+  //   sum_s w_s (v_s + b) = sum_s w_s v_s + b sum_s w_s   with w_s the in-range, unpadded corner weights
+  // (dd:1048-1052: padded rows of value are zero, not b; out-of-range corners contribute nothing).
+  float wsum = 0.f;
+  if (SPLIT) {
+    __shared__ float4 s_part[kWaves - 1][64];
+#pragma unroll
+    for (int i = 0; i < 16 / kWaves; ++i) {
+      const int s = wave * (16 / kWaves) + i;
+      const int4 o = ro[s];
+      const float4 w = rw[s];
+      wsum += (w.x + w.y) + (w.z + w.w);
+      const float4 v0 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.x);
+      const float4 v1 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.y);
+      const float4 v2 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.z);
+      const float4 v3 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.w);
+      acc.x += w.x * v0.x + w.y * v1.x + w.z * v2.x + w.w * v3.x;
+      acc.y += w.x * v0.y + w.y * v1.y + w.z * v2.y + w.w * v3.y;
+      acc.z += w.x * v0.z + w.y * v1.z + w.z * v2.z + w.w * v3.z;
+      acc.w += w.x * v0.w + w.y * v1.w + w.z * v2.w + w.w * v3.w;
+    }
+    if (vbias != nullptr) {
+      const float4 vb = reinterpret_cast<const float4*>(vbias)[lane];
+      acc.x += vb.x * wsum;
+      acc.y += vb.y * wsum;
+      acc.z += vb.z * wsum;
+      acc.w += vb.w * wsum;
+    }
+    if (wave > 0) s_part[wave - 1][lane] = acc;
+    __syncthreads();  // q is the same for the four waves: nobody has returned
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 0; w < kWaves - 1; ++w) {
+        const float4 p = s_part[w][lane];
+        acc.x += p.x;
+        acc.y += p.y;
+        acc.z += p.z;
+        acc.w += p.w;
+      }
+      reinterpret_cast<float4*>(out + (size_t)q * 256)[lane] = acc;
+    }
+    return;
+  }
 #pragma unroll 4
   for (int s = 0; s < 16; ++s) {
     const int4 o = ro[s];
@@ -156,6 +204,18 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     acc.y += w.x * v0.y + w.y * v1.y + w.z * v2.y + w.w * v3.y;
     acc.z += w.x * v0.z + w.y * v1.z + w.z * v2.z + w.w * v3.z;
     acc.w += w.x * v0.w + w.y * v1.w + w.z * v2.w + w.w * v3.w;
+  }
+  if (vbias != nullptr) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float4 w = rw[s];
+      wsum += (w.x + w.y) + (w.z + w.w);
+    }
+    const float4 vb = reinterpret_cast<const float4*>(vbias)[lane];
+    acc.x += vb.x * wsum;
+    acc.y += vb.y * wsum;
+    acc.z += vb.z * wsum;
+    acc.w += vb.w * wsum;
   }
   reinterpret_cast<float4*>(out + (size_t)q * 256)[lane] = acc;
 }
@@ -591,12 +651,17 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   if (variant == 2)
     return egtr_launch_msda_fwd_tile_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
                                          out, batch, num_query, spatial_size, num_levels, num_point);
-  if (variant == 1) {
+  if (variant == 1 && nq <= kSplitMaxQueries && num_levels * num_point == 16) {
+    hipLaunchKernelGGL((msda_fwd_q64_f32<false, true>), dim3((int)nq), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+                       level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
+                       num_levels, num_point, (int)nq, (const float*)nullptr, (float*)nullptr, 256, 128,
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
+  } else if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(msda_fwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
                        num_levels, num_point, nblk, (const float*)nullptr, (float*)nullptr, 256, 128,
-                       (const unsigned char*)nullptr, (const unsigned*)nullptr);
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
   } else {
     const long long n = nq * num_heads * channels;
     const int threads = 256;
@@ -637,14 +702,14 @@ extern "C" int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* va
                                        sampling_loc, attn_weight, out, batch, num_query, spatial_size, kind, cycles);
 }
 
-extern "C" int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const float* value,
-                                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                                   const float* sampling_offsets, const float* attn_logits,
-                                                   const float* reference_points, int batch, int spatial_size,
-                                                   int num_heads, int channels, int num_levels, int num_query,
-                                                   int num_point, float* out, float* attn_weight_out, int ld_offsets,
-                                                   int ld_logits, const unsigned char* keep_mask,
-                                                   const unsigned* keep_bits, int variant) {
+extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value,
+                                                 const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                                 const float* sampling_offsets, const float* attn_logits,
+                                                 const float* reference_points, int batch, int spatial_size,
+                                                 int num_heads, int channels, int num_levels, int num_query,
+                                                 int num_point, float* out, float* attn_weight_out, int ld_offsets,
+                                                 int ld_logits, const unsigned char* keep_mask,
+                                                 const unsigned* keep_bits, int variant, const float* value_bias) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
       !out)
     return EGTR_E_ARG;
@@ -662,17 +727,40 @@ extern "C" int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const f
     variant = (e == 1 || (e >= 8 && e <= 13)) ? e : kAutoEncoderVariant;
     if (!(num_query == spatial_size && num_query >= 1024)) variant = 1;
   }
-  if (variant >= 8)
+  if (variant >= 8) {
+    if (value_bias != nullptr) return EGTR_E_UNSUPPORTED;  // the LDS-window kernels take finished values only
     return egtr_launch_msda_fwd_win_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
                                         sampling_offsets, attn_logits, out, batch, num_query, spatial_size,
                                         num_levels, num_point, variant - 8, reference_points, attn_weight_out,
                                         ld_offsets, ld_logits, keep_mask, keep_bits, nullptr);
+  }
+  if (nq <= kSplitMaxQueries) {  // fewer waves than SIMDs: split each query's samples over a workgroup
+    hipLaunchKernelGGL((msda_fwd_q64_f32<true, true>), dim3((int)nq), dim3(kWaves * 64), 0,
+                       static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index, sampling_offsets,
+                       attn_logits, out, (int)nq, num_query, spatial_size, num_levels, num_point, (int)nq,
+                       reference_points, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias);
+    return egtr_check_launch();
+  }
   const int nblk = (int)((nq + kWaves - 1) / kWaves);
   hipLaunchKernelGGL(msda_fwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
                      spatial_shapes, level_start_index, sampling_offsets, attn_logits, out, (int)nq, num_query,
                      spatial_size, num_levels, num_point, nblk, reference_points, attn_weight_out, ld_offsets,
-                     ld_logits, keep_mask, keep_bits);
+                     ld_logits, keep_mask, keep_bits, value_bias);
   return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const float* value,
+                                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                                   const float* sampling_offsets, const float* attn_logits,
+                                                   const float* reference_points, int batch, int spatial_size,
+                                                   int num_heads, int channels, int num_levels, int num_query,
+                                                   int num_point, float* out, float* attn_weight_out, int ld_offsets,
+                                                   int ld_logits, const unsigned char* keep_mask,
+                                                   const unsigned* keep_bits, int variant) {
+  return egtr_msda_forward_fused_vbias_f32(stream, value, spatial_shapes, level_start_index, sampling_offsets,
+                                           attn_logits, reference_points, batch, spatial_size, num_heads, channels,
+                                           num_levels, num_query, num_point, out, attn_weight_out, ld_offsets,
+                                           ld_logits, keep_mask, keep_bits, variant, nullptr);
 }
 
 extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,

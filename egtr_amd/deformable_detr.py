@@ -363,7 +363,12 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
 
         fast = ops.inference_fast_path(hidden_states)
         value_is_masked = True
-        if precomputed_value is not None:
+        value_bias = None
+        if isinstance(precomputed_value, tuple):
+            # (W x, b): the bias-free projection; bias and padding mask are applied by the fused kernel below
+            value, value_bias = precomputed_value
+            value_is_masked = attention_mask is None
+        elif precomputed_value is not None:
             value = precomputed_value
         else:
             value = ops.module_linear(self.value_proj, encoder_hidden_states)
@@ -392,6 +397,8 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                                                    self.n_levels * self.n_points)
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but got {reference_points.shape[-1]}")
+        if value_bias is not None and value.dtype != torch.float32:
+            value, value_bias = value + value_bias, None
         needs_grad = torch.is_grad_enabled() and (value.requires_grad or sampling_offsets.requires_grad
                                                   or attention_weights.requires_grad or reference_points.requires_grad)
         if (not needs_grad and value.is_cuda and reference_points.shape[-1] == 2
@@ -405,8 +412,11 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
             output, attention_weights = ops.msda_forward_fused(
                 value.contiguous(), spatial_shapes, level_start_index, sampling_offsets, attention_weights,
                 reference_points.contiguous(), want_weights=output_attentions,
-                keep_mask=None if value_is_masked else attention_mask)
+                keep_mask=None if value_is_masked else attention_mask,
+                value_bias=value_bias if value.dtype == torch.float32 else None)
         else:
+            if value_bias is not None:
+                value = value + value_bias
             if not value_is_masked:
                 # dd:1052 `value.masked_fill(~mask[..., None], 0)` as one select (no mask inversion, no clone)
                 value = torch.where(attention_mask[..., None], value, _zero_scalar(value))
@@ -755,8 +765,17 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                          torch.stack([l.encoder_attn.value_proj.bias for l in self.layers]).contiguous()))
             bsz_, seq_, dm_ = encoder_hidden_states.shape
             x2 = encoder_hidden_states.reshape(1, bsz_ * seq_, dm_).expand(nl, -1, -1)
-            values = ops.bias_mask_rows_(torch.bmm(x2, w_t), b_all, encoder_attention_mask)
-            values = values.view(nl, bsz_, seq_, dm_)
+            values = torch.bmm(x2, w_t).view(nl, bsz_, seq_, dm_)
+            lay0 = self.layers[0].encoder_attn
+            if (reference_points.shape[-1] == 2 and self.bbox_embed is None and not output_attentions
+                    and ops.msda_fused_supported(lay0.n_heads, lay0.d_model // lay0.n_heads, lay0.n_levels,
+                                                 lay0.n_points)):
+                # the fused MSDA kernel applies the bias (times the sum of the valid corner weights) and skips padded
+                # tokens itself: no pass over the [Ld, S, 256] values at all
+                values = [(values[i], b_all[i]) for i in range(nl)]
+            else:
+                values = ops.bias_mask_rows_(values.view(nl, bsz_ * seq_, dm_), b_all,
+                                             encoder_attention_mask).view(nl, bsz_, seq_, dm_)
         hoisted_reference = None
         if self.bbox_embed is None and reference_points.shape[-1] == 2:  # no refinement: same input for every layer
             hoisted_reference = reference_points[:, :, None] * valid_ratios[:, None]

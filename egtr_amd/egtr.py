@@ -190,9 +190,10 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         if not self.config.with_box_refine:
             # class_embed / bbox_embed alias ONE module for every level (egtr:152-158): apply them once to the stacked
             # [B, Ld, N, d] states instead of Ld times (same arithmetic per row as egtr:286-305)
-            refs = torch.cat([init_reference[:, None], inter_references[:, :-1]], 1)
             box_layers = self.bbox_embed[0].layers
-            if ops.inference_fast_path(hidden_states) and hidden_states.numel() // hidden_states.shape[-1] <= ops.SKINNY_MAX_ROWS:
+            fast = (ops.inference_fast_path(hidden_states)
+                    and hidden_states.numel() // hidden_states.shape[-1] <= ops.SKINNY_MAX_ROWS)
+            if fast:
                 # class logits and the first box-MLP layer read the same rows: one grouped launch
                 outputs_class, delta_bbox = ops.linear_grouped([
                     dict(x=hidden_states, w=self.class_embed[0].weight, b=self.class_embed[0].bias),
@@ -202,7 +203,14 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             else:
                 outputs_class = ops.module_linear(self.class_embed[0], hidden_states)
                 delta_bbox = self.bbox_embed[0](hidden_states)
-            if refs.shape[-1] == 4:
+            if fast and init_reference.shape[-1] in (2, 4):
+                outputs_coord = ops.box_decode(delta_bbox, init_reference, inter_references)
+                refs = None
+            else:
+                refs = torch.cat([init_reference[:, None], inter_references[:, :-1]], 1)
+            if refs is None:
+                pass
+            elif refs.shape[-1] == 4:
                 outputs_coord = (delta_bbox + inverse_sigmoid(refs)).sigmoid()
             elif refs.shape[-1] == 2:
                 outputs_coord = torch.cat([delta_bbox[..., :2] + inverse_sigmoid(refs), delta_bbox[..., 2:]],

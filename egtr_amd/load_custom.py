@@ -63,11 +63,14 @@ class _MultiScaleDeformableAttention:
 
     @staticmethod
     def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                     reference_points, want_weights=False, keep_mask=None, variant=0):
+                                     reference_points, want_weights=False, keep_mask=None, variant=0,
+                                     value_bias=None):
         """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` computed in the kernel
         (deformable_detr.py:1055-1073, 2-d reference points).  fp32, M = 8, D = 32, L*P = 16; no autograd.
         sampling_offsets [B,Lq,M,L,P,2] / attn_logits [B,Lq,M,L*P] may be column blocks of one wider Linear output
         (any row stride, unit inner strides); keep_mask [B,S] bool: padded tokens are skipped (== zeroed value rows).
+        value_bias [M*D]: ``value`` is the bias-free value projection and the bias is applied inside the kernel (times the
+        sum of the in-range, unpadded corner weights).
         Returns (out [B,Lq,M*D], attention weights [B,Lq,M,L,P] or None)."""
         lib = _lib.lib()
         B, S, M, D = value.shape
@@ -104,12 +107,18 @@ class _MultiScaleDeformableAttention:
                 _chk(km, "keep_mask")
         out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
         wts = torch.empty(B, Lq, M, L, P, dtype=value.dtype, device=value.device) if want_weights else None
-        st = lib.egtr_msda_forward_fused_f32_variant(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
-                                                     level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
-                                                     reference_points.data_ptr(), B, S, M, D, L, Lq, P,
-                                                     out.data_ptr(), wts.data_ptr() if want_weights else None, ld_off,
-                                                     ld_log, km.data_ptr() if km is not None else None,
-                                                     kbits.data_ptr() if kbits is not None else None, variant)
+        vb = None
+        if value_bias is not None:
+            vb = _chk(value_bias.detach().contiguous(), "value_bias", torch.float32)
+            if vb.numel() != M * D:
+                raise RuntimeError(f"value_bias must have {M * D} elements, got {vb.numel()}")
+        st = lib.egtr_msda_forward_fused_vbias_f32(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
+                                                   level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
+                                                   reference_points.data_ptr(), B, S, M, D, L, Lq, P,
+                                                   out.data_ptr(), wts.data_ptr() if want_weights else None, ld_off,
+                                                   ld_log, km.data_ptr() if km is not None else None,
+                                                   kbits.data_ptr() if kbits is not None else None, variant,
+                                                   vb.data_ptr() if vb is not None else None)
         _lib.check(st, "ms_deform_attn_forward_fused")
         return out, wts
 

@@ -51,17 +51,18 @@ def msda_fused_supported(num_heads, channels, num_levels, num_points):
 
 
 def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
-                       want_weights=False, keep_mask=None):
-    """MSDA forward with its softmax / sampling-location prologue fused in (no autograd: inference path)."""
+                       want_weights=False, keep_mask=None, value_bias=None):
+    """MSDA forward with its softmax / sampling-location prologue fused in (no autograd: inference path).  With
+    ``value_bias`` (fp32 only) ``value`` is the bias-free value projection and the kernel applies the bias."""
     from .load_custom import load_hip_kernels
     k = load_hip_kernels()
     if value.dtype == torch.bfloat16:
-        if want_weights:
-            raise NotImplementedError("the bf16 fused MSDA forward does not return attention weights")
+        if want_weights or value_bias is not None:
+            raise NotImplementedError("the bf16 fused MSDA forward returns no attention weights and takes no value_bias")
         return k.ms_deform_attn_forward_fused_bf16(value, spatial_shapes, level_start_index, sampling_offsets,
                                                    attn_logits, reference_points, keep_mask), None
     return k.ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                          reference_points, want_weights, keep_mask)
+                                          reference_points, want_weights, keep_mask, value_bias=value_bias)
 
 
 class DecoderSelfAttentionFunction(Function):
@@ -238,6 +239,28 @@ def linear_grouped(items):
                                      FA(*ax), FA(*al), IA(*rl), K)
     _lib.check(st, "egtr_linear_grouped_f32")
     return outs
+
+
+def box_decode(delta, init_reference, inter_references, eps=1e-5):
+    """sigmoid(delta + [inverse_sigmoid(reference_l), 0..]) for all decoder levels in one HIP launch (egtr:286-305 without
+    box refinement; reference_0 = init_reference, reference_l = inter_references[:, l-1]).  Inference only."""
+    lib = _lib.lib()
+    B, Ld, N, four = delta.shape
+    if four != 4:
+        raise ValueError(f"delta must be [B, Ld, N, 4], got {tuple(delta.shape)}")
+    d = _chk(delta.contiguous(), "delta", torch.float32)
+    r0 = _chk(init_reference.contiguous(), "init_reference", torch.float32)
+    r1 = _chk(inter_references.contiguous(), "inter_references", torch.float32)
+    RD = r0.shape[-1]
+    if tuple(r0.shape) != (B, N, RD) or tuple(r1.shape) != (B, Ld, N, RD):
+        raise ValueError(f"reference shapes {tuple(r0.shape)} / {tuple(r1.shape)} do not match delta {tuple(delta.shape)}")
+    if RD not in (2, 4):
+        raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {RD}")
+    out = torch.empty_like(d)
+    st = lib.egtr_box_decode_f32(_stream(), d.data_ptr(), r0.data_ptr(), r1.data_ptr(), B, Ld, N, RD, float(eps),
+                                 out.data_ptr())
+    _lib.check(st, "egtr_box_decode_f32")
+    return out
 
 
 def bias_mask_rows_(y, bias, keep):

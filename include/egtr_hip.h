@@ -84,6 +84,18 @@ int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const float* value
                                         int ld_logits, const unsigned char* keep_mask, const unsigned* keep_bits,
                                         int variant);
 
+/* Same with the value_proj bias applied inside the kernel: `value` is the bias-free projection W x of the (unmasked)
+ * encoder states and value_bias [M*D] the bias; out = sum_s w_s v_s + value_bias * sum_s w_s over the in-range, unpadded
+ * corner weights -- identical to sampling (W x + b) with padded rows zeroed (deformable_detr.py:1048-1052), without the
+ * bias / mask pass over the [S, 256] value tensor.  Wave-per-query kernels only (variant 0 / 1); value_bias may be NULL. */
+int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                      const int64_t* level_start_index, const float* sampling_offsets,
+                                      const float* attn_logits, const float* reference_points, int batch,
+                                      int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                      int num_point, float* out, float* attn_weight_out, int ld_offsets, int ld_logits,
+                                      const unsigned char* keep_mask, const unsigned* keep_bits, int variant,
+                                      const float* value_bias);
+
 /* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
  * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
  * 3 = generic one-thread-per-element, 5 / 6 = lane-per-query with LDS windows in [channel quad][pixel] planes
@@ -213,6 +225,14 @@ int egtr_add_layernorm_pos_f32(egtr_stream_t stream, const float* x, const float
  * deformable_detr.py:1050-1052 for the value projections of all decoder layers at once; keep may be NULL). */
 int egtr_bias_mask_rows_f32(egtr_stream_t stream, float* y, const float* bias, const unsigned char* keep, int groups,
                             int rows, int cols);
+
+/* Box decoding of the detection head for all decoder levels at once (model/egtr.py:286-305 with the shared bbox_embed,
+ * with_box_refine = False): boxes[b, l, n, :] = sigmoid(delta[b, l, n, :] + [inverse_sigmoid(reference_l[b, n, :]), 0..]),
+ * reference_0 = init_reference [B, N, ref_dim], reference_l = inter_references[:, l-1] ([B, Ld, N, ref_dim]) for l >= 1;
+ * inverse_sigmoid as model/deformable_detr.py:658-662 with its eps.  ref_dim 2 or 4; delta / boxes [B, Ld, N, 4]. */
+int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
+                        const float* inter_references, int batch, int num_levels, int num_query, int ref_dim, float eps,
+                        float* boxes);
 
 /* Sine position embedding of DeformableDetrSinePositionEmbedding(normalize=True) (model/deformable_detr.py:850-876)
  * from y_embed / x_embed = cumsum of the mask along H / W ([B,H,W] fp32) and dim_t [E] (the reference's

@@ -706,7 +706,7 @@ def test_add_layernorm_and_bias_act():
     assert (xd.grad.cpu() - x64.grad.float()).abs().max() < 1e-4 and torch.equal(xd.grad, rd.grad)
     assert (lnd.weight.grad.cpu() - w64.grad.float()).abs().max() < 1e-3
     # bias + residual + relu on NCHW, aligned (HW % 4 == 0) and unaligned shapes
-    for (n, c, h, w_) in ((2, 64, 10, 12), (1, 7, 5, 9), (1, 256, 75, 125)):
+    for (n, c, h, w_) in ((2, 64, 10, 12), (1, 7, 5, 9), (1, 256, 75, 125), (2, 24, 38, 63), (3, 5, 2, 3), (1, 3, 150, 250)):
         a = torch.from_numpy(rng.standard_normal((n, c, h, w_))).float()
         res = torch.from_numpy(rng.standard_normal((n, c, h, w_))).float()
         b = torch.from_numpy(rng.standard_normal((c,))).float()
@@ -715,6 +715,30 @@ def test_add_layernorm_and_bias_act():
             exp = a + b.view(1, -1, 1, 1) + (res if use_res else 0)
             exp = torch.relu(exp) if relu else exp
             assert torch.equal(got, exp) or (got - exp).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("RD", [2, 4])
+def test_box_decode_matches_reference_composition(RD):
+    """egtr_box_decode_f32 against sigmoid(delta + inverse_sigmoid(reference)) level by level (egtr:286-305), with
+    reference values at and beyond the clamp points 0, 1, eps."""
+    from egtr_amd import ops
+    from egtr_amd.deformable_detr import inverse_sigmoid
+    g = torch.Generator().manual_seed(40 + RD)
+    B, Ld, N = 2, 3, 37
+    delta = 2.0 * torch.randn(B, Ld, N, 4, generator=g)
+    init = torch.rand(B, N, RD, generator=g)
+    inter = torch.rand(B, Ld, N, RD, generator=g)
+    init[0, :6, 0] = torch.tensor([0.0, 1.0, -0.3, 1.7, 1e-6, 1 - 1e-6])
+    inter[1, 1, :4, -1] = torch.tensor([0.0, 1.0, 5e-6, 2.0])
+    want = []
+    for lvl in range(Ld):
+        r = inverse_sigmoid(init if lvl == 0 else inter[:, lvl - 1])
+        d = delta[:, lvl]
+        want.append((d + r if RD == 4 else torch.cat([d[..., :2] + r, d[..., 2:]], -1)).sigmoid())
+    want = torch.stack(want, 1)
+    got = ops.box_decode(delta.to(DEV), init.to(DEV), inter.to(DEV)).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() < 2e-6
 
 
 def test_sine_position_embedding_matches_reference_formula():
@@ -733,8 +757,9 @@ def test_sine_position_embedding_matches_reference_formula():
         assert (got - ref)[valid].abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("geom", ["small", "multi_block"])
 @pytest.mark.parametrize("mask_dtype", [torch.long, torch.bool])
-def test_level_geometry_matches_reference_composition(mask_dtype):
+def test_level_geometry_matches_reference_composition(mask_dtype, geom):
     """egtr_level_geometry_f32 against the PyTorch composition the reference uses (dd:2195-2278, 1616-1648, 850-876):
     nearest-resized masks, sine position embeddings + level_embed, valid ratios, encoder reference points; one fully
     valid image and two padded ones (valid regions 37x61 and 50x13 of 64x80)."""
@@ -742,13 +767,19 @@ def test_level_geometry_matches_reference_composition(mask_dtype):
     import torch.nn.functional as F
     from egtr_amd import ops
     from egtr_amd.deformable_detr import DeformableDetrEncoder, DeformableDetrSinePositionEmbedding
-    B, H, W_ = 3, 64, 80
-    shapes = [(8, 10), (4, 5), (2, 3), (1, 2)]
+    if geom == "small":
+        B, H, W_ = 3, 64, 80
+        shapes = [(8, 10), (4, 5), (2, 3), (1, 2)]
+        cuts = ((37, 61), (50, 13))
+    else:  # S = 1424 tokens: several workgroups of the mask-resize kernel, a ragged last bit-mask word
+        B, H, W_ = 3, 200, 333
+        shapes = [(25, 42), (13, 21), (7, 11), (4, 6)]
+        cuts = ((131, 290), (180, 77))
     pm = torch.ones(B, H, W_, dtype=torch.long)
-    pm[1, 37:, :] = 0
-    pm[1, :, 61:] = 0
-    pm[2, 50:, :] = 0
-    pm[2, :, 13:] = 0
+    pm[1, cuts[0][0]:, :] = 0
+    pm[1, :, cuts[0][1]:] = 0
+    pm[2, cuts[1][0]:, :] = 0
+    pm[2, :, cuts[1][1]:] = 0
     g = torch.Generator().manual_seed(3)
     level_embed = torch.randn(4, 256, generator=g)
     pe = DeformableDetrSinePositionEmbedding(128, normalize=True)
@@ -772,7 +803,8 @@ def test_level_geometry_matches_reference_composition(mask_dtype):
     assert (posf.cpu() - want_pos)[valid].abs().max() < 2e-5
     # padded tokens: the embedding takes sin / cos of arguments up to ~1e6 (cumsum / eps); compare loosely in the
     # argument domain by checking the values stay in [-1, 1] + level_embed range
-    assert (posf.cpu() - level_embed.repeat_interleave(torch.tensor([80, 20, 6, 2]), 0)[None]).abs().max() <= 1.0 + 1e-6
+    per_level = torch.tensor([h * w for h, w in shapes])
+    assert (posf.cpu() - level_embed.repeat_interleave(per_level, 0)[None]).abs().max() <= 1.0 + 1e-6
 
 
 def test_linear_grouped_matches_torch():
@@ -874,6 +906,35 @@ def test_msda_fused_strided_inputs_and_keep_mask():
     km._egtr_bits = bits
     out_b, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, km)
     assert torch.equal(out_b, out)
+
+
+@pytest.mark.parametrize("Lq", [50, 300, 1400])
+def test_msda_fused_value_bias_in_kernel(Lq):
+    """value_bias applied inside the kernel (times the sum of the in-range, unpadded corner weights) against sampling the
+    finished values (W x + b, padded rows zeroed).  Lq <= 1024 takes the sample-split workgroup kernel, 1400 the
+    wave-per-query one; 10 % of the samples fall outside the maps, 25 % of the tokens are padding."""
+    k = _kernels()
+    g = torch.Generator().manual_seed(90 + Lq)
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    B, S = 2, sum(h * w for h, w in shapes)
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    raw = torch.randn(B, S, 8, 32, generator=g)
+    bias = torch.randn(256, generator=g)
+    off = torch.randn(B, Lq, 8, 4, 4, 2, generator=g) * 3
+    logits = torch.randn(B, Lq, 8, 16, generator=g) * 2
+    ref = torch.rand(B, Lq, 4, 2, generator=g) * 1.2 - 0.1
+    keep = torch.rand(B, S, generator=g) > 0.25
+    d = [t.to(DEV) for t in (raw, shp, lsi, off, logits, ref, keep, bias)]
+    for km in (d[6], None):
+        out, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], d[3], d[4], d[5], False, km, value_bias=d[7])
+        full = d[0] + d[7].view(1, 1, 8, 32)
+        if km is not None:
+            full = torch.where(km[..., None, None], full, torch.zeros((), device=DEV))
+        want, _ = k.ms_deform_attn_forward_fused(full.contiguous(), d[1], d[2], d[3], d[4], d[5], False, None)
+        assert (out - want).abs().max().item() < 5e-6
+    with pytest.raises(RuntimeError):  # the LDS-window kernels take finished values only
+        k.ms_deform_attn_forward_fused(d[0], d[1], d[2], d[3], d[4], d[5], False, None, variant=8, value_bias=d[7])
 
 
 # ------------------------------------------------------------------------------------------- bf16 epilogues
