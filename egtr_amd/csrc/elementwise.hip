@@ -478,10 +478,23 @@ __global__ __launch_bounds__(1024) void gn_stats_levels(GnLevels P, int C, int G
   for (int c = 0; c < cpg; ++c) {
     const float cb = P.conv_bias[l][g * cpg + c];
     const float* xc = x + (size_t)c * hw;
-    for (int i = threadIdx.x; i < hw; i += 1024) {
-      const float v = xc[i] + cb;
-      s1 += v;
-      s2 += v * v;
+    // 8 loads in flight per thread, accumulated in the original order (the loop was one dependent load -> add per
+    // ~300 ns: 73 round trips for the 75 000 elements of a level-0 group)
+    for (int i0 = threadIdx.x; i0 < hw; i0 += 8 * 1024) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 1024 * u;
+        v[u] = i < hw ? xc[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + 1024 * u < hw) {
+          const float t = v[u] + cb;
+          s1 += t;
+          s2 += t * t;
+        }
+      }
     }
   }
   double d1 = (double)s1, d2 = (double)s2;
