@@ -76,7 +76,8 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// rows x 256, one wave per row, 4 rows per workgroup
+// rows x 256, one wave per row, 4 rows per workgroup (two rows per wave with both rows' loads requested up front was
+// measured on the 12 537-row encoder calls: 9.5 vs 9.3 us per launch, no gain)
 __global__ __launch_bounds__(256) void add_layernorm_256(const float* __restrict__ x, const float* __restrict__ res,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
@@ -532,11 +533,17 @@ __global__ __launch_bounds__(256) void gn_apply_flatten(GnLevels P, int L, int C
   const int cpg = C / G;
   const int px = threadIdx.x & 31, cs = threadIdx.x >> 5;  // 8 channel sub-lanes
   const float* x = P.x[l] + (size_t)b * C * hw;
-  for (int c = cs; c < C; c += 8) {
+  // C == 256 (checked by the launcher): 32 channels per thread, all 32 activation loads requested before the first use
+  float xv[32];
+  const bool inside = p0 + px < hw;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) xv[k] = inside ? x[(size_t)(cs + 8 * k) * hw + p0 + px] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const int c = cs + 8 * k;
     const float2 st = stats[((size_t)l * gridDim.y + b) * G + c / cpg];
-    float v = 0.f;
-    if (p0 + px < hw) v = (x[(size_t)c * hw + p0 + px] + P.conv_bias[l][c] - st.x) * st.y * P.gamma[l][c] + P.beta[l][c];
-    s_t[px][c] = v;
+    const float v = (xv[k] + P.conv_bias[l][c] - st.x) * st.y * P.gamma[l][c] + P.beta[l][c];
+    s_t[px][c] = inside ? v : 0.f;
   }
   __syncthreads();
   for (int p = 0; p < 32; ++p) {

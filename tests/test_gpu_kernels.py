@@ -717,6 +717,29 @@ def test_add_layernorm_and_bias_act():
             assert torch.equal(got, exp) or (got - exp).abs().max() < 1e-6
 
 
+@pytest.mark.parametrize("rows", [8193, 12537])
+def test_add_layernorm_token_sized(rows):
+    """Token-sized inputs (encoder: 12 537 rows; an odd count that is not a multiple of the 4 rows per workgroup): plain
+    and "+ pos" variants against fp64 LayerNorm."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 256, generator=g)
+    r = torch.randn(rows, 256, generator=g)
+    pos = torch.randn(rows, 256, generator=g)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(256, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(256, generator=g))
+    want = torch.nn.functional.layer_norm((x + r).double(), (256,), ln.weight.double(), ln.bias.double(), ln.eps)
+    lnd = ln.to(DEV)
+    with torch.no_grad():
+        y = ops.add_layer_norm(x.to(DEV), r.to(DEV), lnd)
+        y2, yp = ops.add_layer_norm_pos(x.to(DEV), r.to(DEV), lnd, pos.to(DEV))
+    assert (y.cpu() - want.float()).abs().max() < 2e-5
+    assert torch.equal(y2, y)
+    assert (yp.cpu() - (want + pos.double()).float()).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("RD", [2, 4])
 def test_box_decode_matches_reference_composition(RD):
     """egtr_box_decode_f32 against sigmoid(delta + inverse_sigmoid(reference)) level by level (egtr:286-305), with
