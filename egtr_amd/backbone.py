@@ -126,6 +126,32 @@ class ResNet50Features(nn.Module):
 
         self._folded = None
         self._folded_key = None
+        self._frozen_folded = None
+        self._frozen_key = None
+
+    def _frozen_prefix(self):
+        """Stem + layer1 when none of their parameters takes gradients (the reference freezes exactly these:
+        dd:763-770) -- nothing upstream of them is trainable either, so in training they can run without autograd."""
+        mods = [self.conv1, self.layer1]
+        params = [p for m in mods for p in m.parameters()]
+        return params if params and not any(p.requires_grad for p in params) else None
+
+    def _forward_frozen_prefix(self, x, params):
+        """Stem + layer1 through the folded-BN fused path under no_grad (training steps: 3-4 elementwise passes over the
+        largest activations of the network per convolution become one, and nothing is saved for a backward that never
+        runs).  Folded weights cached on the versions of the frozen parameters only."""
+        from . import ops
+        key = tuple(p._version for p in params) + (str(x.device), x.dtype, self.conv1.weight.data_ptr())
+        with torch.no_grad():
+            if self._frozen_folded is None or key != self._frozen_key:
+                self._frozen_folded = {"stem": _fold(self.conv1, self.bn1),
+                                       1: [blk.folded_params() for blk in self.layer1]}
+                self._frozen_key = key
+            w, b = self._frozen_folded["stem"]
+            x = self.maxpool(ops.bias_act_(F.conv2d(x, w, None, stride=2, padding=3), b))
+            for blk, p in zip(self.layer1, self._frozen_folded[1]):
+                x = blk.forward_folded(x, p)
+        return x
 
     def _fold_key(self):
         return tuple(p._version for p in self.parameters()) + (str(self.conv1.weight.device), self.conv1.weight.dtype,
@@ -153,9 +179,18 @@ class ResNet50Features(nn.Module):
                 if li in self.out_indices:
                     feats.append(x)
             return feats
-        x = self.maxpool(torch.relu(self.bn1(self.conv1(x))))
+        frozen = self._frozen_prefix() if (x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+                                           and self.conv1.weight.dtype == x.dtype) else None
         feats = []
-        for li in range(1, 5):
+        if frozen is not None:
+            x = self._forward_frozen_prefix(x, frozen)
+            if 1 in self.out_indices:
+                feats.append(x)
+            first = 2
+        else:
+            x = self.maxpool(torch.relu(self.bn1(self.conv1(x))))
+            first = 1
+        for li in range(first, 5):
             x = getattr(self, f"layer{li}")(x)
             if li in self.out_indices:
                 feats.append(x)

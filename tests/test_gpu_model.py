@@ -377,3 +377,35 @@ def test_backbone_folded_path_bf16_matches_unfolded_bf16():
         ref = float(b.abs().max())
         assert float((a.float() - b).abs().max()) < 0.06 * max(ref, 1.0)
 
+
+def test_training_runs_frozen_stem_and_layer1_through_the_folded_path():
+    """With stem + layer1 frozen (the reference's setting, dd:763-770) a training forward runs them without autograd
+    through the folded-BN fused path; features and the gradients of the trainable layers must equal the plain path."""
+    from egtr_amd.backbone import ResNet50Features
+    torch.manual_seed(3)
+    net = ResNet50Features().to(DEV).train()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.1)
+    for mod in (net.conv1, net.layer1):
+        for p in mod.parameters():
+            p.requires_grad_(False)
+    x = torch.randn(2, 3, 96, 128, device=DEV)
+    assert net._frozen_prefix() is not None
+    feats = net(x)
+    loss = sum((f * f).mean() for f in feats)
+    loss.backward()
+    g_fast = net.layer2[0].conv1.weight.grad.clone()
+    assert net.conv1.weight.grad is None and net._frozen_folded is not None
+    net.zero_grad(set_to_none=True)
+    net.conv1.weight.requires_grad_(True)  # prefix no longer frozen: plain autograd path
+    assert net._frozen_prefix() is None
+    feats_ref = net(x)
+    sum((f * f).mean() for f in feats_ref).backward()
+    g_ref = net.layer2[0].conv1.weight.grad
+    for a, b in zip(feats, feats_ref):
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max()
+    assert (g_fast - g_ref).abs().max() <= 1e-4 * g_ref.abs().max()
