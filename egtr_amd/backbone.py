@@ -148,10 +148,17 @@ class ResNet50Features(nn.Module):
                                        1: [blk.folded_params() for blk in self.layer1]}
                 self._frozen_key = key
             w, b = self._frozen_folded["stem"]
-            x = self.maxpool(ops.bias_act_(F.conv2d(x, w, None, stride=2, padding=3), b))
+            x = self._stem_folded(x, w, b)
             for blk, p in zip(self.layer1, self._frozen_folded[1]):
                 x = blk.forward_folded(x, p)
         return x
+
+    def _stem_folded(self, x, w, b):
+        """maxpool(relu(conv + shift)) == relu(maxpool(conv) + shift) bit for bit (a per-channel constant and monotone
+        rounding commute with max; the pool pads with -inf): the shift / ReLU pass runs on the pooled tensor, a quarter
+        of the convolution output."""
+        from . import ops
+        return ops.bias_act_(self.maxpool(F.conv2d(x, w, None, stride=2, padding=3)), b)
 
     def _fold_key(self):
         return tuple(p._version for p in self.parameters()) + (str(self.conv1.weight.device), self.conv1.weight.dtype,
@@ -171,7 +178,7 @@ class ResNet50Features(nn.Module):
                 self._folded_key = key
             from . import ops
             w, b = self._folded["stem"]
-            x = self.maxpool(ops.bias_act_(F.conv2d(x, w, None, stride=2, padding=3), b))
+            x = self._stem_folded(x, w, b)
             feats = []
             for li in range(1, 5):
                 for blk, p in zip(getattr(self, f"layer{li}"), self._folded[li]):
