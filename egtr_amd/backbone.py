@@ -158,7 +158,12 @@ class ResNet50Features(nn.Module):
         rounding commute with max; the pool pads with -inf): the shift / ReLU pass runs on the pooled tensor, a quarter
         of the convolution output."""
         from . import ops
-        return ops.bias_act_(self.maxpool(F.conv2d(x, w, None, stride=2, padding=3)), b)
+        y = F.conv2d(x, w, None, stride=2, padding=3)
+        mp = self.maxpool
+        if (y.dtype == torch.float32 and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
+                and mp.dilation == 1 and not mp.ceil_mode and y.shape[0] * y.shape[1] <= 65535):
+            return ops.bias_relu_maxpool(y, b)  # pool + shift + ReLU in one pass over the convolution output
+        return ops.bias_act_(mp(y), b)
 
     def _fold_key(self):
         return tuple(p._version for p in self.parameters()) + (str(self.conv1.weight.device), self.conv1.weight.dtype,

@@ -232,6 +232,39 @@ __global__ __launch_bounds__(256) void bias_mask_rows(float* __restrict__ y, con
   }
 }
 
+// ResNet stem epilogue: y = relu(maxpool3x3/s2/p1(x) + shift[c])  ==  maxpool(relu(x + shift[c]))  bit for bit (a
+// per-channel constant and monotone rounding commute with max; padding is -inf).  x is the bias-free 7x7 convolution
+// output [N, C, H, W] (77 MB at 600 x 1000), y [N, C, Ho, Wo]: one pass over x instead of PyTorch's max-pool kernel (which
+// alone takes 24 us) plus an epilogue pass.  One thread per output pixel; a wave covers 64 consecutive output columns
+// of one row, so its 9 loads walk three input rows with stride-2 lanes (every line is fetched once per wave).
+__global__ __launch_bounds__(256) void bias_relu_maxpool3x3s2(const float* __restrict__ x, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int C, int H, int W, int Ho,
+                                                              int Wo, long long planes) {
+  const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const long long plane = blockIdx.z;
+  if (ox >= Wo || oy >= Ho) return;
+  const float* xp = x + plane * H * W;
+  const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+  float m = -INFINITY;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    const int iy = iy0 + dy;
+    if (iy < 0 || iy >= H) continue;
+    const float* row = xp + (size_t)iy * W;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int ix = ix0 + dx;
+      if (ix >= 0 && ix < W) {
+        const float v = row[ix];
+        m = (v > m || v != v) ? v : m;  // NaN propagates, as in torch max-pool
+      }
+    }
+  }
+  const float r = m + bias[(int)(plane % C)];
+  y[(plane * Ho + oy) * Wo + ox] = (r != r) ? r : fmaxf(r, 0.f);  // relu(NaN) = NaN, as torch
+}
+
 // Box decoding of the detection head for every decoder level at once (model/egtr.py:286-305, with_box_refine = False):
 //   reference_l = init_reference (l == 0) or inter_references[:, l-1];  r = inverse_sigmoid(reference_l)
 //   (deformable_detr.py:658-662: x = clamp(x, 0, 1); log(max(x, eps) / max(1 - x, eps)));
@@ -682,6 +715,19 @@ extern "C" int egtr_add_layernorm_pos_f32(egtr_stream_t stream, const float* x, 
   if (dim != 256) return EGTR_E_UNSUPPORTED;
   hipLaunchKernelGGL(add_layernorm_256, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                      residual, gamma, beta, y, rows, eps, pos, pos_rows, y_plus_pos);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_bias_relu_maxpool3x3s2_f32(egtr_stream_t stream, const float* x, const float* bias, float* y, int N,
+                                               int C, int H, int W) {
+  if (!x || !bias || !y) return EGTR_E_ARG;
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return EGTR_E_ARG;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;  // floor((H + 2 - 3) / 2) + 1
+  const long long planes = (long long)N * C;
+  if (planes > 65535 || (Ho + 3) / 4 > 65535) return EGTR_E_UNSUPPORTED;
+  const dim3 grid((unsigned)((Wo + 63) / 64), (unsigned)((Ho + 3) / 4), (unsigned)planes);
+  hipLaunchKernelGGL(bias_relu_maxpool3x3s2, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, y, C, H, W, Ho,
+                     Wo, planes);
   return egtr_check_launch();
 }
 

@@ -241,6 +241,19 @@ def linear_grouped(items):
     return outs
 
 
+def bias_relu_maxpool(x, bias):
+    """relu(max_pool2d(x, 3, 2, 1) + bias[c]) in one HIP pass (== max_pool2d(relu(x + bias[c]), 3, 2, 1) bit for bit): the
+    ResNet stem epilogue.  fp32 NCHW, inference only."""
+    lib = _lib.lib()
+    N, C, H, W_ = x.shape
+    x2 = _chk(x.contiguous(), "x", torch.float32)
+    b2 = _chk(bias.contiguous(), "bias", torch.float32)
+    y = torch.empty(N, C, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, dtype=torch.float32, device=x.device)
+    st = lib.egtr_bias_relu_maxpool3x3s2_f32(_stream(), x2.data_ptr(), b2.data_ptr(), y.data_ptr(), N, C, H, W_)
+    _lib.check(st, "egtr_bias_relu_maxpool3x3s2_f32")
+    return y
+
+
 def box_decode(delta, init_reference, inter_references, eps=1e-5):
     """sigmoid(delta + [inverse_sigmoid(reference_l), 0..]) for all decoder levels in one HIP launch (egtr:286-305 without
     box refinement; reference_0 = init_reference, reference_l = inter_references[:, l-1]).  Inference only."""

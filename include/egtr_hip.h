@@ -226,6 +226,12 @@ int egtr_add_layernorm_pos_f32(egtr_stream_t stream, const float* x, const float
 int egtr_bias_mask_rows_f32(egtr_stream_t stream, float* y, const float* bias, const unsigned char* keep, int groups,
                             int rows, int cols);
 
+/* ResNet stem epilogue in one pass: y = relu(maxpool(x, 3x3, stride 2, padding 1) + shift[c]), which equals
+ * maxpool(relu(x + shift[c])) bit for bit; x [N, C, H, W] is the bias-free stem convolution output with the frozen BN
+ * scale folded into its weights, y [N, C, (H-1)/2+1, (W-1)/2+1]. */
+int egtr_bias_relu_maxpool3x3s2_f32(egtr_stream_t stream, const float* x, const float* bias, float* y, int N, int C,
+                                    int H, int W);
+
 /* Box decoding of the detection head for all decoder levels at once (model/egtr.py:286-305 with the shared bbox_embed,
  * with_box_refine = False): boxes[b, l, n, :] = sigmoid(delta[b, l, n, :] + [inverse_sigmoid(reference_l[b, n, :]), 0..]),
  * reference_0 = init_reference [B, N, ref_dim], reference_l = inter_references[:, l-1] ([B, Ld, N, ref_dim]) for l >= 1;

@@ -740,6 +740,20 @@ def test_add_layernorm_token_sized(rows):
     assert (yp.cpu() - (want + pos.double()).float()).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("N,C,H,W_", [(1, 64, 300, 500), (2, 7, 33, 41), (1, 3, 8, 130), (3, 5, 1, 1)])
+def test_bias_relu_maxpool_is_bitwise_maxpool_of_relu(N, C, H, W_):
+    """egtr_bias_relu_maxpool3x3s2_f32 == max_pool2d(relu(x + b), 3, 2, 1) bit for bit (odd / even sizes, borders)."""
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + H)
+    x = torch.randn(N, C, H, W_, generator=g)
+    b = torch.randn(C, generator=g)
+    want = F.max_pool2d(torch.relu(x + b.view(1, C, 1, 1)), 3, 2, 1)
+    got = ops.bias_relu_maxpool(x.to(DEV), b.to(DEV)).cpu()
+    assert got.shape == want.shape
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("RD", [2, 4])
 def test_box_decode_matches_reference_composition(RD):
     """egtr_box_decode_f32 against sigmoid(delta + inverse_sigmoid(reference)) level by level (egtr:286-305), with
