@@ -1005,13 +1005,23 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                 attentions=encoder_outputs[2] if len(encoder_outputs) > 2 else None)
 
         batch_size, _, num_channels = encoder_outputs[0].shape
-        query_embed, target = torch.split(query_embeds, num_channels, dim=1)  # dd:2339
         if ops.inference_fast_path(query_embeds):
-            # column slices of the [N, 2d] table: made dense once here instead of once per consumer kernel
-            query_embed, target = query_embed.contiguous(), target.contiguous()
-        query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)
-        target = target.unsqueeze(0).expand(batch_size, -1, -1)
-        reference_points = ops.module_linear(self.reference_points, query_embed).sigmoid()
+            # The dense column slices of the [N, 2d] query table and reference_points = sigmoid(Linear(query_pos))
+            # (dd:2339-2343) depend on parameters only: derived constants, rebuilt when a source tensor changes
+            # (4 launches per forward otherwise).
+            lin = self.reference_points
+            query_embed, target, ref0 = ops.cached_weights(
+                ("query_tables", id(self)), [query_embeds, lin.weight, lin.bias],
+                lambda: (lambda qe, tg: (qe, tg, ops.module_linear(lin, qe).sigmoid()))(
+                    query_embeds[:, :num_channels].contiguous(), query_embeds[:, num_channels:].contiguous()))
+            query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)
+            target = target.unsqueeze(0).expand(batch_size, -1, -1)
+            reference_points = ref0.unsqueeze(0).expand(batch_size, -1, -1)
+        else:
+            query_embed, target = torch.split(query_embeds, num_channels, dim=1)  # dd:2339
+            query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)
+            target = target.unsqueeze(0).expand(batch_size, -1, -1)
+            reference_points = ops.module_linear(self.reference_points, query_embed).sigmoid()
         init_reference_points = reference_points
 
         decoder_outputs = self.decoder(
