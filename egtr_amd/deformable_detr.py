@@ -931,7 +931,10 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                     c = self.input_proj[level][0]
                     if (tuple(c.kernel_size) == (1, 1) and tuple(c.stride) == (1, 1) and tuple(c.padding) == (0, 0)
                             and c.groups == 1):
-                        convs.append(conv1x1_as_gemm(fm, c.weight))  # a tuned GEMM on the NCHW tensor as it lies
+                        # a tuned GEMM on the NCHW tensor as it lies.  detach(): torch.matmul(2-D, 3-D) picks its
+                        # "fold" formulation when the 2-D operand requires grad, whose result is a transposed view that
+                        # then has to be copied back to NCHW (3 copies, 27 us per forward)
+                        convs.append(conv1x1_as_gemm(fm, c.weight.detach()))
                     else:
                         convs.append(F.conv2d(fm, c.weight, None, c.stride, c.padding))
                 if n_extra == 1:  # dd:2228-2241: the extra level is a strided 3x3 convolution of the last feature map
