@@ -84,14 +84,18 @@ def check_kernel(name, items):
                 pending = {}
                 continue
             ops = ins.split(None, 1)[1] if " " in ins else ""
-            hit = regs(ops) & pending.keys()
+            m = LOAD.match(ins)
+            is_dma = m is not None and ("_lds_" in ins.split()[0] or " lds" in ins)  # LDS-DMA: no destination register
+            dest = regs(ops.split(",")[0]) if (m and not is_dma) else set()
+            srcs = regs(ops.split(",", 1)[1]) if (m and not is_dma and "," in ops) else (regs(ops) if not dest else set())
+            # a load that overwrites the destination of an in-flight load is harmless (loads return in order; the
+            # compiler does it when the earlier value is dead): only sources count for a load, everything for the rest
+            hit = srcs & pending.keys()
             if hit and report is not None:
                 r = sorted(hit)[0]
                 report.append((name, ln, ins, f"{r[0]}{r[1]} is the destination of the load at asm line {pending[r]}"))
-            m = LOAD.match(ins)
-            if m and " lds" not in ins:
-                for r in regs(ops.split(",")[0]):
-                    pending[r] = ln
+            for r in dest:
+                pending[r] = ln
         return pending
 
     entry = [dict() for _ in blocks]
