@@ -166,8 +166,10 @@ class ResNet50Features(nn.Module):
         return ops.bias_act_(mp(y), b)
 
     def _fold_key(self):
-        return tuple(p._version for p in self.parameters()) + (str(self.conv1.weight.device), self.conv1.weight.dtype,
-                                                               self.conv1.weight.data_ptr())
+        # parameters AND the frozen-BN buffers (load_state_dict copies into both in place)
+        ts = list(self.parameters()) + list(self.buffers())
+        return tuple(t._version for t in ts) + (str(self.conv1.weight.device), self.conv1.weight.dtype,
+                                                self.conv1.weight.data_ptr(), self.bn1.running_var.data_ptr())
 
     def forward(self, x):
         # Inference (no grad, eval, GPU): folded-BN + fused conv/bias/ReLU path; the folded weights are cached and

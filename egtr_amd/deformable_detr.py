@@ -381,7 +381,7 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
             # token-sized input: both Linears read the same rows -> one vendor GEMM over the concatenated weights; the
             # kernel below reads the two column blocks in place (row stride = 3 * M * L * P)
             w_cat, b_cat = ops.cached_weights(
-                ("msda_offsets_weights", id(self)),
+                self, "msda_offsets_weights",
                 [self.sampling_offsets.weight, self.attention_weights.weight, self.sampling_offsets.bias,
                  self.attention_weights.bias],
                 lambda: (torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
@@ -759,7 +759,7 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
             # GEMM + one bias / padding-mask pass instead of (GEMM + fill + select) per layer
             nl = len(self.layers)
             w_t, b_all = ops.cached_weights(
-                ("decoder_value_proj", id(self)),
+                self, "decoder_value_proj",
                 [l.encoder_attn.value_proj.weight for l in self.layers] + [l.encoder_attn.value_proj.bias for l in self.layers],
                 lambda: (torch.stack([l.encoder_attn.value_proj.weight.t() for l in self.layers]).contiguous(),
                          torch.stack([l.encoder_attn.value_proj.bias for l in self.layers]).contiguous()))
@@ -1014,7 +1014,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             # (4 launches per forward otherwise).
             lin = self.reference_points
             query_embed, target, ref0 = ops.cached_weights(
-                ("query_tables", id(self)), [query_embeds, lin.weight, lin.bias],
+                self, "query_tables", [query_embeds, lin.weight, lin.bias],
                 lambda: (lambda qe, tg: (qe, tg, ops.module_linear(lin, qe).sigmoid()))(
                     query_embeds[:, :num_channels].contiguous(), query_embeds[:, num_channels:].contiguous()))
             query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)

@@ -134,7 +134,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             for i0 in range(0, len(items), 16):
                 ops.linear_grouped(items[i0:i0 + 16])
             w1q, w1k, wgq, wgk, b1 = ops.cached_weights(
-                ("rel_head_first_layer", id(self)),
+                self, "rel_head_first_layer",
                 [rp[0].weight, cl[0].weight, wg, rp[0].bias, cl[0].bias],
                 lambda: (torch.cat([rp[0].weight[:, :d], cl[0].weight[:, :d]], 0).contiguous(),
                          torch.cat([rp[0].weight[:, d:], cl[0].weight[:, d:]], 0).contiguous(),

@@ -137,7 +137,12 @@ def _load_state_file(path):
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
-    sd = torch.load(path, map_location="cpu")
+    try:  # plain tensor checkpoints (pytorch_model.bin)
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        # Lightning .ckpt files pickle hyper-parameter namespaces / callbacks next to the tensors; the caller chose this
+        # file, so load it the way torch < 2.6 did (the reference's evaluate_egtr.py:232-240 does exactly this)
+        sd = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(sd, dict) and "state_dict" in sd and not any(torch.is_tensor(v) for v in sd.values()):
         sd = sd["state_dict"]
     return sd
@@ -193,6 +198,20 @@ class PreTrainedModel(nn.Module):
                 del state_dict[k]
         res = model.load_state_dict(state_dict, strict=False)
         model.eval()
+        # the transformers base class logs these; a silent strict=False load would hand back random weights
+        matched = len(own) - len(res.missing_keys)
+        if matched == 0:
+            raise RuntimeError(
+                f"{pretrained_model_name_or_path}: none of the {len(state_dict)} checkpoint keys matches the model "
+                f"(first checkpoint keys: {list(state_dict)[:3]}; first model keys: {list(own)[:3]}) -- e.g. a Lightning "
+                "checkpoint whose keys carry a 'model.' prefix must be stripped first (evaluate_egtr.py:232-240)")
+        if res.missing_keys or res.unexpected_keys or mismatched:
+            import warnings
+            warnings.warn(
+                f"from_pretrained({pretrained_model_name_or_path}): {len(res.missing_keys)} missing (newly initialised), "
+                f"{len(res.unexpected_keys)} unexpected, {len(mismatched)} size-mismatched keys; "
+                f"missing: {list(res.missing_keys)[:8]} unexpected: {list(res.unexpected_keys)[:8]} "
+                f"mismatched: {[m[0] for m in mismatched][:8]}")
         if output_loading_info:
             info = {"missing_keys": list(res.missing_keys) , "unexpected_keys": list(res.unexpected_keys),
                     "mismatched_keys": mismatched, "error_msgs": []}

@@ -41,6 +41,7 @@ class MultiScaleDeformableAttentionFunction(Function):
         value, shapes, lsi, loc, attn = context.saved_tensors
         grad_value, grad_loc, grad_attn = _msda().ms_deform_attn_backward(
             value, shapes, lsi, loc, attn, grad_output.contiguous(), context.im2col_step)
+        # bf16 values: loc / attn were promoted to fp32 in forward(); autograd casts their gradients back
         return grad_value, None, None, grad_loc, grad_attn, None
 
 
@@ -179,19 +180,36 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
     return torch.relu(y) if relu else y
 
 
-_WCACHE = {}
+def cached_weights(owner, name, tensors, builder):
+    """Derived constants of module weights (stacks, slices, concatenations), built once and rebuilt when a source tensor
+    is replaced, moved or modified in place.  The cache lives ON the owning module (``owner._egtr_derived``), and an
+    entry keeps strong references to its source tensors and compares them by identity, storage pointer and version
+    counter -- a process-global table keyed by ``id(module)`` could hand one model's constants to a later model that
+    happens to reuse the same ids and storage.  Writes through ``.data`` do not bump the version counter: call
+    ``invalidate_derived(model)`` after such an edit."""
+    cache = owner.__dict__.get("_egtr_derived")
+    if cache is None:
+        cache = {}
+        object.__setattr__(owner, "_egtr_derived", cache)
+    hit = cache.get(name)
+    if hit is not None:
+        srcs, key, val = hit
+        if len(srcs) == len(tensors) and all(a is b for a, b in zip(srcs, tensors)) and \
+                key == tuple((t.data_ptr(), t._version) for t in tensors):
+            return val
+    with torch.no_grad():
+        val = builder()
+    cache[name] = (list(tensors), tuple((t.data_ptr(), t._version) for t in tensors), val)
+    return val
 
 
-def cached_weights(name, tensors, builder):
-    """Derived constants of module weights (stacks, slices, concatenations) built once and rebuilt when any source
-    tensor is replaced or modified in place (data pointer / version counter)."""
-    key = tuple((t.data_ptr(), t._version) for t in tensors)
-    hit = _WCACHE.get(name)
-    if hit is None or hit[0] != key:
-        with torch.no_grad():
-            hit = (key, builder())
-        _WCACHE[name] = hit
-    return hit[1]
+def invalidate_derived(model):
+    """Drop every derived constant cached on ``model``'s modules (after an in-place edit through ``.data``)."""
+    for m in model.modules():
+        if "_egtr_derived" in m.__dict__:
+            m.__dict__["_egtr_derived"].clear()
+        if "_folded" in m.__dict__:
+            m.__dict__["_folded"] = None
 
 
 def inference_fast_path(x):

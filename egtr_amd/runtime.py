@@ -17,12 +17,22 @@ class GraphedForward:
     captured HIP graph.  At bs = 1 the forward is ~700 short kernels, i.e. launch-bound when issued eagerly
     (MI355X_MICROARCH.md: eager launch ~3.3-3.8 us host time each); a graph replay issues them back-to-back.
     Inputs are copied into static buffers; outputs are the graph's static tensors (valid until the next call).
-    Falls back to eager launches (``self.graphed = False``) if capture is not possible -- same kernels either way."""
 
-    def __init__(self, model, enabled=True, warmup=2):
+    The captured graph bakes in pointers to DERIVED tensors built at capture time (folded-BN backbone weights, stacked /
+    concatenated projection weights, query tables), so the capture key holds a fingerprint of the model's parameters and
+    buffers (storage pointer + version counter of each): after an optimizer step, ``load_state_dict`` or a dtype /
+    device move the next call re-captures instead of replaying stale constants.  Edits through ``.data`` bypass the
+    version counter -- call ``invalidate()`` after those.
+
+    ``strict=True`` (what bench.py uses): a failed capture raises.  ``strict=False``: falls back to eager launches
+    (``self.graphed = False``, reason in ``capture_error``) -- same kernels either way, about 2x slower at bs = 1."""
+
+    def __init__(self, model, enabled=True, warmup=2, strict=False):
         self.model = model
         self.enabled = enabled
         self.warmup = warmup
+        self.strict = strict
+        self._tensors = None
         self.graphed = False
         self._graph = None
         self._key = None
@@ -48,17 +58,32 @@ class GraphedForward:
             self._static_out = self._eager(*self._static_in)
         self._graph = g
         self._key = (tuple(pv.shape), tuple(pm.shape), pv.device)
+        self._fingerprint_key = self._fingerprint()
         self.graphed = True
+
+    def _fingerprint(self):
+        if self._tensors is None:
+            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+        return [(t.data_ptr(), t._version) for t in self._tensors]
+
+    def invalidate(self):
+        """Forget the captured graph and every derived constant (after weights were edited through ``.data``)."""
+        from . import ops
+        ops.invalidate_derived(self.model)
+        self._graph, self._key, self._tensors = None, None, None
 
     @torch.no_grad()
     def __call__(self, pv, pm):
         if not self.enabled:
             return self._eager(pv, pm)
         key = (tuple(pv.shape), tuple(pm.shape), pv.device)
-        if self._graph is None or key != self._key:
+        if self._graph is None or key != self._key or self._fingerprint() != self._fingerprint_key:
             try:
+                self._tensors = None  # parameters may have been replaced (e.g. .to(dtype)): re-enumerate
                 self._capture(pv, pm)
             except Exception as e:  # capture unsupported by some library call: run eagerly, same kernels
+                if self.strict:
+                    raise
                 self.capture_error = repr(e)
                 self.enabled = False
                 self.graphed = False
@@ -143,10 +168,17 @@ class DataParallelTrainer:
                 def forward(self, pv, pm):
                     return self.m.forward_tensors(pv, pm)
 
+            # gradients accumulated by earlier micro-steps of this window must survive the warm-up / capture backward
+            # passes (a shape change can fall on any micro-step when accumulate > 1): stash, capture, restore
+            params = [p for p in raw.parameters()]
+            stash = [p.grad for p in params]
+            for p in params:
+                p.grad = None
             self._graphed = torch.cuda.make_graphed_callables(
                 _Body(), (pixel_values.detach().clone(), pixel_mask.detach().clone()), num_warmup_iters=3)
             self._graph_key = key
-            self.opt.zero_grad(set_to_none=True)  # the warm-up / capture backward passes left gradients behind
+            for p, g in zip(params, stash):  # drops what the warm-up / capture backward passes left behind
+                p.grad = g
         return self._graphed(pixel_values, pixel_mask)
 
     def common_step(self, batch):

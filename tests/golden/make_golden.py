@@ -13,6 +13,11 @@ Fixtures:
                   eval-mode and train-mode loss dicts, Hungarian indices, matching costs, gradient norms.
   sgg_full.npz    600x1000, N=200, Le=Ld=6, C=150, R=50 (BASELINE config 2) with stub backbone: logits, boxes,
                   strided relation logits + checksums.
+  sgg_stress.npz  800x1333, N=300, Le=6, Ld=8, C=150, R=50 (BASELINE config 5 geometry), 2 images (one padded), stub
+                  backbone, fp32 -- and the same model with weights / pixels rounded to bf16 (fp32 arithmetic): the
+                  reference point for the bf16 product model.
+  sgg_full_train.npz  600x1000, N=200, Le=Ld=6, bs=2, auxiliary losses ON, train mode (dropout 0): the reference's
+                  loss dict, total loss and gradient norms of a few parameters.
 """
 import json
 import os
@@ -206,8 +211,85 @@ def gen_sgg_full():
     print("sgg_full.npz", out.pred_rel.shape, float(res["pred_rel_sum"]))
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32) if t.is_floating_point() else t
+
+
+def gen_sgg_stress():
+    over = dict(num_queries=300, encoder_layers=6, decoder_layers=8, num_labels=150, num_rel_labels=50)
+    model, cfg, cfg_dict, shapes = build_ref_model(over, seed=41)
+    model.eval()
+    rng = W.rng_inputs(42)
+    B, H, Wd = 2, 800, 1333
+    vh, vw = 736, 1216
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    pm[1, vh:, :] = 0
+    pm[1, :, vw:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    res = dict(cfg=json.dumps(cfg_dict), shapes=json.dumps(shapes), seed=41, input_seed=42, H=H, W=Wd,
+               valid1=np.array([vh, vw]))
+
+    def record(tag, pv_):
+        with torch.no_grad():
+            out, cap, qk = run_ref(model, pv_, pm)
+        res.update({f"{tag}logits": np_(out.logits), f"{tag}pred_boxes": np_(out.pred_boxes),
+                    f"{tag}rel_mlp_strided": np_(cap["rel_mlp"][:, ::5, ::7]),
+                    f"{tag}conn_logits": np_(cap["conn"][..., 0]),
+                    f"{tag}last_hidden": np_(qk["inter"][:, -1]),
+                    f"{tag}enc_strided": np_(qk["enc"][:, ::61]),
+                    f"{tag}rel_mlp_abs_sum": np.float64(cap["rel_mlp"].double().abs().sum().item())})
+        print("stress", tag or "f32", out.pred_rel.shape, float(res[f"{tag}rel_mlp_abs_sum"]))
+
+    record("", pv)
+    # the bf16 reference point: identical fp32 arithmetic, weights and pixels rounded to bf16 storage precision
+    sd = {k: _bf16_round(v) for k, v in model.state_dict().items()}
+    keep_t, keep_r = model.state_dict()["triplet_dist"].clone(), model.state_dict()["rel_dist"].clone()
+    sd["triplet_dist"], sd["rel_dist"] = keep_t, keep_r
+    model.load_state_dict(sd)
+    record("bf16w_", _bf16_round(pv))
+    np.savez_compressed(os.path.join(HERE, "sgg_stress.npz"), **res)
+
+
+def gen_sgg_full_train():
+    over = dict(num_queries=200, encoder_layers=6, decoder_layers=6, num_labels=150, num_rel_labels=50,
+                auxiliary_loss=True)
+    model, cfg, cfg_dict, shapes = build_ref_model(over, seed=51)
+    model.train()
+    rng = W.rng_inputs(52)
+    B, H, Wd = 2, 600, 1000
+    vh, vw = 544, 928
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    pm[1, vh:, :] = 0
+    pm[1, :, vw:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    targets = W.make_targets(53, B, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels, tmin=5, tmax=30)
+    out, cap, _ = run_ref(model, pv, pm, labels=targets)
+    out.loss.backward()
+    gn = {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.grad is not None}
+    keep = ("rel_predictor_gate.weight", "rel_predictor.layers.0.weight", "rel_predictor.layers.2.weight",
+            "connectivity_layer.layers.1.weight", "class_embed.0.weight", "bbox_embed.0.layers.2.weight",
+            "proj_q.0.weight", "proj_k.5.weight", "final_sub_proj.weight", "model.level_embed",
+            "model.reference_points.weight", "model.query_position_embeddings.weight",
+            "model.encoder.layers.0.self_attn.sampling_offsets.weight",
+            "model.encoder.layers.5.self_attn.value_proj.weight",
+            "model.decoder.layers.0.encoder_attn.sampling_offsets.bias",
+            "model.decoder.layers.5.self_attn.q_proj.weight", "model.decoder.layers.3.fc1.weight",
+            "model.input_proj.0.0.weight", "model.backbone.conv_encoder.model.2.weight")
+    res = dict(cfg=json.dumps(cfg_dict), shapes=json.dumps(shapes), seed=51, input_seed=52, target_seed=53, H=H, W=Wd,
+               valid1=np.array([vh, vw]), train_loss=np_(out.loss),
+               train_loss_dict=json.dumps({k: float(v) for k, v in out.loss_dict.items()}),
+               grad_norms=json.dumps({k: gn[k] for k in keep if k in gn}),
+               logits=np_(out.logits), pred_boxes=np_(out.pred_boxes))
+    res["grad::rel_predictor_gate.weight"] = np_(dict(model.named_parameters())["rel_predictor_gate.weight"].grad)
+    res["grad::model.level_embed"] = np_(dict(model.named_parameters())["model.level_embed"].grad)
+    np.savez_compressed(os.path.join(HERE, "sgg_full_train.npz"), **res)
+    print("sgg_full_train.npz", float(out.loss), sorted(gn)[:3], len(gn))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["msda", "mha", "small", "full"]
+    which = sys.argv[1:] or ["msda", "mha", "small", "full", "stress", "full_train"]
     torch.set_num_threads(8)
     if "msda" in which:
         gen_msda()
@@ -217,3 +299,7 @@ if __name__ == "__main__":
         gen_sgg_small()
     if "full" in which:
         gen_sgg_full()
+    if "stress" in which:
+        gen_sgg_stress()
+    if "full_train" in which:
+        gen_sgg_full_train()

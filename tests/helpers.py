@@ -51,3 +51,34 @@ def small_inputs(g):
 
 def load_golden(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def product_heads(model, pv, pm):
+    """Product forward returning the PRE-sigmoid relation / connectivity logits (egtr:402-416) next to the detection
+    outputs: the north-star's 1e-3 bar is stated on logits, and saturated sigmoids would hide logit error."""
+    with torch.no_grad():
+        outputs = model.model(pv, pixel_mask=pm, output_attentions=False, output_hidden_states=True,
+                              output_attention_states=True, return_dict=True)
+        enc, last = outputs.encoder_last_hidden_state, outputs.last_hidden_state
+        logits, boxes, _, _, rel, conn, _, _ = model._heads(outputs, want_gate_mean=False)
+    return dict(logits=logits, pred_boxes=boxes, rel_logits=rel, conn_logits=conn, last_hidden=last, enc=enc)
+
+
+def rel_mlp_from_logits(rel_logits, logits, triplet_dist):
+    """rel_logits - frequency bias (egtr:405-413), the bias indexed by the SAME tensor's argmax classes: what the
+    reference's ``rel_predictor`` hook captured before the bias was added."""
+    node = logits.argmax(-1)
+    bias = torch.stack([triplet_dist[n][:, n] for n in node])
+    return rel_logits - bias
+
+
+def padded_inputs(g, B, dtype=torch.float32):
+    rng = W.rng_inputs(int(g["input_seed"]))
+    H, Wd = int(g["H"]), int(g["W"])
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    vh, vw = [int(v) for v in g["valid1"]]
+    pm[1, vh:, :] = 0
+    pm[1, :, vw:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    return pv.to(dtype), pm

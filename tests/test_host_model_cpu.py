@@ -244,3 +244,67 @@ def test_bbox_overlaps_matches_reference_cython_routine():
     assert got.shape == (40, 17) and np.abs(got - want).max() < 1e-12
     assert got[0, 0] == 1.0 and got[1, 1] == 0.0
 
+
+
+def test_cached_weights_live_on_the_owner_and_follow_their_sources():
+    """derived constants must never leak from one model to the next (CPython reuses id(), the
+    allocator reuses storage), and must be rebuilt when a source is modified in place or replaced."""
+    import gc
+    from egtr_amd import ops
+
+    class M(torch.nn.Module):
+        def __init__(self, v):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.full((64, 64), float(v)))
+
+        def derived(self):
+            return ops.cached_weights(self, "double", [self.w], lambda: (self.w * 2).clone())
+
+    for trial in range(20):  # the round-1 cache returned the first model's tensor in 7 of 20 such trials
+        a = M(1.0)
+        assert float(a.derived()[0, 0]) == 2.0
+        del a
+        gc.collect()
+        b = M(2.0)
+        assert float(b.derived()[0, 0]) == 4.0
+        del b
+    m = M(3.0)
+    d0 = m.derived()
+    assert m.derived() is d0                      # cached
+    with torch.no_grad():
+        m.w.add_(1.0)                             # optimizer-style in-place update bumps the version counter
+    assert float(m.derived()[0, 0]) == 8.0
+    m.w = torch.nn.Parameter(torch.full((64, 64), 5.0))   # replaced parameter object
+    assert float(m.derived()[0, 0]) == 10.0
+    m.w.data.fill_(6.0)                           # .data edits bypass the counter: documented, explicit invalidation
+    ops.invalidate_derived(m)
+    assert float(m.derived()[0, 0]) == 12.0
+    assert "_egtr_derived" not in m.state_dict() and not any("derived" in k for k in m.state_dict())
+
+
+def test_from_pretrained_reports_key_mismatches(tmp_path):
+    """a checkpoint whose keys do not match must not load silently."""
+    import warnings
+    from egtr_amd.deformable_detr import DeformableDetrConfig
+    from egtr_amd.hf_compat import PreTrainedModel
+
+    class Tiny(PreTrainedModel):
+        config_class = DeformableDetrConfig
+
+        def __init__(self, config):
+            super().__init__(config)
+            self.lin = torch.nn.Linear(4, 4)
+
+    cfg = DeformableDetrConfig()
+    cfg.save_pretrained(str(tmp_path))
+    good = {"lin.weight": torch.ones(4, 4), "lin.bias": torch.zeros(4)}
+    torch.save({"state_dict": {"model." + k: v for k, v in good.items()}}, str(tmp_path / "pytorch_model.bin"))
+    with pytest.raises(RuntimeError, match="none of the"):
+        Tiny.from_pretrained(str(tmp_path))
+    torch.save({"lin.weight": torch.ones(4, 4), "extra": torch.zeros(1)}, str(tmp_path / "pytorch_model.bin"))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m, info = Tiny.from_pretrained(str(tmp_path), output_loading_info=True)
+    assert info["missing_keys"] == ["lin.bias"] and info["unexpected_keys"] == ["extra"]
+    assert any("missing" in str(x.message) for x in w)
+    assert float(m.lin.weight.sum()) == 16.0

@@ -188,3 +188,51 @@ def test_full_size_600x1000_vs_reference(golden_dir):
     assert ((out["rel_logits"] - bias)[:, ::5, ::7] - _t(g["rel_mlp_strided"])).abs().max() < tol
     assert (out["conn_logits"][..., 0] - _t(g["conn_logits"])).abs().max() < tol
     assert abs(out["pred_rel"].double().sum().item() - float(g["pred_rel_sum"])) < 1.0
+
+
+def O_cfg_of(g):
+    return O_cfg(json.loads(str(g["cfg"])))
+
+
+def test_stress_geometry_800x1333_vs_reference(golden_dir):
+    """BASELINE configs[4] geometry (800x1333, N=300, 6 enc / 8 dec; image 1 padded), fp32 and the bf16-rounded-weights
+    variant: pins the oracle where the stress GPU tests use it."""
+    import helpers as Hh
+    g = _load(golden_dir, "sgg_stress.npz")
+    cfg = O_cfg_of(g)
+    shapes = json.loads(str(g["shapes"]))
+    sd = W.fill_state_dict(shapes, seed=int(g["seed"]))
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg["num_labels"], cfg["num_rel_labels"]),
+                                                            cfg["freq_bias_eps"])
+    pv, pm = Hh.padded_inputs(g, 2)
+    # image 0 only (keeps the CPU suite short); the padded image is covered on the GPU against the same fixture
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv[:1], pm[:1])
+    tol = 5e-4
+    assert (out["logits"] - _t(g["logits"])[:1]).abs().max() < tol
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])[:1]).abs().max() < tol
+    rel_mlp = Hh.rel_mlp_from_logits(out["rel_logits"], out["logits"], sd["triplet_dist"])
+    assert (rel_mlp[:, ::5, ::7] - _t(g["rel_mlp_strided"])[:1]).abs().max() < tol
+    assert (out["conn_logits"][..., 0] - _t(g["conn_logits"])[:1]).abs().max() < tol
+
+
+def test_full_size_train_aux_loss_vs_reference(golden_dir):
+    """600x1000, bs=2 (one padded), N=200, auxiliary losses on, train-mode criterion: every loss-dict entry."""
+    import helpers as Hh
+    g = _load(golden_dir, "sgg_full_train.npz")
+    cfg = O_cfg_of(g)
+    shapes = json.loads(str(g["shapes"]))
+    sd = W.fill_state_dict(shapes, seed=int(g["seed"]))
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg["num_labels"], cfg["num_rel_labels"]),
+                                                            cfg["freq_bias_eps"])
+    pv, pm = Hh.padded_inputs(g, 2)
+    targets = W.make_targets(int(g["target_seed"]), 2, cfg["num_queries"], cfg["num_labels"], cfg["num_rel_labels"],
+                             tmin=5, tmax=30)
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+        total, ld, _, _ = OL.sgg_loss(out, targets, cfg, training=True)
+    ref = json.loads(str(g["train_loss_dict"]))
+    assert set(ref) == set(ld), sorted(set(ref) ^ set(ld))
+    for k, v in ref.items():
+        assert abs(float(ld[k]) - v) < 3e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
+    assert abs(float(total) - float(g["train_loss"])) < 3e-4 * abs(float(g["train_loss"]))
