@@ -13,9 +13,14 @@ A "step" = one forward pass of one batch; inputs are resident in HBM before the 
 Multi-GPU: images are independent, so each rank runs its own replica on its own images (weak scaling, no
 data-path collective); the timed region is bracketed by a barrier + synchronize and the MAX over ranks is used.
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (a child
+`torch.distributed.run`, spawned BEFORE this process touches the GPU); rank 0 reports `n_gpus` = the world size and
+`rccl_ranks` = the result of a real all-reduce over RCCL.
+
 Prints ONE JSON line on rank 0 with the driver's contract plus
   "roofline":     the encoder MSDA kernel (dominant hand-written kernel): algorithmic bytes per launch / its
                   average duration measured with HIP events on the launch stream, against the 8 TB/s HBM peak;
+  "roofline_kernels": the same entry plus the relation-head kernel against the fp32-MFMA peak (157.3 TFLOP/s);
   "cpu_baseline": the CPU oracle (the reference's pure-PyTorch fallback semantics) timed on the host cores on a
                   bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -91,6 +96,54 @@ class MsdaProbe:
         self._ops.msda_forward_fused = self._orig_fused
 
 
+class RelHeadProbe:
+    """Remembers the operands of the most recent relation-head launch (egtr_amd.ops.relation_head)."""
+
+    def __init__(self):
+        from egtr_amd import ops
+        self._ops, self._orig, self.args = ops, ops.relation_head, None
+
+    def __enter__(self):
+        probe, orig = self, self._orig
+
+        def rel(*a, **kw):
+            probe.args = (a, kw)
+            return orig(*a, **kw)
+
+        self._ops.relation_head = rel
+        return self
+
+    def __exit__(self, *a):
+        self._ops.relation_head = self._orig
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+
+
+def time_rel_head_kernel(args, iters=100):
+    """Average duration of the fused relation-head forward (one launch = one image batch) and its algorithmic FLOPs:
+    per (i, j) pair the gated first layer (T slots x 2*Hd outputs, FMA), two Hd x Hd second layers, and the R + 1
+    third-layer outputs: 2 * B * N^2 * (T * 2Hd + 2 * Hd * Hd + Hd * (R + 1))  (DESIGN.md 4.4)."""
+    from egtr_amd import ops
+    a, kw = args
+    fn = lambda: ops.relation_head(*a, **kw)  # noqa: E731
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    gate_q, w2r, w3r = a[0], a[5], a[7]
+    B, N, T = gate_q.shape
+    Hd, R = w2r.shape[1], w3r.shape[0]
+    flops = 2.0 * B * N * N * (T * 2 * Hd + 2 * Hd * Hd + Hd * (R + 1))
+    return us, flops
+
+
 def time_msda_kernel(args, fused, iters=200):
     """Average duration of the encoder MSDA kernel: `iters` back-to-back launches through the C ABI on torch's
     current stream, bracketed by HIP events recorded on that same stream."""
@@ -116,6 +169,34 @@ def time_msda_kernel(args, fused, iters=200):
     # are not counted)
     alg = B * (min(S * M * D * e, Lq * M * 16 * 4 * D * e) + Lq * M * 32 * 4 + Lq * M * 16 * 4 + Lq * M * D * e)
     return us, alg
+
+
+def msda_kernel_name(fused):
+    from egtr_amd import ops
+    name = getattr(ops, "MSDA_ENCODER_KERNEL", "msda_fwd_q64_f32")
+    return name + ("<fused prologue>" if fused else "")
+
+
+def logit_parity(model, ref, pv, pm):
+    """max |product - oracle| on class logits, boxes and the PRE-sigmoid relation / connectivity logits (egtr:402-416).
+    The frequency bias (a table lookup by argmax class, -29 for unseen triplets) is removed from both sides with each
+    side's own argmax, so a class near-tie cannot masquerade as a relation-logit error."""
+    with torch.no_grad():
+        outputs = model.model(pv, pixel_mask=pm, output_attentions=False, output_hidden_states=True,
+                              output_attention_states=True, return_dict=True)
+        logits, boxes, _, _, rel, conn, _, _ = model._heads(outputs, want_gate_mean=False)
+
+    def unbias(rel_, logits_, table):
+        node = logits_.argmax(-1)
+        return rel_ - torch.stack([table[n][:, n] for n in node])
+
+    td = model.triplet_dist
+    got_rel = unbias(rel, logits, td).cpu() if model.config.use_freq_bias else rel.cpu()
+    ref_rel = unbias(ref["rel_logits"], ref["logits"], td.cpu()) if model.config.use_freq_bias else ref["rel_logits"]
+    return {"class_logits": float((logits.cpu() - ref["logits"]).abs().max()),
+            "boxes": float((boxes.cpu() - ref["pred_boxes"]).abs().max()),
+            "rel_logits": float((got_rel - ref_rel).abs().max()),
+            "conn_logits": float((conn.cpu() - ref["conn_logits"]).abs().max())}
 
 
 def usable_cores():
@@ -210,11 +291,65 @@ def train_bench(args, world, rank, dev, dist):
             "value": round(world * batch * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "final_loss": float(loss),
+            "final_loss": float(loss), "rccl_ranks": args.rccl_ranks,
             "config": {"workload": f"VG train step: ResNet-50, N=200, 6 enc/6 dec, bs={batch}/GPU fp32, DDP x{world} "
                                    "(BASELINE configs[2] shape)", "parallelism": f"dp{world}"}}))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks (one process per GPU) as a CHILD
+    `torch.distributed.run` -- the reference's Trainer(gpus=N, strategy=DDPStrategy(...)) (train_egtr.py:770-779) in
+    launcher form.  Called before this process has made any GPU call (a process that has initialised the GPU must
+    never be replaced or forked into workers); the parent only waits and returns the child's exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def rccl_world_check(dist, dev):
+    """A real all-reduce over the process group: every rank contributes 1, so the sum is the number of ranks that
+    actually took part in a collective (RCCL on GPUs, gloo in the CPU launch test)."""
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def launch_check(args):
+    """--launch-check: rendezvous + one all-reduce + the JSON line, without the model (tests/test_distributed_cpu.py
+    runs `bench.py --gpus 2 --launch-check` on CPU under gloo; on a GPU box it exercises RCCL)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    backend = "nccl" if n_dev >= world and n_dev > 0 else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr)
+        dev = torch.device("cuda", lr)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo")
+    ranks = rccl_world_check(dist, dev)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "rccl_ranks": ranks,
+                          "backend": backend, "requested_gpus": args.gpus}))
+    dist.destroy_process_group()
 
 
 def main():
@@ -237,7 +372,13 @@ def main():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = BASELINE configs[1] (default, the headline metric); train = configs[2]-style train "
                          "step (forward + SGG loss + backward + DDP all-reduce + AdamW), batch 4/GPU unless --batch")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only rendezvous, all-reduce and print n_gpus / rccl_ranks (launcher self-test, runs on CPU)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))  # nothing above this line touches the GPU
+    if args.launch_check:
+        return launch_check(args)
     if args.miopen_find:
         torch.backends.cudnn.benchmark = True
     if args.tune_gemm:
@@ -256,6 +397,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+    if rank == 0 and world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE = {world}: reporting n_gpus = {world}",
+              file=sys.stderr)
+    args.rccl_ranks = rccl_world_check(dist, dev) if dist is not None else 1
 
     if args.mode == "train":
         return train_bench(args, world, rank, dev, dist)
@@ -265,12 +410,13 @@ def main():
     pm = torch.ones(args.batch, H_IMG, W_IMG, dtype=torch.long, device=dev)
 
     from egtr_amd.runtime import GraphedForward
-    fwd = GraphedForward(model, enabled=bool(args.graph))
+    # a failed capture is fatal (strict): an eager run would report ~half the throughput with rc = 0
+    fwd = GraphedForward(model, enabled=bool(args.graph), strict=True)
 
-    with MsdaProbe() as probe, torch.no_grad():
+    with MsdaProbe() as probe, RelHeadProbe() as rprobe, torch.no_grad():
         out = model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
                     output_hidden_states=True)  # eager once: fills the probe, loads MIOpen / rocBLAS kernels
-        msda_args = probe.args
+        msda_args, rel_args = probe.args, rprobe.args
     with torch.no_grad():
         for _ in range(args.warmup):
             out = fwd(pv, pm)
@@ -291,18 +437,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     value = world * args.batch * args.steps / dt
-    if rank == 0 and args.graph and not fwd.graphed:
-        print(f"[bench] HIP-graph capture unavailable, ran eager launches: {fwd.capture_error}", file=sys.stderr)
+    if args.graph and not fwd.graphed:
+        raise SystemExit("[bench] HIP-graph capture did not happen (pass --graph 0 to time eager launches)")
 
     msda_us, alg_bytes = time_msda_kernel(msda_args, probe.fused)
     achieved = alg_bytes / (msda_us * 1e-6) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "msda_traffic.json")
-    if os.path.exists(tpath):  # HBM bytes per launch from a separate rocprofv3 --pmc pass of this command
+    rel_us, rel_flops = time_rel_head_kernel(rel_args)
+    rel_tflops = rel_flops / (rel_us * 1e-6) / 1e12
+    msda_kernel = msda_kernel_name(probe.fused)
+    # HBM bytes / cache behaviour per launch come from separate rocprofv3 --pmc passes over THIS command
+    # (tools/pmc_passes.sh + tools/msda_pmc.py -> profiles/r02_msda_pmc.json); used only if they were collected for
+    # the kernel that was just timed, otherwise null.
+    pmc = {}
+    tpath = os.path.join(ROOT, "profiles", "r02_msda_pmc.json")
+    if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            pmc = json.load(open(tpath))
+            if pmc.get("kernel") != msda_kernel:
+                pmc = {}
         except Exception:
-            traffic = None
+            pmc = {}
+    traffic = pmc.get("hbm_bytes_per_launch")
     result = {
         "metric": "images/sec end-to-end SGG, 600x1000 input, N=200 queries",
         "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -312,22 +467,34 @@ def main():
                                f"600x1000, bs={args.batch}/GPU fp32 (BASELINE configs[1])",
                    "images_per_step_per_gpu": args.batch, "hip_graph": bool(args.graph) and fwd.graphed, "gemm_tuning": bool(args.tune_gemm),
                    "parallelism": f"replicas x{world} (independent images, no collective)"},
-        "roofline": {"bound": "hbm", "kernel": "msda_fwd_q64_f32%s (encoder layer, Lq = S = 12537)" % ("<fused softmax + sampling locations>" if probe.fused else ""),
+        "roofline": {"bound": "hbm", "kernel": msda_kernel, "launch": "encoder layer, Lq = S = 12537, fused softmax + "
+                     "sampling locations" if probe.fused else "encoder layer, Lq = S = 12537",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(msda_us, 3)},
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(msda_us, 3),
+                     "l2_hit": pmc.get("l2_hit"), "l1_gather_bytes": pmc.get("l1_gather_bytes"),
+                     "frac_of_l1_gather_ceiling": (round(pmc["l1_gather_bytes"] / (msda_us * 1e-6) / 30.5e12, 3)
+                                                   if pmc.get("l1_gather_bytes") else None)},
+        "rccl_ranks": args.rccl_ranks,
     }
+    result["roofline_kernels"] = [
+        result["roofline"],
+        {"bound": "mfma", "kernel": "rel_head_fwd_f32", "launch": f"B={args.batch}, N=200, T=7, R=50",
+         "achieved": round(rel_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(rel_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+         "algorithmic_flops_per_launch": rel_flops, "avg_launch_us": round(rel_us, 3)}]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncores = usable_cores()
         torch.set_num_threads(ncores)
         print(f"[bench] cpu baseline on {ncores} usable cores (os.cpu_count() = {os.cpu_count()})", file=sys.stderr)
         ips, nimg, ref, cpv, cpm = cpu_baseline(model, cfg_dict, args.cpu_budget)
-        with torch.no_grad():
-            got = model(pixel_values=cpv.to(dev), pixel_mask=cpm.to(dev), output_attention_states=True)
-        err = float((got.pred_boxes.cpu() - ref["pred_boxes"]).abs().max())
-        err_rel = float((got.pred_rel.cpu() - ref["pred_rel"]).abs().max())
-        print(f"[bench] parity vs CPU oracle on the bench workload: max|d boxes| = {err:.2e}, "
-              f"max|d pred_rel| = {err_rel:.2e}", file=sys.stderr)
+        par = logit_parity(model, ref, cpv.to(dev), cpm.to(dev))
+        print("[bench] parity vs CPU oracle on the bench workload (PRE-sigmoid logits, north-star bar 1e-3): "
+              + ", ".join(f"max|d {k}| = {v:.2e}" for k, v in par.items()), file=sys.stderr)
+        result["parity_vs_oracle"] = {k: float(f"{v:.3e}") for k, v in par.items()}
+        if max(par.values()) >= 1e-3:
+            print(json.dumps(result))
+            raise SystemExit("[bench] parity against the CPU oracle FAILED (>= 1e-3 on a logit tensor)")
         result["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
                                   "kind": "port",
                                   "sample": f"{nimg} images after 1 warm-up, same 600x1000 / N=200 "

@@ -91,18 +91,36 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]):
     return NestedTensor(tensor, mask)
 
 
-def bbox_overlaps(boxes, query_boxes):
-    """IoU matrix [N, K] with the "+1 pixel" box convention of the reference's Cython routine
-    (lib/fpn/box_intersections_cpu/bbox.pyx:21-61, used by lib/evaluation/sg_eval.py:318-322), vectorised so that it
-    runs wherever the boxes live (CPU or GPU); zero where the boxes do not overlap.  Computed in float64 like the
-    reference (``np.float``)."""
+def _bbox_pairs(boxes, query_boxes, mode):
     a = torch.as_tensor(boxes).to(torch.float64)
     q = torch.as_tensor(query_boxes, device=a.device).to(torch.float64)
+    if a.is_cuda:
+        # device routine (csrc/postprocess.hip), bit-identical to the reference's Cython loops
+        from . import _lib
+        a, q = a.contiguous(), q.contiguous()
+        out = torch.empty(a.shape[0], q.shape[0], dtype=torch.float64, device=a.device)
+        st = _lib.lib().egtr_bbox_overlaps_f64(torch.cuda.current_stream().cuda_stream, a.data_ptr(), q.data_ptr(),
+                                               a.shape[0], q.shape[0], mode, out.data_ptr())
+        _lib.check(st, "egtr_bbox_overlaps_f64")
+        return out
+    # host tensors (the reference's own habitat for this routine): the same arithmetic, vectorised
     iw = torch.minimum(a[:, None, 2], q[None, :, 2]) - torch.maximum(a[:, None, 0], q[None, :, 0]) + 1
     ih = torch.minimum(a[:, None, 3], q[None, :, 3]) - torch.maximum(a[:, None, 1], q[None, :, 1]) + 1
     area_a = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
     area_q = (q[:, 2] - q[:, 0] + 1) * (q[:, 3] - q[:, 1] + 1)
     inter = iw * ih
-    ua = area_a[:, None] + area_q[None, :] - inter
-    return torch.where((iw > 0) & (ih > 0), inter / ua, torch.zeros((), dtype=torch.float64, device=a.device))
+    den = (area_a[:, None] + area_q[None, :] - inter) if mode == 0 else area_q[None, :].expand_as(inter)
+    return torch.where((iw > 0) & (ih > 0), inter / den, torch.zeros((), dtype=torch.float64, device=a.device))
 
+
+def bbox_overlaps(boxes, query_boxes):
+    """IoU matrix [N, K] with the "+1 pixel" box convention of the reference's Cython routine
+    (lib/fpn/box_intersections_cpu/bbox.pyx:21-61, used by lib/evaluation/sg_eval.py:318-322); zero where the boxes do
+    not overlap; float64 like the reference (``np.float``).  Boxes on the GPU run the HIP routine
+    ``egtr_bbox_overlaps_f64``; host tensors the vectorised host arithmetic."""
+    return _bbox_pairs(boxes, query_boxes, 0)
+
+
+def bbox_intersections(boxes, query_boxes):
+    """Fraction of each query box covered by each box (bbox.pyx:64-108), same conventions as ``bbox_overlaps``."""
+    return _bbox_pairs(boxes, query_boxes, 1)

@@ -240,6 +240,14 @@ int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* i
                         const float* inter_references, int batch, int num_levels, int num_query, int ref_dim, float eps,
                         float* boxes);
 
+/* IoU matrix of the reference's native evaluator routine, lib/fpn/box_intersections_cpu/bbox.pyx: mode 0 =
+ * bbox_overlaps (:21-61), mode 1 = bbox_intersections (:64-108).  boxes [num_boxes, 4], query_boxes [num_query, 4]
+ * (x0, y0, x1, y1), float64 like the reference (DTYPE = np.float), "+1 pixel" convention; out [num_boxes, num_query],
+ * zero where the boxes do not overlap.  Bit-identical to the Cython loops (same operation order, no contraction).
+ * Either count may be 0 (nothing is launched). */
+int egtr_bbox_overlaps_f64(egtr_stream_t stream, const double* boxes, const double* query_boxes, int num_boxes,
+                           int num_query, int mode, double* out);
+
 /* Sine position embedding of DeformableDetrSinePositionEmbedding(normalize=True) (model/deformable_detr.py:850-876)
  * from y_embed / x_embed = cumsum of the mask along H / W ([B,H,W] fp32) and dim_t [E] (the reference's
  * temperature ** (2*(i//2)/E) table); out [B, 2E, H, W]. */

@@ -4,6 +4,11 @@ scene-graph post-processing, the inputs of its evaluators.
     triplet_candidates  <- evaluate_batch, train_egtr.py:54-106 (multiple-predicate branch) with argsort_desc,
                            lib/pytorch_misc.py:27-34, and rescale_bboxes, util/box_ops.py:87-91
     bbox_overlaps       <- lib/fpn/box_intersections_cpu/bbox.pyx:21-61 (Cython in the reference; loops restated)
+
+PINNED: tests/test_oracle_golden.py::test_postprocessing_oracle_vs_reference_evaluate_batch checks both functions
+against tests/golden/postprocess.npz, i.e. against the outputs of the reference's own evaluate_batch (imported from
+/root/reference and run by tests/golden/make_golden_post.py) and of its Cython routines compiled from the reference
+sources (oracle/Makefile -> oracle/_ref/).
 """
 import numpy as np
 import torch

@@ -118,3 +118,44 @@ def make_targets(seed, B, N, C, R, tmin=3, tmax=8):
                             boxes=torch.from_numpy(np.concatenate([cxcy, wh], 1).astype(np.float32)),
                             rel=torch.from_numpy(rel)))
     return targets
+
+
+def post_inputs(seed=61, B=2, N=200, C=150, R=50):
+    """Seeded model outputs + targets for the post-processing fixtures (evaluate_batch, train_egtr.py:43-106).
+    Image 1's relation scores are quantised to multiples of 1/8 and its connectivity to {0.5, 1}, so exactly tied
+    triplet scores occur (argsort order inside a tie group is implementation-defined)."""
+    rng = rng_inputs(seed)
+    logits = torch.from_numpy(rng.standard_normal((B, N, C + 1)) * 2).float()
+    cxcy = rng.uniform(0.15, 0.85, (B, N, 2))
+    wh = rng.uniform(0.04, 0.3, (B, N, 2))
+    boxes = torch.from_numpy(np.concatenate([cxcy, wh], -1)).float()
+    rel = torch.from_numpy(rng.uniform(0, 1, (B, N, N, R))).float()
+    conn = torch.from_numpy(rng.uniform(0, 1, (B, N, N, 1))).float()
+    rel[1] = torch.round(rel[1] * 8) / 8
+    conn[1] = torch.where(conn[1] > 0.5, torch.ones(()), torch.full((), 0.5))
+    outputs = {"logits": logits, "pred_boxes": boxes, "pred_rel": rel, "pred_connectivity": conn}
+    sizes = [(600, 1000), (480, 640)]
+    targets = []
+    for b, t in enumerate(make_targets(seed + 100, B, N, C, R, tmin=5, tmax=30)):
+        t = dict(t)
+        t["orig_size"] = torch.tensor(sizes[b])
+        targets.append(t)
+    return outputs, targets, dict(num_labels=C, sizes=sizes)
+
+
+def bbox_cases(seed=62):
+    """xyxy box sets for bbox_overlaps / bbox_intersections (bbox.pyx:21-108): random, integer-aligned with touching /
+    one-pixel-overlap pairs (the +1 convention makes touching boxes overlap), degenerate and empty inputs."""
+    rng = rng_inputs(seed)
+
+    def rnd(n, size):
+        x0 = rng.uniform(0, size * 0.8, (n, 1))
+        y0 = rng.uniform(0, size * 0.8, (n, 1))
+        return np.concatenate([x0, y0, x0 + rng.uniform(1, size * 0.4, (n, 1)), y0 + rng.uniform(1, size * 0.4, (n, 1))],
+                              1)
+
+    grid = np.array([[0, 0, 9, 9], [10, 0, 19, 9], [9, 9, 20, 20], [0, 10, 9, 19], [5, 5, 5, 5], [20, 20, 30, 30],
+                     [-5, -5, 4, 4], [3, 3, 2, 2]], dtype=np.float64)
+    return {"random": (rnd(200, 1000.0), rnd(37, 1000.0)), "grid": (grid, grid.copy()),
+            "ints": (np.floor(rnd(64, 64.0)), np.floor(rnd(64, 64.0))),
+            "empty_q": (rnd(5, 100.0), np.zeros((0, 4)))}

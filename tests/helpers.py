@@ -82,3 +82,31 @@ def padded_inputs(g, B, dtype=torch.float32):
     pm[1, :, vw:] = 0
     pv[1] = pv[1] * pm[1][None].float()
     return pv.to(dtype), pm
+
+
+def check_pred_entry(got, g, j, atol=1e-6):
+    """``got``: one image's entry (numpy arrays) with the reference's pred_entry keys (+ optional triplet_scores);
+    ``g``: tests/golden/postprocess.npz (outputs of the reference's own evaluate_batch, train_egtr.py:43-106).
+    Rows are index-exact wherever the triplet score is unique; inside a group of exactly tied scores any order is a
+    valid argsort (numpy's quicksort order is not a specification), so tie groups are compared as sets -- except the
+    LAST group, which the top-k cut may truncate differently: there only membership in the full tie class counts."""
+    want_inds, want_rel = g[f"pred{j}_pred_rel_inds"], g[f"pred{j}_rel_scores"]
+    gi = np.asarray(got["pred_rel_inds"])
+    assert gi.shape == want_inds.shape
+    assert np.array_equal(np.asarray(got["pred_classes"]), g[f"pred{j}_pred_classes"])
+    assert np.abs(np.asarray(got["obj_scores"]) - g[f"pred{j}_obj_scores"]).max() < atol
+    assert np.abs(np.asarray(got["pred_boxes"]) - g[f"pred{j}_pred_boxes"]).max() < 1e-3
+    ts = np.asarray(got["triplet_scores"], dtype=np.float64)
+    assert np.all(ts[:-1] >= ts[1:]), "triplets must come in descending score order"
+    # group rows by (exactly) equal triplet score
+    starts = [0] + [i for i in range(1, len(ts)) if ts[i] != ts[i - 1]] + [len(ts)]
+    n_exact = 0
+    for a, b in zip(starts[:-1], starts[1:]):
+        last = b == len(ts)
+        if b - a == 1 and not last:
+            assert tuple(gi[a]) == tuple(want_inds[a]), (a, gi[a], want_inds[a])
+            assert abs(float(got["rel_scores"][a]) - float(want_rel[a])) < atol
+            n_exact += 1
+        elif not last:
+            assert set(map(tuple, gi[a:b])) == set(map(tuple, want_inds[a:b])), (a, b)
+    return n_exact

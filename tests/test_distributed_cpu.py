@@ -158,3 +158,21 @@ def test_ddp_two_ranks_matches_single_process(tmp_path):
                                         output_attention_states=True)
         # the local model has not taken the SGD step, so only check shape / finiteness here
         assert torch.isfinite(o.pred_rel).all()
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus N` must create N ranks by itself (the reference: Trainer(gpus=N,
+    strategy=DDPStrategy(...)), train_egtr.py:770-779).  On CPU the launcher self-test runs under gloo: the parent
+    spawns a child torch.distributed.run, rank 0 prints n_gpus and the result of a real all-reduce."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["requested_gpus"] == 2

@@ -246,6 +246,25 @@ def test_bbox_overlaps_matches_reference_cython_routine():
 
 
 
+def test_postprocessing_host_path_vs_reference_fixture(golden_dir):
+    """runtime.triplet_candidates and util.bbox_overlaps / bbox_intersections on host tensors against the outputs of the
+    reference's evaluate_batch and Cython routines (tests/golden/postprocess.npz)."""
+    import helpers as Hh
+    import weights as W
+    from egtr_amd.runtime import triplet_candidates
+    from egtr_amd.util import bbox_intersections, bbox_overlaps
+    g = Hh.load_golden(golden_dir, "postprocess.npz")
+    outputs, targets, meta = W.post_inputs(int(g["seed"]))
+    sizes = torch.stack([t["orig_size"] for t in targets])
+    got = triplet_candidates(outputs, meta["num_labels"], sizes, max_topk=100)
+    for j in range(2):
+        Hh.check_pred_entry({k: v.numpy() for k, v in got[j].items()}, g, j)
+    for name, (a, b) in W.bbox_cases(int(g["bbox_seed"])).items():
+        assert np.abs(bbox_overlaps(torch.from_numpy(a), torch.from_numpy(b)).numpy() - g[f"iou_{name}"]).max(initial=0) < 1e-15
+        assert np.abs(bbox_intersections(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+                      - g[f"inter_{name}"]).max(initial=0) < 1e-15
+
+
 def test_cached_weights_live_on_the_owner_and_follow_their_sources():
     """derived constants must never leak from one model to the next (CPython reuses id(), the
     allocator reuses storage), and must be rebuilt when a source is modified in place or replaced."""

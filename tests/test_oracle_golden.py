@@ -236,3 +236,36 @@ def test_full_size_train_aux_loss_vs_reference(golden_dir):
     for k, v in ref.items():
         assert abs(float(ld[k]) - v) < 3e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
     assert abs(float(total) - float(g["train_loss"])) < 3e-4 * abs(float(g["train_loss"]))
+
+
+def test_postprocessing_oracle_vs_reference_evaluate_batch(golden_dir):
+    """oracle/postprocess.py pinned against the reference's own evaluate_batch (imported and run by
+    tests/golden/make_golden_post.py) and its Cython bbox routines (compiled by oracle/Makefile): postprocess.npz."""
+    import helpers as Hh
+    from oracle import postprocess as OP
+    g = _load(golden_dir, "postprocess.npz")
+    outputs, targets, meta = W.post_inputs(int(g["seed"]))
+    exact = []
+    for j in range(2):
+        got = OP.triplet_candidates(outputs["logits"][j], outputs["pred_boxes"][j], outputs["pred_rel"][j],
+                                    outputs["pred_connectivity"][j], meta["num_labels"], targets[j]["orig_size"], 100)
+        exact.append(Hh.check_pred_entry(got, g, j))
+        if j == 0:  # continuous scores: the restatement reproduces numpy's order row for row
+            assert np.array_equal(got["pred_rel_inds"], g["pred0_pred_rel_inds"])
+            assert np.array_equal(got["rel_scores"], g["pred0_rel_scores"])
+    assert exact[0] >= 99 and exact[1] < 99   # image 1 was built with tied scores
+    for name, (a, b) in W.bbox_cases(int(g["bbox_seed"])).items():
+        assert np.array_equal(OP.bbox_overlaps(a, b), g[f"iou_{name}"]), name      # bit-exact float64
+
+
+def test_oracle_ref_bbox_module_when_built(golden_dir):
+    """oracle/_ref (the reference's Cython source compiled here) reproduces the committed fixture; skipped where the
+    module was not built (a checkout without /root/reference)."""
+    from oracle import ref_bbox
+    m = ref_bbox.load()
+    if m is None:
+        pytest.skip("oracle/_ref/bbox*.so not built")
+    g = _load(golden_dir, "postprocess.npz")
+    for name, (a, b) in W.bbox_cases(int(g["bbox_seed"])).items():
+        assert np.array_equal(m.bbox_overlaps(a, b), g[f"iou_{name}"])
+        assert np.array_equal(m.bbox_intersections(a, b), g[f"inter_{name}"])
