@@ -600,6 +600,12 @@ int egtr_launch_msda_fwd_win_f32(hipStream_t st, const float* value, const int64
                                  int kind, const float* ref, float* attn_out, int ld_off, int ld_logit,
                                  const unsigned char* keep, const unsigned* keep_bits, unsigned long long* prof);
 
+// msda_region.hip: adaptive region kernel (variant 14; 15 / 16 force its window / wave-per-query scheme)
+int egtr_launch_msda_fwd_region_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
+                                    const float* loc, const float* attn, float* out, int B, int Lq, int S,
+                                    const float* ref, float* attn_out, int ld_off, int ld_logit,
+                                    const unsigned* keep_bits, int mode);
+
 // A/B switch for benchmarks: EGTR_MSDA_FWD_VARIANT=<n> overrides the automatic choice of the forward kernel
 // (read once; never needed for correctness -- every variant computes the same function).
 constexpr int kAutoEncoderVariant = 1;  // what "automatic" picks for encoder-shaped calls
@@ -630,7 +636,13 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   if (variant == 0 && fast && env_fwd_variant() > 0) variant = env_fwd_variant();
   if (variant == 0)
     variant = !fast ? 3 : ((num_query == spatial_size && num_query >= 1024 && !(num_point & 1)) ? kAutoEncoderVariant : 1);
-  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 13)) && !fast) return EGTR_E_UNSUPPORTED;
+  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 16)) && !fast) return EGTR_E_UNSUPPORTED;
+  if (variant >= 14 && variant <= 16) {
+    if (num_levels != 4 || num_point != 4) return EGTR_E_UNSUPPORTED;
+    return egtr_launch_msda_fwd_region_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
+                                           batch, num_query, spatial_size, nullptr, nullptr, 256, 128, nullptr,
+                                           variant - 14);
+  }
   if (variant >= 8 && variant <= 13) {
     if (num_point & 1) return EGTR_E_UNSUPPORTED;
     return egtr_launch_msda_fwd_win_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
@@ -719,13 +731,24 @@ extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const flo
   if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
       (long long)spatial_size * 1024 >= (1ll << 31) || nq >= (1ll << 27))
     return EGTR_E_UNSUPPORTED;
-  if (variant != 0 && variant != 1 && (variant < 8 || variant > 13)) return EGTR_E_UNSUPPORTED;
+  if (variant != 0 && variant != 1 && (variant < 8 || variant > 16)) return EGTR_E_UNSUPPORTED;
   if (variant == 0) {
     // automatic: the LDS-window kernel for encoder-shaped calls (queries = the pixels of the levels), the
     // wave-per-query kernel for short / arbitrary query lists (decoder)
     const int e = env_fwd_variant();
-    variant = (e == 1 || (e >= 8 && e <= 13)) ? e : kAutoEncoderVariant;
+    variant = (e == 1 || (e >= 8 && e <= 16)) ? e : kAutoEncoderVariant;
     if (!(num_query == spatial_size && num_query >= 1024)) variant = 1;
+    if (variant >= 14 && (num_levels != 4 || num_point != 4 || value_bias != nullptr ||
+                          (keep_mask != nullptr && keep_bits == nullptr)))
+      variant = 1;
+  }
+  if (variant >= 14) {
+    if (num_levels != 4 || num_point != 4 || value_bias != nullptr || (keep_mask != nullptr && keep_bits == nullptr))
+      return EGTR_E_UNSUPPORTED;
+    return egtr_launch_msda_fwd_region_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
+                                           sampling_offsets, attn_logits, out, batch, num_query, spatial_size,
+                                           reference_points, attn_weight_out, ld_offsets, ld_logits, keep_bits,
+                                           variant - 14);
   }
   if (variant >= 8) {
     if (value_bias != nullptr) return EGTR_E_UNSUPPORTED;  // the LDS-window kernels take finished values only

@@ -317,6 +317,121 @@ def test_msda_window_variant_fused_prologue_and_keep_mask(variant, shapes, B):
     assert torch.equal(a, b_)
 
 
+PYR_600 = [(75, 125), (38, 63), (19, 32), (10, 16)]
+PYR_800 = [(100, 167), (50, 84), (25, 42), (13, 21)]
+
+
+@pytest.mark.parametrize("variant", [14, 15, 16])
+@pytest.mark.parametrize("shapes,B,jitter", [
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # small pyramid, windows fit
+    ([(19, 32), (10, 16), (5, 8), (3, 4)], 1, 8.0),       # scattered offsets: most samples leave their window
+    ([(38, 63), (19, 32), (10, 16), (5, 8)], 1, 1.0),
+    (PYR_600, 2, 0.0),                                     # the bench pattern, two images
+    (PYR_600, 1, 0.5),
+    (PYR_600, 1, 2.0),                                     # a few per cent of outliers: per-sample global gathers
+    (PYR_600, 1, 4.0),                                     # irregular: regions switch to the wave-per-query scheme
+    (PYR_800, 1, 0.5),                                     # 800x1333: 128 regions
+])
+def test_msda_region_kernel_matches_oracle_and_wave_variant(variant, shapes, B, jitter):
+    """The adaptive region kernel (14) and its two schemes forced (15 window, 16 wave-per-query) on encoder-shaped calls:
+    vs the oracle (2e-5), vs the wave-per-query kernel, bitwise repeatable."""
+    k = _kernels()
+    x = _grid_inputs(9, B, shapes, jitter)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+    o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+    assert (o - ref).abs().max() < 2e-5
+    assert (o - o1).abs().max() < 2e-5
+    ob = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+    assert torch.equal(o, ob)
+
+
+@pytest.mark.parametrize("variant", [14, 15, 16])
+def test_msda_region_kernel_arbitrary_queries_and_borders(variant):
+    """Queries that are NOT the pixel grid (consecutive chunks, wave-per-query scheme), all-out-of-range and NaN
+    locations, half the queries far outside, every sample pushed across an image border (zero-filled window apron);
+    L != 4 is refused."""
+    k = _kernels()
+    shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
+    for Lq in (200, 820, 65):
+        x = W.make_msda_inputs(31 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
+        d = {n: t.to(DEV) for n, t in x.items()}
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], variant).cpu()
+        assert (o - ref).abs().max() < 2e-5, Lq
+    x = _grid_inputs(6, 1, shapes, 0.3)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    for bad in (3.0, float("nan")):
+        loc = torch.full_like(d["loc"], bad)
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant)
+        assert o.abs().max().item() == 0
+    loc = d["loc"].clone()
+    loc[:, ::2] = 5.0
+    o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant).cpu()
+    ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc.cpu(), x["attn"])
+    assert (o - ref).abs().max() < 2e-5
+    for shift in (-0.04, 0.04, -0.3, 0.3):
+        loc = (d["loc"] + shift).contiguous()
+        o = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], loc, d["attn"], variant).cpu()
+        ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], loc.cpu(), x["attn"])
+        assert (o - ref).abs().max() < 2e-5, shift
+    x2 = _grid_inputs(6, 1, [(9, 13), (5, 7)], 0.3)
+    d2 = {n: t.to(DEV) for n, t in x2.items()}
+    with pytest.raises(Exception):
+        k.ms_deform_attn_forward_variant(d2["value"], d2["shapes"], d2["lsi"], d2["loc"], d2["attn"], variant)
+
+
+@pytest.mark.parametrize("variant", [14, 15, 16])
+@pytest.mark.parametrize("shapes,B", [([(19, 32), (10, 16), (5, 8), (3, 4)], 2), (PYR_600, 2)])
+def test_msda_region_kernel_fused_prologue_and_keep_mask(variant, shapes, B):
+    """The fused entry (softmax + sampling locations in the kernel, strided offsets | logits block, bit-packed padding
+    mask -> zeroed window pixels, attention-weight output) served by the region kernel == the wave-per-query kernel."""
+    k = _kernels()
+    g = torch.Generator().manual_seed(13)
+    L, P = 4, 4
+    S = sum(h * w for h, w in shapes)
+    shp = torch.as_tensor(shapes, dtype=torch.long)
+    lsi = torch.cat((shp.new_zeros((1,)), shp.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(B, S, 8, 32, generator=g)
+    both = torch.randn(B, S, 384, generator=g) * 2
+    ref = torch.cat([torch.stack([((torch.arange(h * w) % w) + 0.5) / w, ((torch.arange(h * w) // w) + 0.5) / h], -1)
+                     for h, w in shapes], 0)
+    ref = ref[None, :, None, :].expand(B, S, L, 2).contiguous() * (0.9 + 0.2 * torch.rand(B, 1, L, 2, generator=g))
+    keep = torch.rand(B, S, generator=g) > 0.25
+    d = [t.to(DEV) for t in (value, shp, lsi, both, ref, keep)]
+    off = d[3][..., :256].view(B, S, 8, L, P, 2)
+    logits = d[3][..., 256:].view(B, S, 8, 16)
+    want, ww = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, None, variant=1)
+    got, gw = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, None, variant=variant)
+    assert (got - want).abs().max().item() < 2e-5
+    assert torch.equal(gw, ww)
+    with pytest.raises(Exception):  # a byte mask without its bit-packed copy is not served by this kernel
+        k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5], variant=variant)
+    words = torch.zeros(B, (S + 31) // 32, dtype=torch.int64)
+    idx = torch.arange(S)
+    for bi in range(B):
+        words[bi].index_add_(0, idx // 32, keep[bi].long() << (idx % 32))
+    bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(DEV)
+    kmb = d[5].clone()
+    kmb._egtr_bits = bits
+    want, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5], variant=1)
+    got, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, kmb, variant=variant)
+    assert (got - want).abs().max().item() < 2e-5
+    ones = torch.ones_like(d[5])
+    ones._egtr_bits = torch.full_like(bits, -1)
+    a, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, ones, variant=variant)
+    b_, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, None, variant=variant)
+    assert torch.equal(a, b_)
+    # small offsets (the model's regime): the window scheme is what runs in variant 14
+    small = d[3].clone()
+    small[..., :256] *= 0.5
+    off_s = small[..., :256].view(B, S, 8, L, P, 2)
+    want, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off_s, logits, d[4], False, kmb, variant=1)
+    got, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off_s, logits, d[4], False, kmb, variant=variant)
+    assert (got - want).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("variant", [5, 6])
 @pytest.mark.parametrize("shapes,B,jitter", [
     ([(19, 32), (10, 16), (5, 8), (3, 4)], 2, 0.3),       # windows fit: LDS path
