@@ -49,12 +49,16 @@ SIGNATURES = {
                                 _P, _P],
     "egtr_input_proj_groupnorm_flatten_f32": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_bbox_overlaps_f64": [_P, _P, _P, _I, _I, _I, _P],
+    "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
+                                 ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],
+    "egtr_hungarian_match_scratch_doubles": [_I, _I, ctypes.c_longlong],
     "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_rel_head_forward_bf16w": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_rel_head_forward_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
     "egtr_rel_head_backward_pairs_f32": [_P] * 6 + [_I] * 4 + [_P] * 5,
 }
-_RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p}
+_RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p,
+             "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong}
 
 _lib = None
 

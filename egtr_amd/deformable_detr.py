@@ -1064,8 +1064,13 @@ class DeformableDetrMLPPredictionHead(nn.Module):
 
 
 class DeformableDetrHungarianMatcher(nn.Module):
-    """Hungarian matcher with the adaptive-smoothing cost offset (dd:2886-3015).  Cost matrix on the device,
-    assignment with scipy on the host (float64 inside scipy), exactly as the reference."""
+    """Hungarian matcher with the adaptive-smoothing cost offset (dd:2886-3015).
+
+    Outputs on the GPU: cost matrix AND assignment run on the device in one HIP launch (csrc/matcher.hip,
+    ``ops.hungarian_match``): the reference's per-step copy of the cost matrix to the host (dd:2985 ``.cpu()``) and its
+    scipy call are gone, and the returned index / cost tensors live on the device (the losses index device tensors with
+    them; values and order are scipy's: float64 solve, same tie rule, pinned in oracle/lsa.py).  CPU tensors: the
+    reference's composition + scipy, returning CPU index tensors like the reference."""
 
     def __init__(self, class_cost: float = 1, bbox_cost: float = 1, giou_cost: float = 1, smoothing=0.0):
         super().__init__()
@@ -1078,16 +1083,30 @@ class DeformableDetrHungarianMatcher(nn.Module):
         self.smoothing = smoothing
         self.bias_epsilon = torch.log(torch.tensor(1e-8))
 
+    def _smoothing_scalars(self):
+        """cost_min and inverse_sigmoid_smoothing exactly as the reference forms them (fp32 tensors, dd:2992-2998)."""
+        alpha = 0.25
+        cost_min = self.class_cost * (1 - alpha) * self.bias_epsilon - self.giou_cost
+        inverse_sigmoid_smoothing = -torch.log(torch.tensor((1.0 / self.smoothing) - 1.0))
+        return cost_min, inverse_sigmoid_smoothing
+
     @torch.no_grad()
     def prepare(self, outputs, targets):
-        """First half of ``forward``: the cost matrix on the device and its copy to the host, ENQUEUED only (pinned
-        buffer + event on GPU tensors).  The caller can launch more GPU work (the relation head) before ``finish`` waits
-        for the copy: the assignment then runs on the host while the GPU is busy instead of in a pipeline bubble."""
+        """First half of ``forward``.  GPU: the whole matcher is ENQUEUED here (one launch, asynchronous) and ``finish``
+        only slices its outputs -- no host synchronisation at all.  CPU: the cost matrix."""
+        if outputs["logits"].is_cuda and outputs["logits"].dtype == torch.float32:
+            cm = iss = None
+            if self.smoothing:
+                cm, iss = self._smoothing_scalars()
+            pred_idx, tgt_idx, mcost, n_out = ops.hungarian_match(
+                outputs["logits"], outputs["pred_boxes"], targets, self.class_cost, self.bbox_cost, self.giou_cost,
+                float(cm) if cm is not None else None, float(iss) if iss is not None else None)
+            return ("device", pred_idx, tgt_idx, mcost, n_out)
         bs, num_queries = outputs["logits"].shape[:2]
-        out_prob = outputs["logits"].flatten(0, 1).sigmoid()
-        out_bbox = outputs["pred_boxes"].flatten(0, 1)
+        out_prob = outputs["logits"].flatten(0, 1).float().sigmoid()
+        out_bbox = outputs["pred_boxes"].flatten(0, 1).float()
         tgt_ids = torch.cat([v["class_labels"] for v in targets])
-        tgt_bbox = torch.cat([v["boxes"] for v in targets])
+        tgt_bbox = torch.cat([v["boxes"] for v in targets]).float()
         alpha, gamma = 0.25, 2.0
         neg_cost_class = (1 - alpha) * (out_prob ** gamma) * (-(1 - out_prob + 1e-8).log())
         pos_cost_class = alpha * ((1 - out_prob) ** gamma) * (-(out_prob + 1e-8).log())
@@ -1095,26 +1114,22 @@ class DeformableDetrHungarianMatcher(nn.Module):
         bbox_cost = torch.cdist(out_bbox, tgt_bbox, p=1)
         giou_cost = -generalized_box_iou(center_to_corners_format(out_bbox), center_to_corners_format(tgt_bbox))
         cost_matrix = self.bbox_cost * bbox_cost + self.class_cost * class_cost + self.giou_cost * giou_cost
-        cost_matrix = cost_matrix.view(bs, num_queries, -1)
-        event = None
-        if cost_matrix.is_cuda:
-            host = torch.empty(cost_matrix.shape, dtype=cost_matrix.dtype, pin_memory=True)
-            host.copy_(cost_matrix, non_blocking=True)  # the one D2H transfer of the step (dd:2985)
-            event = torch.cuda.Event()
-            event.record()
-        else:
-            host = cost_matrix
-        return host, event, [len(v["boxes"]) for v in targets], out_prob.device
+        cost_matrix = cost_matrix.view(bs, num_queries, -1).cpu()
+        return ("host", cost_matrix, [len(v["boxes"]) for v in targets], out_prob.device)
 
     @torch.no_grad()
     def finish(self, pending):
-        cost_matrix, event, sizes, device = pending
-        if event is not None:
-            event.synchronize()
-        alpha = 0.25
+        if pending[0] == "device":
+            _, pred_idx, tgt_idx, mcost, n_out = pending
+            indices, costs, o = [], [], 0
+            for n in n_out:
+                indices.append((pred_idx[o:o + n], tgt_idx[o:o + n]))
+                costs.append(mcost[o:o + n])
+                o += n
+            return indices, costs
+        _, cost_matrix, sizes, device = pending
         if self.smoothing:
-            cost_min = self.class_cost * (1 - alpha) * self.bias_epsilon - self.giou_cost
-            inverse_sigmoid_smoothing = -torch.log(torch.tensor((1.0 / self.smoothing) - 1.0))
+            cost_min, inverse_sigmoid_smoothing = self._smoothing_scalars()
             cost_matrix = cost_matrix - cost_min + inverse_sigmoid_smoothing
         indices = [linear_sum_assignment(c[i]) for i, c in enumerate(cost_matrix.split(sizes, -1))]
         matching_costs = [c[i, indices[i][0], indices[i][1]].to(device)

@@ -444,10 +444,12 @@ class SceneGraphGenerationLoss(nn.Module):
         losses, connect_losses = [], []
         dev = outputs["pred_rel"].device
         for i, ((src_index, target_index), target, matching_cost) in enumerate(zip(indices, targets, matching_costs)):
-            full_index = torch.arange(self.num_object_queries)
+            # (the matcher returns device index tensors for device outputs, CPU tensors otherwise)
+            full_index = torch.arange(self.num_object_queries, device=src_index.device)
             uniques, counts = torch.cat([full_index, src_index]).unique(return_counts=True)
             full_src_index = torch.cat([src_index, uniques[counts == 1]]).to(dev)
-            full_target_index = torch.cat([target_index, torch.arange(len(target_index), self.num_object_queries)])
+            full_target_index = torch.cat([target_index, torch.arange(len(target_index), self.num_object_queries,
+                                                                      device=target_index.device)])
             full_matching_cost = torch.cat([matching_cost, torch.full(
                 (self.num_object_queries - len(matching_cost),), float(self.nonmatching_cost),
                 device=matching_cost.device)])
@@ -485,12 +487,10 @@ class SceneGraphGenerationLoss(nn.Module):
             T = int(len(src_index))
             sidx, tidx = src_index.to(dev), target_index.to(dev)
             # target row of every query: matched -> its target, unmatched (ascending) -> rows T, T+1, ... (egtr:761-768)
-            unmatched = torch.ones(N, dtype=torch.bool)
-            unmatched[src_index] = False
-            tq = torch.empty(N, dtype=torch.int64)
-            tq[src_index] = target_index
-            tq[unmatched] = torch.arange(T, N)
-            tq = tq.to(dev)
+            unmatched = torch.ones(N, dtype=torch.bool, device=dev)
+            unmatched[sidx] = False
+            tq = T + torch.cumsum(unmatched, 0) - 1          # unmatched queries, ascending -> rows T, T+1, ...
+            tq[sidx] = tidx
             rel_t = target["rel"]
             block_t = rel_t[tidx][:, tidx]                       # [T, T, R] targets of the matched block
             counts.append(torch.stack([(block_t != 0).sum(), (block_t != 1.0).sum()]))

@@ -625,3 +625,67 @@ def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c,
         return rel.to(dt), conn.to(dt), gm
     return RelationHeadFunction.apply(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,
                                       triplet_dist, node_cls, want_gate_mean)
+
+
+@torch.no_grad()
+def hungarian_match(logits, pred_boxes, targets, class_cost, bbox_cost, giou_cost, cost_min=None,
+                    inverse_sigmoid_smoothing=None, cost_in=None, want_cost=False, want_status=False):
+    """DeformableDetrHungarianMatcher.forward on the device (egtr_hungarian_match_f32): cost matrix + linear sum
+    assignment per image in one launch, nothing copied to the host (the reference's ``.cpu()`` at dd:2985 is a device
+    synchronisation per step).  ``targets``: list of dicts with "class_labels" / "boxes" (device tensors); their COUNTS
+    are host integers (tensor shapes), so output shapes are static.  ``cost_min`` / ``inverse_sigmoid_smoothing``: the two
+    fp32 scalars of the adaptive-smoothing offset (dd:2992-2998) or None.  ``cost_in``: per-image [N, T_b] cost matrices
+    to solve instead (tests).  Returns (pred_idx, tgt_idx, match_cost) flat device tensors + the per-image counts
+    [+ cost blocks] [+ status]: entries of image b are sorted by query index, i.e. scipy's output order."""
+    lib = _lib.lib()
+    if cost_in is not None:
+        B = len(cost_in)
+        N = cost_in[0].shape[0]
+        dev = cost_in[0].device
+        sizes = [int(c.shape[1]) for c in cost_in]
+        cin = torch.cat([_chk(c.contiguous(), "cost_in", torch.float32).reshape(-1) for c in cost_in]) \
+            if sum(sizes) else torch.zeros(1, device=dev)
+        K = 0
+        lg = bx = ti = tb = None
+    else:
+        B, N, K = logits.shape
+        dev = logits.device
+        sizes = [int(t["boxes"].shape[0]) for t in targets]
+        lg = _chk(logits.detach().contiguous(), "logits", torch.float32)
+        bx = _chk(pred_boxes.detach().contiguous(), "pred_boxes", torch.float32)
+        ti = torch.cat([t["class_labels"] for t in targets]).to(device=dev, dtype=torch.int64).contiguous()
+        tb = torch.cat([t["boxes"] for t in targets]).to(device=dev, dtype=torch.float32).contiguous()
+        cin = None
+    n_out = [min(N, t) for t in sizes]
+    offs = [0]
+    for t in sizes:
+        offs.append(offs[-1] + t)
+    ooffs = [0]
+    for t in n_out:
+        ooffs.append(ooffs[-1] + t)
+    meta = torch.tensor(offs + ooffs, dtype=torch.int32).to(dev, non_blocking=True)   # two small host -> device copies
+    tot = max(ooffs[-1], 1)
+    pred_idx = torch.empty(tot, dtype=torch.int64, device=dev)
+    tgt_idx = torch.empty(tot, dtype=torch.int64, device=dev)
+    mcost = torch.empty(tot, dtype=torch.float32, device=dev)
+    cost_out = torch.empty(max(N * offs[-1], 1), dtype=torch.float32, device=dev) if want_cost else None
+    status = torch.zeros(B, dtype=torch.int32, device=dev) if want_status else None
+    smooth = 1 if cost_min is not None else 0
+    n_scr = lib.egtr_hungarian_match_scratch_doubles(N, max(sizes) if sizes else 0, offs[-1])
+    scratch = torch.empty(n_scr, dtype=torch.float64, device=dev) if n_scr > 0 else None
+    st = lib.egtr_hungarian_match_f32(
+        _stream(), lg.data_ptr() if lg is not None else None, bx.data_ptr() if bx is not None else None,
+        ti.data_ptr() if ti is not None and ti.numel() else None, tb.data_ptr() if tb is not None and tb.numel() else None,
+        meta.data_ptr(), meta.data_ptr() + 4 * (B + 1), B, N, K, max(sizes) if sizes else 0, float(class_cost),
+        float(bbox_cost), float(giou_cost), smooth, float(cost_min) if smooth else 0.0,
+        float(inverse_sigmoid_smoothing) if smooth else 0.0, pred_idx.data_ptr(), tgt_idx.data_ptr(), mcost.data_ptr(),
+        cost_out.data_ptr() if want_cost else None, cin.data_ptr() if cin is not None else None,
+        status.data_ptr() if want_status else None,
+        scratch.data_ptr() if scratch is not None else None) if max(sizes, default=0) > 0 else 0
+    _lib.check(st, "egtr_hungarian_match_f32")
+    out = [pred_idx[:ooffs[-1]], tgt_idx[:ooffs[-1]], mcost[:ooffs[-1]], n_out]
+    if want_cost:
+        out.append([cost_out[N * offs[i]: N * offs[i + 1]].view(N, sizes[i]) for i in range(B)])
+    if want_status:
+        out.append(status)
+    return tuple(out)

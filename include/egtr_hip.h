@@ -240,6 +240,32 @@ int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* i
                         const float* inter_references, int batch, int num_levels, int num_query, int ref_dim, float eps,
                         float* boxes);
 
+/* Hungarian matcher on the device: DeformableDetrHungarianMatcher.forward (model/deformable_detr.py:2925-3015) -- the
+ * focal / L1 / GIoU cost matrix (:2949-2982), the adaptive-smoothing offset (:2989-2999) and
+ * scipy.optimize.linear_sum_assignment per image (:3001-3005) -- in one launch, one workgroup per image, without the
+ * reference's copy of the cost matrix to the host.
+ *   logits [batch, num_query, num_logits], boxes [batch, num_query, 4] (cx, cy, w, h);
+ *   tgt_ids int64 / tgt_boxes [sum T_b, 4]: the targets of all images concatenated, tgt_offsets int32 [batch + 1]
+ *   (device) their per-image ranges; out_offsets int32 [batch + 1] (device): image b owns output entries
+ *   [out_offsets[b], out_offsets[b] + min(num_query, T_b)); max_targets = max_b T_b (sizes the LDS request).
+ *   cost = bbox_cost * L1 + class_cost * focal + giou_cost * (-GIoU); with smoothing != 0 additionally
+ *   (cost - cost_min) + inverse_sigmoid_smoothing, both fp32 scalars evaluated by the caller as at :2992-2998.
+ * Outputs: pred_idx / tgt_idx int64 and match_cost fp32 (the cost of each matched pair), sorted by query index within an
+ * image, exactly the index pairs scipy returns for that cost matrix (float64 solve, same tie rule).  Optional:
+ * cost_out fp32 [num_query * sum T_b] (image b's [num_query, T_b] block at num_query * tgt_offsets[b]); cost_in (same
+ * layout): solve GIVEN matrices instead of evaluating the cost (logits / boxes / tgt_* may then be null); status int32
+ * [batch]: 0 ok, 1 NaN / -inf in the matrix (scipy raises ValueError), 2 infeasible -- indices are -1 in those cases.
+ * The float64 matrix of an image (min(N, T_b) x max(N, T_b)) is held in LDS when it fits (~150 KB: T <= 90 at N = 200);
+ * otherwise in `scratch` (device, egtr_hungarian_match_scratch_doubles(...) doubles, 0 = not needed).
+ * Limit: max(num_query, T_b) <= 1024. */
+int egtr_hungarian_match_f32(egtr_stream_t stream, const float* logits, const float* boxes, const int64_t* tgt_ids,
+                             const float* tgt_boxes, const int* tgt_offsets, const int* out_offsets, int batch,
+                             int num_query, int num_logits, int max_targets, float class_cost, float bbox_cost,
+                             float giou_cost, int smoothing, float cost_min, float inverse_sigmoid_smoothing,
+                             int64_t* pred_idx, int64_t* tgt_idx, float* match_cost, float* cost_out,
+                             const float* cost_in, int* status, double* scratch);
+long long egtr_hungarian_match_scratch_doubles(int num_query, int max_targets, long long total_targets);
+
 /* IoU matrix of the reference's native evaluator routine, lib/fpn/box_intersections_cpu/bbox.pyx: mode 0 =
  * bbox_overlaps (:21-61), mode 1 = bbox_intersections (:64-108).  boxes [num_boxes, 4], query_boxes [num_query, 4]
  * (x0, y0, x1, y1), float64 like the reference (DTYPE = np.float), "+1 pixel" convention; out [num_boxes, num_query],

@@ -1154,3 +1154,102 @@ def test_msda_fused_bf16_matches_fp32_composition(shapes, B, Lq):
         assert got.dtype == bf
         assert (got.cpu().float() - want).abs().max() < 2e-2 * max(1.0, float(want.abs().max()))
 
+
+
+# ------------------------------------------------------------------------------------------------ matcher
+def test_device_assignment_equals_scipy_on_random_and_tied_matrices():
+    """egtr_hungarian_match_f32 in solve-only mode against scipy.optimize.linear_sum_assignment, index for index, on
+    1000+ cost matrices: continuous, integer-valued with many exact ties, constant, T from 1 to beyond N (wide problems
+    are not transposed), batches of ragged sizes."""
+    from scipy.optimize import linear_sum_assignment as sp
+    from egtr_amd.ops import hungarian_match
+    rng = np.random.default_rng(5)
+    n_checked = 0
+    for N in (200, 37, 300):
+        for rep in range(14):
+            B = 24
+            sizes = [int(rng.integers(1, 63)) for _ in range(B)]
+            if rep == 0:
+                sizes[:4] = [1, N, N + 3, min(N + 40, 330)]
+            mats = []
+            for i, T in enumerate(sizes):
+                kind = (rep + i) % 5
+                c = rng.standard_normal((N, T)).astype(np.float32)
+                if kind == 1:
+                    c = np.round(c)                                  # integer costs: exact ties everywhere
+                elif kind == 2:
+                    c = rng.integers(0, 2, (N, T)).astype(np.float32)
+                elif kind == 3:
+                    c = np.full((N, T), 0.25, dtype=np.float32)      # constant (scipy issue 11602 ordering)
+                elif kind == 4:
+                    c = np.round(c * 4) / 4
+                mats.append(c)
+            pi, ti, mc, n_out, status = hungarian_match(None, None, None, 1, 1, 1,
+                                                        cost_in=[torch.from_numpy(m).to(DEV) for m in mats],
+                                                        want_status=True)
+            pi, ti, mc = pi.cpu().numpy(), ti.cpu().numpy(), mc.cpu().numpy()
+            assert status.cpu().abs().sum() == 0
+            o = 0
+            for m, n in zip(mats, n_out):
+                a, b = sp(m)
+                assert n == len(a)
+                assert np.array_equal(pi[o:o + n], a) and np.array_equal(ti[o:o + n], b), (N, rep, m.shape)
+                assert np.array_equal(mc[o:o + n], m[a, b])
+                o += n
+                n_checked += 1
+    assert n_checked >= 1000
+    # invalid entries: scipy raises, the kernel flags the image and returns -1 indices
+    bad = np.zeros((8, 3), dtype=np.float32)
+    bad[2, 1] = np.nan
+    pi, ti, mc, n_out, status = hungarian_match(None, None, None, 1, 1, 1, cost_in=[torch.from_numpy(bad).to(DEV)],
+                                                want_status=True)
+    assert int(status[0]) == 1 and (pi.cpu() == -1).all()
+
+
+def test_device_matcher_cost_matrix_and_indices_vs_reference_composition(golden_dir):
+    """The fused cost + assignment launch against (a) the reference's tensor composition of the cost matrix evaluated by
+    PyTorch on the same device and on the CPU (1e-5; the kernel follows the reference's fp32 operation order), (b) scipy on
+    that matrix (indices identical), for VG-sized heads, ragged target counts, with and without the smoothing offset."""
+    from scipy.optimize import linear_sum_assignment as sp
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher
+    from egtr_amd.ops import hungarian_match
+    g = torch.Generator().manual_seed(3)
+    B, N, K = 5, 200, 151
+    logits = torch.randn(B, N, K, generator=g) * 3
+    cxcy = torch.rand(B, N, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(B, N, 2, generator=g) * 0.3 + 0.02
+    boxes = torch.cat([cxcy, wh], -1)
+    targets = []
+    for T in (30, 1, 17, 62, 5):
+        targets.append({"class_labels": torch.randint(0, K - 1, (T,), generator=g),
+                        "boxes": torch.cat([torch.rand(T, 2, generator=g) * 0.6 + 0.2,
+                                            torch.rand(T, 2, generator=g) * 0.3 + 0.02], -1)})
+    targets[2]["boxes"][:3] = boxes[2, :3]            # exact box matches (zero L1, GIoU = 1)
+    for smoothing in (0.0, 1e-14):
+        m = DeformableDetrHungarianMatcher(class_cost=2.0, bbox_cost=5.0, giou_cost=2.0, smoothing=smoothing)
+        # reference composition on the CPU (the reference's own path) -> cost blocks + scipy indices
+        kind, cm, sizes, _ = m.prepare({"logits": logits, "pred_boxes": boxes}, targets)
+        assert kind == "host"
+        idx_ref, cost_ref = m.finish((kind, cm, sizes, torch.device("cpu")))
+        if smoothing:
+            cmn, iss = m._smoothing_scalars()
+            cm = cm - cmn + iss
+        dt = [{k: v.to(DEV) for k, v in t.items()} for t in targets]
+        cmn, iss = (m._smoothing_scalars() if smoothing else (None, None))
+        pi, ti, mc, n_out, blocks = hungarian_match(logits.to(DEV), boxes.to(DEV), dt, 2.0, 5.0, 2.0,
+                                                    float(cmn) if smoothing else None, float(iss) if smoothing else None,
+                                                    want_cost=True)
+        o = 0
+        for i, (blk, n) in enumerate(zip(blocks, n_out)):
+            want = cm[i].split(sizes, -1)[i]
+            assert (blk.cpu() - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max())), (i, smoothing)
+            a, b = sp(blk.cpu().numpy())               # scipy on the DEVICE's matrix: identical indices
+            assert np.array_equal(pi[o:o + n].cpu().numpy(), a) and np.array_equal(ti[o:o + n].cpu().numpy(), b)
+            # and the reference's own result (CPU composition + scipy): identical unless a near-tie flips
+            assert np.array_equal(a, idx_ref[i][0].numpy()) and np.array_equal(b, idx_ref[i][1].numpy()), i
+            assert (mc[o:o + n].cpu() - cost_ref[i]).abs().max() < 2e-5 * max(1.0, float(cost_ref[i].abs().max()))
+            o += n
+        # the module path on device tensors returns the same thing as device tensors
+        idx_dev, cost_dev = m({"logits": logits.to(DEV), "pred_boxes": boxes.to(DEV)}, dt)
+        for (a, b), (ra, rb) in zip(idx_dev, idx_ref):
+            assert a.is_cuda and np.array_equal(a.cpu().numpy(), ra.numpy()) and np.array_equal(b.cpu().numpy(), rb.numpy())

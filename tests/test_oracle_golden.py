@@ -269,3 +269,39 @@ def test_oracle_ref_bbox_module_when_built(golden_dir):
     for name, (a, b) in W.bbox_cases(int(g["bbox_seed"])).items():
         assert np.array_equal(m.bbox_overlaps(a, b), g[f"iou_{name}"])
         assert np.array_equal(m.bbox_intersections(a, b), g[f"inter_{name}"])
+
+
+def test_lsa_restatement_equals_scipy(golden_dir):
+    """oracle/lsa.py (the restated algorithm of scipy.optimize.linear_sum_assignment, the third-party solver behind the
+    reference's matcher, scipy 1.15.3 here) against scipy itself, index for index: random, tie-heavy integer, constant,
+    wide / tall / square / empty matrices, and the matcher's own cost matrix shapes."""
+    from scipy.optimize import linear_sum_assignment as sp
+    from oracle.lsa import linear_sum_assignment as mine
+    rng = np.random.default_rng(0)
+    for trial in range(1500):
+        kind = trial % 6
+        nr, nc = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if kind == 0:
+            c = rng.standard_normal((nr, nc))
+        elif kind == 1:
+            c = rng.integers(0, 3, (nr, nc)).astype(float)
+        elif kind == 2:
+            c = np.full((nr, nc), 1.5)
+        elif kind == 3:
+            c = rng.integers(0, 2, (nr, nc)).astype(float)
+        elif kind == 4:
+            c = rng.standard_normal((nr, nc)).astype(np.float32).astype(float)
+        else:
+            c = np.round(rng.standard_normal((nr, nc)) * 2) / 2
+        a, b = sp(c)
+        a2, b2 = mine(c)
+        assert np.array_equal(a, a2) and np.array_equal(b, b2), (trial, kind, nr, nc)
+    for T in (1, 5, 30, 62, 200, 230):
+        c = rng.standard_normal((200, T)).astype(np.float32)
+        for cc in (c, np.round(c)):
+            a, b = sp(cc)
+            a2, b2 = mine(cc)
+            assert np.array_equal(a, a2) and np.array_equal(b, b2), T
+    assert mine(np.zeros((0, 5)))[0].size == 0
+    with pytest.raises(ValueError):
+        mine(np.array([[np.nan, 1.0]]))
