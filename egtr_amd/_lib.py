@@ -52,13 +52,16 @@ SIGNATURES = {
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],
     "egtr_hungarian_match_scratch_doubles": [_I, _I, ctypes.c_longlong],
+    "egtr_relation_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I, _I, _P, _P, _P, _P],
+    "egtr_relation_loss_workspace_bytes": [_I, _I],
     "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_rel_head_forward_bf16w": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_rel_head_forward_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
     "egtr_rel_head_backward_pairs_f32": [_P] * 6 + [_I] * 4 + [_P] * 5,
 }
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p,
-             "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong}
+             "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong,
+             "egtr_relation_loss_workspace_bytes": ctypes.c_longlong}
 
 _lib = None
 

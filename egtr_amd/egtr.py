@@ -436,6 +436,16 @@ class SceneGraphGenerationLoss(nn.Module):
     def loss_relations(self, outputs, targets, indices, matching_costs, num_boxes):
         """egtr:754-815.  Index tensors are moved to the logits' device once per image (the reference indexes
         device tensors with CPU index tensors, egtr:761-785; same values)."""
+        if (self.model_training and outputs["pred_rel"].is_cuda and outputs["pred_rel"].dtype == torch.float32
+                and self.rel_sample_negatives is not None and self.rel_sample_nonmatching is not None
+                and self.rel_sample_negatives_largest and self.rel_sample_nonmatching_largest
+                and not self.force_device_relations
+                and all(t["rel"].is_cuda and t["rel"].dtype == torch.float32 for t in targets)):
+            # the training configuration (train_egtr.py:514-527): value and gradient in one HIP pass, no host sync
+            loss_rel, loss_conn = ops.relation_losses(
+                outputs["pred_rel"], outputs["pred_connectivity"], targets, indices, matching_costs,
+                float(self.nonmatching_cost), self.rel_sample_negatives, self.rel_sample_nonmatching)
+            return {"loss_rel": loss_rel, "loss_connectivity": loss_conn}
         if (self.model_training and (outputs["pred_rel"].is_cuda or self.force_device_relations)
                 and (self.rel_sample_negatives is not None or self.rel_sample_nonmatching is not None)
                 and (self.rel_sample_negatives is None or self.rel_sample_negatives_largest)

@@ -689,3 +689,60 @@ def hungarian_match(logits, pred_boxes, targets, class_cost, bbox_cost, giou_cos
     if want_status:
         out.append(status)
     return tuple(out)
+
+
+class RelationLossFunction(Function):
+    """loss_rel / loss_connectivity of the SGG criterion (training mode, largest-score sampling) with their gradients
+    from one pass over the logits (csrc/loss.hip, egtr_relation_loss_f32); backward only scales the stored gradients."""
+
+    @staticmethod
+    def forward(ctx, pred_rel, pred_conn, target_ptrs, pred_idx, tgt_idx, match_cost, out_off, nonmatching_cost,
+                sample_negatives, sample_nonmatching):
+        lib = _lib.lib()
+        B, N, _, R = pred_rel.shape
+        pr = _chk(pred_rel.detach().contiguous(), "pred_rel", torch.float32)
+        pc = _chk(pred_conn.detach().contiguous(), "pred_connectivity", torch.float32)
+        dev = pr.device
+        loss = torch.empty(2, dtype=torch.float32, device=dev)
+        grad_rel = torch.empty_like(pr)
+        grad_conn = torch.empty_like(pc)
+        ws = torch.empty(int(lib.egtr_relation_loss_workspace_bytes(B, N)), dtype=torch.uint8, device=dev)
+        st = lib.egtr_relation_loss_f32(_stream(), pr.data_ptr(), pc.data_ptr(), target_ptrs.data_ptr(),
+                                        pred_idx.data_ptr(), tgt_idx.data_ptr(), match_cost.data_ptr(),
+                                        out_off.data_ptr(), B, N, R, float(nonmatching_cost), int(sample_negatives),
+                                        int(sample_nonmatching), loss.data_ptr(), grad_rel.data_ptr(),
+                                        grad_conn.data_ptr(), ws.data_ptr())
+        _lib.check(st, "egtr_relation_loss_f32")
+        ctx.save_for_backward(grad_rel, grad_conn)
+        return loss[0], loss[1]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_rel, g_conn):
+        grad_rel, grad_conn = ctx.saved_tensors
+        return grad_rel * g_rel, grad_conn * g_conn, None, None, None, None, None, None, None, None
+
+
+def relation_losses(pred_rel, pred_conn, targets, indices, matching_costs, nonmatching_cost, sample_negatives,
+                    sample_nonmatching):
+    """(loss_rel, loss_connectivity) for device tensors: see RelationLossFunction.  ``indices`` / ``matching_costs``: the
+    matcher's per-image device tensors; ``targets[b]["rel"]``: dense fp32 [N, N, R] on the device."""
+    dev = pred_rel.device
+    rels = [_chk(t["rel"] if t["rel"].is_contiguous() else t["rel"].contiguous(), "target rel", torch.float32)
+            for t in targets]
+    ptrs = torch.tensor([r.data_ptr() for r in rels], dtype=torch.int64).to(dev, non_blocking=True)
+    offs = [0]
+    for src, _ in indices:
+        offs.append(offs[-1] + int(src.shape[0]))
+    out_off = torch.tensor(offs, dtype=torch.int32).to(dev, non_blocking=True)
+    pi = torch.cat([i[0] for i in indices]).to(device=dev, dtype=torch.int64)
+    ti = torch.cat([i[1] for i in indices]).to(device=dev, dtype=torch.int64)
+    mc = torch.cat(list(matching_costs)).to(device=dev, dtype=torch.float32)
+    if pi.numel() == 0:   # keep the kernels' pointers valid
+        pi = torch.zeros(1, dtype=torch.int64, device=dev)
+        ti = torch.zeros(1, dtype=torch.int64, device=dev)
+        mc = torch.zeros(1, dtype=torch.float32, device=dev)
+    out = RelationLossFunction.apply(pred_rel, pred_conn, ptrs, pi, ti, mc, out_off, nonmatching_cost,
+                                     sample_negatives, sample_nonmatching)
+    del rels   # (kept alive until the launches were enqueued; the caller's targets own the storage)
+    return out

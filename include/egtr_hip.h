@@ -266,6 +266,25 @@ int egtr_hungarian_match_f32(egtr_stream_t stream, const float* logits, const fl
                              const float* cost_in, int* status, double* scratch);
 long long egtr_hungarian_match_scratch_doubles(int num_query, int max_targets, long long total_targets);
 
+/* Relation + connectivity losses of SceneGraphGenerationLoss in training mode (model/egtr.py:754-923 with
+ * rel_sample_negatives / rel_sample_nonmatching set and *_largest = True), value AND gradient, without the reference's
+ * per-image nonzero() index lists, host-side counts and gathers:
+ *   loss_out[0] = loss_rel = mean over {true relations of the matched block} U {k1 highest-logit false candidates of the
+ *                 block} U {k2 highest-logit elements with an unmatched subject or object} of
+ *                 BCEWithLogits(pred_rel, target * w_a w_b),  w = 1 - sigmoid(matching cost), k = min(sample * n_true, #)
+ *   loss_out[1] = loss_connectivity = mean BCEWithLogits(pred_conn, any_r target != 0)  over [batch, N, N]
+ *   grad_rel [batch, N, N, R], grad_conn [batch, N, N] = d loss / d logits (dense, zeros where unselected).
+ * pred_idx / tgt_idx / match_cost / out_offsets: the packed outputs of egtr_hungarian_match_f32 (out_offsets int32
+ * [batch + 1], device); target_rel: DEVICE array of `batch` device pointers to the images' dense [N, N, R] targets;
+ * nonmatching_cost: the criterion's constant (egtr:603-608).  workspace: egtr_relation_loss_workspace_bytes() bytes.
+ * Elements tied with the k-th largest logit are taken in arrival order (the reference's topk leaves that unspecified). */
+int egtr_relation_loss_f32(egtr_stream_t stream, const float* pred_rel, const float* pred_conn,
+                           const float* const* target_rel, const int64_t* pred_idx, const int64_t* tgt_idx,
+                           const float* match_cost, const int* out_offsets, int batch, int num_query, int num_rel,
+                           float nonmatching_cost, int sample_negatives, int sample_nonmatching, float* loss_out,
+                           float* grad_rel, float* grad_conn, void* workspace);
+long long egtr_relation_loss_workspace_bytes(int batch, int num_query);
+
 /* IoU matrix of the reference's native evaluator routine, lib/fpn/box_intersections_cpu/bbox.pyx: mode 0 =
  * bbox_overlaps (:21-61), mode 1 = bbox_intersections (:64-108).  boxes [num_boxes, 4], query_boxes [num_query, 4]
  * (x0, y0, x1, y1), float64 like the reference (DTYPE = np.float), "+1 pixel" convention; out [num_boxes, num_query],

@@ -1253,3 +1253,71 @@ def test_device_matcher_cost_matrix_and_indices_vs_reference_composition(golden_
         idx_dev, cost_dev = m({"logits": logits.to(DEV), "pred_boxes": boxes.to(DEV)}, dt)
         for (a, b), (ra, rb) in zip(idx_dev, idx_ref):
             assert a.is_cuda and np.array_equal(a.cpu().numpy(), ra.numpy()) and np.array_equal(b.cpu().numpy(), rb.numpy())
+
+
+# ------------------------------------------------------------------------------------------- relation loss
+def _criterion(N, R, smoothing=1e-14):
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher
+    from egtr_amd.egtr import SceneGraphGenerationLoss
+    m = DeformableDetrHungarianMatcher(class_cost=2.0, bbox_cost=5.0, giou_cost=2.0, smoothing=smoothing)
+    return SceneGraphGenerationLoss(
+        matcher=m, num_object_queries=N, num_classes=12, num_rel_labels=R, eos_coef=0.1,
+        losses=["relations"], smoothing=smoothing, rel_sample_negatives=80, rel_sample_nonmatching=80,
+        model_training=True, focal_alpha=0.25, rel_sample_negatives_largest=True, rel_sample_nonmatching_largest=True)
+
+
+@pytest.mark.parametrize("B,N,R,Ts,nrel", [
+    (3, 40, 7, (5, 12, 1), 3),        # small: k1 limited by the number of false candidates
+    (2, 200, 50, (30, 9), 3),         # VG-sized
+    (2, 64, 9, (6, 0), 2),            # an image without targets
+    (1, 200, 50, (17,), 0),           # no relation at all: the reference's mean of an empty tensor (NaN), zero gradients
+])
+def test_relation_loss_kernel_vs_reference_loop(B, N, R, Ts, nrel):
+    """egtr_relation_loss_f32 (value + gradient) against the line-by-line mirror of the reference's loss_relations /
+    _loss_relations (egtr:754-923: permutation, nonzero() index lists, topk over gathered scores, BCE) evaluated by
+    PyTorch on the CPU in float64."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(17 + N)
+    crit = _criterion(N, R)
+    pred_rel = (torch.randn(B, N, N, R, generator=g) * 2)
+    pred_conn = torch.randn(B, N, N, 1, generator=g)
+    targets, indices, costs = [], [], []
+    for T in Ts:
+        rel = torch.zeros(N, N, R)
+        if T > 0:
+            so = torch.randint(0, T, (nrel * T, 2), generator=g)
+            rr = torch.randint(0, R, (nrel * T,), generator=g)
+            keep = so[:, 0] != so[:, 1]
+            rel[so[keep, 0], so[keep, 1], rr[keep]] = 1.0
+        targets.append({"rel": rel})
+        src = torch.randperm(N, generator=g)[:T].sort()[0]
+        tgt = torch.randperm(T, generator=g)
+        indices.append((src, tgt))
+        costs.append(torch.randn(T, generator=g) * 3)
+    # reference mirror on the CPU, float64
+    pr64 = pred_rel.double().requires_grad_(True)
+    pc64 = pred_conn.double().requires_grad_(True)
+    crit.nonmatching_cost = crit.nonmatching_cost.double()
+    want = crit.loss_relations({"pred_rel": pr64, "pred_connectivity": pc64},
+                               [{"rel": t["rel"].double()} for t in targets], indices, [c.double() for c in costs], 1.0)
+    nan_case = bool(torch.isnan(want["loss_rel"]))
+    if not nan_case:
+        (want["loss_rel"] * 1.5 + want["loss_connectivity"] * 0.5).backward()
+    else:
+        (want["loss_connectivity"] * 0.5).backward()
+    # device kernel
+    prd = pred_rel.to(DEV).requires_grad_(True)
+    pcd = pred_conn.to(DEV).requires_grad_(True)
+    l_rel, l_conn = ops.relation_losses(prd, pcd, [{"rel": t["rel"].to(DEV)} for t in targets],
+                                        [(a.to(DEV), b_.to(DEV)) for a, b_ in indices], [c.to(DEV) for c in costs],
+                                        float(crit.nonmatching_cost), 80, 80)
+    assert abs(float(l_conn) - float(want["loss_connectivity"])) < 1e-5 * max(1.0, abs(float(want["loss_connectivity"])))
+    if nan_case:
+        assert bool(torch.isnan(l_rel))
+        (l_conn * 0.5).backward()
+        assert prd.grad is None or float(prd.grad.abs().max()) == 0.0
+    else:
+        assert abs(float(l_rel) - float(want["loss_rel"])) < 1e-5 * max(1.0, abs(float(want["loss_rel"])))
+        (l_rel * 1.5 + l_conn * 0.5).backward()
+        assert (prd.grad.cpu().double() - pr64.grad).abs().max() < 1e-7
+    assert (pcd.grad.cpu().double() - pc64.grad).abs().max() < 1e-7
