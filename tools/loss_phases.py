@@ -38,7 +38,8 @@ def main():
         times[name] = times.get(name, 0.0) + time.perf_counter() - t0
         return r
 
-    def fwd(self, outputs, targets):
+    def fwd(self, outputs, targets, matched=None):
+        # (``matched``, the matcher result enqueued before the relation head, is ignored: the matcher is timed here)
         outputs_without_aux = {k: v for k, v in outputs.items() if k not in ("auxiliary_outputs", "enc_outputs")}
         indices, matching_costs = timed("matcher(main)", self.matcher, outputs_without_aux, targets)
         num_boxes = float(max(sum(len(t["class_labels"]) for t in targets), 1))
