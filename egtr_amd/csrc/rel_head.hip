@@ -9,7 +9,11 @@
 //   W1 . sum_t g src = sum_t g[i,j,t] (uq[i,t,:] + uk[j,t,:])   with uq = W1[:, :d] q^, uk = W1[:, d:] k^
 // so the N^2 x (Ld+1) x 2d tensor never exists: live inputs are O(N (Ld+1) d), outputs O(N^2 R).
 //
-// Kernel shape: one wavefront owns 32 consecutive (i,j) pairs of ONE of the two MLPs (blockIdx.y).
+// Kernel shape: a workgroup of TWO wavefronts owns a tile of 32 pairs -- 8 subjects i x 4 objects j -- of ONE of the two
+// MLPs (blockIdx.y): layer 1 then needs only 8 + 4 per-query row sets instead of the 1 + 32 of 32 consecutive pairs.
+// The two waves split layer 1 by subjects (4 each) and layers 2 / 3 by the hidden-2 dimension (n tiles 0-3 / 4-7), the
+// partial layer-3 sums meet in LDS: 5000 half-size work units on 1024 SIMDs (4.9 rounds of 5) instead of 2500 whole
+// ones (2.4 rounds of 3).
 //   layer 1 (VALU): lane (pair = l&31, half = l>>5) builds the 128 hidden-1 channels {128*half + s} of its pair
 //                   directly in the register layout the MFMA wants -- no LDS round trip.
 //   layer 2 (MFMA, v_mfma_f32_32x32x2_f32, exact f32): computed transposed, h2^T = W2 h1^T, so D[row = n][col =
@@ -87,8 +91,10 @@ struct PrefetchRow {
 };
 
 // T = number of slots (decoder layers + 1), OT = number of 32-wide relation-output tiles (R <= 32*OT).
+constexpr int kRhWaves = 2;
+
 template <int T, int OT>
-__global__ __launch_bounds__(64) void rel_head_fwd_f32(
+__global__ __launch_bounds__(64 * kRhWaves) void rel_head_fwd_f32(
     const float* __restrict__ gate_q, const float* __restrict__ gate_k, const float* __restrict__ uq,
     const float* __restrict__ uk, const float* __restrict__ b1, const float* __restrict__ w2r,
     const float* __restrict__ b2r, const float* __restrict__ w3r, const float* __restrict__ b3r,
@@ -99,21 +105,26 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
   // h1_save / h2_save (training only, may be null): post-ReLU hidden activations of both layers, [2 (mlp)][B*N*N][256],
   // so that the backward needs no recomputation (egtr_rel_head_backward_pairs_f32 + rocBLAS GEMMs, egtr_amd/ops.py)
   // one buffer, two lives: the layer-1 transpose (read back into registers before layer 2), then the output tile
-  constexpr int kBuf = 16 * kH1Stride > 32 * (32 * OT + 1) ? 16 * kH1Stride : 32 * (32 * OT + 1);
+  constexpr int kBuf = 32 * kH1Stride > 32 * (32 * OT + 1) ? 32 * kH1Stride : 32 * (32 * OT + 1);
   __shared__ __attribute__((aligned(16))) float s_buf[kBuf];
   float* const s_out = s_buf;
   float* const s_h1 = s_buf;
   __shared__ int s_tb[32];
-  const int lane = threadIdx.x, pi = lane & 31, hf = lane >> 5;
+  __shared__ long long s_pp[32];
+  __shared__ float s_cacc[kRhWaves][32];
+  const int lane = threadIdx.x & 63, pi = lane & 31, hf = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave of the workgroup
   const int mlp = blockIdx.y;  // 0 = relation, 1 = connectivity (wave-uniform)
   const long long total = (long long)B * N * N;
-  const long long p0 = (long long)blockIdx.x * 32;
-  const long long p = p0 + pi;
-  const bool valid = p < total;
-  const long long pc = valid ? p : total - 1;
-  const int b = (int)(pc / ((long long)N * N));
-  const int rem = (int)(pc - (long long)b * N * N);
-  const int i = rem / N, j = rem - i * N;
+  // tile = (image, 8 subjects i0.., 4 objects j0..); pair pi of the tile = (i0 + (pi >> 2), j0 + (pi & 3))
+  const int tj = (N + 3) >> 2, ti = (N + 7) >> 3;
+  const int b = blockIdx.x / (ti * tj);
+  const int trem = blockIdx.x - b * ti * tj;
+  const int i0 = (trem / tj) * 8, j0 = (trem - (trem / tj) * tj) * 4;
+  const int i_raw = i0 + (pi >> 2), j_raw = j0 + (pi & 3);
+  const bool valid = i_raw < N && j_raw < N;
+  const int i = i_raw < N ? i_raw : N - 1, j = j_raw < N ? j_raw : N - 1;   // clamped: loads stay in range
+  const long long p = ((long long)b * N + i) * N + j;
   const size_t qi = (size_t)b * N + i, kj = (size_t)b * N + j;
 
   float g[T];
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
     const float x = gate_q[qi * T + t] + gate_k[kj * T + t];
     g[t] = 1.f / (1.f + expf(-x));
   }
-  if (gate_mean != nullptr && mlp == 0) {  // rel_gate_{t} logging (egtr.py:496-505)
+  if (gate_mean != nullptr && mlp == 0 && wv == 0) {  // rel_gate_{t} logging (egtr.py:496-505)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       float v = (valid && hf == 0) ? g[t] : 0.f;
@@ -141,86 +152,75 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
   // each used at once -- 45 % of the kernel's time went into waiting for those loads.)
   float h1[128];
   {
+    // The tile's 32 pairs share 8 uq row sets (one per subject) and 4 uk row sets (one per object): the 4 uk sets are
+    // loaded once up front (lane = channel quad: every row read is one contiguous 1 KiB per wave), the uq set of the
+    // next subject is in flight while the current subject's 4 pairs are accumulated.  The result goes through LDS
+    // (32 rows padded to 260 floats: conflict-free ds_read_b128) into the layout the MFMA wants: lane (pair, half)
+    // holds the 128 channels {128 half + s} of its pair.
     const int qrow_l = (int)qi, krow_l = (int)kj;
     const float4 bias4 = reinterpret_cast<const float4*>(b1 + mlp * kHd)[lane];
     const float4* uq4 = reinterpret_cast<const float4*>(uq) + mlp * (kHd / 4) + lane;
     const float4* uk4 = reinterpret_cast<const float4*>(uk) + mlp * (kHd / 4) + lane;
     constexpr int ROW4 = 2 * kHd / 4;  // float4 per (row, slot)
-    // uq rows change only when the pair index crosses into the next i (at most twice per 32 consecutive pairs): they
-    // are kept in registers and reloaded on change; the uk rows (a new j every pair) are double-buffered.
-    float4 ua[T];
-    f32x4v rc[2][T];
-    int q_cur = -1;
-    auto issue = [&](int set, int pp) {
-      const int kr = __builtin_amdgcn_readlane(krow_l, pp);
+    float4 kk[4][T];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int kr = __builtin_amdgcn_readlane(krow_l, jj);       // pair jj = (i0, j0 + jj)
       const float4* pk = uk4 + (size_t)kr * T * ROW4;
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        if (set == 0) rc[0][t] = gload_b128<0>(pk + t * ROW4);
-        else rc[1][t] = gload_b128<0>(pk + t * ROW4);
-      }
-    };
-    auto consume = [&](int set, int pp, int row, bool more) {
-      const int qr = __builtin_amdgcn_readlane(qrow_l, pp);
-      if (qr != q_cur) {  // wave-uniform
-        q_cur = qr;
-        const float4* pq = uq4 + (size_t)qr * T * ROW4;
-#pragma unroll
-        for (int t = 0; t < T; ++t) ua[t] = pq[t * ROW4];
-      }
-      float4 acc = bias4;
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        // own loads issued after this one: the rest of this set + (if any) the whole next set
-        if (set == 0) {
-          if (more) { vm_wait1<T + (T - 1)>(rc[0][t], t); } else { vm_wait1<T - 1>(rc[0][t], t); }
-        } else {
-          if (more) { vm_wait1<T + (T - 1)>(rc[1][t], t); } else { vm_wait1<T - 1>(rc[1][t], t); }
-        }
-        const float4 a = ua[t];
-        const f32x4v c = set ? rc[1][t] : rc[0][t];
-        const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[t]), pp));
-        acc.x += gt * (a.x + c.x);
-        acc.y += gt * (a.y + c.y);
-        acc.z += gt * (a.z + c.z);
-        acc.w += gt * (a.w + c.w);
-      }
-      const float4 hv = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
-      *reinterpret_cast<float4*>(&s_h1[row * kH1Stride + 4 * lane]) = hv;
-      if (h1_save != nullptr && p0 + pp < total)  // one contiguous 1 KiB row per wave
-        reinterpret_cast<float4*>(h1_save + ((size_t)mlp * total + (size_t)(p0 + pp)) * kHd)[lane] = hv;
-    };
-    // two rounds of 16 pairs: the transpose buffer is 16 rows (16.6 KB), which leaves room for 2 waves per SIMD, so
-    // that one wave's load-bound layer 1 overlaps another wave's MFMA-bound layers 2-3
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-      const int pbase = half * 16;
-      issue(0, pbase);
-#pragma unroll 1
-      for (int pp = 0; pp < 16; pp += 2) {
-        issue(1, pbase + pp + 1);
-        consume(0, pbase + pp, pp, true);
-        if (pp + 2 < 16) issue(0, pbase + pp + 2);
-        consume(1, pbase + pp + 1, pp + 1, pp + 2 < 16);
-      }
-      // LDS ops of one wave execute in order; the fences only stop the compiler from reordering across lanes
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if ((pi >> 4) == half) {
-        const float4* hp = reinterpret_cast<const float4*>(&s_h1[(pi & 15) * kH1Stride + hf * 128]);
-#pragma unroll
-        for (int s4 = 0; s4 < 32; ++s4) {
-          const float4 v = hp[s4];
-          h1[4 * s4 + 0] = v.x;
-          h1[4 * s4 + 1] = v.y;
-          h1[4 * s4 + 2] = v.z;
-          h1[4 * s4 + 3] = v.w;
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      for (int t = 0; t < T; ++t) kk[jj][t] = pk[t * ROW4];
     }
+    // subject row of tile slot ii, by wave-uniform arithmetic (clamped like the lanes' own rows)
+    auto qrow_of = [&](int ii) { return b * N + (i0 + ii < N ? i0 + ii : N - 1); };
+    const int ii0 = wv * (8 / kRhWaves);   // this wave's subjects
+    float4 ua[2][T];
+    {
+      const float4* pq = uq4 + (size_t)qrow_of(ii0) * T * ROW4;
+#pragma unroll
+      for (int t = 0; t < T; ++t) ua[0][t] = pq[t * ROW4];
+    }
+#pragma unroll
+    for (int iu = 0; iu < 8 / kRhWaves; ++iu) {
+      const int ii = ii0 + iu;
+      if (iu + 1 < 8 / kRhWaves) {
+        const float4* pq = uq4 + (size_t)qrow_of(ii + 1) * T * ROW4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) ua[(iu + 1) & 1][t] = pq[t * ROW4];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int pp = ii * 4 + jj;
+        float4 acc = bias4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float4 a = ua[iu & 1][t];
+          const float4 c = kk[jj][t];
+          const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[t]), pp));
+          acc.x += gt * (a.x + c.x);
+          acc.y += gt * (a.y + c.y);
+          acc.z += gt * (a.z + c.z);
+          acc.w += gt * (a.w + c.w);
+        }
+        const float4 hv = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+        *reinterpret_cast<float4*>(&s_h1[pp * kH1Stride + 4 * lane]) = hv;
+        if (h1_save != nullptr && i0 + ii < N && j0 + jj < N)  // one contiguous 1 KiB row per wave
+          reinterpret_cast<float4*>(h1_save + ((size_t)mlp * total +
+                                               (size_t)(((long long)b * N + i0 + ii) * N + j0 + jj)) * kHd)[lane] = hv;
+      }
+    }
+    __syncthreads();   // both waves' rows are in LDS
+    {
+      const float4* hp = reinterpret_cast<const float4*>(&s_h1[pi * kH1Stride + hf * 128]);
+#pragma unroll
+      for (int s4 = 0; s4 < 32; ++s4) {
+        const float4 v = hp[s4];
+        h1[4 * s4 + 0] = v.x;
+        h1[4 * s4 + 1] = v.y;
+        h1[4 * s4 + 2] = v.z;
+        h1[4 * s4 + 3] = v.w;
+      }
+    }
+    __syncthreads();   // the buffer is reused for the output tiles
   }
 
   const float* w2 = mlp ? w2c : w2r;
@@ -232,8 +232,9 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
     for (int r = 0; r < 16; ++r) racc[ot][r] = 0.f;
   float cacc = 0.f;
 
+  constexpr int kNtPerWave = kHd / 32 / kRhWaves;
 #pragma unroll 1
-  for (int nt = 0; nt < kHd / 32; ++nt) {
+  for (int nt = wv * kNtPerWave; nt < (wv + 1) * kNtPerWave; ++nt) {
     // ---- layer 2: h2^T[n][pair], n = 32 nt + (r&3) + 8 (r>>2) + 4 hf ---------------------------------------
     f32x16 acc;
 #pragma unroll
@@ -289,32 +290,47 @@ __global__ __launch_bounds__(64) void rel_head_fwd_f32(
 
   if (mlp == 1) {
     cacc += __shfl_xor(cacc, 32);
-    if (valid && hf == 0) conn_logits[p] = cacc + b3c[0];
+    if (hf == 0) s_cacc[wv][pi] = cacc;
+    __syncthreads();
+    if (wv == 0 && valid && hf == 0) {
+      float v = s_cacc[0][pi];
+#pragma unroll
+      for (int w = 1; w < kRhWaves; ++w) v += s_cacc[w][pi];
+      conn_logits[p] = v + b3c[0];
+    }
     return;
   }
-  // ---- relation epilogue: stage [pair][r_out] in LDS, add b3 + frequency bias, write one contiguous run -------
+  // ---- relation epilogue: each wave stages its partial [pair][r_out] tile in LDS; the sum + b3 + frequency bias goes out
+  // as one contiguous run of R floats per pair (4 R per subject) ---------------------------------------------------------
   constexpr int kStride = 32 * OT + 1;
+  static_assert(kRhWaves * 32 * kStride <= kBuf, "output tiles fit in the transpose buffer");
+  float* const my_out = s_out + wv * 32 * kStride;
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ro = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-      s_out[pi * kStride + ro] = racc[ot][r];
+      my_out[pi * kStride + ro] = racc[ot][r];
     }
-  if (hf == 0) {
+  if (wv == 0 && hf == 0) {
     int tb = -1;
     if (triplet != nullptr) tb = ((int)node_cls[qi] * C1 + (int)node_cls[kj]) * R;
     s_tb[pi] = tb;
+    s_pp[pi] = valid ? p : -1;
   }
   __syncthreads();
-  const int npair = (int)((total - p0) < 32 ? (total - p0) : 32);
-  float* dst = rel_logits + (size_t)p0 * R;
-  for (int pp = 0; pp < npair; ++pp) {
+  for (int pp = wv; pp < 32; pp += kRhWaves) {
+    const long long po = s_pp[pp];
+    if (po < 0) continue;   // wave-uniform: a slot beyond the N x N grid
     const int tb = s_tb[pp];
+    float* dst = rel_logits + (size_t)po * R;
     for (int r = lane; r < R; r += 64) {
-      float v = s_out[pp * kStride + r] + b3r[r];
+      float v = s_out[pp * kStride + r];
+#pragma unroll
+      for (int w = 1; w < kRhWaves; ++w) v += s_out[(w * 32 + pp) * kStride + r];
+      v += b3r[r];
       if (tb >= 0) v += triplet[tb + r];
-      dst[(size_t)pp * R + r] = v;
+      dst[r] = v;
     }
   }
 }
@@ -568,11 +584,11 @@ int launch_T(hipStream_t st, int R, dim3 grid, const float* gate_q, const float*
              const float* triplet, const int64_t* node_cls, int B, int N, int C1, float* rel, float* conn,
              float* gate_mean, float* h1_save, float* h2_save) {
   if (R <= 32)
-    hipLaunchKernelGGL((rel_head_fwd_f32<T, 1>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
+    hipLaunchKernelGGL((rel_head_fwd_f32<T, 1>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
                        b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean, h1_save,
                        h2_save);
   else
-    hipLaunchKernelGGL((rel_head_fwd_f32<T, 2>), grid, dim3(64), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
+    hipLaunchKernelGGL((rel_head_fwd_f32<T, 2>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r,
                        b3r, w2c, b2c, w3c, b3c, triplet, node_cls, B, N, R, C1, rel, conn, gate_mean, h1_save,
                        h2_save);
   return 0;
@@ -739,8 +755,10 @@ extern "C" int egtr_rel_head_forward_save_f32(egtr_stream_t stream, const float*
   if (batch <= 0 || num_query <= 0 || num_slots <= 0 || num_rel <= 0) return EGTR_E_ARG;
   if (hidden != kHd || num_rel > 64 || num_slots > 10) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const long long total = (long long)batch * num_query * num_query;
-  const dim3 grid((unsigned)((total + 31) / 32), 2);
+  // one wave per (image, 8 x 4 pair tile, MLP)
+  const long long tiles = (long long)batch * ((num_query + 7) / 8) * ((num_query + 3) / 4);
+  if (tiles >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  const dim3 grid((unsigned)tiles, 2);
 #define EGTR_T(TT)                                                                                                  \
   case TT:                                                                                                          \
     launch_T<TT>(st, num_rel, grid, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,             \
