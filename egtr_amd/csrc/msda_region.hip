@@ -2,33 +2,35 @@
 // pixels of the feature levels).
 //
 // Why: the wave-per-query kernel (msda.hip) is bound by the vector L1 / texture addresser -- every 16-byte-per-lane
-// gather instruction costs ~16-19 CU cycles whatever it fetches (tools/l1_mask.hip: masking lanes or repeating a line
+// gather instruction costs ~17-19 CU cycles whatever it fetches (tools/l1_mask.hip: masking lanes or repeating a line
 // inside an instruction saves nothing), and it needs 64 of them per (query, head): 822 MB through a 64 B/clk/CU pipe
-// = 27 us per encoder launch at best.  The LDS serves the same 16 B per lane in 4 cycles.  Earlier LDS designs (8x8
-// query tiles with bounding-box windows) lost the gain to per-tile bookkeeping: small tiles re-stage their halo, and the
-// loc -> bounding box -> copy -> gather dependency chain is paid per tile.
+// = 27 us per encoder launch at best.  The LDS serves the same 16 B per lane in 4 cycles, but the earlier LDS designs
+// (8x8 query tiles with bounding-box windows; lane = (query, channel quad) with per-sample records in LDS) turned out
+// to be bound by INSTRUCTION ISSUE (~5 cycles per instruction per SIMD at 2-4 waves per SIMD): records, cross-lane
+// traffic, per-tile bookkeeping and re-staged halos cost more instructions than the gather itself.
 //
-// This kernel makes the work item as LARGE as the LDS allows and its window STATIC:
+// This kernel minimises instructions per (query, head) unit:
 //   * item = (image, region, head).  The image plane is cut into RY x RX regions in normalised coordinates; a region
 //     owns the queries of ALL four levels whose pixel lies in it (~196 queries at 600x1000 with 8x8 regions).
 //   * per source level the item needs the pixels under its region plus a fixed halo (kHalo px of THAT level: sampling
 //     offsets are expressed in pixels of the sampled level, deformable_detr.py:1067-1073).  The window depends on the
-//     region only, so its copy starts at once -- nothing waits for sampling locations.  Out-of-level window pixels and
-//     padded tokens are stored as zeros (== cuh:55-78 per-corner range checks, dd:1052 masked_fill), so staged samples
-//     need no per-corner masks.
-//   * the four source levels are processed one after the other through ONE window buffer (<= 70 KB: two workgroups per
-//     CU); accumulators stay in registers across the passes, sample order 0..15 as in the reference.
-//   * gather: lane = (query, channel quad) -- 8 queries per wave step -- one 16-byte record pair per sample in LDS
-//     (4 premultiplied bilinear x attention weights, 2 window pixel indices), 4 ds_read_b128 + 8 packed FMAs per sample.
-//   * samples that fall outside their window (large offsets) are gathered from global memory by the lanes concerned,
-//     per sample, so results never depend on the halo; and a region whose sampled outlier rate is high (irregular
-//     offsets: a trained model's far-reaching heads) switches, as a whole and consistently across its 8 heads'
-//     workgroups, to the wave-per-query scheme (8 heads per wave, L1 gathers) -- "window where it fits, L1 where it
-//     does not" inside one launch.
+//     region only, so its copy starts at once.  Out-of-level window pixels and padded tokens are stored as zeros
+//     (== cuh:55-78 per-corner range checks, dd:1052 masked_fill), so staged samples need no per-corner masks.
+//   * the four source levels pass one after the other through ONE window buffer (68 KB: two workgroups per CU);
+//   * LANE = one (query, head) unit with all 32 channels: the lane computes the geometry of its own samples (no
+//     redundancy, no records, no cross-lane traffic), and gathers each bilinear corner with 8 ds_read_b128 whose
+//     channel-quad plane is an instruction-offset immediate -- the window is stored as 8 planes [quad][pixel] of 16-byte
+//     entries, so the 16 lanes of a hardware ds_read_b128 group (x-adjacent queries -> consecutive pixels) hit 16
+//     different 4-bank groups; accumulation in 32 registers with packed FMAs, sample order 0..15 as in the reference.
+//     ~42 instructions per unit against ~160 for the record-based form.
+//   * samples that fall outside their window are gathered from global memory by the lanes concerned, so results never
+//     depend on the halo; and a region whose sampled outlier rate is high (irregular offsets) switches, as a whole and
+//     consistently across its 8 heads' workgroups, to the wave-per-query scheme (8 heads per wave, L1 gathers).
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 #include "msda_common.h"
@@ -42,19 +44,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) f32x4* lds_f4p;   // explicit address spaces: LDS and global reads of one
 typedef const __attribute__((address_space(1))) f32x4* glb_f4p;   // value must never be merged into flat loads
 
-constexpr int kRW = 8;                 // waves per workgroup
+constexpr int kRW = 4;                 // waves per workgroup: 256 lanes = up to 256 (query, head) units
 constexpr int kRT = kRW * 64;          // threads
-constexpr int kMaxSteps = 4;           // 8-query groups per wave -> at most 256 queries per region
-constexpr int kWinPx = 528;            // window pixels per level (x 128 B)
+constexpr int kWinPx = 576;            // window pixels per level: (10 + 11) x (16 + 11) = 567 at 600x1000 with 8 x 8 regions
 constexpr int kZero = 2;               // all-zero pixels in front of the window (target of invalid samples)
-constexpr int kHalo = 5;               // pixels of the sampled level around the region
-constexpr int kProbeQ = 32;            // queries sampled (x 8 heads x 16 samples) for the per-region mode decision
-constexpr int kFillIters = (kWinPx + 63) / 64;
+constexpr int kNP = kZero + kWinPx + 1;   // pixels per channel-quad plane; ODD: conflict-free plane-scattered ds_write_b128
+constexpr int kPlane = kNP * 16;       // bytes per plane
+constexpr int kHalo = 5;               // pixels of the sampled level around the region (levels 1..3)
+constexpr int kHalo0 = 4;              // level 0 (its window is the LDS-capacity limit: 546 px at 600x1000, 575 at 800x1333)
+constexpr int kProbeQ = 16;            // queries sampled (x 8 heads x 16 samples) for the per-region mode decision
+static_assert(kNP % 2 == 1 && 7 * kPlane + 16 < 65536, "plane offsets are ds_read immediates");
 // LDS carve-up in float4 units
-constexpr int kOffWin = 0;                                   // (kZero + kWinPx) * 8
-constexpr int kOffRecW = (kZero + kWinPx) * 8;               // [wave][group 2][query 8][sample 4] float4 weights
-constexpr int kOffRecA = kOffRecW + kRW * 64;                // [wave][group 2][query 8][sample 4] uint2 addresses
-constexpr int kOffMisc = kOffRecA + kRW * 32;                // 16: counters + the region's rectangles / windows
+constexpr int kOffWin = 0;                                   // 8 planes x kNP entries
+constexpr int kOffMisc = 8 * kNP;                            // 16: counters + the region's rectangles / windows
 constexpr int kLdsF4 = kOffMisc + 16;
 // s_misc (ints): [0] outliers, [1] valid samples of the probe, [4+l] queries of level l, [8+4l ..] query rectangle of
 // level l {y0, x0, h, w}, [24+5s ..] window of source level s {y0, x0, h, w, staged}
@@ -62,9 +64,21 @@ constexpr int kMiscN = 4, kMiscRect = 8, kMiscWin = 24;
 static_assert(kLdsF4 * 16 <= 81920, "two workgroups per CU");
 // wave-per-query fallback: per wave 2 x 136 records of 16 B, aliased onto the window
 constexpr int kHeadStride = 17, kWaveEntries = 8 * kHeadStride;
-static_assert(2 * kRW * kWaveEntries <= (kZero + kWinPx) * 8, "fallback records fit in the window buffer");
+static_assert(2 * kRW * kWaveEntries <= 8 * kNP, "fallback records fit in the window buffer");
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+#ifdef EGTR_REGION_PROF
+__device__ unsigned long long g_prof[32];
+#define PROF_T(slot)                                                          \
+  if (tid == 0) {                                                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();             \
+    atomicAdd(&g_prof[slot], now_ - tprev_);                                  \
+    tprev_ = now_;                                                            \
+  }
+#else
+#define PROF_T(slot)
+#endif
 
 struct Rect { int y0, x0, h, w; };     // query rectangle of one level inside the region
 struct Win { int y0, x0, h, w; bool staged; };   // window of one source level (level pixel coordinates)
@@ -111,10 +125,11 @@ __device__ __forceinline__ Win make_window(const int* misc, const LevelGeom& G, 
     }
   }
   Win w;
-  w.x0 = max((int)floorf(xlo) - kHalo, -1);
-  w.y0 = max((int)floorf(ylo) - kHalo, -1);
-  const int x1 = min((int)floorf(xhi) + kHalo + 1, SEL_W(G, s));
-  const int y1 = min((int)floorf(yhi) + kHalo + 1, SEL_H(G, s));
+  const int halo = s == 0 ? kHalo0 : kHalo;
+  w.x0 = max((int)floorf(xlo) - halo, -1);
+  w.y0 = max((int)floorf(ylo) - halo, -1);
+  const int x1 = min((int)floorf(xhi) + halo + 1, SEL_W(G, s));
+  const int y1 = min((int)floorf(yhi) + halo + 1, SEL_H(G, s));
   w.w = x1 - w.x0 + 1;
   w.h = y1 - w.y0 + 1;
   w.staged = grid && w.w > 0 && w.h > 0 && w.w * w.h <= kWinPx;
@@ -201,18 +216,21 @@ __device__ __forceinline__ void query_all_heads(const float* __restrict__ value,
   __builtin_amdgcn_wave_barrier();
 }
 
-// mode_force: 0 = adaptive (probe), 1 = always the window path (outliers per sample from global), 2 = always the
-// wave-per-query path (tests / A-B timing).
+// mode_force: 0 = adaptive (probe), 1 = always the window scheme (outliers per sample from global), 2 = always the
+// wave-per-query scheme (tests / A-B timing).
 template <bool FUSED>
-__global__ __launch_bounds__(kRT, 4) void msda_fwd_region_f32(
+__global__ __launch_bounds__(kRT, 2) void msda_fwd_region_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int B, int Lq, int S,
     const float* __restrict__ ref, float* __restrict__ attn_out, int ld_off, int ld_logit,
-    const unsigned* __restrict__ keep_bits, int RY, int RX, int nblk, int mode_force, int abl) {
+    const unsigned* __restrict__ keep_bits, int RY, int RX, int nblk, int mode_force) {
   __shared__ __attribute__((aligned(16))) float4 s_mem[kLdsF4];
-  const int tid = threadIdx.x, lane = tid & 63, c4 = lane & 7, col = lane >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = rfl(tid >> 6);
   const int item = rfl(xcd_remap(blockIdx.x, nblk));
+#ifdef EGTR_REGION_PROF
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
   const int R_ = RY * RX;
   const int b = rfl(item / (R_ * 8));
   const int rem = item - b * R_ * 8;
@@ -240,7 +258,8 @@ __global__ __launch_bounds__(kRT, 4) void msda_fwd_region_f32(
   const int nwords = (S + 31) >> 5;
   const bool masked = FUSED && keep_bits != nullptr;
   const unsigned* kb_g = masked ? keep_bits + (size_t)b * nwords : nullptr;
-  if (tid < 16) s_mem[kOffWin + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // the zero pixels
+  // the zero pixels (entries 0, 1 of every plane)
+  if (tid < 16) s_mem[(tid >> 1) * kNP + (tid & 1)] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
   if (tid < 4) {
     const Win w = make_window(s_misc, G, grid, tid);
@@ -256,68 +275,58 @@ __global__ __launch_bounds__(kRT, 4) void msda_fwd_region_f32(
   }
   __syncthreads();
 
-  const char* vhead = reinterpret_cast<const char*>(value) + (size_t)b * S * 1024 + head * 128 + c4 * 16;
-  float4* s_win = s_mem + kOffWin;
+  const char* vimg = reinterpret_cast<const char*>(value) + (size_t)b * S * 1024 + head * 128;
+  typedef const __attribute__((address_space(3))) char* lds_cp;
+  typedef const __attribute__((address_space(1))) char* glb_cp;
 
-  // Window copy of source level s by LDS-DMA: 64 pixels per workgroup iteration, wave w owns the contiguous 1 KiB piece
-  // [it * 512 + w * 64, +64) float4 of the window, lane = (pixel, channel quad).  Pixels outside the level and padded
-  // tokens are written as zeros by their lanes instead (cuh:55-78, dd:1052).  Nothing is waited for here.
-  auto issue_fill = [&](int s) {
+  // Window copy of source level s into the 8 channel-quad planes, in two halves so that the global loads of level s + 1
+  // are in flight while level s is gathered: fill_load issues up to NPC loads per lane (flat window pixel index
+  // pi = it * 32 + tid / 8, lane = (pixel, channel quad)), fill_store writes them to LDS after the barrier.  Pixels
+  // outside the level and padded tokens become zeros (cuh:55-78, dd:1052).
+  auto fill_load = [&](int s, float4* v, auto npc_tag) {
+    constexpr int NPC = decltype(npc_tag)::value;
     const Win w = lds_win(s_misc, s);
-    if (!w.staged || (abl & 1)) return;
     const int Hs = SEL_H(G, s), Ws = SEL_W(G, s), ss = SEL_S(G, s);
-    const int wy0 = rfl(w.y0), wx0 = rfl(w.x0), ww = rfl(w.w), wh = rfl(w.h);
-    if (!masked) {
-      // row-structured copy: wave w takes window rows w, w + 8, ...; one DMA instruction = 8 consecutive pixels of a row
-      // (lane = (pixel, channel quad)); everything but the lane's column offset is wave-uniform (scalar) arithmetic
-      const int pc = lane >> 3;
-      const int npc = (ww + 7) >> 3;
-      for (int r = wave; r < wh; r += kRW) {
-        const int y = wy0 + r;
-        const bool rowin = (unsigned)y < (unsigned)Hs;
-        const char* grow = vhead + (size_t)(ss + y * Ws + wx0) * 1024;   // pixel (y, wx0) of this head / quad
-        for (int pp = 0; pp < npc; ++pp) {
-          const int wxp = 8 * pp + pc;
-          const bool colin = wxp < ww;
-          const bool live = rowin && colin && (unsigned)(wx0 + wxp) < (unsigned)Ws;
-          const int widx = kZero + r * ww + 8 * pp;   // first window pixel of the piece
-          if (live) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + (size_t)wxp * 1024),
-                                             (__attribute__((address_space(3))) void*)(s_win + widx * 8), 16, 0, 0);
-          } else if (colin) {
-            s_win[(widx + pc) * 8 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-        }
-      }
-      return;
-    }
-    // padded image: per-pixel mask test (64 pixels per workgroup iteration, wave w owns piece it * 8 + w)
-    const int npx = ww * wh;
-    const float inv = __frcp_rn((float)ww);
-    for (int it = 0; it * 64 < npx; ++it) {
-      const int pi = it * 64 + (tid >> 3);
+    const int wy0 = rfl(w.y0), wx0 = rfl(w.x0), ww = rfl(w.w), npx = w.staged ? rfl(w.w * w.h) : 0;
+    const char* srcq = vimg + (tid & 7) * 16;
+    // window coordinates of this lane's first pixel, then +32 pixels per load with carries (no division per load)
+    int pi = tid >> 3;
+    int wy = (int)(((float)pi + 0.5f) * __frcp_rn((float)ww));   // exact for pi, ww < 4096
+    int wx = pi - wy * ww;
+    const int dy = (kRT / 8) / ww, dxr = (kRT / 8) - dy * ww;     // wave-uniform
+#pragma unroll
+    for (int it = 0; it < NPC; ++it) {
+      v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pi < npx) {
-        const int wy = (int)(((float)pi + 0.5f) * inv);
-        const int wx = pi - wy * ww;
         const int y = wy0 + wy, x = wx0 + wx;
         bool live = (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
         const int p = ss + y * Ws + x;
-        if (live) live = (kb_g[p >> 5] >> (p & 31)) & 1u;
-        if (live) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vhead + (size_t)p * 1024),
-                                           (__attribute__((address_space(3))) void*)(s_win + kZero * 8 + it * 512 + wave * 64),
-                                           16, 0, 0);
-        } else {
-          s_win[(kZero + pi) * 8 + c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        if (live && masked) live = (kb_g[p >> 5] >> (p & 31)) & 1u;
+        if (live) v[it] = *reinterpret_cast<const float4*>(srcq + (size_t)p * 1024);
       }
+      pi += kRT / 8;
+      wx += dxr;
+      wy += dy;
+      if (wx >= ww) { wx -= ww; wy += 1; }
     }
   };
+  auto fill_store = [&](int s, const float4* v, auto npc_tag) {
+    constexpr int NPC = decltype(npc_tag)::value;
+    const Win w = lds_win(s_misc, s);
+    const int npx = w.staged ? rfl(w.w * w.h) : 0;
+    float4* dstq = s_mem + (tid & 7) * kNP + kZero + (tid >> 3);
+#pragma unroll
+    for (int it = 0; it < NPC; ++it)
+      if (it * (kRT / 8) + (tid >> 3) < npx) dstq[it * (kRT / 8)] = v[it];
+  };
+  constexpr int kNpc0 = (kWinPx + kRT / 8 - 1) / (kRT / 8);   // level-0 window: up to kWinPx pixels (17 loads per lane)
+  constexpr int kNpcN = 12;                                     // prefetched windows of the coarser levels (<= 384 pixels)
+  typedef std::integral_constant<int, kNpc0> Npc0;
+  typedef std::integral_constant<int, kNpcN> NpcN;
 
   // ---- mode decision: the same sample of the region's queries (all 8 heads) in each of its 8 workgroups ----------------
-  bool window_mode = grid && nq <= kRW * 8 * kMaxSteps && nq > 0;
+  bool window_mode = grid && nq <= kRT && nq > 0;
   if (mode_force == 2) window_mode = false;
-  if (window_mode) issue_fill(0);   // in flight under the probe and the pre-pass
   if (window_mode && mode_force == 0) {
     const int k = tid >> 4, sub = tid & 15, ph = sub >> 1, half = sub & 1;
     const int pq = region_query(s_misc, G, grid, lin0, (k * nq) / kProbeQ);
@@ -360,238 +369,271 @@ __global__ __launch_bounds__(kRT, 4) void msda_fwd_region_f32(
 
   if (!window_mode) {
     // ---- wave-per-query scheme: this workgroup takes every 8th query of the region, all heads -------------------------
-    __syncthreads();   // a window copy may be in flight: its buffer is reused for this scheme's records
     int4* my_off = reinterpret_cast<int4*>(s_mem + kOffWin) + wave * kWaveEntries;
     float4* my_w = s_mem + kOffWin + kRW * kWaveEntries + wave * kWaveEntries;
-    const unsigned* kb = kb_g;
     for (int idx = head + 8 * wave; idx < nq; idx += 8 * kRW) {
       const int q = region_query(s_misc, G, grid, lin0, idx);
-      query_all_heads<FUSED>(value, loc, attn, out, ref, attn_out, ld_off, ld_logit, kb, G, b, q, Lq, S, lane, my_off,
+      query_all_heads<FUSED>(value, loc, attn, out, ref, attn_out, ld_off, ld_logit, kb_g, G, b, q, Lq, S, lane, my_off,
                              my_w);
     }
     return;
   }
 
-  // ---- window scheme --------------------------------------------------------------------------------------------------
-  // pre-pass, once per query group: lane (col, c4) owns samples 2c4, 2c4+1 (both of level c4 >> 1) of its query and keeps
-  // their finished records in registers: 4 bilinear x attention weights and one address code each --
-  //   window sample : (pixel index of (y0, x0) in the window) | (pixel index of (y0+1, x0)) << 16
-  //   invalid sample: 0 (the zero pixels; weights are 0)
-  //   outlier       : 0x80000000 | clamped top-left pixel << 2 | dx << 1 | dy  (gathered from global memory)
-  const int ngroups = (nq + 7) >> 3;
-  const int my_lvl = c4 >> 1;
-  float wq[kMaxSteps][2][4];
-  unsigned code[kMaxSteps][2];
-  int qv[kMaxSteps];
-  f32x2 acc0[kMaxSteps], acc1[kMaxSteps];
-  {
-    const int Hs = SEL_H(G, my_lvl), Ws = SEL_W(G, my_lvl), ss = SEL_S(G, my_lvl);
-    const float fw = (float)Ws, fh = (float)Hs;
-    const Win w = lds_win(s_misc, my_lvl);
-    float4 lcs[kMaxSteps];
-    float2 aws[kMaxSteps], rps[kMaxSteps];
+  PROF_T(0)   // prologue: geometry, tables, probe
+  // ---- window scheme: lane = (query, head) unit ----------------------------------------------------------------------
+  float4 w0v[kNpc0];
+  fill_load(0, w0v, Npc0());   // level 0's window loads are in flight with this unit's operand loads
+  const int idx = tid;
+  const bool live = idx < nq;
+  int q = 0;
+  float4 lcs[8];        // sampling locations / offsets of the 16 samples, (x, y) pairs in sample order
+  float aws[16];        // attention weights (softmaxed)
+  float2 rps[4];        // reference points per level (FUSED)
+  if (live) {
+    q = region_query(s_misc, G, grid, lin0, idx);
+    const size_t gq = (size_t)b * Lq + q;
+    const float4* pl = reinterpret_cast<const float4*>(loc + gq * (FUSED ? ld_off : 256) + head * 32);
+    const float4* pa = reinterpret_cast<const float4*>(attn + gq * (FUSED ? ld_logit : 128) + head * 16);
 #pragma unroll
-    for (int st = 0; st < kMaxSteps; ++st) {   // every group's loads first: one memory round trip
-      const int g = wave + st * kRW;
-      const int idx = g * 8 + col;
-      acc0[st] = (f32x2){0.f, 0.f};
-      acc1[st] = (f32x2){0.f, 0.f};
-      qv[st] = -1;
-      lcs[st] = make_float4(9.f, 9.f, 9.f, 9.f);   // far outside: invalid
-      aws[st] = make_float2(0.f, 0.f);
-      rps[st] = make_float2(0.f, 0.f);
-      if (g < ngroups && idx < nq && !(abl & 4)) {
-        const int q = region_query(s_misc, G, grid, lin0, idx);
-        qv[st] = q;
-        const size_t gq = (size_t)b * Lq + q;
-        lcs[st] = *reinterpret_cast<const float4*>(loc + gq * (FUSED ? ld_off : 256) + head * 32 + c4 * 4);
-        aws[st] = *reinterpret_cast<const float2*>(attn + gq * (FUSED ? ld_logit : 128) + head * 16 + c4 * 2);
-        if (FUSED) rps[st] = *reinterpret_cast<const float2*>(ref + (gq * 4 + my_lvl) * 2);
-      }
+    for (int i = 0; i < 8; ++i) lcs[i] = pl[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = pa[i];
+      aws[4 * i + 0] = a.x; aws[4 * i + 1] = a.y; aws[4 * i + 2] = a.z; aws[4 * i + 3] = a.w;
     }
+    if (FUSED) {
+      const float4* pr = reinterpret_cast<const float4*>(ref + gq * 8);
+      const float4 r0 = pr[0], r1 = pr[1];
+      rps[0] = make_float2(r0.x, r0.y); rps[1] = make_float2(r0.z, r0.w);
+      rps[2] = make_float2(r1.x, r1.y); rps[3] = make_float2(r1.z, r1.w);
+    }
+  } else {
 #pragma unroll
-    for (int st = 0; st < kMaxSteps; ++st) {
-      __builtin_amdgcn_sched_barrier(0);   // one group's geometry at a time (register budget)
-      float4 lc = lcs[st];
-      float2 aw = aws[st];
-      if (FUSED) {  // all lanes take part in the DPP reduce (padding slots hold zeros)
-        if (qv[st] >= 0) {
-          const float2 r = rps[st];
-          lc = make_float4(r.x + lc.x / fw, r.y + lc.y / fh, r.x + lc.z / fw, r.y + lc.w / fh);
-        }
-        softmax16<FUSED>(aw);
-        if (qv[st] < 0) aw = make_float2(0.f, 0.f);
-        if (attn_out != nullptr && qv[st] >= 0)
-          *reinterpret_cast<float2*>(attn_out + ((size_t)b * Lq + qv[st]) * 128 + head * 16 + c4 * 2) = aw;
+    for (int i = 0; i < 8; ++i) lcs[i] = make_float4(9.f, 9.f, 9.f, 9.f);   // far outside: invalid
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aws[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rps[i] = make_float2(0.f, 0.f);
+  }
+  if (FUSED) {
+    // softmax over the unit's 16 logits, lane-private (same operations as the wave-per-query kernel's DPP form)
+    float m = aws[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, aws[i]);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { aws[i] = __expf(aws[i] - m); }   // (2 ulp; the wave-per-query kernel uses expf)
+    // the DPP butterfly adds (e0 + e1) per lane first, then lanes ^1, ^2, mirror: same association here
+    {
+      float p2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) p2[i] = aws[2 * i] + aws[2 * i + 1];
+      float p4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p4[i] = p2[2 * i] + p2[2 * i + 1];
+      const float lo = p4[0] + p4[1], hi = p4[2] + p4[3];
+      sum = lo + hi;
+    }
+    const float rsum = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) aws[i] = aws[i] * rsum;
+    if (attn_out != nullptr && live) {
+      float4* po = reinterpret_cast<float4*>(attn_out + ((size_t)b * Lq + q) * 128 + head * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) po[i] = make_float4(aws[4 * i], aws[4 * i + 1], aws[4 * i + 2], aws[4 * i + 3]);
+    }
+  }
+
+  PROF_T(1)   // operand loads + softmax
+  f32x2 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (f32x2){0.f, 0.f};
+  const lds_cp lwin = (lds_cp)(s_mem);
+  const glb_cp gimg = (glb_cp)(vimg);
+
+  // The level loop is NOT unrolled: the whole kernel has to stay well inside the 64 KB instruction cache (a fully
+  // unrolled build was ~100 KB of straight-line code executed once per workgroup: instruction fetch, not LDS or the
+  // ALUs, set its time -- 60 us).  The level's operands are selected into level-local registers at the top.
+  fill_store(0, w0v, Npc0());
+#pragma unroll 1
+  for (int s = 0; s < 4; ++s) {
+    const Win w = lds_win(s_misc, s);
+    const int Hs = SEL_H(G, s), Ws = SEL_W(G, s), ss = SEL_S(G, s);
+    const float fw = (float)Ws, fh = (float)Hs;
+    const int wy0 = rfl(w.y0), wx0 = rfl(w.x0), wh = rfl(w.h), ww = rfl(w.w);
+    const bool staged = w.staged;
+    // this level's operands are ALWAYS in lcs[0..1] / aws[0..3] / rps[0]: the arrays are rotated at the end of the pass
+    // (a selection by the loop counter would be turned into a scratch-memory table by the compiler)
+    const float4 la = lcs[0], lb = lcs[1];
+    const float a4[4] = {aws[0], aws[1], aws[2], aws[3]};
+    const float2 rp = rps[0];
+    __syncthreads();    // window s is in LDS
+    PROF_T(2)
+    // the loads of the NEXT level's window are in flight during this level's gather (when they fit the registers)
+    float4 nxt[kNpcN];
+    bool nxt_ok = false;
+    if (s + 1 < 4) {
+      const Win wn = lds_win(s_misc, s + 1);
+      nxt_ok = rfl(wn.w * wn.h) <= kNpcN * (kRT / 8);   // wave-uniform
+      if (nxt_ok) fill_load(s + 1, nxt, NpcN());
+    }
+
+    // geometry of the unit's 4 samples of this level
+    int p00[4], prow[4];
+    float wc[4][4];
+    bool outl[4];
+    int sy0[4], sx0[4];
+#pragma unroll
+    for (int pt = 0; pt < 4; ++pt) {
+      const float4 l4 = pt < 2 ? la : lb;
+      float lx = (pt & 1) ? l4.z : l4.x, ly = (pt & 1) ? l4.w : l4.y;
+      if (FUSED) {
+        lx = rp.x + lx / fw;
+        ly = rp.y + ly / fh;
+      }
+      float x = lx * fw - 0.5f, y = ly * fh - 0.5f;
+      const bool val = (y > -1.f) && (x > -1.f) && (y < fh) && (x < fw);
+      x = val ? x : 0.f;
+      y = val ? y : 0.f;
+      const float a = val ? a4[pt] : 0.f;
+      const float yf = floorf(y), xf = floorf(x);
+      const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+      const int y0 = (int)yf, x0 = (int)xf;
+      wc[pt][0] = hh * hw * a;
+      wc[pt][1] = hh * lw * a;
+      wc[pt][2] = lh * hw * a;
+      wc[pt][3] = lh * lw * a;
+      const bool in = staged && y0 >= wy0 && x0 >= wx0 && y0 + 1 < wy0 + wh && x0 + 1 < wx0 + ww;
+      outl[pt] = val && !in;
+      // window pixel of (y0, x0); invalid samples read the zero pixels with zero weights
+      p00[pt] = (val && in) ? kZero + (y0 - wy0) * ww + (x0 - wx0) : 0;
+      prow[pt] = (val && in) ? ww : 0;
+      sy0[pt] = y0;
+      sx0[pt] = x0;
+    }
+    PROF_T(3)   // next window's loads issued + geometry
+    if (!__any((int)(outl[0] || outl[1] || outl[2] || outl[3]))) {
+      // every sample of the wave is in the window: 16 corners, each 8 ds_read_b128 (plane = offset immediate) + 16
+      // packed FMAs, the reads of corner c + 1 in flight while corner c is accumulated
+      auto corner_ptr = [&](int c) -> lds_cp {
+        const int pt = c >> 2, cn = c & 3;
+        return lwin + (p00[pt] + ((cn & 2) ? prow[pt] : 0) + (cn & 1)) * 16;
+      };
+      f32x4 vb[2][8];
+      {
+        const lds_cp pc_ = corner_ptr(0);
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) vb[0][qd] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(pc_ + qd * kPlane);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float x = (j ? lc.z : lc.x) * fw - 0.5f, y = (j ? lc.w : lc.y) * fh - 0.5f;
-        const bool val = (y > -1.f) && (x > -1.f) && (y < fh) && (x < fw);
-        x = val ? x : 0.f;
-        y = val ? y : 0.f;
-        const float a = val ? (j ? aw.y : aw.x) : 0.f;
-        const float yf = floorf(y), xf = floorf(x);
-        const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
-        const int y0 = (int)yf, x0 = (int)xf;
-        float w0 = hh * hw * a, w1 = hh * lw * a, w2 = lh * hw * a, w3 = lh * lw * a;
-        const bool in = w.staged && y0 >= w.y0 && x0 >= w.x0 && y0 + 1 < w.y0 + w.h && x0 + 1 < w.x0 + w.w;
-        unsigned cd = 0u;
-        if (val && in) {
-          const int p00 = kZero + (y0 - w.y0) * w.w + (x0 - w.x0);
-          cd = (unsigned)p00 | ((unsigned)(p00 + w.w) << 16);
-        } else if (val) {
-          // outside the window: out-of-range corners and padded tokens folded into the weights (cuh:55-78, dd:1052)
+      for (int c = 0; c < 16; ++c) {
+        if (c + 1 < 16) {
+          const lds_cp pc_ = corner_ptr(c + 1);
+#pragma unroll
+          for (int qd = 0; qd < 8; ++qd)
+            vb[(c + 1) & 1][qd] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(pc_ + qd * kPlane);
+        }
+        const float wgt = wc[c >> 2][c & 3];
+#pragma unroll
+        for (int qd = 0; qd < 8; ++qd) {
+          acc[2 * qd] += (f32x2){wgt, wgt} * (f32x2){vb[c & 1][qd].x, vb[c & 1][qd].y};
+          acc[2 * qd + 1] += (f32x2){wgt, wgt} * (f32x2){vb[c & 1][qd].z, vb[c & 1][qd].w};
+        }
+        __builtin_amdgcn_sched_barrier(0);   // two corners (16 reads) in flight at most
+      }
+    } else {
+#ifdef EGTR_REGION_PROF
+      if (lane == 0) atomicAdd(&g_prof[16 + s], 1ull);
+      {
+        const int no = (int)outl[0] + (int)outl[1] + (int)outl[2] + (int)outl[3];
+        atomicAdd(&g_prof[20 + s], (unsigned long long)no);
+        if (!staged && lane == 0) atomicAdd(&g_prof[24 + s], 1ull);
+      }
+#endif
+      // some lane has a sample outside its window: those lanes read that sample's corners from global memory (out-of-range
+      // corners and padded tokens folded into the weights, cuh:55-78 / dd:1052), the others from the window
+#pragma unroll 1
+      for (int pt = 0; pt < 4; ++pt) {
+        const bool ol = pt == 0 ? outl[0] : pt == 1 ? outl[1] : pt == 2 ? outl[2] : outl[3];
+        const int y0 = pt == 0 ? sy0[0] : pt == 1 ? sy0[1] : pt == 2 ? sy0[2] : sy0[3];
+        const int x0 = pt == 0 ? sx0[0] : pt == 1 ? sx0[1] : pt == 2 ? sx0[2] : sx0[3];
+        const int pp0 = pt == 0 ? p00[0] : pt == 1 ? p00[1] : pt == 2 ? p00[2] : p00[3];
+        const int pr0 = pt == 0 ? prow[0] : pt == 1 ? prow[1] : pt == 2 ? prow[2] : prow[3];
+        float w4[4];
+#pragma unroll
+        for (int cn = 0; cn < 4; ++cn) w4[cn] = pt == 0 ? wc[0][cn] : pt == 1 ? wc[1][cn] : pt == 2 ? wc[2][cn] : wc[3][cn];
+        unsigned gpix = 0;
+        int dx = 0, dy = 0;
+        if (ol) {
           const int ya = max(y0, 0), yb = min(y0 + 1, Hs - 1), xa = max(x0, 0), xb = min(x0 + 1, Ws - 1);
-          const int p00 = ss + ya * Ws + xa;
-          const int dx = xb - xa, dy = yb - ya;
+          const int g00 = ss + ya * Ws + xa;
+          dx = xb - xa;
+          dy = yb - ya;
           bool k0 = y0 >= 0 && x0 >= 0, k1 = y0 >= 0 && x0 + 1 <= Ws - 1, k2 = y0 + 1 <= Hs - 1 && x0 >= 0,
                k3 = y0 + 1 <= Hs - 1 && x0 + 1 <= Ws - 1;
           if (masked) {
-            const int p01 = p00 + dx, p10 = p00 + dy * Ws, p11 = p10 + dx;
-            k0 = k0 && ((kb_g[p00 >> 5] >> (p00 & 31)) & 1u);
-            k1 = k1 && ((kb_g[p01 >> 5] >> (p01 & 31)) & 1u);
-            k2 = k2 && ((kb_g[p10 >> 5] >> (p10 & 31)) & 1u);
-            k3 = k3 && ((kb_g[p11 >> 5] >> (p11 & 31)) & 1u);
+            const int g01 = g00 + dx, g10 = g00 + dy * Ws, g11 = g10 + dx;
+            k0 = k0 && ((kb_g[g00 >> 5] >> (g00 & 31)) & 1u);
+            k1 = k1 && ((kb_g[g01 >> 5] >> (g01 & 31)) & 1u);
+            k2 = k2 && ((kb_g[g10 >> 5] >> (g10 & 31)) & 1u);
+            k3 = k3 && ((kb_g[g11 >> 5] >> (g11 & 31)) & 1u);
           }
-          w0 = k0 ? w0 : 0.f;
-          w1 = k1 ? w1 : 0.f;
-          w2 = k2 ? w2 : 0.f;
-          w3 = k3 ? w3 : 0.f;
-          cd = 0x80000000u | (unsigned)((p00 << 2) | (dx << 1) | dy);
+          w4[0] = k0 ? w4[0] : 0.f;
+          w4[1] = k1 ? w4[1] : 0.f;
+          w4[2] = k2 ? w4[2] : 0.f;
+          w4[3] = k3 ? w4[3] : 0.f;
+          gpix = (unsigned)g00;
         }
-        wq[st][j][0] = w0;
-        wq[st][j][1] = w1;
-        wq[st][j][2] = w2;
-        wq[st][j][3] = w3;
-        code[st][j] = cd;
-      }
-    }
-  }
-
-  float4* rec_w = s_mem + kOffRecW + wave * 64;                          // [group 2][query col 8][sample p 4]
-  uint2* rec_a = reinterpret_cast<uint2*>(s_mem + kOffRecA) + wave * 64;   // [group 2][query col 8][sample p 4]
-  typedef const __attribute__((address_space(3))) char* lds_cp;
-  const lds_cp lbase = (lds_cp)(s_win) + c4 * 16;   // + a record's byte address = this lane's quad of that pixel
-  const glb_f4p gval = (glb_f4p)(vhead);
-
 #pragma unroll 1
-  for (int s = 0; s < 4; ++s) {
-    const int Ws = SEL_W(G, s);
-    if (s > 0) {
-      __syncthreads();  // the previous level's gathers are done with the window buffer
-      issue_fill(s);
+        for (int cn = 0; cn < 4; ++cn) {
+          f32x4 v[8];
+          if (ol) {
+            const glb_cp gp = gimg + ((size_t)gpix + ((cn & 1) ? dx : 0) + ((cn & 2) ? dy * Ws : 0)) * 1024;
+#pragma unroll
+            for (int qd = 0; qd < 8; ++qd) v[qd] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(gp + qd * 16);
+          } else {
+            const lds_cp pc_ = lwin + (pp0 + ((cn & 2) ? pr0 : 0) + (cn & 1)) * 16;
+#pragma unroll
+            for (int qd = 0; qd < 8; ++qd) v[qd] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(pc_ + qd * kPlane);
+          }
+          const float wgt = cn == 0 ? w4[0] : cn == 1 ? w4[1] : cn == 2 ? w4[2] : w4[3];
+#pragma unroll
+          for (int qd = 0; qd < 8; ++qd) {
+            acc[2 * qd] += (f32x2){wgt, wgt} * (f32x2){v[qd].x, v[qd].y};
+            acc[2 * qd + 1] += (f32x2){wgt, wgt} * (f32x2){v[qd].z, v[qd].w};
+          }
+        }
+      }
     }
-    __syncthreads();    // window copy landed (the fence of the barrier drains the DMA), zero pixels written
-
-#pragma unroll
-    for (int pr = 0; pr < kMaxSteps; pr += 2) {       // two query groups at a time: their LDS latencies overlap
-      if (wave + pr * kRW >= ngroups || (abl & 2)) continue;   // wave-uniform
-      if (my_lvl == s) {
-        // owner lanes publish their two samples' records (points 2(c4&1), +1 of level s) for both groups
-        const int p = 2 * (c4 & 1);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int st = pr + u;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            rec_w[u * 32 + col * 4 + p + j] = make_float4(wq[st][j][0], wq[st][j][1], wq[st][j][2], wq[st][j][3]);
-            const unsigned cd = code[st][j];
-            // byte addresses of the two window rows (bit 31 of .x: outlier, .x then carries the global code)
-            rec_a[u * 32 + col * 4 + p + j] =
-                (cd >> 31) ? make_uint2(cd, 0u) : make_uint2((cd & 0xffffu) << 7, (cd >> 16) << 7);
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-      const bool two = wave + (pr + 1) * kRW < ngroups;   // wave-uniform (odd number of groups: the second is empty)
-      uint4 A01[2], A23[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        A01[u] = *reinterpret_cast<const uint4*>(rec_a + u * 32 + col * 4);
-        A23[u] = *reinterpret_cast<const uint4*>(rec_a + u * 32 + col * 4 + 2);
-      }
-      const bool any_out = __any((int)((A01[0].x | A01[0].z | A23[0].x | A23[0].z | A01[1].x | A01[1].z | A23[1].x |
-                                        A23[1].z) >> 31));
-      if (!any_out) {
-        // every sample of both groups is in the window: 4 ds_read_b128 + 8 packed FMAs per sample, nothing else
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !two) continue;
-            const int st = pr + u;
-            const unsigned a0s = p == 0 ? A01[u].x : p == 1 ? A01[u].z : p == 2 ? A23[u].x : A23[u].z;
-            const unsigned a1s = p == 0 ? A01[u].y : p == 1 ? A01[u].w : p == 2 ? A23[u].y : A23[u].w;
-            const float4 wv = rec_w[u * 32 + col * 4 + p];
-            const lds_f4p r0 = (lds_f4p)(lbase + a0s), r1 = (lds_f4p)(lbase + a1s);
-            const f32x4 v00 = r0[0], v01 = r0[8], v10 = r1[0], v11 = r1[8];
-            f32x2 a0 = acc0[st], a1 = acc1[st];
-            a0 += (f32x2){wv.x, wv.x} * (f32x2){v00.x, v00.y};
-            a1 += (f32x2){wv.x, wv.x} * (f32x2){v00.z, v00.w};
-            a0 += (f32x2){wv.y, wv.y} * (f32x2){v01.x, v01.y};
-            a1 += (f32x2){wv.y, wv.y} * (f32x2){v01.z, v01.w};
-            a0 += (f32x2){wv.z, wv.z} * (f32x2){v10.x, v10.y};
-            a1 += (f32x2){wv.z, wv.z} * (f32x2){v10.z, v10.w};
-            a0 += (f32x2){wv.w, wv.w} * (f32x2){v11.x, v11.y};
-            a1 += (f32x2){wv.w, wv.w} * (f32x2){v11.z, v11.w};
-            acc0[st] = a0;
-            acc1[st] = a1;
-          }
-          __builtin_amdgcn_sched_barrier(0);   // one sample of each group in flight at a time (register budget)
-        }
+    PROF_T(4)   // gather
+    if (s + 1 < 4) {
+      __syncthreads();  // this level's gathers are done with the window buffer
+      if (nxt_ok) {
+        fill_store(s + 1, nxt, NpcN());
       } else {
-        // some lane has a sample outside its window: those lanes gather that sample from global memory
-#pragma unroll 1
-        for (int p = 0; p < 4; ++p) {
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            if (u == 1 && !two) continue;
-            const int st = pr + u;
-            const uint2 ar = rec_a[u * 32 + col * 4 + p];
-            const float4 wv = rec_w[u * 32 + col * 4 + p];
-            f32x4 v00, v01, v10, v11;
-            if (ar.x >> 31) {
-              const unsigned c = ar.x & 0x7fffffffu;
-              const glb_f4p gp = gval + (size_t)(c >> 2) * 64;
-              const size_t ox = (size_t)((c >> 1) & 1u) * 64, oy = (size_t)(c & 1u) * Ws * 64;
-              v00 = gp[0];
-              v01 = gp[ox];
-              v10 = gp[oy];
-              v11 = gp[oy + ox];
-            } else {
-              const lds_f4p r0 = (lds_f4p)(lbase + ar.x), r1 = (lds_f4p)(lbase + ar.y);
-              v00 = r0[0]; v01 = r0[8]; v10 = r1[0]; v11 = r1[8];
-            }
-            f32x2 a0 = acc0[st], a1 = acc1[st];
-            a0 += (f32x2){wv.x, wv.x} * (f32x2){v00.x, v00.y};
-            a1 += (f32x2){wv.x, wv.x} * (f32x2){v00.z, v00.w};
-            a0 += (f32x2){wv.y, wv.y} * (f32x2){v01.x, v01.y};
-            a1 += (f32x2){wv.y, wv.y} * (f32x2){v01.z, v01.w};
-            a0 += (f32x2){wv.z, wv.z} * (f32x2){v10.x, v10.y};
-            a1 += (f32x2){wv.z, wv.z} * (f32x2){v10.z, v10.w};
-            a0 += (f32x2){wv.w, wv.w} * (f32x2){v11.x, v11.y};
-            a1 += (f32x2){wv.w, wv.w} * (f32x2){v11.z, v11.w};
-            acc0[st] = a0;
-            acc1[st] = a1;
-          }
-        }
+        float4 tmp[kNpc0];
+        fill_load(s + 1, tmp, Npc0());
+        fill_store(s + 1, tmp, Npc0());
       }
-      // this wave's records are rewritten by its next pair of groups
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
+    PROF_T(5)   // next window's stores
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lcs[i] = lcs[i + 2];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) aws[i] = aws[i + 4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rps[i] = rps[i + 1];
   }
 
+  if (live) {
+    float4* po = reinterpret_cast<float4*>(out + ((size_t)b * Lq + q) * 256 + head * 32);
 #pragma unroll
-  for (int st = 0; st < kMaxSteps; ++st) {
-    if (qv[st] >= 0)
-      *reinterpret_cast<float4*>(out + ((size_t)b * Lq + qv[st]) * 256 + head * 32 + c4 * 4) =
-          make_float4(acc0[st].x, acc0[st].y, acc1[st].x, acc1[st].y);
+    for (int qd = 0; qd < 8; ++qd) po[qd] = make_float4(acc[2 * qd].x, acc[2 * qd].y, acc[2 * qd + 1].x, acc[2 * qd + 1].y);
   }
+  PROF_T(14)  // output stores issued
+#ifdef EGTR_REGION_PROF
+  if (tid == 0) atomicAdd(&g_prof[15], 1ull);
+#endif
 }
 
 }  // namespace
@@ -611,12 +653,20 @@ int egtr_launch_msda_fwd_region_f32(hipStream_t st, const float* value, const in
   const int RY = 1 << (k / 2), RX = R / RY;
   const long long nblk = (long long)B * R * 8;
   if (nblk >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
-  static const int abl = [] { const char* e = getenv("EGTR_REGION_ABLATE"); return e ? atoi(e) : 0; }();  // timing only
   if (ref != nullptr)
     hipLaunchKernelGGL(msda_fwd_region_f32<true>, dim3((unsigned)nblk), dim3(kRT), 0, st, value, shapes, lsi, loc, attn,
-                       out, B, Lq, S, ref, attn_out, ld_off, ld_logit, keep_bits, RY, RX, (int)nblk, mode, abl);
+                       out, B, Lq, S, ref, attn_out, ld_off, ld_logit, keep_bits, RY, RX, (int)nblk, mode);
   else
     hipLaunchKernelGGL(msda_fwd_region_f32<false>, dim3((unsigned)nblk), dim3(kRT), 0, st, value, shapes, lsi, loc, attn,
-                       out, B, Lq, S, nullptr, nullptr, 256, 128, nullptr, RY, RX, (int)nblk, mode, abl);
+                       out, B, Lq, S, nullptr, nullptr, 256, 128, nullptr, RY, RX, (int)nblk, mode);
   return egtr_check_launch();
 }
+
+#ifdef EGTR_REGION_PROF
+extern "C" int egtr_debug_region_prof(unsigned long long* out32) {
+  unsigned long long z[32] = {0};
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_prof), sizeof(z)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

@@ -405,7 +405,7 @@ def test_msda_region_kernel_fused_prologue_and_keep_mask(variant, shapes, B):
     want, ww = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, None, variant=1)
     got, gw = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], True, None, variant=variant)
     assert (got - want).abs().max().item() < 2e-5
-    assert torch.equal(gw, ww)
+    assert (gw - ww).abs().max().item() < 1e-6   # (the window scheme uses __expf and one reciprocal per softmax)
     with pytest.raises(Exception):  # a byte mask without its bit-packed copy is not served by this kernel
         k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5], variant=variant)
     words = torch.zeros(B, (S + 31) // 32, dtype=torch.int64)
