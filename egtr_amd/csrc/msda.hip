@@ -348,9 +348,10 @@ __device__ __forceinline__ float ld_elt<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float ld_elt<uint16_t>(const uint16_t* p) { return __uint_as_float(((unsigned)*p) << 16); }
 
-__global__ void msda_fwd_generic_f32(const float* __restrict__ value, const int64_t* __restrict__ shapes,
-                                     const int64_t* __restrict__ lsi, const float* __restrict__ loc,
-                                     const float* __restrict__ attn, float* __restrict__ out, long long n, int S,
+template <typename T>
+__global__ void msda_fwd_generic(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                                     const int64_t* __restrict__ lsi, const T* __restrict__ loc,
+                                     const T* __restrict__ attn, T* __restrict__ out, long long n, int S,
                                      int M, int D, int L, int Lq, int P) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -359,24 +360,24 @@ __global__ void msda_fwd_generic_f32(const float* __restrict__ value, const int6
     const int m = (int)(t % M);
     t /= M;  // t = b*Lq + q
     const int b = (int)(t / Lq);
-    const float* vb = value + (size_t)b * S * M * D + m * D + c;
-    const float* lp = loc + (size_t)(t * M + m) * L * P * 2;
-    const float* ap = attn + (size_t)(t * M + m) * L * P;
-    float col = 0.f;
+    const T* vb = value + (size_t)b * S * M * D + m * D + c;
+    const T* lp = loc + (size_t)(t * M + m) * L * P * 2;
+    const T* ap = attn + (size_t)(t * M + m) * L * P;
+    T col = 0;
     for (int l = 0; l < L; ++l) {
       const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
       for (int p = 0; p < P; ++p) {
-        const float x = lp[(l * P + p) * 2] * W - 0.5f, y = lp[(l * P + p) * 2 + 1] * H - 0.5f;
-        if (!(y > -1.f && x > -1.f && y < (float)H && x < (float)W)) continue;
-        const float yf = floorf(y), xf = floorf(x);
+        const T x = lp[(l * P + p) * 2] * W - (T)0.5, y = lp[(l * P + p) * 2 + 1] * H - (T)0.5;
+        if (!(y > (T)-1 && x > (T)-1 && y < (T)H && x < (T)W)) continue;
+        const T yf = floor(y), xf = floor(x);
         const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
-        const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
-        float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        const T lh = y - yf, lw = x - xf, hh = (T)1 - lh, hw = (T)1 - lw;
+        T v1 = 0, v2 = 0, v3 = 0, v4 = 0;
         if (y0 >= 0 && x0 >= 0) v1 = vb[(size_t)(st + y0 * W + x0) * M * D];
         if (y0 >= 0 && x1 <= W - 1) v2 = vb[(size_t)(st + y0 * W + x1) * M * D];
         if (y1 <= H - 1 && x0 >= 0) v3 = vb[(size_t)(st + y1 * W + x0) * M * D];
         if (y1 <= H - 1 && x1 <= W - 1) v4 = vb[(size_t)(st + y1 * W + x1) * M * D];
-        const float val = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
+        const T val = hh * hw * v1 + hh * lw * v2 + lh * hw * v3 + lh * lw * v4;
         col += val * ap[l * P + p];
       }
     }
@@ -527,11 +528,12 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
 }
 
 // Generic backward: one thread per (b,q,m,l,p) sample, loops over the D channels; atomics for grad_value.
-__global__ void msda_bwd_generic_f32(const float* __restrict__ grad_out, const float* __restrict__ value,
+template <typename T>
+__global__ void msda_bwd_generic(const T* __restrict__ grad_out, const T* __restrict__ value,
                                      const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-                                     const float* __restrict__ loc, const float* __restrict__ attn,
-                                     float* __restrict__ grad_value, float* __restrict__ grad_loc,
-                                     float* __restrict__ grad_attn, long long n, int S, int M, int D, int L, int Lq,
+                                     const T* __restrict__ loc, const T* __restrict__ attn,
+                                     T* __restrict__ grad_value, T* __restrict__ grad_loc,
+                                     T* __restrict__ grad_attn, long long n, int S, int M, int D, int L, int Lq,
                                      int P) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
        idx += (long long)gridDim.x * blockDim.x) {
@@ -543,23 +545,23 @@ __global__ void msda_bwd_generic_f32(const float* __restrict__ grad_out, const f
     t /= M;  // b*Lq + q
     const int b = (int)(t / Lq);
     const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1], st = (int)lsi[l];
-    const float x = loc[idx * 2] * W - 0.5f, y = loc[idx * 2 + 1] * H - 0.5f;
-    float ga = 0.f, gw = 0.f, gh = 0.f;
-    if (y > -1.f && x > -1.f && y < (float)H && x < (float)W) {
-      const float yf = floorf(y), xf = floorf(x);
+    const T x = loc[idx * 2] * W - (T)0.5, y = loc[idx * 2 + 1] * H - (T)0.5;
+    T ga = 0, gw = 0, gh = 0;
+    if (y > (T)-1 && x > (T)-1 && y < (T)H && x < (T)W) {
+      const T yf = floor(y), xf = floor(x);
       const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
-      const float lh = y - yf, lw = x - xf, hh = 1.f - lh, hw = 1.f - lw;
+      const T lh = y - yf, lw = x - xf, hh = (T)1 - lh, hw = (T)1 - lw;
       const bool k0 = y0 >= 0 && x0 >= 0, k1 = y0 >= 0 && x1 <= W - 1, k2 = y1 <= H - 1 && x0 >= 0,
                  k3 = y1 <= H - 1 && x1 <= W - 1;
       const size_t bo = (size_t)b * S * M * D + m * D;
       const size_t o0 = bo + (size_t)(st + y0 * W + x0) * M * D, o1 = bo + (size_t)(st + y0 * W + x1) * M * D,
                    o2 = bo + (size_t)(st + y1 * W + x0) * M * D, o3 = bo + (size_t)(st + y1 * W + x1) * M * D;
-      const float a = attn[idx];
-      const float* go = grad_out + (size_t)(t * M + m) * D;
+      const T a = attn[idx];
+      const T* go = grad_out + (size_t)(t * M + m) * D;
       for (int c = 0; c < D; ++c) {
-        const float v0 = k0 ? value[o0 + c] : 0.f, v1 = k1 ? value[o1 + c] : 0.f, v2 = k2 ? value[o2 + c] : 0.f,
-                    v3 = k3 ? value[o3 + c] : 0.f;
-        const float top = go[c] * a;
+        const T v0 = k0 ? value[o0 + c] : (T)0, v1 = k1 ? value[o1 + c] : (T)0, v2 = k2 ? value[o2 + c] : (T)0,
+                v3 = k3 ? value[o3 + c] : (T)0;
+        const T top = go[c] * a;
         if (k0) unsafeAtomicAdd(grad_value + o0 + c, hh * hw * top);
         if (k1) unsafeAtomicAdd(grad_value + o1 + c, hh * lw * top);
         if (k2) unsafeAtomicAdd(grad_value + o2 + c, lh * hw * top);
@@ -581,45 +583,9 @@ bool fast_shape(int M, int D, int L, int P) { return M == 8 && D == 32 && L >= 1
 
 }  // namespace
 
-int egtr_launch_msda_fwd_tile_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
-                                  const float* loc, const float* attn, float* out, int B, int Lq, int S, int L,
-                                  int P);
-int egtr_launch_msda_fwd_tile16_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
-                                    const float* loc, const float* attn, float* out, int B, int Lq, int S, int L,
-                                    int P);
-
-int egtr_launch_msda_fwd_lane_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
-                                  const float* loc, const float* attn, float* out, int B, int Lq, int S, int kind,
-                                  unsigned long long* prof);
-
-int egtr_launch_msda_fwd_res_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
-                                 const float* loc, const float* attn, float* out, int B, int Lq, int S, int L, int P);
-
-int egtr_launch_msda_fwd_win_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
-                                 const float* loc, const float* attn, float* out, int B, int Lq, int S, int L, int P,
-                                 int kind, const float* ref, float* attn_out, int ld_off, int ld_logit,
-                                 const unsigned char* keep, const unsigned* keep_bits, unsigned long long* prof);
-
-// msda_region.hip: adaptive region kernel (variant 14; 15 / 16 force its window / wave-per-query scheme)
-int egtr_launch_msda_fwd_region_f32(hipStream_t st, const float* value, const int64_t* shapes, const int64_t* lsi,
-                                    const float* loc, const float* attn, float* out, int B, int Lq, int S,
-                                    const float* ref, float* attn_out, int ld_off, int ld_logit,
-                                    const unsigned* keep_bits, int mode);
-
-// A/B switch for benchmarks: EGTR_MSDA_FWD_VARIANT=<n> overrides the automatic choice of the forward kernel
-// (read once; never needed for correctness -- every variant computes the same function).
-constexpr int kAutoEncoderVariant = 1;  // what "automatic" picks for encoder-shaped calls
-
-static int env_fwd_variant() {
-  static const int v = [] {
-    const char* e = getenv("EGTR_MSDA_FWD_VARIANT");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-
-// variant: 0 = automatic (wave-per-query when M = 8, D = 32, L*P = 16, else generic),
-//          1 = wave-per-query, 2 = tile x head with LDS windows, 3 = generic one-thread-per-element.
+// variant: 0 = automatic (wave-per-query when M = 8, D = 32, L*P = 16, else generic), 1 = wave-per-query,
+//          3 = generic one-thread-per-element (A/B parity tests).  The LDS-window designs that used to sit behind other
+//          variant numbers were measured slower and removed.
 extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value,
                                              const int64_t* spatial_shapes, const int64_t* level_start_index,
                                              const float* sampling_loc, const float* attn_weight, int batch,
@@ -629,40 +595,13 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
       num_point <= 0)
     return EGTR_E_ARG;
+  if (variant != 0 && variant != 1 && variant != 3) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long nq = (long long)batch * num_query;
   const bool fast = fast_shape(num_heads, channels, num_levels, num_point) &&
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
-  if (variant == 0 && fast && env_fwd_variant() > 0) variant = env_fwd_variant();
-  if (variant == 0)
-    variant = !fast ? 3 : ((num_query == spatial_size && num_query >= 1024 && !(num_point & 1)) ? kAutoEncoderVariant : 1);
-  if ((variant == 1 || variant == 2 || (variant >= 4 && variant <= 16)) && !fast) return EGTR_E_UNSUPPORTED;
-  if (variant >= 14 && variant <= 16) {
-    if (num_levels != 4 || num_point != 4) return EGTR_E_UNSUPPORTED;
-    return egtr_launch_msda_fwd_region_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
-                                           batch, num_query, spatial_size, nullptr, nullptr, 256, 128, nullptr,
-                                           variant - 14);
-  }
-  if (variant >= 8 && variant <= 13) {
-    if (num_point & 1) return EGTR_E_UNSUPPORTED;
-    return egtr_launch_msda_fwd_win_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
-                                        batch, num_query, spatial_size, num_levels, num_point, variant - 8, nullptr,
-                                        nullptr, 256, 128, nullptr, nullptr, nullptr);
-  }
-  if (variant == 7)
-    return egtr_launch_msda_fwd_res_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
-                                        batch, num_query, spatial_size, num_levels, num_point);
-  if (variant == 5 || variant == 6) {
-    if (num_levels != 4 || num_point != 4) return EGTR_E_UNSUPPORTED;
-    return egtr_launch_msda_fwd_lane_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, out,
-                                         batch, num_query, spatial_size, variant - 5, nullptr);
-  }
-  if (variant == 4)
-    return egtr_launch_msda_fwd_tile16_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                           out, batch, num_query, spatial_size, num_levels, num_point);
-  if (variant == 2)
-    return egtr_launch_msda_fwd_tile_f32(st, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                         out, batch, num_query, spatial_size, num_levels, num_point);
+  if (variant == 0) variant = fast ? 1 : 3;
+  if (variant == 1 && !fast) return EGTR_E_UNSUPPORTED;
   if (variant == 1 && nq <= kSplitMaxQueries && num_levels * num_point == 16) {
     hipLaunchKernelGGL((msda_fwd_q64_f32<false, true>), dim3((int)nq), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
@@ -678,40 +617,11 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
     const long long n = nq * num_heads * channels;
     const int threads = 256;
     const int blocks = (int)std::min<long long>((n + threads - 1) / threads, 65535ll * 16);
-    hipLaunchKernelGGL(msda_fwd_generic_f32, dim3(blocks), dim3(threads), 0, st, value, spatial_shapes,
+    hipLaunchKernelGGL(msda_fwd_generic<float>, dim3(blocks), dim3(threads), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, n, spatial_size, num_heads, channels,
                        num_levels, num_query, num_point);
   }
   return egtr_check_launch();
-}
-
-extern "C" int egtr_msda_win_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                          const int64_t* level_start_index, const float* sampling_loc,
-                                          const float* attn_weight, int batch, int spatial_size, int num_levels,
-                                          int num_query, int num_point, int kind, float* out,
-                                          unsigned long long* cycles) {
-  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out || !cycles)
-    return EGTR_E_ARG;
-  if (batch <= 0 || spatial_size <= 0 || num_query <= 0 || kind < 0 || kind > 5) return EGTR_E_ARG;
-  if (num_levels < 1 || num_levels > 4 || num_levels * num_point != 16 || (num_point & 1) ||
-      (long long)spatial_size * 1024 >= (1ll << 31))
-    return EGTR_E_UNSUPPORTED;
-  return egtr_launch_msda_fwd_win_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
-                                      sampling_loc, attn_weight, out, batch, num_query, spatial_size, num_levels,
-                                      num_point, kind, nullptr, nullptr, 256, 128, nullptr, nullptr, cycles);
-}
-
-extern "C" int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                           const int64_t* level_start_index, const float* sampling_loc,
-                                           const float* attn_weight, int batch, int spatial_size, int num_query,
-                                           int kind, float* out, unsigned long long* cycles) {
-  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out || !cycles)
-    return EGTR_E_ARG;
-  if (batch <= 0 || spatial_size <= 0 || num_query <= 0 || kind < 0 || kind > 1) return EGTR_E_ARG;
-  if ((long long)spatial_size * 1024 >= (1ll << 31) || (long long)batch * num_query >= (1ll << 27))
-    return EGTR_E_UNSUPPORTED;
-  return egtr_launch_msda_fwd_lane_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
-                                       sampling_loc, attn_weight, out, batch, num_query, spatial_size, kind, cycles);
 }
 
 extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value,
@@ -721,7 +631,7 @@ extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const flo
                                                  int num_heads, int channels, int num_levels, int num_query,
                                                  int num_point, float* out, float* attn_weight_out, int ld_offsets,
                                                  int ld_logits, const unsigned char* keep_mask,
-                                                 const unsigned* keep_bits, int variant, const float* value_bias) {
+                                                 const unsigned* keep_bits, const float* value_bias) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
       !out)
     return EGTR_E_ARG;
@@ -731,32 +641,6 @@ extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const flo
   if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
       (long long)spatial_size * 1024 >= (1ll << 31) || nq >= (1ll << 27))
     return EGTR_E_UNSUPPORTED;
-  if (variant != 0 && variant != 1 && (variant < 8 || variant > 16)) return EGTR_E_UNSUPPORTED;
-  if (variant == 0) {
-    // automatic: the LDS-window kernel for encoder-shaped calls (queries = the pixels of the levels), the
-    // wave-per-query kernel for short / arbitrary query lists (decoder)
-    const int e = env_fwd_variant();
-    variant = (e == 1 || (e >= 8 && e <= 16)) ? e : kAutoEncoderVariant;
-    if (!(num_query == spatial_size && num_query >= 1024)) variant = 1;
-    if (variant >= 14 && (num_levels != 4 || num_point != 4 || value_bias != nullptr ||
-                          (keep_mask != nullptr && keep_bits == nullptr)))
-      variant = 1;
-  }
-  if (variant >= 14) {
-    if (num_levels != 4 || num_point != 4 || value_bias != nullptr || (keep_mask != nullptr && keep_bits == nullptr))
-      return EGTR_E_UNSUPPORTED;
-    return egtr_launch_msda_fwd_region_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
-                                           sampling_offsets, attn_logits, out, batch, num_query, spatial_size,
-                                           reference_points, attn_weight_out, ld_offsets, ld_logits, keep_bits,
-                                           variant - 14);
-  }
-  if (variant >= 8) {
-    if (value_bias != nullptr) return EGTR_E_UNSUPPORTED;  // the LDS-window kernels take finished values only
-    return egtr_launch_msda_fwd_win_f32(static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index,
-                                        sampling_offsets, attn_logits, out, batch, num_query, spatial_size,
-                                        num_levels, num_point, variant - 8, reference_points, attn_weight_out,
-                                        ld_offsets, ld_logits, keep_mask, keep_bits, nullptr);
-  }
   if (nq <= kSplitMaxQueries) {  // fewer waves than SIMDs: split each query's samples over a workgroup
     hipLaunchKernelGGL((msda_fwd_q64_f32<true, true>), dim3((int)nq), dim3(kWaves * 64), 0,
                        static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index, sampling_offsets,
@@ -772,20 +656,6 @@ extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const flo
   return egtr_check_launch();
 }
 
-extern "C" int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const float* value,
-                                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                                   const float* sampling_offsets, const float* attn_logits,
-                                                   const float* reference_points, int batch, int spatial_size,
-                                                   int num_heads, int channels, int num_levels, int num_query,
-                                                   int num_point, float* out, float* attn_weight_out, int ld_offsets,
-                                                   int ld_logits, const unsigned char* keep_mask,
-                                                   const unsigned* keep_bits, int variant) {
-  return egtr_msda_forward_fused_vbias_f32(stream, value, spatial_shapes, level_start_index, sampling_offsets,
-                                           attn_logits, reference_points, batch, spatial_size, num_heads, channels,
-                                           num_levels, num_query, num_point, out, attn_weight_out, ld_offsets,
-                                           ld_logits, keep_mask, keep_bits, variant, nullptr);
-}
-
 extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                            const int64_t* level_start_index, const float* sampling_offsets,
                                            const float* attn_logits, const float* reference_points, int batch,
@@ -793,10 +663,10 @@ extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* va
                                            int num_query, int num_point, float* out, float* attn_weight_out,
                                            int ld_offsets, int ld_logits, const unsigned char* keep_mask,
                                            const unsigned* keep_bits) {
-  return egtr_msda_forward_fused_f32_variant(stream, value, spatial_shapes, level_start_index, sampling_offsets,
-                                             attn_logits, reference_points, batch, spatial_size, num_heads, channels,
-                                             num_levels, num_query, num_point, out, attn_weight_out, ld_offsets,
-                                             ld_logits, keep_mask, keep_bits, 0);
+  return egtr_msda_forward_fused_vbias_f32(stream, value, spatial_shapes, level_start_index, sampling_offsets,
+                                           attn_logits, reference_points, batch, spatial_size, num_heads, channels,
+                                           num_levels, num_query, num_point, out, attn_weight_out, ld_offsets,
+                                           ld_logits, keep_mask, keep_bits, nullptr);
 }
 
 extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
@@ -901,7 +771,7 @@ extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float*
     const long long n = nq * num_heads * num_levels * num_point;
     const int threads = 256;
     const int blocks = (int)std::min<long long>((n + threads - 1) / threads, 65535ll * 16);
-    hipLaunchKernelGGL(msda_bwd_generic_f32, dim3(blocks), dim3(threads), 0, st, grad_out, value, spatial_shapes,
+    hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(blocks), dim3(threads), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
                        grad_attn_weight, n, spatial_size, num_heads, channels, num_levels, num_query, num_point);
   }
@@ -917,4 +787,83 @@ extern "C" int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_ou
   return egtr_msda_backward_f32_variant(stream, grad_out, value, spatial_shapes, level_start_index, sampling_loc,
                                         attn_weight, batch, spatial_size, num_heads, channels, num_levels, num_query,
                                         num_point, grad_value, grad_sampling_loc, grad_attn_weight, 0);
+}
+
+
+// ---- float64 entries: the reference dispatches AT_DISPATCH_FLOATING_TYPES (ms_deform_attn_cuda.cu:67, 137), so a
+// gradcheck-style caller of the extension passes double.  Served by the generic kernels (any M, D, L, P).
+extern "C" int egtr_msda_forward_f64(egtr_stream_t stream, const double* value, const int64_t* spatial_shapes,
+                                     const int64_t* level_start_index, const double* sampling_loc,
+                                     const double* attn_weight, int batch, int spatial_size, int num_heads,
+                                     int channels, int num_levels, int num_query, int num_point, double* out) {
+  if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out) return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
+      num_point <= 0)
+    return EGTR_E_ARG;
+  const long long n = (long long)batch * num_query * num_heads * channels;
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 65535ll * 16);
+  hipLaunchKernelGGL(msda_fwd_generic<double>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), value,
+                     spatial_shapes, level_start_index, sampling_loc, attn_weight, out, n, spatial_size, num_heads,
+                     channels, num_levels, num_query, num_point);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_msda_backward_f64(egtr_stream_t stream, const double* grad_out, const double* value,
+                                      const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                      const double* sampling_loc, const double* attn_weight, int batch,
+                                      int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                      int num_point, double* grad_value, double* grad_sampling_loc,
+                                      double* grad_attn_weight) {
+  if (!grad_out || !value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_value ||
+      !grad_sampling_loc || !grad_attn_weight)
+    return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_levels <= 0 || num_query <= 0 ||
+      num_point <= 0)
+    return EGTR_E_ARG;
+  const long long n = (long long)batch * num_query * num_heads * num_levels * num_point;
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 65535ll * 16);
+  hipLaunchKernelGGL(msda_bwd_generic<double>, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), grad_out,
+                     value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                     grad_attn_weight, n, spatial_size, num_heads, channels, num_levels, num_query, num_point);
+  return egtr_check_launch();
+}
+
+// ---- bf16 backward (the reference has no half / bf16 kernel; the stress configuration trains in bf16): bf16 value and
+// upstream gradient, fp32 sampling geometry and fp32 gradients.  The bf16 operands are widened once into `workspace`
+// (B*S*M*D + B*Lq*M*D floats) and the fp32 kernels do the rest -- for encoder-shaped calls that is the matrix-core
+// grad_value kernel, which is what makes this faster than a bf16 gather / fp32 atomic-scatter kernel would be.
+namespace {
+__global__ __launch_bounds__(256) void widen_bf16(const uint16_t* __restrict__ a, float* __restrict__ oa, long long na,
+                                                  const uint16_t* __restrict__ b, float* __restrict__ ob, long long nb) {
+  const long long n8 = (na + nb) / 8;   // both counts are multiples of 8 (M * D = 256 elements per row)
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 8;
+    const bool first = e < na;
+    const uint4 v = *reinterpret_cast<const uint4*>(first ? a + e : b + (e - na));
+    float* o = first ? oa + e : ob + (e - na);
+    reinterpret_cast<float4*>(o)[0] = make_float4(bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y));
+    reinterpret_cast<float4*>(o)[1] = make_float4(bf16_lo(v.z), bf16_hi(v.z), bf16_lo(v.w), bf16_hi(v.w));
+  }
+}
+}  // namespace
+
+extern "C" int egtr_msda_backward_bf16(egtr_stream_t stream, const uint16_t* grad_out, const uint16_t* value,
+                                       const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                       const float* sampling_loc, const float* attn_weight, int batch,
+                                       int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                       int num_point, float* grad_value, float* grad_sampling_loc,
+                                       float* grad_attn_weight, float* workspace) {
+  if (!grad_out || !value || !workspace) return EGTR_E_ARG;
+  if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_query <= 0) return EGTR_E_ARG;
+  const long long nv = (long long)batch * spatial_size * num_heads * channels;
+  const long long ng = (long long)batch * num_query * num_heads * channels;
+  if ((nv & 7) || (ng & 7)) return EGTR_E_UNSUPPORTED;
+  const int blocks = (int)std::min<long long>(((nv + ng) / 8 + 255) / 256, 65535ll);
+  hipLaunchKernelGGL(widen_bf16, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), value, workspace, nv,
+                     grad_out, workspace + nv, ng);
+  const int st = egtr_check_launch();
+  if (st != EGTR_OK) return st;
+  return egtr_msda_backward_f32(stream, workspace + nv, workspace, spatial_shapes, level_start_index, sampling_loc,
+                                attn_weight, batch, spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                grad_value, grad_sampling_loc, grad_attn_weight);
 }

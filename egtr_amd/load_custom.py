@@ -42,6 +42,15 @@ class _MultiScaleDeformableAttention:
         Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
         _chk(spatial_shapes, "spatial_shapes", torch.int64)
         _chk(level_start_index, "level_start_index", torch.int64)
+        if value.dtype == torch.float64:  # AT_DISPATCH_FLOATING_TYPES (ms_deform_attn_cuda.cu:67): double is served too
+            for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")):
+                _chk(t, n, torch.float64)
+            out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
+            st = lib.egtr_msda_forward_f64(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
+                                           level_start_index.data_ptr(), sampling_loc.data_ptr(),
+                                           attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr())
+            _lib.check(st, "ms_deform_attn_forward")
+            return out
         _chk(sampling_loc, "sampling_loc", torch.float32)
         _chk(attn_weight, "attn_weight", torch.float32)
         if value.dtype == torch.float32:
@@ -63,8 +72,7 @@ class _MultiScaleDeformableAttention:
 
     @staticmethod
     def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                     reference_points, want_weights=False, keep_mask=None, variant=0,
-                                     value_bias=None):
+                                     reference_points, want_weights=False, keep_mask=None, value_bias=None):
         """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` computed in the kernel
         (deformable_detr.py:1055-1073, 2-d reference points).  fp32, M = 8, D = 32, L*P = 16; no autograd.
         sampling_offsets [B,Lq,M,L,P,2] / attn_logits [B,Lq,M,L*P] may be column blocks of one wider Linear output
@@ -117,7 +125,7 @@ class _MultiScaleDeformableAttention:
                                                    reference_points.data_ptr(), B, S, M, D, L, Lq, P,
                                                    out.data_ptr(), wts.data_ptr() if want_weights else None, ld_off,
                                                    ld_log, km.data_ptr() if km is not None else None,
-                                                   kbits.data_ptr() if kbits is not None else None, variant,
+                                                   kbits.data_ptr() if kbits is not None else None,
                                                    vb.data_ptr() if vb is not None else None)
         _lib.check(st, "ms_deform_attn_forward_fused")
         return out, wts
@@ -184,11 +192,39 @@ class _MultiScaleDeformableAttention:
         B, S, M, D = value.shape
         L = spatial_shapes.shape[0]
         Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
+        _chk(spatial_shapes, "spatial_shapes", torch.int64)
+        _chk(level_start_index, "level_start_index", torch.int64)
+        if value.dtype == torch.float64:      # ms_deform_attn_cuda.cu:137 dispatches double as well
+            for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"),
+                         (grad_output, "grad_output")):
+                _chk(t, n, torch.float64)
+            grad_value = torch.zeros_like(value)
+            grad_loc = torch.empty_like(sampling_loc)
+            grad_attn = torch.empty_like(attn_weight)
+            st = lib.egtr_msda_backward_f64(_stream(), grad_output.data_ptr(), value.data_ptr(),
+                                            spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                            sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P,
+                                            grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
+            _lib.check(st, "ms_deform_attn_backward")
+            return grad_value, grad_loc, grad_attn
+        if value.dtype == torch.bfloat16:     # bf16 values / upstream gradient, fp32 geometry and gradients
+            _chk(value, "value", torch.bfloat16)
+            _chk(grad_output, "grad_output", torch.bfloat16)
+            _chk(sampling_loc, "sampling_loc", torch.float32)
+            _chk(attn_weight, "attn_weight", torch.float32)
+            gv32 = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+            grad_loc = torch.empty_like(sampling_loc)
+            grad_attn = torch.empty_like(attn_weight)
+            ws = torch.empty(value.numel() + grad_output.numel(), dtype=torch.float32, device=value.device)
+            st = lib.egtr_msda_backward_bf16(_stream(), grad_output.data_ptr(), value.data_ptr(),
+                                             spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                             sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P,
+                                             gv32.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), ws.data_ptr())
+            _lib.check(st, "ms_deform_attn_backward")
+            return gv32.to(torch.bfloat16), grad_loc, grad_attn
         for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"),
                      (grad_output, "grad_output")):
             _chk(t, n, torch.float32)
-        _chk(spatial_shapes, "spatial_shapes", torch.int64)
-        _chk(level_start_index, "level_start_index", torch.int64)
         grad_value = torch.zeros_like(value)  # accumulated with atomics (reference: cu:124)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)

@@ -74,64 +74,25 @@ int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const 
                                 float* attn_weight_out, int ld_offsets, int ld_logits,
                                 const unsigned char* keep_mask, const unsigned* keep_bits);
 
-/* Same with an explicit kernel choice: 0 = automatic, 1 = wave-per-query, 8 / 9 / 10 = the LDS-window kernel
- * (see egtr_msda_forward_f32_variant). */
-int egtr_msda_forward_fused_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                        const int64_t* level_start_index, const float* sampling_offsets,
-                                        const float* attn_logits, const float* reference_points, int batch,
-                                        int spatial_size, int num_heads, int channels, int num_levels, int num_query,
-                                        int num_point, float* out, float* attn_weight_out, int ld_offsets,
-                                        int ld_logits, const unsigned char* keep_mask, const unsigned* keep_bits,
-                                        int variant);
-
 /* Same with the value_proj bias applied inside the kernel: `value` is the bias-free projection W x of the (unmasked)
  * encoder states and value_bias [M*D] the bias; out = sum_s w_s v_s + value_bias * sum_s w_s over the in-range, unpadded
  * corner weights -- identical to sampling (W x + b) with padded rows zeroed (deformable_detr.py:1048-1052), without the
- * bias / mask pass over the [S, 256] value tensor.  Wave-per-query kernels only (variant 0 / 1); value_bias may be NULL. */
+ * bias / mask pass over the [S, 256] value tensor.  value_bias may be NULL (then identical to the entry above). */
 int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                       const int64_t* level_start_index, const float* sampling_offsets,
                                       const float* attn_logits, const float* reference_points, int batch,
                                       int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                       int num_point, float* out, float* attn_weight_out, int ld_offsets, int ld_logits,
-                                      const unsigned char* keep_mask, const unsigned* keep_bits, int variant,
+                                      const unsigned char* keep_mask, const unsigned* keep_bits,
                                       const float* value_bias);
 
-/* Same, with an explicit kernel choice (benchmarks / A-B tests): 0 = automatic (what egtr_msda_forward_f32 does),
- * 1 = wave-per-query, 2 / 4 = query-tile x head with LDS-staged windows (64- / 16-query tiles, 8 lanes per query),
- * 3 = generic one-thread-per-element, 5 / 6 = lane-per-query with LDS windows in [channel quad][pixel] planes
- * (2 waves / 1 wave per workgroup; needs num_levels = num_point = 4), 7 = one head per workgroup with that head's
- * coarsest levels resident in LDS, 8 / 9 / 10 = query tile x head with one 16-byte record per sample, zero-filled
- * bounding windows of the unclamped corners, conflict-free gather lanes and non-persistent small workgroups
- * (4x8 tiles, 4 workgroups per CU / 8x8 tiles, 2 per CU / 4x8 tiles with a larger window, 3 per CU; num_point even).
- * The environment variable EGTR_MSDA_FWD_VARIANT overrides "automatic" (A/B runs of whole-model benchmarks).
- * Every variant computes the same function; EGTR_E_UNSUPPORTED if the shape rules out the requested variant. */
+/* egtr_msda_forward_f32 with an explicit kernel choice (A/B parity tests): 0 = automatic, 1 = the wave-per-query
+ * kernel (M = 8, D = 32, L*P = 16), 3 = the generic one-thread-per-element kernel (any shape).  Both compute the same
+ * function; EGTR_E_UNSUPPORTED if the shape rules out the requested kernel. */
 int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                   const int64_t* level_start_index, const float* sampling_loc,
                                   const float* attn_weight, int batch, int spatial_size, int num_heads, int channels,
                                   int num_levels, int num_query, int num_point, float* out, int variant);
-
-/* Profiling hook for variant 2 (M = 8, D = 32): runs the tile kernel with per-phase accounting.  cycles (device,
- * 4 x uint64, zero it first) receives the shader-clock cycles summed over work items of phase A (geometry + bounding
- * boxes), phase B (records + window staging), phase C (gather) and the number of work items. */
-int egtr_msda_tile_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                const int64_t* level_start_index, const float* sampling_loc,
-                                const float* attn_weight, int batch, int spatial_size, int num_levels, int num_query,
-                                int num_point, float* out, unsigned long long* cycles);
-
-/* Same for variants 8 / 9 / 10 (kind 0 / 1 / 2; kind 3 = variant 11: 8 x uint64, see msda_win.hip).  cycles: 6 x uint64 (zero it first): loc/attn issue + first barrier,
- * geometry + bounding boxes, records + window copy, gather + store, number of work items, number of staged levels. */
-int egtr_msda_win_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                               const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
-                               int batch, int spatial_size, int num_levels, int num_query, int num_point, int kind,
-                               float* out, unsigned long long* cycles);
-
-/* Same for variants 5 (kind 0) and 6 (kind 1).  cycles: 8 x uint64 (zero it first): loc/attn + bounding boxes,
- * window staging, gather, output, number of work items; then, for the work items whose four windows were all staged:
- * their number, their gather cycles, their total cycles. */
-int egtr_msda_lane_phase_cycles(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                const int64_t* level_start_index, const float* sampling_loc,
-                                const float* attn_weight, int batch, int spatial_size, int num_query, int kind,
-                                float* out, unsigned long long* cycles);
 
 /* grad_value [B,S,M,D] MUST be zero-initialised by the caller (accumulated with atomics, as cu:124 relies on);
  * grad_sampling_loc [B,Lq,M,L,P,2] and grad_attn_weight [B,Lq,M,L,P] are fully overwritten. */
@@ -141,8 +102,32 @@ int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const fl
                            int num_heads, int channels, int num_levels, int num_query, int num_point,
                            float* grad_value, float* grad_sampling_loc, float* grad_attn_weight);
 
-/* Same with an explicit kernel choice: 0 = automatic, 1 = wave-per-query (global atomics per sample), 2 = query-tile
- * x head with grad_value accumulated in LDS windows and flushed once per element, 3 = generic. */
+/* float64 forward / backward: the reference extension dispatches AT_DISPATCH_FLOATING_TYPES
+ * (model/custom_kernel/cuda/ms_deform_attn_cuda.cu:67, 137), so double callers (gradcheck) are served too -- by the
+ * generic one-thread-per-element kernels, any (M, D, L, P).  Same argument meaning as the f32 entries; grad_value must be
+ * zero-initialised. */
+int egtr_msda_forward_f64(egtr_stream_t stream, const double* value, const int64_t* spatial_shapes,
+                          const int64_t* level_start_index, const double* sampling_loc, const double* attn_weight,
+                          int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                          int num_point, double* out);
+int egtr_msda_backward_f64(egtr_stream_t stream, const double* grad_out, const double* value,
+                           const int64_t* spatial_shapes, const int64_t* level_start_index, const double* sampling_loc,
+                           const double* attn_weight, int batch, int spatial_size, int num_heads, int channels,
+                           int num_levels, int num_query, int num_point, double* grad_value, double* grad_sampling_loc,
+                           double* grad_attn_weight);
+
+/* bf16 backward (we add bf16; the reference has no half kernel): grad_out [B,Lq,M*D] and value [B,S,M,D] are raw
+ * bfloat16, sampling_loc / attn_weight and all three gradients fp32 (grad_value zero-initialised by the caller).
+ * workspace: B*S*M*D + B*Lq*M*D floats (the widened operands). */
+int egtr_msda_backward_bf16(egtr_stream_t stream, const uint16_t* grad_out, const uint16_t* value,
+                            const int64_t* spatial_shapes, const int64_t* level_start_index, const float* sampling_loc,
+                            const float* attn_weight, int batch, int spatial_size, int num_heads, int channels,
+                            int num_levels, int num_query, int num_point, float* grad_value, float* grad_sampling_loc,
+                            float* grad_attn_weight, float* workspace);
+
+/* Same with an explicit kernel choice (A/B parity tests): 0 = automatic, 1 = wave-per-query with one global atomic per
+ * (sample, corner, channel) like the reference, 2 = grad_attn / grad_loc by the wave-per-query kernel + grad_value as a
+ * dense product per (query tile, head) on the matrix cores (encoder-shaped calls), 3 = generic. */
 int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
                                    const int64_t* spatial_shapes, const int64_t* level_start_index,
                                    const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,

@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import check_async_loads as lint  # noqa: E402
 
+CSRC = os.path.join(ROOT, "egtr_amd", "csrc")
+
 GOOD = """
 kern_a:
 \ts_load_dwordx2 s[0:1], s[4:5], 0x0
@@ -83,10 +85,9 @@ def test_lint_ignores_lds_dma_and_load_after_load():
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
-@pytest.mark.parametrize("src", ["rel_head.hip", "linear.hip", "msda.hip", "msda_win.hip", "msda_tile.hip",
-                                 "msda_lane.hip", "msda_res.hip", "self_attn.hip", "elementwise.hip"])
+@pytest.mark.parametrize("src", sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")))
 def test_inline_asm_loads_are_waited_for_before_any_use(src):
-    """Every kernel source: rel_head.hip (fp32 + bf16 kernels), linear.hip and msda_win.hip issue loads through inline asm
-    with hand-counted waits; the others only have compiler-managed loads and must pass trivially."""
+    """Every kernel source: rel_head.hip (fp32 + bf16 kernels) and linear.hip issue loads through inline asm with
+    hand-counted waits; the others only have compiler-managed loads and must pass trivially."""
     findings = lint.check_asm(lint.compile_to_asm(os.path.join(ROOT, "egtr_amd", "csrc", src)))
     assert findings == [], findings[:5]

@@ -56,9 +56,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="800x1333 shapes")
     ap.add_argument("--bf16", action="store_true")
-    ap.add_argument("--phases", action="store_true", help="print per-phase cycles of the tile kernel")
     ap.add_argument("--graph", action="store_true", help="replay 20 launches per HIP graph (no CPU launch floor)")
-    ap.add_argument("--variant", type=int, default=0, help="forward kernel variant (include/egtr_hip.h)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel choice of the *_variant entries (include/egtr_hip.h)")
     ap.add_argument("--fused", action="store_true", help="fused-prologue entry (offsets | logits block + ref points)")
     a = ap.parse_args()
     from egtr_amd.load_custom import load_hip_kernels
@@ -79,70 +78,7 @@ def main():
         both = torch.cat([offs.reshape(B_, Lq_, 256), torch.log(attn.reshape(B_, Lq_, 128))], -1).contiguous()
         off_v = both[..., :256].view(B_, Lq_, 8, len(shapes), 4, 2)
         log_v = both[..., 256:].view(B_, Lq_, 8, 16)
-        fn = lambda: k.ms_deform_attn_forward_fused(value, shp, lsi, off_v, log_v, refp, False, None, variant=a.variant)
-    if a.phases and a.variant in (11, 13):
-        from egtr_amd import _lib
-        cyc = torch.zeros(8, dtype=torch.int64, device=dev)
-        out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
-        for _ in range(3):
-            cyc.zero_()
-            st = _lib.lib().egtr_msda_win_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
-                                                       shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
-                                                       attn.data_ptr(), a.batch, value.shape[1], shp.shape[0],
-                                                       loc.shape[1], 4, 3 if a.variant == 11 else 5, out.data_ptr(), cyc.data_ptr())
-            _lib.check(st, "phase cycles")
-            torch.cuda.synchronize()
-        c = cyc.tolist()
-        n = max(c[7], 1)
-        print(f"pipelined window kernel, wave 0, ticks per item: barrierX={c[0]/n:.0f} geometry={c[1]/n:.0f} "
-              f"barrierY={c[2]/n:.0f} pack+copy+records={c[3]/n:.0f} gather={c[4]/n:.0f} dma_wait={c[5]/n:.0f}; "
-              f"items={c[7]}; ticks per workgroup={c[6]/(512 if a.variant == 11 else 1024):.0f}")
-    elif a.phases and a.variant in (8, 9, 10):
-        from egtr_amd import _lib
-        cyc = torch.zeros(6, dtype=torch.int64, device=dev)
-        out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
-        for _ in range(3):
-            cyc.zero_()
-            st = _lib.lib().egtr_msda_win_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
-                                                       shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
-                                                       attn.data_ptr(), a.batch, value.shape[1], shp.shape[0],
-                                                       loc.shape[1], 4, a.variant - 8, out.data_ptr(), cyc.data_ptr())
-            _lib.check(st, "phase cycles")
-            torch.cuda.synchronize()
-        c = cyc.tolist()
-        print(f"window kernel phases per work item (s_memtime ticks = 100 MHz?): P0={c[0]/c[4]:.0f} A={c[1]/c[4]:.0f} "
-              f"B={c[2]/c[4]:.0f} C={c[3]/c[4]:.0f} items={c[4]} staged levels/item={c[5]/c[4]:.2f}")
-    elif a.phases and a.variant in (5, 6):
-        from egtr_amd import _lib
-        cyc = torch.zeros(8, dtype=torch.int64, device=dev)
-        out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
-        for _ in range(3):
-            cyc.zero_()
-            st = _lib.lib().egtr_msda_lane_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
-                                                        shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
-                                                        attn.data_ptr(), a.batch, value.shape[1], loc.shape[1],
-                                                        a.variant - 5, out.data_ptr(), cyc.data_ptr())
-            _lib.check(st, "phase cycles")
-            torch.cuda.synchronize()
-        c = cyc.tolist()
-        print(f"lane kernel phases per work item (s_memtime ticks): load+geom+bbox={c[0]/c[4]:.0f} "
-              f"stage={c[1]/c[4]:.0f} gather={c[2]/c[4]:.0f} out={c[3]/c[4]:.0f} items={c[4]}; "
-              f"all-staged items={c[5]} gather={c[6]/max(c[5],1):.0f} total={c[7]/max(c[5],1):.0f}")
-    elif a.phases:
-        from egtr_amd import _lib
-        cyc = torch.zeros(4, dtype=torch.int64, device=dev)
-        out = torch.empty(a.batch, loc.shape[1], 256, device=dev)
-        for _ in range(3):
-            cyc.zero_()
-            st = _lib.lib().egtr_msda_tile_phase_cycles(torch.cuda.current_stream().cuda_stream, value.data_ptr(),
-                                                        shp.data_ptr(), lsi.data_ptr(), loc.data_ptr(),
-                                                        attn.data_ptr(), a.batch, value.shape[1], shp.shape[0],
-                                                        loc.shape[1], 4, out.data_ptr(), cyc.data_ptr())
-            _lib.check(st, "phase cycles")
-            torch.cuda.synchronize()
-        c = cyc.tolist()
-        print(f"tile kernel phases per work item (s_memtime ticks): A={c[0]/c[3]:.0f} B={c[1]/c[3]:.0f} "
-              f"C={c[2]/c[3]:.0f} items={c[3]}")
+        fn = lambda: k.ms_deform_attn_forward_fused(value, shp, lsi, off_v, log_v, refp, False, None)
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
