@@ -254,6 +254,79 @@ def make_targets(batch, cfg, dev, seed):
     return out
 
 
+class MsdaBwdProbe:
+    """Remembers the operands of the most recent encoder-shaped (Lq == S) MSDA backward launch."""
+
+    def __init__(self):
+        from egtr_amd import load_custom
+        self._cls = load_custom._MultiScaleDeformableAttention
+        self._orig = self._cls.ms_deform_attn_backward
+        self.args = None
+
+    def __enter__(self):
+        probe, orig = self, self._orig
+
+        def bwd(value, shapes, lsi, loc, attn, grad_out, step, variant=0):
+            if loc.shape[1] == value.shape[1]:
+                probe.args = (value, shapes, lsi, loc, attn, grad_out, step)
+            return orig(value, shapes, lsi, loc, attn, grad_out, step, variant)
+
+        self._cls.ms_deform_attn_backward = staticmethod(bwd)
+        return self
+
+    def __exit__(self, *a):
+        self._cls.ms_deform_attn_backward = staticmethod(self._orig)
+
+
+def time_msda_backward(args, iters=50):
+    """Average duration of the encoder-shaped MSDA backward (both kernels: grad_loc / grad_attn by the wave-per-query
+    kernel, grad_value by the matrix-core tile kernel; the zero-fill of grad_value is part of the call) and its algorithmic
+    bytes: forward reads + grad_out + 2 x grad_value (zero-init + accumulate) + grad_loc + grad_attn."""
+    from egtr_amd.load_custom import load_hip_kernels
+    k = load_hip_kernels()
+    for _ in range(5):
+        k.ms_deform_attn_backward(*args)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        k.ms_deform_attn_backward(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    value, loc = args[0], args[3]
+    B, S, M, D = value.shape
+    Lq = loc.shape[1]
+    fwd = min(S * M * D * 4, Lq * M * 16 * 4 * D * 4) + Lq * M * 32 * 4 + Lq * M * 16 * 4
+    alg = B * (fwd + Lq * M * D * 4 + 2 * S * M * D * 4 + Lq * M * 32 * 4 + Lq * M * 16 * 4)
+    return us, alg
+
+
+def cpu_train_baseline(model, cfg_dict, labels_cpu, budget_s=25.0):
+    """The CPU oracle's train step on the host cores: forward (reference fallback semantics) + Hungarian matching + SGG
+    loss + autograd backward of ONE 600x1000 image per iteration (bounded sample of the bs = 4 step)."""
+    from oracle import detr as O
+    from oracle import loss as OL
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = dict(d_model=256, num_feature_levels=4, encoder_attention_heads=8, bbox_cost=5, giou_cost=2,
+               bbox_loss_coefficient=5, giou_loss_coefficient=2, focal_alpha=0.25)
+    cfg.update(cfg_dict)
+    cfg["dropout"] = 0.0
+    torch.manual_seed(1)
+    pv = torch.randn(1, 3, H_IMG, W_IMG)
+    pm = torch.ones(1, H_IMG, W_IMG, dtype=torch.long)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        out = O.sgg_forward(sd, cfg, pv, pm, backbone=O.resnet50_backbone)
+        total, _, _, _ = OL.sgg_loss(out, labels_cpu[:1], cfg, training=True)
+        total.backward()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 4:
+            break
+    return n / dt, n
+
+
 def train_bench(args, world, rank, dev, dist):
     """Train-step throughput (BASELINE configs[2] shape: 600x1000, N=200, VG heads, fp32, batch 4/GPU, DDP over
     RCCL when world > 1, accumulate 1 so every step carries the gradient all-reduce).  Secondary metric."""
@@ -267,8 +340,10 @@ def train_bench(args, world, rank, dev, dist):
     b = {"pixel_values": torch.randn(batch, 3, H_IMG, W_IMG, device=dev),
          "pixel_mask": torch.ones(batch, H_IMG, W_IMG, dtype=torch.long, device=dev),
          "labels": make_targets(batch, cfg, dev, 7 + rank)}
-    for _ in range(args.warmup):
-        tr.training_step(b)
+    with MsdaBwdProbe() as bprobe:
+        for _ in range(args.warmup):
+            tr.training_step(b)
+        bwd_args = bprobe.args
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -286,14 +361,31 @@ def train_bench(args, world, rank, dev, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        print(json.dumps({
+        result = {
             "metric": "images/sec SGG train step (fwd + loss + bwd + grad all-reduce + AdamW), 600x1000, N=200",
             "value": round(world * batch * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "final_loss": float(loss), "rccl_ranks": args.rccl_ranks,
             "config": {"workload": f"VG train step: ResNet-50, N=200, 6 enc/6 dec, bs={batch}/GPU fp32, DDP x{world} "
-                                   "(BASELINE configs[2] shape)", "parallelism": f"dp{world}"}}))
+                                   "(BASELINE configs[2] shape)", "parallelism": f"dp{world}"}}
+        if bwd_args is not None:
+            us, alg = time_msda_backward(bwd_args)
+            ach = alg / (us * 1e-6) / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_q64_f32<no atomics> + msda_bwd_value_tile_f32",
+                                  "launch": f"encoder layer backward, B={batch}, Lq = S = 12537",
+                                  "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2)}
+        if world == 1 and not args.no_cpu_baseline:
+            ncores = usable_cores()
+            torch.set_num_threads(ncores)
+            labels_cpu = [{k: v.cpu() for k, v in t.items()} for t in b["labels"]]
+            ips, nimg = cpu_train_baseline(model, cfg_dict, labels_cpu, args.cpu_budget)
+            result["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+                                      "kind": "port", "sample": f"{nimg} single-image train iterations (oracle forward "
+                                      "+ matcher + SGG loss + autograd backward, incl. ResNet-50) at 600x1000 / N=200"}
+        print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
 

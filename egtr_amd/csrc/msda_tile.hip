@@ -31,7 +31,11 @@ constexpr int kRecStride = 17;  // record entries per query (16 samples + 1 pad:
 // chunks, never a different code path).  History: per-(sample, corner, channel) global atomics as in
 // the reference (cuh:125-152) = 2.4 ms per encoder launch; LDS ds_add_f32 accumulation = 1.2 ms (LDS float atomics
 // are serialised per lane, ~130 cycles per instruction).
-constexpr int kChunk = 448;  // columns of A per pass (multiple of 32)
+#ifndef EGTR_BWD_CHUNK
+#define EGTR_BWD_CHUNK 448
+#endif
+constexpr int kChunk = EGTR_BWD_CHUNK;  // columns of A per pass (multiple of 32)
+constexpr int kBwdGrid = kChunk <= 160 ? 512 : 256;   // persistent workgroups: 2 per CU when the LDS allows it
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
 int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
                                         const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
                                         int B, int Lq, int S, int L, int P) {
-  hipLaunchKernelGGL(msda_bwd_value_tile_f32, dim3(256), dim3(kThreads), 0, st, grad_out, shapes, lsi, loc, attn,
+  hipLaunchKernelGGL(msda_bwd_value_tile_f32, dim3(kBwdGrid), dim3(kThreads), 0, st, grad_out, shapes, lsi, loc, attn,
                      grad_value, B, Lq, S, L, P);
   return egtr_check_launch();
 }

@@ -77,8 +77,10 @@ def matcher_cost_matrix(logits, boxes, targets, class_cost, bbox_cost, giou_cost
 
 
 def hungarian_match(logits, boxes, targets, class_cost, bbox_cost, giou_cost, smoothing):
-    """dd:2925-3015. Returns (indices [(i_pred, j_tgt) int64 tensors], matching_costs [tensors])."""
-    cost = matcher_cost_matrix(logits, boxes, targets, class_cost, bbox_cost, giou_cost, smoothing).cpu()
+    """dd:2925-3015 (``@torch.no_grad()`` like the reference). Returns (indices [(i_pred, j_tgt) int64 tensors],
+    matching_costs [tensors])."""
+    with torch.no_grad():
+        cost = matcher_cost_matrix(logits, boxes, targets, class_cost, bbox_cost, giou_cost, smoothing).cpu()
     sizes = [len(t["boxes"]) for t in targets]
     idx, costs = [], []
     for i, c in enumerate(cost.split(sizes, -1)):

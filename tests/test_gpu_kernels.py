@@ -808,6 +808,13 @@ def test_device_assignment_equals_scipy_on_random_and_tied_matrices():
                 o += n
                 n_checked += 1
     assert n_checked >= 1000
+    # an image without targets between two ordinary ones: empty assignment, neighbours unaffected
+    mats = [rng.standard_normal((50, 7)).astype(np.float32), np.zeros((50, 0), dtype=np.float32),
+            rng.standard_normal((50, 3)).astype(np.float32)]
+    pi, ti, mc, n_out = hungarian_match(None, None, None, 1, 1, 1, cost_in=[torch.from_numpy(m).to(DEV) for m in mats])
+    assert n_out == [7, 0, 3]
+    a, b = sp(mats[2])
+    assert np.array_equal(pi[7:].cpu().numpy(), a) and np.array_equal(ti[7:].cpu().numpy(), b)
     # invalid entries: scipy raises, the kernel flags the image and returns -1 indices
     bad = np.zeros((8, 3), dtype=np.float32)
     bad[2, 1] = np.nan
