@@ -50,7 +50,9 @@ constexpr int kWaveEntries = 8 * kHeadStride;   // per array per wave
 // one query per workgroup, wave w gathers samples 4w .. 4w+3 (16 loads in flight at once) and the four partial sums
 // are added in sample order through LDS.
 constexpr long long kSplitMaxQueries = 1024;
-template <bool FUSED, bool SPLIT = false>
+// BOX (FUSED only): `ref` holds 4-d reference boxes [nq, L, 4] = (cx, cy, w, h) and the locations are
+// ref.xy + offset / P * ref.wh * 0.5 (deformable_detr.py:1074-1081, iterative box refinement / two-stage heads).
+template <bool FUSED, bool SPLIT = false, bool BOX = false>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
@@ -85,9 +87,16 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
   const int head_s = lane >> 3, s0 = (lane & 7) * 2;
   if (FUSED) {
     const int lvl = s0 / P;  // both samples of the lane lie in one level (P is even)
-    const float2 r = *reinterpret_cast<const float2*>(ref + ((size_t)q * L + lvl) * 2);
-    const float fw = (float)SEL_W(G, lvl), fh = (float)SEL_H(G, lvl);
-    lc = make_float4(r.x + lc.x / fw, r.y + lc.y / fh, r.x + lc.z / fw, r.y + lc.w / fh);
+    if (BOX) {
+      const float4 r = *reinterpret_cast<const float4*>(ref + ((size_t)q * L + lvl) * 4);
+      const float fp = (float)P;  // same operation order as the reference: ((offset / P) * wh) * 0.5
+      lc = make_float4(r.x + lc.x / fp * r.z * 0.5f, r.y + lc.y / fp * r.w * 0.5f, r.x + lc.z / fp * r.z * 0.5f,
+                       r.y + lc.w / fp * r.w * 0.5f);
+    } else {
+      const float2 r = *reinterpret_cast<const float2*>(ref + ((size_t)q * L + lvl) * 2);
+      const float fw = (float)SEL_W(G, lvl), fh = (float)SEL_H(G, lvl);
+      lc = make_float4(r.x + lc.x / fw, r.y + lc.y / fh, r.x + lc.z / fw, r.y + lc.w / fh);
+    }
     // softmax over the 16 logits of the head: 8 lanes x 2
     float m = fmaxf(aw.x, aw.y);
     m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
@@ -624,14 +633,14 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
   return egtr_check_launch();
 }
 
-extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value,
-                                                 const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                                 const float* sampling_offsets, const float* attn_logits,
-                                                 const float* reference_points, int batch, int spatial_size,
-                                                 int num_heads, int channels, int num_levels, int num_query,
-                                                 int num_point, float* out, float* attn_weight_out, int ld_offsets,
-                                                 int ld_logits, const unsigned char* keep_mask,
-                                                 const unsigned* keep_bits, const float* value_bias) {
+namespace {
+template <bool BOX>
+int launch_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                     const int64_t* level_start_index, const float* sampling_offsets, const float* attn_logits,
+                     const float* reference_points, int batch, int spatial_size, int num_heads, int channels,
+                     int num_levels, int num_query, int num_point, float* out, float* attn_weight_out, int ld_offsets,
+                     int ld_logits, const unsigned char* keep_mask, const unsigned* keep_bits,
+                     const float* value_bias) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
       !out)
     return EGTR_E_ARG;
@@ -642,18 +651,47 @@ extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const flo
       (long long)spatial_size * 1024 >= (1ll << 31) || nq >= (1ll << 27))
     return EGTR_E_UNSUPPORTED;
   if (nq <= kSplitMaxQueries) {  // fewer waves than SIMDs: split each query's samples over a workgroup
-    hipLaunchKernelGGL((msda_fwd_q64_f32<true, true>), dim3((int)nq), dim3(kWaves * 64), 0,
+    hipLaunchKernelGGL((msda_fwd_q64_f32<true, true, BOX>), dim3((int)nq), dim3(kWaves * 64), 0,
                        static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index, sampling_offsets,
                        attn_logits, out, (int)nq, num_query, spatial_size, num_levels, num_point, (int)nq,
                        reference_points, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias);
     return egtr_check_launch();
   }
   const int nblk = (int)((nq + kWaves - 1) / kWaves);
-  hipLaunchKernelGGL(msda_fwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
-                     spatial_shapes, level_start_index, sampling_offsets, attn_logits, out, (int)nq, num_query,
-                     spatial_size, num_levels, num_point, nblk, reference_points, attn_weight_out, ld_offsets,
-                     ld_logits, keep_mask, keep_bits, value_bias);
+  hipLaunchKernelGGL((msda_fwd_q64_f32<true, false, BOX>), dim3(nblk), dim3(kWaves * 64), 0,
+                     static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index, sampling_offsets,
+                     attn_logits, out, (int)nq, num_query, spatial_size, num_levels, num_point, nblk,
+                     reference_points, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias);
   return egtr_check_launch();
+}
+}  // namespace
+
+extern "C" int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value,
+                                                 const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                                 const float* sampling_offsets, const float* attn_logits,
+                                                 const float* reference_points, int batch, int spatial_size,
+                                                 int num_heads, int channels, int num_levels, int num_query,
+                                                 int num_point, float* out, float* attn_weight_out, int ld_offsets,
+                                                 int ld_logits, const unsigned char* keep_mask,
+                                                 const unsigned* keep_bits, const float* value_bias) {
+  return launch_fused_f32<false>(stream, value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                 reference_points, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                 num_point, out, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits,
+                                 value_bias);
+}
+
+extern "C" int egtr_msda_forward_fused_box_f32(egtr_stream_t stream, const float* value,
+                                               const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                               const float* sampling_offsets, const float* attn_logits,
+                                               const float* reference_boxes, int batch, int spatial_size,
+                                               int num_heads, int channels, int num_levels, int num_query,
+                                               int num_point, float* out, float* attn_weight_out, int ld_offsets,
+                                               int ld_logits, const unsigned char* keep_mask,
+                                               const unsigned* keep_bits, const float* value_bias) {
+  return launch_fused_f32<true>(stream, value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
+                                reference_boxes, batch, spatial_size, num_heads, channels, num_levels, num_query,
+                                num_point, out, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits,
+                                value_bias);
 }
 
 extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,

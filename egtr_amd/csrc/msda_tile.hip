@@ -31,11 +31,11 @@ constexpr int kRecStride = 17;  // record entries per query (16 samples + 1 pad:
 // chunks, never a different code path).  History: per-(sample, corner, channel) global atomics as in
 // the reference (cuh:125-152) = 2.4 ms per encoder launch; LDS ds_add_f32 accumulation = 1.2 ms (LDS float atomics
 // are serialised per lane, ~130 cycles per instruction).
-#ifndef EGTR_BWD_CHUNK
-#define EGTR_BWD_CHUNK 448
-#endif
-constexpr int kChunk = EGTR_BWD_CHUNK;  // columns of A per pass (multiple of 32)
-constexpr int kBwdGrid = kChunk <= 160 ? 512 : 256;   // persistent workgroups: 2 per CU when the LDS allows it
+// kChunk: columns of A per pass (multiple of 32).  448 -> 115 KB of A, one workgroup per CU.  Measured round 2 with two
+// workgroups per CU instead (chunk 160 / 128 / 96, grid 512): 321 / 309 / 376 us at B = 1 against 284 us, 653 / 642 /
+// 750 us at B = 4 against 657 us (whole backward) -- the extra chunk passes cost what the second workgroup hides.
+constexpr int kChunk = 448;
+constexpr int kBwdGrid = 256;  // persistent workgroups, one per CU
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -401,9 +401,9 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
             value, value_bias = value + value_bias, None
         needs_grad = torch.is_grad_enabled() and (value.requires_grad or sampling_offsets.requires_grad
                                                   or attention_weights.requires_grad or reference_points.requires_grad)
-        if (not needs_grad and value.is_cuda and reference_points.shape[-1] == 2
+        if (not needs_grad and value.is_cuda
                 and (value.dtype == torch.float32
-                     or (value.dtype == torch.bfloat16 and not output_attentions
+                     or (value.dtype == torch.bfloat16 and not output_attentions and reference_points.shape[-1] == 2
                          and sampling_offsets.dtype == torch.bfloat16))
                 and ops.msda_fused_supported(self.n_heads, self.d_model // self.n_heads, self.n_levels, self.n_points)):
             # inference: softmax + sampling locations (dd:1055-1073) are formed inside the HIP kernel, which also
@@ -441,10 +441,13 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
 class DeformableDetrMultiheadAttention(nn.Module):
     """Decoder self-attention with position embeddings added to queries and keys (dd:1107-1262).
 
-    Returns ``(attn_output, attn_weights(None), scaled_queries [B,M,N,D], keys [B,M,N,D])``; the last two only when
-    ``output_attention_states``.  The probability map itself is never materialised, so ``output_attentions=True``
-    and attention masks / attention dropout are not supported (EGTR runs with output_attentions=False,
-    attention_dropout=0 and no decoder mask: train_egtr.py:294-315, dd:1853)."""
+    Returns ``(attn_output, attn_weights, scaled_queries [B,M,N,D], keys [B,M,N,D])``; the last two only when
+    ``output_attention_states``.  EGTR's configuration (output_attentions=False, attention_dropout=0, no decoder
+    mask: train_egtr.py:294-315, dd:1853) runs the fused HIP kernel, which never materialises the probability map.
+    The three options that need the map -- ``output_attentions=True``, an ``attention_mask`` ([B, N] padding mask,
+    expanded like dd:1198-1213) and attention dropout in training (dd:1232-1234) -- take the explicit route
+    ``softmax(q k^T + mask)`` as two batched device GEMMs (``_attention_with_map``), same order of operations as
+    dd:1187-1237."""
 
     def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0, bias: bool = True):
         super().__init__()
@@ -467,12 +470,7 @@ class DeformableDetrMultiheadAttention(nn.Module):
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_embeddings: Optional[torch.Tensor] = None, output_attentions: bool = False,
                 output_attention_states: bool = False, hidden_with_pos=None):
-        if attention_mask is not None:
-            raise NotImplementedError("decoder self-attention masks are not supported by the fused kernel")
-        if output_attentions:
-            raise NotImplementedError("the fused kernel does not materialise attention probabilities")
-        if self.dropout != 0.0 and self.training:
-            raise NotImplementedError("attention dropout is not supported by the fused kernel (EGTR uses 0.0)")
+        need_map = attention_mask is not None or output_attentions or (self.dropout != 0.0 and self.training)
         hidden_states_original = hidden_states
         if hidden_with_pos is not None:
             hidden_states = hidden_with_pos
@@ -487,8 +485,13 @@ class DeformableDetrMultiheadAttention(nn.Module):
             query_states = ops.module_linear(self.q_proj, hidden_states, alpha=self.scaling)  # dd:1166, scale fused
             key_states = ops.module_linear(self.k_proj, hidden_states)
             value_states = ops.module_linear(self.v_proj, hidden_states_original)
-        attn_output, _, _ = ops.decoder_self_attention(query_states, key_states, value_states, self.num_heads,
-                                                       want_maps=False)
+        attn_weights = None
+        if need_map:
+            attn_output, attn_weights = self._attention_with_map(query_states, key_states, value_states,
+                                                                 attention_mask, output_attentions)
+        else:
+            attn_output, _, _ = ops.decoder_self_attention(query_states, key_states, value_states, self.num_heads,
+                                                           want_maps=False)
         q_maps = k_maps = None
         if output_attention_states:
             # the retained maps [B, M, N, D] (dd:1179-1185) are pure re-layouts of the projections: hand them out
@@ -498,7 +501,28 @@ class DeformableDetrMultiheadAttention(nn.Module):
             q_maps = query_states.view(b_, n_, self.num_heads, self.head_dim).transpose(1, 2)
             k_maps = key_states.view(b_, n_, self.num_heads, self.head_dim).transpose(1, 2)
         attn_output = ops.module_linear(self.out_proj, attn_output)
-        return attn_output, None, q_maps, k_maps
+        return attn_output, attn_weights, q_maps, k_maps
+
+    def _attention_with_map(self, query_states, key_states, value_states, attention_mask, output_attentions):
+        """dd:1187-1237 with the probability map materialised: [B, M, N, N] scores (+ expanded padding mask),
+        softmax, dropout, times V.  Returns (attn_output [B, N, C], map [B, M, N, N] or None)."""
+        b, n, _ = query_states.shape
+        m, d = self.num_heads, self.head_dim
+        q = query_states.view(b, n, m, d).transpose(1, 2)
+        k = key_states.view(b, -1, m, d).transpose(1, 2)
+        v = value_states.view(b, -1, m, d).transpose(1, 2)
+        src = k.shape[2]
+        scores = torch.matmul(q, k.transpose(2, 3))  # queries are already scaled (dd:1166)
+        if attention_mask is not None:
+            if attention_mask.dim() == 2:  # [B, src] of 1 = attend / 0 = padding  ->  additive [B, 1, N, src]
+                keep = attention_mask[:, None, None, :].to(scores.dtype).expand(b, 1, n, src)
+                attention_mask = (1.0 - keep).masked_fill((1.0 - keep).bool(), torch.finfo(scores.dtype).min)
+            if attention_mask.shape != (b, 1, n, src):
+                raise ValueError(f"Attention mask should be of size {(b, 1, n, src)}, but is {tuple(attention_mask.shape)}")
+            scores = scores + attention_mask
+        probs = nn.functional.softmax(scores, dim=-1)
+        out = torch.matmul(nn.functional.dropout(probs, p=self.dropout, training=self.training), v)
+        return out.transpose(1, 2).reshape(b, n, m * d), (probs if output_attentions else None)
 
 
 class DeformableDetrEncoderLayer(nn.Module):
@@ -767,7 +791,7 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
             x2 = encoder_hidden_states.reshape(1, bsz_ * seq_, dm_).expand(nl, -1, -1)
             values = torch.bmm(x2, w_t).view(nl, bsz_, seq_, dm_)
             lay0 = self.layers[0].encoder_attn
-            if (reference_points.shape[-1] == 2 and self.bbox_embed is None and not output_attentions
+            if (not output_attentions and (reference_points.shape[-1] == 2 or values.dtype == torch.float32)
                     and ops.msda_fused_supported(lay0.n_heads, lay0.d_model // lay0.n_heads, lay0.n_levels,
                                                  lay0.n_points)):
                 # the fused MSDA kernel applies the bias (times the sum of the valid corner weights) and skips padded

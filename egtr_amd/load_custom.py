@@ -73,8 +73,9 @@ class _MultiScaleDeformableAttention:
     @staticmethod
     def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
                                      reference_points, want_weights=False, keep_mask=None, value_bias=None):
-        """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` computed in the kernel
-        (deformable_detr.py:1055-1073, 2-d reference points).  fp32, M = 8, D = 32, L*P = 16; no autograd.
+        """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` (2-d reference points) or
+        ``loc = box.xy + offset / P * box.wh * 0.5`` (4-d reference boxes) computed in the kernel
+        (deformable_detr.py:1055-1081).  fp32, M = 8, D = 32, L*P = 16; no autograd.
         sampling_offsets [B,Lq,M,L,P,2] / attn_logits [B,Lq,M,L*P] may be column blocks of one wider Linear output
         (any row stride, unit inner strides); keep_mask [B,S] bool: padded tokens are skipped (== zeroed value rows).
         value_bias [M*D]: ``value`` is the bias-free value projection and the bias is applied inside the kernel (times the
@@ -88,9 +89,12 @@ class _MultiScaleDeformableAttention:
             _chk(t, n, torch.float32)
         _chk(spatial_shapes, "spatial_shapes", torch.int64)
         _chk(level_start_index, "level_start_index", torch.int64)
-        if tuple(reference_points.shape) != (B, Lq, L, 2):
-            raise RuntimeError(f"ms_deform_attn_forward_fused: reference_points must be [B, Lq, L, 2], "
-                               f"got {tuple(reference_points.shape)}")
+        if tuple(reference_points.shape) not in ((B, Lq, L, 2), (B, Lq, L, 4)):
+            raise RuntimeError(f"ms_deform_attn_forward_fused: reference_points must be [B, Lq, L, 2] or "
+                               f"[B, Lq, L, 4], got {tuple(reference_points.shape)}")
+        # 4-d reference boxes: loc = box.xy + offset / P * box.wh * 0.5 (deformable_detr.py:1074-1081)
+        entry = (lib.egtr_msda_forward_fused_box_f32 if reference_points.shape[-1] == 4
+                 else lib.egtr_msda_forward_fused_vbias_f32)
 
         def rows(t, width, name):  # [B, Lq, width...] -> row stride in floats (dense inner dims, uniform row stride)
             if not t.is_cuda or t.dtype != torch.float32:
@@ -120,13 +124,11 @@ class _MultiScaleDeformableAttention:
             vb = _chk(value_bias.detach().contiguous(), "value_bias", torch.float32)
             if vb.numel() != M * D:
                 raise RuntimeError(f"value_bias must have {M * D} elements, got {vb.numel()}")
-        st = lib.egtr_msda_forward_fused_vbias_f32(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
-                                                   level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
-                                                   reference_points.data_ptr(), B, S, M, D, L, Lq, P,
-                                                   out.data_ptr(), wts.data_ptr() if want_weights else None, ld_off,
-                                                   ld_log, km.data_ptr() if km is not None else None,
-                                                   kbits.data_ptr() if kbits is not None else None,
-                                                   vb.data_ptr() if vb is not None else None)
+        st = entry(_stream(), value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                   off2.data_ptr(), log2.data_ptr(), reference_points.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(),
+                   wts.data_ptr() if want_weights else None, ld_off, ld_log,
+                   km.data_ptr() if km is not None else None, kbits.data_ptr() if kbits is not None else None,
+                   vb.data_ptr() if vb is not None else None)
         _lib.check(st, "ms_deform_attn_forward_fused")
         return out, wts
 

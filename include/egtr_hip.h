@@ -86,6 +86,17 @@ int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value, 
                                       const unsigned char* keep_mask, const unsigned* keep_bits,
                                       const float* value_bias);
 
+/* The same with 4-d reference BOXES [B, Lq, L, 4] = (cx, cy, w, h) scaled by the valid ratios: sampling location =
+ * box.xy + offset / num_point * box.wh * 0.5 (model/deformable_detr.py:1074-1081) -- the form the decoder's
+ * cross-attention takes from its second layer on under iterative box refinement (dd:1903-1918, egtr.py:148-154). */
+int egtr_msda_forward_fused_box_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                    const int64_t* level_start_index, const float* sampling_offsets,
+                                    const float* attn_logits, const float* reference_boxes, int batch,
+                                    int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                    int num_point, float* out, float* attn_weight_out, int ld_offsets, int ld_logits,
+                                    const unsigned char* keep_mask, const unsigned* keep_bits,
+                                    const float* value_bias);
+
 /* egtr_msda_forward_f32 with an explicit kernel choice (A/B parity tests): 0 = automatic, 1 = the wave-per-query
  * kernel (M = 8, D = 32, L*P = 16), 3 = the generic one-thread-per-element kernel (any shape).  Both compute the same
  * function; EGTR_E_UNSUPPORTED if the shape rules out the requested kernel. */

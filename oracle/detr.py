@@ -199,7 +199,8 @@ def resnet50_backbone(sd, pixel_values, pixel_mask, prefix="model.backbone.conv_
 
 # --------------------------------------------------------------------------------------- full model
 def detr_model_forward(sd, cfg, pixel_values, pixel_mask, backbone=stub_backbone, core=None):
-    """DeformableDetrModel.forward (dd:2161-2390), single-stage, no box refinement.
+    """DeformableDetrModel.forward (dd:2161-2390), single-stage; ``cfg["with_box_refine"]`` turns the decoder's
+    iterative box refinement on (dd:1903-1918).
 
     Returns dict with encoder_last_hidden_state, intermediate_hidden_states [B,Ld,N,d],
     init_reference_points [B,N,2], intermediate_reference_points [B,Ld,N,2], queries/keys tuples."""
@@ -249,15 +250,26 @@ def detr_model_forward(sd, cfg, pixel_values, pixel_mask, backbone=stub_backbone
     ref = _lin(sd, "model.reference_points", query_embed).sigmoid()  # :2342
     h = target
     inter, inter_ref, qs, ks = [], [], [], []
+    init_ref = ref
     for i in range(cfg["decoder_layers"]):
-        ref_in = ref[:, :, None] * vr[:, None]  # :1865-1867
+        if ref.shape[-1] == 4:  # :1857-1862 (after the first refinement step)
+            ref_in = ref[:, :, None] * torch.cat([vr, vr], -1)[:, None]
+        else:
+            ref_in = ref[:, :, None] * vr[:, None]  # :1865-1867
         h, q, k = decoder_layer(sd, f"model.decoder.layers.{i}", h, query_embed, ref_in, shapes, lsi, enc, mask, core)
+        if cfg.get("with_box_refine", False):  # iterative box refinement, :1903-1918 (egtr:152-154 hands the heads in)
+            tmp = _mlp(sd, f"bbox_embed.{i}", h, 3)
+            if ref.shape[-1] == 4:
+                new_ref = (tmp + inverse_sigmoid(ref)).sigmoid()
+            else:
+                new_ref = torch.cat([tmp[..., :2] + inverse_sigmoid(ref), tmp[..., 2:]], -1).sigmoid()
+            ref = new_ref.detach()
         inter.append(h)
         inter_ref.append(ref)
         qs.append(q)
         ks.append(k)
     return dict(encoder_last_hidden_state=enc, last_hidden_state=h,
-                intermediate_hidden_states=torch.stack(inter, 1), init_reference_points=ref,
+                intermediate_hidden_states=torch.stack(inter, 1), init_reference_points=init_ref,
                 intermediate_reference_points=torch.stack(inter_ref, 1),
                 decoder_attention_queries=tuple(qs), decoder_attention_keys=tuple(ks),
                 spatial_shapes=shapes, level_start_index=lsi, valid_ratios=vr, mask_flatten=mask)
@@ -272,7 +284,10 @@ def detection_heads(sd, cfg, mo):
         ref = inverse_sigmoid(ref)
         lg = _lin(sd, f"class_embed.{lvl}", hs[:, lvl])
         bx = _mlp(sd, f"bbox_embed.{lvl}", hs[:, lvl], 3).clone()
-        bx[..., :2] += ref  # :297
+        if ref.shape[-1] == 4:
+            bx = bx + ref  # :294-295 (refined references)
+        else:
+            bx[..., :2] += ref  # :297
         logits_all.append(lg)
         boxes_all.append(bx.sigmoid())
     return torch.stack(logits_all, 1), torch.stack(boxes_all, 1)

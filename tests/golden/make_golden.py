@@ -7,7 +7,8 @@ the shims of _ref_import.py) on seeded inputs.  Runs only in the build container
 Fixtures:
   msda.npz        reference ms_deform_attn_core_pytorch (dd:925-960) fwd + autograd bwd, fp32 & fp64,
                   incl. out-of-range samples; M=8,D=32 and an odd M=3,D=20,P=2,L=2 case.
-  mha.npz         DeformableDetrMultiheadAttention (dd:1107-1262): out, scaled q, k.
+  mha.npz         DeformableDetrMultiheadAttention (dd:1107-1262): out, scaled q, k; and a run with a padding mask
+                  and output_attentions=True (dd:1198-1237): out, probability map.
   sgg_small.npz   full DetrForSceneGraphGeneration (stub backbone), 2 images (one padded), N=24, Le=2, Ld=3:
                   encoder/decoder states, q/k, logits, boxes, relation logits, connectivity, gate;
                   eval-mode and train-mode loss dicts, Hungarian indices, matching costs, gradient norms.
@@ -42,7 +43,7 @@ def np_(t):
 def ref_config(**over):
     base = dict(num_queries=24, encoder_layers=2, decoder_layers=3, dropout=0.0, auxiliary_loss=False)
     base.update({k: v for k, v in over.items() if k in ("num_queries", "encoder_layers", "decoder_layers",
-                                                         "dropout", "auxiliary_loss")})
+                                                         "dropout", "auxiliary_loss", "with_box_refine")})
     cfg = dd.DeformableDetrConfig(**base)
     extra = dict(num_labels=12, num_rel_labels=7, ce_loss_coefficient=2.0, rel_loss_coefficient=15.0,
                  connectivity_loss_coefficient=30.0, smoothing=1e-14, rel_sample_negatives=80,
@@ -89,8 +90,13 @@ def gen_mha():
     pos = torch.from_numpy(rng.standard_normal((2, 37, 256))).float()
     with torch.no_grad():
         o, _, q, k = m(x, position_embeddings=pos, output_attention_states=True)
+        # the options EGTR leaves off (dd:1198-1237): a [B, N] padding mask and the probability map handed back
+        mask = torch.ones(2, 37)
+        mask[0, 30:] = 0
+        mask[1, ::5] = 0
+        om, wm, _, _ = m(x, attention_mask=mask, position_embeddings=pos, output_attentions=True)
     np.savez_compressed(os.path.join(HERE, "mha.npz"), shapes=json.dumps(shapes), seed=11, x=np_(x), pos=np_(pos),
-                        out=np_(o), q=np_(q), k=np_(k))
+                        out=np_(o), q=np_(q), k=np_(k), mask=np_(mask), out_masked=np_(om), attn_masked=np_(wm))
     print("mha.npz", o.shape, q.shape)
 
 
@@ -101,7 +107,7 @@ def build_ref_model(cfg_over, seed):
     model = eg.DetrForSceneGraphGeneration(cfg, fg_matrix=fg)
     full = model.state_dict()
     shapes = {k: tuple(v.shape) for k, v in full.items()}
-    sd = W.fill_state_dict(shapes, seed=seed)
+    sd = W.fill_state_dict(shapes, seed=seed, alias_heads=not cfg_over.get("with_box_refine", False))
     sd["triplet_dist"], sd["rel_dist"] = full["triplet_dist"].clone(), full["rel_dist"].clone()
     # the reference's tables must equal our restated construction (egtr:169-183 precedence quirk)
     t2, r2 = W.freq_bias_tables(fg, eps=cfg.freq_bias_eps)
@@ -188,6 +194,38 @@ def gen_sgg_small():
     np.savez_compressed(os.path.join(HERE, "sgg_small_aux.npz"), cfg=json.dumps(cfg_dict2), train_loss=np_(out_a.loss),
                         train_loss_dict=json.dumps({k: float(v) for k, v in out_a.loss_dict.items()}))
     print("sgg_small_aux.npz", float(out_a.loss))
+
+
+def gen_sgg_small_refine():
+    """with_box_refine=True (egtr:148-154, dd:1903-1918): per-level heads, 4-d reference points from the second
+    decoder layer on (dd:1074-1081 in the cross-attention, egtr:294-295 in the box head)."""
+    model, cfg, cfg_dict, shapes = build_ref_model(dict(with_box_refine=True, auxiliary_loss=True), seed=71)
+    model.eval()
+    rng = W.rng_inputs(72)
+    B, H, Wd = 2, 96, 128
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    pm[1, 72:, :] = 0
+    pm[1, :, 112:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    targets = W.make_targets(73, B, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)
+    res = dict(cfg=json.dumps(cfg_dict), shapes=json.dumps(shapes), seed=71, input_seed=72, target_seed=73,
+               H=H, W=Wd, valid1=np.array([72, 112]))
+    with torch.no_grad():
+        out, cap, qk = run_ref(model, pv, pm)
+    res.update(logits=np_(out.logits), pred_boxes=np_(out.pred_boxes), rel_mlp=np_(cap["rel_mlp"]),
+               conn_logits=np_(cap["conn"]), inter=np_(qk["inter"]), init_ref=np_(qk["init_ref"]),
+               inter_ref=np_(cap["mo"].intermediate_reference_points))
+    model.train()
+    model.zero_grad()
+    out_t, _, _ = run_ref(model, pv, pm, labels=targets)
+    out_t.loss.backward()
+    res["train_loss"] = np_(out_t.loss)
+    res["train_loss_dict"] = json.dumps({k: float(v) for k, v in out_t.loss_dict.items()})
+    res["grad_norms"] = json.dumps({n: float(p.grad.norm()) for n, p in model.named_parameters()
+                                    if p.grad is not None})
+    np.savez_compressed(os.path.join(HERE, "sgg_small_refine.npz"), **res)
+    print("sgg_small_refine.npz", float(out_t.loss), res["inter_ref"].shape)
 
 
 def gen_sgg_full():
@@ -289,7 +327,7 @@ def gen_sgg_full_train():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["msda", "mha", "small", "full", "stress", "full_train"]
+    which = sys.argv[1:] or ["msda", "mha", "small", "refine", "full", "stress", "full_train"]
     torch.set_num_threads(8)
     if "msda" in which:
         gen_msda()
@@ -297,6 +335,8 @@ if __name__ == "__main__":
         gen_mha()
     if "small" in which:
         gen_sgg_small()
+    if "refine" in which:
+        gen_sgg_small_refine()
     if "full" in which:
         gen_sgg_full()
     if "stress" in which:

@@ -35,8 +35,9 @@ def _scale_for(name, shape):
     return ("normal", 0.1)
 
 
-def fill_state_dict(shapes, seed, dtype=torch.float32, skip=("triplet_dist", "rel_dist")):
-    """shapes: {key: tuple}. Keys are filled in sorted order from one PCG64 stream."""
+def fill_state_dict(shapes, seed, dtype=torch.float32, skip=("triplet_dist", "rel_dist"), alias_heads=True):
+    """shapes: {key: tuple}. Keys are filled in sorted order from one PCG64 stream.  ``alias_heads=False``: a
+    with_box_refine=True model, whose per-level heads are separate clones (egtr:148-154)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = {}
     for k in sorted(shapes):
@@ -56,9 +57,12 @@ def fill_state_dict(shapes, seed, dtype=torch.float32, skip=("triplet_dist", "re
     # checkpoint carries identical tensors under every index, so make the synthetic one do the same.
     for k in list(sd):
         for head in ("class_embed.", "bbox_embed."):
-            if k.startswith(head):
+            if alias_heads and k.startswith(head):
                 rest = k[len(head):].split(".", 1)[1]
                 sd[k] = sd[head + "0." + rest]
+        # with_box_refine=True registers the box heads a second time under the decoder (egtr:154): same tensors
+        if k.startswith("model.decoder.bbox_embed."):
+            sd[k] = sd[k[len("model.decoder."):]]
     return sd
 
 

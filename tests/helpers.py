@@ -10,7 +10,7 @@ import weights as W
 
 def product_config(cfg_dict):
     from egtr_amd.deformable_detr import DeformableDetrConfig
-    base_keys = ("num_queries", "encoder_layers", "decoder_layers", "dropout", "auxiliary_loss")
+    base_keys = ("num_queries", "encoder_layers", "decoder_layers", "dropout", "auxiliary_loss", "with_box_refine")
     cfg = DeformableDetrConfig(**{k: cfg_dict[k] for k in base_keys if k in cfg_dict})
     for k, v in cfg_dict.items():
         if k not in base_keys:
@@ -32,7 +32,7 @@ def build_product_model(cfg_dict, shapes, seed, stub_backbone=True, device="cpu"
         model = DetrForSceneGraphGeneration(cfg, fg_matrix=fg)
     finally:
         pdd.DeformableDetrTimmConvEncoder = orig
-    sd = W.fill_state_dict(shapes, seed=seed)
+    sd = W.fill_state_dict(shapes, seed=seed, alias_heads=not cfg_dict.get("with_box_refine", False))
     sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(fg, cfg.freq_bias_eps)
     return model, cfg, sd
 
@@ -61,7 +61,8 @@ def product_heads(model, pv, pm):
                               output_attention_states=True, return_dict=True)
         enc, last = outputs.encoder_last_hidden_state, outputs.last_hidden_state
         logits, boxes, _, _, rel, conn, _, _ = model._heads(outputs, want_gate_mean=False)
-    return dict(logits=logits, pred_boxes=boxes, rel_logits=rel, conn_logits=conn, last_hidden=last, enc=enc)
+    return dict(logits=logits, pred_boxes=boxes, rel_logits=rel, conn_logits=conn, last_hidden=last, enc=enc,
+                inter=outputs.intermediate_hidden_states, inter_ref=outputs.intermediate_reference_points)
 
 
 def rel_mlp_from_logits(rel_logits, logits, triplet_dist):

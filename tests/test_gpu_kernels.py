@@ -294,6 +294,36 @@ def test_self_attention_vs_reference_golden(golden_dir):
     assert (q.cpu() - _t(g["q"])).abs().max() < 1e-5 and (k.cpu() - _t(g["k"])).abs().max() < 1e-5
 
 
+def test_self_attention_mask_map_and_dropout_options(golden_dir):
+    """dd:1198-1237: padding mask + output_attentions=True against the reference module's fixture; without a mask the
+    explicit route equals the fused kernel; attention dropout in training runs and keeps the expectation."""
+    from egtr_amd.deformable_detr import DeformableDetrMultiheadAttention
+    g = Hh.load_golden(golden_dir, "mha.npz")
+    shapes = json.loads(str(g["shapes"]))
+    m = DeformableDetrMultiheadAttention(256, 8)
+    m.load_state_dict(W.fill_state_dict(shapes, seed=int(g["seed"])))
+    m = m.to(DEV).eval()
+    x, pos = _t(g["x"]).to(DEV), _t(g["pos"]).to(DEV)
+    with torch.no_grad():
+        o, w, _, _ = m(x, attention_mask=_t(g["mask"]).to(DEV), position_embeddings=pos, output_attentions=True)
+        o_fused, w_none, _, _ = m(x, position_embeddings=pos)
+        o_map, w_map, _, _ = m(x, position_embeddings=pos, output_attentions=True)
+    assert w_none is None and w.shape == (2, 8, 37, 37)
+    assert (o.cpu() - _t(g["out_masked"])).abs().max() < 2e-5
+    assert (w.cpu() - _t(g["attn_masked"])).abs().max() < 1e-6
+    assert (o_map - o_fused).abs().max() < 2e-5 and (w_map.sum(-1) - 1).abs().max() < 1e-5
+    md = DeformableDetrMultiheadAttention(256, 8, dropout=0.25)
+    md.load_state_dict(m.state_dict())
+    md = md.to(DEV).train()
+    torch.manual_seed(0)
+    outs = torch.stack([md(x, position_embeddings=pos)[0].detach() for _ in range(200)])
+    assert (outs[0] - outs[1]).abs().max() > 1e-3  # dropout is live
+    assert (outs.mean(0) - o_fused).abs().max() < 0.25 * float(o_fused.abs().max())  # E[dropout(p) v] = p v
+    md.eval()
+    with torch.no_grad():
+        assert (md(x, position_embeddings=pos)[0] - o_fused).abs().max() == 0  # eval: the fused kernel again
+
+
 # --------------------------------------------------------------------------------------------- relation head
 def _head_inputs(seed, B, N, T, R, C):
     rng = W.rng_inputs(seed)

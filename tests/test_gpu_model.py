@@ -88,6 +88,45 @@ def test_loss_and_grads_small_vs_reference(small, training):
                 assert (params[k[6:]].grad.cpu() - ref_g).abs().max() < 5e-3 * max(1.0, float(ref_g.abs().max())), k
 
 
+def test_box_refine_model_vs_reference(golden_dir):
+    """with_box_refine=True (egtr:148-154, dd:1903-1918): per-level heads and 4-d reference boxes -- in inference through
+    the fused MSDA kernel's box form (dd:1074-1081), in training through the autograd composition -- against the
+    reference's own outputs, loss dict (auxiliary losses on) and gradient norms."""
+    g = Hh.load_golden(golden_dir, "sgg_small_refine.npz")
+    cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    assert set(sd) == set(model.state_dict()), sorted(set(sd) ^ set(model.state_dict()))[:5]
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    pv, pm = Hh.small_inputs(g)
+    pv, pm = pv.to(DEV), pm.to(DEV)
+    ph = Hh.product_heads(model, pv, pm)
+    logits, boxes, rel, conn = ph["logits"], ph["pred_boxes"], ph["rel_logits"], ph["conn_logits"]
+    tol = 1e-3
+    assert ph["inter_ref"].shape[-1] == 4
+    assert (ph["inter_ref"].cpu() - _t(g["inter_ref"])).abs().max() < tol
+    assert (ph["inter"].cpu() - _t(g["inter"])).abs().max() < tol
+    assert (logits.cpu() - _t(g["logits"])).abs().max() < tol
+    assert (boxes.cpu() - _t(g["pred_boxes"])).abs().max() < tol
+    assert (conn.cpu() - _t(g["conn_logits"])).abs().max() < tol
+    rel_mlp = Hh.rel_mlp_from_logits(rel.cpu(), logits.cpu(), sd["triplet_dist"])
+    assert (rel_mlp - _t(g["rel_mlp"])).abs().max() < tol
+    model.train()
+    targets = [{k: t.to(DEV) for k, t in d.items()}
+               for d in W.make_targets(int(g["target_seed"]), 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+    out = model(pixel_values=pv, pixel_mask=pm, labels=targets, output_attention_states=True)
+    ref = json.loads(str(g["train_loss_dict"]))
+    assert set(ref) == set(out.loss_dict)
+    for k, v in ref.items():
+        assert abs(float(out.loss_dict[k]) - v) < 1e-3 * max(1.0, abs(v)), (k, float(out.loss_dict[k]), v)
+    assert abs(float(out.loss) - float(g["train_loss"])) < 1e-3 * abs(float(g["train_loss"]))
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    for n, v in json.loads(str(g["grad_norms"])).items():
+        got = float(params[n].grad.norm())
+        assert abs(got - v) < 5e-3 * max(abs(v), 1e-2), (n, got, v)
+
+
 def test_hungarian_indices_bit_exact_on_device_outputs(small):
     """Matcher fed with the DEVICE model's own outputs must reproduce the reference's assignment."""
     from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher

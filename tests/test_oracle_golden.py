@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+import helpers as Hh
 import weights as W
 from oracle import detr as O
 from oracle import loss as OL
@@ -159,6 +160,36 @@ def test_aux_loss_vs_reference(golden_dir):
     for k, v in ref.items():
         assert abs(float(ld[k]) - v) < 2e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
     assert abs(float(total) - float(ga["train_loss"])) < 2e-4 * abs(float(ga["train_loss"]))
+
+
+def test_box_refine_forward_and_loss_vs_reference(golden_dir):
+    """with_box_refine=True (egtr:148-154): per-level heads, decoder-side refinement (dd:1903-1918), 4-d reference
+    points in the cross-attention (dd:1074-1081) and in the box head (egtr:294-295)."""
+    g = _load(golden_dir, "sgg_small_refine.npz")
+    cfg = O_cfg(json.loads(str(g["cfg"])))
+    sd = W.fill_state_dict(json.loads(str(g["shapes"])), seed=int(g["seed"]), alias_heads=False)
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg["num_labels"], cfg["num_rel_labels"]),
+                                                            cfg["freq_bias_eps"])
+    pv, pm = Hh.small_inputs(g)
+    targets = W.make_targets(int(g["target_seed"]), 2, cfg["num_queries"], cfg["num_labels"], cfg["num_rel_labels"])
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+    tol = 2e-4
+    assert out["intermediate_reference_points"].shape[-1] == 4
+    assert (out["intermediate_reference_points"] - _t(g["inter_ref"])).abs().max() < tol
+    assert (out["intermediate_hidden_states"] - _t(g["inter"])).abs().max() < tol
+    assert (out["logits"] - _t(g["logits"])).abs().max() < tol
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < tol
+    assert (out["conn_logits"] - _t(g["conn_logits"])).abs().max() < tol
+    node = out["logits"].argmax(-1)
+    bias = torch.stack([sd["triplet_dist"][node[i]][:, node[i]] for i in range(2)], 0)
+    assert (out["rel_logits"] - bias - _t(g["rel_mlp"])).abs().max() < tol
+    total, ld, _, _ = OL.sgg_loss(out, targets, cfg, training=True)
+    ref = json.loads(str(g["train_loss_dict"]))
+    assert set(ref) == set(ld), sorted(set(ref) ^ set(ld))
+    for k, v in ref.items():
+        assert abs(float(ld[k]) - v) < 2e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
+    assert abs(float(total) - float(g["train_loss"])) < 2e-4 * abs(float(g["train_loss"]))
 
 
 def full_case(golden_dir):

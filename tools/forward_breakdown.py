@@ -13,12 +13,10 @@ SEQ = len(sys.argv) > 3  # also print the kernel sequence of each stage
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if "rel_head_fwd" in r[0]]
-# the last rel-head launches of a bench run are the stand-alone roofline probe: take the last segment that holds a
-# whole forward (a few hundred kernels between two relation-head launches)
-k = len(idx) - 1
-while k > 0 and idx[k] - idx[k - 1] < 50:
-    k -= 1
-seg = rows[idx[k - 1] + 1: idx[k] + 1]
+# a bench run also holds eager forwards (warm-up, parity pass) and the stand-alone roofline probes: take the whole
+# forwards (>= 100 kernels between two relation-head launches) and of those the one with the shortest span = a graph replay
+cands = [rows[idx[k - 1] + 1: idx[k] + 1] for k in range(1, len(idx)) if idx[k] - idx[k - 1] >= 100]
+seg = min(cands, key=lambda s_: s_[-1][2] - s_[0][1])
 names = [r[0] for r in seg]
 print(f"one forward: {len(seg)} kernels, span {(seg[-1][2] - seg[0][1]) / 1e6:.3f} ms, busy {sum(r[2] - r[1] for r in seg) / 1e6:.3f} ms")
 
