@@ -403,12 +403,6 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
-__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
-  unsafeAtomicAdd(p + 0, v.x);
-  unsafeAtomicAdd(p + 1, v.y);
-  unsafeAtomicAdd(p + 2, v.z);
-  unsafeAtomicAdd(p + 3, v.w);
-}
 
 // fp32, M = 8, D = 32, L*P = 16.  One wave per query.  LDS record per (head, sample): three 16-byte entries:
 //   off[4] | {w-validity bits, lh, lw, attn} | {Wf, Hf, -, -}
@@ -426,6 +420,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   __shared__ __attribute__((aligned(16))) float2 s_wh[kWaves * kWaveEntries];  // {W, H}
   __shared__ __attribute__((aligned(16))) float s_gl[kWaves * 256];            // grad_loc staging
   __shared__ __attribute__((aligned(16))) float s_ga[kWaves * 128];            // grad_attn staging
+  __shared__ __attribute__((aligned(16))) float s_go[VALUE_ATOMICS ? kWaves * 256 : 4];  // grad_out row, [head][32]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = xcd_remap(blockIdx.x, nblk);
   const int gw = blk * kWaves + wave;
@@ -456,12 +451,13 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     my_a[head_s * kHeadStride + s] = make_float4(__int_as_float(bits), g.lh, g.lw, j ? aw.y : aw.x);
     my_wh[head_s * kHeadStride + s] = make_float2((float)W, (float)H);
   }
+  const int head = lane >> 3, c4 = lane & 7;
+  const float4 g = reinterpret_cast<const float4*>(grad_out + (size_t)q * 256)[lane];
+  if (VALUE_ATOMICS) reinterpret_cast<float4*>(s_go + wave * 256)[lane] = g;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  const int head = lane >> 3, c4 = lane & 7;
-  const float4 g = reinterpret_cast<const float4*>(grad_out + (size_t)q * 256)[lane];
   const int4* ro = my_off + head * kHeadStride;
   const float4* ra = my_a + head * kHeadStride;
   const float2* rwh = my_wh + head * kHeadStride;
@@ -480,17 +476,28 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     float4 v1 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.y);
     float4 v2 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.z);
     float4 v3 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.w);
-    const float w0 = hh * hw * m0, w1 = hh * lw * m1, w2 = lh * hw * m2, w3 = lh * lw * m3;
     // top = grad_out * attn (cuh:114)
     const float4 top = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);
-    if (VALUE_ATOMICS && (bits & 1)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.x),
-                              make_float4(w0 * top.x, w0 * top.y, w0 * top.z, w0 * top.w));
-    if (VALUE_ATOMICS && (bits & 2)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.y),
-                              make_float4(w1 * top.x, w1 * top.y, w1 * top.z, w1 * top.w));
-    if (VALUE_ATOMICS && (bits & 4)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.z),
-                              make_float4(w2 * top.x, w2 * top.y, w2 * top.z, w2 * top.w));
-    if (VALUE_ATOMICS && (bits & 8)) atomic_add4(reinterpret_cast<float*>(gvbase + c4 * 16 + (unsigned)o.w),
-                              make_float4(w3 * top.x, w3 * top.y, w3 * top.z, w3 * top.w));
+    if (VALUE_ATOMICS) {
+      // grad_value scatter (cuh:125-152) in a lane = channel layout: one atomic instruction covers the 32 contiguous
+      // channels of TWO heads = two whole 128-byte lines.  (Device-scope float atomics execute memory-side on this
+      // part, one request per touched line: the (head, channel-quad) layout of the gather above would touch 8 lines
+      // with each of its 4 instructions -- 4x the line requests for the same 256 values.)
+      const float* gs = s_go + wave * 256;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int h2 = 2 * k + (lane >> 5), ch = lane & 31;
+        const int4 o2 = my_off[h2 * kHeadStride + s];
+        const float4 r2 = my_a[h2 * kHeadStride + s];
+        const int b2 = __float_as_int(r2.x);
+        const float lh2 = r2.y, lw2 = r2.z, hh2 = 1.f - lh2, hw2 = 1.f - lw2;
+        const float t2 = gs[h2 * 32 + ch] * r2.w;  // top = grad_out * attn (cuh:114)
+        if (b2 & 1) unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)o2.x) + ch, hh2 * hw2 * t2);
+        if (b2 & 2) unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)o2.y) + ch, hh2 * lw2 * t2);
+        if (b2 & 4) unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)o2.z) + ch, lh2 * hw2 * t2);
+        if (b2 & 8) unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)o2.w) + ch, lh2 * lw2 * t2);
+      }
+    }
     // masked corner values (an out-of-range corner contributes 0 everywhere, cuh:121-150)
     v0.x *= m0; v0.y *= m0; v0.z *= m0; v0.w *= m0;
     v1.x *= m1; v1.y *= m1; v1.z *= m1; v1.w *= m1;
@@ -546,7 +553,6 @@ __global__ void msda_bwd_generic(const T* __restrict__ grad_out, const T* __rest
                                      int P) {
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < n;
        idx += (long long)gridDim.x * blockDim.x) {
-    const int p = (int)(idx % P);
     long long t = idx / P;
     const int l = (int)(t % L);
     t /= L;

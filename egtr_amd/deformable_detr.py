@@ -831,9 +831,10 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 if reference_points.shape[-1] == 4:
                     new_reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
                 else:
-                    new_reference_points = tmp
-                    new_reference_points[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
-                    new_reference_points = new_reference_points.sigmoid()
+                    # same values as the reference's in-place update of tmp[..., :2] (dd:1913-1916), out of place: the
+                    # box head's last Linear is a custom autograd function here, whose output must not be edited
+                    new_reference_points = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points),
+                                                      tmp[..., 2:]], -1).sigmoid()
                 reference_points = new_reference_points.detach()
             intermediate += (hidden_states,)
             intermediate_reference_points += (reference_points,)
