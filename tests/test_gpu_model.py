@@ -356,8 +356,13 @@ def test_graphed_train_step_matches_eager_train_step(small):
     (l0, p0), (l1, p1) = results
     for a, b in zip(l0, l1):
         assert abs(a - b) < 2e-4 * max(1.0, abs(a)), (l0, l1)
+    # AdamW moves an element by ~lr per step whatever the size of its gradient, so an element whose gradient is at
+    # rounding-noise level (the atomics of the MSDA / relation-head backward add in a different order every run) may
+    # step the other way: bounded by 2 * lr * steps per element, and negligible in the norm of the tensor
     for n in p0:
-        assert (p0[n] - p1[n]).abs().max() < 2e-5 * max(1.0, float(p0[n].abs().max())), n
+        d = (p0[n] - p1[n]).float()
+        assert d.abs().max() < 2 * 1e-4 * 3 + 2e-5 * max(1.0, float(p0[n].abs().max())), n
+        assert d.norm() < 1e-4 * max(1.0, float(p0[n].float().norm())), n
 
 
 def test_backbone_folded_inference_path_matches_unfolded():
