@@ -577,6 +577,320 @@ __global__ __launch_bounds__(64) void rel_head_fwd_bf16w(
   }
 }
 
+// ------------------------------------------------------------------------------ fp32 through split-bf16 operands
+// On gfx950 the fp32 matrix rate (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD) IS the fp32 vector rate; the bf16 matrix
+// rate is 16x that.  This kernel is rel_head_fwd_f32 with layers 2 and 3 evaluated on v_mfma_f32_32x32x16_bf16 from
+// THREE-way bf16 splits of both operands:  x = x_hi + x_mid + x_lo  EXACTLY (each piece a bf16 holding 8 of the 24
+// mantissa bits of the fp32 value; the residuals x - x_hi and (x - x_hi) - x_mid are exact in fp32), and
+//   w . h  ~=  w_hi h_hi + (w_hi h_mid + w_mid h_hi) + (w_hi h_lo + w_mid h_mid + w_lo h_hi)
+// -- the six leading cross terms; the three dropped ones are <= 2^-24 |w||h|, the size of ONE fp32 rounding of the
+// product.  Every bf16 x bf16 product is exact in fp32 and the accumulation is fp32 (the main term and the five
+// correction terms in separate accumulators, added once per 32-wide tile), so the result carries fp32-level error
+// (tests/test_gpu_kernels.py::test_relation_head_split_bf16_is_fp32_accurate measures both kernels against float64):
+// 6 MFMAs of 32 cycles per K = 16 instead of 8 of 64 cycles -- 2.67x less matrix time at the same accuracy.
+// Layer 1 (gates, gated sum, ReLU) and the connectivity output layer stay fp32 VALU work.  Inference only (no saved
+// activations).  Operands:
+//   h1 pieces: LDS, [3][32 pairs][264] bf16 (pitch 528 B: conflict-free ds_read_b128), written by layer 1;
+//   W2 / W3 pieces: pre-split and pre-ordered on the host into the exact operand order (egtr_amd/ops.py), so that a
+//   wave-level operand load is one contiguous KiB:
+//     w2x[nt 8][t 16][piece 3][lane 64][8]      A[i = n (lane & 31)][k = 16 t + 8 (lane >> 5) + e]
+//     w3x[nt 8][kb 2][ot OT][piece 3][lane 64][8]  k slot e <-> n = 32 nt + 16 kb + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+constexpr int kHp = 264;  // bf16 elements per LDS row of an h1 piece
+
+// x = hi + mid + lo EXACTLY, by truncation: hi = the top 8 mantissa bits of x (its upper 16 bits as they are), the
+// residual x - hi is exact in fp32 and holds the remaining <= 16 bits, mid = its top 8, and what is left has <= 8
+// significant bits, i.e. already is a bf16.  Pieces are kept as fp32 bit patterns whose low 16 bits are zero; two of
+// them are packed into one dword of bf16 pairs with a single v_perm_b32.
+struct Split3 {
+  unsigned hi, mid, lo;
+};
+__device__ __forceinline__ Split3 split3(float x) {
+  Split3 s;
+  s.hi = __float_as_uint(x) & 0xffff0000u;
+  const float r = x - __uint_as_float(s.hi);
+  s.mid = __float_as_uint(r) & 0xffff0000u;
+  s.lo = __float_as_uint(r - __uint_as_float(s.mid));
+  return s;
+}
+// {bf16(a) in the low half, bf16(b) in the high half} from two fp32 bit patterns with zero low halves
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+__device__ __forceinline__ f32x4v gload_b128_s(unsigned voff, const void* sbase) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase));
+  return v;
+}
+__device__ __forceinline__ f32x4v gload_b128_s1k(unsigned voff, const void* sbase) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(v) : "v"(voff), "s"(sbase));
+  return v;
+}
+__device__ __forceinline__ f32x4v gload_b128_s2k(unsigned voff, const void* sbase) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(v) : "v"(voff), "s"(sbase));
+  return v;
+}
+
+// layer-2 K loop of one 32-wide n tile: 16 steps, the three W2 pieces of a step are three contiguous KiB; PRE steps of
+// loads in flight (counted vmcnt, as in PrefetchRow)
+template <int PRE>
+struct PrefetchX6 {
+  template <int I>
+  static __device__ __forceinline__ void issue(f32x4v (&wq)[PRE][3], unsigned voff, const char* wtile) {
+    wq[I][0] = gload_b128_s(voff, wtile + I * 3072);
+    wq[I][1] = gload_b128_s1k(voff, wtile + I * 3072);
+    wq[I][2] = gload_b128_s2k(voff, wtile + I * 3072);
+    if constexpr (I + 1 < PRE) issue<I + 1>(wq, voff, wtile);
+  }
+  template <int S>
+  static __device__ __forceinline__ void run(f32x4v (&wq)[PRE][3], unsigned voff, const char* wtile,
+                                             const __bf16* hrow, f32x16& acc_m, f32x16& acc_c) {
+    constexpr int newer = 3 * ((15 - S) < (PRE - 1) ? (15 - S) : (PRE - 1));  // own loads issued after this step's
+    vm_wait<newer>(wq[S % PRE][0]);
+    vm_wait<newer>(wq[S % PRE][1]);
+    vm_wait<newer>(wq[S % PRE][2]);
+    const bf16x8 whi = __builtin_bit_cast(bf16x8, wq[S % PRE][0]);
+    const bf16x8 wmid = __builtin_bit_cast(bf16x8, wq[S % PRE][1]);
+    const bf16x8 wlo = __builtin_bit_cast(bf16x8, wq[S % PRE][2]);
+    const bf16x8 hhi = *reinterpret_cast<const bf16x8*>(hrow + 16 * S);
+    const bf16x8 hmid = *reinterpret_cast<const bf16x8*>(hrow + 32 * kHp + 16 * S);
+    const bf16x8 hlo = *reinterpret_cast<const bf16x8*>(hrow + 64 * kHp + 16 * S);
+    acc_c = mfma_bf16(whi, hlo, acc_c);
+    acc_m = mfma_bf16(whi, hhi, acc_m);
+    acc_c = mfma_bf16(wlo, hhi, acc_c);
+    acc_c = mfma_bf16(wmid, hmid, acc_c);
+    acc_c = mfma_bf16(whi, hmid, acc_c);
+    acc_c = mfma_bf16(wmid, hhi, acc_c);
+    if constexpr (S + PRE < 16) {
+      wq[S % PRE][0] = gload_b128_s(voff, wtile + (S + PRE) * 3072);
+      wq[S % PRE][1] = gload_b128_s1k(voff, wtile + (S + PRE) * 3072);
+      wq[S % PRE][2] = gload_b128_s2k(voff, wtile + (S + PRE) * 3072);
+    }
+    if constexpr (S + 1 < 16) run<S + 1>(wq, voff, wtile, hrow, acc_m, acc_c);
+  }
+};
+
+template <int T, int OT>
+__global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void rel_head_fwd_x6(
+    const float* __restrict__ gate_q, const float* __restrict__ gate_k, const float* __restrict__ uq,
+    const float* __restrict__ uk, const float* __restrict__ b1, const unsigned short* __restrict__ w2xr,
+    const float* __restrict__ b2r, const unsigned short* __restrict__ w3xr, const float* __restrict__ b3r,
+    const unsigned short* __restrict__ w2xc, const float* __restrict__ b2c, const float* __restrict__ w3c,
+    const float* __restrict__ b3c, const float* __restrict__ triplet, const int64_t* __restrict__ node_cls, int B,
+    int N, int R, int C1, float* __restrict__ rel_logits, float* __restrict__ conn_logits,
+    float* __restrict__ gate_mean) {
+  // one buffer, two lives: the three h1 pieces (read by every layer-2 step), then the output tiles
+  constexpr int kStride = 32 * OT + 1;
+  static_assert(kRhWaves * 32 * kStride * 4 <= 3 * 32 * kHp * 2, "output tiles fit in the h1 buffer");
+  __shared__ __attribute__((aligned(16))) __bf16 s_h[3 * 32 * kHp];
+  float* const s_out = reinterpret_cast<float*>(s_h);
+  __shared__ int s_tb[32];
+  __shared__ long long s_pp[32];
+  __shared__ float s_cacc[kRhWaves][32];
+  const int lane = threadIdx.x & 63, pi = lane & 31, hf = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int mlp = blockIdx.y;
+  const long long total = (long long)B * N * N;
+  const int tj = (N + 3) >> 2, ti = (N + 7) >> 3;
+  const int b = blockIdx.x / (ti * tj);
+  const int trem = blockIdx.x - b * ti * tj;
+  const int i0 = (trem / tj) * 8, j0 = (trem - (trem / tj) * tj) * 4;
+  const int i_raw = i0 + (pi >> 2), j_raw = j0 + (pi & 3);
+  const bool valid = i_raw < N && j_raw < N;
+  const int i = i_raw < N ? i_raw : N - 1, j = j_raw < N ? j_raw : N - 1;
+  const long long p = ((long long)b * N + i) * N + j;
+  const size_t qi = (size_t)b * N + i, kj = (size_t)b * N + j;
+
+  float g[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float x = gate_q[qi * T + t] + gate_k[kj * T + t];
+    g[t] = 1.f / (1.f + expf(-x));
+  }
+  if (gate_mean != nullptr && mlp == 0 && wv == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      float v = (valid && hf == 0) ? g[t] : 0.f;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      if (lane == 0) unsafeAtomicAdd(gate_mean + t, v / (float)total);
+    }
+  }
+
+  // ---- layer 1: as rel_head_fwd_f32 (fp32); the ReLU output is split into its three bf16 pieces on the way to LDS ------
+  {
+    const int krow_l = (int)kj;
+    const float4 bias4 = reinterpret_cast<const float4*>(b1 + mlp * kHd)[lane];
+    const float4* uq4 = reinterpret_cast<const float4*>(uq) + mlp * (kHd / 4) + lane;
+    const float4* uk4 = reinterpret_cast<const float4*>(uk) + mlp * (kHd / 4) + lane;
+    constexpr int ROW4 = 2 * kHd / 4;
+    float4 kk[4][T];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int kr = __builtin_amdgcn_readlane(krow_l, jj);
+      const float4* pk = uk4 + (size_t)kr * T * ROW4;
+#pragma unroll
+      for (int t = 0; t < T; ++t) kk[jj][t] = pk[t * ROW4];
+    }
+    auto qrow_of = [&](int ii) { return b * N + (i0 + ii < N ? i0 + ii : N - 1); };
+    const int ii0 = wv * (8 / kRhWaves);
+    float4 ua[2][T];
+    {
+      const float4* pq = uq4 + (size_t)qrow_of(ii0) * T * ROW4;
+#pragma unroll
+      for (int t = 0; t < T; ++t) ua[0][t] = pq[t * ROW4];
+    }
+#pragma unroll
+    for (int iu = 0; iu < 8 / kRhWaves; ++iu) {
+      const int ii = ii0 + iu;
+      if (iu + 1 < 8 / kRhWaves) {
+        const float4* pq = uq4 + (size_t)qrow_of(ii + 1) * T * ROW4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) ua[(iu + 1) & 1][t] = pq[t * ROW4];
+      }
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int pp = ii * 4 + jj;
+        float4 acc = bias4;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float4 a = ua[iu & 1][t];
+          const float4 c = kk[jj][t];
+          const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[t]), pp));
+          acc.x += gt * (a.x + c.x);
+          acc.y += gt * (a.y + c.y);
+          acc.z += gt * (a.z + c.z);
+          acc.w += gt * (a.w + c.w);
+        }
+        const Split3 sx = split3(fmaxf(acc.x, 0.f)), sy = split3(fmaxf(acc.y, 0.f)), sz = split3(fmaxf(acc.z, 0.f)),
+                     sw = split3(fmaxf(acc.w, 0.f));
+        __bf16* hp = s_h + pp * kHp + 4 * lane;
+        *reinterpret_cast<uint2*>(hp) = make_uint2(pack_hi16(sx.hi, sy.hi), pack_hi16(sz.hi, sw.hi));
+        *reinterpret_cast<uint2*>(hp + 32 * kHp) = make_uint2(pack_hi16(sx.mid, sy.mid), pack_hi16(sz.mid, sw.mid));
+        *reinterpret_cast<uint2*>(hp + 64 * kHp) = make_uint2(pack_hi16(sx.lo, sy.lo), pack_hi16(sz.lo, sw.lo));
+      }
+    }
+    __syncthreads();   // both waves' rows are in LDS
+  }
+
+  const char* w2x = reinterpret_cast<const char*>(mlp ? w2xc : w2xr);
+  const float* b2 = mlp ? b2c : b2r;
+  f32x16 racc[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[ot][r] = 0.f;
+  float cacc = 0.f;
+  const unsigned voff = (unsigned)lane * 16u;
+  const __bf16* hrow = s_h + pi * kHp + 8 * hf;
+
+  constexpr int kNtPerWave = kHd / 32 / kRhWaves;
+#pragma unroll 1
+  for (int nt = wv * kNtPerWave; nt < (wv + 1) * kNtPerWave; ++nt) {
+    // ---- layer 2: h2^T[n][pair], n = 32 nt + (r&3) + 8 (r>>2) + 4 hf ---------------------------------------
+    f32x16 acc, accc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accc[r] = 0.f; }
+    const char* wtile = w2x + (size_t)nt * (16 * 3072);
+    constexpr int kPre = 4;
+    f32x4v wq[kPre][3];
+    PrefetchX6<kPre>::template issue<0>(wq, voff, wtile);
+    PrefetchX6<kPre>::template run<0>(wq, voff, wtile, hrow, acc, accc);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int n0 = nt * 32 + 8 * rq + 4 * hf;
+      const float4 bb = *reinterpret_cast<const float4*>(b2 + n0);
+      acc[4 * rq + 0] = fmaxf(acc[4 * rq + 0] + accc[4 * rq + 0] + bb.x, 0.f);
+      acc[4 * rq + 1] = fmaxf(acc[4 * rq + 1] + accc[4 * rq + 1] + bb.y, 0.f);
+      acc[4 * rq + 2] = fmaxf(acc[4 * rq + 2] + accc[4 * rq + 2] + bb.z, 0.f);
+      acc[4 * rq + 3] = fmaxf(acc[4 * rq + 3] + accc[4 * rq + 3] + bb.w, 0.f);
+    }
+    if (mlp == 0) {
+      // ---- layer 3 (relation): two K = 16 steps per n tile on the split accumulators; W3 pieces pre-ordered ----------
+      const char* w3t = reinterpret_cast<const char*>(w3xr) + (size_t)nt * (2 * OT * 3072) + voff;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        uint4 phi, pmid, plo;
+        {
+          Split3 sp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sp[e] = split3(acc[8 * kb + e]);
+          phi = make_uint4(pack_hi16(sp[0].hi, sp[1].hi), pack_hi16(sp[2].hi, sp[3].hi), pack_hi16(sp[4].hi, sp[5].hi),
+                           pack_hi16(sp[6].hi, sp[7].hi));
+          pmid = make_uint4(pack_hi16(sp[0].mid, sp[1].mid), pack_hi16(sp[2].mid, sp[3].mid),
+                            pack_hi16(sp[4].mid, sp[5].mid), pack_hi16(sp[6].mid, sp[7].mid));
+          plo = make_uint4(pack_hi16(sp[0].lo, sp[1].lo), pack_hi16(sp[2].lo, sp[3].lo), pack_hi16(sp[4].lo, sp[5].lo),
+                           pack_hi16(sp[6].lo, sp[7].lo));
+        }
+        const bf16x8 hhi = __builtin_bit_cast(bf16x8, phi), hmid = __builtin_bit_cast(bf16x8, pmid),
+                     hlo = __builtin_bit_cast(bf16x8, plo);
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const char* wp = w3t + (kb * OT + ot) * 3072;
+          const bf16x8 whi = *reinterpret_cast<const bf16x8*>(wp);
+          const bf16x8 wmid = *reinterpret_cast<const bf16x8*>(wp + 1024);
+          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wp + 2048);
+          racc[ot] = mfma_bf16(whi, hlo, racc[ot]);
+          racc[ot] = mfma_bf16(wlo, hhi, racc[ot]);
+          racc[ot] = mfma_bf16(wmid, hmid, racc[ot]);
+          racc[ot] = mfma_bf16(whi, hmid, racc[ot]);
+          racc[ot] = mfma_bf16(wmid, hhi, racc[ot]);
+          racc[ot] = mfma_bf16(whi, hhi, racc[ot]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float4 w = *reinterpret_cast<const float4*>(w3c + nt * 32 + 8 * rq + 4 * hf);
+        cacc += w.x * acc[4 * rq + 0] + w.y * acc[4 * rq + 1] + w.z * acc[4 * rq + 2] + w.w * acc[4 * rq + 3];
+      }
+    }
+  }
+
+  if (mlp == 1) {
+    cacc += __shfl_xor(cacc, 32);
+    if (hf == 0) s_cacc[wv][pi] = cacc;
+    __syncthreads();
+    if (wv == 0 && valid && hf == 0) {
+      float v = s_cacc[0][pi];
+#pragma unroll
+      for (int w = 1; w < kRhWaves; ++w) v += s_cacc[w][pi];
+      conn_logits[p] = v + b3c[0];
+    }
+    return;
+  }
+  __syncthreads();   // every wave has finished reading the h1 pieces: the buffer becomes the output staging area
+  float* const my_out = s_out + wv * 32 * kStride;
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      my_out[pi * kStride + ro] = racc[ot][r];
+    }
+  if (wv == 0 && hf == 0) {
+    int tb = -1;
+    if (triplet != nullptr) tb = ((int)node_cls[qi] * C1 + (int)node_cls[kj]) * R;
+    s_tb[pi] = tb;
+    s_pp[pi] = valid ? p : -1;
+  }
+  __syncthreads();
+  for (int pp = wv; pp < 32; pp += kRhWaves) {
+    const long long po = s_pp[pp];
+    if (po < 0) continue;
+    const int tb = s_tb[pp];
+    float* dst = rel_logits + (size_t)po * R;
+    for (int r = lane; r < R; r += 64) {
+      float v = s_out[pp * kStride + r];
+#pragma unroll
+      for (int w = 1; w < kRhWaves; ++w) v += s_out[(w * 32 + pp) * kStride + r];
+      v += b3r[r];
+      if (tb >= 0) v += triplet[tb + r];
+      dst[r] = v;
+    }
+  }
+}
+
 template <int T>
 int launch_T(hipStream_t st, int R, dim3 grid, const float* gate_q, const float* gate_k, const float* uq,
              const float* uk, const float* b1, const float* w2r, const float* b2r, const float* w3r,
@@ -845,3 +1159,40 @@ extern "C" int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* ga
   return egtr_check_launch();
 }
 
+
+extern "C" int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k,
+                                                const float* uq, const float* uk, const float* b1,
+                                                const uint16_t* w2x_rel, const float* b2r, const uint16_t* w3x_rel,
+                                                const float* b3r, const uint16_t* w2x_conn, const float* b2c,
+                                                const float* w3c, const float* b3c, const float* triplet_dist,
+                                                const int64_t* node_cls, int batch, int num_query, int num_slots,
+                                                int hidden, int num_rel, int num_cls_plus1, float* rel_logits,
+                                                float* conn_logits, float* gate_mean) {
+  if (!gate_q || !gate_k || !uq || !uk || !b1 || !w2x_rel || !b2r || !w3x_rel || !b3r || !w2x_conn || !b2c || !w3c ||
+      !b3c || !rel_logits || !conn_logits)
+    return EGTR_E_ARG;
+  if (triplet_dist != nullptr && node_cls == nullptr) return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_slots <= 0 || num_rel <= 0) return EGTR_E_ARG;
+  if (hidden != kHd || num_rel > 64 || num_slots > 10) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long tiles = (long long)batch * ((num_query + 7) / 8) * ((num_query + 3) / 4);
+  if (tiles >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  const dim3 grid((unsigned)tiles, 2);
+#define EGTR_TX(TT)                                                                                                  \
+  case TT:                                                                                                           \
+    if (num_rel <= 32)                                                                                               \
+      hipLaunchKernelGGL((rel_head_fwd_x6<TT, 1>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1,     \
+                         w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c, triplet_dist, node_cls, batch,         \
+                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean);                     \
+    else                                                                                                             \
+      hipLaunchKernelGGL((rel_head_fwd_x6<TT, 2>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1,     \
+                         w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c, triplet_dist, node_cls, batch,         \
+                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean);                     \
+    break;
+  switch (num_slots) {
+    EGTR_TX(1) EGTR_TX(2) EGTR_TX(3) EGTR_TX(4) EGTR_TX(5) EGTR_TX(6) EGTR_TX(7) EGTR_TX(8) EGTR_TX(9) EGTR_TX(10)
+    default: return EGTR_E_UNSUPPORTED;
+  }
+#undef EGTR_TX
+  return egtr_check_launch();
+}

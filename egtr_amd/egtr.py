@@ -169,7 +169,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             node = torch.argmax(logits, dim=-1)
         return ops.relation_head(gate_q, gate_k, uq, uk, b1, rp[1].weight, rp[1].bias, rp[2].weight, rp[2].bias,
                                  cl[1].weight, cl[1].bias, cl[2].weight, cl[2].bias, triplet, node,
-                                 want_gate_mean)
+                                 want_gate_mean, owner=self)
 
     def _matcher(self):
         return DeformableDetrHungarianMatcher(

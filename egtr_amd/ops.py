@@ -3,6 +3,8 @@
 Every op here enqueues on torch's current HIP stream through the C ABI (include/egtr_hip.h); none has a CPU or
 eager-PyTorch fallback -- a missing library raises ``egtr_amd._lib.EgtrHipError``.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -610,8 +612,94 @@ def relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c
     return rel, conn.unsqueeze(-1), gm
 
 
+# fp32 relation head on the bf16 matrix cores through three-way operand splits (csrc/rel_head.hip, rel_head_fwd_x6):
+# fp32-level accuracy (tested against float64) at 2.67x less matrix time.  Inference only; set to False to run the
+# exact-f32 MFMA kernel (v_mfma_f32_32x32x2_f32) everywhere.
+REL_HEAD_SPLIT_BF16 = os.environ.get("EGTR_REL_HEAD_SPLIT_BF16", "1") != "0"
+
+
+def _split3_bf16(w):
+    """fp32 tensor -> [3, ...] bf16 pieces hi / mid / lo with hi + mid + lo == w to fp32 precision (round-to-nearest
+    pieces; the residuals w - hi and (w - hi) - mid are exact in fp32)."""
+    w = w.detach().float()
+    hi = w.to(torch.bfloat16)
+    r = w - hi.float()
+    mid = r.to(torch.bfloat16)
+    lo = (r - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo])
+
+
+def rel_head_split_weights(w2r, w3r, w2c):
+    """The MFMA operand streams of rel_head_fwd_x6 (layouts documented in csrc/rel_head.hip):
+    w2x [8 nt][16 t][3 piece][64 lane][8] per MLP, w3x [8 nt][2 kb][OT][3 piece][64 lane][8] (relation MLP)."""
+    def w2x(w2):
+        p = _split3_bf16(w2).view(3, 8, 32, 16, 2, 8)         # [piece, nt, pi, t, hf, e]
+        return p.permute(1, 3, 0, 4, 2, 5).contiguous()        # [nt, t, piece, hf, pi, e]; lane = 32 hf + pi
+
+    R = w3r.shape[0]
+    OT = 1 if R <= 32 else 2
+    w3p = torch.zeros(32 * OT, w3r.shape[1], dtype=torch.float32, device=w3r.device)
+    w3p[:R] = w3r.detach().float()
+    q = _split3_bf16(w3p).view(3, OT, 32, w3r.shape[1])       # [piece, ot, pi, n]
+    dev = w3r.device
+    nt = torch.arange(8, device=dev).view(8, 1, 1, 1)
+    kb = torch.arange(2, device=dev).view(1, 2, 1, 1)
+    hf = torch.arange(2, device=dev).view(1, 1, 2, 1)
+    e = torch.arange(8, device=dev).view(1, 1, 1, 8)
+    nidx = 32 * nt + 16 * kb + (e & 3) + 8 * (e >> 2) + 4 * hf  # [nt, kb, hf, e]
+    g = q[:, :, :, nidx]                                        # [piece, ot, pi, nt, kb, hf, e]
+    w3x = g.permute(3, 4, 1, 0, 5, 2, 6).contiguous()           # [nt, kb, ot, piece, hf, pi, e]
+    return w2x(w2r), w3x, w2x(w2c)
+
+
+def relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c,
+                             num_rel, triplet_dist=None, node_cls=None, want_gate_mean=False):
+    """Inference forward, fp32 in / fp32 out, layers 2 and 3 on the bf16 matrix cores from split operands
+    (egtr_rel_head_forward_bf16x6_f32; ``w2x_*`` / ``w3x_rel`` from ``rel_head_split_weights``).  No autograd."""
+    lib = _lib.lib()
+    B, N, T = gate_q.shape
+    dev = gate_q.device
+    f32 = [_chk(t.detach().contiguous(), n, torch.float32)
+           for t, n in ((gate_q, "gate_q"), (gate_k, "gate_k"), (uq, "uq"), (uk, "uk"), (b1, "b1"), (b2r, "b2r"),
+                        (b3r, "b3r"), (b2c, "b2c"), (w3c, "w3c"), (b3c, "b3c"))]
+    gq, gk, uq_, uk_, b1_, b2r_, b3r_, b2c_, w3c_, b3c_ = f32
+    R = int(num_rel)
+    OT = 1 if R <= 32 else 2
+    for t, n, shape in ((w2x_rel, "w2x_rel", (8, 16, 3, 2, 32, 8)), (w2x_conn, "w2x_conn", (8, 16, 3, 2, 32, 8)),
+                        (w3x_rel, "w3x_rel", (8, 2, OT, 3, 2, 32, 8))):
+        _chk(t, n, torch.bfloat16)
+        if tuple(t.shape) != shape:
+            raise RuntimeError(f"{n} must have shape {shape}, got {tuple(t.shape)}")
+    rel = torch.empty(B, N, N, R, dtype=torch.float32, device=dev)
+    conn = torch.empty(B, N, N, dtype=torch.float32, device=dev)
+    gm = torch.zeros(T, dtype=torch.float32, device=dev) if want_gate_mean else None
+    td = None
+    c1 = 0
+    if triplet_dist is not None:
+        td = _chk(triplet_dist.detach().contiguous(), "triplet_dist", torch.float32)
+        _chk(node_cls, "node_cls", torch.int64)
+        c1 = td.shape[0]
+    st = lib.egtr_rel_head_forward_bf16x6_f32(
+        _stream(), gq.data_ptr(), gk.data_ptr(), uq_.data_ptr(), uk_.data_ptr(), b1_.data_ptr(), w2x_rel.data_ptr(),
+        b2r_.data_ptr(), w3x_rel.data_ptr(), b3r_.data_ptr(), w2x_conn.data_ptr(), b2c_.data_ptr(), w3c_.data_ptr(),
+        b3c_.data_ptr(), td.data_ptr() if td is not None else None,
+        node_cls.data_ptr() if td is not None else None, B, N, T, 256, R, c1, rel.data_ptr(), conn.data_ptr(),
+        gm.data_ptr() if want_gate_mean else None)
+    _lib.check(st, "egtr_rel_head_forward_bf16x6_f32")
+    return rel, conn.unsqueeze(-1), gm
+
+
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
-                  node_cls=None, want_gate_mean=False):
+                  node_cls=None, want_gate_mean=False, owner=None):
+    """``owner`` (optional nn.Module): where the derived split-bf16 weight streams of the inference kernel are cached."""
+    if (REL_HEAD_SPLIT_BF16 and owner is not None and gate_q.dtype == torch.float32 and gate_q.is_cuda
+            and w2r.shape == (256, 256) and w3r.shape[0] <= 64 and gate_q.shape[-1] <= 10
+            and not (torch.is_grad_enabled() and any(
+                t.requires_grad for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c)))):
+        w2xr, w3xr, w2xc = cached_weights(owner, "rel_head_split_bf16", [w2r, w3r, w2c],
+                                          lambda: rel_head_split_weights(w2r, w3r, w2c))
+        return relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2xr, b2r, w3xr, b3r, w2xc, b2c, w3c, b3c,
+                                        w3r.shape[0], triplet_dist, node_cls, want_gate_mean)
     if gate_q.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and any(
             t.requires_grad for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c))):
         rel, conn, gm = relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,

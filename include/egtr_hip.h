@@ -359,6 +359,23 @@ int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* gate_q, const
                                 int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
                                 float* gate_mean);
 
+/* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
+ * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
+ * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the
+ * bf16 matrix rate is 16x that, so this is 2.67x less matrix time than egtr_rel_head_forward_f32 for the same result to
+ * fp32 rounding.  Inference only.  The weights arrive pre-split and in operand order (raw bfloat16 bits):
+ *   w2x_*  [8 nt][16 t][3 piece][64 lane][8]:  piece(W2)[32 nt + (lane & 31)][16 t + 8 (lane >> 5) + e]
+ *   w3x_rel [8 nt][2 kb][OT][3 piece][64 lane][8], OT = 1 if num_rel <= 32 else 2:
+ *           piece(W3)[32 ot + (lane & 31)][32 nt + 16 kb + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)], rows >= num_rel zero
+ * (egtr_amd/ops.py::rel_head_split_weights builds them); w3c / all biases / tables are fp32 as in the f32 entry. */
+int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
+                                     const float* uk, const float* b1, const uint16_t* w2x_rel, const float* b2r,
+                                     const uint16_t* w3x_rel, const float* b3r, const uint16_t* w2x_conn,
+                                     const float* b2c, const float* w3c, const float* b3c, const float* triplet_dist,
+                                     const int64_t* node_cls, int batch, int num_query, int num_slots, int hidden,
+                                     int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
+                                     float* gate_mean);
+
 /* Pairwise part of the relation-head backward (everything that is not a plain GEMM).  dh1 [2][B*N*N][hidden] is the
  * gradient wrt the pre-ReLU layer-1 output (relation half, connectivity half), produced by rocBLAS GEMMs from the
  * saved activations.  Outputs (fully overwritten): grad_uq / grad_uk [B,N,T,2*hidden], grad_gate_q / grad_gate_k

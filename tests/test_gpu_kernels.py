@@ -354,6 +354,48 @@ def test_relation_head_forward(B, N, T, R):
     assert (rel2.cpu() - rrel2.float()).abs().max() < 2e-4 and gm2 is None
 
 
+@pytest.mark.parametrize("B,N,T,R", [(1, 200, 7, 50), (2, 24, 4, 7), (1, 100, 4, 30), (1, 33, 9, 64), (1, 7, 1, 1),
+                                     (2, 37, 7, 32)])
+def test_relation_head_split_bf16_is_fp32_accurate(B, N, T, R):
+    """The inference kernel evaluates layers 2 / 3 on the bf16 matrix cores from three-way bf16 splits of both operands
+    (six cross terms, fp32 accumulation).  Claim under test: the result is an fp32 result -- against the float64
+    restatement its error is the same size as the error of the exact-f32 MFMA kernel (same 2e-4 bar as
+    test_relation_head_forward, and within 2.5x of that kernel's own max / Frobenius error)."""
+    import cpu_kernels as ck
+    from egtr_amd import ops
+    d, trip, node = _head_inputs(60 + N, B, N, T, R, 11)
+    dd = {k: v.to(DEV) for k, v in d.items()}
+    d64 = {k: v.double() for k, v in d.items()}
+    rrel, rconn, rgm = ck.relation_head(*d64.values(), trip.double(), node, True)
+    rel32, conn32, _ = ops.RelationHeadFunction.apply(*dd.values(), trip.to(DEV), node.to(DEV), True)
+    w2xr, w3xr, w2xc = ops.rel_head_split_weights(dd["w2r"], dd["w3r"], dd["w2c"])
+    rel, conn, gm = ops.relation_head_split_bf16(
+        dd["gate_q"], dd["gate_k"], dd["uq"], dd["uk"], dd["b1"], w2xr, dd["b2r"], w3xr, dd["b3r"], w2xc, dd["b2c"],
+        dd["w3c"], dd["b3c"], R, trip.to(DEV), node.to(DEV), True)
+    for got, got32, ref in ((rel, rel32, rrel), (conn, conn32, rconn)):
+        e = (got.cpu().double() - ref).abs()
+        e32 = (got32.cpu().double() - ref).abs()
+        assert e.max() < 2e-4
+        assert e.max() <= 2.5 * e32.max() + 1e-6, (float(e.max()), float(e32.max()))
+        assert e.norm() <= 2.5 * e32.norm() + 1e-6, (float(e.norm()), float(e32.norm()))
+    assert (gm.cpu() - rgm.float()).abs().max() < 1e-5
+    rel2, _, gm2 = ops.relation_head_split_bf16(
+        dd["gate_q"], dd["gate_k"], dd["uq"], dd["uk"], dd["b1"], w2xr, dd["b2r"], w3xr, dd["b3r"], w2xc, dd["b2c"],
+        dd["w3c"], dd["b3c"], R, None, None, False)
+    rrel2, _, _ = ck.relation_head(*d64.values(), None, None, False)
+    assert (rel2.cpu().double() - rrel2).abs().max() < 2e-4 and gm2 is None
+
+
+def test_relation_head_split_weights_sum_to_the_fp32_weights():
+    """hi + mid + lo reproduces every fp32 weight to <= 2^-24 relative, incl. large / tiny / denormal-range values."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(256, 256, generator=g) * torch.logspace(-12, 6, 256)[:, None]
+    p = ops._split3_bf16(w.to(DEV)).float().cpu()
+    rec = (p[0].double() + p[1].double() + p[2].double()).float()
+    assert ((rec - w).abs() <= w.abs() * 2.0 ** -23).all()
+
+
 @pytest.mark.parametrize("B,N,T,R", [(1, 200, 7, 50), (2, 24, 4, 7), (1, 33, 9, 64), (1, 7, 1, 1), (2, 300, 9, 50)])
 def test_relation_head_forward_bf16_matrix_cores(B, N, T, R):
     """bf16-weight forward (layers 2 / 3 on v_mfma_f32_32x32x16_bf16) against the fp64 restatement evaluated with the

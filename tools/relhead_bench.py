@@ -29,6 +29,20 @@ def main():
     us = e0.elapsed_time(e1) * 1e3 / 50
     fl = 2.0 * B * 200 * 200 * (2 * 256 * 256 + 256 * 64)
     print(f"rel_head fwd B={B}: {us:.1f} us/launch, {fl / us / 1e6:.1f} TFLOP/s (f32 MFMA peak 157)")
+    from egtr_amd import ops
+    w2xr, w3xr, w2xc = ops.rel_head_split_weights(dd["w2r"], dd["w3r"], dd["w2c"])
+    args = (dd["gate_q"], dd["gate_k"], dd["uq"], dd["uk"], dd["b1"], w2xr, dd["b2r"], w3xr, dd["b3r"], w2xc, dd["b2c"],
+            dd["w3c"], dd["b3c"], 50, trip, node, False)
+    for _ in range(5):
+        ops.relation_head_split_bf16(*args)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        ops.relation_head_split_bf16(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    print(f"rel_head fwd B={B} split-bf16 (x6): {us:.1f} us/launch, {fl / us / 1e6:.1f} TFLOP/s algorithmic")
     from egtr_amd.ops import relation_head_bf16w
     wn = ("w2r", "w3r", "w2c", "w3c")
     db = {k: (v.bfloat16() if k in wn else v) for k, v in dd.items()}

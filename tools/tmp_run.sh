@@ -1,4 +1,5 @@
 set -u
 cd "$GRAFT_REPO_ROOT"
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "Warning\|warn" > gpurun_out/suite2.log
-grep -n "Error\|^E \|assert\|passed\|failed" gpurun_out/suite2.log | head -40
+timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "split" 2>&1 | tail -5
+python tools/relhead_bench.py 2>&1 | grep "fwd B"
+python tools/relhead_bench.py 4 2>&1 | grep "x6"
