@@ -126,7 +126,10 @@ def time_rel_head_kernel(args, iters=100):
     third-layer outputs: 2 * B * N^2 * (T * 2Hd + 2 * Hd * Hd + Hd * (R + 1))  (DESIGN.md 4.4)."""
     from egtr_amd import ops
     a, kw = args
-    fn = lambda: ops.relation_head(*a, **kw)  # noqa: E731
+    def fn():
+        with torch.no_grad():  # as in the timed forward: the inference kernel, nothing saved for a backward
+            return ops.relation_head(*a, **kw)
+
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
@@ -569,12 +572,25 @@ def main():
                                                    if pmc.get("l1_gather_bytes") else None)},
         "rccl_ranks": args.rccl_ranks,
     }
-    result["roofline_kernels"] = [
-        result["roofline"],
-        {"bound": "mfma", "kernel": "rel_head_fwd_f32", "launch": f"B={args.batch}, N=200, T=7, R=50",
-         "achieved": round(rel_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-         "frac": round(rel_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-         "algorithmic_flops_per_launch": rel_flops, "avg_launch_us": round(rel_us, 3)}]
+    from egtr_amd import ops as _ops
+    split = bool(_ops.REL_HEAD_SPLIT_BF16) and rel_args[1].get("owner") is not None
+    rel_entry = {"bound": "mfma", "kernel": "rel_head_fwd_x6" if split else "rel_head_fwd_f32",
+                 "launch": f"B={args.batch}, N=200, T=7, R=50",
+                 "achieved": round(rel_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(rel_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                 "algorithmic_flops_per_launch": rel_flops, "avg_launch_us": round(rel_us, 3)}
+    if split:
+        # fp32 result from exact three-way bf16 splits of both operands, six cross terms on v_mfma_f32_32x32x16_bf16,
+        # fp32 accumulation (accuracy vs float64: tests/test_gpu_kernels.py::
+        # test_relation_head_split_bf16_is_fp32_accurate).  `achieved` / `peak` price the ALGORITHMIC fp32 FLOPs against
+        # the fp32 matrix peak; the matrix cores execute 6x the layer-2 / layer-3 products in bf16:
+        n2 = args.batch * 200 * 200
+        executed = 2.0 * n2 * 6 * (2 * 256 * 256 + 256 * 64)
+        rel_entry["arithmetic"] = "fp32 via bf16x6 operand split, fp32 accumulate"
+        rel_entry["bf16_mfma_flops_executed"] = executed
+        rel_entry["frac_of_bf16_dense_peak"] = round(executed / (rel_us * 1e-6) / 1e12 / 2500.0, 4)
+    result["roofline_kernels"] = [result["roofline"], rel_entry]
+    result["config"]["relation_head"] = rel_entry.get("arithmetic", "exact-f32 MFMA")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncores = usable_cores()
         torch.set_num_threads(ncores)

@@ -1,5 +1,5 @@
 set -u
 cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "split" 2>&1 | tail -5
-python tools/relhead_bench.py 2>&1 | grep "fwd B"
-python tools/relhead_bench.py 4 2>&1 | grep "x6"
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+timeout 900 python bench.py 2>gpurun_out/bench_stderr.log | tee gpurun_out/bench_x6.json | cut -c1-3000
+tail -3 gpurun_out/bench_stderr.log
