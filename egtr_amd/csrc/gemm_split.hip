@@ -1,0 +1,215 @@
+// Token-sized fp32 linear layers on the bf16 matrix cores:  C[M, N] = act(A[M, K] . W[N, K]^T + bias)  with fp32 operands
+// in, fp32 out and fp32-level accuracy, from exact three-way bf16 splits of both operands (see rel_head.hip,
+// rel_head_fwd_x6, for the argument: x = hi + mid + lo exactly, the six leading cross terms kept, every bf16 x bf16
+// product exact in fp32, fp32 accumulation; the three dropped terms are <= 2^-24 of the product).
+//
+// Why: the encoder applies five nn.Linear layers per layer to S = 12 537 token rows (value / output projections,
+// sampling offsets + attention weights, the two FFN layers): 1.05 of the 4.1 ms forward, running at 100-125 TFLOP/s in
+// hipBLASLt -- 65-80 % of the fp32 matrix peak of this part, which is its fp32 VECTOR rate (157 TFLOP/s).  The bf16
+// matrix rate is 16x that; six bf16 MFMAs per K = 16 replace eight fp32 MFMAs of twice the length: 2.67x less matrix
+// time for the same result to fp32 rounding.
+//
+// Tiling: a workgroup of 8 waves owns a 128 x 128 (or 64 x 128) tile of C, each wave 32 x 64 (32 x 32) of it on
+// v_mfma_f32_32x32x16_bf16.  K runs in stages of 32: the fp32 A tile is split into its three pieces on the way into
+// LDS; W arrives pre-split and pre-tiled from the host (one contiguous 24 KiB block per stage:
+// wt[N/128][K/32][3 pieces][128 rows][32] bf16, egtr_amd/ops.py::gemm_split_weights).  The global loads of stage s + 1
+// are in flight (inline asm, counted) while stage s is multiplied out of LDS; rows are 80 bytes apart in LDS, which
+// makes the 16-byte operand reads of 32 consecutive rows conflict-free.  60 (45) KiB of LDS and <= 128 registers per
+// lane: two workgroups = sixteen waves per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kBN = 128, kBK = 32;
+constexpr int kPitch = 40;  // bf16 elements per LDS row: 32 + 8 (80 bytes)
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4v gload(const void* p) {
+  f32x4v v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+  return v;
+}
+__device__ __forceinline__ void vm_wait0(f32x4v& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
+
+struct Split3 {
+  unsigned hi, mid, lo;
+};
+// exact truncation split (rel_head.hip): pieces as fp32 bit patterns with zero low halves
+__device__ __forceinline__ Split3 split3(float x) {
+  Split3 s;
+  s.hi = __float_as_uint(x) & 0xffff0000u;
+  const float r = x - __uint_as_float(s.hi);
+  s.mid = __float_as_uint(r) & 0xffff0000u;
+  s.lo = __float_as_uint(r - __uint_as_float(s.mid));
+  return s;
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// A workgroup is 8 waves on a BM x 128 tile, BM = 128 (wave tile 32 x 64) or 64 (wave tile 32 x 32; chosen when 128-row
+// tiles would not give every CU two workgroups).  <= 128 registers per lane: four waves per SIMD, so that the load /
+// split / store phases of one wave run under the matrix work of the others -- with one or two waves per SIMD every
+// per-stage latency (operand reads, barrier, vmcnt, LDS stores) was exposed and the kernel ran at the vendor fp32 rate.
+// MFMA roles: A operand = weight piece (i = n), B operand = activation piece (j = m), so that a lane ends up with 4
+// CONSECUTIVE output columns per accumulator quad: the epilogue stores float4.
+template <int BM, bool RELU>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_bf16_f32(
+    const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wt, const float* __restrict__ bias,
+    float* __restrict__ C, int ldc, int M, int N, int K) {
+  constexpr int WAVES_M = BM / 32;            // 4 or 2
+  constexpr int WAVES_N = 8 / WAVES_M;        // 2 or 4
+  constexpr int NT = 4 / WAVES_N;             // 32-column MFMA tiles per wave: 2 or 1
+  constexpr int AQ = BM / 64;                 // float4 of A per thread and stage (BM rows x 8 float4 / 512 threads)
+  __shared__ __attribute__((aligned(16))) __bf16 sA[3 * BM * kPitch];
+  __shared__ __attribute__((aligned(16))) __bf16 sW[3 * kBN * kPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, hf = lane >> 5;
+  const int nb = blockIdx.x, m0 = blockIdx.y * BM;
+  const int nk = K / kBK;
+
+  // global -> register mapping of one stage
+  //   A: BM x 8 float4, thread t takes idx = t + 512 q: row = idx >> 3, c4 = idx & 7
+  //   W: 1536 16-byte chunks of the contiguous stage block, thread t takes idx = t + 512 q
+  const float* arow[AQ];
+#pragma unroll
+  for (int q = 0; q < AQ; ++q) {
+    const int idx = tid + 512 * q;
+    const int row = min(m0 + (idx >> 3), M - 1);
+    arow[q] = A + (size_t)row * lda + 4 * (idx & 7);
+  }
+  const char* wblk = reinterpret_cast<const char*>(Wt) + (size_t)nb * nk * (3 * kBN * kBK * 2) + (size_t)tid * 16;
+
+  f32x4v ra[AQ], rw[3];
+  auto issue = [&](int s) {
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) ra[q] = gload(arow[q] + s * kBK);
+    const char* wp = wblk + (size_t)s * (3 * kBN * kBK * 2);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) rw[q] = gload(wp + q * 8192);
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) vm_wait0(ra[q]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) vm_wait0(rw[q]);
+#pragma unroll
+    for (int q = 0; q < AQ; ++q) {
+      const int idx = tid + 512 * q;
+      const int row = idx >> 3, c4 = idx & 7;
+      const Split3 s0 = split3(ra[q].x), s1 = split3(ra[q].y), s2 = split3(ra[q].z), s3 = split3(ra[q].w);
+      __bf16* p = sA + row * kPitch + 4 * c4;
+      *reinterpret_cast<uint2*>(p) = make_uint2(pack_hi16(s0.hi, s1.hi), pack_hi16(s2.hi, s3.hi));
+      *reinterpret_cast<uint2*>(p + BM * kPitch) = make_uint2(pack_hi16(s0.mid, s1.mid), pack_hi16(s2.mid, s3.mid));
+      *reinterpret_cast<uint2*>(p + 2 * BM * kPitch) = make_uint2(pack_hi16(s0.lo, s1.lo), pack_hi16(s2.lo, s3.lo));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = tid + 512 * q;          // chunk of the stage block: [piece][row 128][4 chunks of 8 bf16]
+      const int piece = idx >> 9, row = (idx >> 2) & 127, c = idx & 3;
+      *reinterpret_cast<f32x4v*>(sW + (piece * kBN + row) * kPitch + 8 * c) = rw[q];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  issue(0);
+  stash();
+  __syncthreads();
+  const __bf16* pa = sA + (wm * 32 + li) * kPitch + 8 * hf;
+  const __bf16* pw = sW + (wn * (32 * NT) + li) * kPitch + 8 * hf;
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[3], w[NT][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[p] = *reinterpret_cast<const bf16x8*>(pa + p * BM * kPitch + 16 * ks);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          w[t][p] = *reinterpret_cast<const bf16x8*>(pw + (p * kBN + t * 32) * kPitch + 16 * ks);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x16 c = acc[nt];
+        c = mfma_bf16(w[nt][2], a[0], c);
+        c = mfma_bf16(w[nt][0], a[2], c);
+        c = mfma_bf16(w[nt][1], a[1], c);
+        c = mfma_bf16(w[nt][1], a[0], c);
+        c = mfma_bf16(w[nt][0], a[1], c);
+        c = mfma_bf16(w[nt][0], a[0], c);
+        acc[nt] = c;
+      }
+    }
+  };
+  // every iteration issues the loads of the NEXT stage, multiplies the current one out of LDS and stores the next one
+  // (issue and stash unconditionally paired: no path leaves a load in flight); the last stage is peeled
+#pragma unroll 1
+  for (int s = 0; s + 1 < nk; ++s) {
+    issue(s + 1);
+    compute();
+    __syncthreads();   // every wave has read stage s out of LDS
+    stash();
+    __syncthreads();
+  }
+  compute();
+
+  // epilogue: D[i = n][j = m]; accumulator r <-> column n = (r & 3) + 8 (r >> 2) + 4 hf of the 32-wide n tile, row m =
+  // lane & 31: one float4 (4 consecutive columns) per accumulator quad
+  const int row = m0 + wm * 32 + li;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = nb * kBN + wn * (32 * NT) + nt * 32 + 8 * q + 4 * hf;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + col);
+      float4 v = make_float4(acc[nt][4 * q + 0] + bv.x, acc[nt][4 * q + 1] + bv.y, acc[nt][4 * q + 2] + bv.z,
+                             acc[nt][4 * q + 3] + bv.w);
+      if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (row < M) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, const uint16_t* w_tiled,
+                                          const float* bias, float* y, int ldy, int M, int K, int N, int relu) {
+  if (!x || !w_tiled || !y) return EGTR_E_ARG;
+  if (M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return EGTR_E_ARG;
+  if (K % kBK != 0 || N % kBN != 0 || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return EGTR_E_UNSUPPORTED;
+  if ((ldy & 3) || (reinterpret_cast<uintptr_t>(y) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+    return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // 128-row tiles when they fill the chip twice over (two co-resident workgroups per CU overlap each other's load /
+  // store phases), 64-row tiles otherwise
+  const long long tiles128 = (long long)(N / kBN) * ((M + 127) / 128);
+  if (tiles128 >= 512) {
+    const dim3 grid(N / kBN, (M + 127) / 128);
+    if (grid.y > 65535) return EGTR_E_UNSUPPORTED;
+    if (relu)
+      hipLaunchKernelGGL((gemm_split_bf16_f32<128, true>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
+    else
+      hipLaunchKernelGGL((gemm_split_bf16_f32<128, false>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
+  } else {
+    const dim3 grid(N / kBN, (M + 63) / 64);
+    if (grid.y > 65535) return EGTR_E_UNSUPPORTED;
+    if (relu)
+      hipLaunchKernelGGL((gemm_split_bf16_f32<64, true>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
+    else
+      hipLaunchKernelGGL((gemm_split_bf16_f32<64, false>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
+  }
+  return egtr_check_launch();
+}

@@ -386,7 +386,13 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                  self.attention_weights.bias],
                 lambda: (torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0).contiguous(),
                          torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0).contiguous()))
-            both = F.linear(hidden_states, w_cat, b_cat)
+            if ops.gemm_split_supported(hidden_states, w_cat.shape[0], w_cat.shape[1]):
+                wt = ops.cached_weights(self, "msda_offsets_weights_split",
+                                        [self.sampling_offsets.weight, self.attention_weights.weight],
+                                        lambda: ops.gemm_split_weights(w_cat))
+                both = ops.linear_split_bf16(hidden_states, wt, b_cat, w_cat.shape[0])
+            else:
+                both = F.linear(hidden_states, w_cat, b_cat)
             n_off = self.sampling_offsets.weight.shape[0]
             sampling_offsets, attention_weights = both[..., :n_off], both[..., n_off:]
         else:
@@ -788,8 +794,18 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 lambda: (torch.stack([l.encoder_attn.value_proj.weight.t() for l in self.layers]).contiguous(),
                          torch.stack([l.encoder_attn.value_proj.bias for l in self.layers]).contiguous()))
             bsz_, seq_, dm_ = encoder_hidden_states.shape
-            x2 = encoder_hidden_states.reshape(1, bsz_ * seq_, dm_).expand(nl, -1, -1)
-            values = torch.bmm(x2, w_t).view(nl, bsz_, seq_, dm_)
+            if ops.gemm_split_supported(encoder_hidden_states, dm_, dm_):
+                values = torch.empty(nl, bsz_ * seq_, dm_, dtype=encoder_hidden_states.dtype,
+                                     device=encoder_hidden_states.device)
+                for i, l in enumerate(self.layers):
+                    vp = l.encoder_attn.value_proj
+                    wt = ops.cached_weights(vp, "gemm_split_bf16", [vp.weight],
+                                            lambda vp=vp: ops.gemm_split_weights(vp.weight))
+                    ops.linear_split_bf16(encoder_hidden_states, wt, None, dm_, out=values[i])
+                values = values.view(nl, bsz_, seq_, dm_)
+            else:
+                x2 = encoder_hidden_states.reshape(1, bsz_ * seq_, dm_).expand(nl, -1, -1)
+                values = torch.bmm(x2, w_t).view(nl, bsz_, seq_, dm_)
             lay0 = self.layers[0].encoder_attn
             if (not output_attentions and (reference_points.shape[-1] == 2 or values.dtype == torch.float32)
                     and ops.msda_fused_supported(lay0.n_heads, lay0.d_model // lay0.n_heads, lay0.n_levels,

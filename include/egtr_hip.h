@@ -359,6 +359,16 @@ int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* gate_q, const
                                 int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
                                 float* gate_mean);
 
+/* Token-sized nn.Linear, y[M, N] (row stride ldy) = act(x[M, K] (row stride ldx) . W[N, K]^T + bias): fp32 in, fp32 out,
+ * fp32-level accuracy, evaluated on the bf16 matrix cores from exact three-way bf16 splits of both operands (six cross
+ * terms, fp32 accumulation; csrc/gemm_split.hip).  Replaces the vendor fp32 GEMM behind the reference's encoder
+ * nn.Linear layers (model/deformable_detr.py:1049, 1053-1058, 1102, 1337-1343) in inference.  w_tiled: W pre-split and
+ * pre-tiled, raw bfloat16 bits, [N/128][K/32][3 pieces hi, mid, lo][128 rows][32]
+ * (egtr_amd/ops.py::gemm_split_weights).  K % 32 == 0, N % 128 == 0, x 16-byte aligned with ldx % 4 == 0, else
+ * EGTR_E_UNSUPPORTED.  bias may be NULL; relu != 0 applies max(., 0). */
+int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, const uint16_t* w_tiled,
+                               const float* bias, float* y, int ldy, int M, int K, int N, int relu);
+
 /* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
  * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
  * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the

@@ -386,6 +386,36 @@ def test_relation_head_split_bf16_is_fp32_accurate(B, N, T, R):
     assert (rel2.cpu().double() - rrel2).abs().max() < 2e-4 and gm2 is None
 
 
+@pytest.mark.parametrize("M,K,N,relu", [(12537, 256, 256, False), (12537, 256, 1024, True), (12537, 1024, 256, False),
+                                        (5000, 256, 384, False), (4099, 32, 128, True), (129, 64, 128, False)])
+def test_linear_split_bf16_is_fp32_accurate(M, K, N, relu):
+    """Token-sized linear on the bf16 matrix cores from three-way operand splits (csrc/gemm_split.hip) against float64:
+    error of the same size as the vendor fp32 GEMM's (within 2.5x in max and Frobenius norm), incl. a row-strided input,
+    a partial last row tile and the ReLU epilogue."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(700 + M + K)
+    x = torch.from_numpy(rng.standard_normal((M, K + 8))).float()
+    w = torch.from_numpy(rng.standard_normal((N, K)) / np.sqrt(K)).float()
+    b = torch.from_numpy(rng.standard_normal(N) * 0.1).float()
+    xd = x.to(DEV)[:, :K]           # row stride K + 8: a column block of a wider buffer
+    wt = ops.gemm_split_weights(w.to(DEV))
+    y = ops.linear_split_bf16(xd, wt, b.to(DEV), N, relu=relu)
+    ref = x[:, :K].double() @ w.double().t() + b.double()
+    y32 = torch.nn.functional.linear(xd.contiguous(), w.to(DEV), b.to(DEV))
+    if relu:
+        ref, y32 = ref.clamp_min(0), y32.clamp_min(0)
+    e = (y.cpu().double() - ref).abs()
+    e32 = (y32.cpu().double() - ref).abs()
+    assert y.shape == (M, N)
+    assert e.max() < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert e.max() <= 2.5 * e32.max() + 1e-7, (float(e.max()), float(e32.max()))
+    assert e.norm() <= 2.5 * e32.norm() + 1e-7, (float(e.norm()), float(e32.norm()))
+    out = torch.full((M, N), 7.0, device=DEV)
+    y2 = ops.linear_split_bf16(xd, wt, None, N, relu=False, out=out)     # no bias, caller's buffer
+    assert y2.data_ptr() == out.data_ptr()
+    assert (out.cpu().double() - x[:, :K].double() @ w.double().t()).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_relation_head_split_weights_sum_to_the_fp32_weights():
     """hi + mid + lo reproduces every fp32 weight to <= 2^-24 relative, incl. large / tiny / denormal-range values."""
     from egtr_amd import ops
