@@ -31,7 +31,7 @@ def decoder_self_attention(q, k, v, num_heads, want_maps=True):
 
 
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
-                  node_cls=None, want_gate_mean=False):
+                  node_cls=None, want_gate_mean=False, owner=None):
     F = torch.nn.functional
     Hd = w2r.shape[1]
     g = torch.sigmoid(gate_q[:, :, None, :] + gate_k[:, None, :, :])
