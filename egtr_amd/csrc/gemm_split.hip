@@ -35,7 +35,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
 }
 __device__ __forceinline__ f32x4v gload(const void* p) {
   f32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p));
   return v;
 }
 __device__ __forceinline__ void vm_wait0(f32x4v& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }

@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ f32x4 gload16(const float4* p) {
   f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(v) : "v"(p), "n"(OFF));
   return v;
 }
 template <int N>

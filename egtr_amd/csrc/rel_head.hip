@@ -46,7 +46,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <int OFF>
 __device__ __forceinline__ f32x4v gload_b128(const float4* p) {
   f32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(p), "n"(OFF));
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(v) : "v"(p), "n"(OFF));
   return v;
 }
 template <int N>
@@ -617,17 +617,17 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 
 __device__ __forceinline__ f32x4v gload_b128_s(unsigned voff, const void* sbase) {
   f32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase));
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v) : "v"(voff), "s"(sbase));
   return v;
 }
 __device__ __forceinline__ f32x4v gload_b128_s1k(unsigned voff, const void* sbase) {
   f32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(v) : "v"(voff), "s"(sbase));
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(v) : "v"(voff), "s"(sbase));
   return v;
 }
 __device__ __forceinline__ f32x4v gload_b128_s2k(unsigned voff, const void* sbase) {
   f32x4v v;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(v) : "v"(voff), "s"(sbase));
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(v) : "v"(voff), "s"(sbase));
   return v;
 }
 
@@ -1173,7 +1173,8 @@ extern "C" int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const floa
     return EGTR_E_ARG;
   if (triplet_dist != nullptr && node_cls == nullptr) return EGTR_E_ARG;
   if (batch <= 0 || num_query <= 0 || num_slots <= 0 || num_rel <= 0) return EGTR_E_ARG;
-  if (hidden != kHd || num_rel > 64 || num_slots > 10) return EGTR_E_UNSUPPORTED;
+  // 9 slots (8 decoder layers + 1) is the largest instantiation that stays within 256 registers without scratch
+  if (hidden != kHd || num_rel > 64 || num_slots > 9) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long tiles = (long long)batch * ((num_query + 7) / 8) * ((num_query + 3) / 4);
   if (tiles >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
@@ -1190,7 +1191,7 @@ extern "C" int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const floa
                          num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean);                     \
     break;
   switch (num_slots) {
-    EGTR_TX(1) EGTR_TX(2) EGTR_TX(3) EGTR_TX(4) EGTR_TX(5) EGTR_TX(6) EGTR_TX(7) EGTR_TX(8) EGTR_TX(9) EGTR_TX(10)
+    EGTR_TX(1) EGTR_TX(2) EGTR_TX(3) EGTR_TX(4) EGTR_TX(5) EGTR_TX(6) EGTR_TX(7) EGTR_TX(8) EGTR_TX(9)
     default: return EGTR_E_UNSUPPORTED;
   }
 #undef EGTR_TX

@@ -743,7 +743,7 @@ def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c,
                   node_cls=None, want_gate_mean=False, owner=None):
     """``owner`` (optional nn.Module): where the derived split-bf16 weight streams of the inference kernel are cached."""
     if (REL_HEAD_SPLIT_BF16 and owner is not None and gate_q.dtype == torch.float32 and gate_q.is_cuda
-            and w2r.shape == (256, 256) and w3r.shape[0] <= 64 and gate_q.shape[-1] <= 10
+            and w2r.shape == (256, 256) and w3r.shape[0] <= 64 and gate_q.shape[-1] <= 9
             and not (torch.is_grad_enabled() and any(
                 t.requires_grad for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c)))):
         w2xr, w3xr, w2xc = cached_weights(owner, "rel_head_split_bf16", [w2r, w3r, w2c],

@@ -377,7 +377,8 @@ int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, co
  *   w2x_*  [8 nt][16 t][3 piece][64 lane][8]:  piece(W2)[32 nt + (lane & 31)][16 t + 8 (lane >> 5) + e]
  *   w3x_rel [8 nt][2 kb][OT][3 piece][64 lane][8], OT = 1 if num_rel <= 32 else 2:
  *           piece(W3)[32 ot + (lane & 31)][32 nt + 16 kb + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)], rows >= num_rel zero
- * (egtr_amd/ops.py::rel_head_split_weights builds them); w3c / all biases / tables are fp32 as in the f32 entry. */
+ * (egtr_amd/ops.py::rel_head_split_weights builds them); w3c / all biases / tables are fp32 as in the f32 entry.
+ * num_slots <= 9 (EGTR_E_UNSUPPORTED above: the f32 entry serves 10). */
 int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
                                      const float* uk, const float* b1, const uint16_t* w2x_rel, const float* b2r,
                                      const uint16_t* w3x_rel, const float* b3r, const uint16_t* w2x_conn,
