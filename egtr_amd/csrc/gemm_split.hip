@@ -89,18 +89,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const char* wblk = reinterpret_cast<const char*>(Wt) + (size_t)nb * nk * (3 * kBN * kBK * 2) + (size_t)tid * 16;
 
   f32x4v ra[AQ], rw[3];
-  auto issue_a = [&](int s) {
+  auto issue = [&](int s) {
 #pragma unroll
     for (int q = 0; q < AQ; ++q) ra[q] = gload(arow[q] + s * kBK);
-  };
-  auto issue_w = [&](int s) {
     const char* wp = wblk + (size_t)s * (3 * kBN * kBK * 2);
 #pragma unroll
     for (int q = 0; q < 3; ++q) rw[q] = gload(wp + q * 8192);
-  };
-  auto issue = [&](int s) {
-    issue_a(s);
-    issue_w(s);
   };
   auto stash = [&]() {
 #pragma unroll
@@ -136,10 +130,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   __syncthreads();
   const __bf16* pa = sA + (wm * 32 + li) * kPitch + 8 * hf;
   const __bf16* pw = sW + (wn * (32 * NT) + li) * kPitch + 8 * hf;
-  // next >= 0: the loads of stage `next` are requested BETWEEN the two MFMA groups of this stage (W pieces) and after
-  // them (activations) instead of in one burst right after the barrier, when all sixteen waves of the CU would queue
-  // on the L1 at once
-  auto compute = [&](int next) {
+  auto compute = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[3], w[NT][3];
@@ -161,22 +152,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         c = mfma_bf16(w[nt][0], a[0], c);
         acc[nt] = c;
       }
-      if (next >= 0) {
-        if (ks == 0) issue_w(next);
-        else issue_a(next);
-      }
     }
   };
   // every iteration issues the loads of the NEXT stage, multiplies the current one out of LDS and stores the next one
   // (issue and stash unconditionally paired: no path leaves a load in flight); the last stage is peeled
 #pragma unroll 1
   for (int s = 0; s + 1 < nk; ++s) {
-    compute(s + 1);
+    issue(s + 1);
+    compute();
     __syncthreads();   // every wave has read stage s out of LDS
     stash();
     __syncthreads();
   }
-  compute(-1);
+  compute();
 
   // epilogue: D[i = n][j = m]; accumulator r <-> column n = (r & 3) + 8 (r >> 2) + 4 hf of the 32-wide n tile, row m =
   // lane & 31: one float4 (4 consecutive columns) per accumulator quad
