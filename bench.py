@@ -147,6 +147,30 @@ def time_rel_head_kernel(args, iters=100):
     return us, flops
 
 
+def time_split_gemm(dev, iters=100):
+    """The encoder's first FFN layer (S = 12 537 rows, 256 -> 1024, ReLU) through egtr_linear_split_bf16_f32
+    (csrc/gemm_split.hip); algorithmic FLOPs = 2 M K N."""
+    from egtr_amd import ops
+    M, K, N = 12537, 256, 1024
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    wt = ops.gemm_split_weights(w)
+    out = torch.empty(M, N, device=dev)
+    with torch.no_grad():
+        for _ in range(5):
+            ops.linear_split_bf16(x, wt, b, N, relu=True, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.linear_split_bf16(x, wt, b, N, relu=True, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * M * K * N
+
+
 def time_msda_kernel(args, fused, iters=200):
     """Average duration of the encoder MSDA kernel: `iters` back-to-back launches through the C ABI on torch's
     current stream, bracketed by HIP events recorded on that same stream."""
@@ -590,6 +614,16 @@ def main():
         rel_entry["bf16_mfma_flops_executed"] = executed
         rel_entry["frac_of_bf16_dense_peak"] = round(executed / (rel_us * 1e-6) / 1e12 / 2500.0, 4)
     result["roofline_kernels"] = [result["roofline"], rel_entry]
+    if _ops.GEMM_SPLIT_BF16:
+        g_us, g_flops = time_split_gemm(dev)
+        g_tf = g_flops / (g_us * 1e-6) / 1e12
+        result["roofline_kernels"].append(
+            {"bound": "mfma", "kernel": "gemm_split_bf16_f32", "launch": "encoder FFN layer 1: M=12537, K=256, N=1024, ReLU",
+             "achieved": round(g_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(g_tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flops_per_launch": g_flops,
+             "avg_launch_us": round(g_us, 3), "arithmetic": "fp32 via bf16x6 operand split, fp32 accumulate",
+             "frac_of_bf16_dense_peak": round(6 * g_flops / (g_us * 1e-6) / 1e12 / 2500.0, 4)})
+        result["config"]["encoder_linears"] = "fp32 via bf16x6 operand split, fp32 accumulate"
     result["config"]["relation_head"] = rel_entry.get("arithmetic", "exact-f32 MFMA")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncores = usable_cores()
