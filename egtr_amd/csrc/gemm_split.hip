@@ -60,10 +60,41 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 // per-stage latency (operand reads, barrier, vmcnt, LDS stores) was exposed and the kernel ran at the vendor fp32 rate.
 // MFMA roles: A operand = weight piece (i = n), B operand = activation piece (j = m), so that a lane ends up with 4
 // CONSECUTIVE output columns per accumulator quad: the epilogue stores float4.
-template <int BM, bool RELU>
+// Up to kMaxProblems independent products with the same M and K in ONE launch (the value projection and the offsets /
+// attention-weights projection of an encoder layer; the six value projections of the decoder): their tiles share the
+// grid, so that products which do not fill the chip on their own (196-588 tiles on 512 workgroup slots) fill it together.
+constexpr int kMaxProblems = 8;
+struct GemmProblem {
+  const float* A;
+  const unsigned short* Wt;
+  const float* bias;
+  float* C;
+  int lda, ldc, N, relu;
+};
+struct GemmProblems {
+  GemmProblem p[kMaxProblems];
+};
+
+template <int BM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_bf16_f32(
-    const float* __restrict__ A, int lda, const unsigned short* __restrict__ Wt, const float* __restrict__ bias,
-    float* __restrict__ C, int ldc, int M, int N, int K) {
+    GemmProblems P, int nprob, int M, int K) {
+  // tile -> (problem, n block, m block): n blocks of one m block are neighbours (they read the same activation rows)
+  const int mblocks = (M + BM - 1) / BM;
+  int tile = blockIdx.x, pi = 0;
+  for (; pi + 1 < nprob; ++pi) {
+    const int t = (P.p[pi].N / kBN) * mblocks;
+    if (tile < t) break;
+    tile -= t;
+  }
+  const GemmProblem& G = P.p[pi];
+  const int nblocks = G.N / kBN;
+  const int nb = tile % nblocks, m0 = (tile / nblocks) * BM;
+  const float* __restrict__ A = G.A;
+  const unsigned short* __restrict__ Wt = G.Wt;
+  const float* __restrict__ bias = G.bias;
+  float* __restrict__ C = G.C;
+  const int lda = G.lda, ldc = G.ldc;
+  const bool RELU = G.relu != 0;
   constexpr int WAVES_M = BM / 32;            // 4 or 2
   constexpr int WAVES_N = 8 / WAVES_M;        // 2 or 4
   constexpr int NT = 4 / WAVES_N;             // 32-column MFMA tiles per wave: 2 or 1
@@ -73,7 +104,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, hf = lane >> 5;
-  const int nb = blockIdx.x, m0 = blockIdx.y * BM;
   const int nk = K / kBK;
 
   // global -> register mapping of one stage
@@ -185,31 +215,51 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 }  // namespace
 
+namespace {
+int launch_grouped(hipStream_t st, const GemmProblems& P, int nprob, int M, int K) {
+  long long tiles128 = 0, tiles64 = 0;
+  for (int i = 0; i < nprob; ++i) {
+    tiles128 += (long long)(P.p[i].N / kBN) * ((M + 127) / 128);
+    tiles64 += (long long)(P.p[i].N / kBN) * ((M + 63) / 64);
+  }
+  if (tiles64 >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  // 128-row tiles when they fill the chip twice over (two co-resident workgroups per CU overlap each other's load /
+  // store phases), 64-row tiles otherwise
+  if (tiles128 >= 512)
+    hipLaunchKernelGGL(gemm_split_bf16_f32<128>, dim3((unsigned)tiles128), dim3(512), 0, st, P, nprob, M, K);
+  else
+    hipLaunchKernelGGL(gemm_split_bf16_f32<64>, dim3((unsigned)tiles64), dim3(512), 0, st, P, nprob, M, K);
+  return egtr_check_launch();
+}
+bool problem_ok(const float* x, int ldx, const uint16_t* w, const float* bias, float* y, int ldy, int K, int N) {
+  return x && w && y && ldx >= K && ldy >= N && N > 0 && N % kBN == 0 && !(ldx & 3) && !(ldy & 3) &&
+         !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(y) & 15) &&
+         !(bias && (reinterpret_cast<uintptr_t>(bias) & 15));
+}
+}  // namespace
+
 extern "C" int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, const uint16_t* w_tiled,
                                           const float* bias, float* y, int ldy, int M, int K, int N, int relu) {
   if (!x || !w_tiled || !y) return EGTR_E_ARG;
   if (M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return EGTR_E_ARG;
-  if (K % kBK != 0 || N % kBN != 0 || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return EGTR_E_UNSUPPORTED;
-  if ((ldy & 3) || (reinterpret_cast<uintptr_t>(y) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
-    return EGTR_E_UNSUPPORTED;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  // 128-row tiles when they fill the chip twice over (two co-resident workgroups per CU overlap each other's load /
-  // store phases), 64-row tiles otherwise
-  const long long tiles128 = (long long)(N / kBN) * ((M + 127) / 128);
-  if (tiles128 >= 512) {
-    const dim3 grid(N / kBN, (M + 127) / 128);
-    if (grid.y > 65535) return EGTR_E_UNSUPPORTED;
-    if (relu)
-      hipLaunchKernelGGL((gemm_split_bf16_f32<128, true>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
-    else
-      hipLaunchKernelGGL((gemm_split_bf16_f32<128, false>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
-  } else {
-    const dim3 grid(N / kBN, (M + 63) / 64);
-    if (grid.y > 65535) return EGTR_E_UNSUPPORTED;
-    if (relu)
-      hipLaunchKernelGGL((gemm_split_bf16_f32<64, true>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
-    else
-      hipLaunchKernelGGL((gemm_split_bf16_f32<64, false>), grid, dim3(512), 0, st, x, ldx, w_tiled, bias, y, ldy, M, N, K);
+  if (K % kBK != 0 || !problem_ok(x, ldx, w_tiled, bias, y, ldy, K, N)) return EGTR_E_UNSUPPORTED;
+  GemmProblems P = {};
+  P.p[0] = GemmProblem{x, w_tiled, bias, y, ldx, ldy, N, relu};
+  return launch_grouped(static_cast<hipStream_t>(stream), P, 1, M, K);
+}
+
+extern "C" int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, const float* const* x,
+                                                  const int* ldx, const uint16_t* const* w_tiled,
+                                                  const float* const* bias, float* const* y, const int* ldy,
+                                                  const int* N, const int* relu, int M, int K) {
+  if (!x || !ldx || !w_tiled || !bias || !y || !ldy || !N || !relu) return EGTR_E_ARG;
+  if (num_problems <= 0 || num_problems > kMaxProblems || M <= 0 || K <= 0) return EGTR_E_ARG;
+  if (K % kBK != 0) return EGTR_E_UNSUPPORTED;
+  GemmProblems P = {};
+  for (int i = 0; i < num_problems; ++i) {
+    if (!x[i] || !w_tiled[i] || !y[i]) return EGTR_E_ARG;
+    if (!problem_ok(x[i], ldx[i], w_tiled[i], bias[i], y[i], ldy[i], K, N[i])) return EGTR_E_UNSUPPORTED;
+    P.p[i] = GemmProblem{x[i], w_tiled[i], bias[i], y[i], ldx[i], ldy[i], N[i], relu[i]};
   }
-  return egtr_check_launch();
+  return launch_grouped(static_cast<hipStream_t>(stream), P, num_problems, M, K);
 }

@@ -371,8 +371,14 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         elif precomputed_value is not None:
             value = precomputed_value
         else:
-            value = ops.module_linear(self.value_proj, encoder_hidden_states)
+            value = None   # projected below (token-sized inputs: together with the offsets / weights projection)
             value_is_masked = attention_mask is None
+            if not (fast and batch_size * num_queries > ops.SKINNY_MAX_ROWS
+                    and hidden_states.shape[:2] == encoder_hidden_states.shape[:2]
+                    and ops.gemm_split_supported(encoder_hidden_states, *self.value_proj.weight.shape)
+                    and ops.gemm_split_supported(hidden_states, 3 * self.n_heads * self.n_levels * self.n_points,
+                                                 hidden_states.shape[-1])):
+                value = ops.module_linear(self.value_proj, encoder_hidden_states)
         if fast and batch_size * num_queries <= ops.SKINNY_MAX_ROWS:
             sampling_offsets, attention_weights = ops.linear_grouped([
                 dict(x=hidden_states, w=self.sampling_offsets.weight, b=self.sampling_offsets.bias),
@@ -390,7 +396,18 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                 wt = ops.cached_weights(self, "msda_offsets_weights_split",
                                         [self.sampling_offsets.weight, self.attention_weights.weight],
                                         lambda: ops.gemm_split_weights(w_cat))
-                both = ops.linear_split_bf16(hidden_states, wt, b_cat, w_cat.shape[0])
+                if value is None:
+                    # encoder layer: the value projection (input: hidden) and this one (input: hidden + pos) are
+                    # independent and neither fills the chip: their tiles share one launch
+                    vp = self.value_proj
+                    wv = ops.cached_weights(vp, "gemm_split_bf16", [vp.weight], lambda: ops.gemm_split_weights(vp.weight))
+                    value, both = ops.linear_split_bf16_grouped([
+                        dict(x=encoder_hidden_states, wt=wv, N=vp.weight.shape[0], b=vp.bias),
+                        dict(x=hidden_states, wt=wt, N=w_cat.shape[0], b=b_cat)])
+                    value = value.view(batch_size, sequence_length, -1)
+                    both = both.view(batch_size, num_queries, -1)
+                else:
+                    both = ops.linear_split_bf16(hidden_states, wt, b_cat, w_cat.shape[0])
             else:
                 both = F.linear(hidden_states, w_cat, b_cat)
             n_off = self.sampling_offsets.weight.shape[0]
@@ -797,11 +814,14 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
             if ops.gemm_split_supported(encoder_hidden_states, dm_, dm_):
                 values = torch.empty(nl, bsz_ * seq_, dm_, dtype=encoder_hidden_states.dtype,
                                      device=encoder_hidden_states.device)
+                items = []
                 for i, l in enumerate(self.layers):
                     vp = l.encoder_attn.value_proj
                     wt = ops.cached_weights(vp, "gemm_split_bf16", [vp.weight],
                                             lambda vp=vp: ops.gemm_split_weights(vp.weight))
-                    ops.linear_split_bf16(encoder_hidden_states, wt, None, dm_, out=values[i])
+                    items.append(dict(x=encoder_hidden_states, wt=wt, N=dm_, out=values[i]))
+                for i0 in range(0, nl, 8):   # all layers' projections share one grid
+                    ops.linear_split_bf16_grouped(items[i0:i0 + 8])
                 values = values.view(nl, bsz_, seq_, dm_)
             else:
                 x2 = encoder_hidden_states.reshape(1, bsz_ * seq_, dm_).expand(nl, -1, -1)

@@ -379,6 +379,49 @@ def linear_split_bf16(x, w_tiled, bias, N, relu=False, out=None):
     return y if out is not None else y.view(*x.shape[:-1], N)
 
 
+def linear_split_bf16_grouped(items):
+    """Several token-sized linears with the same row count and K in ONE launch (egtr_linear_split_bf16_grouped_f32).
+    ``items``: dicts with x [..., K], wt (from ``gemm_split_weights``), N, optional b, relu, out ([rows, N] contiguous).
+    Returns the outputs ([rows, N]).  Inference only."""
+    import ctypes
+    lib = _lib.lib()
+    n = len(items)
+    K = items[0]["x"].shape[-1]
+    xs, outs, keep = [], [], []
+    for it in items:
+        x2 = it["x"].reshape(-1, K)
+        if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+            x2 = x2.contiguous()
+        if not x2.is_cuda or x2.dtype != torch.float32:
+            raise RuntimeError("linear_split_bf16_grouped: x must be a float32 CUDA/HIP tensor")
+        N = int(it["N"])
+        _chk(it["wt"], "wt", torch.bfloat16)
+        if tuple(it["wt"].shape) != (N // 128, K // 32, 3, 128, 32):
+            raise RuntimeError(f"wt must be [{N // 128}, {K // 32}, 3, 128, 32], got {tuple(it['wt'].shape)}")
+        y = it.get("out")
+        if y is None:
+            y = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
+        else:
+            _chk(y, "out", torch.float32)
+        b = it.get("b")
+        if b is not None:
+            b = _chk(b.detach().contiguous(), "bias", torch.float32)
+        keep.append((x2, b))
+        xs.append(x2)
+        outs.append(y)
+    M = xs[0].shape[0]
+    if any(x2.shape[0] != M for x2 in xs):
+        raise RuntimeError("linear_split_bf16_grouped: all inputs must have the same number of rows")
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    st = lib.egtr_linear_split_bf16_grouped_f32(
+        _stream(), n, PA(*[x2.data_ptr() for x2 in xs]), IA(*[x2.stride(0) for x2 in xs]),
+        PA(*[it["wt"].data_ptr() for it in items]), PA(*[(b.data_ptr() if b is not None else None) for _, b in keep]),
+        PA(*[y.data_ptr() for y in outs]), IA(*[y.stride(0) for y in outs]), IA(*[int(it["N"]) for it in items]),
+        IA(*[1 if it.get("relu") else 0 for it in items]), M, K)
+    _lib.check(st, "egtr_linear_split_bf16_grouped_f32")
+    return outs
+
+
 def module_linear(mod, x, alpha=1.0, relu=False):
     w = mod.weight
     if alpha == 1.0 and gemm_split_supported(x, w.shape[0], w.shape[1]):

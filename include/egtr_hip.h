@@ -369,6 +369,13 @@ int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* gate_q, const
 int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, const uint16_t* w_tiled,
                                const float* bias, float* y, int ldy, int M, int K, int N, int relu);
 
+/* Up to 8 such products with the same M and K in ONE launch (their tiles share the grid): the value projection and the
+ * offsets / attention-weights projection of an encoder layer, the six value projections of the decoder.  All arrays are
+ * HOST arrays of num_problems entries (pointers inside are device pointers; bias[i] may be NULL). */
+int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, const float* const* x, const int* ldx,
+                                       const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
+                                       const int* ldy, const int* N, const int* relu, int M, int K);
+
 /* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
  * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
  * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the

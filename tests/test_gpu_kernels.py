@@ -416,6 +416,28 @@ def test_linear_split_bf16_is_fp32_accurate(M, K, N, relu):
     assert (out.cpu().double() - x[:, :K].double() @ w.double().t()).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
 
 
+def test_linear_split_bf16_grouped_equals_single_launches():
+    """Several products in one launch (shared grid) give bit-identical results to one launch each."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(321)
+    M, K = 12537, 256
+    xa = torch.from_numpy(rng.standard_normal((M, K))).float().to(DEV)
+    xb = torch.from_numpy(rng.standard_normal((M, K))).float().to(DEV)
+    ws = [torch.from_numpy(rng.standard_normal((n, K)) / 16).float().to(DEV) for n in (256, 384, 256)]
+    bs = [torch.from_numpy(rng.standard_normal(n) * 0.1).float().to(DEV) for n in (256, 384, 256)]
+    wts = [ops.gemm_split_weights(w) for w in ws]
+    single = [ops.linear_split_bf16(x, wt, b, w.shape[0], relu=r)
+              for x, wt, b, w, r in ((xa, wts[0], bs[0], ws[0], False), (xb, wts[1], None, ws[1], True),
+                                     (xa, wts[2], bs[2], ws[2], False))]
+    out2 = torch.empty(M, 256, device=DEV)
+    grouped = ops.linear_split_bf16_grouped([dict(x=xa, wt=wts[0], N=256, b=bs[0]),
+                                             dict(x=xb, wt=wts[1], N=384, relu=True),
+                                             dict(x=xa, wt=wts[2], N=256, b=bs[2], out=out2)])
+    for a, b in zip(single, grouped):
+        assert torch.equal(a, b)
+    assert grouped[2].data_ptr() == out2.data_ptr()
+
+
 def test_relation_head_split_weights_sum_to_the_fp32_weights():
     """hi + mid + lo reproduces every fp32 weight to <= 2^-24 relative, incl. large / tiny / denormal-range values."""
     from egtr_amd import ops
