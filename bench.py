@@ -486,8 +486,9 @@ def main():
     ap.add_argument("--tune-gemm", type=int, default=1,
                     help="1 = PyTorch TunableOp picks the fastest rocBLAS / hipBLASLt solution per GEMM shape during "
                          "warm-up (egtr_amd.runtime.enable_gemm_tuning)")
-    ap.add_argument("--miopen-find", type=int, default=0,
-                    help="1 = torch.backends.cudnn.benchmark (MIOpen exhaustive find for the backbone convolutions)")
+    ap.add_argument("--miopen-find", type=int, default=-1,
+                    help="1 = torch.backends.cudnn.benchmark (MIOpen find mode for the backbone convolutions during "
+                         "warm-up: 250 -> 261 images/s); -1 = on for --mode infer, off for --mode train (no gain there)")
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = BASELINE configs[1] (default, the headline metric); train = configs[2]-style train "
                          "step (forward + SGG loss + backward + DDP all-reduce + AdamW), batch 4/GPU unless --batch")
@@ -498,7 +499,7 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))  # nothing above this line touches the GPU
     if args.launch_check:
         return launch_check(args)
-    if args.miopen_find:
+    if args.miopen_find == 1 or (args.miopen_find < 0 and args.mode == "infer"):
         torch.backends.cudnn.benchmark = True
     if args.tune_gemm:
         from egtr_amd.runtime import enable_gemm_tuning
@@ -585,6 +586,7 @@ def main():
         "config": {"workload": "VG inference: ResNet-50, N=200, 6 enc/6 dec, 150 classes, 50 predicates, "
                                f"600x1000, bs={args.batch}/GPU fp32 (BASELINE configs[1])",
                    "images_per_step_per_gpu": args.batch, "hip_graph": bool(args.graph) and fwd.graphed, "gemm_tuning": bool(args.tune_gemm),
+                   "miopen_find": bool(torch.backends.cudnn.benchmark),
                    "parallelism": f"replicas x{world} (independent images, no collective)"},
         "roofline": {"bound": "hbm", "kernel": msda_kernel, "launch": "encoder layer, Lq = S = 12537, fused softmax + "
                      "sampling locations" if probe.fused else "encoder layer, Lq = S = 12537",
