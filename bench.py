@@ -500,7 +500,8 @@ def main():
     if args.launch_check:
         return launch_check(args)
     if args.miopen_find == 1 or (args.miopen_find < 0 and args.mode == "infer"):
-        torch.backends.cudnn.benchmark = True
+        from egtr_amd.runtime import enable_conv_tuning
+        enable_conv_tuning()
     if args.tune_gemm:
         from egtr_amd.runtime import enable_gemm_tuning
         enable_gemm_tuning()
