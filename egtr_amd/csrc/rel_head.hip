@@ -678,7 +678,8 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     const unsigned short* __restrict__ w2xc, const float* __restrict__ b2c, const float* __restrict__ w3c,
     const float* __restrict__ b3c, const float* __restrict__ triplet, const int64_t* __restrict__ node_cls, int B,
     int N, int R, int C1, float* __restrict__ rel_logits, float* __restrict__ conn_logits,
-    float* __restrict__ gate_mean) {
+    float* __restrict__ gate_mean, int apply_sigmoid) {
+  // apply_sigmoid: write sigmoid(logit) (egtr.py:450-454, the model's pred_rel / pred_connectivity) instead of the logit
   // one buffer, two lives: the three h1 pieces (read by every layer-2 step), then the output tiles
   constexpr int kStride = 32 * OT + 1;
   static_assert(kRhWaves * 32 * kStride * 4 <= 3 * 32 * kHp * 2, "output tiles fit in the h1 buffer");
@@ -855,7 +856,8 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
       float v = s_cacc[0][pi];
 #pragma unroll
       for (int w = 1; w < kRhWaves; ++w) v += s_cacc[w][pi];
-      conn_logits[p] = v + b3c[0];
+      v += b3c[0];
+      conn_logits[p] = apply_sigmoid ? 1.f / (1.f + expf(-v)) : v;
     }
     return;
   }
@@ -886,7 +888,7 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
       for (int w = 1; w < kRhWaves; ++w) v += s_out[(w * 32 + pp) * kStride + r];
       v += b3r[r];
       if (tb >= 0) v += triplet[tb + r];
-      dst[r] = v;
+      dst[r] = apply_sigmoid ? 1.f / (1.f + expf(-v)) : v;
     }
   }
 }
@@ -1167,7 +1169,7 @@ extern "C" int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const floa
                                                 const float* w3c, const float* b3c, const float* triplet_dist,
                                                 const int64_t* node_cls, int batch, int num_query, int num_slots,
                                                 int hidden, int num_rel, int num_cls_plus1, float* rel_logits,
-                                                float* conn_logits, float* gate_mean) {
+                                                float* conn_logits, float* gate_mean, int apply_sigmoid) {
   if (!gate_q || !gate_k || !uq || !uk || !b1 || !w2x_rel || !b2r || !w3x_rel || !b3r || !w2x_conn || !b2c || !w3c ||
       !b3c || !rel_logits || !conn_logits)
     return EGTR_E_ARG;
@@ -1184,11 +1186,11 @@ extern "C" int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const floa
     if (num_rel <= 32)                                                                                               \
       hipLaunchKernelGGL((rel_head_fwd_x6<TT, 1>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1,     \
                          w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c, triplet_dist, node_cls, batch,         \
-                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean);                     \
+                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean, apply_sigmoid);      \
     else                                                                                                             \
       hipLaunchKernelGGL((rel_head_fwd_x6<TT, 2>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1,     \
                          w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c, triplet_dist, node_cls, batch,         \
-                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean);                     \
+                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean, apply_sigmoid);      \
     break;
   switch (num_slots) {
     EGTR_TX(1) EGTR_TX(2) EGTR_TX(3) EGTR_TX(4) EGTR_TX(5) EGTR_TX(6) EGTR_TX(7) EGTR_TX(8) EGTR_TX(9)

@@ -106,7 +106,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         return [{"logits": a, "pred_boxes": b} for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
 
     # ---------------------------------------------------------------------------------------- relation head
-    def _relation_head(self, queries, keys, sequence_output, logits, want_gate_mean):
+    def _relation_head(self, queries, keys, sequence_output, logits, want_gate_mean, sigmoid=False):
         """egtr:322-418 via the separable algebra.  Returns pre-sigmoid (rel [B,N,N,R], conn [B,N,N,1], gate_mean)."""
         bsz, N, d = sequence_output.shape
         unscaling = self.head_dim ** 0.5
@@ -169,17 +169,18 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             node = torch.argmax(logits, dim=-1)
         return ops.relation_head(gate_q, gate_k, uq, uk, b1, rp[1].weight, rp[1].bias, rp[2].weight, rp[2].bias,
                                  cl[1].weight, cl[1].bias, cl[2].weight, cl[2].bias, triplet, node,
-                                 want_gate_mean, owner=self)
+                                 want_gate_mean, owner=self, sigmoid=sigmoid)
 
     def _matcher(self):
         return DeformableDetrHungarianMatcher(
             class_cost=self.config.ce_loss_coefficient, bbox_cost=self.config.bbox_cost,
             giou_cost=self.config.giou_cost, smoothing=self.config.smoothing)
 
-    def _heads(self, outputs, want_gate_mean, labels=None):
+    def _heads(self, outputs, want_gate_mean, labels=None, sigmoid=False):
         """Detection heads + relation head on the base model's outputs (egtr:283-418).  Returns
         (logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending_match); the
-        relation / connectivity logits are PRE-sigmoid.  With ``labels`` on the GPU the Hungarian cost matrix and its
+        relation / connectivity logits are PRE-sigmoid unless ``sigmoid`` (inference: applied in the relation-head
+        kernel's epilogue).  With ``labels`` on the GPU the Hungarian cost matrix and its
         copy to the host are enqueued BEFORE the relation head is launched (the matcher needs only logits and boxes), so
         that the host-side assignment overlaps the relation-head kernel instead of idling the GPU."""
         sequence_output = outputs["last_hidden_state"]
@@ -250,7 +251,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         outputs["decoder_attention_keys"] = None
         pred_rel, pred_connectivity, gate_mean = self._relation_head(
             decoder_attention_queries, decoder_attention_keys, sequence_output, logits,
-            want_gate_mean=want_gate_mean)
+            want_gate_mean=want_gate_mean, sigmoid=sigmoid)
         return logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending
 
     def forward_tensors(self, pixel_values, pixel_mask):
@@ -320,8 +321,10 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
                              output_hidden_states=output_hidden_states,
                              output_attention_states=True,  # the relation head needs the retained q / k maps
                              return_dict=True)
+        # no loss and no logit adjustment: the final sigmoids (egtr:450-454) run in the relation-head epilogue
+        fold_sigmoid = labels is None and not self.config.logit_adjustment and not torch.is_grad_enabled()
         logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending = \
-            self._heads(outputs, want_gate_mean=labels is not None, labels=labels)
+            self._heads(outputs, want_gate_mean=labels is not None, labels=labels, sigmoid=fold_sigmoid)
 
         loss, loss_dict, auxiliary_outputs = None, None, None
         if labels is not None:
@@ -330,8 +333,9 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
 
         if self.config.logit_adjustment:  # egtr:509-512
             pred_rel = pred_rel - self.config.logit_adj_tau * self.rel_dist.log().to(pred_rel.device)
-        pred_rel = pred_rel.sigmoid()
-        pred_connectivity = pred_connectivity.sigmoid()
+        if not fold_sigmoid:
+            pred_rel = pred_rel.sigmoid()
+            pred_connectivity = pred_connectivity.sigmoid()
 
         if not return_dict:
             output = (logits, pred_boxes) + ((auxiliary_outputs,) if auxiliary_outputs is not None else ()) \

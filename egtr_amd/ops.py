@@ -746,7 +746,7 @@ def rel_head_split_weights(w2r, w3r, w2c):
 
 
 def relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c,
-                             num_rel, triplet_dist=None, node_cls=None, want_gate_mean=False):
+                             num_rel, triplet_dist=None, node_cls=None, want_gate_mean=False, sigmoid=False):
     """Inference forward, fp32 in / fp32 out, layers 2 and 3 on the bf16 matrix cores from split operands
     (egtr_rel_head_forward_bf16x6_f32; ``w2x_*`` / ``w3x_rel`` from ``rel_head_split_weights``).  No autograd."""
     lib = _lib.lib()
@@ -777,14 +777,25 @@ def relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2x_rel, b2r, w3x_rel, 
         b2r_.data_ptr(), w3x_rel.data_ptr(), b3r_.data_ptr(), w2x_conn.data_ptr(), b2c_.data_ptr(), w3c_.data_ptr(),
         b3c_.data_ptr(), td.data_ptr() if td is not None else None,
         node_cls.data_ptr() if td is not None else None, B, N, T, 256, R, c1, rel.data_ptr(), conn.data_ptr(),
-        gm.data_ptr() if want_gate_mean else None)
+        gm.data_ptr() if want_gate_mean else None, 1 if sigmoid else 0)
     _lib.check(st, "egtr_rel_head_forward_bf16x6_f32")
     return rel, conn.unsqueeze(-1), gm
 
 
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
-                  node_cls=None, want_gate_mean=False, owner=None):
-    """``owner`` (optional nn.Module): where the derived split-bf16 weight streams of the inference kernel are cached."""
+                  node_cls=None, want_gate_mean=False, owner=None, sigmoid=False):
+    """``owner`` (optional nn.Module): where the derived split-bf16 weight streams of the inference kernel are cached.
+    ``sigmoid``: return sigmoid(logits) (the model outputs) instead of the logits -- in the inference kernel's epilogue."""
+    if sigmoid:
+        rel, conn, gm = _relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist,
+                                       node_cls, want_gate_mean, owner, True)
+        return rel, conn, gm
+    return _relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist, node_cls,
+                          want_gate_mean, owner, False)
+
+
+def _relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist, node_cls,
+                   want_gate_mean, owner, sigmoid):
     if (REL_HEAD_SPLIT_BF16 and owner is not None and gate_q.dtype == torch.float32 and gate_q.is_cuda
             and w2r.shape == (256, 256) and w3r.shape[0] <= 64 and gate_q.shape[-1] <= 9
             and not (torch.is_grad_enabled() and any(
@@ -792,7 +803,11 @@ def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c,
         w2xr, w3xr, w2xc = cached_weights(owner, "rel_head_split_bf16", [w2r, w3r, w2c],
                                           lambda: rel_head_split_weights(w2r, w3r, w2c))
         return relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2xr, b2r, w3xr, b3r, w2xc, b2c, w3c, b3c,
-                                        w3r.shape[0], triplet_dist, node_cls, want_gate_mean)
+                                        w3r.shape[0], triplet_dist, node_cls, want_gate_mean, sigmoid)
+    if sigmoid:   # every other kernel returns logits
+        rel, conn, gm = _relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist,
+                                       node_cls, want_gate_mean, None, False)
+        return rel.sigmoid(), conn.sigmoid(), gm
     if gate_q.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and any(
             t.requires_grad for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c))):
         rel, conn, gm = relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,

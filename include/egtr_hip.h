@@ -385,14 +385,15 @@ int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, c
  *   w3x_rel [8 nt][2 kb][OT][3 piece][64 lane][8], OT = 1 if num_rel <= 32 else 2:
  *           piece(W3)[32 ot + (lane & 31)][32 nt + 16 kb + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)], rows >= num_rel zero
  * (egtr_amd/ops.py::rel_head_split_weights builds them); w3c / all biases / tables are fp32 as in the f32 entry.
- * num_slots <= 9 (EGTR_E_UNSUPPORTED above: the f32 entry serves 10). */
+ * num_slots <= 9 (EGTR_E_UNSUPPORTED above: the f32 entry serves 10).  apply_sigmoid != 0: the outputs are
+ * sigmoid(logit), i.e. the model's pred_rel / pred_connectivity (model/egtr.py:450-454), not the logits. */
 int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
                                      const float* uk, const float* b1, const uint16_t* w2x_rel, const float* b2r,
                                      const uint16_t* w3x_rel, const float* b3r, const uint16_t* w2x_conn,
                                      const float* b2c, const float* w3c, const float* b3c, const float* triplet_dist,
                                      const int64_t* node_cls, int batch, int num_query, int num_slots, int hidden,
                                      int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
-                                     float* gate_mean);
+                                     float* gate_mean, int apply_sigmoid);
 
 /* Pairwise part of the relation-head backward (everything that is not a plain GEMM).  dh1 [2][B*N*N][hidden] is the
  * gradient wrt the pre-ReLU layer-1 output (relation half, connectivity half), produced by rocBLAS GEMMs from the

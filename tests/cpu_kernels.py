@@ -31,7 +31,7 @@ def decoder_self_attention(q, k, v, num_heads, want_maps=True):
 
 
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
-                  node_cls=None, want_gate_mean=False, owner=None):
+                  node_cls=None, want_gate_mean=False, owner=None, sigmoid=False):
     F = torch.nn.functional
     Hd = w2r.shape[1]
     g = torch.sigmoid(gate_q[:, :, None, :] + gate_k[:, None, :, :])
@@ -41,4 +41,6 @@ def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c,
     if triplet_dist is not None:
         rel = rel + torch.stack([triplet_dist[node_cls[i]][:, node_cls[i]] for i in range(rel.shape[0])], 0)
     gm = g.reshape(-1, g.shape[-1]).mean(0) if want_gate_mean else None
+    if sigmoid:
+        rel, conn = rel.sigmoid(), conn.sigmoid()
     return rel, conn, gm

@@ -384,6 +384,11 @@ def test_relation_head_split_bf16_is_fp32_accurate(B, N, T, R):
         dd["w3c"], dd["b3c"], R, None, None, False)
     rrel2, _, _ = ck.relation_head(*d64.values(), None, None, False)
     assert (rel2.cpu().double() - rrel2).abs().max() < 2e-4 and gm2 is None
+    # sigmoid in the epilogue == sigmoid of the logits
+    rel3, conn3, _ = ops.relation_head_split_bf16(
+        dd["gate_q"], dd["gate_k"], dd["uq"], dd["uk"], dd["b1"], w2xr, dd["b2r"], w3xr, dd["b3r"], w2xc, dd["b2c"],
+        dd["w3c"], dd["b3c"], R, trip.to(DEV), node.to(DEV), False, sigmoid=True)
+    assert (rel3 - rel.sigmoid()).abs().max() < 1e-6 and (conn3 - conn.sigmoid()).abs().max() < 1e-6
 
 
 @pytest.mark.parametrize("M,K,N,relu", [(12537, 256, 256, False), (12537, 256, 1024, True), (12537, 1024, 256, False),
