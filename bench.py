@@ -396,7 +396,7 @@ def train_bench(args, world, rank, dev, dist):
             "final_loss": float(loss), "rccl_ranks": args.rccl_ranks,
             "config": {"workload": f"VG train step: ResNet-50, N=200, 6 enc/6 dec, bs={batch}/GPU fp32, DDP x{world} "
                                    "(BASELINE configs[2] shape)", "parallelism": f"dp{world}"}}
-        if bwd_args is not None:
+        if bwd_args is not None and not args.no_kernel_probes:
             us, alg = time_msda_backward(bwd_args)
             ach = alg / (us * 1e-6) / 1e9
             result["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_q64_f32<no atomics> + msda_bwd_value_tile_f32",
@@ -478,6 +478,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1, help="images per step per GPU (reference FPS path: 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-probes", action="store_true",
+                    help="--mode train: skip the stand-alone timing loop of the MSDA backward after the timed steps (used "
+                         "for rocprofv3 traces of the steady-state step)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU-baseline work (bounded sample)")
     ap.add_argument("--graph", type=int, default=1, help="replay the forward from a HIP graph (0 = eager launches)")
     ap.add_argument("--train-graph", type=int, default=0,

@@ -14,7 +14,7 @@ rm -rf gpurun_out/prof_bench
 timeout 600 rocprofv3 --kernel-trace -d gpurun_out/prof_fb -o fb -- python bench.py --no-cpu-baseline --steps 20 > /dev/null 2>&1
 python tools/forward_breakdown.py gpurun_out/prof_fb/fb_results.db 14 > gpurun_out/${tag}_forward_breakdown.txt 2>&1
 rm -rf gpurun_out/prof_fb
-timeout 900 rocprofv3 --kernel-trace -d gpurun_out/prof_train -o train -- python bench.py --mode train --steps 8 --warmup 6 > gpurun_out/${tag}_train_rocprofv3.log 2>&1
+timeout 900 rocprofv3 --kernel-trace -d gpurun_out/prof_train -o train -- python bench.py --mode train --steps 8 --warmup 6 --no-cpu-baseline --no-kernel-probes > gpurun_out/${tag}_train_rocprofv3.log 2>&1
 python tools/rocpd_stats.py gpurun_out/prof_train/train_results.db --last-ms 300 --top 60 > gpurun_out/${tag}_train_steady_state_kernel_stats.txt 2>&1
 rm -rf gpurun_out/prof_train
 tail -c 400 gpurun_out/${tag}_bench_rocprofv3.log | head -c 0
