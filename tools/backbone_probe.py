@@ -52,7 +52,10 @@ def conv1x1_gemm(x, w2d, b, relu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tune", type=int, default=1)
+    ap.add_argument("--find", type=int, default=0, help="1 = MIOpen find mode (torch.backends.cudnn.benchmark)")
     a = ap.parse_args()
+    if a.find:
+        torch.backends.cudnn.benchmark = True
     from egtr_amd.backbone import ResNet50Features
     from egtr_amd import runtime
     dev = "cuda:0"
@@ -148,6 +151,28 @@ def main():
 
         t_d, fd = graph_time(fwd_d)
         print(f"(d) NCHW, stride-1 1x1 as W.X GEMM:  {t_d:.3f} ms")
+
+        # (e) NCHW, EVERY convolution through MIOpen (its own choice for the 1x1 ones) + the shipped epilogue kernel
+        def fwd_e():
+            w, b = P["stem"]
+            y = net.maxpool(ops.bias_act_(F.conv2d(x, w, None, stride=2, padding=3), b))
+            feats = []
+            for li in range(1, 5):
+                for blk, p in zip(getattr(net, f"layer{li}"), P[li]):
+                    s_ = blk.conv2.stride
+                    idt = y
+                    if blk.downsample is not None:
+                        idt = ops.bias_act_(F.conv2d(y, p[3][0], None, stride=blk.downsample[0].stride), p[3][1], None,
+                                            relu=False)
+                    z = ops.bias_act_(F.conv2d(y, p[0][0]), p[0][1])
+                    z = ops.bias_act_(F.conv2d(z, p[1][0], None, stride=s_, padding=1), p[1][1])
+                    y = ops.bias_act_(F.conv2d(z, p[2][0]), p[2][1], idt)
+                if li in net.out_indices:
+                    feats.append(y)
+            return feats
+
+        t_e, fe = graph_time(fwd_e)
+        print(f"(e) NCHW, every convolution through MIOpen:  {t_e:.3f} ms")
         for i in range(3):
             print(f"  C{i + 3}: max |d - a| = {(fd[i] - fa[i]).abs().max().item():.3e}")
         for i in range(3):
