@@ -14,6 +14,8 @@ Fixtures:
                   eval-mode and train-mode loss dicts, Hungarian indices, matching costs, gradient norms.
   sgg_full.npz    600x1000, N=200, Le=Ld=6, C=150, R=50 (BASELINE config 2) with stub backbone: logits, boxes,
                   strided relation logits + checksums.
+  sgg_cfg0.npz    the same for BASELINE configs[0] (N=100, 3 decoder layers); sgg_oi.npz for configs[3] (Open Images V6
+                  heads: C=601, R=30).
   sgg_stress.npz  800x1333, N=300, Le=6, Ld=8, C=150, R=50 (BASELINE config 5 geometry), 2 images (one padded), stub
                   backbone, fp32 -- and the same model with weights / pixels rounded to bf16 (fp32 arithmetic): the
                   reference point for the bf16 product model.
@@ -228,25 +230,41 @@ def gen_sgg_small_refine():
     print("sgg_small_refine.npz", float(out_t.loss), res["inter_ref"].shape)
 
 
-def gen_sgg_full():
-    over = dict(num_queries=200, encoder_layers=6, decoder_layers=6, num_labels=150, num_rel_labels=50)
-    model, cfg, cfg_dict, shapes = build_ref_model(over, seed=31)
+def _gen_full(fname, over, seed, input_seed):
+    model, cfg, cfg_dict, shapes = build_ref_model(over, seed=seed)
     model.eval()
-    rng = W.rng_inputs(32)
+    rng = W.rng_inputs(input_seed)
     pv = torch.from_numpy(rng.standard_normal((1, 3, 600, 1000))).float()
     pm = torch.ones(1, 600, 1000, dtype=torch.long)
     with torch.no_grad():
         out, cap, qk = run_ref(model, pv, pm)
-    bias = out.pred_rel.new_zeros(())
-    res = dict(cfg=json.dumps(cfg_dict), shapes=json.dumps(shapes), seed=31, input_seed=32,
+    res = dict(cfg=json.dumps(cfg_dict), shapes=json.dumps(shapes), seed=seed, input_seed=input_seed,
                logits=np_(out.logits), pred_boxes=np_(out.pred_boxes),
                rel_mlp_strided=np_(cap["rel_mlp"][:, ::5, ::7]), conn_logits=np_(cap["conn"][..., 0]),
                pred_rel_sum=np.float64(out.pred_rel.double().sum().item()),
                pred_conn_sum=np.float64(out.pred_connectivity.double().sum().item()),
                rel_mlp_abs_sum=np.float64(cap["rel_mlp"].double().abs().sum().item()),
                enc_strided=np_(qk["enc"][:, ::37]), last_hidden=np_(qk["inter"][:, -1]))
-    np.savez_compressed(os.path.join(HERE, "sgg_full.npz"), **res)
-    print("sgg_full.npz", out.pred_rel.shape, float(res["pred_rel_sum"]))
+    np.savez_compressed(os.path.join(HERE, fname), **res)
+    print(fname, out.pred_rel.shape, float(res["pred_rel_sum"]))
+
+
+def gen_sgg_full():
+    """BASELINE configs[1] / [2] shape: Visual Genome heads, N = 200, 6 + 6 layers, one 600x1000 image."""
+    _gen_full("sgg_full.npz", dict(num_queries=200, encoder_layers=6, decoder_layers=6, num_labels=150,
+                                   num_rel_labels=50), 31, 32)
+
+
+def gen_sgg_cfg0():
+    """BASELINE configs[0]: one 600x1000 image, N = 100 queries, 3 decoder layers."""
+    _gen_full("sgg_cfg0.npz", dict(num_queries=100, encoder_layers=6, decoder_layers=3, num_labels=150,
+                                   num_rel_labels=50), 81, 82)
+
+
+def gen_sgg_oi():
+    """BASELINE configs[3]: Open Images V6 heads (601 object classes / 30 predicates), N = 200, one 600x1000 image."""
+    _gen_full("sgg_oi.npz", dict(num_queries=200, encoder_layers=6, decoder_layers=6, num_labels=601,
+                                 num_rel_labels=30), 91, 92)
 
 
 def _bf16_round(t):
@@ -327,7 +345,7 @@ def gen_sgg_full_train():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["msda", "mha", "small", "refine", "full", "stress", "full_train"]
+    which = sys.argv[1:] or ["msda", "mha", "small", "refine", "full", "cfg0", "oi", "stress", "full_train"]
     torch.set_num_threads(8)
     if "msda" in which:
         gen_msda()
@@ -339,6 +357,10 @@ if __name__ == "__main__":
         gen_sgg_small_refine()
     if "full" in which:
         gen_sgg_full()
+    if "cfg0" in which:
+        gen_sgg_cfg0()
+    if "oi" in which:
+        gen_sgg_oi()
     if "stress" in which:
         gen_sgg_stress()
     if "full_train" in which:

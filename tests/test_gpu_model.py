@@ -148,10 +148,12 @@ def test_hungarian_indices_bit_exact_on_device_outputs(small):
         assert (costs[i].cpu() - _t(g[f"match_cost_{i}"])).abs().max() < 1e-3
 
 
-def test_full_size_600x1000_vs_reference(golden_dir):
-    """BASELINE config 2 shape: N=200, 6 enc / 6 dec, C=150, R=50, stub backbone (the fixture's).  Relation and
-    connectivity outputs are compared as PRE-sigmoid logits at the north-star's 1e-3 (egtr:402-416, 450-454)."""
-    g = Hh.load_golden(golden_dir, "sgg_full.npz")
+@pytest.mark.parametrize("fixture", ["sgg_full.npz", "sgg_cfg0.npz", "sgg_oi.npz"])
+def test_full_size_600x1000_vs_reference(golden_dir, fixture):
+    """One 600x1000 image, stub backbone (the fixture's), at BASELINE configs[1]/[2] (N=200, 6 enc / 6 dec, C=150, R=50),
+    configs[0] (N=100, 3 decoder layers) and configs[3] (Open Images V6 heads: C=601, R=30).  Relation and connectivity
+    outputs are compared as PRE-sigmoid logits at the north-star's 1e-3 (egtr:402-416, 450-454)."""
+    g = Hh.load_golden(golden_dir, fixture)
     cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
     model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
     model.load_state_dict(sd)

@@ -192,8 +192,8 @@ def test_box_refine_forward_and_loss_vs_reference(golden_dir):
     assert abs(float(total) - float(g["train_loss"])) < 2e-4 * abs(float(g["train_loss"]))
 
 
-def full_case(golden_dir):
-    g = _load(golden_dir, "sgg_full.npz")
+def full_case(golden_dir, fixture="sgg_full.npz"):
+    g = _load(golden_dir, fixture)
     cfg = O_cfg(json.loads(str(g["cfg"])))
     shapes = json.loads(str(g["shapes"]))
     sd = W.fill_state_dict(shapes, seed=int(g["seed"]))
@@ -204,9 +204,11 @@ def full_case(golden_dir):
     return g, cfg, sd, pv, pm
 
 
-def test_full_size_600x1000_vs_reference(golden_dir):
-    """BASELINE config 2 shape (N=200, 6 enc / 6 dec, C=150, R=50) with the stub backbone."""
-    g, cfg, sd, pv, pm = full_case(golden_dir)
+@pytest.mark.parametrize("fixture", ["sgg_full.npz", "sgg_cfg0.npz", "sgg_oi.npz"])
+def test_full_size_600x1000_vs_reference(golden_dir, fixture):
+    """One 600x1000 image with the stub backbone at BASELINE configs[1]/[2] (N=200, 6 + 6 layers, C=150, R=50),
+    configs[0] (N=100, 3 decoder layers) and configs[3] (Open Images V6 heads: C=601, R=30)."""
+    g, cfg, sd, pv, pm = full_case(golden_dir, fixture)
     with torch.no_grad():
         out = O.sgg_forward(sd, cfg, pv, pm)
     tol = 5e-4
