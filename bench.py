@@ -619,6 +619,15 @@ def main():
         rel_entry["arithmetic"] = "fp32 via bf16x6 operand split, fp32 accumulate"
         rel_entry["bf16_mfma_flops_executed"] = executed
         rel_entry["frac_of_bf16_dense_peak"] = round(executed / (rel_us * 1e-6) / 1e12 / 2500.0, 4)
+    rpath = os.path.join(ROOT, "profiles", "r02_rel_head_pmc.json")   # same provenance as the MSDA counters above
+    if os.path.exists(rpath):
+        try:
+            rp = json.load(open(rpath))
+            if rp.get("kernel") == rel_entry["kernel"]:
+                rel_entry["traffic"] = rp.get("hbm_bytes_per_launch")
+                rel_entry["l2_hit"] = rp.get("l2_hit")
+        except Exception:
+            pass
     result["roofline_kernels"] = [result["roofline"], rel_entry]
     if _ops.GEMM_SPLIT_BF16:
         g_us, g_flops = time_split_gemm(dev)
