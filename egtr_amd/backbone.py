@@ -84,6 +84,8 @@ class Bottleneck(nn.Module):
         p = [_fold(self.conv1, self.bn1), _fold(self.conv2, self.bn2), _fold(self.conv3, self.bn3)]
         if self.downsample is not None:
             p.append(_fold(self.downsample[0], self.downsample[1]))
+            # the shortcut's shift is applied together with conv3's (one epilogue pass instead of two)
+            p.append((None, (p[2][1] + p[3][1]).contiguous()))
         return p
 
     def forward_folded(self, x, p):
@@ -93,15 +95,18 @@ class Bottleneck(nn.Module):
         from . import ops
         s = self.conv2.stride
         idt = x
+        shift3 = p[2][1]
         if self.downsample is not None:
+            # raw shortcut convolution: its frozen-BN shift rides along with conv3's in the final epilogue pass,
+            # relu(conv3 + (shift3 + shift_d) + shortcut) -- one pass over the block output instead of two
             if tuple(self.downsample[0].stride) == (1, 1):
-                idt = ops.bias_act_(conv1x1_as_gemm(x, p[3][0]), p[3][1], None, relu=False)
+                idt = conv1x1_as_gemm(x, p[3][0])
             else:
-                idt = ops.bias_act_(F.conv2d(x, p[3][0], None, stride=self.downsample[0].stride), p[3][1], None,
-                                    relu=False)
+                idt = F.conv2d(x, p[3][0], None, stride=self.downsample[0].stride)
+            shift3 = p[4][1]
         y = ops.bias_act_(conv1x1_as_gemm(x, p[0][0]), p[0][1])
         y = ops.bias_act_(F.conv2d(y, p[1][0], None, stride=s, padding=1), p[1][1])
-        return ops.bias_act_(conv1x1_as_gemm(y, p[2][0]), p[2][1], idt)
+        return ops.bias_act_(conv1x1_as_gemm(y, p[2][0]), shift3, idt)
 
 
 class ResNet50Features(nn.Module):

@@ -84,7 +84,7 @@ def main():
                          w2=p[1][0].contiguous(memory_format=CL), b2=p[1][1], w3=p[2][0].flatten(1).contiguous(),
                          b3=p[2][1], w1c=p[0][0].contiguous(memory_format=CL),
                          w3c=p[2][0].contiguous(memory_format=CL))
-                if len(p) == 4:
+                if len(p) >= 4:
                     d.update(wd=p[3][0].flatten(1).contiguous(), bd=p[3][1], wdc=p[3][0].contiguous(memory_format=CL),
                              dstride=blk.downsample[0].stride)
                 blocks.append((li, d))
