@@ -52,6 +52,8 @@ SIGNATURES = {
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],
     "egtr_hungarian_match_scratch_doubles": [_I, _I, ctypes.c_longlong],
+    "egtr_detection_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P,
+                                _P, _P],
     "egtr_relation_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I, _I, _P, _P, _P, _P],
     "egtr_relation_loss_workspace_bytes": [_I, _I],
     "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,

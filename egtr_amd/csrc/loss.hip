@@ -397,3 +397,147 @@ extern "C" int egtr_relation_loss_f32(egtr_stream_t stream, const float* pred_re
                      partial_rel, (int)(B * rows), total_sel, done, loss_out);
   return egtr_check_launch();
 }
+
+// ---- detection losses of one output set (labels / boxes / cardinality, egtr:611-659, 661-670, 692-712) ------------------
+// The reference evaluates them as ~40 small tensor ops per output set (7 sets with auxiliary losses), plus their autograd
+// graph.  One workgroup per image: target-class map in LDS from the matcher's packed indices, sigmoid focal loss + its
+// gradient over the [N, C] logits, argmax-based cardinality count, L1 + generalised-IoU loss + gradients of the matched
+// boxes.  Sums are formed in a fixed order (per-thread partial -> LDS -> thread 0): bit-reproducible.  The caller divides
+// nothing: every sum and every gradient already carries 1 / num_boxes.
+namespace {
+
+constexpr int kDT = 256;
+constexpr int kDetMaxN = 2048;
+
+__device__ __forceinline__ float softplusf(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
+
+__global__ __launch_bounds__(kDT) void det_loss_f32(
+    const float* __restrict__ logits, const float* __restrict__ boxes, const long long* __restrict__ pred_idx,
+    const long long* __restrict__ tgt_idx, const int* __restrict__ moff, const long long* __restrict__ tlabels,
+    const float* __restrict__ tboxes, const int* __restrict__ toff, int N, int C, float alpha, float inv_num_boxes,
+    float* __restrict__ d_logits, float* __restrict__ d_l1, float* __restrict__ d_giou, float* __restrict__ out) {
+  __shared__ int s_cls[kDetMaxN];
+  __shared__ float s_red[3][kDT];
+  __shared__ int s_cnt[kDT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = moff[b], m1 = moff[b + 1], t0 = toff[b];
+  for (int n = tid; n < N; n += kDT) s_cls[n] = C;                 // "no object" (egtr:640-642)
+  for (int e = tid; e < N * 4; e += kDT) {
+    d_l1[(size_t)b * N * 4 + e] = 0.f;
+    d_giou[(size_t)b * N * 4 + e] = 0.f;
+  }
+  __syncthreads();
+  for (int k = m0 + tid; k < m1; k += kDT) s_cls[(int)pred_idx[k]] = (int)tlabels[t0 + (int)tgt_idx[k]];
+  __syncthreads();
+
+  // ---- sigmoid focal loss, gamma = 2 (egtr:647-656, dd:2687-2722) --------------------------------------------------
+  float fsum = 0.f;
+  const float* lg = logits + (size_t)b * N * C;
+  float* dl = d_logits + (size_t)b * N * C;
+  for (int e = tid; e < N * C; e += kDT) {
+    const int n = e / C, c = e - n * C;
+    const float x = lg[e];
+    const bool t = s_cls[n] == c;
+    const float p = 1.f / (1.f + expf(-x));
+    const float ce = t ? softplusf(-x) : softplusf(x);            // = -log p_t
+    const float pt = t ? p : 1.f - p;
+    const float om = 1.f - pt;
+    const float a = alpha >= 0.f ? (t ? alpha : 1.f - alpha) : 1.f;
+    fsum += a * om * om * ce;
+    const float g = a * om * om * (2.f * pt * (-ce) - om);         // d f / d x up to the sign of dp_t/dx
+    dl[e] = (t ? g : -g) * inv_num_boxes;
+  }
+
+  // ---- cardinality (egtr:661-670): rows whose argmax is not the LAST class; first maximum on ties, like torch.argmax ---
+  int cnt = 0;
+  for (int n = wave; n < N; n += kDT / 64) {
+    float best = -INFINITY;
+    int bi = C;
+    for (int c = lane; c < C; c += 64) {
+      const float v = lg[(size_t)n * C + c];
+      if (v > best) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float ov = __shfl_xor(best, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    cnt += (bi != C - 1) ? 1 : 0;
+  }
+  if (lane == 0) s_cnt[wave] = cnt;
+
+  // ---- matched boxes: L1 + generalised IoU (egtr:692-712, dd util generalized_box_iou) -----------------------------------
+  float l1sum = 0.f, gsum = 0.f;
+  for (int k = m0 + tid; k < m1; k += kDT) {
+    const int n = (int)pred_idx[k];
+    const float4 s = *reinterpret_cast<const float4*>(boxes + ((size_t)b * N + n) * 4);
+    const float4 t = *reinterpret_cast<const float4*>(tboxes + (size_t)(t0 + (int)tgt_idx[k]) * 4);
+    l1sum += fabsf(s.x - t.x) + fabsf(s.y - t.y) + fabsf(s.z - t.z) + fabsf(s.w - t.w);
+    auto sgn = [](float d) { return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); };
+    *reinterpret_cast<float4*>(d_l1 + ((size_t)b * N + n) * 4) =
+        make_float4(sgn(s.x - t.x) * inv_num_boxes, sgn(s.y - t.y) * inv_num_boxes, sgn(s.z - t.z) * inv_num_boxes,
+                    sgn(s.w - t.w) * inv_num_boxes);
+    // corners
+    const float x0 = s.x - 0.5f * s.z, y0 = s.y - 0.5f * s.w, x1 = s.x + 0.5f * s.z, y1 = s.y + 0.5f * s.w;
+    const float u0 = t.x - 0.5f * t.z, v0 = t.y - 0.5f * t.w, u1 = t.x + 0.5f * t.z, v1 = t.y + 0.5f * t.w;
+    const float as = (x1 - x0) * (y1 - y0), at = (u1 - u0) * (v1 - v0);
+    const float iwr = fminf(x1, u1) - fmaxf(x0, u0), ihr = fminf(y1, v1) - fmaxf(y0, v0);
+    const float iw = fmaxf(iwr, 0.f), ih = fmaxf(ihr, 0.f);
+    const float inter = iw * ih, uni = as + at - inter;
+    const float ew = fmaxf(fmaxf(x1, u1) - fminf(x0, u0), 0.f), eh = fmaxf(fmaxf(y1, v1) - fminf(y0, v0), 0.f);
+    const float ea = ew * eh;
+    const float giou = inter / uni - (ea - uni) / ea;
+    gsum += 1.f - giou;
+    // d(iw) / d(x0, x1), d(ew) / d(x0, x1) and the same for y
+    const float iw_x1 = (iwr > 0.f && x1 < u1) ? 1.f : 0.f, iw_x0 = (iwr > 0.f && x0 > u0) ? -1.f : 0.f;
+    const float ih_y1 = (ihr > 0.f && y1 < v1) ? 1.f : 0.f, ih_y0 = (ihr > 0.f && y0 > v0) ? -1.f : 0.f;
+    const float ew_x1 = x1 > u1 ? 1.f : 0.f, ew_x0 = x0 < u0 ? -1.f : 0.f;
+    const float eh_y1 = y1 > v1 ? 1.f : 0.f, eh_y0 = y0 < v0 ? -1.f : 0.f;
+    auto dgiou = [&](float d_as, float d_inter, float d_ea) {
+      const float d_uni = d_as - d_inter;
+      return (d_inter * uni - inter * d_uni) / (uni * uni) + (d_uni * ea - uni * d_ea) / (ea * ea);
+    };
+    const float g_x0 = dgiou(-(y1 - y0), iw_x0 * ih, ew_x0 * eh), g_x1 = dgiou((y1 - y0), iw_x1 * ih, ew_x1 * eh);
+    const float g_y0 = dgiou(-(x1 - x0), iw * ih_y0, ew * eh_y0), g_y1 = dgiou((x1 - x0), iw * ih_y1, ew * eh_y1);
+    // loss = 1 - giou; corners -> (cx, cy, w, h)
+    *reinterpret_cast<float4*>(d_giou + ((size_t)b * N + n) * 4) =
+        make_float4(-(g_x0 + g_x1) * inv_num_boxes, -(g_y0 + g_y1) * inv_num_boxes,
+                    -0.5f * (g_x1 - g_x0) * inv_num_boxes, -0.5f * (g_y1 - g_y0) * inv_num_boxes);
+  }
+  s_red[0][tid] = fsum;
+  s_red[1][tid] = l1sum;
+  s_red[2][tid] = gsum;
+  __syncthreads();
+  if (tid == 0) {
+    double f = 0.0, l = 0.0, g = 0.0;
+    for (int i = 0; i < kDT; ++i) { f += s_red[0][i]; l += s_red[1][i]; g += s_red[2][i]; }
+    int c = 0;
+    for (int w = 0; w < kDT / 64; ++w) c += s_cnt[w];
+    out[b * 4 + 0] = (float)(f * inv_num_boxes);
+    out[b * 4 + 1] = (float)(l * inv_num_boxes);
+    out[b * 4 + 2] = (float)(g * inv_num_boxes);
+    out[b * 4 + 3] = (float)c;
+  }
+}
+
+}  // namespace
+
+extern "C" int egtr_detection_loss_f32(egtr_stream_t stream, const float* logits, const float* pred_boxes,
+                                       const int64_t* pred_idx, const int64_t* tgt_idx, const int* match_offsets,
+                                       const int64_t* target_labels, const float* target_boxes,
+                                       const int* target_offsets, int batch, int num_query, int num_classes,
+                                       float focal_alpha, float num_boxes, float* grad_logits, float* grad_boxes_l1,
+                                       float* grad_boxes_giou, float* out) {
+  if (!logits || !pred_boxes || !pred_idx || !tgt_idx || !match_offsets || !target_labels || !target_boxes ||
+      !target_offsets || !grad_logits || !grad_boxes_l1 || !grad_boxes_giou || !out)
+    return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_classes <= 0 || !(num_boxes > 0.f)) return EGTR_E_ARG;
+  if (num_query > kDetMaxN) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(det_loss_f32, dim3(batch), dim3(kDT), 0, static_cast<hipStream_t>(stream), logits, pred_boxes,
+                     reinterpret_cast<const long long*>(pred_idx), reinterpret_cast<const long long*>(tgt_idx),
+                     match_offsets, reinterpret_cast<const long long*>(target_labels), target_boxes, target_offsets,
+                     num_query, num_classes, focal_alpha, 1.0f / num_boxes, grad_logits, grad_boxes_l1,
+                     grad_boxes_giou, out);
+  return egtr_check_launch();
+}

@@ -1124,6 +1124,12 @@ class DeformableDetrMLPPredictionHead(nn.Module):
         return x
 
 
+class MatchedIndices(list):
+    """The matcher's per-image (prediction indices, target indices) list; ``flat`` additionally holds the packed device
+    tensors they are views of (device matcher only)."""
+    flat = None
+
+
 class DeformableDetrHungarianMatcher(nn.Module):
     """Hungarian matcher with the adaptive-smoothing cost offset (dd:2886-3015).
 
@@ -1182,11 +1188,12 @@ class DeformableDetrHungarianMatcher(nn.Module):
     def finish(self, pending):
         if pending[0] == "device":
             _, pred_idx, tgt_idx, mcost, n_out = pending
-            indices, costs, o = [], [], 0
+            indices, costs, o = MatchedIndices(), [], 0
             for n in n_out:
                 indices.append((pred_idx[o:o + n], tgt_idx[o:o + n]))
                 costs.append(mcost[o:o + n])
                 o += n
+            indices.flat = (pred_idx, tgt_idx, list(n_out))   # the packed form, for the fused detection losses
             return indices, costs
         _, cost_matrix, sizes, device = pending
         if self.smoothing:

@@ -630,13 +630,38 @@ class SceneGraphGenerationLoss(nn.Module):
         indices, matching_costs = matched if matched is not None else self.matcher(outputs_without_aux, targets)
         num_boxes = float(max(sum(len(t["class_labels"]) for t in targets), 1))
         losses = {}
+        # labels + cardinality + boxes of an output set as ONE HIP launch (values and gradients) when the device matcher
+        # packed the indices: ~40 small tensor ops per set otherwise, 7 sets with the auxiliary losses
+        fused = ("labels", "cardinality", "boxes")
+        packed = None
+
+        def fused_ok(out, idx):
+            lg = out.get("logits")
+            return (all(k in self.losses for k in fused) and getattr(idx, "flat", None) is not None and lg is not None
+                    and lg.is_cuda and lg.dtype == torch.float32 and out["pred_boxes"].dtype == torch.float32
+                    and lg.shape[1] <= 2048)
+
+        def detection(out, idx):
+            nonlocal packed
+            if packed is None:
+                packed = ops.pack_detection_targets(targets, out["logits"].device)
+            return ops.detection_losses(out["logits"], out["pred_boxes"], idx.flat, packed, self.focal_alpha, num_boxes)
+
+        use_fused = fused_ok(outputs, indices)
+        if use_fused:
+            losses.update(detection(outputs, indices))
         for loss in self.losses:
+            if use_fused and loss in fused:
+                continue
             losses.update(self.get_loss(loss, outputs, targets, indices, matching_costs, num_boxes))
         if "auxiliary_outputs" in outputs:
             for i, auxiliary_outputs in enumerate(outputs["auxiliary_outputs"]):
                 indices, matching_costs = self.matcher(auxiliary_outputs, targets)
+                aux_fused = fused_ok(auxiliary_outputs, indices)
+                if aux_fused:
+                    losses.update({k + f"_{i}": v for k, v in detection(auxiliary_outputs, indices).items()})
                 for loss in self.losses:
-                    if loss in ["masks", "relations", "uncertainty"]:
+                    if loss in ["masks", "relations", "uncertainty"] or (aux_fused and loss in fused):
                         continue
                     l_dict = self.get_loss(loss, auxiliary_outputs, targets, indices, matching_costs, num_boxes)
                     losses.update({k + f"_{i}": v for k, v in l_dict.items()})

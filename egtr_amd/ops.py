@@ -919,6 +919,78 @@ class RelationLossFunction(Function):
         return grad_rel * g_rel, grad_conn * g_conn, None, None, None, None, None, None, None, None
 
 
+class DetectionLossFunction(Function):
+    """loss_ce / loss_bbox / loss_giou (+ the cardinality counts) of one output set with their gradients from one launch
+    (csrc/loss.hip, egtr_detection_loss_f32); backward only scales the stored gradients."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, pred_idx, tgt_idx, match_off, tgt_labels, tgt_boxes, tgt_off, focal_alpha,
+                num_boxes):
+        lib = _lib.lib()
+        B, N, C = logits.shape
+        lg = _chk(logits.detach().contiguous(), "logits", torch.float32)
+        bx = _chk(boxes.detach().contiguous(), "pred_boxes", torch.float32)
+        dev = lg.device
+        out = torch.empty(B, 4, dtype=torch.float32, device=dev)
+        d_logits = torch.empty_like(lg)
+        d_l1 = torch.empty_like(bx)
+        d_giou = torch.empty_like(bx)
+        st = lib.egtr_detection_loss_f32(_stream(), lg.data_ptr(), bx.data_ptr(), pred_idx.data_ptr(),
+                                         tgt_idx.data_ptr(), match_off.data_ptr(), tgt_labels.data_ptr(),
+                                         tgt_boxes.data_ptr(), tgt_off.data_ptr(), B, N, C, float(focal_alpha),
+                                         float(num_boxes), d_logits.data_ptr(), d_l1.data_ptr(), d_giou.data_ptr(),
+                                         out.data_ptr())
+        _lib.check(st, "egtr_detection_loss_f32")
+        ctx.save_for_backward(d_logits, d_l1, d_giou)
+        sums = out.sum(0)
+        card = out[:, 3]
+        ctx.mark_non_differentiable(card)
+        return sums[0], sums[1], sums[2], card
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_ce, g_bbox, g_giou, g_card):
+        d_logits, d_l1, d_giou = ctx.saved_tensors
+        return (d_logits * g_ce, d_l1 * g_bbox + d_giou * g_giou, None, None, None, None, None, None, None, None)
+
+
+def pack_detection_targets(targets, device):
+    """Concatenated class labels / boxes of a batch + per-image offsets, built once per step and shared by the output
+    sets (main + auxiliary) of ``detection_losses``."""
+    sizes = [int(t["class_labels"].shape[0]) for t in targets]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    if offs[-1]:
+        labels = torch.cat([t["class_labels"] for t in targets]).to(device=device, dtype=torch.int64).contiguous()
+        boxes = torch.cat([t["boxes"] for t in targets]).to(device=device, dtype=torch.float32).contiguous()
+    else:   # keep the kernel's pointers valid
+        labels = torch.zeros(1, dtype=torch.int64, device=device)
+        boxes = torch.zeros(1, 4, dtype=torch.float32, device=device)
+    toff = torch.tensor(offs, dtype=torch.int32).to(device, non_blocking=True)
+    lengths = torch.tensor(sizes, dtype=torch.float32).to(device, non_blocking=True)
+    return labels, boxes, toff, lengths
+
+
+def detection_losses(logits, pred_boxes, flat_match, packed_targets, focal_alpha, num_boxes):
+    """{"loss_ce", "loss_bbox", "loss_giou", "cardinality_error"} of one output set (egtr:611-712) from one launch.
+    ``flat_match``: (pred_idx, tgt_idx, n_out) as the device matcher packs them; ``packed_targets``:
+    ``pack_detection_targets``."""
+    pred_idx, tgt_idx, n_out = flat_match
+    labels, boxes, toff, lengths = packed_targets
+    offs = [0]
+    for n in n_out:
+        offs.append(offs[-1] + int(n))
+    moff = torch.tensor(offs, dtype=torch.int32).to(logits.device, non_blocking=True)
+    if pred_idx.numel() == 0:
+        pred_idx = torch.zeros(1, dtype=torch.int64, device=logits.device)
+        tgt_idx = torch.zeros(1, dtype=torch.int64, device=logits.device)
+    ce, bbox, giou, card = DetectionLossFunction.apply(logits, pred_boxes, pred_idx, tgt_idx, moff, labels, boxes, toff,
+                                                       focal_alpha, num_boxes)
+    return {"loss_ce": ce, "loss_bbox": bbox, "loss_giou": giou,
+            "cardinality_error": (card - lengths).abs().mean()}
+
+
 def relation_losses(pred_rel, pred_conn, targets, indices, matching_costs, nonmatching_cost, sample_negatives,
                     sample_nonmatching):
     """(loss_rel, loss_connectivity) for device tensors: see RelationLossFunction.  ``indices`` / ``matching_costs``: the

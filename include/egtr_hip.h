@@ -404,6 +404,20 @@ int egtr_rel_head_backward_pairs_f32(egtr_stream_t stream, const float* dh1, con
                                      int hidden, float* grad_uq, float* grad_uk, float* grad_gate_q,
                                      float* grad_gate_k, float* dz_workspace);
 
+/* Detection losses of ONE output set in one launch (model/egtr.py:611-659 loss_labels, 661-670 loss_cardinality,
+ * 692-712 loss_boxes): sigmoid focal loss (gamma = 2) over logits [B, N, C] against the matched target classes, the
+ * argmax-based cardinality count, L1 and generalised-IoU loss of the matched boxes -- values AND gradients.
+ * pred_idx / tgt_idx: the matcher's packed indices (egtr_hungarian_match_f32), entries match_offsets[b] ..
+ * match_offsets[b + 1] belong to image b, tgt_idx is relative to the image's own targets; target_labels / target_boxes:
+ * all targets concatenated, image b's at target_offsets[b] ...  out [B, 4] = per image {focal, L1, GIoU} sums already
+ * divided by num_boxes, and the cardinality count; grad_logits [B, N, C], grad_boxes_l1 / grad_boxes_giou [B, N, 4]:
+ * gradients of the three (summed) losses w.r.t. logits / pred_boxes.  num_query <= 2048. */
+int egtr_detection_loss_f32(egtr_stream_t stream, const float* logits, const float* pred_boxes, const int64_t* pred_idx,
+                            const int64_t* tgt_idx, const int* match_offsets, const int64_t* target_labels,
+                            const float* target_boxes, const int* target_offsets, int batch, int num_query,
+                            int num_classes, float focal_alpha, float num_boxes, float* grad_logits,
+                            float* grad_boxes_l1, float* grad_boxes_giou, float* out);
+
 #ifdef __cplusplus
 }
 #endif

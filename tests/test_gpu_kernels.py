@@ -1114,3 +1114,52 @@ def test_msda_bf16_backward(B, Lq, shapes):
     assert (v.grad.float().cpu() - rgv).abs().max() < 2 ** -7 * max(1.0, float(rgv.abs().max()))
     assert (at.grad.cpu() - rga).abs().max() < 1e-3 * max(1.0, float(rga.abs().max()))
     assert (loc.grad.cpu() - rgl).abs().max() < 1e-3 * max(1.0, float(rgl.abs().max()))
+
+
+@pytest.mark.parametrize("B,N,C,Ts", [(2, 200, 150, (30, 9)), (3, 40, 12, (5, 12, 1)), (2, 64, 601, (6, 0)),
+                                      (1, 300, 150, (40,))])
+def test_detection_loss_kernel_vs_tensor_composition(B, N, C, Ts):
+    """labels / cardinality / boxes of one output set in one launch (egtr_detection_loss_f32) against the line-by-line
+    tensor composition (egtr:611-712) with autograd: values and gradients w.r.t. logits and boxes, incl. an image
+    without targets and the aux-style weighting of the three terms."""
+    from egtr_amd import ops
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher
+    from egtr_amd.egtr import SceneGraphGenerationLoss
+    rng = W.rng_inputs(2300 + N + C)
+    m = DeformableDetrHungarianMatcher(class_cost=2.0, bbox_cost=5.0, giou_cost=2.0, smoothing=1e-14)
+    crit = SceneGraphGenerationLoss(
+        matcher=m, num_object_queries=N, num_classes=C, num_rel_labels=7, eos_coef=0.1,
+        losses=["labels", "cardinality", "boxes"], smoothing=1e-14, rel_sample_negatives=80, rel_sample_nonmatching=80,
+        model_training=True, focal_alpha=0.25, rel_sample_negatives_largest=True, rel_sample_nonmatching_largest=True)
+    logits = torch.from_numpy(rng.standard_normal((B, N, C)) * 2).float().to(DEV)
+    cxcy = rng.uniform(0.2, 0.8, (B, N, 2))
+    wh = rng.uniform(0.05, 0.4, (B, N, 2))
+    boxes = torch.from_numpy(np.concatenate([cxcy, wh], -1)).float().to(DEV)
+    targets = []
+    for t in Ts:
+        tc = rng.uniform(0.2, 0.8, (t, 2))
+        tw = rng.uniform(0.05, 0.4, (t, 2))
+        targets.append({"class_labels": torch.from_numpy(rng.integers(0, C, t)).long().to(DEV),
+                        "boxes": torch.from_numpy(np.concatenate([tc, tw], -1)).float().to(DEV)})
+    weights = {"loss_ce": 2.0, "loss_bbox": 5.0, "loss_giou": 2.0}
+
+    def run(fused):
+        lg = logits.clone().requires_grad_(True)
+        bx = boxes.clone().requires_grad_(True)
+        out = {"logits": lg, "pred_boxes": bx}
+        indices, costs = m(out, targets)
+        assert getattr(indices, "flat", None) is not None
+        if not fused:
+            indices = list(indices)      # plain list: the tensor composition
+        losses = crit(out, targets, matched=(indices, costs))
+        total = sum(losses[k] * w for k, w in weights.items())
+        total.backward()
+        return {k: float(v) for k, v in losses.items()}, lg.grad.clone(), bx.grad.clone()
+
+    lf, glf, gbf = run(True)
+    lr, glr, gbr = run(False)
+    assert set(lf) == set(lr) == {"loss_ce", "loss_bbox", "loss_giou", "cardinality_error"}
+    for k in lr:
+        assert abs(lf[k] - lr[k]) < 2e-5 * max(1.0, abs(lr[k])), (k, lf[k], lr[k])
+    assert (glf - glr).abs().max() < 2e-5 * max(1e-3, float(glr.abs().max()))
+    assert (gbf - gbr).abs().max() < 2e-5 * max(1e-3, float(gbr.abs().max()))
