@@ -52,6 +52,8 @@ SIGNATURES = {
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],
     "egtr_hungarian_match_scratch_doubles": [_I, _I, ctypes.c_longlong],
+    "egtr_any_nonfinite_f32": [_P, _P, ctypes.c_longlong, _P],
+    "egtr_clamp_if_flag_f32": [_P, _P, _P, ctypes.c_longlong, _P, ctypes.c_float, _I],
     "egtr_detection_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P,
                                 _P, _P],
     "egtr_relation_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I, _I, _P, _P, _P, _P],

@@ -787,3 +787,64 @@ extern "C" int egtr_add_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, 
   return egtr_check_launch();
 }
 
+
+// ---- "clamp iff any element is inf / nan" of the encoder layers in training (model/deformable_detr.py:1346-1351) ------
+// The reference branches on the host (two synchronisations per layer).  Here: one pass raises a device flag if any element
+// is non-finite; the clamp pass and the masking pass of the backward return at once while the flag is clear -- which is
+// every step of a healthy run -- so the states are neither copied nor re-read.
+namespace {
+
+__global__ __launch_bounds__(256) void any_nonfinite_f32(const float* __restrict__ x, long long n4, long long n,
+                                                         int* __restrict__ flag) {
+  bool bad = false;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    // finite <=> exponent field not all ones
+    bad |= ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) |
+           ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u);
+  }
+  if (blockIdx.x == 0)
+    for (long long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x)
+      bad |= (__float_as_uint(x[i]) & 0x7f800000u) == 0x7f800000u;
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// MASK = false: x <- clamp(x, -c, c) in place (NaN stays NaN, as torch.clamp); MASK = true: g <- g * [|x| < c] (the
+// gradient of that clamp).  Both are no-ops unless *flag != 0.
+template <bool MASK>
+__global__ __launch_bounds__(256) void clamp_if_flag_f32(float* __restrict__ t, const float* __restrict__ x, long long n,
+                                                         const int* __restrict__ flag, float c) {
+  if (*flag == 0) return;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (MASK) {
+      const float v = x[i];
+      if (!(fabsf(v) < c)) t[i] = 0.f;   // clamped (and NaN) elements pass no gradient, as torch's clamp backward
+    } else {
+      const float v = t[i];
+      t[i] = v != v ? v : fminf(fmaxf(v, -c), c);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int egtr_any_nonfinite_f32(egtr_stream_t stream, const float* x, long long n, int* flag) {
+  if (!x || !flag || n <= 0) return EGTR_E_ARG;
+  if (reinterpret_cast<uintptr_t>(x) & 15) return EGTR_E_UNSUPPORTED;
+  const long long n4 = n / 4;
+  const int blocks = (int)std::min<long long>((n4 + 255) / 256 + 1, 2048);
+  hipLaunchKernelGGL(any_nonfinite_f32, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n4, n, flag);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_clamp_if_flag_f32(egtr_stream_t stream, float* t, const float* x, long long n, const int* flag,
+                                      float clamp_value, int mask_gradient) {
+  if (!t || !flag || n <= 0 || (mask_gradient && !x)) return EGTR_E_ARG;
+  const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (mask_gradient)
+    hipLaunchKernelGGL(clamp_if_flag_f32<true>, dim3(blocks), dim3(256), 0, st, t, x, n, flag, clamp_value);
+  else
+    hipLaunchKernelGGL(clamp_if_flag_f32<false>, dim3(blocks), dim3(256), 0, st, t, x, n, flag, clamp_value);
+  return egtr_check_launch();
+}

@@ -596,11 +596,9 @@ class DeformableDetrEncoderLayer(nn.Module):
         if self.training:
             # dd:1346-1351 clamps the states iff any element is inf / nan -- a data-dependent branch that costs the
             # reference two host synchronisations per encoder layer.  Same function without the sync (and therefore
-            # capturable in a HIP graph): the "any non-finite" flag stays on the device and selects the clamped tensor.
-            bad = torch.logical_not(torch.isfinite(hidden_states).all())
-            clamp_value = torch.finfo(hidden_states.dtype).max - 1000
-            hidden_states = torch.where(bad, torch.clamp(hidden_states, min=-clamp_value, max=clamp_value),
-                                        hidden_states)
+            # capturable in a HIP graph): the "any non-finite" flag stays on the device; the clamp pass (and the gradient
+            # mask of the backward) return at once while it is clear (ops.clamp_nonfinite_).
+            hidden_states = ops.clamp_nonfinite_(hidden_states)
         outputs = (hidden_states,)
         if output_attentions:
             outputs += (attn_weights,)

@@ -919,6 +919,46 @@ class RelationLossFunction(Function):
         return grad_rel * g_rel, grad_conn * g_conn, None, None, None, None, None, None, None, None
 
 
+class ClampNonFiniteFunction(Function):
+    """dd:1346-1351 ("clamp the states iff any element is inf / nan") with the decision on the device: one reduction pass
+    raises a flag, the in-place clamp and the gradient mask return at once while it is clear (csrc/elementwise.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.lib()
+        _chk(x, "hidden_states", torch.float32)
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        cv = torch.finfo(torch.float32).max - 1000
+        _lib.check(lib.egtr_any_nonfinite_f32(_stream(), x.data_ptr(), x.numel(), flag.data_ptr()),
+                   "egtr_any_nonfinite_f32")
+        _lib.check(lib.egtr_clamp_if_flag_f32(_stream(), x.data_ptr(), None, x.numel(), flag.data_ptr(), cv, 0),
+                   "egtr_clamp_if_flag_f32")
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x, flag)
+        ctx.cv = cv
+        return x
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, flag = ctx.saved_tensors
+        g = g if g.is_contiguous() else g.contiguous()
+        # in place on the incoming gradient: a no-op unless the forward clamped (then the clamped elements get zero)
+        _lib.check(_lib.lib().egtr_clamp_if_flag_f32(_stream(), g.data_ptr(), x.data_ptr(), g.numel(), flag.data_ptr(),
+                                                     ctx.cv, 1), "egtr_clamp_if_flag_f32")
+        return g
+
+
+def clamp_nonfinite_(x):
+    """In place: x <- clamp(x, +-(finfo.max - 1000)) iff x holds an inf / nan (no host synchronisation).  fp32 contiguous
+    device tensors; anything else takes the tensor composition of the same function."""
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0:
+        return ClampNonFiniteFunction.apply(x)
+    bad = torch.logical_not(torch.isfinite(x).all())
+    cv = torch.finfo(x.dtype).max - 1000
+    return torch.where(bad, torch.clamp(x, min=-cv, max=cv), x)
+
+
 class DetectionLossFunction(Function):
     """loss_ce / loss_bbox / loss_giou (+ the cardinality counts) of one output set with their gradients from one launch
     (csrc/loss.hip, egtr_detection_loss_f32); backward only scales the stored gradients."""

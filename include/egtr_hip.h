@@ -418,6 +418,15 @@ int egtr_detection_loss_f32(egtr_stream_t stream, const float* logits, const flo
                             int num_classes, float focal_alpha, float num_boxes, float* grad_logits,
                             float* grad_boxes_l1, float* grad_boxes_giou, float* out);
 
+/* "Clamp the encoder states iff any element is inf / nan" (model/deformable_detr.py:1346-1351) without the reference's
+ * host branch: egtr_any_nonfinite_f32 raises *flag (int, zero before the call) if x [n] holds a non-finite value;
+ * egtr_clamp_if_flag_f32 then clamps t [n] to +-clamp_value in place (mask_gradient = 0; NaN stays NaN), or zeroes the
+ * gradient t [n] where |x| >= clamp_value or x is NaN (mask_gradient = 1, x = the clamped states) -- both return at once
+ * while *flag == 0. */
+int egtr_any_nonfinite_f32(egtr_stream_t stream, const float* x, long long n, int* flag);
+int egtr_clamp_if_flag_f32(egtr_stream_t stream, float* t, const float* x, long long n, const int* flag,
+                           float clamp_value, int mask_gradient);
+
 #ifdef __cplusplus
 }
 #endif

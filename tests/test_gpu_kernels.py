@@ -1163,3 +1163,33 @@ def test_detection_loss_kernel_vs_tensor_composition(B, N, C, Ts):
         assert abs(lf[k] - lr[k]) < 2e-5 * max(1.0, abs(lr[k])), (k, lf[k], lr[k])
     assert (glf - glr).abs().max() < 2e-5 * max(1e-3, float(glr.abs().max()))
     assert (gbf - gbr).abs().max() < 2e-5 * max(1e-3, float(gbr.abs().max()))
+
+
+def test_clamp_nonfinite_matches_reference_branch():
+    """dd:1346-1351: untouched (same storage) when every element is finite; clamped to +-(finfo.max - 1000) when an inf or
+    a NaN is present (NaN stays NaN); gradients pass except through clamped / NaN elements."""
+    from egtr_amd import ops
+    cv = torch.finfo(torch.float32).max - 1000
+    x = torch.randn(1000, 256, device=DEV)
+    xin = x.clone().requires_grad_(True)
+    y = ops.clamp_nonfinite_(xin * 1.0)
+    assert torch.equal(y, x)
+    y.sum().backward()
+    assert torch.equal(xin.grad, torch.ones_like(x))
+    x2 = x.clone()
+    x2[3, 7] = float("inf")
+    x2[5, 0] = float("-inf")
+    x2[9, 9] = float("nan")
+    x2[11, 1] = 3e38   # finite, inside the clamp range: untouched
+    x2in = x2.clone().requires_grad_(True)
+    y2 = ops.clamp_nonfinite_(x2in * 1.0)
+    ref = torch.clamp(x2, min=-cv, max=cv)
+    assert torch.equal(torch.nan_to_num(y2.detach(), nan=123.0), torch.nan_to_num(ref, nan=123.0))
+    assert y2[3, 7] == cv and y2[5, 0] == -cv and torch.isnan(y2[9, 9]) and y2[11, 1] == 3e38
+    y2.nan_to_num(0.0).sum().backward()
+    g = xin.grad * 0 + x2in.grad
+    assert g[3, 7] == 0 and g[5, 0] == 0 and g[9, 9] == 0 and g[11, 1] == 1 and g[0, 0] == 1
+    # odd sizes / tails
+    z = torch.randn(4 * 77 + 3, device=DEV)
+    z[-1] = float("inf")
+    assert ops.clamp_nonfinite_(z.clone())[-1] == cv
