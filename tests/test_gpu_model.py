@@ -397,89 +397,9 @@ def test_backbone_folded_inference_path_matches_unfolded():
     assert (fast2[0] - fast[0]).abs().max() > 1e-3
 
 
-@pytest.mark.parametrize("name,over,img", [
-    ("open_images_v6", dict(num_queries=200, encoder_layers=1, decoder_layers=2, num_labels=601, num_rel_labels=30), (160, 224)),
-    ("stress_heads", dict(num_queries=300, encoder_layers=1, decoder_layers=8, num_labels=150, num_rel_labels=50), (128, 160)),
-])
-def test_other_baseline_configs_vs_oracle(name, over, img):
-    """BASELINE configs[3] (Open Images V6 heads: 601 classes / 30 predicates) and the stress shape's N = 300 / 8 decoder
-    layers (T = 9 relation slots): product on the GPU vs the CPU oracle with identical seeded weights (fp32)."""
-    from oracle import detr as O
-    cfg_dict = dict(num_queries=24, encoder_layers=2, decoder_layers=3, dropout=0.0, auxiliary_loss=False,
-                    num_labels=12, num_rel_labels=7, use_freq_bias=True, use_log_softmax=False, freq_bias_eps=1e-12,
-                    logit_adjustment=False, logit_adj_tau=0.3)
-    cfg_dict.update(over)
-    import egtr_amd.deformable_detr as pdd
-    from egtr_amd.egtr import DetrForSceneGraphGeneration
-    import _ref_import
-    cfg = Hh.product_config(cfg_dict)
-    fg = W.fg_matrix(cfg.num_labels, cfg.num_rel_labels, seed=0)
-    orig = pdd.DeformableDetrTimmConvEncoder
-    pdd.DeformableDetrTimmConvEncoder = _ref_import.make_stub_backbone_class()
-    try:
-        model = DetrForSceneGraphGeneration(cfg, fg_matrix=fg)
-    finally:
-        pdd.DeformableDetrTimmConvEncoder = orig
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = W.fill_state_dict(shapes, seed=77)
-    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(fg, cfg.freq_bias_eps)
-    model.load_state_dict(sd)
-    model = model.to(DEV).eval()
-    rng = W.rng_inputs(5)
-    pv = torch.from_numpy(rng.standard_normal((2, 3) + img)).float()
-    pm = torch.ones((2,) + img, dtype=torch.long)
-    pm[1, img[0] - 32:, :] = 0
-    pv[1] = pv[1] * pm[1][None].float()
-    if name == "stress_heads":   # the oracle materialises [B, 300, 300, 9, 512] floats: the padded image alone
-        pv, pm = pv[1:], pm[1:]
-    with torch.no_grad():
-        got = model(pixel_values=pv.to(DEV), pixel_mask=pm.to(DEV), output_attention_states=True)
-        ocfg = dict(d_model=256, num_feature_levels=4, encoder_attention_heads=8)
-        ocfg.update(cfg_dict)
-        ref = O.sgg_forward(sd, ocfg, pv, pm)
-    assert (got.logits.cpu() - ref["logits"]).abs().max() < 1e-3
-    assert (got.pred_boxes.cpu() - ref["pred_boxes"]).abs().max() < 1e-3
-    assert (got.pred_rel.cpu() - ref["pred_rel"]).abs().max() < 1e-3
-    assert (got.pred_connectivity.cpu() - ref["pred_connectivity"]).abs().max() < 1e-3
-
-
-def test_stress_config_bf16_forward_runs():
-    """BASELINE configs[4] flavour: N = 300 queries, 8 decoder layers, bf16 weights and activations, a padded image.
-    The HIP kernels take bf16 values (MSDA) or compute in fp32 and cast back (self-attention, relation head); the check
-    is shape / dtype / finiteness and closeness of the detection logits to the fp32 run (the relation logits are a
-    discontinuous function of argmax(class logits) through the frequency bias, so they are only checked to be finite)."""
-    import egtr_amd.deformable_detr as pdd
-    from egtr_amd.egtr import DetrForSceneGraphGeneration
-    import _ref_import
-    cfg_dict = dict(num_queries=300, encoder_layers=1, decoder_layers=8, dropout=0.0, auxiliary_loss=False,
-                    num_labels=150, num_rel_labels=50, use_freq_bias=True, use_log_softmax=False, freq_bias_eps=1e-12,
-                    logit_adjustment=False, logit_adj_tau=0.3)
-    cfg = Hh.product_config(cfg_dict)
-    fg = W.fg_matrix(cfg.num_labels, cfg.num_rel_labels, seed=0)
-    orig = pdd.DeformableDetrTimmConvEncoder
-    pdd.DeformableDetrTimmConvEncoder = _ref_import.make_stub_backbone_class()
-    try:
-        model = DetrForSceneGraphGeneration(cfg, fg_matrix=fg)
-    finally:
-        pdd.DeformableDetrTimmConvEncoder = orig
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = W.fill_state_dict(shapes, seed=78)
-    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(fg, cfg.freq_bias_eps)
-    model.load_state_dict(sd)
-    model = model.to(DEV).eval()
-    rng = W.rng_inputs(6)
-    img = (160, 224)
-    pv = torch.from_numpy(rng.standard_normal((2, 3) + img)).float().to(DEV)
-    pm = torch.ones((2,) + img, dtype=torch.long, device=DEV)
-    pm[1, 128:, :] = 0
-    with torch.no_grad():
-        o32 = model(pixel_values=pv, pixel_mask=pm, output_attention_states=True)
-        ob = model.to(torch.bfloat16)(pixel_values=pv.to(torch.bfloat16), pixel_mask=pm, output_attention_states=True)
-    assert ob.pred_rel.dtype == torch.bfloat16 and tuple(ob.pred_rel.shape) == (2, 300, 300, 50)
-    for t in (ob.logits, ob.pred_boxes, ob.pred_rel, ob.pred_connectivity):
-        assert torch.isfinite(t.float()).all()
-    assert (ob.logits.float() - o32.logits).abs().max() < 0.25
-    assert (ob.pred_boxes.float() - o32.pred_boxes).abs().max() < 0.05
+# (The oracle comparisons of the Open Images V6 heads / the N = 300, 8-layer shape at reduced image size and the bf16
+#  "forward runs" smoke test of round 1 were replaced by REFERENCE fixtures at full size: sgg_oi.npz, sgg_stress.npz --
+#  test_full_size_600x1000_vs_reference, test_stress_geometry_fp32_bs16_vs_reference, test_stress_geometry_bf16_*.)
 
 
 def test_triplet_candidates_on_device_match_reference_postprocessing():
