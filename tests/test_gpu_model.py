@@ -303,6 +303,17 @@ def test_kernels_are_bitwise_deterministic():
     dd = {a: b.to(DEV) for a, b in dd.items()}
     r = [relation_head(*dd.values(), trip.to(DEV), node.to(DEV), False)[0] for _ in range(4)]
     assert all(torch.equal(r[0], t) for t in r)
+    # the split-bf16 kernels of the inference path (no atomics in either)
+    from egtr_amd import ops
+    w2xr, w3xr, w2xc = ops.rel_head_split_weights(dd["w2r"], dd["w3r"], dd["w2c"])
+    r6 = [ops.relation_head_split_bf16(dd["gate_q"], dd["gate_k"], dd["uq"], dd["uk"], dd["b1"], w2xr, dd["b2r"], w3xr,
+                                       dd["b3r"], w2xc, dd["b2c"], dd["w3c"], dd["b3c"], 50, trip.to(DEV), node.to(DEV),
+                                       False)[0] for _ in range(4)]
+    assert all(torch.equal(r6[0], t) for t in r6)
+    xg = torch.randn(12537, 256, device=DEV)
+    wt = ops.gemm_split_weights(torch.randn(1024, 256, device=DEV) / 16)
+    g6 = [ops.linear_split_bf16(xg, wt, None, 1024, relu=True) for _ in range(4)]
+    assert all(torch.equal(g6[0], t) for t in g6)
 
 
 def test_graph_replay_matches_eager():
