@@ -35,9 +35,26 @@ def _scale_for(name, shape):
     return ("normal", 0.1)
 
 
+_FILL_CACHE = {}
+
+
 def fill_state_dict(shapes, seed, dtype=torch.float32, skip=("triplet_dist", "rel_dist"), alias_heads=True):
     """shapes: {key: tuple}. Keys are filled in sorted order from one PCG64 stream.  ``alias_heads=False``: a
-    with_box_refine=True model, whose per-level heads are separate clones (egtr:148-154)."""
+    with_box_refine=True model, whose per-level heads are separate clones (egtr:148-154).  The last few results are
+    memoised (several tests build the same seeded model; callers only copy the tensors into a module)."""
+    key = (tuple(sorted((k, tuple(int(s) for s in v)) for k, v in shapes.items())), int(seed), str(dtype), tuple(skip),
+           bool(alias_heads))
+    hit = _FILL_CACHE.get(key)
+    if hit is not None:
+        return dict(hit)
+    sd = _fill_state_dict(shapes, seed, dtype, skip, alias_heads)
+    if len(_FILL_CACHE) >= 3:
+        _FILL_CACHE.pop(next(iter(_FILL_CACHE)))
+    _FILL_CACHE[key] = sd
+    return dict(sd)
+
+
+def _fill_state_dict(shapes, seed, dtype, skip, alias_heads):
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = {}
     for k in sorted(shapes):
