@@ -800,8 +800,8 @@ __global__ __launch_bounds__(256) void any_nonfinite_f32(const float* __restrict
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     // finite <=> exponent field not all ones
-    bad |= ((__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u) |
-           ((__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u) | ((__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u);
+    bad |= (__float_as_uint(v.x) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(v.y) & 0x7f800000u) == 0x7f800000u ||
+           (__float_as_uint(v.z) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(v.w) & 0x7f800000u) == 0x7f800000u;
   }
   if (blockIdx.x == 0)
     for (long long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x)
@@ -846,5 +846,137 @@ extern "C" int egtr_clamp_if_flag_f32(egtr_stream_t stream, float* t, const floa
     hipLaunchKernelGGL(clamp_if_flag_f32<true>, dim3(blocks), dim3(256), 0, st, t, x, n, flag, clamp_value);
   else
     hipLaunchKernelGGL(clamp_if_flag_f32<false>, dim3(blocks), dim3(256), 0, st, t, x, n, flag, clamp_value);
+  return egtr_check_launch();
+}
+
+// ---- bias gradient of a token-sized linear layer: column sums of g [M, N] (optionally of g masked by y > 0, the ReLU
+// backward, written out on the way) -- two passes, fixed summation order (bit-reproducible) --------------------------------
+namespace {
+
+constexpr int kCsRows = 64;
+
+// One workgroup per 64-row slab.  LPR lanes cover a row in float4 columns (256 / LPR rows in flight per pass); the row
+// lanes of a column are folded through LDS in a fixed order.
+template <int LPR, bool MASK>
+__global__ __launch_bounds__(256) void colsum_partial_v4_f32(const float* __restrict__ g, const float* __restrict__ y,
+                                                             float* __restrict__ g_masked, float* __restrict__ partial,
+                                                             int M, int N) {
+  constexpr int RP = 256 / LPR;
+  __shared__ float4 sm[256];
+  const int lane = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+  const int r0 = blockIdx.x * kCsRows, r1 = min(r0 + kCsRows, M);
+  const int n4 = N >> 2;
+  for (int cb = 0; cb < n4; cb += LPR) {
+    const int c4 = cb + lane;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < n4) {
+#pragma unroll 8
+      for (int r = r0 + rl; r < r1; r += RP) {
+        const size_t i = (size_t)r * n4 + c4;
+        float4 v = reinterpret_cast<const float4*>(g)[i];
+        if (MASK) {
+          const float4 t = reinterpret_cast<const float4*>(y)[i];
+          v.x = t.x > 0.f ? v.x : 0.f;
+          v.y = t.y > 0.f ? v.y : 0.f;
+          v.z = t.z > 0.f ? v.z : 0.f;
+          v.w = t.w > 0.f ? v.w : 0.f;
+          reinterpret_cast<float4*>(g_masked)[i] = v;
+        }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    if (RP > 1) {
+      sm[threadIdx.x] = s;
+      __syncthreads();
+      if (rl == 0) {
+#pragma unroll
+        for (int k = 1; k < RP; ++k) {
+          const float4 o = sm[k * LPR + lane];
+          s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+      }
+      __syncthreads();
+    }
+    if (rl == 0 && c4 < n4) reinterpret_cast<float4*>(partial)[(size_t)blockIdx.x * n4 + c4] = s;
+  }
+}
+
+// N % 4 != 0: scalar columns
+__global__ __launch_bounds__(256) void colsum_partial_f32(const float* __restrict__ g, const float* __restrict__ y,
+                                                          float* __restrict__ g_masked, float* __restrict__ partial,
+                                                          int M, int N) {
+  const int r0 = blockIdx.x * kCsRows, r1 = min(r0 + kCsRows, M);
+  for (int c = threadIdx.x; c < N; c += 256) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const size_t i = (size_t)r * N + c;
+      float v = g[i];
+      if (y != nullptr) {
+        v = y[i] > 0.f ? v : 0.f;
+        g_masked[i] = v;
+      }
+      s += v;
+    }
+    partial[(size_t)blockIdx.x * N + c] = s;
+  }
+}
+
+// 16 columns per workgroup, 16 slab lanes per column (fixed order: lane-strided sums, then the 16 lanes in sequence)
+__global__ __launch_bounds__(256) void colsum_final_f32(const float* __restrict__ partial, int chunks, int N,
+                                                        float* __restrict__ out) {
+  __shared__ float sm[256];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < N) {
+#pragma unroll 8
+    for (int k = kl; k < chunks; k += 16) s += partial[(size_t)k * N + c];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (kl == 0 && c < N) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += sm[k * 16 + cl];
+    out[c] = s;
+  }
+}
+
+template <int LPR>
+void launch_colsum_v4(hipStream_t st, int chunks, const float* g, const float* y, float* g_masked, float* partial, int M,
+                      int N) {
+  if (y)
+    hipLaunchKernelGGL((colsum_partial_v4_f32<LPR, true>), dim3(chunks), dim3(256), 0, st, g, y, g_masked, partial, M, N);
+  else
+    hipLaunchKernelGGL((colsum_partial_v4_f32<LPR, false>), dim3(chunks), dim3(256), 0, st, g, y, g_masked, partial, M, N);
+}
+
+}  // namespace
+
+extern "C" long long egtr_column_sum_workspace_floats(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (long long)((M + kCsRows - 1) / kCsRows) * N;
+}
+
+extern "C" int egtr_column_sum_f32(egtr_stream_t stream, const float* g, const float* relu_output, float* g_masked,
+                                   float* workspace, float* out, int M, int N) {
+  if (!g || !workspace || !out || M <= 0 || N <= 0) return EGTR_E_ARG;
+  if ((relu_output != nullptr) != (g_masked != nullptr)) return EGTR_E_ARG;
+  const int chunks = (M + kCsRows - 1) / kCsRows;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool v4 = N % 4 == 0 && ((uintptr_t)g % 16) == 0 && (!relu_output || (((uintptr_t)relu_output | (uintptr_t)g_masked) % 16) == 0);
+  const int n4 = N / 4;
+  if (!v4)
+    hipLaunchKernelGGL(colsum_partial_f32, dim3(chunks), dim3(256), 0, st, g, relu_output, g_masked, workspace, M, N);
+  else if (n4 <= 32)
+    launch_colsum_v4<32>(st, chunks, g, relu_output, g_masked, workspace, M, N);
+  else if (n4 <= 64)
+    launch_colsum_v4<64>(st, chunks, g, relu_output, g_masked, workspace, M, N);
+  else if (n4 <= 128)
+    launch_colsum_v4<128>(st, chunks, g, relu_output, g_masked, workspace, M, N);
+  else
+    launch_colsum_v4<256>(st, chunks, g, relu_output, g_masked, workspace, M, N);
+  int rc = egtr_check_launch();
+  if (rc != EGTR_OK) return rc;
+  hipLaunchKernelGGL(colsum_final_f32, dim3((N + 15) / 16), dim3(256), 0, st, workspace, chunks, N, out);
   return egtr_check_launch();
 }

@@ -237,6 +237,32 @@ bool problem_ok(const float* x, int ldx, const uint16_t* w, const float* bias, f
          !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(y) & 15) &&
          !(bias && (reinterpret_cast<uintptr_t>(bias) & 15));
 }
+// W [N, K] fp32 (or its transpose: `transposed`, element (n, k) at w[k * ldw + n]) -> the operand stream of the kernel
+// above, [N/128][K/32][3 pieces][128][32] bf16.  Pieces are rounded to nearest even like ops._split3_bf16 (the residuals
+// stay exact in fp32); one thread per element, consecutive threads along k of one row -> 64-byte output segments.
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__global__ __launch_bounds__(256) void tile_weights_f32(const float* __restrict__ w, int ldw, int transposed, int N, int K,
+                                                        unsigned short* __restrict__ out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * K) return;
+  const int kk = idx & 31, nn = (idx >> 5) & 127, blk = idx >> 12;
+  const int ktiles = K / kBK, kt = blk % ktiles, nt = blk / ktiles;
+  const int n = nt * kBN + nn, k = kt * kBK + kk;
+  const float x = transposed ? w[(size_t)k * ldw + n] : w[(size_t)n * ldw + k];
+  const unsigned hi = bf16_rne(x);
+  const float r1 = x - __uint_as_float(hi << 16);
+  const unsigned mid = bf16_rne(r1);
+  const unsigned lo = bf16_rne(r1 - __uint_as_float(mid << 16));
+  unsigned short* o = out + (size_t)blk * (3 * kBN * kBK) + nn * kBK + kk;
+  o[0] = (unsigned short)hi;
+  o[kBN * kBK] = (unsigned short)mid;
+  o[2 * kBN * kBK] = (unsigned short)lo;
+}
+
 }  // namespace
 
 extern "C" int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, const uint16_t* w_tiled,
@@ -263,4 +289,13 @@ extern "C" int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_
     P.p[i] = GemmProblem{x[i], w_tiled[i], bias[i], y[i], ldx[i], ldy[i], N[i], relu[i]};
   }
   return launch_grouped(static_cast<hipStream_t>(stream), P, num_problems, M, K);
+}
+
+extern "C" int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int ldw, int transposed, int N, int K,
+                                                uint16_t* w_tiled) {
+  if (!w || !w_tiled || N <= 0 || K <= 0 || ldw < (transposed ? N : K)) return EGTR_E_ARG;
+  if (N % kBN != 0 || K % kBK != 0 || (long long)N * K > (1LL << 30)) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(tile_weights_f32, dim3(N * K / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w, ldw,
+                     transposed, N, K, reinterpret_cast<unsigned short*>(w_tiled));
+  return egtr_check_launch();
 }

@@ -176,10 +176,71 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
         # token-sized GEMM with the ReLU in the hipBLASLt epilogue (saves one pass over the [S, 1024] activation)
         y = torch._addmm_activation(bias, x.reshape(-1, x.shape[-1]), weight.t(), use_gelu=False)
         return y.view(*x.shape[:-1], weight.shape[0])
+    if (alpha == 1.0 and bias is not None and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and rows > SKINNY_MAX_ROWS and torch.is_grad_enabled() and os.environ.get("EGTR_TOKEN_LINEAR", "1") == "1"
+            and (x.requires_grad or weight.requires_grad or bias.requires_grad)):
+        return TokenLinearFunction.apply(x, weight, bias, relu)   # training, token-sized: bias gradient in one HIP pass
     y = torch.nn.functional.linear(x, weight, bias)
     if alpha != 1.0:
         y = y * alpha
     return torch.relu(y) if relu else y
+
+
+class TokenLinearFunction(Function):
+    """nn.Linear (+ ReLU) on token-sized inputs in TRAINING (reference: the encoder / cross-attention nn.Linear layers,
+    model/deformable_detr.py:1049, 1053-1058, 1102, 1337-1343, under autograd).  Forward and data gradient g W run on the
+    bf16 matrix cores through the exact three-way split (csrc/gemm_split.hip; W and W^T are re-tiled by one launch each,
+    egtr_gemm_split_tile_weights_f32) where the shape allows (out features % 128, reduction % 32), else on the vendor
+    GEMM; the weight gradient x^T g is the vendor GEMM autograd would call; the bias gradient -- a [rows, N] column sum
+    per layer, with the ReLU mask applied on the way -- is egtr_column_sum_f32 (one pass instead of threshold_backward +
+    a generic reduction).  EGTR_TOKEN_LINEAR=0 keeps plain autograd; EGTR_GEMM_SPLIT_BF16=0 keeps the vendor GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x2 = x.reshape(-1, x.shape[-1])
+        N, K = weight.shape
+        ctx.split = GEMM_SPLIT_BF16 and x2.shape[0] >= GEMM_SPLIT_MIN_ROWS and weight.stride(1) == 1
+        if ctx.split and N % 128 == 0 and K % 32 == 0:
+            y = linear_split_bf16(x2, gemm_split_tile(weight), bias, N, relu=relu)
+        elif relu and hasattr(torch, "_addmm_activation"):
+            y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
+        else:
+            y = torch.addmm(bias, x2, weight.t())
+            if relu:
+                y = torch.relu_(y)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x2, weight, y if relu else None)
+        ctx.in_shape = x.shape
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y):
+        lib = _lib.lib()
+        x2, weight, y = ctx.saved_tensors
+        N = weight.shape[0]
+        g = grad_y.reshape(-1, N)
+        g = _chk(g if g.is_contiguous() else g.contiguous(), "grad", torch.float32)
+        M = g.shape[0]
+        ws = torch.empty(int(lib.egtr_column_sum_workspace_floats(M, N)), dtype=torch.float32, device=g.device)
+        gb = torch.empty(N, dtype=torch.float32, device=g.device)
+        gm = torch.empty_like(g) if ctx.relu else None
+        st = lib.egtr_column_sum_f32(_stream(), g.data_ptr(), y.data_ptr() if ctx.relu else None,
+                                     gm.data_ptr() if ctx.relu else None, ws.data_ptr(), gb.data_ptr(), M, N)
+        _lib.check(st, "egtr_column_sum_f32")
+        if ctx.relu:
+            g = gm
+        gx = None
+        if ctx.needs_input_grad[0]:
+            K = weight.shape[1]
+            if ctx.split and K % 128 == 0 and N % 32 == 0:
+                gx = linear_split_bf16(g, gemm_split_tile(weight, transposed=True), None, K)   # g W = "linear" with W^T
+            else:
+                gx = g.mm(weight)
+            gx = gx.view(ctx.in_shape)
+        # the product autograd forms for addmm (x^T g, viewed transposed): the same vendor kernel as the plain path
+        gw = x2.t().mm(g).t() if ctx.needs_input_grad[1] else None
+        return gx, gw, gb if ctx.needs_input_grad[2] else None, None
 
 
 def cached_weights(owner, name, tensors, builder):
@@ -345,6 +406,21 @@ def gemm_split_weights(weight):
     N, K = weight.shape
     p = _split3_bf16(weight).view(3, N // 128, 128, K // 32, 32)
     return p.permute(1, 3, 0, 2, 4).contiguous()
+
+
+def gemm_split_tile(weight, transposed=False):
+    """``gemm_split_weights(weight)`` (``transposed``: of ``weight.t()``) in one launch (egtr_gemm_split_tile_weights_f32):
+    the training step re-tiles each weight after every optimizer step, for the forward (W) and the data gradient (W^T)."""
+    lib = _lib.lib()
+    w = weight.detach()
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+        raise RuntimeError("gemm_split_tile: weight must be a 2-d float32 CUDA/HIP tensor with unit inner stride")
+    N, K = (w.shape[1], w.shape[0]) if transposed else (w.shape[0], w.shape[1])
+    out = torch.empty(N // 128, K // 32, 3, 128, 32, dtype=torch.bfloat16, device=w.device)
+    st = lib.egtr_gemm_split_tile_weights_f32(_stream(), w.data_ptr(), w.stride(0), 1 if transposed else 0, N, K,
+                                              out.data_ptr())
+    _lib.check(st, "egtr_gemm_split_tile_weights_f32")
+    return out
 
 
 def gemm_split_supported(x, N, K):

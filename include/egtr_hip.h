@@ -369,6 +369,13 @@ int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* gate_q, const
 int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, const uint16_t* w_tiled,
                                const float* bias, float* y, int ldy, int M, int K, int N, int relu);
 
+/* The w_tiled stream of the two entries around this one from W [N, K] fp32 (row stride ldw), or, with transposed != 0,
+ * from the [K, N] array w holding W^T (element (n, k) at w[k * ldw + n]: the data-gradient product g . W of the training
+ * backward is "linear" with weight W^T).  Pieces rounded to nearest even, bit-identical to ops.gemm_split_weights.
+ * One launch -- the training step re-tiles every weight after each optimizer step. */
+int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int ldw, int transposed, int N, int K,
+                                     uint16_t* w_tiled);
+
 /* Up to 8 such products with the same M and K in ONE launch (their tiles share the grid): the value projection and the
  * offsets / attention-weights projection of an encoder layer, the six value projections of the decoder.  All arrays are
  * HOST arrays of num_problems entries (pointers inside are device pointers; bias[i] may be NULL). */
@@ -426,6 +433,13 @@ int egtr_detection_loss_f32(egtr_stream_t stream, const float* logits, const flo
 int egtr_any_nonfinite_f32(egtr_stream_t stream, const float* x, long long n, int* flag);
 int egtr_clamp_if_flag_f32(egtr_stream_t stream, float* t, const float* x, long long n, const int* flag,
                            float clamp_value, int mask_gradient);
+
+/* Bias gradient of a token-sized nn.Linear in training: out [N] = column sums of g [M, N].  With relu_output (the layer's
+ * post-ReLU output y [M, N]) the ReLU backward is applied on the way: g_masked = g * [y > 0] is written and summed.
+ * workspace: egtr_column_sum_workspace_floats(M, N) floats.  Fixed summation order (bit-reproducible). */
+long long egtr_column_sum_workspace_floats(int M, int N);
+int egtr_column_sum_f32(egtr_stream_t stream, const float* g, const float* relu_output, float* g_masked,
+                        float* workspace, float* out, int M, int N);
 
 #ifdef __cplusplus
 }

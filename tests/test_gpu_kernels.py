@@ -1193,3 +1193,55 @@ def test_clamp_nonfinite_matches_reference_branch():
     z = torch.randn(4 * 77 + 3, device=DEV)
     z[-1] = float("inf")
     assert ops.clamp_nonfinite_(z.clone())[-1] == cv
+
+
+@pytest.mark.parametrize("M,K,N,relu", [(12537, 256, 1024, True), (12537, 1024, 256, False), (5000, 256, 384, False),
+                                        (4133, 256, 128, False), (4200, 96, 200, True), (4200, 64, 150, False)])
+def test_token_linear_training_function_matches_float64(M, K, N, relu):
+    """Token-sized nn.Linear (+ ReLU) in training (ops.TokenLinearFunction: split-bf16 GEMM for the forward and the data
+    gradient where the shape allows, vendor GEMM otherwise and for the weight gradient, egtr_column_sum_f32 for the bias
+    gradient / ReLU mask): output and all three gradients against float64, no further from it than 2.5x plain fp32
+    autograd (+ a floor).  The ReLU mask of the reference is taken from the output under test (entries within rounding
+    of zero may fall on either side)."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(3100 + N)
+    x = torch.from_numpy(rng.standard_normal((M, K))).float().to(DEV)
+    w = torch.from_numpy(rng.standard_normal((N, K)) / np.sqrt(K)).float().to(DEV)
+    b = torch.from_numpy(rng.standard_normal(N) * 0.1).float().to(DEV)
+    go = torch.from_numpy(rng.standard_normal((M, N))).float().to(DEV)
+    outs = []
+    for fn in ("custom", "autograd"):
+        xi, wi, bi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        if fn == "custom":
+            y = ops.linear(xi, wi, bi, 1.0, relu)
+            assert y.grad_fn.name().startswith("TokenLinearFunction")
+        else:
+            y = torch.nn.functional.linear(xi, wi, bi)
+            y = torch.relu(y) if relu else y
+        (y * go).sum().backward()
+        outs.append((y.detach(), xi.grad, wi.grad, bi.grad))
+    y64 = x.double() @ w.double().t() + b.double()
+    for k, (yk, gx, gw, gb) in enumerate(outs):
+        mask = (yk > 0).double() if relu else torch.ones_like(y64)
+        g64 = go.double() * mask
+        refs = (torch.relu(y64) if relu else y64, g64 @ w.double(), g64.t() @ x.double(), g64.sum(0))
+        errs = [float((a.double() - r).abs().max() / max(1.0, float(r.abs().max()))) for a, r in zip((yk, gx, gw, gb), refs)]
+        outs[k] = errs
+    for e_custom, e_plain in zip(*outs):
+        assert e_custom <= 2.5 * e_plain + 2e-6, (outs[0], outs[1])
+
+
+def test_gemm_split_tile_kernel_equals_host_tiling():
+    """egtr_gemm_split_tile_weights_f32 (one launch per weight per training step) is bit-identical to the torch
+    composition ops.gemm_split_weights, for W and for W^T read in place, incl. a strided source and denormal / huge
+    entries."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(3200)
+    for N, K in ((256, 256), (1024, 256), (128, 1024), (384, 32)):
+        big = torch.from_numpy(rng.standard_normal((N, K + 8))).float().to(DEV)
+        big[0, 0], big[1, 1], big[2, 2], big[3, 3] = 1e-40, -3e38, 0.0, 1.0 + 2.0 ** -9
+        w = big[:, :K]                                   # row stride K + 8
+        assert torch.equal(ops.gemm_split_tile(w).view(torch.int16), ops.gemm_split_weights(w).view(torch.int16))
+        if K % 128 == 0 and N % 32 == 0:
+            wt = ops.gemm_split_tile(w, transposed=True)     # tiles of W^T [K, N]
+            assert torch.equal(wt.view(torch.int16), ops.gemm_split_weights(w.t().contiguous()).view(torch.int16))
