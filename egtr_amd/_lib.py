@@ -52,6 +52,8 @@ SIGNATURES = {
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],
     "egtr_hungarian_match_scratch_doubles": [_I, _I, ctypes.c_longlong],
+    "egtr_add_layernorm_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
+    "egtr_add_layernorm_backward_workspace_floats": [_I],
     "egtr_column_sum_f32": [_P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_column_sum_workspace_floats": [_I, _I],
     "egtr_any_nonfinite_f32": [_P, _P, ctypes.c_longlong, _P],
@@ -64,6 +66,7 @@ SIGNATURES = {
     "egtr_rel_head_forward_bf16w": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_linear_split_bf16_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I],
     "egtr_gemm_split_tile_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "egtr_gemm_split_tile_weights_pair_f32": [_P, _P, _I, _I, _I, _P],
     "egtr_linear_split_bf16_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_rel_head_forward_bf16x6_f32": [_P] * 16 + [_I] * 6 + [_P] * 3 + [_I],
     "egtr_rel_head_forward_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
@@ -72,7 +75,8 @@ SIGNATURES = {
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p,
              "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong,
              "egtr_relation_loss_workspace_bytes": ctypes.c_longlong,
-             "egtr_column_sum_workspace_floats": ctypes.c_longlong}
+             "egtr_column_sum_workspace_floats": ctypes.c_longlong,
+             "egtr_add_layernorm_backward_workspace_floats": ctypes.c_longlong}
 
 _lib = None
 

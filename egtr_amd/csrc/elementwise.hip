@@ -104,6 +104,57 @@ __global__ __launch_bounds__(256) void add_layernorm_256(const float* __restrict
   }
 }
 
+// Backward of y = LayerNorm(x + res) * gamma + beta over rows of 256 channels: the statistics are recomputed from x + res
+// (nothing but the inputs is kept from the forward), gs = d loss / d (x + res) is written, and the wave's share of
+// d gamma = sum_rows gy * xhat, d beta = sum_rows gy stays in registers across its `rpw` consecutive rows; the four waves
+// of a workgroup fold through LDS into partial[blockIdx][512] (fixed order; egtr_add_layernorm_backward_f32 sums the
+// workgroup partials with colsum_final_f32).
+__global__ __launch_bounds__(256) void add_layernorm_256_bwd(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ gy, float* __restrict__ gs,
+                                                             float* __restrict__ partial, int rows, int rpw, float eps) {
+  __shared__ float4 sm[2][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float4 gm = reinterpret_cast<const float4*>(gamma)[lane];
+  float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+  const int r0 = (blockIdx.x * 4 + wave) * rpw, r1 = min(r0 + rpw, rows);
+#pragma unroll 2
+  for (int row = r0; row < r1; ++row) {
+    float4 v = reinterpret_cast<const float4*>(x + (size_t)row * 256)[lane];
+    const float4 g = reinterpret_cast<const float4*>(gy + (size_t)row * 256)[lane];
+    if (res != nullptr) {
+      const float4 r = reinterpret_cast<const float4*>(res + (size_t)row * 256)[lane];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.f / 256.f);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.f / 256.f);
+    const float rstd = rsqrtf(var + eps);
+    const float hx = dx * rstd, hy = dy * rstd, hz = dz * rstd, hw = dw * rstd;      // xhat
+    const float ax = g.x * gm.x, ay = g.y * gm.y, az = g.z * gm.z, aw = g.w * gm.w;  // gy * gamma
+    const float c1 = wave_sum(ax + ay + az + aw) * (1.f / 256.f);
+    const float c2 = wave_sum(ax * hx + ay * hy + az * hz + aw * hw) * (1.f / 256.f);
+    reinterpret_cast<float4*>(gs + (size_t)row * 256)[lane] =
+        make_float4(rstd * (ax - c1 - hx * c2), rstd * (ay - c1 - hy * c2), rstd * (az - c1 - hz * c2),
+                    rstd * (aw - c1 - hw * c2));
+    dg.x += g.x * hx; dg.y += g.y * hy; dg.z += g.z * hz; dg.w += g.w * hw;
+    db.x += g.x; db.y += g.y; db.z += g.z; db.w += g.w;
+  }
+  sm[0][threadIdx.x] = dg;
+  sm[1][threadIdx.x] = db;
+  __syncthreads();
+  if (threadIdx.x < 128) {   // 64 lanes x {d gamma, d beta}
+    const int which = threadIdx.x >> 6;
+    float4 a = sm[which][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 o = sm[which][w * 64 + lane];
+      a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    }
+    reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 512 + which * 256)[lane] = a;
+  }
+}
+
 // ---- bf16 storage, fp32 arithmetic (the bf16 stress configuration; raw bfloat16 bits as uint16_t) ---------------------
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even; NaN stays NaN
@@ -963,6 +1014,10 @@ extern "C" int egtr_column_sum_f32(egtr_stream_t stream, const float* g, const f
   if ((relu_output != nullptr) != (g_masked != nullptr)) return EGTR_E_ARG;
   const int chunks = (M + kCsRows - 1) / kCsRows;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!relu_output && M <= 2048) {   // object-query-sized inputs: the final pass alone, over the rows of g
+    hipLaunchKernelGGL(colsum_final_f32, dim3((N + 15) / 16), dim3(256), 0, st, g, M, N, out);
+    return egtr_check_launch();
+  }
   const bool v4 = N % 4 == 0 && ((uintptr_t)g % 16) == 0 && (!relu_output || (((uintptr_t)relu_output | (uintptr_t)g_masked) % 16) == 0);
   const int n4 = N / 4;
   if (!v4)
@@ -978,5 +1033,31 @@ extern "C" int egtr_column_sum_f32(egtr_stream_t stream, const float* g, const f
   int rc = egtr_check_launch();
   if (rc != EGTR_OK) return rc;
   hipLaunchKernelGGL(colsum_final_f32, dim3((N + 15) / 16), dim3(256), 0, st, workspace, chunks, N, out);
+  return egtr_check_launch();
+}
+
+// ---- backward of egtr_add_layernorm_f32 ------------------------------------------------------------------------------
+namespace {
+inline int ln_bwd_rows_per_wave(int rows) { return rows >= 16384 ? 8 : 1; }
+}  // namespace
+
+extern "C" long long egtr_add_layernorm_backward_workspace_floats(int rows) {
+  if (rows <= 0) return 0;
+  const int per_wg = 4 * ln_bwd_rows_per_wave(rows);
+  return (long long)((rows + per_wg - 1) / per_wg) * 512;
+}
+
+extern "C" int egtr_add_layernorm_backward_f32(egtr_stream_t stream, const float* x, const float* residual,
+                                               const float* gamma, const float* grad_y, float* grad_sum,
+                                               float* workspace, float* grad_gamma_beta, int rows, int dim, float eps) {
+  if (!x || !gamma || !grad_y || !grad_sum || !workspace || !grad_gamma_beta || rows <= 0) return EGTR_E_ARG;
+  if (dim != 256) return EGTR_E_UNSUPPORTED;
+  const int rpw = ln_bwd_rows_per_wave(rows), per_wg = 4 * rpw, wgs = (rows + per_wg - 1) / per_wg;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(add_layernorm_256_bwd, dim3(wgs), dim3(256), 0, st, x, residual, gamma, grad_y, grad_sum, workspace,
+                     rows, rpw, eps);
+  int rc = egtr_check_launch();
+  if (rc != EGTR_OK) return rc;
+  hipLaunchKernelGGL(colsum_final_f32, dim3(512 / 16), dim3(256), 0, st, workspace, wgs, 512, grad_gamma_beta);
   return egtr_check_launch();
 }

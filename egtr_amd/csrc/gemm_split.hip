@@ -245,9 +245,19 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
   if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;
   return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
+// `pair`: the second half of the grid writes the tiling of W^T behind the first one (out + 3 N K), so that the forward
+// of a training step prepares the operand of its data-gradient product in the same launch.
 __global__ __launch_bounds__(256) void tile_weights_f32(const float* __restrict__ w, int ldw, int transposed, int N, int K,
-                                                        unsigned short* __restrict__ out) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+                                                        unsigned short* __restrict__ out, int pair) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (pair && idx >= N * K) {   // W^T [K, N] read in place
+    idx -= N * K;
+    out += (size_t)3 * N * K;
+    transposed = 1;
+    const int t = N;
+    N = K;
+    K = t;
+  }
   if (idx >= N * K) return;
   const int kk = idx & 31, nn = (idx >> 5) & 127, blk = idx >> 12;
   const int ktiles = K / kBK, kt = blk % ktiles, nt = blk / ktiles;
@@ -296,6 +306,15 @@ extern "C" int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const floa
   if (!w || !w_tiled || N <= 0 || K <= 0 || ldw < (transposed ? N : K)) return EGTR_E_ARG;
   if (N % kBN != 0 || K % kBK != 0 || (long long)N * K > (1LL << 30)) return EGTR_E_UNSUPPORTED;
   hipLaunchKernelGGL(tile_weights_f32, dim3(N * K / 256), dim3(256), 0, static_cast<hipStream_t>(stream), w, ldw,
-                     transposed, N, K, reinterpret_cast<unsigned short*>(w_tiled));
+                     transposed, N, K, reinterpret_cast<unsigned short*>(w_tiled), 0);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_gemm_split_tile_weights_pair_f32(egtr_stream_t stream, const float* w, int ldw, int N, int K,
+                                                     uint16_t* w_tiled_pair) {
+  if (!w || !w_tiled_pair || N <= 0 || K <= 0 || ldw < K) return EGTR_E_ARG;
+  if (N % kBN != 0 || K % kBN != 0 || (long long)N * K > (1LL << 29)) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(tile_weights_f32, dim3(2 * (N * K / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, ldw, 0,
+                     N, K, reinterpret_cast<unsigned short*>(w_tiled_pair), 1);
   return egtr_check_launch();
 }

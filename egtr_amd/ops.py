@@ -154,13 +154,19 @@ class SkinnyLinearFunction(Function):
     def backward(ctx, grad_y):
         x2, w, y = ctx.saved_tensors
         g = grad_y.reshape(-1, grad_y.shape[-1])
-        if ctx.relu:
-            g = g * (y > 0).to(g.dtype)
-        if ctx.alpha != 1.0:
-            g = g * ctx.alpha
+        gb = None
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.relu and ctx.alpha == 1.0 and want_gb:
+            g, gb = column_sum(g, relu_output=y)   # ReLU mask and bias gradient in one pass
+        else:
+            if ctx.relu:
+                g = g * (y > 0).to(g.dtype)
+            if ctx.alpha != 1.0:
+                g = g * ctx.alpha
+            if want_gb:
+                gb = column_sum(g)
         gx = (g @ w).view(*grad_y.shape[:-1], w.shape[1]) if ctx.needs_input_grad[0] else None
         gw = g.t() @ x2 if ctx.needs_input_grad[1] else None
-        gb = g.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None
 
 
@@ -186,6 +192,22 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
     return torch.relu(y) if relu else y
 
 
+def column_sum(g, relu_output=None):
+    """g [M, N] fp32 -> column sums [N] (the bias gradient of a linear layer), egtr_column_sum_f32: one launch for
+    object-query-sized M.  With ``relu_output`` (the layer's post-ReLU output) returns (g * [y > 0], its column sums)."""
+    lib = _lib.lib()
+    g = _chk(g.contiguous(), "grad", torch.float32)
+    M, N = g.shape
+    ws = torch.empty(int(lib.egtr_column_sum_workspace_floats(M, N)), dtype=torch.float32, device=g.device)
+    out = torch.empty(N, dtype=torch.float32, device=g.device)
+    gm = torch.empty_like(g) if relu_output is not None else None
+    _lib.check(lib.egtr_column_sum_f32(_stream(), g.data_ptr(),
+                                       _chk(relu_output, "relu_output", torch.float32).data_ptr() if gm is not None else None,
+                                       gm.data_ptr() if gm is not None else None, ws.data_ptr(), out.data_ptr(), M, N),
+               "egtr_column_sum_f32")
+    return out if gm is None else (gm, out)
+
+
 class TokenLinearFunction(Function):
     """nn.Linear (+ ReLU) on token-sized inputs in TRAINING (reference: the encoder / cross-attention nn.Linear layers,
     model/deformable_detr.py:1049, 1053-1058, 1102, 1337-1343, under autograd).  Forward and data gradient g W run on the
@@ -200,7 +222,11 @@ class TokenLinearFunction(Function):
         x2 = x.reshape(-1, x.shape[-1])
         N, K = weight.shape
         ctx.split = GEMM_SPLIT_BF16 and x2.shape[0] >= GEMM_SPLIT_MIN_ROWS and weight.stride(1) == 1
-        if ctx.split and N % 128 == 0 and K % 32 == 0:
+        ctx.wt_t = None
+        if ctx.split and N % 128 == 0 and K % 128 == 0 and ctx.needs_input_grad[0]:
+            wt, ctx.wt_t = gemm_split_tile_pair(weight)   # W^T for the data gradient, same launch
+            y = linear_split_bf16(x2, wt, bias, N, relu=relu)
+        elif ctx.split and N % 128 == 0 and K % 32 == 0:
             y = linear_split_bf16(x2, gemm_split_tile(weight), bias, N, relu=relu)
         elif relu and hasattr(torch, "_addmm_activation"):
             y = torch._addmm_activation(bias, x2, weight.t(), use_gelu=False)
@@ -216,25 +242,20 @@ class TokenLinearFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_y):
-        lib = _lib.lib()
         x2, weight, y = ctx.saved_tensors
         N = weight.shape[0]
         g = grad_y.reshape(-1, N)
         g = _chk(g if g.is_contiguous() else g.contiguous(), "grad", torch.float32)
-        M = g.shape[0]
-        ws = torch.empty(int(lib.egtr_column_sum_workspace_floats(M, N)), dtype=torch.float32, device=g.device)
-        gb = torch.empty(N, dtype=torch.float32, device=g.device)
-        gm = torch.empty_like(g) if ctx.relu else None
-        st = lib.egtr_column_sum_f32(_stream(), g.data_ptr(), y.data_ptr() if ctx.relu else None,
-                                     gm.data_ptr() if ctx.relu else None, ws.data_ptr(), gb.data_ptr(), M, N)
-        _lib.check(st, "egtr_column_sum_f32")
         if ctx.relu:
-            g = gm
+            g, gb = column_sum(g, relu_output=y)
+        else:
+            gb = column_sum(g)
         gx = None
         if ctx.needs_input_grad[0]:
             K = weight.shape[1]
-            if ctx.split and K % 128 == 0 and N % 32 == 0:
-                gx = linear_split_bf16(g, gemm_split_tile(weight, transposed=True), None, K)   # g W = "linear" with W^T
+            if ctx.split and K % 128 == 0 and N % 32 == 0:   # g W = "linear" with W^T
+                wt_t = ctx.wt_t if ctx.wt_t is not None else gemm_split_tile(weight, transposed=True)
+                gx = linear_split_bf16(g, wt_t, None, K)
             else:
                 gx = g.mm(weight)
             gx = gx.view(ctx.in_shape)
@@ -421,6 +442,19 @@ def gemm_split_tile(weight, transposed=False):
                                               out.data_ptr())
     _lib.check(st, "egtr_gemm_split_tile_weights_f32")
     return out
+
+
+def gemm_split_tile_pair(weight):
+    """(tiling of W, tiling of W^T) in one launch (egtr_gemm_split_tile_weights_pair_f32); N, K % 128 == 0."""
+    lib = _lib.lib()
+    w = weight.detach()
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1:
+        raise RuntimeError("gemm_split_tile_pair: weight must be a 2-d float32 CUDA/HIP tensor with unit inner stride")
+    N, K = w.shape
+    out = torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=w.device)
+    st = lib.egtr_gemm_split_tile_weights_pair_f32(_stream(), w.data_ptr(), w.stride(0), N, K, out.data_ptr())
+    _lib.check(st, "egtr_gemm_split_tile_weights_pair_f32")
+    return out[0].view(N // 128, K // 32, 3, 128, 32), out[1].view(K // 128, N // 32, 3, 128, 32)
 
 
 def gemm_split_supported(x, N, K):
@@ -619,8 +653,9 @@ def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, 
 
 
 class AddLayerNormFunction(Function):
-    """LayerNorm(x + residual) over 256 channels in one pass (csrc/elementwise.hip).  Backward: recomputation with
-    PyTorch-ROCm ops (training only)."""
+    """LayerNorm(x + residual) over 256 channels in one pass (csrc/elementwise.hip).  Backward: one pass as well
+    (egtr_add_layernorm_backward_f32: statistics recomputed from the saved inputs, gamma / beta gradients from
+    per-workgroup partials in a fixed order)."""
 
     @staticmethod
     def forward(ctx, x, residual, weight, bias, eps):
@@ -638,13 +673,18 @@ class AddLayerNormFunction(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
+        lib = _lib.lib()
         x, r, w, b = ctx.saved_tensors
-        with torch.enable_grad():
-            s = (x + r).detach().requires_grad_(True)
-            wd, bd = w.detach().requires_grad_(True), b.detach().requires_grad_(True)
-            y = torch.nn.functional.layer_norm(s, (s.shape[-1],), wd, bd, ctx.eps)
-            gs, gw, gb = torch.autograd.grad(y, (s, wd, bd), gy)
-        return gs, gs, gw, gb, None
+        g = _chk(gy.contiguous(), "grad", torch.float32)
+        rows = x.numel() // x.shape[-1]
+        gs = torch.empty_like(x)
+        ws = torch.empty(int(lib.egtr_add_layernorm_backward_workspace_floats(rows)), dtype=torch.float32, device=x.device)
+        gwb = torch.empty(2, x.shape[-1], dtype=torch.float32, device=x.device)
+        st = lib.egtr_add_layernorm_backward_f32(_stream(), x.data_ptr(), r.data_ptr(), w.data_ptr(), g.data_ptr(),
+                                                 gs.data_ptr(), ws.data_ptr(), gwb.data_ptr(), rows, x.shape[-1],
+                                                 float(ctx.eps))
+        _lib.check(st, "egtr_add_layernorm_backward_f32")
+        return gs, gs, gwb[0], gwb[1], None
 
 
 def add_layer_norm(x, residual, ln):

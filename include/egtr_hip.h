@@ -202,6 +202,14 @@ int egtr_bias_act_nchw_f32(egtr_stream_t stream, const float* x, const float* bi
  * sqrt: the residual + LayerNorm of every encoder / decoder sub-layer (model/deformable_detr.py:1329-1330 etc.). */
 int egtr_add_layernorm_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,
                            const float* beta, float* y, int rows, int dim, float eps);
+/* Backward of egtr_add_layernorm_f32 (training; autograd of model/deformable_detr.py:1329-1330 etc.): from x, residual
+ * (may be NULL), gamma and grad_y [rows, 256] writes grad_sum [rows, 256] = d loss / d (x + residual) (the gradient of both
+ * inputs) and grad_gamma_beta [512] = (d gamma [256], d beta [256]).  The row statistics are recomputed (nothing is kept
+ * from the forward).  workspace: egtr_add_layernorm_backward_workspace_floats(rows) floats.  Fixed summation order. */
+long long egtr_add_layernorm_backward_workspace_floats(int rows);
+int egtr_add_layernorm_backward_f32(egtr_stream_t stream, const float* x, const float* residual, const float* gamma,
+                                    const float* grad_y, float* grad_sum, float* workspace, float* grad_gamma_beta,
+                                    int rows, int dim, float eps);
 
 /* bf16 storage (raw bfloat16 bits), fp32 arithmetic -- the same two epilogues for the bf16 stress configuration:
  * y = act(x + bias[c] (+ residual)) on an NCHW activation (bias fp32), and y = LayerNorm(x + residual) over 256 channels
@@ -375,6 +383,9 @@ int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, co
  * One launch -- the training step re-tiles every weight after each optimizer step. */
 int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int ldw, int transposed, int N, int K,
                                      uint16_t* w_tiled);
+/* Both streams of W [N, K] in one launch: w_tiled_pair = [tiling of W (3 N K) | tiling of W^T (3 N K)] (N, K % 128 == 0). */
+int egtr_gemm_split_tile_weights_pair_f32(egtr_stream_t stream, const float* w, int ldw, int N, int K,
+                                          uint16_t* w_tiled_pair);
 
 /* Up to 8 such products with the same M and K in ONE launch (their tiles share the grid): the value projection and the
  * offsets / attention-weights projection of an encoder layer, the six value projections of the decoder.  All arrays are

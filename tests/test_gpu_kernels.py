@@ -1244,4 +1244,61 @@ def test_gemm_split_tile_kernel_equals_host_tiling():
         assert torch.equal(ops.gemm_split_tile(w).view(torch.int16), ops.gemm_split_weights(w).view(torch.int16))
         if K % 128 == 0 and N % 32 == 0:
             wt = ops.gemm_split_tile(w, transposed=True)     # tiles of W^T [K, N]
-            assert torch.equal(wt.view(torch.int16), ops.gemm_split_weights(w.t().contiguous()).view(torch.int16))
+            ref_t = ops.gemm_split_weights(w.t().contiguous()).view(torch.int16)
+            assert torch.equal(wt.view(torch.int16), ref_t)
+            if N % 128 == 0:                                 # both in one launch
+                a, b = ops.gemm_split_tile_pair(w)
+                assert torch.equal(a.view(torch.int16), ops.gemm_split_weights(w).view(torch.int16))
+                assert torch.equal(b.view(torch.int16), ref_t)
+
+
+@pytest.mark.parametrize("rows", [1, 7, 800, 16385, 50148])
+def test_add_layernorm_backward_kernel_vs_float64(rows):
+    """egtr_add_layernorm_backward_f32 (gradient of x + residual, gamma, beta in one pass) against float64 autograd, no
+    further from it than 3x fp32 autograd (+ floor); bit-reproducible."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(3300 + rows)
+    x = torch.from_numpy(rng.standard_normal((rows, 256))).float().to(DEV)
+    r = torch.from_numpy(rng.standard_normal((rows, 256)) * 2 + 0.5).float().to(DEV)
+    gy = torch.from_numpy(rng.standard_normal((rows, 256))).float().to(DEV)
+    ln = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(torch.from_numpy(rng.standard_normal(256)).float() * 0.3 + 1.0)
+        ln.bias.copy_(torch.from_numpy(rng.standard_normal(256)).float() * 0.1)
+
+    def run(kind):
+        dt = torch.float64 if kind == "f64" else torch.float32
+        xi, ri = x.to(dt).requires_grad_(True), r.to(dt).requires_grad_(True)
+        wi, bi = ln.weight.detach().to(dt).requires_grad_(True), ln.bias.detach().to(dt).requires_grad_(True)
+        if kind == "hip":
+            y = ops.AddLayerNormFunction.apply(xi, ri, wi, bi, ln.eps)
+        else:
+            y = torch.nn.functional.layer_norm(xi + ri, (256,), wi, bi, ln.eps)
+        y.backward(gy.to(dt))
+        return [t.grad for t in (xi, ri, wi, bi)]
+
+    ref, hip, plain = run("f64"), run("hip"), run("f32")
+    assert torch.equal(hip[0], hip[1])
+    for a, p, t in zip(hip, plain, ref):
+        scale = max(1.0, float(t.abs().max()))
+        assert float((a.double() - t).abs().max()) / scale <= 3 * float((p.double() - t).abs().max()) / scale + 2e-6
+    again = run("hip")
+    assert all(torch.equal(a, b) for a, b in zip(hip, again))
+
+
+@pytest.mark.parametrize("M,N", [(800, 256), (1, 4), (2048, 151), (2049, 151), (4133, 128), (800, 1024)])
+def test_column_sum_kernel_and_relu_mask(M, N):
+    """egtr_column_sum_f32: the single-launch path (M <= 2048), the scalar-column path (N % 4 != 0) and the masked variant
+    (g * [y > 0] written out) against float64."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(3400 + M + N)
+    g = torch.from_numpy(rng.standard_normal((M, N))).float().to(DEV)
+    y = torch.relu(torch.from_numpy(rng.standard_normal((M, N))).float().to(DEV))
+    s = ops.column_sum(g)
+    ref = g.double().sum(0)
+    assert (s.double() - ref).abs().max() <= 1e-5 * max(1.0, float(g.abs().sum(0).max()))
+    gm, sm = ops.column_sum(g, relu_output=y)
+    assert torch.equal(gm, g * (y > 0))
+    refm = gm.double().sum(0)
+    assert (sm.double() - refm).abs().max() <= 1e-5 * max(1.0, float(g.abs().sum(0).max()))
+    assert torch.equal(ops.column_sum(g), s)

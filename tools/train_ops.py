@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     import bench
     from egtr_amd.runtime import DataParallelTrainer, configure_optimizers, enable_gemm_tuning
-    rows = int(sys.argv[1]) if len(sys.argv) > 1 else 45
+    shapes = "--shapes" in sys.argv          # group by input shapes as well (which elementwise passes are token-sized)
+    argv = [a for a in sys.argv[1:] if a != "--shapes"]
+    rows = int(argv[0]) if argv else 45
     enable_gemm_tuning()
     dev = torch.device("cuda", 0)
     model, cfg, cfg_dict = bench.build_model(dev, {"dropout": 0.1})
@@ -27,10 +29,17 @@ def main():
         tr.training_step(batch)
     torch.cuda.synchronize()
     from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=shapes) as prof:
         for _ in range(3):
             tr.training_step(batch)
         torch.cuda.synchronize()
+    if shapes:
+        evs = [e for e in prof.key_averages(group_by_input_shape=True) if e.self_device_time_total > 0]
+        evs.sort(key=lambda e: -e.self_device_time_total)
+        print("self GPU ms / 3 steps   calls   op   input shapes")
+        for e in evs[:rows]:
+            print(f"{e.self_device_time_total / 1e3:9.3f} {e.count:6d}  {e.key[:44]:44s} {str(e.input_shapes)[:110]}")
+        return
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=rows, max_name_column_width=60))
     print(prof.key_averages().table(sort_by="count", row_limit=25, max_name_column_width=60))
 
