@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * kRhWaves) void rel_head_fwd_f32(
     // next subject is in flight while the current subject's 4 pairs are accumulated.  The result goes through LDS
     // (32 rows padded to 260 floats: conflict-free ds_read_b128) into the layout the MFMA wants: lane (pair, half)
     // holds the 128 channels {128 half + s} of its pair.
-    const int qrow_l = (int)qi, krow_l = (int)kj;
+    const int krow_l = (int)kj;
     const float4 bias4 = reinterpret_cast<const float4*>(b1 + mlp * kHd)[lane];
     const float4* uq4 = reinterpret_cast<const float4*>(uq) + mlp * (kHd / 4) + lane;
     const float4* uk4 = reinterpret_cast<const float4*>(uk) + mlp * (kHd / 4) + lane;

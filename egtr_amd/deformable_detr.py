@@ -415,6 +415,7 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         else:
             sampling_offsets = ops.module_linear(self.sampling_offsets, hidden_states)
             attention_weights = ops.module_linear(self.attention_weights, hidden_states)
+        offsets_flat, logits_flat = sampling_offsets, attention_weights   # [B, Lq, M*L*P*2], [B, Lq, M*L*P]
         sampling_offsets = sampling_offsets.view(batch_size, num_queries, self.n_heads, self.n_levels, self.n_points, 2)
         attention_weights = attention_weights.view(batch_size, num_queries, self.n_heads,
                                                    self.n_levels * self.n_points)
@@ -444,15 +445,22 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                 # dd:1052 `value.masked_fill(~mask[..., None], 0)` as one select (no mask inversion, no clone)
                 value = torch.where(attention_mask[..., None], value, _zero_scalar(value))
             value = value.view(batch_size, sequence_length, self.n_heads, self.d_model // self.n_heads)
-            attention_weights = F.softmax(attention_weights, -1).view(
-                batch_size, num_queries, self.n_heads, self.n_levels, self.n_points)
-            if reference_points.shape[-1] == 2:
-                offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)  # (W, H)
-                sampling_locations = (reference_points[:, :, None, :, None, :]
-                                      + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
+            if ops.msda_geometry_supported(offsets_flat, logits_flat, reference_points, self.n_heads, self.n_levels,
+                                           self.n_points):
+                # softmax + sampling locations (dd:1055-1073) and their backward as one HIP pass per direction
+                sampling_locations, attention_weights = ops.MSDAGeometryFunction.apply(
+                    offsets_flat, logits_flat, reference_points, spatial_shapes, self.n_heads, self.n_levels,
+                    self.n_points)
             else:
-                sampling_locations = (reference_points[:, :, None, :, None, :2]
-                                      + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5)
+                attention_weights = F.softmax(attention_weights, -1).view(
+                    batch_size, num_queries, self.n_heads, self.n_levels, self.n_points)
+                if reference_points.shape[-1] == 2:
+                    offset_normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)  # (W, H)
+                    sampling_locations = (reference_points[:, :, None, :, None, :]
+                                          + sampling_offsets / offset_normalizer[None, None, None, :, None, :])
+                else:
+                    sampling_locations = (reference_points[:, :, None, :, None, :2]
+                                          + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5)
             # HIP kernel; NO try/except fallback (the reference swallows every exception here, dd:1096-1101)
             output = MultiScaleDeformableAttentionFunction.apply(
                 value.contiguous(), spatial_shapes, level_start_index, sampling_locations.contiguous(),

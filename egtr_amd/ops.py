@@ -47,6 +47,63 @@ class MultiScaleDeformableAttentionFunction(Function):
         return grad_value, None, None, grad_loc, grad_attn, None
 
 
+class MSDAGeometryFunction(Function):
+    """(sampling_offsets [B, Lq, M*L*P*2], attention logits [B, Lq, M*L*P], reference_points [B, Lq, L, 2 | 4]) ->
+    (sampling_locations [B, Lq, M, L, P, 2], attention_weights [B, Lq, M, L, P]) under autograd: softmax + location
+    arithmetic of model/deformable_detr.py:1055-1073 in one pass per direction (csrc/msda_geom.hip)."""
+
+    @staticmethod
+    def forward(ctx, offsets, logits, reference_points, spatial_shapes, M, L, P):
+        lib = _lib.lib()
+        B, Lq = offsets.shape[:2]
+        off = offsets.reshape(B * Lq, -1)
+        lg = logits.reshape(B * Lq, -1)
+        off = off if off.stride(1) == 1 else off.contiguous()
+        lg = lg if lg.stride(1) == 1 else lg.contiguous()
+        ref = _chk(reference_points.contiguous(), "reference_points", torch.float32)
+        shp = _chk(spatial_shapes.contiguous(), "spatial_shapes", torch.int64)
+        loc = torch.empty(B, Lq, M, L, P, 2, dtype=torch.float32, device=off.device)
+        probs = torch.empty(B, Lq, M, L, P, dtype=torch.float32, device=off.device)
+        st = lib.egtr_msda_geometry_forward_f32(_stream(), off.data_ptr(), off.stride(0), lg.data_ptr(), lg.stride(0),
+                                                ref.data_ptr(), ref.shape[-1], shp.data_ptr(), loc.data_ptr(),
+                                                probs.data_ptr(), B * Lq, M, L, P)
+        _lib.check(st, "egtr_msda_geometry_forward_f32")
+        ctx.save_for_backward(off, ref, shp, probs)
+        ctx.dims = (M, L, P)
+        ctx.shapes = (offsets.shape, logits.shape)
+        return loc, probs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_loc, g_probs):
+        lib = _lib.lib()
+        off, ref, shp, probs = ctx.saved_tensors
+        M, L, P = ctx.dims
+        rows = off.shape[0]
+        g_loc = _chk(g_loc.contiguous(), "grad_locations", torch.float32)
+        g_probs = _chk(g_probs.contiguous(), "grad_weights", torch.float32)
+        g_off = torch.empty(ctx.shapes[0], dtype=torch.float32, device=off.device)
+        g_lg = torch.empty(ctx.shapes[1], dtype=torch.float32, device=off.device)
+        g_ref = torch.empty_like(ref) if ctx.needs_input_grad[2] else None
+        st = lib.egtr_msda_geometry_backward_f32(_stream(), g_loc.data_ptr(), g_probs.data_ptr(), probs.data_ptr(),
+                                                 off.data_ptr(), off.stride(0), ref.data_ptr(), ref.shape[-1],
+                                                 shp.data_ptr(), g_off.data_ptr(), g_lg.data_ptr(),
+                                                 g_ref.data_ptr() if g_ref is not None else None, rows, M, L, P)
+        _lib.check(st, "egtr_msda_geometry_backward_f32")
+        return g_off, g_lg, g_ref, None, None, None, None
+
+
+def msda_geometry_supported(offsets, logits, reference_points, M, L, P):
+    """Shapes / dtypes served by MSDAGeometryFunction (else the ATen composition)."""
+    return (MSDA_GEOMETRY and offsets.is_cuda and offsets.dtype == torch.float32 and logits.dtype == torch.float32
+            and reference_points.dtype == torch.float32 and L == 4 and P == 4 and 1 <= M <= 64 and M & (M - 1) == 0
+            and reference_points.shape[-1] in (2, 4) and offsets.dim() == 3 and logits.dim() == 3
+            and reference_points.dim() == 4 and reference_points.shape[2] == L)
+
+
+MSDA_GEOMETRY = os.environ.get("EGTR_MSDA_GEOMETRY", "1") != "0"
+
+
 def msda_fused_supported(num_heads, channels, num_levels, num_points):
     """Shapes served by egtr_msda_forward_fused_f32 (the wave-per-query kernel)."""
     return num_heads == 8 and channels == 32 and num_levels * num_points == 16 and num_levels <= 4 \

@@ -193,6 +193,28 @@ int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* c
                             const float* const* bias, float* const* y, const int* M, const int* N, const int* ldy,
                             const float* alpha_x, const float* alpha, const int* relu, int K);
 
+/* ---- MSDA prologue under autograd (training) -------------------------------------------------------------------- */
+/* sampling_locations [rows, M, L, P, 2] and attention_weights [rows, M, L, P] (softmax over the L * P samples of a head)
+ * from the two nn.Linear outputs sampling_offsets [rows, M * L * P * 2] / attention_logits [rows, M * L * P] (row strides
+ * ld_*, floats) and reference_points [rows, L, ref_dim]: ref_dim 2 -> ref + offset / (W_l, H_l); ref_dim 4 ->
+ * ref_xy + offset / P * ref_wh * 0.5 -- model/deformable_detr.py:1055-1073 in ONE pass (the reference: softmax, division,
+ * multiplications, addition as separate kernels).  rows = batch * queries; spatial_shapes int64 [L, 2] (H, W) on the
+ * device.  L = P = 4, M a power of two <= 64, 16-byte aligned inputs with ld % 4 == 0, else EGTR_E_UNSUPPORTED. */
+int egtr_msda_geometry_forward_f32(egtr_stream_t stream, const float* sampling_offsets, long long ld_offsets,
+                                   const float* attention_logits, long long ld_logits, const float* reference_points,
+                                   int ref_dim, const int64_t* spatial_shapes, float* sampling_locations,
+                                   float* attention_weights, long long rows, int num_heads, int num_levels,
+                                   int num_points);
+/* Its backward: from d loss / d sampling_locations, d loss / d attention_weights and the saved attention_weights writes
+ * grad_offsets [rows, M * L * P * 2], grad_logits [rows, M * L * P] (both contiguous) and, when grad_reference != NULL,
+ * d loss / d reference_points [rows, L, ref_dim] (sum over heads and points; the decoder's reference points are a learned
+ * function of the queries). */
+int egtr_msda_geometry_backward_f32(egtr_stream_t stream, const float* grad_locations, const float* grad_weights,
+                                    const float* attention_weights, const float* sampling_offsets, long long ld_offsets,
+                                    const float* reference_points, int ref_dim, const int64_t* spatial_shapes,
+                                    float* grad_offsets, float* grad_logits, float* grad_reference, long long rows,
+                                    int num_heads, int num_levels, int num_points);
+
 /* ---- fused memory-bound epilogues --------------------------------------------------------------------------- */
 /* y = act(x + bias[c] (+ residual)) on an NCHW fp32 activation [N, C, HW]; residual may be NULL; y may alias x.
  * (Folded frozen-BN shift + bottleneck residual + ReLU of the ResNet-50 backbone in one pass.) */

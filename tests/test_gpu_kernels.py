@@ -1302,3 +1302,45 @@ def test_column_sum_kernel_and_relu_mask(M, N):
     refm = gm.double().sum(0)
     assert (sm.double() - refm).abs().max() <= 1e-5 * max(1.0, float(g.abs().sum(0).max()))
     assert torch.equal(ops.column_sum(g), s)
+
+
+@pytest.mark.parametrize("B,Lq,ref_dim,ref_grad", [(2, 700, 2, False), (1, 33, 2, True), (2, 50, 4, True), (4, 12537, 2, False)])
+def test_msda_geometry_function_matches_reference_composition(B, Lq, ref_dim, ref_grad):
+    """ops.MSDAGeometryFunction (softmax + sampling locations of dd:1055-1073 and their backward, one HIP pass each)
+    against the reference's ATen composition: forward to fp32 rounding, gradients against float64 autograd no further
+    than 3x the fp32 composition (+ floor).  The offsets arrive as a column block of a wider buffer (row stride 384)."""
+    from egtr_amd import ops
+    M, L, P = 8, 4, 4
+    rng = W.rng_inputs(3500 + Lq)
+    both = torch.from_numpy(rng.standard_normal((B, Lq, 384)) * 2).float().to(DEV)
+    ref = torch.from_numpy(rng.uniform(0.1, 0.9, (B, Lq, L, ref_dim))).float().to(DEV)
+    shapes = torch.tensor([[75, 125], [38, 63], [19, 32], [10, 16]], dtype=torch.int64, device=DEV)
+    g_loc = torch.from_numpy(rng.standard_normal((B, Lq, M, L, P, 2))).float().to(DEV)
+    g_att = torch.from_numpy(rng.standard_normal((B, Lq, M, L, P))).float().to(DEV)
+
+    def run(kind):
+        dt = torch.float64 if kind == "f64" else torch.float32
+        bi = both.to(dt).requires_grad_(True)
+        ri = ref.to(dt).requires_grad_(ref_grad)
+        off, lg = bi[..., :256], bi[..., 256:]
+        if kind == "hip":
+            loc, att = ops.MSDAGeometryFunction.apply(off, lg, ri, shapes, M, L, P)
+        else:
+            att = torch.softmax(lg.reshape(B, Lq, M, L * P), -1).view(B, Lq, M, L, P)
+            o6 = off.reshape(B, Lq, M, L, P, 2)
+            if ref_dim == 2:
+                norm = torch.stack([shapes[..., 1], shapes[..., 0]], -1)
+                loc = ri[:, :, None, :, None, :] + o6 / norm[None, None, None, :, None, :]
+            else:
+                loc = ri[:, :, None, :, None, :2] + o6 / P * ri[:, :, None, :, None, 2:] * 0.5
+        ((loc * g_loc.to(dt)).sum() + (att * g_att.to(dt)).sum()).backward()
+        return loc.detach(), att.detach(), bi.grad, (ri.grad if ref_grad else None)
+
+    assert ops.msda_geometry_supported(both[..., :256], both[..., 256:], ref, M, L, P)
+    t, h, p = run("f64"), run("hip"), run("f32")
+    assert (h[0] - p[0]).abs().max() <= 1e-6 and (h[1] - p[1]).abs().max() <= 1e-6
+    for a, b, r in zip(h, p, t):
+        if r is None:
+            continue
+        scale = max(1.0, float(r.abs().max()))
+        assert float((a.double() - r).abs().max()) / scale <= 3 * float((b.double() - r).abs().max()) / scale + 2e-6
