@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void msda_geometry_bwd(const float* __restrict
                                                          const float* __restrict__ probs, const float* __restrict__ off,
                                                          long long ld_off, const float* __restrict__ ref,
                                                          const int64_t* __restrict__ shapes, float* __restrict__ g_off,
-                                                         float* __restrict__ g_logits, float* __restrict__ g_ref,
+                                                         long long ld_goff, float* __restrict__ g_logits,
+                                                         long long ld_glogits, float* __restrict__ g_ref,
                                                          long long rows, int M) {
   constexpr int LP = L * P;
   const long long idx = blockIdx.x * 256ll + threadIdx.x;
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void msda_geometry_bwd(const float* __restrict
     dot += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
   }
   if (live) {
-    float4* o = reinterpret_cast<float4*>(g_logits + e * LP);
+    float4* o = reinterpret_cast<float4*>(g_logits + row * ld_glogits + (size_t)m * LP);
 #pragma unroll
     for (int i = 0; i < LP / 4; ++i)
       o[i] = make_float4(p[4 * i] * (g[4 * i] - dot), p[4 * i + 1] * (g[4 * i + 1] - dot),
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void msda_geometry_bwd(const float* __restrict
   }
   const float* r = ref + row * (size_t)(L * (BOX ? 4 : 2));
   const float4* o4 = reinterpret_cast<const float4*>(off + row * ld_off + (size_t)m * LP * 2);
-  float4* go4 = reinterpret_cast<float4*>(g_off + e * LP * 2);
+  float4* go4 = reinterpret_cast<float4*>(g_off + row * ld_goff + (size_t)m * LP * 2);
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     float sx, sy;
@@ -193,24 +194,27 @@ extern "C" int egtr_msda_geometry_backward_f32(egtr_stream_t stream, const float
                                                const float* grad_weights, const float* attention_weights,
                                                const float* sampling_offsets, long long ld_offsets,
                                                const float* reference_points, int ref_dim,
-                                               const int64_t* spatial_shapes, float* grad_offsets, float* grad_logits,
-                                               float* grad_reference, long long rows, int num_heads, int num_levels,
-                                               int num_points) {
+                                               const int64_t* spatial_shapes, float* grad_offsets,
+                                               long long ld_grad_offsets, float* grad_logits,
+                                               long long ld_grad_logits, float* grad_reference, long long rows,
+                                               int num_heads, int num_levels, int num_points) {
   if (!grad_locations || !grad_weights || !attention_weights || !sampling_offsets || !reference_points ||
       !spatial_shapes || !grad_offsets || !grad_logits || rows <= 0)
     return EGTR_E_ARG;
   if (!geometry_ok(num_heads, num_levels, num_points, ref_dim)) return EGTR_E_UNSUPPORTED;
-  if (ld_offsets % 4 || ((uintptr_t)sampling_offsets | (uintptr_t)reference_points) % 16) return EGTR_E_UNSUPPORTED;
+  if (ld_offsets % 4 || ld_grad_offsets % 4 || ld_grad_logits % 4 ||
+      ((uintptr_t)sampling_offsets | (uintptr_t)reference_points | (uintptr_t)grad_offsets | (uintptr_t)grad_logits) % 16)
+    return EGTR_E_UNSUPPORTED;
   const long long n = rows * num_heads;
   const dim3 grid((unsigned)((n + 255) / 256));
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (ref_dim == 4)
     hipLaunchKernelGGL((msda_geometry_bwd<4, 4, true>), grid, dim3(256), 0, st, grad_locations, grad_weights,
                        attention_weights, sampling_offsets, ld_offsets, reference_points, spatial_shapes, grad_offsets,
-                       grad_logits, grad_reference, rows, num_heads);
+                       ld_grad_offsets, grad_logits, ld_grad_logits, grad_reference, rows, num_heads);
   else
     hipLaunchKernelGGL((msda_geometry_bwd<4, 4, false>), grid, dim3(256), 0, st, grad_locations, grad_weights,
                        attention_weights, sampling_offsets, ld_offsets, reference_points, spatial_shapes, grad_offsets,
-                       grad_logits, grad_reference, rows, num_heads);
+                       ld_grad_offsets, grad_logits, ld_grad_logits, grad_reference, rows, num_heads);
   return egtr_check_launch();
 }

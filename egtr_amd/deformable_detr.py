@@ -364,6 +364,7 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         fast = ops.inference_fast_path(hidden_states)
         value_is_masked = True
         value_bias = None
+        both_train = None
         if isinstance(precomputed_value, tuple):
             # (W x, b): the bias-free projection; bias and padding mask are applied by the fused kernel below
             value, value_bias = precomputed_value
@@ -412,13 +413,23 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                 both = F.linear(hidden_states, w_cat, b_cat)
             n_off = self.sampling_offsets.weight.shape[0]
             sampling_offsets, attention_weights = both[..., :n_off], both[..., n_off:]
+        elif (hidden_states.is_cuda and batch_size * num_queries > ops.SKINNY_MAX_ROWS and torch.is_grad_enabled()
+              and hidden_states.dtype == torch.float32 and ops.MSDA_GEOMETRY):
+            # training, token-sized input: both Linears read the same rows -> ONE linear over the concatenated weights
+            # (one forward / data-gradient / weight-gradient product instead of two, one gradient accumulation less);
+            # MSDAGeometryFunction below reads the two column blocks in place and writes their gradient as one buffer
+            both_train = ops.linear(hidden_states,
+                                    torch.cat([self.sampling_offsets.weight, self.attention_weights.weight], 0),
+                                    torch.cat([self.sampling_offsets.bias, self.attention_weights.bias], 0))
+            n_off = self.sampling_offsets.weight.shape[0]
+            sampling_offsets, attention_weights = both_train[..., :n_off], both_train[..., n_off:]
         else:
             sampling_offsets = ops.module_linear(self.sampling_offsets, hidden_states)
             attention_weights = ops.module_linear(self.attention_weights, hidden_states)
         offsets_flat, logits_flat = sampling_offsets, attention_weights   # [B, Lq, M*L*P*2], [B, Lq, M*L*P]
-        sampling_offsets = sampling_offsets.view(batch_size, num_queries, self.n_heads, self.n_levels, self.n_points, 2)
-        attention_weights = attention_weights.view(batch_size, num_queries, self.n_heads,
-                                                   self.n_levels * self.n_points)
+        sampling_offsets = sampling_offsets.reshape(batch_size, num_queries, self.n_heads, self.n_levels, self.n_points, 2)
+        attention_weights = attention_weights.reshape(batch_size, num_queries, self.n_heads,
+                                                      self.n_levels * self.n_points)
         if reference_points.shape[-1] not in (2, 4):
             raise ValueError(f"Last dim of reference_points must be 2 or 4, but got {reference_points.shape[-1]}")
         if value_bias is not None and value.dtype != torch.float32:
@@ -449,8 +460,9 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                                            self.n_points):
                 # softmax + sampling locations (dd:1055-1073) and their backward as one HIP pass per direction
                 sampling_locations, attention_weights = ops.MSDAGeometryFunction.apply(
-                    offsets_flat, logits_flat, reference_points, spatial_shapes, self.n_heads, self.n_levels,
-                    self.n_points)
+                    both_train if both_train is not None else offsets_flat,
+                    None if both_train is not None else logits_flat, reference_points, spatial_shapes, self.n_heads,
+                    self.n_levels, self.n_points)
             else:
                 attention_weights = F.softmax(attention_weights, -1).view(
                     batch_size, num_queries, self.n_heads, self.n_levels, self.n_points)

@@ -50,16 +50,23 @@ class MultiScaleDeformableAttentionFunction(Function):
 class MSDAGeometryFunction(Function):
     """(sampling_offsets [B, Lq, M*L*P*2], attention logits [B, Lq, M*L*P], reference_points [B, Lq, L, 2 | 4]) ->
     (sampling_locations [B, Lq, M, L, P, 2], attention_weights [B, Lq, M, L, P]) under autograd: softmax + location
-    arithmetic of model/deformable_detr.py:1055-1073 in one pass per direction (csrc/msda_geom.hip)."""
+    arithmetic of model/deformable_detr.py:1055-1073 in one pass per direction (csrc/msda_geom.hip).
+    ``logits`` None: ``offsets`` is the output [B, Lq, 3*M*L*P] of ONE nn.Linear over the concatenated weights (offsets
+    columns first); its gradient is then written as one buffer as well."""
 
     @staticmethod
     def forward(ctx, offsets, logits, reference_points, spatial_shapes, M, L, P):
         lib = _lib.lib()
         B, Lq = offsets.shape[:2]
-        off = offsets.reshape(B * Lq, -1)
-        lg = logits.reshape(B * Lq, -1)
-        off = off if off.stride(1) == 1 else off.contiguous()
-        lg = lg if lg.stride(1) == 1 else lg.contiguous()
+        n_off = M * L * P * 2
+        both = offsets.reshape(B * Lq, -1)
+        both = both if both.stride(1) == 1 else both.contiguous()
+        if logits is None:
+            off, lg = both[:, :n_off], both[:, n_off:]
+        else:
+            off = both
+            lg = logits.reshape(B * Lq, -1)
+            lg = lg if lg.stride(1) == 1 else lg.contiguous()
         ref = _chk(reference_points.contiguous(), "reference_points", torch.float32)
         shp = _chk(spatial_shapes.contiguous(), "spatial_shapes", torch.int64)
         loc = torch.empty(B, Lq, M, L, P, 2, dtype=torch.float32, device=off.device)
@@ -70,7 +77,7 @@ class MSDAGeometryFunction(Function):
         _lib.check(st, "egtr_msda_geometry_forward_f32")
         ctx.save_for_backward(off, ref, shp, probs)
         ctx.dims = (M, L, P)
-        ctx.shapes = (offsets.shape, logits.shape)
+        ctx.shapes = (offsets.shape, logits.shape if logits is not None else None)
         return loc, probs
 
     @staticmethod
@@ -80,14 +87,19 @@ class MSDAGeometryFunction(Function):
         off, ref, shp, probs = ctx.saved_tensors
         M, L, P = ctx.dims
         rows = off.shape[0]
+        n_off = M * L * P * 2
         g_loc = _chk(g_loc.contiguous(), "grad_locations", torch.float32)
         g_probs = _chk(g_probs.contiguous(), "grad_weights", torch.float32)
         g_off = torch.empty(ctx.shapes[0], dtype=torch.float32, device=off.device)
-        g_lg = torch.empty(ctx.shapes[1], dtype=torch.float32, device=off.device)
+        if ctx.shapes[1] is None:
+            g_lg, p_lg, ld_off, ld_lg = None, g_off.data_ptr() + 4 * n_off, g_off.shape[-1], g_off.shape[-1]
+        else:
+            g_lg = torch.empty(ctx.shapes[1], dtype=torch.float32, device=off.device)
+            p_lg, ld_off, ld_lg = g_lg.data_ptr(), n_off, n_off // 2
         g_ref = torch.empty_like(ref) if ctx.needs_input_grad[2] else None
         st = lib.egtr_msda_geometry_backward_f32(_stream(), g_loc.data_ptr(), g_probs.data_ptr(), probs.data_ptr(),
                                                  off.data_ptr(), off.stride(0), ref.data_ptr(), ref.shape[-1],
-                                                 shp.data_ptr(), g_off.data_ptr(), g_lg.data_ptr(),
+                                                 shp.data_ptr(), g_off.data_ptr(), ld_off, p_lg, ld_lg,
                                                  g_ref.data_ptr() if g_ref is not None else None, rows, M, L, P)
         _lib.check(st, "egtr_msda_geometry_backward_f32")
         return g_off, g_lg, g_ref, None, None, None, None
@@ -98,7 +110,7 @@ def msda_geometry_supported(offsets, logits, reference_points, M, L, P):
     return (MSDA_GEOMETRY and offsets.is_cuda and offsets.dtype == torch.float32 and logits.dtype == torch.float32
             and reference_points.dtype == torch.float32 and L == 4 and P == 4 and 1 <= M <= 64 and M & (M - 1) == 0
             and reference_points.shape[-1] in (2, 4) and offsets.dim() == 3 and logits.dim() == 3
-            and reference_points.dim() == 4 and reference_points.shape[2] == L)
+            and reference_points.dim() == 4 and reference_points.shape[2] == L and M * L * P * 2 % 4 == 0)
 
 
 MSDA_GEOMETRY = os.environ.get("EGTR_MSDA_GEOMETRY", "1") != "0"

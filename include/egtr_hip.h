@@ -206,14 +206,16 @@ int egtr_msda_geometry_forward_f32(egtr_stream_t stream, const float* sampling_o
                                    float* attention_weights, long long rows, int num_heads, int num_levels,
                                    int num_points);
 /* Its backward: from d loss / d sampling_locations, d loss / d attention_weights and the saved attention_weights writes
- * grad_offsets [rows, M * L * P * 2], grad_logits [rows, M * L * P] (both contiguous) and, when grad_reference != NULL,
+ * grad_offsets [rows, M * L * P * 2], grad_logits [rows, M * L * P] (row strides ld_grad_*: two column blocks of one
+ * buffer when one nn.Linear produced both inputs) and, when grad_reference != NULL,
  * d loss / d reference_points [rows, L, ref_dim] (sum over heads and points; the decoder's reference points are a learned
  * function of the queries). */
 int egtr_msda_geometry_backward_f32(egtr_stream_t stream, const float* grad_locations, const float* grad_weights,
                                     const float* attention_weights, const float* sampling_offsets, long long ld_offsets,
                                     const float* reference_points, int ref_dim, const int64_t* spatial_shapes,
-                                    float* grad_offsets, float* grad_logits, float* grad_reference, long long rows,
-                                    int num_heads, int num_levels, int num_points);
+                                    float* grad_offsets, long long ld_grad_offsets, float* grad_logits,
+                                    long long ld_grad_logits, float* grad_reference, long long rows, int num_heads,
+                                    int num_levels, int num_points);
 
 /* ---- fused memory-bound epilogues --------------------------------------------------------------------------- */
 /* y = act(x + bias[c] (+ residual)) on an NCHW fp32 activation [N, C, HW]; residual may be NULL; y may alias x.

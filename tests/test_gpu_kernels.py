@@ -1325,6 +1325,8 @@ def test_msda_geometry_function_matches_reference_composition(B, Lq, ref_dim, re
         off, lg = bi[..., :256], bi[..., 256:]
         if kind == "hip":
             loc, att = ops.MSDAGeometryFunction.apply(off, lg, ri, shapes, M, L, P)
+        elif kind == "hip_both":     # one Linear produced both blocks: gradient written as one buffer
+            loc, att = ops.MSDAGeometryFunction.apply(bi, None, ri, shapes, M, L, P)
         else:
             att = torch.softmax(lg.reshape(B, Lq, M, L * P), -1).view(B, Lq, M, L, P)
             o6 = off.reshape(B, Lq, M, L, P, 2)
@@ -1338,6 +1340,8 @@ def test_msda_geometry_function_matches_reference_composition(B, Lq, ref_dim, re
 
     assert ops.msda_geometry_supported(both[..., :256], both[..., 256:], ref, M, L, P)
     t, h, p = run("f64"), run("hip"), run("f32")
+    hb = run("hip_both")
+    assert all(x is y or torch.equal(x, y) for x, y in zip(h, hb))
     assert (h[0] - p[0]).abs().max() <= 1e-6 and (h[1] - p[1]).abs().max() <= 1e-6
     for a, b, r in zip(h, p, t):
         if r is None:
