@@ -67,6 +67,8 @@ SIGNATURES = {
     "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_rel_head_forward_bf16w": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_linear_split_bf16_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I],
+    "egtr_linear_split_bf16_wgrad_f32": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
+    "egtr_linear_split_bf16_wgrad_workspace_floats": [_I, _I, _I],
     "egtr_gemm_split_tile_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "egtr_gemm_split_tile_weights_pair_f32": [_P, _P, _I, _I, _I, _P],
     "egtr_linear_split_bf16_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
@@ -78,7 +80,8 @@ _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctype
              "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong,
              "egtr_relation_loss_workspace_bytes": ctypes.c_longlong,
              "egtr_column_sum_workspace_floats": ctypes.c_longlong,
-             "egtr_add_layernorm_backward_workspace_floats": ctypes.c_longlong}
+             "egtr_add_layernorm_backward_workspace_floats": ctypes.c_longlong,
+             "egtr_linear_split_bf16_wgrad_workspace_floats": ctypes.c_longlong}
 
 _lib = None
 

@@ -237,6 +237,156 @@ bool problem_ok(const float* x, int ldx, const uint16_t* w, const float* bias, f
          !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(y) & 15) &&
          !(bias && (reinterpret_cast<uintptr_t>(bias) & 15));
 }
+// ---- weight gradient of a token-sized linear layer: gw[n][k] = sum_m g[m][n] x[m][k] (M ~ 50 000 rows, N, K a few
+// hundred) with the same six-term split arithmetic.  Both operands arrive "reduction-major" (m is the slow index), so the
+// transpose happens on the way in: a thread loads 8 consecutive rows m of ONE column (dword loads, a wave covers 64
+// consecutive columns = 256 contiguous bytes per row), splits them and stores the 8 bf16 of a piece as one 16-byte LDS
+// row segment -- LDS then holds [column][m] tiles exactly like the forward kernel's [row][k] tiles and the MFMA part is
+// the same.  The M rows are cut into chunks (split-K) so that (N/128)(K/128) x chunks workgroups fill the chip; every
+// workgroup writes its 128 x 128 partial to the workspace and wgrad_reduce_f32 sums the chunks in a fixed order.
+// MFMA roles: A operand = x piece (i = k), B operand = g piece (j = n): float4 stores along k of the row-major [N, K]
+// result.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad_split_bf16_f32(
+    const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, float* __restrict__ partial, int M, int N,
+    int K, int rows_per_chunk) {
+  constexpr int BM = 128;
+  const int ktiles = K / kBN, tiles = (N / BM) * ktiles;
+  const int chunk = blockIdx.x / tiles, t = blockIdx.x - chunk * tiles;
+  const int n0 = (t / ktiles) * BM, k0 = (t % ktiles) * kBN;
+  const int mbeg = chunk * rows_per_chunk, mend = min(M, mbeg + rows_per_chunk);
+  const int nstage = (mend - mbeg + kBK - 1) / kBK;
+  __shared__ __attribute__((aligned(16))) __bf16 sG[3 * BM * kPitch];
+  __shared__ __attribute__((aligned(16))) __bf16 sX[3 * kBN * kPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;     // 4 x 2 waves: 32 rows (n) x 64 columns (k) each
+  const int li = lane & 31, hf = lane >> 5;
+  const int col = tid & 127, mq = tid >> 7;    // loader: column of the tile, rows 8 mq .. 8 mq + 7 of the stage
+  const float* gp = G + n0 + col;
+  const float* xp = X + k0 + col;
+
+  float rg[8], rx[8];
+  auto issue = [&](int s) {
+    const int m = mbeg + s * kBK + mq * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = m + e < mend;
+      const size_t r = (size_t)(ok ? m + e : mbeg);
+      const float a = gp[r * ldg], b = xp[r * ldx];
+      rg[e] = ok ? a : 0.f;
+      rx[e] = ok ? b : 0.f;
+    }
+  };
+  auto stash_one = [&](const float (&v)[8], __bf16* base) {
+    Split3 sp[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sp[e] = split3(v[e]);
+    __bf16* p = base + col * kPitch + mq * 8;
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_hi16(sp[0].hi, sp[1].hi), pack_hi16(sp[2].hi, sp[3].hi),
+                                              pack_hi16(sp[4].hi, sp[5].hi), pack_hi16(sp[6].hi, sp[7].hi));
+    *reinterpret_cast<uint4*>(p + BM * kPitch) =
+        make_uint4(pack_hi16(sp[0].mid, sp[1].mid), pack_hi16(sp[2].mid, sp[3].mid), pack_hi16(sp[4].mid, sp[5].mid),
+                   pack_hi16(sp[6].mid, sp[7].mid));
+    *reinterpret_cast<uint4*>(p + 2 * BM * kPitch) =
+        make_uint4(pack_hi16(sp[0].lo, sp[1].lo), pack_hi16(sp[2].lo, sp[3].lo), pack_hi16(sp[4].lo, sp[5].lo),
+                   pack_hi16(sp[6].lo, sp[7].lo));
+  };
+  auto stash = [&]() {
+    stash_one(rg, sG);
+    stash_one(rx, sX);
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+  const __bf16* pa = sG + (wm * 32 + li) * kPitch + 8 * hf;
+  const __bf16* pw = sX + (wn * 64 + li) * kPitch + 8 * hf;
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[3], w[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        a[p] = *reinterpret_cast<const bf16x8*>(pa + p * BM * kPitch + 16 * ks);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) w[q][p] = *reinterpret_cast<const bf16x8*>(pw + (p * kBN + q * 32) * kPitch + 16 * ks);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x16 c = acc[nt];
+        c = mfma_bf16(w[nt][2], a[0], c);
+        c = mfma_bf16(w[nt][0], a[2], c);
+        c = mfma_bf16(w[nt][1], a[1], c);
+        c = mfma_bf16(w[nt][1], a[0], c);
+        c = mfma_bf16(w[nt][0], a[1], c);
+        c = mfma_bf16(w[nt][0], a[0], c);
+        acc[nt] = c;
+      }
+    }
+  };
+  if (nstage > 0) {
+    issue(0);
+    stash();
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s + 1 < nstage; ++s) {
+      issue(s + 1);
+      compute();
+      __syncthreads();
+      stash();
+      __syncthreads();
+    }
+    compute();
+  }
+  // D[i = k][j = n]: accumulator r <-> k = (r & 3) + 8 (r >> 2) + 4 hf of the 32-wide k tile, n = lane & 31
+  float* out = partial + ((size_t)chunk * N + n0 + wm * 32 + li) * K + k0 + wn * 64 + 4 * hf;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(out + nt * 32 + 8 * q) =
+          make_float4(acc[nt][4 * q + 0], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]);
+}
+
+// out[i] = sum over chunks of partial[c][i] (float4 columns; 16 columns x 16 chunk lanes per workgroup, fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_f32(const float4* __restrict__ partial, int chunks, int n4,
+                                                        float4* __restrict__ out) {
+  __shared__ float4 sm[256];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < n4) {
+#pragma unroll 4
+    for (int k = kl; k < chunks; k += 16) {
+      const float4 v = partial[(size_t)k * n4 + c];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (kl == 0 && c < n4) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+      const float4 v = sm[k * 16 + cl];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[c] = s;
+  }
+}
+
+struct WgradPlan {
+  int chunks, rows_per_chunk;
+};
+WgradPlan wgrad_plan(int M, int N, int K) {
+  const int tiles = (N / 128) * (K / 128);
+  int chunks = std::max(1, (512 + tiles - 1) / tiles);
+  chunks = std::min(chunks, (M + kBK - 1) / kBK);
+  const int rpc = ((M + chunks - 1) / chunks + kBK - 1) / kBK * kBK;
+  return WgradPlan{(M + rpc - 1) / rpc, rpc};
+}
+
 // W [N, K] fp32 (or its transpose: `transposed`, element (n, k) at w[k * ldw + n]) -> the operand stream of the kernel
 // above, [N/128][K/32][3 pieces][128][32] bf16.  Pieces are rounded to nearest even like ops._split3_bf16 (the residuals
 // stay exact in fp32); one thread per element, consecutive threads along k of one row -> 64-byte output segments.
@@ -316,5 +466,29 @@ extern "C" int egtr_gemm_split_tile_weights_pair_f32(egtr_stream_t stream, const
   if (N % kBN != 0 || K % kBN != 0 || (long long)N * K > (1LL << 29)) return EGTR_E_UNSUPPORTED;
   hipLaunchKernelGGL(tile_weights_f32, dim3(2 * (N * K / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), w, ldw, 0,
                      N, K, reinterpret_cast<unsigned short*>(w_tiled_pair), 1);
+  return egtr_check_launch();
+}
+
+extern "C" long long egtr_linear_split_bf16_wgrad_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 128) return 0;
+  return (long long)wgrad_plan(M, N, K).chunks * N * K;
+}
+
+extern "C" int egtr_linear_split_bf16_wgrad_f32(egtr_stream_t stream, const float* g, int ldg, const float* x, int ldx,
+                                                float* grad_weight, float* workspace, int M, int N, int K) {
+  if (!g || !x || !grad_weight || !workspace || M <= 0 || N <= 0 || K <= 0 || ldg < N || ldx < K) return EGTR_E_ARG;
+  if (N % 128 || K % 128 || (reinterpret_cast<uintptr_t>(grad_weight) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return EGTR_E_UNSUPPORTED;
+  const WgradPlan pl = wgrad_plan(M, N, K);
+  const long long wgs = (long long)pl.chunks * (N / 128) * (K / 128);
+  if (wgs >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(wgrad_split_bf16_f32, dim3((unsigned)wgs), dim3(512), 0, st, g, ldg, x, ldx, workspace, M, N, K,
+                     pl.rows_per_chunk);
+  int rc = egtr_check_launch();
+  if (rc != EGTR_OK) return rc;
+  const int n4 = N * K / 4;
+  hipLaunchKernelGGL(wgrad_reduce_f32, dim3((n4 + 15) / 16), dim3(256), 0, st, reinterpret_cast<const float4*>(workspace),
+                     pl.chunks, n4, reinterpret_cast<float4*>(grad_weight));
   return egtr_check_launch();
 }

@@ -328,8 +328,14 @@ class TokenLinearFunction(Function):
             else:
                 gx = g.mm(weight)
             gx = gx.view(ctx.in_shape)
-        # the product autograd forms for addmm (x^T g, viewed transposed): the same vendor kernel as the plain path
-        gw = x2.t().mm(g).t() if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            K = weight.shape[1]
+            if ctx.split and GEMM_SPLIT_WGRAD and N % 128 == 0 and K % 128 == 0 and x2.stride(1) == 1:
+                gw = linear_split_bf16_wgrad(g, x2)
+            else:
+                # the product autograd forms for addmm (x^T g, viewed transposed): the same vendor kernel as the plain path
+                gw = x2.t().mm(g).t()
         return gx, gw, gb if ctx.needs_input_grad[2] else None, None
 
 
@@ -489,6 +495,7 @@ def add_layer_norm_pos(x, residual, ln, pos):
 # Inference only; EGTR_GEMM_SPLIT_BF16=0 keeps the vendor fp32 GEMM.
 GEMM_SPLIT_BF16 = os.environ.get("EGTR_GEMM_SPLIT_BF16", "1") != "0"
 GEMM_SPLIT_MIN_ROWS = 4096
+GEMM_SPLIT_WGRAD = os.environ.get("EGTR_GEMM_SPLIT_WGRAD", "1") != "0"
 
 
 def gemm_split_weights(weight):
@@ -524,6 +531,22 @@ def gemm_split_tile_pair(weight):
     st = lib.egtr_gemm_split_tile_weights_pair_f32(_stream(), w.data_ptr(), w.stride(0), N, K, out.data_ptr())
     _lib.check(st, "egtr_gemm_split_tile_weights_pair_f32")
     return out[0].view(N // 128, K // 32, 3, 128, 32), out[1].view(K // 128, N // 32, 3, 128, 32)
+
+
+def linear_split_bf16_wgrad(g, x):
+    """g [M, N]^T . x [M, K] -> [N, K] (the weight gradient of a token-sized linear layer) through
+    egtr_linear_split_bf16_wgrad_f32; unit inner strides, N, K % 128 == 0."""
+    lib = _lib.lib()
+    M, N = g.shape
+    K = x.shape[1]
+    if x.shape[0] != M or g.stride(1) != 1 or x.stride(1) != 1:
+        raise RuntimeError("linear_split_bf16_wgrad: g [M, N] and x [M, K] with unit inner strides expected")
+    ws = torch.empty(int(lib.egtr_linear_split_bf16_wgrad_workspace_floats(M, N, K)), dtype=torch.float32, device=g.device)
+    gw = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    st = lib.egtr_linear_split_bf16_wgrad_f32(_stream(), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0),
+                                              gw.data_ptr(), ws.data_ptr(), M, N, K)
+    _lib.check(st, "egtr_linear_split_bf16_wgrad_f32")
+    return gw
 
 
 def gemm_split_supported(x, N, K):

@@ -411,6 +411,15 @@ int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int l
 int egtr_gemm_split_tile_weights_pair_f32(egtr_stream_t stream, const float* w, int ldw, int N, int K,
                                           uint16_t* w_tiled_pair);
 
+/* Weight gradient of such a layer in training: grad_weight [N, K] (contiguous) = g[M, N]^T . x[M, K] (row strides ldg,
+ * ldx), same split arithmetic; the M rows are cut into chunks whose 128 x 128 partial products go through `workspace`
+ * (egtr_linear_split_bf16_wgrad_workspace_floats(M, N, K) floats) and are summed in a fixed order (bit-reproducible).
+ * Replaces the vendor GEMM autograd calls for model/deformable_detr.py's encoder nn.Linear layers (K = rows of the token
+ * sequence: 66 TFLOP/s in the vendor library for N = K = 256).  N, K % 128 == 0, else EGTR_E_UNSUPPORTED. */
+long long egtr_linear_split_bf16_wgrad_workspace_floats(int M, int N, int K);
+int egtr_linear_split_bf16_wgrad_f32(egtr_stream_t stream, const float* g, int ldg, const float* x, int ldx,
+                                     float* grad_weight, float* workspace, int M, int N, int K);
+
 /* Up to 8 such products with the same M and K in ONE launch (their tiles share the grid): the value projection and the
  * offsets / attention-weights projection of an encoder layer, the six value projections of the decoder.  All arrays are
  * HOST arrays of num_problems entries (pointers inside are device pointers; bias[i] may be NULL). */

@@ -1348,3 +1348,21 @@ def test_msda_geometry_function_matches_reference_composition(B, Lq, ref_dim, re
             continue
         scale = max(1.0, float(r.abs().max()))
         assert float((a.double() - r).abs().max()) / scale <= 3 * float((b.double() - r).abs().max()) / scale + 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(50148, 256, 256), (12537, 384, 256), (4100, 128, 1024), (33, 128, 128), (777, 256, 128)])
+def test_linear_split_bf16_wgrad_is_fp32_accurate(M, N, K):
+    """egtr_linear_split_bf16_wgrad_f32 (g^T x over the token rows, split-K with a fixed-order reduction) against float64:
+    within 2.5x of the vendor fp32 GEMM's own error (+ floor), strided operands, ragged last chunk, bit-reproducible."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(3600 + M)
+    gbig = torch.from_numpy(rng.standard_normal((M, N + 128))).float().to(DEV)
+    g = gbig[:, 128:]                                   # column block of a wider buffer
+    x = torch.from_numpy(rng.standard_normal((M, K)) + 0.3).float().to(DEV)
+    ref = g.double().t() @ x.double()
+    out = ops.linear_split_bf16_wgrad(g, x)
+    vend = g.t() @ x
+    scale = float(ref.abs().max())
+    e_out, e_vend = float((out.double() - ref).abs().max()) / scale, float((vend.double() - ref).abs().max()) / scale
+    assert e_out <= 2.5 * e_vend + 1e-6, (e_out, e_vend)
+    assert torch.equal(out, ops.linear_split_bf16_wgrad(g, x))

@@ -58,10 +58,11 @@ def main():
             t_mm = timeit(lambda: x.mm(w.t()))
             g = torch.randn(M, N, device="cuda")
             t_wgrad = timeit(lambda: x.t().mm(g))
+            t_wsplit = timeit(lambda: ops.linear_split_bf16_wgrad(g, x)) if N % 128 == 0 and K % 128 == 0 else float("nan")
             t_sum = timeit(lambda: g.sum(0))
             t_col = timeit(lambda: column_sum(g))
         fl = 2.0 * M * K * N
-        print(f"    mm without bias {t_mm:.1f} us, weight gradient x^T g {t_wgrad:.1f} us; column sum of [M, {N}]: "
+        print(f"    mm without bias {t_mm:.1f} us, weight gradient x^T g {t_wgrad:.1f} us (split-bf16 {t_wsplit:.1f} us); column sum of [M, {N}]: "
               f"torch {t_sum:.1f} us, egtr_column_sum_f32 {t_col:.1f} us")
         print(f"M={M} K={K} N={N} relu={relu}: split-bf16 {t_split:.1f} us ({fl / t_split / 1e6:.0f} TFLOP/s), "
               f"vendor fp32 {t_vendor:.1f} us ({fl / t_vendor / 1e6:.0f} TFLOP/s)")
