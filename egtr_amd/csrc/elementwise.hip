@@ -907,10 +907,11 @@ namespace {
 constexpr int kCsRows = 64;
 
 // One workgroup per 64-row slab.  LPR lanes cover a row in float4 columns (256 / LPR rows in flight per pass); the row
-// lanes of a column are folded through LDS in a fixed order.
+// lanes of a column are folded through LDS in a fixed order.  g_masked may alias g (an element is read and written by the
+// same thread).
 template <int LPR, bool MASK>
-__global__ __launch_bounds__(256) void colsum_partial_v4_f32(const float* __restrict__ g, const float* __restrict__ y,
-                                                             float* __restrict__ g_masked, float* __restrict__ partial,
+__global__ __launch_bounds__(256) void colsum_partial_v4_f32(const float* g, const float* __restrict__ y,
+                                                             float* g_masked, float* __restrict__ partial,
                                                              int M, int N) {
   constexpr int RP = 256 / LPR;
   __shared__ float4 sm[256];
@@ -953,8 +954,8 @@ __global__ __launch_bounds__(256) void colsum_partial_v4_f32(const float* __rest
 }
 
 // N % 4 != 0: scalar columns
-__global__ __launch_bounds__(256) void colsum_partial_f32(const float* __restrict__ g, const float* __restrict__ y,
-                                                          float* __restrict__ g_masked, float* __restrict__ partial,
+__global__ __launch_bounds__(256) void colsum_partial_f32(const float* g, const float* __restrict__ y,
+                                                          float* g_masked, float* __restrict__ partial,
                                                           int M, int N) {
   const int r0 = blockIdx.x * kCsRows, r1 = min(r0 + kCsRows, M);
   for (int c = threadIdx.x; c < N; c += 256) {

@@ -261,15 +261,16 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
     return torch.relu(y) if relu else y
 
 
-def column_sum(g, relu_output=None):
+def column_sum(g, relu_output=None, inplace=False):
     """g [M, N] fp32 -> column sums [N] (the bias gradient of a linear layer), egtr_column_sum_f32: one launch for
-    object-query-sized M.  With ``relu_output`` (the layer's post-ReLU output) returns (g * [y > 0], its column sums)."""
+    object-query-sized M.  With ``relu_output`` (the layer's post-ReLU output) returns (g * [y > 0], its column sums);
+    ``inplace``: the masked gradient overwrites ``g`` (every element is read and written by the same thread)."""
     lib = _lib.lib()
     g = _chk(g.contiguous(), "grad", torch.float32)
     M, N = g.shape
     ws = torch.empty(int(lib.egtr_column_sum_workspace_floats(M, N)), dtype=torch.float32, device=g.device)
     out = torch.empty(N, dtype=torch.float32, device=g.device)
-    gm = torch.empty_like(g) if relu_output is not None else None
+    gm = (g if inplace else torch.empty_like(g)) if relu_output is not None else None
     _lib.check(lib.egtr_column_sum_f32(_stream(), g.data_ptr(),
                                        _chk(relu_output, "relu_output", torch.float32).data_ptr() if gm is not None else None,
                                        gm.data_ptr() if gm is not None else None, ws.data_ptr(), out.data_ptr(), M, N),
@@ -845,27 +846,25 @@ class RelationHeadFunction(Function):
         Hd = w2r.shape[1]
         R = w3r.shape[0]
         P_ = B * N * N
-        tb = torch.ops.aten.threshold_backward
         G = grad_rel.reshape(P_, R).contiguous()
         gc = grad_conn.reshape(P_, 1).contiguous()
         dh1 = torch.empty(2, P_, Hd, dtype=torch.float32, device=G.device)
-        # relation MLP
-        dh2 = tb(G @ w3r, h2s[0], 0.0)
+        wgrad = (linear_split_bf16_wgrad if GEMM_SPLIT_BF16 and GEMM_SPLIT_WGRAD and Hd % 128 == 0
+                 else (lambda g, h: g.t() @ h))
+        # relation MLP (ReLU masks and bias gradients: one pass each, egtr_column_sum_f32, the mask applied in place)
+        dh2, db2r = column_sum(G @ w3r, relu_output=h2s[0], inplace=True)
         dw3r = G.t() @ h2s[0]
-        db3r = G.sum(0)
+        db3r = G.sum(0)   # 50 columns: the generic reduction is faster (19 vs 30 us)
         torch.mm(dh2, w2r, out=dh1[0])
-        dw2r = dh2.t() @ h1s[0]
-        db2r = dh2.sum(0)
+        dw2r = wgrad(dh2, h1s[0])
         # connectivity MLP (one output)
-        dh2 = tb(gc * w3c, h2s[1], 0.0)
+        dh2, db2c = column_sum(gc * w3c, relu_output=h2s[1], inplace=True)
         dw3c = gc.t() @ h2s[1]
         db3c = gc.sum(0)
         torch.mm(dh2, w2c, out=dh1[1])
-        dw2c = dh2.t() @ h1s[1]
-        db2c = dh2.sum(0)
+        dw2c = wgrad(dh2, h1s[1])
         del dh2
-        dh1 = tb(dh1, h1s, 0.0)
-        db1 = dh1.sum(1).reshape(-1)
+        db1 = torch.cat([column_sum(dh1[i], relu_output=h1s[i], inplace=True)[1] for i in range(2)])
         duq = torch.empty_like(uq)
         duk = torch.empty_like(uk)
         dgq = torch.empty_like(gate_q)

@@ -480,7 +480,8 @@ int egtr_clamp_if_flag_f32(egtr_stream_t stream, float* t, const float* x, long 
 
 /* Bias gradient of a token-sized nn.Linear in training: out [N] = column sums of g [M, N].  With relu_output (the layer's
  * post-ReLU output y [M, N]) the ReLU backward is applied on the way: g_masked = g * [y > 0] is written and summed.
- * workspace: egtr_column_sum_workspace_floats(M, N) floats.  Fixed summation order (bit-reproducible). */
+ * g_masked may alias g.  workspace: egtr_column_sum_workspace_floats(M, N) floats.  Fixed summation order
+ * (bit-reproducible). */
 long long egtr_column_sum_workspace_floats(int M, int N);
 int egtr_column_sum_f32(egtr_stream_t stream, const float* g, const float* relu_output, float* g_masked,
                         float* workspace, float* out, int M, int N);

@@ -1302,6 +1302,9 @@ def test_column_sum_kernel_and_relu_mask(M, N):
     refm = gm.double().sum(0)
     assert (sm.double() - refm).abs().max() <= 1e-5 * max(1.0, float(g.abs().sum(0).max()))
     assert torch.equal(ops.column_sum(g), s)
+    g2 = g.clone()
+    gm2, sm2 = ops.column_sum(g2, relu_output=y, inplace=True)   # masked gradient written over g
+    assert gm2.data_ptr() == g2.data_ptr() and torch.equal(gm2, gm) and torch.equal(sm2, sm)
 
 
 @pytest.mark.parametrize("B,Lq,ref_dim,ref_grad", [(2, 700, 2, False), (1, 33, 2, True), (2, 50, 4, True), (4, 12537, 2, False)])
