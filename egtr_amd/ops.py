@@ -108,7 +108,7 @@ class MSDAGeometryFunction(Function):
 def msda_geometry_supported(offsets, logits, reference_points, M, L, P):
     """Shapes / dtypes served by MSDAGeometryFunction (else the ATen composition)."""
     return (MSDA_GEOMETRY and offsets.is_cuda and offsets.dtype == torch.float32 and logits.dtype == torch.float32
-            and reference_points.dtype == torch.float32 and L == 4 and P == 4 and 1 <= M <= 64 and M & (M - 1) == 0
+            and reference_points.dtype == torch.float32 and L == 4 and P == 4 and M == 8
             and reference_points.shape[-1] in (2, 4) and offsets.dim() == 3 and logits.dim() == 3
             and reference_points.dim() == 4 and reference_points.shape[2] == L and M * L * P * 2 % 4 == 0)
 

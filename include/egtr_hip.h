@@ -199,7 +199,7 @@ int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* c
  * ld_*, floats) and reference_points [rows, L, ref_dim]: ref_dim 2 -> ref + offset / (W_l, H_l); ref_dim 4 ->
  * ref_xy + offset / P * ref_wh * 0.5 -- model/deformable_detr.py:1055-1073 in ONE pass (the reference: softmax, division,
  * multiplications, addition as separate kernels).  rows = batch * queries; spatial_shapes int64 [L, 2] (H, W) on the
- * device.  L = P = 4, M a power of two <= 64, 16-byte aligned inputs with ld % 4 == 0, else EGTR_E_UNSUPPORTED. */
+ * device.  M = 8, L = P = 4 (one wavefront per row), 16-byte aligned inputs with ld % 4 == 0, else EGTR_E_UNSUPPORTED. */
 int egtr_msda_geometry_forward_f32(egtr_stream_t stream, const float* sampling_offsets, long long ld_offsets,
                                    const float* attention_logits, long long ld_logits, const float* reference_points,
                                    int ref_dim, const int64_t* spatial_shapes, float* sampling_locations,
