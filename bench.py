@@ -226,6 +226,10 @@ def logit_parity(model, ref, pv, pm):
             "conn_logits": float((conn.cpu() - ref["conn_logits"]).abs().max())}
 
 
+def _train_switch(name):
+    return os.environ.get(name, "1") != "0"
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota if one is set
     (os.cpu_count() reports the whole machine and badly oversubscribes inside a container)."""
@@ -395,7 +399,11 @@ def train_bench(args, world, rank, dev, dist):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "final_loss": float(loss), "rccl_ranks": args.rccl_ranks,
             "config": {"workload": f"VG train step: ResNet-50, N=200, 6 enc/6 dec, bs={batch}/GPU fp32, DDP x{world} "
-                                   "(BASELINE configs[2] shape)", "parallelism": f"dp{world}"}}
+                                   "(BASELINE configs[2] shape)", "parallelism": f"dp{world}",
+                       "token_linears": ("fp32 via bf16x6 operand split (forward, data and weight gradients)"
+                                         if _train_switch("EGTR_TOKEN_LINEAR") and _train_switch("EGTR_GEMM_SPLIT_BF16")
+                                         else "vendor fp32 GEMM"),
+                       "gemm_tuning": bool(args.tune_gemm), "miopen_find": bool(torch.backends.cudnn.benchmark)}}
         if bwd_args is not None and not args.no_kernel_probes:
             us, alg = time_msda_backward(bwd_args)
             ach = alg / (us * 1e-6) / 1e9
