@@ -381,6 +381,8 @@ struct WgradPlan {
 };
 WgradPlan wgrad_plan(int M, int N, int K) {
   const int tiles = (N / 128) * (K / 128);
+  // two workgroups per CU; measured for 256 x 256 / 256 x 1024 over 50 148 rows with 256 / 384 / 512 / 768 / 1024 / 1536
+  // workgroups: 53.6 / 56.4 / 53.2 / 59.8 / 64.4 / 69.8 us and 181.8 / 190.4 / 175.5 / 181.6 / 183.7 / 192.7 us
   int chunks = std::max(1, (512 + tiles - 1) / tiles);
   chunks = std::min(chunks, (M + kBK - 1) / kBK);
   const int rpc = ((M + chunks - 1) / chunks + kBK - 1) / kBK * kBK;
