@@ -193,6 +193,193 @@ __global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, in
   }
 }
 
+// ---- backward of the skinny linear layer in ONE launch -------------------------------------------------------------------
+// With g' = alpha * g * [y > 0] (y: the layer's post-ReLU output, optional):
+//   gx[M, K] = g' . W        (reduction over the N output features)
+//   gw[N, K] = g'^T . x      (reduction over the M rows)
+//   gb[N]    = column sums of g'
+// autograd issues two vendor GEMMs (9 us each at M = 800: one or two workgroups' worth of work), a mask pass and a
+// reduction per layer; ~70 such layers per train step are launch-bound.  Here the first `x_tiles` workgroups own
+// 16 x 64 tiles of gx and the rest 32 x 32 tiles of gw; in both the reduction is split 16 ways over (wave, lane group) as
+// in the forward kernel -- a lane group's "k" slot of v_mfma_f32_16x16x4_f32 carries its own span of the reduction -- and
+// the operands whose reduction index is the SLOW one in memory (W for gx, g and x for gw) are read as float4 / float2
+// along the OUTPUT index instead: the 4 (2) values feed 4 (2) MFMAs whose output columns interleave.
+struct SkinnyBwdArgs {
+  const float* g;
+  const float* y;   // post-ReLU output or nullptr
+  const float* x;
+  const float* w;
+  float* gx;        // nullable
+  float* gw;        // nullable
+  float* gb;        // nullable (needs gw tiles: computed by the k0 == 0 column of gw workgroups)
+  int M, N, K, x_tiles;
+  float alpha;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// loads of a whole batch are issued up front (asm keeps them in program order and out of the compiler's reach: it
+// otherwise sinks every load next to its first use, one memory round trip per reduction step) and consumed behind one
+// s_waitcnt tied to each destination register
+__device__ __forceinline__ f32x4 gload_x4(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p));
+  return v;
+}
+__device__ __forceinline__ f32x2 gload_x2(const float* p) {
+  f32x2 v;
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p));
+  return v;
+}
+__device__ __forceinline__ void vm_wait0(f32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
+__device__ __forceinline__ void vm_wait0(f32x2& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
+
+// MASK: ReLU mask from y; B4: float4 steps of the gx reduction per batch (divides N / 64)
+template <bool MASK, int B4>
+__global__ __launch_bounds__(256) void linear_skinny_bwd_f32(SkinnyBwdArgs P) {
+  __shared__ float s_red[4 * 4 * 64 * 4];
+  __shared__ float s_gb[16 * 32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, gq = lane >> 4;
+  const int grp = wave * 4 + gq;   // 0..15: its share of the reduction
+  const int M = P.M, N = P.N, K = P.K;
+  f32x4 acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if ((int)blockIdx.x < P.x_tiles) {
+    // ---- gx tile: rows m0..m0+15, columns k0..k0+63; reduction n in [grp * span, (grp + 1) * span)
+    const int ktiles = K / 64;
+    const int m0 = ((int)blockIdx.x / ktiles) * 16, k0 = ((int)blockIdx.x % ktiles) * 64;
+    const int span = N / 16;
+    const int row = min(m0 + c, M - 1);
+    const float* gp = P.g + (size_t)row * N + grp * span;
+    const float* yp = P.y + (size_t)row * N + grp * span;
+    const float* wp = P.w + (size_t)(grp * span) * K + k0 + 4 * c;
+#pragma unroll 1
+    for (int t0 = 0; t0 < span; t0 += 4 * B4) {
+      f32x4 a[B4], mk[B4], b[B4][4];
+#pragma unroll
+      for (int q = 0; q < B4; ++q) {
+        a[q] = gload_x4(gp + t0 + 4 * q);
+        if (MASK) mk[q] = gload_x4(yp + t0 + 4 * q);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[q][t] = gload_x4(wp + (size_t)(t0 + 4 * q + t) * K);
+      }
+#pragma unroll
+      for (int q = 0; q < B4; ++q) {
+        vm_wait0(a[q]);
+        if (MASK) vm_wait0(mk[q]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vm_wait0(b[q][t]);
+      }
+#pragma unroll
+      for (int q = 0; q < B4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float av = (MASK && !(mk[q][t] > 0.f)) ? 0.f : a[q][t];
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q][t].x, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q][t].y, acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q][t].z, acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[q][t].w, acc[3], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) reinterpret_cast<f32x4*>(s_red)[(wave * 4 + e) * 64 + lane] = acc[e];
+    __syncthreads();
+    // thread (ln, r): row m0 + 4 (ln >> 4) + r, columns k0 + 4 (ln & 15) + e
+    const int ln = tid >> 2, r = tid & 3;
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      o[e] = s_red[((0 * 4 + e) * 64 + ln) * 4 + r] + s_red[((1 * 4 + e) * 64 + ln) * 4 + r] +
+             s_red[((2 * 4 + e) * 64 + ln) * 4 + r] + s_red[((3 * 4 + e) * 64 + ln) * 4 + r];
+    const int orow = m0 + (ln >> 4) * 4 + r;
+    if (orow < M)
+      *reinterpret_cast<float4*>(P.gx + (size_t)orow * K + k0 + 4 * (ln & 15)) =
+          make_float4(o[0] * P.alpha, o[1] * P.alpha, o[2] * P.alpha, o[3] * P.alpha);
+    return;
+  }
+  // ---- gw tile: rows n0..n0+31, columns k0..k0+31; reduction m in [grp * rpg, (grp + 1) * rpg)
+  const int bt = (int)blockIdx.x - P.x_tiles;
+  const int ktiles = K / 32;
+  const int n0 = (bt / ktiles) * 32, k0 = (bt % ktiles) * 32;
+  const int rpg = (M + 15) / 16;
+  const int mb = grp * rpg;
+  const float* gp = P.g + n0 + 2 * c;
+  const float* yp = P.y + n0 + 2 * c;
+  const float* xp = P.x + k0 + 2 * c;
+  float sb0 = 0.f, sb1 = 0.f;
+  constexpr int TB = 16;   // rows per batch
+  // the same trip count in every lane group (the matrix instruction runs on all 64 lanes): rows past the group's share
+  // or past M are read from a valid row and contribute zeros
+#pragma unroll 1
+  for (int t0 = 0; t0 < rpg; t0 += TB) {
+    f32x2 a[TB], mk[TB], b[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const bool ok = t0 + t < rpg && mb + t0 + t < M;
+      const size_t m = (size_t)(ok ? mb + t0 + t : M - 1);
+      a[t] = gload_x2(gp + m * N);
+      if (MASK) mk[t] = gload_x2(yp + m * N);
+      b[t] = gload_x2(xp + m * K);
+    }
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      vm_wait0(a[t]);
+      if (MASK) vm_wait0(mk[t]);
+      vm_wait0(b[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const bool ok = t0 + t < rpg && mb + t0 + t < M;
+      const float ax = (!ok || (MASK && !(mk[t].x > 0.f))) ? 0.f : a[t].x;
+      const float ay = (!ok || (MASK && !(mk[t].y > 0.f))) ? 0.f : a[t].y;
+      sb0 += ax;
+      sb1 += ay;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, b[t].x, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, b[t].y, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, b[t].x, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, b[t].y, acc[3], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) reinterpret_cast<f32x4*>(s_red)[(wave * 4 + e) * 64 + lane] = acc[e];
+  s_gb[grp * 32 + 2 * c] = sb0;
+  s_gb[grp * 32 + 2 * c + 1] = sb1;
+  __syncthreads();
+  if (P.gw != nullptr) {
+    // accumulator e = 2 ei + ej of lane (c', gq') register r: row n0 + 2 (4 gq' + r) + ei, column k0 + 2 c' + ej
+    const int ln = tid >> 2, r = tid & 3;
+#pragma unroll
+    for (int ei = 0; ei < 2; ++ei) {
+      float o[2];
+#pragma unroll
+      for (int ej = 0; ej < 2; ++ej) {
+        const int e = 2 * ei + ej;
+        o[ej] = s_red[((0 * 4 + e) * 64 + ln) * 4 + r] + s_red[((1 * 4 + e) * 64 + ln) * 4 + r] +
+                s_red[((2 * 4 + e) * 64 + ln) * 4 + r] + s_red[((3 * 4 + e) * 64 + ln) * 4 + r];
+      }
+      const int orow = n0 + 2 * (4 * (ln >> 4) + r) + ei;
+      *reinterpret_cast<float2*>(P.gw + (size_t)orow * K + k0 + 2 * (ln & 15)) = make_float2(o[0] * P.alpha, o[1] * P.alpha);
+    }
+  }
+  if (P.gb != nullptr && k0 == 0 && tid < 32) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += s_gb[q * 32 + tid];
+    P.gb[n0 + tid] = s * P.alpha;
+  }
+}
+
+template <bool MASK>
+void launch_skinny_bwd(hipStream_t st, const SkinnyBwdArgs& P, int grid) {
+  const int steps = P.N / 64;   // float4 steps of the gx reduction per lane group
+  if (steps % 4 == 0)
+    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 4>), dim3(grid), dim3(256), 0, st, P);
+  else if (steps % 2 == 0)
+    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 2>), dim3(grid), dim3(256), 0, st, P);
+  else
+    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 1>), dim3(grid), dim3(256), 0, st, P);
+}
+
 }  // namespace
 
 extern "C" int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* const* x,
@@ -241,5 +428,27 @@ extern "C" int egtr_linear_f32(egtr_stream_t stream, const float* x, const float
     hipLaunchKernelGGL(linear_skinny_f32<64>, grid, dim3(256), 0, st, x, w, bias, y, M, K, N, alpha, relu, span);
   else
     hipLaunchKernelGGL(linear_skinny_f32<0>, grid, dim3(256), 0, st, x, w, bias, y, M, K, N, alpha, relu, span);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_linear_backward_f32(egtr_stream_t stream, const float* grad_y, const float* relu_output,
+                                        const float* x, const float* w, float alpha, float* grad_x, float* grad_w,
+                                        float* grad_bias, int M, int K, int N) {
+  if (!grad_y || !x || !w || M <= 0 || K <= 0 || N <= 0) return EGTR_E_ARG;
+  if (!grad_x && !grad_w && !grad_bias) return EGTR_E_ARG;
+  if (K % 64 != 0 || N % 64 != 0) return EGTR_E_UNSUPPORTED;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(relu_output) |
+                       reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
+                       reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(grad_w);
+  if (al & 15) return EGTR_E_UNSUPPORTED;
+  SkinnyBwdArgs P;
+  P.g = grad_y; P.y = relu_output; P.x = x; P.w = w; P.gx = grad_x; P.gw = grad_w; P.gb = grad_bias;
+  P.M = M; P.N = N; P.K = K; P.alpha = alpha;
+  P.x_tiles = grad_x ? ((M + 15) / 16) * (K / 64) : 0;
+  const int w_tiles = (grad_w || grad_bias) ? (N / 32) * (K / 32) : 0;
+  if (relu_output)
+    launch_skinny_bwd<true>(static_cast<hipStream_t>(stream), P, P.x_tiles + w_tiles);
+  else
+    launch_skinny_bwd<false>(static_cast<hipStream_t>(stream), P, P.x_tiles + w_tiles);
   return egtr_check_launch();
 }

@@ -195,11 +195,13 @@ def decoder_self_attention(q, k, v, num_heads, want_maps=True):
     return DecoderSelfAttentionFunction.apply(q.contiguous(), k.contiguous(), v.contiguous(), num_heads, want_maps)
 
 
+SKINNY_BACKWARD_FUSED = os.environ.get("EGTR_SKINNY_BACKWARD", "1") != "0"
 SKINNY_MAX_ROWS = 4096  # above this the vendor GEMM (rocBLAS / hipBLASLt) fills the chip and is the right tool
 
 
 class SkinnyLinearFunction(Function):
-    """act((x W^T + b) * alpha) through egtr_linear_f32 (csrc/linear.hip).  Backward: plain GEMMs (PyTorch-ROCm)."""
+    """act((x W^T + b) * alpha) through egtr_linear_f32 (csrc/linear.hip).  Backward: egtr_linear_backward_f32 (data, weight
+    and bias gradient in one launch) for N % 64 == 0, else vendor GEMMs + egtr_column_sum_f32."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, alpha, relu):
@@ -225,6 +227,23 @@ class SkinnyLinearFunction(Function):
         g = grad_y.reshape(-1, grad_y.shape[-1])
         gb = None
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
+        N, K = w.shape
+        if SKINNY_BACKWARD_FUSED and N % 64 == 0 and K % 64 == 0 and g.dtype == torch.float32:
+            # gx, gw, gb (+ ReLU mask and alpha) in one launch (egtr_linear_backward_f32)
+            lib = _lib.lib()
+            g = _chk(g.contiguous(), "grad", torch.float32)
+            M = g.shape[0]
+            gx = torch.empty(M, K, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+            gw = torch.empty(N, K, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+            gb = torch.empty(N, dtype=torch.float32, device=g.device) if want_gb else None
+            if gx is not None or gw is not None or gb is not None:
+                st = lib.egtr_linear_backward_f32(_stream(), g.data_ptr(), y.data_ptr() if ctx.relu else None,
+                                                  x2.data_ptr(), w.data_ptr(), ctx.alpha,
+                                                  gx.data_ptr() if gx is not None else None,
+                                                  gw.data_ptr() if gw is not None else None,
+                                                  gb.data_ptr() if gb is not None else None, M, K, N)
+                _lib.check(st, "egtr_linear_backward_f32")
+            return (gx.view(*grad_y.shape[:-1], K) if gx is not None else None), gw, gb, None, None
         if ctx.relu and ctx.alpha == 1.0 and want_gb:
             g, gb = column_sum(g, relu_output=y)   # ReLU mask and bias gradient in one pass
         else:

@@ -186,6 +186,14 @@ int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const floa
 int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const float* bias, float* y, int M, int K,
                     int N, float alpha, int relu);
 
+/* Backward of egtr_linear_f32 in ONE launch (training; autograd of the same nn.Linear call sites): with
+ * g' = alpha * grad_y * [relu_output > 0] (relu_output: the layer's post-ReLU output, NULL without ReLU) writes
+ * grad_x [M, K] = g' . w, grad_w [N, K] = g'^T . x and grad_bias [N] = column sums of g' (each output may be NULL).
+ * Exact-f32 MFMA.  K % 64 == 0 and N % 64 == 0, 16-byte aligned contiguous operands, else EGTR_E_UNSUPPORTED. */
+int egtr_linear_backward_f32(egtr_stream_t stream, const float* grad_y, const float* relu_output, const float* x,
+                             const float* w, float alpha, float* grad_x, float* grad_w, float* grad_bias, int M, int K,
+                             int N);
+
 /* Up to 16 independent skinny linears in ONE launch (every launch costs ~5 us in a graph-replayed forward):
  *   y_g[M_g, N_g] (row stride ldy_g floats) = act((alpha_x_g * X_g W_g^T + b_g) * alpha_g),  X_g [M_g, K], W_g [N_g, K].
  * All arrays are HOST arrays of num_groups entries (pointers are device pointers; bias[g] may be NULL); K % 64 == 0. */

@@ -506,7 +506,8 @@ def test_relation_head_backward_matches_autograd(B, N, T, R):
 
 # ---------------------------------------------------------------------------------------------- skinny linear
 @pytest.mark.parametrize("M,K,N", [(200, 256, 256), (200, 256, 1024), (200, 1024, 256), (400, 256, 150),
-                                   (1400, 256, 513), (7, 64, 2), (300, 512, 50), (33, 320, 4), (1, 256, 1)])
+                                   (1400, 256, 513), (7, 64, 2), (300, 512, 50), (33, 320, 4), (1, 256, 1),
+                                   (800, 256, 128), (13, 64, 64), (801, 256, 512), (3, 1024, 64)])
 def test_skinny_linear(M, K, N):
     from egtr_amd.ops import linear
     rng = W.rng_inputs(K + N + M)
