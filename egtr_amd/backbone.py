@@ -7,9 +7,14 @@ architecture is defined directly with timm's parameter names (``conv1``, ``bn1``
 ``model.backbone.conv_encoder.model.*`` keys load unchanged.  Out of scope for hand-written kernels per the
 north-star ("host code stays Python on PyTorch-ROCm for the ResNet-50 backbone").
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+
+TRAIN_FUSED_EPILOGUE = os.environ.get("EGTR_BACKBONE_TRAIN_FUSED", "1") != "0"
 
 
 def _fold(conv, bn):
@@ -74,11 +79,46 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         # (training path: the 1x1 convolutions stay on MIOpen -- as torch.matmul their backward through the batch
         # broadcast was measured slower, 86.8 vs 68.2 ms per bs=4 train step)
+        if (TRAIN_FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and self.conv1.weight.dtype == torch.float32):
+            return self.forward_train_fused(x)
         idt = x if self.downsample is None else self.downsample(x)
         y = torch.relu(self.bn1(self.conv1(x)))
         y = torch.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
         return torch.relu(y + idt)
+
+    def forward_train_fused(self, x):
+        """Training with trainable convolutions (layers 2-4): the frozen BN's scale multiplies the convolution WEIGHT under
+        autograd (a [Cout, Cin, k, k] product instead of a pass over the activation; d loss / d weight picks the scale
+        up through that product), and shift + residual + ReLU are one HIP pass forward (egtr_bias_act_nchw_f32) and one
+        mask pass backward -- instead of rsqrt / mul / sub on the statistics (5 launches per BN, every step), a
+        multiplication and an addition over the activation, the residual add, the ReLU and their three backward passes.
+        Same algebra as the folded inference path (fp32 rounding differs from scale-after-conv by ~1e-7 relative)."""
+        from . import ops
+        bns = [self.bn1, self.bn2, self.bn3] + ([self.downsample[1]] if self.downsample is not None else [])
+
+        def build():
+            out = []
+            for bn in bns:
+                scale = bn.weight.float() * (bn.running_var.float() + 1e-5).rsqrt()
+                out.append((scale.reshape(-1, 1, 1, 1).contiguous(),
+                            (bn.bias.float() - bn.running_mean.float() * scale).contiguous()))
+            if self.downsample is not None:
+                out.append((None, (out[2][1] + out[3][1]).contiguous()))   # the shortcut's shift rides with conv3's
+            return out
+
+        with torch.no_grad():
+            c = ops.cached_weights(self, "bn_affine_train",
+                                   [t for bn in bns for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)], build)
+        idt, shift3 = x, c[2][1]
+        if self.downsample is not None:
+            ds = self.downsample[0]
+            idt = F.conv2d(x, ds.weight * c[3][0], None, stride=ds.stride)
+            shift3 = c[4][1]
+        y = ops.bias_act(F.conv2d(x, self.conv1.weight * c[0][0]), c[0][1])
+        y = ops.bias_act(F.conv2d(y, self.conv2.weight * c[1][0], None, stride=self.conv2.stride, padding=1), c[1][1])
+        return ops.bias_act(F.conv2d(y, self.conv3.weight * c[2][0]), shift3, idt)
 
     def folded_params(self):
         p = [_fold(self.conv1, self.bn1), _fold(self.conv2, self.bn2), _fold(self.conv3, self.bn3)]

@@ -678,6 +678,38 @@ def bias_act_(x, bias, residual=None, relu=True):
     return x
 
 
+class BiasActFunction(Function):
+    """y = relu(x + bias[c] (+ residual)) on an NCHW fp32 activation under autograd: one HIP pass forward
+    (egtr_bias_act_nchw_f32), one mask pass backward (the masked gradient is the gradient of x AND of the residual)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual):
+        lib = _lib.lib()
+        x = _chk(x.contiguous(), "x", torch.float32)
+        _chk(bias, "bias", torch.float32)
+        r = _chk(residual.contiguous(), "residual", torch.float32) if residual is not None else None
+        N, C, H, W_ = x.shape
+        y = torch.empty_like(x)
+        st = lib.egtr_bias_act_nchw_f32(_stream(), x.data_ptr(), bias.data_ptr(), r.data_ptr() if r is not None else None,
+                                        y.data_ptr(), N, C, H * W_, 1)
+        _lib.check(st, "egtr_bias_act_nchw_f32")
+        ctx.save_for_backward(y)
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        gm = torch.ops.aten.threshold_backward(g.contiguous(), y, 0.0)
+        return gm, None, gm if ctx.has_residual else None
+
+
+def bias_act(x, bias, residual=None):
+    """relu(x + bias[c] (+ residual)) with autograd through x and residual (bias: a constant, e.g. a frozen-BN shift)."""
+    return BiasActFunction.apply(x, bias, residual)
+
+
 def sine_position_embedding(pixel_mask, embedding_dim, temperature, scale, eps=1e-6):
     """DeformableDetrSinePositionEmbedding(normalize=True) (dd:850-876) with the ~20 elementwise kernels after the two
     cumulative sums fused into one HIP kernel.  pixel_mask [B,H,W] bool/int -> [B, 2*embedding_dim, H, W] fp32."""

@@ -579,3 +579,36 @@ def test_postprocessing_on_device_vs_reference_fixture(golden_dir):
     # the evaluator's use: predicted boxes (rescaled by the device routine) vs ground truth
     iou = bbox_overlaps(got[0]["pred_boxes"], torch.from_numpy(g["gt0_gt_boxes"]).to(DEV)).cpu().numpy()
     assert np.abs(iou - g["iou_pred0_vs_gt0"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("downsample,stride", [(True, 2), (False, 1)])
+def test_bottleneck_training_fused_epilogue_matches_reference_order(downsample, stride):
+    """Trainable bottleneck in training: frozen-BN scale folded into the convolution weight under autograd + one fused
+    shift / residual / ReLU pass (Bottleneck.forward_train_fused) against the reference's operation order (convolution,
+    x * scale + shift, add, ReLU): output, input gradient and every weight gradient."""
+    import egtr_amd.backbone as bb
+    torch.manual_seed(5)
+    inpl = 64 if downsample else 128
+    blk = bb.Bottleneck(inpl, 32, stride, downsample=downsample).to(DEV)
+    for m in blk.modules():
+        if isinstance(m, bb.DeformableDetrFrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.2)
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(2, inpl, 37, 41, device=DEV)
+    go = torch.randn(2, 128, (37 + stride - 1) // stride, (41 + stride - 1) // stride, device=DEV)
+    outs = []
+    for fused in (True, False):
+        bb.TRAIN_FUSED_EPILOGUE = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            blk.zero_grad(set_to_none=True)
+            y = blk(xi)
+            (y * go).sum().backward()
+            outs.append([y.detach(), xi.grad] + [p.grad.clone() for p in blk.parameters()])
+        finally:
+            bb.TRAIN_FUSED_EPILOGUE = True
+    for a, b in zip(*outs):
+        assert (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max()))
