@@ -57,6 +57,7 @@ SIGNATURES = {
     "egtr_msda_geometry_forward_f32": [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, ctypes.c_longlong, _I, _I, _I],
     "egtr_msda_geometry_backward_f32": [_P, _P, _P, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _I, _I],
     "egtr_linear_backward_f32": [_P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _I, _I, _I],
+    "egtr_weighted_column_sum_f32": [_P, _P, _P, _P, _P, _I, _I],
     "egtr_column_sum_f32": [_P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_column_sum_workspace_floats": [_I, _I],
     "egtr_any_nonfinite_f32": [_P, _P, ctypes.c_longlong, _P],

@@ -912,7 +912,7 @@ constexpr int kCsRows = 64;
 template <int LPR, bool MASK>
 __global__ __launch_bounds__(256) void colsum_partial_v4_f32(const float* g, const float* __restrict__ y,
                                                              float* g_masked, float* __restrict__ partial,
-                                                             int M, int N) {
+                                                             int M, int N, const float* __restrict__ row_weight) {
   constexpr int RP = 256 / LPR;
   __shared__ float4 sm[256];
   const int lane = threadIdx.x % LPR, rl = threadIdx.x / LPR;
@@ -933,6 +933,10 @@ __global__ __launch_bounds__(256) void colsum_partial_v4_f32(const float* g, con
           v.z = t.z > 0.f ? v.z : 0.f;
           v.w = t.w > 0.f ? v.w : 0.f;
           reinterpret_cast<float4*>(g_masked)[i] = v;
+        }
+        if (!MASK && row_weight != nullptr) {   // weighted column sum: sum_r w[r] g[r][c]
+          const float w = row_weight[r];
+          v.x *= w; v.y *= w; v.z *= w; v.w *= w;
         }
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       }
@@ -995,11 +999,13 @@ __global__ __launch_bounds__(256) void colsum_final_f32(const float* __restrict_
 
 template <int LPR>
 void launch_colsum_v4(hipStream_t st, int chunks, const float* g, const float* y, float* g_masked, float* partial, int M,
-                      int N) {
+                      int N, const float* row_weight = nullptr) {
   if (y)
-    hipLaunchKernelGGL((colsum_partial_v4_f32<LPR, true>), dim3(chunks), dim3(256), 0, st, g, y, g_masked, partial, M, N);
+    hipLaunchKernelGGL((colsum_partial_v4_f32<LPR, true>), dim3(chunks), dim3(256), 0, st, g, y, g_masked, partial, M, N,
+                       (const float*)nullptr);
   else
-    hipLaunchKernelGGL((colsum_partial_v4_f32<LPR, false>), dim3(chunks), dim3(256), 0, st, g, y, g_masked, partial, M, N);
+    hipLaunchKernelGGL((colsum_partial_v4_f32<LPR, false>), dim3(chunks), dim3(256), 0, st, g, y, g_masked, partial, M, N,
+                       row_weight);
 }
 
 }  // namespace
@@ -1060,5 +1066,27 @@ extern "C" int egtr_add_layernorm_backward_f32(egtr_stream_t stream, const float
   int rc = egtr_check_launch();
   if (rc != EGTR_OK) return rc;
   hipLaunchKernelGGL(colsum_final_f32, dim3(512 / 16), dim3(256), 0, st, workspace, wgs, 512, grad_gamma_beta);
+  return egtr_check_launch();
+}
+
+// out [N] = sum_r row_weight[r] * g[r][:] -- the [1, M] x [M, N] product behind the weight gradient of a one-output linear
+// layer (the relation head's connectivity output), which the vendor library serves as a 220 us GEMV at M = 160 000
+extern "C" int egtr_weighted_column_sum_f32(egtr_stream_t stream, const float* g, const float* row_weight,
+                                            float* workspace, float* out, int M, int N) {
+  if (!g || !row_weight || !workspace || !out || M <= 0 || N <= 0) return EGTR_E_ARG;
+  if (N % 4 != 0 || ((uintptr_t)g % 16) != 0) return EGTR_E_UNSUPPORTED;
+  const int chunks = (M + kCsRows - 1) / kCsRows, n4 = N / 4;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n4 <= 32)
+    launch_colsum_v4<32>(st, chunks, g, nullptr, nullptr, workspace, M, N, row_weight);
+  else if (n4 <= 64)
+    launch_colsum_v4<64>(st, chunks, g, nullptr, nullptr, workspace, M, N, row_weight);
+  else if (n4 <= 128)
+    launch_colsum_v4<128>(st, chunks, g, nullptr, nullptr, workspace, M, N, row_weight);
+  else
+    launch_colsum_v4<256>(st, chunks, g, nullptr, nullptr, workspace, M, N, row_weight);
+  int rc = egtr_check_launch();
+  if (rc != EGTR_OK) return rc;
+  hipLaunchKernelGGL(colsum_final_f32, dim3((N + 15) / 16), dim3(256), 0, st, workspace, chunks, N, out);
   return egtr_check_launch();
 }

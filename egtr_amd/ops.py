@@ -297,6 +297,21 @@ def column_sum(g, relu_output=None, inplace=False):
     return out if gm is None else (gm, out)
 
 
+def weighted_column_sum(g, row_weight):
+    """sum_r row_weight[r] * g[r, :] for g [M, N] fp32 (egtr_weighted_column_sum_f32)."""
+    lib = _lib.lib()
+    g = _chk(g.contiguous(), "g", torch.float32)
+    w = _chk(row_weight.reshape(-1).contiguous(), "row_weight", torch.float32)
+    M, N = g.shape
+    if w.numel() != M:
+        raise RuntimeError("weighted_column_sum: one weight per row expected")
+    ws = torch.empty(int(lib.egtr_column_sum_workspace_floats(M, N)), dtype=torch.float32, device=g.device)
+    out = torch.empty(N, dtype=torch.float32, device=g.device)
+    _lib.check(lib.egtr_weighted_column_sum_f32(_stream(), g.data_ptr(), w.data_ptr(), ws.data_ptr(), out.data_ptr(), M, N),
+               "egtr_weighted_column_sum_f32")
+    return out
+
+
 class TokenLinearFunction(Function):
     """nn.Linear (+ ReLU) on token-sized inputs in TRAINING (reference: the encoder / cross-attention nn.Linear layers,
     model/deformable_detr.py:1049, 1053-1058, 1102, 1337-1343, under autograd).  Forward and data gradient g W run on the
@@ -910,7 +925,7 @@ class RelationHeadFunction(Function):
         dw2r = wgrad(dh2, h1s[0])
         # connectivity MLP (one output)
         dh2, db2c = column_sum(gc * w3c, relu_output=h2s[1], inplace=True)
-        dw3c = gc.t() @ h2s[1]
+        dw3c = weighted_column_sum(h2s[1], gc).view(1, -1)   # gc^T h2: one pass instead of a 220 us GEMV
         db3c = gc.sum(0)
         torch.mm(dh2, w2c, out=dh1[1])
         dw2c = wgrad(dh2, h1s[1])

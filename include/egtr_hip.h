@@ -493,6 +493,10 @@ int egtr_clamp_if_flag_f32(egtr_stream_t stream, float* t, const float* x, long 
 long long egtr_column_sum_workspace_floats(int M, int N);
 int egtr_column_sum_f32(egtr_stream_t stream, const float* g, const float* relu_output, float* g_masked,
                         float* workspace, float* out, int M, int N);
+/* out [N] = sum_r row_weight[r] * g[r][:]  ([1, M] x [M, N]: the weight gradient of a one-output linear layer -- the
+ * relation head's connectivity output, model/egtr.py:414-416 under autograd); workspace as above; N % 4 == 0. */
+int egtr_weighted_column_sum_f32(egtr_stream_t stream, const float* g, const float* row_weight, float* workspace,
+                                 float* out, int M, int N);
 
 #ifdef __cplusplus
 }

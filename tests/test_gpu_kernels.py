@@ -1370,3 +1370,16 @@ def test_linear_split_bf16_wgrad_is_fp32_accurate(M, N, K):
     e_out, e_vend = float((out.double() - ref).abs().max()) / scale, float((vend.double() - ref).abs().max()) / scale
     assert e_out <= 2.5 * e_vend + 1e-6, (e_out, e_vend)
     assert torch.equal(out, ops.linear_split_bf16_wgrad(g, x))
+
+
+@pytest.mark.parametrize("M,N", [(160000, 256), (777, 128), (65, 1024)])
+def test_weighted_column_sum_vs_float64(M, N):
+    """egtr_weighted_column_sum_f32 ([1, M] x [M, N]) against float64, bit-reproducible."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(3800 + M)
+    g = torch.from_numpy(rng.standard_normal((M, N))).float().to(DEV)
+    w = torch.from_numpy(rng.standard_normal((M, 1))).float().to(DEV)
+    out = ops.weighted_column_sum(g, w)
+    ref = (w.double().t() @ g.double()).reshape(-1)
+    assert (out.double() - ref).abs().max() <= 1e-5 * float((w.abs() * g.abs()).sum(0).max())
+    assert torch.equal(out, ops.weighted_column_sum(g, w))
