@@ -59,3 +59,17 @@ def test_null_arguments_are_rejected_without_a_gpu(lib_path):
     assert b"invalid" in h.egtr_status_string(-1)
     with pytest.raises(_lib.EgtrHipError):
         _lib.check(st, "x")
+
+
+def test_usable_cpus_respects_affinity_and_is_applied_to_torch():
+    """tests/conftest.py sizes torch's intra-op pool to the CPUs this process may use (the GPU boxes show 256 cores behind
+    a 16-CPU quota; the default 128 threads made the oracle passes several times slower)."""
+    import os
+
+    import torch
+
+    import conftest
+    n = conftest.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    assert n <= len(os.sched_getaffinity(0))
+    assert torch.get_num_threads() == max(1, min(n, 16))
