@@ -63,6 +63,15 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 // Up to kMaxProblems independent products with the same M and K in ONE launch (the value projection and the offsets /
 // attention-weights projection of an encoder layer; the six value projections of the decoder): their tiles share the
 // grid, so that products which do not fill the chip on their own (196-588 tiles on 512 workgroup slots) fill it together.
+// Workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Logical tile t = xcd_tile(...)
+// hands every XCD a CONTIGUOUS range of tiles, so that the tiles running side by side on one XCD are neighbours in the
+// tile order below and find the operand rows they share in that XCD's L2 (instead of every n block of a row tile
+// fetching the activation rows again through another L2).
+__device__ __forceinline__ int xcd_tile(int bid, int total) {
+  const int q = total >> 3, r = total & 7, x = bid & 7;
+  return x * q + min(x, r) + (bid >> 3);
+}
+
 constexpr int kMaxProblems = 8;
 struct GemmProblem {
   const float* A;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     GemmProblems P, int nprob, int M, int K) {
   // tile -> (problem, n block, m block): n blocks of one m block are neighbours (they read the same activation rows)
   const int mblocks = (M + BM - 1) / BM;
-  int tile = blockIdx.x, pi = 0;
+  int tile = xcd_tile(blockIdx.x, gridDim.x), pi = 0;
   for (; pi + 1 < nprob; ++pi) {
     const int t = (P.p[pi].N / kBN) * mblocks;
     if (tile < t) break;
@@ -251,7 +260,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int K, int rows_per_chunk) {
   constexpr int BM = 128;
   const int ktiles = K / kBN, tiles = (N / BM) * ktiles;
-  const int chunk = blockIdx.x / tiles, t = blockIdx.x - chunk * tiles;
+  const int lb = xcd_tile(blockIdx.x, gridDim.x);
+  const int chunk = lb / tiles, t = lb - chunk * tiles;
   const int n0 = (t / ktiles) * BM, k0 = (t % ktiles) * kBN;
   const int mbeg = chunk * rows_per_chunk, mend = min(M, mbeg + rows_per_chunk);
   const int nstage = (mend - mbeg + kBK - 1) / kBK;
