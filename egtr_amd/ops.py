@@ -260,8 +260,10 @@ class SkinnyLinearFunction(Function):
 
 def linear(x, weight, bias=None, alpha=1.0, relu=False):
     """nn.Linear (+ optional scale and ReLU).  Object-query-sized inputs on the GPU (rows <= SKINNY_MAX_ROWS,
-    K % 64 == 0, fp32) run the hand-written skinny MFMA kernel; token-sized inputs (encoder, S ~ 12.5k rows) go to
-    the vendor GEMM, which is the right tool there.  (On CPU tensors -- host-logic tests -- this is F.linear.)"""
+    K % 64 == 0, fp32) run the hand-written skinny MFMA kernel (forward and backward); token-sized inputs (encoder,
+    S ~ 12.5k rows per image) run the split-bf16 GEMM kernels -- in inference through ``module_linear`` /
+    ``linear_split_bf16``, under autograd through ``TokenLinearFunction`` -- and the vendor GEMM where those do not apply
+    (feature counts that are not multiples of 128 / 32, bf16 models).  (On CPU tensors -- host-logic tests -- F.linear.)"""
     rows = x.numel() // x.shape[-1]
     if x.is_cuda and x.dtype == torch.float32 and rows <= SKINNY_MAX_ROWS and x.shape[-1] % 64 == 0:
         return SkinnyLinearFunction.apply(x, weight, bias, alpha, relu)
@@ -527,7 +529,8 @@ def add_layer_norm_pos(x, residual, ln, pos):
 
 # Token-sized fp32 linears (encoder: S ~ 12.5k rows) on the bf16 matrix cores through exact three-way operand splits
 # (csrc/gemm_split.hip): fp32-level accuracy at 2.67x less matrix time than the fp32 MFMA / vendor fp32 GEMM.
-# Inference only; EGTR_GEMM_SPLIT_BF16=0 keeps the vendor fp32 GEMM.
+# Inference (module_linear) and training (TokenLinearFunction: forward, data and weight gradients);
+# EGTR_GEMM_SPLIT_BF16=0 keeps the vendor fp32 GEMM.
 GEMM_SPLIT_BF16 = os.environ.get("EGTR_GEMM_SPLIT_BF16", "1") != "0"
 GEMM_SPLIT_MIN_ROWS = 4096
 GEMM_SPLIT_WGRAD = os.environ.get("EGTR_GEMM_SPLIT_WGRAD", "1") != "0"
