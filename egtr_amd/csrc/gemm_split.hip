@@ -234,7 +234,8 @@ int launch_grouped(hipStream_t st, const GemmProblems& P, int nprob, int M, int 
   if (tiles64 >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
   // 128-row tiles when they fill the chip twice over (two co-resident workgroups per CU overlap each other's load /
   // store phases), 64-row tiles otherwise.  (128-row tiles for the K = 1024 product too measured 46.0 vs 53.0 us stand-alone
-  // but 262.6 vs 264.5 images/s in the forward, same box, alternating builds: not taken.)
+  // but 262.6 vs 264.5 images/s in the forward, same box, alternating builds: not taken; again with the XCD-aware tile
+  // order: 259.0 vs 262.8 / 261.5 images/s.)
   if (tiles128 >= 512)
     hipLaunchKernelGGL(gemm_split_bf16_f32<128>, dim3((unsigned)tiles128), dim3(512), 0, st, P, nprob, M, K);
   else
