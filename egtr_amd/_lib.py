@@ -74,6 +74,9 @@ SIGNATURES = {
     "egtr_gemm_split_tile_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "egtr_gemm_split_tile_weights_pair_f32": [_P, _P, _I, _I, _I, _P],
     "egtr_linear_split_bf16_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
+    "egtr_xs_bytes": [_I, _I],
+    "egtr_xs_split_f32": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _I],
+    "egtr_gemm_x6_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_rel_head_forward_bf16x6_f32": [_P] * 16 + [_I] * 6 + [_P] * 3 + [_I],
     "egtr_rel_head_forward_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
     "egtr_rel_head_backward_pairs_f32": [_P] * 6 + [_I] * 4 + [_P] * 5,
@@ -83,7 +86,8 @@ _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctype
              "egtr_relation_loss_workspace_bytes": ctypes.c_longlong,
              "egtr_column_sum_workspace_floats": ctypes.c_longlong,
              "egtr_add_layernorm_backward_workspace_floats": ctypes.c_longlong,
-             "egtr_linear_split_bf16_wgrad_workspace_floats": ctypes.c_longlong}
+             "egtr_linear_split_bf16_wgrad_workspace_floats": ctypes.c_longlong,
+             "egtr_xs_bytes": ctypes.c_longlong}
 
 _lib = None
 

@@ -435,6 +435,30 @@ int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, c
                                        const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
                                        const int* ldy, const int* N, const int* relu, int M, int K);
 
+/* ---- second-generation split-bf16 GEMM (csrc/gemm_x6.hip): BOTH operands pre-split into the "XS" format -------------
+ * XS(X) of a logical fp32 matrix X[rows][K] (K % 16 == 0): the exact three-way bf16 split x = hi + mid + lo, stored as
+ * 1 KiB fragments of 32 rows x 16 k of ONE piece; fragment (rb = row / 32, ks = k / 16, piece p) at byte
+ * ((rb * (K / 16) + ks) * 3 + p) * 1024, element (r = row % 32, kk = k % 16) inside it at (kk / 8) * 512 + r * 16 +
+ * (kk % 8) * 2 (csrc/xs_format.h).  A fragment is what one global_load_lds_dwordx4 wave-instruction moves and what one
+ * ds_read_b128 wave-instruction hands to v_mfma_f32_32x32x16_bf16.  egtr_xs_bytes: size of XS(X) in bytes (rows rounded
+ * up to 32; 0 for K % 16 != 0). */
+long long egtr_xs_bytes(int rows, int K);
+/* fp32 row-major x [rows, K] (row stride ldx) -> XS(x) in xs_out and / or XS(x + pos) in xs_pos_out (pos [pos_rows, K]
+ * contiguous, row r uses pos[r % pos_rows]; either output may be NULL).  round_to_nearest != 0: pieces rounded to nearest
+ * even (weights, prepared once); 0: truncation split (activations).  Non-finite elements: hi carries the inf / quiet NaN,
+ * mid = lo = 0. */
+int egtr_xs_split_f32(egtr_stream_t stream, const float* x, int ldx, const float* pos, int pos_rows, int rows, int K,
+                      void* xs_out, void* xs_pos_out, int round_to_nearest);
+/* Up to 8 products C_i[M, N_i] = act(A_i[M, K] . W_i[N_i, K]^T + bias_i) with the same M and K in ONE launch, fp32-level
+ * accuracy (six bf16 cross terms, fp32 accumulation) -- the encoder's nn.Linear layers in inference
+ * (model/deformable_detr.py:1049-1058, 1102, 1337-1343).  a_xs[i] = XS(A_i), w_xs[i] = XS(W_i) (rows = output features);
+ * outputs: c[i] fp32 [M, ldc[i]] and / or c_xs[i] = XS(C_i) (the A operand of a following product with K' = N_i), at least
+ * one of them.  All arrays are HOST arrays of num_problems entries.  K % 32 == 0, K >= 64, N_i % 128 == 0, else
+ * EGTR_E_UNSUPPORTED. */
+int egtr_gemm_x6_f32(egtr_stream_t stream, int num_problems, const void* const* a_xs, const void* const* w_xs,
+                     const float* const* bias, float* const* c, const int* ldc, void* const* c_xs, const int* N,
+                     const int* relu, int M, int K);
+
 /* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
  * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
  * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the
