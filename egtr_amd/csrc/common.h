@@ -8,3 +8,6 @@
 
 // Records hipGetLastError() for egtr_last_hip_error() and maps it to an EGTR_* status.
 int egtr_check_launch();
+
+// ReLU as torch computes it: relu(NaN) = NaN (fmaxf / v_max_f32 would return 0 and hide a diverged activation).
+__device__ __forceinline__ float egtr_relu(float x) { return x < 0.f ? 0.f : x; }

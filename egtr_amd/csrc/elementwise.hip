@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_vec4(const float* __restric
       const float4 r = reinterpret_cast<const float4*>(res)[i];
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (relu) { v.x = egtr_relu(v.x); v.y = egtr_relu(v.y); v.z = egtr_relu(v.z); v.w = egtr_relu(v.w); }
     reinterpret_cast<float4*>(y)[i] = v;
   }
 }
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_flat4(const float* __restri
       const float4 r = reinterpret_cast<const float4*>(res)[i];
       v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
     }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (relu) { v.x = egtr_relu(v.x); v.y = egtr_relu(v.y); v.z = egtr_relu(v.z); v.w = egtr_relu(v.w); }
     reinterpret_cast<float4*>(y)[i] = v;
   }
 }
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_scalar(const float* __restr
     const int c = (int)((i / HW) % C);
     float v = x[i] + bias[c];
     if (res != nullptr) v += res[i];
-    if (relu) v = fmaxf(v, 0.f);
+    if (relu) v = egtr_relu(v);
     y[i] = v;
   }
 }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_flat8_bf16(const unsigned s
     }
     if (relu) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+      for (int k = 0; k < 8; ++k) v[k] = egtr_relu(v[k]);
     }
     reinterpret_cast<uint4*>(y)[i] = pack8(v);
   }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void bias_act_nchw_scalar_bf16(const unsigned 
     const int c = (int)((i / HW) % C);
     float v = bf2f(x[i]) + bias[c];
     if (res != nullptr) v += bf2f(res[i]);
-    if (relu) v = fmaxf(v, 0.f);
+    if (relu) v = egtr_relu(v);
     y[i] = f2bf(v);
   }
 }

@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "xs_format.h"
 
 namespace {
 
@@ -40,18 +41,10 @@ __device__ __forceinline__ f32x4v gload(const void* p) {
 }
 __device__ __forceinline__ void vm_wait0(f32x4v& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
 
-struct Split3 {
-  unsigned hi, mid, lo;
-};
 // exact truncation split (rel_head.hip): pieces as fp32 bit patterns with zero low halves
-__device__ __forceinline__ Split3 split3(float x) {
-  Split3 s;
-  s.hi = __float_as_uint(x) & 0xffff0000u;
-  const float r = x - __uint_as_float(s.hi);
-  s.mid = __float_as_uint(r) & 0xffff0000u;
-  s.lo = __float_as_uint(r - __uint_as_float(s.mid));
-  return s;
-}
+// (xs_format.h: non-finite x keeps the inf / a quiet NaN in hi alone, mid = lo = 0 -- `x - hi` would be inf - inf)
+using Split3 = xs::Split3;
+__device__ __forceinline__ Split3 split3(float x) { return xs::split3(x); }
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // A workgroup is 8 waves on a BM x 128 tile, BM = 128 (wave tile 32 x 64) or 64 (wave tile 32 x 32; chosen when 128-row
@@ -217,7 +210,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       if (bias != nullptr) bv = *reinterpret_cast<const float4*>(bias + col);
       float4 v = make_float4(acc[nt][4 * q + 0] + bv.x, acc[nt][4 * q + 1] + bv.y, acc[nt][4 * q + 2] + bv.z,
                              acc[nt][4 * q + 3] + bv.w);
-      if (RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      if (RELU) v = make_float4(egtr_relu(v.x), egtr_relu(v.y), egtr_relu(v.z), egtr_relu(v.w));
       if (row < M) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
     }
 }

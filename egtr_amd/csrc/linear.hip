@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void linear_skinny_f32(const float* __restrict
     if (orow < M && ocol < N) {
       if (bias != nullptr) v += bias[ocol];
       v *= alpha;
-      if (relu) v = fmaxf(v, 0.f);
+      if (relu) v = egtr_relu(v);
       y[(size_t)orow * N + ocol] = v;
     }
   }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, in
       if (G.alpha_x != 1.f) v *= G.alpha_x;  // (alpha_x X) W^T: the product is scaled before the bias is added
       if (G.b != nullptr) v += G.b[ocol];
       v *= G.alpha;
-      if (G.relu) v = fmaxf(v, 0.f);
+      if (G.relu) v = egtr_relu(v);
       G.y[(size_t)orow * G.ldy + ocol] = v;
     }
   }

@@ -29,6 +29,7 @@
 #include <stdint.h>
 
 #include "common.h"
+#include "xs_format.h"
 
 namespace {
 
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(64 * kRhWaves) void rel_head_fwd_f32(
           acc.z += gt * (a.z + c.z);
           acc.w += gt * (a.w + c.w);
         }
-        const float4 hv = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+        const float4 hv = make_float4(egtr_relu(acc.x), egtr_relu(acc.y), egtr_relu(acc.z), egtr_relu(acc.w));
         *reinterpret_cast<float4*>(&s_h1[pp * kH1Stride + 4 * lane]) = hv;
         if (h1_save != nullptr && i0 + ii < N && j0 + jj < N)  // one contiguous 1 KiB row per wave
           reinterpret_cast<float4*>(h1_save + ((size_t)mlp * total +
@@ -253,10 +254,10 @@ __global__ __launch_bounds__(64 * kRhWaves) void rel_head_fwd_f32(
     for (int rq = 0; rq < 4; ++rq) {
       const int n0 = nt * 32 + 8 * rq + 4 * hf;
       const float4 bb = *reinterpret_cast<const float4*>(b2 + n0);
-      acc[4 * rq + 0] = fmaxf(acc[4 * rq + 0] + bb.x, 0.f);
-      acc[4 * rq + 1] = fmaxf(acc[4 * rq + 1] + bb.y, 0.f);
-      acc[4 * rq + 2] = fmaxf(acc[4 * rq + 2] + bb.z, 0.f);
-      acc[4 * rq + 3] = fmaxf(acc[4 * rq + 3] + bb.w, 0.f);
+      acc[4 * rq + 0] = egtr_relu(acc[4 * rq + 0] + bb.x);
+      acc[4 * rq + 1] = egtr_relu(acc[4 * rq + 1] + bb.y);
+      acc[4 * rq + 2] = egtr_relu(acc[4 * rq + 2] + bb.z);
+      acc[4 * rq + 3] = egtr_relu(acc[4 * rq + 3] + bb.w);
       if (h2_save != nullptr && valid)
         *reinterpret_cast<float4*>(h2_save + ((size_t)mlp * total + (size_t)p) * kHd + n0) =
             make_float4(acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(64) void rel_head_fwd_bf16w(
         acc.w += gt * (a.w + c.w);
       }
       *reinterpret_cast<float4*>(&s_h1[row * kH1Stride + 4 * lane]) =
-          make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+          make_float4(egtr_relu(acc.x), egtr_relu(acc.y), egtr_relu(acc.z), egtr_relu(acc.w));
     };
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -511,10 +512,10 @@ __global__ __launch_bounds__(64) void rel_head_fwd_bf16w(
     for (int rq = 0; rq < 4; ++rq) {
       const int n0 = nt * 32 + 8 * rq + 4 * hf;
       const float4 bb = *reinterpret_cast<const float4*>(b2 + n0);
-      acc[4 * rq + 0] = fmaxf(acc[4 * rq + 0] + bb.x, 0.f);
-      acc[4 * rq + 1] = fmaxf(acc[4 * rq + 1] + bb.y, 0.f);
-      acc[4 * rq + 2] = fmaxf(acc[4 * rq + 2] + bb.z, 0.f);
-      acc[4 * rq + 3] = fmaxf(acc[4 * rq + 3] + bb.w, 0.f);
+      acc[4 * rq + 0] = egtr_relu(acc[4 * rq + 0] + bb.x);
+      acc[4 * rq + 1] = egtr_relu(acc[4 * rq + 1] + bb.y);
+      acc[4 * rq + 2] = egtr_relu(acc[4 * rq + 2] + bb.z);
+      acc[4 * rq + 3] = egtr_relu(acc[4 * rq + 3] + bb.w);
     }
     if (mlp == 0) {
       // ---- layer 3 (relation): two K = 16 steps per n tile; k slot e <-> n = nt*32 + 16 kb + (e&3) + 8 (e>>2) + 4 hf ----
@@ -601,17 +602,9 @@ constexpr int kHp = 264;  // bf16 elements per LDS row of an h1 piece
 // residual x - hi is exact in fp32 and holds the remaining <= 16 bits, mid = its top 8, and what is left has <= 8
 // significant bits, i.e. already is a bf16.  Pieces are kept as fp32 bit patterns whose low 16 bits are zero; two of
 // them are packed into one dword of bf16 pairs with a single v_perm_b32.
-struct Split3 {
-  unsigned hi, mid, lo;
-};
-__device__ __forceinline__ Split3 split3(float x) {
-  Split3 s;
-  s.hi = __float_as_uint(x) & 0xffff0000u;
-  const float r = x - __uint_as_float(s.hi);
-  s.mid = __float_as_uint(r) & 0xffff0000u;
-  s.lo = __float_as_uint(r - __uint_as_float(s.mid));
-  return s;
-}
+// (xs_format.h: non-finite x keeps the inf / a quiet NaN in hi alone, mid = lo = 0 -- `x - hi` would be inf - inf)
+using Split3 = xs::Split3;
+__device__ __forceinline__ Split3 split3(float x) { return xs::split3(x); }
 // {bf16(a) in the low half, bf16(b) in the high half} from two fp32 bit patterns with zero low halves
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
@@ -763,8 +756,8 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
           acc.z += gt * (a.z + c.z);
           acc.w += gt * (a.w + c.w);
         }
-        const Split3 sx = split3(fmaxf(acc.x, 0.f)), sy = split3(fmaxf(acc.y, 0.f)), sz = split3(fmaxf(acc.z, 0.f)),
-                     sw = split3(fmaxf(acc.w, 0.f));
+        const Split3 sx = split3(egtr_relu(acc.x)), sy = split3(egtr_relu(acc.y)), sz = split3(egtr_relu(acc.z)),
+                     sw = split3(egtr_relu(acc.w));
         __bf16* hp = s_h + pp * kHp + 4 * lane;
         *reinterpret_cast<uint2*>(hp) = make_uint2(pack_hi16(sx.hi, sy.hi), pack_hi16(sz.hi, sw.hi));
         *reinterpret_cast<uint2*>(hp + 32 * kHp) = make_uint2(pack_hi16(sx.mid, sy.mid), pack_hi16(sz.mid, sw.mid));
@@ -801,10 +794,10 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     for (int rq = 0; rq < 4; ++rq) {
       const int n0 = nt * 32 + 8 * rq + 4 * hf;
       const float4 bb = *reinterpret_cast<const float4*>(b2 + n0);
-      acc[4 * rq + 0] = fmaxf(acc[4 * rq + 0] + accc[4 * rq + 0] + bb.x, 0.f);
-      acc[4 * rq + 1] = fmaxf(acc[4 * rq + 1] + accc[4 * rq + 1] + bb.y, 0.f);
-      acc[4 * rq + 2] = fmaxf(acc[4 * rq + 2] + accc[4 * rq + 2] + bb.z, 0.f);
-      acc[4 * rq + 3] = fmaxf(acc[4 * rq + 3] + accc[4 * rq + 3] + bb.w, 0.f);
+      acc[4 * rq + 0] = egtr_relu(acc[4 * rq + 0] + accc[4 * rq + 0] + bb.x);
+      acc[4 * rq + 1] = egtr_relu(acc[4 * rq + 1] + accc[4 * rq + 1] + bb.y);
+      acc[4 * rq + 2] = egtr_relu(acc[4 * rq + 2] + accc[4 * rq + 2] + bb.z);
+      acc[4 * rq + 3] = egtr_relu(acc[4 * rq + 3] + accc[4 * rq + 3] + bb.w);
     }
     if (mlp == 0) {
       // ---- layer 3 (relation): two K = 16 steps per n tile on the split accumulators; W3 pieces pre-ordered ----------

@@ -129,6 +129,30 @@ def _loss_relations_one(pred_rel, target_rel, matching_cost, nm_cost, num_rel, n
     return bce(p, t, reduction="none")
 
 
+def relation_losses(rel_logits, conn_logits, targets, indices, mcosts, nm_cost, neg, nonm, training):
+    """loss_relations (egtr:754-814): per image the permutation "matched queries first" of the predictions and of the
+    targets, the connectivity target, _loss_relations; loss_rel = mean over the concatenated per-image terms,
+    loss_connectivity = mean over the stacked [N, N, 1] BCE maps.  rel_logits [B,N,N,R], conn_logits [B,N,N,1]
+    (pre-sigmoid); indices / mcosts as the matcher returns them.  Returns (loss_rel, loss_connectivity)."""
+    N, R = rel_logits.shape[1], rel_logits.shape[-1]
+    rel_losses, conn_losses = [], []
+    for i, ((si, ti), tgt, mc) in enumerate(zip(indices, targets, mcosts)):  # egtr:757-810
+        full = torch.arange(N)
+        uniq, cnt = torch.cat([full, si]).unique(return_counts=True)
+        fsi = torch.cat([si, uniq[cnt == 1]])
+        fti = torch.cat([ti, torch.arange(len(ti), N)])
+        fmc = torch.cat([mc, torch.full((N - len(mc),), float(nm_cost), dtype=mc.dtype)])
+        pr = rel_logits[i, fsi][:, fsi]
+        tr = tgt["rel"][fti][:, fti]
+        ri = torch.nonzero(tr)
+        tconn = torch.zeros(N, N, 1, dtype=conn_logits.dtype)
+        tconn[ri[:, 0], ri[:, 1]] = 1
+        pc = conn_logits[i, fsi][:, fsi]
+        conn_losses.append(F.binary_cross_entropy_with_logits(pc, tconn, reduction="none"))
+        rel_losses.append(_loss_relations_one(pr, tr, fmc, nm_cost, R, neg, nonm, training))
+    return torch.cat(rel_losses).mean(), torch.stack(conn_losses).mean()
+
+
 def sgg_loss(out, targets, cfg, training):
     """SceneGraphGenerationLoss.forward (egtr:953-1034) + the weighted sum of egtr:470-494.
 
@@ -166,24 +190,9 @@ def sgg_loss(out, targets, cfg, training):
 
     labels_boxes_card(logits, boxes, indices)
 
-    rel_losses, conn_losses = [], []
-    for i, ((si, ti), tgt, mc) in enumerate(zip(indices, targets, mcosts)):  # egtr:757-810
-        full = torch.arange(N)
-        uniq, cnt = torch.cat([full, si]).unique(return_counts=True)
-        fsi = torch.cat([si, uniq[cnt == 1]])
-        fti = torch.cat([ti, torch.arange(len(ti), N)])
-        fmc = torch.cat([mc, torch.full((N - len(mc),), float(nm_cost))])
-        pr = out["rel_logits"][i, fsi][:, fsi]
-        tr = tgt["rel"][fti][:, fti]
-        ri = torch.nonzero(tr)
-        tconn = torch.zeros(N, N, 1)
-        tconn[ri[:, 0], ri[:, 1]] = 1
-        pc = out["conn_logits"][i, fsi][:, fsi]
-        conn_losses.append(F.binary_cross_entropy_with_logits(pc, tconn, reduction="none"))
-        rel_losses.append(_loss_relations_one(pr, tr, fmc, nm_cost, R, cfg["rel_sample_negatives"],
-                                              cfg["rel_sample_nonmatching"], training))
-    losses["loss_rel"] = torch.cat(rel_losses).mean()
-    losses["loss_connectivity"] = torch.stack(conn_losses).mean()
+    losses["loss_rel"], losses["loss_connectivity"] = relation_losses(
+        out["rel_logits"], out["conn_logits"], targets, indices, mcosts, nm_cost, cfg["rel_sample_negatives"],
+        cfg["rel_sample_nonmatching"], training)
 
     with torch.no_grad():  # egtr:680-689
         unc = []
