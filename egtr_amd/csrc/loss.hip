@@ -61,7 +61,17 @@ __global__ __launch_bounds__(kLT) void rel_loss_prep(const int64_t* __restrict__
   __shared__ int s_cnt[2];
   __shared__ int s_scan[kLT];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int o0 = out_off[b], T = out_off[b + 1] - o0;
+  const int o0 = out_off[b];
+  int T = out_off[b + 1] - o0;
+  // The device matcher writes -1 indices for an image whose cost matrix holds NaN / -inf (scipy raises there): such an
+  // image is treated as having NO matches here (never an out-of-bounds access); the Python side turns the matcher's
+  // status into a NaN loss and a ValueError (ops.MatcherStatus).
+  int bad_local = 0;
+  for (int t = tid; t < T; t += kLT) {
+    const long long q = pred_idx[o0 + t], g = tgt_idx[o0 + t];
+    bad_local |= (q < 0 || q >= N || g < 0 || g >= N) ? 1 : 0;
+  }
+  if (__syncthreads_or(bad_local)) T = 0;
   int* tq_b = tq + (size_t)b * N;
   float* wq_b = wq + (size_t)b * N;
   unsigned char* mq_b = mq + (size_t)b * N;
@@ -427,7 +437,14 @@ __global__ __launch_bounds__(kDT) void det_loss_f32(
     d_giou[(size_t)b * N * 4 + e] = 0.f;
   }
   __syncthreads();
-  for (int k = m0 + tid; k < m1; k += kDT) s_cls[(int)pred_idx[k]] = (int)tlabels[t0 + (int)tgt_idx[k]];
+  // invalid entries (-1 from a matcher that refused the image's cost matrix) are skipped, never dereferenced
+  const int nt_img = toff[b + 1] - t0;
+  for (int k = m0 + tid; k < m1; k += kDT) {
+    const long long n = pred_idx[k], g = tgt_idx[k];
+    if (n < 0 || n >= N || g < 0 || g >= nt_img) continue;
+    const int cls = (int)tlabels[t0 + (int)g];
+    s_cls[(int)n] = (cls >= 0 && cls < C) ? cls : C;
+  }
   __syncthreads();
 
   // ---- sigmoid focal loss, gamma = 2 (egtr:647-656, dd:2687-2722) --------------------------------------------------
@@ -470,6 +487,7 @@ __global__ __launch_bounds__(kDT) void det_loss_f32(
   // ---- matched boxes: L1 + generalised IoU (egtr:692-712, dd util generalized_box_iou) -----------------------------------
   float l1sum = 0.f, gsum = 0.f;
   for (int k = m0 + tid; k < m1; k += kDT) {
+    if (pred_idx[k] < 0 || pred_idx[k] >= N || tgt_idx[k] < 0 || tgt_idx[k] >= nt_img) continue;
     const int n = (int)pred_idx[k];
     const float4 s = *reinterpret_cast<const float4*>(boxes + ((size_t)b * N + n) * 4);
     const float4 t = *reinterpret_cast<const float4*>(tboxes + (size_t)(t0 + (int)tgt_idx[k]) * 4);

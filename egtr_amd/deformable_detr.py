@@ -1142,10 +1142,24 @@ class DeformableDetrMLPPredictionHead(nn.Module):
         return x
 
 
+# (pinned host copy of a solver status, the event that marks the copy complete), oldest first
+_PENDING_MATCHER_STATUS = []
+
+
 class MatchedIndices(list):
     """The matcher's per-image (prediction indices, target indices) list; ``flat`` additionally holds the packed device
-    tensors they are views of (device matcher only)."""
+    tensors they are views of (device matcher only) and ``status`` the per-image solver status (int32 [B] on the device:
+    0 = assigned; 1 = the cost matrix holds NaN / -inf, 2 = infeasible -- where scipy raises ValueError)."""
     flat = None
+    status = None
+
+    def poison(self, value):
+        """``value`` (a 0-dim loss tensor) or NaN if the matcher refused an image's cost matrix: the failure reaches the
+        caller through the loss without a host synchronisation (the reference stops the step with scipy's ValueError;
+        ``DeformableDetrHungarianMatcher.raise_if_invalid`` is that exception, raised at the next host sync)."""
+        if self.status is None:
+            return value
+        return torch.where(self.status.ne(0).any(), torch.full_like(value, float("nan")), value)
 
 
 class DeformableDetrHungarianMatcher(nn.Module):
@@ -1168,6 +1182,22 @@ class DeformableDetrHungarianMatcher(nn.Module):
         self.smoothing = smoothing
         self.bias_epsilon = torch.log(torch.tensor(1e-8))
 
+    @staticmethod
+    def raise_if_invalid():
+        """The reference's failure mode, deferred: scipy raises ``ValueError("matrix contains invalid numeric entries")``
+        when a cost matrix holds NaN / -inf (diverged logits or boxes).  The device matcher records a per-image status
+        instead (no host synchronisation inside the step; the losses skip the refused image and come out NaN) and copies
+        it to pinned host memory asynchronously; this waits for the copies made so far and raises.
+        egtr_amd.runtime.DataParallelTrainer calls it at the top of every step (= one step late, never a stall)."""
+        pending = list(_PENDING_MATCHER_STATUS)
+        _PENDING_MATCHER_STATUS.clear()
+        for host, event in pending:
+            event.synchronize()
+            if bool((host == 1).any()):
+                raise ValueError("matrix contains invalid numeric entries")
+            if bool((host != 0).any()):
+                raise ValueError("cost matrix is infeasible")
+
     def _smoothing_scalars(self):
         """cost_min and inverse_sigmoid_smoothing exactly as the reference forms them (fp32 tensors, dd:2992-2998)."""
         alpha = 0.25
@@ -1183,10 +1213,10 @@ class DeformableDetrHungarianMatcher(nn.Module):
             cm = iss = None
             if self.smoothing:
                 cm, iss = self._smoothing_scalars()
-            pred_idx, tgt_idx, mcost, n_out = ops.hungarian_match(
+            pred_idx, tgt_idx, mcost, n_out, status = ops.hungarian_match(
                 outputs["logits"], outputs["pred_boxes"], targets, self.class_cost, self.bbox_cost, self.giou_cost,
-                float(cm) if cm is not None else None, float(iss) if iss is not None else None)
-            return ("device", pred_idx, tgt_idx, mcost, n_out)
+                float(cm) if cm is not None else None, float(iss) if iss is not None else None, want_status=True)
+            return ("device", pred_idx, tgt_idx, mcost, n_out, status)
         bs, num_queries = outputs["logits"].shape[:2]
         out_prob = outputs["logits"].flatten(0, 1).float().sigmoid()
         out_bbox = outputs["pred_boxes"].flatten(0, 1).float()
@@ -1205,8 +1235,16 @@ class DeformableDetrHungarianMatcher(nn.Module):
     @torch.no_grad()
     def finish(self, pending):
         if pending[0] == "device":
-            _, pred_idx, tgt_idx, mcost, n_out = pending
+            _, pred_idx, tgt_idx, mcost, n_out, status = pending
             indices, costs, o = MatchedIndices(), [], 0
+            indices.status = status
+            if not torch.cuda.is_current_stream_capturing():
+                host = torch.empty(status.shape, dtype=status.dtype, pin_memory=True)
+                host.copy_(status, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record()
+                _PENDING_MATCHER_STATUS.append((host, event))
+                del _PENDING_MATCHER_STATUS[:-64]   # bounded when nobody asks
             for n in n_out:
                 indices.append((pred_idx[o:o + n], tgt_idx[o:o + n]))
                 costs.append(mcost[o:o + n])

@@ -18,6 +18,7 @@ from torch import nn
 
 from . import ops
 from .deformable_detr import (DeformableDetrHungarianMatcher, DeformableDetrMLPPredictionHead, DeformableDetrModel,
+                              MatchedIndices,
                               DeformableDetrPreTrainedModel, inverse_sigmoid)
 from .hf_compat import ModelOutput
 from .util import (center_to_corners_format, dice_loss, generalized_box_iou, nested_tensor_from_tensor_list,
@@ -648,6 +649,7 @@ class SceneGraphGenerationLoss(nn.Module):
             return ops.detection_losses(out["logits"], out["pred_boxes"], idx.flat, packed, self.focal_alpha, num_boxes)
 
         use_fused = fused_ok(outputs, indices)
+        main_indices = indices
         if use_fused:
             losses.update(detection(outputs, indices))
         for loss in self.losses:
@@ -665,4 +667,7 @@ class SceneGraphGenerationLoss(nn.Module):
                         continue
                     l_dict = self.get_loss(loss, auxiliary_outputs, targets, indices, matching_costs, num_boxes)
                     losses.update({k + f"_{i}": v for k, v in l_dict.items()})
+        # a cost matrix the device matcher refused (NaN / -inf entries; scipy raises there): the loss comes out NaN
+        if isinstance(main_indices, MatchedIndices) and main_indices.status is not None and "loss_ce" in losses:
+            losses["loss_ce"] = main_indices.poison(losses["loss_ce"])
         return losses

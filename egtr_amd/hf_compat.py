@@ -14,6 +14,7 @@ Only the behaviours the reference's callers rely on are provided:
 import copy
 import json
 import os
+import warnings
 from collections import OrderedDict
 from dataclasses import fields, is_dataclass
 
@@ -139,9 +140,15 @@ def _load_state_file(path):
         return load_file(path)
     try:  # plain tensor checkpoints (pytorch_model.bin)
         sd = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
-        # Lightning .ckpt files pickle hyper-parameter namespaces / callbacks next to the tensors; the caller chose this
-        # file, so load it the way torch < 2.6 did (the reference's evaluate_egtr.py:232-240 does exactly this)
+    except Exception as err:
+        # Lightning .ckpt files pickle hyper-parameter namespaces / callbacks next to the tensors (the reference's
+        # evaluate_egtr.py:232-240 loads them with full unpickling).  Full unpickling executes code from the file, so it is
+        # limited to that case (a .ckpt path) or an explicit opt-in, and never silent.
+        if not (path.endswith(".ckpt") or os.environ.get("EGTR_TRUST_CHECKPOINT_PICKLE") == "1"):
+            raise RuntimeError(
+                f"{path}: not loadable with weights_only=True ({type(err).__name__}: {err}).  If this is a trusted "
+                "pickled checkpoint, set EGTR_TRUST_CHECKPOINT_PICKLE=1 (full unpickling runs code from the file).") from err
+        warnings.warn(f"{path}: falling back to full unpickling (weights_only=False); only do this for trusted files")
         sd = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(sd, dict) and "state_dict" in sd and not any(torch.is_tensor(v) for v in sd.values()):
         sd = sd["state_dict"]

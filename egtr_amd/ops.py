@@ -15,6 +15,13 @@ from .load_custom import _chk, _stream, load_hip_kernels
 _MSDA = None
 
 
+def _c16(t):
+    """Contiguous AND 16-byte aligned (a contiguous view with an odd storage offset is copied): what the C entries'
+    vector loads require; they answer EGTR_E_UNSUPPORTED otherwise."""
+    t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
 def _msda():
     global _MSDA
     if _MSDA is None:
@@ -107,10 +114,14 @@ class MSDAGeometryFunction(Function):
 
 def msda_geometry_supported(offsets, logits, reference_points, M, L, P):
     """Shapes / dtypes served by MSDAGeometryFunction (else the ATen composition)."""
+    def rows_ok(t):   # what egtr_msda_geometry_*_f32 asks of a row-strided operand: 16-byte base, row stride % 4 floats
+        return t.data_ptr() % 16 == 0 and (t.stride(-1) != 1 or t.stride(-2) % 4 == 0)
+
     return (MSDA_GEOMETRY and offsets.is_cuda and offsets.dtype == torch.float32 and logits.dtype == torch.float32
             and reference_points.dtype == torch.float32 and L == 4 and P == 4 and M == 8
             and reference_points.shape[-1] in (2, 4) and offsets.dim() == 3 and logits.dim() == 3
-            and reference_points.dim() == 4 and reference_points.shape[2] == L and M * L * P * 2 % 4 == 0)
+            and reference_points.dim() == 4 and reference_points.shape[2] == L and M * L * P * 2 % 4 == 0
+            and rows_ok(offsets) and rows_ok(logits))
 
 
 MSDA_GEOMETRY = os.environ.get("EGTR_MSDA_GEOMETRY", "1") != "0"
@@ -231,7 +242,7 @@ class SkinnyLinearFunction(Function):
         if SKINNY_BACKWARD_FUSED and N % 64 == 0 and K % 64 == 0 and g.dtype == torch.float32:
             # gx, gw, gb (+ ReLU mask and alpha) in one launch (egtr_linear_backward_f32)
             lib = _lib.lib()
-            g = _chk(g.contiguous(), "grad", torch.float32)
+            g = _chk(_c16(g), "grad", torch.float32)
             M = g.shape[0]
             gx = torch.empty(M, K, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
             gw = torch.empty(N, K, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
@@ -287,13 +298,13 @@ def column_sum(g, relu_output=None, inplace=False):
     object-query-sized M.  With ``relu_output`` (the layer's post-ReLU output) returns (g * [y > 0], its column sums);
     ``inplace``: the masked gradient overwrites ``g`` (every element is read and written by the same thread)."""
     lib = _lib.lib()
-    g = _chk(g.contiguous(), "grad", torch.float32)
+    g = _chk(_c16(g), "grad", torch.float32)
     M, N = g.shape
     ws = torch.empty(int(lib.egtr_column_sum_workspace_floats(M, N)), dtype=torch.float32, device=g.device)
     out = torch.empty(N, dtype=torch.float32, device=g.device)
     gm = (g if inplace else torch.empty_like(g)) if relu_output is not None else None
     _lib.check(lib.egtr_column_sum_f32(_stream(), g.data_ptr(),
-                                       _chk(relu_output, "relu_output", torch.float32).data_ptr() if gm is not None else None,
+                                       _chk(_c16(relu_output), "relu_output", torch.float32).data_ptr() if gm is not None else None,
                                        gm.data_ptr() if gm is not None else None, ws.data_ptr(), out.data_ptr(), M, N),
                "egtr_column_sum_f32")
     return out if gm is None else (gm, out)
@@ -1292,8 +1303,10 @@ class ClampNonFiniteFunction(Function):
     @once_differentiable
     def backward(ctx, g):
         x, flag = ctx.saved_tensors
-        g = g if g.is_contiguous() else g.contiguous()
-        # in place on the incoming gradient: a no-op unless the forward clamped (then the clamped elements get zero)
+        # Autograd forbids mutating a grad_output (the same buffer may be another branch's gradient: AddLayerNorm's backward
+        # hands ONE tensor to x and to the residual), so the mask is applied to a private copy: one extra pass over the
+        # states per encoder layer (~0.3 % of a step) for a result that is correct on the steps that did clamp.
+        g = g.clone(memory_format=torch.contiguous_format)
         _lib.check(_lib.lib().egtr_clamp_if_flag_f32(_stream(), g.data_ptr(), x.data_ptr(), g.numel(), flag.data_ptr(),
                                                      ctx.cv, 1), "egtr_clamp_if_flag_f32")
         return g

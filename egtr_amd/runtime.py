@@ -191,6 +191,10 @@ class DataParallelTrainer:
 
     def training_step(self, batch):
         """One micro-batch; returns (loss, loss_dict, stepped)."""
+        # a cost matrix the device matcher refused during the PREVIOUS step (NaN / -inf: the reference raises scipy's
+        # ValueError inside the step) surfaces here, without a host synchronisation inside the step
+        from .deformable_detr import DeformableDetrHungarianMatcher
+        DeformableDetrHungarianMatcher.raise_if_invalid()
         self._micro += 1
         boundary = self._micro % self.accumulate == 0
         ctx = contextlib.nullcontext() if (boundary or self.world == 1) else self.model.no_sync()

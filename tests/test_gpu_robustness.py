@@ -1,0 +1,113 @@
+"""GPU (-m gpu): failure behaviour the reference has and a device port can silently lose.
+
+  * a cost matrix with NaN entries: scipy raises ValueError("matrix contains invalid numeric entries") inside the
+    reference's matcher (model/deformable_detr.py:3001-3005).  The device matcher must not hand -1 indices to kernels
+    that dereference them: the losses skip the image, the total loss comes out NaN, and the same ValueError is raised at
+    the next host synchronisation point (DeformableDetrHungarianMatcher.raise_if_invalid);
+  * the "clamp iff inf / nan" backward must not modify the gradient buffer autograd handed in;
+  * operands with an odd storage offset take a working path instead of EGTR_E_UNSUPPORTED.
+"""
+import pytest
+import torch
+
+import weights as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _criterion(N, C, R):
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher
+    from egtr_amd.egtr import SceneGraphGenerationLoss
+    m = DeformableDetrHungarianMatcher(class_cost=2.0, bbox_cost=5.0, giou_cost=2.0, smoothing=1e-14)
+    return SceneGraphGenerationLoss(
+        matcher=m, num_object_queries=N, num_classes=C, num_rel_labels=R, eos_coef=0.1,
+        losses=["labels", "boxes", "relations", "cardinality", "uncertainty"], smoothing=1e-14, rel_sample_negatives=80,
+        rel_sample_nonmatching=80, model_training=True, focal_alpha=0.25, rel_sample_negatives_largest=True,
+        rel_sample_nonmatching_largest=True).to(DEV)
+
+
+@pytest.mark.parametrize("poison", [None, "logit", "box"])
+def test_matcher_refusal_reaches_the_caller(poison):
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher as Matcher
+    B, N, C, R = 3, 50, 12, 7
+    g = torch.Generator().manual_seed(5)
+    targets = [{k: v.to(DEV) for k, v in t.items()} for t in W.make_targets(3, B, N, C, R)]
+    logits = torch.randn(B, N, C, generator=g).to(DEV)
+    boxes = (torch.rand(B, N, 4, generator=g) * 0.5 + 0.25).to(DEV)
+    if poison == "logit":
+        logits[1, 7, :] = float("nan")     # (the cost matrix reads the target classes only: poison them all)
+    elif poison == "box":
+        boxes[2, 11, 0] = float("nan")
+    out = {"logits": logits.clone().requires_grad_(True), "pred_boxes": boxes.clone().requires_grad_(True),
+           "pred_rel": torch.randn(B, N, N, R, generator=g).to(DEV).requires_grad_(True),
+           "pred_connectivity": torch.randn(B, N, N, 1, generator=g).to(DEV).requires_grad_(True)}
+    Matcher.raise_if_invalid()                       # drain what earlier tests left behind
+    crit = _criterion(N, C, R)
+    losses = crit(out, targets)
+    total = sum(losses[k] for k in ("loss_ce", "loss_bbox", "loss_giou", "loss_rel", "loss_connectivity"))
+    total.backward()
+    torch.cuda.synchronize()                           # (a fault from an out-of-bounds access would surface here)
+    clean = [b for b in range(B) if not (poison == "logit" and b == 1) and not (poison == "box" and b == 2)]
+    for b in clean:                                    # the other images' gradients are the usual finite ones
+        assert torch.isfinite(out["pred_boxes"].grad[b]).all() and torch.isfinite(out["pred_connectivity"].grad[b]).all()
+    if poison is None:
+        assert torch.isfinite(total).item()
+        Matcher.raise_if_invalid()                   # nothing to report
+    else:
+        assert torch.isnan(losses["loss_ce"]).item() and torch.isnan(total).item()
+        with pytest.raises(ValueError, match="matrix contains invalid numeric entries"):
+            Matcher.raise_if_invalid()
+        Matcher.raise_if_invalid()                   # reported once
+
+
+def test_trainer_raises_the_matchers_error_one_step_late():
+    """DataParallelTrainer.training_step checks the statuses of the previous step first."""
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher as Matcher, _PENDING_MATCHER_STATUS
+    Matcher.raise_if_invalid()
+    host = torch.ones(2, dtype=torch.int32).pin_memory()
+    ev = torch.cuda.Event()
+    ev.record()
+    _PENDING_MATCHER_STATUS.append((host, ev))
+    from egtr_amd.runtime import DataParallelTrainer
+
+    class _M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+    tr = DataParallelTrainer(_M().to(DEV), optimizer=torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1))
+    with pytest.raises(ValueError, match="invalid numeric entries"):
+        tr.training_step({})
+
+
+def test_clamp_nonfinite_backward_leaves_the_incoming_gradient_alone():
+    from egtr_amd import ops
+    x = torch.randn(64, 256, device=DEV)
+    x[3, 5] = float("inf")
+    x[10, 0] = float("nan")
+    xin = x.clone().requires_grad_(True)
+    y = ops.clamp_nonfinite_(xin * 1.0)
+    g = torch.randn(64, 256, device=DEV)
+    keep = g.clone()
+    y.backward(g)
+    assert torch.equal(g, keep)                              # autograd's buffer was not modified
+    assert float(xin.grad[3, 5]) == 0.0 and float(xin.grad[10, 0]) == 0.0
+    mask = torch.ones_like(g, dtype=torch.bool)
+    mask[3, 5] = mask[10, 0] = False
+    assert torch.equal(xin.grad[mask], g[mask])
+
+
+def test_misaligned_views_are_served():
+    """A contiguous view that starts 4 bytes into its storage: column sums and the MSDA geometry pass either take an
+    aligned copy or report "unsupported" to their caller's predicate -- never an exception in the step."""
+    from egtr_amd import ops
+    base = torch.randn(801 * 256 + 1, device=DEV)
+    g = base[1:].view(801, 256)
+    assert g.data_ptr() % 16 != 0 and g.is_contiguous()
+    assert (ops.column_sum(g) - g.double().sum(0).float()).abs().max() < 1e-3
+    off = torch.randn(2 * 40 * 384 + 1, device=DEV)[1:].view(2, 40, 384)
+    ref = torch.rand(2, 40, 4, 2, device=DEV)
+    assert not ops.msda_geometry_supported(off[..., :256], off[..., 256:], ref, 8, 4, 4)
+    ok = torch.randn(2, 40, 384, device=DEV)
+    assert ops.msda_geometry_supported(ok[..., :256], ok[..., 256:], ref, 8, 4, 4)
