@@ -177,7 +177,10 @@ def time_msda_kernel(args, fused, iters=200):
     from egtr_amd.load_custom import load_hip_kernels
     k = load_hip_kernels()
     value, loc = args[0], args[3]
-    fn = (lambda: k.ms_deform_attn_forward_fused(*args)) if fused else (lambda: k.ms_deform_attn_forward(*args))
+    if fused and value.dtype == torch.bfloat16:
+        fn = lambda: k.ms_deform_attn_forward_fused_bf16(*args[:6], args[7])  # noqa: E731
+    else:
+        fn = (lambda: k.ms_deform_attn_forward_fused(*args)) if fused else (lambda: k.ms_deform_attn_forward(*args))
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
@@ -358,7 +361,7 @@ def cpu_train_baseline(model, cfg_dict, labels_cpu, budget_s=25.0):
     return n / dt, n
 
 
-def train_bench(args, world, rank, dev, dist):
+def train_bench(args, world, rank, dev, dist, emit=True):
     """Train-step throughput (BASELINE configs[2] shape: 600x1000, N=200, VG heads, fp32, batch 4/GPU, DDP over
     RCCL when world > 1, accumulate 1 so every step carries the gradient all-reduce).  Secondary metric."""
     from egtr_amd.runtime import DataParallelTrainer, configure_optimizers
@@ -391,6 +394,7 @@ def train_bench(args, world, rank, dev, dist):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    result = None
     if rank == 0:
         result = {
             "metric": "images/sec SGG train step (fwd + loss + bwd + grad all-reduce + AdamW), 600x1000, N=200",
@@ -420,9 +424,73 @@ def train_bench(args, world, rank, dev, dist):
             result["cpu_baseline"] = {"value": round(ips, 4), "unit": "images/sec", "cores": torch.get_num_threads(),
                                       "kind": "port", "sample": f"{nimg} single-image train iterations (oracle forward "
                                       "+ matcher + SGG loss + autograd backward, incl. ResNet-50) at 600x1000 / N=200"}
-        print(json.dumps(result))
-    if dist is not None:
+        if emit:
+            print(json.dumps(result))
+    if dist is not None and emit:
         dist.destroy_process_group()
+    return result if rank == 0 else None
+
+
+def stress_bench(dev, steps, warmup, batch=16):
+    """BASELINE configs[4] shape on ONE GPU: 800x1333, N = 300 queries, 8 decoder layers, bf16 weights and activations,
+    `batch` images per step (HIP-graph replay).  Returns the extra-key dict of the default bench line."""
+    from egtr_amd.runtime import GraphedForward
+    model, cfg, _ = build_model(dev, {"num_queries": 300, "decoder_layers": 8})
+    model = model.to(torch.bfloat16).eval()
+    torch.manual_seed(300)
+    pv = torch.randn(batch, 3, 800, 1333, device=dev, dtype=torch.bfloat16)
+    pm = torch.ones(batch, 800, 1333, dtype=torch.long, device=dev)
+    fwd = GraphedForward(model, enabled=True, strict=True)
+    with MsdaProbe() as probe, torch.no_grad():
+        model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
+              output_hidden_states=True)
+        msda_args, fused = probe.args, probe.fused
+    with torch.no_grad():
+        for _ in range(warmup):
+            fwd(pv, pm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fwd(pv, pm)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    out = {"metric": "images/sec end-to-end SGG forward, stress shape", "value": round(batch * steps / dt, 2),
+           "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+           "dtype": "bf16", "n_gpus": 1,
+           "config": {"workload": f"Stress: ResNet-50, 800x1333, N=300, 6 enc/8 dec, bf16, bs={batch}/GPU "
+                                  "(BASELINE configs[4] shape on one GPU)", "hip_graph": bool(fwd.graphed)}}
+    if msda_args is not None:
+        us, alg = time_msda_kernel(msda_args, fused, iters=50)
+        ach = alg / (us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "msda_fwd_q32_bf16<fused prologue>" if fused else "msda_fwd_q32_bf16",
+                           "launch": f"encoder layer, B={batch}, Lq = S = 22223, bf16 values",
+                           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2)}
+    del fwd, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def newest_pmc(pattern, kernel):
+    """The most recent profiles/<pattern> (rocprofv3 --pmc passes over this command, tools/pmc_passes.sh + tools/*_pmc.py)
+    whose `kernel` field names the kernel that was just timed; (dict, "file name (mtime)") or ({}, None).  Counters are
+    collected in separate profiler runs, never inside the timed run, so the line says which file they come from."""
+    import glob
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", pattern)):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("kernel") != kernel:
+            continue
+        m = os.path.getmtime(path)
+        if best is None or m > best[0]:
+            best = (m, path, d)
+    if best is None:
+        return {}, None
+    return best[2], f"profiles/{os.path.basename(best[1])} (mtime {time.strftime('%Y-%m-%d %H:%M', time.gmtime(best[0]))} UTC)"
 
 
 def _free_port():
@@ -503,6 +571,10 @@ def main():
     ap.add_argument("--mode", default="infer", choices=["infer", "train"],
                     help="infer = BASELINE configs[1] (default, the headline metric); train = configs[2]-style train "
                          "step (forward + SGG loss + backward + DDP all-reduce + AdamW), batch 4/GPU unless --batch")
+    ap.add_argument("--extras", type=int, default=1,
+                    help="--mode infer on one GPU: after the timed region also run a short bs = 4 train loop and the bf16 "
+                         "stress forward and append them to the JSON line as `train_step` / `stress_bf16` (0 = skip)")
+    ap.add_argument("--extra-steps", type=int, default=8, help="timed steps of each extra workload")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous, all-reduce and print n_gpus / rccl_ranks (launcher self-test, runs on CPU)")
     args = ap.parse_args()
@@ -580,15 +652,7 @@ def main():
     # HBM bytes / cache behaviour per launch come from separate rocprofv3 --pmc passes over THIS command
     # (tools/pmc_passes.sh + tools/msda_pmc.py -> profiles/r02_msda_pmc.json); used only if they were collected for
     # the kernel that was just timed, otherwise null.
-    pmc = {}
-    tpath = os.path.join(ROOT, "profiles", "r02_msda_pmc.json")
-    if os.path.exists(tpath):
-        try:
-            pmc = json.load(open(tpath))
-            if pmc.get("kernel") != msda_kernel:
-                pmc = {}
-        except Exception:
-            pmc = {}
+    pmc, pmc_src = newest_pmc("r*_msda_pmc.json", msda_kernel)
     traffic = pmc.get("hbm_bytes_per_launch")
     result = {
         "metric": "images/sec end-to-end SGG, 600x1000 input, N=200 queries",
@@ -605,6 +669,7 @@ def main():
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(msda_us, 3),
+                     "traffic_source": pmc_src,
                      "l2_hit": pmc.get("l2_hit"), "l1_gather_bytes": pmc.get("l1_gather_bytes"),
                      "frac_of_l1_gather_ceiling": (round(pmc["l1_gather_bytes"] / (msda_us * 1e-6) / 30.5e12, 3)
                                                    if pmc.get("l1_gather_bytes") else None)},
@@ -627,15 +692,11 @@ def main():
         rel_entry["arithmetic"] = "fp32 via bf16x6 operand split, fp32 accumulate"
         rel_entry["bf16_mfma_flops_executed"] = executed
         rel_entry["frac_of_bf16_dense_peak"] = round(executed / (rel_us * 1e-6) / 1e12 / 2500.0, 4)
-    rpath = os.path.join(ROOT, "profiles", "r02_rel_head_pmc.json")   # same provenance as the MSDA counters above
-    if os.path.exists(rpath):
-        try:
-            rp = json.load(open(rpath))
-            if rp.get("kernel") == rel_entry["kernel"]:
-                rel_entry["traffic"] = rp.get("hbm_bytes_per_launch")
-                rel_entry["l2_hit"] = rp.get("l2_hit")
-        except Exception:
-            pass
+    rp, rp_src = newest_pmc("r*_rel_head_pmc.json", rel_entry["kernel"])   # same provenance as the MSDA counters above
+    if rp:
+        rel_entry["traffic"] = rp.get("hbm_bytes_per_launch")
+        rel_entry["l2_hit"] = rp.get("l2_hit")
+        rel_entry["traffic_source"] = rp_src
     result["roofline_kernels"] = [result["roofline"], rel_entry]
     if _ops.GEMM_SPLIT_BF16:
         g_us, g_flops = time_split_gemm(dev)
@@ -665,6 +726,25 @@ def main():
                                   "sample": f"{nimg} images after 1 warm-up, same 600x1000 / N=200 "
                                             "workload incl. ResNet-50, oracle = reference's pure-PyTorch "
                                             "grid_sample MSDA fallback semantics, torch CPU threads = cores"}
+    if rank == 0 and world == 1 and args.extras:
+        # The reference's other two workloads, driver-visible in the SAME line (bounded: a few steps each): the train step
+        # (train_egtr.py:303-319, 770-779; BASELINE configs[2] shape on this GPU) and the stress shape (configs[4]).
+        del fwd, out
+        torch.cuda.empty_cache()
+        import copy
+        targs = copy.copy(args)
+        targs.mode, targs.batch, targs.steps, targs.warmup = "train", 4, args.extra_steps, max(3, args.extra_steps // 2)
+        targs.no_cpu_baseline, targs.no_kernel_probes = True, False
+        torch.backends.cudnn.benchmark = False      # MIOpen find mode: no gain for the train step
+        try:
+            result["train_step"] = train_bench(targs, 1, 0, dev, None, emit=False)
+        except Exception as e:  # the headline stays valid; the failure is visible
+            result["train_step"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+        try:
+            result["stress_bf16"] = stress_bench(dev, steps=args.extra_steps, warmup=3)
+        except Exception as e:
+            result["stress_bf16"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -11,7 +11,7 @@ grep -E '^\{"metric"' gpurun_out/${tag}_bench_rocprofv3.log > gpurun_out/${tag}_
 python tools/rocpd_stats.py gpurun_out/prof_bench/bench_results.db --top 60 --split-grid msda_fwd_q64:1000 --csv gpurun_out/${tag}_bench_kernel_stats.csv > gpurun_out/${tag}_bench_kernel_stats.txt 2>&1
 rm -rf gpurun_out/prof_bench
 # one graph-replayed forward split into stages (no CPU baseline / parity pass in the trace)
-timeout 600 rocprofv3 --kernel-trace -d gpurun_out/prof_fb -o fb -- python bench.py --no-cpu-baseline --steps 20 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace -d gpurun_out/prof_fb -o fb -- python bench.py --no-cpu-baseline --extras 0 --steps 20 > /dev/null 2>&1
 python tools/forward_breakdown.py gpurun_out/prof_fb/fb_results.db 14 > gpurun_out/${tag}_forward_breakdown.txt 2>&1
 rm -rf gpurun_out/prof_fb
 timeout 900 rocprofv3 --kernel-trace -d gpurun_out/prof_train -o train -- python bench.py --mode train --steps 8 --warmup 6 --no-cpu-baseline --no-kernel-probes > gpurun_out/${tag}_train_rocprofv3.log 2>&1
