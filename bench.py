@@ -582,6 +582,8 @@ def main():
         raise SystemExit(launch_ranks(args.gpus))  # nothing above this line touches the GPU
     if args.launch_check:
         return launch_check(args)
+    from egtr_amd.runtime import private_miopen_db
+    private_miopen_db()   # N ranks: one MIOpen user database / kernel cache directory per rank (no-op for one rank)
     if args.miopen_find == 1 or (args.miopen_find < 0 and args.mode == "infer"):
         from egtr_amd.runtime import enable_conv_tuning
         enable_conv_tuning()

@@ -132,7 +132,7 @@ class DataParallelTrainer:
     once per optimizer step -- micro-steps before the accumulation boundary run under ``no_sync`` -- then
     clip-grad-norm 0.1 and AdamW.  ``num_boxes`` stays per-rank (model/egtr.py:976-980)."""
 
-    def __init__(self, model, optimizer=None, accumulate=2, clip=0.1, bucket_cap_mb=25, graph=False):
+    def __init__(self, model, optimizer=None, accumulate=2, clip=0.1, bucket_cap_mb=25, graph=False, force_ddp=False):
         """graph=True (single process, GPU, fixed image size): the static-shape part of the step -- backbone, encoder,
         decoder, detection + relation heads, forward AND backward -- is captured once into two HIP graphs
         (torch.cuda.make_graphed_callables over ``model.forward_tensors``) and replayed; the Hungarian matcher and the
@@ -143,7 +143,9 @@ class DataParallelTrainer:
         self._graph_wanted = bool(graph) and self.world == 1
         self._graphed = None
         self._graph_key = None
-        if self.world > 1:
+        # force_ddp: wrap even in a one-rank process group, so that DDP's reducer (bucket hooks on the autograd Functions
+        # that launch through the C ABI, gradient_as_bucket_view) can be exercised on a single-GPU box
+        if self.world > 1 or (force_ddp and dist.is_initialized()):
             ids = [torch.cuda.current_device()] if next(model.parameters()).is_cuda else None
             self.model = torch.nn.parallel.DistributedDataParallel(
                 model, device_ids=ids, find_unused_parameters=False, bucket_cap_mb=bucket_cap_mb,
@@ -197,7 +199,8 @@ class DataParallelTrainer:
         DeformableDetrHungarianMatcher.raise_if_invalid()
         self._micro += 1
         boundary = self._micro % self.accumulate == 0
-        ctx = contextlib.nullcontext() if (boundary or self.world == 1) else self.model.no_sync()
+        wrapped = self.model is not self.raw
+        ctx = contextlib.nullcontext() if (boundary or not wrapped) else self.model.no_sync()
         with ctx:
             loss, loss_dict = self.common_step(batch)
             (loss / self.accumulate).backward()
@@ -222,7 +225,9 @@ def enable_gemm_tuning(results_file=None):
     tunable.enable(True)
     tunable.tuning_enable(True)
     if results_file is None:
-        results_file = os.path.join(tempfile.gettempdir(), f"egtr_tunableop_{os.getpid()}.csv")
+        # one results file per PROCESS (= per rank): eight ranks tuning concurrently must not share a csv
+        results_file = os.path.join(tempfile.gettempdir(),
+                                    f"egtr_tunableop_r{os.environ.get('RANK', '0')}_{os.getpid()}.csv")
     tunable.set_filename(results_file, insert_device_ordinal=True)
     return True
 
@@ -232,8 +237,21 @@ def enable_conv_tuning():
     solver that measures fastest the first time it is seen, instead of the heuristic choice (ResNet-50 at 600x1000, fp32
     inference: 250 -> 261 images/s end to end).  Call before the first forward; shapes must have been seen eagerly
     before a HIP-graph capture.  No effect on the train step."""
+    private_miopen_db()
     torch.backends.cudnn.benchmark = True
     return True
+
+
+def private_miopen_db():
+    """Multi-rank runs: give every rank its own MIOpen user database directory (find mode WRITES the tuned solvers
+    there; eight ranks appending to one sqlite file race).  Must run before the first convolution; no-op for one rank
+    or when the user already chose a path."""
+    import tempfile
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "MIOPEN_USER_DB_PATH" not in os.environ:
+        d = os.path.join(tempfile.gettempdir(), f"egtr_miopen_r{os.environ.get('RANK', '0')}")
+        os.makedirs(d, exist_ok=True)
+        os.environ["MIOPEN_USER_DB_PATH"] = d
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", d)
 
 
 @torch.no_grad()
