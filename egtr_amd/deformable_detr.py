@@ -1265,3 +1265,241 @@ class DeformableDetrHungarianMatcher(nn.Module):
     @torch.no_grad()
     def forward(self, outputs, targets):
         return self.finish(self.prepare(outputs, targets))
+
+
+# ------------------------------------------------------------------------------------------ detection heads
+def detection_heads(config, class_embed, bbox_embed, hidden_states, init_reference, inter_references):
+    """Class logits and boxes of every decoder level (dd:2530-2557 == egtr:283-305): ``logits_l = class_embed[l](h_l)``,
+    ``box_l = sigmoid(bbox_embed[l](h_l) + [inverse_sigmoid(reference_l), 0, 0])`` with reference_0 = the initial
+    reference points and reference_l = the decoder's intermediate ones.  hidden_states [B, Ld, N, d] ->
+    (outputs_class [B, Ld, N, C], outputs_coord [B, Ld, N, 4])."""
+    if not config.with_box_refine:
+        # class_embed / bbox_embed alias ONE module for every level (dd:2439-2446): apply them once to the stacked
+        # [B, Ld, N, d] states instead of Ld times (same arithmetic per row)
+        box_layers = bbox_embed[0].layers
+        fast = (ops.inference_fast_path(hidden_states)
+                and hidden_states.numel() // hidden_states.shape[-1] <= ops.SKINNY_MAX_ROWS)
+        if fast:
+            # class logits and the first box-MLP layer read the same rows: one grouped launch
+            outputs_class, delta_bbox = ops.linear_grouped([
+                dict(x=hidden_states, w=class_embed[0].weight, b=class_embed[0].bias),
+                dict(x=hidden_states, w=box_layers[0].weight, b=box_layers[0].bias, relu=len(box_layers) > 1)])
+            for i, layer in enumerate(box_layers[1:], 1):
+                delta_bbox = ops.module_linear(layer, delta_bbox, relu=i < len(box_layers) - 1)
+        else:
+            outputs_class = ops.module_linear(class_embed[0], hidden_states)
+            delta_bbox = bbox_embed[0](hidden_states)
+        if fast and init_reference.shape[-1] in (2, 4):
+            return outputs_class, ops.box_decode(delta_bbox, init_reference, inter_references)
+        refs = torch.cat([init_reference[:, None], inter_references[:, :-1]], 1)
+        if refs.shape[-1] == 4:
+            outputs_coord = (delta_bbox + inverse_sigmoid(refs)).sigmoid()
+        elif refs.shape[-1] == 2:
+            outputs_coord = torch.cat([delta_bbox[..., :2] + inverse_sigmoid(refs), delta_bbox[..., 2:]], -1).sigmoid()
+        else:
+            raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {refs.shape[-1]}")
+        return outputs_class, outputs_coord
+    outputs_classes, outputs_coords = [], []
+    for level in range(hidden_states.shape[1]):
+        reference = init_reference if level == 0 else inter_references[:, level - 1]
+        reference = inverse_sigmoid(reference)
+        outputs_class = ops.module_linear(class_embed[level], hidden_states[:, level])
+        delta_bbox = bbox_embed[level](hidden_states[:, level])
+        if reference.shape[-1] == 4:
+            outputs_coord_logits = delta_bbox + reference
+        elif reference.shape[-1] == 2:
+            outputs_coord_logits = torch.cat([delta_bbox[..., :2] + reference, delta_bbox[..., 2:]], -1)
+        else:
+            raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {reference.shape[-1]}")
+        outputs_classes.append(outputs_class)
+        outputs_coords.append(outputs_coord_logits.sigmoid())
+    return torch.stack(outputs_classes, dim=1), torch.stack(outputs_coords, dim=1)
+
+
+class DeformableDetrLoss(nn.Module):
+    """Criterion of DeformableDetrForObjectDetection (dd:2650-2861): Hungarian assignment, sigmoid focal classification
+    loss, L1 + generalised-IoU box losses, the cardinality error; repeated per auxiliary output set.  On GPU tensors the
+    three losses of an output set are ONE HIP launch with their gradients (``ops.detection_losses``, csrc/loss.hip) and the
+    assignment runs on the device (csrc/matcher.hip); CPU tensors take the reference's composition."""
+
+    def __init__(self, matcher, num_classes, eos_coef, losses, focal_alpha=0.25):
+        super().__init__()
+        self.matcher = matcher
+        self.num_classes = num_classes
+        self.losses = losses
+        self.focal_alpha = focal_alpha
+
+    def loss_labels(self, outputs, targets, indices, num_boxes, log=True):
+        if "logits" not in outputs:
+            raise ValueError("No logits were found in the outputs")
+        source_logits = outputs["logits"]
+        idx = self._get_source_permutation_idx(indices)
+        target_classes_o = torch.cat([t["class_labels"][J] for t, (_, J) in zip(targets, indices)])
+        target_classes = torch.full(source_logits.shape[:2], self.num_classes, dtype=torch.int64,
+                                    device=source_logits.device)
+        target_classes[idx] = target_classes_o.to(source_logits.device)
+        onehot = torch.zeros([source_logits.shape[0], source_logits.shape[1], source_logits.shape[2] + 1],
+                             dtype=source_logits.dtype, layout=source_logits.layout, device=source_logits.device)
+        onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
+        loss_ce = sigmoid_focal_loss(source_logits, onehot[:, :, :-1], num_boxes, alpha=self.focal_alpha,
+                                     gamma=2) * source_logits.shape[1]
+        return {"loss_ce": loss_ce}
+
+    @torch.no_grad()
+    def loss_cardinality(self, outputs, targets, indices, num_boxes):
+        logits = outputs["logits"]
+        target_lengths = torch.as_tensor([len(v["class_labels"]) for v in targets], device=logits.device)
+        card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
+        return {"cardinality_error": F.l1_loss(card_pred.float(), target_lengths.float())}
+
+    def loss_boxes(self, outputs, targets, indices, num_boxes):
+        if "pred_boxes" not in outputs:
+            raise ValueError("No predicted boxes found in outputs")
+        idx = self._get_source_permutation_idx(indices)
+        source_boxes = outputs["pred_boxes"][idx]
+        target_boxes = torch.cat([t["boxes"][i] for t, (_, i) in zip(targets, indices)], dim=0)
+        losses = {"loss_bbox": F.l1_loss(source_boxes, target_boxes, reduction="none").sum() / num_boxes}
+        loss_giou = 1 - torch.diag(generalized_box_iou(center_to_corners_format(source_boxes),
+                                                       center_to_corners_format(target_boxes)))
+        losses["loss_giou"] = loss_giou.sum() / num_boxes
+        return losses
+
+    def _get_source_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(source, i) for i, (source, _) in enumerate(indices)])
+        source_idx = torch.cat([source for (source, _) in indices])
+        return batch_idx, source_idx
+
+    def _get_target_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(target, i) for i, (_, target) in enumerate(indices)])
+        target_idx = torch.cat([target for (_, target) in indices])
+        return batch_idx, target_idx
+
+    def get_loss(self, loss, outputs, targets, indices, num_boxes):
+        loss_map = {"labels": self.loss_labels, "cardinality": self.loss_cardinality, "boxes": self.loss_boxes}
+        if loss not in loss_map:
+            raise ValueError(f"Loss {loss} not supported")
+        return loss_map[loss](outputs, targets, indices, num_boxes)
+
+    def _set_losses(self, out, targets, num_boxes, suffix, packed):
+        indices, _ = self.matcher(out, targets)
+        lg = out["logits"]
+        fused = (all(k in self.losses for k in ("labels", "cardinality", "boxes"))
+                 and getattr(indices, "flat", None) is not None and lg.is_cuda and lg.dtype == torch.float32
+                 and out["pred_boxes"].dtype == torch.float32 and lg.shape[1] <= 2048)
+        losses = {}
+        if fused:
+            if packed[0] is None:
+                packed[0] = ops.pack_detection_targets(targets, lg.device)
+            d = ops.detection_losses(lg, out["pred_boxes"], indices.flat, packed[0], self.focal_alpha, num_boxes)
+            d["loss_ce"] = indices.poison(d["loss_ce"])   # a cost matrix the device matcher refused: NaN, not garbage
+            losses.update({k + suffix: v for k, v in d.items()})
+        for loss in self.losses:
+            if fused and loss in ("labels", "cardinality", "boxes"):
+                continue
+            losses.update({k + suffix: v for k, v in self.get_loss(loss, out, targets, indices, num_boxes).items()})
+        return losses
+
+    def forward(self, outputs, targets):
+        outputs_without_aux = {k: v for k, v in outputs.items() if k not in ("auxiliary_outputs", "enc_outputs")}
+        # per-rank normalisation: the reference's all-reduce of num_boxes is commented out (dd:2822-2826)
+        num_boxes = float(max(sum(len(t["class_labels"]) for t in targets), 1))
+        packed = [None]
+        losses = self._set_losses(outputs_without_aux, targets, num_boxes, "", packed)
+        if "auxiliary_outputs" in outputs:
+            for i, auxiliary_outputs in enumerate(outputs["auxiliary_outputs"]):
+                losses.update(self._set_losses(auxiliary_outputs, targets, num_boxes, f"_{i}", packed))
+        if "enc_outputs" in outputs:   # two-stage proposals: class-agnostic targets (dd:2847-2858)
+            bin_targets = copy.deepcopy(targets)
+            for bt in bin_targets:
+                bt["class_labels"] = torch.zeros_like(bt["class_labels"])
+            losses.update(self._set_losses(outputs["enc_outputs"], bin_targets, num_boxes, "_enc", [None]))
+        return losses
+
+
+class DeformableDetrForObjectDetection(DeformableDetrPreTrainedModel):
+    """Deformable DETR with detection heads only (dd:2400-2647) -- what pretrain_detr.py:21-26, 60-75 trains before the
+    relation head is added.  Same parameters, forward signature and outputs as the reference class; the hot path is the
+    shared ``DeformableDetrModel`` (HIP MSDA / self-attention / fused epilogues) plus ``detection_heads``."""
+
+    def __init__(self, config: DeformableDetrConfig):
+        super().__init__(config)
+        self.model = DeformableDetrModel(config)
+        self.class_embed = nn.Linear(config.d_model, config.num_labels)
+        self.bbox_embed = DeformableDetrMLPPredictionHead(input_dim=config.d_model, hidden_dim=config.d_model,
+                                                          output_dim=4, num_layers=3)
+        prior_prob = 0.01
+        bias_value = -math.log((1 - prior_prob) / prior_prob)
+        self.class_embed.bias.data = torch.ones(config.num_labels) * bias_value
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        if config.two_stage:
+            raise NotImplementedError("the two-stage Deformable-DETR variant is outside the EGTR path (DESIGN.md 6)")
+        num_pred = config.decoder_layers
+        if config.with_box_refine:
+            self.class_embed = _get_clones(self.class_embed, num_pred)
+            self.bbox_embed = _get_clones(self.bbox_embed, num_pred)
+            nn.init.constant_(self.bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            self.model.decoder.bbox_embed = self.bbox_embed   # iterative bounding box refinement
+        else:
+            nn.init.constant_(self.bbox_embed.layers[-1].bias.data[2:], -2.0)
+            self.class_embed = nn.ModuleList([self.class_embed for _ in range(num_pred)])
+            self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(num_pred)])
+            self.model.decoder.bbox_embed = None
+        self.post_init()
+
+    @torch.jit.unused
+    def _set_aux_loss(self, outputs_class, outputs_coord):
+        return [{"logits": a, "pred_boxes": b} for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
+
+    def forward(self, pixel_values, pixel_mask=None, decoder_attention_mask=None, encoder_outputs=None,
+                inputs_embeds=None, decoder_inputs_embeds=None, labels=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None):
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        outputs = self.model(pixel_values, pixel_mask=pixel_mask, decoder_attention_mask=decoder_attention_mask,
+                             encoder_outputs=encoder_outputs, inputs_embeds=inputs_embeds,
+                             decoder_inputs_embeds=decoder_inputs_embeds, output_attentions=output_attentions,
+                             output_hidden_states=output_hidden_states, return_dict=True)
+        outputs_class, outputs_coord = detection_heads(
+            self.config, self.class_embed, self.bbox_embed, outputs.intermediate_hidden_states,
+            outputs.init_reference_points, outputs.intermediate_reference_points)
+        logits = outputs_class[:, -1]
+        pred_boxes = outputs_coord[:, -1]
+
+        loss, loss_dict, auxiliary_outputs = None, None, None
+        if labels is not None:
+            matcher = DeformableDetrHungarianMatcher(class_cost=self.config.ce_loss_coefficient,
+                                                     bbox_cost=self.config.bbox_cost, giou_cost=self.config.giou_cost)
+            criterion = DeformableDetrLoss(matcher=matcher, num_classes=self.config.num_labels,
+                                           eos_coef=self.config.eos_coefficient, focal_alpha=self.config.focal_alpha,
+                                           losses=["labels", "boxes", "cardinality"])
+            criterion.to(logits.device)
+            outputs_loss = {"logits": logits, "pred_boxes": pred_boxes}
+            if self.config.auxiliary_loss:
+                auxiliary_outputs = self._set_aux_loss(outputs_class.permute(1, 0, 2, 3),
+                                                       outputs_coord.permute(1, 0, 2, 3))
+                outputs_loss["auxiliary_outputs"] = auxiliary_outputs
+            loss_dict = criterion(outputs_loss, labels)
+            weight_dict = {"loss_ce": self.config.ce_loss_coefficient, "loss_bbox": self.config.bbox_loss_coefficient,
+                           "loss_giou": self.config.giou_loss_coefficient}
+            if self.config.auxiliary_loss:
+                aux = {}
+                for i in range(self.config.decoder_layers - 1):
+                    aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
+                weight_dict.update(aux)
+            loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+
+        if not return_dict:
+            output = (logits, pred_boxes) + (tuple(auxiliary_outputs) if auxiliary_outputs is not None else ()) \
+                + outputs.to_tuple()
+            return ((loss, loss_dict) + output) if loss is not None else output
+        return DeformableDetrObjectDetectionOutput(
+            loss=loss, loss_dict=loss_dict, logits=logits, pred_boxes=pred_boxes, auxiliary_outputs=auxiliary_outputs,
+            last_hidden_state=outputs.last_hidden_state, decoder_hidden_states=outputs.decoder_hidden_states,
+            decoder_attentions=outputs.decoder_attentions, cross_attentions=outputs.cross_attentions,
+            encoder_last_hidden_state=outputs.encoder_last_hidden_state,
+            encoder_hidden_states=outputs.encoder_hidden_states, encoder_attentions=outputs.encoder_attentions,
+            intermediate_hidden_states=outputs.intermediate_hidden_states,
+            init_reference_points=outputs.init_reference_points,
+            intermediate_reference_points=outputs.intermediate_reference_points,
+            enc_outputs_class=getattr(outputs, "enc_outputs_class", None),
+            enc_outputs_coord_logits=getattr(outputs, "enc_outputs_coord_logits", None))

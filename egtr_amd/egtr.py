@@ -18,7 +18,7 @@ from torch import nn
 
 from . import ops
 from .deformable_detr import (DeformableDetrHungarianMatcher, DeformableDetrMLPPredictionHead, DeformableDetrModel,
-                              MatchedIndices,
+                              MatchedIndices, detection_heads,
                               DeformableDetrPreTrainedModel, inverse_sigmoid)
 from .hf_compat import ModelOutput
 from .util import (center_to_corners_format, dice_loss, generalized_box_iou, nested_tensor_from_tensor_list,
@@ -189,53 +189,8 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         init_reference = outputs.init_reference_points
         inter_references = outputs.intermediate_reference_points
 
-        if not self.config.with_box_refine:
-            # class_embed / bbox_embed alias ONE module for every level (egtr:152-158): apply them once to the stacked
-            # [B, Ld, N, d] states instead of Ld times (same arithmetic per row as egtr:286-305)
-            box_layers = self.bbox_embed[0].layers
-            fast = (ops.inference_fast_path(hidden_states)
-                    and hidden_states.numel() // hidden_states.shape[-1] <= ops.SKINNY_MAX_ROWS)
-            if fast:
-                # class logits and the first box-MLP layer read the same rows: one grouped launch
-                outputs_class, delta_bbox = ops.linear_grouped([
-                    dict(x=hidden_states, w=self.class_embed[0].weight, b=self.class_embed[0].bias),
-                    dict(x=hidden_states, w=box_layers[0].weight, b=box_layers[0].bias, relu=len(box_layers) > 1)])
-                for i, layer in enumerate(box_layers[1:], 1):
-                    delta_bbox = ops.module_linear(layer, delta_bbox, relu=i < len(box_layers) - 1)
-            else:
-                outputs_class = ops.module_linear(self.class_embed[0], hidden_states)
-                delta_bbox = self.bbox_embed[0](hidden_states)
-            if fast and init_reference.shape[-1] in (2, 4):
-                outputs_coord = ops.box_decode(delta_bbox, init_reference, inter_references)
-                refs = None
-            else:
-                refs = torch.cat([init_reference[:, None], inter_references[:, :-1]], 1)
-            if refs is None:
-                pass
-            elif refs.shape[-1] == 4:
-                outputs_coord = (delta_bbox + inverse_sigmoid(refs)).sigmoid()
-            elif refs.shape[-1] == 2:
-                outputs_coord = torch.cat([delta_bbox[..., :2] + inverse_sigmoid(refs), delta_bbox[..., 2:]],
-                                          -1).sigmoid()
-            else:
-                raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {refs.shape[-1]}")
-        else:
-            outputs_classes, outputs_coords = [], []
-            for level in range(hidden_states.shape[1]):  # egtr:286-305
-                reference = init_reference if level == 0 else inter_references[:, level - 1]
-                reference = inverse_sigmoid(reference)
-                outputs_class = ops.module_linear(self.class_embed[level], hidden_states[:, level])
-                delta_bbox = self.bbox_embed[level](hidden_states[:, level])
-                if reference.shape[-1] == 4:
-                    outputs_coord_logits = delta_bbox + reference
-                elif reference.shape[-1] == 2:
-                    outputs_coord_logits = torch.cat([delta_bbox[..., :2] + reference, delta_bbox[..., 2:]], -1)
-                else:
-                    raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {reference.shape[-1]}")
-                outputs_classes.append(outputs_class)
-                outputs_coords.append(outputs_coord_logits.sigmoid())
-            outputs_class = torch.stack(outputs_classes, dim=1)
-            outputs_coord = torch.stack(outputs_coords, dim=1)
+        outputs_class, outputs_coord = detection_heads(self.config, self.class_embed, self.bbox_embed, hidden_states,
+                                                       init_reference, inter_references)
         logits = outputs_class[:, -1]
         pred_boxes = outputs_coord[:, -1]
         if self.config.auxiliary_loss:

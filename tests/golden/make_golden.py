@@ -19,6 +19,8 @@ Fixtures:
   sgg_stress.npz  800x1333, N=300, Le=6, Ld=8, C=150, R=50 (BASELINE config 5 geometry), 2 images (one padded), stub
                   backbone, fp32 -- and the same model with weights / pixels rounded to bf16 (fp32 arithmetic): the
                   reference point for the bf16 product model.
+  det_small.npz   DeformableDetrForObjectDetection + DeformableDetrLoss (dd:2400-2861), stub backbone, auxiliary losses,
+                  plain and with_box_refine heads: outputs, loss dict, gradient norms.
   sgg_full_train.npz  600x1000, N=200, Le=Ld=6, bs=2, auxiliary losses ON, train mode (dropout 0): the reference's
                   loss dict, total loss and gradient norms of a few parameters.
 """
@@ -344,8 +346,53 @@ def gen_sgg_full_train():
     print("sgg_full_train.npz", float(out.loss), sorted(gn)[:3], len(gn))
 
 
+def gen_det_small():
+    """DeformableDetrForObjectDetection + DeformableDetrLoss (dd:2400-2861; what pretrain_detr.py trains): stub backbone,
+    2 images (one padded), N = 24, Le = 2, Ld = 3, auxiliary losses ON -- plain heads and with_box_refine=True.
+    Outputs, loss dict, total loss, every gradient norm, two full gradients."""
+    res = {}
+    for tag, over, seed in (("plain", dict(auxiliary_loss=True), 81), ("refine", dict(auxiliary_loss=True,
+                                                                                     with_box_refine=True), 85)):
+        cfg, cfg_dict = ref_config(**over)
+        cfg.output_attention_states = False          # pretrain_detr.py:70
+        cfg_dict["output_attention_states"] = False
+        torch.manual_seed(0)
+        model = dd.DeformableDetrForObjectDetection(cfg)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = W.fill_state_dict(shapes, seed=seed, alias_heads=not over.get("with_box_refine", False))
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        rng = W.rng_inputs(seed + 1)
+        B, H, Wd = 2, 96, 128
+        pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+        pm = torch.ones(B, H, Wd, dtype=torch.long)
+        pm[1, 80:, :] = 0
+        pm[1, :, 104:] = 0
+        pv[1] = pv[1] * pm[1][None].float()
+        targets = [{k: v for k, v in t.items() if k != "rel"}
+                   for t in W.make_targets(seed + 2, B, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+        model.eval()
+        with torch.no_grad():
+            out = model(pixel_values=pv, pixel_mask=pm)
+        model.train()
+        model.zero_grad()
+        out_t = model(pixel_values=pv, pixel_mask=pm, labels=targets)
+        out_t.loss.backward()
+        res.update({f"{tag}_cfg": json.dumps(cfg_dict), f"{tag}_shapes": json.dumps(shapes), f"{tag}_seed": seed,
+                    f"{tag}_logits": np_(out.logits), f"{tag}_pred_boxes": np_(out.pred_boxes),
+                    f"{tag}_train_loss": np_(out_t.loss),
+                    f"{tag}_train_loss_dict": json.dumps({k: float(v) for k, v in out_t.loss_dict.items()}),
+                    f"{tag}_grad_norms": json.dumps({n: float(p.grad.norm()) for n, p in model.named_parameters()
+                                                     if p.grad is not None})})
+        for n in ("class_embed.0.bias", "model.reference_points.weight"):
+            res[f"{tag}_grad::" + n] = np_(dict(model.named_parameters())[n].grad)
+        print("det_small", tag, float(out_t.loss), len(out_t.loss_dict))
+    res.update(H=96, W=128, valid1=np.array([80, 104]))
+    np.savez_compressed(os.path.join(HERE, "det_small.npz"), **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["msda", "mha", "small", "refine", "full", "cfg0", "oi", "stress", "full_train"]
+    which = sys.argv[1:] or ["msda", "mha", "small", "refine", "full", "cfg0", "oi", "stress", "full_train", "det"]
     torch.set_num_threads(8)
     if "msda" in which:
         gen_msda()
@@ -365,3 +412,5 @@ if __name__ == "__main__":
         gen_sgg_stress()
     if "full_train" in which:
         gen_sgg_full_train()
+    if "det" in which:
+        gen_det_small()

@@ -111,3 +111,30 @@ def check_pred_entry(got, g, j, atol=1e-6):
         elif not last:
             assert set(map(tuple, gi[a:b])) == set(map(tuple, want_inds[a:b])), (a, b)
     return n_exact
+
+
+def build_product_detector(cfg_dict, shapes, seed, device="cpu"):
+    """Product DeformableDetrForObjectDetection with the det_small fixture's seeded weights (stub backbone)."""
+    import egtr_amd.deformable_detr as pdd
+    import _ref_import
+    cfg = product_config(cfg_dict)
+    orig = pdd.DeformableDetrTimmConvEncoder
+    pdd.DeformableDetrTimmConvEncoder = _ref_import.make_stub_backbone_class()
+    try:
+        model = pdd.DeformableDetrForObjectDetection(cfg)
+    finally:
+        pdd.DeformableDetrTimmConvEncoder = orig
+    sd = W.fill_state_dict(shapes, seed=seed, alias_heads=not cfg_dict.get("with_box_refine", False))
+    return model, cfg, sd
+
+
+def det_inputs(g, seed):
+    rng = W.rng_inputs(seed + 1)
+    B, H, Wd = 2, int(g["H"]), int(g["W"])
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    vh, vw = [int(v) for v in g["valid1"]]
+    pm[1, vh:, :] = 0
+    pm[1, :, vw:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    return pv, pm

@@ -612,3 +612,36 @@ def test_bottleneck_training_fused_epilogue_matches_reference_order(downsample, 
             bb.TRAIN_FUSED_EPILOGUE = True
     for a, b in zip(*outs):
         assert (a - b).abs().max() <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["plain", "refine"])
+def test_object_detection_model_vs_reference(golden_dir, tag):
+    """DeformableDetrForObjectDetection + DeformableDetrLoss (dd:2400-2861, pretrain_detr.py:21-26) on the HIP path
+    against the reference's own run (det_small.npz): outputs 1e-3 (north-star bar), loss dict incl. the auxiliary sets
+    (device matcher + one-launch detection losses), every gradient norm."""
+    g = Hh.load_golden(golden_dir, "det_small.npz")
+    cfg_dict, shapes = json.loads(str(g[f"{tag}_cfg"])), json.loads(str(g[f"{tag}_shapes"]))
+    seed = int(g[f"{tag}_seed"])
+    model, cfg, sd = Hh.build_product_detector(cfg_dict, shapes, seed)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV).eval()
+    pv, pm = Hh.det_inputs(g, seed)
+    pv, pm = pv.to(DEV), pm.to(DEV)
+    with torch.no_grad():
+        out = model(pixel_values=pv, pixel_mask=pm)
+    assert (out.logits.cpu() - _t(g[f"{tag}_logits"])).abs().max() < 1e-3
+    assert (out.pred_boxes.cpu() - _t(g[f"{tag}_pred_boxes"])).abs().max() < 1e-3
+    targets = [{k: v.to(DEV) for k, v in t.items() if k != "rel"}
+               for t in W.make_targets(seed + 2, 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+    model.train()
+    out_t = model(pixel_values=pv, pixel_mask=pm, labels=targets)
+    ref = json.loads(str(g[f"{tag}_train_loss_dict"]))
+    assert set(ref) == set(out_t.loss_dict)
+    for k, v in ref.items():
+        assert abs(float(out_t.loss_dict[k]) - v) < 1e-3 * max(1.0, abs(v)), (k, float(out_t.loss_dict[k]), v)
+    assert abs(float(out_t.loss) - float(g[f"{tag}_train_loss"])) < 1e-3 * abs(float(g[f"{tag}_train_loss"]))
+    out_t.loss.backward()
+    params = dict(model.named_parameters())
+    for n, v in json.loads(str(g[f"{tag}_grad_norms"])).items():
+        got = float(params[n].grad.norm())
+        assert abs(got - v) < 5e-3 * max(abs(v), 1e-2), (n, got, v)

@@ -327,3 +327,43 @@ def test_from_pretrained_reports_key_mismatches(tmp_path):
     assert info["missing_keys"] == ["lin.bias"] and info["unexpected_keys"] == ["extra"]
     assert any("missing" in str(x.message) for x in w)
     assert float(m.lin.weight.sum()) == 16.0
+
+
+@pytest.mark.parametrize("tag", ["plain", "refine"])
+def test_object_detection_model_matches_reference(golden_dir, cpu_kernels, tag):
+    """DeformableDetrForObjectDetection + DeformableDetrLoss (dd:2400-2861; imported by pretrain_detr.py:21-26) against
+    the reference's own run (tests/golden/det_small.npz): state-dict contract, outputs, loss dict with auxiliary losses,
+    every gradient norm.  HIP ops replaced by the oracle stand-ins: host logic only (GPU: tests/test_gpu_model.py)."""
+    import weights as W
+    from model.deformable_detr import DeformableDetrForObjectDetection  # the reference's import path
+    g = Hh.load_golden(golden_dir, "det_small.npz")
+    cfg_dict, shapes = json.loads(str(g[f"{tag}_cfg"])), json.loads(str(g[f"{tag}_shapes"]))
+    seed = int(g[f"{tag}_seed"])
+    model, cfg, sd = Hh.build_product_detector(cfg_dict, shapes, seed)
+    assert isinstance(model, DeformableDetrForObjectDetection)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    model.load_state_dict(sd, strict=True)
+    pv, pm = Hh.det_inputs(g, seed)
+    model.eval()
+    with torch.no_grad():
+        out = model(pixel_values=pv, pixel_mask=pm)
+    assert (out.logits - _t(g[f"{tag}_logits"])).abs().max() < 2e-4
+    assert (out.pred_boxes - _t(g[f"{tag}_pred_boxes"])).abs().max() < 2e-4
+    assert out.loss is None and out.auxiliary_outputs is None
+    targets = [{k: v for k, v in t.items() if k != "rel"}
+               for t in W.make_targets(seed + 2, 2, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+    model.train()
+    out_t = model(pixel_values=pv, pixel_mask=pm, labels=targets)
+    ref = json.loads(str(g[f"{tag}_train_loss_dict"]))
+    assert set(ref) == set(out_t.loss_dict)
+    for k, v in ref.items():
+        assert abs(float(out_t.loss_dict[k]) - v) < 3e-4 * max(1.0, abs(v)), (k, float(out_t.loss_dict[k]), v)
+    assert abs(float(out_t.loss) - float(g[f"{tag}_train_loss"])) < 3e-4 * abs(float(g[f"{tag}_train_loss"]))
+    assert len(out_t.auxiliary_outputs) == cfg.decoder_layers - 1
+    out_t.loss.backward()
+    params = dict(model.named_parameters())
+    for n, v in json.loads(str(g[f"{tag}_grad_norms"])).items():
+        got = float(params[n].grad.norm())
+        assert abs(got - v) < 2e-3 * max(abs(v), 1e-2), (n, got, v)
+    for n in ("class_embed.0.bias", "model.reference_points.weight"):
+        assert (params[n].grad - _t(g[f"{tag}_grad::" + n])).abs().max() < 1e-3 * max(1.0, float(np.abs(g[f"{tag}_grad::" + n]).max()))
