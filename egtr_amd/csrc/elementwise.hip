@@ -1090,3 +1090,37 @@ extern "C" int egtr_weighted_column_sum_f32(egtr_stream_t stream, const float* g
   hipLaunchKernelGGL(colsum_final_f32, dim3((N + 15) / 16), dim3(256), 0, st, workspace, chunks, N, out);
   return egtr_check_launch();
 }
+
+// ---- pad_and_create_pixel_mask on the device (DeformableDetrFeatureExtractor, reference preprocessing at
+// model/deformable_detr.py:270-385 via HF's DetrFeatureExtractor.pad_and_create_pixel_mask): B images [C, h_b, w_b] ->
+// zero-padded batch [B, C, H, W] (top-left aligned) + int64 mask [B, H, W] (1 = real pixel), ONE launch.
+namespace {
+__global__ __launch_bounds__(256) void pad_batch_f32(const float* const* __restrict__ imgs, const int* __restrict__ hw,
+                                                     int B, int C, int H, int W, float* __restrict__ out,
+                                                     long long* __restrict__ mask) {
+  const long long row = blockIdx.x;                 // (b, c, y), plus one extra "channel" per image for the mask rows
+  const int y = (int)(row % H);
+  const int c = (int)((row / H) % (C + 1));
+  const int b = (int)(row / ((long long)H * (C + 1)));
+  const int h = hw[2 * b], w = hw[2 * b + 1];
+  if (c == C) {
+    long long* m = mask + ((size_t)b * H + y) * W;
+    for (int x = threadIdx.x; x < W; x += 256) m[x] = (y < h && x < w) ? 1 : 0;
+    return;
+  }
+  float* o = out + (((size_t)b * C + c) * H + y) * W;
+  const float* src = imgs[b] + ((size_t)c * h + y) * w;
+  for (int x = threadIdx.x; x < W; x += 256) o[x] = (y < h && x < w) ? src[x] : 0.f;
+}
+}  // namespace
+
+extern "C" int egtr_pad_batch_f32(egtr_stream_t stream, const float* const* images, const int* heights_widths, int batch,
+                                  int channels, int H, int W, float* pixel_values, int64_t* pixel_mask) {
+  if (!images || !heights_widths || !pixel_values || !pixel_mask || batch <= 0 || channels <= 0 || H <= 0 || W <= 0)
+    return EGTR_E_ARG;
+  const long long rows = (long long)batch * (channels + 1) * H;
+  if (rows >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(pad_batch_f32, dim3((unsigned)rows), dim3(256), 0, static_cast<hipStream_t>(stream), images,
+                     heights_widths, batch, channels, H, W, pixel_values, reinterpret_cast<long long*>(pixel_mask));
+  return egtr_check_launch();
+}

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(X6Problems P, int nprob
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ABLK = 2 * MT;              // 32-row blocks of A per workgroup tile
   constexpr int NFRAG = (ABLK + 4) * 3;     // fragments per stage (A blocks + 4 W blocks, 3 pieces each)
-  constexpr int STAGE = NFRAG * xs::kFragBytes;
-  constexpr int NL = NFRAG / 4;             // DMA instructions per wave and stage
-  static_assert(NFRAG % 4 == 0, "fragments must divide over the four waves");
+  constexpr int NL = (NFRAG + 3) / 4;       // DMA instructions per wave and stage: the same for every wave, so that the
+  constexpr int NSLOT = 4 * NL;             // counted vmcnt waits are immediates; slots >= NFRAG (MT = 1: two of twenty)
+  constexpr int STAGE = NSLOT * xs::kFragBytes;   // re-load fragments 0, 1 into a tail of the stage nobody reads
   constexpr int BM = 64 * MT;
 
   const int KS = K >> 4;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(X6Problems P, int nprob
   unsigned ldst[NL];
 #pragma unroll
   for (int i = 0; i < NL; ++i) {
-    const int f = wave * NL + i, blk = f / 3, p = f - 3 * blk;
+    const int f = wave * NL + i, fs = f < NFRAG ? f : f - NFRAG, blk = fs / 3, p = fs - 3 * blk;
     const char* base;
     if (blk < ABLK) {
       const int rb = min((m0 >> 5) + blk, RB - 1);   // past the matrix: re-read the last block (its outputs are not stored)
@@ -308,19 +309,28 @@ __global__ __launch_bounds__(256) void split_tile_kernel(const float* __restrict
   }
 }
 
-int launch_x6(hipStream_t st, const X6Problems& P, int nprob, int M, int K) {
-  long long tiles = 0;
-  for (int i = 0; i < nprob; ++i) tiles += (long long)(P.p[i].N >> 7) * ((M + 127) / 128);
-  if (tiles <= 0 || tiles >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
-  constexpr int kLds = kStages * 24 * xs::kFragBytes;
-  static bool attr_set = false;   // idempotent; a race would only set the same value twice
+int launch_x6(hipStream_t st, const X6Problems& P, int nprob, int M, int K, int force_mt) {
+  long long tiles128 = 0, tiles64 = 0;
+  for (int i = 0; i < nprob; ++i) {
+    tiles128 += (long long)(P.p[i].N >> 7) * ((M + 127) / 128);
+    tiles64 += (long long)(P.p[i].N >> 7) * ((M + 63) / 64);
+  }
+  if (tiles128 <= 0 || tiles64 >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  constexpr int kLds2 = kStages * 24 * xs::kFragBytes, kLds1 = kStages * 20 * xs::kFragBytes;
+  static bool attr_set = false;   // idempotent; a race would only set the same values twice
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLds) != hipSuccess)
+                            kLds2) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_x6_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLds1) != hipSuccess)
       return egtr_check_launch();
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_x6_kernel<2>, dim3((unsigned)tiles), dim3(256), kLds, st, P, nprob, M, K);
+  // 128-row tiles when they give every CU its two workgroups, 64-row tiles otherwise (a lone workgroup per CU = one wave
+  // per SIMD exposes every barrier and DMA wait; measured in tools/gemm_x6_bench.hip)
+  const bool big = force_mt == 2 || (force_mt != 1 && tiles128 >= 512);
+  if (big) hipLaunchKernelGGL(gemm_x6_kernel<2>, dim3((unsigned)tiles128), dim3(256), kLds2, st, P, nprob, M, K);
+  else hipLaunchKernelGGL(gemm_x6_kernel<1>, dim3((unsigned)tiles64), dim3(256), kLds1, st, P, nprob, M, K);
   return egtr_check_launch();
 }
 
@@ -367,5 +377,6 @@ extern "C" int egtr_gemm_x6_f32(egtr_stream_t stream, int num_problems, const vo
     P.p[i] = X6Problem{static_cast<const char*>(a_xs[i]), static_cast<const char*>(w_xs[i]), bias[i], c[i],
                        static_cast<char*>(c_xs[i]), ldc[i], N[i], relu[i]};
   }
-  return launch_x6(static_cast<hipStream_t>(stream), P, num_problems, M, K);
+  const char* f = getenv("EGTR_X6_TILE");   // development: 1 / 2 forces 64- / 128-row tiles
+  return launch_x6(static_cast<hipStream_t>(stream), P, num_problems, M, K, f ? atoi(f) : 0);
 }

@@ -95,11 +95,26 @@ class DeformableDetrFeatureExtractor:
         return enc
 
     def pad_and_create_pixel_mask(self, pixel_values_list, return_tensors="pt"):
-        """Pad to the largest H, W in the batch (top-left aligned); mask 1 = real pixel, 0 = padding."""
+        """Pad to the largest H, W in the batch (top-left aligned); mask 1 = real pixel, 0 = padding.  Images that already
+        live on the GPU (fp32 [C, h, w]) are batched there by one HIP launch (egtr_pad_batch_f32); host images take the
+        host loop, like the reference."""
         mh = max(int(x.shape[-2]) for x in pixel_values_list)
         mw = max(int(x.shape[-1]) for x in pixel_values_list)
         b = len(pixel_values_list)
         c = pixel_values_list[0].shape[0]
+        if all(torch.is_tensor(x) and x.is_cuda for x in pixel_values_list):
+            from . import _lib
+            from .load_custom import _stream
+            dev = pixel_values_list[0].device
+            imgs = [x.to(dtype=torch.float32).contiguous() for x in pixel_values_list]
+            ptrs = torch.tensor([x.data_ptr() for x in imgs], dtype=torch.int64).to(dev, non_blocking=True)
+            hw = torch.tensor([[int(x.shape[-2]), int(x.shape[-1])] for x in imgs], dtype=torch.int32).to(dev, non_blocking=True)
+            pv = torch.empty(b, c, mh, mw, dtype=torch.float32, device=dev)
+            pm = torch.empty(b, mh, mw, dtype=torch.int64, device=dev)
+            _lib.check(_lib.lib().egtr_pad_batch_f32(_stream(), ptrs.data_ptr(), hw.data_ptr(), b, c, mh, mw,
+                                                     pv.data_ptr(), pm.data_ptr()), "egtr_pad_batch_f32")
+            del imgs   # (alive until the launch was enqueued on the stream that also frees them)
+            return {"pixel_values": pv, "pixel_mask": pm}
         pv = torch.zeros(b, c, mh, mw, dtype=torch.float32)
         pm = torch.zeros(b, mh, mw, dtype=torch.int64)
         for i, x in enumerate(pixel_values_list):

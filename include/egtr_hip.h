@@ -97,14 +97,6 @@ int egtr_msda_forward_fused_box_f32(egtr_stream_t stream, const float* value, co
                                     const unsigned char* keep_mask, const unsigned* keep_bits,
                                     const float* value_bias);
 
-/* egtr_msda_forward_f32 with an explicit kernel choice (A/B parity tests): 0 = automatic, 1 = the wave-per-query
- * kernel (M = 8, D = 32, L*P = 16), 3 = the generic one-thread-per-element kernel (any shape).  Both compute the same
- * function; EGTR_E_UNSUPPORTED if the shape rules out the requested kernel. */
-int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                  const int64_t* level_start_index, const float* sampling_loc,
-                                  const float* attn_weight, int batch, int spatial_size, int num_heads, int channels,
-                                  int num_levels, int num_query, int num_point, float* out, int variant);
-
 /* grad_value [B,S,M,D] MUST be zero-initialised by the caller (accumulated with atomics, as cu:124 relies on);
  * grad_sampling_loc [B,Lq,M,L,P,2] and grad_attn_weight [B,Lq,M,L,P] are fully overwritten. */
 int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const float* value,
@@ -135,15 +127,6 @@ int egtr_msda_backward_bf16(egtr_stream_t stream, const uint16_t* grad_out, cons
                             const float* attn_weight, int batch, int spatial_size, int num_heads, int channels,
                             int num_levels, int num_query, int num_point, float* grad_value, float* grad_sampling_loc,
                             float* grad_attn_weight, float* workspace);
-
-/* Same with an explicit kernel choice (A/B parity tests): 0 = automatic, 1 = wave-per-query with one global atomic per
- * (sample, corner, channel) like the reference, 2 = grad_attn / grad_loc by the wave-per-query kernel + grad_value as a
- * dense product per (query tile, head) on the matrix cores (encoder-shaped calls), 3 = generic. */
-int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
-                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                   const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,
-                                   int num_heads, int channels, int num_levels, int num_query, int num_point,
-                                   float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int variant);
 
 /* bf16 storage (uint16_t = raw bfloat16 bits), fp32 accumulation.  The reference dispatches float/double only
  * (cu:67,137); this is the added path for the bf16 stress configuration.  loc / attn stay fp32. */
@@ -521,6 +504,13 @@ int egtr_column_sum_f32(egtr_stream_t stream, const float* g, const float* relu_
  * relation head's connectivity output, model/egtr.py:414-416 under autograd); workspace as above; N % 4 == 0. */
 int egtr_weighted_column_sum_f32(egtr_stream_t stream, const float* g, const float* row_weight, float* workspace,
                                  float* out, int M, int N);
+
+/* pad_and_create_pixel_mask on the device (the feature extractor's batching step; reference preprocessing around
+ * model/deformable_detr.py:270-385): `images` is a DEVICE array of `batch` device pointers to fp32 [channels, h_b, w_b]
+ * images, heights_widths a DEVICE array [batch][2] = (h_b, w_b); writes the zero-padded, top-left aligned batch
+ * pixel_values [batch, channels, H, W] and pixel_mask [batch, H, W] int64 (1 = real pixel) in one launch. */
+int egtr_pad_batch_f32(egtr_stream_t stream, const float* const* images, const int* heights_widths, int batch,
+                       int channels, int H, int W, float* pixel_values, int64_t* pixel_mask);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,35 @@
+/*
+ * egtr_hip_test.h -- TEST-ONLY entry points of libegtr_hip.so: explicit kernel-variant selection for A/B parity tests and
+ * benchmarks (tests/test_gpu_kernels.py, tools/msda_bench.py).  Not part of the drop-in boundary (include/egtr_hip.h): a
+ * product caller never chooses a kernel variant.
+ */
+#ifndef EGTR_HIP_TEST_H
+#define EGTR_HIP_TEST_H
+
+#include "egtr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* egtr_msda_forward_f32 with an explicit kernel choice (A/B parity tests): 0 = automatic, 1 = the wave-per-query
+ * kernel (M = 8, D = 32, L*P = 16), 3 = the generic one-thread-per-element kernel (any shape).  Both compute the same
+ * function; EGTR_E_UNSUPPORTED if the shape rules out the requested kernel. */
+int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const float* sampling_loc,
+                                  const float* attn_weight, int batch, int spatial_size, int num_heads, int channels,
+                                  int num_levels, int num_query, int num_point, float* out, int variant);
+
+/* Same with an explicit kernel choice (A/B parity tests): 0 = automatic, 1 = wave-per-query with one global atomic per
+ * (sample, corner, channel) like the reference, 2 = grad_attn / grad_loc by the wave-per-query kernel + grad_value as a
+ * dense product per (query tile, head) on the matrix cores (encoder-shaped calls), 3 = generic. */
+int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
+                                   const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                   const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,
+                                   int num_heads, int channels, int num_levels, int num_query, int num_point,
+                                   float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGTR_HIP_TEST_H */

@@ -18,10 +18,20 @@ def lib_path():
     return path
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "egtr_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(egtr_[a-z0-9_]+)\s*\(", src)))
+def _declared(headers=("egtr_hip.h", "egtr_hip_test.h")):
+    """Every entry point declared under include/ (the drop-in boundary + the test-only variant selectors)."""
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(egtr_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_variant_selectors_are_not_part_of_the_public_boundary():
+    public = _declared(("egtr_hip.h",))
+    assert not [n for n in public if n.endswith("_variant")]
+    assert [n for n in _declared(("egtr_hip_test.h",)) if n.endswith("_variant")]
 
 
 def test_header_declares_the_expected_entry_points():

@@ -111,3 +111,17 @@ def test_misaligned_views_are_served():
     assert not ops.msda_geometry_supported(off[..., :256], off[..., 256:], ref, 8, 4, 4)
     ok = torch.randn(2, 40, 384, device=DEV)
     assert ops.msda_geometry_supported(ok[..., :256], ok[..., 256:], ref, 8, 4, 4)
+
+
+def test_pad_and_create_pixel_mask_on_device_equals_host_loop():
+    """DeformableDetrFeatureExtractor.pad_and_create_pixel_mask with device images: one HIP launch, bit-identical to the
+    host loop (pixel values and mask)."""
+    from egtr_amd.feature_extraction import DeformableDetrFeatureExtractor
+    fe = DeformableDetrFeatureExtractor()
+    g = torch.Generator().manual_seed(2)
+    imgs = [torch.randn(3, h, w, generator=g) for h, w in ((37, 61), (50, 40), (1, 1), (50, 61))]
+    host = fe.pad_and_create_pixel_mask(imgs)
+    dev = fe.pad_and_create_pixel_mask([x.to(DEV) for x in imgs])
+    assert dev["pixel_values"].is_cuda and dev["pixel_mask"].dtype == torch.int64
+    assert torch.equal(dev["pixel_values"].cpu(), host["pixel_values"])
+    assert torch.equal(dev["pixel_mask"].cpu(), host["pixel_mask"])
