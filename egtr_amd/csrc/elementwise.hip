@@ -321,14 +321,30 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool3x3s2(const float* __res
 //   (deformable_detr.py:658-662: x = clamp(x, 0, 1); log(max(x, eps) / max(1 - x, eps)));
 //   box = sigmoid(delta + [r, 0, 0]) for 2-d references, sigmoid(delta + r) for 4-d ones.
 // One thread per (b, l, n) row; replaces cat + 3 clamp + sub + div + log + add + cat + sigmoid launches on ~5 KB tensors.
+// inter_ref == nullptr: every level uses init_ref (no iterative box refinement: the decoder hands the same reference
+// points to every layer, dd:1903-1918 inactive).  logits_all != nullptr ([B, Ld, N, C]): the thread of the LAST level also
+// writes node_cls[b, n] = argmax_c logits_all[b, Ld - 1, n, c] (first maximum on ties, NaN counts as the maximum -- as
+// torch.argmax; egtr:405-413: the frequency-bias lookup of the relation head).
 __global__ __launch_bounds__(256) void box_decode(const float* __restrict__ delta, const float* __restrict__ init_ref,
                                                   const float* __restrict__ inter_ref, int B, int Ld, int N, int RD,
-                                                  float eps, float* __restrict__ out) {
+                                                  float eps, float* __restrict__ out,
+                                                  const float* __restrict__ logits_all, int C,
+                                                  long long* __restrict__ node_cls) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * Ld * N) return;
   const int n = i % N, l = (i / N) % Ld, b = i / (N * Ld);
-  const float* rp = (l == 0) ? init_ref + ((size_t)b * N + n) * RD
-                             : inter_ref + (((size_t)b * Ld + (l - 1)) * N + n) * RD;
+  if (logits_all != nullptr && l == Ld - 1) {
+    const float* lg = logits_all + (size_t)i * C;
+    float best = lg[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = lg[c];
+      if (v > best || (v != v && best == best)) { best = v; arg = c; }
+    }
+    node_cls[(size_t)b * N + n] = arg;
+  }
+  const float* rp = (l == 0 || inter_ref == nullptr) ? init_ref + ((size_t)b * N + n) * RD
+                                                      : inter_ref + (((size_t)b * Ld + (l - 1)) * N + n) * RD;
   const float4 d = reinterpret_cast<const float4*>(delta)[i];
   float v[4] = {d.x, d.y, d.z, d.w};
   for (int k = 0; k < RD; ++k) {
@@ -782,18 +798,28 @@ extern "C" int egtr_bias_relu_maxpool3x3s2_f32(egtr_stream_t stream, const float
   return egtr_check_launch();
 }
 
-extern "C" int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
-                                   const float* inter_references, int batch, int num_levels, int num_query,
-                                   int ref_dim, float eps, float* boxes) {
+extern "C" int egtr_box_decode_argmax_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
+                                          const float* inter_references, int batch, int num_levels, int num_query,
+                                          int ref_dim, float eps, float* boxes, const float* logits_all,
+                                          int num_classes, int64_t* node_cls) {
   if (!delta || !init_reference || !boxes) return EGTR_E_ARG;
   if (batch <= 0 || num_levels <= 0 || num_query <= 0) return EGTR_E_ARG;
-  if (num_levels > 1 && !inter_references) return EGTR_E_ARG;
+  if (logits_all && (!node_cls || num_classes <= 0)) return EGTR_E_ARG;
   if (ref_dim != 2 && ref_dim != 4) return EGTR_E_UNSUPPORTED;
   const long long n = (long long)batch * num_levels * num_query;
   if (n >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
   hipLaunchKernelGGL(box_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), delta,
-                     init_reference, inter_references, batch, num_levels, num_query, ref_dim, eps, boxes);
+                     init_reference, inter_references, batch, num_levels, num_query, ref_dim, eps, boxes, logits_all,
+                     num_classes, reinterpret_cast<long long*>(node_cls));
   return egtr_check_launch();
+}
+
+extern "C" int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
+                                   const float* inter_references, int batch, int num_levels, int num_query,
+                                   int ref_dim, float eps, float* boxes) {
+  if (num_levels > 1 && !inter_references) return EGTR_E_ARG;
+  return egtr_box_decode_argmax_f32(stream, delta, init_reference, inter_references, batch, num_levels, num_query,
+                                    ref_dim, eps, boxes, nullptr, 0, nullptr);
 }
 
 extern "C" int egtr_bias_mask_rows_f32(egtr_stream_t stream, float* y, const float* bias, const unsigned char* keep,

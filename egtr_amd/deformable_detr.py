@@ -650,9 +650,10 @@ class DeformableDetrDecoderLayer(nn.Module):
     def forward(self, hidden_states, attention_mask=None, position_embeddings=None, reference_points=None,
                 spatial_shapes=None, level_start_index=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, output_attentions=False, output_attention_states=False,
-                spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False, precomputed_value=None):
-        """``hidden_with_pos`` / ``return_with_pos`` / ``precomputed_value``: inference plumbing, see the encoder layer
-        and DeformableDetrDecoder.forward."""
+                spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False, precomputed_value=None,
+                out=None):
+        """``hidden_with_pos`` / ``return_with_pos`` / ``precomputed_value`` / ``out`` (destination of the layer's output
+        states): inference plumbing, see the encoder layer and DeformableDetrDecoder.forward."""
         fast = position_embeddings is not None and ops.inference_fast_path(hidden_states)
         residual = hidden_states
         hidden_states, self_attn_weights, self_attn_queries, self_attn_keys = self.self_attn(
@@ -687,7 +688,7 @@ class DeformableDetrDecoderLayer(nn.Module):
         next_with_pos = None
         if fast and return_with_pos:
             hidden_states, next_with_pos = ops.add_layer_norm_pos(hidden_states, residual, self.final_layer_norm,
-                                                                  _pos_rows(position_embeddings))
+                                                                  _pos_rows(position_embeddings), out=out)
         else:
             hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
         outputs = (hidden_states,)
@@ -802,7 +803,9 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
     def forward(self, inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 position_embeddings=None, reference_points=None, spatial_shapes=None, level_start_index=None,
                 valid_ratios=None, output_attentions=None, output_hidden_states=None, output_attention_states=None,
-                return_dict=None, spatial_shapes_list=None):
+                return_dict=None, spatial_shapes_list=None, first_with_pos=None):
+        """``first_with_pos`` (inference plumbing): inputs_embeds + position_embeddings, when the caller has it as a
+        derived constant of the query table."""
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_attention_states = (output_attention_states if output_attention_states is not None
                                    else self.config.output_attention_states)
@@ -857,7 +860,13 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
         hoisted_reference = None
         if self.bbox_embed is None and reference_points.shape[-1] == 2:  # no refinement: same input for every layer
             hoisted_reference = reference_points[:, :, None] * valid_ratios[:, None]
-        with_pos = None
+        with_pos = first_with_pos if fast else None
+        # inference: every layer's final LayerNorm writes its states straight into the stacked [Ld, B, N, d] buffer the
+        # heads read (viewed [B, Ld, N, d]) -- no torch.stack copy at the end
+        inter_buf = None
+        if fast and hidden_states.dtype == torch.float32 and hidden_states.shape[-1] == 256:
+            inter_buf = torch.empty(len(self.layers), *hidden_states.shape, dtype=hidden_states.dtype,
+                                    device=hidden_states.device)
         for idx, decoder_layer in enumerate(self.layers):
             if hoisted_reference is not None:
                 reference_points_input = hoisted_reference
@@ -877,7 +886,8 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 encoder_attention_mask=encoder_attention_mask, output_attentions=output_attentions,
                 output_attention_states=output_attention_states, spatial_shapes_list=spatial_shapes_list,
                 hidden_with_pos=with_pos, return_with_pos=True,
-                precomputed_value=values[idx] if values is not None else None)
+                precomputed_value=values[idx] if values is not None else None,
+                out=inter_buf[idx] if inter_buf is not None else None)
             hidden_states = layer_outputs[0]
             with_pos = layer_outputs[-1]
             if self.bbox_embed is not None:  # iterative box refinement (dd:1903-1918)
@@ -902,8 +912,15 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
             elif output_attention_states:
                 all_attention_queries += (layer_outputs[1],)
                 all_attention_keys += (layer_outputs[2],)
-        intermediate = torch.stack(intermediate, dim=1)
-        intermediate_reference_points = torch.stack(intermediate_reference_points, dim=1)
+        if inter_buf is not None and all(t.data_ptr() == inter_buf[i].data_ptr() for i, t in enumerate(intermediate)):
+            intermediate = inter_buf.permute(1, 0, 2, 3)
+        else:
+            intermediate = torch.stack(intermediate, dim=1)
+        if self.bbox_embed is None and fast:
+            # no refinement: every layer saw the same reference points -- a view expanded over the level axis
+            intermediate_reference_points = reference_points.unsqueeze(1).expand(-1, len(self.layers), -1, -1)
+        else:
+            intermediate_reference_points = torch.stack(intermediate_reference_points, dim=1)
         if output_hidden_states:
             all_hidden_states += (hidden_states,)
         if not return_dict:
@@ -1092,18 +1109,20 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             # (dd:2339-2343) depend on parameters only: derived constants, rebuilt when a source tensor changes
             # (4 launches per forward otherwise).
             lin = self.reference_points
-            query_embed, target, ref0 = ops.cached_weights(
+            query_embed, target, ref0, tp0 = ops.cached_weights(
                 self, "query_tables", [query_embeds, lin.weight, lin.bias],
-                lambda: (lambda qe, tg: (qe, tg, ops.module_linear(lin, qe).sigmoid()))(
+                lambda: (lambda qe, tg: (qe, tg, ops.module_linear(lin, qe).sigmoid(), tg + qe))(
                     query_embeds[:, :num_channels].contiguous(), query_embeds[:, num_channels:].contiguous()))
             query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)
             target = target.unsqueeze(0).expand(batch_size, -1, -1)
             reference_points = ref0.unsqueeze(0).expand(batch_size, -1, -1)
+            first_with_pos = tp0.unsqueeze(0).expand(batch_size, -1, -1)   # decoder layer 0: queries + positions
         else:
             query_embed, target = torch.split(query_embeds, num_channels, dim=1)  # dd:2339
             query_embed = query_embed.unsqueeze(0).expand(batch_size, -1, -1)
             target = target.unsqueeze(0).expand(batch_size, -1, -1)
             reference_points = ops.module_linear(self.reference_points, query_embed).sigmoid()
+            first_with_pos = None
         init_reference_points = reference_points
 
         decoder_outputs = self.decoder(
@@ -1111,7 +1130,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             encoder_attention_mask=mask_flatten, reference_points=reference_points, spatial_shapes=spatial_shapes,
             level_start_index=level_start_index, valid_ratios=valid_ratios, output_attentions=output_attentions,
             output_attention_states=output_attention_states, output_hidden_states=output_hidden_states,
-            return_dict=return_dict, spatial_shapes_list=spatial_shapes_list)
+            return_dict=return_dict, spatial_shapes_list=spatial_shapes_list, first_with_pos=first_with_pos)
 
         if not return_dict:
             return (init_reference_points,) + decoder_outputs + encoder_outputs
@@ -1268,11 +1287,21 @@ class DeformableDetrHungarianMatcher(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------ detection heads
-def detection_heads(config, class_embed, bbox_embed, hidden_states, init_reference, inter_references):
+def detection_heads(config, class_embed, bbox_embed, hidden_states, init_reference, inter_references,
+                    want_node_cls=False):
     """Class logits and boxes of every decoder level (dd:2530-2557 == egtr:283-305): ``logits_l = class_embed[l](h_l)``,
     ``box_l = sigmoid(bbox_embed[l](h_l) + [inverse_sigmoid(reference_l), 0, 0])`` with reference_0 = the initial
     reference points and reference_l = the decoder's intermediate ones.  hidden_states [B, Ld, N, d] ->
-    (outputs_class [B, Ld, N, C], outputs_coord [B, Ld, N, 4])."""
+    (outputs_class [B, Ld, N, C], outputs_coord [B, Ld, N, 4]) [+ node_cls [B, N] = argmax of the last level's logits,
+    or None where the fused launch does not apply, with ``want_node_cls``]."""
+    if want_node_cls:
+        oc, ob, node = _detection_heads(config, class_embed, bbox_embed, hidden_states, init_reference, inter_references,
+                                        True)
+        return oc, ob, node
+    return _detection_heads(config, class_embed, bbox_embed, hidden_states, init_reference, inter_references, False)[:2]
+
+
+def _detection_heads(config, class_embed, bbox_embed, hidden_states, init_reference, inter_references, want_node):
     if not config.with_box_refine:
         # class_embed / bbox_embed alias ONE module for every level (dd:2439-2446): apply them once to the stacked
         # [B, Ld, N, d] states instead of Ld times (same arithmetic per row)
@@ -1290,7 +1319,10 @@ def detection_heads(config, class_embed, bbox_embed, hidden_states, init_referen
             outputs_class = ops.module_linear(class_embed[0], hidden_states)
             delta_bbox = bbox_embed[0](hidden_states)
         if fast and init_reference.shape[-1] in (2, 4):
-            return outputs_class, ops.box_decode(delta_bbox, init_reference, inter_references)
+            if want_node:   # class arg-max of the last level in the same launch (the relation head's lookup)
+                boxes, node = ops.box_decode(delta_bbox, init_reference, inter_references, logits_all=outputs_class)
+                return outputs_class, boxes, node
+            return outputs_class, ops.box_decode(delta_bbox, init_reference, inter_references), None
         refs = torch.cat([init_reference[:, None], inter_references[:, :-1]], 1)
         if refs.shape[-1] == 4:
             outputs_coord = (delta_bbox + inverse_sigmoid(refs)).sigmoid()
@@ -1298,7 +1330,7 @@ def detection_heads(config, class_embed, bbox_embed, hidden_states, init_referen
             outputs_coord = torch.cat([delta_bbox[..., :2] + inverse_sigmoid(refs), delta_bbox[..., 2:]], -1).sigmoid()
         else:
             raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {refs.shape[-1]}")
-        return outputs_class, outputs_coord
+        return outputs_class, outputs_coord, None
     outputs_classes, outputs_coords = [], []
     for level in range(hidden_states.shape[1]):
         reference = init_reference if level == 0 else inter_references[:, level - 1]
@@ -1313,7 +1345,7 @@ def detection_heads(config, class_embed, bbox_embed, hidden_states, init_referen
             raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {reference.shape[-1]}")
         outputs_classes.append(outputs_class)
         outputs_coords.append(outputs_coord_logits.sigmoid())
-    return torch.stack(outputs_classes, dim=1), torch.stack(outputs_coords, dim=1)
+    return torch.stack(outputs_classes, dim=1), torch.stack(outputs_coords, dim=1), None
 
 
 class DeformableDetrLoss(nn.Module):

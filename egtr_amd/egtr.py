@@ -107,8 +107,9 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         return [{"logits": a, "pred_boxes": b} for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
 
     # ---------------------------------------------------------------------------------------- relation head
-    def _relation_head(self, queries, keys, sequence_output, logits, want_gate_mean, sigmoid=False):
-        """egtr:322-418 via the separable algebra.  Returns pre-sigmoid (rel [B,N,N,R], conn [B,N,N,1], gate_mean)."""
+    def _relation_head(self, queries, keys, sequence_output, logits, want_gate_mean, sigmoid=False, node_cls=None):
+        """egtr:322-418 via the separable algebra.  Returns pre-sigmoid (rel [B,N,N,R], conn [B,N,N,1], gate_mean).
+        ``node_cls``: argmax(logits, -1) when the box-decode launch already produced it."""
         bsz, N, d = sequence_output.shape
         unscaling = self.head_dim ** 0.5
         rp, cl = self.rel_predictor.layers, self.connectivity_layer.layers
@@ -167,7 +168,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         triplet, node = None, None
         if self.config.use_freq_bias:  # egtr:405-413
             triplet = self.triplet_dist
-            node = torch.argmax(logits, dim=-1)
+            node = node_cls if node_cls is not None else torch.argmax(logits, dim=-1)
         return ops.relation_head(gate_q, gate_k, uq, uk, b1, rp[1].weight, rp[1].bias, rp[2].weight, rp[2].bias,
                                  cl[1].weight, cl[1].bias, cl[2].weight, cl[2].bias, triplet, node,
                                  want_gate_mean, owner=self, sigmoid=sigmoid)
@@ -189,8 +190,11 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         init_reference = outputs.init_reference_points
         inter_references = outputs.intermediate_reference_points
 
-        outputs_class, outputs_coord = detection_heads(self.config, self.class_embed, self.bbox_embed, hidden_states,
-                                                       init_reference, inter_references)
+        outputs_class, outputs_coord, node_cls = detection_heads(
+            self.config, self.class_embed, self.bbox_embed, hidden_states, init_reference, inter_references,
+            want_node_cls=True)
+        if not self.config.use_freq_bias:
+            node_cls = None
         logits = outputs_class[:, -1]
         pred_boxes = outputs_coord[:, -1]
         if self.config.auxiliary_loss:
@@ -207,7 +211,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         outputs["decoder_attention_keys"] = None
         pred_rel, pred_connectivity, gate_mean = self._relation_head(
             decoder_attention_queries, decoder_attention_keys, sequence_output, logits,
-            want_gate_mean=want_gate_mean, sigmoid=sigmoid)
+            want_gate_mean=want_gate_mean, sigmoid=sigmoid, node_cls=node_cls)
         return logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending
 
     def forward_tensors(self, pixel_values, pixel_mask):

@@ -479,26 +479,44 @@ def bias_relu_maxpool(x, bias):
     return y
 
 
-def box_decode(delta, init_reference, inter_references, eps=1e-5):
-    """sigmoid(delta + [inverse_sigmoid(reference_l), 0..]) for all decoder levels in one HIP launch (egtr:286-305 without
-    box refinement; reference_0 = init_reference, reference_l = inter_references[:, l-1]).  Inference only."""
+def box_decode(delta, init_reference, inter_references, eps=1e-5, logits_all=None):
+    """sigmoid(delta + [inverse_sigmoid(reference_l), 0..]) for all decoder levels in one HIP launch (egr:286-305;
+    reference_0 = init_reference, reference_l = inter_references[:, l-1]).  ``inter_references`` expanded from ONE tensor
+    (stride 0 over the level axis: no box refinement) is not materialised.  With ``logits_all`` [B, Ld, N, C] the launch
+    also returns argmax(logits_all[:, -1], -1) (the relation head's class lookup, egtr:405-413): (boxes, node_cls).
+    Inference only."""
     lib = _lib.lib()
     B, Ld, N, four = delta.shape
     if four != 4:
         raise ValueError(f"delta must be [B, Ld, N, 4], got {tuple(delta.shape)}")
     d = _chk(delta.contiguous(), "delta", torch.float32)
     r0 = _chk(init_reference.contiguous(), "init_reference", torch.float32)
-    r1 = _chk(inter_references.contiguous(), "inter_references", torch.float32)
     RD = r0.shape[-1]
-    if tuple(r0.shape) != (B, N, RD) or tuple(r1.shape) != (B, Ld, N, RD):
-        raise ValueError(f"reference shapes {tuple(r0.shape)} / {tuple(r1.shape)} do not match delta {tuple(delta.shape)}")
+    # every level = the initial reference points, expanded over the level axis (the decoder without box refinement)
+    same = (inter_references.dim() == 4 and Ld > 1 and inter_references.stride(1) == 0
+            and inter_references.data_ptr() == init_reference.data_ptr()
+            and inter_references.stride(0) == init_reference.stride(0)
+            and tuple(inter_references.stride()[2:]) == tuple(init_reference.stride()[1:]))
+    r1 = None if same else _chk(inter_references.contiguous(), "inter_references", torch.float32)
+    if tuple(r0.shape) != (B, N, RD) or tuple(inter_references.shape) != (B, Ld, N, RD):
+        raise ValueError(f"reference shapes {tuple(r0.shape)} / {tuple(inter_references.shape)} do not match delta "
+                         f"{tuple(delta.shape)}")
     if RD not in (2, 4):
         raise ValueError(f"reference.shape[-1] should be 4 or 2, but got {RD}")
     out = torch.empty_like(d)
-    st = lib.egtr_box_decode_f32(_stream(), d.data_ptr(), r0.data_ptr(), r1.data_ptr(), B, Ld, N, RD, float(eps),
-                                 out.data_ptr())
-    _lib.check(st, "egtr_box_decode_f32")
-    return out
+    lg, node, C = None, None, 0
+    if logits_all is not None:
+        lg = _chk(logits_all.contiguous(), "logits_all", torch.float32)
+        C = lg.shape[-1]
+        if tuple(lg.shape[:3]) != (B, Ld, N):
+            raise ValueError("logits_all must be [B, Ld, N, C]")
+        node = torch.empty(B, N, dtype=torch.int64, device=d.device)
+    st = lib.egtr_box_decode_argmax_f32(_stream(), d.data_ptr(), r0.data_ptr(), r1.data_ptr() if r1 is not None else None,
+                                        B, Ld, N, RD, float(eps), out.data_ptr(),
+                                        lg.data_ptr() if lg is not None else None, C,
+                                        node.data_ptr() if node is not None else None)
+    _lib.check(st, "egtr_box_decode_argmax_f32")
+    return out if logits_all is None else (out, node)
 
 
 def bias_mask_rows_(y, bias, keep):
@@ -518,9 +536,10 @@ def bias_mask_rows_(y, bias, keep):
     return y
 
 
-def add_layer_norm_pos(x, residual, ln, pos):
+def add_layer_norm_pos(x, residual, ln, pos, out=None):
     """(ln(residual + x), ln(residual + x) + pos) in one HIP launch; pos is [rows_p, 256] with rows % rows_p == 0
-    (broadcast over the batch).  Inference only."""
+    (broadcast over the batch).  ``out``: optional contiguous destination of the first result (e.g. a slice of the
+    decoder's stacked intermediate states).  Inference only."""
     lib = _lib.lib()
     x2 = _chk(x.contiguous(), "x", torch.float32)
     r2 = _chk(residual.contiguous(), "residual", torch.float32)
@@ -529,7 +548,9 @@ def add_layer_norm_pos(x, residual, ln, pos):
     prow = p2.numel() // 256
     if x2.shape[-1] != 256 or rows % prow != 0:
         raise ValueError("add_layer_norm_pos: d_model must be 256 and pos must tile the rows")
-    y = torch.empty_like(x2)
+    y = torch.empty_like(x2) if out is None else _chk(out, "out", torch.float32)
+    if y.shape != x2.shape:
+        raise ValueError("add_layer_norm_pos: out must have the shape of x")
     yp = torch.empty_like(x2)
     st = lib.egtr_add_layernorm_pos_f32(_stream(), x2.data_ptr(), r2.data_ptr(), ln.weight.data_ptr(),
                                         ln.bias.data_ptr(), y.data_ptr(), rows, 256, float(ln.eps), p2.data_ptr(),

@@ -258,6 +258,14 @@ int egtr_bias_relu_maxpool3x3s2_f32(egtr_stream_t stream, const float* x, const 
 int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
                         const float* inter_references, int batch, int num_levels, int num_query, int ref_dim, float eps,
                         float* boxes);
+/* The same with two fusions of the inference forward: inter_references == NULL means "every level uses init_reference"
+ * (no iterative box refinement: the decoder passes the same reference points to every layer), and with logits_all
+ * ([batch, num_levels, num_query, num_classes], may be NULL) node_cls [batch, num_query] int64 receives
+ * argmax_c logits_all[b, num_levels - 1, n, c] -- the class lookup of the relation head's frequency bias
+ * (model/egtr.py:405-413), first maximum on ties and NaN as maximum like torch.argmax. */
+int egtr_box_decode_argmax_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
+                               const float* inter_references, int batch, int num_levels, int num_query, int ref_dim,
+                               float eps, float* boxes, const float* logits_all, int num_classes, int64_t* node_cls);
 
 /* Hungarian matcher on the device: DeformableDetrHungarianMatcher.forward (model/deformable_detr.py:2925-3015) -- the
  * focal / L1 / GIoU cost matrix (:2949-2982), the adaptive-smoothing offset (:2989-2999) and

@@ -125,3 +125,24 @@ def test_pad_and_create_pixel_mask_on_device_equals_host_loop():
     assert dev["pixel_values"].is_cuda and dev["pixel_mask"].dtype == torch.int64
     assert torch.equal(dev["pixel_values"].cpu(), host["pixel_values"])
     assert torch.equal(dev["pixel_mask"].cpu(), host["pixel_mask"])
+
+
+def test_box_decode_with_class_argmax_and_shared_reference():
+    """egtr_box_decode_argmax_f32: boxes identical to the plain entry; node_cls == torch.argmax of the last level's logits
+    incl. exact ties (first index) and NaN (counts as the maximum); reference points expanded over the level axis (no box
+    refinement) are read in place."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, Ld, N, C = 2, 6, 200, 150
+    delta = torch.randn(B, Ld, N, 4, generator=g).to(DEV)
+    ref = torch.rand(B, N, 2, generator=g).to(DEV)
+    logits = torch.randn(B, Ld, N, C, generator=g).to(DEV)
+    logits[0, -1, 3, 10] = logits[0, -1, 3, 77] = 9.0            # tie: first index wins
+    logits[1, -1, 5, 40] = float("nan")                          # NaN is the maximum
+    logits[1, -1, 6, 0] = 50.0
+    inter = ref.unsqueeze(1).expand(-1, Ld, -1, -1)              # stride 0 over the level axis
+    boxes, node = ops.box_decode(delta, ref, inter, logits_all=logits)
+    want = ops.box_decode(delta, ref, inter.contiguous())
+    assert torch.equal(boxes, want)
+    assert torch.equal(node, torch.argmax(logits[:, -1], -1))
+    assert int(node[0, 3]) == 10 and int(node[1, 5]) == 40 and int(node[1, 6]) == 0
