@@ -1,0 +1,401 @@
+// The encoder layer's feed-forward block as ONE kernel, fp32 in / fp32 out with fp32-level accuracy on the bf16 matrix cores:
+//     y = LayerNorm(x + fc2(relu(fc1(x))))   [+ y + pos]          (model/deformable_detr.py:1335-1345, d_model = 256)
+// (the LayerNorm / residual part is optional: without it y = fc2(relu(fc1(x)))).  The reference runs two token-sized
+// nn.Linear layers with a [S, 1024] fp32 activation (51 MB at S = 12 537) written and read in between, plus an add and a
+// LayerNorm kernel.  Here a workgroup owns 64 token rows for the whole block and the hidden activation never leaves the CU:
+//
+//   * the 64 x 256 input panel is split ONCE into its three bf16 pieces (xs_format.h): hi and mid live in LDS as MFMA
+//     operand fragments (64 KiB), lo in registers (each wave: the 16 fragments of its 32 rows);
+//   * the hidden dimension is walked in chunks of 64 units: layer 1 for the chunk (K = 256: 4 stages of 4 k-steps), bias +
+//     ReLU + split of the 64 x 64 chunk into LDS (24 KiB), layer 2 accumulating the chunk into the 64 x 256 output tile
+//     (K = 64: 4 stages of 1 k-step, 4 accumulator tiles per wave);
+//   * the weights arrive pre-split in the XS format and stream through a ring of three 24 KiB LDS stages filled by LDS-DMA
+//     two stages ahead (counted vmcnt, raw s_barrier, one barrier per stage): every stage, of either layer, is 24 fragments
+//     and 24 MFMAs per wave, so the two layers form ONE uniform stream of 8 stages per chunk;
+//   * the six-term split product (x6_common.h) everywhere: fp32 operands, fp32 accumulation, error of an fp32 GEMM.
+// LDS: 64 (panel) + 24 (hidden chunk) + 72 (ring) = 160 KiB, one workgroup of four waves per CU.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "x6_common.h"
+#include "xs_format.h"
+
+#ifndef FFN_ABL
+#define FFN_ABL 0   // development ablations (tools/ffn_x6_bench.hip): 1 no in-loop DMA, 2 no barriers, 3 no hidden-chunk epilogue, 4 no weight reads
+#endif
+
+#ifdef FFN_TIMING
+#define FFN_STAMP(k)                                                                             \
+  do {                                                                                           \
+    if (A.tdbg != nullptr && blockIdx.x == 0 && tid == 0 && c == 2)                              \
+      A.tdbg[s * 6 + (k)] = (long long)__builtin_readcyclecounter();                             \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
+#else
+#define FFN_STAMP(k)
+#endif
+
+namespace {
+using namespace x6;
+
+constexpr int kD = 256;                          // d_model: K of layer 1, N of layer 2
+constexpr int kRows = 64;                        // token rows per workgroup
+constexpr int kKS = kD / 16;                     // k-steps over d_model
+constexpr int kFrag = xs::kFragBytes;
+constexpr int kPanel = 2 * kKS * 2 * kFrag;      // [row block 2][k-step 16][hi, mid]        64 KiB
+constexpr int kHbuf = 2 * 4 * 3 * kFrag;         // XS(hidden chunk): [row block 2][k-step 4][3]   24 KiB
+constexpr int kStage = 24 * kFrag;               // one weight stage                              24 KiB
+constexpr int kLds = kPanel + kHbuf + 3 * kStage;
+static_assert(kLds == 160 * 1024, "the whole LDS of a CU");
+constexpr int NL = 6;                            // DMA instructions per wave and stage
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+struct FfnArgs {
+  const float* x;        // [M, ldx] fp32
+  const char* w1;        // XS(W1 [F, 256])
+  const float* b1;       // [F]
+  const char* w2;        // XS(W2 [256, F])
+  const float* b2;       // [256]
+  const float* gamma;    // LayerNorm weight / bias [256], or null: no residual, no LayerNorm
+  const float* beta;
+  const float* pos;      // [pos_rows, 256] or null
+  float* out;            // [M, 256]
+  float* out_pos;        // [M, 256] = out + pos[row % pos_rows], or null
+  int M, ldx, F, pos_rows;
+  float eps;
+  long long* tdbg;   // development: cycle stamps of wave 0 of workgroup 0 (FFN_TIMING builds), else null
+};
+
+__global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const panel = smem;
+  char* const hbuf = smem + kPanel;
+  char* const ring = smem + kPanel + kHbuf;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, hf = lane >> 5;
+  const unsigned lds_ring = (unsigned)reinterpret_cast<uintptr_t>((lds_char*)ring);
+  const int r0 = blockIdx.x * kRows;
+  const int nchunk = A.F >> 6, KSf = A.F >> 4;
+
+  // ---- weight stream: stage g = 8 c + s; s < 4: layer 1, hidden units 64 c .., k-steps 4 s .. 4 s + 3 of d_model
+  //      ([2 n-blocks][4 k-steps][3 pieces]); s >= 4: layer 2, k-step 4 c + (s - 4) of the hidden dimension, all 256 outputs
+  //      ([8 n-blocks][3 pieces]).  Wave w moves fragments 6 w .. 6 w + 5 of the stage image: contiguous in LDS, and in
+  //      global memory one 6 KiB run (layer 1) or two 3 KiB runs (layer 2).
+  const unsigned voff = lane * 16;
+  // stage (c, s) beyond the last one: re-load the last stage (never read; keeps every wait count an immediate)
+  // Workgroup b walks the hidden chunks in the rotated order b, b + 1, .. (mod nchunk): workgroups that run side by side
+  // then stream DIFFERENT weight fragments at any moment (all of them fetching the same 24 KiB stage at once makes a few
+  // L2 channels the bottleneck: 91 -> 8x us at S = 12 537).  The sum over chunks is the same set in a rotated order.
+  const int crot = blockIdx.x % nchunk;
+  auto chunk_of = [&](int c) { const int t = c + crot; return t >= nchunk ? t - nchunk : t; };
+  auto issue = [&](int c, int s, int slot) {
+    if (c >= nchunk) { c = nchunk - 1; s = 7; }
+    c = chunk_of(c);
+    const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
+    if (s < 4) {
+      const char* src = A.w1 + ((size_t)((2 * c + (wave >> 1)) * kKS + 4 * s + 2 * (wave & 1)) * 3) * kFrag;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) dma16s(src + i * kFrag, voff, dst + i * kFrag);
+    } else {
+      const int kh = 4 * c + (s - 4);
+#pragma unroll
+      for (int i = 0; i < NL; ++i)
+        dma16s(A.w2 + ((size_t)((2 * wave + i / 3) * KSf + kh) * 3 + i % 3) * kFrag, voff, dst + i * kFrag);
+    }
+  };
+  issue(0, 0, 0);
+  issue(0, 1, 1);
+
+  // ---- input panel: 64 rows x 256 fp32 -> hi / mid fragments in LDS, lo fragments via LDS into registers
+  {
+    float4 v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = min(r0 + it * 4 + (tid >> 6), A.M - 1);
+      v[it] = *reinterpret_cast<const float4*>(A.x + (size_t)row * A.ldx + 4 * lane);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + (tid >> 6), rb = row >> 5, r = row & 31;
+      const int ks = lane >> 2, off = ((lane >> 1) & 1) * 512 + r * 16 + (lane & 1) * 8;
+      const xs::Split3 s0 = xs::split3(v[it].x), s1 = xs::split3(v[it].y), s2 = xs::split3(v[it].z),
+                       s3 = xs::split3(v[it].w);
+      char* p = panel + ((rb * kKS + ks) * 2) * kFrag + off;
+      *reinterpret_cast<uint2*>(p) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
+      *reinterpret_cast<uint2*>(p + kFrag) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
+      // lo pieces: row block 0 parks in the hidden-chunk buffer, row block 1 in ring slot 2 (both idle until stage 0)
+      char* q = (rb == 0 ? hbuf : ring + 2 * kStage) + ks * kFrag + off;
+      *reinterpret_cast<uint2*>(q) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
+    }
+  }
+  __syncthreads();
+  bf16x8 lo[kKS];
+  {
+    const char* q = (wm == 0 ? hbuf : ring + 2 * kStage) + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag);
+  }
+
+  f32x16 acc2[4], acc1[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+
+  const char* const pa = panel + (wm * kKS * 2) * kFrag + lane * 16;   // hi / mid fragments of this wave's 32 rows
+  const char* const ph = hbuf + (wm * 4 * 3) * kFrag + lane * 16;      // hidden-chunk fragments of this wave's 32 rows
+  // weight fragments of a stage, as this wave reads them: layer 1 = [k-step 4][piece 3] of n-block wn, layer 2 = [n tile
+  // 4][piece 3] of n-blocks 4 wn ..: in both images fragment (u, p) sits at ((4 wn + u) * 3 + p) KiB
+  const char* const pw = ring + (4 * wn * 3) * kFrag + lane * 16;
+  auto frag = [](const char* p) { return *reinterpret_cast<const bf16x8*>(p); };
+
+  // One stage in PINNED program order (sched_barrier(0) between the items; left alone, hipcc reads every operand right
+  // before its use and chains six dependent MFMAs on one accumulator): 24 MFMAs, consecutive ones on different
+  // accumulators; behind MFMAs 1, 3, .., 11 the six DMA instructions of stage g + 3; behind MFMAs 12 .. 17 the twelve
+  // weight fragments of stage g + 1 (other register set), two at a time; the hi / mid fragments of the input panel
+  // (layer 1) one k-step ahead of their use.  Everything but the matrix instructions issues in the shadow of an MFMA.
+  // a / anx: operand A of this / the next stage: layer 1 = [k-step 4][hi, mid] (lo comes from the registers), layer 2 =
+  // the three pieces of the hidden k-step in a[0][0], a[0][1], a[1][0]
+  auto stage = [&](auto S, const bf16x8 (&w)[4][3], bf16x8 (&wnx)[4][3], const bf16x8 (&a)[4][2], bf16x8 (&anx)[4][2], int c,
+                   int slot_next, int slot_fill) {
+    constexpr int s = decltype(S)::value;
+    const char* const wn_src = pw + slot_next * kStage;
+    const unsigned dst = lds_ring + (unsigned)slot_fill * kStage + (unsigned)wave * (NL * kFrag);
+    constexpr int s3 = (s + 3) & 7;
+    int c3 = c + ((s + 3) >> 3);
+    const bool past = c3 >= nchunk;          // stage g + 3 does not exist: re-load the last stage (never read)
+    c3 = chunk_of(past ? nchunk - 1 : c3);
+    const char* src1 = A.w1 + ((size_t)((2 * c3 + (wave >> 1)) * kKS + 4 * (s3 & 3) + 2 * (wave & 1)) * 3) * kFrag;
+    const char* src2 = A.w2 + ((size_t)(2 * wave * KSf + 4 * c3 + (s3 & 3)) * 3) * kFrag;
+    const size_t nb_stride = (size_t)KSf * 3 * kFrag;
+    static_for<24>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      // the six cross terms, small ones first: (w piece, a piece)
+      constexpr int pwt[6] = {2, 0, 1, 1, 0, 0}, pat[6] = {0, 2, 1, 0, 1, 0};
+      if constexpr (s < 4) {
+        // MFMA i: k-step pair (i / 12), term (i % 12) / 2, k-step parity i & 1 -> accumulator i & 1 (four accumulators, one
+        // per k-step, measured slower: 92.4 vs 87.3 us -- register pressure)
+        constexpr int pair = i / 12, term = (i % 12) / 2, par = i & 1, kl = 2 * pair + par;
+        if constexpr (pat[term] == 2) acc1[par] = mfma(w[kl][pwt[term]], lo[4 * s + kl], acc1[par]);
+        else acc1[par] = mfma(w[kl][pwt[term]], a[kl][pat[term]], acc1[par]);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        constexpr int term = i / 4, t = i % 4;   // term-major over the four output tiles
+        constexpr int ap = pat[term];
+        acc2[t] = mfma(w[t][pwt[term]], a[ap >> 1][ap & 1], acc2[t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (FFN_ABL != 1 && (i & 1) && (i >> 1) < NL) {
+        constexpr int j = i >> 1;
+        if constexpr (s3 < 4) dma16s(src1 + j * kFrag, voff, dst + j * kFrag);
+        else dma16s(src2 + (j / 3) * nb_stride + (j % 3) * kFrag, voff, dst + j * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (FFN_ABL != 4 && i >= 12 && i < 18) {
+        constexpr int j = 2 * (i - 12);
+        wnx[j / 3][j % 3] = frag(wn_src + j * kFrag);
+        wnx[(j + 1) / 3][(j + 1) % 3] = frag(wn_src + (j + 1) * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // operand A of the next stage, where nothing orders it behind the next barrier: layer 1 reads the read-only input
+      // panel, k-steps 1 .. 3 of layer 2 a hidden chunk finished at least a stage ago (k-step 0: after the barrier)
+      constexpr int sx = (s + 1) & 7;
+      if constexpr (i >= 18 && i < 22 && sx < 4) {
+        constexpr int kl = i - 18;
+        anx[kl][0] = frag(pa + ((4 * sx + kl) * 2 + 0) * kFrag);
+        anx[kl][1] = frag(pa + ((4 * sx + kl) * 2 + 1) * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (i == 18 && sx > 4) {
+        anx[0][0] = frag(ph + ((sx - 4) * 3 + 0) * kFrag);
+        anx[0][1] = frag(ph + ((sx - 4) * 3 + 1) * kFrag);
+        anx[1][0] = frag(ph + ((sx - 4) * 3 + 2) * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+
+  // Stage g lives in ring slot g % 3.  At the top of stage g: this wave's DMAs of stage g + 1 have landed (those of g + 2
+  // may stay in flight: counted vmcnt), everybody's LDS traffic of stage g - 1 is finished (lgkmcnt(0) + barrier): the
+  // weights of stage g + 1 may be read (into the other register set) and the slot of stage g refilled with stage g + 3.
+  bf16x8 w0[4][3], w1[4][3], a0[4][2], a1[4][2];
+  f32x8 bias[4];
+  wait_vm<NL>();                      // stage 0 (stage 1 in flight)
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+  issue(0, 2, 2);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) w0[u][p] = frag(pw + (u * 3 + p) * kFrag);
+    a0[u][0] = frag(pa + (u * 2 + 0) * kFrag);
+    a0[u][1] = frag(pa + (u * 2 + 1) * kFrag);
+  }
+  int slot = 0;   // ring slot of the stage being multiplied
+#pragma unroll 1
+  for (int c = 0; c < nchunk; ++c) {
+    static_for<8>([&](auto S) {
+      constexpr int s = decltype(S)::value;
+      const int sn = slot == 2 ? 0 : slot + 1;       // slot of stage g + 1
+      // top of stage g: this wave's DMAs of stage g + 1 have landed (those of g + 2 stay in flight), everybody's LDS traffic
+      // of stage g - 1 is finished (lgkmcnt(0) + barrier)
+      FFN_STAMP(0);
+      if (FFN_ABL == 1) wait_vm<0>(); else wait_vm<NL>();
+      FFN_STAMP(1);
+      wait_lgkm0();
+      FFN_STAMP(2);
+      if (FFN_ABL != 2) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      FFN_STAMP(3);
+      if constexpr (s == 4) {          // the hidden chunk was written by the stage before: visible after this barrier
+        a0[0][0] = frag(ph + 0 * kFrag);
+        a0[0][1] = frag(ph + 1 * kFrag);
+        a0[1][0] = frag(ph + 2 * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (s == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+        // the chunk's 32 layer-1 bias values of this wave (wave-uniform) as SCALAR loads, three stages ahead of their use.
+        // (A vector load here would be waited for with vmcnt(0) by the compiler -- draining the two stages of DMA in
+        // flight: measured 35 of 91 us.)
+        const float* bp = A.b1 + 64 * chunk_of(c) + 32 * wn;
+        asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\t"
+                     "s_load_dwordx8 %3, %4, 0x60"
+                     : "=&s"(bias[0]), "=&s"(bias[1]), "=&s"(bias[2]), "=&s"(bias[3])
+                     : "s"(bp));
+      }
+      if constexpr ((s & 1) == 0) stage(S, w0, w1, a0, a1, c, sn, slot);
+      else stage(S, w1, w0, a1, a0, c, sn, slot);
+      FFN_STAMP(4);
+      if constexpr (s == 3 && FFN_ABL != 3) {
+        // bias + ReLU + split of the wave's 32 x 32 piece of the hidden chunk -> XS fragments in LDS.  The 32 bias values
+        // are wave-uniform: SCALAR loads (they do not touch the vmcnt queue the DMA waits are counted on).
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bias[0]), "+s"(bias[1]), "+s"(bias[2]), "+s"(bias[3]));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float h[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float blo = bias[q][j], bhi = bias[q][4 + j];   // bias[q] = values 8 q .. 8 q + 7 of the 32
+            h[j] = egtr_relu(acc1[0][4 * q + j] + acc1[1][4 * q + j] + (hf ? bhi : blo));
+          }
+          // hidden index inside the chunk: 32 wn + 8 q + 4 hf + j -> k-step 2 wn + (q >> 1), k-group q & 1
+          char* dst = hbuf + ((wm * 4 + 2 * wn + (q >> 1)) * 3) * kFrag + (q & 1) * 512 + li * 16 + hf * 8;
+          const xs::Split3 s0 = xs::split3_fast(h[0]), s1 = xs::split3_fast(h[1]), s2 = xs::split3_fast(h[2]),
+                           s3 = xs::split3_fast(h[3]);
+          *reinterpret_cast<uint2*>(dst) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
+          *reinterpret_cast<uint2*>(dst + kFrag) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
+          *reinterpret_cast<uint2*>(dst + 2 * kFrag) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
+        }
+      }
+      FFN_STAMP(5);
+      slot = sn;
+    });
+  }
+  wait_vm<0>();   // the surplus re-loads of the tail must have landed before this workgroup's LDS can be handed on
+
+  // ---- epilogue: D[i = n][j = m]: accumulator r <-> n = (r & 3) + 8 (r >> 2) + 4 hf of the 32-wide tile, m = lane & 31
+  const int row = r0 + wm * 32 + li;
+  const bool ln = A.gamma != nullptr;
+  float4 y[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
+      const float4 b = *reinterpret_cast<const float4*>(A.b2 + col);
+      y[t][q] = make_float4(acc2[t][4 * q + 0] + b.x, acc2[t][4 * q + 1] + b.y, acc2[t][4 * q + 2] + b.z,
+                            acc2[t][4 * q + 3] + b.w);
+    }
+  if (ln) {
+    // y = LayerNorm(x + ffn(x)) over the 256 channels of a row (dd:1343-1345).  A lane holds 64 channels of its row, lane ^ 32
+    // another 64, the wave next door (wn ^ 1) the other 128: row sums through a cross-lane swap and one LDS exchange (the
+    // ring is idle now), mean first, then the centred sum of squares.
+    const float* xr = A.x + (size_t)min(row, A.M - 1) * A.ldx;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 r = *reinterpret_cast<const float4*>(xr + (4 * wn + t) * 32 + 8 * q + 4 * hf);
+        y[t][q].x += r.x; y[t][q].y += r.y; y[t][q].z += r.z; y[t][q].w += r.w;
+      }
+    float* const red = reinterpret_cast<float*>(ring);   // [2 passes][4 waves][32 rows]
+    __syncthreads();                                      // every wave is done with the ring / the hidden chunk
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum += (y[t][q].x + y[t][q].y) + (y[t][q].z + y[t][q].w);
+    sum += __shfl_xor(sum, 32);
+    if (hf == 0) red[wave * 32 + li] = sum;
+    __syncthreads();
+    const float mean = (sum + red[(wave ^ 1) * 32 + li]) * (1.f / kD);
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y[t][q].x -= mean; y[t][q].y -= mean; y[t][q].z -= mean; y[t][q].w -= mean;
+        sq += (y[t][q].x * y[t][q].x + y[t][q].y * y[t][q].y) + (y[t][q].z * y[t][q].z + y[t][q].w * y[t][q].w);
+      }
+    sq += __shfl_xor(sq, 32);
+    if (hf == 0) red[128 + wave * 32 + li] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf((sq + red[128 + (wave ^ 1) * 32 + li]) * (1.f / kD) + A.eps);
+    const float* pr = A.out_pos != nullptr ? A.pos + (size_t)(min(row, A.M - 1) % A.pos_rows) * kD : nullptr;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
+        const float4 g = *reinterpret_cast<const float4*>(A.gamma + col), b = *reinterpret_cast<const float4*>(A.beta + col);
+        y[t][q] = make_float4(y[t][q].x * rstd * g.x + b.x, y[t][q].y * rstd * g.y + b.y, y[t][q].z * rstd * g.z + b.z,
+                              y[t][q].w * rstd * g.w + b.w);
+        if (pr != nullptr && row < A.M) {
+          const float4 p = *reinterpret_cast<const float4*>(pr + col);
+          *reinterpret_cast<float4*>(A.out_pos + (size_t)row * kD + col) =
+              make_float4(y[t][q].x + p.x, y[t][q].y + p.y, y[t][q].z + p.z, y[t][q].w + p.w);
+        }
+      }
+  }
+  if (row < A.M) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(A.out + (size_t)row * kD + (4 * wn + t) * 32 + 8 * q + 4 * hf) = y[t][q];
+  }
+}
+
+}  // namespace
+
+long long* g_ffn_tdbg = nullptr;   // development hook (tools/ffn_x6_bench.hip, FFN_TIMING builds)
+
+extern "C" int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w1_xs, const float* b1,
+                               const void* w2_xs, const float* b2, const float* ln_gamma, const float* ln_beta, float eps,
+                               const float* pos, int pos_rows, float* out, float* out_pos, int M, int d_model, int ffn_dim) {
+  if (!x || !w1_xs || !b1 || !w2_xs || !b2 || !out || M <= 0 || ldx < d_model) return EGTR_E_ARG;
+  if ((ln_gamma == nullptr) != (ln_beta == nullptr) || (out_pos && (!pos || pos_rows <= 0 || !ln_gamma))) return EGTR_E_ARG;
+  if (d_model != kD || ffn_dim <= 0 || ffn_dim % 64 || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(w1_xs) & 15) ||
+      (reinterpret_cast<uintptr_t>(w2_xs) & 15) || (reinterpret_cast<uintptr_t>(b2) & 15) ||
+      (out_pos && (reinterpret_cast<uintptr_t>(out_pos) & 15)) || (pos && (reinterpret_cast<uintptr_t>(pos) & 15)))
+    return EGTR_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLds) != hipSuccess)
+      return egtr_check_launch();
+    attr_set = true;
+  }
+  FfnArgs a{x, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln_gamma, ln_beta, pos, out,
+            out_pos, M, ldx, ffn_dim, pos_rows, eps, g_ffn_tdbg};
+  hipLaunchKernelGGL(ffn_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
+  return egtr_check_launch();
+}

@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "xs_format.h"
+#include "x6_common.h"
 
 #ifndef X6_ABL
 #define X6_ABL 0   // development ablations (tools/gemm_x6_bench.hip): 1 = no steady-state DMA, 2 = no MFMAs, 3 = no barriers
@@ -33,9 +34,7 @@
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) char lds_char;
+using namespace x6;
 
 constexpr int kMaxProblems = 8;
 constexpr int kStages = 3;
@@ -55,35 +54,6 @@ struct X6Problems {
 __device__ __forceinline__ int xcd_tile(int bid, int total) {   // every XCD owns a contiguous range of the tile order
   const int q = total >> 3, r = total & 7, x = bid & 7;
   return x * q + min(x, r) + (bid >> 3);
-}
-
-// one LDS-DMA wave-instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_dst, lds_dst + 1 KiB)
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
-}
-// lgkmcnt(0) as the BUILTIN (vmcnt 63, expcnt 7 untouched): the compiler's own wait-count bookkeeping sees it, so it does
-// not re-wait for the operand reads of the previous step in front of the MFMAs
-__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xc07f); }
-
-template <int N, int I = 0, class Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<N, I + 1>(f);
-  }
-}
-
-__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 // MT = 32-row MFMA tiles per wave along m (2: workgroup tile 128 x 128).

@@ -49,6 +49,18 @@ __device__ __forceinline__ Split3 split3(float x) {
   return s;
 }
 
+// The same without the non-finite special cases (4 VALU operations instead of 10): for a non-finite x the lower pieces come
+// out NaN (inf - inf), so the products of its row are NaN instead of +-inf / NaN -- still non-finite, still only that row.
+// Used where the split sits on a kernel's critical path (the hidden activations of the fused FFN).
+__device__ __forceinline__ Split3 split3_fast(float x) {
+  Split3 s;
+  s.hi = __float_as_uint(x) & 0xffff0000u;
+  const float r = x - __uint_as_float(s.hi);
+  s.mid = __float_as_uint(r) & 0xffff0000u;
+  s.lo = __float_as_uint(r - __uint_as_float(s.mid));
+  return s;
+}
+
 // round-to-nearest-even split (weights: prepared once, the residuals stay exact in fp32)
 __device__ __forceinline__ unsigned bf16_rne_bits(float x) {   // result in the UPPER half, low half zero
   const unsigned u = __float_as_uint(x);

@@ -768,6 +768,55 @@ def gemm_x6(items, M, K):
     return outs
 
 
+FFN_FUSED = os.environ.get("EGTR_FFN_FUSED", "1") != "0"
+
+
+def ffn_fused_supported(x, fc1, fc2, ln):
+    """The encoder layer's feed-forward block as one launch (csrc/ffn_x6.hip): fp32 inference, token-sized row counts,
+    d_model = 256, hidden width a multiple of 64."""
+    rows = x.numel() // x.shape[-1]
+    return (FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
+            and x.shape[-1] == 256 and tuple(fc1.weight.shape)[1] == 256 and fc1.weight.shape[0] % 64 == 0
+            and tuple(fc2.weight.shape) == (256, fc1.weight.shape[0]) and fc1.bias is not None and fc2.bias is not None
+            and ln.weight.shape[0] == 256 and fc1.weight.dtype == torch.float32)
+
+
+def ffn_fused(x, fc1, fc2, ln=None, pos=None):
+    """LayerNorm(x + fc2(relu(fc1(x)))) [and that + pos] in ONE HIP launch (egtr_ffn_x6_f32; reference:
+    model/deformable_detr.py:1335-1345 in eval mode); without ``ln``: fc2(relu(fc1(x))).  The [rows, ffn_dim] hidden
+    activation never leaves the compute units.  Returns y or (y, y + pos).  Inference only."""
+    lib = _lib.lib()
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    rows, F = x2.shape[0], fc1.weight.shape[0]
+    w1 = cached_weights(fc1, "xs_weight", [fc1.weight], lambda: xs_split(fc1.weight, weights=True))
+    w2 = cached_weights(fc2, "xs_weight", [fc2.weight], lambda: xs_split(fc2.weight, weights=True))
+    b1 = _chk(fc1.bias.detach().contiguous(), "fc1.bias", torch.float32)
+    b2 = _chk(fc2.bias.detach().contiguous(), "fc2.bias", torch.float32)
+    y = torch.empty(rows, K, dtype=torch.float32, device=x.device)
+    g = bt = p2 = yp = None
+    eps = 0.0
+    if ln is not None:
+        g = _chk(ln.weight.detach().contiguous(), "ln.weight", torch.float32)
+        bt = _chk(ln.bias.detach().contiguous(), "ln.bias", torch.float32)
+        eps = float(ln.eps)
+        if pos is not None:
+            p2 = _chk(pos.reshape(-1, K).contiguous(), "pos", torch.float32)
+            if rows % p2.shape[0]:
+                raise ValueError("ffn_fused: pos must tile the rows")
+            yp = torch.empty_like(y)
+    st = lib.egtr_ffn_x6_f32(_stream(), x2.data_ptr(), x2.stride(0), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                             b2.data_ptr(), g.data_ptr() if g is not None else None,
+                             bt.data_ptr() if bt is not None else None, eps, p2.data_ptr() if p2 is not None else None,
+                             p2.shape[0] if p2 is not None else 0, y.data_ptr(), yp.data_ptr() if yp is not None else None,
+                             rows, K, F)
+    _lib.check(st, "egtr_ffn_x6_f32")
+    y = y.view(x.shape)
+    return y if yp is None else (y, yp.view(x.shape))
+
+
 def module_linear(mod, x, alpha=1.0, relu=False):
     w = mod.weight
     if alpha == 1.0 and gemm_split_supported(x, w.shape[0], w.shape[1]):

@@ -450,6 +450,16 @@ int egtr_gemm_x6_f32(egtr_stream_t stream, int num_problems, const void* const* 
                      const float* const* bias, float* const* c, const int* ldc, void* const* c_xs, const int* N,
                      const int* relu, int M, int K);
 
+/* The encoder layer's feed-forward block in ONE launch (csrc/ffn_x6.hip; reference: two nn.Linear + ReLU + dropout(eval) +
+ * residual + LayerNorm, model/deformable_detr.py:1335-1345): out = fc2(relu(fc1(x))), or with ln_gamma / ln_beta
+ * out = LayerNorm(x + fc2(relu(fc1(x)))) and optionally out_pos = out + pos[row % pos_rows].  x [M, ldx] fp32;
+ * w1_xs = XS(W1 [ffn_dim, d_model]), w2_xs = XS(W2 [d_model, ffn_dim]) (egtr_xs_split_f32, round_to_nearest = 1); fp32
+ * biases; fp32-level accuracy (six bf16 cross terms per product, fp32 accumulation).  The [M, ffn_dim] hidden activation
+ * never leaves the compute units.  d_model == 256 and ffn_dim % 64 == 0, else EGTR_E_UNSUPPORTED.  Inference only. */
+int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w1_xs, const float* b1, const void* w2_xs,
+                    const float* b2, const float* ln_gamma, const float* ln_beta, float eps, const float* pos,
+                    int pos_rows, float* out, float* out_pos, int M, int d_model, int ffn_dim);
+
 /* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
  * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
  * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the

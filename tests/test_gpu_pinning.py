@@ -402,3 +402,84 @@ def test_relation_head_split_bf16_on_adversarial_operands(kind):
         assert torch.isfinite(got).all()
         assert e.max() <= 2.5 * e32.max() + 2e-6 * scale, (kind, float(e.max()), float(e32.max()), scale)
         assert e.norm() <= 2.5 * e32.norm() + 2e-6 * scale * e.numel() ** 0.5
+
+
+# ------------------------------------------------------------------------------------------------ fused FFN (csrc/ffn_x6.hip)
+def _ffn_modules(F, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    fc1, fc2, ln = torch.nn.Linear(256, F), torch.nn.Linear(F, 256), torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        fc1.weight.copy_(torch.randn(F, 256, generator=g) / 16 * scale)
+        fc1.bias.copy_(torch.randn(F, generator=g) * 0.3)
+        fc2.weight.copy_(torch.randn(256, F, generator=g) / F ** 0.5)
+        fc2.bias.copy_(torch.randn(256, generator=g) * 0.3)
+        ln.weight.copy_(1 + 0.2 * torch.randn(256, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(256, generator=g))
+    return fc1, fc2, ln
+
+
+def _ffn_ref64(x, fc1, fc2, ln=None):
+    x = x.double()
+    h = torch.relu(x @ fc1.weight.double().t() + fc1.bias.double())
+    y = h @ fc2.weight.double().t() + fc2.bias.double()
+    if ln is None:
+        return y
+    return torch.nn.functional.layer_norm(x + y, (256,), ln.weight.double(), ln.bias.double(), ln.eps)
+
+
+@pytest.mark.parametrize("M,F,kind", [(12537, 1024, "plain"), (4100, 1024, "large"), (4100, 2048, "wide-range"),
+                                      (333, 64, "plain"), (4100, 1024, "cancelling")])
+def test_fused_ffn_vs_float64(M, F, kind):
+    """egtr_ffn_x6_f32 -- fc1 + ReLU + fc2 (+ residual + LayerNorm + position output) in one launch, the hidden activation
+    never in HBM -- against float64, and against the fp32 composition it replaces (dd:1335-1345): no further from float64
+    than 2.5x that composition (+ a floor of 2e-6 of the output scale), rows of every magnitude."""
+    from egtr_amd import ops
+    fc1, fc2, ln = _ffn_modules(F, 11 + F)
+    rng = W.rng_inputs(6000 + M)
+    x = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    if kind == "large":
+        x = x * 300
+    elif kind == "wide-range":
+        x = x * torch.pow(2.0, torch.from_numpy(rng.integers(-40, 30, (M, 1))).float())
+    elif kind == "cancelling":
+        x[:, 1::2] = -x[:, 0::2] * (1 + 1e-6)
+        with torch.no_grad():
+            fc1.weight[:, 1::2] = fc1.weight[:, 0::2]
+    pos = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    import copy
+    fd1, fd2, lnd = (copy.deepcopy(m).to(DEV) for m in (fc1, fc2, ln))
+    xd = x.to(DEV)
+    with torch.no_grad():
+        y_plain = ops.ffn_fused(xd, fd1, fd2)
+        y_ln, y_pos = ops.ffn_fused(xd, fd1, fd2, lnd, pos.to(DEV))
+        h32 = torch.relu(torch.nn.functional.linear(xd, fd1.weight, fd1.bias))
+        c_plain = torch.nn.functional.linear(h32, fd2.weight, fd2.bias)
+        c_ln = lnd(xd + c_plain)
+    r_plain, r_ln = _ffn_ref64(x, fc1, fc2), _ffn_ref64(x, fc1, fc2, ln)
+    for got, comp, ref in ((y_plain, c_plain, r_plain), (y_ln, c_ln, r_ln)):
+        e, e32 = (got.cpu().double() - ref).abs(), (comp.cpu().double() - ref).abs()
+        scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-30)            # per row: rows differ by many binades
+        assert torch.isfinite(got).all()
+        assert ((e / scale).amax(1) <= 2.5 * (e32 / scale).amax(1) + 2e-6).all(), (kind, float((e / scale).max()))
+    assert torch.equal(y_pos, y_ln + pos.to(DEV))
+    assert torch.equal(y_ln, ops.ffn_fused(xd, fd1, fd2, lnd))               # bit-reproducible, with or without pos
+
+
+def test_fused_ffn_non_finite_rows_only():
+    """An inf / NaN input element makes exactly ITS output row non-finite; every other row is bit-identical."""
+    from egtr_amd import ops
+    fc1, fc2, ln = _ffn_modules(1024, 5)
+    M = 4100
+    x = torch.from_numpy(W.rng_inputs(6100).standard_normal((M, 256))).float()
+    bad = {0: float("inf"), 63: float("nan"), 64: float("-inf"), 4099: float("nan")}
+    xb = x.clone()
+    for r, v in bad.items():
+        xb[r, (5 * r) % 256] = v
+    import copy
+    fd1, fd2, lnd = (copy.deepcopy(m).to(DEV) for m in (fc1, fc2, ln))
+    with torch.no_grad():
+        clean, dirty = ops.ffn_fused(x.to(DEV), fd1, fd2, lnd).cpu(), ops.ffn_fused(xb.to(DEV), fd1, fd2, lnd).cpu()
+    good = torch.ones(M, dtype=torch.bool)
+    good[list(bad)] = False
+    assert torch.equal(clean[good], dirty[good])
+    assert not torch.isfinite(dirty[~good]).any()
