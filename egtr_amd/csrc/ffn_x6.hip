@@ -53,6 +53,7 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 struct FfnArgs {
   const float* x;        // [M, ldx] fp32
+  const float* res;      // residual rows [M, ldr] added before the LayerNorm (the FFN: x itself)
   const char* w1;        // XS(W1 [F, 256])
   const float* b1;       // [F]
   const char* w2;        // XS(W2 [256, F])
@@ -62,10 +63,109 @@ struct FfnArgs {
   const float* pos;      // [pos_rows, 256] or null
   float* out;            // [M, 256]
   float* out_pos;        // [M, 256] = out + pos[row % pos_rows], or null
-  int M, ldx, F, pos_rows;
+  int M, ldx, ldr, F, pos_rows;
   float eps;
   long long* tdbg;   // development: cycle stamps of wave 0 of workgroup 0 (FFN_TIMING builds), else null
 };
+
+// The 64 x 256 fp32 input panel of a workgroup -> MFMA operand fragments: hi / mid pieces into `panel`
+// ([row block 2][k-step 16][hi, mid] KiB), lo pieces of row block 0 / 1 into lo0 / lo1 ([k-step 16] KiB each, parking
+// places from which every wave then reads the 16 lo fragments of ITS row block into registers).  No synchronisation inside.
+__device__ __forceinline__ void build_panel(const float* __restrict__ x, int ldx, int M, int r0, int tid, int lane,
+                                            char* panel, char* lo0, char* lo1) {
+  float4 v[16];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = min(r0 + it * 4 + (tid >> 6), M - 1);
+    v[it] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + 4 * lane);
+  }
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + (tid >> 6), rb = row >> 5, r = row & 31;
+    const int ks = lane >> 2, off = ((lane >> 1) & 1) * 512 + r * 16 + (lane & 1) * 8;
+    const xs::Split3 s0 = xs::split3(v[it].x), s1 = xs::split3(v[it].y), s2 = xs::split3(v[it].z), s3 = xs::split3(v[it].w);
+    char* p = panel + ((rb * kKS + ks) * 2) * kFrag + off;
+    *reinterpret_cast<uint2*>(p) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
+    *reinterpret_cast<uint2*>(p + kFrag) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
+    char* q = (rb == 0 ? lo0 : lo1) + ks * kFrag + off;
+    *reinterpret_cast<uint2*>(q) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
+  }
+}
+
+// Output tile of a workgroup: y = acc + bias2; with LayerNorm parameters y = LayerNorm(res + y) over the 256 channels of a
+// row (dd:1329-1330, 1343-1345) and optionally y + pos.  D[i = n][j = m]: accumulator r <-> n = (r & 3) + 8 (r >> 2) + 4 hf
+// of the 32-wide tile, m = lane & 31: a lane holds 64 channels of its row, lane ^ 32 another 64, the wave next door (wn ^ 1)
+// the other 128 -- row sums through a cross-lane swap and one exchange through `red` (1 KiB of idle LDS), mean first, then
+// the centred sum of squares.
+__device__ __forceinline__ void final_epilogue(const f32x16 (&acc2)[4], const FfnArgs& A, int r0, int wave, int lane,
+                                               float* red) {
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hf = lane >> 5;
+  const int row = r0 + wm * 32 + li;
+  float4 y[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
+      const float4 b = *reinterpret_cast<const float4*>(A.b2 + col);
+      y[t][q] = make_float4(acc2[t][4 * q + 0] + b.x, acc2[t][4 * q + 1] + b.y, acc2[t][4 * q + 2] + b.z,
+                            acc2[t][4 * q + 3] + b.w);
+    }
+  if (A.gamma != nullptr) {
+    const float* xr = A.res + (size_t)min(row, A.M - 1) * A.ldr;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 r = *reinterpret_cast<const float4*>(xr + (4 * wn + t) * 32 + 8 * q + 4 * hf);
+        y[t][q].x += r.x; y[t][q].y += r.y; y[t][q].z += r.z; y[t][q].w += r.w;
+      }
+    __syncthreads();                                      // every wave is done with the LDS `red` aliases
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum += (y[t][q].x + y[t][q].y) + (y[t][q].z + y[t][q].w);
+    sum += __shfl_xor(sum, 32);
+    if (hf == 0) red[wave * 32 + li] = sum;
+    __syncthreads();
+    const float mean = (sum + red[(wave ^ 1) * 32 + li]) * (1.f / kD);
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y[t][q].x -= mean; y[t][q].y -= mean; y[t][q].z -= mean; y[t][q].w -= mean;
+        sq += (y[t][q].x * y[t][q].x + y[t][q].y * y[t][q].y) + (y[t][q].z * y[t][q].z + y[t][q].w * y[t][q].w);
+      }
+    sq += __shfl_xor(sq, 32);
+    if (hf == 0) red[128 + wave * 32 + li] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf((sq + red[128 + (wave ^ 1) * 32 + li]) * (1.f / kD) + A.eps);
+    const float* pr = A.out_pos != nullptr ? A.pos + (size_t)(min(row, A.M - 1) % A.pos_rows) * kD : nullptr;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
+        const float4 g = *reinterpret_cast<const float4*>(A.gamma + col), b = *reinterpret_cast<const float4*>(A.beta + col);
+        y[t][q] = make_float4(y[t][q].x * rstd * g.x + b.x, y[t][q].y * rstd * g.y + b.y, y[t][q].z * rstd * g.z + b.z,
+                              y[t][q].w * rstd * g.w + b.w);
+        if (pr != nullptr && row < A.M) {
+          const float4 p = *reinterpret_cast<const float4*>(pr + col);
+          *reinterpret_cast<float4*>(A.out_pos + (size_t)row * kD + col) =
+              make_float4(y[t][q].x + p.x, y[t][q].y + p.y, y[t][q].z + p.z, y[t][q].w + p.w);
+        }
+      }
+  }
+  if (row < A.M) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(A.out + (size_t)row * kD + (4 * wn + t) * 32 + 8 * q + 4 * hf) = y[t][q];
+  }
+}
 
 __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -109,28 +209,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   issue(0, 0, 0);
   issue(0, 1, 1);
 
-  // ---- input panel: 64 rows x 256 fp32 -> hi / mid fragments in LDS, lo fragments via LDS into registers
-  {
-    float4 v[16];
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = min(r0 + it * 4 + (tid >> 6), A.M - 1);
-      v[it] = *reinterpret_cast<const float4*>(A.x + (size_t)row * A.ldx + 4 * lane);
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int row = it * 4 + (tid >> 6), rb = row >> 5, r = row & 31;
-      const int ks = lane >> 2, off = ((lane >> 1) & 1) * 512 + r * 16 + (lane & 1) * 8;
-      const xs::Split3 s0 = xs::split3(v[it].x), s1 = xs::split3(v[it].y), s2 = xs::split3(v[it].z),
-                       s3 = xs::split3(v[it].w);
-      char* p = panel + ((rb * kKS + ks) * 2) * kFrag + off;
-      *reinterpret_cast<uint2*>(p) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
-      *reinterpret_cast<uint2*>(p + kFrag) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
-      // lo pieces: row block 0 parks in the hidden-chunk buffer, row block 1 in ring slot 2 (both idle until stage 0)
-      char* q = (rb == 0 ? hbuf : ring + 2 * kStage) + ks * kFrag + off;
-      *reinterpret_cast<uint2*>(q) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
-    }
-  }
+  build_panel(A.x, A.ldx, A.M, r0, tid, lane, panel, hbuf, ring + 2 * kStage);
   __syncthreads();
   bf16x8 lo[kKS];
   {
@@ -300,77 +379,99 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   }
   wait_vm<0>();   // the surplus re-loads of the tail must have landed before this workgroup's LDS can be handed on
 
-  // ---- epilogue: D[i = n][j = m]: accumulator r <-> n = (r & 3) + 8 (r >> 2) + 4 hf of the 32-wide tile, m = lane & 31
-  const int row = r0 + wm * 32 + li;
-  const bool ln = A.gamma != nullptr;
-  float4 y[4][4];
+  final_epilogue(acc2, A, r0, wave, lane, reinterpret_cast<float*>(ring));
+}
+
+
+// y = [LayerNorm(res +] x . W^T + b [)] for a 256 -> 256 linear layer (the attention block's output projection with its
+// residual + LayerNorm, dd:1102, 1329-1330) with the same machinery: input panel split once (hi / mid in LDS, lo in
+// registers), the weights as 16 stages of one k-step ([8 n-blocks][3 pieces] = 24 KiB, 24 MFMAs per wave) through the
+// three-slot DMA ring, the output tile 64 x 256 in four accumulators per wave.
+__global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const panel = smem;
+  char* const ring = smem + kPanel;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned lds_ring = (unsigned)reinterpret_cast<uintptr_t>((lds_char*)ring);
+  const int r0 = blockIdx.x * kRows;
+  const unsigned voff = lane * 16;
+  // stage ks: fragments (nb, p) of W's k-step ks at ((nb * 16 + ks) * 3 + p) KiB; wave w moves n-blocks 2 w, 2 w + 1
+  auto issue = [&](int ks, int slot) {
+    ks = min(ks, kKS - 1);   // past the end: re-load the last stage (never read)
+    const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+      dma16s(A.w2 + ((size_t)((2 * wave + i / 3) * kKS + ks) * 3 + i % 3) * kFrag, voff, dst + i * kFrag);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  build_panel(A.x, A.ldx, A.M, r0, tid, lane, panel, ring + 2 * kStage, ring + 2 * kStage + kKS * kFrag);
+  __syncthreads();
+  bf16x8 lo[kKS];
+  {
+    const char* q = ring + 2 * kStage + wm * (kKS * kFrag) + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag);
+  }
+  f32x16 acc2[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
-      const float4 b = *reinterpret_cast<const float4*>(A.b2 + col);
-      y[t][q] = make_float4(acc2[t][4 * q + 0] + b.x, acc2[t][4 * q + 1] + b.y, acc2[t][4 * q + 2] + b.z,
-                            acc2[t][4 * q + 3] + b.w);
-    }
-  if (ln) {
-    // y = LayerNorm(x + ffn(x)) over the 256 channels of a row (dd:1343-1345).  A lane holds 64 channels of its row, lane ^ 32
-    // another 64, the wave next door (wn ^ 1) the other 128: row sums through a cross-lane swap and one LDS exchange (the
-    // ring is idle now), mean first, then the centred sum of squares.
-    const float* xr = A.x + (size_t)min(row, A.M - 1) * A.ldx;
+    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+  const char* const pa = panel + (wm * kKS * 2) * kFrag + lane * 16;
+  const char* const pw = ring + (4 * wn * 3) * kFrag + lane * 16;
+  auto frag = [](const char* p) { return *reinterpret_cast<const bf16x8*>(p); };
+  bf16x8 w0[4][3], w1[4][3];
+  wait_vm<NL>();
+  wait_lgkm0();
+  __builtin_amdgcn_s_barrier();
+  issue(2, 2);
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 r = *reinterpret_cast<const float4*>(xr + (4 * wn + t) * 32 + 8 * q + 4 * hf);
-        y[t][q].x += r.x; y[t][q].y += r.y; y[t][q].z += r.z; y[t][q].w += r.w;
+    for (int p = 0; p < 3; ++p) w0[u][p] = frag(pw + (u * 3 + p) * kFrag);
+  bf16x8 ahi = frag(pa), amid = frag(pa + kFrag);
+  static_for<kKS>([&](auto S) {
+    constexpr int ks = decltype(S)::value;
+    constexpr int slot = ks % 3, sn = (ks + 1) % 3;
+    wait_vm<NL>();
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const bf16x8 (&w)[4][3] = (ks & 1) ? w1 : w0;
+    bf16x8 (&wnx)[4][3] = (ks & 1) ? w0 : w1;
+    const bf16x8 a0 = ahi, a1 = amid;
+    const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
+    constexpr int ks3 = ks + 3 < kKS ? ks + 3 : kKS - 1;
+    static_for<24>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      constexpr int pwt[6] = {2, 0, 1, 1, 0, 0}, pat[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int term = i / 4, t = i % 4;
+      if constexpr (pat[term] == 2) acc2[t] = mfma(w[t][pwt[term]], lo[ks], acc2[t]);
+      else acc2[t] = mfma(w[t][pwt[term]], pat[term] == 0 ? a0 : a1, acc2[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((i & 1) && (i >> 1) < NL) {
+        constexpr int j = i >> 1;
+        dma16s(A.w2 + ((size_t)((2 * wave + j / 3) * kKS + ks3) * 3 + j % 3) * kFrag, voff, dst + j * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    float* const red = reinterpret_cast<float*>(ring);   // [2 passes][4 waves][32 rows]
-    __syncthreads();                                      // every wave is done with the ring / the hidden chunk
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sum += (y[t][q].x + y[t][q].y) + (y[t][q].z + y[t][q].w);
-    sum += __shfl_xor(sum, 32);
-    if (hf == 0) red[wave * 32 + li] = sum;
-    __syncthreads();
-    const float mean = (sum + red[(wave ^ 1) * 32 + li]) * (1.f / kD);
-    float sq = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        y[t][q].x -= mean; y[t][q].y -= mean; y[t][q].z -= mean; y[t][q].w -= mean;
-        sq += (y[t][q].x * y[t][q].x + y[t][q].y * y[t][q].y) + (y[t][q].z * y[t][q].z + y[t][q].w * y[t][q].w);
+      if constexpr (i >= 12 && i < 18) {
+        constexpr int j = 2 * (i - 12);
+        wnx[j / 3][j % 3] = frag(pw + sn * kStage + j * kFrag);
+        wnx[(j + 1) / 3][(j + 1) % 3] = frag(pw + sn * kStage + (j + 1) * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
       }
-    sq += __shfl_xor(sq, 32);
-    if (hf == 0) red[128 + wave * 32 + li] = sq;
-    __syncthreads();
-    const float rstd = rsqrtf((sq + red[128 + (wave ^ 1) * 32 + li]) * (1.f / kD) + A.eps);
-    const float* pr = A.out_pos != nullptr ? A.pos + (size_t)(min(row, A.M - 1) % A.pos_rows) * kD : nullptr;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
-        const float4 g = *reinterpret_cast<const float4*>(A.gamma + col), b = *reinterpret_cast<const float4*>(A.beta + col);
-        y[t][q] = make_float4(y[t][q].x * rstd * g.x + b.x, y[t][q].y * rstd * g.y + b.y, y[t][q].z * rstd * g.z + b.z,
-                              y[t][q].w * rstd * g.w + b.w);
-        if (pr != nullptr && row < A.M) {
-          const float4 p = *reinterpret_cast<const float4*>(pr + col);
-          *reinterpret_cast<float4*>(A.out_pos + (size_t)row * kD + col) =
-              make_float4(y[t][q].x + p.x, y[t][q].y + p.y, y[t][q].z + p.z, y[t][q].w + p.w);
-        }
+      if constexpr (i == 18 && ks + 1 < kKS) {
+        ahi = frag(pa + ((ks + 1) * 2) * kFrag);
+        amid = frag(pa + ((ks + 1) * 2 + 1) * kFrag);
+        __builtin_amdgcn_sched_barrier(0);
       }
-  }
-  if (row < A.M) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(A.out + (size_t)row * kD + (4 * wn + t) * 32 + 8 * q + 4 * hf) = y[t][q];
-  }
+    });
+  });
+  wait_vm<0>();
+  final_epilogue(acc2, A, r0, wave, lane, reinterpret_cast<float*>(ring));
 }
 
 }  // namespace
@@ -394,8 +495,34 @@ extern "C" int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, co
       return egtr_check_launch();
     attr_set = true;
   }
-  FfnArgs a{x, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln_gamma, ln_beta, pos, out,
-            out_pos, M, ldx, ffn_dim, pos_rows, eps, g_ffn_tdbg};
+  FfnArgs a{x, x, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln_gamma, ln_beta, pos, out,
+            out_pos, M, ldx, ldx, ffn_dim, pos_rows, eps, g_ffn_tdbg};
   hipLaunchKernelGGL(ffn_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_proj_ln_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w_xs, const float* bias,
+                                   const float* residual, int ldr, const float* ln_gamma, const float* ln_beta, float eps,
+                                   const float* pos, int pos_rows, float* out, float* out_pos, int M, int d_model) {
+  if (!x || !w_xs || !bias || !out || M <= 0 || ldx < d_model) return EGTR_E_ARG;
+  if ((ln_gamma == nullptr) != (ln_beta == nullptr) || (ln_gamma && (!residual || ldr < d_model)) ||
+      (out_pos && (!pos || pos_rows <= 0 || !ln_gamma)))
+    return EGTR_E_ARG;
+  if (d_model != kD || (ldx & 3) || (ldr & 3) || (reinterpret_cast<uintptr_t>(x) & 15) ||
+      (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(w_xs) & 15) ||
+      (reinterpret_cast<uintptr_t>(bias) & 15) || (reinterpret_cast<uintptr_t>(residual) & 15) ||
+      (out_pos && (reinterpret_cast<uintptr_t>(out_pos) & 15)) || (pos && (reinterpret_cast<uintptr_t>(pos) & 15)))
+    return EGTR_E_UNSUPPORTED;
+  constexpr int lds = kPanel + 3 * kStage + 8 * kFrag;   // + 8 KiB: parking place of the second row block's lo pieces
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(proj_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return egtr_check_launch();
+    attr_set = true;
+  }
+  FfnArgs a{x, residual, nullptr, nullptr, static_cast<const char*>(w_xs), bias, ln_gamma, ln_beta, pos, out, out_pos,
+            M, ldx, ldr, 0, pos_rows, eps, nullptr};
+  hipLaunchKernelGGL(proj_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), lds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }

@@ -344,7 +344,7 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                 encoder_hidden_states=None, encoder_attention_mask=None,
                 position_embeddings: Optional[torch.Tensor] = None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, output_attentions: bool = False, spatial_shapes_list=None,
-                hidden_with_pos=None, precomputed_value=None):
+                hidden_with_pos=None, precomputed_value=None, residual_ln=None):
         # hidden_with_pos / precomputed_value: inference-only hand-ins that save launches (the previous LayerNorm
         # kernel also wrote hidden + pos; the decoder projects the values of all its layers in one batched GEMM)
         if hidden_with_pos is not None:
@@ -477,6 +477,13 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
             output = MultiScaleDeformableAttentionFunction.apply(
                 value.contiguous(), spatial_shapes, level_start_index, sampling_locations.contiguous(),
                 attention_weights.contiguous(), self.im2col_step)
+        if residual_ln is not None:
+            # inference plumbing: (residual, LayerNorm) of the enclosing layer -- the output projection, the residual add
+            # and the LayerNorm (dd:1102, 1326-1330) as ONE launch where it applies; the third result says whether it did
+            residual, ln = residual_ln
+            if ops.proj_ln_fused_supported(output, self.output_proj, ln):
+                return ops.proj_ln_fused(output, self.output_proj, residual, ln), attention_weights, True
+            return ops.module_linear(self.output_proj, output), attention_weights, False
         output = ops.module_linear(self.output_proj, output)
         return output, attention_weights
 
@@ -591,14 +598,17 @@ class DeformableDetrEncoderLayer(nn.Module):
         """``hidden_with_pos`` / ``return_with_pos`` (inference plumbing): hidden + position embeddings handed in by
         the previous layer / appended to the outputs for the next one (written by the final LayerNorm kernel)."""
         residual = hidden_states
-        hidden_states, attn_weights = self.self_attn(
+        fuse = not self.training and ops.inference_fast_path(hidden_states)
+        res = self.self_attn(
             hidden_states=hidden_states, attention_mask=attention_mask, encoder_hidden_states=hidden_states,
             encoder_attention_mask=attention_mask, position_embeddings=position_embeddings,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
-            hidden_with_pos=hidden_with_pos)
-        hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
+            hidden_with_pos=hidden_with_pos, residual_ln=(residual, self.self_attn_layer_norm) if fuse else None)
+        hidden_states, attn_weights = res[0], res[1]
+        if not (fuse and res[2]):
+            hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
+            hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
         residual = hidden_states
         if (self.activation_fn is F.relu and not self.training
                 and ops.ffn_fused_supported(hidden_states, self.fc1, self.fc2, self.final_layer_norm)):

@@ -817,6 +817,48 @@ def ffn_fused(x, fc1, fc2, ln=None, pos=None):
     return y if yp is None else (y, yp.view(x.shape))
 
 
+def proj_ln_fused_supported(x, lin, ln):
+    rows = x.numel() // x.shape[-1]
+    return (FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
+            and x.shape[-1] == 256 and tuple(lin.weight.shape) == (256, 256) and lin.bias is not None
+            and ln.weight.shape[0] == 256 and lin.weight.dtype == torch.float32)
+
+
+def proj_ln_fused(x, lin, residual=None, ln=None, pos=None):
+    """LayerNorm(residual + lin(x)) [and that + pos] for a 256 -> 256 nn.Linear in ONE HIP launch (egtr_proj_ln_x6_f32;
+    reference: the attention output projection + residual + LayerNorm, model/deformable_detr.py:1102, 1326-1330); without
+    ``ln``: lin(x).  Returns y or (y, y + pos).  Inference only."""
+    lib = _lib.lib()
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    w = cached_weights(lin, "xs_weight", [lin.weight], lambda: xs_split(lin.weight, weights=True))
+    b = _chk(lin.bias.detach().contiguous(), "bias", torch.float32)
+    y = torch.empty(rows, K, dtype=torch.float32, device=x.device)
+    g = bt = p2 = yp = r2 = None
+    eps = 0.0
+    if ln is not None:
+        r2 = residual.reshape(-1, K)
+        if r2.stride(1) != 1 or r2.stride(0) % 4 or r2.data_ptr() % 16:
+            r2 = r2.contiguous()
+        g = _chk(ln.weight.detach().contiguous(), "ln.weight", torch.float32)
+        bt = _chk(ln.bias.detach().contiguous(), "ln.bias", torch.float32)
+        eps = float(ln.eps)
+        if pos is not None:
+            p2 = _chk(pos.reshape(-1, K).contiguous(), "pos", torch.float32)
+            yp = torch.empty_like(y)
+    st = lib.egtr_proj_ln_x6_f32(_stream(), x2.data_ptr(), x2.stride(0), w.data_ptr(), b.data_ptr(),
+                                 r2.data_ptr() if r2 is not None else None, r2.stride(0) if r2 is not None else 0,
+                                 g.data_ptr() if g is not None else None, bt.data_ptr() if bt is not None else None, eps,
+                                 p2.data_ptr() if p2 is not None else None, p2.shape[0] if p2 is not None else 0,
+                                 y.data_ptr(), yp.data_ptr() if yp is not None else None, rows, K)
+    _lib.check(st, "egtr_proj_ln_x6_f32")
+    y = y.view(x.shape)
+    return y if yp is None else (y, yp.view(x.shape))
+
+
 def module_linear(mod, x, alpha=1.0, relu=False):
     w = mod.weight
     if alpha == 1.0 and gemm_split_supported(x, w.shape[0], w.shape[1]):

@@ -460,6 +460,15 @@ int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w
                     const float* b2, const float* ln_gamma, const float* ln_beta, float eps, const float* pos,
                     int pos_rows, float* out, float* out_pos, int M, int d_model, int ffn_dim);
 
+/* y = x . W^T + bias for a 256 -> 256 linear layer, or with ln_gamma / ln_beta y = LayerNorm(residual + x . W^T + bias) and
+ * optionally out_pos = y + pos[row % pos_rows], in ONE launch (csrc/ffn_x6.hip, proj_x6_kernel): the attention block's
+ * output projection with its residual add and LayerNorm (model/deformable_detr.py:1102, 1326-1330).  w_xs = XS(W [256, 256])
+ * (egtr_xs_split_f32, round_to_nearest = 1); x [M, ldx], residual [M, ldr] fp32; fp32-level accuracy.  d_model == 256,
+ * else EGTR_E_UNSUPPORTED.  Inference only. */
+int egtr_proj_ln_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w_xs, const float* bias,
+                        const float* residual, int ldr, const float* ln_gamma, const float* ln_beta, float eps,
+                        const float* pos, int pos_rows, float* out, float* out_pos, int M, int d_model);
+
 /* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
  * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
  * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the

@@ -483,3 +483,42 @@ def test_fused_ffn_non_finite_rows_only():
     good[list(bad)] = False
     assert torch.equal(clean[good], dirty[good])
     assert not torch.isfinite(dirty[~good]).any()
+
+
+@pytest.mark.parametrize("M,kind", [(12537, "plain"), (4100, "large"), (4133, "wide-range"), (65, "plain")])
+def test_fused_projection_layernorm_vs_float64(M, kind):
+    """egtr_proj_ln_x6_f32 -- the attention output projection + residual + LayerNorm (+ position output) in one launch
+    (dd:1102, 1326-1330) -- against float64 and against the fp32 composition it replaces: per row within 2.5x (+ 2e-6 of
+    the row's scale)."""
+    import copy
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(77)
+    lin, ln = torch.nn.Linear(256, 256), torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(256, 256, generator=g) / 16)
+        lin.bias.copy_(torch.randn(256, generator=g) * 0.3)
+        ln.weight.copy_(1 + 0.2 * torch.randn(256, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(256, generator=g))
+    rng = W.rng_inputs(6300 + M)
+    x = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    res = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    if kind == "large":
+        x, res = x * 300, res * 300
+    elif kind == "wide-range":
+        sc = torch.pow(2.0, torch.from_numpy(rng.integers(-40, 30, (M, 1))).float())
+        x, res = x * sc, res * sc
+    pos = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    lind, lnd = copy.deepcopy(lin).to(DEV), copy.deepcopy(ln).to(DEV)
+    with torch.no_grad():
+        y_plain = ops.proj_ln_fused(x.to(DEV), lind)
+        y_ln, y_pos = ops.proj_ln_fused(x.to(DEV), lind, res.to(DEV), lnd, pos.to(DEV))
+        c_plain = lind(x.to(DEV))
+        c_ln = lnd(res.to(DEV) + c_plain)
+    r_plain = x.double() @ lin.weight.double().t() + lin.bias.double()
+    r_ln = torch.nn.functional.layer_norm(res.double() + r_plain, (256,), ln.weight.double(), ln.bias.double(), ln.eps)
+    for got, comp, ref in ((y_plain, c_plain, r_plain), (y_ln, c_ln, r_ln)):
+        e, e32 = (got.cpu().double() - ref).abs(), (comp.cpu().double() - ref).abs()
+        scale = ref.abs().amax(1, keepdim=True).clamp_min(1e-30)
+        assert torch.isfinite(got).all()
+        assert ((e / scale).amax(1) <= 2.5 * (e32 / scale).amax(1) + 2e-6).all(), (kind, float((e / scale).max()))
+    assert torch.equal(y_pos, y_ln + pos.to(DEV))
