@@ -78,6 +78,7 @@ SIGNATURES = {
     "egtr_pad_batch_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "egtr_ffn_x6_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I, _I],
     "egtr_proj_ln_x6_f32": [_P, _P, _I, _P, _P, _P, _I, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I],
+    "egtr_proj_multi_x6_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I],
     "egtr_xs_bytes": [_I, _I],
     "egtr_xs_split_f32": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _I],
     "egtr_gemm_x6_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],

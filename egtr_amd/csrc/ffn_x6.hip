@@ -32,8 +32,15 @@
       A.tdbg[s * 6 + (k)] = (long long)__builtin_readcyclecounter();                             \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   } while (0)
+#define FFN_PHASE(k)                                                                             \
+  do {                                                                                           \
+    if (A.tdbg != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))                 \
+      A.tdbg[48 + (blockIdx.x ? 4 : 0) + (k)] = (long long)__builtin_readcyclecounter();         \
+    __builtin_amdgcn_sched_barrier(0);                                                           \
+  } while (0)
 #else
 #define FFN_STAMP(k)
+#define FFN_PHASE(k)
 #endif
 
 namespace {
@@ -107,7 +114,7 @@ __device__ __forceinline__ void final_epilogue(const f32x16 (&acc2)[4], const Ff
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
-      const float4 b = *reinterpret_cast<const float4*>(A.b2 + col);
+      const float4 b = A.b2 != nullptr ? *reinterpret_cast<const float4*>(A.b2 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
       y[t][q] = make_float4(acc2[t][4 * q + 0] + b.x, acc2[t][4 * q + 1] + b.y, acc2[t][4 * q + 2] + b.z,
                             acc2[t][4 * q + 3] + b.w);
     }
@@ -378,15 +385,19 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
     });
   }
   wait_vm<0>();   // the surplus re-loads of the tail must have landed before this workgroup's LDS can be handed on
-
+  FFN_PHASE(2);
   final_epilogue(acc2, A, r0, wave, lane, reinterpret_cast<float*>(ring));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FFN_PHASE(3);
 }
 
 
-// y = [LayerNorm(res +] x . W^T + b [)] for a 256 -> 256 linear layer (the attention block's output projection with its
-// residual + LayerNorm, dd:1102, 1329-1330) with the same machinery: input panel split once (hi / mid in LDS, lo in
-// registers), the weights as 16 stages of one k-step ([8 n-blocks][3 pieces] = 24 KiB, 24 MFMAs per wave) through the
-// three-slot DMA ring, the output tile 64 x 256 in four accumulators per wave.
+// y_w = x . W_w^T + b_w for nw stacked 256 -> 256 linear layers applied to the SAME rows (nw = 1: optionally followed by
+// LayerNorm(res + y), the attention block's output projection with its residual + LayerNorm, dd:1102, 1326-1330; nw = 6: the
+// decoder's six cross-attention value projections of the encoder output, dd:1048-1049) with the same machinery: the input
+// panel is split once (hi / mid in LDS, lo in registers) and re-used by every weight, the weights run as 16 nw stages of one
+// k-step ([8 n-blocks][3 pieces] = 24 KiB, 24 MFMAs per wave) through the three-slot DMA ring, the 64 x 256 output tile sits
+// in four accumulators per wave; the stores of weight w drain while weight w + 1 is multiplied.
 __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const panel = smem;
@@ -397,13 +408,18 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
   const unsigned lds_ring = (unsigned)reinterpret_cast<uintptr_t>((lds_char*)ring);
   const int r0 = blockIdx.x * kRows;
   const unsigned voff = lane * 16;
-  // stage ks: fragments (nb, p) of W's k-step ks at ((nb * 16 + ks) * 3 + p) KiB; wave w moves n-blocks 2 w, 2 w + 1
+  const int nw = A.F;
+  // stage (w, ks): fragments (nb, p) of k-step ks of weight w at (((8 w + nb) * 16 + ks) * 3 + p) KiB; a wave moves
+  // n-blocks 2 wave, 2 wave + 1.  Past the last stage: re-load it (never read; keeps the wait counts immediates).
+  auto src_of = [&](int w, int ks, int j) {
+    if (ks >= kKS) { ks -= kKS; ++w; }
+    if (w >= nw) { w = nw - 1; ks = kKS - 1; }
+    return A.w2 + ((size_t)((8 * w + 2 * wave + j / 3) * kKS + ks) * 3 + j % 3) * kFrag;
+  };
   auto issue = [&](int ks, int slot) {
-    ks = min(ks, kKS - 1);   // past the end: re-load the last stage (never read)
     const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
 #pragma unroll
-    for (int i = 0; i < NL; ++i)
-      dma16s(A.w2 + ((size_t)((2 * wave + i / 3) * kKS + ks) * 3 + i % 3) * kFrag, voff, dst + i * kFrag);
+    for (int i = 0; i < NL; ++i) dma16s(src_of(0, ks, i), voff, dst + i * kFrag);
   };
   issue(0, 0);
   issue(1, 1);
@@ -415,11 +431,6 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag);
   }
-  f32x16 acc2[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
   const char* const pa = panel + (wm * kKS * 2) * kFrag + lane * 16;
   const char* const pw = ring + (4 * wn * 3) * kFrag + lane * 16;
   auto frag = [](const char* p) { return *reinterpret_cast<const bf16x8*>(p); };
@@ -433,45 +444,57 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) w0[u][p] = frag(pw + (u * 3 + p) * kFrag);
   bf16x8 ahi = frag(pa), amid = frag(pa + kFrag);
-  static_for<kKS>([&](auto S) {
-    constexpr int ks = decltype(S)::value;
-    constexpr int slot = ks % 3, sn = (ks + 1) % 3;
-    wait_vm<NL>();
-    wait_lgkm0();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    const bf16x8 (&w)[4][3] = (ks & 1) ? w1 : w0;
-    bf16x8 (&wnx)[4][3] = (ks & 1) ? w0 : w1;
-    const bf16x8 a0 = ahi, a1 = amid;
-    const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
-    constexpr int ks3 = ks + 3 < kKS ? ks + 3 : kKS - 1;
-    static_for<24>([&](auto I) {
-      constexpr int i = decltype(I)::value;
-      constexpr int pwt[6] = {2, 0, 1, 1, 0, 0}, pat[6] = {0, 2, 1, 0, 1, 0};
-      constexpr int term = i / 4, t = i % 4;
-      if constexpr (pat[term] == 2) acc2[t] = mfma(w[t][pwt[term]], lo[ks], acc2[t]);
-      else acc2[t] = mfma(w[t][pwt[term]], pat[term] == 0 ? a0 : a1, acc2[t]);
+  int slot = 0;   // ring slot of the stage being multiplied
+#pragma unroll 1
+  for (int w = 0; w < nw; ++w) {
+    f32x16 acc2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+    static_for<kKS>([&](auto S) {
+      constexpr int ks = decltype(S)::value;
+      const int sn = slot == 2 ? 0 : slot + 1;
+      wait_vm<NL>();
+      wait_lgkm0();
+      __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr ((i & 1) && (i >> 1) < NL) {
-        constexpr int j = i >> 1;
-        dma16s(A.w2 + ((size_t)((2 * wave + j / 3) * kKS + ks3) * 3 + j % 3) * kFrag, voff, dst + j * kFrag);
+      const bf16x8 (&wc)[4][3] = (ks & 1) ? w1 : w0;
+      bf16x8 (&wnx)[4][3] = (ks & 1) ? w0 : w1;
+      const bf16x8 a0 = ahi, a1 = amid;
+      const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
+      const char* const wn_src = pw + sn * kStage;
+      static_for<24>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        constexpr int pwt[6] = {2, 0, 1, 1, 0, 0}, pat[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int term = i / 4, t = i % 4;
+        if constexpr (pat[term] == 2) acc2[t] = mfma(wc[t][pwt[term]], lo[ks], acc2[t]);
+        else acc2[t] = mfma(wc[t][pwt[term]], pat[term] == 0 ? a0 : a1, acc2[t]);
         __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (i >= 12 && i < 18) {
-        constexpr int j = 2 * (i - 12);
-        wnx[j / 3][j % 3] = frag(pw + sn * kStage + j * kFrag);
-        wnx[(j + 1) / 3][(j + 1) % 3] = frag(pw + sn * kStage + (j + 1) * kFrag);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (i == 18 && ks + 1 < kKS) {
-        ahi = frag(pa + ((ks + 1) * 2) * kFrag);
-        amid = frag(pa + ((ks + 1) * 2 + 1) * kFrag);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        if constexpr ((i & 1) && (i >> 1) < NL) {
+          dma16s(src_of(w, ks + 3, i >> 1), voff, dst + (i >> 1) * kFrag);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (i >= 12 && i < 18) {
+          constexpr int j = 2 * (i - 12);
+          wnx[j / 3][j % 3] = frag(wn_src + j * kFrag);
+          wnx[(j + 1) / 3][(j + 1) % 3] = frag(wn_src + (j + 1) * kFrag);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (i == 18) {   // hi / mid of the next k-step (the first one again for the next weight)
+          ahi = frag(pa + (((ks + 1) & (kKS - 1)) * 2) * kFrag);
+          amid = frag(pa + (((ks + 1) & (kKS - 1)) * 2 + 1) * kFrag);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      slot = sn;
     });
-  });
-  wait_vm<0>();
-  final_epilogue(acc2, A, r0, wave, lane, reinterpret_cast<float*>(ring));
+    FfnArgs Aw = A;
+    Aw.out = A.out + (size_t)w * A.M * kD;
+    Aw.b2 = A.b2 != nullptr ? A.b2 + w * kD : nullptr;
+    if (w + 1 == nw) wait_vm<0>();   // the surplus re-loads of the tail must have landed before the LDS is handed on
+    final_epilogue(acc2, Aw, r0, wave, lane, reinterpret_cast<float*>(ring));
+  }
 }
 
 }  // namespace
@@ -522,7 +545,27 @@ extern "C" int egtr_proj_ln_x6_f32(egtr_stream_t stream, const float* x, int ldx
     attr_set = true;
   }
   FfnArgs a{x, residual, nullptr, nullptr, static_cast<const char*>(w_xs), bias, ln_gamma, ln_beta, pos, out, out_pos,
-            M, ldx, ldr, 0, pos_rows, eps, nullptr};
+            M, ldx, ldr, 1, pos_rows, eps, nullptr};
+  hipLaunchKernelGGL(proj_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_proj_multi_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w_xs, const float* bias,
+                                      float* out, int M, int d_model, int num_weights) {
+  if (!x || !w_xs || !out || M <= 0 || ldx < d_model || num_weights <= 0) return EGTR_E_ARG;
+  if (d_model != kD || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (reinterpret_cast<uintptr_t>(w_xs) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+    return EGTR_E_UNSUPPORTED;
+  constexpr int lds = kPanel + 3 * kStage + 8 * kFrag;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(proj_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+        hipSuccess)
+      return egtr_check_launch();
+    attr_set = true;
+  }
+  FfnArgs a{x, nullptr, nullptr, nullptr, static_cast<const char*>(w_xs), bias, nullptr, nullptr, nullptr, out, nullptr,
+            M, ldx, 0, num_weights, 0, 0.f, nullptr};
   hipLaunchKernelGGL(proj_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), lds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }

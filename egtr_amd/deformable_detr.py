@@ -858,7 +858,14 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 lambda: (torch.stack([l.encoder_attn.value_proj.weight.t() for l in self.layers]).contiguous(),
                          torch.stack([l.encoder_attn.value_proj.bias for l in self.layers]).contiguous()))
             bsz_, seq_, dm_ = encoder_hidden_states.shape
-            if ops.gemm_split_supported(encoder_hidden_states, dm_, dm_):
+            if ops.proj_multi_fused_supported(encoder_hidden_states):
+                # one launch: a workgroup splits its 64 encoder rows once and multiplies them by all nl weights
+                w_xs = ops.cached_weights(
+                    self, "decoder_value_proj_xs", [l.encoder_attn.value_proj.weight for l in self.layers],
+                    lambda: ops.xs_split(torch.cat([l.encoder_attn.value_proj.weight for l in self.layers], 0),
+                                         weights=True))
+                values = ops.proj_multi_fused(encoder_hidden_states, w_xs, nl).view(nl, bsz_, seq_, dm_)
+            elif ops.gemm_split_supported(encoder_hidden_states, dm_, dm_):
                 values = torch.empty(nl, bsz_ * seq_, dm_, dtype=encoder_hidden_states.dtype,
                                      device=encoder_hidden_states.device)
                 items = []

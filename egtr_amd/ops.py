@@ -824,6 +824,12 @@ def proj_ln_fused_supported(x, lin, ln):
             and ln.weight.shape[0] == 256 and lin.weight.dtype == torch.float32)
 
 
+def proj_multi_fused_supported(x):
+    rows = x.numel() // x.shape[-1]
+    return (FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
+            and x.shape[-1] == 256 and x.dtype == torch.float32)
+
+
 def proj_ln_fused(x, lin, residual=None, ln=None, pos=None):
     """LayerNorm(residual + lin(x)) [and that + pos] for a 256 -> 256 nn.Linear in ONE HIP launch (egtr_proj_ln_x6_f32;
     reference: the attention output projection + residual + LayerNorm, model/deformable_detr.py:1102, 1326-1330); without
@@ -857,6 +863,27 @@ def proj_ln_fused(x, lin, residual=None, ln=None, pos=None):
     _lib.check(st, "egtr_proj_ln_x6_f32")
     y = y.view(x.shape)
     return y if yp is None else (y, yp.view(x.shape))
+
+
+def proj_multi_fused(x, w_xs, num_weights, bias=None):
+    """out[w] = x @ W_w^T (+ bias_w) for ``num_weights`` stacked 256 -> 256 weights applied to the same rows, ONE launch
+    (egtr_proj_multi_x6_f32): ``w_xs`` = ``xs_split(torch.cat(weights, 0), weights=True)``.  Returns [num_weights, rows, 256].
+    Inference only."""
+    lib = _lib.lib()
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    _chk(w_xs, "w_xs", torch.uint8)
+    if w_xs.numel() != xs_bytes(num_weights * 256, 256):
+        raise RuntimeError("proj_multi_fused: w_xs does not have the XS size of [num_weights * 256, 256]")
+    b = _chk(bias.detach().contiguous(), "bias", torch.float32) if bias is not None else None
+    out = torch.empty(num_weights, rows, K, dtype=torch.float32, device=x.device)
+    st = lib.egtr_proj_multi_x6_f32(_stream(), x2.data_ptr(), x2.stride(0), w_xs.data_ptr(),
+                                    b.data_ptr() if b is not None else None, out.data_ptr(), rows, K, num_weights)
+    _lib.check(st, "egtr_proj_multi_x6_f32")
+    return out
 
 
 def module_linear(mod, x, alpha=1.0, relu=False):

@@ -469,6 +469,13 @@ int egtr_proj_ln_x6_f32(egtr_stream_t stream, const float* x, int ldx, const voi
                         const float* residual, int ldr, const float* ln_gamma, const float* ln_beta, float eps,
                         const float* pos, int pos_rows, float* out, float* out_pos, int M, int d_model);
 
+/* out[w] = x . W_w^T + bias_w for num_weights stacked 256 -> 256 linear layers applied to the SAME rows x [M, ldx], one
+ * launch: the input panel of a workgroup is split once and re-used by every weight (the decoder's six cross-attention value
+ * projections of the encoder output, model/deformable_detr.py:1048-1049).  w_xs = XS of the stacked weights
+ * [num_weights * 256, 256]; bias [num_weights * 256] or NULL; out [num_weights, M, 256] contiguous. */
+int egtr_proj_multi_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w_xs, const float* bias, float* out,
+                           int M, int d_model, int num_weights);
+
 /* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
  * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
  * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the

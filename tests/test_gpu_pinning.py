@@ -522,3 +522,31 @@ def test_fused_projection_layernorm_vs_float64(M, kind):
         assert torch.isfinite(got).all()
         assert ((e / scale).amax(1) <= 2.5 * (e32 / scale).amax(1) + 2e-6).all(), (kind, float((e / scale).max()))
     assert torch.equal(y_pos, y_ln + pos.to(DEV))
+
+
+@pytest.mark.parametrize("M,nw,with_bias", [(12537, 6, False), (4100, 6, True), (65, 1, True), (6000, 3, False)])
+def test_fused_multi_projection_vs_float64(M, nw, with_bias):
+    """egtr_proj_multi_x6_f32 -- the decoder's cross-attention value projections of the encoder output (dd:1048-1049), all
+    layers in one launch -- against float64 and the fp32 vendor product per weight; a non-finite row stays in its row."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(91 + nw)
+    w = torch.randn(nw, 256, 256, generator=g) / 16
+    b = torch.randn(nw, 256, generator=g) * 0.3 if with_bias else None
+    rng = W.rng_inputs(6400 + M)
+    x = torch.from_numpy(rng.standard_normal((M, 256))).float() * 3
+    x[M // 2, 7] = float("inf")
+    with torch.no_grad():
+        w_xs = ops.xs_split(w.reshape(nw * 256, 256).to(DEV), weights=True)
+        got = ops.proj_multi_fused(x.to(DEV), w_xs, nw, None if b is None else b.reshape(-1).to(DEV)).cpu()
+    assert got.shape == (nw, M, 256)
+    bad = torch.zeros(M, dtype=torch.bool)
+    bad[M // 2] = True
+    assert not torch.isfinite(got[:, bad]).all(-1).any()
+    assert torch.isfinite(got[:, ~bad]).all()
+    xd = x[~bad].double()
+    for i in range(nw):
+        ref = xd @ w[i].double().t() + (b[i].double() if b is not None else 0)
+        comp = (x[~bad].to(DEV) @ w[i].to(DEV).t()).cpu().double() + (b[i].double() if b is not None else 0)
+        e, e32 = (got[i][~bad].double() - ref).abs(), (comp - ref).abs()
+        scale = ref.abs().amax(1, keepdim=True)
+        assert ((e / scale).amax(1) <= 2.5 * (e32 / scale).amax(1) + 2e-6).all(), (i, float((e / scale).max()))

@@ -105,12 +105,12 @@ int main(int argc, char** argv) {
   printf("M=%d F=%d ln=%d  max|err| = %.3e (max|ref| %.2f)  bad = %lld\n", M, F, ln, max_err, max_ref, bad);
   if (getenv("FFN_TIMING")) {
     long long* td;
-    CK(hipMalloc(&td, 48 * 8));
-    CK(hipMemset(td, 0, 48 * 8));
+    CK(hipMalloc(&td, 64 * 8));
+    CK(hipMemset(td, 0, 64 * 8));
     g_ffn_tdbg = td;
     run();
     CK(hipDeviceSynchronize());
-    long long h[48];
+    long long h[64];
     CK(hipMemcpy(h, td, sizeof(h), hipMemcpyDeviceToHost));
     g_ffn_tdbg = nullptr;
     printf("stage: entry->vmcnt  ->lgkm  ->barrier  ->MFMAs  ->epilogue | next entry\n");
@@ -118,6 +118,9 @@ int main(int argc, char** argv) {
       printf("  s=%d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", s, h[s * 6 + 1] - h[s * 6], h[s * 6 + 2] - h[s * 6 + 1],
              h[s * 6 + 3] - h[s * 6 + 2], h[s * 6 + 4] - h[s * 6 + 3], h[s * 6 + 5] - h[s * 6 + 4],
              s < 7 ? h[(s + 1) * 6] - h[s * 6 + 5] : 0);
+    for (int b = 0; b < 2; ++b)
+      printf("  workgroup %d: panel %lld  loop %lld  epilogue %lld cycles\n", b ? 100 : 0, h[48 + 4 * b + 1] - h[48 + 4 * b],
+             h[48 + 4 * b + 2] - h[48 + 4 * b + 1], h[48 + 4 * b + 3] - h[48 + 4 * b + 2]);
   }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Split ONE graph-replayed forward of bench.py (taken from a rocprofv3 rocpd trace) into stages and list the top
-kernels of each.  Stage boundaries: first MSDA launch (encoder start), first self-attention launch (decoder
-start), relation-head launch (end)."""
+kernels of each.  Stage boundaries: the input projection's GroupNorm (encoder start), the last encoder layer's
+closing LayerNorm before the first self-attention launch (decoder start), relation-head launch (end)."""
 import re
 import sqlite3
 import sys
@@ -28,8 +28,19 @@ def first(pat):
     return None
 
 
+def last_before(end, pats, default):
+    for i in range(end - 1, -1, -1):
+        if any(p in names[i] for p in pats):
+            return i + 1
+    return default
+
+
 i_enc, i_dec = first("msda_fwd"), first("self_attn_fwd")
-cuts = [("backbone+input_proj", 0, i_enc - 6), ("encoder", i_enc - 6, i_dec - 6), ("decoder+heads", i_dec - 6, len(seg))]
+# the encoder starts after the input projection's GroupNorm + flatten, the decoder after the last encoder layer's closing
+# LayerNorm (fused into the FFN kernel or stand-alone)
+c_enc = last_before(i_enc, ("gn_apply_flatten",), i_enc - 6)
+c_dec = last_before(i_dec, ("ffn_x6_kernel", "add_layernorm"), i_dec - 6)
+cuts = [("backbone+input_proj", 0, c_enc), ("encoder", c_enc, c_dec), ("decoder+heads", c_dec, len(seg))]
 for label, a, b in cuts:
     s = seg[a:b]
     print(f"\n{label}: {len(s)} kernels, span {(s[-1][2] - s[0][1]) / 1e6:.3f} ms, busy {sum(r[2] - r[1] for r in s) / 1e6:.3f} ms")
