@@ -679,8 +679,7 @@ def main():
     }
     from egtr_amd import ops as _ops
     split = bool(_ops.REL_HEAD_SPLIT_BF16) and rel_args[1].get("owner") is not None
-    panel = split and bool(_ops.REL_HEAD_PANEL)
-    rel_entry = {"bound": "mfma", "kernel": ("rel_panel_x6_kernel" if panel else "rel_head_fwd_x6") if split else "rel_head_fwd_f32",
+    rel_entry = {"bound": "mfma", "kernel": "rel_head_fwd_x6" if split else "rel_head_fwd_f32",
                  "launch": f"B={args.batch}, N=200, T=7, R=50",
                  "achieved": round(rel_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                  "frac": round(rel_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,

@@ -61,39 +61,6 @@ __device__ __forceinline__ Split3 split3_fast(float x) {
   return s;
 }
 
-// relu + split3_fast of N values (N % 4 == 0) in STAGES, each stage one instruction per value with the program order pinned:
-// a single value is a chain of six dependent VALU instructions, and a dependent chain issues at ~8.4 cycles per instruction on
-// gfx950 against ~5 for four or more interleaved chains (tools/valu_chain.hip) -- hipcc, left alone, emits the chains one after
-// the other.  out[q] (q = N / 4 groups of four consecutive values): .x/.y of hi, mid, lo = the packed pieces.
-template <int N, bool RELU>
-__device__ __forceinline__ void split_staged(const float (&x)[N], uint2 (&hi)[N / 4], uint2 (&mid)[N / 4], uint2 (&lo)[N / 4]) {
-  float y[N], r[N], l[N];
-  unsigned h[N], m[N];
-#pragma unroll
-  for (int e = 0; e < N; ++e) y[e] = RELU ? (x[e] < 0.f ? 0.f : x[e]) : x[e];
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int e = 0; e < N; ++e) h[e] = __float_as_uint(y[e]) & 0xffff0000u;
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int e = 0; e < N; ++e) r[e] = y[e] - __uint_as_float(h[e]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int e = 0; e < N; ++e) m[e] = __float_as_uint(r[e]) & 0xffff0000u;
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int e = 0; e < N; ++e) l[e] = r[e] - __uint_as_float(m[e]);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int q = 0; q < N / 4; ++q) {
-    hi[q] = make_uint2(__builtin_amdgcn_perm(h[4 * q + 1], h[4 * q], 0x07060302u), __builtin_amdgcn_perm(h[4 * q + 3], h[4 * q + 2], 0x07060302u));
-    mid[q] = make_uint2(__builtin_amdgcn_perm(m[4 * q + 1], m[4 * q], 0x07060302u), __builtin_amdgcn_perm(m[4 * q + 3], m[4 * q + 2], 0x07060302u));
-    lo[q] = make_uint2(__builtin_amdgcn_perm(__float_as_uint(l[4 * q + 1]), __float_as_uint(l[4 * q]), 0x07060302u),
-                       __builtin_amdgcn_perm(__float_as_uint(l[4 * q + 3]), __float_as_uint(l[4 * q + 2]), 0x07060302u));
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-
 // round-to-nearest-even split (weights: prepared once, the residuals stay exact in fp32)
 __device__ __forceinline__ unsigned bf16_rne_bits(float x) {   // result in the UPPER half, low half zero
   const unsigned u = __float_as_uint(x);

@@ -1282,54 +1282,6 @@ def relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2x_rel, b2r, w3x_rel, 
     return rel, conn.unsqueeze(-1), gm
 
 
-# The row-panel successor of rel_head_fwd_x6 (csrc/rel_panel_x6.hip): same arithmetic, the weights stream through LDS shared
-# by the four waves of a 64-pair panel.  "0": the per-wave register-stream kernel.
-REL_HEAD_PANEL = os.environ.get("EGTR_REL_HEAD_PANEL", "1") != "0"
-
-
-def rel_head_panel_weights(w2r, w3r, w2c):
-    """XS(W2) of both MLPs and XS(W3 of the relation MLP, zero-padded to 64 rows) for relation_head_panel."""
-    w3p = torch.zeros(64, w3r.shape[1], dtype=torch.float32, device=w3r.device)
-    w3p[:w3r.shape[0]] = w3r.detach().float()
-    return (xs_split(w2r.detach().float().contiguous(), weights=True), xs_split(w3p, weights=True),
-            xs_split(w2c.detach().float().contiguous(), weights=True))
-
-
-def relation_head_panel(gate_q, gate_k, uq, uk, b1, w2_xs_rel, b2r, w3_xs_rel, b3r, w2_xs_conn, b2c, w3c, b3c,
-                        num_rel, triplet_dist=None, node_cls=None, want_gate_mean=False, sigmoid=False):
-    """Inference forward of the relation head (model/egtr.py:366-416), fp32 in / fp32 out, as the row-panel kernel
-    (egtr_rel_head_forward_panel_x6_f32; weights from ``rel_head_panel_weights``).  No autograd."""
-    lib = _lib.lib()
-    B, N, T = gate_q.shape
-    dev = gate_q.device
-    f32 = [_chk(t.detach().contiguous(), n, torch.float32)
-           for t, n in ((gate_q, "gate_q"), (gate_k, "gate_k"), (uq, "uq"), (uk, "uk"), (b1, "b1"), (b2r, "b2r"),
-                        (b3r, "b3r"), (b2c, "b2c"), (w3c, "w3c"), (b3c, "b3c"))]
-    gq, gk, uq_, uk_, b1_, b2r_, b3r_, b2c_, w3c_, b3c_ = f32
-    R = int(num_rel)
-    for t, n, rows in ((w2_xs_rel, "w2_xs_rel", 256), (w2_xs_conn, "w2_xs_conn", 256), (w3_xs_rel, "w3_xs_rel", 64)):
-        _chk(t, n, torch.uint8)
-        if t.numel() != xs_bytes(rows, 256):
-            raise RuntimeError(f"{n} must be the XS buffer of a [{rows}, 256] matrix")
-    rel = torch.empty(B, N, N, R, dtype=torch.float32, device=dev)
-    conn = torch.empty(B, N, N, dtype=torch.float32, device=dev)
-    gm = torch.zeros(T, dtype=torch.float32, device=dev) if want_gate_mean else None
-    td = None
-    c1 = 0
-    if triplet_dist is not None:
-        td = _chk(triplet_dist.detach().contiguous(), "triplet_dist", torch.float32)
-        _chk(node_cls, "node_cls", torch.int64)
-        c1 = td.shape[0]
-    st = lib.egtr_rel_head_forward_panel_x6_f32(
-        _stream(), gq.data_ptr(), gk.data_ptr(), uq_.data_ptr(), uk_.data_ptr(), b1_.data_ptr(), w2_xs_rel.data_ptr(),
-        b2r_.data_ptr(), w3_xs_rel.data_ptr(), b3r_.data_ptr(), w2_xs_conn.data_ptr(), b2c_.data_ptr(), w3c_.data_ptr(),
-        b3c_.data_ptr(), td.data_ptr() if td is not None else None,
-        node_cls.data_ptr() if td is not None else None, B, N, T, 256, R, c1, rel.data_ptr(), conn.data_ptr(),
-        gm.data_ptr() if want_gate_mean else None, 1 if sigmoid else 0)
-    _lib.check(st, "egtr_rel_head_forward_panel_x6_f32")
-    return rel, conn.unsqueeze(-1), gm
-
-
 def relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
                   node_cls=None, want_gate_mean=False, owner=None, sigmoid=False):
     """``owner`` (optional nn.Module): where the derived split-bf16 weight streams of the inference kernel are cached.
@@ -1348,11 +1300,6 @@ def _relation_head(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c
             and w2r.shape == (256, 256) and w3r.shape[0] <= 64 and gate_q.shape[-1] <= 9
             and not (torch.is_grad_enabled() and any(
                 t.requires_grad for t in (gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c)))):
-        if REL_HEAD_PANEL:
-            xs_r, xs_3, xs_c = cached_weights(owner, "rel_head_panel_xs", [w2r, w3r, w2c],
-                                              lambda: rel_head_panel_weights(w2r, w3r, w2c))
-            return relation_head_panel(gate_q, gate_k, uq, uk, b1, xs_r, b2r, xs_3, b3r, xs_c, b2c, w3c, b3c,
-                                       w3r.shape[0], triplet_dist, node_cls, want_gate_mean, sigmoid)
         w2xr, w3xr, w2xc = cached_weights(owner, "rel_head_split_bf16", [w2r, w3r, w2c],
                                           lambda: rel_head_split_weights(w2r, w3r, w2c))
         return relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2xr, b2r, w3xr, b3r, w2xc, b2c, w3c, b3c,

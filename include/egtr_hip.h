@@ -495,19 +495,6 @@ int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const float* gate_q, 
                                      int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
                                      float* gate_mean, int apply_sigmoid);
 
-/* The same forward as egtr_rel_head_forward_bf16x6_f32 (same arithmetic: six-term split products, fp32 accumulation; same
- * outputs to fp32 rounding) as a ROW-PANEL kernel: a workgroup owns 64 pairs (8 subjects x 8 objects) of one MLP for the whole
- * chain and the layer-2 / layer-3 weights stream through LDS (LDS-DMA ring) shared by its four waves, instead of every wave
- * pulling W2 into registers per 32 pairs (csrc/rel_panel_x6.hip; reference model/egtr.py:366-416).  The weights arrive in the
- * XS format (egtr_xs_split_f32, round_to_nearest = 1): w2_xs_* = XS(W2 [256, 256]), w3_xs_rel = XS(W3 zero-padded to
- * [64, 256]).  hidden == 256, num_rel <= 64, num_slots <= 9 (EGTR_E_UNSUPPORTED otherwise). */
-int egtr_rel_head_forward_panel_x6_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
-                                       const float* uk, const float* b1, const void* w2_xs_rel, const float* b2r,
-                                       const void* w3_xs_rel, const float* b3r, const void* w2_xs_conn, const float* b2c,
-                                       const float* w3c, const float* b3c, const float* triplet_dist,
-                                       const int64_t* node_cls, int batch, int num_query, int num_slots, int hidden,
-                                       int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
-                                       float* gate_mean, int apply_sigmoid);
 
 /* Pairwise part of the relation-head backward (everything that is not a plain GEMM).  dh1 [2][B*N*N][hidden] is the
  * gradient wrt the pre-ReLU layer-1 output (relation half, connectivity half), produced by rocBLAS GEMMs from the

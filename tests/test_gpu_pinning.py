@@ -342,10 +342,9 @@ def test_split_bf16_linears_propagate_non_finite_rows_only():
     assert not torch.isfinite(gw_d[:, ~cols]).any()
 
 
-@pytest.mark.parametrize("kernel", ["x6", "panel"])
 @pytest.mark.parametrize("kind", ["large", "cancelling", "tiny", "non-finite"])
-def test_relation_head_split_bf16_on_adversarial_operands(kind, kernel):
-    """rel_head_fwd_x6 / the row-panel kernel (layers 2 / 3 from split operands) vs the exact-f32 MFMA kernel, both against the float64
+def test_relation_head_split_bf16_on_adversarial_operands(kind):
+    """rel_head_fwd_x6 (layers 2 / 3 from split operands) vs the exact-f32 MFMA kernel, both against the float64
     restatement: hidden activations ~1e4 ("large"), paired +- columns in W2 ("cancelling"), activations ~1e-30 ("tiny"),
     and an inf / NaN in one subject's table ("non-finite": exactly the pairs of that subject become non-finite)."""
     import cpu_kernels as ck
@@ -373,12 +372,8 @@ def test_relation_head_split_bf16_on_adversarial_operands(kind, kernel):
         for i, v in poisoned.items():
             d["uq"][0, i, 1, 5 + i] = v
     dd = {k: v.to(DEV) for k, v in d.items()}
-    if kernel == "x6":
-        w2xr, w3xr, w2xc = ops.rel_head_split_weights(dd["w2r"], dd["w3r"], dd["w2c"])
-        fwd = ops.relation_head_split_bf16
-    else:
-        w2xr, w3xr, w2xc = ops.rel_head_panel_weights(dd["w2r"], dd["w3r"], dd["w2c"])
-        fwd = ops.relation_head_panel
+    w2xr, w3xr, w2xc = ops.rel_head_split_weights(dd["w2r"], dd["w3r"], dd["w2c"])
+    fwd = ops.relation_head_split_bf16
     rel6, conn6, _ = fwd(
         dd["gate_q"], dd["gate_k"], dd["uq"], dd["uk"], dd["b1"], w2xr, dd["b2r"], w3xr, dd["b3r"], w2xc, dd["b2c"],
         dd["w3c"], dd["b3c"], R, None, None, False)
