@@ -75,9 +75,18 @@ struct FfnArgs {
   long long* tdbg;   // development: cycle stamps of wave 0 of workgroup 0 (FFN_TIMING builds), else null
 };
 
-// The 64 x 256 fp32 input panel of a workgroup -> MFMA operand fragments: hi / mid pieces into `panel`
+// Logical 16-byte slot x (= row + 32 * k-group) of a panel fragment of k-step ks -> where it is stored.  build_panel's lane
+// owns four consecutive channels of ONE row: a store instruction covers the 16 k-steps x 2 k-groups of a row, i.e. fragments
+// 2 KiB apart -- unswizzled, the 16 lanes of a ds_write_b64 group would share 16 bytes' worth of banks (8-way conflict; the
+// stores of the prologue alone cost ~3 us per launch).  With the XOR they cover all 32 banks, and the MFMA operand read (slot =
+// lane) stays a permutation of the fragment's 64 slots inside each ds_read_b128 lane group: conflict-free as before.
+__device__ __forceinline__ int swz(int x, int ks) { return x ^ (ks & 15) ^ ((x >> 5) << 2); }
+
+// The 64 x 256 fp32 input panel of a workgroup -> MFMA operand fragments (slots swizzled, swz()): hi / mid pieces into `panel`
 // ([row block 2][k-step 16][hi, mid] KiB), lo pieces of row block 0 / 1 into lo0 / lo1 ([k-step 16] KiB each, parking
 // places from which every wave then reads the 16 lo fragments of ITS row block into registers).  No synchronisation inside.
+// split3_fast: a non-finite input makes the lower pieces NaN, so its output ROW is NaN rather than +-inf / NaN -- non-finite
+// either way, and only that row (tests/test_gpu_pinning.py).
 __device__ __forceinline__ void build_panel(const float* __restrict__ x, int ldx, int M, int r0, int tid, int lane,
                                             char* panel, char* lo0, char* lo1) {
   float4 v[16];
@@ -89,8 +98,9 @@ __device__ __forceinline__ void build_panel(const float* __restrict__ x, int ldx
 #pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int row = it * 4 + (tid >> 6), rb = row >> 5, r = row & 31;
-    const int ks = lane >> 2, off = ((lane >> 1) & 1) * 512 + r * 16 + (lane & 1) * 8;
-    const xs::Split3 s0 = xs::split3(v[it].x), s1 = xs::split3(v[it].y), s2 = xs::split3(v[it].z), s3 = xs::split3(v[it].w);
+    const int ks = lane >> 2, off = (swz(r + 32 * ((lane >> 1) & 1), ks) << 4) + (lane & 1) * 8;
+    const xs::Split3 s0 = xs::split3_fast(v[it].x), s1 = xs::split3_fast(v[it].y), s2 = xs::split3_fast(v[it].z),
+                     s3 = xs::split3_fast(v[it].w);
     char* p = panel + ((rb * kKS + ks) * 2) * kFrag + off;
     *reinterpret_cast<uint2*>(p) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
     *reinterpret_cast<uint2*>(p + kFrag) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
@@ -220,9 +230,9 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   __syncthreads();
   bf16x8 lo[kKS];
   {
-    const char* q = (wm == 0 ? hbuf : ring + 2 * kStage) + lane * 16;
+    const char* q = (wm == 0 ? hbuf : ring + 2 * kStage);
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag);
+    for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag + (swz(lane, ks) << 4));
   }
 
   f32x16 acc2[4], acc1[2];
@@ -231,7 +241,10 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
 
-  const char* const pa = panel + (wm * kKS * 2) * kFrag + lane * 16;   // hi / mid fragments of this wave's 32 rows
+  // hi (piece 0) / mid (piece 1) fragment of k-step ks of this wave's 32 panel rows
+  auto pfrag = [&](int ks, int piece) {
+    return *reinterpret_cast<const bf16x8*>(panel + ((wm * kKS + ks) * 2 + piece) * kFrag + (swz(lane, ks) << 4));
+  };
   const char* const ph = hbuf + (wm * 4 * 3) * kFrag + lane * 16;      // hidden-chunk fragments of this wave's 32 rows
   // weight fragments of a stage, as this wave reads them: layer 1 = [k-step 4][piece 3] of n-block wn, layer 2 = [n tile
   // 4][piece 3] of n-blocks 4 wn ..: in both images fragment (u, p) sits at ((4 wn + u) * 3 + p) KiB
@@ -291,8 +304,8 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       constexpr int sx = (s + 1) & 7;
       if constexpr (i >= 18 && i < 22 && sx < 4) {
         constexpr int kl = i - 18;
-        anx[kl][0] = frag(pa + ((4 * sx + kl) * 2 + 0) * kFrag);
-        anx[kl][1] = frag(pa + ((4 * sx + kl) * 2 + 1) * kFrag);
+        anx[kl][0] = pfrag(4 * sx + kl, 0);
+        anx[kl][1] = pfrag(4 * sx + kl, 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (i == 18 && sx > 4) {
@@ -317,8 +330,8 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   for (int u = 0; u < 4; ++u) {
 #pragma unroll
     for (int p = 0; p < 3; ++p) w0[u][p] = frag(pw + (u * 3 + p) * kFrag);
-    a0[u][0] = frag(pa + (u * 2 + 0) * kFrag);
-    a0[u][1] = frag(pa + (u * 2 + 1) * kFrag);
+    a0[u][0] = pfrag(u, 0);
+    a0[u][1] = pfrag(u, 1);
   }
   int slot = 0;   // ring slot of the stage being multiplied
 #pragma unroll 1
@@ -427,11 +440,13 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
   __syncthreads();
   bf16x8 lo[kKS];
   {
-    const char* q = ring + 2 * kStage + wm * (kKS * kFrag) + lane * 16;
+    const char* q = ring + 2 * kStage + wm * (kKS * kFrag);
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag);
+    for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag + (swz(lane, ks) << 4));
   }
-  const char* const pa = panel + (wm * kKS * 2) * kFrag + lane * 16;
+  auto pfrag = [&](int ks, int piece) {
+    return *reinterpret_cast<const bf16x8*>(panel + ((wm * kKS + ks) * 2 + piece) * kFrag + (swz(lane, ks) << 4));
+  };
   const char* const pw = ring + (4 * wn * 3) * kFrag + lane * 16;
   auto frag = [](const char* p) { return *reinterpret_cast<const bf16x8*>(p); };
   bf16x8 w0[4][3], w1[4][3];
@@ -443,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
   for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int p = 0; p < 3; ++p) w0[u][p] = frag(pw + (u * 3 + p) * kFrag);
-  bf16x8 ahi = frag(pa), amid = frag(pa + kFrag);
+  bf16x8 ahi = pfrag(0, 0), amid = pfrag(0, 1);
   int slot = 0;   // ring slot of the stage being multiplied
 #pragma unroll 1
   for (int w = 0; w < nw; ++w) {
@@ -482,8 +497,8 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (i == 18) {   // hi / mid of the next k-step (the first one again for the next weight)
-          ahi = frag(pa + (((ks + 1) & (kKS - 1)) * 2) * kFrag);
-          amid = frag(pa + (((ks + 1) & (kKS - 1)) * 2 + 1) * kFrag);
+          ahi = pfrag((ks + 1) & (kKS - 1), 0);
+          amid = pfrag((ks + 1) & (kKS - 1), 1);
           __builtin_amdgcn_sched_barrier(0);
         }
       });
