@@ -330,19 +330,34 @@ __global__ __launch_bounds__(256) void box_decode(const float* __restrict__ delt
                                                   float eps, float* __restrict__ out,
                                                   const float* __restrict__ logits_all, int C,
                                                   long long* __restrict__ node_cls) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= B * Ld * N) return;
-  const int n = i % N, l = (i / N) % Ld, b = i / (N * Ld);
-  if (logits_all != nullptr && l == Ld - 1) {
-    const float* lg = logits_all + (size_t)i * C;
-    float best = lg[0];
-    int arg = 0;
-    for (int c = 1; c < C; ++c) {
+  const int nb_decode = (B * Ld * N + 255) / 256;
+  if ((int)blockIdx.x >= nb_decode) {
+    // torch.argmax over the last decoder layer's class logits (model/egtr.py:401-403), one WAVE per query row: lanes stride
+    // over the classes, then a butterfly; the first maximal index wins, a NaN beats every number (torch semantics).
+    const int row = ((int)blockIdx.x - nb_decode) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * N) return;
+    const int b = row / N, n = row - b * N;
+    const float* lg = logits_all + (((size_t)b * Ld + (Ld - 1)) * N + n) * C;
+    float best = lane < C ? lg[lane] : 0.f;
+    int arg = lane < C ? lane : 0x7fffffff;
+    for (int c = lane + 64; c < C; c += 64) {
       const float v = lg[c];
       if (v > best || (v != v && best == best)) { best = v; arg = c; }
     }
-    node_cls[(size_t)b * N + n] = arg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float v = __shfl_xor(best, o);
+      const int a = __shfl_xor(arg, o);
+      const bool vn = v != v, bn = best != best;
+      const bool take = a != 0x7fffffff && (arg == 0x7fffffff || (vn && !bn) || (!bn && v > best) || ((vn == bn) && (vn || v == best) && a < arg));
+      if (take) { best = v; arg = a; }
+    }
+    if (lane == 0) node_cls[row] = arg;
+    return;
   }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * Ld * N) return;
+  const int n = i % N, l = (i / N) % Ld, b = i / (N * Ld);
   const float* rp = (l == 0 || inter_ref == nullptr) ? init_ref + ((size_t)b * N + n) * RD
                                                       : inter_ref + (((size_t)b * Ld + (l - 1)) * N + n) * RD;
   const float4 d = reinterpret_cast<const float4*>(delta)[i];
@@ -808,7 +823,9 @@ extern "C" int egtr_box_decode_argmax_f32(egtr_stream_t stream, const float* del
   if (ref_dim != 2 && ref_dim != 4) return EGTR_E_UNSUPPORTED;
   const long long n = (long long)batch * num_levels * num_query;
   if (n >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
-  hipLaunchKernelGGL(box_decode, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), delta,
+  // the decode blocks, then (with logits) one wave per query row for the class argmax
+  const long long blocks = (n + 255) / 256 + (logits_all ? ((long long)batch * num_query + 3) / 4 : 0);
+  hipLaunchKernelGGL(box_decode, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), delta,
                      init_reference, inter_references, batch, num_levels, num_query, ref_dim, eps, boxes, logits_all,
                      num_classes, reinterpret_cast<long long*>(node_cls));
   return egtr_check_launch();

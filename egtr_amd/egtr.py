@@ -142,9 +142,20 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
                          torch.cat([rp[0].weight[:, d:], cl[0].weight[:, d:]], 0).contiguous(),
                          wg[:, :d].contiguous(), wg[:, d:].contiguous(),
                          torch.cat([rp[0].bias, cl[0].bias], 0).contiguous()))
-            uq, uk, gate_q, gate_k = ops.linear_grouped([
-                dict(x=Q, w=w1q), dict(x=K, w=w1k), dict(x=Q, w=wgq),
-                dict(x=K, w=wgk, b=self.rel_predictor_gate.bias)])
+            if ops.GEMM_SPLIT_BF16 and Q.dtype == torch.float32 and d % 32 == 0 and w1q.shape[0] % 128 == 0:
+                # [B N T, d] x [d, 2 Hd]: ~1400 rows -- below the token-sized linears' policy threshold, but the split-bf16
+                # tile kernel already beats the exact-f32 skinny kernel here (measured 30 -> 12 us with the gate launch)
+                wtq, wtk = ops.cached_weights(self, "rel_head_first_layer_split", [rp[0].weight, cl[0].weight],
+                                              lambda: (ops.gemm_split_weights(w1q), ops.gemm_split_weights(w1k)))
+                uq, uk = ops.linear_split_bf16_grouped([dict(x=Q, wt=wtq, N=w1q.shape[0]),
+                                                        dict(x=K, wt=wtk, N=w1k.shape[0])])
+                uq, uk = uq.view(bsz, N, T, -1), uk.view(bsz, N, T, -1)
+                gate_q, gate_k = ops.linear_grouped([dict(x=Q, w=wgq),
+                                                     dict(x=K, w=wgk, b=self.rel_predictor_gate.bias)])
+            else:
+                uq, uk, gate_q, gate_k = ops.linear_grouped([
+                    dict(x=Q, w=w1q), dict(x=K, w=w1k), dict(x=Q, w=wgq),
+                    dict(x=K, w=wgk, b=self.rel_predictor_gate.bias)])
             gate_q, gate_k = gate_q[..., 0], gate_k[..., 0]
         else:
             # slot projections q^[b,i,t,:], k^[b,j,t,:]  (t < Ld: decoder layers, t = Ld: final hidden state)

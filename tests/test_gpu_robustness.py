@@ -146,3 +146,13 @@ def test_box_decode_with_class_argmax_and_shared_reference():
     assert torch.equal(boxes, want)
     assert torch.equal(node, torch.argmax(logits[:, -1], -1))
     assert int(node[0, 3]) == 10 and int(node[1, 5]) == 40 and int(node[1, 6]) == 0
+    # fewer classes than lanes, several NaNs (first one wins), a tie inside one lane's stride (c, c + 64)
+    for C2 in (31, 151):
+        lg = torch.randn(B, Ld, N, C2, generator=g).to(DEV)
+        lg[0, -1, 8, C2 - 1] = lg[0, -1, 8, 2] = float("nan")
+        lg[1, -1, 9, 5] = 30.0
+        if C2 > 69:
+            lg[1, -1, 9, 69] = 30.0
+        _, node2 = ops.box_decode(delta, ref, inter, logits_all=lg)
+        assert torch.equal(node2, torch.argmax(lg[:, -1], -1))
+        assert int(node2[0, 8]) == 2 and int(node2[1, 9]) == 5
