@@ -36,6 +36,7 @@ SIGNATURES = {
     "egtr_self_attn_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "egtr_linear_f32": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I],
     "egtr_linear_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I],
+    "egtr_linear_grouped_ln_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "egtr_add_layernorm_pos_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _I, _P],
     "egtr_bias_mask_rows_f32": [_P, _P, _P, _P, _I, _I, _I],
     "egtr_bias_relu_maxpool3x3s2_f32": [_P, _P, _P, _P, _I, _I, _I, _I],

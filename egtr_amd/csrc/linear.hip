@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,14 @@ __device__ __forceinline__ f32x4 gload16(const float4* p) {
 template <int N>
 __device__ __forceinline__ void vmwait(f32x4& v) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+template <int N, int I = 0, class Fn>
+__device__ __forceinline__ void static_for_lin(Fn&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_lin<N, I + 1>(f);
+  }
 }
 
 // one batch of NB K-steps (4 floats each) starting at float4 index T0 of the three operand rows
@@ -137,6 +147,15 @@ struct LinGroup {
   float* y;
   int M, N, ldy, relu;
   float alpha_x, alpha;
+  // LayerNorm prologue (K == 256 only; gamma == nullptr: none): the layer's input is LayerNorm(x + res) * gamma + beta
+  // [+ pos[row % pos_rows]]; the workgroups of output-column tile 0 also store the LayerNorm result (without pos) to ln_out
+  const float* res;
+  const float* gamma;
+  const float* beta;
+  const float* pos;
+  float* ln_out;
+  int pos_rows;
+  float eps;
 };
 struct LinGroups {
   LinGroup g[16];
@@ -158,7 +177,84 @@ __global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, in
   const float4* w0 = reinterpret_cast<const float4*>(G.w + (size_t)wr0 * K + kb);
   const float4* w1 = reinterpret_cast<const float4*>(G.w + (size_t)wr1 * K + kb);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  if constexpr (SPAN > 0) {
+  if constexpr (SPAN == 16) {
+    if (G.gamma != nullptr) {   // uniform per workgroup
+      // ---- LayerNorm prologue (K = 256): the 16 (wave, lane group) parts of a row hold 16 channels each.  The decoder's
+      // residual add + LayerNorm launches (4.8 us apiece at 200 rows: pure launch floor) disappear into their consumers;
+      // every column tile recomputes the statistics of its 16 rows (8 KiB of input), tile 0 stores the result.
+      __shared__ float s_stat[2][4][16];
+      const float4* rp = reinterpret_cast<const float4*>(G.res + (size_t)row * K + kb);
+      const float4* gp = reinterpret_cast<const float4*>(G.gamma + kb);
+      const float4* bp = reinterpret_cast<const float4*>(G.beta + kb);
+      const float4* pp = G.pos != nullptr ? reinterpret_cast<const float4*>(G.pos + (size_t)(row % G.pos_rows) * K + kb) : gp;
+      f32x4 a[4], rr[4], b0[4], b1[4], ga[4], be[4], po[4];
+      static_for_lin<4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        a[i] = gload16<i * 16>(xp);
+        rr[i] = gload16<i * 16>(rp);
+      });
+      static_for_lin<4>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        ga[i] = gload16<i * 16>(gp);
+        be[i] = gload16<i * 16>(bp);
+        po[i] = gload16<i * 16>(pp);
+        b0[i] = gload16<i * 16>(w0);
+        b1[i] = gload16<i * 16>(w1);
+      });
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vmwait<0>(a[i]); vmwait<0>(rr[i]); vmwait<0>(ga[i]); vmwait<0>(be[i]); vmwait<0>(po[i]); vmwait<0>(b0[i]);
+        vmwait<0>(b1[i]);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] += rr[i];
+        sum += (a[i].x + a[i].y) + (a[i].z + a[i].w);
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      if (g == 0) s_stat[0][wave][c] = sum;
+      __syncthreads();
+      const float mean = ((s_stat[0][0][c] + s_stat[0][1][c]) + (s_stat[0][2][c] + s_stat[0][3][c])) * (1.f / 256.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] -= mean;
+        sq += (a[i].x * a[i].x + a[i].y * a[i].y) + (a[i].z * a[i].z + a[i].w * a[i].w);
+      }
+      sq += __shfl_xor(sq, 16);
+      sq += __shfl_xor(sq, 32);
+      if (g == 0) s_stat[1][wave][c] = sq;
+      __syncthreads();
+      const float rstd =
+          rsqrtf(((s_stat[1][0][c] + s_stat[1][1][c]) + (s_stat[1][2][c] + s_stat[1][3][c])) * (1.f / 256.f) + G.eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = a[i] * rstd * ga[i] + be[i];
+      if (blockIdx.x == 0 && G.ln_out != nullptr && m0 + c < M) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<float4*>(G.ln_out + (size_t)row * K + kb + 4 * i) = make_float4(a[i].x, a[i].y, a[i].z, a[i].w);
+      }
+      if (G.pos != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] += po[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b0[i].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b1[i].x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b0[i].y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b1[i].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b0[i].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b1[i].z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b0[i].w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b1[i].w, acc1, 0, 0, 0);
+      }
+    } else {
+      skinny_kloop<SPAN>(xp, w0, w1, acc0, acc1);
+    }
+  } else if constexpr (SPAN > 0) {
     skinny_kloop<SPAN>(xp, w0, w1, acc0, acc1);
   } else
 #pragma unroll 4
@@ -382,19 +478,32 @@ void launch_skinny_bwd(hipStream_t st, const SkinnyBwdArgs& P, int grid) {
 
 }  // namespace
 
-extern "C" int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* const* x,
-                                       const float* const* w, const float* const* bias, float* const* y, const int* M,
-                                       const int* N, const int* ldy, const float* alpha_x, const float* alpha,
-                                       const int* relu, int K) {
+extern "C" int egtr_linear_grouped_ln_f32(egtr_stream_t stream, int num_groups, const float* const* x,
+                                          const float* const* w, const float* const* bias, float* const* y, const int* M,
+                                          const int* N, const int* ldy, const float* alpha_x, const float* alpha,
+                                          const int* relu, int K, const float* const* ln_residual,
+                                          const float* const* ln_gamma, const float* const* ln_beta, const float* ln_eps,
+                                          const float* const* pos, const int* pos_rows, float* const* ln_out) {
   if (!x || !w || !bias || !y || !M || !N || !ldy || !alpha_x || !alpha || !relu) return EGTR_E_ARG;
   if (num_groups <= 0 || num_groups > 16 || K <= 0) return EGTR_E_ARG;
   if (K % 64 != 0) return EGTR_E_UNSUPPORTED;
+  const bool any_ln = ln_gamma != nullptr;
+  if (any_ln && (!ln_residual || !ln_beta || !ln_eps || !pos || !pos_rows || !ln_out)) return EGTR_E_ARG;
   LinGroups P;
   int maxM = 0, maxN = 0;
   for (int i = 0; i < 16; ++i) {
     const int s = i < num_groups ? i : 0;
     if (!x[s] || !w[s] || !y[s] || M[s] <= 0 || N[s] <= 0 || ldy[s] < N[s]) return EGTR_E_ARG;
-    P.g[i] = LinGroup{x[s], w[s], bias[s], y[s], M[s], N[s], ldy[s], relu[s], alpha_x[s], alpha[s]};
+    P.g[i] = LinGroup{x[s], w[s], bias[s], y[s], M[s], N[s], ldy[s], relu[s], alpha_x[s], alpha[s],
+                      nullptr, nullptr, nullptr, nullptr, nullptr, 1, 0.f};
+    if (any_ln && ln_gamma[s] != nullptr) {
+      if (K != 256) return EGTR_E_UNSUPPORTED;
+      if (!ln_residual[s] || !ln_beta[s] || (pos[s] != nullptr && pos_rows[s] <= 0)) return EGTR_E_ARG;
+      LinGroup& g = P.g[i];
+      g.res = ln_residual[s]; g.gamma = ln_gamma[s]; g.beta = ln_beta[s]; g.pos = pos[s]; g.ln_out = ln_out[s];
+      g.pos_rows = pos[s] != nullptr ? pos_rows[s] : 1;
+      g.eps = ln_eps[s];
+    }
     if (i < num_groups) {
       maxM = M[s] > maxM ? M[s] : maxM;
       maxN = N[s] > maxN ? N[s] : maxN;
@@ -410,6 +519,14 @@ extern "C" int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, con
   else
     hipLaunchKernelGGL(linear_skinny_grouped_f32<0>, grid, dim3(256), 0, st, P, K, span);
   return egtr_check_launch();
+}
+
+extern "C" int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* const* x,
+                                       const float* const* w, const float* const* bias, float* const* y, const int* M,
+                                       const int* N, const int* ldy, const float* alpha_x, const float* alpha,
+                                       const int* relu, int K) {
+  return egtr_linear_grouped_ln_f32(stream, num_groups, x, w, bias, y, M, N, ldy, alpha_x, alpha, relu, K, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const float* bias, float* y,

@@ -347,7 +347,10 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                 hidden_with_pos=None, precomputed_value=None, residual_ln=None):
         # hidden_with_pos / precomputed_value: inference-only hand-ins that save launches (the previous LayerNorm
         # kernel also wrote hidden + pos; the decoder projects the values of all its layers in one batched GEMM)
-        if hidden_with_pos is not None:
+        deferred = hidden_states if isinstance(hidden_states, ops.DeferredLayerNorm) else None
+        if deferred is not None:
+            pass   # LayerNorm (+ pos) runs as the prologue of the offsets / weights projection below
+        elif hidden_with_pos is not None:
             hidden_states = hidden_with_pos
         elif position_embeddings is not None:
             hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
@@ -361,7 +364,7 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         if total != sequence_length:
             raise ValueError("Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
 
-        fast = ops.inference_fast_path(hidden_states)
+        fast = deferred is not None or ops.inference_fast_path(hidden_states)
         value_is_masked = True
         value_bias = None
         both_train = None
@@ -380,7 +383,12 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                     and ops.gemm_split_supported(hidden_states, 3 * self.n_heads * self.n_levels * self.n_points,
                                                  hidden_states.shape[-1])):
                 value = ops.module_linear(self.value_proj, encoder_hidden_states)
-        if fast and batch_size * num_queries <= ops.SKINNY_MAX_ROWS:
+        if deferred is not None:
+            dpos = _pos_rows(position_embeddings) if position_embeddings is not None else None
+            sampling_offsets, attention_weights = ops.linear_grouped([
+                dict(x=deferred, pos=dpos, w=self.sampling_offsets.weight, b=self.sampling_offsets.bias),
+                dict(x=deferred, pos=dpos, w=self.attention_weights.weight, b=self.attention_weights.bias)])
+        elif fast and batch_size * num_queries <= ops.SKINNY_MAX_ROWS:
             sampling_offsets, attention_weights = ops.linear_grouped([
                 dict(x=hidden_states, w=self.sampling_offsets.weight, b=self.sampling_offsets.bias),
                 dict(x=hidden_states, w=self.attention_weights.weight, b=self.attention_weights.bias)])
@@ -522,11 +530,20 @@ class DeformableDetrMultiheadAttention(nn.Module):
                 output_attention_states: bool = False, hidden_with_pos=None):
         need_map = attention_mask is not None or output_attentions or (self.dropout != 0.0 and self.training)
         hidden_states_original = hidden_states
-        if hidden_with_pos is not None:
+        if isinstance(hidden_states, ops.DeferredLayerNorm):
+            # the previous layer's closing LayerNorm (+ pos for q / k) runs as the prologue of the three projections
+            dpos = _pos_rows(position_embeddings) if position_embeddings is not None else None
+            query_states, key_states, value_states = ops.linear_grouped([
+                dict(x=hidden_states, pos=dpos, w=self.q_proj.weight, b=self.q_proj.bias, alpha=self.scaling),
+                dict(x=hidden_states, pos=dpos, w=self.k_proj.weight, b=self.k_proj.bias),
+                dict(x=hidden_states, w=self.v_proj.weight, b=self.v_proj.bias)])
+        elif hidden_with_pos is not None:
             hidden_states = hidden_with_pos
         elif position_embeddings is not None:
             hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
-        if ops.inference_fast_path(hidden_states):  # q / k / v projections in one launch
+        if isinstance(hidden_states_original, ops.DeferredLayerNorm):
+            pass
+        elif ops.inference_fast_path(hidden_states):  # q / k / v projections in one launch
             query_states, key_states, value_states = ops.linear_grouped([
                 dict(x=hidden_states, w=self.q_proj.weight, b=self.q_proj.bias, alpha=self.scaling),
                 dict(x=hidden_states, w=self.k_proj.weight, b=self.k_proj.bias),
@@ -680,7 +697,18 @@ class DeformableDetrDecoderLayer(nn.Module):
                 out=None):
         """``hidden_with_pos`` / ``return_with_pos`` / ``precomputed_value`` / ``out`` (destination of the layer's output
         states): inference plumbing, see the encoder layer and DeformableDetrDecoder.forward."""
-        fast = position_embeddings is not None and ops.inference_fast_path(hidden_states)
+        incoming = hidden_states if isinstance(hidden_states, ops.DeferredLayerNorm) else None
+        fast = position_embeddings is not None and (incoming is not None or ops.inference_fast_path(hidden_states))
+        if (fast and ops.DEFER_LAYERNORM and not output_attentions and attention_mask is None
+                and self.activation_fn is F.relu and self.embed_dim == 256
+                and hidden_states.shape[0] * hidden_states.shape[1] <= ops.SKINNY_MAX_ROWS
+                and (incoming is not None or hidden_states.dtype == torch.float32)):
+            return self._forward_deferred(hidden_states, position_embeddings, reference_points, spatial_shapes,
+                                          level_start_index, encoder_hidden_states, encoder_attention_mask,
+                                          output_attention_states, spatial_shapes_list, hidden_with_pos, return_with_pos,
+                                          precomputed_value, out)
+        if incoming is not None:
+            hidden_states = incoming.materialize()
         residual = hidden_states
         hidden_states, self_attn_weights, self_attn_queries, self_attn_keys = self.self_attn(
             hidden_states=hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
@@ -724,6 +752,37 @@ class DeformableDetrDecoderLayer(nn.Module):
             outputs += (self_attn_queries, self_attn_keys)
         if return_with_pos:
             outputs += (next_with_pos,)
+        return outputs
+
+
+    def _forward_deferred(self, hidden_states, position_embeddings, reference_points, spatial_shapes, level_start_index,
+                          encoder_hidden_states, encoder_attention_mask, output_attention_states, spatial_shapes_list,
+                          hidden_with_pos, return_with_pos, precomputed_value, out):
+        """The layer at inference (fp32, <= SKINNY_MAX_ROWS query rows) without stand-alone LayerNorm launches: each of the
+        three residual-add + LayerNorm steps (dd:1437-1438, 1456-1457, 1466-1468) is an ``ops.DeferredLayerNorm`` that the
+        next skinny linear evaluates as its prologue -- the sampling-offset / attention-weight projections, fc1, and the next
+        layer's q / k / v projections.  With ``return_with_pos`` the closing LayerNorm is handed to the caller unevaluated
+        (its result lands in ``out`` when the next layer -- or ``materialize()`` -- runs)."""
+        incoming = hidden_states if isinstance(hidden_states, ops.DeferredLayerNorm) else None
+        attn_out, _, self_attn_queries, self_attn_keys = self.self_attn(
+            hidden_states=hidden_states, position_embeddings=position_embeddings,
+            output_attention_states=output_attention_states, hidden_with_pos=hidden_with_pos)
+        residual = incoming.out if incoming is not None else hidden_states
+        d1 = ops.DeferredLayerNorm(attn_out, residual, self.self_attn_layer_norm)
+        cross_out, _ = self.encoder_attn(
+            hidden_states=d1, attention_mask=encoder_attention_mask, encoder_hidden_states=encoder_hidden_states,
+            encoder_attention_mask=encoder_attention_mask, position_embeddings=position_embeddings,
+            reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+            spatial_shapes_list=spatial_shapes_list, precomputed_value=precomputed_value)
+        d2 = ops.DeferredLayerNorm(cross_out, d1.out, self.encoder_attn_layer_norm)
+        hidden = ops.linear_grouped([dict(x=d2, w=self.fc1.weight, b=self.fc1.bias, relu=True)])[0]
+        hidden = ops.module_linear(self.fc2, hidden)
+        d3 = ops.DeferredLayerNorm(hidden, d2.out, self.final_layer_norm, out=out)
+        outputs = (d3 if return_with_pos else d3.materialize(),)
+        if output_attention_states:
+            outputs += (self_attn_queries, self_attn_keys)
+        if return_with_pos:
+            outputs += (None,)
         return outputs
 
 
@@ -910,8 +969,9 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 if reference_points.shape[-1] != 2:
                     raise ValueError("Reference points' last dimension must be of size 2")
                 reference_points_input = reference_points[:, :, None] * valid_ratios[:, None]
-            if output_hidden_states:
-                all_hidden_states += (hidden_states,)
+            if output_hidden_states:   # a pending LayerNorm's buffer: filled by the launch that consumes it
+                all_hidden_states += (hidden_states.out if isinstance(hidden_states, ops.DeferredLayerNorm)
+                                      else hidden_states,)
             layer_outputs = decoder_layer(
                 hidden_states, attention_mask=None, position_embeddings=position_embeddings,
                 encoder_hidden_states=encoder_hidden_states, reference_points=reference_points_input,
@@ -923,6 +983,11 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 out=inter_buf[idx] if inter_buf is not None else None)
             hidden_states = layer_outputs[0]
             with_pos = layer_outputs[-1]
+            if isinstance(hidden_states, ops.DeferredLayerNorm):
+                # the layer's closing LayerNorm is still pending: the next layer's q / k / v projections evaluate it (its
+                # result lands in inter_buf[idx]); whoever needs the states before that gets them now
+                if idx + 1 == len(self.layers) or self.bbox_embed is not None:
+                    hidden_states = hidden_states.materialize()
             if self.bbox_embed is not None:  # iterative box refinement (dd:1903-1918)
                 tmp = self.bbox_embed[idx](hidden_states)
                 if reference_points.shape[-1] == 4:
@@ -933,7 +998,7 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                     new_reference_points = torch.cat([tmp[..., :2] + inverse_sigmoid(reference_points),
                                                       tmp[..., 2:]], -1).sigmoid()
                 reference_points = new_reference_points.detach()
-            intermediate += (hidden_states,)
+            intermediate += (hidden_states.out if isinstance(hidden_states, ops.DeferredLayerNorm) else hidden_states,)
             intermediate_reference_points += (reference_points,)
             if output_attentions:
                 all_self_attns += (layer_outputs[1],)

@@ -425,21 +425,96 @@ def inference_fast_path(x):
     return x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
 
 
+# Decoder at inference: the residual-add + LayerNorm steps run as prologues of the skinny linears that consume them
+# (DeferredLayerNorm below) instead of in launches of their own.  "0": stand-alone add_layernorm_256 launches.
+DEFER_LAYERNORM = os.environ.get("EGTR_DEFER_LAYERNORM", "1") != "0"
+
+
+class DeferredLayerNorm:
+    """y = LayerNorm(a + b) that has NOT been computed yet: the skinny linears that consume y apply it as a prologue
+    (``linear_grouped`` items with ``x=<DeferredLayerNorm>``; egtr_linear_grouped_ln_f32) and the first such launch also
+    stores y into ``.out``.  Replaces the decoder's stand-alone residual-add + LayerNorm launches (4.8 us each at 200 rows:
+    launch floor) at inference.  ``materialize()`` runs the stand-alone kernel when no linear consumes y."""
+
+    def __init__(self, a, b, ln, out=None):
+        if a.shape != b.shape or a.shape[-1] != 256:
+            raise ValueError("DeferredLayerNorm: two [.., 256] tensors")
+        self.a, self.b, self.ln = a, b, ln
+        self.out = out if out is not None else torch.empty_like(a)
+        self.done = False
+
+    @property
+    def shape(self):
+        return self.a.shape
+
+    @property
+    def device(self):
+        return self.a.device
+
+    def materialize(self):
+        if not self.done:
+            add_layer_norm_into(self.a, self.b, self.ln, self.out)
+            self.done = True
+        return self.out
+
+
+def add_layer_norm_into(x, residual, ln, out):
+    """out = LayerNorm(x + residual) through the stand-alone kernel (egtr_add_layernorm_f32; inference, 256 channels)."""
+    lib = _lib.lib()
+    x2 = _chk(x.contiguous(), "x", torch.float32)
+    r2 = _chk(residual.contiguous(), "residual", torch.float32)
+    _chk(out, "out", torch.float32)
+    if out.shape != x2.shape or x2.shape[-1] != 256:
+        raise ValueError("add_layer_norm_into: out must have the shape of x, 256 channels")
+    st = lib.egtr_add_layernorm_f32(_stream(), x2.data_ptr(), r2.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                    out.data_ptr(), x2.numel() // 256, 256, float(ln.eps))
+    _lib.check(st, "egtr_add_layernorm_f32")
+    return out
+
+
 def linear_grouped(items):
-    """Several independent skinny linears in ONE HIP launch (egtr_linear_grouped_f32).  ``items`` is a list of dicts:
-    x [.., K], w [N, K], b [N] or None, optional out (2-D view [rows, N] with unit inner stride: rows of a larger
-    buffer), alpha_x (scale on x), alpha (scale after the bias), relu.  Returns the list of outputs ([.., N], or the
-    given ``out`` views).  Inference only (no autograd)."""
+    """Several independent skinny linears in ONE HIP launch (egtr_linear_grouped_ln_f32).  ``items`` is a list of dicts:
+    x [.., K] (or a ``DeferredLayerNorm``: the LayerNorm runs as the layer's prologue, K = 256), w [N, K], b [N] or None,
+    optional pos ([pos_rows, 256], added to a DeferredLayerNorm input after the LayerNorm), out (2-D view [rows, N] with
+    unit inner stride: rows of a larger buffer), alpha_x (scale on x), alpha (scale after the bias), relu.  Returns the
+    list of outputs ([.., N], or the given ``out`` views).  Inference only (no autograd)."""
     import ctypes
     lib = _lib.lib()
     G = len(items)
     if not 0 < G <= 16:
         raise ValueError("linear_grouped: 1..16 groups")
-    K = items[0]["x"].shape[-1]
+    x0 = items[0]["x"]
+    K = x0.shape[-1]
     xs, ws, bs, ys, Ms, Ns, lds, ax, al, rl, outs, keep = [], [], [], [], [], [], [], [], [], [], [], []
+    lres, lga, lbe, leps, lpos, lprows, lout = [], [], [], [], [], [], []
+    any_ln = False
     for it in items:
         x, w, b = it["x"], it["w"], it.get("b")
-        x2 = _chk(x.reshape(-1, K).contiguous(), "x", torch.float32)
+        dln = x if isinstance(x, DeferredLayerNorm) else None
+        if dln is not None and dln.done:
+            x, dln = dln.out, None
+        lead = tuple(x.shape[:-1])
+        if dln is not None:
+            any_ln = True
+            x2 = _chk(dln.a.reshape(-1, K).contiguous(), "x", torch.float32)
+            r2 = _chk(dln.b.reshape(-1, K).contiguous(), "residual", torch.float32)
+            ga = _chk(dln.ln.weight.detach().contiguous(), "ln.weight", torch.float32)
+            be = _chk(dln.ln.bias.detach().contiguous(), "ln.bias", torch.float32)
+            pos = it.get("pos")
+            p2 = _chk(pos.reshape(-1, K).contiguous(), "pos", torch.float32) if pos is not None else None
+            first = not getattr(dln, "_claimed", False)   # one group of the launch stores the LayerNorm result
+            dln._claimed = True
+            o2 = _chk(dln.out.view(-1, K), "ln_out", torch.float32) if first else None
+            keep += [r2, ga, be, p2, o2]
+            lres.append(r2.data_ptr()); lga.append(ga.data_ptr()); lbe.append(be.data_ptr()); leps.append(float(dln.ln.eps))
+            lpos.append(p2.data_ptr() if p2 is not None else None); lprows.append(p2.shape[0] if p2 is not None else 1)
+            lout.append(o2.data_ptr() if o2 is not None else None)
+        else:
+            if it.get("pos") is not None:
+                raise ValueError("linear_grouped: pos needs a DeferredLayerNorm input")
+            x2 = _chk(x.reshape(-1, K).contiguous(), "x", torch.float32)
+            lres.append(None); lga.append(None); lbe.append(None); leps.append(0.0); lpos.append(None); lprows.append(1)
+            lout.append(None)
         w2 = _chk(w.detach().contiguous(), "w", torch.float32)
         b2 = _chk(b.detach().contiguous(), "b", torch.float32) if b is not None else None
         if w2.shape[1] != K or x.shape[-1] != K:
@@ -447,8 +522,8 @@ def linear_grouped(items):
         M, N = x2.shape[0], w2.shape[0]
         out = it.get("out")
         if out is None:
-            y2 = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            outs.append(y2.view(*x.shape[:-1], N))
+            y2 = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+            outs.append(y2.view(*lead, N))
         else:
             if out.dim() != 2 or out.shape != (M, N) or out.stride(1) != 1:
                 raise ValueError("linear_grouped: out must be a [rows, N] view with unit inner stride")
@@ -460,9 +535,18 @@ def linear_grouped(items):
         ax.append(float(it.get("alpha_x", 1.0))); al.append(float(it.get("alpha", 1.0)))
         rl.append(1 if it.get("relu") else 0)
     PA, IA, FA = ctypes.c_void_p * G, ctypes.c_int * G, ctypes.c_float * G
-    st = lib.egtr_linear_grouped_f32(_stream(), G, PA(*xs), PA(*ws), PA(*bs), PA(*ys), IA(*Ms), IA(*Ns), IA(*lds),
-                                     FA(*ax), FA(*al), IA(*rl), K)
-    _lib.check(st, "egtr_linear_grouped_f32")
+    if any_ln:
+        st = lib.egtr_linear_grouped_ln_f32(_stream(), G, PA(*xs), PA(*ws), PA(*bs), PA(*ys), IA(*Ms), IA(*Ns), IA(*lds),
+                                            FA(*ax), FA(*al), IA(*rl), K, PA(*lres), PA(*lga), PA(*lbe), FA(*leps),
+                                            PA(*lpos), IA(*lprows), PA(*lout))
+        _lib.check(st, "egtr_linear_grouped_ln_f32")
+        for it in items:
+            if isinstance(it["x"], DeferredLayerNorm):
+                it["x"].done = True
+    else:
+        st = lib.egtr_linear_grouped_f32(_stream(), G, PA(*xs), PA(*ws), PA(*bs), PA(*ys), IA(*Ms), IA(*Ns), IA(*lds),
+                                         FA(*ax), FA(*al), IA(*rl), K)
+        _lib.check(st, "egtr_linear_grouped_f32")
     return outs
 
 

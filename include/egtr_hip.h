@@ -184,6 +184,18 @@ int egtr_linear_grouped_f32(egtr_stream_t stream, int num_groups, const float* c
                             const float* const* bias, float* const* y, const int* M, const int* N, const int* ldy,
                             const float* alpha_x, const float* alpha, const int* relu, int K);
 
+/* egtr_linear_grouped_f32 with a LayerNorm PROLOGUE per group (K == 256): where ln_gamma[g] != NULL the layer's input is
+ *   LayerNorm(x_g + ln_residual_g) * ln_gamma_g + ln_beta_g  [+ pos_g[row % pos_rows_g]]       (rows of 256 channels)
+ * -- the decoder's "residual add + LayerNorm" (model/deformable_detr.py:1437-1438, 1456-1457, 1466-1468) evaluated by its
+ * consumer instead of in a launch of its own -- and ln_out[g] (may be NULL) receives the LayerNorm result (without pos),
+ * [M_g, 256] contiguous, written by the workgroups of output-column tile 0.  Groups with ln_gamma[g] == NULL behave as in
+ * egtr_linear_grouped_f32; ln_gamma == NULL: no group has a prologue (the other ln_* / pos arrays are then ignored). */
+int egtr_linear_grouped_ln_f32(egtr_stream_t stream, int num_groups, const float* const* x, const float* const* w,
+                               const float* const* bias, float* const* y, const int* M, const int* N, const int* ldy,
+                               const float* alpha_x, const float* alpha, const int* relu, int K,
+                               const float* const* ln_residual, const float* const* ln_gamma, const float* const* ln_beta,
+                               const float* ln_eps, const float* const* pos, const int* pos_rows, float* const* ln_out);
+
 /* ---- MSDA prologue under autograd (training) -------------------------------------------------------------------- */
 /* sampling_locations [rows, M, L, P, 2] and attention_weights [rows, M, L, P] (softmax over the L * P samples of a head)
  * from the two nn.Linear outputs sampling_offsets [rows, M * L * P * 2] / attention_logits [rows, M * L * P] (row strides

@@ -1383,3 +1383,38 @@ def test_weighted_column_sum_vs_float64(M, N):
     ref = (w.double().t() @ g.double()).reshape(-1)
     assert (out.double() - ref).abs().max() <= 1e-5 * float((w.abs() * g.abs()).sum(0).max())
     assert torch.equal(out, ops.weighted_column_sum(g, w))
+
+
+@pytest.mark.parametrize("B,N", [(1, 200), (2, 37), (1, 16)])
+def test_linear_grouped_layernorm_prologue(B, N):
+    """egtr_linear_grouped_ln_f32: groups whose input is a DeferredLayerNorm evaluate LayerNorm(a + b) [+ pos] themselves
+    (dd:1437-1438, 1456-1457, 1466-1468 folded into the consuming nn.Linear), exactly one of them stores the LayerNorm
+    result; plain groups in the same launch are unaffected.  Against the fp32 torch composition, 2e-5."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(5 + N)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(DEV)  # noqa: E731
+    a, b, pos, other = r(B, N, 256), r(B, N, 256, sc=2.0), r(1, N, 256), r(B, N, 256)
+    ln = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * r(256))
+        ln.bias.copy_(0.2 * r(256))
+    ws = [r(n, 256, sc=1 / 16) for n in (256, 256, 384, 1024, 256)]
+    bs = [r(n, sc=0.1) for n in (256, 256, 384, 1024, 256)]
+    with torch.no_grad():
+        y = ln(a + b)
+        want = [torch.nn.functional.linear(y + pos, ws[0], bs[0]) * 0.25, torch.nn.functional.linear(y + pos, ws[1], bs[1]),
+                torch.nn.functional.linear(y, ws[2], bs[2]), torch.relu(torch.nn.functional.linear(y, ws[3], bs[3])),
+                torch.nn.functional.linear(other, ws[4], bs[4])]
+        d = ops.DeferredLayerNorm(a, b, ln)
+        got = ops.linear_grouped([dict(x=d, pos=pos[0], w=ws[0], b=bs[0], alpha=0.25), dict(x=d, pos=pos[0], w=ws[1], b=bs[1]),
+                                  dict(x=d, w=ws[2], b=bs[2]), dict(x=d, w=ws[3], b=bs[3], relu=True),
+                                  dict(x=other, w=ws[4], b=bs[4])])
+    assert d.done and (d.out - y).abs().max() < 2e-5
+    for gt, wt in zip(got, want):
+        assert gt.shape == wt.shape and (gt - wt).abs().max() < 2e-5 * max(1.0, float(wt.abs().max()))
+    # a consumed DeferredLayerNorm is a plain tensor for later launches; an unconsumed one can be materialised directly
+    with torch.no_grad():
+        again = ops.linear_grouped([dict(x=d, w=ws[2], b=bs[2])])[0]
+        d2 = ops.DeferredLayerNorm(a, b, ln)
+        assert (again - want[2]).abs().max() < 2e-5 * float(want[2].abs().max())
+        assert (d2.materialize() - y).abs().max() < 2e-5 and d2.done
