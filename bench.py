@@ -411,10 +411,14 @@ def train_bench(args, world, rank, dev, dist, emit=True):
         if bwd_args is not None and not args.no_kernel_probes:
             us, alg = time_msda_backward(bwd_args)
             ach = alg / (us * 1e-6) / 1e9
-            result["roofline"] = {"bound": "hbm", "kernel": "msda_bwd_q64_f32<no atomics> + msda_bwd_value_tile_f32",
+            bwd_kernel = "msda_bwd_q64_f32<no atomics> + msda_bwd_value_tile_f32"
+            # HBM bytes of the pair from separate --pmc passes over the train command (tools/pmc_train.sh), batch 4
+            bp, bp_src = newest_pmc("r*_msda_bwd_pmc.json", bwd_kernel) if batch == 4 else ({}, None)
+            result["roofline"] = {"bound": "hbm", "kernel": bwd_kernel,
                                   "launch": f"encoder layer backward, B={batch}, Lq = S = 12537",
                                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": bp.get("hbm_bytes_per_launch"),
+                                  "traffic_source": bp_src, "l2_hit": bp.get("l2_hit"),
                                   "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2)}
         if world == 1 and not args.no_cpu_baseline:
             ncores = usable_cores()
@@ -735,7 +739,8 @@ def main():
         torch.cuda.empty_cache()
         import copy
         targs = copy.copy(args)
-        targs.mode, targs.batch, targs.steps, targs.warmup = "train", 4, args.extra_steps, max(3, args.extra_steps // 2)
+        # 10 warm-up steps as in `--mode train`: TunableOp picks and the caching allocator's pool settle over the first steps
+        targs.mode, targs.batch, targs.steps, targs.warmup = "train", 4, 2 * args.extra_steps, 10
         targs.no_cpu_baseline, targs.no_kernel_probes = True, False
         torch.backends.cudnn.benchmark = False      # MIOpen find mode: no gain for the train step
         try:
