@@ -209,32 +209,57 @@ def test_stress_geometry_fp32_bs16_vs_reference(golden_dir):
 
 
 def test_stress_geometry_bf16_vs_reference_with_bf16_weights(golden_dir):
-    """The stress config's dtype: the bf16 product model (bf16 weights AND activations, bf16 MSDA / relation-head
-    kernels) at 800x1333, N = 300, 8 decoder layers, against the REFERENCE evaluated in fp32 arithmetic with the same
-    bf16-rounded weights and pixels (fixture keys bf16w_*).  What differs is therefore only the bf16 rounding of
-    activations through 6 + 8 layers; stated tolerances (absolute, on O(1) quantities): class logits 0.3, boxes
-    0.03, relation-MLP logits 0.3, connectivity logits 0.3 (max), and mean errors 10x below that.  The frequency bias is
-    switched off for this run so that the relation output IS the MLP logit (a bf16 tensor cannot hold -29 + x)."""
+    """The stress config's dtype AND batch: the bf16 product model (bf16 weights and activations, bf16 MSDA / relation-head
+    kernels) at 800x1333, N = 300, 8 decoder layers, bs = 16 (the fixture's 2 distinct images, one padded, repeated 8x),
+    against the REFERENCE evaluated in fp32 arithmetic with the same bf16-rounded weights and pixels (fixture keys bf16w_*).
+    What differs is therefore only the bf16 rounding of activations through 6 + 8 layers.
+      * ALL 16 images are compared (replicas are not bit-identical: the GroupNorm statistics of the input projection are
+        accumulated with float atomics, an fp32-rounding-level difference that bf16 layers amplify to ~0.05);
+      * errors on O(1) quantities: class logits, boxes, relation-MLP logits, connectivity logits; (max, mean) tolerances ~1.6x what
+        this code measures over the 16 images (printed below);
+      * with the frequency bias ON (as the bench's stress line runs it) the model's pred_rel = sigmoid(MLP + bias) is
+        compared with sigmoid(reference MLP logit + bias) on the pairs whose argmax classes agree with the reference's."""
     g, model, cfg = _stress_model(golden_dir)
     model = model.to(DEV).eval().to(torch.bfloat16)
-    model.config.use_freq_bias = False
+    model.config.use_freq_bias = False      # the relation output IS the MLP logit (a bf16 tensor cannot hold -29 + x)
     pv2, pm2 = Hh.padded_inputs(g, 2)
-    pv, pm = pv2.to(DEV).to(torch.bfloat16), pm2.to(DEV)
+    pv, pm = pv2.repeat(8, 1, 1, 1).to(DEV).to(torch.bfloat16), pm2.repeat(8, 1, 1).to(DEV)
     h = Hh.product_heads(model, pv, pm)
-    assert h["rel_logits"].dtype == torch.bfloat16
+    assert h["rel_logits"].dtype == torch.bfloat16 and h["rel_logits"].shape[0] == 16
+    rep = lambda a: _t(a).repeat(8, *([1] * (a.ndim - 1)))  # noqa: E731
     errs = {}
-    tols = {"logits": 0.3, "pred_boxes": 0.03, "conn_logits": 0.3, "rel_mlp": 0.3}
+    # (max, mean); measured in round 3 over the 16 images: logits 0.166 / 0.0136, boxes 0.0096 / 0.0018, connectivity
+    # 0.133 / 0.0129, relation MLP 0.138 / 0.0127 (round 2 asserted 0.3 / 0.03 on two images)
+    tols = {"logits": (0.27, 0.022), "pred_boxes": (0.016, 0.003), "conn_logits": (0.22, 0.021), "rel_mlp": (0.22, 0.021)}
     for key, ref in (("logits", "bf16w_logits"), ("pred_boxes", "bf16w_pred_boxes"),
                      ("conn_logits", "bf16w_conn_logits")):
         got = h[key].float().cpu()
         got = got[..., 0] if key == "conn_logits" else got
-        d = (got - _t(g[ref])).abs()
+        d = (got - rep(g[ref])).abs()
         errs[key] = (float(d.max()), float(d.mean()))
-    d = (h["rel_logits"].float().cpu()[:, ::5, ::7] - _t(g["bf16w_rel_mlp_strided"])).abs()
+    d = (h["rel_logits"].float().cpu()[:, ::5, ::7] - rep(g["bf16w_rel_mlp_strided"])).abs()
     errs["rel_mlp"] = (float(d.max()), float(d.mean()))
     print("bf16 stress errors (max, mean):", errs)
     for key, (mx, mean) in errs.items():
-        assert mx < tols[key] and mean < tols[key] / 10, (key, errs)
+        assert mx < tols[key][0] and mean < tols[key][1], (key, errs)
+    # frequency bias on: probabilities, where the looked-up classes are the reference's
+    del h
+    model.config.use_freq_bias = True
+    with torch.no_grad():
+        out = model(pixel_values=pv[:2], pixel_mask=pm[:2])
+    node = out.logits.float().argmax(-1).cpu()                       # [2, N]
+    node_ref = _t(g["bf16w_logits"]).argmax(-1)
+    trip = model.triplet_dist.float().cpu()
+    ii, jj = torch.arange(0, 300, 5), torch.arange(0, 300, 7)
+    bias = torch.stack([trip[node_ref[b][ii]][:, node_ref[b][jj]] for b in range(2)])        # [2, 60, 43, R]
+    want = torch.sigmoid(_t(g["bf16w_rel_mlp_strided"]) + bias)
+    got = out.pred_rel.float().cpu()[:, ::5, ::7]
+    same = (node == node_ref)
+    pair_ok = same[:, ii][:, :, None] & same[:, jj][:, None, :]
+    assert pair_ok.float().mean() > 0.9, float(pair_ok.float().mean())
+    dp = (got - want).abs()[pair_ok]
+    print("bf16 stress pred_rel with frequency bias (max, mean):", float(dp.max()), float(dp.mean()))
+    assert dp.max() < 0.045 and dp.mean() < 0.003      # measured 0.028 / 0.0018
 
 
 def test_train_step_600x1000_bs2_aux_vs_reference(golden_dir):
