@@ -213,8 +213,9 @@ def test_stress_geometry_bf16_vs_reference_with_bf16_weights(golden_dir):
     kernels) at 800x1333, N = 300, 8 decoder layers, bs = 16 (the fixture's 2 distinct images, one padded, repeated 8x),
     against the REFERENCE evaluated in fp32 arithmetic with the same bf16-rounded weights and pixels (fixture keys bf16w_*).
     What differs is therefore only the bf16 rounding of activations through 6 + 8 layers.
-      * ALL 16 images are compared (replicas are not bit-identical: the GroupNorm statistics of the input projection are
-        accumulated with float atomics, an fp32-rounding-level difference that bf16 layers amplify to ~0.05);
+      * ALL 16 images are compared (replicas are deterministic but not bit-identical: the summation order of a token row
+        depends on where the row sits in the batch -- vendor GEMM tilings here, the rotated chunk order of the fused FFN
+        kernel in the fp32 model -- a rounding-level difference that fourteen bf16 layers amplify to ~0.05);
       * errors on O(1) quantities: class logits, boxes, relation-MLP logits, connectivity logits; (max, mean) tolerances ~1.6x what
         this code measures over the 16 images (printed below);
       * with the frequency bias ON (as the bench's stress line runs it) the model's pred_rel = sigmoid(MLP + bias) is
