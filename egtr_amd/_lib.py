@@ -78,6 +78,8 @@ SIGNATURES = {
     "egtr_linear_split_bf16_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_pad_batch_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "egtr_ffn_x6_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I, _I],
+    "egtr_encoder_tail_x6_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, ctypes.c_float,
+                                 _P, _I, _P, _P, _I, _I, _I],
     "egtr_proj_ln_x6_f32": [_P, _P, _I, _P, _P, _P, _I, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I],
     "egtr_proj_multi_x6_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I],
     "egtr_xs_bytes": [_I, _I],

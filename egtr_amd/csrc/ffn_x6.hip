@@ -73,6 +73,13 @@ struct FfnArgs {
   int M, ldx, ldr, F, pos_rows;
   float eps;
   long long* tdbg;   // development: cycle stamps of wave 0 of workgroup 0 (FFN_TIMING builds), else null
+  // ffn_x6_kernel<true> (encoder layer tail): x is the attention context; y1 = LayerNorm1(res + x . Wp^T + bp) is the
+  // FFN's input AND its residual (res / ldr = the layer input, the residual of LayerNorm1)
+  const char* wp;        // XS(Wp [256, 256])
+  const float* bp;       // [256]
+  const float* gamma1;   // LayerNorm1 weight / bias
+  const float* beta1;
+  float eps1;
 };
 
 // Logical 16-byte slot x (= row + 32 * k-group) of a panel fragment of k-step ks -> where it is stored.  build_panel's lane
@@ -114,8 +121,11 @@ __device__ __forceinline__ void build_panel(const float* __restrict__ x, int ldx
 // of the 32-wide tile, m = lane & 31: a lane holds 64 channels of its row, lane ^ 32 another 64, the wave next door (wn ^ 1)
 // the other 128 -- row sums through a cross-lane swap and one exchange through `red` (1 KiB of idle LDS), mean first, then
 // the centred sum of squares.
+// res_of(t, q): the residual values of register group (t, q) when they are NOT read from A.res (encoder tail: LayerNorm1's
+// result still in registers); USE_RES_OF selects.
+template <bool USE_RES_OF, class ResFn>
 __device__ __forceinline__ void final_epilogue(const f32x16 (&acc2)[4], const FfnArgs& A, int r0, int wave, int lane,
-                                               float* red) {
+                                               float* red, ResFn&& res_of) {
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, hf = lane >> 5;
   const int row = r0 + wm * 32 + li;
   float4 y[4][4];
@@ -134,7 +144,10 @@ __device__ __forceinline__ void final_epilogue(const f32x16 (&acc2)[4], const Ff
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 r = *reinterpret_cast<const float4*>(xr + (4 * wn + t) * 32 + 8 * q + 4 * hf);
+        // the residual rows: from memory, or (encoder tail) LayerNorm1's result still in registers
+        float4 r;
+        if constexpr (USE_RES_OF) r = res_of(t, q);
+        else r = *reinterpret_cast<const float4*>(xr + (4 * wn + t) * 32 + 8 * q + 4 * hf);
         y[t][q].x += r.x; y[t][q].y += r.y; y[t][q].z += r.z; y[t][q].w += r.w;
       }
     __syncthreads();                                      // every wave is done with the LDS `red` aliases
@@ -184,6 +197,51 @@ __device__ __forceinline__ void final_epilogue(const f32x16 (&acc2)[4], const Ff
   }
 }
 
+// LayerNorm over the 256 channels of the rows of a 64 x 256 tile held in the accumulator layout (see final_epilogue), in
+// place.  `red`: 1 KiB of LDS nobody else touches meanwhile.  Three workgroup barriers.
+__device__ __forceinline__ void layernorm_rows(float4 (&y)[4][4], const float* gamma, const float* beta, float eps, int wave,
+                                               int lane, float* red) {
+  const int wn = wave & 1, li = lane & 31, hf = lane >> 5;
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum += (y[t][q].x + y[t][q].y) + (y[t][q].z + y[t][q].w);
+  sum += __shfl_xor(sum, 32);
+  if (hf == 0) red[wave * 32 + li] = sum;
+  __syncthreads();
+  const float mean = (sum + red[(wave ^ 1) * 32 + li]) * (1.f / kD);
+  float sq = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      y[t][q].x -= mean; y[t][q].y -= mean; y[t][q].z -= mean; y[t][q].w -= mean;
+      sq += (y[t][q].x * y[t][q].x + y[t][q].y * y[t][q].y) + (y[t][q].z * y[t][q].z + y[t][q].w * y[t][q].w);
+    }
+  sq += __shfl_xor(sq, 32);
+  if (hf == 0) red[128 + wave * 32 + li] = sq;
+  __syncthreads();
+  const float rstd = rsqrtf((sq + red[128 + (wave ^ 1) * 32 + li]) * (1.f / kD) + eps);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
+      const float4 g = *reinterpret_cast<const float4*>(gamma + col), b = *reinterpret_cast<const float4*>(beta + col);
+      y[t][q] = make_float4(y[t][q].x * rstd * g.x + b.x, y[t][q].y * rstd * g.y + b.y, y[t][q].z * rstd * g.z + b.z,
+                            y[t][q].w * rstd * g.w + b.w);
+    }
+}
+
+// PROJ = false: the FFN block of the header.  PROJ = true: the whole TAIL of an encoder layer in one launch --
+//     y1 = self_attn_layer_norm(hidden + output_proj(context));  out = final_layer_norm(y1 + fc2(relu(fc1(y1))))  [+ pos]
+// (model/deformable_detr.py:1102, 1326-1345): sixteen weight stages of the output projection run first on the same ring
+// (context panel in, 64 x 256 tile in the layer-2 accumulators), LayerNorm1 happens in registers, its result is split into the
+// panel in place of the context (lo pieces through the idle chunk buffer, one row block at a time) and kept in registers as
+// the FFN's residual -- y1 never goes to memory, and one prologue, one epilogue burst and one launch disappear.
+template <bool PROJ>
 __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const panel = smem;
@@ -197,34 +255,47 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   const int r0 = blockIdx.x * kRows;
   const int nchunk = A.F >> 6, KSf = A.F >> 4;
 
-  // ---- weight stream: stage g = 8 c + s; s < 4: layer 1, hidden units 64 c .., k-steps 4 s .. 4 s + 3 of d_model
+  // ---- weight stream.  Global stage g: [PROJ: g < 16 = k-step g of the output projection, all 256 outputs ([8 n-blocks][3
+  //      pieces]), then] stage 8 c + s of the FFN -- s < 4: layer 1, hidden units 64 c .., k-steps 4 s .. 4 s + 3 of d_model
   //      ([2 n-blocks][4 k-steps][3 pieces]); s >= 4: layer 2, k-step 4 c + (s - 4) of the hidden dimension, all 256 outputs
   //      ([8 n-blocks][3 pieces]).  Wave w moves fragments 6 w .. 6 w + 5 of the stage image: contiguous in LDS, and in
-  //      global memory one 6 KiB run (layer 1) or two 3 KiB runs (layer 2).
+  //      global memory one 6 KiB run (layer 1) or two 3 KiB runs (layer 2, projection).
   const unsigned voff = lane * 16;
-  // stage (c, s) beyond the last one: re-load the last stage (never read; keeps every wait count an immediate)
   // Workgroup b walks the hidden chunks in the rotated order b, b + 1, .. (mod nchunk): workgroups that run side by side
   // then stream DIFFERENT weight fragments at any moment (all of them fetching the same 24 KiB stage at once makes a few
   // L2 channels the bottleneck: 91 -> 8x us at S = 12 537).  The sum over chunks is the same set in a rotated order.
   const int crot = blockIdx.x % nchunk;
   auto chunk_of = [&](int c) { const int t = c + crot; return t >= nchunk ? t - nchunk : t; };
-  auto issue = [&](int c, int s, int slot) {
-    if (c >= nchunk) { c = nchunk - 1; s = 7; }
-    c = chunk_of(c);
-    const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
-    if (s < 4) {
-      const char* src = A.w1 + ((size_t)((2 * c + (wave >> 1)) * kKS + 4 * s + 2 * (wave & 1)) * 3) * kFrag;
-#pragma unroll
-      for (int i = 0; i < NL; ++i) dma16s(src + i * kFrag, voff, dst + i * kFrag);
-    } else {
-      const int kh = 4 * c + (s - 4);
-#pragma unroll
-      for (int i = 0; i < NL; ++i)
-        dma16s(A.w2 + ((size_t)((2 * wave + i / 3) * KSf + kh) * 3 + i % 3) * kFrag, voff, dst + i * kFrag);
+  constexpr int NP = PROJ ? kKS : 0;           // stages of the output projection in front of the FFN stream
+  const int nstages = NP + 8 * nchunk;
+  const size_t nb_stride = (size_t)KSf * 3 * kFrag;
+  // source of this wave's six fragments of global stage g: fragment j at base + (j / 3) * stride + (j % 3) KiB -- scalar
+  // arithmetic, the same instruction sequence for every kind of stage (no branch between MFMAs).  Beyond the last stage:
+  // the last one again (never read; keeps every wait count an immediate).
+  auto stage_src = [&](int g, const char*& base, size_t& stride) {
+    g = g < nstages ? g : nstages - 1;
+    const bool pj = g < NP;
+    const int gg = g - NP, c = chunk_of(pj ? 0 : gg >> 3), st = gg & 7;
+    const bool l1 = st < 4;
+    const char* b1 = A.w1 + ((size_t)((2 * c + (wave >> 1)) * kKS + 4 * (st & 3) + 2 * (wave & 1)) * 3) * kFrag;
+    const char* b2 = A.w2 + ((size_t)(2 * wave * KSf + 4 * c + (st & 3)) * 3) * kFrag;
+    base = l1 ? b1 : b2;
+    stride = l1 ? (size_t)3 * kFrag : nb_stride;
+    if constexpr (PROJ) {
+      base = pj ? A.wp + ((size_t)(2 * wave * kKS + g) * 3) * kFrag : base;
+      stride = pj ? (size_t)kKS * 3 * kFrag : stride;
     }
   };
-  issue(0, 0, 0);
-  issue(0, 1, 1);
+  auto issue = [&](int g, int slot) {
+    const unsigned dst = lds_ring + (unsigned)slot * kStage + (unsigned)wave * (NL * kFrag);
+    const char* base;
+    size_t stride;
+    stage_src(g, base, stride);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) dma16s(base + (i / 3) * stride + (i % 3) * kFrag, voff, dst + i * kFrag);
+  };
+  issue(0, 0);
+  issue(1, 1);
 
   build_panel(A.x, A.ldx, A.M, r0, tid, lane, panel, hbuf, ring + 2 * kStage);
   __syncthreads();
@@ -246,30 +317,27 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
     return *reinterpret_cast<const bf16x8*>(panel + ((wm * kKS + ks) * 2 + piece) * kFrag + (swz(lane, ks) << 4));
   };
   const char* const ph = hbuf + (wm * 4 * 3) * kFrag + lane * 16;      // hidden-chunk fragments of this wave's 32 rows
-  // weight fragments of a stage, as this wave reads them: layer 1 = [k-step 4][piece 3] of n-block wn, layer 2 = [n tile
-  // 4][piece 3] of n-blocks 4 wn ..: in both images fragment (u, p) sits at ((4 wn + u) * 3 + p) KiB
+  // weight fragments of a stage, as this wave reads them: layer 1 = [k-step 4][piece 3] of n-block wn, layer 2 / projection
+  // = [n tile 4][piece 3] of n-blocks 4 wn ..: in both images fragment (u, p) sits at ((4 wn + u) * 3 + p) KiB
   const char* const pw = ring + (4 * wn * 3) * kFrag + lane * 16;
   auto frag = [](const char* p) { return *reinterpret_cast<const bf16x8*>(p); };
 
   // One stage in PINNED program order (sched_barrier(0) between the items; left alone, hipcc reads every operand right
   // before its use and chains six dependent MFMAs on one accumulator): 24 MFMAs, consecutive ones on different
   // accumulators; behind MFMAs 1, 3, .., 11 the six DMA instructions of stage g + 3; behind MFMAs 12 .. 17 the twelve
-  // weight fragments of stage g + 1 (other register set), two at a time; the hi / mid fragments of the input panel
-  // (layer 1) one k-step ahead of their use.  Everything but the matrix instructions issues in the shadow of an MFMA.
-  // a / anx: operand A of this / the next stage: layer 1 = [k-step 4][hi, mid] (lo comes from the registers), layer 2 =
-  // the three pieces of the hidden k-step in a[0][0], a[0][1], a[1][0]
-  auto stage = [&](auto S, const bf16x8 (&w)[4][3], bf16x8 (&wnx)[4][3], const bf16x8 (&a)[4][2], bf16x8 (&anx)[4][2], int c,
+  // weight fragments of stage g + 1 (other register set), two at a time; the operand A fragments of the next stage where
+  // nothing orders them behind the next barrier.  Everything but the matrix instructions issues in the shadow of an MFMA.
+  // S: 0 .. 3 = layer 1 step S; 4 .. 7 = layer 2 step S - 4; 8 + ks = projection k-step ks (PROJ).
+  // a / anx: operand A of this / the next stage: layer 1 = [k-step 4][hi, mid] (lo comes from the registers); layer 2 and
+  // projection = the three pieces of ONE k-step in a[0][0], a[0][1], a[1][0].
+  auto stage = [&](auto S, const bf16x8 (&w)[4][3], bf16x8 (&wnx)[4][3], const bf16x8 (&a)[4][2], bf16x8 (&anx)[4][2], int g,
                    int slot_next, int slot_fill) {
     constexpr int s = decltype(S)::value;
     const char* const wn_src = pw + slot_next * kStage;
     const unsigned dst = lds_ring + (unsigned)slot_fill * kStage + (unsigned)wave * (NL * kFrag);
-    constexpr int s3 = (s + 3) & 7;
-    int c3 = c + ((s + 3) >> 3);
-    const bool past = c3 >= nchunk;          // stage g + 3 does not exist: re-load the last stage (never read)
-    c3 = chunk_of(past ? nchunk - 1 : c3);
-    const char* src1 = A.w1 + ((size_t)((2 * c3 + (wave >> 1)) * kKS + 4 * (s3 & 3) + 2 * (wave & 1)) * 3) * kFrag;
-    const char* src2 = A.w2 + ((size_t)(2 * wave * KSf + 4 * c3 + (s3 & 3)) * 3) * kFrag;
-    const size_t nb_stride = (size_t)KSf * 3 * kFrag;
+    const char* src;
+    size_t sstride;
+    stage_src(g + 3, src, sstride);
     static_for<24>([&](auto I) {
       constexpr int i = decltype(I)::value;
       // the six cross terms, small ones first: (w piece, a piece)
@@ -289,8 +357,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       }
       if constexpr (FFN_ABL != 1 && (i & 1) && (i >> 1) < NL) {
         constexpr int j = i >> 1;
-        if constexpr (s3 < 4) dma16s(src1 + j * kFrag, voff, dst + j * kFrag);
-        else dma16s(src2 + (j / 3) * nb_stride + (j % 3) * kFrag, voff, dst + j * kFrag);
+        dma16s(src + (j / 3) * sstride + (j % 3) * kFrag, voff, dst + j * kFrag);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (FFN_ABL != 4 && i >= 12 && i < 18) {
@@ -299,20 +366,30 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
         wnx[(j + 1) / 3][(j + 1) % 3] = frag(wn_src + (j + 1) * kFrag);
         __builtin_amdgcn_sched_barrier(0);
       }
-      // operand A of the next stage, where nothing orders it behind the next barrier: layer 1 reads the read-only input
-      // panel, k-steps 1 .. 3 of layer 2 a hidden chunk finished at least a stage ago (k-step 0: after the barrier)
-      constexpr int sx = (s + 1) & 7;
-      if constexpr (i >= 18 && i < 22 && sx < 4) {
-        constexpr int kl = i - 18;
-        anx[kl][0] = pfrag(4 * sx + kl, 0);
-        anx[kl][1] = pfrag(4 * sx + kl, 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if constexpr (i == 18 && sx > 4) {
-        anx[0][0] = frag(ph + ((sx - 4) * 3 + 0) * kFrag);
-        anx[0][1] = frag(ph + ((sx - 4) * 3 + 1) * kFrag);
-        anx[1][0] = frag(ph + ((sx - 4) * 3 + 2) * kFrag);
-        __builtin_amdgcn_sched_barrier(0);
+      if constexpr (s < 8) {
+        // layer 1 reads the read-only input panel, steps 1 .. 3 of layer 2 a hidden chunk finished at least a stage ago
+        // (step 0: after the barrier)
+        constexpr int sx = (s + 1) & 7;
+        if constexpr (i >= 18 && i < 22 && sx < 4) {
+          constexpr int kl = i - 18;
+          anx[kl][0] = pfrag(4 * sx + kl, 0);
+          anx[kl][1] = pfrag(4 * sx + kl, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (i == 18 && sx > 4) {
+          anx[0][0] = frag(ph + ((sx - 4) * 3 + 0) * kFrag);
+          anx[0][1] = frag(ph + ((sx - 4) * 3 + 1) * kFrag);
+          anx[1][0] = frag(ph + ((sx - 4) * 3 + 2) * kFrag);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else if constexpr (s - 8 + 1 < kKS) {
+        // projection: the next k-step of the context panel (after the last one the panel is rebuilt first)
+        if constexpr (i == 18) {
+          anx[0][0] = pfrag(s - 8 + 1, 0);
+          anx[0][1] = pfrag(s - 8 + 1, 1);
+          anx[1][0] = lo[s - 8 + 1];
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     });
   };
@@ -325,29 +402,98 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   wait_vm<NL>();                      // stage 0 (stage 1 in flight)
   wait_lgkm0();
   __builtin_amdgcn_s_barrier();
-  issue(0, 2, 2);
+  issue(2, 2);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
     for (int p = 0; p < 3; ++p) w0[u][p] = frag(pw + (u * 3 + p) * kFrag);
+  int slot = 0;   // ring slot of the stage being multiplied
+  int g = 0;      // its global index
+  auto stage_top = [&]() {
+    // this wave's DMAs of stage g + 1 have landed (those of g + 2 stay in flight), everybody's LDS traffic of stage g - 1
+    // is finished (lgkmcnt(0) + barrier)
+    if (FFN_ABL == 1) wait_vm<0>(); else wait_vm<NL>();
+    wait_lgkm0();
+    if (FFN_ABL != 2) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  float4 y1[4][4];   // PROJ: LayerNorm1's result in the accumulator layout = the residual of the final LayerNorm
+  if constexpr (PROJ) {
+    a0[0][0] = pfrag(0, 0);
+    a0[0][1] = pfrag(0, 1);
+    a0[1][0] = lo[0];
+    static_for<kKS>([&](auto KS) {
+      constexpr int ks = decltype(KS)::value;
+      const int sn = slot == 2 ? 0 : slot + 1;
+      stage_top();
+      if constexpr ((ks & 1) == 0) stage(std::integral_constant<int, 8 + ks>{}, w0, w1, a0, a1, g, sn, slot);
+      else stage(std::integral_constant<int, 8 + ks>{}, w1, w0, a1, a0, g, sn, slot);
+      slot = sn;
+      ++g;
+    });
+    // ---- y1 = LayerNorm1(res + context . Wp^T + bp) in registers (accumulator layout, see final_epilogue)
+    const int row = r0 + wm * 32 + li;
+    const float* xr = A.res + (size_t)min(row, A.M - 1) * A.ldr;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = (4 * wn + t) * 32 + 8 * q + 4 * hf;
+        const float4 b = *reinterpret_cast<const float4*>(A.bp + col), r = *reinterpret_cast<const float4*>(xr + col);
+        y1[t][q] = make_float4(acc2[t][4 * q + 0] + b.x + r.x, acc2[t][4 * q + 1] + b.y + r.y, acc2[t][4 * q + 2] + b.z + r.z,
+                               acc2[t][4 * q + 3] + b.w + r.w);
+        acc2[t][4 * q + 0] = 0.f; acc2[t][4 * q + 1] = 0.f; acc2[t][4 * q + 2] = 0.f; acc2[t][4 * q + 3] = 0.f;
+      }
+    float* red = reinterpret_cast<float*>(hbuf + 16 * kFrag);     // the chunk buffer is idle until the first hand-over
+    layernorm_rows(y1, A.gamma1, A.beta1, A.eps1, wave, lane, red);   // its first barrier: everybody is done with the context panel
+    // ---- y1 -> the panel (hi / mid in place of the context), lo through hbuf[0, 16 KiB) one row block at a time.
+    //      Accumulator register group (t, q) = channels 32 (4 wn + t) + 8 q + 4 hf .. + 3 of row li: k-step 2 (4 wn + t) +
+    //      (q >> 1), k-group q & 1, bytes 8 hf .. 8 hf + 7 of the row's slot.
+    uint2 plo[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const xs::Split3 s0 = xs::split3_fast(y1[t][q].x), s1 = xs::split3_fast(y1[t][q].y), s2 = xs::split3_fast(y1[t][q].z),
+                         s3 = xs::split3_fast(y1[t][q].w);
+        const int ks = 2 * (4 * wn + t) + (q >> 1);
+        char* d = panel + ((wm * kKS + ks) * 2) * kFrag + (swz(li + 32 * (q & 1), ks) << 4) + 8 * hf;
+        *reinterpret_cast<uint2*>(d) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
+        *reinterpret_cast<uint2*>(d + kFrag) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
+        plo[t][q] = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
+      }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      if (wm == rb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ks = 2 * (4 * wn + t) + (q >> 1);
+            *reinterpret_cast<uint2*>(hbuf + ks * kFrag + (swz(li + 32 * (q & 1), ks) << 4) + 8 * hf) = plo[t][q];
+          }
+      }
+      __syncthreads();
+      if (wm == rb) {
+#pragma unroll
+        for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(hbuf + ks * kFrag + (swz(lane, ks) << 4));
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
     a0[u][0] = pfrag(u, 0);
     a0[u][1] = pfrag(u, 1);
   }
-  int slot = 0;   // ring slot of the stage being multiplied
 #pragma unroll 1
   for (int c = 0; c < nchunk; ++c) {
     static_for<8>([&](auto S) {
       constexpr int s = decltype(S)::value;
       const int sn = slot == 2 ? 0 : slot + 1;       // slot of stage g + 1
-      // top of stage g: this wave's DMAs of stage g + 1 have landed (those of g + 2 stay in flight), everybody's LDS traffic
-      // of stage g - 1 is finished (lgkmcnt(0) + barrier)
       FFN_STAMP(0);
-      if (FFN_ABL == 1) wait_vm<0>(); else wait_vm<NL>();
-      FFN_STAMP(1);
-      wait_lgkm0();
-      FFN_STAMP(2);
-      if (FFN_ABL != 2) __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+      stage_top();
       FFN_STAMP(3);
       if constexpr (s == 4) {          // the hidden chunk was written by the stage before: visible after this barrier
         a0[0][0] = frag(ph + 0 * kFrag);
@@ -362,15 +508,16 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
           for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
         // the chunk's 32 layer-1 bias values of this wave (wave-uniform) as SCALAR loads, three stages ahead of their use.
         // (A vector load here would be waited for with vmcnt(0) by the compiler -- draining the two stages of DMA in
-        // flight: measured 35 of 91 us.)
+        // flight: measured 35 of 91 us.)  Sound only while the compiler does not spill these SGPRs while the loads are in
+        // flight: tests/test_build_resources.py fails the build if this kernel has any SGPR spill.
         const float* bp = A.b1 + 64 * chunk_of(c) + 32 * wn;
         asm volatile("s_load_dwordx8 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x20\n\ts_load_dwordx8 %2, %4, 0x40\n\t"
                      "s_load_dwordx8 %3, %4, 0x60"
                      : "=&s"(bias[0]), "=&s"(bias[1]), "=&s"(bias[2]), "=&s"(bias[3])
                      : "s"(bp));
       }
-      if constexpr ((s & 1) == 0) stage(S, w0, w1, a0, a1, c, sn, slot);
-      else stage(S, w1, w0, a1, a0, c, sn, slot);
+      if constexpr ((s & 1) == 0) stage(S, w0, w1, a0, a1, g, sn, slot);
+      else stage(S, w1, w0, a1, a0, g, sn, slot);
       FFN_STAMP(4);
       if constexpr (s == 3 && FFN_ABL != 3) {
         // bias + ReLU + split of the wave's 32 x 32 piece of the hidden chunk -> XS fragments in LDS.  The 32 bias values
@@ -395,11 +542,12 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       }
       FFN_STAMP(5);
       slot = sn;
+      ++g;
     });
   }
   wait_vm<0>();   // the surplus re-loads of the tail must have landed before this workgroup's LDS can be handed on
   FFN_PHASE(2);
-  final_epilogue(acc2, A, r0, wave, lane, reinterpret_cast<float*>(ring));
+  final_epilogue<PROJ>(acc2, A, r0, wave, lane, reinterpret_cast<float*>(ring), [&](int t, int q) { return y1[t][q]; });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   FFN_PHASE(3);
 }
@@ -508,7 +656,7 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
     Aw.out = A.out + (size_t)w * A.M * kD;
     Aw.b2 = A.b2 != nullptr ? A.b2 + w * kD : nullptr;
     if (w + 1 == nw) wait_vm<0>();   // the surplus re-loads of the tail must have landed before the LDS is handed on
-    final_epilogue(acc2, Aw, r0, wave, lane, reinterpret_cast<float*>(ring));
+    final_epilogue<false>(acc2, Aw, r0, wave, lane, reinterpret_cast<float*>(ring), [](int, int) { return float4{}; });
   }
 }
 
@@ -528,14 +676,42 @@ extern "C" int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, co
     return EGTR_E_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kLds) != hipSuccess)
       return egtr_check_launch();
     attr_set = true;
   }
   FfnArgs a{x, x, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln_gamma, ln_beta, pos, out,
-            out_pos, M, ldx, ldx, ffn_dim, pos_rows, eps, g_ffn_tdbg};
-  hipLaunchKernelGGL(ffn_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
+            out_pos, M, ldx, ldx, ffn_dim, pos_rows, eps, g_ffn_tdbg, nullptr, nullptr, nullptr, nullptr, 0.f};
+  hipLaunchKernelGGL(ffn_x6_kernel<false>, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_encoder_tail_x6_f32(egtr_stream_t stream, const float* context, int ldc, const float* hidden, int ldh,
+                                        const void* wp_xs, const float* bp, const float* ln1_gamma, const float* ln1_beta,
+                                        float eps1, const void* w1_xs, const float* b1, const void* w2_xs, const float* b2,
+                                        const float* ln2_gamma, const float* ln2_beta, float eps2, const float* pos,
+                                        int pos_rows, float* out, float* out_pos, int M, int d_model, int ffn_dim) {
+  if (!context || !hidden || !wp_xs || !bp || !ln1_gamma || !ln1_beta || !w1_xs || !b1 || !w2_xs || !b2 || !ln2_gamma ||
+      !ln2_beta || !out || M <= 0 || ldc < d_model || ldh < d_model)
+    return EGTR_E_ARG;
+  if (out_pos && (!pos || pos_rows <= 0)) return EGTR_E_ARG;
+  if (d_model != kD || ffn_dim <= 0 || ffn_dim % 64 || (ldc & 3) || (ldh & 3)) return EGTR_E_UNSUPPORTED;
+  for (const void* p : {(const void*)context, (const void*)hidden, wp_xs, (const void*)bp, (const void*)ln1_gamma,
+                        (const void*)ln1_beta, w1_xs, w2_xs, (const void*)b2, (const void*)ln2_gamma, (const void*)ln2_beta,
+                        (const void*)out, (const void*)out_pos, (const void*)pos})
+    if (reinterpret_cast<uintptr_t>(p) & 15) return EGTR_E_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLds) != hipSuccess)
+      return egtr_check_launch();
+    attr_set = true;
+  }
+  FfnArgs a{context, hidden, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln2_gamma, ln2_beta,
+            pos, out, out_pos, M, ldc, ldh, ffn_dim, pos_rows, eps2, nullptr, static_cast<const char*>(wp_xs), bp, ln1_gamma,
+            ln1_beta, eps1};
+  hipLaunchKernelGGL(ffn_x6_kernel<true>, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }
 

@@ -488,7 +488,14 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         if residual_ln is not None:
             # inference plumbing: (residual, LayerNorm) of the enclosing layer -- the output projection, the residual add
             # and the LayerNorm (dd:1102, 1326-1330) as ONE launch where it applies; the third result says whether it did
-            residual, ln = residual_ln
+            residual, ln = residual_ln[:2]
+            tail = residual_ln[2] if len(residual_ln) > 2 else None
+            if tail is not None and ops.encoder_tail_fused_supported(output, self.output_proj, ln, tail["fc1"], tail["fc2"],
+                                                                     tail["ln"]):
+                # the enclosing encoder layer's WHOLE tail -- this projection, its LayerNorm, the FFN block and the closing
+                # LayerNorm (dd:1102, 1326-1345) -- as one launch; the third result says so
+                return (ops.encoder_tail_fused(output, residual, self.output_proj, ln, tail["fc1"], tail["fc2"], tail["ln"],
+                                               tail["pos"]), attention_weights, "tail")
             if ops.proj_ln_fused_supported(output, self.output_proj, ln):
                 return ops.proj_ln_fused(output, self.output_proj, residual, ln), attention_weights, True
             return ops.module_linear(self.output_proj, output), attention_weights, False
@@ -616,12 +623,23 @@ class DeformableDetrEncoderLayer(nn.Module):
         the previous layer / appended to the outputs for the next one (written by the final LayerNorm kernel)."""
         residual = hidden_states
         fuse = not self.training and ops.inference_fast_path(hidden_states)
+        tail = None
+        if fuse and self.activation_fn is F.relu and not output_attentions:
+            tail = dict(fc1=self.fc1, fc2=self.fc2, ln=self.final_layer_norm,
+                        pos=_pos_rows(position_embeddings) if return_with_pos and position_embeddings is not None else None)
         res = self.self_attn(
             hidden_states=hidden_states, attention_mask=attention_mask, encoder_hidden_states=hidden_states,
             encoder_attention_mask=attention_mask, position_embeddings=position_embeddings,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
-            hidden_with_pos=hidden_with_pos, residual_ln=(residual, self.self_attn_layer_norm) if fuse else None)
+            hidden_with_pos=hidden_with_pos,
+            residual_ln=(residual, self.self_attn_layer_norm, tail) if fuse else None)
+        if fuse and res[2] == "tail":      # the attention module ran the layer's whole tail (one launch)
+            out = res[0]
+            outputs = (out[0] if isinstance(out, tuple) else out,)
+            if return_with_pos:
+                outputs += (out[1] if isinstance(out, tuple) else None,)
+            return outputs
         hidden_states, attn_weights = res[0], res[1]
         if not (fuse and res[2]):
             hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)

@@ -901,6 +901,57 @@ def ffn_fused(x, fc1, fc2, ln=None, pos=None):
     return y if yp is None else (y, yp.view(x.shape))
 
 
+# The whole tail of an encoder layer (output projection + LayerNorm + FFN block + LayerNorm) as ONE launch
+# (egtr_encoder_tail_x6_f32); "0": projection + LayerNorm and the FFN block as two launches.
+ENCODER_TAIL_FUSED = os.environ.get("EGTR_ENCODER_TAIL_FUSED", "1") != "0"
+
+
+def encoder_tail_fused_supported(context, out_proj, ln1, fc1, fc2, ln2):
+    return (ENCODER_TAIL_FUSED and proj_ln_fused_supported(context, out_proj, ln1)
+            and ffn_fused_supported(context, fc1, fc2, ln2))
+
+
+def encoder_tail_fused(context, hidden, out_proj, ln1, fc1, fc2, ln2, pos=None):
+    """ln2(y1 + fc2(relu(fc1(y1)))) with y1 = ln1(hidden + out_proj(context)) [and the result + pos] in ONE HIP launch
+    (egtr_encoder_tail_x6_f32; reference: model/deformable_detr.py:1102, 1326-1345 in eval mode).  ``context``: the
+    deformable attention's output before its output projection.  Returns y or (y, y + pos).  Inference only."""
+    lib = _lib.lib()
+    K = context.shape[-1]
+
+    def rows_of(t):
+        t2 = t.reshape(-1, K)
+        if t2.stride(1) != 1 or t2.stride(0) % 4 or t2.data_ptr() % 16:
+            t2 = t2.contiguous()
+        return t2
+
+    c2, h2 = rows_of(context), rows_of(hidden)
+    rows, F = c2.shape[0], fc1.weight.shape[0]
+    if h2.shape[0] != rows:
+        raise ValueError("encoder_tail_fused: context and hidden must have the same rows")
+    wp = cached_weights(out_proj, "xs_weight", [out_proj.weight], lambda: xs_split(out_proj.weight, weights=True))
+    w1 = cached_weights(fc1, "xs_weight", [fc1.weight], lambda: xs_split(fc1.weight, weights=True))
+    w2 = cached_weights(fc2, "xs_weight", [fc2.weight], lambda: xs_split(fc2.weight, weights=True))
+    f32 = [_chk(t.detach().contiguous(), n, torch.float32)
+           for t, n in ((out_proj.bias, "out_proj.bias"), (ln1.weight, "ln1.weight"), (ln1.bias, "ln1.bias"),
+                        (fc1.bias, "fc1.bias"), (fc2.bias, "fc2.bias"), (ln2.weight, "ln2.weight"), (ln2.bias, "ln2.bias"))]
+    bp, g1, be1, b1, b2, g2, be2 = f32
+    y = torch.empty(rows, K, dtype=torch.float32, device=context.device)
+    p2 = yp = None
+    if pos is not None:
+        p2 = _chk(pos.reshape(-1, K).contiguous(), "pos", torch.float32)
+        if rows % p2.shape[0]:
+            raise ValueError("encoder_tail_fused: pos must tile the rows")
+        yp = torch.empty_like(y)
+    st = lib.egtr_encoder_tail_x6_f32(
+        _stream(), c2.data_ptr(), c2.stride(0), h2.data_ptr(), h2.stride(0), wp.data_ptr(), bp.data_ptr(), g1.data_ptr(),
+        be1.data_ptr(), float(ln1.eps), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), g2.data_ptr(),
+        be2.data_ptr(), float(ln2.eps), p2.data_ptr() if p2 is not None else None, p2.shape[0] if p2 is not None else 0,
+        y.data_ptr(), yp.data_ptr() if yp is not None else None, rows, K, F)
+    _lib.check(st, "egtr_encoder_tail_x6_f32")
+    y = y.view(hidden.shape)
+    return y if yp is None else (y, yp.view(hidden.shape))
+
+
 def proj_ln_fused_supported(x, lin, ln):
     rows = x.numel() // x.shape[-1]
     return (FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS

@@ -472,6 +472,18 @@ int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w
                     const float* b2, const float* ln_gamma, const float* ln_beta, float eps, const float* pos,
                     int pos_rows, float* out, float* out_pos, int M, int d_model, int ffn_dim);
 
+/* The whole TAIL of an encoder layer in one launch (csrc/ffn_x6.hip, ffn_x6_kernel<true>):
+ *   y1  = LayerNorm1(hidden + context . Wp^T + bp)                 (output_proj + self_attn_layer_norm, dd:1102, 1326-1330)
+ *   out = LayerNorm2(y1 + fc2(relu(fc1(y1))))   [out_pos = out + pos[row % pos_rows]]            (dd:1335-1345)
+ * context = the multi-scale deformable attention's output before its output projection [M, ldc], hidden = the layer's input
+ * [M, ldh]; wp_xs / w1_xs / w2_xs in the XS format (egtr_xs_split_f32, round_to_nearest = 1).  y1 never goes to memory.
+ * d_model == 256, ffn_dim % 64 == 0, 16-byte aligned operands (EGTR_E_UNSUPPORTED otherwise).  Inference only. */
+int egtr_encoder_tail_x6_f32(egtr_stream_t stream, const float* context, int ldc, const float* hidden, int ldh,
+                             const void* wp_xs, const float* bp, const float* ln1_gamma, const float* ln1_beta, float eps1,
+                             const void* w1_xs, const float* b1, const void* w2_xs, const float* b2, const float* ln2_gamma,
+                             const float* ln2_beta, float eps2, const float* pos, int pos_rows, float* out, float* out_pos,
+                             int M, int d_model, int ffn_dim);
+
 /* y = x . W^T + bias for a 256 -> 256 linear layer, or with ln_gamma / ln_beta y = LayerNorm(residual + x . W^T + bias) and
  * optionally out_pos = y + pos[row % pos_rows], in ONE launch (csrc/ffn_x6.hip, proj_x6_kernel): the attention block's
  * output projection with its residual add and LayerNorm (model/deformable_detr.py:1102, 1326-1330).  w_xs = XS(W [256, 256])

@@ -551,3 +551,49 @@ def test_fused_multi_projection_vs_float64(M, nw, with_bias):
         e, e32 = (got[i][~bad].double() - ref).abs(), (comp - ref).abs()
         scale = ref.abs().amax(1, keepdim=True)
         assert ((e / scale).amax(1) <= 2.5 * (e32 / scale).amax(1) + 2e-6).all(), (i, float((e / scale).max()))
+
+
+@pytest.mark.parametrize("M,F,kind", [(12537, 1024, "plain"), (4100, 1024, "large"), (4133, 2048, "wide-range"),
+                                      (333, 64, "plain"), (65, 128, "non-finite")])
+def test_fused_encoder_tail_vs_float64(M, F, kind):
+    """egtr_encoder_tail_x6_f32 -- output projection + residual + LayerNorm, then the FFN block + residual + LayerNorm
+    (+ position output), ONE launch, the intermediate states never in memory (dd:1102, 1326-1345) -- against float64 and
+    against the fp32 composition it replaces: per row no further from float64 than 2.5x that composition (+ 2e-6 of the row
+    scale); a non-finite context element makes exactly its own output row non-finite."""
+    import copy
+    from egtr_amd import ops
+    fc1, fc2, ln2 = _ffn_modules(F, 21 + F)
+    g = torch.Generator().manual_seed(97)
+    proj, ln1 = torch.nn.Linear(256, 256), torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        proj.weight.copy_(torch.randn(256, 256, generator=g) / 16)
+        proj.bias.copy_(torch.randn(256, generator=g) * 0.3)
+        ln1.weight.copy_(1 + 0.2 * torch.randn(256, generator=g))
+        ln1.bias.copy_(0.2 * torch.randn(256, generator=g))
+    rng = W.rng_inputs(6600 + M)
+    ctx = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    hid = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    if kind == "large":
+        ctx, hid = ctx * 300, hid * 300
+    elif kind == "wide-range":
+        sc = torch.pow(2.0, torch.from_numpy(rng.integers(-40, 30, (M, 1))).float())
+        ctx, hid = ctx * sc, hid * sc
+    bad = torch.zeros(M, dtype=torch.bool)
+    if kind == "non-finite":
+        ctx[7, 3], ctx[40, 200] = float("inf"), float("nan")
+        bad[[7, 40]] = True
+    pos = torch.from_numpy(rng.standard_normal((M, 256))).float()
+    mods = [copy.deepcopy(m).to(DEV) for m in (proj, ln1, fc1, fc2, ln2)]
+    with torch.no_grad():
+        y, y_pos = ops.encoder_tail_fused(ctx.to(DEV), hid.to(DEV), *mods, pos.to(DEV))
+        y_nopos = ops.encoder_tail_fused(ctx.to(DEV), hid.to(DEV), *mods)
+        y1c = mods[1](hid.to(DEV) + mods[0](ctx.to(DEV)))
+        comp = mods[4](y1c + mods[3](torch.relu(mods[2](y1c))))
+    assert torch.equal(y[~bad], y_nopos[~bad]) and torch.equal(y_pos[~bad], (y + pos.to(DEV))[~bad])
+    assert not torch.isfinite(y[bad]).all(-1).any() and torch.isfinite(y[~bad]).all()
+    y1 = torch.nn.functional.layer_norm(hid.double() + ctx.double() @ proj.weight.double().t() + proj.bias.double(), (256,),
+                                        ln1.weight.double(), ln1.bias.double(), ln1.eps)
+    ref = _ffn_ref64(y1, fc1, fc2, ln2)
+    e, e32 = (y.cpu().double() - ref).abs()[~bad], (comp.cpu().double() - ref).abs()[~bad]
+    scale = ref[~bad].abs().amax(1, keepdim=True).clamp_min(1e-30)
+    assert ((e / scale).amax(1) <= 2.5 * (e32 / scale).amax(1) + 2e-6).all(), (kind, float((e / scale).max()))
