@@ -147,6 +147,31 @@ def time_rel_head_kernel(args, iters=100):
     return us, flops
 
 
+def time_encoder_tail(dev, iters=100):
+    """One encoder layer's tail at S = 12 537 rows -- output projection + LayerNorm + FFN block (256 -> 1024 -> 256) +
+    LayerNorm + position output -- through egtr_encoder_tail_x6_f32 (csrc/ffn_x6.hip, one launch); algorithmic FLOPs =
+    2 M (256 * 256 + 2 * 256 * 1024)."""
+    from egtr_amd import ops
+    M, D, F = 12537, 256, 1024
+    g = torch.Generator(device="cpu").manual_seed(0)
+    mods = [torch.nn.Linear(D, D), torch.nn.LayerNorm(D), torch.nn.Linear(D, F), torch.nn.Linear(F, D), torch.nn.LayerNorm(D)]
+    mods = [m.to(dev) for m in mods]
+    ctx, hid, pos = (torch.randn(M, D, generator=g).to(dev) for _ in range(3))
+    if not ops.encoder_tail_fused_supported(ctx, *mods):
+        return None, None
+    with torch.no_grad():
+        for _ in range(5):
+            ops.encoder_tail_fused(ctx, hid, *mods, pos)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.encoder_tail_fused(ctx, hid, *mods, pos)
+        e1.record()
+        torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * M * (D * D + 2 * D * F)
+
+
 def time_split_gemm(dev, iters=100):
     """The encoder's first FFN layer (S = 12 537 rows, 256 -> 1024, ReLU) through egtr_linear_split_bf16_f32
     (csrc/gemm_split.hip); algorithmic FLOPs = 2 M K N."""
@@ -714,6 +739,22 @@ def main():
              "avg_launch_us": round(g_us, 3), "arithmetic": "fp32 via bf16x6 operand split, fp32 accumulate",
              "frac_of_bf16_dense_peak": round(6 * g_flops / (g_us * 1e-6) / 1e12 / 2500.0, 4)})
         result["config"]["encoder_linears"] = "fp32 via bf16x6 operand split, fp32 accumulate"
+        t_us, t_flops = time_encoder_tail(dev)
+        if t_us is not None:
+            t_tf = t_flops / (t_us * 1e-6) / 1e12
+            tail_entry = {"bound": "mfma", "kernel": "ffn_x6_kernel<true>",
+                          "launch": "encoder layer tail: output projection + LayerNorm + FFN 256-1024-256 + LayerNorm, M=12537",
+                          "achieved": round(t_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": round(t_tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                          "algorithmic_flops_per_launch": t_flops, "avg_launch_us": round(t_us, 3),
+                          "arithmetic": "fp32 via bf16x6 operand split, fp32 accumulate",
+                          "frac_of_bf16_dense_peak": round(6 * t_flops / (t_us * 1e-6) / 1e12 / 2500.0, 4)}
+            tp, tp_src = newest_pmc("r*_ffn_x6_pmc.json", tail_entry["kernel"])
+            if tp:
+                tail_entry["traffic"] = tp.get("hbm_bytes_per_launch")
+                tail_entry["l2_hit"] = tp.get("l2_hit")
+                tail_entry["traffic_source"] = tp_src
+            result["roofline_kernels"].append(tail_entry)
     result["config"]["relation_head"] = rel_entry.get("arithmetic", "exact-f32 MFMA")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncores = usable_cores()
