@@ -76,6 +76,7 @@ SIGNATURES = {
     "egtr_gemm_split_tile_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "egtr_gemm_split_tile_weights_pair_f32": [_P, _P, _I, _I, _I, _P],
     "egtr_linear_split_bf16_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
+    "egtr_linear_split_bf16_grouped_pos_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "egtr_pad_batch_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "egtr_ffn_x6_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I, _I],
     "egtr_encoder_tail_x6_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, ctypes.c_float,

@@ -35,7 +35,7 @@
 #define FFN_PHASE(k)                                                                             \
   do {                                                                                           \
     if (A.tdbg != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))                 \
-      A.tdbg[48 + (blockIdx.x ? 4 : 0) + (k)] = (long long)__builtin_readcyclecounter();         \
+      A.tdbg[48 + (blockIdx.x ? 8 : 0) + (k)] = (long long)__builtin_readcyclecounter();         \
     __builtin_amdgcn_sched_barrier(0);                                                           \
   } while (0)
 #else
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) dma16s(base + (i / 3) * stride + (i % 3) * kFrag, voff, dst + i * kFrag);
   };
+  FFN_PHASE(0);
   issue(0, 0);
   issue(1, 1);
 
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag + (swz(lane, ks) << 4));
   }
+  FFN_PHASE(1);
 
   f32x16 acc2[4], acc1[2];
 #pragma unroll
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       slot = sn;
       ++g;
     });
+    FFN_PHASE(4);
     // ---- y1 = LayerNorm1(res + context . Wp^T + bp) in registers (accumulator layout, see final_epilogue)
     const int row = r0 + wm * 32 + li;
     const float* xr = A.res + (size_t)min(row, A.M - 1) * A.ldr;
@@ -447,6 +450,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       }
     float* red = reinterpret_cast<float*>(hbuf + 16 * kFrag);     // the chunk buffer is idle until the first hand-over
     layernorm_rows(y1, A.gamma1, A.beta1, A.eps1, wave, lane, red);   // its first barrier: everybody is done with the context panel
+    FFN_PHASE(5);
     // ---- y1 -> the panel (hi / mid in place of the context), lo through hbuf[0, 16 KiB) one row block at a time.
     //      Accumulator register group (t, q) = channels 32 (4 wn + t) + 8 q + 4 hf .. + 3 of row li: k-step 2 (4 wn + t) +
     //      (q >> 1), k-group q & 1, bytes 8 hf .. 8 hf + 7 of the row's slot.
@@ -481,6 +485,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       }
       __syncthreads();
     }
+    FFN_PHASE(6);
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -709,7 +714,7 @@ extern "C" int egtr_encoder_tail_x6_f32(egtr_stream_t stream, const float* conte
     attr_set = true;
   }
   FfnArgs a{context, hidden, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln2_gamma, ln2_beta,
-            pos, out, out_pos, M, ldc, ldh, ffn_dim, pos_rows, eps2, nullptr, static_cast<const char*>(wp_xs), bp, ln1_gamma,
+            pos, out, out_pos, M, ldc, ldh, ffn_dim, pos_rows, eps2, g_ffn_tdbg, static_cast<const char*>(wp_xs), bp, ln1_gamma,
             ln1_beta, eps1};
   hipLaunchKernelGGL(ffn_x6_kernel<true>, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();

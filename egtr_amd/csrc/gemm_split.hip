@@ -72,6 +72,8 @@ struct GemmProblem {
   const float* bias;
   float* C;
   int lda, ldc, N, relu;
+  const float* pos;   // optional [pos_rows, K] added to the rows of A on their way into LDS (row % pos_rows): the encoder's
+  int pos_rows;       // `hidden_states + position_embeddings` (dd:1041) without a materialised sum
 };
 struct GemmProblems {
   GemmProblem p[kMaxProblems];
@@ -119,11 +121,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     arow[q] = A + (size_t)row * lda + 4 * (idx & 7);
   }
   const char* wblk = reinterpret_cast<const char*>(Wt) + (size_t)nb * nk * (3 * kBN * kBK * 2) + (size_t)tid * 16;
+  const bool has_pos = G.pos != nullptr;   // uniform per workgroup
+  const float* prow[AQ];
+#pragma unroll
+  for (int q = 0; q < AQ; ++q) {
+    const int idx = tid + 512 * q;
+    const int row = min(m0 + (idx >> 3), M - 1);
+    prow[q] = has_pos ? G.pos + (size_t)(row % G.pos_rows) * K + 4 * (idx & 7) : arow[q];
+  }
 
-  f32x4v ra[AQ], rw[3];
+  f32x4v ra[AQ], rp[AQ], rw[3];
   auto issue = [&](int s) {
 #pragma unroll
     for (int q = 0; q < AQ; ++q) ra[q] = gload(arow[q] + s * kBK);
+    if (has_pos) {
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) rp[q] = gload(prow[q] + s * kBK);
+    }
     const char* wp = wblk + (size_t)s * (3 * kBN * kBK * 2);
 #pragma unroll
     for (int q = 0; q < 3; ++q) rw[q] = gload(wp + q * 8192);
@@ -133,6 +147,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int q = 0; q < AQ; ++q) vm_wait0(ra[q]);
 #pragma unroll
     for (int q = 0; q < 3; ++q) vm_wait0(rw[q]);
+    if (has_pos) {
+#pragma unroll
+      for (int q = 0; q < AQ; ++q) {
+        vm_wait0(rp[q]);
+        ra[q] += rp[q];
+      }
+    }
 #pragma unroll
     for (int q = 0; q < AQ; ++q) {
       const int idx = tid + 512 * q;
@@ -437,24 +458,37 @@ extern "C" int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, 
   if (M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return EGTR_E_ARG;
   if (K % kBK != 0 || !problem_ok(x, ldx, w_tiled, bias, y, ldy, K, N)) return EGTR_E_UNSUPPORTED;
   GemmProblems P = {};
-  P.p[0] = GemmProblem{x, w_tiled, bias, y, ldx, ldy, N, relu};
+  P.p[0] = GemmProblem{x, w_tiled, bias, y, ldx, ldy, N, relu, nullptr, 1};
   return launch_grouped(static_cast<hipStream_t>(stream), P, 1, M, K);
+}
+
+extern "C" int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int num_problems, const float* const* x,
+                                                      const int* ldx, const uint16_t* const* w_tiled,
+                                                      const float* const* bias, float* const* y, const int* ldy,
+                                                      const int* N, const int* relu, int M, int K,
+                                                      const float* const* pos, const int* pos_rows) {
+  if (!x || !ldx || !w_tiled || !bias || !y || !ldy || !N || !relu) return EGTR_E_ARG;
+  if (num_problems <= 0 || num_problems > kMaxProblems || M <= 0 || K <= 0) return EGTR_E_ARG;
+  if (pos != nullptr && pos_rows == nullptr) return EGTR_E_ARG;
+  if (K % kBK != 0) return EGTR_E_UNSUPPORTED;
+  GemmProblems P = {};
+  for (int i = 0; i < num_problems; ++i) {
+    if (!x[i] || !w_tiled[i] || !y[i]) return EGTR_E_ARG;
+    if (!problem_ok(x[i], ldx[i], w_tiled[i], bias[i], y[i], ldy[i], K, N[i])) return EGTR_E_UNSUPPORTED;
+    const float* p = pos != nullptr ? pos[i] : nullptr;
+    if (p != nullptr && pos_rows[i] <= 0) return EGTR_E_ARG;
+    if (p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15)) return EGTR_E_UNSUPPORTED;
+    P.p[i] = GemmProblem{x[i], w_tiled[i], bias[i], y[i], ldx[i], ldy[i], N[i], relu[i], p, p != nullptr ? pos_rows[i] : 1};
+  }
+  return launch_grouped(static_cast<hipStream_t>(stream), P, num_problems, M, K);
 }
 
 extern "C" int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, const float* const* x,
                                                   const int* ldx, const uint16_t* const* w_tiled,
                                                   const float* const* bias, float* const* y, const int* ldy,
                                                   const int* N, const int* relu, int M, int K) {
-  if (!x || !ldx || !w_tiled || !bias || !y || !ldy || !N || !relu) return EGTR_E_ARG;
-  if (num_problems <= 0 || num_problems > kMaxProblems || M <= 0 || K <= 0) return EGTR_E_ARG;
-  if (K % kBK != 0) return EGTR_E_UNSUPPORTED;
-  GemmProblems P = {};
-  for (int i = 0; i < num_problems; ++i) {
-    if (!x[i] || !w_tiled[i] || !y[i]) return EGTR_E_ARG;
-    if (!problem_ok(x[i], ldx[i], w_tiled[i], bias[i], y[i], ldy[i], K, N[i])) return EGTR_E_UNSUPPORTED;
-    P.p[i] = GemmProblem{x[i], w_tiled[i], bias[i], y[i], ldx[i], ldy[i], N[i], relu[i]};
-  }
-  return launch_grouped(static_cast<hipStream_t>(stream), P, num_problems, M, K);
+  return egtr_linear_split_bf16_grouped_pos_f32(stream, num_problems, x, ldx, w_tiled, bias, y, ldy, N, relu, M, K, nullptr,
+                                                nullptr);
 }
 
 extern "C" int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int ldw, int transposed, int N, int K,

@@ -340,6 +340,17 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
     def with_pos_embed(self, tensor: torch.Tensor, position_embeddings: Optional[Tensor]):
         return tensor if position_embeddings is None else tensor + position_embeddings
 
+    def lazy_pos_supported(self, hidden_states, encoder_hidden_states):
+        """True when forward() takes the route whose offsets / weights projection can add the position embeddings itself
+        (token-sized self-attention at inference: value projection and that projection share one split-GEMM launch)."""
+        if not (ops.LAZY_POS and torch.is_tensor(hidden_states) and ops.inference_fast_path(hidden_states)):
+            return False
+        rows = hidden_states.shape[0] * hidden_states.shape[1]
+        return (rows > ops.SKINNY_MAX_ROWS and hidden_states.shape[:2] == encoder_hidden_states.shape[:2]
+                and ops.gemm_split_supported(encoder_hidden_states, *self.value_proj.weight.shape)
+                and ops.gemm_split_supported(hidden_states, 3 * self.n_heads * self.n_levels * self.n_points,
+                                             hidden_states.shape[-1]))
+
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 encoder_hidden_states=None, encoder_attention_mask=None,
                 position_embeddings: Optional[torch.Tensor] = None, reference_points=None, spatial_shapes=None,
@@ -348,12 +359,18 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
         # hidden_with_pos / precomputed_value: inference-only hand-ins that save launches (the previous LayerNorm
         # kernel also wrote hidden + pos; the decoder projects the values of all its layers in one batched GEMM)
         deferred = hidden_states if isinstance(hidden_states, ops.DeferredLayerNorm) else None
+        lazy_pos = None
         if deferred is not None:
             pass   # LayerNorm (+ pos) runs as the prologue of the offsets / weights projection below
         elif hidden_with_pos is not None:
             hidden_states = hidden_with_pos
         elif position_embeddings is not None:
-            hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
+            if precomputed_value is None and self.lazy_pos_supported(hidden_states, encoder_hidden_states):
+                # encoder self-attention at inference: the split GEMM of the offsets / weights projection adds the position
+                # rows while it loads its operand -- `hidden + pos` (dd:1041) is never materialised
+                lazy_pos = _pos_rows(position_embeddings)
+            else:
+                hidden_states = self.with_pos_embed(hidden_states, position_embeddings)
         batch_size, num_queries, _ = hidden_states.shape
         batch_size, sequence_length, _ = encoder_hidden_states.shape
         # dd:1044-1047; done on the host copy of the shapes when the caller has one (no device sync)
@@ -412,7 +429,7 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                     wv = ops.cached_weights(vp, "gemm_split_bf16", [vp.weight], lambda: ops.gemm_split_weights(vp.weight))
                     value, both = ops.linear_split_bf16_grouped([
                         dict(x=encoder_hidden_states, wt=wv, N=vp.weight.shape[0], b=vp.bias),
-                        dict(x=hidden_states, wt=wt, N=w_cat.shape[0], b=b_cat)])
+                        dict(x=hidden_states, wt=wt, N=w_cat.shape[0], b=b_cat, pos=lazy_pos)])
                     value = value.view(batch_size, sequence_length, -1)
                     both = both.view(batch_size, num_queries, -1)
                 else:
@@ -874,13 +891,17 @@ class DeformableDetrEncoder(DeformableDetrPreTrainedModel):
         for encoder_layer in self.layers:
             if output_hidden_states:
                 encoder_states = encoder_states + (hidden_states,)
+            # hidden + pos for the next layer: written by this layer's closing kernel, unless that layer's attention adds the
+            # position rows itself while loading its operand (lazy_pos_supported)
+            want_pos = not (position_embeddings is not None
+                            and encoder_layer.self_attn.lazy_pos_supported(hidden_states, hidden_states))
             layer_outputs = encoder_layer(
                 hidden_states, attention_mask, position_embeddings=position_embeddings,
                 reference_points=reference_points, spatial_shapes=spatial_shapes,
                 level_start_index=level_start_index, output_attentions=output_attentions,
-                spatial_shapes_list=spatial_shapes_list, hidden_with_pos=with_pos, return_with_pos=True)
+                spatial_shapes_list=spatial_shapes_list, hidden_with_pos=with_pos, return_with_pos=want_pos)
             hidden_states = layer_outputs[0]
-            with_pos = layer_outputs[-1]
+            with_pos = layer_outputs[-1] if want_pos else None
             if output_attentions:
                 all_attentions = all_attentions + (layer_outputs[1],)
         if output_hidden_states:

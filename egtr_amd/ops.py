@@ -648,6 +648,9 @@ def add_layer_norm_pos(x, residual, ln, pos, out=None):
 # Inference (module_linear) and training (TokenLinearFunction: forward, data and weight gradients);
 # EGTR_GEMM_SPLIT_BF16=0 keeps the vendor fp32 GEMM.
 GEMM_SPLIT_BF16 = os.environ.get("EGTR_GEMM_SPLIT_BF16", "1") != "0"
+# encoder at inference: the offsets / weights projection adds the position embeddings while loading its operand instead of
+# reading a materialised `hidden + pos` written by the previous layer's epilogue ("0": materialise)
+LAZY_POS = os.environ.get("EGTR_LAZY_POS", "1") != "0"
 GEMM_SPLIT_MIN_ROWS = 4096
 GEMM_SPLIT_WGRAD = os.environ.get("EGTR_GEMM_SPLIT_WGRAD", "1") != "0"
 
@@ -736,14 +739,15 @@ def linear_split_bf16(x, w_tiled, bias, N, relu=False, out=None):
 
 
 def linear_split_bf16_grouped(items):
-    """Several token-sized linears with the same row count and K in ONE launch (egtr_linear_split_bf16_grouped_f32).
-    ``items``: dicts with x [..., K], wt (from ``gemm_split_weights``), N, optional b, relu, out ([rows, N] contiguous).
-    Returns the outputs ([rows, N]).  Inference only."""
+    """Several token-sized linears with the same row count and K in ONE launch (egtr_linear_split_bf16_grouped_pos_f32).
+    ``items``: dicts with x [..., K], wt (from ``gemm_split_weights``), N, optional b, relu, out ([rows, N] contiguous),
+    pos ([pos_rows, K], added to x's rows (row % pos_rows) on the way into the kernel).  Returns the outputs ([rows, N]).
+    Inference only."""
     import ctypes
     lib = _lib.lib()
     n = len(items)
     K = items[0]["x"].shape[-1]
-    xs, outs, keep = [], [], []
+    xs, outs, keep, poss = [], [], [], []
     for it in items:
         x2 = it["x"].reshape(-1, K)
         if x2.stride(1) != 1 or x2.stride(0) % 4 or x2.data_ptr() % 16:
@@ -762,6 +766,12 @@ def linear_split_bf16_grouped(items):
         b = it.get("b")
         if b is not None:
             b = _chk(b.detach().contiguous(), "bias", torch.float32)
+        pos = it.get("pos")
+        if pos is not None:
+            pos = _chk(pos.reshape(-1, K).contiguous(), "pos", torch.float32)
+            if x2.shape[0] % pos.shape[0]:
+                raise RuntimeError("linear_split_bf16_grouped: pos must tile the rows")
+        poss.append(pos)
         keep.append((x2, b))
         xs.append(x2)
         outs.append(y)
@@ -769,12 +779,13 @@ def linear_split_bf16_grouped(items):
     if any(x2.shape[0] != M for x2 in xs):
         raise RuntimeError("linear_split_bf16_grouped: all inputs must have the same number of rows")
     PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
-    st = lib.egtr_linear_split_bf16_grouped_f32(
+    st = lib.egtr_linear_split_bf16_grouped_pos_f32(
         _stream(), n, PA(*[x2.data_ptr() for x2 in xs]), IA(*[x2.stride(0) for x2 in xs]),
         PA(*[it["wt"].data_ptr() for it in items]), PA(*[(b.data_ptr() if b is not None else None) for _, b in keep]),
         PA(*[y.data_ptr() for y in outs]), IA(*[y.stride(0) for y in outs]), IA(*[int(it["N"]) for it in items]),
-        IA(*[1 if it.get("relu") else 0 for it in items]), M, K)
-    _lib.check(st, "egtr_linear_split_bf16_grouped_f32")
+        IA(*[1 if it.get("relu") else 0 for it in items]), M, K,
+        PA(*[(p.data_ptr() if p is not None else None) for p in poss]), IA(*[(p.shape[0] if p is not None else 1) for p in poss]))
+    _lib.check(st, "egtr_linear_split_bf16_grouped_pos_f32")
     return outs
 
 

@@ -438,6 +438,14 @@ int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, c
                                        const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
                                        const int* ldy, const int* N, const int* relu, int M, int K);
 
+/* egtr_linear_split_bf16_grouped_f32 whose problems may add a [pos_rows[g], K] table to the rows of x_g on the way in (row %
+ * pos_rows): `hidden_states + position_embeddings` (model/deformable_detr.py:1041) as the input of the sampling-offset /
+ * attention-weight projection without a materialised sum.  pos == NULL or pos[g] == NULL: none. */
+int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int num_problems, const float* const* x, const int* ldx,
+                                           const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
+                                           const int* ldy, const int* N, const int* relu, int M, int K,
+                                           const float* const* pos, const int* pos_rows);
+
 /* ---- second-generation split-bf16 GEMM (csrc/gemm_x6.hip): BOTH operands pre-split into the "XS" format -------------
  * XS(X) of a logical fp32 matrix X[rows][K] (K % 16 == 0): the exact three-way bf16 split x = hi + mid + lo, stored as
  * 1 KiB fragments of 32 rows x 16 k of ONE piece; fragment (rb = row / 32, ks = k / 16, piece p) at byte

@@ -1418,3 +1418,19 @@ def test_linear_grouped_layernorm_prologue(B, N):
         d2 = ops.DeferredLayerNorm(a, b, ln)
         assert (again - want[2]).abs().max() < 2e-5 * float(want[2].abs().max())
         assert (d2.materialize() - y).abs().max() < 2e-5 and d2.done
+
+
+def test_linear_split_bf16_grouped_adds_position_rows_on_load():
+    """egtr_linear_split_bf16_grouped_pos_f32: a problem with ``pos`` multiplies (x + pos[row % pos_rows]) -- bit-identical
+    to handing it the materialised sum; the other problem of the launch is untouched."""
+    from egtr_amd import ops
+    rng = W.rng_inputs(654)
+    B, S, K = 2, 6300, 256
+    x = torch.from_numpy(rng.standard_normal((B, S, K))).float().to(DEV)
+    pos = torch.from_numpy(rng.standard_normal((S, K))).float().to(DEV)
+    ws = [torch.from_numpy(rng.standard_normal((n, K)) / 16).float().to(DEV) for n in (256, 384)]
+    bs = [torch.from_numpy(rng.standard_normal(n) * 0.1).float().to(DEV) for n in (256, 384)]
+    wts = [ops.gemm_split_weights(w) for w in ws]
+    want = ops.linear_split_bf16_grouped([dict(x=x, wt=wts[0], N=256, b=bs[0]), dict(x=x + pos, wt=wts[1], N=384, b=bs[1])])
+    got = ops.linear_split_bf16_grouped([dict(x=x, wt=wts[0], N=256, b=bs[0]), dict(x=x, wt=wts[1], N=384, b=bs[1], pos=pos)])
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])

@@ -119,8 +119,8 @@ int main(int argc, char** argv) {
              h[s * 6 + 3] - h[s * 6 + 2], h[s * 6 + 4] - h[s * 6 + 3], h[s * 6 + 5] - h[s * 6 + 4],
              s < 7 ? h[(s + 1) * 6] - h[s * 6 + 5] : 0);
     for (int b = 0; b < 2; ++b)
-      printf("  workgroup %d: panel %lld  loop %lld  epilogue %lld cycles\n", b ? 100 : 0, h[48 + 4 * b + 1] - h[48 + 4 * b],
-             h[48 + 4 * b + 2] - h[48 + 4 * b + 1], h[48 + 4 * b + 3] - h[48 + 4 * b + 2]);
+      printf("  workgroup %d: panel %lld  loop %lld  epilogue %lld cycles\n", b ? 100 : 0, h[48 + 8 * b + 1] - h[48 + 8 * b],
+             h[48 + 8 * b + 2] - h[48 + 8 * b + 1], h[48 + 8 * b + 3] - h[48 + 8 * b + 2]);
   }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
