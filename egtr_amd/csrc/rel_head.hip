@@ -603,6 +603,7 @@ constexpr int kHp = 264;  // bf16 elements per LDS row of an h1 piece
 // significant bits, i.e. already is a bf16.  Pieces are kept as fp32 bit patterns whose low 16 bits are zero; two of
 // them are packed into one dword of bf16 pairs with a single v_perm_b32.
 // (xs_format.h: non-finite x keeps the inf / a quiet NaN in hi alone, mid = lo = 0 -- `x - hi` would be inf - inf)
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 using Split3 = xs::Split3;
 __device__ __forceinline__ Split3 split3(float x) { return xs::split3(x); }
 // {bf16(a) in the low half, bf16(b) in the high half} from two fp32 bit patterns with zero low halves
@@ -745,19 +746,21 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int pp = ii * 4 + jj;
-        float4 acc = bias4;
+        // two-wide (v_pk_add_f32 / v_pk_fma_f32) and the split without its non-finite special cases: the kernel issues ~9 VALU
+        // instructions per MFMA (profiles/r03_x6_mfma_pmc.txt), this loop and the two splits are most of them
+        f32x2v a01 = {bias4.x, bias4.y}, a23 = {bias4.z, bias4.w};
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const float4 a = ua[iu & 1][t];
           const float4 c = kk[jj][t];
           const float gt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g[t]), pp));
-          acc.x += gt * (a.x + c.x);
-          acc.y += gt * (a.y + c.y);
-          acc.z += gt * (a.z + c.z);
-          acc.w += gt * (a.w + c.w);
+          const f32x2v gg = {gt, gt};
+          const f32x2v u01 = {a.x + c.x, a.y + c.y}, u23 = {a.z + c.z, a.w + c.w};
+          a01 = gg * u01 + a01;
+          a23 = gg * u23 + a23;
         }
-        const Split3 sx = split3(egtr_relu(acc.x)), sy = split3(egtr_relu(acc.y)), sz = split3(egtr_relu(acc.z)),
-                     sw = split3(egtr_relu(acc.w));
+        const Split3 sx = xs::split3_fast(egtr_relu(a01.x)), sy = xs::split3_fast(egtr_relu(a01.y)),
+                     sz = xs::split3_fast(egtr_relu(a23.x)), sw = xs::split3_fast(egtr_relu(a23.y));
         __bf16* hp = s_h + pp * kHp + 4 * lane;
         *reinterpret_cast<uint2*>(hp) = make_uint2(pack_hi16(sx.hi, sy.hi), pack_hi16(sz.hi, sw.hi));
         *reinterpret_cast<uint2*>(hp + 32 * kHp) = make_uint2(pack_hi16(sx.mid, sy.mid), pack_hi16(sz.mid, sw.mid));
@@ -808,7 +811,7 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
         {
           Split3 sp[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) sp[e] = split3(acc[8 * kb + e]);
+          for (int e = 0; e < 8; ++e) sp[e] = xs::split3_fast(acc[8 * kb + e]);
           phi = make_uint4(pack_hi16(sp[0].hi, sp[1].hi), pack_hi16(sp[2].hi, sp[3].hi), pack_hi16(sp[4].hi, sp[5].hi),
                            pack_hi16(sp[6].hi, sp[7].hi));
           pmid = make_uint4(pack_hi16(sp[0].mid, sp[1].mid), pack_hi16(sp[2].mid, sp[3].mid),
