@@ -157,9 +157,9 @@ def time_encoder_tail(dev, iters=100):
     mods = [torch.nn.Linear(D, D), torch.nn.LayerNorm(D), torch.nn.Linear(D, F), torch.nn.Linear(F, D), torch.nn.LayerNorm(D)]
     mods = [m.to(dev) for m in mods]
     ctx, hid, pos = (torch.randn(M, D, generator=g).to(dev) for _ in range(3))
-    if not ops.encoder_tail_fused_supported(ctx, *mods):
-        return None, None
     with torch.no_grad():
+        if not ops.encoder_tail_fused_supported(ctx, *mods):
+            return None, None
         for _ in range(5):
             ops.encoder_tail_fused(ctx, hid, *mods, pos)
         torch.cuda.synchronize()

@@ -178,6 +178,37 @@ def test_full_size_600x1000_vs_reference(golden_dir, fixture):
     assert abs(out.pred_connectivity.double().sum().item() - float(g["pred_conn_sum"])) < 0.5
 
 
+@pytest.mark.parametrize("switch", ["FFN_FUSED", "ENCODER_TAIL_FUSED", "LAZY_POS", "DEFER_LAYERNORM", "GEMM_SPLIT_BF16",
+                                    "REL_HEAD_SPLIT_BF16"])
+def test_full_size_with_each_fusion_switched_off_vs_reference(golden_dir, switch, monkeypatch):
+    """Every inference fusion of round 2 / 3 has an environment switch that restores the composition it replaced
+    (EGTR_<switch>=0).  Those routes are product code too: the 600x1000 / N = 200 fixture of the reference must hold at the
+    same 1e-3 with each switch off, and the outputs must stay within fp32 rounding of the default route's."""
+    from egtr_amd import ops
+    g = Hh.load_golden(golden_dir, "sgg_full.npz")
+    cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    rng = W.rng_inputs(int(g["input_seed"]))
+    pv = torch.from_numpy(rng.standard_normal((1, 3, 600, 1000))).float().to(DEV)
+    pm = torch.ones(1, 600, 1000, dtype=torch.long, device=DEV)
+    base = Hh.product_heads(model, pv, pm)
+    assert getattr(ops, switch) is True
+    monkeypatch.setattr(ops, switch, False)
+    h = Hh.product_heads(model, pv, pm)
+    tol = 1e-3
+    assert (h["logits"].cpu() - _t(g["logits"])).abs().max() < tol
+    assert (h["pred_boxes"].cpu() - _t(g["pred_boxes"])).abs().max() < tol
+    assert (h["last_hidden"].cpu() - _t(g["last_hidden"])).abs().max() < tol
+    assert (h["enc"].cpu()[:, ::37] - _t(g["enc_strided"])).abs().max() < tol
+    assert (h["conn_logits"].cpu()[..., 0] - _t(g["conn_logits"])).abs().max() < tol
+    for key in ("logits", "pred_boxes", "last_hidden", "enc", "conn_logits"):
+        assert (h[key] - base[key]).abs().max() < 2e-4, key
+    rm = lambda x: Hh.rel_mlp_from_logits(x["rel_logits"], x["logits"], model.triplet_dist)  # noqa: E731
+    assert (rm(h) - rm(base)).abs().max() < 2e-4
+
+
 def _stress_model(golden_dir):
     g = Hh.load_golden(golden_dir, "sgg_stress.npz")
     cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
