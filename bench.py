@@ -149,24 +149,24 @@ def time_rel_head_kernel(args, iters=100):
 
 def time_encoder_tail(dev, iters=100):
     """One encoder layer's tail at S = 12 537 rows -- output projection + LayerNorm + FFN block (256 -> 1024 -> 256) +
-    LayerNorm + position output -- through egtr_encoder_tail_x6_f32 (csrc/ffn_x6.hip, one launch); algorithmic FLOPs =
+    LayerNorm (as the model runs it: no position output) -- through egtr_encoder_tail_x6_f32 (csrc/ffn_x6.hip, one launch); algorithmic FLOPs =
     2 M (256 * 256 + 2 * 256 * 1024)."""
     from egtr_amd import ops
     M, D, F = 12537, 256, 1024
     g = torch.Generator(device="cpu").manual_seed(0)
     mods = [torch.nn.Linear(D, D), torch.nn.LayerNorm(D), torch.nn.Linear(D, F), torch.nn.Linear(F, D), torch.nn.LayerNorm(D)]
     mods = [m.to(dev) for m in mods]
-    ctx, hid, pos = (torch.randn(M, D, generator=g).to(dev) for _ in range(3))
+    ctx, hid = (torch.randn(M, D, generator=g).to(dev) for _ in range(2))
     with torch.no_grad():
         if not ops.encoder_tail_fused_supported(ctx, *mods):
             return None, None
         for _ in range(5):
-            ops.encoder_tail_fused(ctx, hid, *mods, pos)
+            ops.encoder_tail_fused(ctx, hid, *mods)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.encoder_tail_fused(ctx, hid, *mods, pos)
+            ops.encoder_tail_fused(ctx, hid, *mods)
         e1.record()
         torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * M * (D * D + 2 * D * F)
