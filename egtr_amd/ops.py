@@ -441,7 +441,8 @@ class DeferredLayerNorm:
             raise ValueError("DeferredLayerNorm: two [.., 256] tensors")
         self.a, self.b, self.ln = a, b, ln
         self.out = out if out is not None else torch.empty_like(a)
-        self.done = False
+        self.done = False        # .out holds y
+        self.claimed = False     # a group of a launch being assembled will store y
 
     @property
     def shape(self):
@@ -454,7 +455,7 @@ class DeferredLayerNorm:
     def materialize(self):
         if not self.done:
             add_layer_norm_into(self.a, self.b, self.ln, self.out)
-            self.done = True
+            self.done = self.claimed = True
         return self.out
 
 
@@ -502,8 +503,8 @@ def linear_grouped(items):
             be = _chk(dln.ln.bias.detach().contiguous(), "ln.bias", torch.float32)
             pos = it.get("pos")
             p2 = _chk(pos.reshape(-1, K).contiguous(), "pos", torch.float32) if pos is not None else None
-            first = not getattr(dln, "_claimed", False)   # one group of the launch stores the LayerNorm result
-            dln._claimed = True
+            first = not dln.claimed     # exactly one group of the launch stores the LayerNorm result
+            dln.claimed = True
             o2 = _chk(dln.out.view(-1, K), "ln_out", torch.float32) if first else None
             keep += [r2, ga, be, p2, o2]
             lres.append(r2.data_ptr()); lga.append(ga.data_ptr()); lbe.append(be.data_ptr()); leps.append(float(dln.ln.eps))
