@@ -791,6 +791,19 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     const char* wtile = w2x + (size_t)nt * (16 * 3072);
     constexpr int kPre = 4;
     f32x4v wq[kPre][3];
+    // relation MLP: the 12 W3 operand fragments of this n tile are requested BEFORE the layer-2 loop (asm loads, oldest in the
+    // in-order queue: the loop's own counted waits cover them).  Loaded at their use they were twelve exposed L2 round trips
+    // per n tile -- about as long as the tile's MFMAs.
+    f32x4v w3q[2 * OT][3];
+    if (mlp == 0) {
+      const char* w3t = reinterpret_cast<const char*>(w3xr) + (size_t)nt * (2 * OT * 3072);
+#pragma unroll
+      for (int f = 0; f < 2 * OT; ++f) {
+        w3q[f][0] = gload_b128_s(voff, w3t + f * 3072);
+        w3q[f][1] = gload_b128_s1k(voff, w3t + f * 3072);
+        w3q[f][2] = gload_b128_s2k(voff, w3t + f * 3072);
+      }
+    }
     PrefetchX6<kPre>::template issue<0>(wq, voff, wtile);
     PrefetchX6<kPre>::template run<0>(wq, voff, wtile, hrow, acc, accc);
 #pragma unroll
@@ -804,7 +817,10 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     }
     if (mlp == 0) {
       // ---- layer 3 (relation): two K = 16 steps per n tile on the split accumulators; W3 pieces pre-ordered ----------
-      const char* w3t = reinterpret_cast<const char*>(w3xr) + (size_t)nt * (2 * OT * 3072) + voff;
+#pragma unroll
+      for (int f = 0; f < 2 * OT; ++f) {   // the layer-2 loop ended on vmcnt(0): everything has landed
+        asm volatile("" : "+v"(w3q[f][0]), "+v"(w3q[f][1]), "+v"(w3q[f][2]));
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         uint4 phi, pmid, plo;
@@ -823,10 +839,9 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
                      hlo = __builtin_bit_cast(bf16x8, plo);
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
-          const char* wp = w3t + (kb * OT + ot) * 3072;
-          const bf16x8 whi = *reinterpret_cast<const bf16x8*>(wp);
-          const bf16x8 wmid = *reinterpret_cast<const bf16x8*>(wp + 1024);
-          const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wp + 2048);
+          const bf16x8 whi = __builtin_bit_cast(bf16x8, w3q[kb * OT + ot][0]);
+          const bf16x8 wmid = __builtin_bit_cast(bf16x8, w3q[kb * OT + ot][1]);
+          const bf16x8 wlo = __builtin_bit_cast(bf16x8, w3q[kb * OT + ot][2]);
           racc[ot] = mfma_bf16(whi, hlo, racc[ot]);
           racc[ot] = mfma_bf16(wlo, hhi, racc[ot]);
           racc[ot] = mfma_bf16(wmid, hmid, racc[ot]);
