@@ -173,27 +173,33 @@ def time_encoder_tail(dev, iters=100):
 
 
 def time_split_gemm(dev, iters=100):
-    """The encoder's first FFN layer (S = 12 537 rows, 256 -> 1024, ReLU) through egtr_linear_split_bf16_f32
-    (csrc/gemm_split.hip); algorithmic FLOPs = 2 M K N."""
+    """The split-bf16 tile GEMM as the encoder layer launches it since round 3 (csrc/gemm_split.hip, one grouped launch):
+    value projection 256 -> 256 of the layer input and sampling-offset / attention-weight projection 256 -> 384 of
+    (input + position rows, added on load), S = 12 537 rows; algorithmic FLOPs = 2 M K (256 + 384)."""
     from egtr_amd import ops
-    M, K, N = 12537, 256, 1024
+    M, K = 12537, 256
     g = torch.Generator(device="cpu").manual_seed(0)
-    x = torch.randn(M, K, generator=g).to(dev)
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
-    b = torch.randn(N, generator=g).to(dev)
-    wt = ops.gemm_split_weights(w)
-    out = torch.empty(M, N, device=dev)
+    x, pos = torch.randn(M, K, generator=g).to(dev), torch.randn(M, K, generator=g).to(dev)
+    ws = [(torch.randn(n, K, generator=g) / K ** 0.5).to(dev) for n in (256, 384)]
+    bs = [torch.randn(n, generator=g).to(dev) for n in (256, 384)]
+    wts = [ops.gemm_split_weights(w) for w in ws]
+    outs = [torch.empty(M, n, device=dev) for n in (256, 384)]
+
+    def fn():
+        ops.linear_split_bf16_grouped([dict(x=x, wt=wts[0], N=256, b=bs[0], out=outs[0]),
+                                       dict(x=x, wt=wts[1], N=384, b=bs[1], out=outs[1], pos=pos)])
+
     with torch.no_grad():
         for _ in range(5):
-            ops.linear_split_bf16(x, wt, b, N, relu=True, out=out)
+            fn()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):
-            ops.linear_split_bf16(x, wt, b, N, relu=True, out=out)
+            fn()
         e1.record()
         torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * M * K * N
+    return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * M * K * (256 + 384)
 
 
 def time_msda_kernel(args, fused, iters=200):
@@ -733,7 +739,8 @@ def main():
         g_us, g_flops = time_split_gemm(dev)
         g_tf = g_flops / (g_us * 1e-6) / 1e12
         result["roofline_kernels"].append(
-            {"bound": "mfma", "kernel": "gemm_split_bf16_f32", "launch": "encoder FFN layer 1: M=12537, K=256, N=1024, ReLU",
+            {"bound": "mfma", "kernel": "gemm_split_bf16_f32",
+             "launch": "encoder layer: value (256->256) + offsets/weights (256->384, + position rows on load), M=12537, one launch",
              "achieved": round(g_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
              "frac": round(g_tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flops_per_launch": g_flops,
              "avg_launch_us": round(g_us, 3), "arithmetic": "fp32 via bf16x6 operand split, fp32 accumulate",
