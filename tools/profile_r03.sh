@@ -10,7 +10,7 @@ bash tools/pmc_bench.sh $tag
 cd "$GRAFT_REPO_ROOT"
 # the fused FFN / projection kernels from the same memory passes cannot be re-read (dbs deleted): own short passes
 bash tools/pmc_passes.sh gpurun_out/pmc_x6_${tag} bench mem -- python3 bench.py --no-cpu-baseline --extras 0 --steps 3 --warmup 2 --tune-gemm 0
-python3 tools/msda_pmc.py gpurun_out/pmc_x6_${tag} --kernel-regex 'ffn_x6_kernel<true>' --name 'ffn_x6_kernel<true>' --alg-bytes 67728384 \
+python3 tools/msda_pmc.py gpurun_out/pmc_x6_${tag} --kernel-regex 'ffn_x6_kernel<true>' --name 'ffn_x6_kernel<true>' --alg-bytes 42052608 \
     --out gpurun_out/${tag}_ffn_x6_pmc.json > gpurun_out/${tag}_ffn_x6_pmc.txt 2>&1
 python3 tools/msda_pmc.py gpurun_out/pmc_x6_${tag} --kernel-regex 'proj_x6_kernel' --name 'proj_x6_kernel' \
     --out gpurun_out/${tag}_proj_x6_pmc.json >> gpurun_out/${tag}_ffn_x6_pmc.txt 2>&1
