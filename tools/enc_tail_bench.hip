@@ -1,7 +1,7 @@
 // Stand-alone development harness of the encoder-tail kernel (csrc/ffn_x6.hip, ffn_x6_kernel<true>): launch time on random
 // inputs and, in a -DFFN_TIMING build, the cycle stamps of its phases (correctness: tests/test_gpu_pinning.py).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFFN_TIMING] tools/enc_tail_bench.hip egtr_amd/csrc/ffn_x6.hip \
-//         egtr_amd/csrc/gemm_x6.hip egtr_amd/csrc/capi.hip -o build/enc_tail_bench && build/enc_tail_bench [M F iters]
+//         egtr_amd/csrc/gemm_x6.hip egtr_amd/csrc/capi.hip -o build/enc_tail_bench && build/enc_tail_bench [M F iters with_pos]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -24,6 +24,7 @@ extern long long* g_ffn_tdbg;
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 12537, F = argc > 2 ? atoi(argv[2]) : 1024, iters = argc > 3 ? atoi(argv[3]) : 100;
+  const int with_pos = argc > 4 ? atoi(argv[4]) : 0;   // the model runs it without the position output since the lazy-pos GEMM
   const int D = 256;
   std::mt19937 rng(4);
   std::normal_distribution<float> nd(0.f, 1.f);
@@ -51,8 +52,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&out, (size_t)M * D * 4));
   CK(hipMalloc(&outp, (size_t)M * D * 4));
   auto run = [&]() {
-    return egtr_encoder_tail_x6_f32(nullptr, ctx, D, hid, D, xp, bp, g1, be1, 1e-5f, x1, b1, x2, b2, g2, be2, 1e-5f, pos, M, out,
-                                    outp, M, D, F);
+    return egtr_encoder_tail_x6_f32(nullptr, ctx, D, hid, D, xp, bp, g1, be1, 1e-5f, x1, b1, x2, b2, g2, be2, 1e-5f, with_pos ? pos : nullptr, M, out,
+                                    with_pos ? outp : nullptr, M, D, F);
   };
   int rc = run();
   CK(hipDeviceSynchronize());
