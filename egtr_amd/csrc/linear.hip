@@ -201,10 +201,12 @@ __global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, in
         b0[i] = gload16<i * 16>(w0);
         b1[i] = gload16<i * 16>(w1);
       });
+      // the statistics start as soon as x and the residual (the 8 oldest of the 28 loads) have landed; the LayerNorm
+      // parameters, the position rows and the weights are waited for where they are used
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        vmwait<0>(a[i]); vmwait<0>(rr[i]); vmwait<0>(ga[i]); vmwait<0>(be[i]); vmwait<0>(po[i]); vmwait<0>(b0[i]);
-        vmwait<0>(b1[i]);
+        vmwait<20>(a[i]);
+        vmwait<20>(rr[i]);
       }
       float sum = 0.f;
 #pragma unroll
@@ -229,6 +231,10 @@ __global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, in
       __syncthreads();
       const float rstd =
           rsqrtf(((s_stat[1][0][c] + s_stat[1][1][c]) + (s_stat[1][2][c] + s_stat[1][3][c])) * (1.f / 256.f) + G.eps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vmwait<0>(ga[i]); vmwait<0>(be[i]); vmwait<0>(po[i]); vmwait<0>(b0[i]); vmwait<0>(b1[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = a[i] * rstd * ga[i] + be[i];
       if (blockIdx.x == 0 && G.ln_out != nullptr && m0 + c < M) {
