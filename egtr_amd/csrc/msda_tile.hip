@@ -57,9 +57,11 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   const int nwork = B * tm.ntiles * 8;
 
   for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
-    const int wlog = xcd_remap(work, nwork);
-    const int head = wlog & 7;
-    const int t = wlog >> 3;
+    // head = XCD: workgroups are dealt to the eight XCDs round-robin by id and the grid is a multiple of 8, so work & 7 ==
+    // blockIdx & 7 == the XCD this workgroup runs on.  All atomics on the 128-byte head slice [.., head, :] of a pixel then
+    // come from ONE XCD: the lines stay in that L2 instead of bouncing between eight of them (L2 hit of this kernel was 0.05).
+    const int head = work & 7;
+    const int t = work >> 3;
     const int b = t / tm.ntiles, tile = t - b * tm.ntiles;
     const int q = tile_query(tm, G, tile, ql, Lq);
     char* gvbase = reinterpret_cast<char*>(grad_value) + (size_t)b * S * 1024;
