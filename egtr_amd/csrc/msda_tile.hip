@@ -59,7 +59,9 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
     // head = XCD: workgroups are dealt to the eight XCDs round-robin by id and the grid is a multiple of 8, so work & 7 ==
     // blockIdx & 7 == the XCD this workgroup runs on.  All atomics on the 128-byte head slice [.., head, :] of a pixel then
-    // come from ONE XCD: the lines stay in that L2 instead of bouncing between eight of them (L2 hit of this kernel was 0.05).
+    // come from ONE XCD.  Measured 437 -> 394 us per launch at B = 4 (284 -> 221 at B = 1); the atomics themselves still
+    // execute on the fabric side (WRITE_SIZE unchanged at 205 MB, L2 hit ~0: profiles/r03_msda_bwd_pmc.json) -- what
+    // improved is eight sources no longer interleaving their requests to the same lines.
     const int head = work & 7;
     const int t = work >> 3;
     const int b = t / tm.ntiles, tile = t - b * tm.ntiles;
