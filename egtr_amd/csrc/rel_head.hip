@@ -787,7 +787,14 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     // ---- layer 2: h2^T[n][pair], n = 32 nt + (r&3) + 8 (r>>2) + 4 hf ---------------------------------------
     f32x16 acc, accc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accc[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) accc[r] = 0.f;
+    // the main accumulator starts from the layer-2 bias (requested before the weight loads, not behind the loop): register
+    // 4 rq + j <-> hidden-2 unit 32 nt + 8 rq + 4 hf + j
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const float4 bb = *reinterpret_cast<const float4*>(b2 + nt * 32 + 8 * rq + 4 * hf);
+      acc[4 * rq + 0] = bb.x; acc[4 * rq + 1] = bb.y; acc[4 * rq + 2] = bb.z; acc[4 * rq + 3] = bb.w;
+    }
     const char* wtile = w2x + (size_t)nt * (16 * 3072);
     constexpr int kPre = 4;
     f32x4v wq[kPre][3];
@@ -807,14 +814,7 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     PrefetchX6<kPre>::template issue<0>(wq, voff, wtile);
     PrefetchX6<kPre>::template run<0>(wq, voff, wtile, hrow, acc, accc);
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int n0 = nt * 32 + 8 * rq + 4 * hf;
-      const float4 bb = *reinterpret_cast<const float4*>(b2 + n0);
-      acc[4 * rq + 0] = egtr_relu(acc[4 * rq + 0] + accc[4 * rq + 0] + bb.x);
-      acc[4 * rq + 1] = egtr_relu(acc[4 * rq + 1] + accc[4 * rq + 1] + bb.y);
-      acc[4 * rq + 2] = egtr_relu(acc[4 * rq + 2] + accc[4 * rq + 2] + bb.z);
-      acc[4 * rq + 3] = egtr_relu(acc[4 * rq + 3] + accc[4 * rq + 3] + bb.w);
-    }
+    for (int r = 0; r < 16; ++r) acc[r] = egtr_relu(acc[r] + accc[r]);
     if (mlp == 0) {
       // ---- layer 3 (relation): two K = 16 steps per n tile on the split accumulators; W3 pieces pre-ordered ----------
 #pragma unroll
