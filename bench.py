@@ -20,7 +20,9 @@ data-path collective); the timed region is bracketed by a barrier + synchronize 
 Prints ONE JSON line on rank 0 with the driver's contract plus
   "roofline":     the encoder MSDA kernel (dominant hand-written kernel): algorithmic bytes per launch / its
                   average duration measured with HIP events on the launch stream, against the 8 TB/s HBM peak;
-  "roofline_kernels": the same entry plus the relation-head kernel against the fp32-MFMA peak (157.3 TFLOP/s);
+  "roofline_kernels": the same entry plus the matrix-core kernels; the split-bf16 ("x6") ones are priced against the unit
+                  they run on (executed bf16 FLOPs / time against the 2.5 PFLOP/s dense bf16 peak; the fp32-equivalent
+                  rate is kept as `achieved_fp32_equiv`, the matrix-pipe busy counter as `mfma_busy`);
   "cpu_baseline": the CPU oracle (the reference's pure-PyTorch fallback semantics) timed on the host cores on a
                   bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -118,6 +120,7 @@ class RelHeadProbe:
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (what the split-bf16 "x6" kernels run on)
 
 
 def time_rel_head_kernel(args, iters=100):
@@ -336,10 +339,10 @@ class MsdaBwdProbe:
     def __enter__(self):
         probe, orig = self, self._orig
 
-        def bwd(value, shapes, lsi, loc, attn, grad_out, step, variant=0):
+        def bwd(value, shapes, lsi, loc, attn, grad_out, step):
             if loc.shape[1] == value.shape[1]:
                 probe.args = (value, shapes, lsi, loc, attn, grad_out, step)
-            return orig(value, shapes, lsi, loc, attn, grad_out, step, variant)
+            return orig(value, shapes, lsi, loc, attn, grad_out, step)
 
         self._cls.ms_deform_attn_backward = staticmethod(bwd)
         return self
@@ -426,10 +429,8 @@ def train_bench(args, world, rank, dev, dist, emit=True):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    tr.finalize()   # a cost matrix the device matcher refused in the last step would surface here (ValueError)
+    dt, spread = rank_times(dt, args.steps, dist, dev, world)
     result = None
     if rank == 0:
         result = {
@@ -437,7 +438,7 @@ def train_bench(args, world, rank, dev, dist, emit=True):
             "value": round(world * batch * args.steps / dt, 3), "unit": "images/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "final_loss": float(loss), "rccl_ranks": args.rccl_ranks,
+            "final_loss": float(loss), "rccl_ranks": args.rccl_ranks, "rank_ms_per_step": spread,
             "config": {"workload": f"VG train step: ResNet-50, N=200, 6 enc/6 dec, bs={batch}/GPU fp32, DDP x{world} "
                                    "(BASELINE configs[2] shape)", "parallelism": f"dp{world}",
                        "token_linears": ("fp32 via bf16x6 operand split (forward, data and weight gradients)"
@@ -531,6 +532,39 @@ def newest_pmc(pattern, kernel):
     if best is None:
         return {}, None
     return best[2], f"profiles/{os.path.basename(best[1])} (mtime {time.strftime('%Y-%m-%d %H:%M', time.gmtime(best[0]))} UTC)"
+
+
+def rank_times(dt, steps, dist, dev, world):
+    """(max-over-ranks seconds, {"per_rank_ms_per_step": [...], "min", "max", "slowest_rank"}): every rank's own time for the
+    timed region -- `value` uses the MAX (the contract), the spread shows a straggler that the one number would hide."""
+    if dist is None:
+        ms = dt / steps * 1e3
+        return dt, {"per_rank_ms_per_step": [round(ms, 4)], "min": round(ms, 4), "max": round(ms, 4), "slowest_rank": 0}
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    all_t = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(all_t, t)
+    per = [float(x.item()) / steps * 1e3 for x in all_t]
+    return max(float(x.item()) for x in all_t), {"per_rank_ms_per_step": [round(v, 4) for v in per], "min": round(min(per), 4),
+                                                  "max": round(max(per), 4), "slowest_rank": per.index(max(per))}
+
+
+def newest_mfma_busy():
+    """{kernel name: matrix-pipe busy fraction} from the most recent profiles/r*_x6_mfma_pmc.json (tools/mfma_busy.py over
+    separate rocprofv3 --pmc passes: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)), and its provenance string."""
+    import glob
+    best = None
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_x6_mfma_pmc.json")):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        m = os.path.getmtime(path)
+        if best is None or m > best[0]:
+            best = (m, path, d)
+    if best is None:
+        return {}, None
+    return ({k: v.get("mfma_busy") for k, v in best[2].get("kernels", {}).items()},
+            f"profiles/{os.path.basename(best[1])} (mtime {time.strftime('%Y-%m-%d %H:%M', time.gmtime(best[0]))} UTC)")
 
 
 def _free_port():
@@ -678,10 +712,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, spread = rank_times(dt, args.steps, dist, dev, world)
     value = world * args.batch * args.steps / dt
     if args.graph and not fwd.graphed:
         raise SystemExit("[bench] HIP-graph capture did not happen (pass --graph 0 to time eager launches)")
@@ -715,25 +746,37 @@ def main():
                      "l2_hit": pmc.get("l2_hit"), "l1_gather_bytes": pmc.get("l1_gather_bytes"),
                      "frac_of_l1_gather_ceiling": (round(pmc["l1_gather_bytes"] / (msda_us * 1e-6) / 30.5e12, 3)
                                                    if pmc.get("l1_gather_bytes") else None)},
-        "rccl_ranks": args.rccl_ranks,
+        "rccl_ranks": args.rccl_ranks, "rank_ms_per_step": spread,
     }
     from egtr_amd import ops as _ops
     split = bool(_ops.REL_HEAD_SPLIT_BF16) and rel_args[1].get("owner") is not None
-    rel_entry = {"bound": "mfma", "kernel": "rel_head_fwd_x6" if split else "rel_head_fwd_f32",
-                 "launch": f"B={args.batch}, N=200, T=7, R=50",
-                 "achieved": round(rel_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": round(rel_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                 "algorithmic_flops_per_launch": rel_flops, "avg_launch_us": round(rel_us, 3)}
+    busy, busy_src = newest_mfma_busy()
+
+    def x6_entry(kernel, launch, us, alg_flops, executed_flops, busy_key):
+        """A kernel that computes fp32 results on the bf16 matrix cores (exact three-way operand splits, six cross terms per
+        product on v_mfma_f32_32x32x16_bf16, fp32 accumulation): priced against the unit it RUNS on -- `achieved` = executed
+        bf16 FLOPs / time, `peak` = the dense bf16 MFMA peak; the algorithmic fp32 rate is `achieved_fp32_equiv`."""
+        e = {"bound": "mfma", "kernel": kernel, "launch": launch,
+             "achieved": round(executed_flops / (us * 1e-6) / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": round(executed_flops / (us * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+             "algorithmic_flops_per_launch": alg_flops, "bf16_mfma_flops_executed": executed_flops,
+             "achieved_fp32_equiv": round(alg_flops / (us * 1e-6) / 1e12, 2), "avg_launch_us": round(us, 3),
+             "arithmetic": "fp32 via bf16x6 operand split, fp32 accumulate"}
+        if busy.get(busy_key) is not None:     # matrix pipe busy fraction from separate --pmc passes (tools/mfma_busy.py)
+            e["mfma_busy"], e["mfma_busy_source"] = busy[busy_key], busy_src
+        return e
+
     if split:
-        # fp32 result from exact three-way bf16 splits of both operands, six cross terms on v_mfma_f32_32x32x16_bf16,
-        # fp32 accumulation (accuracy vs float64: tests/test_gpu_kernels.py::
-        # test_relation_head_split_bf16_is_fp32_accurate).  `achieved` / `peak` price the ALGORITHMIC fp32 FLOPs against
-        # the fp32 matrix peak; the matrix cores execute 6x the layer-2 / layer-3 products in bf16:
+        # accuracy vs float64: tests/test_gpu_kernels.py::test_relation_head_split_bf16_is_fp32_accurate; the matrix cores
+        # execute 6x the layer-2 / layer-3 products (layer 1 and the gates run on the vector ALUs)
         n2 = args.batch * 200 * 200
-        executed = 2.0 * n2 * 6 * (2 * 256 * 256 + 256 * 64)
-        rel_entry["arithmetic"] = "fp32 via bf16x6 operand split, fp32 accumulate"
-        rel_entry["bf16_mfma_flops_executed"] = executed
-        rel_entry["frac_of_bf16_dense_peak"] = round(executed / (rel_us * 1e-6) / 1e12 / 2500.0, 4)
+        rel_entry = x6_entry("rel_head_fwd_x6", f"B={args.batch}, N=200, T=7, R=50", rel_us, rel_flops,
+                             2.0 * n2 * 6 * (2 * 256 * 256 + 256 * 64), "rel_head_fwd_x6")
+    else:
+        rel_entry = {"bound": "mfma", "kernel": "rel_head_fwd_f32", "launch": f"B={args.batch}, N=200, T=7, R=50",
+                     "achieved": round(rel_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(rel_tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                     "algorithmic_flops_per_launch": rel_flops, "avg_launch_us": round(rel_us, 3)}
     rp, rp_src = newest_pmc("r*_rel_head_pmc.json", rel_entry["kernel"])   # same provenance as the MSDA counters above
     if rp:
         rel_entry["traffic"] = rp.get("hbm_bytes_per_launch")
@@ -742,25 +785,19 @@ def main():
     result["roofline_kernels"] = [result["roofline"], rel_entry]
     if _ops.GEMM_SPLIT_BF16:
         g_us, g_flops = time_split_gemm(dev)
-        g_tf = g_flops / (g_us * 1e-6) / 1e12
-        result["roofline_kernels"].append(
-            {"bound": "mfma", "kernel": "gemm_split_bf16_f32",
-             "launch": "encoder layer: value (256->256) + offsets/weights (256->384, + position rows on load), M=12537, one launch",
-             "achieved": round(g_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": round(g_tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flops_per_launch": g_flops,
-             "avg_launch_us": round(g_us, 3), "arithmetic": "fp32 via bf16x6 operand split, fp32 accumulate",
-             "frac_of_bf16_dense_peak": round(6 * g_flops / (g_us * 1e-6) / 1e12 / 2500.0, 4)})
+        # (until round 3 this key timed the 256 -> 1024 + ReLU product; since the FFN moved into the row-panel kernel the
+        # model's only stand-alone launch of this kernel is the grouped one named here -- not comparable across that change)
+        result["roofline_kernels"].append(x6_entry(
+            "gemm_split_bf16_f32<grouped: value + offsets/weights>",
+            "encoder layer: value (256->256) + offsets/weights (256->384, + position rows on load), M=12537, one launch",
+            g_us, g_flops, 6 * g_flops, "gemm_split_bf16_f32"))
         result["config"]["encoder_linears"] = "fp32 via bf16x6 operand split, fp32 accumulate"
         t_us, t_flops = time_encoder_tail(dev)
         if t_us is not None:
-            t_tf = t_flops / (t_us * 1e-6) / 1e12
-            tail_entry = {"bound": "mfma", "kernel": "ffn_x6_kernel<true>",
-                          "launch": "encoder layer tail: output projection + LayerNorm + FFN 256-1024-256 + LayerNorm, M=12537",
-                          "achieved": round(t_tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": round(t_tf / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                          "algorithmic_flops_per_launch": t_flops, "avg_launch_us": round(t_us, 3),
-                          "arithmetic": "fp32 via bf16x6 operand split, fp32 accumulate",
-                          "frac_of_bf16_dense_peak": round(6 * t_flops / (t_us * 1e-6) / 1e12 / 2500.0, 4)}
+            tail_entry = x6_entry(
+                "ffn_x6_kernel<true>",
+                "encoder layer tail: output projection + LayerNorm + FFN 256-1024-256 + LayerNorm, M=12537",
+                t_us, t_flops, 6 * t_flops, "ffn_x6_kernel")
             tp, tp_src = newest_pmc("r*_ffn_x6_pmc.json", tail_entry["kernel"])
             if tp:
                 tail_entry["traffic"] = tp.get("hbm_bytes_per_launch")

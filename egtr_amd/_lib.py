@@ -19,14 +19,11 @@ SIGNATURES = {
     "egtr_status_string": [_I],
     "egtr_last_hip_error": [],
     "egtr_msda_forward_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "egtr_msda_forward_fused_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P],
     "egtr_msda_forward_fused_vbias_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P,
                                           _P],
     "egtr_msda_forward_fused_box_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P,
                                         _P],
-    "egtr_msda_forward_f32_variant": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I],
     "egtr_msda_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    "egtr_msda_backward_f32_variant": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I],
     "egtr_msda_forward_f64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "egtr_msda_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "egtr_msda_backward_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -40,7 +37,6 @@ SIGNATURES = {
     "egtr_add_layernorm_pos_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _I, _P],
     "egtr_bias_mask_rows_f32": [_P, _P, _P, _P, _I, _I, _I],
     "egtr_bias_relu_maxpool3x3s2_f32": [_P, _P, _P, _P, _I, _I, _I, _I],
-    "egtr_box_decode_f32": [_P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P],
     "egtr_box_decode_argmax_f32": [_P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P, _P, _I, _P],
     "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_bias_act_nchw_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
@@ -68,14 +64,12 @@ SIGNATURES = {
                                 _P, _P],
     "egtr_relation_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I, _I, _P, _P, _P, _P],
     "egtr_relation_loss_workspace_bytes": [_I, _I],
-    "egtr_rel_head_forward_f32": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_rel_head_forward_bf16w": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_linear_split_bf16_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I],
     "egtr_linear_split_bf16_wgrad_f32": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
     "egtr_linear_split_bf16_wgrad_workspace_floats": [_I, _I, _I],
     "egtr_gemm_split_tile_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "egtr_gemm_split_tile_weights_pair_f32": [_P, _P, _I, _I, _I, _P],
-    "egtr_linear_split_bf16_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_linear_split_bf16_grouped_pos_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "egtr_pad_batch_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "egtr_ffn_x6_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I, _I],
@@ -85,7 +79,6 @@ SIGNATURES = {
     "egtr_proj_multi_x6_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I],
     "egtr_xs_bytes": [_I, _I],
     "egtr_xs_split_f32": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _I],
-    "egtr_gemm_x6_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_rel_head_forward_bf16x6_f32": [_P] * 16 + [_I] * 6 + [_P] * 3 + [_I],
     "egtr_rel_head_forward_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
     "egtr_rel_head_backward_pairs_f32": [_P] * 6 + [_I] * 4 + [_P] * 5,

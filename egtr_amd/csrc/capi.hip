@@ -14,6 +14,16 @@ int egtr_check_launch() {
   return EGTR_OK;
 }
 
+int egtr_raise_dynamic_lds(const void* kernel, int bytes, unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return egtr_check_launch();
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return EGTR_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return egtr_check_launch();
+  __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+  return EGTR_OK;
+}
+
 extern "C" int egtr_abi_version(void) { return 1; }
 
 extern "C" const char* egtr_status_string(int status) {

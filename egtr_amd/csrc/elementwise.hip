@@ -831,14 +831,6 @@ extern "C" int egtr_box_decode_argmax_f32(egtr_stream_t stream, const float* del
   return egtr_check_launch();
 }
 
-extern "C" int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
-                                   const float* inter_references, int batch, int num_levels, int num_query,
-                                   int ref_dim, float eps, float* boxes) {
-  if (num_levels > 1 && !inter_references) return EGTR_E_ARG;
-  return egtr_box_decode_argmax_f32(stream, delta, init_reference, inter_references, batch, num_levels, num_query,
-                                    ref_dim, eps, boxes, nullptr, 0, nullptr);
-}
-
 extern "C" int egtr_bias_mask_rows_f32(egtr_stream_t stream, float* y, const float* bias, const unsigned char* keep,
                                        int groups, int rows, int cols) {
   if (!y || !bias) return EGTR_E_ARG;

@@ -21,28 +21,6 @@
 #include "x6_common.h"
 #include "xs_format.h"
 
-#ifndef FFN_ABL
-#define FFN_ABL 0   // development ablations (tools/ffn_x6_bench.hip): 1 no in-loop DMA, 2 no barriers, 3 no hidden-chunk epilogue, 4 no weight reads
-#endif
-
-#ifdef FFN_TIMING
-#define FFN_STAMP(k)                                                                             \
-  do {                                                                                           \
-    if (A.tdbg != nullptr && blockIdx.x == 0 && tid == 0 && c == 2)                              \
-      A.tdbg[s * 6 + (k)] = (long long)__builtin_readcyclecounter();                             \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-  } while (0)
-#define FFN_PHASE(k)                                                                             \
-  do {                                                                                           \
-    if (A.tdbg != nullptr && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))                 \
-      A.tdbg[48 + (blockIdx.x ? 8 : 0) + (k)] = (long long)__builtin_readcyclecounter();         \
-    __builtin_amdgcn_sched_barrier(0);                                                           \
-  } while (0)
-#else
-#define FFN_STAMP(k)
-#define FFN_PHASE(k)
-#endif
-
 namespace {
 using namespace x6;
 
@@ -72,7 +50,6 @@ struct FfnArgs {
   float* out_pos;        // [M, 256] = out + pos[row % pos_rows], or null
   int M, ldx, ldr, F, pos_rows;
   float eps;
-  long long* tdbg;   // development: cycle stamps of wave 0 of workgroup 0 (FFN_TIMING builds), else null
   // ffn_x6_kernel<true> (encoder layer tail): x is the attention context; y1 = LayerNorm1(res + x . Wp^T + bp) is the
   // FFN's input AND its residual (res / ldr = the layer input, the residual of LayerNorm1)
   const char* wp;        // XS(Wp [256, 256])
@@ -294,7 +271,6 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) dma16s(base + (i / 3) * stride + (i % 3) * kFrag, voff, dst + i * kFrag);
   };
-  FFN_PHASE(0);
   issue(0, 0);
   issue(1, 1);
 
@@ -306,7 +282,6 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
 #pragma unroll
     for (int ks = 0; ks < kKS; ++ks) lo[ks] = *reinterpret_cast<const bf16x8*>(q + ks * kFrag + (swz(lane, ks) << 4));
   }
-  FFN_PHASE(1);
 
   f32x16 acc2[4], acc1[2];
 #pragma unroll
@@ -357,12 +332,12 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
         acc2[t] = mfma(w[t][pwt[term]], a[ap >> 1][ap & 1], acc2[t]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (FFN_ABL != 1 && (i & 1) && (i >> 1) < NL) {
+      if constexpr ((i & 1) && (i >> 1) < NL) {
         constexpr int j = i >> 1;
         dma16s(src + (j / 3) * sstride + (j % 3) * kFrag, voff, dst + j * kFrag);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (FFN_ABL != 4 && i >= 12 && i < 18) {
+      if constexpr (i >= 12 && i < 18) {
         constexpr int j = 2 * (i - 12);
         wnx[j / 3][j % 3] = frag(wn_src + j * kFrag);
         wnx[(j + 1) / 3][(j + 1) % 3] = frag(wn_src + (j + 1) * kFrag);
@@ -414,9 +389,9 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
   auto stage_top = [&]() {
     // this wave's DMAs of stage g + 1 have landed (those of g + 2 stay in flight), everybody's LDS traffic of stage g - 1
     // is finished (lgkmcnt(0) + barrier)
-    if (FFN_ABL == 1) wait_vm<0>(); else wait_vm<NL>();
+    wait_vm<NL>();
     wait_lgkm0();
-    if (FFN_ABL != 2) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -434,7 +409,6 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       slot = sn;
       ++g;
     });
-    FFN_PHASE(4);
     // ---- y1 = LayerNorm1(res + context . Wp^T + bp) in registers (accumulator layout, see final_epilogue)
     const int row = r0 + wm * 32 + li;
     const float* xr = A.res + (size_t)min(row, A.M - 1) * A.ldr;
@@ -450,7 +424,6 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       }
     float* red = reinterpret_cast<float*>(hbuf + 16 * kFrag);     // the chunk buffer is idle until the first hand-over
     layernorm_rows(y1, A.gamma1, A.beta1, A.eps1, wave, lane, red);   // its first barrier: everybody is done with the context panel
-    FFN_PHASE(5);
     // ---- y1 -> the panel (hi / mid in place of the context), lo through hbuf[0, 16 KiB) one row block at a time.
     //      Accumulator register group (t, q) = channels 32 (4 wn + t) + 8 q + 4 hf .. + 3 of row li: k-step 2 (4 wn + t) +
     //      (q >> 1), k-group q & 1, bytes 8 hf .. 8 hf + 7 of the row's slot.
@@ -485,7 +458,6 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       }
       __syncthreads();
     }
-    FFN_PHASE(6);
   }
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
@@ -497,9 +469,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
     static_for<8>([&](auto S) {
       constexpr int s = decltype(S)::value;
       const int sn = slot == 2 ? 0 : slot + 1;       // slot of stage g + 1
-      FFN_STAMP(0);
       stage_top();
-      FFN_STAMP(3);
       if constexpr (s == 4) {          // the hidden chunk was written by the stage before: visible after this barrier
         a0[0][0] = frag(ph + 0 * kFrag);
         a0[0][1] = frag(ph + 1 * kFrag);
@@ -523,8 +493,7 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
       }
       if constexpr ((s & 1) == 0) stage(S, w0, w1, a0, a1, g, sn, slot);
       else stage(S, w1, w0, a1, a0, g, sn, slot);
-      FFN_STAMP(4);
-      if constexpr (s == 3 && FFN_ABL != 3) {
+      if constexpr (s == 3) {
         // bias + ReLU + split of the wave's 32 x 32 piece of the hidden chunk -> XS fragments in LDS.  The 32 bias values
         // are wave-uniform: SCALAR loads (they do not touch the vmcnt queue the DMA waits are counted on).
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bias[0]), "+s"(bias[1]), "+s"(bias[2]), "+s"(bias[3]));
@@ -545,16 +514,13 @@ __global__ __launch_bounds__(256, 1) void ffn_x6_kernel(FfnArgs A) {
           *reinterpret_cast<uint2*>(dst + 2 * kFrag) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
         }
       }
-      FFN_STAMP(5);
       slot = sn;
       ++g;
     });
   }
   wait_vm<0>();   // the surplus re-loads of the tail must have landed before this workgroup's LDS can be handed on
-  FFN_PHASE(2);
   final_epilogue<PROJ>(acc2, A, r0, wave, lane, reinterpret_cast<float*>(ring), [&](int t, int q) { return y1[t][q]; });
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  FFN_PHASE(3);
 }
 
 
@@ -667,8 +633,6 @@ __global__ __launch_bounds__(256, 1) void proj_x6_kernel(FfnArgs A) {
 
 }  // namespace
 
-long long* g_ffn_tdbg = nullptr;   // development hook (tools/ffn_x6_bench.hip, FFN_TIMING builds)
-
 extern "C" int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w1_xs, const float* b1,
                                const void* w2_xs, const float* b2, const float* ln_gamma, const float* ln_beta, float eps,
                                const float* pos, int pos_rows, float* out, float* out_pos, int M, int d_model, int ffn_dim) {
@@ -679,15 +643,10 @@ extern "C" int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, co
       (reinterpret_cast<uintptr_t>(w2_xs) & 15) || (reinterpret_cast<uintptr_t>(b2) & 15) ||
       (out_pos && (reinterpret_cast<uintptr_t>(out_pos) & 15)) || (pos && (reinterpret_cast<uintptr_t>(pos) & 15)))
     return EGTR_E_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x6_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLds) != hipSuccess)
-      return egtr_check_launch();
-    attr_set = true;
-  }
+  static unsigned long long lds_raised = 0;   // per-device
+  if (int st = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(ffn_x6_kernel<false>), kLds, &lds_raised)) return st;
   FfnArgs a{x, x, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln_gamma, ln_beta, pos, out,
-            out_pos, M, ldx, ldx, ffn_dim, pos_rows, eps, g_ffn_tdbg, nullptr, nullptr, nullptr, nullptr, 0.f};
+            out_pos, M, ldx, ldx, ffn_dim, pos_rows, eps, nullptr, nullptr, nullptr, nullptr, 0.f};
   hipLaunchKernelGGL(ffn_x6_kernel<false>, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }
@@ -706,15 +665,10 @@ extern "C" int egtr_encoder_tail_x6_f32(egtr_stream_t stream, const float* conte
                         (const void*)ln1_beta, w1_xs, w2_xs, (const void*)b2, (const void*)ln2_gamma, (const void*)ln2_beta,
                         (const void*)out, (const void*)out_pos, (const void*)pos})
     if (reinterpret_cast<uintptr_t>(p) & 15) return EGTR_E_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_x6_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kLds) != hipSuccess)
-      return egtr_check_launch();
-    attr_set = true;
-  }
+  static unsigned long long lds_raised = 0;   // per-device
+  if (int st = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(ffn_x6_kernel<true>), kLds, &lds_raised)) return st;
   FfnArgs a{context, hidden, static_cast<const char*>(w1_xs), b1, static_cast<const char*>(w2_xs), b2, ln2_gamma, ln2_beta,
-            pos, out, out_pos, M, ldc, ldh, ffn_dim, pos_rows, eps2, g_ffn_tdbg, static_cast<const char*>(wp_xs), bp, ln1_gamma,
+            pos, out, out_pos, M, ldc, ldh, ffn_dim, pos_rows, eps2, static_cast<const char*>(wp_xs), bp, ln1_gamma,
             ln1_beta, eps1};
   hipLaunchKernelGGL(ffn_x6_kernel<true>, dim3((M + kRows - 1) / kRows), dim3(256), kLds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
@@ -733,15 +687,10 @@ extern "C" int egtr_proj_ln_x6_f32(egtr_stream_t stream, const float* x, int ldx
       (out_pos && (reinterpret_cast<uintptr_t>(out_pos) & 15)) || (pos && (reinterpret_cast<uintptr_t>(pos) & 15)))
     return EGTR_E_UNSUPPORTED;
   constexpr int lds = kPanel + 3 * kStage + 8 * kFrag;   // + 8 KiB: parking place of the second row block's lo pieces
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(proj_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return egtr_check_launch();
-    attr_set = true;
-  }
+  static unsigned long long lds_raised = 0;   // per-device
+  if (int st = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(proj_x6_kernel), lds, &lds_raised)) return st;
   FfnArgs a{x, residual, nullptr, nullptr, static_cast<const char*>(w_xs), bias, ln_gamma, ln_beta, pos, out, out_pos,
-            M, ldx, ldr, 1, pos_rows, eps, nullptr};
+            M, ldx, ldr, 1, pos_rows, eps};
   hipLaunchKernelGGL(proj_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), lds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }
@@ -753,15 +702,10 @@ extern "C" int egtr_proj_multi_x6_f32(egtr_stream_t stream, const float* x, int 
       (reinterpret_cast<uintptr_t>(w_xs) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
     return EGTR_E_UNSUPPORTED;
   constexpr int lds = kPanel + 3 * kStage + 8 * kFrag;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(proj_x6_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-        hipSuccess)
-      return egtr_check_launch();
-    attr_set = true;
-  }
+  static unsigned long long lds_raised = 0;   // per-device
+  if (int st = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(proj_x6_kernel), lds, &lds_raised)) return st;
   FfnArgs a{x, nullptr, nullptr, nullptr, static_cast<const char*>(w_xs), bias, nullptr, nullptr, nullptr, out, nullptr,
-            M, ldx, 0, num_weights, 0, 0.f, nullptr};
+            M, ldx, 0, num_weights, 0, 0.f};
   hipLaunchKernelGGL(proj_x6_kernel, dim3((M + kRows - 1) / kRows), dim3(256), lds, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }

@@ -483,14 +483,6 @@ extern "C" int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int 
   return launch_grouped(static_cast<hipStream_t>(stream), P, num_problems, M, K);
 }
 
-extern "C" int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, const float* const* x,
-                                                  const int* ldx, const uint16_t* const* w_tiled,
-                                                  const float* const* bias, float* const* y, const int* ldy,
-                                                  const int* N, const int* relu, int M, int K) {
-  return egtr_linear_split_bf16_grouped_pos_f32(stream, num_problems, x, ldx, w_tiled, bias, y, ldy, N, relu, M, K, nullptr,
-                                                nullptr);
-}
-
 extern "C" int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int ldw, int transposed, int N, int K,
                                                 uint16_t* w_tiled) {
   if (!w || !w_tiled || N <= 0 || K <= 0 || ldw < (transposed ? N : K)) return EGTR_E_ARG;

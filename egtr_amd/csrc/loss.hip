@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kLT) void rel_loss_prep(const int64_t* __restrict__
   int T = out_off[b + 1] - o0;
   // The device matcher writes -1 indices for an image whose cost matrix holds NaN / -inf (scipy raises there): such an
   // image is treated as having NO matches here (never an out-of-bounds access); the Python side turns the matcher's
-  // status into a NaN loss and a ValueError (ops.MatcherStatus).
+  // status into NaN loss terms for that output set (SceneGraphGenerationLoss.forward) and a ValueError
+  // (DeformableDetrHungarianMatcher.raise_if_invalid).
   int bad_local = 0;
   for (int t = tid; t < T; t += kLT) {
     const long long q = pred_idx[o0 + t], g = tgt_idx[o0 + t];

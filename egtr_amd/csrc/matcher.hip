@@ -292,13 +292,9 @@ extern "C" int egtr_hungarian_match_f32(egtr_stream_t stream, const float* logit
     return egtr_check_launch();
   }
   if (lds > 64 * 1024) {
-    static bool raised = false;   // dynamic LDS above 64 KB has to be requested once per process
-    if (!raised) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(hungarian_match_f32<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess)
-        return EGTR_E_LAUNCH;
-      raised = true;
-    }
+    static unsigned long long lds_raised = 0;   // dynamic LDS above 64 KB has to be requested once per device
+    if (int rc = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(hungarian_match_f32<false>), kLdsBytes, &lds_raised))
+      return rc;
   }
   hipLaunchKernelGGL(hungarian_match_f32<false>, dim3(batch), dim3(kMT), lds, st, logits, boxes, tgt_ids, tgt_boxes,
                      tgt_offsets, out_offsets, num_query, num_logits, class_cost, bbox_cost, giou_cost, smoothing,

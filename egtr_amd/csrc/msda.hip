@@ -700,19 +700,6 @@ extern "C" int egtr_msda_forward_fused_box_f32(egtr_stream_t stream, const float
                                 value_bias);
 }
 
-extern "C" int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                           const int64_t* level_start_index, const float* sampling_offsets,
-                                           const float* attn_logits, const float* reference_points, int batch,
-                                           int spatial_size, int num_heads, int channels, int num_levels,
-                                           int num_query, int num_point, float* out, float* attn_weight_out,
-                                           int ld_offsets, int ld_logits, const unsigned char* keep_mask,
-                                           const unsigned* keep_bits) {
-  return egtr_msda_forward_fused_vbias_f32(stream, value, spatial_shapes, level_start_index, sampling_offsets,
-                                           attn_logits, reference_points, batch, spatial_size, num_heads, channels,
-                                           num_levels, num_query, num_point, out, attn_weight_out, ld_offsets,
-                                           ld_logits, keep_mask, keep_bits, nullptr);
-}
-
 extern "C" int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                      const int64_t* level_start_index, const float* sampling_loc,
                                      const float* attn_weight, int batch, int spatial_size, int num_heads,

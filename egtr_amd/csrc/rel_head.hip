@@ -1100,18 +1100,6 @@ extern "C" int egtr_rel_head_forward_save_f32(egtr_stream_t stream, const float*
   return egtr_check_launch();
 }
 
-extern "C" int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k,
-                                         const float* uq, const float* uk, const float* b1, const float* w2r,
-                                         const float* b2r, const float* w3r, const float* b3r, const float* w2c,
-                                         const float* b2c, const float* w3c, const float* b3c,
-                                         const float* triplet_dist, const int64_t* node_cls, int batch,
-                                         int num_query, int num_slots, int hidden, int num_rel, int num_cls_plus1,
-                                         float* rel_logits, float* conn_logits, float* gate_mean) {
-  return egtr_rel_head_forward_save_f32(stream, gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c,
-                                        triplet_dist, node_cls, batch, num_query, num_slots, hidden, num_rel,
-                                        num_cls_plus1, rel_logits, conn_logits, gate_mean, nullptr, nullptr);
-}
-
 extern "C" int egtr_rel_head_backward_pairs_f32(egtr_stream_t stream, const float* dh1, const float* gate_q,
                                                 const float* gate_k, const float* uq, const float* uk, int batch,
                                                 int num_query, int num_slots, int hidden, float* grad_uq,

@@ -734,7 +734,8 @@ class DeformableDetrDecoderLayer(nn.Module):
         states): inference plumbing, see the encoder layer and DeformableDetrDecoder.forward."""
         incoming = hidden_states if isinstance(hidden_states, ops.DeferredLayerNorm) else None
         fast = position_embeddings is not None and (incoming is not None or ops.inference_fast_path(hidden_states))
-        if (fast and ops.DEFER_LAYERNORM and not output_attentions and attention_mask is None
+        # (not self.training: the deferred route has no dropout calls -- a model in train() mode under no_grad() keeps them)
+        if (fast and ops.DEFER_LAYERNORM and not self.training and not output_attentions and attention_mask is None
                 and self.activation_fn is F.relu and self.embed_dim == 256
                 and hidden_states.shape[0] * hidden_states.shape[1] <= ops.SKINNY_MAX_ROWS
                 and (incoming is not None or hidden_states.dtype == torch.float32)):
@@ -1300,6 +1301,9 @@ class DeformableDetrMLPPredictionHead(nn.Module):
 
 # (pinned host copy of a solver status, the event that marks the copy complete), oldest first
 _PENDING_MATCHER_STATUS = []
+# device-side statuses (int32 [B] each) of the matcher calls made since the last ``take_step_statuses()``: what a trainer
+# folds into the optimizer's skip flag at the accumulation boundary (egtr_amd.runtime.DataParallelTrainer)
+_STEP_MATCHER_STATUS = []
 _STATUS_SLOTS = {}     # (numel, dtype) -> [ring of (pinned buffer, event), next index]
 
 
@@ -1330,6 +1334,15 @@ class MatchedIndices(list):
         if self.status is None:
             return value
         return torch.where(self.status.ne(0).any(), torch.full_like(value, float("nan")), value)
+
+    def poison_terms(self, terms):
+        """``poison`` for every floating-point tensor of a dict of loss terms (one output set): the loss kernels skip a
+        refused image, so its terms would otherwise look healthy in a logged loss_dict."""
+        if self.status is None:
+            return terms
+        bad = self.status.ne(0).any()
+        return {k: (torch.where(bad, torch.full_like(v, float("nan")), v)
+                    if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in terms.items()}
 
 
 class DeformableDetrHungarianMatcher(nn.Module):
@@ -1368,6 +1381,16 @@ class DeformableDetrHungarianMatcher(nn.Module):
                 if (worst == 1).any():
                     raise ValueError("matrix contains invalid numeric entries")
                 raise ValueError("cost matrix is infeasible")
+
+    @staticmethod
+    def take_step_statuses():
+        """The per-image solver statuses (device int32 tensors, one per matcher call) recorded since the last call, and
+        forget them.  A trainer reduces them to one "some cost matrix was refused" flag ON THE DEVICE and hands it to the
+        optimizer as its skip flag, so that a refused step (NaN loss, NaN gradients) never reaches the weights -- the
+        reference stops inside the step with scipy's ValueError, before backward."""
+        out = list(_STEP_MATCHER_STATUS)
+        _STEP_MATCHER_STATUS.clear()
+        return out
 
     def _smoothing_scalars(self):
         """cost_min and inverse_sigmoid_smoothing exactly as the reference forms them (fp32 tensors, dd:2992-2998)."""
@@ -1415,6 +1438,8 @@ class DeformableDetrHungarianMatcher(nn.Module):
                 event.record()
                 _PENDING_MATCHER_STATUS.append((host, event))
                 del _PENDING_MATCHER_STATUS[:-64]   # bounded when nobody asks
+                _STEP_MATCHER_STATUS.append(status)
+                del _STEP_MATCHER_STATUS[:-64]
             for n in n_out:
                 indices.append((pred_idx[o:o + n], tgt_idx[o:o + n]))
                 costs.append(mcost[o:o + n])
@@ -1574,12 +1599,13 @@ class DeformableDetrLoss(nn.Module):
             if packed[0] is None:
                 packed[0] = ops.pack_detection_targets(targets, lg.device)
             d = ops.detection_losses(lg, out["pred_boxes"], indices.flat, packed[0], self.focal_alpha, num_boxes)
-            d["loss_ce"] = indices.poison(d["loss_ce"])   # a cost matrix the device matcher refused: NaN, not garbage
             losses.update({k + suffix: v for k, v in d.items()})
         for loss in self.losses:
             if fused and loss in ("labels", "cardinality", "boxes"):
                 continue
             losses.update({k + suffix: v for k, v in self.get_loss(loss, out, targets, indices, num_boxes).items()})
+        if isinstance(indices, MatchedIndices):   # a cost matrix the device matcher refused: NaN terms, not garbage
+            losses = indices.poison_terms(losses)
         return losses
 
     def forward(self, outputs, targets):

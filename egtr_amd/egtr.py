@@ -618,26 +618,32 @@ class SceneGraphGenerationLoss(nn.Module):
                 packed = ops.pack_detection_targets(targets, out["logits"].device)
             return ops.detection_losses(out["logits"], out["pred_boxes"], idx.flat, packed, self.focal_alpha, num_boxes)
 
+        def poisoned(idx, terms):
+            # a cost matrix the device matcher refused (NaN / -inf entries; scipy raises there): every loss term of THAT
+            # output set comes out NaN -- the kernels skip a refused image, so without this its terms would look healthy
+            # in a logged loss_dict (the ValueError itself follows at the next host synchronisation point)
+            return idx.poison_terms(terms) if isinstance(idx, MatchedIndices) else terms
+
         use_fused = fused_ok(outputs, indices)
-        main_indices = indices
+        main = {}
         if use_fused:
-            losses.update(detection(outputs, indices))
+            main.update(detection(outputs, indices))
         for loss in self.losses:
             if use_fused and loss in fused:
                 continue
-            losses.update(self.get_loss(loss, outputs, targets, indices, matching_costs, num_boxes))
+            main.update(self.get_loss(loss, outputs, targets, indices, matching_costs, num_boxes))
+        losses.update(poisoned(indices, main))
         if "auxiliary_outputs" in outputs:
             for i, auxiliary_outputs in enumerate(outputs["auxiliary_outputs"]):
                 indices, matching_costs = self.matcher(auxiliary_outputs, targets)
                 aux_fused = fused_ok(auxiliary_outputs, indices)
+                aux = {}
                 if aux_fused:
-                    losses.update({k + f"_{i}": v for k, v in detection(auxiliary_outputs, indices).items()})
+                    aux.update({k + f"_{i}": v for k, v in detection(auxiliary_outputs, indices).items()})
                 for loss in self.losses:
                     if loss in ["masks", "relations", "uncertainty"] or (aux_fused and loss in fused):
                         continue
                     l_dict = self.get_loss(loss, auxiliary_outputs, targets, indices, matching_costs, num_boxes)
-                    losses.update({k + f"_{i}": v for k, v in l_dict.items()})
-        # a cost matrix the device matcher refused (NaN / -inf entries; scipy raises there): the loss comes out NaN
-        if isinstance(main_indices, MatchedIndices) and main_indices.status is not None and "loss_ce" in losses:
-            losses["loss_ce"] = main_indices.poison(losses["loss_ce"])
+                    aux.update({k + f"_{i}": v for k, v in l_dict.items()})
+                losses.update(poisoned(indices, aux))
         return losses

@@ -172,24 +172,8 @@ class _MultiScaleDeformableAttention:
         return out
 
     @staticmethod
-    def ms_deform_attn_forward_variant(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, variant):
-        """fp32 forward with an explicit kernel variant (include/egtr_hip.h); benchmarks and A/B parity tests."""
-        lib = _lib.lib()
-        B, S, M, D = value.shape
-        L = spatial_shapes.shape[0]
-        Lq, P = sampling_loc.shape[1], sampling_loc.shape[4]
-        for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight")):
-            _chk(t, n, torch.float32)
-        out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
-        st = lib.egtr_msda_forward_f32_variant(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
-                                               level_start_index.data_ptr(), sampling_loc.data_ptr(),
-                                               attn_weight.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(), variant)
-        _lib.check(st, f"ms_deform_attn_forward(variant={variant})")
-        return out
-
-    @staticmethod
     def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output,
-                                im2col_step, variant=0):
+                                im2col_step):
         lib = _lib.lib()
         B, S, M, D = value.shape
         L = spatial_shapes.shape[0]
@@ -230,11 +214,10 @@ class _MultiScaleDeformableAttention:
         grad_value = torch.zeros_like(value)  # accumulated with atomics (reference: cu:124)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
-        st = lib.egtr_msda_backward_f32_variant(_stream(), grad_output.data_ptr(), value.data_ptr(),
-                                                spatial_shapes.data_ptr(), level_start_index.data_ptr(),
-                                                sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq,
-                                                P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                                                variant)
+        st = lib.egtr_msda_backward_f32(_stream(), grad_output.data_ptr(), value.data_ptr(),
+                                        spatial_shapes.data_ptr(), level_start_index.data_ptr(),
+                                        sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq,
+                                        P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())
         _lib.check(st, "ms_deform_attn_backward")
         return grad_value, grad_loc, grad_attn
 

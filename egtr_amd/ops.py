@@ -790,7 +790,7 @@ def linear_split_bf16_grouped(items):
     return outs
 
 
-# ---- second-generation split-bf16 GEMM (csrc/gemm_x6.hip): both operands pre-split into the XS format ----------------
+# ---- the XS operand format (csrc/xs_format.h, csrc/xs_split.hip): weights of the row-panel kernels ----------------------
 def xs_bytes(rows, K):
     return int(_lib.lib().egtr_xs_bytes(int(rows), int(K)))
 
@@ -820,48 +820,6 @@ def xs_split(x, pos=None, weights=False, plain=True):
                                out_pos.data_ptr() if out_pos is not None else None, 1 if weights else 0)
     _lib.check(st, "egtr_xs_split_f32")
     return out if pos is None else (out, out_pos)
-
-
-def gemm_x6(items, M, K):
-    """Up to 8 products act(A W^T + b) with the same M and K in one launch (egtr_gemm_x6_f32).  ``items``: dicts with
-    a (XS(A), from xs_split / a producer kernel), w (XS(W), ``xs_split(W, weights=True)``), N, optional b, relu,
-    out ([M, N] fp32 destination with unit inner stride, or False for "no fp32 output"), xs (True: also return XS(C)).
-    Returns per item the fp32 output, or XS(C), or (fp32, XS(C)).  Inference only."""
-    import ctypes
-    lib = _lib.lib()
-    n = len(items)
-    outs, cs, cxs, keep = [], [], [], []
-    for it in items:
-        N = int(it["N"])
-        _chk(it["a"], "a", torch.uint8)
-        _chk(it["w"], "w", torch.uint8)
-        if it["a"].numel() != xs_bytes(M, K) or it["w"].numel() != xs_bytes(N, K):
-            raise RuntimeError("gemm_x6: operand buffers do not have the XS size of [M, K] / [N, K]")
-        y = it.get("out")
-        if y is None:
-            y = torch.empty(M, N, dtype=torch.float32, device=it["a"].device)
-        elif y is not False:
-            if not y.is_cuda or y.dtype != torch.float32 or tuple(y.shape) != (M, N) or y.stride(1) != 1:
-                raise RuntimeError(f"gemm_x6: out must be a float32 [M, N] device tensor with unit inner stride")
-        x = torch.empty(xs_bytes(M, N), dtype=torch.uint8, device=it["a"].device) if it.get("xs") else None
-        if y is False and x is None:
-            raise RuntimeError("gemm_x6: an item needs an fp32 output, an XS output, or both")
-        b = it.get("b")
-        if b is not None:
-            b = _chk(b.detach().contiguous(), "bias", torch.float32)
-        keep.append(b)
-        cs.append(None if y is False else y)
-        cxs.append(x)
-        outs.append(x if y is False else (y if x is None else (y, x)))
-    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
-    st = lib.egtr_gemm_x6_f32(
-        _stream(), n, PA(*[it["a"].data_ptr() for it in items]), PA(*[it["w"].data_ptr() for it in items]),
-        PA(*[(b.data_ptr() if b is not None else None) for b in keep]),
-        PA(*[(c.data_ptr() if c is not None else None) for c in cs]), IA(*[(c.stride(0) if c is not None else 0) for c in cs]),
-        PA(*[(x.data_ptr() if x is not None else None) for x in cxs]), IA(*[int(it["N"]) for it in items]),
-        IA(*[1 if it.get("relu") else 0 for it in items]), int(M), int(K))
-    _lib.check(st, "egtr_gemm_x6_f32")
-    return outs
 
 
 FFN_FUSED = os.environ.get("EGTR_FFN_FUSED", "1") != "0"

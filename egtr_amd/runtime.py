@@ -191,10 +191,27 @@ class DataParallelTrainer:
                          output_attentions=False, output_attention_states=True, output_hidden_states=True)
         return out.loss, out.loss_dict
 
+    def _refused_flag(self):
+        """float32 [1] on the device: 1 if the device matcher refused a cost matrix (NaN / -inf entries, infeasible) in any
+        forward since the last optimizer step, on any rank; None when no device matcher ran.  No host synchronisation."""
+        from .deformable_detr import DeformableDetrHungarianMatcher
+        statuses = DeformableDetrHungarianMatcher.take_step_statuses()
+        if not statuses:
+            return None
+        flag = torch.cat([s.reshape(-1) for s in statuses]).ne(0).any().to(torch.float32).reshape(1)
+        if self.world > 1:   # replicas must skip together (4 bytes; the refusing rank raises at its next step)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return flag
+
     def training_step(self, batch):
-        """One micro-batch; returns (loss, loss_dict, stepped)."""
-        # a cost matrix the device matcher refused during the PREVIOUS step (NaN / -inf: the reference raises scipy's
-        # ValueError inside the step) surfaces here, without a host synchronisation inside the step
+        """One micro-batch; returns (loss, loss_dict, stepped).
+
+        A cost matrix the device matcher refuses (NaN / -inf: the reference raises scipy's ValueError inside the step,
+        before backward) makes the loss and every gradient NaN.  The optimizer step of such a window is SKIPPED on the
+        device (the fused AdamW's ``found_inf`` operand -- the mechanism of torch's GradScaler), so the weights and the
+        optimizer state stay intact; the ValueError itself is raised by ``raise_if_invalid`` at the top of the next step
+        (or by ``finalize()`` after the last one), without a host synchronisation inside the step that produced it.
+        Optimizers without a device-side skip flag wait for the recorded status copy instead (one host wait per step)."""
         from .deformable_detr import DeformableDetrHungarianMatcher
         DeformableDetrHungarianMatcher.raise_if_invalid()
         self._micro += 1
@@ -205,10 +222,34 @@ class DataParallelTrainer:
             loss, loss_dict = self.common_step(batch)
             (loss / self.accumulate).backward()
         if boundary:
+            refused = self._refused_flag()
             torch.nn.utils.clip_grad_norm_(self.raw.parameters(), self.clip)
-            self.opt.step()
+            skip_on_device = refused is not None and all(g.get("fused") for g in self.opt.param_groups)
+            if refused is not None and not skip_on_device:
+                # no device-side skip in this optimizer: wait for the status copies and raise the matcher's ValueError now,
+                # before the step (weights still intact); `refused` also covers the other ranks
+                try:
+                    DeformableDetrHungarianMatcher.raise_if_invalid()
+                    if bool(refused.item()):
+                        raise ValueError("matrix contains invalid numeric entries")
+                except ValueError:
+                    self.opt.zero_grad(set_to_none=True)
+                    raise
+            if skip_on_device:
+                self.opt.found_inf = refused
+            try:
+                self.opt.step()
+            finally:
+                if skip_on_device:
+                    del self.opt.found_inf
             self.opt.zero_grad(set_to_none=True)
         return loss.detach(), loss_dict, boundary
+
+    def finalize(self):
+        """After the last step of a run: raise what the device matcher refused in it (``training_step`` reports a refusal at
+        the top of the NEXT step; there is none after the last one)."""
+        from .deformable_detr import DeformableDetrHungarianMatcher
+        DeformableDetrHungarianMatcher.raise_if_invalid()
 
 
 def enable_gemm_tuning(results_file=None):
@@ -274,25 +315,53 @@ def calculate_fps(model, batches, warmup=3):
 
 
 @torch.no_grad()
-def triplet_candidates(outputs, num_labels, orig_sizes, max_topk=100):
-    """The evaluator inputs of the reference's ``evaluate_batch`` (train_egtr.py:54-106, multiple-predicate branch)
-    computed where the model outputs live: per image the ``max_topk`` best (subject, object, predicate) triplets by
-    ``pred_rel * pred_connectivity * score_s * score_o`` (self-pairs excluded), their relation scores, object
-    classes / scores and boxes rescaled to the original image size.
+def triplet_candidates(outputs, num_labels, orig_sizes, max_topk=100, mode="multiple"):
+    """The evaluator inputs of the reference's ``evaluate_batch`` (train_egtr.py:54-175) computed where the model outputs
+    live.  Per image: object scores / classes (softmax over the first ``num_labels`` logits), boxes rescaled to the original
+    image size, and -- by ``mode`` --
+      * "multiple" (train_egtr.py:85-106, multiple-predicate evaluator): the ``max_topk`` best (subject, object, predicate)
+        triplets by ``pred_rel * pred_connectivity * score_s * score_o`` (self-pairs excluded): ``pred_rel_inds`` [k, 3],
+        ``rel_scores`` [k];
+      * "single" (train_egtr.py:120-139, single-predicate evaluator): the ``max_topk`` best (subject, object) PAIRS by
+        ``max_p(pred_rel * pred_connectivity) * score_s * score_o``: ``pred_rel_inds`` [k, 2], ``rel_scores`` [k, R] (the
+        pair's whole predicate row);
+      * "oi" (train_egtr.py:154-174, Open Images evaluator): every pair, ``sbj_obj_inds`` [N*N, 2] (cartesian product in
+        row-major order) and ``pred_scores`` [N*N, R].
 
     The reference copies ``pred_rel`` [N, N, R] (8 MB at N = 200) to the host and runs a full numpy argsort over its
-    2 M entries per image (lib/pytorch_misc.py:27-34); here it is one batched ``topk`` on the device and only
-    ``max_topk`` rows leave it.  Ties between equal triplet scores may be ordered differently from numpy's argsort
-    (both orders are valid argsorts).  ``orig_sizes``: [B, 2] (h, w).  Returns a list of dicts of tensors on the
-    outputs' device with the reference's ``pred_entry`` keys (+ ``triplet_scores``)."""
+    entries per image (lib/pytorch_misc.py:27-34); here it is one batched ``topk`` on the device and only ``max_topk`` rows
+    leave it.  Ties between equal scores may be ordered differently from numpy's argsort (both orders are valid argsorts).
+    ``orig_sizes``: [B, 2] (h, w).  Returns a list of dicts of tensors on the outputs' device with the reference's
+    ``pred_entry`` keys (+ ``triplet_scores`` for the two top-k modes)."""
+    if mode not in ("multiple", "single", "oi"):
+        raise ValueError(f"mode must be 'multiple', 'single' or 'oi', got {mode!r}")
     logits, boxes = outputs["logits"], outputs["pred_boxes"]
     rel = torch.clamp(outputs["pred_rel"], 0.0, 1.0)
     if "pred_connectivity" in outputs and outputs["pred_connectivity"] is not None:
         rel = rel * torch.clamp(outputs["pred_connectivity"], 0.0, 1.0)
     B, N, _, R = rel.shape
     obj_scores, pred_classes = torch.max(logits.softmax(-1)[..., :num_labels], -1)         # [B, N]
+    sizes = torch.as_tensor(orig_sizes, dtype=torch.float32, device=rel.device).reshape(B, 2)
+    cx, cy, w, h = boxes.unbind(-1)
+    xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+    scale = torch.stack([sizes[:, 1], sizes[:, 0], sizes[:, 1], sizes[:, 0]], -1)            # (w, h, w, h)
+    xyxy = xyxy * scale[:, None, :]
+    common = [{"pred_boxes": xyxy[b], "pred_classes": pred_classes[b], "obj_scores": obj_scores[b]} for b in range(B)]
+    if mode == "oi":
+        ar = torch.arange(N, device=rel.device)
+        pairs = torch.cartesian_prod(ar, ar)
+        return [dict(c, sbj_obj_inds=pairs, pred_scores=rel[b].reshape(N * N, R)) for b, c in enumerate(common)]
     sub_ob = obj_scores[:, :, None] * obj_scores[:, None, :]
     sub_ob = sub_ob.masked_fill(torch.eye(N, dtype=torch.bool, device=rel.device)[None], 0.0)
+    if mode == "single":
+        scores = (rel.max(-1)[0] * sub_ob).reshape(B, -1)                                     # [B, N*N]
+        k = min(max_topk, scores.shape[1])
+        top, flat = torch.topk(scores, k, dim=1)
+        s_idx = torch.div(flat, N, rounding_mode="floor")
+        o_idx = flat % N
+        rows = rel.reshape(B, N * N, R).gather(1, flat[:, :, None].expand(-1, -1, R))         # [B, k, R]
+        return [dict(c, pred_rel_inds=torch.stack([s_idx[b], o_idx[b]], -1), rel_scores=rows[b], triplet_scores=top[b])
+                for b, c in enumerate(common)]
     scores = (rel * sub_ob.unsqueeze(-1)).reshape(B, -1)
     k = min(max_topk, scores.shape[1])
     top, flat = torch.topk(scores, k, dim=1)                                                  # sorted descending
@@ -300,12 +369,5 @@ def triplet_candidates(outputs, num_labels, orig_sizes, max_topk=100):
     o_idx = torch.div(flat, R, rounding_mode="floor") % N
     p_idx = flat % R
     rel_scores = rel.reshape(B, -1).gather(1, flat)
-    sizes = torch.as_tensor(orig_sizes, dtype=torch.float32, device=rel.device).reshape(B, 2)
-    cx, cy, w, h = boxes.unbind(-1)
-    xyxy = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
-    scale = torch.stack([sizes[:, 1], sizes[:, 0], sizes[:, 1], sizes[:, 0]], -1)            # (w, h, w, h)
-    xyxy = xyxy * scale[:, None, :]
-    return [{"pred_boxes": xyxy[b], "pred_classes": pred_classes[b], "obj_scores": obj_scores[b],
-             "pred_rel_inds": torch.stack([s_idx[b], o_idx[b], p_idx[b]], -1), "rel_scores": rel_scores[b],
-             "triplet_scores": top[b]} for b in range(B)]
-
+    return [dict(c, pred_rel_inds=torch.stack([s_idx[b], o_idx[b], p_idx[b]], -1), rel_scores=rel_scores[b],
+                 triplet_scores=top[b]) for b, c in enumerate(common)]

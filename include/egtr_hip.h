@@ -66,18 +66,11 @@ int egtr_msda_forward_f32(egtr_stream_t stream, const float* value, const int64_
  * takes precedence, kept in LDS): padded tokens are skipped in the sum, which equals zeroing their value rows
  * (deformable_detr.py:1050-1052).
  * Only M = 8, D = 32, L*P = 16, P even; EGTR_E_UNSUPPORTED otherwise (compose the prologue on the host and call
- * egtr_msda_forward_f32). */
-int egtr_msda_forward_fused_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
-                                const int64_t* level_start_index, const float* sampling_offsets,
-                                const float* attn_logits, const float* reference_points, int batch, int spatial_size,
-                                int num_heads, int channels, int num_levels, int num_query, int num_point, float* out,
-                                float* attn_weight_out, int ld_offsets, int ld_logits,
-                                const unsigned char* keep_mask, const unsigned* keep_bits);
-
-/* Same with the value_proj bias applied inside the kernel: `value` is the bias-free projection W x of the (unmasked)
- * encoder states and value_bias [M*D] the bias; out = sum_s w_s v_s + value_bias * sum_s w_s over the in-range, unpadded
- * corner weights -- identical to sampling (W x + b) with padded rows zeroed (deformable_detr.py:1048-1052), without the
- * bias / mask pass over the [S, 256] value tensor.  value_bias may be NULL (then identical to the entry above). */
+ * egtr_msda_forward_f32).
+ * value_bias (optional, [M*D]): the value_proj bias applied inside the kernel -- `value` is then the bias-free projection
+ * W x of the (unmasked) encoder states; out = sum_s w_s v_s + value_bias * sum_s w_s over the in-range, unpadded corner
+ * weights, identical to sampling (W x + b) with padded rows zeroed (deformable_detr.py:1048-1052), without the bias / mask
+ * pass over the [S, 256] value tensor. */
 int egtr_msda_forward_fused_vbias_f32(egtr_stream_t stream, const float* value, const int64_t* spatial_shapes,
                                       const int64_t* level_start_index, const float* sampling_offsets,
                                       const float* attn_logits, const float* reference_points, int batch,
@@ -135,7 +128,7 @@ int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* value, const in
                            int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                            int num_point, uint16_t* out);
 
-/* bf16 forward with the prologue fused in (see egtr_msda_forward_fused_f32): sampling_offsets / attn_logits /
+/* bf16 forward with the prologue fused in (see egtr_msda_forward_fused_vbias_f32): sampling_offsets / attn_logits /
  * reference_points are raw bf16 tensors ([B,Lq,M,L,P,2] / [B,Lq,M,L*P] with row strides ld_offsets / ld_logits elements,
  * [B,Lq,L,2]); softmax and sampling locations are formed in fp32 inside the kernel; keep_mask (optional, [B,S] bytes). */
 int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,
@@ -266,11 +259,8 @@ int egtr_bias_relu_maxpool3x3s2_f32(egtr_stream_t stream, const float* x, const 
 /* Box decoding of the detection head for all decoder levels at once (model/egtr.py:286-305 with the shared bbox_embed,
  * with_box_refine = False): boxes[b, l, n, :] = sigmoid(delta[b, l, n, :] + [inverse_sigmoid(reference_l[b, n, :]), 0..]),
  * reference_0 = init_reference [B, N, ref_dim], reference_l = inter_references[:, l-1] ([B, Ld, N, ref_dim]) for l >= 1;
- * inverse_sigmoid as model/deformable_detr.py:658-662 with its eps.  ref_dim 2 or 4; delta / boxes [B, Ld, N, 4]. */
-int egtr_box_decode_f32(egtr_stream_t stream, const float* delta, const float* init_reference,
-                        const float* inter_references, int batch, int num_levels, int num_query, int ref_dim, float eps,
-                        float* boxes);
-/* The same with two fusions of the inference forward: inter_references == NULL means "every level uses init_reference"
+ * inverse_sigmoid as model/deformable_detr.py:658-662 with its eps.  ref_dim 2 or 4; delta / boxes [B, Ld, N, 4].
+ * Two fusions of the inference forward: inter_references == NULL means "every level uses init_reference"
  * (no iterative box refinement: the decoder passes the same reference points to every layer), and with logits_all
  * ([batch, num_levels, num_query, num_classes], may be NULL) node_cls [batch, num_query] int64 receives
  * argmax_c logits_all[b, num_levels - 1, n, c] -- the class lookup of the relation head's frequency bias
@@ -372,17 +362,9 @@ int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, 
  *   pass triplet_dist = NULL to disable (use_freq_bias = False).
  * Outputs: rel_logits [B, N, N, R] (incl. frequency bias), conn_logits [B, N, N] (pre-sigmoid, what the loss
  * consumes, egtr.py:450-454); gate_mean (optional) [T] = mean over (b,i,j) of the gate (egtr.py:496-505);
- * it is accumulated with atomics, zero it first. */
-int egtr_rel_head_forward_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
-                              const float* uk, const float* b1, const float* w2r, const float* b2r,
-                              const float* w3r, const float* b3r, const float* w2c, const float* b2c,
-                              const float* w3c, const float* b3c, const float* triplet_dist,
-                              const int64_t* node_cls, int batch, int num_query, int num_slots, int hidden,
-                              int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
-                              float* gate_mean);
-
-/* Training variant of the forward: additionally stores the post-ReLU hidden activations of layer 1 and layer 2 of both
- * MLPs, h1_save / h2_save [2 (0 = relation, 1 = connectivity)][B*N*N][hidden] (either may be NULL), for the backward. */
+ * it is accumulated with atomics, zero it first.
+ * Training: h1_save / h2_save [2 (0 = relation, 1 = connectivity)][B*N*N][hidden] (each may be NULL) receive the post-ReLU
+ * hidden activations of layer 1 and layer 2 of both MLPs for the backward. */
 int egtr_rel_head_forward_save_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
                                    const float* uk, const float* b1, const float* w2r, const float* b2r,
                                    const float* w3r, const float* b3r, const float* w2c, const float* b2c,
@@ -433,20 +415,15 @@ int egtr_linear_split_bf16_wgrad_f32(egtr_stream_t stream, const float* g, int l
 
 /* Up to 8 such products with the same M and K in ONE launch (their tiles share the grid): the value projection and the
  * offsets / attention-weights projection of an encoder layer, the six value projections of the decoder.  All arrays are
- * HOST arrays of num_problems entries (pointers inside are device pointers; bias[i] may be NULL). */
-int egtr_linear_split_bf16_grouped_f32(egtr_stream_t stream, int num_problems, const float* const* x, const int* ldx,
-                                       const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
-                                       const int* ldy, const int* N, const int* relu, int M, int K);
-
-/* egtr_linear_split_bf16_grouped_f32 whose problems may add a [pos_rows[g], K] table to the rows of x_g on the way in (row %
- * pos_rows): `hidden_states + position_embeddings` (model/deformable_detr.py:1041) as the input of the sampling-offset /
+ * HOST arrays of num_problems entries (pointers inside are device pointers; bias[i] may be NULL).
+ * A problem may add a [pos_rows[g], K] table to the rows of x_g on the way in (row % pos_rows): `hidden_states + position_embeddings` (model/deformable_detr.py:1041) as the input of the sampling-offset /
  * attention-weight projection without a materialised sum.  pos == NULL or pos[g] == NULL: none. */
 int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int num_problems, const float* const* x, const int* ldx,
                                            const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
                                            const int* ldy, const int* N, const int* relu, int M, int K,
                                            const float* const* pos, const int* pos_rows);
 
-/* ---- second-generation split-bf16 GEMM (csrc/gemm_x6.hip): BOTH operands pre-split into the "XS" format -------------
+/* ---- the "XS" operand format of the row-panel kernels (csrc/xs_format.h, csrc/xs_split.hip) --------------------------
  * XS(X) of a logical fp32 matrix X[rows][K] (K % 16 == 0): the exact three-way bf16 split x = hi + mid + lo, stored as
  * 1 KiB fragments of 32 rows x 16 k of ONE piece; fragment (rb = row / 32, ks = k / 16, piece p) at byte
  * ((rb * (K / 16) + ks) * 3 + p) * 1024, element (r = row % 32, kk = k % 16) inside it at (kk / 8) * 512 + r * 16 +
@@ -460,15 +437,6 @@ long long egtr_xs_bytes(int rows, int K);
  * mid = lo = 0. */
 int egtr_xs_split_f32(egtr_stream_t stream, const float* x, int ldx, const float* pos, int pos_rows, int rows, int K,
                       void* xs_out, void* xs_pos_out, int round_to_nearest);
-/* Up to 8 products C_i[M, N_i] = act(A_i[M, K] . W_i[N_i, K]^T + bias_i) with the same M and K in ONE launch, fp32-level
- * accuracy (six bf16 cross terms, fp32 accumulation) -- the encoder's nn.Linear layers in inference
- * (model/deformable_detr.py:1049-1058, 1102, 1337-1343).  a_xs[i] = XS(A_i), w_xs[i] = XS(W_i) (rows = output features);
- * outputs: c[i] fp32 [M, ldc[i]] and / or c_xs[i] = XS(C_i) (the A operand of a following product with K' = N_i), at least
- * one of them.  All arrays are HOST arrays of num_problems entries.  K % 32 == 0, K >= 64, N_i % 128 == 0, else
- * EGTR_E_UNSUPPORTED. */
-int egtr_gemm_x6_f32(egtr_stream_t stream, int num_problems, const void* const* a_xs, const void* const* w_xs,
-                     const float* const* bias, float* const* c, const int* ldc, void* const* c_xs, const int* N,
-                     const int* relu, int M, int K);
 
 /* The encoder layer's feed-forward block in ONE launch (csrc/ffn_x6.hip; reference: two nn.Linear + ReLU + dropout(eval) +
  * residual + LayerNorm, model/deformable_detr.py:1335-1345): out = fc2(relu(fc1(x))), or with ln_gamma / ln_beta
@@ -511,7 +479,7 @@ int egtr_proj_multi_x6_f32(egtr_stream_t stream, const float* x, int ldx, const 
 /* fp32 forward (fp32 operands in, fp32 out, fp32-level accuracy) with layers 2 and 3 on the bf16 matrix cores from
  * THREE-way bf16 splits of both operands, x = hi + mid + lo, keeping the six leading cross terms (the dropped ones are
  * <= 2^-24 of the product) and accumulating in fp32: on gfx950 the fp32 matrix rate equals the fp32 vector rate, the
- * bf16 matrix rate is 16x that, so this is 2.67x less matrix time than egtr_rel_head_forward_f32 for the same result to
+ * bf16 matrix rate is 16x that, so this is 2.67x less matrix time than egtr_rel_head_forward_save_f32 for the same result to
  * fp32 rounding.  Inference only.  The weights arrive pre-split and in operand order (raw bfloat16 bits):
  *   w2x_*  [8 nt][16 t][3 piece][64 lane][8]:  piece(W2)[32 nt + (lane & 31)][16 t + 8 (lane >> 5) + e]
  *   w3x_rel [8 nt][2 kb][OT][3 piece][64 lane][8], OT = 1 if num_rel <= 32 else 2:

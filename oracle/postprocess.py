@@ -3,10 +3,12 @@ scene-graph post-processing, the inputs of its evaluators.
 
     triplet_candidates  <- evaluate_batch, train_egtr.py:54-106 (multiple-predicate branch) with argsort_desc,
                            lib/pytorch_misc.py:27-34, and rescale_bboxes, util/box_ops.py:87-91
+    pair_candidates     <- evaluate_batch, train_egtr.py:120-139 (single-predicate branch)
+    oi_candidates       <- evaluate_batch, train_egtr.py:154-174 (Open Images branch: every pair)
     bbox_overlaps       <- lib/fpn/box_intersections_cpu/bbox.pyx:21-61 (Cython in the reference; loops restated)
 
 PINNED: tests/test_oracle_golden.py::test_postprocessing_oracle_vs_reference_evaluate_batch checks both functions
-against tests/golden/postprocess.npz, i.e. against the outputs of the reference's own evaluate_batch (imported from
+against tests/golden/postprocess.npz (and postprocess_branches.npz for the single-predicate / Open Images branches), i.e. against the outputs of the reference's own evaluate_batch (imported from
 /root/reference and run by tests/golden/make_golden_post.py) and of its Cython routines compiled from the reference
 sources (oracle/Makefile -> oracle/_ref/).
 """
@@ -35,6 +37,44 @@ def triplet_candidates(logits, pred_boxes, pred_rel, pred_connectivity, num_labe
     boxes = (xyxy * torch.tensor([w, h, w, h], dtype=torch.float32)).numpy()
     return {"pred_boxes": boxes, "pred_classes": pred_classes.numpy(), "obj_scores": obj_scores.numpy(),
             "pred_rel_inds": inds, "rel_scores": rel_scores, "triplet_scores": scores[inds[:, 0], inds[:, 1], inds[:, 2]]}
+
+
+def _common(logits, pred_boxes, pred_rel, pred_connectivity, num_labels, orig_size):
+    obj_scores, pred_classes = torch.max(logits.softmax(-1)[:, :num_labels], -1)      # train_egtr.py:57-59
+    sub_ob = torch.outer(obj_scores, obj_scores)
+    n = logits.size(0)
+    sub_ob[torch.arange(n), torch.arange(n)] = 0.0                                     # :61-63
+    rel = torch.clamp(pred_rel, 0.0, 1.0)                                              # :66
+    if pred_connectivity is not None:
+        rel = rel * torch.clamp(pred_connectivity, 0.0, 1.0)                           # :67-69
+    h, w = float(orig_size[0]), float(orig_size[1])
+    cx, cy, bw, bh = pred_boxes.unbind(-1)                                             # box_ops.py:87-91
+    xyxy = torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh], -1)
+    boxes = (xyxy * torch.tensor([w, h, w, h], dtype=torch.float32)).numpy()
+    return obj_scores, pred_classes, sub_ob, rel, boxes
+
+
+def pair_candidates(logits, pred_boxes, pred_rel, pred_connectivity, num_labels, orig_size, max_topk=100):
+    """train_egtr.py:120-139 (single-predicate evaluator): the best (subject, object) pairs by
+    max_p(pred_rel) * score_s * score_o; rel_scores = the pair's whole predicate row [k, R]."""
+    obj_scores, pred_classes, sub_ob, rel, boxes = _common(logits, pred_boxes, pred_rel, pred_connectivity, num_labels,
+                                                           orig_size)
+    scores = (rel.max(-1)[0] * sub_ob).numpy()                                         # :121
+    order = np.argsort(-scores.ravel())                                                # pytorch_misc.py:34
+    inds = np.column_stack(np.unravel_index(order, scores.shape))[:max_topk]           # :122-124
+    rel_scores = rel.numpy()[inds[:, 0], inds[:, 1]]                                   # :125-127
+    return {"pred_boxes": boxes, "pred_classes": pred_classes.numpy(), "obj_scores": obj_scores.numpy(),
+            "pred_rel_inds": inds, "rel_scores": rel_scores, "triplet_scores": scores[inds[:, 0], inds[:, 1]]}
+
+
+def oi_candidates(logits, pred_boxes, pred_rel, pred_connectivity, num_labels, orig_size):
+    """train_egtr.py:154-174 (Open Images evaluator): every (subject, object) pair with its predicate row."""
+    obj_scores, pred_classes, _, rel, boxes = _common(logits, pred_boxes, pred_rel, pred_connectivity, num_labels,
+                                                      orig_size)
+    n = logits.size(0)
+    pairs = torch.cartesian_prod(torch.arange(n), torch.arange(n)).numpy()            # :155-157
+    return {"pred_boxes": boxes, "pred_classes": pred_classes.numpy(), "obj_scores": obj_scores.numpy(),
+            "sbj_obj_inds": pairs, "pred_scores": rel.numpy().reshape(-1, rel.size(-1))}   # :158-160
 
 
 def bbox_overlaps(boxes, query_boxes):

@@ -50,20 +50,36 @@ def main(out_path):
         opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-3)
         tr = DataParallelTrainer(model, optimizer=opt, accumulate=2, clip=0.1, force_ddp=force)
         assert (tr.model is not tr.raw) == force
-        losses, grads = [], None
+        calls = {"n": 0, "bytes": 0}
+        if force:
+            # count the reducer's bucket all-reduces: the default hook behind a counter
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+            def counting_hook(state, bucket):
+                calls["n"] += 1
+                calls["bytes"] += bucket.buffer().numel() * bucket.buffer().element_size()
+                return default_hooks.allreduce_hook(state, bucket)
+
+            tr.model.register_comm_hook(None, counting_hook)
+        losses, grads, per_micro = [], None, []
         for i, b in enumerate(batches + batches[:1]):       # 4 micro-steps = 2 optimizer steps (accumulate 2, no_sync)
+            before = calls["n"]
             loss, _, stepped = tr.training_step(b)
+            per_micro.append((calls["n"] - before, bool(stepped)))
             losses.append(float(loss))
             if i == 0:
                 grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         torch.cuda.synchronize()
         res[name] = (losses, grads, {n: p.detach().clone() for n, p in model.named_parameters()})
+        if force:
+            grad_bytes = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
+            comm = {"allreduces_per_micro_step": per_micro, "allreduce_bytes_total": calls["bytes"], "grad_bytes": grad_bytes}
     (l_a, g_a, p_a), (l_b, g_b, p_b) = res["ddp"], res["plain"]
     gmax = max(float((g_a[n] - g_b[n]).abs().max()) for n in g_b)
     pmax = max(float((p_a[n] - p_b[n]).abs().max()) for n in p_b)
     gscale = max(float(g_b[n].abs().max()) for n in g_b)
     json.dump({"ranks": int(t.item()), "loss_ddp": l_a, "loss_plain": l_b, "grad_max_diff": gmax, "grad_scale": gscale, "param_max_diff": pmax,
-               "n_grads": len(g_b), "grads_missing_under_ddp": sorted(set(g_b) - set(g_a))}, open(out_path, "w"))
+               "n_grads": len(g_b), "grads_missing_under_ddp": sorted(set(g_b) - set(g_a)), "comm": comm}, open(out_path, "w"))
     dist.destroy_process_group()
 
 

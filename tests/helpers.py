@@ -85,18 +85,18 @@ def padded_inputs(g, B, dtype=torch.float32):
     return pv.to(dtype), pm
 
 
-def check_pred_entry(got, g, j, atol=1e-6):
+def check_pred_entry(got, g, j, atol=1e-6, prefix="pred"):
     """``got``: one image's entry (numpy arrays) with the reference's pred_entry keys (+ optional triplet_scores);
     ``g``: tests/golden/postprocess.npz (outputs of the reference's own evaluate_batch, train_egtr.py:43-106).
     Rows are index-exact wherever the triplet score is unique; inside a group of exactly tied scores any order is a
     valid argsort (numpy's quicksort order is not a specification), so tie groups are compared as sets -- except the
     LAST group, which the top-k cut may truncate differently: there only membership in the full tie class counts."""
-    want_inds, want_rel = g[f"pred{j}_pred_rel_inds"], g[f"pred{j}_rel_scores"]
+    want_inds, want_rel = g[f"{prefix}{j}_pred_rel_inds"], g[f"{prefix}{j}_rel_scores"]
     gi = np.asarray(got["pred_rel_inds"])
     assert gi.shape == want_inds.shape
-    assert np.array_equal(np.asarray(got["pred_classes"]), g[f"pred{j}_pred_classes"])
-    assert np.abs(np.asarray(got["obj_scores"]) - g[f"pred{j}_obj_scores"]).max() < atol
-    assert np.abs(np.asarray(got["pred_boxes"]) - g[f"pred{j}_pred_boxes"]).max() < 1e-3
+    assert np.array_equal(np.asarray(got["pred_classes"]), g[f"{prefix}{j}_pred_classes"])
+    assert np.abs(np.asarray(got["obj_scores"]) - g[f"{prefix}{j}_obj_scores"]).max() < atol
+    assert np.abs(np.asarray(got["pred_boxes"]) - g[f"{prefix}{j}_pred_boxes"]).max() < 1e-3
     ts = np.asarray(got["triplet_scores"], dtype=np.float64)
     assert np.all(ts[:-1] >= ts[1:]), "triplets must come in descending score order"
     # group rows by (exactly) equal triplet score
@@ -106,11 +106,24 @@ def check_pred_entry(got, g, j, atol=1e-6):
         last = b == len(ts)
         if b - a == 1 and not last:
             assert tuple(gi[a]) == tuple(want_inds[a]), (a, gi[a], want_inds[a])
-            assert abs(float(got["rel_scores"][a]) - float(want_rel[a])) < atol
+            assert np.abs(np.asarray(got["rel_scores"][a], dtype=np.float64) - want_rel[a]).max() < atol
             n_exact += 1
         elif not last:
             assert set(map(tuple, gi[a:b])) == set(map(tuple, want_inds[a:b])), (a, b)
     return n_exact
+
+
+def check_oi_entry(got, g, j, atol=1e-6):
+    """One image's Open Images entry (numpy arrays, train_egtr.py:154-174) against postprocess_branches.npz."""
+    ps, inds = np.asarray(got["pred_scores"]), np.asarray(got["sbj_obj_inds"])
+    assert tuple(ps.shape) == tuple(g[f"oi{j}_pred_scores_shape"]) and inds.shape == (ps.shape[0], 2)
+    assert np.abs(ps[::97] - g[f"oi{j}_pred_scores_strided"]).max() < atol
+    assert abs(ps.astype(np.float64).sum() - float(g[f"oi{j}_pred_scores_sum"])) < 1e-6 * abs(float(g[f"oi{j}_pred_scores_sum"]))
+    assert np.array_equal(inds[::97], g[f"oi{j}_sbj_obj_inds_strided"])
+    assert int((inds.astype(np.int64) * np.array([1000003, 7])).sum()) == int(g[f"oi{j}_sbj_obj_inds_checksum"])
+    assert np.array_equal(np.asarray(got["pred_classes"]), g[f"oi{j}_pred_classes"])
+    assert np.abs(np.asarray(got["obj_scores"]) - g[f"oi{j}_obj_scores"]).max() < atol
+    assert np.abs(np.asarray(got["pred_boxes"]) - g[f"oi{j}_pred_boxes"]).max() < 1e-3
 
 
 def build_product_detector(cfg_dict, shapes, seed, device="cpu"):

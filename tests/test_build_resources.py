@@ -37,7 +37,6 @@ def _resources(src, tmp_path):
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not installed")
 @pytest.mark.parametrize("src,kernels,no_sgpr_spill", [
     ("ffn_x6.hip", ("ffn_x6_kernel", "proj_x6_kernel"), ("ffn_x6_kernel",)),
-    ("gemm_x6.hip", ("gemm_x6_kernel",), ()),
 ])
 def test_pipeline_kernels_have_no_scratch_and_safe_scalar_loads(src, kernels, no_sgpr_spill, tmp_path):
     res = _resources(src, tmp_path)

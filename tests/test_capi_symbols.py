@@ -37,7 +37,7 @@ def test_variant_selectors_are_not_part_of_the_public_boundary():
 def test_header_declares_the_expected_entry_points():
     names = _declared()
     for n in ("egtr_msda_forward_f32", "egtr_msda_backward_f32", "egtr_msda_forward_bf16",
-              "egtr_self_attn_forward_f32", "egtr_self_attn_backward_f32", "egtr_rel_head_forward_f32",
+              "egtr_self_attn_forward_f32", "egtr_self_attn_backward_f32", "egtr_rel_head_forward_save_f32",
               "egtr_abi_version", "egtr_status_string", "egtr_last_hip_error"):
         assert n in names
 
@@ -53,9 +53,15 @@ def test_library_exports_every_declared_symbol(lib_path):
 
 
 def test_ctypes_binding_covers_the_header(lib_path):
+    """The product binding (egtr_amd/_lib.py) is exactly the public boundary; the test-only selectors of egtr_hip_test.h
+    are bound by tests/hip_test_abi.py alone."""
     from egtr_amd import _lib
-    assert sorted(_lib.SIGNATURES) == _declared()
+    import hip_test_abi
+    assert sorted(_lib.SIGNATURES) == _declared(("egtr_hip.h",))
+    assert sorted(hip_test_abi.SIGNATURES) == _declared(("egtr_hip_test.h",))
+    assert not set(_lib.SIGNATURES) & set(hip_test_abi.SIGNATURES)
     _lib.lib()  # resolves every symbol with its argtypes
+    hip_test_abi._handle()
 
 
 def test_null_arguments_are_rejected_without_a_gpu(lib_path):

@@ -37,3 +37,12 @@ def test_ddp_wrapped_step_equals_plain_step_on_one_gpu(tmp_path):
     # differ by the order of the float atomics of the decoder-shaped MSDA backward (run to run as well)
     assert d["loss_ddp"] == pytest.approx(d["loss_plain"], rel=1e-6)
     assert d["grad_max_diff"] < 1e-5 * d["grad_scale"] and d["param_max_diff"] < 1e-6, d
+    # accumulate = 2: the micro-step before the boundary runs under no_sync (NO collective), the boundary step all-reduces
+    # every gradient exactly once, in ceil(gradient bytes / 25 MB bucket cap)-ish buckets (one bucketed pass per optimizer step)
+    micro = d["comm"]["allreduces_per_micro_step"]
+    assert [stepped for _, stepped in micro] == [False, True, False, True]
+    assert micro[0][0] == 0 and micro[2][0] == 0, micro
+    gb = d["comm"]["grad_bytes"]
+    for n_buckets in (micro[1][0], micro[3][0]):     # (DDP re-cuts its buckets after the first backward: 1, then ~bytes / 25 MB)
+        assert 1 <= n_buckets <= gb // (25 * 2 ** 20) + 3, (micro, gb)     # bucketed, not one collective per parameter
+    assert 2 * gb <= d["comm"]["allreduce_bytes_total"] <= 2.02 * gb       # each gradient crossed the wire once per step

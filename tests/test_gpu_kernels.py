@@ -12,6 +12,7 @@ import pytest
 import torch
 
 import helpers as Hh
+import hip_test_abi as TA
 import weights as W
 from oracle import detr as O
 from oracle import msda as OM
@@ -111,14 +112,14 @@ def test_msda_wave_kernel_equals_generic_kernel_on_encoder_shapes(shapes, B, jit
     k = _kernels()
     x = _grid_inputs(9, B, shapes, jitter)
     d = {n: t.to(DEV) for n, t in x.items()}
-    o1 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
-    o3 = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 3).cpu()
+    o1 = TA.msda_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
+    o3 = TA.msda_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 3).cpu()
     ref = OM.msda_forward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"])
     assert (o1 - ref).abs().max() < 2e-5 and (o3 - ref).abs().max() < 2e-5
-    o1b = k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
+    o1b = TA.msda_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 1).cpu()
     assert torch.equal(o1, o1b)
     with pytest.raises(Exception):
-        k.ms_deform_attn_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 13)
+        TA.msda_forward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"], 13)
 
 
 @pytest.mark.parametrize("shapes,B,jitter", [
@@ -134,8 +135,8 @@ def test_msda_backward_tile_variant(shapes, B, jitter):
     d = {n: t.to(DEV) for n, t in x.items()}
     rgv, rgl, rga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"])
     for variant in (2, 1):
-        gv, gl, ga = k.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"],
-                                               d["grad_out"], 64, variant)
+        gv, gl, ga = TA.msda_backward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"],
+                                              d["grad_out"], variant)
         assert (gv.cpu() - rgv).abs().max() < 3e-4 * max(1.0, float(rgv.abs().max())), variant
         assert (ga.cpu() - rga).abs().max() < 2e-4, variant
         assert (gl.cpu() - rgl).abs().max() < 5e-3 * max(1.0, float(rgl.abs().max()) / 50), variant
@@ -147,16 +148,16 @@ def test_msda_backward_tile_variant_arbitrary_queries():
     for Lq in (1100, 65):
         x = W.make_msda_inputs(41 + Lq, 2, Lq, 8, 32, shapes, 4, oob_frac=0.2)
         d = {n: t.to(DEV) for n, t in x.items()}
-        gv, gl, ga = k.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"],
-                                               d["grad_out"], 64, 2)
+        gv, gl, ga = TA.msda_backward_variant(d["value"], d["shapes"], d["lsi"], d["loc"], d["attn"],
+                                              d["grad_out"], 2)
         rgv, rgl, rga = OM.msda_backward(x["value"], x["shapes"], x["lsi"], x["loc"], x["attn"], x["grad_out"])
         assert (gv.cpu() - rgv).abs().max() < 3e-4 * max(1.0, float(rgv.abs().max()))
         assert (ga.cpu() - rga).abs().max() < 2e-4
         assert (gl.cpu() - rgl).abs().max() < 5e-3 * max(1.0, float(rgl.abs().max()) / 50)
     x = _grid_inputs(6, 1, shapes, 0.3)
     d = {n: t.to(DEV) for n, t in x.items()}
-    gv, gl, ga = k.ms_deform_attn_backward(d["value"], d["shapes"], d["lsi"], torch.full_like(d["loc"], 3.0),
-                                           d["attn"], d["grad_out"], 64, 2)
+    gv, gl, ga = TA.msda_backward_variant(d["value"], d["shapes"], d["lsi"], torch.full_like(d["loc"], 3.0),
+                                          d["attn"], d["grad_out"], 2)
     assert gv.abs().max().item() == 0 and gl.abs().max().item() == 0 and ga.abs().max().item() == 0
 
 
@@ -613,7 +614,7 @@ def test_bias_relu_maxpool_is_bitwise_maxpool_of_relu(N, C, H, W_):
 
 @pytest.mark.parametrize("RD", [2, 4])
 def test_box_decode_matches_reference_composition(RD):
-    """egtr_box_decode_f32 against sigmoid(delta + inverse_sigmoid(reference)) level by level (egtr:286-305), with
+    """egtr_box_decode_argmax_f32 against sigmoid(delta + inverse_sigmoid(reference)) level by level (egtr:286-305), with
     reference values at and beyond the clamp points 0, 1, eps."""
     from egtr_amd import ops
     from egtr_amd.deformable_detr import inverse_sigmoid

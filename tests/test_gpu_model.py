@@ -636,6 +636,15 @@ def test_postprocessing_on_device_vs_reference_fixture(golden_dir):
     # the evaluator's use: predicted boxes (rescaled by the device routine) vs ground truth
     iou = bbox_overlaps(got[0]["pred_boxes"], torch.from_numpy(g["gt0_gt_boxes"]).to(DEV)).cpu().numpy()
     assert np.abs(iou - g["iou_pred0_vs_gt0"]).max() < 1e-6
+    # the single-predicate and Open Images branches (train_egtr.py:120-139, 154-174) on the device
+    gb = Hh.load_golden(golden_dir, "postprocess_branches.npz")
+    dev_out = {k: v.to(DEV) for k, v in outputs.items()}
+    single = triplet_candidates(dev_out, meta["num_labels"], sizes, max_topk=100, mode="single")
+    oi = triplet_candidates(dev_out, meta["num_labels"], sizes, mode="oi")
+    exact = [Hh.check_pred_entry({k: v.cpu().numpy() for k, v in single[j].items()}, gb, j, prefix="single") for j in range(2)]
+    assert exact[0] >= 99 and single[0]["rel_scores"].is_cuda
+    for j in range(2):
+        Hh.check_oi_entry({k: v.cpu().numpy() for k, v in oi[j].items()}, gb, j)
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 """GPU (-m gpu): what the headline number rests on, pinned DIRECTLY against the oracle ("Next round" item 1).
 
-  * the three fused MSDA entries the timed forward calls (egtr_msda_forward_fused_f32 / _vbias_f32 / _box_f32) against
+  * the three fused MSDA entries the timed forward calls (egtr_msda_forward_fused_vbias_f32 with and without the bias / _box_f32) against
     oracle.msda.msda_forward fed with the HOST-composed softmax / sampling locations / masked (+ biased) values
     (reference: model/deformable_detr.py:1048-1081), at the small pyramid and at S = Lq = 12 537 (sampled rows);
   * the relation / connectivity loss kernel against oracle.loss (egtr:754-923 restated, pinned to the reference fixtures);
@@ -272,8 +272,7 @@ def _adversarial_rows(kind, M, K, N, rng):
 
 @pytest.mark.parametrize("kind", ["wide-range", "cancelling", "large", "denormal"])
 def test_split_bf16_linears_on_adversarial_operands(kind):
-    """egtr_linear_split_bf16_f32 (round-2 kernel), egtr_gemm_x6_f32 (pre-split operands) and the training weight-gradient
-    kernel against float64: row by row no further off than 2.5x the vendor fp32 GEMM (+ one ulp-sized floor relative to
+    """egtr_linear_split_bf16_f32 and the training weight-gradient kernel against float64: row by row no further off than 2.5x the vendor fp32 GEMM (+ one ulp-sized floor relative to
     the row's sum |w| |x|), for operands far from N(0, 1).  Denormal inputs: the matrix pipe may flush denormal pieces;
     the bound is then ABSOLUTE, 2^-126 * K (nothing above the smallest normal is lost)."""
     from egtr_amd import ops
@@ -285,9 +284,8 @@ def test_split_bf16_linears_on_adversarial_operands(kind):
     xd, wd = x.to(DEV), w.to(DEV)
     y32 = torch.nn.functional.linear(xd, wd)
     y_old = ops.linear_split_bf16(xd, ops.gemm_split_weights(wd), None, N)
-    y_x6 = ops.gemm_x6([dict(a=ops.xs_split(xd), w=ops.xs_split(wd, weights=True), N=N)], M, K)[0]
     e32 = (y32.double().cpu() - ref).abs()
-    for name, y in (("gemm_split", y_old), ("gemm_x6", y_x6)):
+    for name, y in (("gemm_split", y_old),):
         e = (y.double().cpu() - ref).abs()
         assert torch.isfinite(y).all(), name
         if kind == "denormal":
@@ -325,11 +323,10 @@ def test_split_bf16_linears_propagate_non_finite_rows_only():
     for r, v in bad_rows.items():
         xb[r, (7 * r) % K] = v
     xd, xbd, wd = x.to(DEV), xb.to(DEV), w.to(DEV)
-    wt, wx = ops.gemm_split_weights(wd), ops.xs_split(wd, weights=True)
+    wt = ops.gemm_split_weights(wd)
     good = torch.ones(M, dtype=torch.bool)
     good[list(bad_rows)] = False
-    for name, fn in (("gemm_split", lambda t: ops.linear_split_bf16(t, wt, None, N)),
-                     ("gemm_x6", lambda t: ops.gemm_x6([dict(a=ops.xs_split(t), w=wx, N=N)], M, K)[0])):
+    for name, fn in (("gemm_split", lambda t: ops.linear_split_bf16(t, wt, None, N)),):
         clean, dirty = fn(xd).cpu(), fn(xbd).cpu()
         assert torch.equal(clean[good], dirty[good]), name
         assert not torch.isfinite(dirty[~good]).any(), name      # the whole poisoned row is non-finite

@@ -81,6 +81,67 @@ def test_trainer_raises_the_matchers_error_one_step_late():
         tr.training_step({})
 
 
+def _tiny_train_setup():
+    import helpers as Hh
+    from egtr_amd.egtr import DetrForSceneGraphGeneration
+    cfg = Hh.product_config(dict(num_queries=20, encoder_layers=1, decoder_layers=2, dropout=0.0, auxiliary_loss=True,
+                                 num_labels=12, num_rel_labels=7, ce_loss_coefficient=2.0, rel_loss_coefficient=15.0,
+                                 connectivity_loss_coefficient=30.0, smoothing=1e-14, rel_sample_negatives=80,
+                                 rel_sample_nonmatching=80, rel_sample_negatives_largest=True,
+                                 rel_sample_nonmatching_largest=True, use_freq_bias=True, use_log_softmax=False,
+                                 freq_bias_eps=1e-12, logit_adjustment=False, logit_adj_tau=0.3))
+    torch.manual_seed(0)
+    model = DetrForSceneGraphGeneration(cfg, fg_matrix=W.fg_matrix(12, 7)).to(DEV).train()
+    batch = {"pixel_values": torch.randn(2, 3, 128, 160, device=DEV),
+             "pixel_mask": torch.ones(2, 128, 160, dtype=torch.long, device=DEV),
+             "labels": [{k: t.to(DEV) for k, t in d.items()} for d in W.make_targets(1, 2, 20, 12, 7)]}
+    return model, batch
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_refused_step_leaves_weights_and_optimizer_state_intact(fused):
+    """a cost matrix the device matcher refuses makes loss and gradients NaN; the optimizer step of
+    that window must not run.  With the fused AdamW the step is skipped ON THE DEVICE (found_inf operand) and the
+    ValueError surfaces at the next step / finalize(); with any other optimizer the trainer waits for the status and
+    raises before the step.  Either way parameters, AdamW moments and step counters are those of the last good step."""
+    from egtr_amd.deformable_detr import DeformableDetrHungarianMatcher as Matcher
+    from egtr_amd.runtime import DataParallelTrainer, configure_optimizers
+    Matcher.raise_if_invalid()
+    Matcher.take_step_statuses()
+    model, batch = _tiny_train_setup()
+    opt = configure_optimizers(model, lr=1e-3, lr_backbone=1e-4, lr_initialized=None) if fused else \
+        torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3)
+    tr = DataParallelTrainer(model, optimizer=opt, accumulate=1, clip=0.1)
+    loss, _, stepped = tr.training_step(batch)                    # a good step: weights move
+    assert stepped and torch.isfinite(loss).item()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    state = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in opt.state.items()}
+    bad = dict(batch)
+    bad["labels"] = [dict(t) for t in batch["labels"]]
+    bad["labels"][1]["boxes"] = batch["labels"][1]["boxes"].clone()
+    bad["labels"][1]["boxes"][0, 0] = float("nan")                 # -> NaN cost entries for image 1
+    if fused:
+        loss, _, stepped = tr.training_step(bad)                  # no host sync inside: nothing raised yet
+        assert stepped and torch.isnan(loss).item()
+        with pytest.raises(ValueError, match="invalid numeric entries"):
+            tr.finalize()
+    else:
+        with pytest.raises(ValueError, match="invalid numeric entries"):
+            tr.training_step(bad)
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+    for p, st in opt.state.items():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                assert torch.equal(v, state[id(p)][k]), k
+    assert all(p.grad is None for p in model.parameters())
+    loss, _, _ = tr.training_step(batch)                           # and the trainer goes on with the next good batch
+    tr.finalize()
+    assert torch.isfinite(loss).item()
+    assert any(not torch.equal(p.detach(), before[n]) for n, p in model.named_parameters())
+
+
 def test_clamp_nonfinite_backward_leaves_the_incoming_gradient_alone():
     from egtr_amd import ops
     x = torch.randn(64, 256, device=DEV)

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import helpers as Hh
+import weights as W
 
 
 def _t(a):
@@ -189,6 +190,24 @@ def test_output_object_and_config_roundtrip(tmp_path, small):
     assert cfg2.num_queries == cfg.num_queries and cfg2.num_rel_labels == cfg.num_rel_labels
     assert cfg2.num_labels == cfg.num_labels and cfg2.smoothing == cfg.smoothing
     assert cfg2.use_return_dict and cfg2.hidden_size == 256 and cfg2.num_attention_heads == 8
+
+
+def test_triplet_candidates_single_predicate_and_oi_modes_vs_reference_fixture(golden_dir):
+    """egtr_amd.runtime.triplet_candidates(mode="single" / "oi") -- the other two branches of the reference's evaluate_batch
+    (train_egtr.py:120-139, 154-174) -- against the reference's own outputs (postprocess_branches.npz), host tensors."""
+    import helpers as Hh
+    from egtr_amd.runtime import triplet_candidates
+    g = Hh.load_golden(golden_dir, "postprocess_branches.npz")
+    outputs, targets, meta = W.post_inputs(int(g["seed"]))
+    sizes = torch.stack([t["orig_size"] for t in targets])
+    single = triplet_candidates(outputs, meta["num_labels"], sizes, max_topk=100, mode="single")
+    oi = triplet_candidates(outputs, meta["num_labels"], sizes, mode="oi")
+    exact = [Hh.check_pred_entry({k: v.numpy() for k, v in single[j].items()}, g, j, prefix="single") for j in range(2)]
+    assert exact[0] >= 99 and tuple(single[0]["rel_scores"].shape) == (100, outputs["pred_rel"].shape[-1])
+    for j in range(2):
+        Hh.check_oi_entry({k: v.numpy() for k, v in oi[j].items()}, g, j)
+    with pytest.raises(ValueError):
+        triplet_candidates(outputs, meta["num_labels"], sizes, mode="both")
 
 
 def test_triplet_candidates_match_reference_postprocessing():

@@ -291,6 +291,25 @@ def test_postprocessing_oracle_vs_reference_evaluate_batch(golden_dir):
         assert np.array_equal(OP.bbox_overlaps(a, b), g[f"iou_{name}"]), name      # bit-exact float64
 
 
+def test_postprocessing_oracle_single_predicate_and_oi_branches_vs_reference(golden_dir):
+    """oracle.postprocess.pair_candidates / oi_candidates pinned against the reference's own evaluate_batch run with the
+    single-predicate and Open Images evaluators (tests/golden/make_golden_post_branches.py -> postprocess_branches.npz)."""
+    import helpers as Hh
+    from oracle import postprocess as OP
+    g = _load(golden_dir, "postprocess_branches.npz")
+    outputs, targets, meta = W.post_inputs(int(g["seed"]))
+    for j in range(2):
+        args = (outputs["logits"][j], outputs["pred_boxes"][j], outputs["pred_rel"][j], outputs["pred_connectivity"][j],
+                meta["num_labels"], targets[j]["orig_size"])
+        got = OP.pair_candidates(*args, 100)
+        n_exact = Hh.check_pred_entry(got, g, j, prefix="single")
+        assert got["rel_scores"].shape == (100, outputs["pred_rel"].shape[-1])
+        if j == 0:
+            assert n_exact >= 99 and np.array_equal(got["pred_rel_inds"], g["single0_pred_rel_inds"])
+            assert np.array_equal(got["rel_scores"], g["single0_rel_scores"])
+        Hh.check_oi_entry(OP.oi_candidates(*args), g, j)
+
+
 def test_oracle_ref_bbox_module_when_built(golden_dir):
     """oracle/_ref (the reference's Cython source compiled here) reproduces the committed fixture; skipped where the
     module was not built (a checkout without /root/reference)."""

@@ -1,4 +1,4 @@
-// Micro-benchmark: how fast can a CU pull L2-resident operand fragments into LDS?  (development probe for csrc/gemm_x6.hip)
+// Micro-benchmark: how fast can a CU pull L2-resident operand fragments into LDS?  (development probe for the LDS-DMA rings of csrc/ffn_x6.hip / tools/gemm_x6.hip)
 //   mode 0: global_load_lds_dwordx4 (LDS-DMA), NL instructions per wave in flight, counted vmcnt
 //   mode 1: global_load_dwordx4 into registers + ds_write_b128
 //   mode 2: global_load_dwordx4 into registers only (no LDS write)

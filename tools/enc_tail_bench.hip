@@ -1,7 +1,7 @@
 // Stand-alone development harness of the encoder-tail kernel (csrc/ffn_x6.hip, ffn_x6_kernel<true>): launch time on random
-// inputs and, in a -DFFN_TIMING build, the cycle stamps of its phases (correctness: tests/test_gpu_pinning.py).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DFFN_TIMING] tools/enc_tail_bench.hip egtr_amd/csrc/ffn_x6.hip \
-//         egtr_amd/csrc/gemm_x6.hip egtr_amd/csrc/capi.hip -o build/enc_tail_bench && build/enc_tail_bench [M F iters with_pos]
+// inputs (correctness: tests/test_gpu_pinning.py; the cycle-stamp instrumentation of round 3 is in the history, 7146666).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/enc_tail_bench.hip egtr_amd/csrc/ffn_x6.hip \
+//         egtr_amd/csrc/xs_split.hip egtr_amd/csrc/capi.hip -o build/enc_tail_bench && build/enc_tail_bench [M F iters with_pos]
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -20,7 +20,6 @@
     }                                                                           \
   } while (0)
 
-extern long long* g_ffn_tdbg;
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 12537, F = argc > 2 ? atoi(argv[2]) : 1024, iters = argc > 3 ? atoi(argv[3]) : 100;
@@ -71,20 +70,5 @@ int main(int argc, char** argv) {
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("M=%d F=%d: %.2f us per launch\n", M, F, ms * 1e3 / iters);
-  long long* td;
-  CK(hipMalloc(&td, 64 * 8));
-  CK(hipMemset(td, 0, 64 * 8));
-  g_ffn_tdbg = td;
-  run();
-  CK(hipDeviceSynchronize());
-  long long h[64];
-  CK(hipMemcpy(h, td, sizeof(h), hipMemcpyDeviceToHost));
-  if (h[48]) {
-    for (int b = 0; b < 2; ++b) {
-      const long long* t = &h[48 + 8 * b];
-      printf("  workgroup %3d: context panel %6lld | projection stages %6lld | LayerNorm1 %6lld | panel rebuild %6lld | FFN loop %7lld | "
-             "epilogue %6lld cycles\n", b ? 100 : 0, t[1] - t[0], t[4] - t[1], t[5] - t[4], t[6] - t[5], t[2] - t[6], t[3] - t[2]);
-    }
-  }
   return 0;
 }

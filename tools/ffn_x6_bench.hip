@@ -1,6 +1,6 @@
 // Stand-alone development harness of csrc/ffn_x6.hip: y = [LayerNorm(x +] fc2(relu(fc1(x))) [)] against float64 on sampled
 // rows, and the launch time.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ffn_x6_bench.hip egtr_amd/csrc/ffn_x6.hip egtr_amd/csrc/gemm_x6.hip \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ffn_x6_bench.hip egtr_amd/csrc/ffn_x6.hip egtr_amd/csrc/xs_split.hip \
 //         egtr_amd/csrc/capi.hip -o build/ffn_x6_bench && build/ffn_x6_bench [M F layernorm iters]
 #include <hip/hip_runtime.h>
 
@@ -21,7 +21,6 @@
     }                                                                           \
   } while (0)
 
-extern long long* g_ffn_tdbg;
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 12537, F = argc > 2 ? atoi(argv[2]) : 1024;
@@ -103,25 +102,6 @@ int main(int argc, char** argv) {
     }
   }
   printf("M=%d F=%d ln=%d  max|err| = %.3e (max|ref| %.2f)  bad = %lld\n", M, F, ln, max_err, max_ref, bad);
-  if (getenv("FFN_TIMING")) {
-    long long* td;
-    CK(hipMalloc(&td, 64 * 8));
-    CK(hipMemset(td, 0, 64 * 8));
-    g_ffn_tdbg = td;
-    run();
-    CK(hipDeviceSynchronize());
-    long long h[64];
-    CK(hipMemcpy(h, td, sizeof(h), hipMemcpyDeviceToHost));
-    g_ffn_tdbg = nullptr;
-    printf("stage: entry->vmcnt  ->lgkm  ->barrier  ->MFMAs  ->epilogue | next entry\n");
-    for (int s = 0; s < 8; ++s)
-      printf("  s=%d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", s, h[s * 6 + 1] - h[s * 6], h[s * 6 + 2] - h[s * 6 + 1],
-             h[s * 6 + 3] - h[s * 6 + 2], h[s * 6 + 4] - h[s * 6 + 3], h[s * 6 + 5] - h[s * 6 + 4],
-             s < 7 ? h[(s + 1) * 6] - h[s * 6 + 5] : 0);
-    for (int b = 0; b < 2; ++b)
-      printf("  workgroup %d: panel %lld  loop %lld  epilogue %lld cycles\n", b ? 100 : 0, h[48 + 8 * b + 1] - h[48 + 8 * b],
-             h[48 + 8 * b + 2] - h[48 + 8 * b + 1], h[48 + 8 * b + 3] - h[48 + 8 * b + 2]);
-  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));

@@ -1,3 +1,6 @@
+// STUDY CODE (round 3) -- not part of libegtr_hip.so: the stand-alone XS x XS split-bf16 GEMM with an LDS-DMA
+// ring that measured what a better main loop buys the token-sized products (nothing: 0.31 -> 0.31-0.39 of the bf16 peak).
+// Built only by tools/gemm_x6_bench.hip's command line together with egtr_amd/csrc/xs_split.hip and capi.hip.
 // Token-sized fp32 linear layers on the bf16 matrix cores, second generation:  C[M, N] = act(A[M, K] . W[N, K]^T + bias)
 // with fp32-level accuracy from exact three-way bf16 splits of both operands and the six leading cross terms (the
 // arithmetic of gemm_split.hip / rel_head.hip: every bf16 x bf16 product is exact in fp32, fp32 accumulation, the three
@@ -24,9 +27,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "common.h"
-#include "xs_format.h"
-#include "x6_common.h"
+#include "../egtr_amd/csrc/common.h"
+#include "../egtr_amd/csrc/xs_format.h"
+#include "../egtr_amd/csrc/x6_common.h"
 
 #ifndef X6_ABL
 #define X6_ABL 0   // development ablations (tools/gemm_x6_bench.hip): 1 = no steady-state DMA, 2 = no MFMAs, 3 = no barriers
@@ -259,26 +262,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(X6Problems P, int nprob
   else epilogue(std::false_type{}, std::true_type{});
 }
 
-// ---- fp32 row-major -> XS (the stand-alone split pass: layer-0 input of the encoder, weights, tests) -----------------
-// One thread per group of 4 consecutive k of one row; `pos` (optional, [pos_rows, K], row r uses pos[r % pos_rows]): also
-// writes XS(x + pos).
-template <bool RNE>
-__global__ __launch_bounds__(256) void split_tile_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ pos,
-                                                         int pos_rows, int rows, int K, char* __restrict__ out,
-                                                         char* __restrict__ out_pos) {
-  const int k4 = K >> 2;
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)rows * k4) return;
-  const int row = (int)(idx / k4), k = (int)(idx - (long long)row * k4) * 4;
-  const float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + k);
-  const size_t off = xs::group_offset(row, k, K >> 4);
-  if (out != nullptr) xs::store4<RNE>(out, off, v.x, v.y, v.z, v.w);
-  if (out_pos != nullptr) {
-    const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)(row % pos_rows) * K + k);
-    xs::store4<RNE>(out_pos, off, v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
-  }
-}
-
 int launch_x6(hipStream_t st, const X6Problems& P, int nprob, int M, int K, int force_mt) {
   long long tiles128 = 0, tiles64 = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -305,31 +288,6 @@ int launch_x6(hipStream_t st, const X6Problems& P, int nprob, int M, int K, int 
 }
 
 }  // namespace
-
-extern "C" long long egtr_xs_bytes(int rows, int K) {
-  if (rows <= 0 || K <= 0 || K % 16) return 0;
-  return xs::buffer_bytes(rows, K);
-}
-
-extern "C" int egtr_xs_split_f32(egtr_stream_t stream, const float* x, int ldx, const float* pos, int pos_rows, int rows,
-                                 int K, void* xs_out, void* xs_pos_out, int round_to_nearest) {
-  if (!x || rows <= 0 || K <= 0 || ldx < K || (!xs_out && !xs_pos_out)) return EGTR_E_ARG;
-  if (xs_pos_out && (!pos || pos_rows <= 0)) return EGTR_E_ARG;
-  if (K % 16 || (ldx & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (pos && (reinterpret_cast<uintptr_t>(pos) & 15)) ||
-      (reinterpret_cast<uintptr_t>(xs_out) & 15) || (reinterpret_cast<uintptr_t>(xs_pos_out) & 15))
-    return EGTR_E_UNSUPPORTED;
-  const long long n = (long long)rows * (K / 4);
-  if ((n + 255) / 256 >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
-  const dim3 grid((unsigned)((n + 255) / 256));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (round_to_nearest)
-    hipLaunchKernelGGL(split_tile_kernel<true>, grid, dim3(256), 0, st, x, ldx, pos, pos_rows, rows, K,
-                       static_cast<char*>(xs_out), static_cast<char*>(xs_pos_out));
-  else
-    hipLaunchKernelGGL(split_tile_kernel<false>, grid, dim3(256), 0, st, x, ldx, pos, pos_rows, rows, K,
-                       static_cast<char*>(xs_out), static_cast<char*>(xs_pos_out));
-  return egtr_check_launch();
-}
 
 extern "C" int egtr_gemm_x6_f32(egtr_stream_t stream, int num_problems, const void* const* a_xs, const void* const* w_xs,
                                 const float* const* bias, float* const* c, const int* ldc, void* const* c_xs,

@@ -1,6 +1,6 @@
-// Stand-alone development harness of csrc/gemm_x6.hip (no Python, no torch): builds XS operands with the device split
+// Stand-alone development harness of tools/gemm_x6.hip (no Python, no torch): builds XS operands with the device split
 // pass, runs egtr_gemm_x6_f32, checks sampled outputs against a float64 host product and times the launch with HIP events.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_x6_bench.hip egtr_amd/csrc/gemm_x6.hip egtr_amd/csrc/capi.hip \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_x6_bench.hip tools/gemm_x6.hip egtr_amd/csrc/xs_split.hip egtr_amd/csrc/capi.hip \
 //         -o gpurun_out/gemm_x6_bench && gpurun_out/gemm_x6_bench [M K N relu xs_out iters]
 #include <hip/hip_runtime.h>
 

@@ -57,9 +57,13 @@ def main():
     ap.add_argument("--big", action="store_true", help="800x1333 shapes")
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay 20 launches per HIP graph (no CPU launch floor)")
-    ap.add_argument("--variant", type=int, default=0, help="kernel choice of the *_variant entries (include/egtr_hip.h)")
+    ap.add_argument("--variant", type=int, default=0, help="kernel choice of the *_variant entries (include/egtr_hip_test.h)")
     ap.add_argument("--fused", action="store_true", help="fused-prologue entry (offsets | logits block + ref points)")
+    ap.add_argument("--lib", default=None, help="load this build of libegtr_hip.so instead of the in-tree one (A/B of kernel builds)")
     a = ap.parse_args()
+    if a.lib:
+        from egtr_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     from egtr_amd.load_custom import load_hip_kernels
     k = load_hip_kernels()
     dev = "cuda:0"
@@ -67,8 +71,11 @@ def main():
     value, shp, lsi, loc, attn = make_inputs(a.batch, a.lq, a.jitter, dev, shapes,
                                              dtype=torch.bfloat16 if a.bf16 else torch.float32)
     go = torch.randn(a.batch, loc.shape[1], 256, device=dev)
-    fn = (lambda: k.ms_deform_attn_backward(value, shp, lsi, loc, attn, go, 64, a.variant)) if a.bwd else \
-        ((lambda: k.ms_deform_attn_forward_variant(value, shp, lsi, loc, attn, a.variant))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import hip_test_abi as TA     # the *_variant entries are test-only (include/egtr_hip_test.h)
+    fn = ((lambda: TA.msda_backward_variant(value, shp, lsi, loc, attn, go, a.variant)) if a.variant
+          else (lambda: k.ms_deform_attn_backward(value, shp, lsi, loc, attn, go, 64))) if a.bwd else \
+        ((lambda: TA.msda_forward_variant(value, shp, lsi, loc, attn, a.variant))
          if (a.variant and not a.bf16) else (lambda: k.ms_deform_attn_forward(value, shp, lsi, loc, attn, 64)))
     if a.fused:
         B_, Lq_ = loc.shape[:2]
@@ -110,9 +117,12 @@ def main():
     B, S = value.shape[:2]
     Lq = loc.shape[1]
     e = value.element_size()
-    alg = B * (min(S * 256 * e, Lq * 8 * 16 * 4 * 32 * e) + Lq * 256 * 4 + Lq * 128 * 4 + Lq * 256 * e)
+    # SURVEY.md 8(d), the ONE figure bench.py uses too: forward = value (capped by the gathered bytes) + loc + attn + out;
+    # backward = the forward's READS + grad_out + 2 x grad_value (zero-init + accumulate) + grad_loc + grad_attn
+    reads = B * (min(S * 256 * e, Lq * 8 * 16 * 4 * 32 * e) + Lq * 256 * 4 + Lq * 128 * 4)
+    alg = reads + B * Lq * 256 * e
     if a.bwd:
-        alg += B * (Lq * 256 * 4 + 2 * S * 256 * 4 + Lq * 256 * 4 + Lq * 128 * 4)
+        alg = reads + B * (Lq * 256 * 4 + 2 * S * 256 * 4 + Lq * 256 * 4 + Lq * 128 * 4)
     print(f"msda {'bwd' if a.bwd else 'fwd'} variant={a.variant} jitter={a.jitter} lq={a.lq} B={B} S={S} Lq={Lq} {'bf16' if a.bf16 else 'f32'}: "
           f"{us:.2f} us/launch (incl. the zero-fill of grad_value for bwd), algorithmic {alg / 1e6:.2f} MB -> "
           f"{alg / us / 1e3:.1f} GB/s = {alg / us / 1e3 / 8000 * 100:.1f}% of 8 TB/s")
