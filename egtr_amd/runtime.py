@@ -192,13 +192,14 @@ class DataParallelTrainer:
         return out.loss, out.loss_dict
 
     def _refused_flag(self):
-        """float32 [1] on the device: 1 if the device matcher refused a cost matrix (NaN / -inf entries, infeasible) in any
+        """0-dim float32 on the device: 1 if the device matcher refused a cost matrix (NaN / -inf entries, infeasible) in any
         forward since the last optimizer step, on any rank; None when no device matcher ran.  No host synchronisation."""
         from .deformable_detr import DeformableDetrHungarianMatcher
         statuses = DeformableDetrHungarianMatcher.take_step_statuses()
         if not statuses:
             return None
-        flag = torch.cat([s.reshape(-1) for s in statuses]).ne(0).any().to(torch.float32).reshape(1)
+        # 0-dim float32, the shape torch's GradScaler hands to the fused optimizers as `found_inf`
+        flag = torch.cat([s.reshape(-1) for s in statuses]).ne(0).any().to(torch.float32).reshape(())
         if self.world > 1:   # replicas must skip together (4 bytes; the refusing rank raises at its next step)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         return flag
