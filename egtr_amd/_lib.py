@@ -71,6 +71,12 @@ SIGNATURES = {
     "egtr_gemm_split_tile_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "egtr_gemm_split_tile_weights_pair_f32": [_P, _P, _I, _I, _I, _P],
     "egtr_linear_split_bf16_grouped_pos_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
+    "egtr_linear_split_bf16_ex_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "egtr_linear_split_bf16_wgrad_ex_f32": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P],
+    "egtr_dropout_add_layernorm_f32": [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _I, _I, ctypes.c_float, _P],
+    "egtr_dropout_add_layernorm_backward_workspace_floats": [_I],
+    "egtr_dropout_add_layernorm_backward_f32": [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P,
+                                                _P, _I, _I, ctypes.c_float],
     "egtr_pad_batch_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "egtr_ffn_x6_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I, _I],
     "egtr_encoder_tail_x6_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, ctypes.c_float,
@@ -89,6 +95,7 @@ _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctype
              "egtr_column_sum_workspace_floats": ctypes.c_longlong,
              "egtr_add_layernorm_backward_workspace_floats": ctypes.c_longlong,
              "egtr_linear_split_bf16_wgrad_workspace_floats": ctypes.c_longlong,
+             "egtr_dropout_add_layernorm_backward_workspace_floats": ctypes.c_longlong,
              "egtr_xs_bytes": ctypes.c_longlong}
 
 _lib = None

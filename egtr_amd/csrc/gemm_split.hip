@@ -74,6 +74,16 @@ struct GemmProblem {
   int lda, ldc, N, relu;
   const float* pos;   // optional [pos_rows, K] added to the rows of A on their way into LDS (row % pos_rows): the encoder's
   int pos_rows;       // `hidden_states + position_embeddings` (dd:1041) without a materialised sum
+  // epilogue extensions of the training step (egtr_linear_split_bf16_ex_f32), applied in this order; all optional:
+  const unsigned char* row_keep;   // [M] bytes: rows with 0 produce zeros (value rows of padded tokens, dd:1052, and their
+                                   // gradients in the backward)
+  const float* relu_ref;           // [M, ldref]: v = relu_ref > 0 ? v : 0 -- the ReLU backward of the layer whose OUTPUT
+  int ldref;                       // relu_ref is, applied to this data-gradient product
+  const float* add1;               // [M, ldadd] addends (gradient accumulation of the branches that meet at a tensor);
+  const float* add2;               // add1 / add2 may alias C (an element is read and written by the same lane)
+  int ldadd;
+  float* colpart;                  // [ceil(M / 32), N]: column sums of the stored values over each 32-row block (the bias
+                                   // gradient of the consuming layer: summed in a fixed order by a second tiny launch)
 };
 struct GemmProblems {
   GemmProblem p[kMaxProblems];
@@ -222,6 +232,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   // epilogue: D[i = n][j = m]; accumulator r <-> column n = (r & 3) + 8 (r >> 2) + 4 hf of the 32-wide n tile, row m =
   // lane & 31: one float4 (4 consecutive columns) per accumulator quad
   const int row = m0 + wm * 32 + li;
+  const bool in_range = row < M;
+  const bool keep = in_range && (G.row_keep == nullptr || G.row_keep[row] != 0);
+  const float* __restrict__ relu_ref = G.relu_ref;
+  const float* add1 = G.add1;
+  const float* add2 = G.add2;
+  float* __restrict__ colpart = G.colpart;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -232,7 +248,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       float4 v = make_float4(acc[nt][4 * q + 0] + bv.x, acc[nt][4 * q + 1] + bv.y, acc[nt][4 * q + 2] + bv.z,
                              acc[nt][4 * q + 3] + bv.w);
       if (RELU) v = make_float4(egtr_relu(v.x), egtr_relu(v.y), egtr_relu(v.z), egtr_relu(v.w));
-      if (row < M) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+      if (!keep) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (relu_ref != nullptr && in_range) {
+        const float4 t = *reinterpret_cast<const float4*>(relu_ref + (size_t)row * G.ldref + col);
+        v = make_float4(t.x > 0.f ? v.x : 0.f, t.y > 0.f ? v.y : 0.f, t.z > 0.f ? v.z : 0.f, t.w > 0.f ? v.w : 0.f);
+      }
+      if (add1 != nullptr && in_range) {
+        const float4 t = *reinterpret_cast<const float4*>(add1 + (size_t)row * G.ldadd + col);
+        v = make_float4(v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w);
+      }
+      if (add2 != nullptr && in_range) {
+        const float4 t = *reinterpret_cast<const float4*>(add2 + (size_t)row * G.ldadd + col);
+        v = make_float4(v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w);
+      }
+      if (in_range) *reinterpret_cast<float4*>(C + (size_t)row * ldc + col) = v;
+      if (colpart != nullptr) {   // uniform per workgroup: sum over the wave's 32 rows (the 32 lanes that share hf)
+        float4 s = in_range ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          s.x += __shfl_xor(s.x, o);
+          s.y += __shfl_xor(s.y, o);
+          s.z += __shfl_xor(s.z, o);
+          s.w += __shfl_xor(s.w, o);
+        }
+        if (li == 0) *reinterpret_cast<float4*>(colpart + (size_t)((m0 >> 5) + wm) * G.N + col) = s;
+      }
     }
 }
 
@@ -270,9 +310,11 @@ bool problem_ok(const float* x, int ldx, const uint16_t* w, const float* bias, f
 // workgroup writes its 128 x 128 partial to the workspace and wgrad_reduce_f32 sums the chunks in a fixed order.
 // MFMA roles: A operand = x piece (i = k), B operand = g piece (j = n): float4 stores along k of the row-major [N, K]
 // result.
+// `xpos` (optional, [pos_rows, K]): x[m] + xpos[m % pos_rows] is the operand (the layer's input was `hidden + pos`, added on
+// load in the forward too); `row_keep` (optional, [M] bytes): rows of g with 0 count as zero rows (padded tokens).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad_split_bf16_f32(
     const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, float* __restrict__ partial, int M, int N,
-    int K, int rows_per_chunk) {
+    int K, int rows_per_chunk, const float* __restrict__ xpos, int pos_rows, const unsigned char* __restrict__ row_keep) {
   constexpr int BM = 128;
   const int ktiles = K / kBN, tiles = (N / BM) * ktiles;
   const int lb = xcd_tile(blockIdx.x, gridDim.x);
@@ -288,6 +330,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int col = tid & 127, mq = tid >> 7;    // loader: column of the tile, rows 8 mq .. 8 mq + 7 of the stage
   const float* gp = G + n0 + col;
   const float* xp = X + k0 + col;
+  const float* pp = xpos != nullptr ? xpos + k0 + col : nullptr;
 
   float rg[8], rx[8];
   auto issue = [&](int s) {
@@ -296,7 +339,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (int e = 0; e < 8; ++e) {
       const bool ok = m + e < mend;
       const size_t r = (size_t)(ok ? m + e : mbeg);
-      const float a = gp[r * ldg], b = xp[r * ldx];
+      float a = gp[r * ldg], b = xp[r * ldx];
+      if (pp != nullptr) b += pp[(size_t)(r % (size_t)pos_rows) * K];
+      if (row_keep != nullptr && row_keep[r] == 0) a = 0.f;
       rg[e] = ok ? a : 0.f;
       rx[e] = ok ? b : 0.f;
     }
@@ -458,18 +503,22 @@ extern "C" int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, 
   if (M <= 0 || K <= 0 || N <= 0 || ldx < K || ldy < N) return EGTR_E_ARG;
   if (K % kBK != 0 || !problem_ok(x, ldx, w_tiled, bias, y, ldy, K, N)) return EGTR_E_UNSUPPORTED;
   GemmProblems P = {};
-  P.p[0] = GemmProblem{x, w_tiled, bias, y, ldx, ldy, N, relu, nullptr, 1};
+  P.p[0] = GemmProblem{x, w_tiled, bias, y, ldx, ldy, N, relu, nullptr, 1, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr};
   return launch_grouped(static_cast<hipStream_t>(stream), P, 1, M, K);
 }
 
-extern "C" int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int num_problems, const float* const* x,
-                                                      const int* ldx, const uint16_t* const* w_tiled,
-                                                      const float* const* bias, float* const* y, const int* ldy,
-                                                      const int* N, const int* relu, int M, int K,
-                                                      const float* const* pos, const int* pos_rows) {
+extern "C" int egtr_linear_split_bf16_ex_f32(egtr_stream_t stream, int num_problems, const float* const* x, const int* ldx,
+                                             const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
+                                             const int* ldy, const int* N, const int* relu, int M, int K,
+                                             const float* const* pos, const int* pos_rows,
+                                             const unsigned char* const* row_keep, const float* const* relu_ref,
+                                             const int* ldref, const float* const* add1, const float* const* add2,
+                                             const int* ldadd, float* const* colpart) {
   if (!x || !ldx || !w_tiled || !bias || !y || !ldy || !N || !relu) return EGTR_E_ARG;
   if (num_problems <= 0 || num_problems > kMaxProblems || M <= 0 || K <= 0) return EGTR_E_ARG;
-  if (pos != nullptr && pos_rows == nullptr) return EGTR_E_ARG;
+  if ((pos != nullptr && pos_rows == nullptr) || (relu_ref != nullptr && ldref == nullptr) ||
+      ((add1 != nullptr || add2 != nullptr) && ldadd == nullptr))
+    return EGTR_E_ARG;
   if (K % kBK != 0) return EGTR_E_UNSUPPORTED;
   GemmProblems P = {};
   for (int i = 0; i < num_problems; ++i) {
@@ -478,9 +527,28 @@ extern "C" int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int 
     const float* p = pos != nullptr ? pos[i] : nullptr;
     if (p != nullptr && pos_rows[i] <= 0) return EGTR_E_ARG;
     if (p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15)) return EGTR_E_UNSUPPORTED;
-    P.p[i] = GemmProblem{x[i], w_tiled[i], bias[i], y[i], ldx[i], ldy[i], N[i], relu[i], p, p != nullptr ? pos_rows[i] : 1};
+    const float* rr = relu_ref != nullptr ? relu_ref[i] : nullptr;
+    const float* a1 = add1 != nullptr ? add1[i] : nullptr;
+    const float* a2 = add2 != nullptr ? add2[i] : nullptr;
+    float* cp = colpart != nullptr ? colpart[i] : nullptr;
+    if ((rr && (ldref[i] < N[i] || (ldref[i] & 3) || (reinterpret_cast<uintptr_t>(rr) & 15))) ||
+        ((a1 || a2) && (ldadd[i] < N[i] || (ldadd[i] & 3))) || (reinterpret_cast<uintptr_t>(a1) & 15) ||
+        (reinterpret_cast<uintptr_t>(a2) & 15) || (reinterpret_cast<uintptr_t>(cp) & 15))
+      return EGTR_E_UNSUPPORTED;
+    P.p[i] = GemmProblem{x[i], w_tiled[i], bias[i], y[i], ldx[i], ldy[i], N[i], relu[i], p, p != nullptr ? pos_rows[i] : 1,
+                         row_keep != nullptr ? row_keep[i] : nullptr, rr, rr ? ldref[i] : 0, a1, a2,
+                         (a1 || a2) ? ldadd[i] : 0, cp};
   }
   return launch_grouped(static_cast<hipStream_t>(stream), P, num_problems, M, K);
+}
+
+extern "C" int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int num_problems, const float* const* x,
+                                                      const int* ldx, const uint16_t* const* w_tiled,
+                                                      const float* const* bias, float* const* y, const int* ldy,
+                                                      const int* N, const int* relu, int M, int K,
+                                                      const float* const* pos, const int* pos_rows) {
+  return egtr_linear_split_bf16_ex_f32(stream, num_problems, x, ldx, w_tiled, bias, y, ldy, N, relu, M, K, pos, pos_rows,
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int ldw, int transposed, int N, int K,
@@ -506,9 +574,11 @@ extern "C" long long egtr_linear_split_bf16_wgrad_workspace_floats(int M, int N,
   return (long long)wgrad_plan(M, N, K).chunks * N * K;
 }
 
-extern "C" int egtr_linear_split_bf16_wgrad_f32(egtr_stream_t stream, const float* g, int ldg, const float* x, int ldx,
-                                                float* grad_weight, float* workspace, int M, int N, int K) {
+extern "C" int egtr_linear_split_bf16_wgrad_ex_f32(egtr_stream_t stream, const float* g, int ldg, const float* x, int ldx,
+                                                   float* grad_weight, float* workspace, int M, int N, int K,
+                                                   const float* x_pos, int pos_rows, const unsigned char* row_keep) {
   if (!g || !x || !grad_weight || !workspace || M <= 0 || N <= 0 || K <= 0 || ldg < N || ldx < K) return EGTR_E_ARG;
+  if (x_pos != nullptr && pos_rows <= 0) return EGTR_E_ARG;
   if (N % 128 || K % 128 || (reinterpret_cast<uintptr_t>(grad_weight) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return EGTR_E_UNSUPPORTED;
   const WgradPlan pl = wgrad_plan(M, N, K);
@@ -516,11 +586,16 @@ extern "C" int egtr_linear_split_bf16_wgrad_f32(egtr_stream_t stream, const floa
   if (wgs >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(wgrad_split_bf16_f32, dim3((unsigned)wgs), dim3(512), 0, st, g, ldg, x, ldx, workspace, M, N, K,
-                     pl.rows_per_chunk);
+                     pl.rows_per_chunk, x_pos, pos_rows, row_keep);
   int rc = egtr_check_launch();
   if (rc != EGTR_OK) return rc;
   const int n4 = N * K / 4;
   hipLaunchKernelGGL(wgrad_reduce_f32, dim3((n4 + 15) / 16), dim3(256), 0, st, reinterpret_cast<const float4*>(workspace),
                      pl.chunks, n4, reinterpret_cast<float4*>(grad_weight));
   return egtr_check_launch();
+}
+
+extern "C" int egtr_linear_split_bf16_wgrad_f32(egtr_stream_t stream, const float* g, int ldg, const float* x, int ldx,
+                                                float* grad_weight, float* workspace, int M, int N, int K) {
+  return egtr_linear_split_bf16_wgrad_ex_f32(stream, g, ldg, x, ldx, grad_weight, workspace, M, N, K, nullptr, 1, nullptr);
 }

@@ -638,6 +638,13 @@ class DeformableDetrEncoderLayer(nn.Module):
                 spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False):
         """``hidden_with_pos`` / ``return_with_pos`` (inference plumbing): hidden + position embeddings handed in by
         the previous layer / appended to the outputs for the next one (written by the final LayerNorm kernel)."""
+        if ops.encoder_layer_train_supported(self, hidden_states, position_embeddings, reference_points, attention_mask,
+                                             output_attentions):
+            # training: the whole layer as ONE autograd node (ops.EncoderLayerTrainFunction) -- the same kernels as the
+            # composition below, the ATen glue between them folded into their epilogues
+            out = ops.encoder_layer_train(self, hidden_states, attention_mask, position_embeddings, reference_points,
+                                          spatial_shapes, level_start_index)
+            return (out, None) if return_with_pos else (out,)
         residual = hidden_states
         fuse = not self.training and ops.inference_fast_path(hidden_states)
         tail = None

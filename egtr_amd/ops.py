@@ -387,6 +387,266 @@ class TokenLinearFunction(Function):
         return gx, gw, gb if ctx.needs_input_grad[2] else None, None
 
 
+# ---- training form of the encoder layer (round 4): ONE autograd Function per layer -------------------------------------------
+# "0": the per-op composition of rounds 2 / 3 (TokenLinearFunction + F.dropout + AddLayerNormFunction + clamp_nonfinite_ ...)
+ENCODER_TRAIN_FUSED = os.environ.get("EGTR_ENCODER_TRAIN_FUSED", "1") != "0"
+
+
+def _host_array(ctype, vals):
+    import ctypes
+    return (ctype * len(vals))(*vals)
+
+
+def linear_split_ex(problems, M, K):
+    """Up to 8 token-sized linears with the same M and K in one launch of the split-bf16 GEMM with the training step's epilogue
+    options (egtr_linear_split_bf16_ex_f32).  ``problems``: dicts with x [M, >=K] (unit inner stride), wt (tiled weight), N,
+    and optionally b, relu, out ([M, N] view with unit inner stride), pos ([pos_rows, K]), row_keep ([M] uint8), relu_ref
+    ([M, N]), add1 / add2 ([M, N], may alias out), colpart ([ceil(M / 32), N]).  Returns the outputs.  No autograd."""
+    import ctypes
+    lib = _lib.lib()
+    n = len(problems)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    outs = []
+    for it in problems:
+        y = it.get("out")
+        if y is None:
+            y = torch.empty(M, int(it["N"]), dtype=torch.float32, device=it["x"].device)
+        outs.append(y)
+
+    def ptrs(key):
+        vals = [(it.get(key).data_ptr() if it.get(key) is not None else None) for it in problems]
+        return _host_array(P, vals) if any(v is not None for v in vals) else None
+
+    def ld(key):
+        return _host_array(I, [(it[key].stride(0) if it.get(key) is not None else 0) for it in problems])
+
+    for it in problems:
+        for key in ("x", "relu_ref", "add1", "add2"):
+            t = it.get(key)
+            if t is not None and (t.stride(-1) != 1 or t.dtype != torch.float32 or not t.is_cuda):
+                raise RuntimeError(f"linear_split_ex: {key} must be a float32 device tensor with unit inner stride")
+        if it.get("add1") is not None and it.get("add2") is not None and it["add1"].stride(0) != it["add2"].stride(0):
+            raise RuntimeError("linear_split_ex: add1 and add2 must share their row stride")
+    ldadd = _host_array(I, [((it.get("add1") if it.get("add1") is not None else it.get("add2")).stride(0)
+                             if (it.get("add1") is not None or it.get("add2") is not None) else 0) for it in problems])
+    st = lib.egtr_linear_split_bf16_ex_f32(
+        _stream(), n, _host_array(P, [it["x"].data_ptr() for it in problems]),
+        _host_array(I, [it["x"].stride(0) for it in problems]), _host_array(P, [it["wt"].data_ptr() for it in problems]),
+        _host_array(P, [(it["b"].data_ptr() if it.get("b") is not None else None) for it in problems]),
+        _host_array(P, [y.data_ptr() for y in outs]), _host_array(I, [y.stride(0) for y in outs]),
+        _host_array(I, [int(it["N"]) for it in problems]), _host_array(I, [1 if it.get("relu") else 0 for it in problems]),
+        int(M), int(K), ptrs("pos"),
+        _host_array(I, [(it["pos"].shape[0] if it.get("pos") is not None else 1) for it in problems]),
+        ptrs("row_keep"), ptrs("relu_ref"), ld("relu_ref"), ptrs("add1"), ptrs("add2"), ldadd, ptrs("colpart"))
+    _lib.check(st, "egtr_linear_split_bf16_ex_f32")
+    return outs
+
+
+def dropout_add_layernorm(x, residual, keep, scale, weight, bias, eps, flag=None):
+    """LayerNorm(residual + keep * scale * x) over rows of 256 channels in one pass (egtr_dropout_add_layernorm_f32); ``keep``
+    uint8 [rows, 256] or None; ``flag`` (int32 [1], optional) is OR-ed with 1 when an output element is non-finite."""
+    lib = _lib.lib()
+    rows = x.shape[0]
+    y = torch.empty_like(x)
+    st = lib.egtr_dropout_add_layernorm_f32(_stream(), x.data_ptr(), residual.data_ptr(),
+                                            keep.data_ptr() if keep is not None else None, float(scale), weight.data_ptr(),
+                                            bias.data_ptr(), y.data_ptr(), rows, 256, float(eps),
+                                            flag.data_ptr() if flag is not None else None)
+    _lib.check(st, "egtr_dropout_add_layernorm_f32")
+    return y
+
+
+def dropout_add_layernorm_backward(x, residual, keep, scale, weight, eps, grad_y, flag=None, y_out=None, clamp_value=0.0):
+    """Backward of ``dropout_add_layernorm``: (grad_sum, grad_x (is grad_sum without dropout), [d gamma | d beta | d bias])."""
+    lib = _lib.lib()
+    rows = x.shape[0]
+    gs = torch.empty_like(x)
+    gx = torch.empty_like(x) if keep is not None else None
+    ws = torch.empty(int(lib.egtr_dropout_add_layernorm_backward_workspace_floats(rows)), dtype=torch.float32, device=x.device)
+    out = torch.empty(768, dtype=torch.float32, device=x.device)
+    st = lib.egtr_dropout_add_layernorm_backward_f32(
+        _stream(), x.data_ptr(), residual.data_ptr(), keep.data_ptr() if keep is not None else None, float(scale),
+        weight.data_ptr(), grad_y.data_ptr(), flag.data_ptr() if flag is not None else None,
+        y_out.data_ptr() if (flag is not None and y_out is not None) else None, float(clamp_value), gs.data_ptr(),
+        gx.data_ptr() if gx is not None else None, ws.data_ptr(), out.data_ptr(), rows, 256, float(eps))
+    _lib.check(st, "egtr_dropout_add_layernorm_backward_f32")
+    return gs, (gx if gx is not None else gs), out
+
+
+def _wgrad_ex(g, x, x_pos=None, row_keep=None):
+    """g [M, N]^T . (x [+ x_pos rows]) [M, K] -> [N, K] with optional row mask on g (egtr_linear_split_bf16_wgrad_ex_f32)."""
+    lib = _lib.lib()
+    M, N = g.shape
+    K = x.shape[1]
+    ws = torch.empty(int(lib.egtr_linear_split_bf16_wgrad_workspace_floats(M, N, K)), dtype=torch.float32, device=g.device)
+    gw = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    st = lib.egtr_linear_split_bf16_wgrad_ex_f32(
+        _stream(), g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), gw.data_ptr(), ws.data_ptr(), M, N, K,
+        x_pos.data_ptr() if x_pos is not None else None, x_pos.shape[0] if x_pos is not None else 1,
+        row_keep.data_ptr() if row_keep is not None else None)
+    _lib.check(st, "egtr_linear_split_bf16_wgrad_ex_f32")
+    return gw
+
+
+def _rows256(t):
+    t2 = t.reshape(-1, t.shape[-1])
+    if t2.stride(1) != 1 or t2.stride(0) != t2.shape[1] or t2.data_ptr() % 16:
+        t2 = t2.contiguous()
+        if t2.data_ptr() % 16:
+            t2 = t2.clone()
+    return t2
+
+
+class EncoderLayerTrainFunction(Function):
+    """One Deformable-DETR encoder layer in TRAINING as a single autograd node (reference: DeformableDetrEncoderLayer.forward
+    in train mode, model/deformable_detr.py:1283-1358, with DeformableDetrMultiscaleDeformableAttention.forward, :1026-1104):
+
+        value = mask(value_proj(x));  [offsets | logits] = Linear_cat(x + pos)  (pos added while the GEMM loads its operand)
+        (loc, attn) = softmax / sampling locations;  ctx = MSDA(value, loc, attn)
+        y1 = LayerNorm1(x + dropout(output_proj(ctx)));  y2 = LayerNorm2(y1 + dropout(fc2(relu(fc1(y1)))))
+        y2 = clamp(y2) iff y2 holds an inf / nan (flag on the device, no host synchronisation)
+
+    Why one node: the per-op composition of rounds 2 / 3 spent, per layer and step, ~25 ATen launches on glue around the
+    same kernels -- gradient accumulation adds where branches meet, dropout forward / backward passes, `x + pos`, masked_fill and
+    its backward, isfinite / clamp passes, threshold_backward + bias-gradient column sums over the [rows, 1024] activation
+    (profiles/r04_train_gaps.txt: 5.5 ms of ATen elementwise kernels per step).  Here those are epilogue options of the split-bf16
+    GEMMs (egtr_linear_split_bf16_ex_f32: row mask, ReLU backward, branch accumulation, bias-gradient partials) and of the two
+    dropout + residual + LayerNorm kernels (csrc/enc_train.hip).  Dropout masks are bytes drawn by one bernoulli_ per layer
+    (``masks`` hands in fixed ones for tests).  Arithmetic per product: exactly TokenLinearFunction's (six-term bf16 split)."""
+
+    @staticmethod
+    def forward(ctx, x, pos, ref, keep_rows, shapes, lsi, p_drop, masks, ln_eps, so_w, so_b, aw_w, aw_b, vp_w, vp_b, op_w,
+                op_b, ln1_w, ln1_b, fc1_w, fc1_b, fc2_w, fc2_b, ln2_w, ln2_b):
+        lib = _lib.lib()
+        B, S, D = x.shape
+        M = B * S
+        dev = x.device
+        x2 = _rows256(x.detach())
+        pos2 = _rows256(pos.detach())
+        rk = None
+        if keep_rows is not None:
+            rk = keep_rows.reshape(-1).contiguous()
+            rk = rk.view(torch.uint8) if rk.dtype == torch.bool else rk.to(torch.uint8)
+        wb = torch.cat([so_w.detach(), aw_w.detach()], 0)
+        bb = torch.cat([so_b.detach(), aw_b.detach()], 0)
+        wt_v, wtT_v = gemm_split_tile_pair(vp_w)
+        wt_b, wtT_b = gemm_split_tile_pair(wb)
+        wt_o, wtT_o = gemm_split_tile_pair(op_w)
+        wt_1, wtT_1 = gemm_split_tile_pair(fc1_w)
+        wt_2, wtT_2 = gemm_split_tile_pair(fc2_w)
+        F1 = fc1_w.shape[0]
+        nb = wb.shape[0]
+        n_off = so_w.shape[0]
+        # value projection (padded rows zeroed in the epilogue) + offsets / logits projection of x + pos: one launch
+        value, both = linear_split_ex([dict(x=x2, wt=wt_v, N=D, b=vp_b.detach(), row_keep=rk),
+                                       dict(x=x2, wt=wt_b, N=nb, b=bb, pos=pos2)], M, D)
+        Mh, L, P_ = 8, shapes.shape[0], n_off // (8 * shapes.shape[0] * 2)
+        refc = _chk(ref.detach().contiguous(), "reference_points", torch.float32)
+        shp = _chk(shapes.contiguous(), "spatial_shapes", torch.int64)
+        loc = torch.empty(B, S, Mh, L, P_, 2, dtype=torch.float32, device=dev)
+        attn = torch.empty(B, S, Mh, L, P_, dtype=torch.float32, device=dev)
+        off, lg = both[:, :n_off], both[:, n_off:]
+        _lib.check(lib.egtr_msda_geometry_forward_f32(_stream(), off.data_ptr(), off.stride(0), lg.data_ptr(), lg.stride(0),
+                                                      refc.data_ptr(), refc.shape[-1], shp.data_ptr(), loc.data_ptr(),
+                                                      attn.data_ptr(), M, Mh, L, P_), "egtr_msda_geometry_forward_f32")
+        value4 = value.view(B, S, Mh, D // Mh)
+        att = _msda().ms_deform_attn_forward(value4, shp, lsi, loc, attn, 64).view(M, D)
+        a = linear_split_ex([dict(x=att, wt=wt_o, N=D, b=op_b.detach())], M, D)[0]
+        p = float(p_drop)
+        scale = 1.0 / (1.0 - p) if p > 0.0 else 1.0
+        m1 = m2 = None
+        if masks is not None:
+            m1, m2 = masks
+        elif p > 0.0:
+            mm = torch.empty(2, M, D, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
+            m1, m2 = mm[0], mm[1]
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        eps1, eps2 = float(ln_eps[0]), float(ln_eps[1])
+        y1 = dropout_add_layernorm(a, x2, m1, scale, ln1_w.detach(), ln1_b.detach(), eps1)
+        h = linear_split_ex([dict(x=y1, wt=wt_1, N=F1, b=fc1_b.detach(), relu=True)], M, D)[0]
+        f = linear_split_ex([dict(x=h, wt=wt_2, N=D, b=fc2_b.detach())], M, F1)[0]
+        y2 = dropout_add_layernorm(f, y1, m2, scale, ln2_w.detach(), ln2_b.detach(), eps2, flag=flag)
+        cv = torch.finfo(torch.float32).max - 1000
+        _lib.check(lib.egtr_clamp_if_flag_f32(_stream(), y2.data_ptr(), None, y2.numel(), flag.data_ptr(), cv, 0),
+                   "egtr_clamp_if_flag_f32")
+        ctx.save_for_backward(x2, pos2, refc, shp, lsi, rk, value, both, loc, attn, att, a, m1, y1, h, f, m2, y2, flag,
+                              wtT_v, wtT_b, wtT_o, wtT_1, wtT_2, ln1_w, ln2_w)
+        ctx.dims = (B, S, D, F1, nb, n_off, Mh, L, P_, scale, cv, eps1, eps2)
+        ctx.in_shape = x.shape
+        ctx.pos_shape = pos.shape
+        return y2.view(B, S, D)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_y2):
+        lib = _lib.lib()
+        (x2, pos2, refc, shp, lsi, rk, value, both, loc, attn, att, a, m1, y1, h, f, m2, y2, flag,
+         wtT_v, wtT_b, wtT_o, wtT_1, wtT_2, ln1_w, ln2_w) = ctx.saved_tensors
+        B, S, D, F1, nb, n_off, Mh, L, P_, scale, cv, eps1, eps2 = ctx.dims
+        M = B * S
+        dev = x2.device
+        g = _rows256(g_y2)
+        # LayerNorm2 + dropout backward (+ the clamp's gradient mask when the forward raised its flag)
+        gs2, gf, gbb2 = dropout_add_layernorm_backward(f, y1, m2, scale, ln2_w.detach(), eps2, g, flag, y2, cv)
+        d_w2 = linear_split_bf16_wgrad(gf, h)
+        colp = torch.empty((M + 31) // 32, F1, dtype=torch.float32, device=dev)
+        g_h = linear_split_ex([dict(x=gf, wt=wtT_2, N=F1, relu_ref=h, colpart=colp)], M, D)[0]   # ReLU mask + bias partials
+        d_b1 = column_sum(colp)
+        d_w1 = linear_split_bf16_wgrad(g_h, y1)
+        linear_split_ex([dict(x=g_h, wt=wtT_1, N=D, add1=gs2, out=gs2)], M, F1)                  # gs2 <- d loss / d y1
+        del g_h
+        gs1, ga, gbb1 = dropout_add_layernorm_backward(a, x2, m1, scale, ln1_w.detach(), eps1, gs2)
+        d_wo = linear_split_bf16_wgrad(ga, att)
+        g_att = linear_split_ex([dict(x=ga, wt=wtT_o, N=D)], M, D)[0]
+        g_value, g_loc, g_attn = _msda().ms_deform_attn_backward(value.view(B, S, Mh, D // Mh), shp, lsi, loc, attn,
+                                                                 g_att.view(B, S, D), 64)
+        g_both = torch.empty(M, nb, dtype=torch.float32, device=dev)
+        off = both[:, :n_off]
+        _lib.check(lib.egtr_msda_geometry_backward_f32(
+            _stream(), g_loc.data_ptr(), g_attn.data_ptr(), attn.data_ptr(), off.data_ptr(), off.stride(0), refc.data_ptr(),
+            refc.shape[-1], shp.data_ptr(), g_both.data_ptr(), nb, g_both.data_ptr() + 4 * n_off, nb, None, M, Mh, L, P_),
+            "egtr_msda_geometry_backward_f32")
+        d_bb = column_sum(g_both)
+        d_wb = _wgrad_ex(g_both, x2, x_pos=pos2)
+        g_qin = linear_split_ex([dict(x=g_both, wt=wtT_b, N=D)], M, nb)[0]                       # = d loss / d pos as well
+        gv2 = g_value.view(M, D)
+        d_bv = column_sum(gv2) if rk is None else weighted_column_sum(gv2, rk.to(torch.float32))
+        d_wv = _wgrad_ex(gv2, x2, row_keep=rk)
+        linear_split_ex([dict(x=gv2, wt=wtT_v, N=D, row_keep=rk, add1=gs1, add2=g_qin, out=gs1)], M, D)   # gs1 <- d loss / d x
+        g_pos = g_qin.view(B, S, D)
+        if tuple(ctx.pos_shape) != (B, S, D):
+            g_pos = g_pos.sum_to_size(ctx.pos_shape)
+        return (gs1.view(ctx.in_shape), g_pos, None, None, None, None, None, None, None,
+                d_wb[:n_off], d_bb[:n_off], d_wb[n_off:], d_bb[n_off:], d_wv, d_bv, d_wo, gbb1[512:768],
+                gbb1[0:256], gbb1[256:512], d_w1, d_b1, d_w2, gbb2[512:768], gbb2[0:256], gbb2[256:512])
+
+
+def encoder_layer_train_supported(layer, x, pos, ref, attention_mask, output_attentions):
+    """The fused training node serves the reference's training configuration: fp32 on the GPU, token-sized rows, d_model 256,
+    8 heads x 4 levels x 4 points, 2-d reference points, ReLU FFN with a hidden width that tiles (multiple of 128),
+    activation_dropout 0 (the reference default), no attention maps requested."""
+    sa = layer.self_attn
+    return (ENCODER_TRAIN_FUSED and GEMM_SPLIT_BF16 and torch.is_grad_enabled() and layer.training and not output_attentions
+            and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] == 256
+            and x.shape[0] * x.shape[1] > SKINNY_MAX_ROWS and pos is not None and pos.dtype == torch.float32
+            and tuple(pos.shape) == tuple(x.shape) and ref is not None and ref.dim() == 4 and ref.shape[-1] == 2
+            and sa.n_heads == 8 and sa.n_levels == 4 and sa.n_points == 4 and ref.shape[2] == 4
+            and layer.activation_fn is torch.nn.functional.relu and layer.activation_dropout == 0.0
+            and layer.fc1.weight.shape[0] % 128 == 0 and tuple(layer.fc2.weight.shape) == (256, layer.fc1.weight.shape[0])
+            and layer.fc1.weight.dtype == torch.float32 and 0.0 <= layer.dropout < 1.0
+            and (attention_mask is None or tuple(attention_mask.shape) == tuple(x.shape[:2])))
+
+
+def encoder_layer_train(layer, x, attention_mask, pos, ref, spatial_shapes, level_start_index, masks=None):
+    sa = layer.self_attn
+    return EncoderLayerTrainFunction.apply(
+        x, pos, ref, attention_mask, spatial_shapes, level_start_index, layer.dropout, masks,
+        (layer.self_attn_layer_norm.eps, layer.final_layer_norm.eps), sa.sampling_offsets.weight, sa.sampling_offsets.bias, sa.attention_weights.weight, sa.attention_weights.bias,
+        sa.value_proj.weight, sa.value_proj.bias, sa.output_proj.weight, sa.output_proj.bias,
+        layer.self_attn_layer_norm.weight, layer.self_attn_layer_norm.bias, layer.fc1.weight, layer.fc1.bias,
+        layer.fc2.weight, layer.fc2.bias, layer.final_layer_norm.weight, layer.final_layer_norm.bias)
+
+
 def cached_weights(owner, name, tensors, builder):
     """Derived constants of module weights (stacks, slices, concatenations), built once and rebuilt when a source tensor
     is replaced, moved or modified in place.  The cache lives ON the owning module (``owner._egtr_derived``), and an

@@ -231,6 +231,27 @@ int egtr_add_layernorm_backward_f32(egtr_stream_t stream, const float* x, const 
                                     const float* grad_y, float* grad_sum, float* workspace, float* grad_gamma_beta,
                                     int rows, int dim, float eps);
 
+/* Training form of the encoder layer's "dropout + residual + LayerNorm" (model/deformable_detr.py:1326-1330, 1341-1351 in
+ * train mode) as ONE pass: y = LayerNorm(residual + keep * keep_scale * x) * gamma + beta.  keep [rows, 256] bytes (non-zero =
+ * kept; NULL = no dropout), keep_scale = 1 / (1 - p).  nonfinite_flag (optional, device int, OR-ed with 1 when an output
+ * element is inf / nan): the reference's "clamp the states iff any element is inf / nan" decision (dd:1346-1351) without an
+ * extra pass -- follow with egtr_clamp_if_flag_f32, which returns at once while the flag is clear. */
+int egtr_dropout_add_layernorm_f32(egtr_stream_t stream, const float* x, const float* residual, const unsigned char* keep,
+                                   float keep_scale, const float* gamma, const float* beta, float* y, int rows, int dim,
+                                   float eps, int* nonfinite_flag);
+/* Its backward, one pass + a fixed-order reduction of per-workgroup partials: grad_sum [rows, 256] = d loss / d (residual +
+ * dropped x) (the residual's gradient), grad_x = keep * keep_scale * grad_sum (the gradient of the Linear that produced x;
+ * NULL exactly when keep is NULL: then it equals grad_sum), grad_gamma_beta_bias [768] = (d gamma, d beta, column sums of
+ * grad_x = that Linear's bias gradient).  clamp_flag / y_out / clamp_value (optional): where the forward clamp was active
+ * (*clamp_flag != 0 and |y_out| >= clamp_value, or NaN) the incoming gradient counts as zero (torch.clamp's backward).
+ * workspace: egtr_dropout_add_layernorm_backward_workspace_floats(rows) floats. */
+long long egtr_dropout_add_layernorm_backward_workspace_floats(int rows);
+int egtr_dropout_add_layernorm_backward_f32(egtr_stream_t stream, const float* x, const float* residual,
+                                            const unsigned char* keep, float keep_scale, const float* gamma,
+                                            const float* grad_y, const int* clamp_flag, const float* y_out,
+                                            float clamp_value, float* grad_sum, float* grad_x, float* workspace,
+                                            float* grad_gamma_beta_bias, int rows, int dim, float eps);
+
 /* bf16 storage (raw bfloat16 bits), fp32 arithmetic -- the same two epilogues for the bf16 stress configuration:
  * y = act(x + bias[c] (+ residual)) on an NCHW activation (bias fp32), and y = LayerNorm(x + residual) over 256 channels
  * (gamma / beta bf16; the residual sum is rounded to bf16 before the statistics, as the PyTorch composition does). */
@@ -422,6 +443,29 @@ int egtr_linear_split_bf16_grouped_pos_f32(egtr_stream_t stream, int num_problem
                                            const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
                                            const int* ldy, const int* N, const int* relu, int M, int K,
                                            const float* const* pos, const int* pos_rows);
+
+/* The same with the epilogue options of the TRAINING step (every array may be NULL = none, every entry NULL = none), applied
+ * in this order to v = act(x_g W_g^T + bias_g):
+ *   row_keep[g] [M] bytes      rows with 0 yield zeros (value rows of padded tokens, model/deformable_detr.py:1052; in the
+ *                              backward: their gradients);
+ *   relu_ref[g] [M, ldref[g]]  v = relu_ref > 0 ? v : 0 -- the ReLU backward of the layer whose output relu_ref is, fused into
+ *                              this data-gradient product (replaces threshold_backward over the [M, 1024] FFN activation);
+ *   add1[g], add2[g] [M, ldadd[g]]  v += add1 + add2: the gradients of the other branches that meet at the same tensor
+ *                              (autograd's AccumulateGrad adds); either may alias y[g];
+ *   colpart[g] [ceil(M / 32), N[g]]  column sums of the stored values over each block of 32 rows -- the bias gradient of the
+ *                              layer the gradient flows into, finished in a fixed order by egtr_column_sum_f32 over the blocks. */
+int egtr_linear_split_bf16_ex_f32(egtr_stream_t stream, int num_problems, const float* const* x, const int* ldx,
+                                  const uint16_t* const* w_tiled, const float* const* bias, float* const* y,
+                                  const int* ldy, const int* N, const int* relu, int M, int K, const float* const* pos,
+                                  const int* pos_rows, const unsigned char* const* row_keep, const float* const* relu_ref,
+                                  const int* ldref, const float* const* add1, const float* const* add2, const int* ldadd,
+                                  float* const* colpart);
+/* egtr_linear_split_bf16_wgrad_f32 for a layer whose input was `x + pos` formed on load (x_pos [pos_rows, K], row m uses
+ * x_pos[m % pos_rows]; NULL = none) and / or whose gradient rows are masked (row_keep [M] bytes, 0 = the row counts as zero;
+ * NULL = none). */
+int egtr_linear_split_bf16_wgrad_ex_f32(egtr_stream_t stream, const float* g, int ldg, const float* x, int ldx,
+                                        float* grad_weight, float* workspace, int M, int N, int K, const float* x_pos,
+                                        int pos_rows, const unsigned char* row_keep);
 
 /* ---- the "XS" operand format of the row-panel kernels (csrc/xs_format.h, csrc/xs_split.hip) --------------------------
  * XS(X) of a logical fp32 matrix X[rows][K] (K % 16 == 0): the exact three-way bf16 split x = hi + mid + lo, stored as
