@@ -310,8 +310,11 @@ bool problem_ok(const float* x, int ldx, const uint16_t* w, const float* bias, f
 // workgroup writes its 128 x 128 partial to the workspace and wgrad_reduce_f32 sums the chunks in a fixed order.
 // MFMA roles: A operand = x piece (i = k), B operand = g piece (j = n): float4 stores along k of the row-major [N, K]
 // result.
-// `xpos` (optional, [pos_rows, K]): x[m] + xpos[m % pos_rows] is the operand (the layer's input was `hidden + pos`, added on
-// load in the forward too); `row_keep` (optional, [M] bytes): rows of g with 0 count as zero rows (padded tokens).
+// EXT: `xpos` (optional, [pos_rows, K]): x[m] + xpos[m % pos_rows] is the operand (the layer's input was `hidden + pos`, added
+// on load in the forward too); `row_keep` (optional, [M] bytes): rows of g with 0 count as zero rows (padded tokens).  A
+// template parameter, not a runtime test: with the tests in the load loop the plain kernel lost its batched loads (80 launches
+// per train step: 4.1 -> 5.0 ms).
+template <bool EXT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void wgrad_split_bf16_f32(
     const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, float* __restrict__ partial, int M, int N,
     int K, int rows_per_chunk, const float* __restrict__ xpos, int pos_rows, const unsigned char* __restrict__ row_keep) {
@@ -330,20 +333,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int col = tid & 127, mq = tid >> 7;    // loader: column of the tile, rows 8 mq .. 8 mq + 7 of the stage
   const float* gp = G + n0 + col;
   const float* xp = X + k0 + col;
-  const float* pp = xpos != nullptr ? xpos + k0 + col : nullptr;
+  const float* pp = (EXT && xpos != nullptr) ? xpos + k0 + col : nullptr;
 
   float rg[8], rx[8];
   auto issue = [&](int s) {
     const int m = mbeg + s * kBK + mq * 8;
+    if constexpr (EXT) {
+      float rp[8];
+      unsigned char rk[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const bool ok = m + e < mend;
-      const size_t r = (size_t)(ok ? m + e : mbeg);
-      float a = gp[r * ldg], b = xp[r * ldx];
-      if (pp != nullptr) b += pp[(size_t)(r % (size_t)pos_rows) * K];
-      if (row_keep != nullptr && row_keep[r] == 0) a = 0.f;
-      rg[e] = ok ? a : 0.f;
-      rx[e] = ok ? b : 0.f;
+      for (int e = 0; e < 8; ++e) {   // all loads of the stage first (no test between them), then the arithmetic
+        const bool ok = m + e < mend;
+        const unsigned r = (unsigned)(ok ? m + e : mbeg);
+        rg[e] = gp[(size_t)r * ldg];
+        rx[e] = xp[(size_t)r * ldx];
+        rp[e] = pp != nullptr ? pp[(size_t)(r % (unsigned)pos_rows) * K] : 0.f;
+        rk[e] = row_keep != nullptr ? row_keep[r] : (unsigned char)1;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = m + e < mend;
+        rg[e] = (ok && rk[e] != 0) ? rg[e] : 0.f;
+        rx[e] = ok ? rx[e] + rp[e] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool ok = m + e < mend;
+        const size_t r = (size_t)(ok ? m + e : mbeg);
+        const float a = gp[r * ldg], b = xp[r * ldx];
+        rg[e] = ok ? a : 0.f;
+        rx[e] = ok ? b : 0.f;
+      }
     }
   };
   auto stash_one = [&](const float (&v)[8], __bf16* base) {
@@ -585,8 +606,12 @@ extern "C" int egtr_linear_split_bf16_wgrad_ex_f32(egtr_stream_t stream, const f
   const long long wgs = (long long)pl.chunks * (N / 128) * (K / 128);
   if (wgs >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(wgrad_split_bf16_f32, dim3((unsigned)wgs), dim3(512), 0, st, g, ldg, x, ldx, workspace, M, N, K,
-                     pl.rows_per_chunk, x_pos, pos_rows, row_keep);
+  if (x_pos != nullptr || row_keep != nullptr)
+    hipLaunchKernelGGL(wgrad_split_bf16_f32<true>, dim3((unsigned)wgs), dim3(512), 0, st, g, ldg, x, ldx, workspace, M, N, K,
+                       pl.rows_per_chunk, x_pos, pos_rows, row_keep);
+  else
+    hipLaunchKernelGGL(wgrad_split_bf16_f32<false>, dim3((unsigned)wgs), dim3(512), 0, st, g, ldg, x, ldx, workspace, M, N, K,
+                       pl.rows_per_chunk, x_pos, pos_rows, row_keep);
   int rc = egtr_check_launch();
   if (rc != EGTR_OK) return rc;
   const int n4 = N * K / 4;

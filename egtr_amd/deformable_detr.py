@@ -757,13 +757,14 @@ class DeformableDetrDecoderLayer(nn.Module):
             hidden_states=hidden_states, position_embeddings=position_embeddings, attention_mask=attention_mask,
             output_attentions=output_attentions, output_attention_states=output_attention_states,
             hidden_with_pos=hidden_with_pos)
-        hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         cross_with_pos = None
         if fast:
+            hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
             hidden_states, cross_with_pos = ops.add_layer_norm_pos(hidden_states, residual, self.self_attn_layer_norm,
                                                                    _pos_rows(position_embeddings))
         else:
-            hidden_states = ops.add_layer_norm(hidden_states, residual, self.self_attn_layer_norm)
+            hidden_states = ops.dropout_add_layer_norm(hidden_states, residual, self.self_attn_layer_norm, self.dropout,
+                                                       self.training)
         second_residual = hidden_states
         hidden_states, cross_attn_weights = self.encoder_attn(
             hidden_states=hidden_states, attention_mask=encoder_attention_mask,
@@ -772,8 +773,8 @@ class DeformableDetrDecoderLayer(nn.Module):
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
             hidden_with_pos=cross_with_pos, precomputed_value=precomputed_value)
-        hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
-        hidden_states = ops.add_layer_norm(hidden_states, second_residual, self.encoder_attn_layer_norm)
+        hidden_states = ops.dropout_add_layer_norm(hidden_states, second_residual, self.encoder_attn_layer_norm,
+                                                   self.dropout, self.training)
         residual = hidden_states
         if self.activation_fn is F.relu:
             hidden_states = ops.module_linear(self.fc1, hidden_states, relu=True)
@@ -781,13 +782,14 @@ class DeformableDetrDecoderLayer(nn.Module):
             hidden_states = self.activation_fn(ops.module_linear(self.fc1, hidden_states))
         hidden_states = F.dropout(hidden_states, p=self.activation_dropout, training=self.training)
         hidden_states = ops.module_linear(self.fc2, hidden_states)
-        hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         next_with_pos = None
         if fast and return_with_pos:
+            hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
             hidden_states, next_with_pos = ops.add_layer_norm_pos(hidden_states, residual, self.final_layer_norm,
                                                                   _pos_rows(position_embeddings), out=out)
         else:
-            hidden_states = ops.add_layer_norm(hidden_states, residual, self.final_layer_norm)
+            hidden_states = ops.dropout_add_layer_norm(hidden_states, residual, self.final_layer_norm, self.dropout,
+                                                       self.training)
         outputs = (hidden_states,)
         if output_attentions:
             outputs += (self_attn_weights, cross_attn_weights)
@@ -996,6 +998,11 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
             else:
                 values = ops.bias_mask_rows_(values.view(nl, bsz_ * seq_, dm_), b_all,
                                              encoder_attention_mask).view(nl, bsz_, seq_, dm_)
+        elif (encoder_hidden_states is not None and self.training
+              and ops.decoder_values_train_supported(encoder_hidden_states, encoder_attention_mask, self.layers)):
+            # training: the value projections of all layers' cross-attention as ONE autograd node (one grouped forward launch,
+            # one accumulating chain of data-gradient products; padded rows zeroed in the epilogues)
+            values = ops.decoder_values_train(encoder_hidden_states, encoder_attention_mask, self.layers)
         hoisted_reference = None
         if self.bbox_embed is None and reference_points.shape[-1] == 2:  # no refinement: same input for every layer
             hoisted_reference = reference_points[:, :, None] * valid_ratios[:, None]

@@ -621,6 +621,114 @@ class EncoderLayerTrainFunction(Function):
                 gbb1[0:256], gbb1[256:512], d_w1, d_b1, d_w2, gbb2[512:768], gbb2[0:256], gbb2[256:512])
 
 
+class DecoderValueProjTrainFunction(Function):
+    """The cross-attention value projections of ALL decoder layers in training as one autograd node (reference: value_proj +
+    masked_fill of every DeformableDetrMultiscaleDeformableAttention of the decoder, model/deformable_detr.py:1048-1052):
+    values_l = mask(enc W_l^T + b_l), l = 0 .. Ld - 1.  Forward: ONE grouped launch of the split-bf16 GEMM (the Ld products
+    share the operand rows and the grid; padded rows zeroed in the epilogue).  Backward: d enc = sum_l mask (g_l W_l) as a
+    chain of data-gradient products that accumulate into one buffer (no AccumulateGrad adds, no masked_fill backward), weight
+    gradients with the row mask applied on load, bias gradients as mask-weighted column sums.  Returns Ld separate tensors
+    (views of one stacked tensor would make autograd build a zero-filled [Ld, B, S, 256] gradient per layer)."""
+
+    @staticmethod
+    def forward(ctx, enc, keep_rows, *wb):
+        nl = len(wb) // 2
+        ws, bs = wb[:nl], wb[nl:]
+        B, S, D = enc.shape
+        M = B * S
+        x2 = _rows256(enc.detach())
+        rk = None
+        if keep_rows is not None:
+            rk = keep_rows.reshape(-1).contiguous()
+            rk = rk.view(torch.uint8) if rk.dtype == torch.bool else rk.to(torch.uint8)
+        tiles = [gemm_split_tile_pair(w) for w in ws]
+        outs = []
+        for i0 in range(0, nl, 8):
+            outs += linear_split_ex([dict(x=x2, wt=tiles[i][0], N=D, b=bs[i].detach(), row_keep=rk)
+                                     for i in range(i0, min(nl, i0 + 8))], M, D)
+        ctx.save_for_backward(x2, rk, *[t[1] for t in tiles])
+        ctx.set_materialize_grads(False)   # an unused layer's values: None, not a zero tensor to multiply out
+        ctx.nl = nl
+        ctx.in_shape = enc.shape
+        return tuple(o.view(B, S, D) for o in outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        x2, rk = ctx.saved_tensors[:2]
+        wtT = ctx.saved_tensors[2:]
+        nl = ctx.nl
+        M, D = x2.shape
+        g_enc = None
+        d_w, d_b = [], []
+        rkf = rk.to(torch.float32) if rk is not None else None
+        for i in range(nl):
+            if gs[i] is None:
+                d_w.append(None)
+                d_b.append(None)
+                continue
+            g = _rows256(gs[i])
+            d_b.append(column_sum(g) if rkf is None else weighted_column_sum(g, rkf))
+            d_w.append(_wgrad_ex(g, x2, row_keep=rk))
+            if g_enc is None:
+                g_enc = linear_split_ex([dict(x=g, wt=wtT[i], N=D, row_keep=rk)], M, D)[0]
+            else:
+                linear_split_ex([dict(x=g, wt=wtT[i], N=D, row_keep=rk, add1=g_enc, out=g_enc)], M, D)
+        return (g_enc.view(ctx.in_shape) if g_enc is not None else None, None, *d_w, *d_b)
+
+
+def decoder_values_train_supported(enc, attention_mask, layers):
+    return (ENCODER_TRAIN_FUSED and GEMM_SPLIT_BF16 and torch.is_grad_enabled() and torch.is_tensor(enc) and enc.is_cuda
+            and enc.dtype == torch.float32 and enc.dim() == 3 and enc.shape[-1] == 256
+            and enc.shape[0] * enc.shape[1] > SKINNY_MAX_ROWS
+            and all(tuple(l.encoder_attn.value_proj.weight.shape) == (256, 256) and l.encoder_attn.value_proj.bias is not None
+                    and l.encoder_attn.value_proj.weight.dtype == torch.float32 for l in layers)
+            and (attention_mask is None or tuple(attention_mask.shape) == tuple(enc.shape[:2])))
+
+
+def decoder_values_train(enc, attention_mask, layers):
+    """[value_proj_l(enc) with padded rows zeroed for l in layers] -- see DecoderValueProjTrainFunction."""
+    return DecoderValueProjTrainFunction.apply(
+        enc, attention_mask, *[l.encoder_attn.value_proj.weight for l in layers],
+        *[l.encoder_attn.value_proj.bias for l in layers])
+
+
+class DropoutAddLayerNormFunction(Function):
+    """LayerNorm(residual + dropout(x)) over 256 channels as one pass per direction (csrc/enc_train.hip) -- the decoder layer's
+    three "dropout, add, LayerNorm" steps in training (model/deformable_detr.py:1436-1438, 1455-1457, 1466-1468): instead of
+    fused_dropout + add_layernorm forward and layer-norm backward + masked_scale backward.  The mask is a byte tensor drawn by
+    bernoulli_ (``keep`` hands in a fixed one for tests)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps, p, keep):
+        x2, r2 = _rows256(x.detach()), _rows256(residual.detach())
+        scale = 1.0
+        if keep is None and p > 0.0:
+            keep = torch.empty(x2.shape, dtype=torch.uint8, device=x2.device).bernoulli_(1.0 - p)
+        if keep is not None:
+            scale = 1.0 / (1.0 - p)
+        y = dropout_add_layernorm(x2, r2, keep, scale, weight.detach(), bias.detach(), eps)
+        ctx.save_for_backward(x2, r2, keep, weight)
+        ctx.cfg = (float(eps), float(scale))
+        return y.view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x2, r2, keep, weight = ctx.saved_tensors
+        eps, scale = ctx.cfg
+        gs, gx, gbb = dropout_add_layernorm_backward(x2, r2, keep, scale, weight.detach(), eps, _rows256(gy))
+        return gx.view(gy.shape), gs.view(gy.shape), gbb[0:256], gbb[256:512], None, None, None
+
+
+def dropout_add_layer_norm(x, residual, ln, p, training, keep=None):
+    """ln(residual + dropout(x, p, training)); fp32 device tensors of 256 channels under autograd take the one-pass kernels."""
+    if (ENCODER_TRAIN_FUSED and training and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
+            and x.shape[-1] == 256 and residual.shape == x.shape and 0.0 <= p < 1.0):
+        return DropoutAddLayerNormFunction.apply(x, residual, ln.weight, ln.bias, ln.eps, float(p), keep)
+    return add_layer_norm(torch.nn.functional.dropout(x, p=p, training=training), residual, ln)
+
+
 def encoder_layer_train_supported(layer, x, pos, ref, attention_mask, output_attentions):
     """The fused training node serves the reference's training configuration: fp32 on the GPU, token-sized rows, d_model 256,
     8 heads x 4 levels x 4 points, 2-d reference points, ReLU FFN with a hidden width that tiles (multiple of 128),

@@ -251,3 +251,65 @@ def test_split_gemm_epilogue_options_and_wgrad_options_vs_float64():
     assert (gw.double() - want_w).abs().max() < 2e-5 * float(want_w.abs().max()) + 1e-3
     gw0 = ops._wgrad_ex(gmat, x)
     assert torch.equal(gw0, ops.linear_split_bf16_wgrad(gmat, x))
+
+
+def test_decoder_value_projection_node_vs_float64():
+    """ops.DecoderValueProjTrainFunction: values_l = mask(enc W_l^T + b_l) for six layers, and through arbitrary upstream
+    gradients (one layer's output unused: its gradient is None) d enc, d W_l, d b_l -- against float64 autograd."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, S, nl = 2, 4500, 6
+    enc = torch.randn(B, S, 256, generator=g).to(DEV)
+    mask = (torch.rand(B, S, generator=g) < 0.85).to(DEV)
+    lins = [torch.nn.Linear(256, 256).to(DEV) for _ in range(nl)]
+
+    class _L:   # the attribute path the decoder layers expose
+        def __init__(self, lin):
+            self.encoder_attn = type("A", (), {"value_proj": lin})()
+
+    layers = [_L(m) for m in lins]
+    e = enc.clone().requires_grad_(True)
+    assert ops.decoder_values_train_supported(e, mask, layers)
+    vals = ops.decoder_values_train(e, mask, layers)
+    gys = [torch.randn(B, S, 256, generator=g).to(DEV) for _ in range(nl)]
+    used = [0, 1, 2, 4, 5]                  # layer 3's values take no part in the loss
+    sum((vals[i] * gys[i]).sum() for i in used).backward()
+    e64 = enc.double().requires_grad_(True)
+    P = [(m.weight.detach().double().requires_grad_(True), m.bias.detach().double().requires_grad_(True)) for m in lins]
+    v64 = [F.linear(e64, w, b).masked_fill(~mask[..., None], 0.0) for w, b in P]
+    sum((v64[i] * gys[i].double()).sum() for i in used).backward()
+    for i in range(nl):
+        assert (vals[i].double() - v64[i]).abs().max() < 2e-5, i
+    assert (e.grad.double() - e64.grad).abs().max() < 2e-4 * float(e64.grad.abs().max())
+    for i in used:
+        assert (lins[i].weight.grad.double() - P[i][0].grad).abs().max() < 2e-5 * float(P[i][0].grad.abs().max()) + 1e-3, i
+        assert (lins[i].bias.grad.double() - P[i][1].grad).abs().max() < 2e-5 * float(P[i][1].grad.abs().max()) + 1e-3, i
+    assert lins[3].weight.grad is None and lins[3].bias.grad is None
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_dropout_add_layer_norm_function_vs_torch(p):
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x, r, gy = (torch.randn(4, 200, 256, generator=g).to(DEV) for _ in range(3))
+    ln = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_(0, 0.1)
+    keep = (torch.rand(800, 256, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None
+    xg, rg = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    y = ops.dropout_add_layer_norm(xg, rg, ln, p, True, keep=keep)
+    y.backward(gy)
+    x64, r64 = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    w64, b64 = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+    d = x64 * keep.view(4, 200, 256).double() / (1 - p) if keep is not None else x64
+    y64 = F.layer_norm(r64 + d, (256,), w64, b64, ln.eps)
+    y64.backward(gy.double())
+    assert (y.double() - y64).abs().max() < 1e-5
+    assert (xg.grad.double() - x64.grad).abs().max() < 2e-5 and (rg.grad.double() - r64.grad).abs().max() < 2e-5
+    assert (ln.weight.grad.double() - w64.grad).abs().max() < 1e-4 * float(w64.grad.abs().max())
+    assert (ln.bias.grad.double() - b64.grad).abs().max() < 1e-4 * float(b64.grad.abs().max())
+    # eval mode / no_grad: the plain composition (no dropout)
+    with torch.no_grad():
+        y_eval = ops.dropout_add_layer_norm(x, r, ln, p, False)
+    assert (y_eval - ln(r + x)).abs().max() < 1e-5
