@@ -43,6 +43,9 @@ def column_sum(g):
 
 
 def main():
+    if os.environ.get("EGTR_LIB"):          # A/B of kernel builds: another build of libegtr_hip.so
+        from egtr_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(os.environ["EGTR_LIB"])
     from egtr_amd import ops, runtime
     if len(sys.argv) > 1 and sys.argv[1] == "tune":
         runtime.enable_gemm_tuning()

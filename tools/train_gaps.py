@@ -125,15 +125,15 @@ def family(n):
              ("gemm_split_bf16", "egtr: split-bf16 GEMM (token linears fwd / dgrad)"),
              ("wgrad_", "egtr: split-bf16 weight gradient"), ("tile_weights", "egtr: weight re-tiling"),
              ("ffn_x6|proj_x6|enc_", "egtr: encoder row-panel kernels"),
-             ("rel_head|rel_loss|det_loss|hungarian", "egtr: relation head / losses / matcher"),
+             ("rel_head|rel_loss|conn_loss|det_loss|hungarian", "egtr: relation head / losses / matcher"),
              ("linear_skinny", "egtr: skinny linears"), ("self_attn", "egtr: decoder self-attention"),
              ("colsum|column_sum|weighted_col", "egtr: column sums (bias gradients, ReLU masks)"),
-             ("add_layernorm|layernorm", "egtr: LayerNorm fwd / bwd"), ("bias_act|maxpool|groupnorm|level_geom|sine_pos|clamp|nonfinite|box_decode|pad_batch",
+             ("add_layernorm|layernorm|partial_final", "egtr: LayerNorm fwd / bwd"), ("bias_act|maxpool|groupnorm|level_geom|sine_pos|clamp|nonfinite|box_decode|pad_batch",
                                                                      "egtr: other elementwise"),
              ("miopen|igemm|Sp3AsmConv|batched_transpose|SubTensorOp|gridwise|naive_conv|Im2Col|Col2Im|transpose_", "vendor: MIOpen convolutions + layout"),
              ("Cijk_|rocblas|hipblaslt", "vendor: rocBLAS / hipBLASLt GEMM"),
              ("multi_tensor_apply|FusedOptimizer|lpnorm", "ATen: optimizer / clip (multi-tensor)"),
-             ("fused_dropout|masked_scale", "ATen: dropout"), ("at::native", "ATen: elementwise / reduce / copy / index"),
+             ("fused_dropout|masked_scale|bernoulli", "ATen: dropout"), ("at::native", "ATen: elementwise / reduce / copy / index"),
              ("rocclr", "runtime: copy / fill")]
     for pat, name in rules:
         if re.search(pat, n):
@@ -154,6 +154,7 @@ def report(jpath, db):
     wall_tr = [0.0] * 4
     fam = {}
     fam_n = {}
+    kern = {}
     gaps = []
     for s in range(nsteps):
         for k in range(4):
@@ -165,6 +166,9 @@ def report(jpath, db):
                 f = family(n)
                 fam[f] = fam.get(f, 0.0) + (en - st)
                 fam_n[f] = fam_n.get(f, 0) + 1
+                k = kern.setdefault(n, [0, 0.0])
+                k[0] += 1
+                k[1] += en - st
                 if st > cur_end:
                     gaps.append((st - cur_end, k, n))
                 cur_end = max(cur_end, en)
@@ -197,8 +201,14 @@ def report(jpath, db):
     for f, v in sorted(fam.items(), key=lambda kv: -kv[1]):
         print(f"  {v / nsteps / 1e6:7.3f} ms {fam_n[f] / nsteps:7.1f}  {f}")
     print()
+    print("kernels of one step (traced run, averages over the steps; name, launches per step, us per launch, ms per step, % of kernel time):")
+    tot = sum(v[1] for v in kern.values())
+    for nm, (cnt, dur) in sorted(kern.items(), key=lambda kv: -kv[1][1])[:60]:
+        print(f"  {re.sub(r'^void ', '', re.sub(r'.anonymous namespace.::', '', nm))[:100]:100s} {cnt / nsteps:7.1f} {dur / cnt / 1e3:9.1f} "
+              f"{dur / nsteps / 1e6:8.3f} {100.0 * dur / tot:6.2f}")
+    print()
     print("largest GPU-idle gaps of the TRACED run (tracer-inflated; orientation only), us / phase / next kernel:")
-    for d, k, nm in sorted(gaps, reverse=True)[:25]:
+    for d, k, nm in sorted(gaps, reverse=True)[:12]:
         print(f"  {d / 1e3:8.1f}  {PHASES[k][:24]:24s} {family(nm)[:40]:40s} {re.sub(r'^void ', '', nm)[:80]}")
 
 
