@@ -207,6 +207,8 @@ def decoder_self_attention(q, k, v, num_heads, want_maps=True):
 
 
 SKINNY_BACKWARD_FUSED = os.environ.get("EGTR_SKINNY_BACKWARD", "1") != "0"
+# token-sized linears under autograd through TokenLinearFunction (split-bf16 forward / data / weight gradients); "0": plain autograd
+TOKEN_LINEAR = os.environ.get("EGTR_TOKEN_LINEAR", "1") != "0"
 SKINNY_MAX_ROWS = 4096  # above this the vendor GEMM (rocBLAS / hipBLASLt) fills the chip and is the right tool
 
 
@@ -284,7 +286,7 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
         y = torch._addmm_activation(bias, x.reshape(-1, x.shape[-1]), weight.t(), use_gelu=False)
         return y.view(*x.shape[:-1], weight.shape[0])
     if (alpha == 1.0 and bias is not None and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
-            and rows > SKINNY_MAX_ROWS and torch.is_grad_enabled() and os.environ.get("EGTR_TOKEN_LINEAR", "1") == "1"
+            and rows > SKINNY_MAX_ROWS and torch.is_grad_enabled() and TOKEN_LINEAR
             and (x.requires_grad or weight.requires_grad or bias.requires_grad)):
         return TokenLinearFunction.apply(x, weight, bias, relu)   # training, token-sized: bias gradient in one HIP pass
     y = torch.nn.functional.linear(x, weight, bias)

@@ -294,10 +294,7 @@ def test_stress_geometry_bf16_vs_reference_with_bf16_weights(golden_dir):
     assert dp.max() < 0.045 and dp.mean() < 0.003      # measured 0.028 / 0.0018
 
 
-def test_train_step_600x1000_bs2_aux_vs_reference(golden_dir):
-    """One train-mode step at the bench geometry (600x1000, N=200, 6+6 layers, bs=2 with a padded image, auxiliary
-    losses ON, dropout 0): every loss-dict entry, the total, and gradient norms / two full gradients against the
-    reference fixture (sgg_full_train.npz)."""
+def _train_step_600x1000_bs2_aux(golden_dir):
     g = Hh.load_golden(golden_dir, "sgg_full_train.npz")
     cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
     model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
@@ -324,6 +321,31 @@ def test_train_step_600x1000_bs2_aux_vs_reference(golden_dir):
         if k.startswith("grad::"):
             ref_g = _t(g[k])
             assert (params[k[6:]].grad.cpu() - ref_g).abs().max() < 5e-3 * max(1.0, float(ref_g.abs().max())), k
+
+
+def test_train_step_600x1000_bs2_aux_vs_reference(golden_dir):
+    """One train-mode step at the bench geometry (600x1000, N=200, 6+6 layers, bs=2 with a padded image, auxiliary
+    losses ON, dropout 0): every loss-dict entry, the total, and gradient norms / two full gradients against the
+    reference fixture (sgg_full_train.npz)."""
+    _train_step_600x1000_bs2_aux(golden_dir)
+
+
+@pytest.mark.parametrize("module,switch", [("ops", "ENCODER_TRAIN_FUSED"), ("ops", "TOKEN_LINEAR"), ("ops", "GEMM_SPLIT_WGRAD"),
+                                           ("ops", "MSDA_GEOMETRY"), ("ops", "SKINNY_BACKWARD_FUSED"),
+                                           ("ops", "GEMM_SPLIT_BF16")])
+def test_train_step_with_each_training_fusion_switched_off_vs_reference(golden_dir, module, switch, monkeypatch):
+    """The training twin of test_full_size_with_each_fusion_switched_off_vs_reference: every training-path fusion has a switch
+    (EGTR_<...>=0) that restores the composition it replaced, and that route must hold the reference's 600x1000 train
+    fixture too.  ENCODER_TRAIN_FUSED off exposes the per-op route of rounds 2 / 3, on which the other switches act -- so each
+    of them is flipped together with it.  (EGTR_BACKBONE_TRAIN_FUSED has its own two-route test:
+    test_bottleneck_training_fused_epilogue_matches_reference_order; the fixture's backbone is the stub.)"""
+    import egtr_amd.backbone as backbone
+    from egtr_amd import ops
+    mod = {"ops": ops, "backbone": backbone}[module]
+    assert getattr(mod, switch) is True
+    monkeypatch.setattr(ops, "ENCODER_TRAIN_FUSED", False)
+    monkeypatch.setattr(mod, switch, False)
+    _train_step_600x1000_bs2_aux(golden_dir)
 
 
 def test_resnet50_model_runs_and_is_deterministic():

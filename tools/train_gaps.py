@@ -166,9 +166,9 @@ def report(jpath, db):
                 f = family(n)
                 fam[f] = fam.get(f, 0.0) + (en - st)
                 fam_n[f] = fam_n.get(f, 0) + 1
-                k = kern.setdefault(n, [0, 0.0])
-                k[0] += 1
-                k[1] += en - st
+                kk = kern.setdefault(n, [0, 0.0])
+                kk[0] += 1
+                kk[1] += en - st
                 if st > cur_end:
                     gaps.append((st - cur_end, k, n))
                 cur_end = max(cur_end, en)
