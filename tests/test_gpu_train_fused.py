@@ -34,7 +34,7 @@ def _layer(seed=0, dropout=0.1):
     return layer.to(DEV).train()
 
 
-def _inputs(B, seed=1):
+def _inputs(B, seed=1, SHAPES=SHAPES):
     g = torch.Generator().manual_seed(seed)
     S = sum(h * w for h, w in SHAPES)
     x = torch.randn(B, S, 256, generator=g)
@@ -143,12 +143,16 @@ def test_encoder_layer_train_node_vs_float64_reference(B, p):
     assert len(exact) >= 4, report      # the gradients behind the last LayerNorm see none of those points: fp32-exact
 
 
-def test_encoder_layer_train_node_equals_the_per_op_composition(monkeypatch):
+@pytest.mark.parametrize("B,shapes", [(2, SHAPES), (4, [(100, 167), (50, 84), (25, 42), (13, 21)])])
+def test_encoder_layer_train_node_equals_the_per_op_composition(monkeypatch, B, shapes):
     """Same layer, same inputs, dropout 0: the fused node against the round-2 / 3 composition (TokenLinearFunction,
-    AddLayerNormFunction, MSDAGeometryFunction, clamp_nonfinite_) -- both fp32, the same split-bf16 products."""
+    AddLayerNormFunction, MSDAGeometryFunction, clamp_nonfinite_) -- both fp32, the same split-bf16 products.  Second case:
+    the reference's largest training geometry (800x1333, bs 4: 88 892 token rows -- more than 2 048 32-row blocks of
+    bias-gradient partials, the other branch of their final reduction)."""
     from egtr_amd import ops
+    SHAPES = shapes
     layer = _layer(dropout=0.0)
-    x, pos, ref, mask, shp, lsi, gy = _inputs(2)
+    x, pos, ref, mask, shp, lsi, gy = _inputs(B, SHAPES=shapes)
     res = []
     for fused in (True, False):
         monkeypatch.setattr(ops, "ENCODER_TRAIN_FUSED", fused)
