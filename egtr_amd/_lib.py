@@ -70,6 +70,7 @@ SIGNATURES = {
     "egtr_linear_split_bf16_wgrad_workspace_floats": [_I, _I, _I],
     "egtr_gemm_split_tile_weights_f32": [_P, _P, _I, _I, _I, _I, _P],
     "egtr_gemm_split_tile_weights_pair_f32": [_P, _P, _I, _I, _I, _P],
+    "egtr_gemm_split_tile_weights_multi_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "egtr_linear_split_bf16_grouped_pos_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "egtr_linear_split_bf16_ex_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "egtr_linear_split_bf16_wgrad_ex_f32": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _P, _I, _P],

@@ -516,7 +516,75 @@ __global__ __launch_bounds__(256) void tile_weights_f32(const float* __restrict_
   o[2 * kBN * kBK] = (unsigned short)lo;
 }
 
+// Several weights in ONE launch (a training step re-tiles every encoder weight after each optimizer step: 5 launches + 2
+// concatenations per layer before): problem i = the pair tiling (W and W^T) of a [N_i, K_i] weight whose first `split` rows come
+// from w and the rest from w2 (the offsets | attention-weights projection as one [384, 256] weight without a materialised cat).
+constexpr int kMaxTileProblems = 8;
+struct TileProblem {
+  const float* w;
+  const float* w2;
+  unsigned short* out;
+  int ldw, ldw2, split, N, K, first_block;
+};
+struct TileProblems {
+  TileProblem p[kMaxTileProblems];
+};
+__global__ __launch_bounds__(256) void tile_weights_multi_f32(TileProblems P, int nprob) {
+  int pi = 0;
+  while (pi + 1 < nprob && (int)blockIdx.x >= P.p[pi + 1].first_block) ++pi;
+  const TileProblem& T = P.p[pi];
+  int idx = ((int)blockIdx.x - T.first_block) * 256 + threadIdx.x;
+  int N = T.N, K = T.K;
+  unsigned short* out = T.out;
+  const bool transposed = idx >= N * K;   // second half: the tiling of W^T [K, N] behind the first one
+  if (transposed) {
+    idx -= N * K;
+    out += (size_t)3 * N * K;
+    const int t = N;
+    N = K;
+    K = t;
+  }
+  if (idx >= N * K) return;
+  const int kk = idx & 31, nn = (idx >> 5) & 127, blk = idx >> 12;
+  const int ktiles = K / kBK, kt = blk % ktiles, nt = blk / ktiles;
+  const int n = nt * kBN + nn, k = kt * kBK + kk;
+  const int r = transposed ? k : n, c = transposed ? n : k;   // element (r, c) of the untransposed weight
+  const float x = r < T.split ? T.w[(size_t)r * T.ldw + c] : T.w2[(size_t)(r - T.split) * T.ldw2 + c];
+  const unsigned hi = bf16_rne(x);
+  const float r1 = x - __uint_as_float(hi << 16);
+  const unsigned mid = bf16_rne(r1);
+  const unsigned lo = bf16_rne(r1 - __uint_as_float(mid << 16));
+  unsigned short* o = out + (size_t)blk * (3 * kBN * kBK) + nn * kBK + kk;
+  o[0] = (unsigned short)hi;
+  o[kBN * kBK] = (unsigned short)mid;
+  o[2 * kBN * kBK] = (unsigned short)lo;
+}
+
 }  // namespace
+
+extern "C" int egtr_gemm_split_tile_weights_multi_f32(egtr_stream_t stream, int num_weights, const float* const* w,
+                                                      const int* ldw, const float* const* w2, const int* ldw2,
+                                                      const int* split_rows, const int* N, const int* K,
+                                                      uint16_t* const* w_tiled_pair) {
+  if (!w || !ldw || !N || !K || !w_tiled_pair || num_weights <= 0 || num_weights > kMaxTileProblems) return EGTR_E_ARG;
+  TileProblems P = {};
+  long long blocks = 0;
+  for (int i = 0; i < num_weights; ++i) {
+    const float* second = w2 != nullptr ? w2[i] : nullptr;
+    const int split = second != nullptr ? split_rows[i] : N[i];
+    if (!w[i] || !w_tiled_pair[i] || N[i] <= 0 || K[i] <= 0 || ldw[i] < K[i] || split <= 0 || split > N[i] ||
+        (second != nullptr && (!ldw2 || ldw2[i] < K[i])))
+      return EGTR_E_ARG;
+    if (N[i] % kBN != 0 || K[i] % kBN != 0 || (long long)N[i] * K[i] > (1LL << 29)) return EGTR_E_UNSUPPORTED;
+    P.p[i] = TileProblem{w[i], second, reinterpret_cast<unsigned short*>(w_tiled_pair[i]), ldw[i], second ? ldw2[i] : 0, split,
+                         N[i], K[i], (int)blocks};
+    blocks += 2 * ((long long)N[i] * K[i] / 256);
+  }
+  if (blocks >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(tile_weights_multi_f32, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), P,
+                     num_weights);
+  return egtr_check_launch();
+}
 
 extern "C" int egtr_linear_split_bf16_f32(egtr_stream_t stream, const float* x, int ldx, const uint16_t* w_tiled,
                                           const float* bias, float* y, int ldy, int M, int K, int N, int relu) {

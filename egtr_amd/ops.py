@@ -529,15 +529,13 @@ class EncoderLayerTrainFunction(Function):
         if keep_rows is not None:
             rk = keep_rows.reshape(-1).contiguous()
             rk = rk.view(torch.uint8) if rk.dtype == torch.bool else rk.to(torch.uint8)
-        wb = torch.cat([so_w.detach(), aw_w.detach()], 0)
         bb = torch.cat([so_b.detach(), aw_b.detach()], 0)
-        wt_v, wtT_v = gemm_split_tile_pair(vp_w)
-        wt_b, wtT_b = gemm_split_tile_pair(wb)
-        wt_o, wtT_o = gemm_split_tile_pair(op_w)
-        wt_1, wtT_1 = gemm_split_tile_pair(fc1_w)
-        wt_2, wtT_2 = gemm_split_tile_pair(fc2_w)
+        # every weight of the layer (and its transpose, for the data gradients) into the GEMM's operand stream: one launch;
+        # sampling_offsets | attention_weights as ONE [384, 256] weight without a materialised concatenation
+        (wt_v, wtT_v), (wt_b, wtT_b), (wt_o, wtT_o), (wt_1, wtT_1), (wt_2, wtT_2) = gemm_split_tile_pairs(
+            [vp_w, (so_w, aw_w), op_w, fc1_w, fc2_w])
         F1 = fc1_w.shape[0]
-        nb = wb.shape[0]
+        nb = so_w.shape[0] + aw_w.shape[0]
         n_off = so_w.shape[0]
         # value projection (padded rows zeroed in the epilogue) + offsets / logits projection of x + pos: one launch
         value, both = linear_split_ex([dict(x=x2, wt=wt_v, N=D, b=vp_b.detach(), row_keep=rk),
@@ -643,7 +641,9 @@ class DecoderValueProjTrainFunction(Function):
         if keep_rows is not None:
             rk = keep_rows.reshape(-1).contiguous()
             rk = rk.view(torch.uint8) if rk.dtype == torch.bool else rk.to(torch.uint8)
-        tiles = [gemm_split_tile_pair(w) for w in ws]
+        tiles = []
+        for i0 in range(0, nl, 8):
+            tiles += gemm_split_tile_pairs(list(ws[i0:i0 + 8]))
         outs = []
         for i0 in range(0, nl, 8):
             outs += linear_split_ex([dict(x=x2, wt=tiles[i][0], N=D, b=bs[i].detach(), row_keep=rk)
@@ -1059,6 +1059,37 @@ def gemm_split_tile_pair(weight):
     st = lib.egtr_gemm_split_tile_weights_pair_f32(_stream(), w.data_ptr(), w.stride(0), N, K, out.data_ptr())
     _lib.check(st, "egtr_gemm_split_tile_weights_pair_f32")
     return out[0].view(N // 128, K // 32, 3, 128, 32), out[1].view(K // 128, N // 32, 3, 128, 32)
+
+
+def gemm_split_tile_pairs(weights):
+    """[(tiling of W, tiling of W^T)] for up to 8 weights in ONE launch (egtr_gemm_split_tile_weights_multi_f32).  An entry
+    is a [N, K] tensor or a pair (w_a, w_b) of tensors with the same K: the row-wise concatenation [w_a; w_b] tiled as one
+    weight without materialising it.  N, K multiples of 128."""
+    import ctypes
+    lib = _lib.lib()
+    n = len(weights)
+    P, I = ctypes.c_void_p, ctypes.c_int
+    w1, w2, ld1, ld2, split, Ns, Ks, outs = [], [], [], [], [], [], [], []
+    for e in weights:
+        a, b = (e if isinstance(e, (tuple, list)) else (e, None))
+        a = a.detach()
+        b = b.detach() if b is not None else None
+        for t in (a, b):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1):
+                raise RuntimeError("gemm_split_tile_pairs: 2-d float32 device tensors with unit inner stride expected")
+        N, K = a.shape[0] + (b.shape[0] if b is not None else 0), a.shape[1]
+        if b is not None and b.shape[1] != K:
+            raise RuntimeError("gemm_split_tile_pairs: concatenated weights must share K")
+        out = torch.empty(2, 3 * N * K, dtype=torch.bfloat16, device=a.device)
+        w1.append(a.data_ptr()); ld1.append(a.stride(0)); split.append(a.shape[0])
+        w2.append(b.data_ptr() if b is not None else None); ld2.append(b.stride(0) if b is not None else 0)
+        Ns.append(N); Ks.append(K); outs.append(out)
+    st = lib.egtr_gemm_split_tile_weights_multi_f32(
+        _stream(), n, (P * n)(*w1), (I * n)(*ld1), (P * n)(*w2), (I * n)(*ld2), (I * n)(*split), (I * n)(*Ns), (I * n)(*Ks),
+        (P * n)(*[o.data_ptr() for o in outs]))
+    _lib.check(st, "egtr_gemm_split_tile_weights_multi_f32")
+    return [(o[0].view(N // 128, K // 32, 3, 128, 32), o[1].view(K // 128, N // 32, 3, 128, 32))
+            for o, N, K in zip(outs, Ns, Ks)]
 
 
 def linear_split_bf16_wgrad(g, x):

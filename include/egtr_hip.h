@@ -424,6 +424,15 @@ int egtr_gemm_split_tile_weights_f32(egtr_stream_t stream, const float* w, int l
 /* Both streams of W [N, K] in one launch: w_tiled_pair = [tiling of W (3 N K) | tiling of W^T (3 N K)] (N, K % 128 == 0). */
 int egtr_gemm_split_tile_weights_pair_f32(egtr_stream_t stream, const float* w, int ldw, int N, int K,
                                           uint16_t* w_tiled_pair);
+/* The pair tilings of up to 8 weights in ONE launch (a training step re-tiles every encoder weight after each optimizer
+ * step).  Weight i is [N[i], K[i]] (both multiples of 128): its first split_rows[i] rows are read from w[i] (row stride
+ * ldw[i]) and the remaining rows from w2[i] (row stride ldw2[i]) -- two nn.Linear weights applied to the same input, e.g.
+ * sampling_offsets | attention_weights (model/deformable_detr.py:1053-1058), tiled as ONE weight without a materialised
+ * concatenation; w2 == NULL or w2[i] == NULL: a single source.  w_tiled_pair[i]: 6 N K bf16, as the pair entry writes them.
+ * All arrays are HOST arrays. */
+int egtr_gemm_split_tile_weights_multi_f32(egtr_stream_t stream, int num_weights, const float* const* w, const int* ldw,
+                                           const float* const* w2, const int* ldw2, const int* split_rows, const int* N,
+                                           const int* K, uint16_t* const* w_tiled_pair);
 
 /* Weight gradient of such a layer in training: grad_weight [N, K] (contiguous) = g[M, N]^T . x[M, K] (row strides ldg,
  * ldx), same split arithmetic; the M rows are cut into chunks whose 128 x 128 partial products go through `workspace`

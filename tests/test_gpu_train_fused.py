@@ -317,3 +317,19 @@ def test_dropout_add_layer_norm_function_vs_torch(p):
     with torch.no_grad():
         y_eval = ops.dropout_add_layer_norm(x, r, ln, p, False)
     assert (y_eval - ln(r + x)).abs().max() < 1e-5
+
+
+def test_multi_weight_tiling_equals_the_single_weight_entries():
+    """egtr_gemm_split_tile_weights_multi_f32: several weights (one of them a virtual row-wise concatenation of two) tiled in
+    one launch -- bit-identical to tiling each (materialised) weight with the pair entry."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(41)
+    w_a = torch.randn(256, 256, generator=g).to(DEV)
+    w_b = torch.randn(128, 256, generator=g).to(DEV)
+    w_c = torch.randn(1024, 256, generator=g).to(DEV)
+    w_d = torch.randn(256, 1024, generator=g).to(DEV)[:, :]
+    got = ops.gemm_split_tile_pairs([w_a, (w_a, w_b), w_c, w_d])
+    want = [ops.gemm_split_tile_pair(w) for w in (w_a, torch.cat([w_a, w_b], 0), w_c, w_d)]
+    for (g0, g1), (w0, w1) in zip(got, want):
+        assert g0.shape == w0.shape and g1.shape == w1.shape
+        assert torch.equal(g0.view(torch.int16), w0.view(torch.int16)) and torch.equal(g1.view(torch.int16), w1.view(torch.int16))
