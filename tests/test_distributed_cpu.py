@@ -115,6 +115,33 @@ def _worker(rank, world, port, out_path):
         o = model(pixel_values=_batch(300 + rank)["pixel_values"], pixel_mask=_batch(300 + rank)["pixel_mask"],
                   output_attention_states=True)
     res["pred_rel_sum"] = float(o.pred_rel.double().sum())
+    # a cost matrix refused by the device matcher on ONE rank (simulated: the CPU matcher is scipy and raises by itself) must
+    # reach every rank: the 4-byte flag is all-reduced (MAX) so that the replicas skip / stop together
+    from egtr_amd.deformable_detr import _STEP_MATCHER_STATUS
+    _STEP_MATCHER_STATUS.append(torch.tensor([0, 1 if rank == 1 else 0], dtype=torch.int32))
+    res["refused_flag"] = float(tr._refused_flag())
+    _STEP_MATCHER_STATUS.append(torch.zeros(2, dtype=torch.int32))
+    res["clean_flag"] = float(tr._refused_flag())
+    res["no_status_flag"] = tr._refused_flag() is None
+    # ... and with an optimizer that has no device-side skip (SGD here) the step is stopped on EVERY rank before the weights move
+    model.train()
+    before = float(sum(p.detach().double().sum() for p in model.parameters()))
+    tr._micro = 1                                  # the next micro-step is the accumulation boundary
+    orig_common = tr.common_step
+
+    def common_with_refusal(batch):
+        out_ = orig_common(batch)
+        _STEP_MATCHER_STATUS.append(torch.tensor([2 if rank == 1 else 0], dtype=torch.int32))
+        return out_
+
+    tr.common_step = common_with_refusal
+    try:
+        tr.training_step(_batch(400 + rank))
+        res["raised"] = False
+    except ValueError:
+        res["raised"] = True
+    res["psum_unchanged"] = float(sum(p.detach().double().sum() for p in model.parameters())) == before
+    res["grads_cleared"] = all(p.grad is None for p in model.parameters())
     with open(f"{out_path}.{rank}", "w") as f:
         json.dump(res, f)
     dist.barrier()
@@ -131,6 +158,9 @@ def test_ddp_two_ranks_matches_single_process(tmp_path):
     assert abs(r[0]["psum"] - r[1]["psum"]) < 1e-6 * max(1.0, abs(r[0]["psum"]))
     assert abs(r[0]["gnorm"] - r[1]["gnorm"]) < 1e-6 * r[0]["gnorm"] and r[0]["g_gate"] == r[1]["g_gate"]
     assert "rel_gate_0" in r[0]["keys"] and "loss_rel" in r[0]["keys"]
+    for k in range(world):   # the refusal of rank 1 is seen by both ranks; the step stops on both, weights intact
+        assert r[k]["refused_flag"] == 1.0 and r[k]["clean_flag"] == 0.0 and r[k]["no_status_flag"], r[k]
+        assert r[k]["raised"] and r[k]["psum_unchanged"] and r[k]["grads_cleared"], r[k]
     # single-process reference: same 4 micro-batches, gradient = mean over ranks of (sum over micro-steps / accumulate)
     model = _build()
     total = None
