@@ -55,6 +55,31 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   load_geom(shapes, lsi, L, G);
   const TileMap tm = make_tile_map(G, L, Lq);
   const int nwork = B * tm.ntiles * 8;
+  // A is zero whenever a chunk starts building it: zeroed once here, and every element a chunk filled is zeroed again by the
+  // lane that consumed it in the MFMA phase (round 4: the 115 KB zero pass per chunk and its barrier are gone)
+  for (int e = tid; e < kTQ * kChunk / 4; e += kThreads) reinterpret_cast<float4*>(s_A)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // operands of the NEXT work item are requested while the current one is multiplied out (round 4: the loads of loc / attn /
+  // grad_out were exposed at the top of every item, with one workgroup per CU nothing else runs meanwhile)
+  float4 lc_n = make_float4(9.f, 9.f, 9.f, 9.f), go_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 aw_n = make_float2(0.f, 0.f);
+  auto fetch = [&](int work_) {
+    lc_n = make_float4(9.f, 9.f, 9.f, 9.f);
+    aw_n = make_float2(0.f, 0.f);
+    go_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (work_ < nwork) {
+      const int head_ = work_ & 7, t_ = work_ >> 3;
+      const int b_ = t_ % B, tile_ = tm.ntiles - 1 - t_ / B;   // same order as the main loop below
+      const int q_ = tile_query(tm, G, tile_, ql, Lq);
+      if (q_ >= 0) {
+        const size_t qh = ((size_t)b_ * Lq + q_) * 8 + head_;
+        lc_n = reinterpret_cast<const float4*>(loc + qh * 32)[c4];
+        aw_n = reinterpret_cast<const float2*>(attn + qh * 16)[c4];
+        go_n = reinterpret_cast<const float4*>(grad_out + qh * 32)[c4];
+      }
+    }
+  };
+  fetch(blockIdx.x);
 
   for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
     // head = XCD: workgroups are dealt to the eight XCDs round-robin by id and the grid is a multiple of 8, so work & 7 ==
@@ -64,8 +89,11 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
     // improved is eight sources no longer interleaving their requests to the same lines.
     const int head = work & 7;
     const int t = work >> 3;
-    const int b = t / tm.ntiles, tile = t - b * tm.ntiles;
-    const int q = tile_query(tm, G, tile, ql, Lq);
+    // Largest items first: the tile list is ordered level 0 ... level 3 and the window of a coarse-level tile is many times
+    // that of a level-0 tile (1 chunk against ~10), so the work ids walk the tiles BACKWARDS, the images interleaved -- with the
+    // round-robin assignment every workgroup then gets one item of each size band instead of the big ones arriving last
+    // (round 4: 143.7 -> see DESIGN 4.2 at B = 1, where a workgroup has only ~7 items).
+    const int b = t % B;
     char* gvbase = reinterpret_cast<char*>(grad_value) + (size_t)b * S * 1024;
 
     if (tid < 16) s_bbox[tid] = (tid & 1) ? INT_MIN : INT_MAX;
@@ -79,15 +107,9 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
     bool any[2];
     int ymin = INT_MAX, ymax = INT_MIN, xmin = INT_MAX, xmax = INT_MIN;
     {
-      float4 lc = make_float4(9.f, 9.f, 9.f, 9.f);
-      float2 aw = make_float2(0.f, 0.f);
-      float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q >= 0) {
-        const size_t qh = ((size_t)b * Lq + q) * 8 + head;
-        lc = reinterpret_cast<const float4*>(loc + qh * 32)[c4];
-        aw = reinterpret_cast<const float2*>(attn + qh * 16)[c4];
-        go = reinterpret_cast<const float4*>(grad_out + qh * 32)[c4];
-      }
+      const float4 lc = lc_n, go = go_n;
+      const float2 aw = aw_n;
+      fetch(work + gridDim.x);   // in flight until the next iteration reads lc_n / aw_n / go_n
       s_T[ql * 8 + c4] = go;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -156,13 +178,8 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
     for (int k0 = 0; k0 < ntot; k0 += kChunk) {
       const int ncols = min(kChunk, ntot - k0);
       const int mtiles = (ncols + 31) >> 5;
-      __syncthreads();  // records visible (first chunk) / previous chunk's MFMA reads of A and s_pix finished
+      __syncthreads();  // records visible (first chunk) / previous chunk's MFMA phase (reads + re-zeroing of A, s_pix) finished
       {
-        const int ncol4 = mtiles * 8;
-        for (int e = tid; e < kTQ * ncol4; e += kThreads) {
-          const int r = e / ncol4, c = e - r * ncol4;
-          reinterpret_cast<float4*>(s_A + r * kChunk)[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         if (tid < ncols) {  // global byte offset of chunk column `tid`
           const int p = k0 + tid;
           const int l = (p >= vb[1] ? 1 : 0) + (p >= vb[2] ? 1 : 0) + (p >= vb[3] ? 1 : 0);
@@ -175,19 +192,23 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
           s_pix[tid] = (stl + yy * Wl + xx) * 1024 + head * 128;
         }
       }
-      __syncthreads();
-      // build A: thread (q, level l = c4) owns the samples of level l of query q -> no cross-thread conflicts
-      if (c4 < L) {
+      // build A: the samples of level l of query q belong to TWO threads (c4 = 2 l, 2 l + 1): one adds the two top corners of
+      // every sample, the other the two bottom corners.  Within one instruction the two threads work on the SAME sample, whose
+      // top and bottom corners are different pixels whenever both carry weight (a clamped duplicate has weight 0 and is
+      // skipped), different queries are different rows of A and different levels disjoint column ranges: no two lanes of an
+      // instruction touch one element, and a wave's LDS operations execute in program order -- plain read-modify-writes, no
+      // atomics.  (Round 4: one thread per (query, level) did all four corners: a chain of 16 dependent LDS round trips.)
+      if ((c4 >> 1) < L) {
         float* arow = s_A + ql * kChunk;
+        const int lvl_b = c4 >> 1, bottom = c4 & 1;
         for (int pp = 0; pp < P; ++pp) {
-          const int2 v = s_vp[ql * kRecStride + c4 * P + pp];
-          const float4 w = s_w[ql * kRecStride + c4 * P + pp];
-          const unsigned c0 = (unsigned)((v.x & 0xffff) - k0), c1 = (unsigned)(((unsigned)v.x >> 16) - k0);
-          const unsigned c2 = (unsigned)((v.y & 0xffff) - k0), c3 = (unsigned)(((unsigned)v.y >> 16) - k0);
-          if (w.x != 0.f && c0 < (unsigned)ncols) arow[c0] += w.x;
-          if (w.y != 0.f && c1 < (unsigned)ncols) arow[c1] += w.y;
-          if (w.z != 0.f && c2 < (unsigned)ncols) arow[c2] += w.z;
-          if (w.w != 0.f && c3 < (unsigned)ncols) arow[c3] += w.w;
+          const int2 v = s_vp[ql * kRecStride + lvl_b * P + pp];
+          const float4 w = s_w[ql * kRecStride + lvl_b * P + pp];
+          const int vv = bottom ? v.y : v.x;
+          const float wa = bottom ? w.z : w.x, wb = bottom ? w.w : w.y;
+          const unsigned ca = (unsigned)((vv & 0xffff) - k0), cb = (unsigned)(((unsigned)vv >> 16) - k0);
+          if (wa != 0.f && ca < (unsigned)ncols) arow[ca] += wa;
+          if (wb != 0.f && cb < (unsigned)ncols) arow[cb] += wb;
         }
       }
       __syncthreads();
@@ -198,12 +219,14 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-          const float* acol = s_A + mt * 32 + li;
+          float* acol = s_A + mt * 32 + li;
 #pragma unroll 8
           for (int s2 = 0; s2 < kTQ / 2; ++s2) {
             const int qq = 2 * s2 + hf;
             // D[i = pixel][j = channel] += A_op[i][k = qq] * B_op[k = qq][j]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(acol[qq * kChunk], tmat[qq * 32 + li], acc, 0, 0, 0);
+            const float av = acol[qq * kChunk];
+            acol[qq * kChunk] = 0.f;   // this lane is the element's only consumer: leave it zero for the next chunk / item
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tmat[qq * 32 + li], acc, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
