@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libegtr_hip.so")
+# EGTR_HIP_LIBRARY: another build of the same library (same-box A/B of kernel builds: tools/*_bench.py, bench.py); there is
+# still no fallback -- a path that does not exist raises like a missing in-tree build
+LIB_PATH = os.environ.get("EGTR_HIP_LIBRARY") or os.path.join(_HERE, "libegtr_hip.so")
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int

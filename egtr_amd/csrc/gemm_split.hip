@@ -290,7 +290,11 @@ int launch_grouped(hipStream_t st, const GemmProblems& P, int nprob, int M, int 
   // store phases), 64-row tiles otherwise.  (128-row tiles for the K = 1024 product too measured 46.0 vs 53.0 us stand-alone
   // but 262.6 vs 264.5 images/s in the forward, same box, alternating builds: not taken; again with the XCD-aware tile
   // order: 259.0 vs 262.8 / 261.5 images/s.)
-  if (tiles128 >= 512)
+  // Round 4: "fill the chip twice over" relaxed to 480 of the 512 workgroup slots.  The encoder layer's grouped launch at 600x1000
+  // (value 256 -> 256 + offsets / weights 256 -> 384, M = 12 537) has 490 128-row tiles = 980 64-row tiles: one nearly full round
+  // of the larger tiles beats 1.91 rounds of the smaller ones -- 42.9 -> 37.2 us per launch, 281.9 -> 284.7 images/s end to end
+  // (three alternations on one box, abl/infer_ab.sh).
+  if (tiles128 >= 480)
     hipLaunchKernelGGL(gemm_split_bf16_f32<128>, dim3((unsigned)tiles128), dim3(512), 0, st, P, nprob, M, K);
   else
     hipLaunchKernelGGL(gemm_split_bf16_f32<64>, dim3((unsigned)tiles64), dim3(512), 0, st, P, nprob, M, K);
