@@ -1200,6 +1200,25 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             mask_flatten, lvl_pos_embed_flatten, valid_ratios, encoder_reference_points = ops.level_geometry(
                 pixel_mask, spatial_shapes_list, self.level_embed, pos_mod.embedding_dim, pos_mod.temperature,
                 pos_mod.scale)
+        elif (ops.ENCODER_TRAIN_FUSED and pixel_mask.is_cuda and pixel_values.dtype == torch.float32
+              and self.level_embed.dtype == torch.float32 and isinstance(pos_mod, DeformableDetrSinePositionEmbedding)
+              and pos_mod.normalize and self.config.num_feature_levels <= 4 and self.config.d_model == 256):
+            # training: the input projections stay ordinary autograd modules; everything derived from pixel_mask alone (level
+            # masks, sine position embeddings + level_embed, valid ratios, encoder reference points) comes from the two HIP
+            # launches of the inference path, with the gradient of level_embed as four mask-weighted column sums
+            # (ops.LevelGeometryTrainFunction) instead of ~80 tiny launches and four generic reductions per step
+            conv_encoder = self.backbone.conv_encoder
+            if isinstance(conv_encoder, DeformableDetrTimmConvEncoder):
+                feature_maps = conv_encoder.model(pixel_values)
+            else:  # a user-supplied feature extractor: keep its (feature, mask) interface, drop its masks
+                feature_maps = [fm for fm, _ in conv_encoder(pixel_values, pixel_mask)]
+            sources = [self.input_proj[level](fm) for level, fm in enumerate(feature_maps)]
+            for level in range(len(sources), self.config.num_feature_levels):  # dd:2228-2241
+                sources.append(self.input_proj[level](feature_maps[-1] if level == len(feature_maps) else sources[-1]))
+            spatial_shapes_list = [tuple(src.shape[-2:]) for src in sources]
+            source_flatten = torch.cat([src.flatten(2).transpose(1, 2) for src in sources], 1)
+            mask_flatten, lvl_pos_embed_flatten, valid_ratios, encoder_reference_points = ops.level_geometry_train(
+                pixel_mask, spatial_shapes_list, self.level_embed, pos_mod.embedding_dim, pos_mod.temperature, pos_mod.scale)
         else:
             features, position_embeddings_list = self.backbone(pixel_values, pixel_mask)
             sources, masks = [], []

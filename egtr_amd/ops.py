@@ -1544,6 +1544,47 @@ def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, 
     return mask, pos, vr, ref
 
 
+class LevelGeometryTrainFunction(Function):
+    """``level_geometry`` under autograd: the position embeddings are sine(pixel_mask) + level_embed[level], so the only
+    gradient is d level_embed[l] = sum over the tokens of level l (all images) of d pos -- four mask-weighted column sums over the
+    [B * S, 256] gradient (egtr_weighted_column_sum_f32, ~13 us each) instead of autograd's cat-backward slices and generic
+    `sum` reductions (161 us for the largest level).  Replaces, in training, the per-level mask interpolation, sine embedding,
+    `+ level_embed`, cat, get_valid_ratio and get_reference_points compositions (model/deformable_detr.py:2195-2278, 1616-1648)
+    by the two launches the inference path uses."""
+
+    @staticmethod
+    def forward(ctx, level_embed, pixel_mask, spatial_shapes_list, embedding_dim, temperature, scale):
+        mask, pos, vr, ref = level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale)
+        ctx.shapes = (tuple(spatial_shapes_list), pos.shape[0])
+        ctx.mark_non_differentiable(mask, vr, ref)
+        return pos, mask, vr, ref
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_pos, g_mask, g_vr, g_ref):
+        shapes, B = ctx.shapes
+        g2 = _rows256(g_pos)
+        key = (shapes, B, str(g2.device))
+        w = _LEVEL_ROW_WEIGHTS.get(key)
+        if w is None:   # one-hot level membership of every token row, [L, B * S] floats: a constant of the geometry
+            sizes = [h * w_ for h, w_ in shapes]
+            lvl = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).repeat(B)
+            # (separate allocations: a row of one [L, B * S] tensor is 16-byte aligned only when B * S is a multiple of 4)
+            w = [(lvl == l).to(torch.float32).to(g2.device) for l in range(len(sizes))]
+            _LEVEL_ROW_WEIGHTS[key] = w
+        return torch.stack([weighted_column_sum(g2, wl) for wl in w]), None, None, None, None, None
+
+
+_LEVEL_ROW_WEIGHTS = {}
+
+
+def level_geometry_train(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale):
+    """(mask_flatten, lvl_pos_embed_flatten, valid_ratios, encoder reference points) with autograd through level_embed."""
+    pos, mask, vr, ref = LevelGeometryTrainFunction.apply(level_embed, pixel_mask, list(spatial_shapes_list), embedding_dim,
+                                                          temperature, scale)
+    return mask, pos, vr, ref
+
+
 class AddLayerNormFunction(Function):
     """LayerNorm(x + residual) over 256 channels in one pass (csrc/elementwise.hip).  Backward: one pass as well
     (egtr_add_layernorm_backward_f32: statistics recomputed from the saved inputs, gamma / beta gradients from

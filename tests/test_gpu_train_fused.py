@@ -333,3 +333,39 @@ def test_multi_weight_tiling_equals_the_single_weight_entries():
     for (g0, g1), (w0, w1) in zip(got, want):
         assert g0.shape == w0.shape and g1.shape == w1.shape
         assert torch.equal(g0.view(torch.int16), w0.view(torch.int16)) and torch.equal(g1.view(torch.int16), w1.view(torch.int16))
+
+
+def test_level_geometry_train_function_gradient_of_level_embed():
+    """ops.level_geometry_train: same outputs as the inference kernel, and d level_embed[l] = sum of d pos over the tokens of
+    level l (all images) -- against autograd of the explicit `pos + level_embed[level]` composition."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(51)
+    B, H, Wd = 2, 150, 200
+    shapes = [(19, 25), (10, 13), (5, 7), (3, 4)]     # S = 652: B * S * 4 bytes is not a multiple of 16 for B = 1, 3, ...
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    pm[1, 120:, :] = 0
+    pm[1, :, 170:] = 0
+    pm = pm.to(DEV)
+    le = torch.randn(4, 256, generator=g).to(DEV).requires_grad_(True)
+    mask, pos, vr, ref = ops.level_geometry_train(pm, shapes, le, 128, 10000, 2 * 3.141592653589793)
+    with torch.no_grad():
+        m0, p0, v0, r0 = ops.level_geometry(pm, shapes, le.detach(), 128, 10000, 2 * 3.141592653589793)
+    assert torch.equal(mask, m0) and torch.equal(pos.detach(), p0) and torch.equal(vr, v0) and torch.equal(ref, r0)
+    assert pos.requires_grad and not vr.requires_grad and not ref.requires_grad
+    gy = torch.randn(pos.shape, generator=g).to(DEV)
+    pos.backward(gy)
+    sizes = [h * w for h, w in shapes]
+    want, o = [], 0
+    for n in sizes:
+        want.append(gy[:, o:o + n].double().sum((0, 1)))
+        o += n
+    want = torch.stack(want).float()
+    assert (le.grad - want).abs().max() < 1e-3 * float(want.abs().max())
+    # an odd number of token rows (the per-level row weights must each be 16-byte aligned on their own)
+    le1 = le.detach().clone().requires_grad_(True)
+    shapes1 = [(19, 25), (10, 13), (5, 7), (3, 3)]
+    _, pos1, _, _ = ops.level_geometry_train(pm[:1], shapes1, le1, 128, 10000, 2 * 3.141592653589793)
+    assert pos1.shape[1] % 4 != 0
+    pos1.sum().backward()
+    want1 = torch.tensor([float(h * w) for h, w in shapes1], device=DEV)[:, None].expand(4, 256)
+    assert (le1.grad - want1).abs().max() < 1e-3
