@@ -444,6 +444,9 @@ def train_bench(args, world, rank, dev, dist, emit=True):
                        "token_linears": ("fp32 via bf16x6 operand split (forward, data and weight gradients)"
                                          if _train_switch("EGTR_TOKEN_LINEAR") and _train_switch("EGTR_GEMM_SPLIT_BF16")
                                          else "vendor fp32 GEMM"),
+                       "training_nodes": ("round-4 autograd nodes: encoder layer, decoder value projections, dropout + add + "
+                                          "LayerNorm, level geometry" if _train_switch("EGTR_ENCODER_TRAIN_FUSED")
+                                          else "per-op composition (EGTR_ENCODER_TRAIN_FUSED=0)"),
                        "gemm_tuning": bool(args.tune_gemm), "miopen_find": bool(torch.backends.cudnn.benchmark)}}
         if bwd_args is not None and not args.no_kernel_probes:
             us, alg = time_msda_backward(bwd_args)
