@@ -271,7 +271,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           s.z += __shfl_xor(s.z, o);
           s.w += __shfl_xor(s.w, o);
         }
-        if (li == 0) *reinterpret_cast<float4*>(colpart + (size_t)((m0 >> 5) + wm) * G.N + col) = s;
+        // (a 32-row block that starts at or beyond M does not exist in the [ceil(M / 32), N] buffer)
+        if (li == 0 && m0 + wm * 32 < M) *reinterpret_cast<float4*>(colpart + (size_t)((m0 >> 5) + wm) * G.N + col) = s;
       }
     }
 }

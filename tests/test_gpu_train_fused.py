@@ -240,9 +240,11 @@ def test_split_gemm_epilogue_options_and_wgrad_options_vs_float64():
     want = torch.where(keep.bool()[:, None], base, torch.zeros_like(base))
     want = torch.where(ref.double() > 0, want, torch.zeros_like(want)) + a1.double() + a2.double()
     out = a1.clone()           # add1 aliases the output
-    colp = torch.empty((M + 31) // 32, N, device=DEV)
+    guard = torch.full(((M + 31) // 32 + 4, N), 7.0, device=DEV)      # 4 canary rows behind the [ceil(M / 32), N] partials
+    colp = guard[:(M + 31) // 32]
     y = ops.linear_split_ex([dict(x=x, wt=wt, N=N, b=b, pos=pos, row_keep=keep, relu_ref=ref, add1=out, add2=a2, out=out,
                                   colpart=colp)], M, K)[0]
+    assert bool((guard[(M + 31) // 32:] == 7.0).all()), "column partials written beyond ceil(M / 32) rows"
     assert y.data_ptr() == out.data_ptr()
     assert (y.double() - want).abs().max() < 2e-4
     assert (colp.double().sum(0) - want.sum(0)).abs().max() < 2e-3 * float(want.sum(0).abs().max())
