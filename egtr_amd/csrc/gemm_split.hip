@@ -41,10 +41,14 @@ __device__ __forceinline__ f32x4v gload(const void* p) {
 }
 __device__ __forceinline__ void vm_wait0(f32x4v& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
 
-// exact truncation split (rel_head.hip): pieces as fp32 bit patterns with zero low halves
-// (xs_format.h: non-finite x keeps the inf / a quiet NaN in hi alone, mid = lo = 0 -- `x - hi` would be inf - inf)
+// exact truncation split (rel_head.hip): pieces as fp32 bit patterns with zero low halves.  xs::split3_fast (round 4; the
+// inf-safe xs::split3 until then): 4 VALU operations per element instead of 10 -- these kernels split every activation
+// element N / 128 times over, and the weight-gradient kernel both operands: 3-4.5 % off the forward / data-gradient products
+// and 8-9 % off the weight gradients at the training size (abl/gemm_fast.sh, two alternations on one box).  For a non-finite
+// element the lower pieces come out NaN (inf - inf), so ITS output row (weight gradient: its column) is NaN instead of a mix of
+// +-inf and NaN -- non-finite either way and nothing else is touched (tests/test_gpu_pinning.py).
 using Split3 = xs::Split3;
-__device__ __forceinline__ Split3 split3(float x) { return xs::split3(x); }
+__device__ __forceinline__ Split3 split3(float x) { return xs::split3_fast(x); }
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
 // A workgroup is 8 waves on a BM x 128 tile, BM = 128 (wave tile 32 x 64) or 64 (wave tile 32 x 32; chosen when 128-row
