@@ -404,8 +404,17 @@ __device__ __forceinline__ float group8_sum(float v) {
 }
 
 
-// fp32, M = 8, D = 32, L*P = 16.  One wave per query.  LDS record per (head, sample): three 16-byte entries:
-//   off[4] | {w-validity bits, lh, lw, attn} | {Wf, Hf, -, -}
+// fp32, M = 8, D = 32, L*P = 16.  One wave per query.  Per (head, sample) the wave keeps in LDS the four corner offsets
+// and THREE coefficient vectors over the corners, written once by the lane that owns the sample:
+//   A = masked bilinear weights, B = attn * W * {-hh, +hh, -lh, +lh} (masked), C = attn * H * {-hw, -lw, +hw, +lw} (masked).
+// With d_k = <grad_out[head, :], value[corner k, head, :]> (4 multiply-adds per lane + one 8-lane DPP reduction per
+// corner) the three gradients of the sample are  grad_attn = A.d,  grad_loc.x = B.d,  grad_loc.y = C.d  (cuh:108-158 with
+// the channel sum taken first): lanes 0 / 1 / 2 of the head's group read A / B / C and form one of them each.  (Round 4.
+// Until then every lane formed val / dh / dw per CHANNEL and three reductions followed: ~125 VALU instructions per
+// sample made the kernel VALU-bound at 200 us for B = 4; now ~35.)  Entries are swizzled (slot = sample ^ head) so that
+// the heads served by one ds_read_b128 pass use different banks without padding: 4 waves x 8 KiB = 32 KiB, five
+// workgroups per CU.  A sample's three results overwrite the x components of its own A / B / C (dead by then) and are
+// stored coalesced after the loop.
 // SPLIT > 1 (short query lists, e.g. the decoder's 200 queries per image): SPLIT waves share one query, each taking
 // 16 / SPLIT consecutive samples (= one level for SPLIT = 4), so that a B x 200-query call fills the chip (800 waves of
 // serial atomics -> 3200) -- every wave still builds all 16 records (cheap) but gathers / scatters only its own.
@@ -415,12 +424,10 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, int nq_total,
     int Lq, int S, int L, int P, int nblk) {
-  __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
-  __shared__ __attribute__((aligned(16))) float4 s_a[kWaves * kWaveEntries];   // {bits, lh, lw, attn}
-  __shared__ __attribute__((aligned(16))) float2 s_wh[kWaves * kWaveEntries];  // {W, H}
-  __shared__ __attribute__((aligned(16))) float s_gl[kWaves * 256];            // grad_loc staging
-  __shared__ __attribute__((aligned(16))) float s_ga[kWaves * 128];            // grad_attn staging
-  __shared__ __attribute__((aligned(16))) float s_go[VALUE_ATOMICS ? kWaves * 256 : 4];  // grad_out row, [head][32]
+  __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * 128];
+  __shared__ __attribute__((aligned(16))) float4 s_cf[kWaves * 128 * 3];                      // A | B | C per entry
+  __shared__ __attribute__((aligned(16))) float4 s_a[VALUE_ATOMICS ? kWaves * 128 : 1];      // {bits, lh, lw, attn}
+  __shared__ __attribute__((aligned(16))) float s_go[VALUE_ATOMICS ? kWaves * 256 : 4];      // grad_out row, [head][32]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = xcd_remap(blockIdx.x, nblk);
   const int gw = blk * kWaves + wave;
@@ -437,19 +444,31 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
   const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
   const int head_s = lane >> 3, s0 = (lane & 7) * 2;
-  int4* my_off = s_off + wave * kWaveEntries;
-  float4* my_a = s_a + wave * kWaveEntries;
-  float2* my_wh = s_wh + wave * kWaveEntries;
+  int4* my_off = s_off + wave * 128;
+  float4* my_cf = s_cf + wave * 128 * 3;
+  float4* my_a = s_a + (VALUE_ATOMICS ? wave * 128 : 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int s = s0 + j;
     const int lvl = s / P;
     const int H = SEL_H(G, lvl), W = SEL_W(G, lvl);
     const SampleGeom g = sample_geom<1024, 128>(j ? lc.z : lc.x, j ? lc.w : lc.y, H, W, SEL_S(G, lvl), head_s);
-    const int bits = (g.ok[0] ? 1 : 0) | (g.ok[1] ? 2 : 0) | (g.ok[2] ? 4 : 0) | (g.ok[3] ? 8 : 0);
-    my_off[head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
-    my_a[head_s * kHeadStride + s] = make_float4(__int_as_float(bits), g.lh, g.lw, j ? aw.y : aw.x);
-    my_wh[head_s * kHeadStride + s] = make_float2((float)W, (float)H);
+    const int e = head_s * 16 + (s ^ head_s);
+    const float a = j ? aw.y : aw.x;
+    const float aW = a * (float)W, aH = a * (float)H;  // the "* W" / "* H" of cuh:157-158
+    const float hh = 1.f - g.lh, hw = 1.f - g.lw;
+    my_off[e] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
+    // an out-of-range corner contributes 0 everywhere (cuh:121-150)
+    my_cf[e * 3 + 0] = make_float4(g.ok[0] ? g.w[0] : 0.f, g.ok[1] ? g.w[1] : 0.f, g.ok[2] ? g.w[2] : 0.f,
+                                   g.ok[3] ? g.w[3] : 0.f);
+    my_cf[e * 3 + 1] = make_float4(g.ok[0] ? -hh * aW : 0.f, g.ok[1] ? hh * aW : 0.f, g.ok[2] ? -g.lh * aW : 0.f,
+                                   g.ok[3] ? g.lh * aW : 0.f);
+    my_cf[e * 3 + 2] = make_float4(g.ok[0] ? -hw * aH : 0.f, g.ok[1] ? -g.lw * aH : 0.f, g.ok[2] ? hw * aH : 0.f,
+                                   g.ok[3] ? g.lw * aH : 0.f);
+    if (VALUE_ATOMICS) {
+      const int bits = (g.ok[0] ? 1 : 0) | (g.ok[1] ? 2 : 0) | (g.ok[2] ? 4 : 0) | (g.ok[3] ? 8 : 0);
+      my_a[e] = make_float4(__int_as_float(bits), g.lh, g.lw, a);
+    }
   }
   const int head = lane >> 3, c4 = lane & 7;
   const float4 g = reinterpret_cast<const float4*>(grad_out + (size_t)q * 256)[lane];
@@ -458,26 +477,15 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  const int4* ro = my_off + head * kHeadStride;
-  const float4* ra = my_a + head * kHeadStride;
-  const float2* rwh = my_wh + head * kHeadStride;
-  float* gl_stage = s_gl + wave * 256;
-  float* ga_stage = s_ga + wave * 128;
-#pragma unroll 2
+  const int which = c4 < 3 ? c4 : 0;  // lanes 0 / 1 / 2 of the group: grad_attn / grad_loc.x / grad_loc.y
+#pragma unroll 4
   for (int s = part * NS; s < (part + 1) * NS; ++s) {
-    const int4 o = ro[s];
-    const float4 a4 = ra[s];
-    const float2 wh = rwh[s];
-    const int bits = __float_as_int(a4.x);
-    const float lh = a4.y, lw = a4.z, a = a4.w, hh = 1.f - lh, hw = 1.f - lw;
-    const float m0 = (bits & 1) ? 1.f : 0.f, m1 = (bits & 2) ? 1.f : 0.f, m2 = (bits & 4) ? 1.f : 0.f,
-                m3 = (bits & 8) ? 1.f : 0.f;
-    float4 v0 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.x);
-    float4 v1 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.y);
-    float4 v2 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.z);
-    float4 v3 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.w);
-    // top = grad_out * attn (cuh:114)
-    const float4 top = make_float4(g.x * a, g.y * a, g.z * a, g.w * a);
+    const int e = head * 16 + (s ^ head);
+    const int4 o = my_off[e];
+    const float4 v0 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.x);
+    const float4 v1 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.y);
+    const float4 v2 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.z);
+    const float4 v3 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.w);
     if (VALUE_ATOMICS) {
       // grad_value scatter (cuh:125-152) in a lane = channel layout: one atomic instruction covers the 32 contiguous
       // channels of TWO heads = two whole 128-byte lines.  (Device-scope float atomics execute memory-side on this
@@ -487,8 +495,9 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int h2 = 2 * k + (lane >> 5), ch = lane & 31;
-        const int4 o2 = my_off[h2 * kHeadStride + s];
-        const float4 r2 = my_a[h2 * kHeadStride + s];
+        const int e2 = h2 * 16 + (s ^ h2);
+        const int4 o2 = my_off[e2];
+        const float4 r2 = my_a[e2];
         const int b2 = __float_as_int(r2.x);
         const float lh2 = r2.y, lw2 = r2.z, hh2 = 1.f - lh2, hw2 = 1.f - lw2;
         const float t2 = gs[h2 * 32 + ch] * r2.w;  // top = grad_out * attn (cuh:114)
@@ -498,47 +507,39 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
         if (b2 & 8) unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)o2.w) + ch, lh2 * lw2 * t2);
       }
     }
-    // masked corner values (an out-of-range corner contributes 0 everywhere, cuh:121-150)
-    v0.x *= m0; v0.y *= m0; v0.z *= m0; v0.w *= m0;
-    v1.x *= m1; v1.y *= m1; v1.z *= m1; v1.w *= m1;
-    v2.x *= m2; v2.y *= m2; v2.z *= m2; v2.w *= m2;
-    v3.x *= m3; v3.y *= m3; v3.z *= m3; v3.w *= m3;
-    float ga = 0.f, gw = 0.f, gh = 0.f;
-#define EGTR_ACC(C)                                                                    \
-    {                                                                                   \
-      const float val = hh * hw * v0.C + hh * lw * v1.C + lh * hw * v2.C + lh * lw * v3.C; \
-      const float dh = -hw * v0.C - lw * v1.C + hw * v2.C + lw * v3.C;                  \
-      const float dw = -hh * v0.C + hh * v1.C - lh * v2.C + lh * v3.C;                  \
-      ga += g.C * val;                                                                  \
-      gw += dw * top.C;                                                                 \
-      gh += dh * top.C;                                                                 \
-    }
-    EGTR_ACC(x) EGTR_ACC(y) EGTR_ACC(z) EGTR_ACC(w)
-#undef EGTR_ACC
-    ga = group8_sum(ga);
-    gw = group8_sum(gw) * wh.x;  // * W (cuh:157)
-    gh = group8_sum(gh) * wh.y;  // * H (cuh:158)
-    if (c4 == 0) {
-      ga_stage[head * 16 + s] = ga;
-      gl_stage[(head * 16 + s) * 2] = gw;
-      gl_stage[(head * 16 + s) * 2 + 1] = gh;
-    }
+    const float4 cf = my_cf[e * 3 + which];
+    float d0 = g.x * v0.x + g.y * v0.y + g.z * v0.z + g.w * v0.w;
+    float d1 = g.x * v1.x + g.y * v1.y + g.z * v1.z + g.w * v1.w;
+    float d2 = g.x * v2.x + g.y * v2.y + g.z * v2.z + g.w * v2.w;
+    float d3 = g.x * v3.x + g.y * v3.y + g.z * v3.z + g.w * v3.w;
+    d0 = group8_sum(d0);
+    d1 = group8_sum(d1);
+    d2 = group8_sum(d2);
+    d3 = group8_sum(d3);
+    const float r = cf.x * d0 + cf.y * d1 + cf.z * d2 + cf.w * d3;
+    // lanes 3..7 of a group repeat lane 0's result and store it to the same place: no branch in the loop, so the
+    // compiler can keep the next samples' gathers in flight
+    reinterpret_cast<float*>(my_cf + e * 3 + which)[0] = r;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // result of (head h, sample s), component c (0 = grad_attn, 1 / 2 = grad_loc x / y)
+  auto res = [&](int h, int s, int c) { return reinterpret_cast<const float*>(my_cf + (h * 16 + (s ^ h)) * 3 + c)[0]; };
   if (SPLIT == 1) {
-    reinterpret_cast<float4*>(grad_loc + (size_t)q * 256)[lane] = reinterpret_cast<const float4*>(gl_stage)[lane];
-    reinterpret_cast<float2*>(grad_attn + (size_t)q * 128)[lane] = reinterpret_cast<const float2*>(ga_stage)[lane];
+    const int sa = 2 * c4, sb = 2 * c4 + 1;
+    reinterpret_cast<float4*>(grad_loc + (size_t)q * 256)[lane] =
+        make_float4(res(head, sa, 1), res(head, sa, 2), res(head, sb, 1), res(head, sb, 2));
+    reinterpret_cast<float2*>(grad_attn + (size_t)q * 128)[lane] = make_float2(res(head, sa, 0), res(head, sb, 0));
   } else {
     // this wave's samples: per head 2 * NS location gradients and NS attention gradients
     for (int e = lane; e < 8 * 2 * NS; e += 64) {
-      const int idx = ((e / (2 * NS)) * 16 + part * NS) * 2 + e % (2 * NS);
-      grad_loc[(size_t)q * 256 + idx] = gl_stage[idx];
+      const int h = e / (2 * NS), t = e % (2 * NS), s = part * NS + t / 2;
+      grad_loc[(size_t)q * 256 + (h * 16 + s) * 2 + (t & 1)] = res(h, s, 1 + (t & 1));
     }
     for (int e = lane; e < 8 * NS; e += 64) {
-      const int idx = (e / NS) * 16 + part * NS + e % NS;
-      grad_attn[(size_t)q * 128 + idx] = ga_stage[idx];
+      const int h = e / NS, s = part * NS + e % NS;
+      grad_attn[(size_t)q * 128 + h * 16 + s] = res(h, s, 0);
     }
   }
 }

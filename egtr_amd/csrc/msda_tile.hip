@@ -47,8 +47,9 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   __shared__ __attribute__((aligned(16))) float4 s_T[kTQ * 8];             // T[q][32 channels]
   __shared__ __attribute__((aligned(16))) float4 s_w[kTQ * kRecStride];    // per sample: 4 weights (x attention)
   __shared__ __attribute__((aligned(8))) int2 s_vp[kTQ * kRecStride];      // per sample: 4 virtual pixel ids (16 bit)
-  __shared__ int s_pix[kChunk];                                            // global byte offset of a chunk column
+  __shared__ __attribute__((aligned(16))) int s_pix[kChunk];                                            // global byte offset of a chunk column
   __shared__ int s_bbox[16];
+  __shared__ unsigned s_km[kTQ / 2];                                       // per query pair: column tiles of the chunk it touches
 
   const int tid = threadIdx.x, ql = tid >> 3, c4 = tid & 7;
   LevelGeom G;
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
       // skipped), different queries are different rows of A and different levels disjoint column ranges: no two lanes of an
       // instruction touch one element, and a wave's LDS operations execute in program order -- plain read-modify-writes, no
       // atomics.  (Round 4: one thread per (query, level) did all four corners: a chain of 16 dependent LDS round trips.)
+      unsigned touched = 0;  // bit t: this thread put weight into column tile t (32 columns) of the chunk
       if ((c4 >> 1) < L) {
         float* arow = s_A + ql * kChunk;
         const int lvl_b = c4 >> 1, bottom = c4 & 1;
@@ -207,32 +209,76 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
           const int vv = bottom ? v.y : v.x;
           const float wa = bottom ? w.z : w.x, wb = bottom ? w.w : w.y;
           const unsigned ca = (unsigned)((vv & 0xffff) - k0), cb = (unsigned)(((unsigned)vv >> 16) - k0);
-          if (wa != 0.f && ca < (unsigned)ncols) arow[ca] += wa;
-          if (wb != 0.f && cb < (unsigned)ncols) arow[cb] += wb;
+          if (wa != 0.f && ca < (unsigned)ncols) { arow[ca] += wa; touched |= 1u << (ca >> 5); }
+          if (wb != 0.f && cb < (unsigned)ncols) { arow[cb] += wb; touched |= 1u << (cb >> 5); }
         }
       }
+      // Which column tiles does the query PAIR (2 s2, 2 s2 + 1) = one k step of the MFMA loop = 16 consecutive lanes touch?
+      // OR over the 16 lanes (two quad permutes, then the two mirrors: OR does not care which lane a value came from).
+      touched |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)touched, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+      touched |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)touched, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+      touched |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)touched, 0x141, 0xF, 0xF, true);  // row_half_mirror
+      touched |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)touched, 0x140, 0xF, 0xF, true);  // row_mirror
+      if ((tid & 15) == 0) s_km[tid >> 4] = touched;
       __syncthreads();
       {
         const int wave = tid >> 6, lane = tid & 63, li = lane & 31, hf = lane >> 5;
         const float* tmat = reinterpret_cast<const float*>(s_T);
+        const unsigned kmv = s_km[li];  // lane l (and l + 32): the column tiles query pair l touches
         for (int mt = wave; mt < mtiles; mt += kThreads / 64) {
+          // Only the k steps (query pairs) that put weight into this column tile are multiplied: the rest of the tile's
+          // 64 x 32 block of A is zero.  Rows of A are sparse -- 64 nonzeros in a window of up to thousands of columns for
+          // the coarse-level tiles -- so most (column tile, k step) blocks are empty (round 4; DESIGN 4.2 has the counts).
+          unsigned km = (unsigned)__builtin_amdgcn_ballot_w64(((kmv >> mt) & 1u) != 0);  // low half = high half
+          if (km == 0) continue;   // nobody touched the tile: nothing to add, nothing to re-zero
           f32x16 acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0.f;
           float* acol = s_A + mt * 32 + li;
-#pragma unroll 8
-          for (int s2 = 0; s2 < kTQ / 2; ++s2) {
-            const int qq = 2 * s2 + hf;
-            // D[i = pixel][j = channel] += A_op[i][k = qq] * B_op[k = qq][j]
-            const float av = acol[qq * kChunk];
-            acol[qq * kChunk] = 0.f;   // this lane is the element's only consumer: leave it zero for the next chunk / item
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, tmat[qq * 32 + li], acc, 0, 0, 0);
+          // D[i = pixel][j = channel] += A_op[i][k = qq] * B_op[k = qq][j], four set bits at a time: the operands of the NEXT
+          // four are requested before the current four products are issued (an LDS round trip is ~200 cycles here, a product
+          // 64).  A group's missing steps repeat its first one with a zero A operand.
+          // Every element is set back to zero right behind its read -- this lane is its only consumer, and A has to be zero
+          // when the next chunk / item starts filling it.  A group's missing steps repeat its first one: they read the zero just
+          // written (a wave's LDS operations execute in order) and add nothing.
+          float av[4], tv[4];
+          auto take4 = [&]() {
+            const int first = __builtin_ctz(km);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              int s2 = km != 0 ? __builtin_ctz(km) : first;
+              km &= km - 1;
+              asm volatile("" : "+s"(s2));   // opaque: no per-case code paths, the four read pairs are issued back to back
+              const int qq = 2 * s2 + hf;
+              float* ap = acol + __mul24(qq, kChunk);   // 24-bit multiply: hipcc otherwise picks a 64-bit multiply-add whose
+              av[u] = *ap;                              // unused high half aliased a pending read's register (a stall per group)
+              *ap = 0.f;
+              tv[u] = tmat[qq * 32 + li];
+            }
+          };
+          take4();
+          for (;;) {
+            const float a0 = av[0], a1 = av[1], a2 = av[2], a3 = av[3], t0 = tv[0], t1 = tv[1], t2 = tv[2], t3 = tv[3];
+            const bool more = km != 0;
+            if (more) take4();
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, t0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, t1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, t2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, t3, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!more) break;
           }
+          // one atomic per element of the 32 x 32 result; the 16 column offsets of this lane first, as four 16-byte reads
+          int4 po[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) po[g4] = *reinterpret_cast<const int4*>(&s_pix[mt * 32 + 8 * g4 + 4 * hf]);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int col = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-            if (col < ncols && acc[r] != 0.f)
-              unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)s_pix[col]) + li, acc[r]);
+            const int4 p4 = po[r >> 2];
+            const int pix = (r & 3) == 0 ? p4.x : (r & 3) == 1 ? p4.y : (r & 3) == 2 ? p4.z : p4.w;
+            if (col < ncols && acc[r] != 0.f) unsafeAtomicAdd(reinterpret_cast<float*>(gvbase + (unsigned)pix) + li, acc[r]);
           }
         }
       }
