@@ -391,8 +391,47 @@ def gen_det_small():
     np.savez_compressed(os.path.join(HERE, "det_small.npz"), **res)
 
 
+def gen_sgg_small_edge():
+    """Loss dicts, gradient norms and matcher indices of the reference for the edge-case target sets of
+    weights.edge_targets() -- an image without objects, an image with one object, a crowded image -- on the model and
+    inputs of sgg_small.npz."""
+    res = {}
+    rng = W.rng_inputs(22)
+    B, H, Wd = 2, 96, 128
+    pv = torch.from_numpy(rng.standard_normal((B, 3, H, Wd))).float()
+    pm = torch.ones(B, H, Wd, dtype=torch.long)
+    pm[1, 80:, :] = 0
+    pm[1, :, 104:] = 0
+    pv[1] = pv[1] * pm[1][None].float()
+    for kind in ("empty", "single", "crowded"):
+        model, cfg, cfg_dict, shapes = build_ref_model({}, seed=21)
+        targets = W.edge_targets(kind, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)
+        model.eval()
+        with torch.no_grad():
+            out_e, _, _ = run_ref(model, pv, pm, labels=targets)
+        res[f"{kind}_eval_loss"] = np_(out_e.loss)
+        res[f"{kind}_eval_loss_dict"] = json.dumps({k: float(v) for k, v in out_e.loss_dict.items()})
+        model.train()
+        model.zero_grad()
+        out_t, _, _ = run_ref(model, pv, pm, labels=targets)
+        out_t.loss.backward()
+        res[f"{kind}_train_loss"] = np_(out_t.loss)
+        res[f"{kind}_train_loss_dict"] = json.dumps({k: float(v) for k, v in out_t.loss_dict.items()})
+        res[f"{kind}_grad_norms"] = json.dumps({n: float(p.grad.norm()) for n, p in model.named_parameters()
+                                                if p.grad is not None})
+        matcher = dd.DeformableDetrHungarianMatcher(class_cost=cfg.ce_loss_coefficient, bbox_cost=cfg.bbox_cost,
+                                                    giou_cost=cfg.giou_cost, smoothing=cfg.smoothing)
+        idx, _ = matcher({"logits": out_t.logits.detach(), "pred_boxes": out_t.pred_boxes.detach()}, targets)
+        for i, (a, b) in enumerate(idx):
+            res[f"{kind}_match_pred_{i}"], res[f"{kind}_match_tgt_{i}"] = np_(a), np_(b)
+        print("sgg_small_edge", kind, float(out_e.loss), float(out_t.loss))
+    res.update(cfg=json.dumps(cfg_dict), shapes=json.dumps(shapes), seed=21, input_seed=22, target_seed=23, H=H, W=Wd,
+               valid1=np.array([80, 104]))
+    np.savez_compressed(os.path.join(HERE, "sgg_small_edge.npz"), **res)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["msda", "mha", "small", "refine", "full", "cfg0", "oi", "stress", "full_train", "det"]
+    which = sys.argv[1:] or ["msda", "mha", "small", "refine", "edge", "full", "cfg0", "oi", "stress", "full_train", "det"]
     torch.set_num_threads(8)
     if "msda" in which:
         gen_msda()
@@ -402,6 +441,8 @@ if __name__ == "__main__":
         gen_sgg_small()
     if "refine" in which:
         gen_sgg_small_refine()
+    if "edge" in which:
+        gen_sgg_small_edge()
     if "full" in which:
         gen_sgg_full()
     if "cfg0" in which:

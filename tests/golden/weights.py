@@ -141,6 +141,33 @@ def make_targets(seed, B, N, C, R, tmin=3, tmax=8):
     return targets
 
 
+def edge_targets(kind, N, C, R):
+    """Target sets at the edges of what the criterion sees (used with the model / inputs of sgg_small.npz):
+    "empty" = image 1 without any annotated object, "single" = image 0 with ONE object and no relation,
+    "crowded" = image 0 with 20 objects (of N = 24 queries) and a dense relation tensor."""
+    targets = make_targets(23, 2, N, C, R)
+    rng = rng_inputs(77)
+    if kind == "empty":
+        t = targets[1]
+        t["class_labels"], t["boxes"], t["rel"] = t["class_labels"][:0], t["boxes"][:0], torch.zeros(N, N, R)
+    elif kind == "single":
+        t = targets[0]
+        t["class_labels"], t["boxes"], t["rel"] = t["class_labels"][:1], t["boxes"][:1], torch.zeros(N, N, R)
+    elif kind == "crowded":
+        n = 20
+        cxcy = rng.uniform(0.2, 0.8, (n, 2))
+        wh = rng.uniform(0.05, 0.3, (n, 2))
+        rel = np.zeros((N, N, R), dtype=np.float32)
+        rel[:n, :n] = (rng.uniform(0, 1, (n, n, R)) < 0.15).astype(np.float32)
+        rel[np.arange(n), np.arange(n)] = 0
+        targets[0] = dict(class_labels=torch.from_numpy(rng.integers(0, C, (n,)).astype(np.int64)),
+                          boxes=torch.from_numpy(np.concatenate([cxcy, wh], 1).astype(np.float32)),
+                          rel=torch.from_numpy(rel))
+    else:
+        raise ValueError(kind)
+    return targets
+
+
 def post_inputs(seed=61, B=2, N=200, C=150, R=50):
     """Seeded model outputs + targets for the post-processing fixtures (evaluate_batch, train_egtr.py:43-106).
     Image 1's relation scores are quantised to multiples of 1/8 and its connectivity to {0.5, 1}, so exactly tied

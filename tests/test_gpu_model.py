@@ -88,6 +88,36 @@ def test_loss_and_grads_small_vs_reference(small, training):
                 assert (params[k[6:]].grad.cpu() - ref_g).abs().max() < 5e-3 * max(1.0, float(ref_g.abs().max())), k
 
 
+@pytest.mark.parametrize("kind", ["empty", "single", "crowded"])
+def test_loss_and_grads_on_edge_case_targets_vs_reference(small, golden_dir, kind):
+    """The train step's criterion at the edges: an image WITHOUT objects (empty assignment, no relation), an image with
+    one object, a crowded image (20 objects for 24 queries) -- device matcher, device losses and every gradient norm
+    against the reference's own run on the same targets (tests/golden/sgg_small_edge.npz, make_golden.py edge)."""
+    g, cfg_dict, shapes = small
+    ge = Hh.load_golden(golden_dir, "sgg_small_edge.npz")
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    pv, pm = Hh.small_inputs(g)
+    targets = [{k: t.to(DEV) for k, t in d.items()}
+               for d in W.edge_targets(kind, cfg.num_queries, cfg.num_labels, cfg.num_rel_labels)]
+    for training in (False, True):
+        model = model.to(DEV).train(training)
+        model.zero_grad()
+        key = f"{kind}_{'train' if training else 'eval'}"
+        with torch.set_grad_enabled(training):
+            out = model(pixel_values=pv.to(DEV), pixel_mask=pm.to(DEV), labels=targets, output_attention_states=True)
+        ref = json.loads(str(ge[f"{key}_loss_dict"]))
+        assert set(ref) == set(out.loss_dict)
+        for k, v in ref.items():
+            assert abs(float(out.loss_dict[k]) - v) < 1e-3 * max(1.0, abs(v)), (k, float(out.loss_dict[k]), v)
+        assert abs(float(out.loss) - float(ge[f"{key}_loss"])) < 1e-3 * abs(float(ge[f"{key}_loss"]))
+    out.loss.backward()
+    params = dict(model.named_parameters())
+    for n, v in json.loads(str(ge[f"{kind}_grad_norms"])).items():
+        got = float(params[n].grad.norm())
+        assert abs(got - v) < 5e-3 * max(abs(v), 1e-2), (n, got, v)
+
+
 def test_box_refine_model_vs_reference(golden_dir):
     """with_box_refine=True (egtr:148-154, dd:1903-1918): per-level heads and 4-d reference boxes -- in inference through
     the fused MSDA kernel's box form (dd:1074-1081), in training through the autograd composition -- against the

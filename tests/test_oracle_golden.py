@@ -148,6 +148,31 @@ def test_loss_vs_reference(golden_dir, training):
     assert abs(float(total) - float(g[f"{key}_loss"])) < 2e-4 * abs(float(g[f"{key}_loss"]))
 
 
+@pytest.mark.parametrize("kind", ["empty", "single", "crowded"])
+def test_loss_and_matcher_on_edge_case_targets_vs_reference(golden_dir, kind):
+    """An image without objects, an image with one object and no relation, a crowded image (20 objects for 24 queries,
+    dense relations): the reference's own loss dicts (eval + train) and matcher indices (sgg_small_edge.npz,
+    make_golden.py edge) against the restated criterion."""
+    g, cfg, sd, pv, pm, _ = _small(golden_dir)
+    ge = _load(golden_dir, "sgg_small_edge.npz")
+    targets = W.edge_targets(kind, cfg["num_queries"], cfg["num_labels"], cfg["num_rel_labels"])
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+    for training in (False, True):
+        total, ld, _, _ = OL.sgg_loss(out, targets, cfg, training=training)
+        key = f"{kind}_{'train' if training else 'eval'}"
+        ref = json.loads(str(ge[f"{key}_loss_dict"]))
+        assert set(ref) == set(ld), (sorted(ref), sorted(ld))
+        for k, v in ref.items():
+            assert abs(float(ld[k]) - v) < 2e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
+        assert abs(float(total) - float(ge[f"{key}_loss"])) < 2e-4 * abs(float(ge[f"{key}_loss"]))
+    idx, _ = OL.hungarian_match(out["logits"], out["pred_boxes"], targets, cfg["ce_loss_coefficient"], cfg["bbox_cost"],
+                                cfg["giou_cost"], cfg["smoothing"])
+    for i, (a, b) in enumerate(idx):
+        assert np.array_equal(a.numpy(), ge[f"{kind}_match_pred_{i}"])
+        assert np.array_equal(b.numpy(), ge[f"{kind}_match_tgt_{i}"])
+
+
 def test_aux_loss_vs_reference(golden_dir):
     g, cfg, sd, pv, pm, targets = _small(golden_dir)
     ga = _load(golden_dir, "sgg_small_aux.npz")
