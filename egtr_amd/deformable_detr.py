@@ -736,9 +736,10 @@ class DeformableDetrDecoderLayer(nn.Module):
                 spatial_shapes=None, level_start_index=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, output_attentions=False, output_attention_states=False,
                 spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False, precomputed_value=None,
-                out=None):
+                out=None, dropout_masks=None):
         """``hidden_with_pos`` / ``return_with_pos`` / ``precomputed_value`` / ``out`` (destination of the layer's output
-        states): inference plumbing, see the encoder layer and DeformableDetrDecoder.forward."""
+        states): inference plumbing, see the encoder layer and DeformableDetrDecoder.forward.  ``dropout_masks`` (training):
+        the byte masks [3, rows, 256] of the layer's three dropouts, drawn by the decoder for all its layers at once."""
         incoming = hidden_states if isinstance(hidden_states, ops.DeferredLayerNorm) else None
         fast = position_embeddings is not None and (incoming is not None or ops.inference_fast_path(hidden_states))
         # (not self.training: the deferred route has no dropout calls -- a model in train() mode under no_grad() keeps them)
@@ -764,7 +765,7 @@ class DeformableDetrDecoderLayer(nn.Module):
                                                                    _pos_rows(position_embeddings))
         else:
             hidden_states = ops.dropout_add_layer_norm(hidden_states, residual, self.self_attn_layer_norm, self.dropout,
-                                                       self.training)
+                                                       self.training, keep=dropout_masks[0] if dropout_masks is not None else None)
         second_residual = hidden_states
         hidden_states, cross_attn_weights = self.encoder_attn(
             hidden_states=hidden_states, attention_mask=encoder_attention_mask,
@@ -774,7 +775,8 @@ class DeformableDetrDecoderLayer(nn.Module):
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
             hidden_with_pos=cross_with_pos, precomputed_value=precomputed_value)
         hidden_states = ops.dropout_add_layer_norm(hidden_states, second_residual, self.encoder_attn_layer_norm,
-                                                   self.dropout, self.training)
+                                                   self.dropout, self.training,
+                                                   keep=dropout_masks[1] if dropout_masks is not None else None)
         residual = hidden_states
         if self.activation_fn is F.relu:
             hidden_states = ops.module_linear(self.fc1, hidden_states, relu=True)
@@ -789,7 +791,7 @@ class DeformableDetrDecoderLayer(nn.Module):
                                                                   _pos_rows(position_embeddings), out=out)
         else:
             hidden_states = ops.dropout_add_layer_norm(hidden_states, residual, self.final_layer_norm, self.dropout,
-                                                       self.training)
+                                                       self.training, keep=dropout_masks[2] if dropout_masks is not None else None)
         outputs = (hidden_states,)
         if output_attentions:
             outputs += (self_attn_weights, cross_attn_weights)
@@ -1013,6 +1015,15 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
         if fast and hidden_states.dtype == torch.float32 and hidden_states.shape[-1] == 256:
             inter_buf = torch.empty(len(self.layers), *hidden_states.shape, dtype=hidden_states.dtype,
                                     device=hidden_states.device)
+        # training: the byte masks of the layers' 3 x Ld dropout + add + LayerNorm steps from ONE bernoulli_ launch (a mask of
+        # [B N, 256] bytes is launch-bound; ops.DropoutAddLayerNormFunction draws its own when it is not handed one)
+        layer_masks = None
+        if (self.training and torch.is_grad_enabled() and ops.ENCODER_TRAIN_FUSED and 0.0 < self.dropout < 1.0
+                and torch.is_tensor(hidden_states) and hidden_states.is_cuda and hidden_states.dtype == torch.float32
+                and hidden_states.shape[-1] == 256):
+            rows = hidden_states.shape[0] * hidden_states.shape[1]
+            layer_masks = torch.empty(len(self.layers), 3, rows, 256, dtype=torch.uint8,
+                                      device=hidden_states.device).bernoulli_(1.0 - self.dropout)
         for idx, decoder_layer in enumerate(self.layers):
             if hoisted_reference is not None:
                 reference_points_input = hoisted_reference
@@ -1034,7 +1045,8 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 output_attention_states=output_attention_states, spatial_shapes_list=spatial_shapes_list,
                 hidden_with_pos=with_pos, return_with_pos=True,
                 precomputed_value=values[idx] if values is not None else None,
-                out=inter_buf[idx] if inter_buf is not None else None)
+                out=inter_buf[idx] if inter_buf is not None else None,
+                dropout_masks=layer_masks[idx] if layer_masks is not None else None)
             hidden_states = layer_outputs[0]
             with_pos = layer_outputs[-1]
             if isinstance(hidden_states, ops.DeferredLayerNorm):
