@@ -61,6 +61,8 @@ def test_msda_vs_reference_golden(golden_dir, case):
     (4, 7, [(5, 5), (3, 3), (2, 2), (1, 1)]),             # ragged tail: nq not a multiple of waves/block
     (1, 1, [(1, 1), (1, 1), (1, 1), (1, 1)]),             # degenerate 1x1 levels
     (3, 33, [(8, 8), (4, 4)]),                            # L=2, P=8 (L*P = 16 fast path)
+    (2, 2500, [(19, 32), (10, 16), (5, 8), (3, 4)]),      # long arbitrary query list (Lq != S, B Lq > 4096): the backward's
+                                                          # one-wave-per-query form WITH its atomics (msda_bwd_q64_f32<true, 1>)
 ])
 def test_msda_vs_oracle(B, Lq, shapes):
     P = 16 // len(shapes)
