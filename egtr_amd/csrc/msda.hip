@@ -423,8 +423,10 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, int nq_total,
-    int Lq, int S, int L, int P, int nblk) {
+    int Lq, int S, int L, int P, int nblk, unsigned* __restrict__ zero8) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * 128];
+  // the work counters of the value-tile kernel that runs behind this launch (msda_tile.hip) are reset here: no launch of their own
+  if (zero8 != nullptr && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0u;
   __shared__ __attribute__((aligned(16))) float4 s_cf[kWaves * 128 * 3];                      // A | B | C per entry
   __shared__ __attribute__((aligned(16))) float4 s_a[VALUE_ATOMICS ? kWaves * 128 : 1];      // {bits, lh, lw, attn}
   __shared__ __attribute__((aligned(16))) float s_go[VALUE_ATOMICS ? kWaves * 256 : 4];      // grad_out row, [head][32]
@@ -753,7 +755,8 @@ extern "C" int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t
 
 int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
                                         const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
-                                        int B, int Lq, int S, int L, int P);
+                                        int B, int Lq, int S, int L, int P, unsigned* counters);
+unsigned* egtr_msda_tile_counters();   // eight zero-initialised work counters for one launch pair (msda_tile.hip)
 
 // variant: 0 = automatic, 1 = wave-per-query with per-sample global atomics (reference scheme), 2 = two kernels:
 // wave-per-query for grad_attn / grad_loc (no atomics) + query-tile x head MFMA accumulation of grad_value
@@ -779,26 +782,28 @@ extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float*
   if ((variant == 1 || variant == 2) && !fast) return EGTR_E_UNSUPPORTED;
   if (variant == 2) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
+    unsigned* counters = egtr_msda_tile_counters();
+    if (counters == nullptr) return EGTR_E_LAUNCH;
     hipLaunchKernelGGL(msda_bwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk);
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, counters);
     const int st1 = egtr_check_launch();
     if (st1 != EGTR_OK) return st1;
     return egtr_launch_msda_bwd_value_tile_f32(st, grad_out, spatial_shapes, level_start_index, sampling_loc,
                                                attn_weight, grad_value, batch, num_query, spatial_size, num_levels,
-                                               num_point);
+                                               num_point, counters);
   }
   if (variant == 1 && nq * 4 <= 16384 && (num_point == 4 || num_point == 8 || num_point == 16)) {
     // short query list: 4 waves per query (one level's samples each for L = P = 4)
     const int nblk = (int)((nq * 4 + kWaves - 1) / kWaves);
     hipLaunchKernelGGL((msda_bwd_q64_f32<true, 4>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
                        spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk);
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr);
   } else if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(msda_bwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk);
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr);
   } else {
     const long long n = nq * num_heads * num_levels * num_point;
     const int threads = 256;

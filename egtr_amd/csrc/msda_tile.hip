@@ -39,10 +39,15 @@ constexpr int kBwdGrid = 256;  // persistent workgroups, one per CU
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Work counters of the launches in flight: 8 per launch (one per head = XCD), a ring of kCounterSlots launches.  A slot is
+// zeroed by the wave-per-query kernel that precedes its value-tile kernel on the stream (msda.hip).
+constexpr int kCounterSlots = 1024;
+__device__ unsigned g_tile_counters[kCounterSlots * 8];
+
 __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
     const float* __restrict__ grad_out, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ grad_value, int B, int Lq,
-    int S, int L, int P) {
+    int S, int L, int P, unsigned* __restrict__ counters) {
   __shared__ __attribute__((aligned(16))) float s_A[kTQ * kChunk];         // A[q][column]
   __shared__ __attribute__((aligned(16))) float4 s_T[kTQ * 8];             // T[q][32 channels]
   __shared__ __attribute__((aligned(16))) float4 s_w[kTQ * kRecStride];    // per sample: 4 weights (x attention)
@@ -50,12 +55,24 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   __shared__ __attribute__((aligned(16))) int s_pix[kChunk];                                            // global byte offset of a chunk column
   __shared__ int s_bbox[16];
   __shared__ unsigned s_km[kTQ / 2];                                       // per query pair: column tiles of the chunk it touches
+  __shared__ int s_grab[4];                                                // item indices handed from thread 0 to the workgroup ([1], [2])
 
   const int tid = threadIdx.x, ql = tid >> 3, c4 = tid & 7;
   LevelGeom G;
   load_geom(shapes, lsi, L, G);
   const TileMap tm = make_tile_map(G, L, Lq);
-  const int nwork = B * tm.ntiles * 8;
+  // Items are handed out dynamically, largest first.  head = XCD: workgroups are dealt to the eight XCDs round-robin by id and
+  // the grid is a multiple of 8, so blockIdx & 7 is the XCD this workgroup runs on; it takes the items of THAT head, so that all
+  // atomics on the 128-byte head slice [.., head, :] of a pixel come from one XCD (437 -> 394 us per launch at B = 4 in round 3;
+  // the atomics themselves still execute on the fabric side -- WRITE_SIZE unchanged at 205 MB, L2 hit ~0).  Item j of a head is
+  // (image j % B, tile ntiles - 1 - j / B): the tile list is ordered level 0 ... level 3 and the window of a coarse-level tile
+  // is many times that of a level-0 tile (1 chunk against ~14), so the big items go first and the 32 workgroups of an XCD pull
+  // the next item from the head's counter when they finish one (round 4; with the static round-robin of before, the slowest
+  // workgroup took 814 k cycles against a mean of 685 k).  An index is drawn three items ahead of its use -- the operands of
+  // the next item are in flight while the current one is multiplied out, and the atomic's result is picked up an item later.
+  const int head = blockIdx.x & 7;
+  const int nitems = B * tm.ntiles;
+  unsigned* ctr = counters + head;
   // A is zero whenever a chunk starts building it: zeroed once here, and every element a chunk filled is zeroed again by the
   // lane that consumed it in the MFMA phase (round 4: the 115 KB zero pass per chunk and its barrier are gone)
   for (int e = tid; e < kTQ * kChunk / 4; e += kThreads) reinterpret_cast<float4*>(s_A)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -64,40 +81,42 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   // grad_out were exposed at the top of every item, with one workgroup per CU nothing else runs meanwhile)
   float4 lc_n = make_float4(9.f, 9.f, 9.f, 9.f), go_n = make_float4(0.f, 0.f, 0.f, 0.f);
   float2 aw_n = make_float2(0.f, 0.f);
-  auto fetch = [&](int work_) {
+  auto fetch = [&](int item_) {
     lc_n = make_float4(9.f, 9.f, 9.f, 9.f);
     aw_n = make_float2(0.f, 0.f);
     go_n = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (work_ < nwork) {
-      const int head_ = work_ & 7, t_ = work_ >> 3;
-      const int b_ = t_ % B, tile_ = tm.ntiles - 1 - t_ / B;   // same order as the main loop below
+    if (item_ < nitems) {
+      const int b_ = item_ % B, tile_ = tm.ntiles - 1 - item_ / B;
       const int q_ = tile_query(tm, G, tile_, ql, Lq);
       if (q_ >= 0) {
-        const size_t qh = ((size_t)b_ * Lq + q_) * 8 + head_;
+        const size_t qh = ((size_t)b_ * Lq + q_) * 8 + head;
         lc_n = reinterpret_cast<const float4*>(loc + qh * 32)[c4];
         aw_n = reinterpret_cast<const float2*>(attn + qh * 16)[c4];
         go_n = reinterpret_cast<const float4*>(grad_out + qh * 32)[c4];
       }
     }
   };
-  fetch(blockIdx.x);
+  // The first three items of a workgroup are fixed -- w, npx + w, 2 npx + w for the w-th of the npx workgroups of its XCD, so
+  // that the largest items land on different workgroups -- and the counter hands out the indices from 3 npx on; the fourth is
+  // requested here (thread 0 keeps the pending result).
+  const int npx = (int)(gridDim.x >> 3), w = (int)(blockIdx.x >> 3);
+  const unsigned drawn0 = 3u * (unsigned)npx;
+  unsigned pending = 0;
+  if (tid == 0) pending = atomicAdd(ctr, 1u) + drawn0;
+  int cur = w, nxt = npx + w, nxt2 = 2 * npx + w;
+  int par = 0;   // hand-over slot of this item: the other one may still be read by a wave that is behind (an item without
+                 // columns has no barrier between its read and the next item's write)
+  fetch(cur);
 
-  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
-    // head = XCD: workgroups are dealt to the eight XCDs round-robin by id and the grid is a multiple of 8, so work & 7 ==
-    // blockIdx & 7 == the XCD this workgroup runs on.  All atomics on the 128-byte head slice [.., head, :] of a pixel then
-    // come from ONE XCD.  Measured 437 -> 394 us per launch at B = 4 (284 -> 221 at B = 1); the atomics themselves still
-    // execute on the fabric side (WRITE_SIZE unchanged at 205 MB, L2 hit ~0: profiles/r03_msda_bwd_pmc.json) -- what
-    // improved is eight sources no longer interleaving their requests to the same lines.
-    const int head = work & 7;
-    const int t = work >> 3;
-    // Largest items first: the tile list is ordered level 0 ... level 3 and the window of a coarse-level tile is many times
-    // that of a level-0 tile (1 chunk against ~10), so the work ids walk the tiles BACKWARDS, the images interleaved -- with the
-    // round-robin assignment every workgroup then gets one item of each size band instead of the big ones arriving last
-    // (round 4: 143.7 -> see DESIGN 4.2 at B = 1, where a workgroup has only ~7 items).
-    const int b = t % B;
+  while (cur < nitems) {
+    const int b = cur % B;
     char* gvbase = reinterpret_cast<char*>(grad_value) + (size_t)b * S * 1024;
 
     if (tid < 16) s_bbox[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+    if (tid == 0) {
+      s_grab[1 + par] = (int)pending;    // drawn during the previous item: arrived long ago
+      pending = atomicAdd(ctr, 1u) + drawn0;   // picked up at the top of the next item
+    }
     __syncthreads();
 
     // ---- A: geometry of samples 2*c4, 2*c4+1 + per-level bounding boxes ------------------------------------------
@@ -110,7 +129,7 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
     {
       const float4 lc = lc_n, go = go_n;
       const float2 aw = aw_n;
-      fetch(work + gridDim.x);   // in flight until the next iteration reads lc_n / aw_n / go_n
+      fetch(nxt);   // in flight until the next iteration reads lc_n / aw_n / go_n
       s_T[ql * 8 + c4] = go;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -143,6 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
       atomicMax(&s_bbox[lvl * 4 + 3], xmax);
     }
     __syncthreads();
+    const int nxt3 = s_grab[1 + par];   // written before the first barrier of this item
 
     // ---- B: concatenate the level windows into one virtual pixel range; per-sample records ------------------------
     int wy0[4], wx0[4], ww[4], vb[5];
@@ -283,16 +303,36 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
         }
       }
     }
+    cur = nxt;
+    nxt = nxt2;
+    nxt2 = nxt3;
+    par ^= 1;
   }
 }
 
 }  // namespace
 
+// Eight zero-initialised-by-the-caller work counters for one launch pair: the next slot of the ring on the current device.
+unsigned* egtr_msda_tile_counters() {
+  static unsigned* base[64] = {};
+  static unsigned next_slot = 0;   // launches of one process are issued from one thread at a time per device in practice;
+                                   // a torn increment would only make two launches share a slot index modulo the ring
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (base[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_counters)) != hipSuccess) return nullptr;
+    base[dev] = static_cast<unsigned*>(p);
+  }
+  const unsigned slot = __atomic_fetch_add(&next_slot, 1u, __ATOMIC_RELAXED) % kCounterSlots;
+  return base[dev] + slot * 8;
+}
+
 // Launcher used by egtr_msda_backward_f32 (msda.hip): grad_value of encoder-shaped calls (M = 8, D = 32, L*P = 16).
 int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
                                         const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
-                                        int B, int Lq, int S, int L, int P) {
+                                        int B, int Lq, int S, int L, int P, unsigned* counters) {
   hipLaunchKernelGGL(msda_bwd_value_tile_f32, dim3(kBwdGrid), dim3(kThreads), 0, st, grad_out, shapes, lsi, loc, attn,
-                     grad_value, B, Lq, S, L, P);
+                     grad_value, B, Lq, S, L, P, counters);
   return egtr_check_launch();
 }
