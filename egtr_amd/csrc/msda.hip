@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, int nq_total,
-    int Lq, int S, int L, int P, int nblk, unsigned* __restrict__ zero8) {
+    int Lq, int S, int L, int P, int nblk, unsigned* __restrict__ zero8, int zero_value_rows) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * 128];
   // the work counters of the value-tile kernel that runs behind this launch (msda_tile.hip) are reset here: no launch of their own
   if (zero8 != nullptr && blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0u;
@@ -445,6 +445,10 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
 
   const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
   const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
+  // encoder-shaped calls without atomics here (Lq == S, the value-tile kernel accumulates grad_value behind this launch): query q
+  // clears row q of grad_value, 1 KiB per wave -- the caller's 51 MB zero-fill launch folded into this gather-bound kernel
+  if (!VALUE_ATOMICS && zero_value_rows)
+    reinterpret_cast<float4*>(gvbase + (size_t)(q - b * Lq) * 1024)[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   const int head_s = lane >> 3, s0 = (lane & 7) * 2;
   int4* my_off = s_off + wave * 128;
   float4* my_cf = s_cf + wave * 128 * 3;
@@ -762,12 +766,15 @@ unsigned* egtr_msda_tile_counters();   // eight zero-initialised work counters f
 // wave-per-query for grad_attn / grad_loc (no atomics) + query-tile x head MFMA accumulation of grad_value
 // (msda_tile.hip), 3 = generic.  Automatic = 2 for encoder-shaped calls (Lq == S: queries are the pixels, so tiles
 // have compact windows), 1 for short / arbitrary query lists, 3 for shapes other than M = 8, D = 32, L*P = 16.
-extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
-                                              const int64_t* spatial_shapes, const int64_t* level_start_index,
-                                              const float* sampling_loc, const float* attn_weight, int batch,
-                                              int spatial_size, int num_heads, int channels, int num_levels,
-                                              int num_query, int num_point, float* grad_value,
-                                              float* grad_sampling_loc, float* grad_attn_weight, int variant) {
+namespace {
+// zero_inside: grad_value arrives uninitialised and is cleared here -- by the wave-per-query kernel itself where the value-tile
+// kernel follows it (variant 2), by a memset on the stream otherwise
+int msda_backward_f32_impl(egtr_stream_t stream, const float* grad_out, const float* value,
+                           const int64_t* spatial_shapes, const int64_t* level_start_index,
+                           const float* sampling_loc, const float* attn_weight, int batch,
+                           int spatial_size, int num_heads, int channels, int num_levels,
+                           int num_query, int num_point, float* grad_value,
+                           float* grad_sampling_loc, float* grad_attn_weight, int variant, bool zero_inside) {
   if (!grad_out || !value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_value ||
       !grad_sampling_loc || !grad_attn_weight)
     return EGTR_E_ARG;
@@ -780,13 +787,18 @@ extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float*
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
   if (variant == 0) variant = fast ? ((num_query == spatial_size && num_query >= 256) ? 2 : 1) : 3;
   if ((variant == 1 || variant == 2) && !fast) return EGTR_E_UNSUPPORTED;
+  const bool zero_in_kernel = zero_inside && variant == 2 && num_query == spatial_size;
+  if (zero_inside && !zero_in_kernel &&
+      hipMemsetAsync(grad_value, 0, (size_t)batch * spatial_size * num_heads * channels * sizeof(float), st) != hipSuccess)
+    return EGTR_E_LAUNCH;
   if (variant == 2) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     unsigned* counters = egtr_msda_tile_counters();
     if (counters == nullptr) return EGTR_E_LAUNCH;
     hipLaunchKernelGGL(msda_bwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, counters);
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, counters,
+                       zero_in_kernel ? 1 : 0);
     const int st1 = egtr_check_launch();
     if (st1 != EGTR_OK) return st1;
     return egtr_launch_msda_bwd_value_tile_f32(st, grad_out, spatial_shapes, level_start_index, sampling_loc,
@@ -798,12 +810,12 @@ extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float*
     const int nblk = (int)((nq * 4 + kWaves - 1) / kWaves);
     hipLaunchKernelGGL((msda_bwd_q64_f32<true, 4>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
                        spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr);
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
   } else if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     hipLaunchKernelGGL(msda_bwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr);
+                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
   } else {
     const long long n = nq * num_heads * num_levels * num_point;
     const int threads = 256;
@@ -813,6 +825,29 @@ extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float*
                        grad_attn_weight, n, spatial_size, num_heads, channels, num_levels, num_query, num_point);
   }
   return egtr_check_launch();
+}
+}  // namespace
+
+extern "C" int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, const float* value,
+                                              const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                              const float* sampling_loc, const float* attn_weight, int batch,
+                                              int spatial_size, int num_heads, int channels, int num_levels,
+                                              int num_query, int num_point, float* grad_value,
+                                              float* grad_sampling_loc, float* grad_attn_weight, int variant) {
+  return msda_backward_f32_impl(stream, grad_out, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, batch,
+                                spatial_size, num_heads, channels, num_levels, num_query, num_point, grad_value,
+                                grad_sampling_loc, grad_attn_weight, variant, false);
+}
+
+extern "C" int egtr_msda_backward_out_f32(egtr_stream_t stream, const float* grad_out, const float* value,
+                                          const int64_t* spatial_shapes, const int64_t* level_start_index,
+                                          const float* sampling_loc, const float* attn_weight, int batch,
+                                          int spatial_size, int num_heads, int channels, int num_levels, int num_query,
+                                          int num_point, float* grad_value, float* grad_sampling_loc,
+                                          float* grad_attn_weight) {
+  return msda_backward_f32_impl(stream, grad_out, value, spatial_shapes, level_start_index, sampling_loc, attn_weight, batch,
+                                spatial_size, num_heads, channels, num_levels, num_query, num_point, grad_value,
+                                grad_sampling_loc, grad_attn_weight, 0, true);
 }
 
 extern "C" int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const float* value,

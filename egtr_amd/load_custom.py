@@ -211,10 +211,12 @@ class _MultiScaleDeformableAttention:
         for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"),
                      (grad_output, "grad_output")):
             _chk(t, n, torch.float32)
-        grad_value = torch.zeros_like(value)  # accumulated with atomics (reference: cu:124)
+        # accumulated with atomics (reference: zeros_like, cu:124); cleared by the call itself -- encoder-shaped calls inside
+        # the first kernel of the pair, no 51 MB fill launch (egtr_msda_backward_out_f32)
+        grad_value = torch.empty_like(value)
         grad_loc = torch.empty_like(sampling_loc)
         grad_attn = torch.empty_like(attn_weight)
-        st = lib.egtr_msda_backward_f32(_stream(), grad_output.data_ptr(), value.data_ptr(),
+        st = lib.egtr_msda_backward_out_f32(_stream(), grad_output.data_ptr(), value.data_ptr(),
                                         spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                         sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq,
                                         P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr())

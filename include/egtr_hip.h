@@ -98,6 +98,16 @@ int egtr_msda_backward_f32(egtr_stream_t stream, const float* grad_out, const fl
                            int num_heads, int channels, int num_levels, int num_query, int num_point,
                            float* grad_value, float* grad_sampling_loc, float* grad_attn_weight);
 
+/* The same backward with ALL three gradients written by the call: grad_value need not be initialised -- what the reference's
+ * op does one level up, where `ms_deform_attn_cuda_backward` allocates `at::zeros_like(value)` itself
+ * (model/custom_kernel/cuda/ms_deform_attn_cuda.cu:124).  Encoder-shaped calls (num_query == spatial_size) clear grad_value
+ * inside the first kernel of the pair instead of in a 4 * B * S * 256-byte fill launch; other shapes run a memset on the stream. */
+int egtr_msda_backward_out_f32(egtr_stream_t stream, const float* grad_out, const float* value,
+                               const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const float* sampling_loc, const float* attn_weight, int batch, int spatial_size,
+                               int num_heads, int channels, int num_levels, int num_query, int num_point,
+                               float* grad_value, float* grad_sampling_loc, float* grad_attn_weight);
+
 /* float64 forward / backward: the reference extension dispatches AT_DISPATCH_FLOATING_TYPES
  * (model/custom_kernel/cuda/ms_deform_attn_cuda.cu:67, 137), so double callers (gradcheck) are served too -- by the
  * generic one-thread-per-element kernels, any (M, D, L, P).  Same argument meaning as the f32 entries; grad_value must be

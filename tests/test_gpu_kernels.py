@@ -144,6 +144,35 @@ def test_msda_backward_tile_variant(shapes, B, jitter):
         assert (gl.cpu() - rgl).abs().max() < 5e-3 * max(1.0, float(rgl.abs().max()) / 50), variant
 
 
+@pytest.mark.parametrize("encoder_shaped", [True, False])
+def test_msda_backward_out_entry_clears_grad_value_itself(encoder_shaped):
+    """egtr_msda_backward_out_f32: grad_value arrives as garbage (NaN) and comes back equal to what the zero-initialised
+    entry accumulates -- encoder-shaped calls clear it inside the wave-per-query kernel, others through a memset."""
+    from egtr_amd import _lib, ops
+    lib = _lib.lib()
+    shapes = [(38, 63), (19, 32), (10, 16), (5, 8)]
+    if encoder_shaped:
+        x = _grid_inputs(13, 2, shapes, 0.7)
+    else:
+        x = W.make_msda_inputs(14, 2, 300, 8, 32, shapes, 4, oob_frac=0.2)
+    d = {n: t.to(DEV) for n, t in x.items()}
+    B, S, M, D = d["value"].shape
+    Lq, L, P = d["loc"].shape[1], d["shapes"].shape[0], d["loc"].shape[4]
+    outs = []
+    for entry, fill in ((lib.egtr_msda_backward_f32, 0.0), (lib.egtr_msda_backward_out_f32, float("nan"))):
+        gv = torch.full_like(d["value"], fill)
+        gl = torch.full_like(d["loc"], float("nan"))
+        ga = torch.full_like(d["attn"], float("nan"))
+        _lib.check(entry(ops._stream(), d["grad_out"].data_ptr(), d["value"].data_ptr(), d["shapes"].data_ptr(),
+                         d["lsi"].data_ptr(), d["loc"].data_ptr(), d["attn"].data_ptr(), B, S, M, D, L, Lq, P,
+                         gv.data_ptr(), gl.data_ptr(), ga.data_ptr()), "msda backward")
+        outs.append((gv.cpu(), gl.cpu(), ga.cpu()))
+    (gv0, gl0, ga0), (gv1, gl1, ga1) = outs
+    assert torch.isfinite(gv1).all()
+    assert (gv0 - gv1).abs().max() < 1e-5 * max(1.0, float(gv0.abs().max()))   # atomics: order of the additions only
+    assert torch.equal(gl0, gl1) and torch.equal(ga0, ga1)
+
+
 def test_msda_backward_tile_variant_arbitrary_queries():
     k = _kernels()
     shapes = [(19, 32), (10, 16), (5, 8), (3, 4)]
