@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   __shared__ __attribute__((aligned(16))) int s_pix[kChunk];                                            // global byte offset of a chunk column
   __shared__ int s_bbox[16];
   __shared__ unsigned s_km[kTQ / 2];                                       // per query pair: column tiles of the chunk it touches
-  __shared__ int s_grab[4];                                                // item indices handed from thread 0 to the workgroup ([1], [2])
+  __shared__ int s_grab[2];                                                // next item's index, handed from thread 0 to the workgroup
 
   const int tid = threadIdx.x, ql = tid >> 3, c4 = tid & 7;
   LevelGeom G;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
   // (image j % B, tile ntiles - 1 - j / B): the tile list is ordered level 0 ... level 3 and the window of a coarse-level tile
   // is many times that of a level-0 tile (1 chunk against ~14), so the big items go first and the 32 workgroups of an XCD pull
   // the next item from the head's counter when they finish one (round 4; with the static round-robin of before, the slowest
-  // workgroup took 814 k cycles against a mean of 685 k).  An index is drawn three items ahead of its use -- the operands of
+  // workgroup took 814 k cycles against a mean of 685 k).  An index is drawn two items ahead of its use -- the operands of
   // the next item are in flight while the current one is multiplied out, and the atomic's result is picked up an item later.
   const int head = blockIdx.x & 7;
   const int nitems = B * tm.ntiles;
@@ -96,16 +96,14 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
       }
     }
   };
-  // The first three items of a workgroup are fixed -- w, npx + w, 2 npx + w for the w-th of the npx workgroups of its XCD, so
-  // that the largest items land on different workgroups -- and the counter hands out the indices from 3 npx on; the fourth is
-  // requested here (thread 0 keeps the pending result).
+  // The first two items of a workgroup are fixed -- w and npx + w for the w-th of the npx workgroups of its XCD, so that the
+  // largest items land on different workgroups -- and the counter hands out the indices from 2 npx on.  Thread 0 keeps the
+  // index requested during the previous item in `pending` and publishes it at the top of the next one.
   const int npx = (int)(gridDim.x >> 3), w = (int)(blockIdx.x >> 3);
-  const unsigned drawn0 = 3u * (unsigned)npx;
-  unsigned pending = 0;
-  if (tid == 0) pending = atomicAdd(ctr, 1u) + drawn0;
-  int cur = w, nxt = npx + w, nxt2 = 2 * npx + w;
-  int par = 0;   // hand-over slot of this item: the other one may still be read by a wave that is behind (an item without
-                 // columns has no barrier between its read and the next item's write)
+  const unsigned drawn0 = 2u * (unsigned)npx;
+  unsigned pending = (unsigned)(npx + w);
+  int cur = w;
+  int par = 0;   // hand-over slot of this item (the other one may still be read by a wave that is behind)
   fetch(cur);
 
   while (cur < nitems) {
@@ -114,10 +112,11 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
 
     if (tid < 16) s_bbox[tid] = (tid & 1) ? INT_MIN : INT_MAX;
     if (tid == 0) {
-      s_grab[1 + par] = (int)pending;    // drawn during the previous item: arrived long ago
+      s_grab[par] = (int)pending;              // requested during the previous item: arrived long ago
       pending = atomicAdd(ctr, 1u) + drawn0;   // picked up at the top of the next item
     }
     __syncthreads();
+    const int nxt = s_grab[par];
 
     // ---- A: geometry of samples 2*c4, 2*c4+1 + per-level bounding boxes ------------------------------------------
     const int lvl = (2 * c4) / P;
@@ -162,7 +161,6 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
       atomicMax(&s_bbox[lvl * 4 + 3], xmax);
     }
     __syncthreads();
-    const int nxt3 = s_grab[1 + par];   // written before the first barrier of this item
 
     // ---- B: concatenate the level windows into one virtual pixel range; per-sample records ------------------------
     int wy0[4], wx0[4], ww[4], vb[5];
@@ -304,8 +302,6 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
       }
     }
     cur = nxt;
-    nxt = nxt2;
-    nxt2 = nxt3;
     par ^= 1;
   }
 }
