@@ -90,6 +90,8 @@ SIGNATURES = {
     "egtr_xs_bytes": [_I, _I],
     "egtr_xs_split_f32": [_P, _P, _I, _P, _I, _I, _I, _P, _P, _I],
     "egtr_rel_head_forward_bf16x6_f32": [_P] * 16 + [_I] * 6 + [_P] * 3 + [_I],
+    "egtr_rel_head_forward_bf16x6_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
+    "egtr_rel_head_streams_f32": [_P] * 4 + [_I] * 2 + [_P] * 3,
     "egtr_rel_head_forward_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
     "egtr_rel_head_backward_pairs_f32": [_P] * 6 + [_I] * 4 + [_P] * 5,
 }

@@ -664,7 +664,9 @@ struct PrefetchX6 {
   }
 };
 
-template <int T, int OT>
+// SAVE (training forward): the post-ReLU activations of layers 1 and 2 go to h1_save / h2_save [2 (mlp)][B N N][256] as in
+// rel_head_fwd_f32 -- the backward's GEMMs read them (ops.RelationHeadFunction).
+template <int T, int OT, bool SAVE = false>
 __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2, 2))) void rel_head_fwd_x6(
     const float* __restrict__ gate_q, const float* __restrict__ gate_k, const float* __restrict__ uq,
     const float* __restrict__ uk, const float* __restrict__ b1, const unsigned short* __restrict__ w2xr,
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     const unsigned short* __restrict__ w2xc, const float* __restrict__ b2c, const float* __restrict__ w3c,
     const float* __restrict__ b3c, const float* __restrict__ triplet, const int64_t* __restrict__ node_cls, int B,
     int N, int R, int C1, float* __restrict__ rel_logits, float* __restrict__ conn_logits,
-    float* __restrict__ gate_mean, int apply_sigmoid) {
+    float* __restrict__ gate_mean, int apply_sigmoid, float* __restrict__ h1_save, float* __restrict__ h2_save) {
   // apply_sigmoid: write sigmoid(logit) (egtr.py:450-454, the model's pred_rel / pred_connectivity) instead of the logit
   // one buffer, two lives: the three h1 pieces (read by every layer-2 step), then the output tiles
   constexpr int kStride = 32 * OT + 1;
@@ -682,6 +684,12 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
   __shared__ int s_tb[32];
   __shared__ long long s_pp[32];
   __shared__ float s_cacc[kRhWaves][32];
+  // SAVE: a wave's 32 x 32 hidden-2 tile goes through this buffer so that it leaves as whole 128-byte row segments (written
+  // straight from the accumulator layout, every store instruction touched 32 lines with 32 bytes each)
+  // (eight pairs at a time: with a whole tile staged the kernel's LDS would allow two workgroups per CU instead of three, and it
+  // is latency-bound -- 750 us against 4 x 98 us for the same work at inference)
+  constexpr int kH2Pitch = 36;
+  __shared__ __attribute__((aligned(16))) float s_h2[SAVE ? kRhWaves * 8 * kH2Pitch : 4];
   const int lane = threadIdx.x & 63, pi = lane & 31, hf = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int mlp = blockIdx.y;
@@ -696,6 +704,7 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
   const long long p = ((long long)b * N + i) * N + j;
   const size_t qi = (size_t)b * N + i, kj = (size_t)b * N + j;
 
+  if (SAVE && wv == 0 && hf == 0) s_pp[pi] = valid ? p : -1;   // visible behind the barrier that closes layer 1
   float g[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -759,6 +768,10 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
           a01 = gg * u01 + a01;
           a23 = gg * u23 + a23;
         }
+        if (SAVE && i0 + ii < N && j0 + jj < N)   // one contiguous 1 KiB row per wave
+          reinterpret_cast<float4*>(h1_save + ((size_t)mlp * total +
+                                               (size_t)(((long long)b * N + i0 + ii) * N + j0 + jj)) * kHd)[lane] =
+              make_float4(egtr_relu(a01.x), egtr_relu(a01.y), egtr_relu(a23.x), egtr_relu(a23.y));
         const Split3 sx = xs::split3_fast(egtr_relu(a01.x)), sy = xs::split3_fast(egtr_relu(a01.y)),
                      sz = xs::split3_fast(egtr_relu(a23.x)), sw = xs::split3_fast(egtr_relu(a23.y));
         __bf16* hp = s_h + pp * kHp + 4 * lane;
@@ -815,6 +828,28 @@ __global__ __launch_bounds__(64 * kRhWaves) __attribute__((amdgpu_waves_per_eu(2
     PrefetchX6<kPre>::template run<0>(wq, voff, wtile, hrow, acc, accc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = egtr_relu(acc[r] + accc[r]);
+    if (SAVE) {
+      float* stg = s_h2 + wv * (8 * kH2Pitch);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((pi >> 3) == i) {
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<float4*>(stg + (pi & 7) * kH2Pitch + 8 * rq + 4 * hf) =
+                make_float4(acc[4 * rq + 0], acc[4 * rq + 1], acc[4 * rq + 2], acc[4 * rq + 3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // a wave's LDS operations execute in order: the fences only
+        __builtin_amdgcn_wave_barrier();                          // keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int pr = lane >> 3, ch = lane & 7;                  // 8 lanes = the 128 bytes of one pair's 32 units
+        const float4 v = *reinterpret_cast<const float4*>(stg + pr * kH2Pitch + 4 * ch);
+        const long long po = s_pp[8 * i + pr];
+        if (po >= 0) *reinterpret_cast<float4*>(h2_save + ((size_t)mlp * total + (size_t)po) * kHd + nt * 32 + 4 * ch) = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
     if (mlp == 0) {
       // ---- layer 3 (relation): two K = 16 steps per n tile on the split accumulators; W3 pieces pre-ordered ----------
 #pragma unroll
@@ -1185,16 +1220,101 @@ extern "C" int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const floa
     if (num_rel <= 32)                                                                                               \
       hipLaunchKernelGGL((rel_head_fwd_x6<TT, 1>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1,     \
                          w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c, triplet_dist, node_cls, batch,         \
-                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean, apply_sigmoid);      \
+                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean, apply_sigmoid,       \
+                         (float*)nullptr, (float*)nullptr);                                                          \
     else                                                                                                             \
       hipLaunchKernelGGL((rel_head_fwd_x6<TT, 2>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1,     \
                          w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c, triplet_dist, node_cls, batch,         \
-                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean, apply_sigmoid);      \
+                         num_query, num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean, apply_sigmoid,       \
+                         (float*)nullptr, (float*)nullptr);                                                          \
     break;
   switch (num_slots) {
     EGTR_TX(1) EGTR_TX(2) EGTR_TX(3) EGTR_TX(4) EGTR_TX(5) EGTR_TX(6) EGTR_TX(7) EGTR_TX(8) EGTR_TX(9)
     default: return EGTR_E_UNSUPPORTED;
   }
 #undef EGTR_TX
+  return egtr_check_launch();
+}
+
+// Training forward on the split arithmetic: as above, and the post-ReLU activations of both layers are stored for the backward.
+// num_slots 4 (three decoder layers: the small fixtures) or 7 (six: the reference's configuration); others: EGTR_E_UNSUPPORTED
+// (the caller keeps the exact-f32 kernel, egtr_rel_head_forward_save_f32).
+extern "C" int egtr_rel_head_forward_bf16x6_save_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k,
+                                                     const float* uq, const float* uk, const float* b1,
+                                                     const uint16_t* w2x_rel, const float* b2r, const uint16_t* w3x_rel,
+                                                     const float* b3r, const uint16_t* w2x_conn, const float* b2c,
+                                                     const float* w3c, const float* b3c, const float* triplet_dist,
+                                                     const int64_t* node_cls, int batch, int num_query, int num_slots,
+                                                     int hidden, int num_rel, int num_cls_plus1, float* rel_logits,
+                                                     float* conn_logits, float* gate_mean, float* h1_save,
+                                                     float* h2_save) {
+  if (!gate_q || !gate_k || !uq || !uk || !b1 || !w2x_rel || !b2r || !w3x_rel || !b3r || !w2x_conn || !b2c || !w3c ||
+      !b3c || !rel_logits || !conn_logits || !h1_save || !h2_save)
+    return EGTR_E_ARG;
+  if (triplet_dist != nullptr && node_cls == nullptr) return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_rel <= 0) return EGTR_E_ARG;
+  if (hidden != kHd || num_rel > 64 || (num_slots != 4 && num_slots != 7)) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long tiles = (long long)batch * ((num_query + 7) / 8) * ((num_query + 3) / 4);
+  if (tiles >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  const dim3 grid((unsigned)tiles, 2);
+#define EGTR_TXS(TT, OTT)                                                                                            \
+  hipLaunchKernelGGL((rel_head_fwd_x6<TT, OTT, true>), grid, dim3(64 * kRhWaves), 0, st, gate_q, gate_k, uq, uk, b1,  \
+                     w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c, triplet_dist, node_cls, batch, num_query,   \
+                     num_rel, num_cls_plus1, rel_logits, conn_logits, gate_mean, 0, h1_save, h2_save)
+  if (num_slots == 4) {
+    if (num_rel <= 32) EGTR_TXS(4, 1); else EGTR_TXS(4, 2);
+  } else {
+    if (num_rel <= 32) EGTR_TXS(7, 1); else EGTR_TXS(7, 2);
+  }
+#undef EGTR_TXS
+  return egtr_check_launch();
+}
+
+// The operand streams of rel_head_fwd_x6 from the fp32 weights in ONE launch (training rebuilds them every step):
+//   w2x [8 nt][16 t][3 piece][2 hf][32 pi][8 e]      = piece of W2[32 nt + pi][16 t + 8 hf + e]          (both MLPs)
+//   w3x [8 nt][2 kb][OT][3 piece][2 hf][32 pi][8 e]  = piece of W3[32 ot + pi][32 nt + 16 kb + (e & 3) + 8 (e >> 2) + 4 hf]
+// (rows of W3 beyond num_rel are zero), pieces rounded to nearest (hi + mid + lo == w to fp32 precision).
+namespace {
+__global__ __launch_bounds__(256) void rel_head_streams_f32(const float* __restrict__ w2r, const float* __restrict__ w2c,
+                                                            const float* __restrict__ w3r, int R, int OT,
+                                                            unsigned short* __restrict__ w2xr,
+                                                            unsigned short* __restrict__ w2xc,
+                                                            unsigned short* __restrict__ w3x) {
+  const int n2 = kHd * kHd, n3 = 8 * 2 * OT * 2 * 32 * 8;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < 2 * n2 + n3; i += gridDim.x * 256) {
+    if (i < 2 * n2) {
+      const int which = i / n2, j = i - which * n2;        // j walks the DESTINATION order without the piece index
+      const int e = j & 7, pi = (j >> 3) & 31, hf = (j >> 8) & 1, t = (j >> 9) & 15, nt = j >> 13;
+      const float w = (which ? w2c : w2r)[(32 * nt + pi) * kHd + 16 * t + 8 * hf + e];
+      const xs::Split3 sp = xs::split3_rne(w);
+      unsigned short* d = (which ? w2xc : w2xr) + (size_t)((nt * 16 + t) * 3) * 512 + (hf * 32 + pi) * 8 + e;
+      d[0] = (unsigned short)(sp.hi >> 16);
+      d[512] = (unsigned short)(sp.mid >> 16);
+      d[1024] = (unsigned short)(sp.lo >> 16);
+    } else {
+      const int j = i - 2 * n2;
+      const int e = j & 7, pi = (j >> 3) & 31, hf = (j >> 8) & 1;
+      const int rest = j >> 9, ot = rest % OT, kb = (rest / OT) & 1, nt = rest / (2 * OT);
+      const int row = 32 * ot + pi, col = 32 * nt + 16 * kb + (e & 3) + 8 * (e >> 2) + 4 * hf;
+      const float w = row < R ? w3r[row * kHd + col] : 0.f;
+      const xs::Split3 sp = xs::split3_rne(w);
+      unsigned short* d = w3x + (size_t)(((nt * 2 + kb) * OT + ot) * 3) * 512 + (hf * 32 + pi) * 8 + e;
+      d[0] = (unsigned short)(sp.hi >> 16);
+      d[512] = (unsigned short)(sp.mid >> 16);
+      d[1024] = (unsigned short)(sp.lo >> 16);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int egtr_rel_head_streams_f32(egtr_stream_t stream, const float* w2_rel, const float* w2_conn,
+                                         const float* w3_rel, int hidden, int num_rel, uint16_t* w2x_rel,
+                                         uint16_t* w2x_conn, uint16_t* w3x_rel) {
+  if (!w2_rel || !w2_conn || !w3_rel || !w2x_rel || !w2x_conn || !w3x_rel || num_rel <= 0) return EGTR_E_ARG;
+  if (hidden != kHd || num_rel > 64) return EGTR_E_UNSUPPORTED;
+  const int OT = num_rel <= 32 ? 1 : 2;
+  hipLaunchKernelGGL(rel_head_streams_f32, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), w2_rel, w2_conn,
+                     w3_rel, num_rel, OT, w2x_rel, w2x_conn, w3x_rel);
   return egtr_check_launch();
 }

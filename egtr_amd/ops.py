@@ -392,6 +392,8 @@ class TokenLinearFunction(Function):
 # ---- training form of the encoder layer (round 4): ONE autograd Function per layer -------------------------------------------
 # "0": the per-op composition of rounds 2 / 3 (TokenLinearFunction + F.dropout + AddLayerNormFunction + clamp_nonfinite_ ...)
 ENCODER_TRAIN_FUSED = os.environ.get("EGTR_ENCODER_TRAIN_FUSED", "1") != "0"
+# training forward of the relation head on the split-bf16 arithmetic (rel_head_fwd_x6 with the activation stores); 0: exact-f32 kernel
+REL_HEAD_TRAIN_X6 = os.environ.get("EGTR_REL_HEAD_TRAIN_X6", "1") != "0"
 
 
 def _host_array(ctype, vals):
@@ -1664,12 +1666,25 @@ class RelationHeadFunction(Function):
         P_ = B * N * N
         h1s = torch.empty(2, P_, Hd, dtype=torch.float32, device=gate_q.device) if need_grad else None
         h2s = torch.empty(2, P_, Hd, dtype=torch.float32, device=gate_q.device) if need_grad else None
-        st = lib.egtr_rel_head_forward_save_f32(
-            _stream(), *[t.data_ptr() for t in tens], triplet_dist.data_ptr() if triplet_dist is not None else None,
-            node_cls.data_ptr() if triplet_dist is not None else None, B, N, T, Hd, R, c1, rel.data_ptr(),
-            conn.data_ptr(), gm.data_ptr() if want_gate_mean else None,
-            h1s.data_ptr() if need_grad else None, h2s.data_ptr() if need_grad else None)
-        _lib.check(st, "egtr_rel_head_forward_save_f32")
+        if REL_HEAD_TRAIN_X6 and need_grad and GEMM_SPLIT_BF16 and Hd == 256 and R <= 64 and T in (4, 7):
+            # layers 2 and 3 on the bf16 matrix cores from split operands (the inference kernel with the two activation stores the
+            # backward needs); the weight streams are rebuilt by one launch -- the weights change every step
+            gq_, gk_, uq_, uk_, b1_, w2r_, b2r_, w3r_, b3r_, w2c_, b2c_, w3c_, b3c_ = tens
+            w2xr, w3x, w2xc = rel_head_streams(w2r_, w3r_, w2c_)
+            st = lib.egtr_rel_head_forward_bf16x6_save_f32(
+                _stream(), gq_.data_ptr(), gk_.data_ptr(), uq_.data_ptr(), uk_.data_ptr(), b1_.data_ptr(), w2xr.data_ptr(),
+                b2r_.data_ptr(), w3x.data_ptr(), b3r_.data_ptr(), w2xc.data_ptr(), b2c_.data_ptr(), w3c_.data_ptr(),
+                b3c_.data_ptr(), triplet_dist.data_ptr() if triplet_dist is not None else None,
+                node_cls.data_ptr() if triplet_dist is not None else None, B, N, T, Hd, R, c1, rel.data_ptr(),
+                conn.data_ptr(), gm.data_ptr() if want_gate_mean else None, h1s.data_ptr(), h2s.data_ptr())
+            _lib.check(st, "egtr_rel_head_forward_bf16x6_save_f32")
+        else:
+            st = lib.egtr_rel_head_forward_save_f32(
+                _stream(), *[t.data_ptr() for t in tens], triplet_dist.data_ptr() if triplet_dist is not None else None,
+                node_cls.data_ptr() if triplet_dist is not None else None, B, N, T, Hd, R, c1, rel.data_ptr(),
+                conn.data_ptr(), gm.data_ptr() if want_gate_mean else None,
+                h1s.data_ptr() if need_grad else None, h2s.data_ptr() if need_grad else None)
+            _lib.check(st, "egtr_rel_head_forward_save_f32")
         if need_grad:
             ctx.save_for_backward(*tens, h1s, h2s)
         return rel, conn.unsqueeze(-1), gm
@@ -1790,6 +1805,24 @@ def rel_head_split_weights(w2r, w3r, w2c):
     g = q[:, :, :, nidx]                                        # [piece, ot, pi, nt, kb, hf, e]
     w3x = g.permute(3, 4, 1, 0, 5, 2, 6).contiguous()           # [nt, kb, ot, piece, hf, pi, e]
     return w2x(w2r), w3x, w2x(w2c)
+
+
+def rel_head_streams(w2r, w3r, w2c):
+    """``rel_head_split_weights`` as ONE launch (egtr_rel_head_streams_f32): the same three streams, bit for bit; what the
+    training forward rebuilds after every optimizer step."""
+    lib = _lib.lib()
+    w2r_, w3r_, w2c_ = (_chk(t.detach().contiguous(), n, torch.float32)
+                        for t, n in ((w2r, "w2r"), (w3r, "w3r"), (w2c, "w2c")))
+    R = w3r_.shape[0]
+    OT = 1 if R <= 32 else 2
+    dev = w2r_.device
+    w2xr = torch.empty(8, 16, 3, 2, 32, 8, dtype=torch.bfloat16, device=dev)
+    w2xc = torch.empty(8, 16, 3, 2, 32, 8, dtype=torch.bfloat16, device=dev)
+    w3x = torch.empty(8, 2, OT, 3, 2, 32, 8, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.egtr_rel_head_streams_f32(_stream(), w2r_.data_ptr(), w2c_.data_ptr(), w3r_.data_ptr(), w2r_.shape[1], R,
+                                             w2xr.data_ptr(), w2xc.data_ptr(), w3x.data_ptr()),
+               "egtr_rel_head_streams_f32")
+    return w2xr, w3x, w2xc
 
 
 def relation_head_split_bf16(gate_q, gate_k, uq, uk, b1, w2x_rel, b2r, w3x_rel, b3r, w2x_conn, b2c, w3c, b3c,

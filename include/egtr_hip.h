@@ -558,6 +558,22 @@ int egtr_rel_head_forward_bf16x6_f32(egtr_stream_t stream, const float* gate_q, 
                                      int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
                                      float* gate_mean, int apply_sigmoid);
 
+/* The same kernel as the TRAINING forward: logits (never the sigmoid) and, for the backward, the post-ReLU activations of both
+ * layers h1_save / h2_save [2 (mlp)][B*N*N][hidden] exactly as egtr_rel_head_forward_save_f32 stores them.  num_slots 4 or 7
+ * (three / six decoder layers), else EGTR_E_UNSUPPORTED: the caller stays on egtr_rel_head_forward_save_f32. */
+int egtr_rel_head_forward_bf16x6_save_f32(egtr_stream_t stream, const float* gate_q, const float* gate_k, const float* uq,
+                                          const float* uk, const float* b1, const uint16_t* w2x_rel, const float* b2r,
+                                          const uint16_t* w3x_rel, const float* b3r, const uint16_t* w2x_conn,
+                                          const float* b2c, const float* w3c, const float* b3c,
+                                          const float* triplet_dist, const int64_t* node_cls, int batch, int num_query,
+                                          int num_slots, int hidden, int num_rel, int num_cls_plus1, float* rel_logits,
+                                          float* conn_logits, float* gate_mean, float* h1_save, float* h2_save);
+
+/* The three operand streams above from the fp32 weights W2_rel / W2_conn [hidden, hidden] and W3_rel [num_rel, hidden] in one
+ * launch (pieces rounded to nearest): what a training step rebuilds after every optimizer step.  hidden = 256, num_rel <= 64. */
+int egtr_rel_head_streams_f32(egtr_stream_t stream, const float* w2_rel, const float* w2_conn, const float* w3_rel,
+                              int hidden, int num_rel, uint16_t* w2x_rel, uint16_t* w2x_conn, uint16_t* w3x_rel);
+
 
 /* Pairwise part of the relation-head backward (everything that is not a plain GEMM).  dh1 [2][B*N*N][hidden] is the
  * gradient wrt the pre-ReLU layer-1 output (relation half, connectivity half), produced by rocBLAS GEMMs from the

@@ -507,6 +507,53 @@ def test_relation_head_forward_bf16_matrix_cores(B, N, T, R):
     assert (rel2.cpu().double() - rrel2).abs().max() < 3e-2 and gm2 is None
 
 
+def test_relation_head_streams_kernel_equals_torch_composition():
+    """egtr_rel_head_streams_f32 (one launch; rebuilt every training step) == ops.rel_head_split_weights, bit for bit."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for R in (50, 7, 64):
+        w2r = (torch.randn(256, 256, generator=g) * torch.logspace(-6, 3, 256)[None]).to(DEV)
+        w2c = torch.randn(256, 256, generator=g).to(DEV)
+        w3r = torch.randn(R, 256, generator=g).to(DEV)
+        a = ops.rel_head_split_weights(w2r, w3r, w2c)
+        b = ops.rel_head_streams(w2r, w3r, w2c)
+        for x, y in zip(a, b):
+            assert x.shape == y.shape and torch.equal(x.view(torch.int16), y.view(torch.int16))
+
+
+@pytest.mark.parametrize("B,N,T,R", [(2, 24, 4, 7), (1, 37, 7, 50)])
+def test_relation_head_training_forward_on_split_arithmetic_vs_exact(B, N, T, R, monkeypatch):
+    """ops.RelationHeadFunction with its forward on the split-bf16 kernel (EGTR_REL_HEAD_TRAIN_X6, the default) against the
+    exact-f32 kernel: logits to fp32 rounding, every gradient within 1e-4 of its scale (a hidden-2 unit within rounding
+    of zero may take the other side of its ReLU)."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(31 + N)
+    Hd, C1 = 256, 11
+    def mk(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(DEV)
+    base = dict(gate_q=mk(B, N, T), gate_k=mk(B, N, T), uq=mk(B, N, T, 2 * Hd, scale=0.3), uk=mk(B, N, T, 2 * Hd, scale=0.3),
+                b1=mk(2 * Hd, scale=0.1), w2r=mk(Hd, Hd, scale=Hd ** -0.5), b2r=mk(Hd, scale=0.1), w3r=mk(R, Hd, scale=Hd ** -0.5),
+                b3r=mk(R, scale=0.1), w2c=mk(Hd, Hd, scale=Hd ** -0.5), b2c=mk(Hd, scale=0.1), w3c=mk(1, Hd, scale=Hd ** -0.5),
+                b3c=mk(1, scale=0.1))
+    trip = mk(C1, C1, R, scale=0.5)
+    node = torch.randint(0, C1, (B, N), generator=g).to(DEV)
+    gr, gc = mk(B, N, N, R), mk(B, N, N, 1)
+    res = {}
+    for flag in (True, False):
+        monkeypatch.setattr(ops, "REL_HEAD_TRAIN_X6", flag)
+        t = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        rel, conn, gm = ops.RelationHeadFunction.apply(*[t[k] for k in base], trip, node, True)
+        (rel * gr).sum().add((conn * gc).sum()).backward()
+        res[flag] = (rel.detach(), conn.detach(), gm.detach(), {k: v.grad for k, v in t.items()})
+    (r1, c1_, g1, d1), (r0, c0, g0, d0) = res[True], res[False]
+    assert (r1 - r0).abs().max() < 2e-5 * max(1.0, float(r0.abs().max()))
+    assert (c1_ - c0).abs().max() < 2e-5 * max(1.0, float(c0.abs().max()))
+    assert (g1 - g0).abs().max() < 1e-5
+    for k in base:
+        scale = max(1e-3, float(d0[k].abs().max()))
+        assert (d1[k] - d0[k]).abs().max() < 1e-4 * scale, k
+
+
 @pytest.mark.parametrize("B,N,T,R", [(2, 12, 4, 7), (1, 200, 7, 50), (3, 40, 7, 50), (1, 33, 9, 64), (2, 7, 1, 1),
                                      (1, 300, 9, 50)])
 def test_relation_head_backward_matches_autograd(B, N, T, R):
