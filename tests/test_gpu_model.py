@@ -362,7 +362,7 @@ def test_train_step_600x1000_bs2_aux_vs_reference(golden_dir):
 
 @pytest.mark.parametrize("module,switch", [("ops", "ENCODER_TRAIN_FUSED"), ("ops", "TOKEN_LINEAR"), ("ops", "GEMM_SPLIT_WGRAD"),
                                            ("ops", "MSDA_GEOMETRY"), ("ops", "SKINNY_BACKWARD_FUSED"),
-                                           ("ops", "GEMM_SPLIT_BF16")])
+                                           ("ops", "GEMM_SPLIT_BF16"), ("ops", "REL_HEAD_TRAIN_X6")])
 def test_train_step_with_each_training_fusion_switched_off_vs_reference(golden_dir, module, switch, monkeypatch):
     """The training twin of test_full_size_with_each_fusion_switched_off_vs_reference: every training-path fusion has a switch
     (EGTR_<...>=0) that restores the composition it replaced, and that route must hold the reference's 600x1000 train
