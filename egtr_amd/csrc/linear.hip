@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void linear_skinny_grouped_f32(LinGroups P, in
 //   gb[N]    = column sums of g'
 // autograd issues two vendor GEMMs (9 us each at M = 800: one or two workgroups' worth of work), a mask pass and a
 // reduction per layer; ~70 such layers per train step are launch-bound.  Here the first `x_tiles` workgroups own
-// 16 x 64 tiles of gx and the rest 32 x 32 tiles of gw; in both the reduction is split 16 ways over (wave, lane group) as
+// 16 x 64 tiles of gx and the rest 16 x 16 tiles of gw; in both the reduction is split 16 ways over (wave, lane group) as
 // in the forward kernel -- a lane group's "k" slot of v_mfma_f32_16x16x4_f32 carries its own span of the reduction -- and
 // the operands whose reduction index is the SLOW one in memory (W for gx, g and x for gw) are read as float4 / float2
 // along the OUTPUT index instead: the 4 (2) values feed 4 (2) MFMAs whose output columns interleave.
@@ -332,21 +332,32 @@ __device__ __forceinline__ f32x2 gload_x2(const float* p) {
   asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p));
   return v;
 }
+__device__ __forceinline__ float gload_x1(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p));
+  return v;
+}
+__device__ __forceinline__ void vm_wait0(float& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
 __device__ __forceinline__ void vm_wait0(f32x4& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
 __device__ __forceinline__ void vm_wait0(f32x2& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); }
 
 // MASK: ReLU mask from y; B4: float4 steps of the gx reduction per batch (divides N / 64)
-template <bool MASK, int B4>
-__global__ __launch_bounds__(256) void linear_skinny_bwd_f32(SkinnyBwdArgs P) {
-  __shared__ float s_red[4 * 4 * 64 * 4];
-  __shared__ float s_gb[16 * 32];
+// Workgroups of EIGHT waves: a gw tile's reduction over the M rows is split 32 ways (round 4: 16 ways over four waves left every
+// lane group a chain of M / 16 rows = two dependent load batches at M = 800 -- the launch's critical path, 10.4 us against 4.2 us
+// for the gx tiles; 25 rows are one batch).  gx tiles keep their four-wave form: waves 4..7 of those workgroups leave at once.
+constexpr int kBwdWaves = 8;
+template <bool MASK, int B4, bool GW32>
+__global__ __launch_bounds__(64 * kBwdWaves) void linear_skinny_bwd_f32(SkinnyBwdArgs P) {
+  __shared__ float s_red[kBwdWaves * 4 * 64 * 4];
+  __shared__ float s_gb[4 * kBwdWaves * 32];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, gq = lane >> 4;
-  const int grp = wave * 4 + gq;   // 0..15: its share of the reduction
+  const int grp = wave * 4 + gq;   // its share of the reduction: 0..15 (gx tiles), 0..31 (gw tiles)
   const int M = P.M, N = P.N, K = P.K;
   f32x4 acc[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] = f32x4{0.f, 0.f, 0.f, 0.f};
   if ((int)blockIdx.x < P.x_tiles) {
+    if (wave >= 4) return;   // (a finished wave no longer counts at the workgroup's barriers)
     // ---- gx tile: rows m0..m0+15, columns k0..k0+63; reduction n in [grp * span, (grp + 1) * span)
     const int ktiles = K / 64;
     const int m0 = ((int)blockIdx.x / ktiles) * 16, k0 = ((int)blockIdx.x % ktiles) * 64;
@@ -399,17 +410,20 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_f32(SkinnyBwdArgs P) {
           make_float4(o[0] * P.alpha, o[1] * P.alpha, o[2] * P.alpha, o[3] * P.alpha);
     return;
   }
-  // ---- gw tile: rows n0..n0+31, columns k0..k0+31; reduction m in [grp * rpg, (grp + 1) * rpg)
+  if (GW32) {
+  // ---- gw tile, 32 x 32 form (layers with more than 512 16 x 16 tiles: fc1 / fc2): rows n0..n0+31, columns k0..k0+31; four
+  // accumulators per wave; reduction m in [grp * rpg, (grp + 1) * rpg)
   const int bt = (int)blockIdx.x - P.x_tiles;
   const int ktiles = K / 32;
   const int n0 = (bt / ktiles) * 32, k0 = (bt % ktiles) * 32;
-  const int rpg = (M + 15) / 16;
+  constexpr int kGroups = 4 * kBwdWaves;
+  const int rpg = (M + kGroups - 1) / kGroups;
   const int mb = grp * rpg;
   const float* gp = P.g + n0 + 2 * c;
   const float* yp = P.y + n0 + 2 * c;
   const float* xp = P.x + k0 + 2 * c;
   float sb0 = 0.f, sb1 = 0.f;
-  constexpr int TB = 32;   // rows per batch (800 rows = 50 per lane group: two memory round trips; 16: four, 15.5 us per call)
+  constexpr int TB = 32;   // rows per batch
   // the same trip count in every lane group (the matrix instruction runs on all 64 lanes): rows past the group's share
   // or past M are read from a valid row and contribute zeros
 #pragma unroll 1
@@ -447,7 +461,7 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_f32(SkinnyBwdArgs P) {
   s_gb[grp * 32 + 2 * c] = sb0;
   s_gb[grp * 32 + 2 * c + 1] = sb1;
   __syncthreads();
-  if (P.gw != nullptr) {
+  if (P.gw != nullptr && tid < 256) {
     // accumulator e = 2 ei + ej of lane (c', gq') register r: row n0 + 2 (4 gq' + r) + ei, column k0 + 2 c' + ej
     const int ln = tid >> 2, r = tid & 3;
 #pragma unroll
@@ -456,8 +470,10 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_f32(SkinnyBwdArgs P) {
 #pragma unroll
       for (int ej = 0; ej < 2; ++ej) {
         const int e = 2 * ei + ej;
-        o[ej] = s_red[((0 * 4 + e) * 64 + ln) * 4 + r] + s_red[((1 * 4 + e) * 64 + ln) * 4 + r] +
-                s_red[((2 * 4 + e) * 64 + ln) * 4 + r] + s_red[((3 * 4 + e) * 64 + ln) * 4 + r];
+        float acc_o = 0.f;
+#pragma unroll
+        for (int wq = 0; wq < kBwdWaves; ++wq) acc_o += s_red[((wq * 4 + e) * 64 + ln) * 4 + r];   // fixed order
+        o[ej] = acc_o;
       }
       const int orow = n0 + 2 * (4 * (ln >> 4) + r) + ei;
       *reinterpret_cast<float2*>(P.gw + (size_t)orow * K + k0 + 2 * (ln & 15)) = make_float2(o[0] * P.alpha, o[1] * P.alpha);
@@ -466,20 +482,89 @@ __global__ __launch_bounds__(256) void linear_skinny_bwd_f32(SkinnyBwdArgs P) {
   if (P.gb != nullptr && k0 == 0 && tid < 32) {
     float s = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) s += s_gb[q * 32 + tid];
+    for (int q = 0; q < kGroups; ++q) s += s_gb[q * 32 + tid];
+    P.gb[n0 + tid] = s * P.alpha;
+  }
+  return;
+  }
+  // ---- gw tile: rows n0..n0+15, columns k0..k0+15 -- ONE 16 x 16 accumulator per wave; reduction m in [grp * rpg, (grp + 1) * rpg).
+  // (Round 4.  32 x 32 tiles were (N / 32)(K / 32) = 64 workgroups for a 256 x 256 layer -- a quarter of the chip -- each with
+  // 800 matrix instructions to issue: the launch's critical path at 10 us.  16 x 16 tiles are 256 workgroups of 200.)
+  const int bt = (int)blockIdx.x - P.x_tiles;
+  const int ktiles = K / 16;
+  const int n0 = (bt / ktiles) * 16, k0 = (bt % ktiles) * 16;
+  constexpr int kGroups = 4 * kBwdWaves;
+  const int rpg = (M + kGroups - 1) / kGroups;
+  const int mb = grp * rpg;
+  const float* gp = P.g + n0 + c;
+  const float* yp = P.y + n0 + c;
+  const float* xp = P.x + k0 + c;
+  float sb = 0.f;
+  f32x4 accw = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int TB = 32;   // rows per batch (800 rows = 25 per lane group: one memory round trip)
+  // the same trip count in every lane group (the matrix instruction runs on all 64 lanes): rows past the group's share
+  // or past M are read from a valid row and contribute zeros
+#pragma unroll 1
+  for (int t0 = 0; t0 < rpg; t0 += TB) {
+    float a[TB], mk[TB], b[TB];
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const bool ok = t0 + t < rpg && mb + t0 + t < M;
+      const size_t m = (size_t)(ok ? mb + t0 + t : M - 1);
+      a[t] = gload_x1(gp + m * N);
+      if (MASK) mk[t] = gload_x1(yp + m * N);
+      b[t] = gload_x1(xp + m * K);
+    }
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      vm_wait0(a[t]);
+      if (MASK) vm_wait0(mk[t]);
+      vm_wait0(b[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const bool ok = t0 + t < rpg && mb + t0 + t < M;
+      const float av = (!ok || (MASK && !(mk[t] > 0.f))) ? 0.f : a[t];
+      sb += av;
+      accw = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t], accw, 0, 0, 0);
+    }
+  }
+  reinterpret_cast<f32x4*>(s_red)[wave * 64 + lane] = accw;
+  s_gb[grp * 16 + c] = sb;
+  __syncthreads();
+  if (P.gw != nullptr && tid < 256) {
+    // lane (c', gq') register r of a wave's accumulator: row n0 + 4 gq' + r, column k0 + c'
+    const int ln = tid >> 2, r = tid & 3;
+    float o = 0.f;
+#pragma unroll
+    for (int wq = 0; wq < kBwdWaves; ++wq) o += s_red[(wq * 64 + ln) * 4 + r];   // fixed order
+    P.gw[(size_t)(n0 + 4 * (ln >> 4) + r) * K + k0 + (ln & 15)] = o * P.alpha;
+  }
+  if (P.gb != nullptr && k0 == 0 && tid < 16) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < kGroups; ++q) s += s_gb[q * 16 + tid];
     P.gb[n0 + tid] = s * P.alpha;
   }
 }
 
-template <bool MASK>
-void launch_skinny_bwd(hipStream_t st, const SkinnyBwdArgs& P, int grid) {
+template <bool MASK, bool GW32>
+void launch_skinny_bwd2(hipStream_t st, const SkinnyBwdArgs& P, int grid) {
   const int steps = P.N / 64;   // float4 steps of the gx reduction per lane group
   if (steps % 4 == 0)
-    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 4>), dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 4, GW32>), dim3(grid), dim3(64 * kBwdWaves), 0, st, P);
   else if (steps % 2 == 0)
-    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 2>), dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 2, GW32>), dim3(grid), dim3(64 * kBwdWaves), 0, st, P);
   else
-    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 1>), dim3(grid), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((linear_skinny_bwd_f32<MASK, 1, GW32>), dim3(grid), dim3(64 * kBwdWaves), 0, st, P);
+}
+
+template <bool MASK>
+void launch_skinny_bwd(hipStream_t st, const SkinnyBwdArgs& P, int grid, bool gw32) {
+  if (gw32)
+    launch_skinny_bwd2<MASK, true>(st, P, grid);
+  else
+    launch_skinny_bwd2<MASK, false>(st, P, grid);
 }
 
 }  // namespace
@@ -568,10 +653,12 @@ extern "C" int egtr_linear_backward_f32(egtr_stream_t stream, const float* grad_
   P.g = grad_y; P.y = relu_output; P.x = x; P.w = w; P.gx = grad_x; P.gw = grad_w; P.gb = grad_bias;
   P.M = M; P.N = N; P.K = K; P.alpha = alpha;
   P.x_tiles = grad_x ? ((M + 15) / 16) * (K / 64) : 0;
-  const int w_tiles = (grad_w || grad_bias) ? (N / 32) * (K / 32) : 0;
+  // gw tiles: 16 x 16 while that is at most two workgroups per CU, 32 x 32 (four accumulators per wave) for the wide layers
+  const bool gw32 = (N / 16) * (K / 16) > 512;
+  const int w_tiles = (grad_w || grad_bias) ? (gw32 ? (N / 32) * (K / 32) : (N / 16) * (K / 16)) : 0;
   if (relu_output)
-    launch_skinny_bwd<true>(static_cast<hipStream_t>(stream), P, P.x_tiles + w_tiles);
+    launch_skinny_bwd<true>(static_cast<hipStream_t>(stream), P, P.x_tiles + w_tiles, gw32);
   else
-    launch_skinny_bwd<false>(static_cast<hipStream_t>(stream), P, P.x_tiles + w_tiles);
+    launch_skinny_bwd<false>(static_cast<hipStream_t>(stream), P, P.x_tiles + w_tiles, gw32);
   return egtr_check_launch();
 }
