@@ -51,8 +51,9 @@ __device__ __forceinline__ float bce_logits(float x, float y) {   // BCEWithLogi
   return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
 }
 
+constexpr int kPrepT = 1024;   // one workgroup per image, sixteen waves: the T x T x R count below is ~500 dependent gathers per thread with four
 // ---- prep: per image  tq (query -> target row), wq (1 - sigmoid(matching cost)), mq (matched), block counts ------------
-__global__ __launch_bounds__(kLT) void rel_loss_prep(const int64_t* __restrict__ pred_idx,
+__global__ __launch_bounds__(kPrepT) void rel_loss_prep(const int64_t* __restrict__ pred_idx,
                                                      const int64_t* __restrict__ tgt_idx,
                                                      const float* __restrict__ match_cost,
                                                      const int* __restrict__ out_off,
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(kLT) void rel_loss_prep(const int64_t* __restrict__
                                                      float nonmatching_cost, int k_neg, int k_nm, ImgState* st,
                                                      int* tq, float* wq, unsigned char* mq, int* total_sel) {
   __shared__ int s_cnt[2];
-  __shared__ int s_scan[kLT];
+  __shared__ int s_scan[kPrepT];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int o0 = out_off[b];
   int T = out_off[b + 1] - o0;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kLT) void rel_loss_prep(const int64_t* __restrict__
   // status into NaN loss terms for that output set (SceneGraphGenerationLoss.forward) and a ValueError
   // (DeformableDetrHungarianMatcher.raise_if_invalid).
   int bad_local = 0;
-  for (int t = tid; t < T; t += kLT) {
+  for (int t = tid; t < T; t += kPrepT) {
     const long long q = pred_idx[o0 + t], g = tgt_idx[o0 + t];
     bad_local |= (q < 0 || q >= N || g < 0 || g >= N) ? 1 : 0;
   }
@@ -78,9 +79,9 @@ __global__ __launch_bounds__(kLT) void rel_loss_prep(const int64_t* __restrict__
   float* wq_b = wq + (size_t)b * N;
   unsigned char* mq_b = mq + (size_t)b * N;
   if (tid < 2) s_cnt[tid] = 0;
-  for (int q = tid; q < N; q += kLT) { mq_b[q] = 0; wq_b[q] = 1.0f - 1.0f / (1.0f + expf(-nonmatching_cost)); }
+  for (int q = tid; q < N; q += kPrepT) { mq_b[q] = 0; wq_b[q] = 1.0f - 1.0f / (1.0f + expf(-nonmatching_cost)); }
   __syncthreads();
-  for (int t = tid; t < T; t += kLT) {
+  for (int t = tid; t < T; t += kPrepT) {
     const int q = (int)pred_idx[o0 + t];
     mq_b[q] = 1;
     tq_b[q] = (int)tgt_idx[o0 + t];
@@ -89,26 +90,26 @@ __global__ __launch_bounds__(kLT) void rel_loss_prep(const int64_t* __restrict__
   __syncthreads();
   // unmatched queries in ascending order take target rows T, T + 1, ... (egtr:761-768)
   int base = 0;
-  for (int q0 = 0; q0 < N; q0 += kLT) {
+  for (int q0 = 0; q0 < N; q0 += kPrepT) {
     const int q = q0 + tid;
     const int un = (q < N && !mq_b[q]) ? 1 : 0;
     s_scan[tid] = un;
     __syncthreads();
-    for (int o = 1; o < kLT; o <<= 1) {
+    for (int o = 1; o < kPrepT; o <<= 1) {
       const int v = tid >= o ? s_scan[tid - o] : 0;
       __syncthreads();
       s_scan[tid] += v;
       __syncthreads();
     }
     if (un) tq_b[q] = T + base + s_scan[tid] - 1;
-    base += s_scan[kLT - 1];
+    base += s_scan[kPrepT - 1];
     __syncthreads();
   }
   // counts over the matched block: true = target != 0, false candidates = target != 1 (egtr:838-840)
   const float* rel = target_rel[b];
   int nt = 0, nf = 0;
   const int tot = T * T * R;
-  for (int e = tid; e < tot; e += kLT) {
+  for (int e = tid; e < tot; e += kPrepT) {
     const int a = e / (T * R), rem = e - a * T * R, c = rem / R, r = rem - c * R;
     const float t = rel[((size_t)tgt_idx[o0 + a] * N + (size_t)tgt_idx[o0 + c]) * R + r];
     nt += (t != 0.f);
@@ -326,14 +327,34 @@ __global__ __launch_bounds__(kLT) void conn_loss(const float* __restrict__ pred_
     s_last = atomicAdd(done, 1u) == gridDim.x - 1;
   }
   __syncthreads();
-  if (s_last && tid == 0) {
+  if (s_last) {
+    // The last workgroup sums the partials of both losses -- every thread a fixed strided share, then lanes and waves in a fixed
+    // order: bit-reproducible.  (Round 4: thread 0 alone walked the ~1 400 partials with dependent volatile loads: 125 of the
+    // launch's 132 us.)
+    __shared__ double s_fin[2][kLT / 64];
     __threadfence();
     double sc = 0.0, sr = 0.0;
     const volatile double* pc = partial_conn;   // written by other workgroups of this launch (released above)
-    for (unsigned i = 0; i < gridDim.x; ++i) sc += pc[i];
-    for (int i = 0; i < n_partial_rel; ++i) sr += partial_rel[i];
-    loss_out[0] = (float)(sr / (double)(*total_sel));   // 0 / 0 = NaN: the reference's mean of an empty tensor
-    loss_out[1] = (float)(sc / (double)n_pairs);
+    for (unsigned i = tid; i < gridDim.x; i += kLT) sc += pc[i];
+    for (int i = tid; i < n_partial_rel; i += kLT) sr += partial_rel[i];
+    for (int o = 32; o > 0; o >>= 1) {
+      sc += __shfl_xor(sc, o);
+      sr += __shfl_xor(sr, o);
+    }
+    if ((tid & 63) == 0) {
+      s_fin[0][tid >> 6] = sc;
+      s_fin[1][tid >> 6] = sr;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double tc = 0.0, tr = 0.0;
+      for (int w = 0; w < kLT / 64; ++w) {
+        tc += s_fin[0][w];
+        tr += s_fin[1][w];
+      }
+      loss_out[0] = (float)(tr / (double)(*total_sel));   // 0 / 0 = NaN: the reference's mean of an empty tensor
+      loss_out[1] = (float)(tc / (double)n_pairs);
+    }
   }
 }
 
@@ -391,7 +412,7 @@ extern "C" int egtr_relation_loss_f32(egtr_stream_t stream, const float* pred_re
   p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 7) & ~(uintptr_t)7);
   double* partial_rel = reinterpret_cast<double*>(p);
   double* partial_conn = partial_rel + B * rows;
-  hipLaunchKernelGGL(rel_loss_prep, dim3(batch), dim3(kLT), 0, st, pred_idx, tgt_idx, match_cost, out_offsets, target_rel,
+  hipLaunchKernelGGL(rel_loss_prep, dim3(batch), dim3(kPrepT), 0, st, pred_idx, tgt_idx, match_cost, out_offsets, target_rel,
                      num_query, num_rel, nonmatching_cost, sample_negatives, sample_nonmatching, state, tq, wq, mq,
                      total_sel);
   const dim3 gh(rows, batch), gf(2, batch);
@@ -418,7 +439,7 @@ extern "C" int egtr_relation_loss_f32(egtr_stream_t stream, const float* pred_re
 // nothing: every sum and every gradient already carries 1 / num_boxes.
 namespace {
 
-constexpr int kDT = 256;
+constexpr int kDT = 1024;   // one workgroup per image: sixteen waves (round 4; four left ~120 dependent iterations per thread)
 constexpr int kDetMaxN = 2048;
 
 __device__ __forceinline__ float softplusf(float z) { return fmaxf(z, 0.f) + log1pf(expf(-fabsf(z))); }
@@ -429,7 +450,7 @@ __global__ __launch_bounds__(kDT) void det_loss_f32(
     const float* __restrict__ tboxes, const int* __restrict__ toff, int N, int C, float alpha, float inv_num_boxes,
     float* __restrict__ d_logits, float* __restrict__ d_l1, float* __restrict__ d_giou, float* __restrict__ out) {
   __shared__ int s_cls[kDetMaxN];
-  __shared__ float s_red[3][kDT];
+  __shared__ double s_red[3][kDT / 64];
   __shared__ int s_cnt[kDT / 64];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = moff[b], m1 = moff[b + 1], t0 = toff[b];
@@ -525,13 +546,22 @@ __global__ __launch_bounds__(kDT) void det_loss_f32(
         make_float4(-(g_x0 + g_x1) * inv_num_boxes, -(g_y0 + g_y1) * inv_num_boxes,
                     -0.5f * (g_x1 - g_x0) * inv_num_boxes, -0.5f * (g_y1 - g_y0) * inv_num_boxes);
   }
-  s_red[0][tid] = fsum;
-  s_red[1][tid] = l1sum;
-  s_red[2][tid] = gsum;
+  // fixed order: the lanes of a wave (butterfly), then the waves in index order
+  double fd = (double)fsum, ld = (double)l1sum, gd = (double)gsum;
+  for (int o = 32; o > 0; o >>= 1) {
+    fd += __shfl_xor(fd, o);
+    ld += __shfl_xor(ld, o);
+    gd += __shfl_xor(gd, o);
+  }
+  if (lane == 0) {
+    s_red[0][wave] = fd;
+    s_red[1][wave] = ld;
+    s_red[2][wave] = gd;
+  }
   __syncthreads();
   if (tid == 0) {
     double f = 0.0, l = 0.0, g = 0.0;
-    for (int i = 0; i < kDT; ++i) { f += s_red[0][i]; l += s_red[1][i]; g += s_red[2][i]; }
+    for (int i = 0; i < kDT / 64; ++i) { f += s_red[0][i]; l += s_red[1][i]; g += s_red[2][i]; }
     int c = 0;
     for (int w = 0; w < kDT / 64; ++w) c += s_cnt[w];
     out[b * 4 + 0] = (float)(f * inv_num_boxes);
