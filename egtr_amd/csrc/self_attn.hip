@@ -166,13 +166,15 @@ __global__ __launch_bounds__(64 * KS) void self_attn_fwd_split_f32(
 }
 
 // Backward.  See file header.  grad wrt the kernel's inputs q (already scaled), k, v.
-__global__ __launch_bounds__(64) void self_attn_bwd_f32(const float* __restrict__ q, const float* __restrict__ k,
+constexpr int kBwdSplit = 4;   // waves per workgroup: each takes every fourth tile of the reduction, partials summed in LDS
+__global__ __launch_bounds__(64 * kBwdSplit) void self_attn_bwd_f32(const float* __restrict__ q, const float* __restrict__ k,
                                                         const float* __restrict__ v, const float* __restrict__ out,
                                                         const float* __restrict__ lse,
                                                         const float* __restrict__ grad_out,
                                                         float* __restrict__ grad_q, float* __restrict__ grad_k,
                                                         float* __restrict__ grad_v, int B, int N, int M) {
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  __shared__ f32x4 s_acc[kBwdSplit][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int ntile = (N + 15) >> 4;
   int wid = blockIdx.x;
   const int tile = wid % ntile;
@@ -182,8 +184,11 @@ __global__ __launch_bounds__(64) void self_attn_bwd_f32(const float* __restrict_
   const int r0 = tile * 16;
   const float* lse_bh = lse + ((size_t)b * M + h) * N;
 
+  // The two roles are independent and run as separate workgroups (blockIdx.y), and the reduction loop of a role is dealt to
+  // the four waves of its workgroup, whose partial sums meet in LDS in wave order (round 4: one wave did both roles in turn,
+  // 416 waves for B = 4, N = 200 on 1 024 SIMDs: 44 us per call).
   // ---------------- role A: dQ for query rows r0..r0+15 (layout: scores transposed, query row = c) ------------
-  {
+  if (blockIdx.y == 0) {
     float qf[8], dof[8], of[8];
     load_frag8(q, N, MD, b, r0 + c, h, g, qf);
     load_frag8(grad_out, N, MD, b, r0 + c, h, g, dof);
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64) void self_attn_bwd_f32(const float* __restrict_
     delta = xor16_32_sum(delta);
     const float l_row = lse_bh[min(r0 + c, N - 1)];
     f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < ntile; ++kt) {
+    for (int kt = wave; kt < ntile; kt += kBwdSplit) {
       const int k0 = kt * 16;
       float kf[8], vf[8];
       load_frag8(k, N, MD, b, k0 + c, h, g, kf);
@@ -220,21 +225,29 @@ __global__ __launch_bounds__(64) void self_attn_bwd_f32(const float* __restrict_
         dq1 = mfma16(kp[16], ds[t], dq1);
       }
     }
-    if (r0 + c < N) {
+    s_acc[wave][0][lane] = dq0;
+    s_acc[wave][1][lane] = dq1;
+    __syncthreads();
+    if (wave == 0 && r0 + c < N) {
+#pragma unroll
+      for (int w = 1; w < kBwdSplit; ++w) {
+        dq0 += s_acc[w][0][lane];
+        dq1 += s_acc[w][1][lane];
+      }
       float* p = grad_q + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
       *reinterpret_cast<float4*>(p) = make_float4(dq0[0], dq0[1], dq0[2], dq0[3]);
       *reinterpret_cast<float4*>(p + 16) = make_float4(dq1[0], dq1[1], dq1[2], dq1[3]);
     }
   }
   // ---------------- role B: dK, dV for key rows r0..r0+15 (scores NOT transposed: D[row = qrow][col = key]) ----
-  {
+  else {
     float kf[8], vf[8];
     load_frag8(k, N, MD, b, r0 + c, h, g, kf);
     load_frag8(v, N, MD, b, r0 + c, h, g, vf);
     const bool key_ok = (r0 + c) < N;
     f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = {0.f, 0.f, 0.f, 0.f}, dv0 = {0.f, 0.f, 0.f, 0.f},
           dv1 = {0.f, 0.f, 0.f, 0.f};
-    for (int qt = 0; qt < ntile; ++qt) {
+    for (int qt = wave; qt < ntile; qt += kBwdSplit) {
       const int q0 = qt * 16;
       float qf[8], dof[8], of[8];
       load_frag8(q, N, MD, b, q0 + c, h, g, qf);
@@ -271,7 +284,19 @@ __global__ __launch_bounds__(64) void self_attn_bwd_f32(const float* __restrict_
         dk1 = mfma16(qp[16], ds[t], dk1);
       }
     }
-    if (key_ok) {
+    s_acc[wave][0][lane] = dk0;
+    s_acc[wave][1][lane] = dk1;
+    s_acc[wave][2][lane] = dv0;
+    s_acc[wave][3][lane] = dv1;
+    __syncthreads();
+    if (wave == 0 && key_ok) {
+#pragma unroll
+      for (int w = 1; w < kBwdSplit; ++w) {
+        dk0 += s_acc[w][0][lane];
+        dk1 += s_acc[w][1][lane];
+        dv0 += s_acc[w][2][lane];
+        dv1 += s_acc[w][3][lane];
+      }
       float* pk = grad_k + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
       float* pv = grad_v + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
       *reinterpret_cast<float4*>(pk) = make_float4(dk0[0], dk0[1], dk0[2], dk0[3]);
@@ -312,7 +337,7 @@ extern "C" int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q,
   if (head_dim != 32) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntile = (num_query + 15) / 16;
-  hipLaunchKernelGGL(self_attn_bwd_f32, dim3(batch * num_heads * ntile), dim3(64), 0, st, q, k, v, out, lse, grad_out,
+  hipLaunchKernelGGL(self_attn_bwd_f32, dim3(batch * num_heads * ntile, 2), dim3(64 * kBwdSplit), 0, st, q, k, v, out, lse, grad_out,
                      grad_q, grad_k, grad_v, batch, num_query, num_heads);
   return egtr_check_launch();
 }
