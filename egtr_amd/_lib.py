@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("EGTR_HIP_LIBRARY") or os.path.join(_HERE, "libegtr_hi
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
+ABI_VERSION = 2   # include/egtr_hip.h: EGTR_ABI_VERSION of the header these signatures were written against
 
 # name -> argtypes (restype is always int status unless listed in _RESTYPES)
 SIGNATURES = {
@@ -94,6 +95,8 @@ SIGNATURES = {
     "egtr_rel_head_streams_f32": [_P] * 4 + [_I] * 2 + [_P] * 3,
     "egtr_rel_head_forward_save_f32": [_P] * 16 + [_I] * 6 + [_P] * 5,
     "egtr_rel_head_backward_pairs_f32": [_P] * 6 + [_I] * 4 + [_P] * 5,
+    "egtr_decoder_layer_f32": [_P, _P],
+    "egtr_decoder_layer_workspace": [_I, _I, _P, _P, _P],
 }
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p,
              "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong,
@@ -120,6 +123,14 @@ def lib():
                 f"{LIB_PATH} not found: the HIP extension has not been built "
                 "(run `make -C egtr_amd/csrc` or __graft_entry__.build()). There is no CPU fallback.")
         handle = ctypes.CDLL(LIB_PATH)
+        handle.egtr_abi_version.restype = ctypes.c_int
+        got = handle.egtr_abi_version()
+        if got != ABI_VERSION:   # a stale or foreign build: same symbol names, other contracts
+            raise EgtrHipError(f"{LIB_PATH} has ABI version {got}, this package was written against {ABI_VERSION}: "
+                               "rebuild it (make -C egtr_amd/csrc)")
+        if os.environ.get("EGTR_HIP_LIBRARY"):
+            import sys
+            print(f"egtr_amd: EGTR_HIP_LIBRARY is set -- using {LIB_PATH} instead of the in-tree build", file=sys.stderr)
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing -> loud
             fn.argtypes = argtypes

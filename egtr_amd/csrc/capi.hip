@@ -24,7 +24,7 @@ int egtr_raise_dynamic_lds(const void* kernel, int bytes, unsigned long long* do
   return EGTR_OK;
 }
 
-extern "C" int egtr_abi_version(void) { return 1; }
+extern "C" int egtr_abi_version(void) { return EGTR_ABI_VERSION; }
 
 extern "C" const char* egtr_status_string(int status) {
   switch (status) {

@@ -1,0 +1,549 @@
+// One decoder layer of Deformable-DETR as ONE launch (inference, fp32, 8 heads x 32 channels, 4 levels x 4 points,
+// 1024 hidden units): reference model/deformable_detr.py:1390-1489 (layer), :1107-1262 (self-attention with retained
+// q / k), :1026-1104 (cross-attention = MSDA), the loop of :1774-1968 runs one launch per layer.
+//
+// Why: at 200 query rows the layer is a chain of eight dependent products of <= 100 MFLOP; as eight (then nine) launches
+// it paid ~4.8 us of launch floor per link, 59 launches / 0.58 ms for decoder + heads (profiles/r04_forward_breakdown.txt).
+// A barrier between workgroups that share ONE XCD's L2 costs ~1 us (tools/xcd_barrier.hip, profiles/r03_xcd_barrier.txt).
+//
+// Design.  The rows of a layer are independent except inside the self-attention (every query reads all keys / values),
+// and the keys / values of layer l + 1 are products of layer l's output rows.  So:
+//   * one launch per layer; the kernel boundary is the only device-wide meeting point (q / k / v of the NEXT layer are
+//     written by the closing phase of this one);
+//   * a CLUSTER of 8 workgroups owns 8 query rows of one image; workgroup h of the cluster owns head h: its slice of every
+//     product -- head h of the attention, the 32 input channels of head h in the two output projections (split K), 128 of
+//     the 1024 hidden units (fc1 columns = fc2 split K), head h of the next layer's q / k / v;
+//   * the cluster's workgroups sit on one XCD (workgroup ids are dealt round-robin to the 8 XCDs: ids with equal id % 8
+//     share an L2; verified per launch from HW_REG_XCC_ID) and meet three times per layer: each writes its PARTIAL 8 x 256
+//     result, passes an L2-local barrier (atomic in the L2, agent-scope polls), and every workgroup then adds the eight
+//     partials in head order (deterministic), the bias and the residual, and applies the LayerNorm itself.  No fences: the
+//     partials go L1-write-through -> L2 and are read back with sc1 loads (past the L1, served by that L2);
+//   * products run on v_mfma_f32_4x4x1_16b_f32 (exact fp32): 16 blocks of 4 x 4 = 4 rows x 64 columns per instruction,
+//     lane = output column, so a weight tile is stored pre-packed [k / 4][64 lanes][4] and streams with one coalesced
+//     16-byte load per lane per four k, straight into the B operand; the 8 rows are two row groups.  (16 x 16 x 4 would
+//     idle half its rows on an 8-row panel.)
+// 25 clusters x 8 workgroups = 200 CUs at N = 200; larger batches loop the 32 physical clusters over the row panels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "msda_common.h"
+
+namespace {
+
+using namespace egtr_msda;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kR = 8;            // rows per cluster
+constexpr int kH = 8;            // workgroups per cluster = heads
+constexpr int kPhys = 32;        // physical clusters (4 per XCD)
+constexpr int kLdx = 260;        // LDS row stride of a 256-wide panel (floats): rows 4 banks apart
+constexpr int kMaxKeys = 320;    // self-attention keys held in LDS
+constexpr int kLds = kMaxKeys + 4;
+constexpr int kLdh = 132;        // hidden slice 128 + 4
+constexpr int kLda = 36;         // 32-wide head panels
+constexpr int kMaxSpins = 400000;
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+// 16-byte load served by the XCD's L2 (sc1 = agent scope: misses the CU's L1); the caller waits with wait_loads().
+__device__ __forceinline__ f32x4 ld_l2(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// Barrier between the kH workgroups of a cluster.  The counter only grows: an arrival learns its generation from the value
+// it replaces, so nothing is ever reset (wrap-around is harmless: 2^32 is a multiple of kH).  Never hangs: after kMaxSpins
+// polls the workgroup raises bit 0 of *status and goes on (the host reads the word; results are then void).
+__device__ __forceinline__ void cluster_barrier(unsigned* ctr, unsigned* status) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial stores have reached the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned old;
+    const unsigned one = 1u;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ctr), "v"(one) : "memory");
+    const unsigned target = (old / kH + 1u) * kH;
+    int spins = 0;
+    while (true) {
+      unsigned cur;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(cur) : "v"(ctr) : "memory");
+      if ((int)(cur - target) >= 0) break;
+      if (++spins > kMaxSpins) {
+        atomicOr(status, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+struct Args {
+  EgtrDecoderLayer p;
+};
+
+// acc[row group] += X[8 rows][k range] . Wtile[64 columns][k range]^T over NSTEP groups of four k.
+//   wp: packed tile [k / 4][64][4] at (first group, this lane); xs: LDS, row (lane & 3) of the panel at the first k.
+template <int NSTEP>
+__device__ __forceinline__ void tile_mma(const float4* __restrict__ wp, const float* xs, int ld, f32x4& lo, f32x4& hi) {
+  constexpr int U = NSTEP < 8 ? NSTEP : 8;
+#pragma unroll
+  for (int s0 = 0; s0 < NSTEP; s0 += U) {
+    f32x4 b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float4 t = wp[(s0 + u) * 64];
+      b[u] = f32x4{t.x, t.y, t.z, t.w};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + (s0 + u) * 4);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + 4 * ld + (s0 + u) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        lo = mfma4(a0[j], b[u][j], lo);
+        hi = mfma4(a1[j], b[u][j], hi);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float half_sum(float v) {   // sum over the 32 lanes of a half wave
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  v += __shfl_xor(v, 16);
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 1));
+  v = fmaxf(v, __shfl_xor(v, 2));
+  v = fmaxf(v, __shfl_xor(v, 4));
+  v = fmaxf(v, __shfl_xor(v, 8));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return v;
+}
+
+// Thread (r = tid >> 5, j = tid & 31) owns columns 4j .. 4j+3 and 128 + 4j .. of row r of the cluster's panel:
+// y = sum of the 8 partials (head order) + bias + residual, then LayerNorm over the row (32 lanes).
+__device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of this cluster */, int r, int j,
+                                          const float* __restrict__ bias, f32x4 res0, f32x4 res1,
+                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                          f32x4& o0, f32x4& o1) {
+  f32x4 p0[kH], p1[kH];
+#pragma unroll
+  for (int hh = 0; hh < kH; ++hh) {
+    p0[hh] = ld_l2(part + (hh * kR + r) * 256 + 4 * j);
+    p1[hh] = ld_l2(part + (hh * kR + r) * 256 + 128 + 4 * j);
+  }
+  wait_loads(p0[0], p0[1], p0[2], p0[3]);
+  wait_loads(p0[4], p0[5], p0[6], p0[7]);
+  wait_loads(p1[0], p1[1], p1[2], p1[3]);
+  wait_loads(p1[4], p1[5], p1[6], p1[7]);
+  f32x4 y0 = p0[0], y1 = p1[0];
+#pragma unroll
+  for (int hh = 1; hh < kH; ++hh) {
+    y0 += p0[hh];
+    y1 += p1[hh];
+  }
+  const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * j), b1 = *reinterpret_cast<const float4*>(bias + 128 + 4 * j);
+  y0 += f32x4{b0.x, b0.y, b0.z, b0.w};
+  y1 += f32x4{b1.x, b1.y, b1.z, b1.w};
+  y0 += res0;
+  y1 += res1;
+  const float mean = half_sum((y0[0] + y0[1]) + (y0[2] + y0[3]) + (y1[0] + y1[1]) + (y1[2] + y1[3])) * (1.f / 256.f);
+  y0 -= mean;
+  y1 -= mean;
+  const float var = half_sum((y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) + (y1[0] * y1[0] + y1[1] * y1[1]) +
+                             (y1[2] * y1[2] + y1[3] * y1[3])) * (1.f / 256.f);
+  const float rstd = rsqrtf(var + eps);
+  const float4 g0 = *reinterpret_cast<const float4*>(gamma + 4 * j), g1 = *reinterpret_cast<const float4*>(gamma + 128 + 4 * j);
+  const float4 e0 = *reinterpret_cast<const float4*>(beta + 4 * j), e1 = *reinterpret_cast<const float4*>(beta + 128 + 4 * j);
+  o0 = y0 * rstd * f32x4{g0.x, g0.y, g0.z, g0.w} + f32x4{e0.x, e0.y, e0.z, e0.w};
+  o1 = y1 * rstd * f32x4{g1.x, g1.y, g1.z, g1.w} + f32x4{e1.x, e1.y, e1.z, e1.w};
+}
+
+// Store the 8 x 64 tile held by a wave (lane = column) as rows of the cluster's partial buffer.
+__device__ __forceinline__ void store_partial(float* part_h /* [8][256] of this head */, int col, const f32x4& lo, const f32x4& hi) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    part_h[i * 256 + col] = lo[i];
+    part_h[(4 + i) * 256 + col] = hi[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
+  const EgtrDecoderLayer& P = A.p;
+  __shared__ __attribute__((aligned(16))) float s_x[kR * kLdx];     // the panel (LayerNorm output)
+  __shared__ __attribute__((aligned(16))) float s_xp[kR * kLdx];    // panel + position rows
+  __shared__ __attribute__((aligned(16))) float s_s[kR * kLds];     // attention scores / probabilities
+  __shared__ __attribute__((aligned(16))) float s_red[4 * kR * 64]; // per-wave partial tiles
+  __shared__ __attribute__((aligned(16))) float s_hid[kR * kLdh];   // hidden slice after ReLU
+  __shared__ __attribute__((aligned(16))) float s_a[kR * kLda];     // 8 x 32 head panel (q rows, attention / MSDA output)
+  __shared__ __attribute__((aligned(16))) float s_ol[kR * 64];      // offsets (32) + logits (16) of the head
+  __shared__ __attribute__((aligned(16))) int4 s_ro[kR * 16];       // per (row, sample): 4 corner byte offsets
+  __shared__ __attribute__((aligned(16))) float4 s_rw[kR * 16];     // per (row, sample): 4 corner weights x attention
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int slot = idx >> 3, h = idx & 7;
+  const int pc = slot * 8 + xcd;
+  if (idx >= kPhys / 8 * kH || pc >= P.num_clusters) return;   // the whole cluster leaves together
+  unsigned* ctr = P.barriers + pc * 32;
+  const int N = P.num_query, ppi = (N + kR - 1) / kR;
+  const int r = tid >> 5, j = tid & 31;     // panel mapping of the reduce / LayerNorm steps
+  LevelGeom G;
+  load_geom(P.spatial_shapes, P.level_start_index, 4, G);
+  unsigned my_xcc = 0;
+  if (tid == 0) {
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
+    my_xcc &= 0xf;
+  }
+
+  for (int c = pc; c < P.num_clusters; c += kPhys) {
+    const int b = c / ppi, r0 = (c - b * ppi) * kR;
+    const int nvalid = min(kR, N - r0);
+    const size_t row0 = (size_t)b * N + r0;                 // first global row of the panel
+    const int rc = min(r, nvalid - 1);                      // clamped row of this thread
+    const size_t grow = row0 + rc;
+    float* part1 = P.partials + ((size_t)(0 * P.num_clusters + c) * kH) * kR * 256;
+    float* part2 = P.partials + ((size_t)(1 * P.num_clusters + c) * kH) * kR * 256;
+    float* part3 = P.partials + ((size_t)(2 * P.num_clusters + c) * kH) * kR * 256;
+    if (tid == 0) P.xcc_ids[c * kH + h] = (int)my_xcc;
+
+    // ================================================================= phase 1: self-attention of head h, 8 rows ======
+    // q rows of the head -> s_a
+    if (tid < 64) {
+      const int rr = min(tid >> 3, nvalid - 1), d4 = tid & 7;
+      const float4 t = *reinterpret_cast<const float4*>(P.q + ((row0 + rr) % P.qkv_rows) * 256 + h * 32 + d4 * 4);
+      *reinterpret_cast<float4*>(s_a + (tid >> 3) * kLda + d4 * 4) = t;
+    }
+    __syncthreads();
+    const int nkt = (N + 63) >> 6;
+    for (int kt = wave; kt < nkt; kt += 4) {   // scores S[row][key], lane = key
+      const int key = kt * 64 + lane;
+      const float4* kp = reinterpret_cast<const float4*>(P.k + (((size_t)b * N + min(key, N - 1)) % P.qkv_rows) * 256 + h * 32);
+      f32x4 kb[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const float4 t = kp[s];
+        kb[s] = f32x4{t.x, t.y, t.z, t.w};
+      }
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      const float* xs = s_a + (lane & 3) * kLda;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + s * 4);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + 4 * kLda + s * 4);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          lo = mfma4(a0[jj], kb[s][jj], lo);
+          hi = mfma4(a1[jj], kb[s][jj], hi);
+        }
+      }
+      const bool ok = key < N;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_s[i * kLds + key] = ok ? lo[i] : -INFINITY;
+        s_s[(4 + i) * kLds + key] = ok ? hi[i] : -INFINITY;
+      }
+    }
+    __syncthreads();
+    {   // softmax of row r over the keys (32 lanes per row)
+      const int nk = nkt * 64;
+      float m = -INFINITY;
+      for (int kk = j; kk < nk; kk += 32) m = fmaxf(m, s_s[r * kLds + kk]);
+      m = half_max(m);
+      float sum = 0.f;
+      for (int kk = j; kk < nk; kk += 32) {
+        const float e = __expf(s_s[r * kLds + kk] - m);
+        s_s[r * kLds + kk] = e;
+        sum += e;
+      }
+      sum = half_sum(sum);
+      const float inv = 1.f / sum;
+      for (int kk = j; kk < nk; kk += 32) s_s[r * kLds + kk] *= inv;
+    }
+    __syncthreads();
+    {   // O = P V: lane = (key half kh, channel d); the wave's key tiles; the two halves are added at the end
+      const int d = lane & 31, kh = lane >> 5;
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      for (int kt = wave; kt < nkt; kt += 4) {
+        const int key0 = kt * 64 + kh * 32;
+        const float* vp = P.v + (((size_t)b * N) % P.qkv_rows) * 256 + h * 32 + d;
+        const float* ps = s_s + (lane & 3) * kLds + key0;
+#pragma unroll
+        for (int s0 = 0; s0 < 32; s0 += 8) {
+          float vb[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) vb[u] = vp[(size_t)min(key0 + s0 + u, N - 1) * 256];
+#pragma unroll
+          for (int u4 = 0; u4 < 2; ++u4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ps + s0 + u4 * 4);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ps + 4 * kLds + s0 + u4 * 4);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              lo = mfma4(a0[jj], vb[u4 * 4 + jj], lo);
+              hi = mfma4(a1[jj], vb[u4 * 4 + jj], hi);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        lo[i] += __shfl_xor(lo[i], 32);
+        hi[i] += __shfl_xor(hi[i], 32);
+      }
+      if (lane < 32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s_red[(wave * kR + i) * 64 + d] = lo[i];
+          s_red[(wave * kR + 4 + i) * 64 + d] = hi[i];
+        }
+      }
+    }
+    __syncthreads();
+    s_a[r * kLda + j] = (s_red[(0 * kR + r) * 64 + j] + s_red[(1 * kR + r) * 64 + j]) +
+                        (s_red[(2 * kR + r) * 64 + j] + s_red[(3 * kR + r) * 64 + j]);
+    __syncthreads();
+    {   // output projection, this head's 32 input channels (split K): wave = output tile
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      tile_mma<8>(reinterpret_cast<const float4*>(P.w_attn_out) + ((size_t)wave * 64 + 8 * h) * 64 + lane,
+                  s_a + (lane & 3) * kLda, kLda, lo, hi);
+      store_partial(part1 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
+    }
+    cluster_barrier(ctr, P.status);
+    if (tid == 0) {   // the cluster must share one L2: every member reports the XCD it runs on
+      bool same = true;
+      for (int hh = 0; hh < kH; ++hh) {
+        int v;
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(P.xcc_ids + c * kH + hh) : "memory");
+        same = same && v == (int)my_xcc;
+      }
+      if (!same) atomicOr(P.status, 2u);
+    }
+
+    // ================================================================= phase 2: LayerNorm 1, cross-attention of head h ==
+    f32x4 x1a, x1b;
+    {
+      const float4 t0 = *reinterpret_cast<const float4*>(P.x_in + (grow % P.x_rows) * 256 + 4 * j);
+      const float4 t1 = *reinterpret_cast<const float4*>(P.x_in + (grow % P.x_rows) * 256 + 128 + 4 * j);
+      reduce_ln(part1, r, j, P.b_attn_out, f32x4{t0.x, t0.y, t0.z, t0.w}, f32x4{t1.x, t1.y, t1.z, t1.w}, P.ln1_gamma,
+                P.ln1_beta, P.ln_eps, x1a, x1b);
+      const float* pr = P.pos + (size_t)((row0 + rc) % P.pos_rows) * 256;
+      const float4 q0 = *reinterpret_cast<const float4*>(pr + 4 * j), q1 = *reinterpret_cast<const float4*>(pr + 128 + 4 * j);
+      *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x1a;
+      *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x1b;
+      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x1a + f32x4{q0.x, q0.y, q0.z, q0.w};
+      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 128 + 4 * j) = x1b + f32x4{q1.x, q1.y, q1.z, q1.w};
+    }
+    __syncthreads();
+    {   // sampling offsets (32) + attention logits (16) of head h: one 64-column tile, the waves split K
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      tile_mma<16>(reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64 + lane,
+                   s_xp + (lane & 3) * kLdx + 64 * wave, kLdx, lo, hi);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_red[(wave * kR + i) * 64 + lane] = lo[i];
+        s_red[(wave * kR + 4 + i) * 64 + lane] = hi[i];
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < kR * 64; e += 256) {
+      const int rr = e >> 6, cc = e & 63;
+      s_ol[e] = (s_red[(0 * kR + rr) * 64 + cc] + s_red[(1 * kR + rr) * 64 + cc]) +
+                (s_red[(2 * kR + rr) * 64 + cc] + s_red[(3 * kR + rr) * 64 + cc]) + P.b_off_logit[h * 64 + cc];
+    }
+    __syncthreads();
+    if (tid < kR * 16) {   // (row, sample): softmax over the head's 16 logits, sampling location, bilinear geometry
+      const int rr = tid >> 4, smp = tid & 15, lvl = smp >> 2;
+      const float ox = s_ol[rr * 64 + 2 * smp], oy = s_ol[rr * 64 + 2 * smp + 1], lg = s_ol[rr * 64 + 32 + smp];
+      float m = lg;
+      m = fmaxf(m, __shfl_xor(m, 1));
+      m = fmaxf(m, __shfl_xor(m, 2));
+      m = fmaxf(m, __shfl_xor(m, 4));
+      m = fmaxf(m, __shfl_xor(m, 8));
+      const float ex = expf(lg - m);
+      float sum = ex;
+      sum += __shfl_xor(sum, 1);
+      sum += __shfl_xor(sum, 2);
+      sum += __shfl_xor(sum, 4);
+      sum += __shfl_xor(sum, 8);
+      const float a = ex / sum;
+      const size_t gr = row0 + min(rr, nvalid - 1);
+      const float2 rp = *reinterpret_cast<const float2*>(P.reference_points + (gr * 4 + lvl) * 2);
+      const int Wl = SEL_W(G, lvl), Hl = SEL_H(G, lvl);
+      const SampleGeom g = sample_geom<1024, 128>(rp.x + ox / (float)Wl, rp.y + oy / (float)Hl, Hl, Wl, SEL_S(G, lvl), h);
+      bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
+      if (P.keep_bits != nullptr) {   // padded tokens contribute nothing (dd:1050-1052)
+        const unsigned* kb = P.keep_bits + (size_t)b * ((P.spatial_size + 31) >> 5);
+        const int p0 = g.off[0] >> 10, p1 = g.off[1] >> 10, p2 = g.off[2] >> 10, p3 = g.off[3] >> 10;
+        k0 = k0 && ((kb[p0 >> 5] >> (p0 & 31)) & 1u);
+        k1 = k1 && ((kb[p1 >> 5] >> (p1 & 31)) & 1u);
+        k2 = k2 && ((kb[p2 >> 5] >> (p2 & 31)) & 1u);
+        k3 = k3 && ((kb[p3 >> 5] >> (p3 & 31)) & 1u);
+      }
+      s_ro[tid] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
+      s_rw[tid] = make_float4(k0 ? g.w[0] * a : 0.f, k1 ? g.w[1] * a : 0.f, k2 ? g.w[2] * a : 0.f, k3 ? g.w[3] * a : 0.f);
+    }
+    __syncthreads();
+    {   // gather: thread = (row, sample quad, channel quad): 16 corner loads of 16 bytes in flight
+      const int sq = (tid >> 3) & 3, c4 = tid & 7;
+      const char* vb = reinterpret_cast<const char*>(P.value) + (size_t)b * P.spatial_size * 1024 + c4 * 16;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      float wsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int4 o = s_ro[r * 16 + sq * 4 + i];
+        const float4 w = s_rw[r * 16 + sq * 4 + i];
+        const float4 v0 = *reinterpret_cast<const float4*>(vb + (unsigned)o.x);
+        const float4 v1 = *reinterpret_cast<const float4*>(vb + (unsigned)o.y);
+        const float4 v2 = *reinterpret_cast<const float4*>(vb + (unsigned)o.z);
+        const float4 v3 = *reinterpret_cast<const float4*>(vb + (unsigned)o.w);
+        wsum += (w.x + w.y) + (w.z + w.w);
+        acc[0] += w.x * v0.x + w.y * v1.x + w.z * v2.x + w.w * v3.x;
+        acc[1] += w.x * v0.y + w.y * v1.y + w.z * v2.y + w.w * v3.y;
+        acc[2] += w.x * v0.z + w.y * v1.z + w.z * v2.z + w.w * v3.z;
+        acc[3] += w.x * v0.w + w.y * v1.w + w.z * v2.w + w.w * v3.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] += __shfl_xor(acc[i], 8);
+        acc[i] += __shfl_xor(acc[i], 16);
+      }
+      wsum += __shfl_xor(wsum, 8);
+      wsum += __shfl_xor(wsum, 16);
+      if (sq == 0) {
+        if (P.value_bias != nullptr) {   // sum_s w_s (v_s + b) = sum_s w_s v_s + b sum_s w_s
+          const float4 bv = *reinterpret_cast<const float4*>(P.value_bias + h * 32 + c4 * 4);
+          acc[0] += bv.x * wsum;
+          acc[1] += bv.y * wsum;
+          acc[2] += bv.z * wsum;
+          acc[3] += bv.w * wsum;
+        }
+        *reinterpret_cast<f32x4*>(s_a + r * kLda + c4 * 4) = acc;
+      }
+    }
+    __syncthreads();
+    {   // cross-attention output projection, split K by head
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      tile_mma<8>(reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64 + lane,
+                  s_a + (lane & 3) * kLda, kLda, lo, hi);
+      store_partial(part2 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
+    }
+    cluster_barrier(ctr, P.status);
+
+    // ================================================================= phase 3: LayerNorm 2, 128 hidden units ==========
+    f32x4 x2a, x2b;
+    reduce_ln(part2, r, j, P.b_cross_out, x1a, x1b, P.ln2_gamma, P.ln2_beta, P.ln_eps, x2a, x2b);
+    *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x2a;
+    *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x2b;
+    __syncthreads();
+    {   // fc1: columns 128 h .. 128 h + 127 = two tiles x two K halves
+      const int tile = wave & 1, khalf = wave >> 1;
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      tile_mma<32>(reinterpret_cast<const float4*>(P.w_fc1) + ((size_t)(2 * h + tile) * 64 + 32 * khalf) * 64 + lane,
+                   s_x + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_red[(wave * kR + i) * 64 + lane] = lo[i];
+        s_red[(wave * kR + 4 + i) * 64 + lane] = hi[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cc = 4 * j + i, tile = cc >> 6, ln = cc & 63;
+      const float v = s_red[(tile * kR + r) * 64 + ln] + s_red[((2 + tile) * kR + r) * 64 + ln] + P.b_fc1[h * 128 + cc];
+      s_hid[r * kLdh + cc] = egtr_relu(v);
+    }
+    __syncthreads();
+    {   // fc2, split K over the hidden slice: wave = output tile
+      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+      tile_mma<32>(reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64 + lane,
+                   s_hid + (lane & 3) * kLdh, kLdh, lo, hi);
+      store_partial(part3 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
+    }
+    cluster_barrier(ctr, P.status);
+
+    // ================================================================= phase 4: LayerNorm 3, next layer's q / k / v ====
+    f32x4 x3a, x3b;
+    reduce_ln(part3, r, j, P.b_fc2, x2a, x2b, P.ln3_gamma, P.ln3_beta, P.ln_eps, x3a, x3b);
+    if (h == 0 && r < nvalid) {
+      *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 4 * j) = x3a;
+      *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 128 + 4 * j) = x3b;
+    }
+    if (P.q_next != nullptr) {
+      const float* pr = P.pos + (size_t)((row0 + rc) % P.pos_rows) * 256;
+      const float4 q0 = *reinterpret_cast<const float4*>(pr + 4 * j), q1 = *reinterpret_cast<const float4*>(pr + 128 + 4 * j);
+      *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x3a;
+      *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x3b;
+      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x3a + f32x4{q0.x, q0.y, q0.z, q0.w};
+      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 128 + 4 * j) = x3b + f32x4{q1.x, q1.y, q1.z, q1.w};
+      __syncthreads();
+      {   // tile 0 = [q_h | k_h] of (x + pos), tile 1 = [v_h | 0] of x; two K halves each
+        const int tile = wave & 1, khalf = wave >> 1;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        tile_mma<32>(reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + tile) * 64 + 32 * khalf) * 64 + lane,
+                     (tile == 0 ? s_xp : s_x) + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s_red[(wave * kR + i) * 64 + lane] = lo[i];
+          s_red[(wave * kR + 4 + i) * 64 + lane] = hi[i];
+        }
+      }
+      __syncthreads();
+      if (r < nvalid) {
+        const float* bq = P.b_qkv_next + h * 128;
+        const float qv = (s_red[(0 * kR + r) * 64 + j] + s_red[(2 * kR + r) * 64 + j] + bq[j]) * P.q_scale;
+        const float kv = s_red[(0 * kR + r) * 64 + 32 + j] + s_red[(2 * kR + r) * 64 + 32 + j] + bq[32 + j];
+        const float vv = s_red[(1 * kR + r) * 64 + j] + s_red[(3 * kR + r) * 64 + j] + bq[64 + j];
+        P.q_next[grow * 256 + h * 32 + j] = qv;
+        P.k_next[grow * 256 + h * 32 + j] = kv;
+        P.v_next[grow * 256 + h * 32 + j] = vv;
+      }
+    }
+    __syncthreads();   // LDS is reused by the next panel of this physical cluster
+  }
+}
+
+}  // namespace
+
+extern "C" int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLayer* layer) {
+  if (layer == nullptr) return EGTR_E_ARG;
+  const EgtrDecoderLayer& p = *layer;
+  if (p.batch <= 0 || p.num_query <= 0 || p.spatial_size <= 0 || p.pos_rows <= 0 || p.x_rows <= 0 || p.qkv_rows <= 0)
+    return EGTR_E_ARG;
+  // rows shared by the images of a batch come as ONE image's rows
+  if ((p.qkv_rows != p.num_query && p.qkv_rows != p.batch * p.num_query) || p.x_rows % p.num_query || p.pos_rows % p.num_query)
+    return EGTR_E_ARG;
+  if (p.num_query > kMaxKeys) return EGTR_E_UNSUPPORTED;
+  if (p.num_clusters != p.batch * ((p.num_query + kR - 1) / kR)) return EGTR_E_ARG;
+  const void* need[] = {p.x_in, p.pos, p.q, p.k, p.v, p.reference_points, p.value, p.spatial_shapes, p.level_start_index,
+                        p.x_out, p.w_attn_out, p.b_attn_out, p.ln1_gamma, p.ln1_beta, p.w_off_logit, p.b_off_logit,
+                        p.w_cross_out, p.b_cross_out, p.ln2_gamma, p.ln2_beta, p.w_fc1, p.b_fc1, p.w_fc2, p.b_fc2,
+                        p.ln3_gamma, p.ln3_beta, p.partials, p.barriers, p.status, p.xcc_ids};
+  for (const void* q : need)
+    if (q == nullptr) return EGTR_E_ARG;
+  if (p.q_next != nullptr && (p.k_next == nullptr || p.v_next == nullptr || p.w_qkv_next == nullptr || p.b_qkv_next == nullptr))
+    return EGTR_E_ARG;
+  Args a;
+  a.p = p;
+  hipLaunchKernelGGL(decoder_layer_cluster_f32, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_decoder_layer_workspace(int batch, int num_query, long long* partial_floats, int* barrier_words,
+                                            int* id_words) {
+  if (batch <= 0 || num_query <= 0) return EGTR_E_ARG;
+  const long long nc = (long long)batch * ((num_query + kR - 1) / kR);
+  if (partial_floats) *partial_floats = 3 * nc * kH * kR * 256;
+  if (barrier_words) *barrier_words = kPhys * 32;
+  if (id_words) *id_words = (int)(nc * kH);
+  return EGTR_OK;
+}

@@ -1,0 +1,269 @@
+"""Host side of ``egtr_decoder_layer_f32`` (csrc/dec_layer.hip): the decoder stack at inference as ONE launch per layer.
+
+Reference: model/deformable_detr.py:1774-1968 (the loop), :1390-1489 (the layer).  The kernel runs a layer as clusters of
+eight workgroups that meet in the L2 of one XCD; it relies on workgroup ids being dealt round-robin to the XCDs and CHECKS
+that on every launch (status word, bit 1).  ``run`` reads the status after the first eager call on a device and raises
+``DecoderClusterError`` if a cluster timed out or was spread over XCDs -- the caller then uses the per-operation path and
+says so once (``ops.note_fallback``).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from .load_custom import _stream
+
+# "0": the per-operation decoder (eight launches per layer) -- the A/B switch of tools/forward_breakdown.py
+ENABLED = os.environ.get("EGTR_DECODER_CLUSTER", "1") != "0"
+MAX_QUERIES = 320
+
+
+class DecoderClusterError(RuntimeError):
+    pass
+
+
+_P = ctypes.c_void_p
+
+
+class EgtrDecoderLayer(ctypes.Structure):
+    """include/egtr_hip.h: struct EgtrDecoderLayer, field for field."""
+    _fields_ = [(n, _P) for n in (
+        "x_in", "pos", "q", "k", "v", "reference_points", "value", "value_bias", "keep_bits", "spatial_shapes",
+        "level_start_index", "x_out", "q_next", "k_next", "v_next", "w_attn_out", "b_attn_out", "ln1_gamma", "ln1_beta",
+        "w_off_logit", "b_off_logit", "w_cross_out", "b_cross_out", "ln2_gamma", "ln2_beta", "w_fc1", "b_fc1", "w_fc2",
+        "b_fc2", "ln3_gamma", "ln3_beta", "w_qkv_next", "b_qkv_next", "partials", "barriers", "status", "xcc_ids")] + [
+        ("q_scale", ctypes.c_float), ("ln_eps", ctypes.c_float), ("batch", ctypes.c_int), ("num_query", ctypes.c_int),
+        ("spatial_size", ctypes.c_int), ("x_rows", ctypes.c_int), ("pos_rows", ctypes.c_int), ("qkv_rows", ctypes.c_int),
+        ("num_clusters", ctypes.c_int)]
+
+
+def pack(w):
+    """[N, K] -> [N / 64 tiles][K / 4][64 output columns][4 consecutive k] (N % 64 == 0, K % 4 == 0): the order in which a
+    wave of the kernel consumes a weight tile -- one coalesced 16-byte load per lane per four k."""
+    n, k = w.shape
+    assert n % 64 == 0 and k % 4 == 0
+    return w.reshape(n // 64, 64, k // 4, 4).permute(0, 2, 1, 3).contiguous()
+
+
+def _qkv_pack(attn):
+    """Per head two tiles: [q_h | k_h] and [v_h | 0]; biases [8][128] = (q_h, k_h, v_h, 0)."""
+    wq, wk, wv = attn.q_proj.weight, attn.k_proj.weight, attn.v_proj.weight
+    z = wq.new_zeros(32, wq.shape[1])
+    tiles, bias = [], []
+    for h in range(8):
+        s = slice(32 * h, 32 * h + 32)
+        tiles.append(pack(torch.cat([wq[s], wk[s]], 0)))
+        tiles.append(pack(torch.cat([wv[s], z], 0)))
+        bias.append(torch.cat([attn.q_proj.bias[s], attn.k_proj.bias[s], attn.v_proj.bias[s], wq.new_zeros(32)]))
+    return torch.cat(tiles, 0).contiguous(), torch.cat(bias).contiguous()
+
+
+def _layer_constants(layer):
+    """The packed weights of one decoder layer (cached on the layer, rebuilt when a parameter changes)."""
+    from . import ops
+    sa, ca = layer.self_attn, layer.encoder_attn
+    srcs = [sa.out_proj.weight, ca.sampling_offsets.weight, ca.attention_weights.weight, ca.sampling_offsets.bias,
+            ca.attention_weights.bias, ca.output_proj.weight, layer.fc1.weight, layer.fc2.weight, sa.q_proj.weight,
+            sa.k_proj.weight, sa.v_proj.weight, sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias]
+
+    def build():
+        so, aw = ca.sampling_offsets, ca.attention_weights
+        z = so.weight.new_zeros(16, so.weight.shape[1])
+        wol = torch.cat([pack(torch.cat([so.weight[32 * h:32 * h + 32], aw.weight[16 * h:16 * h + 16], z], 0))
+                         for h in range(8)], 0).contiguous()
+        bol = torch.cat([torch.cat([so.bias[32 * h:32 * h + 32], aw.bias[16 * h:16 * h + 16], so.bias.new_zeros(16)])
+                         for h in range(8)]).contiguous()
+        wqkv, bqkv = _qkv_pack(sa)
+        return dict(w_attn_out=pack(sa.out_proj.weight), w_off_logit=wol, b_off_logit=bol,
+                    w_cross_out=pack(ca.output_proj.weight), w_fc1=pack(layer.fc1.weight), w_fc2=pack(layer.fc2.weight),
+                    w_qkv=wqkv, b_qkv=bqkv)
+
+    return ops.cached_weights(layer, "decoder_cluster_pack", srcs, build)
+
+
+def supported(decoder, hidden_states, position_embeddings, reference_points, encoder_hidden_states, output_attentions):
+    """The configuration the kernel is written for: EGTR's decoder (d_model 256, 8 heads, 4 levels x 4 points, 1024 hidden
+    units, ReLU, no box refinement, 2-d reference points) at inference in fp32."""
+    import torch.nn.functional as F
+    if not (ENABLED and torch.is_tensor(hidden_states) and hidden_states.is_cuda and hidden_states.dtype == torch.float32
+            and not torch.is_grad_enabled() and encoder_hidden_states is not None and position_embeddings is not None
+            and not output_attentions and decoder.bbox_embed is None and reference_points.shape[-1] == 2
+            and hidden_states.shape[-1] == 256 and hidden_states.shape[1] <= MAX_QUERIES):
+        return False
+    for l in decoder.layers:
+        ca, sa = l.encoder_attn, l.self_attn
+        if not (l.activation_fn is F.relu and sa.num_heads == 8 and sa.embed_dim == 256 and ca.n_heads == 8
+                and ca.n_levels == 4 and ca.n_points == 4 and ca.d_model == 256 and l.fc1.out_features == 1024
+                and l.self_attn_layer_norm.eps == l.encoder_attn_layer_norm.eps == l.final_layer_norm.eps
+                and sa.q_proj.bias is not None and l.fc1.bias is not None):
+            return False
+    return True
+
+
+_WORKSPACES = {}   # (device index, stream handle) -> persistent (barriers, status) of eager launches
+_POOL = {}         # device index -> zeroed (barriers, status) sets, one per captured graph
+_CHECKED = set()   # device indices whose first eager run was verified
+
+
+def _new_workspace(dev):
+    return (torch.zeros(32 * 32, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+
+
+def _workspace(dev):
+    """The barrier counters only grow and are zeroed exactly once; launches that share a set must be stream-ordered.  Eager
+    launches: one set per (device, stream).  Under stream capture: a set of its own for the graph being captured, taken
+    from a pool that the first eager run filled (an allocation inside the capture would put a memset node into the
+    graph; it still works -- the counters may restart from zero -- and is what happens when the pool is empty)."""
+    if torch.cuda.is_current_stream_capturing():
+        pool = _POOL.get(dev.index)
+        return pool.pop() if pool else _new_workspace(dev)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = _new_workspace(dev)
+        if dev.index not in _POOL:
+            _POOL[dev.index] = [_new_workspace(dev) for _ in range(8)]
+    return ws
+
+
+def _rows(t, n_rows_per_image):
+    """[B, N, 256] (possibly a stride-0 expansion of [N, 256]) -> (dense 2-d tensor, its row count)."""
+    if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) == 0:
+        t = t[0]
+    t2 = t.reshape(-1, t.shape[-1])
+    t2 = t2 if (t2.is_contiguous() and t2.data_ptr() % 16 == 0) else t2.contiguous()
+    return t2, t2.shape[0]
+
+
+def _keep_bits(mask, B, S):
+    """One bit per token (1 = real): the copy the level-geometry kernel left on the mask tensor, or packed here."""
+    kb = getattr(mask, "_egtr_bits", None)
+    if kb is not None and kb.dtype == torch.int32 and tuple(kb.shape) == (B, (S + 31) // 32) and kb.is_cuda:
+        return kb
+    words = (S + 31) // 32
+    m = torch.zeros(B, words * 32, dtype=torch.int64, device=mask.device)
+    m[:, :S] = mask.reshape(B, S).to(torch.int64)
+    w = (m.view(B, words, 32) << torch.arange(32, device=mask.device, dtype=torch.int64)).sum(-1)
+    return ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32).contiguous()
+
+
+def run(decoder, hidden_states, position_embeddings, reference_input, values, value_bias, keep_mask, spatial_shapes,
+        level_start_index, first_with_pos=None):
+    """All layers of ``decoder``.  hidden_states / position_embeddings [B, N, 256] (stride-0 batch expansions are read in
+    place), reference_input [B, N, 4, 2] (reference points x valid ratios), values [Ld, B, S, 256] bias-free value
+    projections, value_bias [Ld, 256].  Returns (states [Ld, B, N, 256], q [Ld, B, N, 256] scaled, k [Ld, B, N, 256];
+    q[0] / k[0] may be stride-0 expansions over the batch)."""
+    from . import ops
+    lib = _lib.lib()
+    dev = hidden_states.device
+    B, N, _ = hidden_states.shape
+    nl = len(decoder.layers)
+    S = values.shape[2]
+    x0, x_rows = _rows(hidden_states, N)
+    pos, pos_rows = _rows(position_embeddings, N)
+    lay0 = decoder.layers[0].self_attn
+    scale = float(lay0.scaling)
+    # layer 0's projections: inputs are rows of the query table when both operands are batch expansions -> constants
+    consts = [_layer_constants(l) for l in decoder.layers]
+    with_pos0 = None
+    if first_with_pos is not None:
+        with_pos0, _ = _rows(first_with_pos, N)
+        if with_pos0.shape[0] != x_rows:
+            with_pos0 = None
+
+    def qkv0():
+        xp = with_pos0 if with_pos0 is not None else (x0 + (pos if pos_rows == x_rows else pos.repeat(x_rows // pos_rows, 1)))
+        q, k, v = ops.linear_grouped([
+            dict(x=xp, w=lay0.q_proj.weight, b=lay0.q_proj.bias, alpha=lay0.scaling),
+            dict(x=xp, w=lay0.k_proj.weight, b=lay0.k_proj.bias),
+            dict(x=x0, w=lay0.v_proj.weight, b=lay0.v_proj.bias)])
+        return q.contiguous(), k.contiguous(), v.contiguous()
+
+    if x_rows == N and pos_rows == N:
+        # both operands are rows of the query table (batch expansions): the projections are derived constants, keyed on the
+        # tensors the views were cut from and on the views' geometry
+        def base(t):
+            return t._base if t._base is not None else t
+        srcs = [lay0.q_proj.weight, lay0.q_proj.bias, lay0.k_proj.weight, lay0.k_proj.bias, lay0.v_proj.weight,
+                lay0.v_proj.bias, base(hidden_states), base(position_embeddings)]
+        name = f"decoder_cluster_qkv0:{x0.data_ptr()}:{pos.data_ptr()}:{with_pos0 is not None}"
+        q0, k0, v0 = ops.cached_weights(decoder, name, srcs, qkv0)
+    else:
+        q0, k0, v0 = qkv0()
+    qkv_rows0 = q0.shape[0]
+
+    states = torch.empty(nl, B * N, 256, dtype=torch.float32, device=dev)
+    qkv = torch.empty(max(nl - 1, 1), 3, B * N, 256, dtype=torch.float32, device=dev)
+    pf, bw, iw = ctypes.c_longlong(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.egtr_decoder_layer_workspace(B, N, ctypes.byref(pf), ctypes.byref(bw), ctypes.byref(iw)),
+               "egtr_decoder_layer_workspace")
+    partials = torch.empty(pf.value, dtype=torch.float32, device=dev)
+    ids = torch.empty(iw.value, dtype=torch.int32, device=dev)
+    barriers, status = _workspace(dev)
+    ref = reference_input.contiguous()
+    kbits = _keep_bits(keep_mask, B, S) if keep_mask is not None else None
+    vals = values if values.is_contiguous() else values.contiguous()
+    vb = value_bias.contiguous() if value_bias is not None else None
+    stream = _stream()
+    nclusters = B * ((N + 7) // 8)
+    for i, layer in enumerate(decoder.layers):
+        c = consts[i]
+        a = EgtrDecoderLayer()
+        if i == 0:
+            a.x_in, a.x_rows = x0.data_ptr(), x_rows
+            a.q, a.k, a.v, a.qkv_rows = q0.data_ptr(), k0.data_ptr(), v0.data_ptr(), qkv_rows0
+        else:
+            a.x_in, a.x_rows = states[i - 1].data_ptr(), B * N
+            a.q, a.k, a.v, a.qkv_rows = (qkv[i - 1, 0].data_ptr(), qkv[i - 1, 1].data_ptr(), qkv[i - 1, 2].data_ptr(),
+                                         B * N)
+        a.pos, a.pos_rows = pos.data_ptr(), pos_rows
+        a.reference_points = ref.data_ptr()
+        a.value = vals[i].data_ptr()
+        a.value_bias = vb[i].data_ptr() if vb is not None else None
+        a.keep_bits = kbits.data_ptr() if kbits is not None else None
+        a.spatial_shapes, a.level_start_index = spatial_shapes.data_ptr(), level_start_index.data_ptr()
+        a.x_out = states[i].data_ptr()
+        if i + 1 < nl:
+            n = consts[i + 1]
+            a.q_next, a.k_next, a.v_next = qkv[i, 0].data_ptr(), qkv[i, 1].data_ptr(), qkv[i, 2].data_ptr()
+            a.w_qkv_next, a.b_qkv_next = n["w_qkv"].data_ptr(), n["b_qkv"].data_ptr()
+        sa, ca = layer.self_attn, layer.encoder_attn
+        a.w_attn_out, a.b_attn_out = c["w_attn_out"].data_ptr(), sa.out_proj.bias.data_ptr()
+        a.ln1_gamma, a.ln1_beta = layer.self_attn_layer_norm.weight.data_ptr(), layer.self_attn_layer_norm.bias.data_ptr()
+        a.w_off_logit, a.b_off_logit = c["w_off_logit"].data_ptr(), c["b_off_logit"].data_ptr()
+        a.w_cross_out, a.b_cross_out = c["w_cross_out"].data_ptr(), ca.output_proj.bias.data_ptr()
+        a.ln2_gamma, a.ln2_beta = (layer.encoder_attn_layer_norm.weight.data_ptr(),
+                                   layer.encoder_attn_layer_norm.bias.data_ptr())
+        a.w_fc1, a.b_fc1 = c["w_fc1"].data_ptr(), layer.fc1.bias.data_ptr()
+        a.w_fc2, a.b_fc2 = c["w_fc2"].data_ptr(), layer.fc2.bias.data_ptr()
+        a.ln3_gamma, a.ln3_beta = layer.final_layer_norm.weight.data_ptr(), layer.final_layer_norm.bias.data_ptr()
+        a.partials, a.barriers, a.status, a.xcc_ids = (partials.data_ptr(), barriers.data_ptr(), status.data_ptr(),
+                                                       ids.data_ptr())
+        a.q_scale, a.ln_eps = scale, float(layer.self_attn_layer_norm.eps)
+        a.batch, a.num_query, a.spatial_size, a.num_clusters = B, N, S, nclusters
+        _lib.check(lib.egtr_decoder_layer_f32(stream, ctypes.byref(a)), "egtr_decoder_layer_f32")
+    if dev.index not in _CHECKED and not torch.cuda.is_current_stream_capturing():
+        st = int(status.item())   # one synchronisation, on the first eager run per device
+        if st != 0:
+            status.zero_()
+            barriers.zero_()
+            raise DecoderClusterError(
+                "egtr_decoder_layer_f32: " + ("a cluster barrier timed out; " if st & 1 else "")
+                + ("the workgroups of a cluster were spread over several XCDs; " if st & 2 else "")
+                + "the per-operation decoder is used instead")
+        _CHECKED.add(dev.index)
+    states = states.view(nl, B, N, 256)
+    if qkv_rows0 == N:   # layer 0's projections are the same rows for every image
+        q_all, k_all = [q0.unsqueeze(0).expand(B, N, 256)], [k0.unsqueeze(0).expand(B, N, 256)]
+    else:
+        q_all, k_all = [q0.view(B, N, 256)], [k0.view(B, N, 256)]
+    for i in range(nl - 1):
+        q_all.append(qkv[i, 0].view(B, N, 256))
+        k_all.append(qkv[i, 1].view(B, N, 256))
+    return states, q_all, k_all
+
+
+def read_status(dev):
+    """The sticky status word of the current (device, stream) workspace: 0 = every launch so far was sound."""
+    return int(_workspace(dev)[1].item())

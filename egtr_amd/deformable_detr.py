@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from . import ops
+from . import decoder_fused, ops
 from .backbone import DeformableDetrFrozenBatchNorm2d, ResNet50Features, conv1x1_as_gemm
 from .hf_compat import ModelOutput, PretrainedConfig, PreTrainedModel
 from .ops import MultiScaleDeformableAttentionFunction
@@ -996,6 +996,7 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                                                  lay0.n_points)):
                 # the fused MSDA kernel applies the bias (times the sum of the valid corner weights) and skips padded
                 # tokens itself: no pass over the [Ld, S, 256] values at all
+                values_all = values
                 values = [(values[i], b_all[i]) for i in range(nl)]
             else:
                 values = ops.bias_mask_rows_(values.view(nl, bsz_ * seq_, dm_), b_all,
@@ -1008,6 +1009,21 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
         hoisted_reference = None
         if self.bbox_embed is None and reference_points.shape[-1] == 2:  # no refinement: same input for every layer
             hoisted_reference = reference_points[:, :, None] * valid_ratios[:, None]
+        if (fast and isinstance(values, list) and hoisted_reference is not None
+                and decoder_fused.supported(self, hidden_states, position_embeddings, reference_points,
+                                            encoder_hidden_states, output_attentions)):
+            # ONE launch per layer (csrc/dec_layer.hip) instead of eight; a device whose dispatch does not keep a cluster's
+            # workgroups on one XCD refuses (checked on the first run) and the per-operation loop below runs
+            try:
+                states, q_all, k_all = decoder_fused.run(
+                    self, hidden_states, position_embeddings, hoisted_reference, values_all, b_all,
+                    encoder_attention_mask, spatial_shapes, level_start_index, first_with_pos=first_with_pos)
+            except decoder_fused.DecoderClusterError as exc:
+                ops.note_fallback("decoder_cluster", str(exc))
+                decoder_fused.ENABLED = False
+            else:
+                return self._fused_outputs(states, q_all, k_all, hidden_states, reference_points, output_hidden_states,
+                                           output_attention_states, return_dict)
         with_pos = first_with_pos if fast else None
         # inference: every layer's final LayerNorm writes its states straight into the stacked [Ld, B, N, d] buffer the
         # heads read (viewed [B, Ld, N, d]) -- no torch.stack copy at the end
@@ -1095,6 +1111,33 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
             intermediate_reference_points=intermediate_reference_points, hidden_states=all_hidden_states,
             attentions=all_self_attns, cross_attentions=all_cross_attentions,
             attention_queries=all_attention_queries, attention_keys=all_attention_keys)
+
+
+    def _fused_outputs(self, states, q_all, k_all, inputs_embeds, reference_points, output_hidden_states,
+                       output_attention_states, return_dict):
+        """Outputs of dd:1927-1968 from the stacked results of ``decoder_fused.run`` (states [Ld, B, N, d]; per-layer scaled
+        queries / keys [B, N, d], handed out as the [B, M, N, D] maps of dd:1179-1185 -- transposed views)."""
+        nl, B, N, d = states.shape
+        M = self.layers[0].self_attn.num_heads
+        hidden_states = states[nl - 1]
+        intermediate = states.permute(1, 0, 2, 3)
+        intermediate_reference_points = reference_points.unsqueeze(1).expand(-1, nl, -1, -1)
+        all_hidden_states = None
+        if output_hidden_states:
+            all_hidden_states = (inputs_embeds,) + tuple(states[i] for i in range(nl))
+        queries = keys = None
+        if output_attention_states:
+            queries = tuple(q.view(B, N, M, d // M).transpose(1, 2) if q.is_contiguous()
+                            else q.reshape(B, N, M, d // M).transpose(1, 2) for q in q_all)
+            keys = tuple(k.view(B, N, M, d // M).transpose(1, 2) if k.is_contiguous()
+                         else k.reshape(B, N, M, d // M).transpose(1, 2) for k in k_all)
+        if not return_dict:
+            return tuple(v for v in [hidden_states, intermediate, intermediate_reference_points, all_hidden_states]
+                         if v is not None)
+        return DeformableDetrDecoderOutput(
+            last_hidden_state=hidden_states, intermediate_hidden_states=intermediate,
+            intermediate_reference_points=intermediate_reference_points, hidden_states=all_hidden_states,
+            attentions=None, cross_attentions=None, attention_queries=queries, attention_keys=keys)
 
 
 class DeformableDetrModel(DeformableDetrPreTrainedModel):

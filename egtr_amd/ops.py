@@ -791,6 +791,29 @@ def invalidate_derived(model):
             m.__dict__["_folded"] = None
 
 
+# ---- leaving a HIP fast path is never silent ------------------------------------------------------------------------------
+# Every route from a hand-written kernel to an ATen composition (unsupported shape, misaligned operand, a device that
+# refuses the cluster kernel) is counted here and announced ONCE per reason; EGTR_STRICT_FAST_PATH=1 (bench.py sets it)
+# turns the first one into an error, so a benchmark number can not come from a deoptimised path.
+FALLBACKS = {}
+STRICT_FAST_PATH = os.environ.get("EGTR_STRICT_FAST_PATH", "0") == "1"
+
+
+class FastPathError(RuntimeError):
+    pass
+
+
+def note_fallback(name, why=""):
+    n = FALLBACKS.get(name, 0)
+    FALLBACKS[name] = n + 1
+    if STRICT_FAST_PATH:
+        raise FastPathError(f"left the HIP fast path '{name}': {why}")
+    if n == 0:
+        import warnings
+        warnings.warn(f"egtr_amd: leaving the HIP fast path '{name}' ({why}); counted in egtr_amd.ops.FALLBACKS",
+                      RuntimeWarning, stacklevel=3)
+
+
 def inference_fast_path(x):
     """True when the launch-count optimisations (grouped linears, LayerNorm + position output, batched value
     projections) apply: fp32 tensors on the GPU and no autograd graph being recorded."""

@@ -44,6 +44,9 @@ enum {
   EGTR_E_UNSUPPORTED = -3
 };
 
+/* Bumped whenever an entry point is added / removed or the meaning of an argument changes; egtr_amd/_lib.py refuses a
+ * library whose number differs from the one it was written against. */
+#define EGTR_ABI_VERSION 2
 int egtr_abi_version(void);
 const char* egtr_status_string(int status);
 /* last HIP error string seen by this thread (for EGTR_E_LAUNCH) */
@@ -198,6 +201,76 @@ int egtr_linear_grouped_ln_f32(egtr_stream_t stream, int num_groups, const float
                                const float* alpha_x, const float* alpha, const int* relu, int K,
                                const float* const* ln_residual, const float* const* ln_gamma, const float* const* ln_beta,
                                const float* ln_eps, const float* const* pos, const int* pos_rows, float* const* ln_out);
+
+/* ---- one decoder layer in ONE launch (inference, fp32) ---------------------------------------------------------------
+ * model/deformable_detr.py:1390-1489 (DeformableDetrDecoderLayer.forward: self-attention with position rows on q / k
+ * :1107-1262, residual + LayerNorm, multi-scale deformable cross-attention :1026-1104, residual + LayerNorm, fc1 / ReLU /
+ * fc2, residual + LayerNorm; dropout is the identity at inference) followed by the NEXT layer's scaled-q / k / v
+ * projections (:1161-1168), for d_model 256, 8 heads, 4 levels x 4 points, 1024 hidden units, 2-d reference points.
+ * The layer's q (already scaled by D^-1/2, the retained query map of :1179-1185), k and v come in; the next layer's go out.
+ * Weight matrices are PRE-PACKED for the kernel: pack(W [N, K]) = W.view(N / 64, 64, K / 4, 4).permute(0, 2, 1, 3), i.e.
+ * [N / 64 tiles][K / 4][64 output columns][4 consecutive k]; per-head tiles are zero-padded to 64 columns:
+ *   w_attn_out   pack(self_attn.out_proj.weight)            [4][64][64][4]      b_attn_out [256]
+ *   w_off_logit  per head h: pack([sampling_offsets.weight[32h:32h+32]; attention_weights.weight[16h:16h+16]; 0 x 16])
+ *                                                           [8][64][64][4]      b_off_logit [8][64] laid out alike
+ *   w_cross_out  pack(encoder_attn.output_proj.weight)      [4][64][64][4]      b_cross_out [256]
+ *   w_fc1        pack(fc1.weight [1024, 256])               [16][64][64][4]     b_fc1 [1024]
+ *   w_fc2        pack(fc2.weight [256, 1024])               [4][256][64][4]     b_fc2 [256]
+ *   w_qkv_next   per head h two tiles: pack([q_proj.weight[32h:32h+32]; k_proj.weight[32h:32h+32]]),
+ *                pack([v_proj.weight[32h:32h+32]; 0 x 32])  [8][2][64][64][4]   b_qkv_next [8][128] = (q, k, v, 0) x 32
+ * value is the BIAS-FREE value projection [B, S, 8, 32] of this layer; value_bias [256] (may be NULL) is applied by the
+ * kernel times the sum of the in-range, unpadded corner weights; keep_bits (may be NULL): one bit per token, 0 = padded
+ * (== the zeroed value rows of :1050-1052).  reference_points [B * N, 4, 2] already carry the valid ratios (:1874-1880).
+ * q_next == NULL (last layer): no projections.  Workspace (egtr_decoder_layer_workspace): `partials` floats, `barriers`
+ * 32-bit words (ZEROED ONCE when allocated, never again), `xcc_ids` ints, `status` one word zeroed by the caller: after
+ * the launch bit 0 = a cluster barrier timed out, bit 1 = the workgroups of a cluster did not share one XCD -- the
+ * results are void in both cases and the caller must use the per-operation entries instead.
+ * num_query <= 320, else EGTR_E_UNSUPPORTED. */
+typedef struct EgtrDecoderLayer {
+  const float* x_in;              /* [x_rows, 256] layer input, row index taken modulo x_rows */
+  const float* pos;               /* [pos_rows, 256] query position rows, row index taken modulo pos_rows */
+  const float* q;                 /* [qkv_rows, 256] this layer's projections, row index modulo qkv_rows */
+  const float* k;
+  const float* v;
+  const float* reference_points;  /* [B * N, 4, 2] */
+  const float* value;             /* [B, S, 8, 32] */
+  const float* value_bias;        /* [256] or NULL */
+  const unsigned* keep_bits;      /* [B, ceil(S / 32)] or NULL */
+  const int64_t* spatial_shapes;  /* [4, 2] (H, W), device */
+  const int64_t* level_start_index;
+  float* x_out;                   /* [B * N, 256] */
+  float* q_next;                  /* [B * N, 256] or NULL */
+  float* k_next;
+  float* v_next;
+  const float* w_attn_out;
+  const float* b_attn_out;
+  const float* ln1_gamma;
+  const float* ln1_beta;
+  const float* w_off_logit;
+  const float* b_off_logit;
+  const float* w_cross_out;
+  const float* b_cross_out;
+  const float* ln2_gamma;
+  const float* ln2_beta;
+  const float* w_fc1;
+  const float* b_fc1;
+  const float* w_fc2;
+  const float* b_fc2;
+  const float* ln3_gamma;
+  const float* ln3_beta;
+  const float* w_qkv_next;
+  const float* b_qkv_next;
+  float* partials;
+  unsigned* barriers;
+  unsigned* status;
+  int* xcc_ids;
+  float q_scale;                  /* D^-1/2 */
+  float ln_eps;
+  /* x_rows / pos_rows / qkv_rows: B * N, or N when the rows are the same for every image (layer 0: query table) */
+  int batch, num_query, spatial_size, x_rows, pos_rows, qkv_rows, num_clusters; /* num_clusters = batch * ceil(num_query / 8) */
+} EgtrDecoderLayer;
+int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLayer* layer);
+int egtr_decoder_layer_workspace(int batch, int num_query, long long* partial_floats, int* barrier_words, int* id_words);
 
 /* ---- MSDA prologue under autograd (training) -------------------------------------------------------------------- */
 /* sampling_locations [rows, M, L, P, 2] and attention_weights [rows, M, L, P] (softmax over the L * P samples of a head)

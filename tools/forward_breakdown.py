@@ -35,7 +35,8 @@ def last_before(end, pats, default):
     return default
 
 
-i_enc, i_dec = first("msda_fwd"), first("self_attn_fwd")
+i_enc = first("msda_fwd")
+i_dec = min(i for i in (first("self_attn_fwd"), first("decoder_layer_cluster")) if i is not None)
 # the encoder starts after the input projection's GroupNorm + flatten, the decoder after the last encoder layer's closing
 # LayerNorm (fused into the FFN kernel or stand-alone)
 c_enc = last_before(i_enc, ("gn_apply_flatten",), i_enc - 6)

@@ -18,7 +18,7 @@ import re
 import sqlite3
 
 
-def collect(paths, rx):
+def collect(paths, rx, min_grid=0):
     out, names = {}, {}
     dbs = []
     for p in paths:
@@ -31,11 +31,16 @@ def collect(paths, rx):
         except sqlite3.Error:
             continue
         ni = cols.index("kernel_name")
+        gi = next((cols.index(x) for x in ("grid_size_x", "grid_x", "grid_size") if x in cols), None)
+        if min_grid and gi is None:
+            print(f"--min-grid: no grid column in {cols}")
         ci = cols.index("counter_name") if "counter_name" in cols else cols.index("name")
         vi = cols.index("value") if "value" in cols else cols.index("counter_value")
         for r in rows:
             kn = str(r[ni])
             if not rx.search(kn):
+                continue
+            if min_grid and gi is not None and int(r[gi]) < min_grid:
                 continue
             names[kn] = names.get(kn, 0) + 1
             s = out.setdefault(r[ci], [0, 0.0])
@@ -51,8 +56,11 @@ def main():
     ap.add_argument("--name", required=True, help="the kernel label bench.py prints (roofline.kernel)")
     ap.add_argument("--alg-bytes", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--min-grid", type=int, default=0,
+                    help="only launches whose grid (work-items in x) is at least this (encoder-shaped launches of a kernel "
+                         "that also runs decoder-shaped)")
     a = ap.parse_args()
-    avg, names = collect(a.paths, re.compile(a.kernel_regex))
+    avg, names = collect(a.paths, re.compile(a.kernel_regex), a.min_grid)
     print("matching kernels:")
     for n, k in sorted(names.items(), key=lambda x: -x[1]):
         print(f"  {k:6d} rows  {n[:150]}")
