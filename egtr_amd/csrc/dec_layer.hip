@@ -56,17 +56,24 @@ __device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b, f32x4& c, f32x4& 
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-// Barrier between the kH workgroups of a cluster.  The counter only grows: an arrival learns its generation from the value
-// it replaces, so nothing is ever reset (wrap-around is harmless: 2^32 is a multiple of kH).  Never hangs: after kMaxSpins
-// polls the workgroup raises bit 0 of *status and goes on (the host reads the word; results are then void).
-__device__ __forceinline__ void cluster_barrier(unsigned* ctr, unsigned* status) {
+// Barrier between the kH workgroups of a cluster, in two halves so that the next phase's weight stream can be issued
+// between them.  The counter only grows: an arrival learns its generation from the value it replaces, so nothing is ever
+// reset (wrap-around is harmless: 2^32 is a multiple of kH).  Never hangs: after kMaxSpins polls the workgroup raises bit 0
+// of *status and goes on (the host reads the word; results are then void).
+__device__ __forceinline__ unsigned barrier_arrive(unsigned* ctr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial stores have reached the L2
   __syncthreads();
+  unsigned target = 0;
   if (threadIdx.x == 0) {
     unsigned old;
     const unsigned one = 1u;
     asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ctr), "v"(one) : "memory");
-    const unsigned target = (old / kH + 1u) * kH;
+    target = (old / kH + 1u) * kH;
+  }
+  return target;
+}
+__device__ __forceinline__ void barrier_wait(unsigned* ctr, unsigned target, unsigned* status) {
+  if (threadIdx.x == 0) {
     int spins = 0;
     while (true) {
       unsigned cur;
@@ -82,32 +89,65 @@ __device__ __forceinline__ void cluster_barrier(unsigned* ctr, unsigned* status)
   __syncthreads();
 }
 
+// ---- weight stream: NSTEP x 16 bytes per lane, issued long before use (inline asm: hipcc sinks ordinary loads next to
+// their first use), waited for with w_wait (tools/check_async_loads.py checks that nothing touches the registers earlier)
+template <int NSTEP>
+__device__ __forceinline__ void w_issue(f32x4 (&b)[NSTEP], const float4* base /* wave-uniform: tile, first k group */,
+                                        unsigned lane_bytes) {
+#ifdef EGTR_DEC_PLAIN_LOADS   // debugging aid: compiler-scheduled loads at the same program points
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base + s * 64) + lane_bytes);
+    b[s] = f32x4{t.x, t.y, t.z, t.w};
+  }
+  return;
+#endif
+  // one scalar base per four loads: the instruction's immediate offset reaches 3 x 1024 bytes
+#pragma unroll
+  for (int s = 0; s < NSTEP; s += 4) {
+    const float4* b4 = base + s * 64;
+    // s_nop 4: the base may have just been restored with v_readlane (VALU write of an SGPR), and a VMEM instruction that
+    // reads such an SGPR needs 5 wait states; the compiler's hazard recogniser does not look into inline asm (without it
+    // the load took a stale base: "memory access fault on address (nil)")
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(b[s]) : "v"(lane_bytes), "s"(b4));
+    if (s + 1 < NSTEP) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(b[s + 1]) : "v"(lane_bytes), "s"(b4));
+    if (s + 2 < NSTEP) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(b[s + 2]) : "v"(lane_bytes), "s"(b4));
+    if (s + 3 < NSTEP) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(b[s + 3]) : "v"(lane_bytes), "s"(b4));
+  }
+}
+template <int NSTEP>
+__device__ __forceinline__ void w_wait(f32x4 (&b)[NSTEP]) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) asm volatile("" : "+v"(b[s]));
+}
+
+#ifdef EGTR_DEC_TIMING
+__device__ unsigned long long g_dec_stamps[kH * 32];
+#define STAMP(i)                                                                       \
+  do {                                                                                 \
+    if (tid == 0 && pc == 0 && c == 0) g_dec_stamps[h * 32 + (i)] = wall_clock64();     \
+  } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 struct Args {
   EgtrDecoderLayer p;
 };
 
 // acc[row group] += X[8 rows][k range] . Wtile[64 columns][k range]^T over NSTEP groups of four k.
-//   wp: packed tile [k / 4][64][4] at (first group, this lane); xs: LDS, row (lane & 3) of the panel at the first k.
+//   b: the lane's NSTEP x 4 weights (packed tile [k / 4][64][4]); xs: LDS, row (lane & 3) of the panel at the first k.
 template <int NSTEP>
-__device__ __forceinline__ void tile_mma(const float4* __restrict__ wp, const float* xs, int ld, f32x4& lo, f32x4& hi) {
-  constexpr int U = NSTEP < 8 ? NSTEP : 8;
+__device__ __forceinline__ void tile_mma(const f32x4 (&b)[NSTEP], const float* xs, int ld, f32x4& lo, f32x4& hi) {
 #pragma unroll
-  for (int s0 = 0; s0 < NSTEP; s0 += U) {
-    f32x4 b[U];
+  for (int u = 0; u < NSTEP; ++u) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + u * 4);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + 4 * ld + u * 4);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float4 t = wp[(s0 + u) * 64];
-      b[u] = f32x4{t.x, t.y, t.z, t.w};
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + (s0 + u) * 4);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + 4 * ld + (s0 + u) * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lo = mfma4(a0[j], b[u][j], lo);
-        hi = mfma4(a1[j], b[u][j], hi);
-      }
+    for (int j = 0; j < 4; ++j) {
+      lo = mfma4(a0[j], b[u][j], lo);
+      hi = mfma4(a1[j], b[u][j], hi);
     }
   }
 }
@@ -189,7 +229,8 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
   __shared__ __attribute__((aligned(16))) int4 s_ro[kR * 16];       // per (row, sample): 4 corner byte offsets
   __shared__ __attribute__((aligned(16))) float4 s_rw[kR * 16];     // per (row, sample): 4 corner weights x attention
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lane_bytes = lane * 16;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int slot = idx >> 3, h = idx & 7;
   const int pc = slot * 8 + xcd;
@@ -215,6 +256,9 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     float* part2 = P.partials + ((size_t)(1 * P.num_clusters + c) * kH) * kR * 256;
     float* part3 = P.partials + ((size_t)(2 * P.num_clusters + c) * kH) * kR * 256;
     if (tid == 0) P.xcc_ids[c * kH + h] = (int)my_xcc;
+    STAMP(0);
+    f32x4 w_o[8];   // output projection: tile = wave, this head's 8 k groups
+    w_issue<8>(w_o, reinterpret_cast<const float4*>(P.w_attn_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
 
     // ================================================================= phase 1: self-attention of head h, 8 rows ======
     // q rows of the head -> s_a
@@ -254,6 +298,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       }
     }
     __syncthreads();
+    STAMP(1);
     {   // softmax of row r over the keys (32 lanes per row)
       const int nk = nkt * 64;
       float m = -INFINITY;
@@ -270,6 +315,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       for (int kk = j; kk < nk; kk += 32) s_s[r * kLds + kk] *= inv;
     }
     __syncthreads();
+    STAMP(2);
     {   // O = P V: lane = (key half kh, channel d); the wave's key tiles; the two halves are added at the end
       const int d = lane & 31, kh = lane >> 5;
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
@@ -311,13 +357,20 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     s_a[r * kLda + j] = (s_red[(0 * kR + r) * 64 + j] + s_red[(1 * kR + r) * 64 + j]) +
                         (s_red[(2 * kR + r) * 64 + j] + s_red[(3 * kR + r) * 64 + j]);
     __syncthreads();
+    STAMP(3);
     {   // output projection, this head's 32 input channels (split K): wave = output tile
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      tile_mma<8>(reinterpret_cast<const float4*>(P.w_attn_out) + ((size_t)wave * 64 + 8 * h) * 64 + lane,
-                  s_a + (lane & 3) * kLda, kLda, lo, hi);
+      w_wait<8>(w_o);
+      tile_mma<8>(w_o, s_a + (lane & 3) * kLda, kLda, lo, hi);
       store_partial(part1 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
-    cluster_barrier(ctr, P.status);
+    STAMP(4);
+    unsigned target = barrier_arrive(ctr);
+    f32x4 w_ol[16], w_c[8];   // phase 2's streams land while the cluster gathers: offsets / logits (K quarter), cross projection
+    w_issue<16>(w_ol, reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64, lane_bytes);
+    w_issue<8>(w_c, reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
+    barrier_wait(ctr, target, P.status);
+    STAMP(5);
     if (tid == 0) {   // the cluster must share one L2: every member reports the XCD it runs on
       bool same = true;
       for (int hh = 0; hh < kH; ++hh) {
@@ -343,10 +396,11 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 128 + 4 * j) = x1b + f32x4{q1.x, q1.y, q1.z, q1.w};
     }
     __syncthreads();
+    STAMP(6);
     {   // sampling offsets (32) + attention logits (16) of head h: one 64-column tile, the waves split K
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      tile_mma<16>(reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64 + lane,
-                   s_xp + (lane & 3) * kLdx + 64 * wave, kLdx, lo, hi);
+      w_wait<16>(w_ol);
+      tile_mma<16>(w_ol, s_xp + (lane & 3) * kLdx + 64 * wave, kLdx, lo, hi);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s_red[(wave * kR + i) * 64 + lane] = lo[i];
@@ -360,6 +414,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
                 (s_red[(2 * kR + rr) * 64 + cc] + s_red[(3 * kR + rr) * 64 + cc]) + P.b_off_logit[h * 64 + cc];
     }
     __syncthreads();
+    STAMP(7);
     if (tid < kR * 16) {   // (row, sample): softmax over the head's 16 logits, sampling location, bilinear geometry
       const int rr = tid >> 4, smp = tid & 15, lvl = smp >> 2;
       const float ox = s_ol[rr * 64 + 2 * smp], oy = s_ol[rr * 64 + 2 * smp + 1], lg = s_ol[rr * 64 + 32 + smp];
@@ -392,6 +447,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       s_rw[tid] = make_float4(k0 ? g.w[0] * a : 0.f, k1 ? g.w[1] * a : 0.f, k2 ? g.w[2] * a : 0.f, k3 ? g.w[3] * a : 0.f);
     }
     __syncthreads();
+    STAMP(8);
     {   // gather: thread = (row, sample quad, channel quad): 16 corner loads of 16 bytes in flight
       const int sq = (tid >> 3) & 3, c4 = tid & 7;
       const char* vb = reinterpret_cast<const char*>(P.value) + (size_t)b * P.spatial_size * 1024 + c4 * 16;
@@ -430,13 +486,20 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       }
     }
     __syncthreads();
+    STAMP(9);
     {   // cross-attention output projection, split K by head
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      tile_mma<8>(reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64 + lane,
-                  s_a + (lane & 3) * kLda, kLda, lo, hi);
+      w_wait<8>(w_c);
+      tile_mma<8>(w_c, s_a + (lane & 3) * kLda, kLda, lo, hi);
       store_partial(part2 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
-    cluster_barrier(ctr, P.status);
+    STAMP(10);
+    target = barrier_arrive(ctr);
+    f32x4 w_f[32];   // fc1: tile 2h + (wave & 1), K half wave >> 1; later fc2 and the next layer's q / k / v
+    w_issue<32>(w_f, reinterpret_cast<const float4*>(P.w_fc1) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
+                lane_bytes);
+    barrier_wait(ctr, target, P.status);
+    STAMP(11);
 
     // ================================================================= phase 3: LayerNorm 2, 128 hidden units ==========
     f32x4 x2a, x2b;
@@ -444,11 +507,14 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x2a;
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x2b;
     __syncthreads();
+    STAMP(12);
     {   // fc1: columns 128 h .. 128 h + 127 = two tiles x two K halves
       const int tile = wave & 1, khalf = wave >> 1;
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      tile_mma<32>(reinterpret_cast<const float4*>(P.w_fc1) + ((size_t)(2 * h + tile) * 64 + 32 * khalf) * 64 + lane,
-                   s_x + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
+      w_wait<32>(w_f);
+      tile_mma<32>(w_f, s_x + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
+      // fc2's stream (tile = wave, this head's 32 k groups) flies during the hidden-slice exchange below
+      w_issue<32>(w_f, reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64, lane_bytes);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         s_red[(wave * kR + i) * 64 + lane] = lo[i];
@@ -462,18 +528,27 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       const float v = s_red[(tile * kR + r) * 64 + ln] + s_red[((2 + tile) * kR + r) * 64 + ln] + P.b_fc1[h * 128 + cc];
       s_hid[r * kLdh + cc] = egtr_relu(v);
     }
+    STAMP(13);
     __syncthreads();
+    STAMP(14);
     {   // fc2, split K over the hidden slice: wave = output tile
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      tile_mma<32>(reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64 + lane,
-                   s_hid + (lane & 3) * kLdh, kLdh, lo, hi);
+      w_wait<32>(w_f);
+      tile_mma<32>(w_f, s_hid + (lane & 3) * kLdh, kLdh, lo, hi);
       store_partial(part3 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
-    cluster_barrier(ctr, P.status);
+    STAMP(15);
+    target = barrier_arrive(ctr);
+    if (P.q_next != nullptr)
+      w_issue<32>(w_f, reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
+                  lane_bytes);
+    barrier_wait(ctr, target, P.status);
+    STAMP(16);
 
     // ================================================================= phase 4: LayerNorm 3, next layer's q / k / v ====
     f32x4 x3a, x3b;
     reduce_ln(part3, r, j, P.b_fc2, x2a, x2b, P.ln3_gamma, P.ln3_beta, P.ln_eps, x3a, x3b);
+    STAMP(17);
     if (h == 0 && r < nvalid) {
       *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 4 * j) = x3a;
       *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 128 + 4 * j) = x3b;
@@ -489,8 +564,8 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       {   // tile 0 = [q_h | k_h] of (x + pos), tile 1 = [v_h | 0] of x; two K halves each
         const int tile = wave & 1, khalf = wave >> 1;
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        tile_mma<32>(reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + tile) * 64 + 32 * khalf) * 64 + lane,
-                     (tile == 0 ? s_xp : s_x) + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
+        w_wait<32>(w_f);
+        tile_mma<32>(w_f, (tile == 0 ? s_xp : s_x) + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           s_red[(wave * kR + i) * 64 + lane] = lo[i];
@@ -508,6 +583,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
         P.v_next[grow * 256 + h * 32 + j] = vv;
       }
     }
+    STAMP(18);
     __syncthreads();   // LDS is reused by the next panel of this physical cluster
   }
 }
@@ -537,6 +613,14 @@ extern "C" int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLay
   hipLaunchKernelGGL(decoder_layer_cluster_f32, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }
+
+#ifdef EGTR_DEC_TIMING
+// instrumented builds only (tools/dec_phases.py): the 100 MHz time stamps of cluster 0's eight workgroups, [8][32]
+extern "C" int egtr_decoder_layer_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dec_stamps), sizeof(unsigned long long) * kH * 32) == hipSuccess ? EGTR_OK
+                                                                                                                   : EGTR_E_LAUNCH;
+}
+#endif
 
 extern "C" int egtr_decoder_layer_workspace(int batch, int num_query, long long* partial_floats, int* barrier_words,
                                             int* id_words) {

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Smallest run of the cluster decoder against the per-operation decoder (debugging aid; EGTR_HIP_LIBRARY selects a build)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+import test_gpu_decoder_cluster as T  # noqa: E402
+
+n, layers = int(sys.argv[1]) if len(sys.argv) > 1 else 200, int(sys.argv[2]) if len(sys.argv) > 2 else 2
+model = T._model(n, layers)
+pv, pm = T._inputs(1, 96, 128)
+ref = T._run(model, pv, pm, fused=False, base=True)
+out = T._run(model, pv, pm, fused=True, base=True)
+torch.cuda.synchronize()
+from egtr_amd import decoder_fused
+print("status", decoder_fused.read_status(torch.device("cuda:0")), "max diff",
+      max(float((a - b).abs().max()) for a, b in zip(out.decoder_hidden_states, ref.decoder_hidden_states)))
