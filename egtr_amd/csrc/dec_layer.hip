@@ -21,7 +21,11 @@
 //   * products run on v_mfma_f32_4x4x1_16b_f32 (exact fp32): 16 blocks of 4 x 4 = 4 rows x 64 columns per instruction,
 //     lane = output column, so a weight tile is stored pre-packed [k / 4][64 lanes][4] and streams with one coalesced
 //     16-byte load per lane per four k, straight into the B operand; the 8 rows are two row groups.  (16 x 16 x 4 would
-//     idle half its rows on an 8-row panel.)
+//     idle half its rows on an 8-row panel.)  The A operand uses the instruction's BROADCAST (cbsz = 4, abid = b: every
+//     block multiplies with block b's four rows; tools/probe/mfma_bcast_probe.hip): lane (b, i) holds x[i][64 q + 4 b + t],
+//     so one 16-byte LDS read per lane covers 64 k of a row group and the product loops contain no LDS traffic at all
+//     (the first version read its A fragments step by step: with one wave per SIMD every read's latency was exposed,
+//     profiles/r05_dec_phases_v1.txt: 4.5 us for the 256 MFMAs of fc1);
 // 25 clusters x 8 workgroups = 200 CUs at N = 200; larger batches loop the 32 physical clusters over the row panels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,12 +43,12 @@ constexpr int kH = 8;            // workgroups per cluster = heads
 constexpr int kPhys = 32;        // physical clusters (4 per XCD)
 constexpr int kLdx = 260;        // LDS row stride of a 256-wide panel (floats): rows 4 banks apart
 constexpr int kMaxKeys = 320;    // self-attention keys held in LDS
+constexpr int kMaxKt = kMaxKeys / 64;
 constexpr int kLds = kMaxKeys + 4;
 constexpr int kLdh = 132;        // hidden slice 128 + 4
 constexpr int kLda = 36;         // 32-wide head panels
+constexpr int kMaxBitWords = 1024;   // padding-mask bits of one image held in LDS (S <= 32768), else read from memory
 constexpr int kMaxSpins = 400000;
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
 // 16-byte load served by the XCD's L2 (sc1 = agent scope: misses the CU's L1); the caller waits with wait_loads().
 __device__ __forceinline__ f32x4 ld_l2(const float* p) {
@@ -56,42 +60,65 @@ __device__ __forceinline__ void wait_loads(f32x4& a, f32x4& b, f32x4& c, f32x4& 
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 
-// Barrier between the kH workgroups of a cluster, in two halves so that the next phase's weight stream can be issued
-// between them.  The counter only grows: an arrival learns its generation from the value it replaces, so nothing is ever
-// reset (wrap-around is harmless: 2^32 is a multiple of kH).  Never hangs: after kMaxSpins polls the workgroup raises bit 0
-// of *status and goes on (the host reads the word; results are then void).
-__device__ __forceinline__ unsigned barrier_arrive(unsigned* ctr) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's partial stores have reached the L2
-  __syncthreads();
-  unsigned target = 0;
-  if (threadIdx.x == 0) {
-    unsigned old;
-    const unsigned one = 1u;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(ctr), "v"(one) : "memory");
-    target = (old / kH + 1u) * kH;
-  }
-  return target;
+// Barrier between the kH workgroups of a cluster, in two halves so that the next phase's weight streams can be issued
+// between them -- kept PER WAVE (4 kH arrivals per barrier): no workgroup barrier in it, no wave waits for a sibling.
+// The counter only grows and is never reset: every wave reads it once when the kernel starts -- at most 4 kH - 1 early
+// arrivals of ITS OWN cluster can be in it then, so rounding down to a multiple of 4 kH gives the generation the launch
+// starts from -- and the n-th barrier of the launch waits for base + 4 n kH.  The arrival is an atomic without return
+// executed in the L2 (nobody waits for it).  The poll is a SCALAR load (glc: past the scalar cache, served by the L2):
+// vector loads return in order, so a vector poll would also wait for the weight streams issued just before it (the first
+// version did: 2 - 3 us per barrier).  Never hangs: after kMaxSpins polls the wave raises bit 0 of *status and goes on (the
+// host reads the word; results are then void).  Wrap-around is harmless (2^32 is a multiple of 4 kH, the comparison is on
+// the difference).  s_nop 4: an SGPR restored by v_readlane needs 5 wait states before an asm instruction may read it.
+constexpr unsigned kArrivals = 4 * kH;
+__device__ __forceinline__ unsigned barrier_base(const unsigned* ctr) {
+  unsigned v;
+  asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
+  return v / kArrivals * kArrivals;
 }
-__device__ __forceinline__ void barrier_wait(unsigned* ctr, unsigned target, unsigned* status) {
-  if (threadIdx.x == 0) {
-    int spins = 0;
-    while (true) {
-      unsigned cur;
-      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(cur) : "v"(ctr) : "memory");
-      if ((int)(cur - target) >= 0) break;
-      if (++spins > kMaxSpins) {
-        atomicOr(status, 1u);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
+__device__ __forceinline__ void barrier_arrive(unsigned* ctr, int lane) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have reached the L2
+  if (lane == 0) {
+    const unsigned one = 1u;
+    asm volatile("global_atomic_add %0, %1, off" ::"v"(ctr), "v"(one) : "memory");
   }
-  __syncthreads();
+}
+__device__ __forceinline__ void barrier_wait(const unsigned* ctr, unsigned target, unsigned* status, int lane) {
+  int spins = 0;
+  while (true) {
+    unsigned cur;
+    asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(cur) : "s"(ctr) : "memory");
+    if ((int)(cur - target) >= 0) break;
+    if (++spins > kMaxSpins) {
+      if (lane == 0) atomicOr(status, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
 }
 
 // ---- weight stream: NSTEP x 16 bytes per lane, issued long before use (inline asm: hipcc sinks ordinary loads next to
 // their first use), waited for with w_wait (tools/check_async_loads.py checks that nothing touches the registers earlier)
-template <int NSTEP>
+// AG: the registers are AGPRs (a load may target them and the MFMA reads its B operand from them directly), which leaves the
+// VGPR file to everything else: fc1's and fc2's streams (2 x 128 registers) are in flight together.
+template <bool AG>
+__device__ __forceinline__ void w_load(f32x4& d, unsigned lane_bytes, const float4* base, int which) {
+  // s_nop 4: the base may have just been restored with v_readlane (VALU write of an SGPR), and a VMEM instruction that
+  // reads such an SGPR needs 5 wait states; the compiler's hazard recogniser does not look into inline asm (without it
+  // the load took a stale base: "memory access fault on address (nil)")
+  if constexpr (AG) {
+    if (which == 0) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&a"(d) : "v"(lane_bytes), "s"(base));
+    if (which == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&a"(d) : "v"(lane_bytes), "s"(base));
+    if (which == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&a"(d) : "v"(lane_bytes), "s"(base));
+    if (which == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&a"(d) : "v"(lane_bytes), "s"(base));
+  } else {
+    if (which == 0) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(lane_bytes), "s"(base));
+    if (which == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(d) : "v"(lane_bytes), "s"(base));
+    if (which == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(d) : "v"(lane_bytes), "s"(base));
+    if (which == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(d) : "v"(lane_bytes), "s"(base));
+  }
+}
+template <int NSTEP, bool AG = false>
 __device__ __forceinline__ void w_issue(f32x4 (&b)[NSTEP], const float4* base /* wave-uniform: tile, first k group */,
                                         unsigned lane_bytes) {
 #ifdef EGTR_DEC_PLAIN_LOADS   // debugging aid: compiler-scheduled loads at the same program points
@@ -104,22 +131,20 @@ __device__ __forceinline__ void w_issue(f32x4 (&b)[NSTEP], const float4* base /*
 #endif
   // one scalar base per four loads: the instruction's immediate offset reaches 3 x 1024 bytes
 #pragma unroll
-  for (int s = 0; s < NSTEP; s += 4) {
-    const float4* b4 = base + s * 64;
-    // s_nop 4: the base may have just been restored with v_readlane (VALU write of an SGPR), and a VMEM instruction that
-    // reads such an SGPR needs 5 wait states; the compiler's hazard recogniser does not look into inline asm (without it
-    // the load took a stale base: "memory access fault on address (nil)")
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(b[s]) : "v"(lane_bytes), "s"(b4));
-    if (s + 1 < NSTEP) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(b[s + 1]) : "v"(lane_bytes), "s"(b4));
-    if (s + 2 < NSTEP) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(b[s + 2]) : "v"(lane_bytes), "s"(b4));
-    if (s + 3 < NSTEP) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(b[s + 3]) : "v"(lane_bytes), "s"(b4));
+  for (int s = 0; s < NSTEP; ++s) w_load<AG>(b[s], lane_bytes, base + (s & ~3) * 64, s & 3);
+}
+template <int NSTEP, bool AG = false>
+__device__ __forceinline__ void w_mark(f32x4 (&b)[NSTEP]) {   // after an s_waitcnt vmcnt(0): the registers may be read
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    if constexpr (AG) asm volatile("" : "+a"(b[s]));
+    else asm volatile("" : "+v"(b[s]));
   }
 }
-template <int NSTEP>
+template <int NSTEP, bool AG = false>
 __device__ __forceinline__ void w_wait(f32x4 (&b)[NSTEP]) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int s = 0; s < NSTEP; ++s) asm volatile("" : "+v"(b[s]));
+  w_mark<NSTEP, AG>(b);
 }
 
 #ifdef EGTR_DEC_TIMING
@@ -136,19 +161,36 @@ struct Args {
   EgtrDecoderLayer p;
 };
 
-// acc[row group] += X[8 rows][k range] . Wtile[64 columns][k range]^T over NSTEP groups of four k.
-//   b: the lane's NSTEP x 4 weights (packed tile [k / 4][64][4]); xs: LDS, row (lane & 3) of the panel at the first k.
-template <int NSTEP>
-__device__ __forceinline__ void tile_mma(const f32x4 (&b)[NSTEP], const float* xs, int ld, f32x4& lo, f32x4& hi) {
+// A fragments of an 8-row panel for the broadcast form: lane (b = lane >> 2, i = lane & 3) holds x[rg * 4 + i][64 q + 4 b + t]
+// (t = 0..3) of 64-k chunk q -- one ds_read_b128 per (row group, chunk).  `xs` points at row (lane & 3), column 4 (lane >> 2)
+// of the first chunk.
+template <int NQ>
+__device__ __forceinline__ void load_a(const float* xs, int ld, f32x4 (&a0)[NQ], f32x4 (&a1)[NQ]) {
 #pragma unroll
-  for (int u = 0; u < NSTEP; ++u) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + u * 4);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + 4 * ld + u * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      lo = mfma4(a0[j], b[u][j], lo);
-      hi = mfma4(a1[j], b[u][j], hi);
-    }
+  for (int q = 0; q < NQ; ++q) {
+    a0[q] = *reinterpret_cast<const f32x4*>(xs + 64 * q);
+    a1[q] = *reinterpret_cast<const f32x4*>(xs + 4 * ld + 64 * q);
+  }
+}
+
+// acc[row group] += X[8 rows][k range] . Wtile[64 columns][k range]^T over NSTEP groups of four k: group s multiplies with
+// block s % 16 of chunk s / 16 (cbsz = 4: the block's four rows are broadcast to all 16 blocks); w: the lane's NSTEP x 4
+// weights of the packed tile.  CB = 3: the two halves of the wave (blocks 0-7 / 8-15) each broadcast their own block s % 8.
+template <int S, int NSTEP, int NQ, int CB = 4>
+__device__ __forceinline__ void mma_steps(const f32x4 (&w)[NSTEP], const f32x4 (&a0)[NQ], const f32x4 (&a1)[NQ], f32x4& lo,
+                                          f32x4& hi) {
+  if constexpr (S < NSTEP) {
+    constexpr int per = CB == 4 ? 16 : 8;
+    constexpr int q = S / per, blk = S % per;
+    lo = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][0], w[S][0], lo, CB, blk, 0);
+    hi = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][0], w[S][0], hi, CB, blk, 0);
+    lo = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][1], w[S][1], lo, CB, blk, 0);
+    hi = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][1], w[S][1], hi, CB, blk, 0);
+    lo = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][2], w[S][2], lo, CB, blk, 0);
+    hi = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][2], w[S][2], hi, CB, blk, 0);
+    lo = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[q][3], w[S][3], lo, CB, blk, 0);
+    hi = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[q][3], w[S][3], hi, CB, blk, 0);
+    mma_steps<S + 1, NSTEP, NQ, CB>(w, a0, a1, lo, hi);
   }
 }
 
@@ -169,12 +211,32 @@ __device__ __forceinline__ float half_max(float v) {
   return v;
 }
 
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  return f32x4{t.x, t.y, t.z, t.w};
+}
+
+// bias / LayerNorm parameters of the columns 4j .. 4j+3 and 128 + 4j .. of one reduce step, fetched while the cluster
+// gathers at the barrier
+struct RowParams {
+  f32x4 b0, b1, g0, g1, e0, e1;
+};
+__device__ __forceinline__ RowParams load_params(const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, int j) {
+  RowParams p;
+  p.b0 = ld4(bias + 4 * j);
+  p.b1 = ld4(bias + 128 + 4 * j);
+  p.g0 = ld4(gamma + 4 * j);
+  p.g1 = ld4(gamma + 128 + 4 * j);
+  p.e0 = ld4(beta + 4 * j);
+  p.e1 = ld4(beta + 128 + 4 * j);
+  return p;
+}
+
 // Thread (r = tid >> 5, j = tid & 31) owns columns 4j .. 4j+3 and 128 + 4j .. of row r of the cluster's panel:
 // y = sum of the 8 partials (head order) + bias + residual, then LayerNorm over the row (32 lanes).
-__device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of this cluster */, int r, int j,
-                                          const float* __restrict__ bias, f32x4 res0, f32x4 res1,
-                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                          f32x4& o0, f32x4& o1) {
+__device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of this cluster */, int r, int j, const RowParams& q,
+                                          f32x4 res0, f32x4 res1, float eps, f32x4& o0, f32x4& o1) {
   f32x4 p0[kH], p1[kH];
 #pragma unroll
   for (int hh = 0; hh < kH; ++hh) {
@@ -191,9 +253,8 @@ __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of th
     y0 += p0[hh];
     y1 += p1[hh];
   }
-  const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * j), b1 = *reinterpret_cast<const float4*>(bias + 128 + 4 * j);
-  y0 += f32x4{b0.x, b0.y, b0.z, b0.w};
-  y1 += f32x4{b1.x, b1.y, b1.z, b1.w};
+  y0 += q.b0;
+  y1 += q.b1;
   y0 += res0;
   y1 += res1;
   const float mean = half_sum((y0[0] + y0[1]) + (y0[2] + y0[3]) + (y1[0] + y1[1]) + (y1[2] + y1[3])) * (1.f / 256.f);
@@ -202,10 +263,8 @@ __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of th
   const float var = half_sum((y0[0] * y0[0] + y0[1] * y0[1]) + (y0[2] * y0[2] + y0[3] * y0[3]) + (y1[0] * y1[0] + y1[1] * y1[1]) +
                              (y1[2] * y1[2] + y1[3] * y1[3])) * (1.f / 256.f);
   const float rstd = rsqrtf(var + eps);
-  const float4 g0 = *reinterpret_cast<const float4*>(gamma + 4 * j), g1 = *reinterpret_cast<const float4*>(gamma + 128 + 4 * j);
-  const float4 e0 = *reinterpret_cast<const float4*>(beta + 4 * j), e1 = *reinterpret_cast<const float4*>(beta + 128 + 4 * j);
-  o0 = y0 * rstd * f32x4{g0.x, g0.y, g0.z, g0.w} + f32x4{e0.x, e0.y, e0.z, e0.w};
-  o1 = y1 * rstd * f32x4{g1.x, g1.y, g1.z, g1.w} + f32x4{e1.x, e1.y, e1.z, e1.w};
+  o0 = y0 * rstd * q.g0 + q.e0;
+  o1 = y1 * rstd * q.g1 + q.e1;
 }
 
 // Store the 8 x 64 tile held by a wave (lane = column) as rows of the cluster's partial buffer.
@@ -214,6 +273,13 @@ __device__ __forceinline__ void store_partial(float* part_h /* [8][256] of this 
   for (int i = 0; i < 4; ++i) {
     part_h[i * 256 + col] = lo[i];
     part_h[(4 + i) * 256 + col] = hi[i];
+  }
+}
+__device__ __forceinline__ void stash_tile(float* s_red, int wave, int lane, const f32x4& lo, const f32x4& hi) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s_red[(wave * kR + i) * 64 + lane] = lo[i];
+    s_red[(wave * kR + 4 + i) * 64 + lane] = hi[i];
   }
 }
 
@@ -225,9 +291,10 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
   __shared__ __attribute__((aligned(16))) float s_red[4 * kR * 64]; // per-wave partial tiles
   __shared__ __attribute__((aligned(16))) float s_hid[kR * kLdh];   // hidden slice after ReLU
   __shared__ __attribute__((aligned(16))) float s_a[kR * kLda];     // 8 x 32 head panel (q rows, attention / MSDA output)
-  __shared__ __attribute__((aligned(16))) float s_ol[kR * 64];      // offsets (32) + logits (16) of the head
   __shared__ __attribute__((aligned(16))) int4 s_ro[kR * 16];       // per (row, sample): 4 corner byte offsets
   __shared__ __attribute__((aligned(16))) float4 s_rw[kR * 16];     // per (row, sample): 4 corner weights x attention
+  __shared__ unsigned s_bits[kMaxBitWords];                         // padding mask of the image, one bit per token
+  __shared__ __attribute__((aligned(16))) float s_bol[64], s_b1[128], s_bq[128], s_ref[kR * 8], s_vb[32], s_inv[kR];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const unsigned lane_bytes = lane * 16;
@@ -238,13 +305,17 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
   unsigned* ctr = P.barriers + pc * 32;
   const int N = P.num_query, ppi = (N + kR - 1) / kR;
   const int r = tid >> 5, j = tid & 31;     // panel mapping of the reduce / LayerNorm steps
+  const int ab = lane >> 2, ai = lane & 3;  // block / row of this lane in the broadcast A fragments
   LevelGeom G;
   load_geom(P.spatial_shapes, P.level_start_index, 4, G);
-  unsigned my_xcc = 0;
+  unsigned my_xcc = 0, bar_base = 0, nbar = 0;
+  bool have_base = false;
   if (tid == 0) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
     my_xcc &= 0xf;
   }
+  const int nwords = (P.spatial_size + 31) >> 5;
+  const bool bits_in_lds = P.keep_bits != nullptr && nwords <= kMaxBitWords;
 
   for (int c = pc; c < P.num_clusters; c += kPhys) {
     const int b = c / ppi, r0 = (c - b * ppi) * kR;
@@ -257,167 +328,179 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     float* part3 = P.partials + ((size_t)(2 * P.num_clusters + c) * kH) * kR * 256;
     if (tid == 0) P.xcc_ids[c * kH + h] = (int)my_xcc;
     STAMP(0);
-    f32x4 w_o[8];   // output projection: tile = wave, this head's 8 k groups
-    w_issue<8>(w_o, reinterpret_cast<const float4*>(P.w_attn_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
 
     // ================================================================= phase 1: self-attention of head h, 8 rows ======
-    // q rows of the head -> s_a
-    if (tid < 64) {
-      const int rr = min(tid >> 3, nvalid - 1), d4 = tid & 7;
-      const float4 t = *reinterpret_cast<const float4*>(P.q + ((row0 + rr) % P.qkv_rows) * 256 + h * 32 + d4 * 4);
-      *reinterpret_cast<float4*>(s_a + (tid >> 3) * kLda + d4 * 4) = t;
-    }
-    __syncthreads();
+    // everything the phase reads from memory is requested up front: the output projection's weights, q rows, keys, values
+    f32x4 w_o[8];   // output projection: tile = wave, this head's 8 k groups
+    w_issue<8, true>(w_o, reinterpret_cast<const float4*>(P.w_attn_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
     const int nkt = (N + 63) >> 6;
-    for (int kt = wave; kt < nkt; kt += 4) {   // scores S[row][key], lane = key
-      const int key = kt * 64 + lane;
-      const float4* kp = reinterpret_cast<const float4*>(P.k + (((size_t)b * N + min(key, N - 1)) % P.qkv_rows) * 256 + h * 32);
-      f32x4 kb[8];
+    const size_t kvrow0 = ((size_t)b * N) % P.qkv_rows;
+    f32x4 kb[8];     // keys of tile `wave`, lane = key
+    float vb[32];    // values of tile `wave`: lane = (key half, channel)
+    {
+      const int key = wave * 64 + lane;
+      const float4* kp = reinterpret_cast<const float4*>(P.k + (kvrow0 + min(key, N - 1)) * 256 + h * 32);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const float4 t = kp[s];
         kb[s] = f32x4{t.x, t.y, t.z, t.w};
       }
-      f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      const float* xs = s_a + (lane & 3) * kLda;
+      const float* vp = P.v + kvrow0 * 256 + h * 32 + (lane & 31);
+      const int key0 = wave * 64 + (lane >> 5) * 32;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(xs + s * 4);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(xs + 4 * kLda + s * 4);
+      for (int u = 0; u < 32; ++u) vb[u] = vp[(size_t)min(key0 + u, N - 1) * 256];
+    }
+    if (tid < 64) {   // q rows of the head -> s_a
+      const int rr = min(tid >> 3, nvalid - 1), d4 = tid & 7;
+      *reinterpret_cast<float4*>(s_a + (tid >> 3) * kLda + d4 * 4) =
+          *reinterpret_cast<const float4*>(P.q + ((row0 + rr) % P.qkv_rows) * 256 + h * 32 + d4 * 4);
+    } else if (tid < 128) {
+      s_bol[tid - 64] = P.b_off_logit[h * 64 + tid - 64];
+    } else {
+      s_b1[tid - 128] = P.b_fc1[h * 128 + tid - 128];
+    }
+    if (tid < 128) {
+      if (P.q_next != nullptr) s_bq[tid] = P.b_qkv_next[h * 128 + tid];
+    } else if (tid < 192) {   // reference points of the 8 rows x 4 levels
+      const int rr = min((tid - 128) >> 3, nvalid - 1);
+      s_ref[tid - 128] = P.reference_points[(row0 + rr) * 8 + ((tid - 128) & 7)];
+    } else if (tid < 224) {
+      s_vb[tid - 192] = P.value_bias != nullptr ? P.value_bias[h * 32 + tid - 192] : 0.f;
+    }
+    if (bits_in_lds)
+      for (int i = tid; i < nwords; i += 256) s_bits[i] = P.keep_bits[(size_t)b * nwords + i];
+    // residual rows and position rows of the reduce steps (phase 2 / 4), LayerNorm 1's parameters
+    const f32x4 xin0 = ld4(P.x_in + (grow % P.x_rows) * 256 + 4 * j), xin1 = ld4(P.x_in + (grow % P.x_rows) * 256 + 128 + 4 * j);
+    const float* pr = P.pos + (size_t)(grow % P.pos_rows) * 256;
+    const f32x4 pos0 = ld4(pr + 4 * j), pos1 = ld4(pr + 128 + 4 * j);
+    RowParams rp = load_params(P.b_attn_out, P.ln1_gamma, P.ln1_beta, j);
+    if (!have_base) {   // the barrier counter's value as the launch starts (scalar load: overlaps the vector loads above)
+      bar_base = barrier_base(ctr);
+      have_base = true;
+    }
+    __syncthreads();
+    {   // scores S[row][key], lane = key: A = the q rows (32 channels = blocks 0..7)
+      f32x4 qa0[1], qa1[1];
+      load_a<1>(s_a + ai * kLda + 4 * (ab & 7), kLda, qa0, qa1);
+      for (int kt = wave; kt < nkt; kt += 4) {
+        if (kt != wave) {   // N > 256: a second tile for this wave
+          const int key = kt * 64 + lane;
+          const float4* kp = reinterpret_cast<const float4*>(P.k + (kvrow0 + min(key, N - 1)) * 256 + h * 32);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          lo = mfma4(a0[jj], kb[s][jj], lo);
-          hi = mfma4(a1[jj], kb[s][jj], hi);
+          for (int s = 0; s < 8; ++s) {
+            const float4 t = kp[s];
+            kb[s] = f32x4{t.x, t.y, t.z, t.w};
+          }
         }
-      }
-      const bool ok = key < N;
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        mma_steps<0, 8, 1>(kb, qa0, qa1, lo, hi);
+        const int key = kt * 64 + lane;
+        const bool ok = key < N;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s_s[i * kLds + key] = ok ? lo[i] : -INFINITY;
-        s_s[(4 + i) * kLds + key] = ok ? hi[i] : -INFINITY;
+        for (int i = 0; i < 4; ++i) {
+          s_s[i * kLds + key] = ok ? lo[i] : -INFINITY;
+          s_s[(4 + i) * kLds + key] = ok ? hi[i] : -INFINITY;
+        }
       }
     }
     __syncthreads();
     STAMP(1);
-    {   // softmax of row r over the keys (32 lanes per row)
+    {   // softmax of row r over the keys (32 lanes per row), one pass: the row's scores stay in registers, e^(s - max) goes
+        // back unnormalised and 1 / sum is applied to the attention output below
       const int nk = nkt * 64;
+      float sv[kMaxKt * 2];
       float m = -INFINITY;
-      for (int kk = j; kk < nk; kk += 32) m = fmaxf(m, s_s[r * kLds + kk]);
+#pragma unroll
+      for (int i = 0; i < kMaxKt * 2; ++i) {
+        const int kk = j + 32 * i;
+        sv[i] = kk < nk ? s_s[r * kLds + kk] : -INFINITY;
+        m = fmaxf(m, sv[i]);
+      }
       m = half_max(m);
       float sum = 0.f;
-      for (int kk = j; kk < nk; kk += 32) {
-        const float e = __expf(s_s[r * kLds + kk] - m);
-        s_s[r * kLds + kk] = e;
+#pragma unroll
+      for (int i = 0; i < kMaxKt * 2; ++i) {
+        const int kk = j + 32 * i;
+        const float e = __expf(sv[i] - m);
+        if (kk < nk) s_s[r * kLds + kk] = e;
         sum += e;
       }
       sum = half_sum(sum);
-      const float inv = 1.f / sum;
-      for (int kk = j; kk < nk; kk += 32) s_s[r * kLds + kk] *= inv;
+      if (j == 0) s_inv[r] = 1.f / sum;
     }
     __syncthreads();
     STAMP(2);
-    {   // O = P V: lane = (key half kh, channel d); the wave's key tiles; the two halves are added at the end
-      const int d = lane & 31, kh = lane >> 5;
+    {   // O = P V: lane = (key half kh, channel d); each half of the wave broadcasts its own block (cbsz = 3): block s of
+        // half kh = keys key0 + 32 kh + 4 s .. + 3; the two halves are added at the end
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
       for (int kt = wave; kt < nkt; kt += 4) {
-        const int key0 = kt * 64 + kh * 32;
-        const float* vp = P.v + (((size_t)b * N) % P.qkv_rows) * 256 + h * 32 + d;
-        const float* ps = s_s + (lane & 3) * kLds + key0;
+        const int key0 = kt * 64 + (lane >> 5) * 32;
+        if (kt != wave) {
+          const float* vp = P.v + kvrow0 * 256 + h * 32 + (lane & 31);
 #pragma unroll
-        for (int s0 = 0; s0 < 32; s0 += 8) {
-          float vb[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) vb[u] = vp[(size_t)min(key0 + s0 + u, N - 1) * 256];
-#pragma unroll
-          for (int u4 = 0; u4 < 2; ++u4) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ps + s0 + u4 * 4);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ps + 4 * kLds + s0 + u4 * 4);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              lo = mfma4(a0[jj], vb[u4 * 4 + jj], lo);
-              hi = mfma4(a1[jj], vb[u4 * 4 + jj], hi);
-            }
-          }
+          for (int u = 0; u < 32; ++u) vb[u] = vp[(size_t)min(key0 + u, N - 1) * 256];
         }
+        f32x4 pa0[1], pa1[1];
+        load_a<1>(s_s + ai * kLds + key0 + 4 * (ab & 7), kLds, pa0, pa1);
+        f32x4 vw[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vw[s] = f32x4{vb[4 * s], vb[4 * s + 1], vb[4 * s + 2], vb[4 * s + 3]};
+        mma_steps<0, 8, 1, 3>(vw, pa0, pa1, lo, hi);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         lo[i] += __shfl_xor(lo[i], 32);
         hi[i] += __shfl_xor(hi[i], 32);
       }
-      if (lane < 32) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          s_red[(wave * kR + i) * 64 + d] = lo[i];
-          s_red[(wave * kR + 4 + i) * 64 + d] = hi[i];
-        }
-      }
+      if (lane < 32) stash_tile(s_red, wave, lane, lo, hi);
     }
     __syncthreads();
-    s_a[r * kLda + j] = (s_red[(0 * kR + r) * 64 + j] + s_red[(1 * kR + r) * 64 + j]) +
-                        (s_red[(2 * kR + r) * 64 + j] + s_red[(3 * kR + r) * 64 + j]);
+    s_a[r * kLda + j] = ((s_red[(0 * kR + r) * 64 + j] + s_red[(1 * kR + r) * 64 + j]) +
+                         (s_red[(2 * kR + r) * 64 + j] + s_red[(3 * kR + r) * 64 + j])) * s_inv[r];
     __syncthreads();
     STAMP(3);
     {   // output projection, this head's 32 input channels (split K): wave = output tile
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      w_wait<8>(w_o);
-      tile_mma<8>(w_o, s_a + (lane & 3) * kLda, kLda, lo, hi);
+      f32x4 a0[1], a1[1];
+      load_a<1>(s_a + ai * kLda + 4 * (ab & 7), kLda, a0, a1);
+      w_wait<8, true>(w_o);
+      mma_steps<0, 8, 1>(w_o, a0, a1, lo, hi);
       store_partial(part1 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
     STAMP(4);
-    unsigned target = barrier_arrive(ctr);
+    barrier_arrive(ctr, lane);
     f32x4 w_ol[16], w_c[8];   // phase 2's streams land while the cluster gathers: offsets / logits (K quarter), cross projection
-    w_issue<16>(w_ol, reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64, lane_bytes);
-    w_issue<8>(w_c, reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
-    barrier_wait(ctr, target, P.status);
+    w_issue<16, true>(w_ol, reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64, lane_bytes);
+    w_issue<8, true>(w_c, reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
+    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(5);
-    if (tid == 0) {   // the cluster must share one L2: every member reports the XCD it runs on
-      bool same = true;
-      for (int hh = 0; hh < kH; ++hh) {
-        int v;
-        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(P.xcc_ids + c * kH + hh) : "memory");
-        same = same && v == (int)my_xcc;
-      }
-      if (!same) atomicOr(P.status, 2u);
-    }
-
     // ================================================================= phase 2: LayerNorm 1, cross-attention of head h ==
     f32x4 x1a, x1b;
-    {
-      const float4 t0 = *reinterpret_cast<const float4*>(P.x_in + (grow % P.x_rows) * 256 + 4 * j);
-      const float4 t1 = *reinterpret_cast<const float4*>(P.x_in + (grow % P.x_rows) * 256 + 128 + 4 * j);
-      reduce_ln(part1, r, j, P.b_attn_out, f32x4{t0.x, t0.y, t0.z, t0.w}, f32x4{t1.x, t1.y, t1.z, t1.w}, P.ln1_gamma,
-                P.ln1_beta, P.ln_eps, x1a, x1b);
-      const float* pr = P.pos + (size_t)((row0 + rc) % P.pos_rows) * 256;
-      const float4 q0 = *reinterpret_cast<const float4*>(pr + 4 * j), q1 = *reinterpret_cast<const float4*>(pr + 128 + 4 * j);
-      *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x1a;
-      *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x1b;
-      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x1a + f32x4{q0.x, q0.y, q0.z, q0.w};
-      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 128 + 4 * j) = x1b + f32x4{q1.x, q1.y, q1.z, q1.w};
-    }
+    reduce_ln(part1, r, j, rp, xin0, xin1, P.ln_eps, x1a, x1b);
+    *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x1a;
+    *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x1b;
+    *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x1a + pos0;
+    *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 128 + 4 * j) = x1b + pos1;
+    rp = load_params(P.b_cross_out, P.ln2_gamma, P.ln2_beta, j);   // for the next reduce step
     __syncthreads();
     STAMP(6);
     {   // sampling offsets (32) + attention logits (16) of head h: one 64-column tile, the waves split K
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      w_wait<16>(w_ol);
-      tile_mma<16>(w_ol, s_xp + (lane & 3) * kLdx + 64 * wave, kLdx, lo, hi);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s_red[(wave * kR + i) * 64 + lane] = lo[i];
-        s_red[(wave * kR + 4 + i) * 64 + lane] = hi[i];
-      }
-    }
-    __syncthreads();
-    for (int e = tid; e < kR * 64; e += 256) {
-      const int rr = e >> 6, cc = e & 63;
-      s_ol[e] = (s_red[(0 * kR + rr) * 64 + cc] + s_red[(1 * kR + rr) * 64 + cc]) +
-                (s_red[(2 * kR + rr) * 64 + cc] + s_red[(3 * kR + rr) * 64 + cc]) + P.b_off_logit[h * 64 + cc];
+      f32x4 a0[1], a1[1];
+      load_a<1>(s_xp + ai * kLdx + 64 * wave + 4 * ab, kLdx, a0, a1);
+      w_wait<16, true>(w_ol);
+      mma_steps<0, 16, 1>(w_ol, a0, a1, lo, hi);
+      stash_tile(s_red, wave, lane, lo, hi);
     }
     __syncthreads();
     STAMP(7);
     if (tid < kR * 16) {   // (row, sample): softmax over the head's 16 logits, sampling location, bilinear geometry
       const int rr = tid >> 4, smp = tid & 15, lvl = smp >> 2;
-      const float ox = s_ol[rr * 64 + 2 * smp], oy = s_ol[rr * 64 + 2 * smp + 1], lg = s_ol[rr * 64 + 32 + smp];
+      auto col = [&](int cc) {
+        return (s_red[(0 * kR + rr) * 64 + cc] + s_red[(1 * kR + rr) * 64 + cc]) +
+               (s_red[(2 * kR + rr) * 64 + cc] + s_red[(3 * kR + rr) * 64 + cc]) + s_bol[cc];
+      };
+      const float ox = col(2 * smp), oy = col(2 * smp + 1), lg = col(32 + smp);
       float m = lg;
       m = fmaxf(m, __shfl_xor(m, 1));
       m = fmaxf(m, __shfl_xor(m, 2));
@@ -430,18 +513,24 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       sum += __shfl_xor(sum, 4);
       sum += __shfl_xor(sum, 8);
       const float a = ex / sum;
-      const size_t gr = row0 + min(rr, nvalid - 1);
-      const float2 rp = *reinterpret_cast<const float2*>(P.reference_points + (gr * 4 + lvl) * 2);
+      const float rx = s_ref[rr * 8 + lvl * 2], ry = s_ref[rr * 8 + lvl * 2 + 1];
       const int Wl = SEL_W(G, lvl), Hl = SEL_H(G, lvl);
-      const SampleGeom g = sample_geom<1024, 128>(rp.x + ox / (float)Wl, rp.y + oy / (float)Hl, Hl, Wl, SEL_S(G, lvl), h);
+      const SampleGeom g = sample_geom<1024, 128>(rx + ox / (float)Wl, ry + oy / (float)Hl, Hl, Wl, SEL_S(G, lvl), h);
       bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
       if (P.keep_bits != nullptr) {   // padded tokens contribute nothing (dd:1050-1052)
-        const unsigned* kb = P.keep_bits + (size_t)b * ((P.spatial_size + 31) >> 5);
         const int p0 = g.off[0] >> 10, p1 = g.off[1] >> 10, p2 = g.off[2] >> 10, p3 = g.off[3] >> 10;
-        k0 = k0 && ((kb[p0 >> 5] >> (p0 & 31)) & 1u);
-        k1 = k1 && ((kb[p1 >> 5] >> (p1 & 31)) & 1u);
-        k2 = k2 && ((kb[p2 >> 5] >> (p2 & 31)) & 1u);
-        k3 = k3 && ((kb[p3 >> 5] >> (p3 & 31)) & 1u);
+        if (bits_in_lds) {
+          k0 = k0 && ((s_bits[p0 >> 5] >> (p0 & 31)) & 1u);
+          k1 = k1 && ((s_bits[p1 >> 5] >> (p1 & 31)) & 1u);
+          k2 = k2 && ((s_bits[p2 >> 5] >> (p2 & 31)) & 1u);
+          k3 = k3 && ((s_bits[p3 >> 5] >> (p3 & 31)) & 1u);
+        } else {
+          const unsigned* kbp = P.keep_bits + (size_t)b * nwords;
+          k0 = k0 && ((kbp[p0 >> 5] >> (p0 & 31)) & 1u);
+          k1 = k1 && ((kbp[p1 >> 5] >> (p1 & 31)) & 1u);
+          k2 = k2 && ((kbp[p2 >> 5] >> (p2 & 31)) & 1u);
+          k3 = k3 && ((kbp[p3 >> 5] >> (p3 & 31)) & 1u);
+        }
       }
       s_ro[tid] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
       s_rw[tid] = make_float4(k0 ? g.w[0] * a : 0.f, k1 ? g.w[1] * a : 0.f, k2 ? g.w[2] * a : 0.f, k3 ? g.w[3] * a : 0.f);
@@ -450,17 +539,17 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     STAMP(8);
     {   // gather: thread = (row, sample quad, channel quad): 16 corner loads of 16 bytes in flight
       const int sq = (tid >> 3) & 3, c4 = tid & 7;
-      const char* vb = reinterpret_cast<const char*>(P.value) + (size_t)b * P.spatial_size * 1024 + c4 * 16;
+      const char* vbase = reinterpret_cast<const char*>(P.value) + (size_t)b * P.spatial_size * 1024 + c4 * 16;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       float wsum = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int4 o = s_ro[r * 16 + sq * 4 + i];
         const float4 w = s_rw[r * 16 + sq * 4 + i];
-        const float4 v0 = *reinterpret_cast<const float4*>(vb + (unsigned)o.x);
-        const float4 v1 = *reinterpret_cast<const float4*>(vb + (unsigned)o.y);
-        const float4 v2 = *reinterpret_cast<const float4*>(vb + (unsigned)o.z);
-        const float4 v3 = *reinterpret_cast<const float4*>(vb + (unsigned)o.w);
+        const float4 v0 = *reinterpret_cast<const float4*>(vbase + (unsigned)o.x);
+        const float4 v1 = *reinterpret_cast<const float4*>(vbase + (unsigned)o.y);
+        const float4 v2 = *reinterpret_cast<const float4*>(vbase + (unsigned)o.z);
+        const float4 v3 = *reinterpret_cast<const float4*>(vbase + (unsigned)o.w);
         wsum += (w.x + w.y) + (w.z + w.w);
         acc[0] += w.x * v0.x + w.y * v1.x + w.z * v2.x + w.w * v3.x;
         acc[1] += w.x * v0.y + w.y * v1.y + w.z * v2.y + w.w * v3.y;
@@ -474,58 +563,73 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       }
       wsum += __shfl_xor(wsum, 8);
       wsum += __shfl_xor(wsum, 16);
-      if (sq == 0) {
-        if (P.value_bias != nullptr) {   // sum_s w_s (v_s + b) = sum_s w_s v_s + b sum_s w_s
-          const float4 bv = *reinterpret_cast<const float4*>(P.value_bias + h * 32 + c4 * 4);
-          acc[0] += bv.x * wsum;
-          acc[1] += bv.y * wsum;
-          acc[2] += bv.z * wsum;
-          acc[3] += bv.w * wsum;
-        }
-        *reinterpret_cast<f32x4*>(s_a + r * kLda + c4 * 4) = acc;
+      if (sq == 0) {   // sum_s w_s (v_s + b) = sum_s w_s v_s + b sum_s w_s   (s_vb is zero without a value bias)
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(s_vb + c4 * 4);
+        *reinterpret_cast<f32x4*>(s_a + r * kLda + c4 * 4) = acc + bv * wsum;
       }
     }
     __syncthreads();
     STAMP(9);
     {   // cross-attention output projection, split K by head
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      w_wait<8>(w_c);
-      tile_mma<8>(w_c, s_a + (lane & 3) * kLda, kLda, lo, hi);
+      f32x4 a0[1], a1[1];
+      load_a<1>(s_a + ai * kLda + 4 * (ab & 7), kLda, a0, a1);
+      w_wait<8, true>(w_c);
+      mma_steps<0, 8, 1>(w_c, a0, a1, lo, hi);
       store_partial(part2 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
     STAMP(10);
-    target = barrier_arrive(ctr);
-    f32x4 w_f[32];   // fc1: tile 2h + (wave & 1), K half wave >> 1; later fc2 and the next layer's q / k / v
-    w_issue<32>(w_f, reinterpret_cast<const float4*>(P.w_fc1) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
-                lane_bytes);
-    barrier_wait(ctr, target, P.status);
+    barrier_arrive(ctr, lane);
+    // fc1's stream (tile 2h + (wave & 1), K half wave >> 1) into AGPRs -- reused for the next layer's q / k / v -- and fc2's
+    // (tile = wave, this head's 32 k groups) into VGPRs: both land while the cluster gathers and LayerNorm 2 runs
+    f32x4 w_f[32];
+#ifdef EGTR_DEC_FC2_EARLY
+    f32x4 w_g[32];
+#else
+    f32x4 (&w_g)[32] = w_f;
+#endif
+    w_issue<32, true>(w_f, reinterpret_cast<const float4*>(P.w_fc1) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
+                      lane_bytes);
+#ifdef EGTR_DEC_FC2_EARLY
+    w_issue<32>(w_g, reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64, lane_bytes);
+#endif
+    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(11);
 
     // ================================================================= phase 3: LayerNorm 2, 128 hidden units ==========
     f32x4 x2a, x2b;
-    reduce_ln(part2, r, j, P.b_cross_out, x1a, x1b, P.ln2_gamma, P.ln2_beta, P.ln_eps, x2a, x2b);
+    reduce_ln(part2, r, j, rp, x1a, x1b, P.ln_eps, x2a, x2b);
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x2a;
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x2b;
+    rp = load_params(P.b_fc2, P.ln3_gamma, P.ln3_beta, j);
     __syncthreads();
     STAMP(12);
     {   // fc1: columns 128 h .. 128 h + 127 = two tiles x two K halves
-      const int tile = wave & 1, khalf = wave >> 1;
+      const int khalf = wave >> 1;
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      w_wait<32>(w_f);
-      tile_mma<32>(w_f, s_x + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
+      f32x4 a0[2], a1[2];
+      load_a<2>(s_x + ai * kLdx + 128 * khalf + 4 * ab, kLdx, a0, a1);
+      w_wait<32, true>(w_f);
+#ifdef EGTR_DEC_FC2_EARLY
+      w_mark<32>(w_g);
+#endif
+      mma_steps<0, 32, 2>(w_f, a0, a1, lo, hi);
+#ifdef EGTR_DEC_FC2_EARLY
+      // the next layer's q / k / v stream takes fc1's registers: it flies through fc2 and the last barrier
+      if (P.q_next != nullptr)
+        w_issue<32, true>(w_f, reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
+                          lane_bytes);
+#else
       // fc2's stream (tile = wave, this head's 32 k groups) flies during the hidden-slice exchange below
-      w_issue<32>(w_f, reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64, lane_bytes);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        s_red[(wave * kR + i) * 64 + lane] = lo[i];
-        s_red[(wave * kR + 4 + i) * 64 + lane] = hi[i];
-      }
+      w_issue<32, true>(w_f, reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64, lane_bytes);
+#endif
+      stash_tile(s_red, wave, lane, lo, hi);
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int cc = 4 * j + i, tile = cc >> 6, ln = cc & 63;
-      const float v = s_red[(tile * kR + r) * 64 + ln] + s_red[((2 + tile) * kR + r) * 64 + ln] + P.b_fc1[h * 128 + cc];
+      const float v = s_red[(tile * kR + r) * 64 + ln] + s_red[((2 + tile) * kR + r) * 64 + ln] + s_b1[cc];
       s_hid[r * kLdh + cc] = egtr_relu(v);
     }
     STAMP(13);
@@ -533,57 +637,66 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     STAMP(14);
     {   // fc2, split K over the hidden slice: wave = output tile
       f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-      w_wait<32>(w_f);
-      tile_mma<32>(w_f, s_hid + (lane & 3) * kLdh, kLdh, lo, hi);
+      f32x4 a0[2], a1[2];
+      load_a<2>(s_hid + ai * kLdh + 4 * ab, kLdh, a0, a1);
+#ifndef EGTR_DEC_FC2_EARLY
+      w_wait<32, true>(w_f);
+#endif
+      mma_steps<0, 32, 2>(w_g, a0, a1, lo, hi);
       store_partial(part3 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
     STAMP(15);
-    target = barrier_arrive(ctr);
+    barrier_arrive(ctr, lane);
+#ifndef EGTR_DEC_FC2_EARLY
     if (P.q_next != nullptr)
-      w_issue<32>(w_f, reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
-                  lane_bytes);
-    barrier_wait(ctr, target, P.status);
+      w_issue<32, true>(w_f, reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
+                        lane_bytes);
+#endif
+    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(16);
 
     // ================================================================= phase 4: LayerNorm 3, next layer's q / k / v ====
     f32x4 x3a, x3b;
-    reduce_ln(part3, r, j, P.b_fc2, x2a, x2b, P.ln3_gamma, P.ln3_beta, P.ln_eps, x3a, x3b);
+    reduce_ln(part3, r, j, rp, x2a, x2b, P.ln_eps, x3a, x3b);
     STAMP(17);
     if (h == 0 && r < nvalid) {
       *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 4 * j) = x3a;
       *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 128 + 4 * j) = x3b;
     }
     if (P.q_next != nullptr) {
-      const float* pr = P.pos + (size_t)((row0 + rc) % P.pos_rows) * 256;
-      const float4 q0 = *reinterpret_cast<const float4*>(pr + 4 * j), q1 = *reinterpret_cast<const float4*>(pr + 128 + 4 * j);
       *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x3a;
       *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x3b;
-      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x3a + f32x4{q0.x, q0.y, q0.z, q0.w};
-      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 128 + 4 * j) = x3b + f32x4{q1.x, q1.y, q1.z, q1.w};
+      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x3a + pos0;
+      *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 128 + 4 * j) = x3b + pos1;
       __syncthreads();
       {   // tile 0 = [q_h | k_h] of (x + pos), tile 1 = [v_h | 0] of x; two K halves each
         const int tile = wave & 1, khalf = wave >> 1;
         f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-        w_wait<32>(w_f);
-        tile_mma<32>(w_f, (tile == 0 ? s_xp : s_x) + (lane & 3) * kLdx + 128 * khalf, kLdx, lo, hi);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          s_red[(wave * kR + i) * 64 + lane] = lo[i];
-          s_red[(wave * kR + 4 + i) * 64 + lane] = hi[i];
-        }
+        f32x4 a0[2], a1[2];
+        load_a<2>((tile == 0 ? s_xp : s_x) + ai * kLdx + 128 * khalf + 4 * ab, kLdx, a0, a1);
+        w_wait<32, true>(w_f);
+        mma_steps<0, 32, 2>(w_f, a0, a1, lo, hi);
+        stash_tile(s_red, wave, lane, lo, hi);
       }
       __syncthreads();
       if (r < nvalid) {
-        const float* bq = P.b_qkv_next + h * 128;
-        const float qv = (s_red[(0 * kR + r) * 64 + j] + s_red[(2 * kR + r) * 64 + j] + bq[j]) * P.q_scale;
-        const float kv = s_red[(0 * kR + r) * 64 + 32 + j] + s_red[(2 * kR + r) * 64 + 32 + j] + bq[32 + j];
-        const float vv = s_red[(1 * kR + r) * 64 + j] + s_red[(3 * kR + r) * 64 + j] + bq[64 + j];
+        const float qv = (s_red[(0 * kR + r) * 64 + j] + s_red[(2 * kR + r) * 64 + j] + s_bq[j]) * P.q_scale;
+        const float kv = s_red[(0 * kR + r) * 64 + 32 + j] + s_red[(2 * kR + r) * 64 + 32 + j] + s_bq[32 + j];
+        const float vv = s_red[(1 * kR + r) * 64 + j] + s_red[(3 * kR + r) * 64 + j] + s_bq[64 + j];
         P.q_next[grow * 256 + h * 32 + j] = qv;
         P.k_next[grow * 256 + h * 32 + j] = kv;
         P.v_next[grow * 256 + h * 32 + j] = vv;
       }
     }
     STAMP(18);
+    if (tid == 0 && h == 0) {   // the cluster must share one L2: every member reported the XCD it runs on (one 32-byte load)
+      typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+      u32x8 id;
+      asm volatile("s_nop 4\n\ts_load_dwordx8 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(id) : "s"(P.xcc_ids + c * kH) : "memory");
+      bool same = true;
+      for (int hh = 0; hh < kH; ++hh) same = same && id[hh] == my_xcc;
+      if (!same) atomicOr(P.status, 2u);
+    }
     __syncthreads();   // LDS is reused by the next panel of this physical cluster
   }
 }

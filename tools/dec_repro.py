@@ -19,3 +19,26 @@ torch.cuda.synchronize()
 from egtr_amd import decoder_fused
 print("status", decoder_fused.read_status(torch.device("cuda:0")), "max diff",
       max(float((a - b).abs().max()) for a, b in zip(out.decoder_hidden_states, ref.decoder_hidden_states)))
+
+if len(sys.argv) > 3 and sys.argv[3] == "time":
+    # average duration of one layer launch: HIP events around every egtr_decoder_layer_f32 call of 30 eager forwards
+    from egtr_amd import _lib
+    lib = _lib.lib()
+    raw = lib.egtr_decoder_layer_f32
+    evs = []
+
+    def wrapped(stream, args):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st = raw(stream, args)
+        e1.record()
+        evs.append((e0, e1))
+        return st
+
+    lib.egtr_decoder_layer_f32 = wrapped
+    for _ in range(30):
+        T._run(model, pv, pm, fused=True, base=True)
+    torch.cuda.synchronize()
+    lib.egtr_decoder_layer_f32 = raw
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs[len(evs) // 3:])
+    print(f"layer launch: median {ts[len(ts) // 2]:.1f} us, min {ts[0]:.1f} us over {len(ts)} launches (event-bracketed, eager)")
