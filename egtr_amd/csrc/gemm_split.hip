@@ -69,7 +69,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int total) {
   return x * q + min(x, r) + (bid >> 3);
 }
 
-constexpr int kMaxProblems = 8;
+constexpr int kMaxProblems = 16;   // (the relation head's 14 slot products share one grid)
 struct GemmProblem {
   const float* A;
   const unsigned short* Wt;

@@ -17,6 +17,10 @@ from .load_custom import _stream
 # "0": the per-operation decoder (eight launches per layer) -- the A/B switch of tools/forward_breakdown.py
 ENABLED = os.environ.get("EGTR_DECODER_CLUSTER", "1") != "0"
 MAX_QUERIES = 320
+# "0" (default): the workgroups of a cluster meet at L2 barriers.  "1": they hand their partial results over as tagged data
+# (every word carries a 2-bit launch tag, the readers re-load until they see it) -- measured SLOWER (34 vs 29 us per layer:
+# the re-loads of the 64 KiB of partials compete with the stores they wait for); kept as the tested alternative.
+DATAFLOW = os.environ.get("EGTR_DECODER_DATAFLOW", "0") != "0"
 
 
 class DecoderClusterError(RuntimeError):
@@ -35,7 +39,7 @@ class EgtrDecoderLayer(ctypes.Structure):
         "b_fc2", "ln3_gamma", "ln3_beta", "w_qkv_next", "b_qkv_next", "partials", "barriers", "status", "xcc_ids")] + [
         ("q_scale", ctypes.c_float), ("ln_eps", ctypes.c_float), ("batch", ctypes.c_int), ("num_query", ctypes.c_int),
         ("spatial_size", ctypes.c_int), ("x_rows", ctypes.c_int), ("pos_rows", ctypes.c_int), ("qkv_rows", ctypes.c_int),
-        ("num_clusters", ctypes.c_int)]
+        ("num_clusters", ctypes.c_int), ("generation", ctypes.c_int)]
 
 
 def pack(w):
@@ -101,30 +105,50 @@ def supported(decoder, hidden_states, position_embeddings, reference_points, enc
     return True
 
 
-_WORKSPACES = {}   # (device index, stream handle) -> persistent (barriers, status) of eager launches
-_POOL = {}         # device index -> zeroed (barriers, status) sets, one per captured graph
+_WORKSPACES = {}   # (device index, stream handle, shape key) -> persistent buffers of eager launches
+_POOL = {}         # (device index, shape key) -> zeroed buffer sets, one per captured graph
 _CHECKED = set()   # device indices whose first eager run was verified
 
 
-def _new_workspace(dev):
-    return (torch.zeros(32 * 32, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+def _new_workspace(dev, shape_key):
+    """(barriers, status, partials): zeroed ONCE.  The barrier counters only grow; the partials' zero words carry tag 0, which
+    no launch uses (dataflow mode)."""
+    B, N, _ = shape_key
+    lib = _lib.lib()
+    pf, bw, iw = ctypes.c_longlong(0), ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.egtr_decoder_layer_workspace(B, N, ctypes.byref(pf), ctypes.byref(bw), ctypes.byref(iw)),
+               "egtr_decoder_layer_workspace")
+    return (torch.zeros(bw.value, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+            torch.zeros(pf.value, dtype=torch.float32, device=dev), torch.empty(iw.value, dtype=torch.int32, device=dev))
 
 
-def _workspace(dev):
-    """The barrier counters only grow and are zeroed exactly once; launches that share a set must be stream-ordered.  Eager
-    launches: one set per (device, stream).  Under stream capture: a set of its own for the graph being captured, taken
-    from a pool that the first eager run filled (an allocation inside the capture would put a memset node into the
-    graph; it still works -- the counters may restart from zero -- and is what happens when the pool is empty)."""
+def _workspace(dev, shape_key):
+    """Launches that share a buffer set must be stream-ordered and of one shape (batch, queries, layers): then consecutive
+    launches on it carry different tags (``_tags``) and the barrier counters stay whole.  Eager launches: one set per
+    (device, stream, shape).  Under stream capture: a set of its own for the graph being captured, taken from a pool that
+    the first eager run of that shape filled (an allocation inside the capture would put memset nodes into the graph; it
+    still works and is what happens when the pool is empty)."""
     if torch.cuda.is_current_stream_capturing():
-        pool = _POOL.get(dev.index)
-        return pool.pop() if pool else _new_workspace(dev)
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        pool = _POOL.get((dev.index, shape_key))
+        return pool.pop() if pool else _new_workspace(dev, shape_key)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, shape_key)
     ws = _WORKSPACES.get(key)
     if ws is None:
-        ws = _WORKSPACES[key] = _new_workspace(dev)
-        if dev.index not in _POOL:
-            _POOL[dev.index] = [_new_workspace(dev) for _ in range(8)]
+        ws = _WORKSPACES[key] = _new_workspace(dev, shape_key)
+        if (dev.index, shape_key) not in _POOL:
+            _POOL[(dev.index, shape_key)] = [_new_workspace(dev, shape_key) for _ in range(4)]
     return ws
+
+
+def _tags(nl):
+    """Tags 1..3 of the nl launches of one forward such that neighbours differ, also across the seam between two forwards
+    (the last launch of one and the first of the next use the same buffers); None when that is impossible (nl == 1)."""
+    if nl < 2:
+        return None
+    t = [1 + (l % 3) for l in range(nl)]
+    if t[-1] == t[0]:
+        t[-1] = next(v for v in (1, 2, 3) if v != t[0] and v != t[-2])
+    return t
 
 
 def _rows(t, n_rows_per_image):
@@ -195,12 +219,9 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
 
     states = torch.empty(nl, B * N, 256, dtype=torch.float32, device=dev)
     qkv = torch.empty(max(nl - 1, 1), 3, B * N, 256, dtype=torch.float32, device=dev)
-    pf, bw, iw = ctypes.c_longlong(0), ctypes.c_int(0), ctypes.c_int(0)
-    _lib.check(lib.egtr_decoder_layer_workspace(B, N, ctypes.byref(pf), ctypes.byref(bw), ctypes.byref(iw)),
-               "egtr_decoder_layer_workspace")
-    partials = torch.empty(pf.value, dtype=torch.float32, device=dev)
-    ids = torch.empty(iw.value, dtype=torch.int32, device=dev)
-    barriers, status = _workspace(dev)
+    tags = _tags(nl) if DATAFLOW else None
+    # (the mode is part of the key: words written in barrier mode carry no tag and must never meet a dataflow reader)
+    barriers, status, partials, ids = _workspace(dev, (B, N, nl if tags is not None else -nl))
     ref = reference_input.contiguous()
     kbits = _keep_bits(keep_mask, B, S) if keep_mask is not None else None
     vals = values if values.is_contiguous() else values.contiguous()
@@ -242,12 +263,14 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
                                                        ids.data_ptr())
         a.q_scale, a.ln_eps = scale, float(layer.self_attn_layer_norm.eps)
         a.batch, a.num_query, a.spatial_size, a.num_clusters = B, N, S, nclusters
+        a.generation = tags[i] if tags is not None else 0
         _lib.check(lib.egtr_decoder_layer_f32(stream, ctypes.byref(a)), "egtr_decoder_layer_f32")
     if dev.index not in _CHECKED and not torch.cuda.is_current_stream_capturing():
         st = int(status.item())   # one synchronisation, on the first eager run per device
         if st != 0:
             status.zero_()
             barriers.zero_()
+            partials.zero_()
             raise DecoderClusterError(
                 "egtr_decoder_layer_f32: " + ("a cluster barrier timed out; " if st & 1 else "")
                 + ("the workgroups of a cluster were spread over several XCDs; " if st & 2 else "")
@@ -265,5 +288,9 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
 
 
 def read_status(dev):
-    """The sticky status word of the current (device, stream) workspace: 0 = every launch so far was sound."""
-    return int(_workspace(dev)[1].item())
+    """The sticky status words of this device's eager workspaces OR-ed together: 0 = every launch so far was sound."""
+    st = 0
+    for (d, _, _), ws in _WORKSPACES.items():
+        if d == dev.index:
+            st |= int(ws[1].item())
+    return st

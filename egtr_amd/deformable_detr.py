@@ -1141,13 +1141,11 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
 
 
 class DeformableDetrModel(DeformableDetrPreTrainedModel):
-    """Backbone + encoder-decoder without heads (dd:1978-2390). Single-stage only (EGTR's configuration);
-    ``two_stage=True`` raises."""
+    """Backbone + encoder-decoder without heads (dd:1978-2390), single-stage (EGTR's configuration) and two-stage
+    (``two_stage=True``: per-pixel proposals from the encoder output, dd:2040-2052, 2075-2159, 2306-2337)."""
 
     def __init__(self, config: DeformableDetrConfig):
         super().__init__(config)
-        if config.two_stage:
-            raise NotImplementedError("two-stage Deformable DETR is outside the EGTR hot path")
         backbone = DeformableDetrTimmConvEncoder(config)
         self.backbone = DeformableDetrConvModel(backbone, build_position_encoding(config))
         if config.num_feature_levels > 1:
@@ -1167,11 +1165,18 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             self.input_proj = nn.ModuleList([nn.Sequential(
                 nn.Conv2d(backbone.intermediate_channel_sizes[-1], config.d_model, kernel_size=1),
                 nn.GroupNorm(32, config.d_model))])
-        self.query_position_embeddings = nn.Embedding(config.num_queries, config.d_model * 2)
+        if not config.two_stage:
+            self.query_position_embeddings = nn.Embedding(config.num_queries, config.d_model * 2)
         self.encoder = DeformableDetrEncoder(config)
         self.decoder = DeformableDetrDecoder(config)
         self.level_embed = nn.Parameter(torch.Tensor(config.num_feature_levels, config.d_model))
-        self.reference_points = nn.Linear(config.d_model, 2)
+        if config.two_stage:   # dd:2040-2044 (same creation order as the reference: the init RNG stream is shared)
+            self.enc_output = nn.Linear(config.d_model, config.d_model)
+            self.enc_output_norm = nn.LayerNorm(config.d_model)
+            self.pos_trans = nn.Linear(config.d_model * 2, config.d_model * 2)
+            self.pos_trans_norm = nn.LayerNorm(config.d_model * 2)
+        else:
+            self.reference_points = nn.Linear(config.d_model, 2)
         self._geom_cache = {}
         self.post_init()
 
@@ -1196,6 +1201,45 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
         valid_width = torch.sum(mask[:, 0, :], 1)
         return torch.stack([valid_width.float() / width, valid_height.float() / height], -1)
 
+    def get_proposal_pos_embed(self, proposals):
+        """Sine embedding of the proposal logits [B, K, 4] -> [B, K, 512] (dd:2075-2096): sigmoid, times 2 pi, 128
+        frequencies per coordinate, (sin, cos) interleaved."""
+        num_pos_feats, temperature = 128, 10000
+        dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=proposals.device)
+        dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / num_pos_feats)
+        pos = (proposals.sigmoid() * (2 * math.pi))[:, :, :, None] / dim_t
+        return torch.stack((pos[:, :, :, 0::2].sin(), pos[:, :, :, 1::2].cos()), dim=4).flatten(2)
+
+    def gen_encoder_output_proposals(self, enc_output, padding_mask, spatial_shapes, spatial_shapes_list=None):
+        """One proposal per encoder token (dd:2098-2159): the token's pixel centre in units of the image's VALID width /
+        height and a level-dependent size 0.05 * 2^level, as logits (inverse sigmoid); padded tokens and proposals outside
+        (0.01, 0.99) get +inf logits and a zeroed feature row.  Returns (LayerNorm(Linear(features)) [B, S, d], proposal
+        logits [B, S, 4]).  ``padding_mask`` is True at PADDED tokens."""
+        batch_size = enc_output.shape[0]
+        shapes = spatial_shapes_list if spatial_shapes_list is not None else [(int(h), int(w)) for h, w in spatial_shapes]
+        proposals, cur = [], 0
+        for level, (height, width) in enumerate(shapes):
+            mask_l = padding_mask[:, cur:cur + height * width].view(batch_size, height, width)
+            valid_height = torch.sum(~mask_l[:, :, 0], 1)
+            valid_width = torch.sum(~mask_l[:, 0, :], 1)
+            grid_y, grid_x = torch.meshgrid(
+                torch.linspace(0, height - 1, height, dtype=torch.float32, device=enc_output.device),
+                torch.linspace(0, width - 1, width, dtype=torch.float32, device=enc_output.device), indexing="ij")
+            grid = torch.stack([grid_x, grid_y], -1)
+            scale = torch.stack([valid_width, valid_height], 1).view(batch_size, 1, 1, 2)
+            grid = (grid.unsqueeze(0).expand(batch_size, -1, -1, -1) + 0.5) / scale
+            width_height = torch.ones_like(grid) * 0.05 * (2.0 ** level)
+            proposals.append(torch.cat((grid, width_height), -1).view(batch_size, -1, 4))
+            cur += height * width
+        output_proposals = torch.cat(proposals, 1)
+        valid = ((output_proposals > 0.01) & (output_proposals < 0.99)).all(-1, keepdim=True)
+        output_proposals = torch.log(output_proposals / (1 - output_proposals))
+        drop = padding_mask.unsqueeze(-1) | ~valid
+        output_proposals = output_proposals.masked_fill(drop, float("inf"))
+        object_query = enc_output.masked_fill(drop, 0.0)
+        object_query = self.enc_output_norm(ops.module_linear(self.enc_output, object_query))
+        return object_query, output_proposals
+
     def forward(self, pixel_values, pixel_mask=None, decoder_attention_mask=None, encoder_outputs=None,
                 inputs_embeds=None, decoder_inputs_embeds=None, output_attentions=None, output_hidden_states=None,
                 output_attention_states=None, return_dict=None):
@@ -1214,7 +1258,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                           and isinstance(pos_mod, DeformableDetrSinePositionEmbedding)
                           and pos_mod.normalize and self.config.num_feature_levels <= 4
                           and not (torch.is_grad_enabled() and self.level_embed.requires_grad))
-        query_embeds = self.query_position_embeddings.weight
+        query_embeds = None if self.config.two_stage else self.query_position_embeddings.weight   # dd:2245-2247
         encoder_reference_points = None
         if fused_geometry:
             # inference: masks, position embeddings (+ level_embed), valid ratios and the encoder reference points of
@@ -1330,7 +1374,23 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                 attentions=encoder_outputs[2] if len(encoder_outputs) > 2 else None)
 
         batch_size, _, num_channels = encoder_outputs[0].shape
-        if ops.inference_fast_path(query_embeds):
+        enc_outputs_class = enc_outputs_coord_logits = None
+        first_with_pos = None
+        if self.config.two_stage:
+            # dd:2306-2337: a detection head on every encoder token, the top-k boxes become the decoder's reference boxes
+            # (detached) and -- through pos_trans of their sine embedding -- its queries and query positions
+            object_query_embedding, output_proposals = self.gen_encoder_output_proposals(
+                encoder_outputs[0], ~mask_flatten.bool(), spatial_shapes, spatial_shapes_list)
+            enc_outputs_class = self.decoder.class_embed[-1](object_query_embedding)
+            enc_outputs_coord_logits = self.decoder.bbox_embed[-1](object_query_embedding) + output_proposals
+            topk = self.config.two_stage_num_proposals
+            topk_proposals = torch.topk(enc_outputs_class[..., 0], topk, dim=1)[1]
+            topk_coords_logits = torch.gather(enc_outputs_coord_logits, 1,
+                                              topk_proposals.unsqueeze(-1).repeat(1, 1, 4)).detach()
+            reference_points = topk_coords_logits.sigmoid()
+            pos_trans_out = self.pos_trans_norm(self.pos_trans(self.get_proposal_pos_embed(topk_coords_logits)))
+            query_embed, target = torch.split(pos_trans_out, num_channels, dim=2)
+        elif ops.inference_fast_path(query_embeds):
             # The dense column slices of the [N, 2d] query table and reference_points = sigmoid(Linear(query_pos))
             # (dd:2339-2343) depend on parameters only: derived constants, rebuilt when a source tensor changes
             # (4 launches per forward otherwise).
@@ -1359,7 +1419,8 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             return_dict=return_dict, spatial_shapes_list=spatial_shapes_list, first_with_pos=first_with_pos)
 
         if not return_dict:
-            return (init_reference_points,) + decoder_outputs + encoder_outputs
+            enc_outputs = tuple(v for v in (enc_outputs_class, enc_outputs_coord_logits) if v is not None)
+            return (init_reference_points,) + decoder_outputs + encoder_outputs + enc_outputs
         return DeformableDetrModelOutput(
             init_reference_points=init_reference_points, last_hidden_state=decoder_outputs.last_hidden_state,
             intermediate_hidden_states=decoder_outputs.intermediate_hidden_states,
@@ -1369,7 +1430,8 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             decoder_attention_queries=decoder_outputs.attention_queries,
             decoder_attention_keys=decoder_outputs.attention_keys,
             encoder_last_hidden_state=encoder_outputs.last_hidden_state,
-            encoder_hidden_states=encoder_outputs.hidden_states, encoder_attentions=encoder_outputs.attentions)
+            encoder_hidden_states=encoder_outputs.hidden_states, encoder_attentions=encoder_outputs.attentions,
+            enc_outputs_class=enc_outputs_class, enc_outputs_coord_logits=enc_outputs_coord_logits)
 
 
 class DeformableDetrMLPPredictionHead(nn.Module):
@@ -1491,7 +1553,10 @@ class DeformableDetrHungarianMatcher(nn.Module):
     def prepare(self, outputs, targets):
         """First half of ``forward``.  GPU: the whole matcher is ENQUEUED here (one launch, asynchronous) and ``finish``
         only slices its outputs -- no host synchronisation at all.  CPU: the cost matrix."""
-        if outputs["logits"].is_cuda and outputs["logits"].dtype == torch.float32:
+        if outputs["logits"].is_cuda and outputs["logits"].dtype == torch.float32 and \
+                max(outputs["logits"].shape[1], max((len(t["class_labels"]) for t in targets), default=0)) <= 1024:
+            # (larger sets -- the two-stage variant's per-token proposals -- take the reference's route below: cost matrix
+            # on the device, scipy on the host; the device solver keeps its matrix in LDS, csrc/matcher.hip)
             cm = iss = None
             if self.smoothing:
                 cm, iss = self._smoothing_scalars()
@@ -1729,9 +1794,8 @@ class DeformableDetrForObjectDetection(DeformableDetrPreTrainedModel):
         self.class_embed.bias.data = torch.ones(config.num_labels) * bias_value
         nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
         nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
-        if config.two_stage:
-            raise NotImplementedError("the two-stage Deformable-DETR variant is outside the EGTR path (DESIGN.md 6)")
-        num_pred = config.decoder_layers
+        # two-stage: the last class / box head scores the encoder tokens (region proposals, dd:2421-2425)
+        num_pred = (config.decoder_layers + 1) if config.two_stage else config.decoder_layers
         if config.with_box_refine:
             self.class_embed = _get_clones(self.class_embed, num_pred)
             self.bbox_embed = _get_clones(self.bbox_embed, num_pred)
@@ -1742,6 +1806,10 @@ class DeformableDetrForObjectDetection(DeformableDetrPreTrainedModel):
             self.class_embed = nn.ModuleList([self.class_embed for _ in range(num_pred)])
             self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(num_pred)])
             self.model.decoder.bbox_embed = None
+        if config.two_stage:   # dd:2439-2443
+            self.model.decoder.class_embed = self.class_embed
+            for box_embed in self.bbox_embed:
+                nn.init.constant_(box_embed.layers[-1].bias.data[2:], 0.0)
         self.post_init()
 
     @torch.jit.unused
@@ -1775,14 +1843,18 @@ class DeformableDetrForObjectDetection(DeformableDetrPreTrainedModel):
                 auxiliary_outputs = self._set_aux_loss(outputs_class.permute(1, 0, 2, 3),
                                                        outputs_coord.permute(1, 0, 2, 3))
                 outputs_loss["auxiliary_outputs"] = auxiliary_outputs
+            if self.config.two_stage:   # dd:2588-2593
+                outputs_loss["enc_outputs"] = {"logits": outputs.enc_outputs_class,
+                                               "pred_boxes": outputs.enc_outputs_coord_logits.sigmoid()}
             loss_dict = criterion(outputs_loss, labels)
             weight_dict = {"loss_ce": self.config.ce_loss_coefficient, "loss_bbox": self.config.bbox_loss_coefficient,
                            "loss_giou": self.config.giou_loss_coefficient}
+            base_weights = dict(weight_dict)
             if self.config.auxiliary_loss:
-                aux = {}
                 for i in range(self.config.decoder_layers - 1):
-                    aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
-                weight_dict.update(aux)
+                    weight_dict.update({k + f"_{i}": v for k, v in base_weights.items()})
+            if self.config.two_stage:   # dd:2608-2612
+                weight_dict.update({k + "_enc": v for k, v in base_weights.items()})
             loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
 
         if not return_dict:

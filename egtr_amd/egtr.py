@@ -8,6 +8,7 @@ never exists.  Citations "egtr:NNN" are to /root/reference/model/egtr.py.
 """
 import copy
 import math
+import os
 import random
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -48,6 +49,11 @@ def _get_clones(module, N):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
 
 
+# "0": slot projections, first MLP layer and gate logits of the relation head as three launches (the A/B switch of the merged
+# preparation below)
+REL_PREP_MERGED = os.environ.get("EGTR_REL_PREP_MERGED", "1") != "0"
+
+
 class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
     def __init__(self, config, **kwargs):
         super().__init__(config)
@@ -60,7 +66,8 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         self.class_embed.bias.data = torch.ones(config.num_labels) * bias_value
         nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
         nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
-        num_pred = config.decoder_layers
+        # two-stage: the last class / box head scores the encoder tokens (region proposals, egtr:142-145)
+        num_pred = (config.decoder_layers + 1) if config.two_stage else config.decoder_layers
         if config.with_box_refine:
             self.class_embed = _get_clones(self.class_embed, num_pred)
             self.bbox_embed = _get_clones(self.bbox_embed, num_pred)
@@ -71,6 +78,10 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             self.class_embed = nn.ModuleList([self.class_embed for _ in range(num_pred)])
             self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(num_pred)])
             self.model.decoder.bbox_embed = None
+        if config.two_stage:   # egtr:159-163
+            self.model.decoder.class_embed = self.class_embed
+            for box_embed in self.bbox_embed:
+                nn.init.constant_(box_embed.layers[-1].bias.data[2:], 0.0)
 
         self.num_queries = self.config.num_queries
         self.head_dim = config.d_model // config.num_attention_heads
@@ -114,7 +125,51 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         unscaling = self.head_dim ** 0.5
         rp, cl = self.rel_predictor.layers, self.connectivity_layer.layers
         wg = self.rel_predictor_gate.weight  # [1, 2d]
-        if ops.inference_fast_path(sequence_output):
+        if (ops.inference_fast_path(sequence_output) and ops.GEMM_SPLIT_BF16 and REL_PREP_MERGED and d % 32 == 0
+                and (rp[0].weight.shape[0] + cl[0].weight.shape[0]) % 128 == 0 and 2 * (len(queries) + 1) <= 16):
+            # Inference: slot projection and first MLP layer are two linear maps in a row -- W1 (P_t x + b_t) =
+            # (W1 P_t) x + W1 b_t -- so their product is formed once per weight set (float64, rounded to fp32) and the
+            # 2 x (Ld + 1) slot inputs go through ONE grouped split-bf16 launch straight into uq / uk; the gate logits
+            # (one output column per slot) follow as one skinny launch.  Three launches -> two, and the [B N T, d]
+            # intermediate never exists.  (sqrt(D) un-scaling of egtr:343 folded into the query slots' weights.)
+            T = len(queries) + 1
+            hd2 = rp[0].weight.shape[0] + cl[0].weight.shape[0]
+            projs_q = list(self.proj_q) + [self.final_sub_proj]
+            projs_k = list(self.proj_k) + [self.final_obj_proj]
+            srcs = [rp[0].weight, cl[0].weight, wg, rp[0].bias, cl[0].bias, self.rel_predictor_gate.bias] + \
+                [t for pj in projs_q + projs_k for t in (pj.weight, pj.bias)]
+
+            def build():
+                f64 = torch.float64
+                w1 = torch.cat([rp[0].weight, cl[0].weight], 0).to(f64)          # [2 Hd, 2 d]
+                w1q, w1k, gq, gk = w1[:, :d], w1[:, d:], wg[:, :d].to(f64), wg[:, d:].to(f64)
+                wts, bs, gws, gbs = [], [], [], []
+                for side, (w1s, gs, pjs) in enumerate(((w1q, gq, projs_q), (w1k, gk, projs_k))):
+                    for t, pj in enumerate(pjs):
+                        sc = unscaling if (side == 0 and t < T - 1) else 1.0
+                        pw, pb = pj.weight.to(f64), pj.bias.to(f64)
+                        wts.append(ops.gemm_split_weights(((w1s @ pw) * sc).float().contiguous()))
+                        bs.append((w1s @ pb).float().contiguous())
+                        gws.append(((gs @ pw) * sc).float().contiguous())        # [1, d]
+                        gb = gs @ pb
+                        if side == 1:
+                            gb = gb + self.rel_predictor_gate.bias.to(f64)
+                        gbs.append(gb.float().contiguous())
+                return wts, bs, gws, gbs, torch.cat([rp[0].bias, cl[0].bias], 0).contiguous()
+
+            wts, bs, gws, gbs, b1 = ops.cached_weights(self, "rel_head_merged_prep", srcs, build)
+            uq = torch.empty(bsz * N, T, hd2, dtype=sequence_output.dtype, device=sequence_output.device)
+            uk = torch.empty_like(uq)
+            gates = [torch.empty(bsz * N, T, dtype=sequence_output.dtype, device=sequence_output.device) for _ in range(2)]
+            xs = [q.transpose(1, 2).reshape(bsz * N, d) for q in queries] + [sequence_output.reshape(bsz * N, d)] + \
+                [k.transpose(1, 2).reshape(bsz * N, d) for k in keys] + [sequence_output.reshape(bsz * N, d)]
+            outs = [uq[:, t, :] for t in range(T)] + [uk[:, t, :] for t in range(T)]
+            ops.linear_split_bf16_grouped([dict(x=x, wt=w, N=hd2, b=b, out=o) for x, w, b, o in zip(xs, wts, bs, outs)])
+            gouts = [gates[0][:, t:t + 1] for t in range(T)] + [gates[1][:, t:t + 1] for t in range(T)]
+            ops.linear_grouped([dict(x=x, w=w, b=b, out=o) for x, w, b, o in zip(xs, gws, gbs, gouts)])
+            uq, uk = uq.view(bsz, N, T, hd2), uk.view(bsz, N, T, hd2)
+            gate_q, gate_k = gates[0].view(bsz, N, T), gates[1].view(bsz, N, T)
+        elif ops.inference_fast_path(sequence_output):
             # Inference: the 2 x (Ld + 1) slot projections run as ONE grouped launch writing straight into the stacked
             # [B,N,T,d] buffers (the x sqrt(D) unscaling of egtr:343 is the group's input scale), and the four
             # separable first-layer / gate products as one more; their weight slices are cached derived constants.
@@ -201,6 +256,13 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         init_reference = outputs.init_reference_points
         inter_references = outputs.intermediate_reference_points
 
+        if (labels is None and ops.inference_fast_path(hidden_states) and not self.config.with_box_refine
+                and hidden_states.shape[1] > 1):
+            # inference: nothing reads the intermediate levels' logits / boxes (they feed the auxiliary losses only,
+            # egtr:307-316) -- the heads run on the last level's 200 rows instead of all Ld x 200 (the reference computes
+            # every level and drops them)
+            init_reference = inter_references[:, -2]
+            hidden_states, inter_references = hidden_states[:, -1:], inter_references[:, -1:]
         outputs_class, outputs_coord, node_cls = detection_heads(
             self.config, self.class_embed, self.bbox_embed, hidden_states, init_reference, inter_references,
             want_node_cls=True)
@@ -233,21 +295,25 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
                              output_attention_states=True, return_dict=True)
         logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, _ = \
             self._heads(outputs, want_gate_mean=True)
+        res = (logits, pred_boxes, pred_rel, pred_connectivity, gate_mean)
         if self.config.auxiliary_loss:
-            return logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord
-        return logits, pred_boxes, pred_rel, pred_connectivity, gate_mean
+            res += (outputs_class, outputs_coord)
+        if self.config.two_stage:   # the per-token proposal heads' outputs close the tuple
+            res += (outputs.enc_outputs_class, outputs.enc_outputs_coord_logits)
+        return res
 
     def loss_from_tensors(self, tensors, labels):
         """Matcher + SGG loss (egtr:420-505) on the tensors ``forward_tensors`` returns."""
         logits, pred_boxes, pred_rel, pred_connectivity, gate_mean = tensors[:5]
         outputs_class = tensors[5] if self.config.auxiliary_loss else None
         outputs_coord = tensors[6] if self.config.auxiliary_loss else None
+        enc = tuple(tensors[-2:]) if self.config.two_stage else None
         loss, loss_dict, _ = self._loss(logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class,
-                                        outputs_coord, labels)
+                                        outputs_coord, labels, enc_outputs=enc)
         return loss, loss_dict
 
     def _loss(self, logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord, labels,
-              pending_match=None):
+              pending_match=None, enc_outputs=None):
         auxiliary_outputs = None
         num_object_queries = logits.shape[1]
         matcher = self._matcher()
@@ -266,17 +332,20 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         if self.config.auxiliary_loss:
             auxiliary_outputs = self._set_aux_loss(outputs_class, outputs_coord)
             outputs_loss["auxiliary_outputs"] = auxiliary_outputs
+        if self.config.two_stage:   # egtr:459-464: (class logits, box logits) of every encoder token
+            outputs_loss["enc_outputs"] = {"logits": enc_outputs[0], "pred_boxes": enc_outputs[1].sigmoid()}
         loss_dict = criterion(outputs_loss, labels,
                               matched=matcher.finish(pending_match) if pending_match is not None else None)
         weight_dict = {"loss_ce": self.config.ce_loss_coefficient, "loss_bbox": self.config.bbox_loss_coefficient,
                        "loss_giou": self.config.giou_loss_coefficient,
                        "loss_rel": self.config.rel_loss_coefficient,
                        "loss_connectivity": self.config.connectivity_loss_coefficient}
+        base_weights = dict(weight_dict)
         if self.config.auxiliary_loss:
-            aux = {}
             for i in range(self.config.decoder_layers - 1):
-                aux.update({f"{k}_{i}": v for k, v in weight_dict.items()})
-            weight_dict.update(aux)
+                weight_dict.update({f"{k}_{i}": v for k, v in base_weights.items()})
+        if self.config.two_stage:   # egtr:484-488
+            weight_dict.update({f"{k}_enc": v for k, v in base_weights.items()})
         loss = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
         for i in range(self.config.decoder_layers + 1):  # rel_gate_{i} logging (egtr:496-505)
             loss_dict[f"rel_gate_{i}"] = gate_mean[i]
@@ -299,8 +368,9 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
 
         loss, loss_dict, auxiliary_outputs = None, None, None
         if labels is not None:
-            loss, loss_dict, auxiliary_outputs = self._loss(logits, pred_boxes, pred_rel, pred_connectivity,
-                                                            gate_mean, outputs_class, outputs_coord, labels, pending)
+            loss, loss_dict, auxiliary_outputs = self._loss(
+                logits, pred_boxes, pred_rel, pred_connectivity, gate_mean, outputs_class, outputs_coord, labels, pending,
+                enc_outputs=(outputs.enc_outputs_class, outputs.enc_outputs_coord_logits))
 
         if self.config.logit_adjustment:  # egtr:509-512
             pred_rel = pred_rel - self.config.logit_adj_tau * self.rel_dist.log().to(pred_rel.device)
@@ -646,4 +716,15 @@ class SceneGraphGenerationLoss(nn.Module):
                     l_dict = self.get_loss(loss, auxiliary_outputs, targets, indices, matching_costs, num_boxes)
                     aux.update({k + f"_{i}": v for k, v in l_dict.items()})
                 losses.update(poisoned(indices, aux))
+        if "enc_outputs" in outputs:   # two-stage proposals against class-agnostic targets (egtr:1019-1033)
+            enc_outputs = outputs["enc_outputs"]
+            bin_targets = [dict(t, class_labels=torch.zeros_like(t["class_labels"])) for t in targets]
+            indices, matching_costs = self.matcher(enc_outputs, bin_targets)
+            enc = {}
+            for loss in self.losses:
+                if loss in ["masks", "relations", "uncertainty"]:
+                    continue
+                l_dict = self.get_loss(loss, enc_outputs, bin_targets, indices, matching_costs, num_boxes)
+                enc.update({k + "_enc": v for k, v in l_dict.items()})
+            losses.update(poisoned(indices, enc))
         return losses

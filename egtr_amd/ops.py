@@ -1188,8 +1188,11 @@ def linear_split_bf16_grouped(items):
         y = it.get("out")
         if y is None:
             y = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x2.device)
-        else:
-            _chk(y, "out", torch.float32)
+        elif not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 2 and tuple(y.shape) == (x2.shape[0], N)
+                  and y.stride(1) == 1 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0):
+            # (rows of a larger buffer are fine: the kernel takes the row stride)
+            raise RuntimeError("linear_split_bf16_grouped: out must be a float32 [rows, N] view with unit inner stride, a "
+                               "row stride that is a multiple of 4 and a 16-byte aligned base")
         b = it.get("b")
         if b is not None:
             b = _chk(b.detach().contiguous(), "bias", torch.float32)

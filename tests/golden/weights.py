@@ -17,7 +17,8 @@ def _scale_for(name, shape):
         return ("normal", 2.0)  # +-2 px spread of the sampling points (plays the role of dd:999-1013)
     if name.endswith("sampling_offsets.weight"):
         return ("normal", 0.3 / math.sqrt(shape[-1]))
-    if "layer_norm.weight" in name or (".input_proj." in name and name.endswith(".1.weight")):
+    if "layer_norm.weight" in name or (".input_proj." in name and name.endswith(".1.weight")) \
+            or name.endswith("_norm.weight"):   # (+ the two-stage variant's enc_output_norm / pos_trans_norm)
         return ("affine", 0.1)  # 1 + 0.1 r
     if name.endswith("level_embed"):
         return ("normal", 0.5)

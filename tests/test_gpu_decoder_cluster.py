@@ -58,10 +58,13 @@ def _run(model, pv, pm, fused, base=False):
         decoder_fused.ENABLED = old
 
 
+@pytest.mark.parametrize("dataflow", [True, False])
 @pytest.mark.parametrize("num_queries,batch,hw", [(200, 1, (160, 224)), (37, 2, (128, 160)), (300, 2, (96, 128)),
                                                   (8, 3, (96, 128))])
-def test_cluster_decoder_matches_the_per_operation_decoder(num_queries, batch, hw):
+def test_cluster_decoder_matches_the_per_operation_decoder(num_queries, batch, hw, dataflow, monkeypatch):
+    """Both hand-over modes of the cluster's partial results: tagged data (default) and L2 barriers."""
     from egtr_amd import decoder_fused, ops
+    monkeypatch.setattr(decoder_fused, "DATAFLOW", dataflow)
     model = _model(num_queries, 3)
     pv, pm = _inputs(batch, *hw)
     ref, ref_base = _run(model, pv, pm, fused=False), _run(model, pv, pm, fused=False, base=True)
@@ -92,7 +95,8 @@ def test_cluster_decoder_is_deterministic_and_survives_graph_replay():
     from egtr_amd.runtime import GraphedForward
     model = _model(200, 6)
     pv, pm = _inputs(1, 160, 224)
-    a = _run(model, pv, pm, fused=True, base=True)
+    for _ in range(3):   # several forwards in a row: the seam between two forwards reuses the tagged buffers
+        a = _run(model, pv, pm, fused=True, base=True)
     enc = (a.encoder_last_hidden_state,)
     from egtr_amd import decoder_fused
     assert decoder_fused.ENABLED
