@@ -760,7 +760,7 @@ extern "C" int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t
 int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
                                         const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
                                         int B, int Lq, int S, int L, int P, unsigned* counters);
-unsigned* egtr_msda_tile_counters();   // eight zero-initialised work counters for one launch pair (msda_tile.hip)
+unsigned* egtr_msda_tile_counters(hipStream_t st);   // eight work counters private to one launch pair (msda_tile.hip)
 
 // variant: 0 = automatic, 1 = wave-per-query with per-sample global atomics (reference scheme), 2 = two kernels:
 // wave-per-query for grad_attn / grad_loc (no atomics) + query-tile x head MFMA accumulation of grad_value
@@ -793,7 +793,7 @@ int msda_backward_f32_impl(egtr_stream_t stream, const float* grad_out, const fl
     return EGTR_E_LAUNCH;
   if (variant == 2) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
-    unsigned* counters = egtr_msda_tile_counters();
+    unsigned* counters = egtr_msda_tile_counters(st);
     if (counters == nullptr) return EGTR_E_LAUNCH;
     hipLaunchKernelGGL(msda_bwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,

@@ -41,8 +41,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Work counters of the launches in flight: 8 per launch (one per head = XCD), a ring of kCounterSlots launches.  A slot is
 // zeroed by the wave-per-query kernel that precedes its value-tile kernel on the stream (msda.hip).
-constexpr int kCounterSlots = 1024;
-__device__ unsigned g_tile_counters[kCounterSlots * 8];
+// Launches recorded into a HIP graph keep their slot for the graph's lifetime (the pointer is baked into the graph and reused on
+// every replay), so they draw from a region of their own that is never handed out twice: an eager launch on another stream
+// can then not wrap the ring onto a slot a replay is using (two launch pairs sharing counters would skip or repeat tiles).
+constexpr int kCounterSlots = 1024;   // eager launches: a ring
+constexpr int kGraphSlots = 8192;     // captured launches: one-way
+__device__ unsigned g_tile_counters[(kCounterSlots + kGraphSlots) * 8];
 
 __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
     const float* __restrict__ grad_out, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
@@ -309,16 +313,21 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
 }  // namespace
 
 // Eight zero-initialised-by-the-caller work counters for one launch pair: the next slot of the ring on the current device.
-unsigned* egtr_msda_tile_counters() {
+unsigned* egtr_msda_tile_counters(hipStream_t st) {
   static unsigned* base[64] = {};
-  static unsigned next_slot = 0;   // launches of one process are issued from one thread at a time per device in practice;
-                                   // a torn increment would only make two launches share a slot index modulo the ring
+  static unsigned next_slot = 0, next_graph_slot = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   if (base[dev] == nullptr) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tile_counters)) != hipSuccess) return nullptr;
     base[dev] = static_cast<unsigned*>(p);
+  }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive) {
+    const unsigned g = __atomic_fetch_add(&next_graph_slot, 1u, __ATOMIC_RELAXED);
+    if (g >= (unsigned)kGraphSlots) return nullptr;   // ~1000 captured train steps: the caller reports EGTR_E_LAUNCH
+    return base[dev] + (kCounterSlots + g) * 8;
   }
   const unsigned slot = __atomic_fetch_add(&next_slot, 1u, __ATOMIC_RELAXED) % kCounterSlots;
   return base[dev] + slot * 8;

@@ -1533,6 +1533,19 @@ class DeformableDetrHungarianMatcher(nn.Module):
                 raise ValueError("cost matrix is infeasible")
 
     @staticmethod
+    def defer_status(flag):
+        """Queue a device-side flag (non-zero = a cost matrix was refused somewhere) for ``raise_if_invalid``: an asynchronous
+        copy to pinned memory now, the ValueError at the next check -- how a rank learns that ANOTHER rank's matcher refused
+        (egtr_amd.runtime.DataParallelTrainer all-reduces the flag first)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        st = flag.detach().reshape(1).to(torch.int32)
+        host, event = _status_slot(st)
+        host.copy_(st, non_blocking=True)
+        event.record()
+        _PENDING_MATCHER_STATUS.append((host, event))
+
+    @staticmethod
     def take_step_statuses():
         """The per-image solver statuses (device int32 tensors, one per matcher call) recorded since the last call, and
         forget them.  A trainer reduces them to one "some cost matrix was refused" flag ON THE DEVICE and hands it to the
@@ -1592,7 +1605,12 @@ class DeformableDetrHungarianMatcher(nn.Module):
                 _PENDING_MATCHER_STATUS.append((host, event))
                 del _PENDING_MATCHER_STATUS[:-64]   # bounded when nobody asks
                 _STEP_MATCHER_STATUS.append(status)
-                del _STEP_MATCHER_STATUS[:-64]
+                if len(_STEP_MATCHER_STATUS) > 64:
+                    # bounded WITHOUT forgetting: the oldest entries are folded into one "worst status so far" word (a long
+                    # accumulation window makes 1 + num_aux calls per micro-step; dropping the oldest would let an early
+                    # refusal slip past the optimizer's skip flag)
+                    head = torch.cat([t.reshape(-1) for t in _STEP_MATCHER_STATUS[:33]]).amax().reshape(1)
+                    _STEP_MATCHER_STATUS[:33] = [head]
             for n in n_out:
                 indices.append((pred_idx[o:o + n], tgt_idx[o:o + n]))
                 costs.append(mcost[o:o + n])

@@ -1592,18 +1592,32 @@ class LevelGeometryTrainFunction(Function):
     def backward(ctx, g_pos, g_mask, g_vr, g_ref):
         shapes, B = ctx.shapes
         g2 = _rows256(g_pos)
-        key = (shapes, B, str(g2.device))
-        w = _LEVEL_ROW_WEIGHTS.get(key)
-        if w is None:   # one-hot level membership of every token row, [L, B * S] floats: a constant of the geometry
-            sizes = [h * w_ for h, w_ in shapes]
-            lvl = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)).repeat(B)
-            # (separate allocations: a row of one [L, B * S] tensor is 16-byte aligned only when B * S is a multiple of 4)
-            w = [(lvl == l).to(torch.float32).to(g2.device) for l in range(len(sizes))]
-            _LEVEL_ROW_WEIGHTS[key] = w
-        return torch.stack([weighted_column_sum(g2, wl) for wl in w]), None, None, None, None, None
+        return torch.stack([weighted_column_sum(g2, wl) for wl in _level_row_weights(shapes, B, g2.device)]), \
+            None, None, None, None, None
 
 
+# One-hot level membership of every token row ([B * S] floats per level): a constant of (level shapes, batch).  Multi-scale
+# training meets a new shape combination in most batches, so the table is a small LRU (each entry is L x B*S floats on the
+# device) and an entry is built ON the device from an arange -- no host tensor, no H2D copy, legal under stream capture.
 _LEVEL_ROW_WEIGHTS = {}
+_LEVEL_ROW_WEIGHTS_MAX = 4
+
+
+def _level_row_weights(shapes, B, device):
+    key = (shapes, B, str(device))
+    w = _LEVEL_ROW_WEIGHTS.pop(key, None)
+    if w is None:
+        sizes = [h * w_ for h, w_ in shapes]
+        S = sum(sizes)
+        tok = torch.arange(B * S, device=device, dtype=torch.int32) % S      # token index within its image
+        w, start = [], 0
+        for n in sizes:   # (separate allocations: a row of one [L, B * S] tensor is 16-byte aligned only when B * S % 4 == 0)
+            w.append(((tok >= start) & (tok < start + n)).to(torch.float32))
+            start += n
+        while len(_LEVEL_ROW_WEIGHTS) >= _LEVEL_ROW_WEIGHTS_MAX:
+            _LEVEL_ROW_WEIGHTS.pop(next(iter(_LEVEL_ROW_WEIGHTS)))
+    _LEVEL_ROW_WEIGHTS[key] = w   # (re-inserted last: most recently used)
+    return w
 
 
 def level_geometry_train(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale):

@@ -201,8 +201,13 @@ class DataParallelTrainer:
             return None
         # 0-dim float32, the shape torch's GradScaler hands to the fused optimizers as `found_inf`
         flag = torch.cat([s.reshape(-1) for s in statuses]).ne(0).any().to(torch.float32).reshape(())
-        if self.world > 1:   # replicas must skip together (4 bytes; the refusing rank raises at its next step)
+        if self.world > 1:
+            # replicas must skip together (4 bytes) -- and RAISE together: the reduced flag is queued for raise_if_invalid on
+            # every rank, otherwise only the refusing rank would stop at its next step and the others would block in the
+            # next gradient all-reduce
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if flag.is_cuda:
+                DeformableDetrHungarianMatcher.defer_status(flag)
         return flag
 
     def training_step(self, batch):

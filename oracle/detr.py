@@ -198,9 +198,40 @@ def resnet50_backbone(sd, pixel_values, pixel_mask, prefix="model.backbone.conv_
 
 
 # --------------------------------------------------------------------------------------- full model
+def proposal_pos_embed(proposals):
+    """dd:2075-2096: sine embedding of proposal logits [B, K, 4] -> [B, K, 512]."""
+    dim_t = torch.arange(128, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / 128)
+    pos = (proposals.sigmoid() * (2 * math.pi))[:, :, :, None] / dim_t
+    return torch.stack((pos[:, :, :, 0::2].sin(), pos[:, :, :, 1::2].cos()), dim=4).flatten(2)
+
+
+def encoder_output_proposals(sd, enc, padding_mask, shapes):
+    """dd:2098-2159: per-token proposals (pixel centre over the VALID extent, size 0.05 * 2^level) as logits, +inf where the
+    token is padded or the proposal leaves (0.01, 0.99); features of those tokens zeroed, then enc_output + LayerNorm."""
+    B = enc.shape[0]
+    props, cur = [], 0
+    for lvl, (H, W) in enumerate(shapes.tolist()):
+        m = padding_mask[:, cur:cur + H * W].view(B, H, W)
+        vh, vw = (~m[:, :, 0]).sum(1), (~m[:, 0, :]).sum(1)
+        gy, gx = torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij")
+        grid = torch.stack([gx, gy], -1)[None].expand(B, -1, -1, -1)
+        grid = (grid + 0.5) / torch.stack([vw, vh], 1).view(B, 1, 1, 2)
+        wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+        props.append(torch.cat([grid, wh], -1).view(B, -1, 4))
+        cur += H * W
+    props = torch.cat(props, 1)
+    valid = ((props > 0.01) & (props < 0.99)).all(-1, keepdim=True)
+    props = torch.log(props / (1 - props))
+    drop = padding_mask.unsqueeze(-1) | ~valid
+    props = props.masked_fill(drop, float("inf"))
+    feat = enc.masked_fill(drop, 0.0)
+    return _ln(sd, "model.enc_output_norm", _lin(sd, "model.enc_output", feat)), props
+
+
 def detr_model_forward(sd, cfg, pixel_values, pixel_mask, backbone=stub_backbone, core=None):
-    """DeformableDetrModel.forward (dd:2161-2390), single-stage; ``cfg["with_box_refine"]`` turns the decoder's
-    iterative box refinement on (dd:1903-1918).
+    """DeformableDetrModel.forward (dd:2161-2390); ``cfg["with_box_refine"]`` turns the decoder's iterative box
+    refinement on (dd:1903-1918), ``cfg["two_stage"]`` the per-token proposal branch (dd:2306-2337).
 
     Returns dict with encoder_last_hidden_state, intermediate_hidden_states [B,Ld,N,d],
     init_reference_points [B,N,2], intermediate_reference_points [B,Ld,N,2], queries/keys tuples."""
@@ -243,11 +274,23 @@ def detr_model_forward(sd, cfg, pixel_values, pixel_mask, backbone=stub_backbone
         x = encoder_layer(sd, f"model.encoder.layers.{i}", x, mask, pos, refs, shapes, lsi, core)
     enc = x
 
-    qe = sd["model.query_position_embeddings.weight"]
-    query_embed, target = torch.split(qe, d, dim=1)  # :2339
-    query_embed = query_embed.unsqueeze(0).expand(B, -1, -1)
-    target = target.unsqueeze(0).expand(B, -1, -1)
-    ref = _lin(sd, "model.reference_points", query_embed).sigmoid()  # :2342
+    enc_cls = enc_box = None
+    if cfg.get("two_stage", False):  # :2306-2337
+        Ld = cfg["decoder_layers"]
+        feat, props = encoder_output_proposals(sd, enc, ~mask, shapes)
+        enc_cls = _lin(sd, f"class_embed.{Ld}", feat)
+        enc_box = _mlp(sd, f"bbox_embed.{Ld}", feat, 3) + props
+        top = torch.topk(enc_cls[..., 0], cfg["two_stage_num_proposals"], dim=1)[1]
+        top_logits = torch.gather(enc_box, 1, top.unsqueeze(-1).repeat(1, 1, 4)).detach()
+        ref = top_logits.sigmoid()
+        pt = _ln(sd, "model.pos_trans_norm", _lin(sd, "model.pos_trans", proposal_pos_embed(top_logits)))
+        query_embed, target = torch.split(pt, d, dim=2)
+    else:
+        qe = sd["model.query_position_embeddings.weight"]
+        query_embed, target = torch.split(qe, d, dim=1)  # :2339
+        query_embed = query_embed.unsqueeze(0).expand(B, -1, -1)
+        target = target.unsqueeze(0).expand(B, -1, -1)
+        ref = _lin(sd, "model.reference_points", query_embed).sigmoid()  # :2342
     h = target
     inter, inter_ref, qs, ks = [], [], [], []
     init_ref = ref
@@ -272,7 +315,8 @@ def detr_model_forward(sd, cfg, pixel_values, pixel_mask, backbone=stub_backbone
                 intermediate_hidden_states=torch.stack(inter, 1), init_reference_points=init_ref,
                 intermediate_reference_points=torch.stack(inter_ref, 1),
                 decoder_attention_queries=tuple(qs), decoder_attention_keys=tuple(ks),
-                spatial_shapes=shapes, level_start_index=lsi, valid_ratios=vr, mask_flatten=mask)
+                spatial_shapes=shapes, level_start_index=lsi, valid_ratios=vr, mask_flatten=mask,
+                enc_outputs_class=enc_cls, enc_outputs_coord_logits=enc_box)
 
 
 def detection_heads(sd, cfg, mo):

@@ -168,16 +168,17 @@ def sgg_loss(out, targets, cfg, training):
     nm_cost = nonmatching_cost(cc, bc, gc, sm)
     losses = {}
 
-    def labels_boxes_card(lg, bx, idx, suffix=""):
+    def labels_boxes_card(lg, bx, idx, suffix="", targets=targets):
+        n_out = lg.shape[1]
         bidx = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(idx)])
         sidx = torch.cat([s for s, _ in idx])
         tc_o = torch.cat([t["class_labels"][j] for t, (_, j) in zip(targets, idx)])
         tc = torch.full(lg.shape[:2], C, dtype=torch.int64)
         tc[bidx, sidx] = tc_o
-        onehot = torch.zeros(B, N, C + 1, dtype=lg.dtype)
+        onehot = torch.zeros(B, n_out, C + 1, dtype=lg.dtype)
         onehot.scatter_(2, tc.unsqueeze(-1), 1)
         losses["loss_ce" + suffix] = sigmoid_focal_loss(lg, onehot[:, :, :-1], num_boxes,
-                                                        alpha=cfg["focal_alpha"], gamma=2) * N  # egtr:647-656
+                                                        alpha=cfg["focal_alpha"], gamma=2) * n_out  # egtr:647-656
         src = bx[bidx, sidx]
         tgt = torch.cat([t["boxes"][j] for t, (_, j) in zip(targets, idx)], dim=0)
         losses["loss_bbox" + suffix] = F.l1_loss(src, tgt, reduction="none").sum() / num_boxes
@@ -208,12 +209,21 @@ def sgg_loss(out, targets, cfg, training):
             aidx, _ = hungarian_match(lg, bx, targets, cc, bc, gc, sm)
             labels_boxes_card(lg, bx, aidx, suffix=f"_{li}")
 
+    if cfg.get("two_stage", False) and out.get("enc_outputs_class") is not None:  # egtr:459-464, 1019-1033
+        bin_targets = [dict(t, class_labels=torch.zeros_like(t["class_labels"])) for t in targets]
+        elg, ebx = out["enc_outputs_class"], out["enc_outputs_coord_logits"].sigmoid()
+        eidx, _ = hungarian_match(elg, ebx, bin_targets, cc, bc, gc, sm)
+        labels_boxes_card(elg, ebx, eidx, suffix="_enc", targets=bin_targets)
+
     weights = {"loss_ce": cc, "loss_bbox": cfg["bbox_loss_coefficient"], "loss_giou": cfg["giou_loss_coefficient"],
                "loss_rel": cfg["rel_loss_coefficient"], "loss_connectivity": cfg["connectivity_loss_coefficient"]}
     if cfg.get("auxiliary_loss", False):
         for li in range(cfg["decoder_layers"] - 1):
             weights.update({f"{k}_{li}": v for k, v in list(weights.items()) if "_" + str(li) not in k
                             and k in ("loss_ce", "loss_bbox", "loss_giou", "loss_rel", "loss_connectivity")})
+    if cfg.get("two_stage", False):  # egtr:484-488
+        weights.update({f"{k}_enc": v for k, v in list(weights.items())
+                        if k in ("loss_ce", "loss_bbox", "loss_giou", "loss_rel", "loss_connectivity")})
     total = sum(losses[k] * weights[k] for k in losses if k in weights)
     if "rel_gate" in out:  # egtr:496-505
         g = out["rel_gate"].reshape(B * N * N, -1).mean(0)

@@ -10,7 +10,8 @@ import weights as W
 
 def product_config(cfg_dict):
     from egtr_amd.deformable_detr import DeformableDetrConfig
-    base_keys = ("num_queries", "encoder_layers", "decoder_layers", "dropout", "auxiliary_loss", "with_box_refine")
+    base_keys = ("num_queries", "encoder_layers", "decoder_layers", "dropout", "auxiliary_loss", "with_box_refine", "two_stage",
+                 "two_stage_num_proposals")
     cfg = DeformableDetrConfig(**{k: cfg_dict[k] for k in base_keys if k in cfg_dict})
     for k, v in cfg_dict.items():
         if k not in base_keys:

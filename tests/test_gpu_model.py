@@ -763,3 +763,47 @@ def test_object_detection_model_vs_reference(golden_dir, tag):
     for n, v in json.loads(str(g[f"{tag}_grad_norms"])).items():
         got = float(params[n].grad.norm())
         assert abs(got - v) < 5e-3 * max(abs(v), 1e-2), (n, got, v)
+
+
+def test_two_stage_model_vs_reference(golden_dir):
+    """two_stage=True (dd:2306-2337 and helpers, egtr:459-464 / 484-488 / 1019-1033) on the HIP kernels: per-token proposal
+    heads, top-k reference boxes (4-d: the fused MSDA kernel's box form), pos_trans queries, *_enc loss terms and every
+    gradient norm against the reference's run (tests/golden/sgg_small_two_stage.npz)."""
+    g = Hh.load_golden(golden_dir, "sgg_small_two_stage.npz")
+    cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
+    model, cfg, _ = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    sd = W.fill_state_dict(shapes, seed=int(g["seed"]), alias_heads=False)
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg.num_labels, cfg.num_rel_labels), cfg.freq_bias_eps)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    pv, pm = Hh.small_inputs(g)
+    pv, pm = pv.to(DEV), pm.to(DEV)
+    with torch.no_grad():
+        out = model(pixel_values=pv, pixel_mask=pm, output_attention_states=True, output_hidden_states=True)
+        base = model.model(pixel_values=pv, pixel_mask=pm, output_attention_states=True)
+    tol = 1e-3
+    ref_box = _t(g["enc_outputs_coord_logits"])
+    finite = torch.isfinite(ref_box)
+    got_box = base.enc_outputs_coord_logits.cpu()
+    assert torch.equal(torch.isfinite(got_box), finite)
+    assert (got_box[finite] - ref_box[finite]).abs().max() < tol
+    assert (base.enc_outputs_class.cpu() - _t(g["enc_outputs_class"])).abs().max() < tol
+    assert float(g["topk_margin"]) > 10 * tol      # the proposal ranking cannot flip within the tolerance
+    assert (base.init_reference_points.cpu() - _t(g["init_ref"])).abs().max() < tol
+    assert (base.intermediate_hidden_states.cpu() - _t(g["inter"])).abs().max() < tol
+    assert (out.logits.cpu() - _t(g["logits"])).abs().max() < tol
+    assert (out.pred_boxes.cpu() - _t(g["pred_boxes"])).abs().max() < tol
+    model.train()
+    targets = [{k: t.to(DEV) for k, t in d.items()}
+               for d in W.make_targets(int(g["target_seed"]), 2, cfg.two_stage_num_proposals, cfg.num_labels, cfg.num_rel_labels)]
+    out_t = model(pixel_values=pv, pixel_mask=pm, labels=targets, output_attention_states=True)
+    ref = json.loads(str(g["train_loss_dict"]))
+    assert set(ref) == set(out_t.loss_dict)
+    for k, v in ref.items():
+        assert abs(float(out_t.loss_dict[k]) - v) < 1e-3 * max(1.0, abs(v)), (k, float(out_t.loss_dict[k]), v)
+    out_t.loss.backward()
+    gn = json.loads(str(g["grad_norms"]))
+    params = dict(model.named_parameters())
+    for n, v in gn.items():
+        got = float(params[n].grad.norm())
+        assert abs(got - v) < 5e-3 * max(abs(v), 1e-2), (n, got, v)

@@ -386,3 +386,46 @@ def test_object_detection_model_matches_reference(golden_dir, cpu_kernels, tag):
         assert abs(got - v) < 2e-3 * max(abs(v), 1e-2), (n, got, v)
     for n in ("class_embed.0.bias", "model.reference_points.weight"):
         assert (params[n].grad - _t(g[f"{tag}_grad::" + n])).abs().max() < 1e-3 * max(1.0, float(np.abs(g[f"{tag}_grad::" + n]).max()))
+
+
+def test_two_stage_model_matches_reference(golden_dir, cpu_kernels):
+    """two_stage=True through the product modules (host logic; CPU stand-ins for the three HIP ops): the branch of
+    DeformableDetrModel.forward at dd:2306-2337 with its helpers (:2075-2159), the extra head pair (egtr:142-163) and the
+    *_enc loss terms (egtr:459-464, 484-488, 1019-1033) against the reference's own run."""
+    import weights as W
+    g = Hh.load_golden(golden_dir, "sgg_small_two_stage.npz")
+    cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
+    model, cfg, _ = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    assert set(model.state_dict()) == set(shapes)
+    sd = W.fill_state_dict(shapes, seed=int(g["seed"]), alias_heads=False)
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg.num_labels, cfg.num_rel_labels), cfg.freq_bias_eps)
+    model.load_state_dict(sd)
+    model.eval()
+    pv, pm = Hh.small_inputs(g)
+    with torch.no_grad():
+        out = model(pixel_values=pv, pixel_mask=pm, output_attention_states=True, output_hidden_states=True)
+        base = model.model(pixel_values=pv, pixel_mask=pm, output_attention_states=True)
+    tol = 2e-4
+    ref_box = _t(g["enc_outputs_coord_logits"])
+    finite = torch.isfinite(ref_box)
+    assert torch.equal(torch.isfinite(base.enc_outputs_coord_logits), finite)
+    assert (base.enc_outputs_coord_logits[finite] - ref_box[finite]).abs().max() < tol
+    assert (base.enc_outputs_class - _t(g["enc_outputs_class"])).abs().max() < tol
+    assert (base.init_reference_points - _t(g["init_ref"])).abs().max() < tol
+    assert (base.intermediate_hidden_states - _t(g["inter"])).abs().max() < tol
+    assert (out.logits - _t(g["logits"])).abs().max() < tol and (out.pred_boxes - _t(g["pred_boxes"])).abs().max() < tol
+    model.train()
+    targets = W.make_targets(int(g["target_seed"]), 2, cfg.two_stage_num_proposals, cfg.num_labels, cfg.num_rel_labels)
+    out_t = model(pixel_values=pv, pixel_mask=pm, labels=targets, output_attention_states=True)
+    ref = json.loads(str(g["train_loss_dict"]))
+    assert set(ref) == set(out_t.loss_dict), sorted(set(ref) ^ set(out_t.loss_dict))
+    for k, v in ref.items():
+        assert abs(float(out_t.loss_dict[k]) - v) < 3e-4 * max(1.0, abs(v)), (k, float(out_t.loss_dict[k]), v)
+    assert abs(float(out_t.loss) - float(g["train_loss"])) < 3e-4 * abs(float(g["train_loss"]))
+    out_t.loss.backward()
+    gn = json.loads(str(g["grad_norms"]))
+    params = dict(model.named_parameters())
+    assert set(gn) == {n for n, p in params.items() if p.grad is not None}
+    for n, v in gn.items():
+        got = float(params[n].grad.norm())
+        assert abs(got - v) < 2e-3 * max(abs(v), 1e-3), (n, got, v)

@@ -217,6 +217,40 @@ def test_box_refine_forward_and_loss_vs_reference(golden_dir):
     assert abs(float(total) - float(g["train_loss"])) < 2e-4 * abs(float(g["train_loss"]))
 
 
+def test_two_stage_forward_and_loss_vs_reference(golden_dir):
+    """two_stage=True (dd:2040-2052, 2075-2159, 2306-2337; egtr:459-464, 484-488, 1019-1033): per-token proposal heads,
+    top-k reference boxes, pos_trans queries, the *_enc loss terms -- the oracle against the reference's own run."""
+    g = _load(golden_dir, "sgg_small_two_stage.npz")
+    cfg = O_cfg(json.loads(str(g["cfg"])))
+    sd = W.fill_state_dict(json.loads(str(g["shapes"])), seed=int(g["seed"]), alias_heads=False)
+    sd["triplet_dist"], sd["rel_dist"] = W.freq_bias_tables(W.fg_matrix(cfg["num_labels"], cfg["num_rel_labels"]),
+                                                            cfg["freq_bias_eps"])
+    pv, pm = Hh.small_inputs(g)
+    K = cfg["two_stage_num_proposals"]
+    targets = W.make_targets(int(g["target_seed"]), 2, K, cfg["num_labels"], cfg["num_rel_labels"])
+    with torch.no_grad():
+        out = O.sgg_forward(sd, cfg, pv, pm)
+    tol = 2e-4
+    ref_box = _t(g["enc_outputs_coord_logits"])
+    finite = torch.isfinite(ref_box)
+    assert torch.equal(torch.isfinite(out["enc_outputs_coord_logits"]), finite) and not finite.all()
+    assert (out["enc_outputs_coord_logits"][finite] - ref_box[finite]).abs().max() < tol
+    assert (out["enc_outputs_class"] - _t(g["enc_outputs_class"])).abs().max() < tol
+    assert out["init_reference_points"].shape == (2, K, 4)
+    assert (out["init_reference_points"] - _t(g["init_ref"])).abs().max() < tol
+    assert (out["intermediate_hidden_states"] - _t(g["inter"])).abs().max() < tol
+    assert (out["logits"] - _t(g["logits"])).abs().max() < tol
+    assert (out["pred_boxes"] - _t(g["pred_boxes"])).abs().max() < tol
+    assert (out["conn_logits"] - _t(g["conn_logits"])).abs().max() < tol
+    total, ld, _, _ = OL.sgg_loss(out, targets, cfg, training=True)
+    ref = json.loads(str(g["train_loss_dict"]))
+    assert set(ref) == set(ld), sorted(set(ref) ^ set(ld))
+    assert {"loss_ce_enc", "loss_bbox_enc", "loss_giou_enc", "cardinality_error_enc"} <= set(ld)
+    for k, v in ref.items():
+        assert abs(float(ld[k]) - v) < 2e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
+    assert abs(float(total) - float(g["train_loss"])) < 2e-4 * abs(float(g["train_loss"]))
+
+
 def full_case(golden_dir, fixture="sgg_full.npz"):
     g = _load(golden_dir, fixture)
     cfg = O_cfg(json.loads(str(g["cfg"])))
