@@ -405,8 +405,10 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     if (tid < 128) {
       if (P.q_next != nullptr) s_bq[tid] = P.b_qkv_next[h * 128 + tid];
     } else if (tid < 192) {   // reference points of the 8 rows x 4 levels
-      const int rr = min((tid - 128) >> 3, nvalid - 1);
-      s_ref[tid - 128] = P.reference_points[(row0 + rr) * 8 + ((tid - 128) & 7)];
+      const int rr = min((tid - 128) >> 3, nvalid - 1), e = (tid - 128) & 7;
+      s_ref[tid - 128] = P.valid_ratios == nullptr
+                             ? P.reference_points[(row0 + rr) * 8 + e]
+                             : P.reference_points[((row0 + rr) % P.ref_rows) * 2 + (e & 1)] * P.valid_ratios[b * 8 + e];
     } else if (tid < 224) {
       s_vb[tid - 192] = P.value_bias != nullptr ? P.value_bias[h * 32 + tid - 192] : 0.f;
     }
@@ -755,6 +757,7 @@ extern "C" int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLay
   if ((p.qkv_rows != p.num_query && p.qkv_rows != p.batch * p.num_query) || p.x_rows % p.num_query || p.pos_rows % p.num_query)
     return EGTR_E_ARG;
   if (p.generation < 0 || p.generation > 3) return EGTR_E_ARG;
+  if (p.valid_ratios != nullptr && p.ref_rows <= 0) return EGTR_E_ARG;
   if (p.num_query > kMaxKeys) return EGTR_E_UNSUPPORTED;
   if (p.num_clusters != p.batch * ((p.num_query + kR - 1) / kR)) return EGTR_E_ARG;
   const void* need[] = {p.x_in, p.pos, p.q, p.k, p.v, p.reference_points, p.value, p.spatial_shapes, p.level_start_index,

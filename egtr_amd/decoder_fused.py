@@ -33,13 +33,13 @@ _P = ctypes.c_void_p
 class EgtrDecoderLayer(ctypes.Structure):
     """include/egtr_hip.h: struct EgtrDecoderLayer, field for field."""
     _fields_ = [(n, _P) for n in (
-        "x_in", "pos", "q", "k", "v", "reference_points", "value", "value_bias", "keep_bits", "spatial_shapes",
+        "x_in", "pos", "q", "k", "v", "reference_points", "valid_ratios", "value", "value_bias", "keep_bits", "spatial_shapes",
         "level_start_index", "x_out", "q_next", "k_next", "v_next", "w_attn_out", "b_attn_out", "ln1_gamma", "ln1_beta",
         "w_off_logit", "b_off_logit", "w_cross_out", "b_cross_out", "ln2_gamma", "ln2_beta", "w_fc1", "b_fc1", "w_fc2",
         "b_fc2", "ln3_gamma", "ln3_beta", "w_qkv_next", "b_qkv_next", "partials", "barriers", "status", "xcc_ids")] + [
         ("q_scale", ctypes.c_float), ("ln_eps", ctypes.c_float), ("batch", ctypes.c_int), ("num_query", ctypes.c_int),
         ("spatial_size", ctypes.c_int), ("x_rows", ctypes.c_int), ("pos_rows", ctypes.c_int), ("qkv_rows", ctypes.c_int),
-        ("num_clusters", ctypes.c_int), ("generation", ctypes.c_int)]
+        ("num_clusters", ctypes.c_int), ("generation", ctypes.c_int), ("ref_rows", ctypes.c_int)]
 
 
 def pack(w):
@@ -107,6 +107,7 @@ def supported(decoder, hidden_states, position_embeddings, reference_points, enc
 
 _WORKSPACES = {}   # (device index, stream handle, shape key) -> persistent buffers of eager launches
 _POOL = {}         # (device index, shape key) -> zeroed buffer sets, one per captured graph
+_GRAPH_WORKSPACES = []   # buffer sets baked into captured graphs, kept alive for the life of the process
 _CHECKED = set()   # device indices whose first eager run was verified
 
 
@@ -130,7 +131,12 @@ def _workspace(dev, shape_key):
     still works and is what happens when the pool is empty)."""
     if torch.cuda.is_current_stream_capturing():
         pool = _POOL.get((dev.index, shape_key))
-        return pool.pop() if pool else _new_workspace(dev, shape_key)
+        ws = pool.pop() if pool else _new_workspace(dev, shape_key)
+        # the captured launches keep the POINTERS: the tensors must outlive the graph.  (Dropping them handed the memory back
+        # to the allocator, and every replay then wrote its partial sums and barrier counters into whatever eager tensor had
+        # been given it since -- tests/test_gpu_model.py::test_graph_replay_matches_eager failed one run in ten.)
+        _GRAPH_WORKSPACES.append(ws)
+        return ws
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, shape_key)
     ws = _WORKSPACES.get(key)
     if ws is None:
@@ -173,9 +179,10 @@ def _keep_bits(mask, B, S):
 
 
 def run(decoder, hidden_states, position_embeddings, reference_input, values, value_bias, keep_mask, spatial_shapes,
-        level_start_index, first_with_pos=None):
+        level_start_index, first_with_pos=None, valid_ratios=None):
     """All layers of ``decoder``.  hidden_states / position_embeddings [B, N, 256] (stride-0 batch expansions are read in
-    place), reference_input [B, N, 4, 2] (reference points x valid ratios), values [Ld, B, S, 256] bias-free value
+    place), reference_input [B, N, 4, 2] (reference points x valid ratios; with ``valid_ratios`` [B, 4, 2]: the plain points [B, N, 2],
+    multiplied in the kernel), values [Ld, B, S, 256] bias-free value
     projections, value_bias [Ld, 256].  Returns (states [Ld, B, N, 256], q [Ld, B, N, 256] scaled, k [Ld, B, N, 256];
     q[0] / k[0] may be stride-0 expansions over the batch)."""
     from . import ops
@@ -222,7 +229,11 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
     tags = _tags(nl) if DATAFLOW else None
     # (the mode is part of the key: words written in barrier mode carry no tag and must never meet a dataflow reader)
     barriers, status, partials, ids = _workspace(dev, (B, N, nl if tags is not None else -nl))
-    ref = reference_input.contiguous()
+    if valid_ratios is not None:   # plain [B, N, 2] points (possibly one image's rows expanded) + [B, 4, 2] ratios
+        ref, ref_rows = _rows(reference_input, N)
+        vr = valid_ratios.contiguous()
+    else:
+        ref, ref_rows, vr = reference_input.contiguous(), 0, None
     kbits = _keep_bits(keep_mask, B, S) if keep_mask is not None else None
     vals = values if values.is_contiguous() else values.contiguous()
     vb = value_bias.contiguous() if value_bias is not None else None
@@ -240,6 +251,7 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
                                          B * N)
         a.pos, a.pos_rows = pos.data_ptr(), pos_rows
         a.reference_points = ref.data_ptr()
+        a.valid_ratios, a.ref_rows = (vr.data_ptr() if vr is not None else None), ref_rows
         a.value = vals[i].data_ptr()
         a.value_bias = vb[i].data_ptr() if vb is not None else None
         a.keep_bits = kbits.data_ptr() if kbits is not None else None

@@ -1007,20 +1007,24 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
             # one accumulating chain of data-gradient products; padded rows zeroed in the epilogues)
             values = ops.decoder_values_train(encoder_hidden_states, encoder_attention_mask, self.layers)
         hoisted_reference = None
-        if self.bbox_embed is None and reference_points.shape[-1] == 2:  # no refinement: same input for every layer
+        use_cluster = (fast and isinstance(values, list) and self.bbox_embed is None and reference_points.shape[-1] == 2
+                       and decoder_fused.supported(self, hidden_states, position_embeddings, reference_points,
+                                                   encoder_hidden_states, output_attentions))
+        if self.bbox_embed is None and reference_points.shape[-1] == 2 and not use_cluster:
+            # no refinement: same input for every layer (the cluster kernel multiplies by the valid ratios itself)
             hoisted_reference = reference_points[:, :, None] * valid_ratios[:, None]
-        if (fast and isinstance(values, list) and hoisted_reference is not None
-                and decoder_fused.supported(self, hidden_states, position_embeddings, reference_points,
-                                            encoder_hidden_states, output_attentions)):
+        if use_cluster:
             # ONE launch per layer (csrc/dec_layer.hip) instead of eight; a device whose dispatch does not keep a cluster's
             # workgroups on one XCD refuses (checked on the first run) and the per-operation loop below runs
             try:
                 states, q_all, k_all = decoder_fused.run(
-                    self, hidden_states, position_embeddings, hoisted_reference, values_all, b_all,
-                    encoder_attention_mask, spatial_shapes, level_start_index, first_with_pos=first_with_pos)
+                    self, hidden_states, position_embeddings, reference_points, values_all, b_all,
+                    encoder_attention_mask, spatial_shapes, level_start_index, first_with_pos=first_with_pos,
+                    valid_ratios=valid_ratios)
             except decoder_fused.DecoderClusterError as exc:
                 ops.note_fallback("decoder_cluster", str(exc))
                 decoder_fused.ENABLED = False
+                hoisted_reference = reference_points[:, :, None] * valid_ratios[:, None]
             else:
                 return self._fused_outputs(states, q_all, k_all, hidden_states, reference_points, output_hidden_states,
                                            output_attention_states, return_dict)

@@ -220,7 +220,8 @@ int egtr_linear_grouped_ln_f32(egtr_stream_t stream, int num_groups, const float
  *                pack([v_proj.weight[32h:32h+32]; 0 x 32])  [8][2][64][64][4]   b_qkv_next [8][128] = (q, k, v, 0) x 32
  * value is the BIAS-FREE value projection [B, S, 8, 32] of this layer; value_bias [256] (may be NULL) is applied by the
  * kernel times the sum of the in-range, unpadded corner weights; keep_bits (may be NULL): one bit per token, 0 = padded
- * (== the zeroed value rows of :1050-1052).  reference_points [B * N, 4, 2] already carry the valid ratios (:1874-1880).
+ * (== the zeroed value rows of :1050-1052).  reference_points: either [B * N, 4, 2] with the valid ratios applied
+ * (:1874-1880), or the plain [ref_rows, 2] points together with valid_ratios [B, 4, 2] -- the kernel multiplies.
  * q_next == NULL (last layer): no projections.  Workspace (egtr_decoder_layer_workspace): `partials` floats (zeroed once for the dataflow mode, see `generation`), `barriers`
  * 32-bit words (ZEROED ONCE when allocated, never again), `xcc_ids` ints, `status` one word zeroed by the caller: after
  * the launch bit 0 = a cluster barrier timed out, bit 1 = the workgroups of a cluster did not share one XCD -- the
@@ -232,7 +233,8 @@ typedef struct EgtrDecoderLayer {
   const float* q;                 /* [qkv_rows, 256] this layer's projections, row index modulo qkv_rows */
   const float* k;
   const float* v;
-  const float* reference_points;  /* [B * N, 4, 2] */
+  const float* reference_points;  /* valid_ratios == NULL: [B * N, 4, 2], the per-level points; else [ref_rows, 2] */
+  const float* valid_ratios;      /* [B, 4, 2] (w, h) or NULL: point of level l = reference_points[row % ref_rows] * valid_ratios[b][l] (:1865-1867) */
   const float* value;             /* [B, S, 8, 32] */
   const float* value_bias;        /* [256] or NULL */
   const unsigned* keep_bits;      /* [B, ceil(S / 32)] or NULL */
@@ -273,6 +275,7 @@ typedef struct EgtrDecoderLayer {
    * must hand CONSECUTIVE launches on the same `partials` buffer different tags and zero the buffer once when it is
    * allocated (zero = tag 0). */
   int generation;
+  int ref_rows;                   /* rows of reference_points when valid_ratios != NULL (N: the same points for every image) */
 } EgtrDecoderLayer;
 int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLayer* layer);
 int egtr_decoder_layer_workspace(int batch, int num_query, long long* partial_floats, int* barrier_words, int* id_words);

@@ -118,6 +118,24 @@ def test_cluster_decoder_is_deterministic_and_survives_graph_replay():
     assert (out["pred_rel"] - eager.pred_rel).abs().max() < 1e-5 and (out["logits"] - eager.logits).abs().max() < 1e-5
 
 
+def test_graph_replays_and_eager_runs_do_not_share_workspace_memory():
+    """A captured graph keeps pointers to its barrier counters and partial sums: the buffers must outlive the capture call
+    (they were dropped once: every replay then scribbled over whatever eager tensor had received the memory, and one run in
+    ten came out wrong).  Replays interleaved with eager forwards on fresh inputs, all compared."""
+    from egtr_amd.runtime import GraphedForward
+    model = _model(40, 2)
+    fwd = GraphedForward(model, enabled=True, strict=True)
+    for it in range(25):
+        pv, pm = _inputs(1, 160, 224, seed=100 + it)
+        a = _run(model, pv, pm, fused=True)
+        b = _run(model, pv, pm, fused=True)
+        with torch.no_grad():
+            r = fwd(pv, pm)
+        assert fwd.graphed
+        assert (a.pred_rel - b.pred_rel).abs().max() < 1e-5, it
+        assert (r["pred_rel"] - a.pred_rel).abs().max() < 1e-5, it
+
+
 def test_cluster_decoder_rejects_what_it_does_not_serve():
     import ctypes
     from egtr_amd import _lib, decoder_fused
