@@ -233,11 +233,43 @@ def time_msda_kernel(args, fused, iters=200):
     B, S, M, D = value.shape
     Lq = loc.shape[1]
     e = value.element_size()
-    # value S*256*e (capped by the gathered bytes) + loc Lq*256*4 + attn Lq*128*4 + out Lq*256*e
-    # (the fused entry reads raw offsets / logits of exactly the loc / attn sizes; its reference points, Lq*L*8 B,
-    # are not counted)
-    alg = B * (min(S * M * D * e, Lq * M * 16 * 4 * D * e) + Lq * M * 32 * 4 + Lq * M * 16 * 4 + Lq * M * D * e)
+    el, ea = loc.element_size(), args[4].element_size()
+    # value S*256*e (capped by the gathered bytes) + loc Lq*256*e_loc + attn Lq*128*e_attn + out Lq*256*e
+    # (the fused entry reads raw offsets / logits of exactly the loc / attn sizes -- bf16 in the bf16 model: until round 5
+    # this line priced them at 4 bytes and overstated the bf16 launch's bytes by 43 %; its reference points, Lq*L*8 B, are
+    # not counted)
+    alg = B * (min(S * M * D * e, Lq * M * 16 * 4 * D * e) + Lq * M * 32 * el + Lq * M * 16 * ea + Lq * M * D * e)
     return us, alg
+
+
+def time_decoder_layer(model, pv, pm, forwards=20):
+    """Average duration of one egtr_decoder_layer_f32 launch (csrc/dec_layer.hip): HIP events on torch's current stream
+    around every launch of `forwards` eager forwards; (us, launches per forward) or (None, 0) when the cluster path is off."""
+    from egtr_amd import _lib
+    lib = _lib.lib()
+    raw = lib.egtr_decoder_layer_f32
+    evs = []
+
+    def wrapped(stream, a):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st = raw(stream, a)
+        e1.record()
+        evs.append((e0, e1))
+        return st
+
+    lib.egtr_decoder_layer_f32 = wrapped
+    try:
+        with torch.no_grad():
+            for _ in range(forwards):
+                model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.egtr_decoder_layer_f32 = raw
+    if not evs:
+        return None, 0
+    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in evs[len(evs) // 4:])
+    return ts[len(ts) // 2], len(evs) // forwards
 
 
 def msda_kernel_name(fused):
@@ -511,6 +543,12 @@ def stress_bench(dev, steps, warmup, batch=16):
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                            "algorithmic_bytes_per_launch": alg, "avg_launch_us": round(us, 2)}
+        # memory counters of this launch from the newest separate rocprofv3 --pmc run over tools/stress_bench.py
+        # (tools/profile_r05_all.sh): HBM-side bytes, L2 hit rate, bytes moved through the vector L1
+        sp, sp_src = newest_pmc("r*_msda_bf16_pmc.json", out["roofline"]["kernel"])
+        if sp:
+            out["roofline"].update(traffic=sp.get("hbm_bytes_per_launch"), l2_hit=sp.get("l2_hit"),
+                                   l1_gather_bytes=sp.get("l1_gather_bytes"), traffic_source=sp_src)
     del fwd, model
     torch.cuda.empty_cache()
     return out
@@ -652,6 +690,8 @@ def main():
                     help="--mode infer on one GPU: after the timed region also run a short bs = 4 train loop and the bf16 "
                          "stress forward and append them to the JSON line as `train_step` / `stress_bf16` (0 = skip)")
     ap.add_argument("--extra-steps", type=int, default=8, help="timed steps of each extra workload")
+    ap.add_argument("--strict-fast-path", type=int, default=1,
+                    help="1: raise when a call falls off a HIP fast path (egtr_amd.ops.FALLBACKS); 0: count and warn")
     ap.add_argument("--launch-check", action="store_true",
                     help="only rendezvous, all-reduce and print n_gpus / rccl_ranks (launcher self-test, runs on CPU)")
     args = ap.parse_args()
@@ -684,6 +724,10 @@ def main():
         print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE = {world}: reporting n_gpus = {world}",
               file=sys.stderr)
     args.rccl_ranks = rccl_world_check(dist, dev) if dist is not None else 1
+    # a call that leaves a hand-written kernel for an ATen composition is an ERROR here (egtr_amd.ops.note_fallback): a
+    # benchmark number must not come from a silently deoptimised path.  --strict-fast-path 0: count and warn instead.
+    from egtr_amd import ops as _ops
+    _ops.STRICT_FAST_PATH = bool(args.strict_fast_path)
 
     if args.mode == "train":
         return train_bench(args, world, rank, dev, dist)
@@ -808,6 +852,23 @@ def main():
                 tail_entry["traffic_source"] = tp_src
             result["roofline_kernels"].append(tail_entry)
     result["config"]["relation_head"] = rel_entry.get("arithmetic", "exact-f32 MFMA")
+    d_us, d_n = time_decoder_layer(model, pv, pm)
+    if d_us is not None:
+        # algorithmic bytes of one layer launch at N = 200, B = batch: the layer's weights once (3.80 MB fp32), states in / out,
+        # q / k / v in and out (7 x N x 1 KiB), and the gathered value lines, at most N x 8 heads x 64 corners x 128 B
+        nq = cfg.num_queries * args.batch
+        d_alg = 3801088 + 8 * nq * 1024 + nq * 8 * 64 * 128
+        d_entry = {"bound": "hbm", "kernel": "decoder_layer_cluster_f32",
+                   "launch": f"one decoder layer (self-attention, MSDA cross-attention, FFN, next q/k/v), N={cfg.num_queries}, "
+                             f"{d_n} launches per forward; latency-bound: 3 L2 barriers + 4 dependent phases per launch",
+                   "achieved": round(d_alg / (d_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(d_alg / (d_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": d_alg,
+                   "avg_launch_us": round(d_us, 2), "traffic": None}
+        dp, dp_src = newest_pmc("r*_dec_layer_pmc.json", "decoder_layer_cluster_f32")
+        if dp:
+            d_entry.update(traffic=dp.get("hbm_bytes_per_launch"), l2_hit=dp.get("l2_hit"), traffic_source=dp_src)
+        result["roofline_kernels"].append(d_entry)
+    result["config"]["fast_path"] = {"strict": bool(_ops.STRICT_FAST_PATH), "fallbacks": dict(_ops.FALLBACKS)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncores = usable_cores()
         torch.set_num_threads(ncores)

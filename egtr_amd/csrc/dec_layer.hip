@@ -76,8 +76,11 @@ __device__ __forceinline__ unsigned barrier_base(const unsigned* ctr) {
   asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
   return v / kArrivals * kArrivals;
 }
+template <bool WAIT_ACK = true>
 __device__ __forceinline__ void barrier_arrive(unsigned* ctr, int lane) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's partial stores have reached the L2
+  // this wave's partial stores have reached the L2 -- or (tagged mode) are merely on their way: the readers then verify the
+  // launch tag of what they load and re-load the rare chunk that has not landed yet
+  if constexpr (WAIT_ACK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) {
     const unsigned one = 1u;
     asm volatile("global_atomic_add %0, %1, off" ::"v"(ctr), "v"(one) : "memory");
@@ -258,14 +261,13 @@ __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of th
     wait_loads(p1[0], p1[1], p1[2], p1[3]);
     wait_loads(p1[4], p1[5], p1[6], p1[7]);
     if constexpr (!TAGGED) break;
+    // one word per 16-byte chunk: the four words of a chunk are neighbours in ONE 128-byte line written by one store
+    // instruction of one wave
     unsigned bad = 0;
 #pragma unroll
     for (int hh = 0; hh < kH; ++hh) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bad |= (__float_as_uint(p0[hh][i]) ^ tag) & 3u;
-        bad |= (__float_as_uint(p1[hh][i]) ^ tag) & 3u;
-      }
+      bad |= (__float_as_uint(p0[hh][0]) ^ tag) & 3u;
+      bad |= (__float_as_uint(p1[hh][0]) ^ tag) & 3u;
     }
     if (__builtin_amdgcn_readfirstlane(__any((int)bad)) == 0) break;   // the whole wave retries together
     if (++spins > kMaxSpins) {
@@ -273,16 +275,6 @@ __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of th
       break;
     }
     __builtin_amdgcn_s_sleep(1);
-  }
-  if constexpr (TAGGED) {
-#pragma unroll
-    for (int hh = 0; hh < kH; ++hh) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        p0[hh][i] = __uint_as_float(__float_as_uint(p0[hh][i]) & ~3u);
-        p1[hh][i] = __uint_as_float(__float_as_uint(p1[hh][i]) & ~3u);
-      }
-    }
   }
   f32x4 y0 = p0[0], y1 = p1[0];
 #pragma unroll
@@ -419,7 +411,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     const float* pr = P.pos + (size_t)(grow % P.pos_rows) * 256;
     const f32x4 pos0 = ld4(pr + 4 * j), pos1 = ld4(pr + 128 + 4 * j);
     RowParams rp = load_params(P.b_attn_out, P.ln1_gamma, P.ln1_beta, j);
-    if (!TAGGED && !have_base) {   // the barrier counter's value as the launch starts (scalar load: overlaps the vector loads above)
+    if (!have_base) {   // the barrier counter's value as the launch starts (scalar load: overlaps the vector loads above)
       bar_base = barrier_base(ctr);
       have_base = true;
     }
@@ -513,11 +505,11 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       store_partial(part1 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi, tag);
     }
     STAMP(4);
-    if constexpr (!TAGGED) barrier_arrive(ctr, lane);
+    barrier_arrive<!TAGGED>(ctr, lane);
     f32x4 w_ol[16], w_c[8];   // phase 2's streams land while the cluster gathers: offsets / logits (K quarter), cross projection
     w_issue<16, true>(w_ol, reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64, lane_bytes);
     w_issue<8, true>(w_c, reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
-    if constexpr (!TAGGED) barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
+    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(5);
     // ================================================================= phase 2: LayerNorm 1, cross-attention of head h ==
     f32x4 x1a, x1b;
@@ -624,7 +616,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       store_partial(part2 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi, tag);
     }
     STAMP(10);
-    if constexpr (!TAGGED) barrier_arrive(ctr, lane);
+    barrier_arrive<!TAGGED>(ctr, lane);
     // fc1's stream (tile 2h + (wave & 1), K half wave >> 1) into AGPRs -- reused for the next layer's q / k / v -- and fc2's
     // (tile = wave, this head's 32 k groups) into VGPRs: both land while the cluster gathers and LayerNorm 2 runs
     f32x4 w_f[32];
@@ -638,7 +630,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
 #ifdef EGTR_DEC_FC2_EARLY
     w_issue<32>(w_g, reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64, lane_bytes);
 #endif
-    if constexpr (!TAGGED) barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
+    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(11);
 
     // ================================================================= phase 3: LayerNorm 2, 128 hidden units ==========
@@ -691,13 +683,13 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       store_partial(part3 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi, tag);
     }
     STAMP(15);
-    if constexpr (!TAGGED) barrier_arrive(ctr, lane);
+    barrier_arrive<!TAGGED>(ctr, lane);
 #ifndef EGTR_DEC_FC2_EARLY
     if (P.q_next != nullptr)
       w_issue<32, true>(w_f, reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
                         lane_bytes);
 #endif
-    if constexpr (!TAGGED) barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
+    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(16);
 
     // ================================================================= phase 4: LayerNorm 3, next layer's q / k / v ====

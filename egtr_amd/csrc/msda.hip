@@ -250,12 +250,25 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
     const uint16_t* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const void* __restrict__ loc, const void* __restrict__ attn, uint16_t* __restrict__ out, int nq_total,
     int Lq, int S, int L, int P, int nblk, const uint16_t* __restrict__ ref, int ld_off, int ld_logit,
-    const unsigned char* __restrict__ keep) {
+    const unsigned char* __restrict__ keep, const unsigned* __restrict__ keep_bits) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * 2 * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * 2 * kWaveEntries];
+  __shared__ unsigned s_bits[FUSED ? kMaxBitWords : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = xcd_remap(blockIdx.x, nblk);
   const int qpair = (blk * kWaves + wave) * 2;
+  // padding mask as ONE BIT per token, the image of the workgroup's first query staged in LDS (2.8 KB at 800x1333): the
+  // byte-mask form costs eight scattered single-byte loads per lane and query pair -- 40 % of this kernel's L1 accesses
+  // (866 vs 512 per query, profiles/r05_msda_bf16_pmc.json before the change) in a kernel that runs at the L1's rate
+  const int nwords = (S + 31) >> 5;
+  int b0 = 0;
+  bool bits_staged = false;
+  if (FUSED && keep_bits != nullptr && nwords <= kMaxBitWords) {
+    b0 = min(blk * kWaves * 2, nq_total - 1) / Lq;
+    for (int i = threadIdx.x; i < nwords; i += kWaves * 64) s_bits[i] = keep_bits[(size_t)b0 * nwords + i];
+    __syncthreads();
+    bits_staged = true;
+  }
   if (qpair >= nq_total) return;
   LevelGeom G;
   load_geom(shapes, lsi, L, G);
@@ -274,24 +287,30 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
       const unsigned lg = reinterpret_cast<const unsigned*>(reinterpret_cast<const uint16_t*>(attn) + (size_t)q * ld_logit)[lane];
       const unsigned rp = reinterpret_cast<const unsigned*>(ref + ((size_t)q * L + lvl) * 2)[0];
       const float rx = bf16_lo(rp), ry = bf16_hi(rp);
-      const float fw = (float)SEL_W(G, lvl), fh = (float)SEL_H(G, lvl);
-      lc = make_float4(rx + bf16_lo(o.x) / fw, ry + bf16_hi(o.x) / fh, rx + bf16_lo(o.y) / fw, ry + bf16_hi(o.y) / fh);
+      // (reciprocal multiplies and the hardware exponential: this kernel is VALU-bound and its operands are bf16 -- a
+      // 1-ulp fp32 difference against the division / expf of the fp32 kernel is three orders below their rounding)
+      const float iw = __frcp_rn((float)SEL_W(G, lvl)), ih = __frcp_rn((float)SEL_H(G, lvl));
+      lc = make_float4(rx + bf16_lo(o.x) * iw, ry + bf16_hi(o.x) * ih, rx + bf16_lo(o.y) * iw, ry + bf16_hi(o.y) * ih);
       aw = make_float2(bf16_lo(lg), bf16_hi(lg));
       float m = fmaxf(aw.x, aw.y);
       m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
       m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
       m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, false)));
-      const float e0 = expf(aw.x - m), e1 = expf(aw.y - m);
+      const float e0 = __expf(aw.x - m), e1 = __expf(aw.y - m);
       float sum = e0 + e1;
       sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
       sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
       sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
-      aw = make_float2(e0 / sum, e1 / sum);
+      const float inv = __frcp_rn(sum);
+      aw = make_float2(e0 * inv, e1 * inv);
     } else {
       lc = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(loc) + (size_t)q * 256)[lane];
       aw = reinterpret_cast<const float2*>(reinterpret_cast<const float*>(attn) + (size_t)q * 128)[lane];
     }
-    const unsigned char* kp = (FUSED && keep != nullptr) ? keep + (size_t)(q / Lq) * S : nullptr;
+    const bool use_bits = FUSED && keep_bits != nullptr;
+    const unsigned char* kp = (FUSED && keep != nullptr && !use_bits) ? keep + (size_t)(q / Lq) * S : nullptr;
+    const bool in_lds = bits_staged && q / Lq == b0;
+    const unsigned* kb = use_bits ? keep_bits + (size_t)(q / Lq) * nwords : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int s = s0 + j;
@@ -300,7 +319,20 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
                                                 SEL_S(G, lvl), head_s);
       const float a = j ? aw.y : aw.x;
       bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
-      if (kp != nullptr) {
+      if (use_bits) {
+        const int p0 = g.off[0] >> 9, p1 = g.off[1] >> 9, p2 = g.off[2] >> 9, p3 = g.off[3] >> 9;
+        if (in_lds) {
+          k0 = k0 && ((s_bits[p0 >> 5] >> (p0 & 31)) & 1u);
+          k1 = k1 && ((s_bits[p1 >> 5] >> (p1 & 31)) & 1u);
+          k2 = k2 && ((s_bits[p2 >> 5] >> (p2 & 31)) & 1u);
+          k3 = k3 && ((s_bits[p3 >> 5] >> (p3 & 31)) & 1u);
+        } else {
+          k0 = k0 && ((kb[p0 >> 5] >> (p0 & 31)) & 1u);
+          k1 = k1 && ((kb[p1 >> 5] >> (p1 & 31)) & 1u);
+          k2 = k2 && ((kb[p2 >> 5] >> (p2 & 31)) & 1u);
+          k3 = k3 && ((kb[p3 >> 5] >> (p3 & 31)) & 1u);
+        }
+      } else if (kp != nullptr) {
         k0 = k0 && kp[g.off[0] >> 9];
         k1 = k1 && kp[g.off[1] >> 9];
         k2 = k2 && kp[g.off[2] >> 9];
@@ -319,32 +351,54 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
   const bool live = q < nq_total;
   const int qc = live ? q : nq_total - 1;
   const int b = qc / Lq;
-  const char* vlane = reinterpret_cast<const char*>(value) + (size_t)b * S * 512 + (lane & 3) * 16;
+  // The loop below is VALU-bound as much as L1-bound (round 5: ~95 VALU instructions per sample and lane against 16 loads),
+  // so the arithmetic is written for the packed pipe -- a uint of two bf16 channels is unpacked into a float2 and multiplied
+  // by the broadcast corner weight with ONE v_pk_fma_f32 -- and the addresses are a wave-uniform base + a 32-bit lane offset
+  // (one v_add_u32 per load instead of a 64-bit add; the launcher checks B * S * 512 < 2^32).
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const char* vbase = reinterpret_cast<const char*>(value);
+  const unsigned lane_off = (unsigned)b * (unsigned)S * 512u + (lane & 3) * 16;
   const int4* ro = my_off + half * kWaveEntries + head * kHeadStride;
   const float4* rw = my_w + half * kWaveEntries + head * kHeadStride;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int s = 0; s < 16; ++s) {
-    const int4 o = ro[s];
-    const float4 w = rw[s];
-    const uint4 v0 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.x);
-    const uint4 v1 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.y);
-    const uint4 v2 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.z);
-    const uint4 v3 = *reinterpret_cast<const uint4*>(vlane + (unsigned)o.w);
-    const unsigned a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
-    const unsigned a2[4] = {v2.x, v2.y, v2.z, v2.w}, a3[4] = {v3.x, v3.y, v3.z, v3.w};
+  f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  // kBatch samples = 4 kBatch corner loads are requested before the first is consumed (the compiler otherwise waits for each
+  // sample's four loads right behind their issue)
+  constexpr int kBatch = 4;   // 16 loads in flight per lane: the kernel is short of memory-level parallelism (16 waves per CU)
+#pragma unroll 1
+  for (int s = 0; s < 16; s += kBatch) {
+    int4 o[kBatch];
+    float4 w[kBatch];
+    uint4 v[kBatch][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      acc[2 * k] += w.x * bf16_lo(a0[k]) + w.y * bf16_lo(a1[k]) + w.z * bf16_lo(a2[k]) + w.w * bf16_lo(a3[k]);
-      acc[2 * k + 1] += w.x * bf16_hi(a0[k]) + w.y * bf16_hi(a1[k]) + w.z * bf16_hi(a2[k]) + w.w * bf16_hi(a3[k]);
+    for (int u = 0; u < kBatch; ++u) {
+      o[u] = ro[s + u];
+      w[u] = rw[s + u];
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      v[u][0] = *reinterpret_cast<const uint4*>(vbase + (lane_off + (unsigned)o[u].x));
+      v[u][1] = *reinterpret_cast<const uint4*>(vbase + (lane_off + (unsigned)o[u].y));
+      v[u][2] = *reinterpret_cast<const uint4*>(vbase + (lane_off + (unsigned)o[u].z));
+      v[u][3] = *reinterpret_cast<const uint4*>(vbase + (lane_off + (unsigned)o[u].w));
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const float wc[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const unsigned a[4] = {v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w};
+        const f32x2 wv = {wc[c], wc[c]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = __builtin_elementwise_fma(f32x2{bf16_lo(a[k]), bf16_hi(a[k])}, wv, acc[k]);
+      }
     }
   }
   if (live) {
     uint4 r;
-    r.x = pack_bf16(acc[0], acc[1]);
-    r.y = pack_bf16(acc[2], acc[3]);
-    r.z = pack_bf16(acc[4], acc[5]);
-    r.w = pack_bf16(acc[6], acc[7]);
+    r.x = pack_bf16(acc[0][0], acc[0][1]);
+    r.y = pack_bf16(acc[1][0], acc[1][1]);
+    r.z = pack_bf16(acc[2][0], acc[2][1]);
+    r.w = pack_bf16(acc[3][0], acc[3][1]);
     reinterpret_cast<uint4*>(out + (size_t)q * 256)[lane & 31] = r;
   }
 }
@@ -722,7 +776,8 @@ extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* valu
                                       int channels, int num_levels, int num_query, int num_point, uint16_t* out) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !out) return EGTR_E_ARG;
   if (batch <= 0 || spatial_size <= 0 || num_query <= 0) return EGTR_E_ARG;
-  if (!fast_shape(num_heads, channels, num_levels, num_point) || (long long)spatial_size * 512 >= (1ll << 31))
+  if (!fast_shape(num_heads, channels, num_levels, num_point) || (long long)spatial_size * 512 >= (1ll << 31) ||
+      (long long)(batch + 1) * spatial_size * 512 >= (1ll << 32))
     return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long nq = (long long)batch * num_query;
@@ -730,7 +785,7 @@ extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* valu
   hipLaunchKernelGGL(msda_fwd_q32_bf16<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                      level_start_index, (const void*)sampling_loc, (const void*)attn_weight, out, (int)nq, num_query,
                      spatial_size, num_levels, num_point, nblk, (const uint16_t*)nullptr, 256, 128,
-                     (const unsigned char*)nullptr);
+                     (const unsigned char*)nullptr, (const unsigned*)nullptr);
   return egtr_check_launch();
 }
 
@@ -739,7 +794,7 @@ extern "C" int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t
                                             const uint16_t* attn_logits, const uint16_t* reference_points, int batch,
                                             int spatial_size, int num_heads, int channels, int num_levels,
                                             int num_query, int num_point, uint16_t* out, int ld_offsets, int ld_logits,
-                                            const unsigned char* keep_mask) {
+                                            const unsigned char* keep_mask, const unsigned* keep_bits) {
   if (!value || !spatial_shapes || !level_start_index || !sampling_offsets || !attn_logits || !reference_points ||
       !out)
     return EGTR_E_ARG;
@@ -747,13 +802,14 @@ extern "C" int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t
   if (ld_offsets < 256 || ld_logits < 128 || (ld_offsets & 3) || (ld_logits & 1)) return EGTR_E_ARG;
   const long long nq = (long long)batch * num_query;
   if (!fast_shape(num_heads, channels, num_levels, num_point) || (num_point & 1) ||
-      (long long)spatial_size * 512 >= (1ll << 31) || nq >= (1ll << 27))
+      (long long)spatial_size * 512 >= (1ll << 31) || nq >= (1ll << 27) ||
+      (long long)(batch + 1) * spatial_size * 512 >= (1ll << 32))   // (32-bit lane offsets into the value tensor)
     return EGTR_E_UNSUPPORTED;
   const int nblk = (int)((nq + 2 * kWaves - 1) / (2 * kWaves));
   hipLaunchKernelGGL(msda_fwd_q32_bf16<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
                      spatial_shapes, level_start_index, (const void*)sampling_offsets, (const void*)attn_logits, out,
                      (int)nq, num_query, spatial_size, num_levels, num_point, nblk, reference_points, ld_offsets,
-                     ld_logits, keep_mask);
+                     ld_logits, keep_mask, keep_bits);
   return egtr_check_launch();
 }
 

@@ -90,19 +90,22 @@ def supported(decoder, hidden_states, position_embeddings, reference_points, enc
     """The configuration the kernel is written for: EGTR's decoder (d_model 256, 8 heads, 4 levels x 4 points, 1024 hidden
     units, ReLU, no box refinement, 2-d reference points) at inference in fp32."""
     import torch.nn.functional as F
-    if not (ENABLED and torch.is_tensor(hidden_states) and hidden_states.is_cuda and hidden_states.dtype == torch.float32
-            and not torch.is_grad_enabled() and encoder_hidden_states is not None and position_embeddings is not None
-            and not output_attentions and decoder.bbox_embed is None and reference_points.shape[-1] == 2
-            and hidden_states.shape[-1] == 256 and hidden_states.shape[1] <= MAX_QUERIES):
+    from . import ops
+    eligible = (ENABLED and torch.is_tensor(hidden_states) and hidden_states.is_cuda and hidden_states.dtype == torch.float32
+                and not torch.is_grad_enabled() and encoder_hidden_states is not None and position_embeddings is not None
+                and not output_attentions and decoder.bbox_embed is None and reference_points.shape[-1] == 2)
+    if not eligible:   # training, bf16, box refinement, attention maps requested, the switch: other paths by design
         return False
+    ok = hidden_states.shape[-1] == 256 and hidden_states.shape[1] <= MAX_QUERIES
     for l in decoder.layers:
         ca, sa = l.encoder_attn, l.self_attn
-        if not (l.activation_fn is F.relu and sa.num_heads == 8 and sa.embed_dim == 256 and ca.n_heads == 8
-                and ca.n_levels == 4 and ca.n_points == 4 and ca.d_model == 256 and l.fc1.out_features == 1024
-                and l.self_attn_layer_norm.eps == l.encoder_attn_layer_norm.eps == l.final_layer_norm.eps
-                and sa.q_proj.bias is not None and l.fc1.bias is not None):
-            return False
-    return True
+        ok = ok and (l.activation_fn is F.relu and sa.num_heads == 8 and sa.embed_dim == 256 and ca.n_heads == 8
+                     and ca.n_levels == 4 and ca.n_points == 4 and ca.d_model == 256 and l.fc1.out_features == 1024
+                     and l.self_attn_layer_norm.eps == l.encoder_attn_layer_norm.eps == l.final_layer_norm.eps
+                     and sa.q_proj.bias is not None and l.fc1.bias is not None)
+    return ops._gate("decoder_cluster", True, ok,
+                     lambda: f"{hidden_states.shape[1]} queries x {hidden_states.shape[-1]} channels: the cluster kernel serves "
+                             "d_model 256, 8 heads, 4 x 4 sampling points, 1024 hidden units, ReLU, <= 320 queries")
 
 
 _WORKSPACES = {}   # (device index, stream handle, shape key) -> persistent buffers of eager launches

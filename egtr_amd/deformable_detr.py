@@ -1712,50 +1712,47 @@ class DeformableDetrLoss(nn.Module):
         self.losses = losses
         self.focal_alpha = focal_alpha
 
+    # ---- the three terms on ANY device (output sets the fused launch does not take: CPU tensors, the two-stage variant's
+    # per-token proposal set), written over the list of matched (image, query, target) triples.  Same values as dd:2683-2800.
+    @staticmethod
+    def _matched_pairs(targets, indices, device):
+        """(image index, query index, target class, target box) of every assignment, images concatenated."""
+        counts = [int(q.numel()) for q, _ in indices]
+        image = torch.repeat_interleave(torch.arange(len(indices), device=device),
+                                        torch.tensor(counts, device=device)) if sum(counts) else \
+            torch.zeros(0, dtype=torch.int64, device=device)
+        query = torch.cat([q.to(device) for q, _ in indices]) if indices else image
+        cls = torch.cat([t["class_labels"][j] for t, (_, j) in zip(targets, indices)]).to(device)
+        box = torch.cat([t["boxes"][j] for t, (_, j) in zip(targets, indices)]).to(device)
+        return image, query, cls, box
+
     def loss_labels(self, outputs, targets, indices, num_boxes, log=True):
+        """Sigmoid focal loss against one-hot targets that are zero except at (image, matched query, its class): summed over
+        classes, averaged over queries, times the query count, over num_boxes (dd:2683-2716) = the plain sum / num_boxes."""
         if "logits" not in outputs:
             raise ValueError("No logits were found in the outputs")
-        source_logits = outputs["logits"]
-        idx = self._get_source_permutation_idx(indices)
-        target_classes_o = torch.cat([t["class_labels"][J] for t, (_, J) in zip(targets, indices)])
-        target_classes = torch.full(source_logits.shape[:2], self.num_classes, dtype=torch.int64,
-                                    device=source_logits.device)
-        target_classes[idx] = target_classes_o.to(source_logits.device)
-        onehot = torch.zeros([source_logits.shape[0], source_logits.shape[1], source_logits.shape[2] + 1],
-                             dtype=source_logits.dtype, layout=source_logits.layout, device=source_logits.device)
-        onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
-        loss_ce = sigmoid_focal_loss(source_logits, onehot[:, :, :-1], num_boxes, alpha=self.focal_alpha,
-                                     gamma=2) * source_logits.shape[1]
-        return {"loss_ce": loss_ce}
+        logits = outputs["logits"]
+        image, query, cls, _ = self._matched_pairs(targets, indices, logits.device)
+        onehot = torch.zeros_like(logits)
+        onehot[image, query, cls] = 1
+        return {"loss_ce": sigmoid_focal_loss(logits, onehot, num_boxes, alpha=self.focal_alpha, gamma=2) * logits.shape[1]}
 
     @torch.no_grad()
     def loss_cardinality(self, outputs, targets, indices, num_boxes):
+        """|#(queries whose arg-max is not the last class) - #targets|, mean over the batch (dd:2718-2732; logging only)."""
         logits = outputs["logits"]
-        target_lengths = torch.as_tensor([len(v["class_labels"]) for v in targets], device=logits.device)
-        card_pred = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
-        return {"cardinality_error": F.l1_loss(card_pred.float(), target_lengths.float())}
+        want = torch.tensor([float(len(t["class_labels"])) for t in targets], device=logits.device)
+        got = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1).float()
+        return {"cardinality_error": (got - want).abs().mean()}
 
     def loss_boxes(self, outputs, targets, indices, num_boxes):
+        """L1 and 1 - GIoU between every matched query box and its target box, summed / num_boxes (dd:2734-2767)."""
         if "pred_boxes" not in outputs:
             raise ValueError("No predicted boxes found in outputs")
-        idx = self._get_source_permutation_idx(indices)
-        source_boxes = outputs["pred_boxes"][idx]
-        target_boxes = torch.cat([t["boxes"][i] for t, (_, i) in zip(targets, indices)], dim=0)
-        losses = {"loss_bbox": F.l1_loss(source_boxes, target_boxes, reduction="none").sum() / num_boxes}
-        loss_giou = 1 - torch.diag(generalized_box_iou(center_to_corners_format(source_boxes),
-                                                       center_to_corners_format(target_boxes)))
-        losses["loss_giou"] = loss_giou.sum() / num_boxes
-        return losses
-
-    def _get_source_permutation_idx(self, indices):
-        batch_idx = torch.cat([torch.full_like(source, i) for i, (source, _) in enumerate(indices)])
-        source_idx = torch.cat([source for (source, _) in indices])
-        return batch_idx, source_idx
-
-    def _get_target_permutation_idx(self, indices):
-        batch_idx = torch.cat([torch.full_like(target, i) for i, (_, target) in enumerate(indices)])
-        target_idx = torch.cat([target for (_, target) in indices])
-        return batch_idx, target_idx
+        image, query, _, want = self._matched_pairs(targets, indices, outputs["pred_boxes"].device)
+        got = outputs["pred_boxes"][image, query]
+        giou = generalized_box_iou(center_to_corners_format(got), center_to_corners_format(want)).diagonal()
+        return {"loss_bbox": (got - want).abs().sum() / num_boxes, "loss_giou": (1 - giou).sum() / num_boxes}
 
     def get_loss(self, loss, outputs, targets, indices, num_boxes):
         loss_map = {"labels": self.loss_labels, "cardinality": self.loss_cardinality, "boxes": self.loss_boxes}
@@ -1793,9 +1790,7 @@ class DeformableDetrLoss(nn.Module):
             for i, auxiliary_outputs in enumerate(outputs["auxiliary_outputs"]):
                 losses.update(self._set_losses(auxiliary_outputs, targets, num_boxes, f"_{i}", packed))
         if "enc_outputs" in outputs:   # two-stage proposals: class-agnostic targets (dd:2847-2858)
-            bin_targets = copy.deepcopy(targets)
-            for bt in bin_targets:
-                bt["class_labels"] = torch.zeros_like(bt["class_labels"])
+            bin_targets = [dict(t, class_labels=torch.zeros_like(t["class_labels"])) for t in targets]
             losses.update(self._set_losses(outputs["enc_outputs"], bin_targets, num_boxes, "_enc", [None]))
         return losses
 

@@ -159,15 +159,23 @@ class _MultiScaleDeformableAttention:
 
         off2, ld_off = rows(sampling_offsets, M * L * P * 2, "sampling_offsets")
         log2, ld_log = rows(attn_logits, M * L * P, "attn_logits")
-        km = None
+        kbits = None
         if keep_mask is not None:
-            km = keep_mask.reshape(B, S).contiguous()
-            km = km.view(torch.uint8) if km.dtype == torch.bool else km.to(torch.uint8)
+            # one bit per token: the copy the level-geometry kernel left on the mask, or packed here ONCE per mask tensor (the
+            # six encoder layers of a forward share it) -- the kernel keeps the bits of its image in LDS
+            kbits = getattr(keep_mask, "_egtr_bits", None)
+            if kbits is None or kbits.dtype != torch.int32 or tuple(kbits.shape) != (B, (S + 31) // 32) or not kbits.is_cuda:
+                from .decoder_fused import _keep_bits
+                kbits = _keep_bits(keep_mask, B, S)
+                try:
+                    keep_mask._egtr_bits = kbits
+                except Exception:   # pragma: no cover - a tensor subclass without attributes
+                    pass
         out = torch.empty(B, Lq, M * D, dtype=bf, device=value.device)
         st = lib.egtr_msda_forward_fused_bf16(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
                                               level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),
-                                              ref.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(), ld_off, ld_log,
-                                              km.data_ptr() if km is not None else None)
+                                              ref.data_ptr(), B, S, M, D, L, Lq, P, out.data_ptr(), ld_off, ld_log, None,
+                                              kbits.data_ptr() if kbits is not None else None)
         _lib.check(st, "ms_deform_attn_forward_fused_bf16")
         return out
 

@@ -682,12 +682,14 @@ class DecoderValueProjTrainFunction(Function):
 
 
 def decoder_values_train_supported(enc, attention_mask, layers):
-    return (ENCODER_TRAIN_FUSED and GEMM_SPLIT_BF16 and torch.is_grad_enabled() and torch.is_tensor(enc) and enc.is_cuda
-            and enc.dtype == torch.float32 and enc.dim() == 3 and enc.shape[-1] == 256
-            and enc.shape[0] * enc.shape[1] > SKINNY_MAX_ROWS
-            and all(tuple(l.encoder_attn.value_proj.weight.shape) == (256, 256) and l.encoder_attn.value_proj.bias is not None
-                    and l.encoder_attn.value_proj.weight.dtype == torch.float32 for l in layers)
-            and (attention_mask is None or tuple(attention_mask.shape) == tuple(enc.shape[:2])))
+    eligible = (ENCODER_TRAIN_FUSED and GEMM_SPLIT_BF16 and torch.is_grad_enabled() and torch.is_tensor(enc) and enc.is_cuda
+                and enc.dtype == torch.float32 and enc.dim() == 3 and enc.shape[0] * enc.shape[1] > SKINNY_MAX_ROWS)
+    ok = (eligible and enc.shape[-1] == 256
+          and all(tuple(l.encoder_attn.value_proj.weight.shape) == (256, 256) and l.encoder_attn.value_proj.bias is not None
+                  and l.encoder_attn.value_proj.weight.dtype == torch.float32 for l in layers)
+          and (attention_mask is None or tuple(attention_mask.shape) == tuple(enc.shape[:2])))
+    return _gate("decoder_values_train", eligible, ok, lambda: f"encoder states {tuple(enc.shape)}: 256 channels, 256 -> 256 value "
+                                                               "projections with biases served")
 
 
 def decoder_values_train(enc, attention_mask, layers):
@@ -738,15 +740,20 @@ def encoder_layer_train_supported(layer, x, pos, ref, attention_mask, output_att
     8 heads x 4 levels x 4 points, 2-d reference points, ReLU FFN with a hidden width that tiles (multiple of 128),
     activation_dropout 0 (the reference default), no attention maps requested."""
     sa = layer.self_attn
-    return (ENCODER_TRAIN_FUSED and GEMM_SPLIT_BF16 and torch.is_grad_enabled() and layer.training and not output_attentions
-            and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[-1] == 256
-            and x.shape[0] * x.shape[1] > SKINNY_MAX_ROWS and pos is not None and pos.dtype == torch.float32
-            and tuple(pos.shape) == tuple(x.shape) and ref is not None and ref.dim() == 4 and ref.shape[-1] == 2
-            and sa.n_heads == 8 and sa.n_levels == 4 and sa.n_points == 4 and ref.shape[2] == 4
-            and layer.activation_fn is torch.nn.functional.relu and layer.activation_dropout == 0.0
-            and layer.fc1.weight.shape[0] % 128 == 0 and tuple(layer.fc2.weight.shape) == (256, layer.fc1.weight.shape[0])
-            and layer.fc1.weight.dtype == torch.float32 and 0.0 <= layer.dropout < 1.0
-            and (attention_mask is None or tuple(attention_mask.shape) == tuple(x.shape[:2])))
+    eligible = (ENCODER_TRAIN_FUSED and GEMM_SPLIT_BF16 and torch.is_grad_enabled() and layer.training and not output_attentions
+                and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3
+                and x.shape[0] * x.shape[1] > SKINNY_MAX_ROWS)
+    ok = (eligible and x.shape[-1] == 256 and pos is not None and pos.dtype == torch.float32
+          and tuple(pos.shape) == tuple(x.shape) and ref is not None and ref.dim() == 4 and ref.shape[-1] == 2
+          and sa.n_heads == 8 and sa.n_levels == 4 and sa.n_points == 4 and ref.shape[2] == 4
+          and layer.activation_fn is torch.nn.functional.relu and layer.activation_dropout == 0.0
+          and layer.fc1.weight.shape[0] % 128 == 0 and tuple(layer.fc2.weight.shape) == (256, layer.fc1.weight.shape[0])
+          and layer.fc1.weight.dtype == torch.float32 and 0.0 <= layer.dropout < 1.0
+          and (attention_mask is None or tuple(attention_mask.shape) == tuple(x.shape[:2])))
+    return _gate("encoder_layer_train", eligible, ok,
+                 lambda: f"states {tuple(x.shape)}, {sa.n_heads} heads x {sa.n_levels} levels x {sa.n_points} points, fc1 "
+                         f"{tuple(layer.fc1.weight.shape)}: the training node serves d_model 256, 8 x 4 x 4, ReLU, a hidden width "
+                         "that is a multiple of 128, activation_dropout 0, 2-d reference points")
 
 
 def encoder_layer_train(layer, x, attention_mask, pos, ref, spatial_shapes, level_start_index, masks=None):
@@ -812,6 +819,14 @@ def note_fallback(name, why=""):
         import warnings
         warnings.warn(f"egtr_amd: leaving the HIP fast path '{name}' ({why}); counted in egtr_amd.ops.FALLBACKS",
                       RuntimeWarning, stacklevel=3)
+
+
+def _gate(name, eligible, ok, why):
+    """A fast-path predicate's verdict, announced when it turns a call away that the path exists for (``eligible``: right
+    device, dtype, mode and size class -- an explicit EGTR_* switch or a CPU / bf16 / tiny call is not a fall-off)."""
+    if eligible and not ok:
+        note_fallback(name, why() if callable(why) else why)
+    return bool(ok)
 
 
 def inference_fast_path(x):
@@ -1135,8 +1150,10 @@ def linear_split_bf16_wgrad(g, x):
 
 def gemm_split_supported(x, N, K):
     rows = x.numel() // x.shape[-1]
-    return (GEMM_SPLIT_BF16 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
-            and rows >= GEMM_SPLIT_MIN_ROWS and K % 32 == 0 and N % 128 == 0)
+    eligible = (GEMM_SPLIT_BF16 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+                and rows >= GEMM_SPLIT_MIN_ROWS)
+    return _gate("gemm_split", eligible, eligible and K % 32 == 0 and N % 128 == 0,
+                 lambda: f"{rows} x {K} -> {N}: K must be a multiple of 32 and N of 128 (vendor GEMM instead)")
 
 
 def linear_split_bf16(x, w_tiled, bias, N, relu=False, out=None):
@@ -1258,10 +1275,13 @@ def ffn_fused_supported(x, fc1, fc2, ln):
     """The encoder layer's feed-forward block as one launch (csrc/ffn_x6.hip): fp32 inference, token-sized row counts,
     d_model = 256, hidden width a multiple of 64."""
     rows = x.numel() // x.shape[-1]
-    return (FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
-            and x.shape[-1] == 256 and tuple(fc1.weight.shape)[1] == 256 and fc1.weight.shape[0] % 64 == 0
-            and tuple(fc2.weight.shape) == (256, fc1.weight.shape[0]) and fc1.bias is not None and fc2.bias is not None
-            and ln.weight.shape[0] == 256 and fc1.weight.dtype == torch.float32)
+    eligible = FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
+    ok = (eligible and x.shape[-1] == 256 and tuple(fc1.weight.shape)[1] == 256 and fc1.weight.shape[0] % 64 == 0
+          and tuple(fc2.weight.shape) == (256, fc1.weight.shape[0]) and fc1.bias is not None and fc2.bias is not None
+          and ln.weight.shape[0] == 256 and fc1.weight.dtype == torch.float32)
+    return _gate("ffn_fused", eligible, ok,
+                 lambda: f"d_model {x.shape[-1]}, fc1 {tuple(fc1.weight.shape)}: the row-panel kernel serves d_model 256, "
+                         "a hidden width that is a multiple of 64, biases present")
 
 
 def ffn_fused(x, fc1, fc2, ln=None, pos=None):
@@ -1353,15 +1373,16 @@ def encoder_tail_fused(context, hidden, out_proj, ln1, fc1, fc2, ln2, pos=None):
 
 def proj_ln_fused_supported(x, lin, ln):
     rows = x.numel() // x.shape[-1]
-    return (FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
-            and x.shape[-1] == 256 and tuple(lin.weight.shape) == (256, 256) and lin.bias is not None
-            and ln.weight.shape[0] == 256 and lin.weight.dtype == torch.float32)
+    eligible = FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
+    ok = (eligible and x.shape[-1] == 256 and tuple(lin.weight.shape) == (256, 256) and lin.bias is not None
+          and ln.weight.shape[0] == 256 and lin.weight.dtype == torch.float32)
+    return _gate("proj_ln_fused", eligible, ok, lambda: f"projection {tuple(lin.weight.shape)}: the kernel serves 256 -> 256 with a bias")
 
 
 def proj_multi_fused_supported(x):
     rows = x.numel() // x.shape[-1]
-    return (FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
-            and x.shape[-1] == 256 and x.dtype == torch.float32)
+    eligible = FFN_FUSED and GEMM_SPLIT_BF16 and inference_fast_path(x) and rows >= GEMM_SPLIT_MIN_ROWS
+    return _gate("proj_multi_fused", eligible, eligible and x.shape[-1] == 256, lambda: f"d_model {x.shape[-1]} (256 served)")
 
 
 def proj_ln_fused(x, lin, residual=None, ln=None, pos=None):

@@ -143,13 +143,15 @@ int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* value, const in
 
 /* bf16 forward with the prologue fused in (see egtr_msda_forward_fused_vbias_f32): sampling_offsets / attn_logits /
  * reference_points are raw bf16 tensors ([B,Lq,M,L,P,2] / [B,Lq,M,L*P] with row strides ld_offsets / ld_logits elements,
- * [B,Lq,L,2]); softmax and sampling locations are formed in fp32 inside the kernel; keep_mask (optional, [B,S] bytes). */
+ * [B,Lq,L,2]); softmax and sampling locations are formed in fp32 inside the kernel; padded tokens are skipped: keep_mask
+ * (optional, [B,S] bytes, 0 = padded) or -- preferred, it wins when both are given -- keep_bits ([B, ceil(S / 32)] words, one
+ * bit per token, staged in LDS by the kernel for S <= 32768). */
 int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,
                                  const int64_t* level_start_index, const uint16_t* sampling_offsets,
                                  const uint16_t* attn_logits, const uint16_t* reference_points, int batch,
                                  int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                  int num_point, uint16_t* out, int ld_offsets, int ld_logits,
-                                 const unsigned char* keep_mask);
+                                 const unsigned char* keep_mask, const unsigned* keep_bits);
 
 /* ---- decoder multi-head self-attention core ------------------------------------------------------------- */
 /* q (already scaled by D^-1/2, dd:1166), k, v: [B, N, M*D] as produced by the q/k/v projections.
