@@ -152,3 +152,41 @@ def test_cluster_decoder_rejects_what_it_does_not_serve():
                                        torch.zeros(1, 5, 256, device=DEV), False)
     out = _run(model, pv, pm, fused=True)   # served by the per-operation decoder
     assert torch.isfinite(out.pred_rel).all()
+
+
+def test_a_refusing_device_falls_back_to_the_per_operation_decoder_and_says_so(monkeypatch):
+    """What happens on a device whose dispatch does not keep a cluster on one XCD (or where a barrier times out): the status
+    word read after the first eager run is non-zero -> DecoderClusterError -> the per-operation decoder serves the call, the
+    fall-off is counted and announced once; under STRICT_FAST_PATH it is an error instead."""
+    import warnings
+    from egtr_amd import decoder_fused, ops
+    model = _model(24, 2)
+    pv, pm = _inputs(1, 96, 128)
+    ref = _run(model, pv, pm, fused=False)
+    monkeypatch.setattr(decoder_fused, "_CHECKED", set())
+    orig = decoder_fused._workspace
+
+    def poisoned(dev, key):
+        ws = orig(dev, key)
+        ws[1].fill_(2)   # "the workgroups of a cluster were spread over several XCDs"
+        return ws
+
+    monkeypatch.setattr(decoder_fused, "_workspace", poisoned)
+    monkeypatch.setattr(ops, "FALLBACKS", {})
+    monkeypatch.setattr(decoder_fused, "ENABLED", True)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            out = model(pixel_values=pv, pixel_mask=pm, output_attention_states=True)
+    assert ops.FALLBACKS.get("decoder_cluster") == 1 and any("decoder_cluster" in str(x.message) for x in w)
+    assert not decoder_fused.ENABLED                      # switched off for the process
+    assert (out.pred_rel - ref.pred_rel).abs().max() < 1e-5
+    monkeypatch.setattr(decoder_fused, "ENABLED", True)
+    monkeypatch.setattr(decoder_fused, "_CHECKED", set())
+    monkeypatch.setattr(ops, "STRICT_FAST_PATH", True)
+    with pytest.raises(ops.FastPathError):
+        with torch.no_grad():
+            model(pixel_values=pv, pixel_mask=pm, output_attention_states=True)
+    monkeypatch.setattr(decoder_fused, "_workspace", orig)
+    for ws in decoder_fused._WORKSPACES.values():         # leave clean status words behind
+        ws[1].zero_()

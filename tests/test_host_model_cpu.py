@@ -429,3 +429,26 @@ def test_two_stage_model_matches_reference(golden_dir, cpu_kernels):
     for n, v in gn.items():
         got = float(params[n].grad.norm())
         assert abs(got - v) < 2e-3 * max(abs(v), 1e-3), (n, got, v)
+
+
+def test_fast_path_gates_announce_fall_offs_once_and_strict_mode_raises(monkeypatch):
+    """egtr_amd.ops._gate / note_fallback: a predicate that turns away a call its path exists for counts it, warns ONCE per
+    path, and raises under STRICT_FAST_PATH (bench.py runs strict); a call the path was never meant for is silent."""
+    import warnings
+    from egtr_amd import ops
+    monkeypatch.setattr(ops, "FALLBACKS", {})
+    monkeypatch.setattr(ops, "STRICT_FAST_PATH", False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert ops._gate("demo", eligible=True, ok=True, why="x") is True
+        assert ops._gate("demo", eligible=False, ok=False, why="x") is False       # not eligible: silent
+        assert not w and ops.FALLBACKS == {}
+        assert ops._gate("demo", eligible=True, ok=False, why=lambda: "K = 100 is not a multiple of 32") is False
+        assert ops._gate("demo", eligible=True, ok=False, why="again") is False
+    assert ops.FALLBACKS == {"demo": 2} and len(w) == 1 and "K = 100" in str(w[0].message)
+    monkeypatch.setattr(ops, "STRICT_FAST_PATH", True)
+    with pytest.raises(ops.FastPathError):
+        ops._gate("demo", eligible=True, ok=False, why="strict")
+    # a CPU tensor is never "eligible" for the split GEMM: no fall-off recorded
+    monkeypatch.setattr(ops, "FALLBACKS", {})
+    assert ops.gemm_split_supported(torch.zeros(5000, 100), 150, 100) is False and ops.FALLBACKS == {}
