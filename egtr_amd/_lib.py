@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("EGTR_HIP_LIBRARY") or os.path.join(_HERE, "libegtr_hi
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
-ABI_VERSION = 2   # include/egtr_hip.h: EGTR_ABI_VERSION of the header these signatures were written against
+ABI_VERSION = 3   # include/egtr_hip.h: EGTR_ABI_VERSION of the header these signatures were written against
 
 # name -> argtypes (restype is always int status unless listed in _RESTYPES)
 SIGNATURES = {
@@ -45,11 +45,15 @@ SIGNATURES = {
     "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_bias_act_nchw_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
+    "egtr_add_layernorm_pos_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _I, _P],
     "egtr_add_layernorm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
     "egtr_sine_pos_embed_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float],
     "egtr_level_geometry_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P,
                                 _P, _P],
+    "egtr_level_geometry_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P,
+                                 _P, _P],
     "egtr_input_proj_groupnorm_flatten_f32": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
+    "egtr_input_proj_groupnorm_flatten_bf16": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_bbox_overlaps_f64": [_P, _P, _P, _I, _I, _I, _P],
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],

@@ -179,42 +179,60 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// rows x 256 bf16, one wave per row, lanes 0..31 hold 8 channels each (16 B); gamma / beta bf16 (a model cast with
-// .to(bfloat16) carries them in bf16), statistics in fp32
+// rows x 256 bf16, one HALF-wave per row: a lane holds 8 channels (16 B), lanes 0..31 one row, lanes 32..63 the next (round 5:
+// one row per wave with the upper half idle moved 3.3 TB/s; the statistics are 32-lane butterflies); gamma / beta bf16 (a
+// model cast with .to(bfloat16) carries them in bf16), statistics in fp32.  Optionally y_pos = bf16(y + pos[row % pos_rows])
+// (the next encoder layer's `hidden + pos`, dd:1041, rounded like the reference's bf16 add of the rounded y).
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 __global__ __launch_bounds__(256) void add_layernorm_256_bf16(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ res,
                                                               const unsigned short* __restrict__ gamma,
                                                               const unsigned short* __restrict__ beta,
-                                                              unsigned short* __restrict__ y, int rows, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bool act = lane < 32;
-  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (act) {
-    unpack8(reinterpret_cast<const uint4*>(x + (size_t)row * 256)[lane], v);
-    if (res != nullptr) {
-      float r[8];
-      unpack8(reinterpret_cast<const uint4*>(res + (size_t)row * 256)[lane], r);
+                                                              unsigned short* __restrict__ y, int rows, float eps,
+                                                              const unsigned short* __restrict__ pos, int pos_rows,
+                                                              unsigned short* __restrict__ y_pos) {
+  const int lane = threadIdx.x & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool act = row < rows;
+  const int r_ = act ? row : rows - 1;
+  float v[8];
+  unpack8(reinterpret_cast<const uint4*>(x + (size_t)r_ * 256)[lane], v);
+  if (res != nullptr) {
+    float r[8];
+    unpack8(reinterpret_cast<const uint4*>(res + (size_t)r_ * 256)[lane], r);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = bf2f(f2bf(v[i] + r[i]));  // the reference rounds the residual sum to bf16
-    }
+    for (int i = 0; i < 8; ++i) v[i] = bf2f(f2bf(v[i] + r[i]));  // the reference rounds the residual sum to bf16
   }
+  float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pos != nullptr) unpack8(reinterpret_cast<const uint4*>(pos + (size_t)(r_ % pos_rows) * 256)[lane], p);
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) sum += v[i];
-  const float mean = wave_sum(sum) * (1.f / 256.f);
+  const float mean = half_wave_sum(sum) * (1.f / 256.f);
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) sq += act ? (v[i] - mean) * (v[i] - mean) : 0.f;
-  const float rstd = rsqrtf(wave_sum(sq) * (1.f / 256.f) + eps);
+  for (int i = 0; i < 8; ++i) sq += (v[i] - mean) * (v[i] - mean);
+  const float rstd = rsqrtf(half_wave_sum(sq) * (1.f / 256.f) + eps);
   if (act) {
     float g[8], b[8], o[8];
     unpack8(reinterpret_cast<const uint4*>(gamma)[lane], g);
     unpack8(reinterpret_cast<const uint4*>(beta)[lane], b);
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = (v[i] - mean) * rstd * g[i] + b[i];
-    reinterpret_cast<uint4*>(y + (size_t)row * 256)[lane] = pack8(o);
+    const uint4 packed = pack8(o);
+    reinterpret_cast<uint4*>(y + (size_t)row * 256)[lane] = packed;
+    if (y_pos != nullptr) {
+      float yr[8];
+      unpack8(packed, yr);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yr[i] += p[i];
+      reinterpret_cast<uint4*>(y_pos + (size_t)row * 256)[lane] = pack8(yr);
+    }
   }
 }
 
@@ -455,10 +473,14 @@ __global__ __launch_bounds__(256) void level_mask_resize(const MaskT* __restrict
   }
 }
 
+// PosT = float, or unsigned short: bf16 position rows for a bf16 model -- bf16(bf16(sine) + level_embed), the two roundings
+// of the reference's `position_embedding(..).to(dtype)` followed by its bf16 `+ level_embed[level]` (dd:2224, 2259);
+// level_embed arrives widened to fp32 (exact).
+template <typename PosT>
 __global__ __launch_bounds__(256) void level_geometry(const unsigned char* __restrict__ mask_all,
                                                       const float* __restrict__ dim_t,
                                                       const float* __restrict__ level_embed, LevelDims ld, int L, int S,
-                                                      int E, float scale, float eps, float* __restrict__ pos_flat,
+                                                      int E, float scale, float eps, PosT* __restrict__ pos_flat,
                                                       float* __restrict__ valid_ratios, float* __restrict__ ref_points) {
   constexpr int TP = 8;
   __shared__ int s_cnt[8];          // [level][row-0 count, column-0 count]
@@ -565,7 +587,12 @@ __global__ __launch_bounds__(256) void level_geometry(const unsigned char* __res
         float sn, cs;
         sincosf(a, &sn, &cs);
         const float2 le = *reinterpret_cast<const float2*>(level_embed + l * 2 * E + c);
-        *reinterpret_cast<float2*>(pos_flat + ((size_t)b * S + s) * (2 * E) + c) = make_float2(sn + le.x, cs + le.y);
+        if constexpr (sizeof(PosT) == 4) {
+          *reinterpret_cast<float2*>(pos_flat + ((size_t)b * S + s) * (2 * E) + c) = make_float2(sn + le.x, cs + le.y);
+        } else {
+          const unsigned lo = f2bf(bf2f(f2bf(sn)) + le.x), hi = f2bf(bf2f(f2bf(cs)) + le.y);
+          *reinterpret_cast<unsigned*>(pos_flat + ((size_t)b * S + s) * (2 * E) + c) = lo | (hi << 16);
+        }
       }
     }
   }
@@ -576,7 +603,7 @@ __global__ __launch_bounds__(256) void level_geometry(const unsigned char* __res
 // (model/deformable_detr.py:2209-2262: nn.Sequential(Conv2d, GroupNorm) per level, then source.flatten(2).transpose(1, 2)
 // and torch.cat).  x_l is the bias-free convolution output [B, C, H_l, W_l]; out is [B, S, C].
 struct GnLevels {
-  const float* x[4];
+  const void* x[4];      // fp32 or bf16 (raw bits) convolution outputs
   const float* conv_bias[4];
   const float* gamma[4];
   const float* beta[4];
@@ -585,15 +612,19 @@ struct GnLevels {
 
 // stats[(l * B + b) * G + g] = (mean, rstd) of (x + conv_bias) over the C/G channels x H_l W_l pixels of one group.
 // One pass: per-thread fp32 partial sums of <= ~100 elements, combined in double (E[x^2] - mean^2 in double).
+__device__ __forceinline__ float gn_load(const float* p) { return *p; }
+__device__ __forceinline__ float gn_load(const unsigned short* p) { return bf2f(*p); }
+
+template <typename T>
 __global__ __launch_bounds__(1024) void gn_stats_levels(GnLevels P, int C, int G, float eps, float2* __restrict__ stats) {
   __shared__ double s_red[2][16];
   const int g = blockIdx.x, b = blockIdx.y, l = blockIdx.z;
   const int cpg = C / G, hw = P.hw[l];
-  const float* x = P.x[l] + ((size_t)b * C + (size_t)g * cpg) * hw;  // the group's channels are contiguous in NCHW
+  const T* x = static_cast<const T*>(P.x[l]) + ((size_t)b * C + (size_t)g * cpg) * hw;  // the group's channels are contiguous in NCHW
   float s1 = 0.f, s2 = 0.f;
   for (int c = 0; c < cpg; ++c) {
     const float cb = P.conv_bias[l][g * cpg + c];
-    const float* xc = x + (size_t)c * hw;
+    const T* xc = x + (size_t)c * hw;
     // 8 loads in flight per thread, accumulated in the original order (the loop was one dependent load -> add per
     // ~300 ns: 73 round trips for the 75 000 elements of a level-0 group)
     for (int i0 = threadIdx.x; i0 < hw; i0 += 8 * 1024) {
@@ -601,7 +632,7 @@ __global__ __launch_bounds__(1024) void gn_stats_levels(GnLevels P, int C, int G
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + 1024 * u;
-        v[u] = i < hw ? xc[i] : 0.f;
+        v[u] = i < hw ? gn_load(xc + i) : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -638,8 +669,9 @@ __global__ __launch_bounds__(1024) void gn_stats_levels(GnLevels P, int C, int G
 
 // one workgroup = 32 pixels of one level x all C = 256 channels: coalesced NCHW reads (lanes along the pixels), LDS
 // transpose, coalesced [.., C] writes (lanes along the channels)
+template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_flatten(GnLevels P, int L, int C, int G, int S, const float2* __restrict__ stats,
-                                                        float* __restrict__ out) {
+                                                        T* __restrict__ out) {
   __shared__ float s_t[32][257];
   const int b = blockIdx.y;
   int l = 0;
@@ -647,12 +679,12 @@ __global__ __launch_bounds__(256) void gn_apply_flatten(GnLevels P, int L, int C
   const int p0 = ((int)blockIdx.x - P.tile0[l]) * 32, hw = P.hw[l];
   const int cpg = C / G;
   const int px = threadIdx.x & 31, cs = threadIdx.x >> 5;  // 8 channel sub-lanes
-  const float* x = P.x[l] + (size_t)b * C * hw;
+  const T* x = static_cast<const T*>(P.x[l]) + (size_t)b * C * hw;
   // C == 256 (checked by the launcher): 32 channels per thread, all 32 activation loads requested before the first use
   float xv[32];
   const bool inside = p0 + px < hw;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) xv[k] = inside ? x[(size_t)(cs + 8 * k) * hw + p0 + px] : 0.f;
+  for (int k = 0; k < 32; ++k) xv[k] = inside ? gn_load(x + (size_t)(cs + 8 * k) * hw + p0 + px) : 0.f;
 #pragma unroll
   for (int k = 0; k < 32; ++k) {
     const int c = cs + 8 * k;
@@ -663,7 +695,8 @@ __global__ __launch_bounds__(256) void gn_apply_flatten(GnLevels P, int L, int C
   __syncthreads();
   for (int p = 0; p < 32; ++p) {
     if (p0 + p >= hw) break;
-    out[((size_t)b * S + P.start[l] + p0 + p) * C + threadIdx.x] = s_t[p][threadIdx.x];
+    if constexpr (sizeof(T) == 4) out[((size_t)b * S + P.start[l] + p0 + p) * C + threadIdx.x] = s_t[p][threadIdx.x];
+    else out[((size_t)b * S + P.start[l] + p0 + p) * C + threadIdx.x] = f2bf(s_t[p][threadIdx.x]);
   }
 }
 
@@ -681,11 +714,11 @@ extern "C" int egtr_sine_pos_embed_f32(egtr_stream_t stream, const float* y_embe
   return egtr_check_launch();
 }
 
-extern "C" int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size,
-                                       const float* dim_t, const float* level_embed, const int* level_hw,
-                                       int num_levels, int batch, int height, int width, int embed_dim, float scale,
-                                       float eps, unsigned char* mask_flat, float* pos_flat, float* valid_ratios,
-                                       float* ref_points, unsigned* mask_bits) {
+static int level_geometry_launch(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size, const float* dim_t,
+                                 const float* level_embed, const int* level_hw, int num_levels, int batch, int height,
+                                 int width, int embed_dim, float scale, float eps, unsigned char* mask_flat,
+                                 void* pos_flat, bool pos_bf16, float* valid_ratios, float* ref_points,
+                                 unsigned* mask_bits) {
   if (!pixel_mask || !dim_t || !level_embed || !level_hw || !mask_flat || !pos_flat || !valid_ratios || !ref_points)
     return EGTR_E_ARG;
   if (num_levels < 1 || num_levels > 4 || batch <= 0 || height <= 0 || width <= 0 || embed_dim <= 0)
@@ -714,16 +747,40 @@ extern "C" int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_m
                        static_cast<const unsigned char*>(pixel_mask), ld, num_levels, S, height, width, mask_flat,
                        mask_bits);
   const dim3 grid((unsigned)((S + 7) / 8), (unsigned)batch);
-  hipLaunchKernelGGL(level_geometry, grid, dim3(256), 0, st, mask_flat, dim_t, level_embed, ld, num_levels, S, embed_dim,
-                     scale, eps, pos_flat, valid_ratios, ref_points);
+  if (pos_bf16)
+    hipLaunchKernelGGL(level_geometry<unsigned short>, grid, dim3(256), 0, st, mask_flat, dim_t, level_embed, ld,
+                       num_levels, S, embed_dim, scale, eps, static_cast<unsigned short*>(pos_flat), valid_ratios,
+                       ref_points);
+  else
+    hipLaunchKernelGGL(level_geometry<float>, grid, dim3(256), 0, st, mask_flat, dim_t, level_embed, ld, num_levels, S,
+                       embed_dim, scale, eps, static_cast<float*>(pos_flat), valid_ratios, ref_points);
   return egtr_check_launch();
 }
 
-extern "C" int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, const float* const* x,
-                                                     const float* const* conv_bias, const float* const* gamma,
-                                                     const float* const* beta, const int* level_hw, int batch,
-                                                     int channels, int num_groups, float eps, float* stats,
-                                                     float* out) {
+extern "C" int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size,
+                                       const float* dim_t, const float* level_embed, const int* level_hw,
+                                       int num_levels, int batch, int height, int width, int embed_dim, float scale,
+                                       float eps, unsigned char* mask_flat, float* pos_flat, float* valid_ratios,
+                                       float* ref_points, unsigned* mask_bits) {
+  return level_geometry_launch(stream, pixel_mask, mask_elem_size, dim_t, level_embed, level_hw, num_levels, batch, height,
+                               width, embed_dim, scale, eps, mask_flat, pos_flat, false, valid_ratios, ref_points,
+                               mask_bits);
+}
+
+extern "C" int egtr_level_geometry_bf16(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size,
+                                        const float* dim_t, const float* level_embed, const int* level_hw,
+                                        int num_levels, int batch, int height, int width, int embed_dim, float scale,
+                                        float eps, unsigned char* mask_flat, uint16_t* pos_flat, float* valid_ratios,
+                                        float* ref_points, unsigned* mask_bits) {
+  return level_geometry_launch(stream, pixel_mask, mask_elem_size, dim_t, level_embed, level_hw, num_levels, batch, height,
+                               width, embed_dim, scale, eps, mask_flat, pos_flat, true, valid_ratios, ref_points,
+                               mask_bits);
+}
+
+static int groupnorm_flatten_launch(egtr_stream_t stream, int num_levels, const void* const* x,
+                                    const float* const* conv_bias, const float* const* gamma, const float* const* beta,
+                                    const int* level_hw, int batch, int channels, int num_groups, float eps, float* stats,
+                                    void* out, bool bf16) {
   if (!x || !conv_bias || !gamma || !beta || !level_hw || !stats || !out) return EGTR_E_ARG;
   if (num_levels < 1 || num_levels > 4 || batch <= 0 || num_groups <= 0) return EGTR_E_ARG;
   if (channels != 256 || channels % num_groups != 0) return EGTR_E_UNSUPPORTED;
@@ -746,11 +803,36 @@ extern "C" int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int n
     }
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_stats_levels, dim3(num_groups, batch, num_levels), dim3(1024), 0, st, P, channels, num_groups, eps,
-                     reinterpret_cast<float2*>(stats));
-  hipLaunchKernelGGL(gn_apply_flatten, dim3(tiles, batch), dim3(256), 0, st, P, num_levels, channels, num_groups, S,
-                     reinterpret_cast<const float2*>(stats), out);
+  if (bf16) {
+    hipLaunchKernelGGL(gn_stats_levels<unsigned short>, dim3(num_groups, batch, num_levels), dim3(1024), 0, st, P, channels,
+                       num_groups, eps, reinterpret_cast<float2*>(stats));
+    hipLaunchKernelGGL(gn_apply_flatten<unsigned short>, dim3(tiles, batch), dim3(256), 0, st, P, num_levels, channels,
+                       num_groups, S, reinterpret_cast<const float2*>(stats), static_cast<unsigned short*>(out));
+  } else {
+    hipLaunchKernelGGL(gn_stats_levels<float>, dim3(num_groups, batch, num_levels), dim3(1024), 0, st, P, channels,
+                       num_groups, eps, reinterpret_cast<float2*>(stats));
+    hipLaunchKernelGGL(gn_apply_flatten<float>, dim3(tiles, batch), dim3(256), 0, st, P, num_levels, channels, num_groups,
+                       S, reinterpret_cast<const float2*>(stats), static_cast<float*>(out));
+  }
   return egtr_check_launch();
+}
+
+extern "C" int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, const float* const* x,
+                                                     const float* const* conv_bias, const float* const* gamma,
+                                                     const float* const* beta, const int* level_hw, int batch,
+                                                     int channels, int num_groups, float eps, float* stats,
+                                                     float* out) {
+  return groupnorm_flatten_launch(stream, num_levels, reinterpret_cast<const void* const*>(x), conv_bias, gamma, beta,
+                                  level_hw, batch, channels, num_groups, eps, stats, out, false);
+}
+
+extern "C" int egtr_input_proj_groupnorm_flatten_bf16(egtr_stream_t stream, int num_levels, const uint16_t* const* x,
+                                                      const float* const* conv_bias, const float* const* gamma,
+                                                      const float* const* beta, const int* level_hw, int batch,
+                                                      int channels, int num_groups, float eps, float* stats,
+                                                      uint16_t* out) {
+  return groupnorm_flatten_launch(stream, num_levels, reinterpret_cast<const void* const*>(x), conv_bias, gamma, beta,
+                                  level_hw, batch, channels, num_groups, eps, stats, out, true);
 }
 
 extern "C" int egtr_bias_act_nchw_f32(egtr_stream_t stream, const float* x, const float* bias, const float* residual,
@@ -868,8 +950,20 @@ extern "C" int egtr_add_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, 
   if (!x || !gamma || !beta || !y) return EGTR_E_ARG;
   if (rows <= 0) return EGTR_E_ARG;
   if (dim != 256) return EGTR_E_UNSUPPORTED;
-  hipLaunchKernelGGL(add_layernorm_256_bf16, dim3((rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                     residual, gamma, beta, y, rows, eps);
+  hipLaunchKernelGGL(add_layernorm_256_bf16, dim3((rows + 7) / 8), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     residual, gamma, beta, y, rows, eps, static_cast<const uint16_t*>(nullptr), 1,
+                     static_cast<uint16_t*>(nullptr));
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_add_layernorm_pos_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual,
+                                           const uint16_t* gamma, const uint16_t* beta, uint16_t* y, int rows, int dim,
+                                           float eps, const uint16_t* pos, int pos_rows, uint16_t* y_pos) {
+  if (!x || !gamma || !beta || !y || !pos || !y_pos) return EGTR_E_ARG;
+  if (rows <= 0 || pos_rows <= 0 || rows % pos_rows != 0) return EGTR_E_ARG;
+  if (dim != 256) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(add_layernorm_256_bf16, dim3((rows + 7) / 8), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     residual, gamma, beta, y, rows, eps, pos, pos_rows, y_pos);
   return egtr_check_launch();
 }
 

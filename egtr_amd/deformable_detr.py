@@ -693,7 +693,13 @@ class DeformableDetrEncoderLayer(nn.Module):
         hidden_states = ops.module_linear(self.fc2, hidden_states)
         hidden_states = F.dropout(hidden_states, p=self.dropout, training=self.training)
         next_with_pos = None
-        if return_with_pos and position_embeddings is not None and ops.inference_fast_path(hidden_states):
+        if return_with_pos and position_embeddings is not None and (
+                ops.inference_fast_path(hidden_states)
+                or (hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16 and not torch.is_grad_enabled()
+                    and position_embeddings.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16
+                    and self.final_layer_norm.weight.dtype == torch.bfloat16 and hidden_states.shape[-1] == 256)):
+            # (bf16 model: the next layer's `hidden + pos` leaves the LayerNorm launch as well -- one elementwise pass over
+            # the token matrix less per layer)
             hidden_states, next_with_pos = ops.add_layer_norm_pos(hidden_states, residual, self.final_layer_norm,
                                                                   _pos_rows(position_embeddings))
         else:
@@ -1257,8 +1263,10 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             pixel_mask = torch.ones((batch_size, height, width), dtype=torch.long, device=device)
 
         pos_mod = self.backbone.position_embedding
-        fused_geometry = (pixel_mask.is_cuda and pixel_values.dtype == torch.float32
-                          and self.level_embed.dtype == torch.float32
+        # (fp32, and the bf16 model of the stress configuration: bf16 activations and position rows, fp32 statistics)
+        fused_geometry = (pixel_mask.is_cuda and pixel_values.dtype in (torch.float32, torch.bfloat16)
+                          and self.level_embed.dtype == pixel_values.dtype
+                          and not (pixel_values.dtype == torch.bfloat16 and torch.is_grad_enabled())
                           and isinstance(pos_mod, DeformableDetrSinePositionEmbedding)
                           and pos_mod.normalize and self.config.num_feature_levels <= 4
                           and not (torch.is_grad_enabled() and self.level_embed.requires_grad))
@@ -1273,7 +1281,8 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             else:  # a user-supplied feature extractor: keep its (feature, mask) interface, drop its masks
                 feature_maps = [fm for fm, _ in conv_encoder(pixel_values, pixel_mask)]
             n_extra = self.config.num_feature_levels - len(feature_maps)
-            if (n_extra <= 1 and self.config.d_model == 256 and feature_maps[0].dtype == torch.float32
+            if (n_extra <= 1 and self.config.d_model == 256 and feature_maps[0].dtype == pixel_values.dtype
+                    and self.input_proj[0][0].weight.dtype == pixel_values.dtype
                     and all(isinstance(p[1], nn.GroupNorm) and p[0].bias is not None for p in self.input_proj)):
                 # input projections: bias-free convolutions, then conv bias + GroupNorm + flatten + transpose + cat
                 # of all levels in two HIP launches

@@ -1036,6 +1036,21 @@ def add_layer_norm_pos(x, residual, ln, pos, out=None):
     (broadcast over the batch).  ``out``: optional contiguous destination of the first result (e.g. a slice of the
     decoder's stacked intermediate states).  Inference only."""
     lib = _lib.lib()
+    if x.dtype == torch.bfloat16:
+        # bf16 model (stress configuration): same launch shape, bf16 storage, fp32 statistics
+        x2 = _chk(x.contiguous(), "x", torch.bfloat16)
+        r2 = _chk(residual.contiguous(), "residual", torch.bfloat16)
+        p2 = _chk(pos.contiguous(), "pos", torch.bfloat16)
+        _chk(ln.weight, "ln.weight", torch.bfloat16)
+        rows, prow = x2.numel() // 256, p2.numel() // 256
+        if x2.shape[-1] != 256 or rows % prow != 0 or out is not None:
+            raise ValueError("add_layer_norm_pos (bf16): d_model must be 256, pos must tile the rows, no `out`")
+        y, yp = torch.empty_like(x2), torch.empty_like(x2)
+        st = lib.egtr_add_layernorm_pos_bf16(_stream(), x2.data_ptr(), r2.data_ptr(), ln.weight.data_ptr(),
+                                             ln.bias.data_ptr(), y.data_ptr(), rows, 256, float(ln.eps), p2.data_ptr(),
+                                             prow, yp.data_ptr())
+        _lib.check(st, "egtr_add_layernorm_pos_bf16")
+        return y, yp
     x2 = _chk(x.contiguous(), "x", torch.float32)
     r2 = _chk(residual.contiguous(), "residual", torch.float32)
     p2 = _chk(pos.contiguous(), "pos", torch.float32)
@@ -1525,32 +1540,41 @@ def sine_position_embedding(pixel_mask, embedding_dim, temperature, scale, eps=1
 
 def input_proj_groupnorm_flatten(conv_outputs, input_projs):
     """Conv bias + GroupNorm + flatten(2).transpose(1, 2) + cat over the levels (dd:2209-2262) in two HIP launches.
-    ``conv_outputs[l]``: bias-free output [B,256,H_l,W_l] of ``input_projs[l][0]``; ``input_projs[l]`` = Sequential(
-    Conv2d, GroupNorm).  Returns [B, S, 256].  Inference only."""
+    ``conv_outputs[l]``: bias-free output [B,256,H_l,W_l] of ``input_projs[l][0]`` (fp32, or bf16 for a bf16 model: bf16
+    activations in and out, fp32 statistics); ``input_projs[l]`` = Sequential(Conv2d, GroupNorm).  Returns [B, S, 256].
+    Inference only."""
     import ctypes
     lib = _lib.lib()
     L = len(conv_outputs)
     B, C = conv_outputs[0].shape[:2]
     gn0 = input_projs[0][1]
-    xs = [_chk(x.contiguous(), "conv output", torch.float32) for x in conv_outputs]
-    keep = []
+    dt = conv_outputs[0].dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise TypeError("input_proj_groupnorm_flatten: fp32 or bf16 convolution outputs")
+    xs = [_chk(x.contiguous(), "conv output", dt) for x in conv_outputs]
     for proj in input_projs[:L]:
         conv, gn = proj[0], proj[1]
         if gn.num_groups != gn0.num_groups or gn.eps != gn0.eps or conv.bias is None:
             raise ValueError("input_proj_groupnorm_flatten: levels must share the GroupNorm configuration")
-        keep.append((_chk(conv.bias.detach().contiguous(), "conv bias", torch.float32),
-                     _chk(gn.weight.detach().contiguous(), "gn weight", torch.float32),
-                     _chk(gn.bias.detach().contiguous(), "gn bias", torch.float32)))
+    srcs = [t for proj in input_projs[:L] for t in (proj[0].bias, proj[1].weight, proj[1].bias)]
+    if dt == torch.float32:
+        keep = [tuple(_chk(t.detach().contiguous(), "input_proj parameter", torch.float32) for t in srcs[3 * l:3 * l + 3])
+                for l in range(L)]
+    else:   # the kernel takes fp32 parameters: widened once per parameter version
+        flat = cached_weights(input_projs, "gn_params_f32", srcs,
+                              lambda: [t.detach().float().contiguous() for t in srcs])
+        keep = [tuple(flat[3 * l:3 * l + 3]) for l in range(L)]
     hw = [int(v) for x in xs for v in x.shape[-2:]]
     S = sum(h * w for h, w in zip(hw[0::2], hw[1::2]))
-    out = torch.empty(B, S, C, dtype=torch.float32, device=xs[0].device)
+    out = torch.empty(B, S, C, dtype=dt, device=xs[0].device)
     stats = torch.empty(L * B * gn0.num_groups * 2, dtype=torch.float32, device=xs[0].device)
     PA, IA = ctypes.c_void_p * L, ctypes.c_int * (2 * L)
-    st = lib.egtr_input_proj_groupnorm_flatten_f32(
+    entry = "egtr_input_proj_groupnorm_flatten_f32" if dt == torch.float32 else "egtr_input_proj_groupnorm_flatten_bf16"
+    st = getattr(lib, entry)(
         _stream(), L, PA(*[x.data_ptr() for x in xs]), PA(*[k[0].data_ptr() for k in keep]),
         PA(*[k[1].data_ptr() for k in keep]), PA(*[k[2].data_ptr() for k in keep]), IA(*hw), B, C, gn0.num_groups,
         float(gn0.eps), stats.data_ptr(), out.data_ptr())
-    _lib.check(st, "egtr_input_proj_groupnorm_flatten_f32")
+    _lib.check(st, entry)
     return out
 
 
@@ -1560,7 +1584,9 @@ _DIM_T = {}
 def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale, eps=1e-6):
     """Everything DeformableDetrModel.forward derives from ``pixel_mask`` alone, in one HIP kernel
     (egtr_level_geometry_f32): returns (mask_flatten [B,S] bool, lvl_pos_embed_flatten [B,S,2E] incl. level_embed,
-    valid_ratios [B,L,2], encoder reference_points [B,S,L,2]).  Inference only (no autograd through level_embed)."""
+    valid_ratios [B,L,2], encoder reference_points [B,S,L,2]).  A bf16 ``level_embed`` (bf16 model) gives bf16 position rows
+    rounded like the reference's composition (egtr_level_geometry_bf16); everything else stays fp32.  Inference only (no
+    autograd through level_embed)."""
     import ctypes
     lib = _lib.lib()
     dev = pixel_mask.device
@@ -1574,20 +1600,25 @@ def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, 
         pixel_mask = (pixel_mask != 0).to(torch.uint8)
     pm = pixel_mask.contiguous()
     _chk(pm, "pixel_mask")
-    le = _chk(level_embed.detach().contiguous(), "level_embed", torch.float32)
+    pos_dtype = level_embed.dtype
+    if pos_dtype == torch.bfloat16:
+        le = level_embed.detach().float().contiguous()     # exact; [L, 2E]
+    else:
+        le = _chk(level_embed.detach().contiguous(), "level_embed", torch.float32)
     B, H, W_ = pm.shape
     L = len(spatial_shapes_list)
     S = sum(h * w for h, w in spatial_shapes_list)
     hw = (ctypes.c_int * (2 * L))(*[int(v) for hw_ in spatial_shapes_list for v in hw_])
     mask_u8 = torch.empty(B, S, dtype=torch.uint8, device=dev)
     bits = torch.empty(B, (S + 31) // 32, dtype=torch.int32, device=dev)
-    pos = torch.empty(B, S, 2 * embedding_dim, dtype=torch.float32, device=dev)
+    pos = torch.empty(B, S, 2 * embedding_dim, dtype=pos_dtype, device=dev)
     vr = torch.empty(B, L, 2, dtype=torch.float32, device=dev)
     ref = torch.empty(B, S, L, 2, dtype=torch.float32, device=dev)
-    st = lib.egtr_level_geometry_f32(_stream(), pm.data_ptr(), pm.element_size(), dim_t.data_ptr(), le.data_ptr(), hw,
-                                     L, B, H, W_, embedding_dim, float(scale), float(eps), mask_u8.data_ptr(),
-                                     pos.data_ptr(), vr.data_ptr(), ref.data_ptr(), bits.data_ptr())
-    _lib.check(st, "egtr_level_geometry_f32")
+    entry = "egtr_level_geometry_bf16" if pos_dtype == torch.bfloat16 else "egtr_level_geometry_f32"
+    st = getattr(lib, entry)(_stream(), pm.data_ptr(), pm.element_size(), dim_t.data_ptr(), le.data_ptr(), hw,
+                             L, B, H, W_, embedding_dim, float(scale), float(eps), mask_u8.data_ptr(),
+                             pos.data_ptr(), vr.data_ptr(), ref.data_ptr(), bits.data_ptr())
+    _lib.check(st, entry)
     mask = mask_u8.view(torch.bool)
     mask._egtr_bits = bits  # one bit per token, consumed by the fused MSDA kernel (kept in LDS there)
     return mask, pos, vr, ref

@@ -46,7 +46,7 @@ enum {
 
 /* Bumped whenever an entry point is added / removed or the meaning of an argument changes; egtr_amd/_lib.py refuses a
  * library whose number differs from the one it was written against. */
-#define EGTR_ABI_VERSION 2
+#define EGTR_ABI_VERSION 3
 int egtr_abi_version(void);
 const char* egtr_status_string(int status);
 /* last HIP error string seen by this thread (for EGTR_E_LAUNCH) */
@@ -352,6 +352,11 @@ int egtr_bias_act_nchw_bf16(egtr_stream_t stream, const uint16_t* x, const float
                             uint16_t* y, int N, int C, int HW, int relu);
 int egtr_add_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual, const uint16_t* gamma,
                             const uint16_t* beta, uint16_t* y, int rows, int dim, float eps);
+/* ... and y_plus_pos = bf16(y + pos[row % pos_rows]) from the SAME launch: the next encoder layer's `hidden + pos`
+ * (deformable_detr.py:1041), rounded like the reference's bf16 add of the already rounded y.  rows % pos_rows == 0. */
+int egtr_add_layernorm_pos_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual, const uint16_t* gamma,
+                                const uint16_t* beta, uint16_t* y, int rows, int dim, float eps, const uint16_t* pos,
+                                int pos_rows, uint16_t* y_plus_pos);
 
 /* Same, and additionally y_plus_pos = y + pos[row % pos_rows] (the "with_pos_embed" input of the next sub-layer,
  * deformable_detr.py:1023-1024 / 1148-1149), saving one elementwise launch per sub-layer. */
@@ -453,6 +458,13 @@ int egtr_level_geometry_f32(egtr_stream_t stream, const void* pixel_mask, int ma
                             const float* level_embed, const int* level_hw, int num_levels, int batch, int height,
                             int width, int embed_dim, float scale, float eps, unsigned char* mask_flat,
                             float* pos_flat, float* valid_ratios, float* ref_points, unsigned* mask_bits);
+/* The same for a bf16 model: pos_flat holds bfloat16 bits, bf16(bf16(sine) + level_embed) -- the two roundings of the
+ * reference's `position_embedding(..).to(dtype)` and its bf16 `+ level_embed[level]` (deformable_detr.py:2224, 2259);
+ * level_embed is passed widened to fp32; the other outputs are as above. */
+int egtr_level_geometry_bf16(egtr_stream_t stream, const void* pixel_mask, int mask_elem_size, const float* dim_t,
+                             const float* level_embed, const int* level_hw, int num_levels, int batch, int height,
+                             int width, int embed_dim, float scale, float eps, unsigned char* mask_flat,
+                             uint16_t* pos_flat, float* valid_ratios, float* ref_points, unsigned* mask_bits);
 
 /* Epilogue of the per-level input projections (model/deformable_detr.py:2209-2262): conv bias + GroupNorm(num_groups)
  * + flatten(2).transpose(1, 2) + concatenation over the levels, in two launches for all levels.  x[l] is the BIAS-FREE
@@ -463,6 +475,11 @@ int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, 
                                           const float* const* conv_bias, const float* const* gamma,
                                           const float* const* beta, const int* level_hw, int batch, int channels,
                                           int num_groups, float eps, float* stats, float* out);
+/* bf16 activations (raw bits) in and out, fp32 parameters and statistics: x[l] is the bf16 bias-free convolution output. */
+int egtr_input_proj_groupnorm_flatten_bf16(egtr_stream_t stream, int num_levels, const uint16_t* const* x,
+                                           const float* const* conv_bias, const float* const* gamma,
+                                           const float* const* beta, const int* level_hw, int batch, int channels,
+                                           int num_groups, float eps, float* stats, uint16_t* out);
 
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):

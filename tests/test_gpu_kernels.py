@@ -928,6 +928,82 @@ def test_add_layer_norm_bf16(rows):
     assert (y.cpu().double() - want).abs().max() < 2e-2 * max(1.0, float(want.abs().max()) / 4)
 
 
+@pytest.mark.parametrize("rows,prow", [(8, 8), (5, 5), (603, 201), (12537, 12537), (2 * 4099, 4099)])
+def test_add_layer_norm_pos_bf16(rows, prow):
+    """egtr_add_layernorm_pos_bf16: the LayerNorm output is the one of egtr_add_layernorm_bf16 bit for bit (row counts that
+    are not a multiple of the 8 rows of a workgroup included) and the second output is torch's bf16 `y + pos` of it."""
+    from egtr_amd.ops import add_layer_norm, add_layer_norm_pos
+    g = torch.Generator().manual_seed(rows + prow)
+    x = torch.randn(rows, 256, generator=g).bfloat16().to(DEV)
+    r = torch.randn(rows, 256, generator=g).bfloat16().to(DEV)
+    pos = torch.randn(prow, 256, generator=g).bfloat16().to(DEV)
+    ln = torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(256, generator=g)); ln.bias.copy_(0.2 * torch.randn(256, generator=g))
+    ln = ln.to(DEV).bfloat16()
+    with torch.no_grad():
+        y0 = add_layer_norm(x, r, ln)
+        y, yp = add_layer_norm_pos(x, r, ln, pos)
+    assert y.dtype == torch.bfloat16 and yp.dtype == torch.bfloat16
+    assert torch.equal(y, y0)
+    assert torch.equal(yp, y0 + pos.repeat(rows // prow, 1))
+
+
+@pytest.mark.parametrize("geom", ["small", "ragged"])
+def test_level_geometry_bf16_rounds_like_the_reference_composition(geom):
+    """egtr_level_geometry_bf16: position rows = bf16(bf16(sine) + level_embed), i.e. the reference's
+    `position_embedding(..).to(bf16)` followed by its bf16 `+ level_embed[level]` (dd:2224, 2259) -- bit for bit against the
+    fp32 kernel's sine part (level_embed = 0) pushed through exactly those two torch roundings; masks, valid ratios and
+    reference points are the fp32 kernel's."""
+    from egtr_amd import ops
+    if geom == "small":
+        B, H, W_, shapes = 3, 64, 80, [(8, 10), (4, 5), (2, 3), (1, 2)]
+    else:
+        B, H, W_, shapes = 3, 200, 333, [(25, 42), (13, 21), (7, 11), (4, 6)]
+    pm = torch.ones(B, H, W_, dtype=torch.long)
+    pm[1, H // 2:, :] = 0
+    pm[2, :, W_ // 3:] = 0
+    pm = pm.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    le16 = torch.randn(4, 256, generator=g).bfloat16().to(DEV)
+    two_pi = 2 * 3.141592653589793
+    m0, sine, vr0, ref0 = ops.level_geometry(pm, shapes, torch.zeros(4, 256, device=DEV), 128, 10000, two_pi)
+    m1, pos16, vr1, ref1 = ops.level_geometry(pm, shapes, le16, 128, 10000, two_pi)
+    assert pos16.dtype == torch.bfloat16 and pos16.shape == sine.shape
+    sizes = [h * w for h, w in shapes]
+    per_tok = torch.cat([le16[l].view(1, 1, -1).expand(B, n, -1) for l, n in enumerate(sizes)], 1)
+    assert torch.equal(pos16, sine.bfloat16() + per_tok)
+    assert torch.equal(m0, m1) and torch.equal(vr0, vr1) and torch.equal(ref0, ref1)
+    assert torch.equal(m0._egtr_bits, m1._egtr_bits)
+
+
+def test_input_proj_groupnorm_flatten_bf16_matches_torch():
+    """bf16 entry (bf16 convolution outputs in, bf16 tokens out, fp32 parameters and statistics) against the fp64 GroupNorm of
+    the same bf16 inputs: one bf16 rounding of an O(1) output; odd plane sizes (2-byte aligned rows only)."""
+    import torch.nn as nn
+    from egtr_amd import ops
+    torch.manual_seed(8)
+    shapes = [(19, 33), (10, 17), (5, 9), (3, 3)]
+    projs = nn.ModuleList([nn.Sequential(nn.Conv2d(8, 256, 1), nn.GroupNorm(32, 256)) for _ in shapes])
+    with torch.no_grad():
+        for p in projs:
+            p[0].bias.normal_()
+            p[1].weight.normal_()
+            p[1].bias.normal_()
+    projs = projs.bfloat16()
+    xs = [(3.0 * torch.randn(2, 256, h, w) + 1.5).bfloat16() for h, w in shapes]
+    with torch.no_grad():
+        want = torch.cat([nn.functional.group_norm(x.double() + p[0].bias.double().view(1, -1, 1, 1), 32, p[1].weight.double(),
+                                                   p[1].bias.double(), p[1].eps).flatten(2).transpose(1, 2)
+                          for p, x in zip(projs, xs)], 1)
+        got = ops.input_proj_groupnorm_flatten([x.to(DEV) for x in xs], projs.to(DEV))
+        again = ops.input_proj_groupnorm_flatten([x.to(DEV) for x in xs], projs.to(DEV))   # cached fp32 parameters
+    assert got.dtype == torch.bfloat16 and got.shape == want.shape
+    err = (got.cpu().double() - want).abs()
+    assert float((err / want.abs().clamp_min(1.0)).max()) < 2.0 ** -8     # half an ulp of bf16 (8 bits of mantissa)
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("N,C,H,Wd", [(2, 64, 25, 42), (1, 256, 100, 167), (3, 8, 3, 3), (1, 5, 1, 7), (2, 16, 50, 84)])
 def test_bias_act_nchw_bf16(N, C, H, Wd):
     from egtr_amd.ops import bias_act_
