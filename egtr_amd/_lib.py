@@ -73,6 +73,8 @@ SIGNATURES = {
     "egtr_relation_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I, _I, _P, _P, _P, _P],
     "egtr_relation_loss_workspace_bytes": [_I, _I],
     "egtr_rel_head_forward_bf16w": [_P] * 16 + [_I] * 6 + [_P] * 3,
+    "egtr_rel_head_forward_bf16p": [_P] * 16 + [_I] * 6 + [_P] * 3,
+    "egtr_rel_head_pack_tables_bf16": [_P, _P, _I, _I, _I, _P],
     "egtr_linear_split_bf16_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I],
     "egtr_linear_split_bf16_wgrad_f32": [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I],
     "egtr_linear_split_bf16_wgrad_workspace_floats": [_I, _I, _I],

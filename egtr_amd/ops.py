@@ -1824,19 +1824,34 @@ class RelationHeadFunction(Function):
         return (dgq, dgk, duq, duk, db1, dw2r, db2r, dw3r, db3r, dw2c, db2c, dw3c, db3c, None, None, None)
 
 
+# bf16 model: layer 1 of the relation head (gated sum over the slots) on the matrix cores as well, tables pre-packed in
+# operand order, W2 resident in LDS (csrc/rel_head_bf16.hip).  "0": the VALU layer 1 of rel_head_fwd_bf16w.
+REL_HEAD_BF16_PACKED = os.environ.get("EGTR_REL_HEAD_BF16_PACKED", "1") != "0"
+
+
 def relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
                         node_cls=None, want_gate_mean=False):
-    """Inference forward of a bf16 model: layers 2 / 3 on the bf16 matrix cores with the bf16 parameters as they are
-    (egtr_rel_head_forward_bf16w); the per-query tables, gates, biases and the outputs are fp32.  No autograd."""
+    """Inference forward of a bf16 model: the matrix products on the bf16 matrix cores with the bf16 parameters as they are
+    (egtr_rel_head_forward_bf16p: all three layers, per-query tables uq / uk rounded to bf16 -- a bf16 model produces them
+    in bf16 -- and packed in operand order by egtr_rel_head_pack_tables_bf16; or, EGTR_REL_HEAD_BF16_PACKED=0,
+    egtr_rel_head_forward_bf16w with an fp32 VALU layer 1); gates, biases and the outputs are fp32.  No autograd."""
     lib = _lib.lib()
     B, N, T = gate_q.shape
     Hd = w2r.shape[1]
     R = w3r.shape[0]
     dev = gate_q.device
+    packed = REL_HEAD_BF16_PACKED and T <= 10 and Hd == 256 and R <= 64
+    tables = []
+    for t, n in ((uq, "uq"), (uk, "uk")):
+        t = t.detach()
+        if packed and t.dtype == torch.bfloat16:
+            tables.append(_chk(t.contiguous(), n, torch.bfloat16))
+        else:
+            tables.append(_chk(t.float().contiguous(), n, torch.float32))
     f32 = [_chk(t.detach().float().contiguous(), n, torch.float32)
-           for t, n in ((gate_q, "gate_q"), (gate_k, "gate_k"), (uq, "uq"), (uk, "uk"), (b1, "b1"), (b2r, "b2r"),
+           for t, n in ((gate_q, "gate_q"), (gate_k, "gate_k"), (b1, "b1"), (b2r, "b2r"),
                         (b3r, "b3r"), (b2c, "b2c"), (b3c, "b3c"))]
-    gq, gk, uq_, uk_, b1_, b2r_, b3r_, b2c_, b3c_ = f32
+    gq, gk, b1_, b2r_, b3r_, b2c_, b3c_ = f32
     wts = [_chk(t.detach().contiguous(), n, torch.bfloat16)
            for t, n in ((w2r, "w2r"), (w3r, "w3r"), (w2c, "w2c"), (w3c, "w3c"))]
     w2r_, w3r_, w2c_, w3c_ = wts
@@ -1849,6 +1864,25 @@ def relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c
         td = _chk(triplet_dist.detach().float().contiguous(), "triplet_dist", torch.float32)
         _chk(node_cls, "node_cls", torch.int64)
         c1 = td.shape[0]
+    if packed:
+        if tuple(tables[0].shape) != (B, N, T, 2 * Hd) or tuple(tables[1].shape) != (B, N, T, 2 * Hd):
+            raise ValueError("relation_head_bf16w: uq / uk must be [B, N, T, 512]")
+        pk = []
+        for t in tables:   # [B * N] rows of [mlp 2][tile 8][half 2][channel 32][8 slots] bf16 = 16 KiB
+            out = torch.empty(B * N, 8192, dtype=torch.bfloat16, device=dev)
+            st = lib.egtr_rel_head_pack_tables_bf16(_stream(), t.data_ptr(), int(t.dtype == torch.bfloat16), B * N, T,
+                                                    out.data_ptr())
+            _lib.check(st, "egtr_rel_head_pack_tables_bf16")
+            pk.append(out)
+        st = lib.egtr_rel_head_forward_bf16p(
+            _stream(), gq.data_ptr(), gk.data_ptr(), pk[0].data_ptr(), pk[1].data_ptr(), b1_.data_ptr(), w2r_.data_ptr(),
+            b2r_.data_ptr(), w3r_.data_ptr(), b3r_.data_ptr(), w2c_.data_ptr(), b2c_.data_ptr(), w3c_.data_ptr(),
+            b3c_.data_ptr(), td.data_ptr() if td is not None else None,
+            node_cls.data_ptr() if td is not None else None, B, N, T, Hd, R, c1, rel.data_ptr(), conn.data_ptr(),
+            gm.data_ptr() if want_gate_mean else None)
+        _lib.check(st, "egtr_rel_head_forward_bf16p")
+        return rel, conn.unsqueeze(-1), gm
+    uq_, uk_ = tables
     st = lib.egtr_rel_head_forward_bf16w(
         _stream(), gq.data_ptr(), gk.data_ptr(), uq_.data_ptr(), uk_.data_ptr(), b1_.data_ptr(), w2r_.data_ptr(),
         b2r_.data_ptr(), w3r_.data_ptr(), b3r_.data_ptr(), w2c_.data_ptr(), b2c_.data_ptr(), w3c_.data_ptr(),

@@ -515,6 +515,22 @@ int egtr_rel_head_forward_bf16w(egtr_stream_t stream, const float* gate_q, const
                                 int num_rel, int num_cls_plus1, float* rel_logits, float* conn_logits,
                                 float* gate_mean);
 
+/* The same forward with ALL three layers on the bf16 matrix cores (csrc/rel_head_bf16.hip): the gated sum over the slots
+ * (egtr.py:386-401) is a matrix product too -- per 32 pairs (4 subjects x 8 objects) twelve K = 16 steps, one per
+ * per-query row set, with the gates as the other operand -- W2 of a workgroup's MLP stays in LDS, and the relation tile is
+ * stored straight from the accumulators.  uq_packed / uk_packed: the per-query tables rounded to bf16 and packed in operand
+ * order by egtr_rel_head_pack_tables_bf16 -- (batch * num_query) rows of [mlp 2][channel tile 8][half 2][channel 32][8 slots]
+ * bfloat16 (16 KiB per row; slot = 8 half + e, zero for slots >= num_slots).  num_slots <= 10, hidden == 256, num_rel <= 64. */
+int egtr_rel_head_pack_tables_bf16(egtr_stream_t stream, const void* u /* [rows, num_slots, 512] fp32, or bf16 bits */,
+                                   int u_is_bf16, int rows, int num_slots, uint16_t* packed);
+int egtr_rel_head_forward_bf16p(egtr_stream_t stream, const float* gate_q, const float* gate_k,
+                                const uint16_t* uq_packed, const uint16_t* uk_packed, const float* b1,
+                                const uint16_t* w2r, const float* b2r, const uint16_t* w3r, const float* b3r,
+                                const uint16_t* w2c, const float* b2c, const uint16_t* w3c, const float* b3c,
+                                const float* triplet_dist, const int64_t* node_cls, int batch, int num_query,
+                                int num_slots, int hidden, int num_rel, int num_cls_plus1, float* rel_logits,
+                                float* conn_logits, float* gate_mean);
+
 /* Token-sized nn.Linear, y[M, N] (row stride ldy) = act(x[M, K] (row stride ldx) . W[N, K]^T + bias): fp32 in, fp32 out,
  * fp32-level accuracy, evaluated on the bf16 matrix cores from exact three-way bf16 splits of both operands (six cross
  * terms, fp32 accumulation; csrc/gemm_split.hip).  Replaces the vendor fp32 GEMM behind the reference's encoder

@@ -485,16 +485,24 @@ def test_relation_head_split_weights_sum_to_the_fp32_weights():
     assert ((rec - w).abs() <= w.abs() * 2.0 ** -23).all()
 
 
-@pytest.mark.parametrize("B,N,T,R", [(1, 200, 7, 50), (2, 24, 4, 7), (1, 33, 9, 64), (1, 7, 1, 1), (2, 300, 9, 50)])
-def test_relation_head_forward_bf16_matrix_cores(B, N, T, R):
-    """bf16-weight forward (layers 2 / 3 on v_mfma_f32_32x32x16_bf16) against the fp64 restatement evaluated with the
-    same bf16-rounded weights.  What differs is the bf16 rounding of the hidden activations as matrix operands:
-    tolerance 3e-2 absolute on logits of magnitude ~1-4 and 5e-3 relative Frobenius (a fragment-layout mistake is O(1))."""
+@pytest.mark.parametrize("packed", [True, False])
+@pytest.mark.parametrize("B,N,T,R", [(1, 200, 7, 50), (2, 24, 4, 7), (1, 33, 9, 64), (1, 7, 1, 1), (2, 300, 9, 50),
+                                     (3, 13, 10, 33)])
+def test_relation_head_forward_bf16_matrix_cores(B, N, T, R, packed, monkeypatch):
+    """bf16-weight forward against the fp64 restatement evaluated with the same bf16-rounded weights AND bf16-rounded
+    per-query tables (a bf16 model produces uq / uk in bf16; both kernels get the rounded values, the packed one as a bf16
+    tensor).  packed: all three layers on v_mfma_f32_32x32x16_bf16 (rel_head_fwd_bf16p: tables in operand order, gates
+    rounded to bf16 as an operand, ragged 4 x 8 pair tiles at N = 33 / 7 / 13 / 300); not packed: fp32 VALU layer 1
+    (rel_head_fwd_bf16w).  What differs from the restatement is the bf16 rounding of operands: tolerance 3e-2 absolute on
+    logits of magnitude ~1-4 and 5e-3 relative Frobenius (a fragment-layout mistake is O(1))."""
     import cpu_kernels as ck
+    from egtr_amd import ops
     from egtr_amd.ops import relation_head_bf16w
+    monkeypatch.setattr(ops, "REL_HEAD_BF16_PACKED", packed)
     d, trip, node = _head_inputs(160 + N, B, N, T, R, 11)
     wnames = ("w2r", "w3r", "w2c", "w3c")
-    dd = {k: (v.to(DEV).bfloat16() if k in wnames else v.to(DEV)) for k, v in d.items()}
+    d["uq"], d["uk"] = d["uq"].bfloat16().float(), d["uk"].bfloat16().float()
+    dd = {k: (v.to(DEV).bfloat16() if k in wnames or (packed and k in ("uq", "uk")) else v.to(DEV)) for k, v in d.items()}
     rel, conn, gm = relation_head_bf16w(*dd.values(), trip.to(DEV), node.to(DEV), True)
     d64 = {k: (v.bfloat16().double() if k in wnames else v.double()) for k, v in d.items()}
     rrel, rconn, rgm = ck.relation_head(*d64.values(), trip.double(), node, True)
