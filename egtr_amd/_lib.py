@@ -73,6 +73,10 @@ SIGNATURES = {
     "egtr_relation_loss_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I, _I, _P, _P, _P, _P],
     "egtr_relation_loss_workspace_bytes": [_I, _I],
     "egtr_rel_head_forward_bf16w": [_P] * 16 + [_I] * 6 + [_P] * 3,
+    "egtr_ffn_layernorm_bf16": [_P] * 7 + [ctypes.c_float, _P, _I, _P, _P, _I, _I, _I],
+    "egtr_ffn_pack_weights_bf16": [_P, _P, _P, _I, _I, _P],
+    "egtr_ffn_packed_weights_bytes": [_I],
+    "egtr_linear_bf16": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, ctypes.c_float],
     "egtr_rel_head_forward_bf16p": [_P] * 16 + [_I] * 6 + [_P] * 3,
     "egtr_rel_head_pack_tables_bf16": [_P, _P, _I, _I, _I, _P],
     "egtr_linear_split_bf16_f32": [_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I],
@@ -105,6 +109,7 @@ SIGNATURES = {
     "egtr_decoder_layer_workspace": [_I, _I, _P, _P, _P],
 }
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p,
+             "egtr_ffn_packed_weights_bytes": ctypes.c_longlong,
              "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong,
              "egtr_relation_loss_workspace_bytes": ctypes.c_longlong,
              "egtr_column_sum_workspace_floats": ctypes.c_longlong,

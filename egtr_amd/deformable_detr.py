@@ -685,6 +685,21 @@ class DeformableDetrEncoderLayer(nn.Module):
             if return_with_pos:
                 outputs += (next_with_pos,)
             return outputs
+        if (self.activation_fn is F.relu and not self.training
+                and ops.ffn_bf16_supported(hidden_states, self.fc1, self.fc2, self.final_layer_norm)):
+            # bf16 model at inference: the same block on the bf16 matrix cores, one launch (csrc/ffn_bf16.hip)
+            next_with_pos = None
+            if (return_with_pos and position_embeddings is not None and position_embeddings.dtype == torch.bfloat16):
+                hidden_states, next_with_pos = ops.ffn_layernorm_bf16(hidden_states, self.fc1, self.fc2, self.final_layer_norm,
+                                                                      _pos_rows(position_embeddings))
+            else:
+                hidden_states = ops.ffn_layernorm_bf16(hidden_states, self.fc1, self.fc2, self.final_layer_norm)
+            outputs = (hidden_states,)
+            if output_attentions:
+                outputs += (attn_weights,)
+            if return_with_pos:
+                outputs += (next_with_pos,)
+            return outputs
         if self.activation_fn is F.relu:
             hidden_states = ops.module_linear(self.fc1, hidden_states, relu=True)
         else:

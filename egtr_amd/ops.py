@@ -280,6 +280,11 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
     rows = x.numel() // x.shape[-1]
     if x.is_cuda and x.dtype == torch.float32 and rows <= SKINNY_MAX_ROWS and x.shape[-1] % 64 == 0:
         return SkinnyLinearFunction.apply(x, weight, bias, alpha, relu)
+    if (LINEAR_BF16 and x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+            and rows <= LINEAR_BF16_MAX_ROWS and x.shape[-1] % 16 == 0 and weight.shape[0] % 32 == 0
+            and (bias is None or bias.dtype == torch.bfloat16)
+            and not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad))):
+        return linear_bf16(x, weight, bias, relu, alpha)
     if (relu and alpha == 1.0 and bias is not None and x.is_cuda and not torch.is_grad_enabled()
             and hasattr(torch, "_addmm_activation")):
         # token-sized GEMM with the ReLU in the hipBLASLt epilogue (saves one pass over the [S, 1024] activation)
@@ -293,6 +298,80 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
     if alpha != 1.0:
         y = y * alpha
     return torch.relu(y) if relu else y
+
+
+# bf16 models: the encoder layer's feed-forward block + residual + LayerNorm (+ position rows) in one launch
+# (csrc/ffn_bf16.hip).  "0": two vendor GEMMs + the LayerNorm launch.
+FFN_BF16_FUSED = os.environ.get("EGTR_FFN_BF16_FUSED", "1") != "0"
+
+
+def ffn_bf16_supported(x, fc1, fc2, ln):
+    return (FFN_BF16_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.shape[-1] == 256
+            and all(t.dtype == torch.bfloat16 for t in (fc1.weight, fc2.weight, ln.weight))
+            and fc1.bias is not None and fc2.bias is not None and tuple(fc1.weight.shape)[1] == 256
+            and tuple(fc2.weight.shape) == (256, fc1.weight.shape[0]) and fc1.weight.shape[0] % 32 == 0
+            and fc1.weight.shape[0] <= 1024 and tuple(ln.weight.shape) == (256,))
+
+
+def ffn_layernorm_bf16(x, fc1, fc2, ln, pos=None):
+    """LayerNorm(x + fc2(relu(fc1(x)))) for a bf16 model in one launch (egtr_ffn_layernorm_bf16); with ``pos`` ([rows_p, 256]
+    bf16, tiled over the rows) also returns the bf16 sum of the result and the position rows.  Inference only."""
+    lib = _lib.lib()
+    x2 = _chk(x.reshape(-1, 256).contiguous(), "x", torch.bfloat16)
+    F_ = fc1.weight.shape[0]
+
+    def pack():
+        w1 = _chk(fc1.weight.detach().contiguous(), "fc1.weight", torch.bfloat16)
+        w2 = _chk(fc2.weight.detach().contiguous(), "fc2.weight", torch.bfloat16)
+        out = torch.empty(int(lib.egtr_ffn_packed_weights_bytes(F_)) // 2, dtype=torch.bfloat16, device=w1.device)
+        _lib.check(lib.egtr_ffn_pack_weights_bf16(_stream(), w1.data_ptr(), w2.data_ptr(), 256, F_, out.data_ptr()),
+                   "egtr_ffn_pack_weights_bf16")
+        return out
+
+    wpk = cached_weights(fc1, "ffn_bf16_packed", [fc1.weight, fc2.weight], pack)
+    ts = [wpk] + [_chk(t.detach().contiguous(), n, torch.bfloat16)
+                  for t, n in ((fc1.bias, "fc1.bias"), (fc2.bias, "fc2.bias"), (ln.weight, "ln.weight"), (ln.bias, "ln.bias"))]
+    M = x2.shape[0]
+    y = torch.empty_like(x2)
+    yp = p2 = None
+    prow = 1
+    if pos is not None:
+        p2 = _chk(pos.reshape(-1, 256).contiguous(), "pos", torch.bfloat16)
+        prow = p2.shape[0]
+        if M % prow != 0:
+            raise ValueError("ffn_layernorm_bf16: pos must tile the rows")
+        yp = torch.empty_like(x2)
+    st = lib.egtr_ffn_layernorm_bf16(_stream(), x2.data_ptr(), *[t.data_ptr() for t in ts], float(ln.eps),
+                                     p2.data_ptr() if p2 is not None else None, prow, y.data_ptr(),
+                                     yp.data_ptr() if yp is not None else None, M, 256, fc1.weight.shape[0])
+    _lib.check(st, "egtr_ffn_layernorm_bf16")
+    y = y.view(x.shape)
+    return y if pos is None else (y, yp.view(x.shape))
+
+
+# bf16 models, object-query-sized rows (the decoder of the stress configuration: 4800 rows): csrc/linear_bf16.hip instead of the
+# vendor library, whose choice for these shapes takes 20 us per layer.  "0": F.linear.
+LINEAR_BF16 = os.environ.get("EGTR_LINEAR_BF16", "1") != "0"
+LINEAR_BF16_MAX_ROWS = 16384
+
+
+def linear_bf16(x, weight, bias=None, relu=False, alpha=1.0):
+    """act(alpha (x . W^T + b)) for bf16 tensors (egtr_linear_bf16): fp32 accumulation, one rounding of the result.
+    Inference only."""
+    lib = _lib.lib()
+    K, N = x.shape[-1], weight.shape[0]
+    x2 = _chk(x.reshape(-1, K).contiguous(), "x", torch.bfloat16)
+    w = _chk(weight.detach().contiguous(), "weight", torch.bfloat16)
+    b = _chk(bias.detach().contiguous(), "bias", torch.bfloat16) if bias is not None else None
+    if weight.shape[1] != K:
+        raise ValueError("linear_bf16: weight must be [N, K]")
+    M = x2.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    if M > 0:
+        st = lib.egtr_linear_bf16(_stream(), x2.data_ptr(), K, w.data_ptr(), b.data_ptr() if b is not None else None,
+                                  y.data_ptr(), N, M, N, K, 1 if relu else 0, float(alpha))
+        _lib.check(st, "egtr_linear_bf16")
+    return y.view(*x.shape[:-1], N)
 
 
 def column_sum(g, relu_output=None, inplace=False):

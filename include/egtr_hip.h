@@ -531,6 +531,13 @@ int egtr_rel_head_forward_bf16p(egtr_stream_t stream, const float* gate_q, const
                                 int num_slots, int hidden, int num_rel, int num_cls_plus1, float* rel_logits,
                                 float* conn_logits, float* gate_mean);
 
+/* Object-query-sized nn.Linear of a bf16 model (csrc/linear_bf16.hip): y[M, N] (row stride ldy) = act(alpha (x[M, K] (row
+ * stride ldx) . W[N, K]^T + bias)), raw bfloat16 bits in and out, fp32 accumulation on v_mfma_f32_32x32x16_bf16, the result
+ * rounded to bf16 once (after bias / scale / ReLU; alpha = the attention scaling of q_proj, deformable_detr.py:1166).  bias
+ * may be NULL.  K % 16 == 0, N % 32 == 0, ldx % 8 == 0, x / weight 16-byte aligned. */
+int egtr_linear_bf16(egtr_stream_t stream, const uint16_t* x, int ldx, const uint16_t* weight, const uint16_t* bias,
+                     uint16_t* y, int ldy, int M, int N, int K, int relu, float alpha);
+
 /* Token-sized nn.Linear, y[M, N] (row stride ldy) = act(x[M, K] (row stride ldx) . W[N, K]^T + bias): fp32 in, fp32 out,
  * fp32-level accuracy, evaluated on the bf16 matrix cores from exact three-way bf16 splits of both operands (six cross
  * terms, fp32 accumulation; csrc/gemm_split.hip).  Replaces the vendor fp32 GEMM behind the reference's encoder
@@ -626,6 +633,20 @@ int egtr_xs_split_f32(egtr_stream_t stream, const float* x, int ldx, const float
 int egtr_ffn_x6_f32(egtr_stream_t stream, const float* x, int ldx, const void* w1_xs, const float* b1, const void* w2_xs,
                     const float* b2, const float* ln_gamma, const float* ln_beta, float eps, const float* pos,
                     int pos_rows, float* out, float* out_pos, int M, int d_model, int ffn_dim);
+
+/* The feed-forward block of a bf16 model in one launch (csrc/ffn_bf16.hip): y = LayerNorm(x + fc2(relu(fc1(x)))) and
+ * optionally y_pos = y + pos[row % pos_rows], raw bfloat16 bits everywhere, fp32 accumulation on v_mfma_f32_32x32x16_bf16,
+ * intermediate roundings where the reference's bf16 tensors have them (fc1 output, fc2 output, residual sum, y before + pos).
+ * The [M, ffn_dim] activation never leaves the registers.  w_packed: both weight matrices in operand order, written once per
+ * weight version by egtr_ffn_pack_weights_bf16 from the nn.Linear layouts w1 [ffn_dim, 256], w2 [256, ffn_dim]
+ * (egtr_ffn_packed_weights_bytes(ffn_dim) bytes = 2 * 256 * ffn_dim * 2).  d_model == 256, ffn_dim % 32 == 0 and <= 1024,
+ * 16-byte aligned tensors; pos and y_pos both NULL or both set.  Inference only. */
+long long egtr_ffn_packed_weights_bytes(int ffn_dim);
+int egtr_ffn_pack_weights_bf16(egtr_stream_t stream, const uint16_t* w1, const uint16_t* w2, int d_model, int ffn_dim,
+                               uint16_t* packed);
+int egtr_ffn_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* w_packed, const uint16_t* b1,
+                            const uint16_t* b2, const uint16_t* gamma, const uint16_t* beta, float eps, const uint16_t* pos,
+                            int pos_rows, uint16_t* y, uint16_t* y_pos, int M, int d_model, int ffn_dim);
 
 /* The whole TAIL of an encoder layer in one launch (csrc/ffn_x6.hip, ffn_x6_kernel<true>):
  *   y1  = LayerNorm1(hidden + context . Wp^T + bp)                 (output_proj + self_attn_layer_norm, dd:1102, 1326-1330)

@@ -1597,3 +1597,54 @@ def test_linear_split_bf16_grouped_adds_position_rows_on_load():
     want = ops.linear_split_bf16_grouped([dict(x=x, wt=wts[0], N=256, b=bs[0]), dict(x=x + pos, wt=wts[1], N=384, b=bs[1])])
     got = ops.linear_split_bf16_grouped([dict(x=x, wt=wts[0], N=256, b=bs[0]), dict(x=x, wt=wts[1], N=384, b=bs[1], pos=pos)])
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+
+
+@pytest.mark.parametrize("M,K,N,relu,bias", [(4800, 256, 256, False, True), (4800, 256, 1024, True, True), (4800, 1024, 256, False, True),
+                                            (37, 256, 384, False, True), (1, 16, 32, True, False), (333, 48, 96, False, True)])
+def test_linear_bf16_small_rows(M, K, N, relu, bias):
+    """egtr_linear_bf16 (object-query-sized linears of a bf16 model) against the fp64 product of the same bf16 operands: fp32
+    accumulation and ONE rounding of the result (half a bf16 ulp); ragged row tiles, N = 32 (one column tile) and K tails."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16() if bias else None
+    want = x.double() @ w.double().t() + (b.double() if bias else 0.0)
+    if relu:
+        want = want.relu()
+    with torch.no_grad():
+        got = ops.linear(x.to(DEV).view(1, M, K), w.to(DEV), b.to(DEV) if bias else None, relu=relu)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (1, M, N)
+    err = (got[0].cpu().double() - want).abs() / want.abs().clamp_min(1.0)
+    assert float(err.max()) < 2.0 ** -8 + 1e-4
+
+
+@pytest.mark.parametrize("M,F,prow", [(256, 1024, 256), (700, 1024, 350), (33, 64, 0), (22223, 1024, 22223), (5, 32, 5)])
+def test_ffn_layernorm_bf16_fused(M, F, prow):
+    """egtr_ffn_layernorm_bf16 (fc1 + ReLU + fc2 + residual + LayerNorm (+ position rows) of a bf16 model, one launch) against
+    (a) the torch bf16 composition of the same modules -- same rounding points, different accumulation order: within 2 bf16
+    ulps of an O(1) LayerNorm output, and (b) the fp64 block: a looser bound that a layout mistake (O(1)) cannot meet."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(M + F)
+    fc1, fc2, ln = torch.nn.Linear(256, F), torch.nn.Linear(F, 256), torch.nn.LayerNorm(256)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(256, generator=g)); ln.bias.copy_(0.2 * torch.randn(256, generator=g))
+        fc1.bias.copy_(0.3 * torch.randn(F, generator=g)); fc2.bias.copy_(0.3 * torch.randn(256, generator=g))
+    fc1, fc2, ln = fc1.to(DEV).bfloat16(), fc2.to(DEV).bfloat16(), ln.to(DEV).bfloat16()
+    x = torch.randn(1, M, 256, generator=g).bfloat16().to(DEV)
+    pos = torch.randn(prow, 256, generator=g).bfloat16().to(DEV) if prow else None
+    with torch.no_grad():
+        assert ops.ffn_bf16_supported(x, fc1, fc2, ln)
+        out = ops.ffn_layernorm_bf16(x, fc1, fc2, ln, pos)
+        y, yp = out if prow else (out, None)
+        want = ln(x + fc2(torch.relu(fc1(x))))
+        x64 = x.double()
+        h64 = torch.relu(x64 @ fc1.weight.double().t() + fc1.bias.double())
+        w64 = torch.nn.functional.layer_norm(x64 + h64 @ fc2.weight.double().t() + fc2.bias.double(), (256,),
+                                             ln.weight.double(), ln.bias.double(), ln.eps)
+    assert y.dtype == torch.bfloat16 and y.shape == x.shape
+    scale = want.float().abs().clamp_min(1.0)
+    assert float(((y.float() - want.float()).abs() / scale).max()) < 2.0 ** -6
+    assert float(((y.double() - w64).abs() / w64.abs().clamp_min(1.0)).max()) < 3e-2
+    if prow:
+        assert torch.equal(yp, y + pos.repeat(M // prow, 1).view(1, M, 256))
