@@ -37,6 +37,7 @@ constexpr int kD = 256;       // d_model
 constexpr int kWaves = 4;     // one wave per SIMD: 512 registers each (the 2 x 8 x 16 fc2 accumulators alone are 256)
 constexpr int kRB = 2;        // 32-row blocks per wave: every weight fragment read from LDS feeds two products
 constexpr int kRowsWg = 32 * kRB * kWaves;
+constexpr int kLds = 128 * 1024;     // two weight slices (64 KiB) during the products; the 256 x 256 bf16 output tile behind them
 constexpr int kSlice = 32 * 1024;   // one hidden tile: W1 [16 k steps][64 lanes] + W2 [8 channel tiles][2 k steps][64 lanes], 16 B each
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
@@ -272,9 +273,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 
   // row (two lanes per bank pair: the two passes 512 bytes need anyway), read back a ROW per instruction -- 64 lanes x 8 bytes
   // = the 512 contiguous bytes of a row of y, and of pos / y_pos (round 5: 8-byte pieces at a 512-byte stride, 32 lines per
   // instruction, made the epilogue half of the kernel: 165 k of 326 k cycles per workgroup).
-  char* const s_out = s_w + wave * (32 * 512);
+  char* const s_out_w = s_w + wave * (kRB * 32 * 512);   // both row blocks of the wave (the dynamic LDS is 128 KiB for this)
   auto epilogue = [&](auto RB) {
     constexpr int rb = decltype(RB)::value;
+    char* const s_out = s_out_w + rb * (32 * 512);
     FFN_T(e_0);
     float sum = 0.f;
 #pragma unroll
@@ -329,35 +331,46 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 
         *reinterpret_cast<uint2*>(s_out + li * 512 + slot * 8) = make_uint2(o01, o23);
       }
     FFN_T(e_b);
-    // rows out: lane = 8-byte channel group `lane` of row r
-    const int rbase = row0 + 32 * rb;
-    auto row_out = [&](int r, uint2 pv) {
-      if (rbase + r < A.M) {
-        const uint2 yv = *reinterpret_cast<const uint2*>(s_out + r * 512 + ((lane ^ r) & 63) * 8);
-        const size_t off = (size_t)(rbase + r) * kD + 4 * lane;
-        *reinterpret_cast<uint2*>(A.y + off) = yv;
-        if (A.y_pos != nullptr)
-          *reinterpret_cast<uint2*>(A.y_pos + off) = make_uint2(pk_bf16(lo_bf(yv.x) + lo_bf(pv.x), hi_bf(yv.x) + hi_bf(pv.x)),
-                                                                pk_bf16(lo_bf(yv.y) + lo_bf(pv.y), hi_bf(yv.y) + hi_bf(pv.y)));
-      }
-    };
-    // position rows: 16 requests in flight (4 at a time left a DRAM round trip exposed per group: 60 k cycles per workgroup)
-#pragma unroll
-    for (int r0 = 0; r0 < 32; r0 += 16) {
-      uint2 pv[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        pv[u] = make_uint2(0u, 0u);
-        if (A.y_pos != nullptr)
-          pv[u] = *reinterpret_cast<const uint2*>(A.pos + (size_t)(min(rbase + r0 + u, A.M - 1) % A.pos_rows) * kD + 4 * lane);
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) row_out(r0 + u, pv[u]);
-    }
-    FFN_T(e_c);
     FFN_ADD(8, e_0, e_a);
     FFN_ADD(9, e_a, e_b);
-    FFN_ADD(10, e_b, e_c);
+  };
+  // rows out: lane = 8-byte channel group `lane` of row r.  The position rows of all 64 rows are requested BEFORE the wave issues
+  // its first store (loads and stores share one counter on this part and the compiler cannot assume they complete in order: a
+  // load issued behind a store was waited for with vmcnt(0), i.e. until every earlier store had COMPLETED -- the rows left one
+  // DRAM write round trip at a time, 72 k cycles per workgroup); then the y rows, then the y + pos rows.
+  auto rows_out = [&]() {
+    uint2 pv[kRB * 32];
+    if (A.y_pos != nullptr) {
+      // (one division per wave: the rows are consecutive, the position row advances with them and wraps)
+      const int rc0 = min(row0, A.M - 1);                 // rows behind M - 1 repeat the last valid one
+      const int p0 = rc0 % A.pos_rows;
+      const unsigned short* pl = A.pos + 4 * lane;
+#pragma unroll
+      for (int u = 0; u < kRB * 32; ++u) {
+        int p = p0 + (min(row0 + u, A.M - 1) - rc0);
+        if (A.pos_rows >= kRB * 32) p -= p >= A.pos_rows ? A.pos_rows : 0;
+        else p %= A.pos_rows;
+        pv[u] = *reinterpret_cast<const uint2*>(pl + (size_t)p * kD);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRB * 32; ++r) {
+      if (row0 + r < A.M) {
+        const uint2 yv = *reinterpret_cast<const uint2*>(s_out_w + r * 512 + ((lane ^ (r & 31)) & 63) * 8);
+        *reinterpret_cast<uint2*>(A.y + (size_t)(row0 + r) * kD + 4 * lane) = yv;
+      }
+    }
+    if (A.y_pos != nullptr) {
+#pragma unroll
+      for (int r = 0; r < kRB * 32; ++r) {
+        if (row0 + r < A.M) {
+          const uint2 yv = *reinterpret_cast<const uint2*>(s_out_w + r * 512 + ((lane ^ (r & 31)) & 63) * 8);
+          *reinterpret_cast<uint2*>(A.y_pos + (size_t)(row0 + r) * kD + 4 * lane) =
+              make_uint2(pk_bf16(lo_bf(yv.x) + lo_bf(pv[r].x), hi_bf(yv.x) + hi_bf(pv[r].x)),
+                         pk_bf16(lo_bf(yv.y) + lo_bf(pv[r].y), hi_bf(yv.y) + hi_bf(pv[r].y)));
+        }
+      }
+    }
   };
   FFN_T(t_epi);
 #ifdef EGTR_FFN_ABL_NO_EPI
@@ -366,6 +379,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 
   {
     epilogue(std::integral_constant<int, 0>{});
     if constexpr (kRB > 1) epilogue(std::integral_constant<int, 1>{});
+    FFN_T(e_r);
+    rows_out();
+    FFN_T(e_s);
+    FFN_ADD(10, e_r, e_s);
   }
 #ifdef EGTR_FFN_TIMING
   __builtin_amdgcn_s_waitcnt(0);
@@ -422,8 +439,8 @@ extern "C" int egtr_ffn_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, 
   A.x = x; A.wpk = reinterpret_cast<const uint4*>(w_packed); A.b1 = b1; A.b2 = b2; A.gamma = gamma; A.beta = beta;
   A.pos = pos; A.y = y; A.y_pos = y_pos; A.M = M; A.F = ffn_dim; A.pos_rows = pos != nullptr ? pos_rows : 1; A.eps = eps;
   static unsigned long long raised = 0;
-  if (int e = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(&ffn_bf16_kernel), 2 * kSlice, &raised)) return e;
+  if (int e = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(&ffn_bf16_kernel), kLds, &raised)) return e;
   const dim3 grid((unsigned)((M + kRowsWg - 1) / kRowsWg));
-  hipLaunchKernelGGL(ffn_bf16_kernel, grid, dim3(64 * kWaves), 2 * kSlice, static_cast<hipStream_t>(stream), A);
+  hipLaunchKernelGGL(ffn_bf16_kernel, grid, dim3(64 * kWaves), kLds, static_cast<hipStream_t>(stream), A);
   return egtr_check_launch();
 }

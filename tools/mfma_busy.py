@@ -15,7 +15,10 @@ import sqlite3
 
 KERNELS = {"ffn_x6_kernel": "ffn_x6_kernel<true", "proj_x6_kernel": "proj_x6_kernel",
            "gemm_split_bf16_f32": "gemm_split_bf16_f32", "rel_head_fwd_x6": "rel_head_fwd_x6",
-           "wgrad_split_bf16_f32": "wgrad_split_bf16_f32", "enc_bwd_x6": "enc_bwd"}
+           "wgrad_split_bf16_f32": "wgrad_split_bf16_f32", "enc_bwd_x6": "enc_bwd",
+           # bf16 model (stress workload, tools/profile_r05_stress.sh)
+           "rel_head_fwd_bf16p": "rel_head_fwd_bf16p", "ffn_bf16_kernel": "ffn_bf16_kernel",
+           "linear_bf16_rows32": "linear_bf16_rows32"}
 NEED = ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_MFMA", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY")
 
 

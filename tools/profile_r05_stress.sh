@@ -7,13 +7,21 @@ tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout 600 rocprofv3 --kernel-trace -d gpurun_out/prof_stress -o st -- python3 tools/stress_bench.py --iters 4 > gpurun_out/${tag}_stress_run.log 2>&1
-python3 tools/forward_breakdown.py gpurun_out/prof_stress/st_results.db 16 > gpurun_out/${tag}_stress_forward_breakdown.txt 2>&1
+python3 tools/forward_breakdown.py gpurun_out/prof_stress/st_results.db 24 > gpurun_out/${tag}_stress_forward_breakdown.txt 2>&1
 rm -rf gpurun_out/prof_stress
 bash tools/pmc_passes.sh gpurun_out/pmc_stress_${tag} stress mem -- python3 tools/stress_bench.py --iters 2 > gpurun_out/${tag}_stress_pmc_passes.log 2>&1
 # algorithmic bytes of one encoder launch at B = 16: S = Lq = 22223, bf16 value + out, bf16 raw offsets / logits (fused entry)
 python3 tools/msda_pmc.py gpurun_out/pmc_stress_${tag} --kernel-regex 'msda_fwd_q32_bf16<true' --name 'msda_fwd_q32_bf16<fused prologue>' \
     --alg-bytes 637177856 --min-grid 1000000 --out gpurun_out/${tag}_msda_bf16_pmc.json > gpurun_out/${tag}_msda_bf16_pmc.txt 2>&1
 find gpurun_out/pmc_stress_${tag} -name "*.db" -delete
+# matrix-pipe busy of the bf16 matrix kernels of the stress forward (relation head, fused feed-forward, small-row linears)
+mkdir -p gpurun_out/pmc_stress_mfma_${tag}
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY \
+    -d gpurun_out/pmc_stress_mfma_${tag}/mfma1 -o pmc -- python3 tools/stress_bench.py --iters 2 > gpurun_out/pmc_stress_mfma_${tag}/mfma1.log 2>&1
+echo "stress mfma pass: rc=$?"
+python3 tools/mfma_busy.py gpurun_out/pmc_stress_mfma_${tag} --out gpurun_out/${tag}_stress_mfma_pmc.json > gpurun_out/${tag}_stress_mfma_pmc.txt 2>&1
+find gpurun_out/pmc_stress_mfma_${tag} -name "*.db" -delete
+tail -8 gpurun_out/${tag}_stress_mfma_pmc.txt
 cat gpurun_out/${tag}_stress_forward_breakdown.txt | cut -c1-180
 tail -30 gpurun_out/${tag}_msda_bf16_pmc.txt
 tail -5 gpurun_out/${tag}_stress_run.log
