@@ -272,6 +272,42 @@ def time_decoder_layer(model, pv, pm, forwards=20):
     return ts[len(ts) // 2], len(evs) // forwards
 
 
+def time_lib_entries(names, run, forwards=3):
+    """Median duration (us) of the launches of the C entries `names` during `forwards` eager calls of `run()`: HIP events on
+    torch's current stream around every call; {name: (us, launches per forward)} for the entries that were called."""
+    from egtr_amd import _lib
+    lib = _lib.lib()
+    raws, evs = {}, {n: [] for n in names}
+
+    def wrap(name, raw):
+        def wrapped(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st = raw(*a)
+            e1.record()
+            evs[name].append((e0, e1))
+            return st
+        return wrapped
+
+    for n in names:
+        raws[n] = getattr(lib, n)
+        setattr(lib, n, wrap(n, raws[n]))
+    try:
+        with torch.no_grad():
+            for _ in range(forwards):
+                run()
+        torch.cuda.synchronize()
+    finally:
+        for n, r in raws.items():
+            setattr(lib, n, r)
+    out = {}
+    for n, ev in evs.items():
+        if ev:
+            ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev[len(ev) // 3:])
+            out[n] = (ts[len(ts) // 2], len(ev) // forwards)
+    return out
+
+
 def msda_kernel_name(fused):
     from egtr_amd import ops
     name = getattr(ops, "MSDA_ENCODER_KERNEL", "msda_fwd_q64_f32")
@@ -549,6 +585,44 @@ def stress_bench(dev, steps, warmup, batch=16):
         if sp:
             out["roofline"].update(traffic=sp.get("hbm_bytes_per_launch"), l2_hit=sp.get("l2_hit"),
                                    l1_gather_bytes=sp.get("l1_gather_bytes"), traffic_source=sp_src)
+    # the bf16 matrix kernels of this forward, timed live (eager forwards, HIP events around each launch), priced against the
+    # dense bf16 MFMA peak on their ALGORITHMIC flops; matrix-pipe busy from the newest profiles/r*_stress_mfma_pmc.json
+    S = msda_args[0].shape[1] if msda_args is not None else 0
+    times = time_lib_entries(["egtr_ffn_layernorm_bf16", "egtr_rel_head_forward_bf16p"],
+                             lambda: model(pixel_values=pv, pixel_mask=pm, output_attentions=False,
+                                           output_attention_states=True, output_hidden_states=False))
+    busy = {}
+    try:
+        import glob
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_stress_mfma_pmc.json")), key=os.path.getmtime)
+        if paths:
+            busy = json.load(open(paths[-1]))
+            busy["_src"] = "profiles/" + os.path.basename(paths[-1])
+    except Exception:
+        busy = {}
+    kernels = []
+    nq, T, R = cfg.num_queries, cfg.decoder_layers + 1, cfg.num_rel_labels if hasattr(cfg, "num_rel_labels") else 50
+    specs = {
+        "egtr_ffn_layernorm_bf16": ("ffn_bf16_kernel", f"encoder layer: fc1 + ReLU + fc2 + residual + LayerNorm (+ position rows), "
+                                    f"M = {batch} x {S} rows, 256 -> {cfg.encoder_ffn_dim} -> 256",
+                                    2.0 * batch * S * 256 * cfg.encoder_ffn_dim * 2),
+        "egtr_rel_head_forward_bf16p": ("rel_head_fwd_bf16p", f"relation + connectivity heads, B = {batch}, N = {nq}, T = {T} slots",
+                                        2.0 * batch * nq * nq * (2 * T * 512 + 2 * 256 * 256 + 256 * (R + 1))),
+    }
+    for entry, (kname, launch, flops) in specs.items():
+        if entry in times:
+            us, n = times[entry]
+            tf = flops / (us * 1e-6) / 1e12
+            e = {"bound": "mfma", "kernel": kname, "launch": f"{launch}; {n} launches per forward", "achieved": round(tf, 1),
+                 "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                 "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 1)}
+            b = busy.get("kernels", {}).get(kname) if isinstance(busy, dict) else None
+            if isinstance(b, dict):
+                e["mfma_busy"] = b.get("mfma_busy")
+                e["mfma_busy_source"] = busy.get("_src")
+            kernels.append(e)
+    if kernels:
+        out["roofline_kernels"] = ([out["roofline"]] if "roofline" in out else []) + kernels
     del fwd, model
     torch.cuda.empty_cache()
     return out

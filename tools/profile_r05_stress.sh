@@ -16,8 +16,8 @@ python3 tools/msda_pmc.py gpurun_out/pmc_stress_${tag} --kernel-regex 'msda_fwd_
 find gpurun_out/pmc_stress_${tag} -name "*.db" -delete
 # matrix-pipe busy of the bf16 matrix kernels of the stress forward (relation head, fused feed-forward, small-row linears)
 mkdir -p gpurun_out/pmc_stress_mfma_${tag}
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY \
-    -d gpurun_out/pmc_stress_mfma_${tag}/mfma1 -o pmc -- python3 tools/stress_bench.py --iters 2 > gpurun_out/pmc_stress_mfma_${tag}/mfma1.log 2>&1
+timeout 1200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY \
+    -d gpurun_out/pmc_stress_mfma_${tag}/mfma1 -o pmc -- python3 tools/stress_bench.py --iters 1 > gpurun_out/pmc_stress_mfma_${tag}/mfma1.log 2>&1
 echo "stress mfma pass: rc=$?"
 python3 tools/mfma_busy.py gpurun_out/pmc_stress_mfma_${tag} --out gpurun_out/${tag}_stress_mfma_pmc.json > gpurun_out/${tag}_stress_mfma_pmc.txt 2>&1
 find gpurun_out/pmc_stress_mfma_${tag} -name "*.db" -delete

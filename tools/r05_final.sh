@@ -1,19 +1,17 @@
 #!/bin/bash
-# The default bench command (untraced) -> gpurun_out/r05_bench.json, then the stress workload's MSDA (bf16) memory counters.
+# The default bench command (untraced) -> gpurun_out/r05_bench.json, then the matrix-pipe counters of the stress forward's bf16
+# matrix kernels (one rocprofv3 --pmc pass over tools/stress_bench.py).  The stress MSDA memory counters and the forward breakdown
+# come from tools/profile_r05_stress.sh.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 python3 bench.py > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err
 cut -c1-900 gpurun_out/r05_bench.json
 tail -5 gpurun_out/r05_bench.err
-mkdir -p gpurun_out/pmc_stress_r05b
-i=0
-for ctrs in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
-  i=$((i+1))
-  timeout 400 rocprofv3 --kernel-trace --pmc $ctrs -d gpurun_out/pmc_stress_r05b/stress_mem$i -o pmc -- python3 tools/stress_bench.py --iters 2 > gpurun_out/pmc_stress_r05b/stress_mem$i.log 2>&1
-  echo "stress pass $i ($ctrs): rc=$?"
-done
-python3 tools/msda_pmc.py gpurun_out/pmc_stress_r05b --kernel-regex 'msda_fwd_q32_bf16<true' --name 'msda_fwd_q32_bf16<fused prologue>' \
-    --alg-bytes 637177856 --min-grid 1000000 --out gpurun_out/r05_msda_bf16_pmc.json > gpurun_out/r05_msda_bf16_pmc.txt 2>&1
-find gpurun_out/pmc_stress_r05b -name "*.db" -delete
-tail -14 gpurun_out/r05_msda_bf16_pmc.txt
+mkdir -p gpurun_out/pmc_stress_mfma_r05
+timeout 1200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY \
+    -d gpurun_out/pmc_stress_mfma_r05/mfma1 -o pmc -- python3 tools/stress_bench.py --iters 1 > gpurun_out/pmc_stress_mfma_r05/mfma1.log 2>&1
+echo "stress mfma pass: rc=$?"
+python3 tools/mfma_busy.py gpurun_out/pmc_stress_mfma_r05 --out gpurun_out/r05_stress_mfma_pmc.json > gpurun_out/r05_stress_mfma_pmc.txt 2>&1
+find gpurun_out/pmc_stress_mfma_r05 -name "*.db" -delete
+tail -8 gpurun_out/r05_stress_mfma_pmc.txt
