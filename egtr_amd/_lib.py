@@ -42,6 +42,7 @@ SIGNATURES = {
     "egtr_bias_mask_rows_f32": [_P, _P, _P, _P, _I, _I, _I],
     "egtr_bias_relu_maxpool3x3s2_f32": [_P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_box_decode_argmax_f32": [_P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, _P, _P, _I, _P],
+    "egtr_scale_rows_multi_f32": [_P, _I, _P, _P, _P, _P, _P],
     "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_bias_act_nchw_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],

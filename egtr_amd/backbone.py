@@ -58,6 +58,32 @@ class DeformableDetrFrozenBatchNorm2d(nn.Module):
         return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
 
 
+class ScaleWeightsFunction(torch.autograd.Function):
+    """w_i * scale_i for ALL trainable convolutions of the backbone in one multi-tensor launch (the frozen BN's scale riding on
+    the convolution weight, Bottleneck.forward_train_fused), and their gradients scaled back in one more: 42 + 42 launches per
+    train step otherwise (aten::mul was the most frequent ATen kernel of the step, tools/train_glue_sources.py)."""
+
+    @staticmethod
+    def forward(ctx, scales, *weights):
+        from . import ops
+        ctx.scales = scales
+        return tuple(ops.scale_rows_multi([w.detach() for w in weights], scales))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        from . import ops
+        present = [i for i, g in enumerate(grads) if g is not None]
+        out = [None] * len(grads)
+        if present:
+            scaled = ops.scale_rows_multi([grads[i] for i in present], [ctx.scales[i] for i in present])
+            for i, v in zip(present, scaled):
+                out[i] = v
+        return (None, *out)
+
+
+SCALE_WEIGHTS_FUSED = os.environ.get("EGTR_BACKBONE_SCALE_FUSED", "1") != "0"
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -76,25 +102,23 @@ class Bottleneck(nn.Module):
         else:
             self.downsample = None
 
-    def forward(self, x):
+    def train_fused_applies(self, x):
+        return (TRAIN_FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and self.conv1.weight.dtype == torch.float32)
+
+    def forward(self, x, scaled=None):
         # (training path: the 1x1 convolutions stay on MIOpen -- as torch.matmul their backward through the batch
         # broadcast was measured slower, 86.8 vs 68.2 ms per bs=4 train step)
-        if (TRAIN_FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-                and self.conv1.weight.dtype == torch.float32):
-            return self.forward_train_fused(x)
+        if self.train_fused_applies(x):
+            return self.forward_train_fused(x, scaled)
         idt = x if self.downsample is None else self.downsample(x)
         y = torch.relu(self.bn1(self.conv1(x)))
         y = torch.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
         return torch.relu(y + idt)
 
-    def forward_train_fused(self, x):
-        """Training with trainable convolutions (layers 2-4): the frozen BN's scale multiplies the convolution WEIGHT under
-        autograd (a [Cout, Cin, k, k] product instead of a pass over the activation; d loss / d weight picks the scale
-        up through that product), and shift + residual + ReLU are one HIP pass forward (egtr_bias_act_nchw_f32) and one
-        mask pass backward -- instead of rsqrt / mul / sub on the statistics (5 launches per BN, every step), a
-        multiplication and an addition over the activation, the residual add, the ReLU and their three backward passes.
-        Same algebra as the folded inference path (fp32 rounding differs from scale-after-conv by ~1e-7 relative)."""
+    def train_affine(self):
+        """[(scale [C,1,1,1], shift [C])] of bn1, bn2, bn3 (, downsample BN, (None, shift3 + shift_d)): cached per buffer version."""
         from . import ops
         bns = [self.bn1, self.bn2, self.bn3] + ([self.downsample[1]] if self.downsample is not None else [])
 
@@ -109,16 +133,31 @@ class Bottleneck(nn.Module):
             return out
 
         with torch.no_grad():
-            c = ops.cached_weights(self, "bn_affine_train",
-                                   [t for bn in bns for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)], build)
+            return ops.cached_weights(self, "bn_affine_train",
+                                      [t for bn in bns for t in (bn.weight, bn.bias, bn.running_mean, bn.running_var)], build)
+
+    def train_convs(self):
+        return [self.conv1, self.conv2, self.conv3] + ([self.downsample[0]] if self.downsample is not None else [])
+
+    def forward_train_fused(self, x, scaled=None):
+        """Training with trainable convolutions (layers 2-4): the frozen BN's scale multiplies the convolution WEIGHT under
+        autograd (a [Cout, Cin, k, k] product instead of a pass over the activation; d loss / d weight picks the scale
+        up through that product), and shift + residual + ReLU are one HIP pass forward (egtr_bias_act_nchw_f32) and one
+        mask pass backward -- instead of rsqrt / mul / sub on the statistics (5 launches per BN, every step), a
+        multiplication and an addition over the activation, the residual add, the ReLU and their three backward passes.
+        Same algebra as the folded inference path (fp32 rounding differs from scale-after-conv by ~1e-7 relative)."""
+        from . import ops
+        c = self.train_affine()
+        if scaled is None:   # (one block on its own: the per-weight products; ResNet50Features hands in all blocks' at once)
+            scaled = [cv.weight * c[i][0] for i, cv in enumerate(self.train_convs())]
         idt, shift3 = x, c[2][1]
         if self.downsample is not None:
             ds = self.downsample[0]
-            idt = F.conv2d(x, ds.weight * c[3][0], None, stride=ds.stride)
+            idt = F.conv2d(x, scaled[3], None, stride=ds.stride)
             shift3 = c[4][1]
-        y = ops.bias_act(F.conv2d(x, self.conv1.weight * c[0][0]), c[0][1])
-        y = ops.bias_act(F.conv2d(y, self.conv2.weight * c[1][0], None, stride=self.conv2.stride, padding=1), c[1][1])
-        return ops.bias_act(F.conv2d(y, self.conv3.weight * c[2][0]), shift3, idt)
+        y = ops.bias_act(F.conv2d(x, scaled[0]), c[0][1])
+        y = ops.bias_act(F.conv2d(y, scaled[1], None, stride=self.conv2.stride, padding=1), c[1][1])
+        return ops.bias_act(F.conv2d(y, scaled[2]), shift3, idt)
 
     def folded_params(self):
         p = [_fold(self.conv1, self.bn1), _fold(self.conv2, self.bn2), _fold(self.conv3, self.bn3)]
@@ -249,8 +288,23 @@ class ResNet50Features(nn.Module):
         else:
             x = self.maxpool(torch.relu(self.bn1(self.conv1(x))))
             first = 1
+        blocks = [blk for li in range(first, 5) for blk in getattr(self, f"layer{li}")]
+        scaled = None
+        if SCALE_WEIGHTS_FUSED and blocks and all(b.train_fused_applies(x) for b in blocks):
+            # every trainable convolution weight times its frozen-BN scale: one multi-tensor launch (and one for the gradients)
+            ws = [cv.weight for b in blocks for cv in b.train_convs()]
+            sc = [b.train_affine()[i][0] for b in blocks for i in range(len(b.train_convs()))]
+            flat = ScaleWeightsFunction.apply(sc, *ws)
+            scaled, o = [], 0
+            for b in blocks:
+                n = len(b.train_convs())
+                scaled.append(list(flat[o:o + n]))
+                o += n
+        bi = 0
         for li in range(first, 5):
-            x = getattr(self, f"layer{li}")(x)
+            for blk in getattr(self, f"layer{li}"):
+                x = blk(x, scaled[bi]) if scaled is not None else blk(x)
+                bi += 1
             if li in self.out_indices:
                 feats.append(x)
         return feats

@@ -835,6 +835,64 @@ extern "C" int egtr_input_proj_groupnorm_flatten_bf16(egtr_stream_t stream, int 
                                   level_hw, batch, channels, num_groups, eps, stats, out, true);
 }
 
+// ---- many weight tensors x per-row scales in ONE launch ------------------------------------------------------------------
+// out_t[r, :] = w_t[r, :] * scale_t[r] for up to 64 tensors (the frozen-BN scale riding on every trainable convolution weight
+// of the backbone, and the same product on the weight gradients: 42 + 42 aten::mul launches per train step otherwise).
+struct ScaleRowsArgs {
+  const float* w[64];
+  const float* scale[64];
+  float* out[64];
+  int rows[64], cols[64], blk0[65];
+  int n;
+};
+
+namespace {
+__global__ __launch_bounds__(256) void scale_rows_multi(ScaleRowsArgs A) {
+  int t = 0;
+  while (t + 1 < A.n && (int)blockIdx.x >= A.blk0[t + 1]) ++t;
+  const int cols = A.cols[t];
+  const long long n4 = (long long)A.rows[t] * cols / 4;
+  const float4* w = reinterpret_cast<const float4*>(A.w[t]);
+  float4* o = reinterpret_cast<float4*>(A.out[t]);
+  const float* sc = A.scale[t];
+  const long long base = (long long)((int)blockIdx.x - A.blk0[t]) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long long i = base + u * 256 + threadIdx.x;
+    if (i < n4) {
+      const float s = sc[(i * 4) / cols];     // cols % 4 == 0: the four elements share a row
+      const float4 v = w[i];
+      o[i] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int egtr_scale_rows_multi_f32(egtr_stream_t stream, int n, const float* const* w, const float* const* scale,
+                                         float* const* out, const int* rows, const int* cols) {
+  if (!w || !scale || !out || !rows || !cols) return EGTR_E_ARG;
+  if (n <= 0 || n > 64) return EGTR_E_UNSUPPORTED;
+  ScaleRowsArgs A;
+  int blocks = 0;
+  for (int t = 0; t < n; ++t) {
+    if (!w[t] || !scale[t] || !out[t] || rows[t] <= 0 || cols[t] <= 0) return EGTR_E_ARG;
+    if (cols[t] % 4 != 0) return EGTR_E_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(w[t]) | reinterpret_cast<uintptr_t>(out[t])) & 15) return EGTR_E_UNSUPPORTED;
+    A.w[t] = w[t];
+    A.scale[t] = scale[t];
+    A.out[t] = out[t];
+    A.rows[t] = rows[t];
+    A.cols[t] = cols[t];
+    A.blk0[t] = blocks;
+    const long long n4 = (long long)rows[t] * cols[t] / 4;
+    blocks += (int)((n4 + 1023) / 1024);
+  }
+  A.blk0[n] = blocks;
+  A.n = n;
+  hipLaunchKernelGGL(scale_rows_multi, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+  return egtr_check_launch();
+}
+
 extern "C" int egtr_bias_act_nchw_f32(egtr_stream_t stream, const float* x, const float* bias, const float* residual,
                                       float* y, int N, int C, int HW, int relu) {
   if (!x || !bias || !y) return EGTR_E_ARG;

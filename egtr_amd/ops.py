@@ -1548,6 +1548,37 @@ def module_linear(mod, x, alpha=1.0, relu=False):
     return linear(x, mod.weight, mod.bias, alpha, relu)
 
 
+def scale_rows_multi(tensors, scales):
+    """[t * s for t, s in zip(tensors, scales)] with s one value per row of t (shape [rows, 1, ...]), in one launch per 64
+    tensors (egtr_scale_rows_multi_f32); tensors that do not qualify (not fp32 / columns not a multiple of 4) are multiplied by
+    torch.  No autograd."""
+    import ctypes
+    lib = _lib.lib()
+    out = [None] * len(tensors)
+    todo = []
+    for i, (t, s) in enumerate(zip(tensors, scales)):
+        rows = t.shape[0]
+        cols = t.numel() // rows if rows else 0
+        if (t.is_cuda and t.dtype == torch.float32 and s.dtype == torch.float32 and s.numel() == rows and cols > 0
+                and cols % 4 == 0):
+            tc = t.contiguous()
+            if tc.data_ptr() % 16 == 0:
+                todo.append((i, tc, s.reshape(-1).contiguous(), rows, cols))
+                continue
+        out[i] = t * s
+    for c0 in range(0, len(todo), 64):
+        grp = todo[c0:c0 + 64]
+        n = len(grp)
+        res = [torch.empty_like(g[1]) for g in grp]
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        st = lib.egtr_scale_rows_multi_f32(_stream(), n, PA(*[g[1].data_ptr() for g in grp]), PA(*[g[2].data_ptr() for g in grp]),
+                                           PA(*[r.data_ptr() for r in res]), IA(*[g[3] for g in grp]), IA(*[g[4] for g in grp]))
+        _lib.check(st, "egtr_scale_rows_multi_f32")
+        for g, r in zip(grp, res):
+            out[g[0]] = r
+    return out
+
+
 def bias_act_(x, bias, residual=None, relu=True):
     """In-place y = act(x + bias[c] (+ residual)) on an NCHW activation (inference only, no autograd).  fp32, or bf16
     activations with an fp32 bias."""

@@ -345,6 +345,12 @@ int egtr_dropout_add_layernorm_backward_f32(egtr_stream_t stream, const float* x
                                             float clamp_value, float* grad_sum, float* grad_x, float* workspace,
                                             float* grad_gamma_beta_bias, int rows, int dim, float eps);
 
+/* out_t[r, :] = w_t[r, :] * scale_t[r] for n <= 64 row-major fp32 tensors in ONE launch (rows[t] x cols[t], cols % 4 == 0,
+ * 16-byte aligned; out_t may alias w_t): the frozen-BN scale riding on every trainable convolution weight of the backbone in
+ * training, and the same product on the weight gradients.  The pointer / size arrays are HOST arrays. */
+int egtr_scale_rows_multi_f32(egtr_stream_t stream, int n, const float* const* w, const float* const* scale,
+                              float* const* out, const int* rows, const int* cols);
+
 /* bf16 storage (raw bfloat16 bits), fp32 arithmetic -- the same two epilogues for the bf16 stress configuration:
  * y = act(x + bias[c] (+ residual)) on an NCHW activation (bias fp32), and y = LayerNorm(x + residual) over 256 channels
  * (gamma / beta bf16; the residual sum is rounded to bf16 before the statistics, as the PyTorch composition does). */
