@@ -361,6 +361,9 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
   const int4* ro = my_off + half * kWaveEntries + head * kHeadStride;
   const float4* rw = my_w + half * kWaveEntries + head * kHeadStride;
   f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#ifndef EGTR_MSDA_BF16_PKFMA
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#endif
   // kBatch samples = 4 kBatch corner loads are requested before the first is consumed (the compiler otherwise waits for each
   // sample's four loads right behind their issue)
   constexpr int kBatch = 4;   // 16 loads in flight per lane: the kernel is short of memory-level parallelism (16 waves per CU)
@@ -387,9 +390,25 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const unsigned a[4] = {v[u][c].x, v[u][c].y, v[u][c].z, v[u][c].w};
+#ifndef EGTR_MSDA_BF16_PKFMA
+        // v_dot2_f32_bf16 on the packed word as it was loaded: the corner weight, rounded to bf16, sits in the low / high half of
+        // the other operand (the half it does not occupy is zero): one instruction per channel, no unpacking -- 10 instead of 13
+        // VALU instructions per corner (round 5: plain bf16 entry 654 -> 571 us at the stress shape, tools/msda_bf16_dot2_ab.sh;
+        // -DEGTR_MSDA_BF16_PKFMA restores v_pk_fma_f32 on unpacked pairs with the fp32 weight)
+        bf16x2 wl;
+        wl[0] = (__bf16)wc[c];
+        wl[1] = (__bf16)0.f;
+        const unsigned wlo = __builtin_bit_cast(unsigned, wl), whi = wlo << 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[k][0] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a[k]), __builtin_bit_cast(bf16x2, wlo), acc[k][0], false);
+          acc[k][1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a[k]), __builtin_bit_cast(bf16x2, whi), acc[k][1], false);
+        }
+#else
         const f32x2 wv = {wc[c], wc[c]};
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = __builtin_elementwise_fma(f32x2{bf16_lo(a[k]), bf16_hi(a[k])}, wv, acc[k]);
+#endif
       }
     }
   }

@@ -135,7 +135,8 @@ int egtr_msda_backward_bf16(egtr_stream_t stream, const uint16_t* grad_out, cons
                             float* grad_attn_weight, float* workspace);
 
 /* bf16 storage (uint16_t = raw bfloat16 bits), fp32 accumulation.  The reference dispatches float/double only
- * (cu:67,137); this is the added path for the bf16 stress configuration.  loc / attn stay fp32. */
+ * (cu:67,137); this is the added path for the bf16 stress configuration.  loc / attn stay fp32; the per-corner sample weight
+ * (bilinear x attention, formed in fp32) is rounded to bf16 as the second operand of v_dot2_f32_bf16. */
 int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* value, const int64_t* spatial_shapes,
                            const int64_t* level_start_index, const float* sampling_loc, const float* attn_weight,
                            int batch, int spatial_size, int num_heads, int channels, int num_levels, int num_query,
