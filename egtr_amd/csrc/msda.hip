@@ -245,16 +245,21 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 // ld_off / ld_logit elements) and `ref` the bf16 reference points [nq, L, 2]; softmax and loc = ref + off / (W, H) are
 // formed here in fp32 (the PyTorch composition rounds every intermediate to bf16); `keep` (optional, bytes per token):
 // padded tokens are skipped == their value rows zeroed (dd:1052).
-template <bool FUSED>
+// PC: the number of points per level as a compile-time constant (4: the model's), 0 = the runtime value -- the level of a sample
+// is s / P, a division by a runtime integer otherwise (~20 instructions each, several per record).
+template <bool FUSED, int PC>
 __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
     const uint16_t* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const void* __restrict__ loc, const void* __restrict__ attn, uint16_t* __restrict__ out, int nq_total,
-    int Lq, int S, int L, int P, int nblk, const uint16_t* __restrict__ ref, int ld_off, int ld_logit,
+    int Lq, int S, int L, int P_rt, int nblk, const uint16_t* __restrict__ ref, int ld_off, int ld_logit,
     const unsigned char* __restrict__ keep, const unsigned* __restrict__ keep_bits) {
+  const int P = PC ? PC : P_rt;
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * 2 * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * 2 * kWaveEntries];
   __shared__ unsigned s_bits[FUSED ? kMaxBitWords : 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a scalar: the query index, the image it belongs to and the mask row derived from it are wave-uniform,
+  // and so are the branches on them -- as a vector value they cost ~1100 VALU instructions and 71 exec-mask branches of prologue)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int blk = xcd_remap(blockIdx.x, nblk);
   const int qpair = (blk * kWaves + wave) * 2;
   // padding mask as ONE BIT per token, the image of the workgroup's first query staged in LDS (2.8 KB at 800x1333): the
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
     }
     const bool use_bits = FUSED && keep_bits != nullptr;
     const unsigned char* kp = (FUSED && keep != nullptr && !use_bits) ? keep + (size_t)(q / Lq) * S : nullptr;
-    const bool in_lds = bits_staged && q / Lq == b0;
+    const bool in_lds = __builtin_amdgcn_readfirstlane((int)(bits_staged && q / Lq == b0)) != 0;   // a scalar branch, two code paths
     const unsigned* kb = use_bits ? keep_bits + (size_t)(q / Lq) * nwords : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -319,24 +324,28 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q32_bf16(
                                                 SEL_S(G, lvl), head_s);
       const float a = j ? aw.y : aw.x;
       bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
+      // (bitwise, not short-circuit: the clamped offsets are always readable, and four independent reads beat four branches)
       if (use_bits) {
         const int p0 = g.off[0] >> 9, p1 = g.off[1] >> 9, p2 = g.off[2] >> 9, p3 = g.off[3] >> 9;
+        unsigned w0, w1, w2, w3;
         if (in_lds) {
-          k0 = k0 && ((s_bits[p0 >> 5] >> (p0 & 31)) & 1u);
-          k1 = k1 && ((s_bits[p1 >> 5] >> (p1 & 31)) & 1u);
-          k2 = k2 && ((s_bits[p2 >> 5] >> (p2 & 31)) & 1u);
-          k3 = k3 && ((s_bits[p3 >> 5] >> (p3 & 31)) & 1u);
+          w0 = s_bits[p0 >> 5]; w1 = s_bits[p1 >> 5]; w2 = s_bits[p2 >> 5]; w3 = s_bits[p3 >> 5];
+          // (keeps the optimiser from sinking the two branches' reads into one FLAT load of a selected pointer: a flat load
+          // counts on both wait counters and costs an LDS read the latency of a global one)
+          asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
         } else {
-          k0 = k0 && ((kb[p0 >> 5] >> (p0 & 31)) & 1u);
-          k1 = k1 && ((kb[p1 >> 5] >> (p1 & 31)) & 1u);
-          k2 = k2 && ((kb[p2 >> 5] >> (p2 & 31)) & 1u);
-          k3 = k3 && ((kb[p3 >> 5] >> (p3 & 31)) & 1u);
+          w0 = kb[p0 >> 5]; w1 = kb[p1 >> 5]; w2 = kb[p2 >> 5]; w3 = kb[p3 >> 5];
         }
+        k0 = k0 & (bool)((w0 >> (p0 & 31)) & 1u);
+        k1 = k1 & (bool)((w1 >> (p1 & 31)) & 1u);
+        k2 = k2 & (bool)((w2 >> (p2 & 31)) & 1u);
+        k3 = k3 & (bool)((w3 >> (p3 & 31)) & 1u);
       } else if (kp != nullptr) {
-        k0 = k0 && kp[g.off[0] >> 9];
-        k1 = k1 && kp[g.off[1] >> 9];
-        k2 = k2 && kp[g.off[2] >> 9];
-        k3 = k3 && kp[g.off[3] >> 9];
+        const unsigned char c0 = kp[g.off[0] >> 9], c1 = kp[g.off[1] >> 9], c2 = kp[g.off[2] >> 9], c3 = kp[g.off[3] >> 9];
+        k0 = k0 & (c0 != 0);
+        k1 = k1 & (c1 != 0);
+        k2 = k2 & (c2 != 0);
+        k3 = k3 & (c3 != 0);
       }
       my_off[qq * kWaveEntries + head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
       my_w[qq * kWaveEntries + head_s * kHeadStride + s] =
@@ -801,10 +810,16 @@ extern "C" int egtr_msda_forward_bf16(egtr_stream_t stream, const uint16_t* valu
   hipStream_t st = static_cast<hipStream_t>(stream);
   const long long nq = (long long)batch * num_query;
   const int nblk = (int)((nq + 2 * kWaves - 1) / (2 * kWaves));
-  hipLaunchKernelGGL(msda_fwd_q32_bf16<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
-                     level_start_index, (const void*)sampling_loc, (const void*)attn_weight, out, (int)nq, num_query,
-                     spatial_size, num_levels, num_point, nblk, (const uint16_t*)nullptr, 256, 128,
-                     (const unsigned char*)nullptr, (const unsigned*)nullptr);
+  if (num_point == 4)
+    hipLaunchKernelGGL((msda_fwd_q32_bf16<false, 4>), dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+                       level_start_index, (const void*)sampling_loc, (const void*)attn_weight, out, (int)nq, num_query,
+                       spatial_size, num_levels, num_point, nblk, (const uint16_t*)nullptr, 256, 128,
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr);
+  else
+    hipLaunchKernelGGL((msda_fwd_q32_bf16<false, 0>), dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+                       level_start_index, (const void*)sampling_loc, (const void*)attn_weight, out, (int)nq, num_query,
+                       spatial_size, num_levels, num_point, nblk, (const uint16_t*)nullptr, 256, 128,
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr);
   return egtr_check_launch();
 }
 
@@ -825,10 +840,16 @@ extern "C" int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t
       (long long)(batch + 1) * spatial_size * 512 >= (1ll << 32))   // (32-bit lane offsets into the value tensor)
     return EGTR_E_UNSUPPORTED;
   const int nblk = (int)((nq + 2 * kWaves - 1) / (2 * kWaves));
-  hipLaunchKernelGGL(msda_fwd_q32_bf16<true>, dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
-                     spatial_shapes, level_start_index, (const void*)sampling_offsets, (const void*)attn_logits, out,
-                     (int)nq, num_query, spatial_size, num_levels, num_point, nblk, reference_points, ld_offsets,
-                     ld_logits, keep_mask, keep_bits);
+  if (num_point == 4)
+    hipLaunchKernelGGL((msda_fwd_q32_bf16<true, 4>), dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
+                       spatial_shapes, level_start_index, (const void*)sampling_offsets, (const void*)attn_logits, out,
+                       (int)nq, num_query, spatial_size, num_levels, num_point, nblk, reference_points, ld_offsets,
+                       ld_logits, keep_mask, keep_bits);
+  else
+    hipLaunchKernelGGL((msda_fwd_q32_bf16<true, 0>), dim3(nblk), dim3(kWaves * 64), 0, static_cast<hipStream_t>(stream), value,
+                       spatial_shapes, level_start_index, (const void*)sampling_offsets, (const void*)attn_logits, out,
+                       (int)nq, num_query, spatial_size, num_levels, num_point, nblk, reference_points, ld_offsets,
+                       ld_logits, keep_mask, keep_bits);
   return egtr_check_launch();
 }
 
