@@ -31,6 +31,7 @@ SIGNATURES = {
     "egtr_msda_forward_f64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "egtr_msda_backward_f64": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "egtr_msda_backward_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "egtr_msda_backward_bf16_workspace_floats": [_I, _I, _I, _I, _I, _I, _I],
     "egtr_msda_forward_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "egtr_msda_forward_fused_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     "egtr_self_attn_forward_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -111,6 +112,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p,
              "egtr_ffn_packed_weights_bytes": ctypes.c_longlong,
+             "egtr_msda_backward_bf16_workspace_floats": ctypes.c_longlong,
              "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong,
              "egtr_relation_loss_workspace_bytes": ctypes.c_longlong,
              "egtr_column_sum_workspace_floats": ctypes.c_longlong,

@@ -500,9 +500,12 @@ __device__ __forceinline__ float group8_sum(float v) {
 // SPLIT > 1 (short query lists, e.g. the decoder's 200 queries per image): SPLIT waves share one query, each taking
 // 16 / SPLIT consecutive samples (= one level for SPLIT = 4), so that a B x 200-query call fills the chip (800 waves of
 // serial atomics -> 3200) -- every wave still builds all 16 records (cheap) but gathers / scatters only its own.
-template <bool VALUE_ATOMICS, int SPLIT = 1>
+// BF: grad_out and value hold raw bfloat16 (the backward of a bf16 model): rows of 512 bytes instead of 1024 -- the record
+// offsets, built for the fp32 grad_value rows, are halved for the value gather -- widened on load; everything behind the loads
+// is the fp32 kernel (same instructions, same results as widening the operands first).
+template <bool VALUE_ATOMICS, int SPLIT = 1, bool BF = false>
 __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
-    const float* __restrict__ grad_out, const float* __restrict__ value, const int64_t* __restrict__ shapes,
+    const void* __restrict__ grad_out_, const void* __restrict__ value_, const int64_t* __restrict__ shapes,
     const int64_t* __restrict__ lsi, const float* __restrict__ loc, const float* __restrict__ attn,
     float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn, int nq_total,
     int Lq, int S, int L, int P, int nblk, unsigned* __restrict__ zero8, int zero_value_rows) {
@@ -513,6 +516,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   __shared__ __attribute__((aligned(16))) float4 s_a[VALUE_ATOMICS ? kWaves * 128 : 1];      // {bits, lh, lw, attn}
   __shared__ __attribute__((aligned(16))) float s_go[VALUE_ATOMICS ? kWaves * 256 : 4];      // grad_out row, [head][32]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c4_ = lane & 7;
   const int blk = xcd_remap(blockIdx.x, nblk);
   const int gw = blk * kWaves + wave;
   const int q = gw / SPLIT, part = gw % SPLIT;
@@ -522,8 +526,16 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   load_geom(shapes, lsi, L, G);
   const int b = q / Lq;
   const size_t boff = (size_t)b * S * (256 * 4);
-  const char* vbase = reinterpret_cast<const char*>(value) + boff;
+  const char* vbase = reinterpret_cast<const char*>(value_) + (BF ? boff / 2 : boff);
   char* gvbase = reinterpret_cast<char*>(grad_value) + boff;
+  auto widen4 = [](uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+  };
+  auto corner = [&](int off) {   // the lane's 4 channels of one corner
+    if constexpr (BF) return widen4(*reinterpret_cast<const uint2*>(vbase + c4_ * 8 + ((unsigned)off >> 1)));
+    else return *reinterpret_cast<const float4*>(vbase + c4_ * 16 + (unsigned)off);
+  };
 
   const float4 lc = reinterpret_cast<const float4*>(loc + (size_t)q * 256)[lane];
   const float2 aw = reinterpret_cast<const float2*>(attn + (size_t)q * 128)[lane];
@@ -559,7 +571,9 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
     }
   }
   const int head = lane >> 3, c4 = lane & 7;
-  const float4 g = reinterpret_cast<const float4*>(grad_out + (size_t)q * 256)[lane];
+  float4 g;
+  if constexpr (BF) g = widen4(reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(grad_out_) + (size_t)q * 256)[lane]);
+  else g = reinterpret_cast<const float4*>(static_cast<const float*>(grad_out_) + (size_t)q * 256)[lane];
   if (VALUE_ATOMICS) reinterpret_cast<float4*>(s_go + wave * 256)[lane] = g;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -570,10 +584,7 @@ __global__ __launch_bounds__(kWaves * 64) void msda_bwd_q64_f32(
   for (int s = part * NS; s < (part + 1) * NS; ++s) {
     const int e = head * 16 + (s ^ head);
     const int4 o = my_off[e];
-    const float4 v0 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.x);
-    const float4 v1 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.y);
-    const float4 v2 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.z);
-    const float4 v3 = *reinterpret_cast<const float4*>(vbase + c4 * 16 + (unsigned)o.w);
+    const float4 v0 = corner(o.x), v1 = corner(o.y), v2 = corner(o.z), v3 = corner(o.w);
     if (VALUE_ATOMICS) {
       // grad_value scatter (cuh:125-152) in a lane = channel layout: one atomic instruction covers the 32 contiguous
       // channels of TWO heads = two whole 128-byte lines.  (Device-scope float atomics execute memory-side on this
@@ -853,7 +864,7 @@ extern "C" int egtr_msda_forward_fused_bf16(egtr_stream_t stream, const uint16_t
   return egtr_check_launch();
 }
 
-int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
+int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const void* grad_out, bool grad_out_bf16, const int64_t* shapes,
                                         const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
                                         int B, int Lq, int S, int L, int P, unsigned* counters);
 unsigned* egtr_msda_tile_counters(hipStream_t st);   // eight work counters private to one launch pair (msda_tile.hip)
@@ -865,12 +876,14 @@ unsigned* egtr_msda_tile_counters(hipStream_t st);   // eight work counters priv
 namespace {
 // zero_inside: grad_value arrives uninitialised and is cleared here -- by the wave-per-query kernel itself where the value-tile
 // kernel follows it (variant 2), by a memset on the stream otherwise
-int msda_backward_f32_impl(egtr_stream_t stream, const float* grad_out, const float* value,
+// bf16_ops: grad_out / value are raw bfloat16 (fast shapes only: EGTR_E_UNSUPPORTED otherwise, the caller widens and comes back)
+int msda_backward_f32_impl(egtr_stream_t stream, const void* grad_out, const void* value,
                            const int64_t* spatial_shapes, const int64_t* level_start_index,
                            const float* sampling_loc, const float* attn_weight, int batch,
                            int spatial_size, int num_heads, int channels, int num_levels,
                            int num_query, int num_point, float* grad_value,
-                           float* grad_sampling_loc, float* grad_attn_weight, int variant, bool zero_inside) {
+                           float* grad_sampling_loc, float* grad_attn_weight, int variant, bool zero_inside,
+                           bool bf16_ops = false) {
   if (!grad_out || !value || !spatial_shapes || !level_start_index || !sampling_loc || !attn_weight || !grad_value ||
       !grad_sampling_loc || !grad_attn_weight)
     return EGTR_E_ARG;
@@ -883,6 +896,7 @@ int msda_backward_f32_impl(egtr_stream_t stream, const float* grad_out, const fl
                     (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27);
   if (variant == 0) variant = fast ? ((num_query == spatial_size && num_query >= 256) ? 2 : 1) : 3;
   if ((variant == 1 || variant == 2) && !fast) return EGTR_E_UNSUPPORTED;
+  if (bf16_ops && variant == 3) return EGTR_E_UNSUPPORTED;
   const bool zero_in_kernel = zero_inside && variant == 2 && num_query == spatial_size;
   if (zero_inside && !zero_in_kernel &&
       hipMemsetAsync(grad_value, 0, (size_t)batch * spatial_size * num_heads * channels * sizeof(float), st) != hipSuccess)
@@ -891,32 +905,49 @@ int msda_backward_f32_impl(egtr_stream_t stream, const float* grad_out, const fl
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
     unsigned* counters = egtr_msda_tile_counters(st);
     if (counters == nullptr) return EGTR_E_LAUNCH;
-    hipLaunchKernelGGL(msda_bwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
-                       level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, counters,
-                       zero_in_kernel ? 1 : 0);
+    if (bf16_ops)
+      hipLaunchKernelGGL((msda_bwd_q64_f32<false, 1, true>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
+                         spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                         grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, counters,
+                         zero_in_kernel ? 1 : 0);
+    else
+      hipLaunchKernelGGL(msda_bwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
+                         level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                         grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, counters,
+                         zero_in_kernel ? 1 : 0);
     const int st1 = egtr_check_launch();
     if (st1 != EGTR_OK) return st1;
-    return egtr_launch_msda_bwd_value_tile_f32(st, grad_out, spatial_shapes, level_start_index, sampling_loc,
+    return egtr_launch_msda_bwd_value_tile_f32(st, grad_out, bf16_ops, spatial_shapes, level_start_index, sampling_loc,
                                                attn_weight, grad_value, batch, num_query, spatial_size, num_levels,
                                                num_point, counters);
   }
   if (variant == 1 && nq * 4 <= 16384 && (num_point == 4 || num_point == 8 || num_point == 16)) {
     // short query list: 4 waves per query (one level's samples each for L = P = 4)
     const int nblk = (int)((nq * 4 + kWaves - 1) / kWaves);
-    hipLaunchKernelGGL((msda_bwd_q64_f32<true, 4>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
-                       spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
+    if (bf16_ops)
+      hipLaunchKernelGGL((msda_bwd_q64_f32<true, 4, true>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
+                         spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                         grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
+    else
+      hipLaunchKernelGGL((msda_bwd_q64_f32<true, 4>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
+                         spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                         grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
   } else if (variant == 1) {
     const int nblk = (int)((nq + kWaves - 1) / kWaves);
-    hipLaunchKernelGGL(msda_bwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
-                       level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
-                       grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
+    if (bf16_ops)
+      hipLaunchKernelGGL((msda_bwd_q64_f32<true, 1, true>), dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value,
+                         spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                         grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
+    else
+      hipLaunchKernelGGL(msda_bwd_q64_f32<true>, dim3(nblk), dim3(kWaves * 64), 0, st, grad_out, value, spatial_shapes,
+                         level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
+                         grad_attn_weight, (int)nq, num_query, spatial_size, num_levels, num_point, nblk, (unsigned*)nullptr, 0);
   } else {
     const long long n = nq * num_heads * num_levels * num_point;
     const int threads = 256;
     const int blocks = (int)std::min<long long>((n + threads - 1) / threads, 65535ll * 16);
-    hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(blocks), dim3(threads), 0, st, grad_out, value, spatial_shapes,
+    hipLaunchKernelGGL(msda_bwd_generic<float>, dim3(blocks), dim3(threads), 0, st, static_cast<const float*>(grad_out),
+                       static_cast<const float*>(value), spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, grad_value, grad_sampling_loc,
                        grad_attn_weight, n, spatial_size, num_heads, channels, num_levels, num_query, num_point);
   }
@@ -997,9 +1028,9 @@ extern "C" int egtr_msda_backward_f64(egtr_stream_t stream, const double* grad_o
 }
 
 // ---- bf16 backward (the reference has no half / bf16 kernel; the stress configuration trains in bf16): bf16 value and
-// upstream gradient, fp32 sampling geometry and fp32 gradients.  The bf16 operands are widened once into `workspace`
-// (B*S*M*D + B*Lq*M*D floats) and the fp32 kernels do the rest -- for encoder-shaped calls that is the matrix-core
-// grad_value kernel, which is what makes this faster than a bf16 gather / fp32 atomic-scatter kernel would be.
+// upstream gradient, fp32 sampling geometry and fp32 gradients.  The fast shapes (M = 8, D = 32, L * P = 16) read the bf16
+// operands directly (msda_bwd_q64_f32<.., BF = true>, msda_bwd_value_tile_f32<true>: widened on load, identical arithmetic
+// behind it); other shapes widen them once into `workspace` (B*S*M*D + B*Lq*M*D floats) for the generic fp32 kernel.
 namespace {
 __global__ __launch_bounds__(256) void widen_bf16(const uint16_t* __restrict__ a, float* __restrict__ oa, long long na,
                                                   const uint16_t* __restrict__ b, float* __restrict__ ob, long long nb) {
@@ -1015,14 +1046,30 @@ __global__ __launch_bounds__(256) void widen_bf16(const uint16_t* __restrict__ a
 }
 }  // namespace
 
+extern "C" long long egtr_msda_backward_bf16_workspace_floats(int batch, int spatial_size, int num_heads, int channels,
+                                                             int num_levels, int num_query, int num_point) {
+  if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_query <= 0) return 0;
+  const long long nq = (long long)batch * num_query;
+  if (fast_shape(num_heads, channels, num_levels, num_point) && (long long)spatial_size * 1024 < (1ll << 31) && nq < (1ll << 27))
+    return 0;   // native bf16 operands
+  return (long long)batch * spatial_size * num_heads * channels + nq * num_heads * channels;
+}
+
 extern "C" int egtr_msda_backward_bf16(egtr_stream_t stream, const uint16_t* grad_out, const uint16_t* value,
                                        const int64_t* spatial_shapes, const int64_t* level_start_index,
                                        const float* sampling_loc, const float* attn_weight, int batch,
                                        int spatial_size, int num_heads, int channels, int num_levels, int num_query,
                                        int num_point, float* grad_value, float* grad_sampling_loc,
                                        float* grad_attn_weight, float* workspace) {
-  if (!grad_out || !value || !workspace) return EGTR_E_ARG;
+  if (!grad_out || !value) return EGTR_E_ARG;
   if (batch <= 0 || spatial_size <= 0 || num_heads <= 0 || channels <= 0 || num_query <= 0) return EGTR_E_ARG;
+  {
+    const int st0 = msda_backward_f32_impl(stream, grad_out, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
+                                           batch, spatial_size, num_heads, channels, num_levels, num_query, num_point,
+                                           grad_value, grad_sampling_loc, grad_attn_weight, 0, false, true);
+    if (st0 != EGTR_E_UNSUPPORTED) return st0;
+  }
+  if (!workspace) return EGTR_E_ARG;
   const long long nv = (long long)batch * spatial_size * num_heads * channels;
   const long long ng = (long long)batch * num_query * num_heads * channels;
   if ((nv & 7) || (ng & 7)) return EGTR_E_UNSUPPORTED;

@@ -48,8 +48,10 @@ constexpr int kCounterSlots = 1024;   // eager launches: a ring
 constexpr int kGraphSlots = 8192;     // captured launches: one-way
 __device__ unsigned g_tile_counters[(kCounterSlots + kGraphSlots) * 8];
 
+// GO_BF16: grad_out holds raw bfloat16 (the backward of a bf16 model); widened on load, everything else is unchanged.
+template <bool GO_BF16>
 __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
-    const float* __restrict__ grad_out, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
+    const void* __restrict__ grad_out_, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ grad_value, int B, int Lq,
     int S, int L, int P, unsigned* __restrict__ counters) {
   __shared__ __attribute__((aligned(16))) float s_A[kTQ * kChunk];         // A[q][column]
@@ -96,7 +98,13 @@ __global__ __launch_bounds__(kThreads, 2) void msda_bwd_value_tile_f32(
         const size_t qh = ((size_t)b_ * Lq + q_) * 8 + head;
         lc_n = reinterpret_cast<const float4*>(loc + qh * 32)[c4];
         aw_n = reinterpret_cast<const float2*>(attn + qh * 16)[c4];
-        go_n = reinterpret_cast<const float4*>(grad_out + qh * 32)[c4];
+        if constexpr (GO_BF16) {
+          const uint2 gb = reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(grad_out_) + qh * 32)[c4];
+          go_n = make_float4(__uint_as_float(gb.x << 16), __uint_as_float(gb.x & 0xffff0000u), __uint_as_float(gb.y << 16),
+                             __uint_as_float(gb.y & 0xffff0000u));
+        } else {
+          go_n = reinterpret_cast<const float4*>(static_cast<const float*>(grad_out_) + qh * 32)[c4];
+        }
       }
     }
   };
@@ -334,10 +342,14 @@ unsigned* egtr_msda_tile_counters(hipStream_t st) {
 }
 
 // Launcher used by egtr_msda_backward_f32 (msda.hip): grad_value of encoder-shaped calls (M = 8, D = 32, L*P = 16).
-int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const float* grad_out, const int64_t* shapes,
+int egtr_launch_msda_bwd_value_tile_f32(hipStream_t st, const void* grad_out, bool grad_out_bf16, const int64_t* shapes,
                                         const int64_t* lsi, const float* loc, const float* attn, float* grad_value,
                                         int B, int Lq, int S, int L, int P, unsigned* counters) {
-  hipLaunchKernelGGL(msda_bwd_value_tile_f32, dim3(kBwdGrid), dim3(kThreads), 0, st, grad_out, shapes, lsi, loc, attn,
-                     grad_value, B, Lq, S, L, P, counters);
+  if (grad_out_bf16)
+    hipLaunchKernelGGL(msda_bwd_value_tile_f32<true>, dim3(kBwdGrid), dim3(kThreads), 0, st, grad_out, shapes, lsi, loc, attn,
+                       grad_value, B, Lq, S, L, P, counters);
+  else
+    hipLaunchKernelGGL(msda_bwd_value_tile_f32<false>, dim3(kBwdGrid), dim3(kThreads), 0, st, grad_out, shapes, lsi, loc, attn,
+                       grad_value, B, Lq, S, L, P, counters);
   return egtr_check_launch();
 }

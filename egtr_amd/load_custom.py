@@ -209,11 +209,14 @@ class _MultiScaleDeformableAttention:
             gv32 = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
             grad_loc = torch.empty_like(sampling_loc)
             grad_attn = torch.empty_like(attn_weight)
-            ws = torch.empty(value.numel() + grad_output.numel(), dtype=torch.float32, device=value.device)
+            # (0 for the model's shapes: the kernels read the bf16 operands directly; other shapes widen them into a workspace)
+            nws = int(lib.egtr_msda_backward_bf16_workspace_floats(B, S, M, D, L, Lq, P))
+            ws = torch.empty(nws, dtype=torch.float32, device=value.device) if nws else None
             st = lib.egtr_msda_backward_bf16(_stream(), grad_output.data_ptr(), value.data_ptr(),
                                              spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                                              sampling_loc.data_ptr(), attn_weight.data_ptr(), B, S, M, D, L, Lq, P,
-                                             gv32.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(), ws.data_ptr())
+                                             gv32.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
+                                             ws.data_ptr() if ws is not None else None)
             _lib.check(st, "ms_deform_attn_backward")
             return gv32.to(torch.bfloat16), grad_loc, grad_attn
         for t, n in ((value, "value"), (sampling_loc, "sampling_loc"), (attn_weight, "attn_weight"),

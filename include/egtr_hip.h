@@ -127,7 +127,11 @@ int egtr_msda_backward_f64(egtr_stream_t stream, const double* grad_out, const d
 
 /* bf16 backward (we add bf16; the reference has no half kernel): grad_out [B,Lq,M*D] and value [B,S,M,D] are raw
  * bfloat16, sampling_loc / attn_weight and all three gradients fp32 (grad_value zero-initialised by the caller).
- * workspace: B*S*M*D + B*Lq*M*D floats (the widened operands). */
+ * For M = 8, D = 32, L * P = 16 the kernels read the bf16 operands directly (widened on load: the same results as widening
+ * first) and workspace may be NULL; other shapes widen them into workspace.  egtr_msda_backward_bf16_workspace_floats
+ * returns the floats a call needs: 0, or B*S*M*D + B*Lq*M*D. */
+long long egtr_msda_backward_bf16_workspace_floats(int batch, int spatial_size, int num_heads, int channels, int num_levels,
+                                                   int num_query, int num_point);
 int egtr_msda_backward_bf16(egtr_stream_t stream, const uint16_t* grad_out, const uint16_t* value,
                             const int64_t* spatial_shapes, const int64_t* level_start_index, const float* sampling_loc,
                             const float* attn_weight, int batch, int spatial_size, int num_heads, int channels,

@@ -1280,6 +1280,26 @@ def test_msda_bf16_backward(B, Lq, shapes):
     assert (loc.grad.cpu() - rgl).abs().max() < 1e-3 * max(1.0, float(rgl.abs().max()))
 
 
+@pytest.mark.parametrize("B,Lq,shapes", [(2, 0, [(19, 32), (10, 16), (5, 8), (3, 4)]), (2, 200, [(19, 32), (10, 16), (5, 8), (3, 4)]),
+                                         (1, 5000, [(19, 32), (10, 16), (5, 8), (3, 4)])])
+def test_msda_bf16_backward_reads_bf16_operands_directly(B, Lq, shapes):
+    """egtr_msda_backward_bf16 on the model's shapes needs no workspace (the kernels widen the bf16 operands on load) and gives
+    the fp32 kernels' results on the widened operands: grad_loc / grad_attn bit for bit (same instructions behind the load);
+    grad_value to the order of its float atomics.  Lq = 0: encoder-shaped (Lq = S: wave-per-query kernel + value-tile
+    kernel); 200: the decoder's four-waves-per-query kernel; 5000: one wave per query with atomics."""
+    k = _kernels()
+    from egtr_amd import _lib
+    S = sum(h * w for h, w in shapes)
+    x = W.make_msda_inputs(91, B, Lq or S, 8, 32, shapes, 4)
+    assert int(_lib.lib().egtr_msda_backward_bf16_workspace_floats(B, S, 8, 32, 4, Lq or S, 4)) == 0
+    vb, gb = x["value"].to(torch.bfloat16).to(DEV), x["grad_out"].to(torch.bfloat16).to(DEV)
+    shp, lsi, loc, at = x["shapes"].to(DEV), x["lsi"].to(DEV), x["loc"].to(DEV), x["attn"].to(DEV)
+    gv, gl, ga = k.ms_deform_attn_backward(vb, shp, lsi, loc, at, gb, 64)
+    rv, rl, ra = k.ms_deform_attn_backward(vb.float(), shp, lsi, loc, at, gb.float(), 64)
+    assert gv.dtype == torch.bfloat16 and torch.equal(gl, rl) and torch.equal(ga, ra)
+    assert (gv.float() - rv).abs().max() <= 2 ** -7 * max(1.0, float(rv.abs().max()))
+
+
 @pytest.mark.parametrize("B,N,C,Ts", [(2, 200, 150, (30, 9)), (3, 40, 12, (5, 12, 1)), (2, 64, 601, (6, 0)),
                                       (1, 300, 150, (40,))])
 def test_detection_loss_kernel_vs_tensor_composition(B, N, C, Ts):
