@@ -73,9 +73,11 @@ def test_two_ranks_real_kernels_one_gpu(tmp_path):
     # (fp32: two per-rank sums averaged by the reducer vs four terms added in sequence, float atomics in the MSDA backward and
     # a clip factor computed from each: measured 2e-5 of the largest gradient entry)
     assert d0["grad_max_diff"] < 1e-4 * d0["grad_scale"], d0
-    # AdamW's first step moves every weight by ~lr * sign(gradient): where a gradient entry is at rounding level the two runs
-    # may disagree on it, by at most one step (lr = 1e-4); the exact statement is the one below -- both ranks hold the SAME weights
-    assert d0["param_max_diff"] < 0.5e-4, d0
+    # AdamW's first step moves every weight by ~lr * g / (|g| + eps): where a gradient entry is at rounding level (float atomics
+    # in the MSDA backward, MIOpen's convolutions: not bit-reproducible run to run) the two runs may disagree on its SIGN, i.e. by
+    # up to two steps (lr = 1e-4).  Measured over repeated runs: 1.5e-5 ... 5.6e-5 -- a bound of half a step was flaky.  The
+    # exact statement is the one below: both ranks hold the SAME weights.
+    assert d0["param_max_diff"] < 2.1e-4, d0
     for d in (d0, d1):
         micro = d["allreduces_per_micro_step"]
         assert micro[0] == [0, False] and micro[1][0] >= 1 and micro[1][1] is True, micro
