@@ -125,7 +125,10 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 
   // system idles during the products and saturates during the epilogues.
   if (blockIdx.x < 256) {
     const int naps = (int)((blockIdx.x >> 3) & 7) * EGTR_FFN_STAGGER;
-    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+#ifndef EGTR_FFN_STAGGER_UNIT
+#define EGTR_FFN_STAGGER_UNIT 127
+#endif
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(EGTR_FFN_STAGGER_UNIT);
   }
 #endif
 #ifdef EGTR_FFN_TIMING
@@ -337,39 +340,43 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 
   // rows out: lane = 8-byte channel group `lane` of row r.  The position rows of all 64 rows are requested BEFORE the wave issues
   // its first store (loads and stores share one counter on this part and the compiler cannot assume they complete in order: a
   // load issued behind a store was waited for with vmcnt(0), i.e. until every earlier store had COMPLETED -- the rows left one
-  // DRAM write round trip at a time, 72 k cycles per workgroup); then the y rows, then the y + pos rows.
-  auto rows_out = [&]() {
+  // DRAM write round trip at a time, 72 k cycles per workgroup); LDS reads eight rows at a time.
+  auto rows_out = [&](auto FULL) {
+    constexpr bool full = decltype(FULL)::value;   // all 64 rows of the wave exist: no per-row branch, LDS reads in batches
+    const bool with_pos = A.y_pos != nullptr;
     uint2 pv[kRB * 32];
-    if (A.y_pos != nullptr) {
+    if (with_pos) {
       // (one division per wave: the rows are consecutive, the position row advances with them and wraps)
       const int rc0 = min(row0, A.M - 1);                 // rows behind M - 1 repeat the last valid one
       const int p0 = rc0 % A.pos_rows;
       const unsigned short* pl = A.pos + 4 * lane;
 #pragma unroll
       for (int u = 0; u < kRB * 32; ++u) {
-        int p = p0 + (min(row0 + u, A.M - 1) - rc0);
+        int p = p0 + (full ? u : min(row0 + u, A.M - 1) - rc0);
         if (A.pos_rows >= kRB * 32) p -= p >= A.pos_rows ? A.pos_rows : 0;
         else p %= A.pos_rows;
         pv[u] = *reinterpret_cast<const uint2*>(pl + (size_t)p * kD);
       }
     }
+    unsigned short* const yl = A.y + (size_t)row0 * kD + 4 * lane;
+    unsigned short* const pl_out = with_pos ? A.y_pos + (size_t)row0 * kD + 4 * lane : nullptr;
+    // the y + pos rows FIRST: their wait for the position rows is a wait for loads only (no store of this wave is in flight yet)
 #pragma unroll
-    for (int r = 0; r < kRB * 32; ++r) {
-      if (row0 + r < A.M) {
-        const uint2 yv = *reinterpret_cast<const uint2*>(s_out_w + r * 512 + ((lane ^ (r & 31)) & 63) * 8);
-        *reinterpret_cast<uint2*>(A.y + (size_t)(row0 + r) * kD + 4 * lane) = yv;
-      }
-    }
-    if (A.y_pos != nullptr) {
+    for (int r0 = 0; r0 < kRB * 32; r0 += 8) {
+      uint2 yv[8];
 #pragma unroll
-      for (int r = 0; r < kRB * 32; ++r) {
-        if (row0 + r < A.M) {
-          const uint2 yv = *reinterpret_cast<const uint2*>(s_out_w + r * 512 + ((lane ^ (r & 31)) & 63) * 8);
-          *reinterpret_cast<uint2*>(A.y_pos + (size_t)(row0 + r) * kD + 4 * lane) =
-              make_uint2(pk_bf16(lo_bf(yv.x) + lo_bf(pv[r].x), hi_bf(yv.x) + hi_bf(pv[r].x)),
-                         pk_bf16(lo_bf(yv.y) + lo_bf(pv[r].y), hi_bf(yv.y) + hi_bf(pv[r].y)));
-        }
+      for (int u = 0; u < 8; ++u) yv[u] = *reinterpret_cast<const uint2*>(s_out_w + (r0 + u) * 512 + ((lane ^ ((r0 + u) & 31)) & 63) * 8);
+      if (with_pos) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (full || row0 + r0 + u < A.M)
+            *reinterpret_cast<uint2*>(pl_out + (size_t)(r0 + u) * kD) =
+                make_uint2(pk_bf16(lo_bf(yv[u].x) + lo_bf(pv[r0 + u].x), hi_bf(yv[u].x) + hi_bf(pv[r0 + u].x)),
+                           pk_bf16(lo_bf(yv[u].y) + lo_bf(pv[r0 + u].y), hi_bf(yv[u].y) + hi_bf(pv[r0 + u].y)));
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (full || row0 + r0 + u < A.M) *reinterpret_cast<uint2*>(yl + (size_t)(r0 + u) * kD) = yv[u];
     }
   };
   FFN_T(t_epi);
@@ -380,7 +387,8 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(1, 
     epilogue(std::integral_constant<int, 0>{});
     if constexpr (kRB > 1) epilogue(std::integral_constant<int, 1>{});
     FFN_T(e_r);
-    rows_out();
+    if (row0 + kRB * 32 <= A.M) rows_out(std::true_type{});
+    else rows_out(std::false_type{});
     FFN_T(e_s);
     FFN_ADD(10, e_r, e_s);
   }
