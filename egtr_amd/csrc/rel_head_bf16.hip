@@ -145,16 +145,30 @@ __global__ __launch_bounds__(64 * kWaves) void rel_head_fwd_bf16p(RhArgs A) {
   }
   __syncthreads();
 
+  // The eight waves of a workgroup take a 2 x 4 block of pair tiles (8 subjects x 32 objects) per step: a subject row set is then
+  // wanted by four waves and an object row set by two at about the same time and comes out of the L1 for all but the first
+  // (40 distinct row sets per step instead of 68 with eight tiles in a row: the kernel is bound by L2 -> L1 operand traffic).
+#ifdef EGTR_RH_TILES_IN_A_ROW
   const int it_n = (N + 3) >> 2, jt_n = (N + 7) >> 3;
-  const int tiles_img = it_n * jt_n;
-  const long long ntiles = (long long)A.B * tiles_img;
+  const int sit_n = it_n, sjt_n = (jt_n + 7) >> 3;
+#else
+  const int it_n = (N + 3) >> 2, jt_n = (N + 7) >> 3;
+  const int sit_n = (it_n + 1) >> 1, sjt_n = (jt_n + 3) >> 2;
+#endif
+  const int supers_img = sit_n * sjt_n;
+  const long long nsupers = (long long)A.B * supers_img;
   const float inv_total = 1.f / ((float)A.B * (float)N * (float)N);
   const int il = pi >> 3, jl = pi & 7;
 
-  for (long long tile = (long long)wg * kWaves + wave; tile < ntiles; tile += (long long)nwg * kWaves) {
-    const int b = __builtin_amdgcn_readfirstlane((int)(tile / tiles_img));
-    const int rem = __builtin_amdgcn_readfirstlane((int)(tile - (long long)b * tiles_img));
-    const int it = rem / jt_n, jt = rem - it * jt_n;
+  for (long long sup = wg; sup < nsupers; sup += nwg) {
+    const int b = __builtin_amdgcn_readfirstlane((int)(sup / supers_img));
+    const int rem = __builtin_amdgcn_readfirstlane((int)(sup - (long long)b * supers_img));
+#ifdef EGTR_RH_TILES_IN_A_ROW
+    const int it = rem / sjt_n, jt = (rem - it * sjt_n) * 8 + wave;
+#else
+    const int it = (rem / sjt_n) * 2 + (wave >> 2), jt = (rem % sjt_n) * 4 + (wave & 3);
+#endif
+    if (it >= it_n || jt >= jt_n) continue;   // (wave-uniform; no workgroup barrier inside the loop)
     const int i = it * 4 + il, j = jt * 8 + jl;
     const bool valid = i < N && j < N;
     const int ic = min(i, N - 1), jc = min(j, N - 1);
@@ -373,7 +387,8 @@ extern "C" int egtr_rel_head_forward_bf16p(egtr_stream_t stream, const float* ga
   A.b1 = b1; A.w2r = w2r; A.b2r = b2r; A.w3r = w3r; A.b3r = b3r; A.w2c = w2c; A.b2c = b2c; A.w3c = w3c; A.b3c = b3c;
   A.triplet = triplet_dist; A.node_cls = node_cls; A.rel_logits = rel_logits; A.conn_logits = conn_logits;
   A.gate_mean = gate_mean; A.B = batch; A.N = num_query; A.R = num_rel; A.C1 = num_cls_plus1;
-  const long long ntiles = (long long)batch * ((num_query + 3) / 4) * ((num_query + 7) / 8);
+  const long long it_n = (num_query + 3) / 4, jt_n = (num_query + 7) / 8;
+  const long long ntiles = (long long)batch * ((it_n + 1) / 2) * ((jt_n + 3) / 4) * kWaves;   // 2 x 4 tile blocks per workgroup step
   // persistent workgroups, one per CU (128 KiB of LDS): even ids the relation MLP, odd ids the connectivity MLP
   int cus = 256;
   {
