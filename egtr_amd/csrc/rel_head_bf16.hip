@@ -248,10 +248,18 @@ __global__ __launch_bounds__(64 * kWaves) void rel_head_fwd_bf16p(RhArgs A) {
         h1b[2 * (C)] = pack8(lo);                                                                                \
         h1b[2 * (C) + 1] = pack8(hi);                                                                            \
       }
+#ifdef EGTR_RH_ABL_NO_L1
+      if (A.B < 0) {
+#endif
       EGTR_L1_ISSUE(0, 0) EGTR_L1_ISSUE(0, 1) EGTR_L1_ISSUE(0, 2) EGTR_L1_ISSUE(0, 3) EGTR_L1_ISSUE(0, 4) EGTR_L1_ISSUE(0, 5)
       EGTR_L1_ISSUE(0, 6) EGTR_L1_ISSUE(0, 7) EGTR_L1_ISSUE(0, 8) EGTR_L1_ISSUE(0, 9) EGTR_L1_ISSUE(0, 10) EGTR_L1_ISSUE(0, 11)
       EGTR_L1_TILE(0) EGTR_L1_TILE(1) EGTR_L1_TILE(2) EGTR_L1_TILE(3) EGTR_L1_TILE(4) EGTR_L1_TILE(5) EGTR_L1_TILE(6)
       EGTR_L1_TILE(7)
+#ifdef EGTR_RH_ABL_NO_L1
+      } else {
+        for (int t2 = 0; t2 < 16; ++t2) h1b[t2] = gop;
+      }
+#endif
 #undef EGTR_L1_TILE
 #undef EGTR_L1_STEP
 #undef EGTR_L1_ISSUE
@@ -264,6 +272,9 @@ __global__ __launch_bounds__(64 * kWaves) void rel_head_fwd_bf16p(RhArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) racc[ot][r] = 0.f;
     float cacc = 0.f;
+#ifdef EGTR_RH_ABL_NO_L23
+    if (A.B < 0)
+#endif
 #pragma unroll 1
     for (int nt = 0; nt < kHd / 32; ++nt) {
       f32x16 acc;
@@ -331,7 +342,11 @@ __global__ __launch_bounds__(64 * kWaves) void rel_head_fwd_bf16p(RhArgs A) {
       const int pr = p0 + 4 * hf, tbp = hf ? tb1 : tb0;
       const int pil = pr >> 3, pjl = pr & 7;
       const int gi = it * 4 + pil, gj = jt * 8 + pjl;
+#ifdef EGTR_RH_ABL_NO_STORE
+      if (gi < N && gj < N && A.B < 0) {
+#else
       if (gi < N && gj < N) {
+#endif
         float* dst = A.rel_logits + (((size_t)b * N + gi) * N + gj) * R;
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) {
