@@ -11,4 +11,11 @@ Layout:
   util.py             loss helpers (mirror of model/util.py)
   runtime.py          one-process-per-GPU data-parallel helpers (RCCL via torch.distributed), HIP-graph capture
 """
+import os as _os
+
+# The bf16 backbone runs channels-last (egtr_amd.backbone, NHWC_BF16): PyTorch-ROCm hands channels-last tensors to MIOpen's NHWC
+# convolutions only with this switch, read ONCE at the process's first convolution -- so it is set at import, before any.  fp32
+# tensors stay contiguous NCHW and are not affected.
+_os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+
 __version__ = "0.1.0"

@@ -46,6 +46,7 @@ SIGNATURES = {
     "egtr_scale_rows_multi_f32": [_P, _I, _P, _P, _P, _P, _P],
     "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_bias_act_nchw_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
+    "egtr_bias_act_nhwc_bf16": [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I],
     "egtr_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
     "egtr_add_layernorm_pos_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _I, _P],
     "egtr_add_layernorm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],

@@ -15,6 +15,11 @@ from torch import nn
 
 
 TRAIN_FUSED_EPILOGUE = os.environ.get("EGTR_BACKBONE_TRAIN_FUSED", "1") != "0"
+# bf16 inference: the backbone behind the stem runs channels-last -- MIOpen's NHWC 3x3 convolutions on the tensors as they lie
+# (on NCHW tensors the same kernels run between two layout transposes: 418 vs 176 us for a layer-1 convolution at bs 16,
+# tools/nhwc_probe.py) and the 1x1 convolutions as plain [N*H*W, Cin] x [Cin, Cout] GEMMs with bias (+ ReLU) in the epilogue.
+# "0": NCHW throughout.
+NHWC_BF16 = os.environ.get("EGTR_BACKBONE_NHWC_BF16", "1") != "0"
 
 
 def _fold(conv, bn):
@@ -167,6 +172,46 @@ class Bottleneck(nn.Module):
             p.append((None, (p[2][1] + p[3][1]).contiguous()))
         return p
 
+    def folded_params_nhwc(self):
+        """Folded weights for the channels-last bf16 path: 1x1 convolutions as [Cout, Cin] matrices (+ their shift as a bf16 bias
+        for the GEMM epilogue where a ReLU follows directly), the 3x3 as a channels-last weight; shifts in fp32 for the epilogue
+        kernel."""
+        p = self.folded_params()
+        w1, b1 = p[0]
+        w2, b2 = p[1]
+        w3, b3 = p[2]
+        out = {"w1": w1.reshape(w1.shape[0], -1).contiguous(), "b1": b1.to(w1.dtype).contiguous(),
+               "w2": w2.contiguous(memory_format=torch.channels_last), "b2": b2,
+               "w3": w3.reshape(w3.shape[0], -1).contiguous(), "b3": b3, "wd": None}
+        if self.downsample is not None:
+            wd = p[3][0]
+            out["wd"] = (wd.reshape(wd.shape[0], -1).contiguous() if tuple(self.downsample[0].stride) == (1, 1)
+                         else wd.contiguous(memory_format=torch.channels_last))
+            out["b3"] = p[4][1]     # the shortcut's shift rides along with conv3's
+        return out
+
+    def forward_folded_nhwc(self, x, q):
+        """Inference, bf16, x a channels-last [B, C, H, W] tensor: conv1 = GEMM + bias + ReLU in its epilogue (no pass of its
+        own), conv2 = MIOpen NHWC + one epilogue pass, conv3 = GEMM, then shift + shortcut + ReLU in one pass."""
+        from . import ops
+        B, C, H, W_ = x.shape
+        x2 = x.permute(0, 2, 3, 1).reshape(-1, C)                      # a view: channels-last IS [B*H*W, C]
+        y = torch._addmm_activation(q["b1"], x2, q["w1"].t(), use_gelu=False)
+        y = y.view(B, H, W_, -1).permute(0, 3, 1, 2)                   # channels-last view of the GEMM's output
+        y = F.conv2d(y, q["w2"], None, stride=self.conv2.stride, padding=1)
+        Ho, Wo = y.shape[-2:]
+        y2 = y.permute(0, 2, 3, 1).reshape(-1, y.shape[1])
+        ops.bias_act_rows_(y2, q["b2"])
+        z = torch.mm(y2, q["w3"].t())
+        if self.downsample is None:
+            idt = x2
+        elif q["wd"].dim() == 2:
+            idt = torch.mm(x2, q["wd"].t())
+        else:
+            idt = F.conv2d(x, q["wd"], None, stride=self.downsample[0].stride).permute(0, 2, 3, 1).reshape(-1, z.shape[1])
+        ops.bias_act_rows_(z, q["b3"], idt)
+        return z.view(B, Ho, Wo, -1).permute(0, 3, 1, 2)
+
     def forward_folded(self, x, p):
         """Inference path: frozen BN folded into the conv weights; the per-channel shift, the residual add and the ReLU
         are ONE fused HIP pass after each convolution (csrc/elementwise.hip).  (torch.miopen_convolution_relu was
@@ -271,6 +316,19 @@ class ResNet50Features(nn.Module):
             w, b = self._folded["stem"]
             x = self._stem_folded(x, w, b)
             feats = []
+            if NHWC_BF16 and x.dtype == torch.bfloat16 and hasattr(torch, "_addmm_activation"):
+                # channels-last behind the stem (the 3-channel stem convolution and the pool stay NCHW)
+                if "nhwc" not in self._folded:
+                    with torch.no_grad():
+                        self._folded["nhwc"] = {li: [blk.folded_params_nhwc() for blk in getattr(self, f"layer{li}")]
+                                                for li in range(1, 5)}
+                x = x.contiguous(memory_format=torch.channels_last)
+                for li in range(1, 5):
+                    for blk, q in zip(getattr(self, f"layer{li}"), self._folded["nhwc"][li]):
+                        x = blk.forward_folded_nhwc(x, q)
+                    if li in self.out_indices:
+                        feats.append(x.contiguous())       # the input projections read NCHW
+                return feats
             for li in range(1, 5):
                 for blk, p in zip(getattr(self, f"layer{li}"), self._folded[li]):
                     x = blk.forward_folded(x, p)

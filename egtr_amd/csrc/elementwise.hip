@@ -269,6 +269,42 @@ __global__ __launch_bounds__(256) void bias_act_nchw_flat8_bf16(const unsigned s
   }
 }
 
+// The same epilogue on a channels-last (NHWC) bf16 activation, i.e. a [rows, C] matrix: the 8 elements of a lane are 8
+// consecutive channels (C % 8 == 0), their biases two 16-byte loads.  Hardware bf16 conversion.
+__global__ __launch_bounds__(256) void bias_act_nhwc_flat8_bf16(const unsigned short* __restrict__ x,
+                                                                const float* __restrict__ bias,
+                                                                const unsigned short* __restrict__ res,
+                                                                unsigned short* __restrict__ y, long long n8, int C, int relu) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const int c0 = (int)((i * 8) % C);
+    const float4 ba = *reinterpret_cast<const float4*>(bias + c0), bb = *reinterpret_cast<const float4*>(bias + c0 + 4);
+    float v[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[i], v);
+    v[0] += ba.x; v[1] += ba.y; v[2] += ba.z; v[3] += ba.w;
+    v[4] += bb.x; v[5] += bb.y; v[6] += bb.z; v[7] += bb.w;
+    if (res != nullptr) {
+      float r[8];
+      unpack8(reinterpret_cast<const uint4*>(res)[i], r);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += r[k];
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = egtr_relu(v[k]);
+    }
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bf16x2 pr;
+      pr[0] = (__bf16)v[2 * k];
+      pr[1] = (__bf16)v[2 * k + 1];
+      w[k] = __builtin_bit_cast(unsigned, pr);
+    }
+    reinterpret_cast<uint4*>(y)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void bias_act_nchw_scalar_bf16(const unsigned short* __restrict__ x,
                                                                  const float* __restrict__ bias,
                                                                  const unsigned short* __restrict__ res,
@@ -999,6 +1035,20 @@ extern "C" int egtr_bias_act_nchw_bf16(egtr_stream_t stream, const uint16_t* x, 
     const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(bias_act_nchw_scalar_bf16, dim3(blocks), dim3(256), 0, st, x, bias, residual, y, n, C, HW, relu);
   }
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_bias_act_nhwc_bf16(egtr_stream_t stream, const uint16_t* x, const float* bias, const uint16_t* residual,
+                                       uint16_t* y, long long rows, int C, int relu) {
+  if (!x || !bias || !y) return EGTR_E_ARG;
+  if (rows <= 0 || C <= 0) return EGTR_E_ARG;
+  if (C % 8 != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+                      reinterpret_cast<uintptr_t>(bias)) & 15))
+    return EGTR_E_UNSUPPORTED;
+  const long long n8 = rows * C / 8;
+  const int blocks = (int)std::min<long long>((n8 + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(bias_act_nhwc_flat8_bf16, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, residual,
+                     y, n8, C, relu);
   return egtr_check_launch();
 }
 

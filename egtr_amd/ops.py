@@ -1579,6 +1579,24 @@ def scale_rows_multi(tensors, scales):
     return out
 
 
+def bias_act_rows_(x2d, bias, residual=None, relu=True):
+    """In-place y = act(x + bias[c] (+ residual)) on a channels-last bf16 activation given as its [rows, C] matrix
+    (egtr_bias_act_nhwc_bf16; fp32 bias).  Inference only."""
+    lib = _lib.lib()
+    _chk(x2d, "x", torch.bfloat16)
+    _chk(bias, "bias", torch.float32)
+    if residual is not None:
+        _chk(residual, "residual", torch.bfloat16)
+        if residual.shape != x2d.shape:
+            raise ValueError("bias_act_rows_: residual must have the shape of x")
+    rows, C = x2d.shape
+    st = lib.egtr_bias_act_nhwc_bf16(_stream(), x2d.data_ptr(), bias.data_ptr(),
+                                     residual.data_ptr() if residual is not None else None, x2d.data_ptr(), rows, C,
+                                     1 if relu else 0)
+    _lib.check(st, "egtr_bias_act_nhwc_bf16")
+    return x2d
+
+
 def bias_act_(x, bias, residual=None, relu=True):
     """In-place y = act(x + bias[c] (+ residual)) on an NCHW activation (inference only, no autograd).  fp32, or bf16
     activations with an fp32 bias."""

@@ -363,6 +363,11 @@ int egtr_bias_act_nchw_bf16(egtr_stream_t stream, const uint16_t* x, const float
                             uint16_t* y, int N, int C, int HW, int relu);
 int egtr_add_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual, const uint16_t* gamma,
                             const uint16_t* beta, uint16_t* y, int rows, int dim, float eps);
+/* The bias / residual / ReLU epilogue on a channels-last (NHWC) bf16 activation = a [rows, C] matrix (rows = N*H*W; C % 8 == 0,
+ * 16-byte aligned; y may alias x): the layout in which the bf16 backbone runs (MIOpen's NHWC convolutions, 1x1 convolutions as
+ * plain GEMMs). */
+int egtr_bias_act_nhwc_bf16(egtr_stream_t stream, const uint16_t* x, const float* bias, const uint16_t* residual, uint16_t* y,
+                            long long rows, int C, int relu);
 /* ... and y_plus_pos = bf16(y + pos[row % pos_rows]) from the SAME launch: the next encoder layer's `hidden + pos`
  * (deformable_detr.py:1041), rounded like the reference's bf16 add of the already rounded y.  rows % pos_rows == 0. */
 int egtr_add_layernorm_pos_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual, const uint16_t* gamma,
