@@ -314,21 +314,26 @@ class ResNet50Features(nn.Module):
                 self._folded_key = key
             from . import ops
             w, b = self._folded["stem"]
-            x = self._stem_folded(x, w, b)
             feats = []
             if NHWC_BF16 and x.dtype == torch.bfloat16 and hasattr(torch, "_addmm_activation"):
-                # channels-last behind the stem (the 3-channel stem convolution and the pool stay NCHW)
+                # channels-last from the pixels on: the stem convolution and the pool on channels-last tensors as well (the
+                # stem ran MIOpen's NHWC kernel between two layout transposes anyway), shift + ReLU on the pooled tensor
                 if "nhwc" not in self._folded:
                     with torch.no_grad():
                         self._folded["nhwc"] = {li: [blk.folded_params_nhwc() for blk in getattr(self, f"layer{li}")]
                                                 for li in range(1, 5)}
-                x = x.contiguous(memory_format=torch.channels_last)
+                        self._folded["nhwc"]["stem"] = w.contiguous(memory_format=torch.channels_last)
+                x = F.conv2d(x.contiguous(memory_format=torch.channels_last), self._folded["nhwc"]["stem"], None, stride=2,
+                             padding=3)
+                x = self.maxpool(x).contiguous(memory_format=torch.channels_last)    # (already channels-last: no copy)
+                ops.bias_act_rows_(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), b)
                 for li in range(1, 5):
                     for blk, q in zip(getattr(self, f"layer{li}"), self._folded["nhwc"][li]):
                         x = blk.forward_folded_nhwc(x, q)
                     if li in self.out_indices:
                         feats.append(x.contiguous())       # the input projections read NCHW
                 return feats
+            x = self._stem_folded(x, w, b)
             for li in range(1, 5):
                 for blk, p in zip(getattr(self, f"layer{li}"), self._folded[li]):
                     x = blk.forward_folded(x, p)
