@@ -57,6 +57,7 @@ SIGNATURES = {
                                  _P, _P],
     "egtr_input_proj_groupnorm_flatten_f32": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_input_proj_groupnorm_flatten_bf16": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
+    "egtr_input_proj_groupnorm_tokens_bf16": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_bbox_overlaps_f64": [_P, _P, _P, _I, _I, _I, _P],
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],

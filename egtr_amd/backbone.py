@@ -331,7 +331,7 @@ class ResNet50Features(nn.Module):
                     for blk, q in zip(getattr(self, f"layer{li}"), self._folded["nhwc"][li]):
                         x = blk.forward_folded_nhwc(x, q)
                     if li in self.out_indices:
-                        feats.append(x.contiguous())       # the input projections read NCHW
+                        feats.append(x)       # channels-last: DeformableDetrModel projects them as token matrices
                 return feats
             x = self._stem_folded(x, w, b)
             for li in range(1, 5):

@@ -853,6 +853,127 @@ static int groupnorm_flatten_launch(egtr_stream_t stream, int num_levels, const 
   return egtr_check_launch();
 }
 
+// ---- the same epilogue for TOKEN-MAJOR bf16 projections (channels-last backbone): x_l is [B, H_l*W_l, 256], the bias-free
+// output of the level's 1x1 convolution run as a plain GEMM.  With 32 groups of 8 channels a 16-byte chunk is exactly one
+// (token, group): no transpose anywhere.  Two launches for all levels.
+struct GnTokLevels {
+  const unsigned short* x[4];
+  const float* conv_bias[4];
+  const float* gamma[4];
+  const float* beta[4];
+  int hw[4], start[4];
+  long long chunk0[5];   // first 16-byte chunk of a level in the flat apply grid (per image)
+};
+
+namespace {
+// stats[(l * B + b) * 32 + g] = (mean, rstd) of (x + conv_bias) over the 8 channels x H_l W_l tokens of group g: one workgroup
+// per (image, level), thread = (group t & 31, token phase t >> 5)
+__global__ __launch_bounds__(1024) void gn_stats_tokens(GnTokLevels P, float eps, float2* __restrict__ stats) {
+  __shared__ double s_red[2][32][33];
+  const int b = blockIdx.x, l = blockIdx.y, B = gridDim.x;
+  const int g = threadIdx.x & 31, ph = threadIdx.x >> 5, hw = P.hw[l];
+  const uint4* x = reinterpret_cast<const uint4*>(P.x[l] + (size_t)b * hw * 256) + g;
+  const float4 ba = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g), bb = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g + 4);
+  const float cb[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+  float s1 = 0.f, s2 = 0.f;
+  for (int t0 = ph; t0 < hw; t0 += 32 * 4) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = t0 + 32 * u < hw ? x[(size_t)(t0 + 32 * u) * 32] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (t0 + 32 * u < hw) {
+        float f[8];
+        unpack8(v[u], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float t = f[k] + cb[k];
+          s1 += t;
+          s2 += t * t;
+        }
+      }
+    }
+  }
+  s_red[0][g][ph] = (double)s1;
+  s_red[1][g][ph] = (double)s2;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < 32; ++w) {
+      t1 += s_red[0][threadIdx.x][w];
+      t2 += s_red[1][threadIdx.x][w];
+    }
+    const double n = 8.0 * hw, mean = t1 / n;
+    const double var = fmax(t2 / n - mean * mean, 0.0);  // biased, as nn.GroupNorm
+    stats[((size_t)l * B + b) * 32 + threadIdx.x] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_tokens(GnTokLevels P, int L, int S, const float2* __restrict__ stats,
+                                                       unsigned short* __restrict__ out) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  const int b = blockIdx.y, B = gridDim.y;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // 16-byte chunk of this image's [S, 256] output
+  if (i >= (long long)S * 32) return;
+  int l = 0;
+  while (l + 1 < L && i >= P.chunk0[l + 1]) ++l;
+  const long long rel = i - P.chunk0[l];
+  const int g = (int)(rel & 31);
+  const uint4 v = reinterpret_cast<const uint4*>(P.x[l] + (size_t)b * P.hw[l] * 256)[rel];
+  const float2 st = stats[((size_t)l * B + b) * 32 + g];
+  float f[8];
+  unpack8(v, f);
+  const float4 ca = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g), cb = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g + 4);
+  const float4 ga = *reinterpret_cast<const float4*>(P.gamma[l] + 8 * g), gb = *reinterpret_cast<const float4*>(P.gamma[l] + 8 * g + 4);
+  const float4 ea = *reinterpret_cast<const float4*>(P.beta[l] + 8 * g), eb = *reinterpret_cast<const float4*>(P.beta[l] + 8 * g + 4);
+  const float c8[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+  const float g8[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+  const float e8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
+  unsigned w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    bf16x2 pr;
+    pr[0] = (__bf16)((f[2 * k] + c8[2 * k] - st.x) * st.y * g8[2 * k] + e8[2 * k]);
+    pr[1] = (__bf16)((f[2 * k + 1] + c8[2 * k + 1] - st.x) * st.y * g8[2 * k + 1] + e8[2 * k + 1]);
+    w[k] = __builtin_bit_cast(unsigned, pr);
+  }
+  reinterpret_cast<uint4*>(out + ((size_t)b * S + P.start[l]) * 256)[rel] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+}  // namespace
+
+extern "C" int egtr_input_proj_groupnorm_tokens_bf16(egtr_stream_t stream, int num_levels, const uint16_t* const* x,
+                                                     const float* const* conv_bias, const float* const* gamma,
+                                                     const float* const* beta, const int* level_tokens, int batch,
+                                                     int channels, int num_groups, float eps, float* stats, uint16_t* out) {
+  if (!x || !conv_bias || !gamma || !beta || !level_tokens || !stats || !out) return EGTR_E_ARG;
+  if (num_levels < 1 || num_levels > 4 || batch <= 0) return EGTR_E_ARG;
+  if (channels != 256 || num_groups != 32) return EGTR_E_UNSUPPORTED;
+  GnTokLevels P;
+  int S = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int s = l < num_levels ? l : 0;
+    if (!x[s] || !conv_bias[s] || !gamma[s] || !beta[s] || level_tokens[s] <= 0) return EGTR_E_ARG;
+    if (reinterpret_cast<uintptr_t>(x[s]) & 15) return EGTR_E_UNSUPPORTED;
+    P.x[l] = x[s];
+    P.conv_bias[l] = conv_bias[s];
+    P.gamma[l] = gamma[s];
+    P.beta[l] = beta[s];
+    P.hw[l] = level_tokens[s];
+    P.start[l] = S;
+    P.chunk0[l] = (long long)S * 32;
+    if (l < num_levels) S += P.hw[l];
+  }
+  P.chunk0[4] = (long long)S * 32;
+  for (int l = num_levels; l < 4; ++l) P.chunk0[l] = (long long)S * 32;
+  if (reinterpret_cast<uintptr_t>(out) & 15) return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gn_stats_tokens, dim3(batch, num_levels), dim3(1024), 0, st, P, eps, reinterpret_cast<float2*>(stats));
+  const long long chunks = (long long)S * 32;
+  hipLaunchKernelGGL(gn_apply_tokens, dim3((unsigned)((chunks + 255) / 256), batch), dim3(256), 0, st, P, num_levels, S,
+                     reinterpret_cast<const float2*>(stats), out);
+  return egtr_check_launch();
+}
+
 extern "C" int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, const float* const* x,
                                                      const float* const* conv_bias, const float* const* gamma,
                                                      const float* const* beta, const int* level_hw, int batch,

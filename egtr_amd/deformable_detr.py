@@ -1296,7 +1296,32 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             else:  # a user-supplied feature extractor: keep its (feature, mask) interface, drop its masks
                 feature_maps = [fm for fm, _ in conv_encoder(pixel_values, pixel_mask)]
             n_extra = self.config.num_feature_levels - len(feature_maps)
-            if (n_extra <= 1 and self.config.d_model == 256 and feature_maps[0].dtype == pixel_values.dtype
+            channels_last = all(fm.dim() == 4 and fm.dtype == torch.bfloat16 and not fm.is_contiguous()
+                                and fm.is_contiguous(memory_format=torch.channels_last) for fm in feature_maps)
+            if (channels_last and n_extra <= 1 and self.config.d_model == 256
+                    and self.input_proj[0][0].weight.dtype == torch.bfloat16
+                    and all(isinstance(p[1], nn.GroupNorm) and p[1].num_groups == 32 and p[0].bias is not None
+                            and p[0].groups == 1 for p in self.input_proj)
+                    and all(tuple(self.input_proj[l][0].kernel_size) == (1, 1) and tuple(self.input_proj[l][0].stride) == (1, 1)
+                            and tuple(self.input_proj[l][0].padding) == (0, 0) for l in range(len(feature_maps)))):
+                # channels-last bf16 backbone: a feature map IS its [B*H*W, C] token matrix, the 1x1 projection a plain GEMM
+                # whose output is already `flatten(2).transpose(1, 2)`; GroupNorm + concatenation without a transpose
+                toks, spatial_shapes_list = [], []
+                for level, fm in enumerate(feature_maps):
+                    c = self.input_proj[level][0]
+                    b_, c_, h_, w_ = fm.shape
+                    toks.append(torch.mm(fm.permute(0, 2, 3, 1).reshape(-1, c_), c.weight.detach().view(c.weight.shape[0], c_).t())
+                                .view(b_, h_ * w_, -1))
+                    spatial_shapes_list.append((h_, w_))
+                if n_extra == 1:  # dd:2228-2241: the extra level is a strided 3x3 convolution of the last feature map
+                    c = self.input_proj[len(feature_maps)][0]
+                    wcl = ops.cached_weights(c, "weight_channels_last", [c.weight],
+                                             lambda: c.weight.detach().contiguous(memory_format=torch.channels_last))
+                    y = F.conv2d(feature_maps[-1], wcl, None, c.stride, c.padding)
+                    toks.append(y.permute(0, 2, 3, 1).reshape(y.shape[0], y.shape[2] * y.shape[3], y.shape[1]))
+                    spatial_shapes_list.append(tuple(y.shape[-2:]))
+                source_flatten = ops.input_proj_groupnorm_tokens(toks, self.input_proj)
+            elif (n_extra <= 1 and self.config.d_model == 256 and feature_maps[0].dtype == pixel_values.dtype
                     and self.input_proj[0][0].weight.dtype == pixel_values.dtype
                     and all(isinstance(p[1], nn.GroupNorm) and p[0].bias is not None for p in self.input_proj)):
                 # input projections: bias-free convolutions, then conv bias + GroupNorm + flatten + transpose + cat

@@ -1711,6 +1711,36 @@ def input_proj_groupnorm_flatten(conv_outputs, input_projs):
     return out
 
 
+def input_proj_groupnorm_tokens(token_outputs, input_projs):
+    """The same for TOKEN-MAJOR bf16 projections [B, H_l*W_l, 256] (the channels-last backbone: the level's 1x1 convolution run as
+    a plain GEMM, bias-free): conv bias + GroupNorm(32) + concatenation in two launches, no transpose
+    (egtr_input_proj_groupnorm_tokens_bf16).  Returns [B, S, 256] bf16.  Inference only."""
+    import ctypes
+    lib = _lib.lib()
+    L = len(token_outputs)
+    B = token_outputs[0].shape[0]
+    gn0 = input_projs[0][1]
+    xs = [_chk(x.contiguous(), "token-major projection", torch.bfloat16) for x in token_outputs]
+    for proj, x in zip(input_projs[:L], xs):
+        conv, gn = proj[0], proj[1]
+        if gn.num_groups != 32 or gn.eps != gn0.eps or conv.bias is None or x.shape[-1] != 256 or x.shape[0] != B:
+            raise ValueError("input_proj_groupnorm_tokens: 256 channels in 32 groups, one GroupNorm configuration")
+    srcs = [t for proj in input_projs[:L] for t in (proj[0].bias, proj[1].weight, proj[1].bias)]
+    flat = cached_weights(input_projs, "gn_params_f32", srcs, lambda: [t.detach().float().contiguous() for t in srcs])
+    keep = [tuple(flat[3 * l:3 * l + 3]) for l in range(L)]
+    toks = [int(x.shape[1]) for x in xs]
+    S = sum(toks)
+    out = torch.empty(B, S, 256, dtype=torch.bfloat16, device=xs[0].device)
+    stats = torch.empty(L * B * 32 * 2, dtype=torch.float32, device=xs[0].device)
+    PA, IA = ctypes.c_void_p * L, ctypes.c_int * L
+    st = lib.egtr_input_proj_groupnorm_tokens_bf16(
+        _stream(), L, PA(*[x.data_ptr() for x in xs]), PA(*[k[0].data_ptr() for k in keep]),
+        PA(*[k[1].data_ptr() for k in keep]), PA(*[k[2].data_ptr() for k in keep]), IA(*toks), B, 256, 32, float(gn0.eps),
+        stats.data_ptr(), out.data_ptr())
+    _lib.check(st, "egtr_input_proj_groupnorm_tokens_bf16")
+    return out
+
+
 _DIM_T = {}
 
 

@@ -497,6 +497,14 @@ int egtr_input_proj_groupnorm_flatten_bf16(egtr_stream_t stream, int num_levels,
                                            const float* const* beta, const int* level_hw, int batch, int channels,
                                            int num_groups, float eps, float* stats, uint16_t* out);
 
+/* The same epilogue for TOKEN-MAJOR bf16 projections (the channels-last backbone): x[l] is [B, level_tokens[l], 256], the
+ * bias-free output of the level's 1x1 convolution run as a plain GEMM on the channels-last feature map; 32 groups of 8 channels
+ * (a 16-byte chunk = one token's group).  stats: num_levels * B * 32 * 2 floats; out: [B, S, 256] bf16. */
+int egtr_input_proj_groupnorm_tokens_bf16(egtr_stream_t stream, int num_levels, const uint16_t* const* x,
+                                          const float* const* conv_bias, const float* const* gamma,
+                                          const float* const* beta, const int* level_tokens, int batch, int channels,
+                                          int num_groups, float eps, float* stats, uint16_t* out);
+
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):
  *   gate_q [B, N, T], gate_k [B, N, T]   : w_g[:d].q^[i,t]  and  w_g[d:].k^[j,t] + b_g      (T = Ld + 1 slots)

@@ -1012,6 +1012,51 @@ def test_input_proj_groupnorm_flatten_bf16_matches_torch():
     assert torch.equal(got, again)
 
 
+def test_input_proj_groupnorm_tokens_bf16_matches_torch_and_the_nchw_kernel():
+    """Token-major entry (channels-last backbone): [B, HW_l, 256] bf16 projections in, conv bias + GroupNorm(32) + concatenation
+    out -- against the fp64 GroupNorm of the same bf16 inputs (half a bf16 ulp) and against the NCHW entry on the transposed
+    inputs (the same fp32 arithmetic: equal up to the order of the statistics' sums, i.e. at most one bf16 ulp apart)."""
+    import torch.nn as nn
+    from egtr_amd import ops
+    torch.manual_seed(9)
+    shapes = [(19, 33), (10, 17), (5, 9), (3, 3)]
+    projs = nn.ModuleList([nn.Sequential(nn.Conv2d(8, 256, 1), nn.GroupNorm(32, 256)) for _ in shapes])
+    with torch.no_grad():
+        for p in projs:
+            p[0].bias.normal_()
+            p[1].weight.normal_()
+            p[1].bias.normal_()
+    projs = projs.bfloat16()
+    xs = [(3.0 * torch.randn(2, 256, h, w) + 1.5).bfloat16() for h, w in shapes]
+    toks = [x.flatten(2).transpose(1, 2).contiguous().to(DEV) for x in xs]
+    with torch.no_grad():
+        want = torch.cat([nn.functional.group_norm(x.double() + p[0].bias.double().view(1, -1, 1, 1), 32, p[1].weight.double(),
+                                                   p[1].bias.double(), p[1].eps).flatten(2).transpose(1, 2)
+                          for p, x in zip(projs, xs)], 1)
+        got = ops.input_proj_groupnorm_tokens(toks, projs.to(DEV))
+        nchw = ops.input_proj_groupnorm_flatten([x.to(DEV) for x in xs], projs.to(DEV))
+    assert got.dtype == torch.bfloat16 and got.shape == want.shape
+    err = (got.cpu().double() - want).abs()
+    assert float((err / want.abs().clamp_min(1.0)).max()) < 2.0 ** -8
+    assert float(((got.float() - nchw.float()).abs() / nchw.float().abs().clamp_min(1.0)).max()) <= 2.0 ** -7
+
+
+@pytest.mark.parametrize("rows,C", [(1, 8), (33, 64), (16 * 1000, 256), (977, 2048)])
+def test_bias_act_rows_bf16_channels_last(rows, C):
+    """egtr_bias_act_nhwc_bf16: y = act(x + bias[c] (+ residual)) on a [rows, C] bf16 matrix, in place, against torch in fp32
+    rounded once."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g).bfloat16().to(DEV)
+    r = torch.randn(rows, C, generator=g).bfloat16().to(DEV)
+    b = torch.randn(C, generator=g).to(DEV)
+    for res, relu in ((None, True), (r, True), (r, False)):
+        want = x.float() + b + (res.float() if res is not None else 0.0)
+        want = (want.relu() if relu else want).bfloat16()
+        got = ops.bias_act_rows_(x.clone(), b, res, relu)
+        assert torch.equal(got, want), (res is not None, relu)
+
+
 @pytest.mark.parametrize("N,C,H,Wd", [(2, 64, 25, 42), (1, 256, 100, 167), (3, 8, 3, 3), (1, 5, 1, 7), (2, 16, 50, 84)])
 def test_bias_act_nchw_bf16(N, C, H, Wd):
     from egtr_amd.ops import bias_act_
