@@ -47,6 +47,7 @@ SIGNATURES = {
     "egtr_bias_act_nchw_f32": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_bias_act_nchw_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _I],
     "egtr_bias_act_nhwc_bf16": [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I],
+    "egtr_bias_act_nhwc_f32": [_P, _P, _P, _P, _P, ctypes.c_longlong, _I, _I],
     "egtr_add_layernorm_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
     "egtr_add_layernorm_pos_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float, _P, _I, _P],
     "egtr_add_layernorm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, ctypes.c_float],
@@ -58,6 +59,7 @@ SIGNATURES = {
     "egtr_input_proj_groupnorm_flatten_f32": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_input_proj_groupnorm_flatten_bf16": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_input_proj_groupnorm_tokens_bf16": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
+    "egtr_input_proj_groupnorm_tokens_f32": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_bbox_overlaps_f64": [_P, _P, _P, _I, _I, _I, _P],
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],

@@ -20,6 +20,10 @@ TRAIN_FUSED_EPILOGUE = os.environ.get("EGTR_BACKBONE_TRAIN_FUSED", "1") != "0"
 # tools/nhwc_probe.py) and the 1x1 convolutions as plain [N*H*W, Cin] x [Cin, Cout] GEMMs with bias (+ ReLU) in the epilogue.
 # "0": NCHW throughout.
 NHWC_BF16 = os.environ.get("EGTR_BACKBONE_NHWC_BF16", "1") != "0"
+# fp32 inference: the same layout behind the (NCHW, fused pool) stem -- MIOpen's NHWC 3x3 kernels measure 10-30 % faster than
+# its NCHW choices at bs 1 (tools/nhwc_probe.py --fp32: 786 -> 660 us over the 16 convolutions) and the conv1 epilogue
+# launches disappear into the GEMMs.  "0": NCHW throughout.
+NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC_F32", "1") != "0"
 
 
 def _fold(conv, bn):
@@ -315,18 +319,23 @@ class ResNet50Features(nn.Module):
             from . import ops
             w, b = self._folded["stem"]
             feats = []
-            if NHWC_BF16 and x.dtype == torch.bfloat16 and hasattr(torch, "_addmm_activation"):
-                # channels-last from the pixels on: the stem convolution and the pool on channels-last tensors as well (the
-                # stem ran MIOpen's NHWC kernel between two layout transposes anyway), shift + ReLU on the pooled tensor
+            if (((NHWC_BF16 and x.dtype == torch.bfloat16) or (NHWC_F32 and x.dtype == torch.float32))
+                    and hasattr(torch, "_addmm_activation")):
                 if "nhwc" not in self._folded:
                     with torch.no_grad():
                         self._folded["nhwc"] = {li: [blk.folded_params_nhwc() for blk in getattr(self, f"layer{li}")]
                                                 for li in range(1, 5)}
                         self._folded["nhwc"]["stem"] = w.contiguous(memory_format=torch.channels_last)
-                x = F.conv2d(x.contiguous(memory_format=torch.channels_last), self._folded["nhwc"]["stem"], None, stride=2,
-                             padding=3)
-                x = self.maxpool(x).contiguous(memory_format=torch.channels_last)    # (already channels-last: no copy)
-                ops.bias_act_rows_(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), b)
+                if x.dtype == torch.bfloat16:
+                    # channels-last from the pixels on: the stem convolution and the pool on channels-last tensors as well (the
+                    # stem ran MIOpen's NHWC kernel between two layout transposes anyway), shift + ReLU on the pooled tensor
+                    x = F.conv2d(x.contiguous(memory_format=torch.channels_last), self._folded["nhwc"]["stem"], None, stride=2,
+                                 padding=3)
+                    x = self.maxpool(x).contiguous(memory_format=torch.channels_last)    # (already channels-last: no copy)
+                    ops.bias_act_rows_(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), b)
+                else:
+                    # fp32: the stem keeps its one-pass pool + shift + ReLU kernel (NCHW); the pooled map changes layout once
+                    x = self._stem_folded(x, w, b).contiguous(memory_format=torch.channels_last)
                 for li in range(1, 5):
                     for blk, q in zip(getattr(self, f"layer{li}"), self._folded["nhwc"][li]):
                         x = blk.forward_folded_nhwc(x, q)

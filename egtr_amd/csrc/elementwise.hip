@@ -857,7 +857,7 @@ static int groupnorm_flatten_launch(egtr_stream_t stream, int num_levels, const 
 // output of the level's 1x1 convolution run as a plain GEMM.  With 32 groups of 8 channels a 16-byte chunk is exactly one
 // (token, group): no transpose anywhere.  Two launches for all levels.
 struct GnTokLevels {
-  const unsigned short* x[4];
+  const void* x[4];        // bf16 bits or fp32
   const float* conv_bias[4];
   const float* gamma[4];
   const float* beta[4];
@@ -866,28 +866,36 @@ struct GnTokLevels {
 };
 
 namespace {
+// the 8 channels of (token, group) number `idx` of a [tokens, 256] matrix
+__device__ __forceinline__ void load_group8(const unsigned short* x, size_t idx, float (&f)[8]) {
+  unpack8(reinterpret_cast<const uint4*>(x)[idx], f);
+}
+__device__ __forceinline__ void load_group8(const float* x, size_t idx, float (&f)[8]) {
+  const float4 a = reinterpret_cast<const float4*>(x)[2 * idx], b = reinterpret_cast<const float4*>(x)[2 * idx + 1];
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
 // stats[(l * B + b) * 32 + g] = (mean, rstd) of (x + conv_bias) over the 8 channels x H_l W_l tokens of group g: one workgroup
 // per (image, level), thread = (group t & 31, token phase t >> 5)
+template <typename T>
 __global__ __launch_bounds__(1024) void gn_stats_tokens(GnTokLevels P, float eps, float2* __restrict__ stats) {
   __shared__ double s_red[2][32][33];
   const int b = blockIdx.x, l = blockIdx.y, B = gridDim.x;
   const int g = threadIdx.x & 31, ph = threadIdx.x >> 5, hw = P.hw[l];
-  const uint4* x = reinterpret_cast<const uint4*>(P.x[l] + (size_t)b * hw * 256) + g;
+  const T* x = static_cast<const T*>(P.x[l]) + (size_t)b * hw * 256;
   const float4 ba = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g), bb = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g + 4);
   const float cb[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
   float s1 = 0.f, s2 = 0.f;
   for (int t0 = ph; t0 < hw; t0 += 32 * 4) {
-    uint4 v[4];
+    float f[4][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = t0 + 32 * u < hw ? x[(size_t)(t0 + 32 * u) * 32] : make_uint4(0u, 0u, 0u, 0u);
+    for (int u = 0; u < 4; ++u)
+      if (t0 + 32 * u < hw) load_group8(x, (size_t)(t0 + 32 * u) * 32 + g, f[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (t0 + 32 * u < hw) {
-        float f[8];
-        unpack8(v[u], f);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float t = f[k] + cb[k];
+          const float t = f[u][k] + cb[k];
           s1 += t;
           s2 += t * t;
         }
@@ -909,8 +917,9 @@ __global__ __launch_bounds__(1024) void gn_stats_tokens(GnTokLevels P, float eps
   }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_tokens(GnTokLevels P, int L, int S, const float2* __restrict__ stats,
-                                                       unsigned short* __restrict__ out) {
+                                                       T* __restrict__ out) {
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   const int b = blockIdx.y, B = gridDim.y;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;      // 16-byte chunk of this image's [S, 256] output
@@ -919,32 +928,39 @@ __global__ __launch_bounds__(256) void gn_apply_tokens(GnTokLevels P, int L, int
   while (l + 1 < L && i >= P.chunk0[l + 1]) ++l;
   const long long rel = i - P.chunk0[l];
   const int g = (int)(rel & 31);
-  const uint4 v = reinterpret_cast<const uint4*>(P.x[l] + (size_t)b * P.hw[l] * 256)[rel];
   const float2 st = stats[((size_t)l * B + b) * 32 + g];
   float f[8];
-  unpack8(v, f);
+  load_group8(static_cast<const T*>(P.x[l]) + (size_t)b * P.hw[l] * 256, (size_t)rel, f);
   const float4 ca = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g), cb = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g + 4);
   const float4 ga = *reinterpret_cast<const float4*>(P.gamma[l] + 8 * g), gb = *reinterpret_cast<const float4*>(P.gamma[l] + 8 * g + 4);
   const float4 ea = *reinterpret_cast<const float4*>(P.beta[l] + 8 * g), eb = *reinterpret_cast<const float4*>(P.beta[l] + 8 * g + 4);
   const float c8[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
   const float g8[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
   const float e8[8] = {ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, eb.z, eb.w};
-  unsigned w[4];
+  float o[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    bf16x2 pr;
-    pr[0] = (__bf16)((f[2 * k] + c8[2 * k] - st.x) * st.y * g8[2 * k] + e8[2 * k]);
-    pr[1] = (__bf16)((f[2 * k + 1] + c8[2 * k + 1] - st.x) * st.y * g8[2 * k + 1] + e8[2 * k + 1]);
-    w[k] = __builtin_bit_cast(unsigned, pr);
+  for (int k = 0; k < 8; ++k) o[k] = (f[k] + c8[k] - st.x) * st.y * g8[k] + e8[k];
+  T* dst = out + ((size_t)b * S + P.start[l]) * 256;
+  if constexpr (sizeof(T) == 2) {
+    unsigned w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bf16x2 pr;
+      pr[0] = (__bf16)o[2 * k];
+      pr[1] = (__bf16)o[2 * k + 1];
+      w[k] = __builtin_bit_cast(unsigned, pr);
+    }
+    reinterpret_cast<uint4*>(dst)[rel] = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    reinterpret_cast<float4*>(dst)[2 * rel] = make_float4(o[0], o[1], o[2], o[3]);
+    reinterpret_cast<float4*>(dst)[2 * rel + 1] = make_float4(o[4], o[5], o[6], o[7]);
   }
-  reinterpret_cast<uint4*>(out + ((size_t)b * S + P.start[l]) * 256)[rel] = make_uint4(w[0], w[1], w[2], w[3]);
 }
 }  // namespace
 
-extern "C" int egtr_input_proj_groupnorm_tokens_bf16(egtr_stream_t stream, int num_levels, const uint16_t* const* x,
-                                                     const float* const* conv_bias, const float* const* gamma,
-                                                     const float* const* beta, const int* level_tokens, int batch,
-                                                     int channels, int num_groups, float eps, float* stats, uint16_t* out) {
+static int groupnorm_tokens_launch(egtr_stream_t stream, int num_levels, const void* const* x, const float* const* conv_bias,
+                                   const float* const* gamma, const float* const* beta, const int* level_tokens, int batch,
+                                   int channels, int num_groups, float eps, float* stats, void* out, bool bf16) {
   if (!x || !conv_bias || !gamma || !beta || !level_tokens || !stats || !out) return EGTR_E_ARG;
   if (num_levels < 1 || num_levels > 4 || batch <= 0) return EGTR_E_ARG;
   if (channels != 256 || num_groups != 32) return EGTR_E_UNSUPPORTED;
@@ -967,11 +983,36 @@ extern "C" int egtr_input_proj_groupnorm_tokens_bf16(egtr_stream_t stream, int n
   for (int l = num_levels; l < 4; ++l) P.chunk0[l] = (long long)S * 32;
   if (reinterpret_cast<uintptr_t>(out) & 15) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(gn_stats_tokens, dim3(batch, num_levels), dim3(1024), 0, st, P, eps, reinterpret_cast<float2*>(stats));
   const long long chunks = (long long)S * 32;
-  hipLaunchKernelGGL(gn_apply_tokens, dim3((unsigned)((chunks + 255) / 256), batch), dim3(256), 0, st, P, num_levels, S,
-                     reinterpret_cast<const float2*>(stats), out);
+  const dim3 agrid((unsigned)((chunks + 255) / 256), batch);
+  if (bf16) {
+    hipLaunchKernelGGL(gn_stats_tokens<unsigned short>, dim3(batch, num_levels), dim3(1024), 0, st, P, eps,
+                       reinterpret_cast<float2*>(stats));
+    hipLaunchKernelGGL(gn_apply_tokens<unsigned short>, agrid, dim3(256), 0, st, P, num_levels, S,
+                       reinterpret_cast<const float2*>(stats), static_cast<unsigned short*>(out));
+  } else {
+    hipLaunchKernelGGL(gn_stats_tokens<float>, dim3(batch, num_levels), dim3(1024), 0, st, P, eps,
+                       reinterpret_cast<float2*>(stats));
+    hipLaunchKernelGGL(gn_apply_tokens<float>, agrid, dim3(256), 0, st, P, num_levels, S,
+                       reinterpret_cast<const float2*>(stats), static_cast<float*>(out));
+  }
   return egtr_check_launch();
+}
+
+extern "C" int egtr_input_proj_groupnorm_tokens_bf16(egtr_stream_t stream, int num_levels, const uint16_t* const* x,
+                                                     const float* const* conv_bias, const float* const* gamma,
+                                                     const float* const* beta, const int* level_tokens, int batch,
+                                                     int channels, int num_groups, float eps, float* stats, uint16_t* out) {
+  return groupnorm_tokens_launch(stream, num_levels, reinterpret_cast<const void* const*>(x), conv_bias, gamma, beta,
+                                 level_tokens, batch, channels, num_groups, eps, stats, out, true);
+}
+
+extern "C" int egtr_input_proj_groupnorm_tokens_f32(egtr_stream_t stream, int num_levels, const float* const* x,
+                                                    const float* const* conv_bias, const float* const* gamma,
+                                                    const float* const* beta, const int* level_tokens, int batch,
+                                                    int channels, int num_groups, float eps, float* stats, float* out) {
+  return groupnorm_tokens_launch(stream, num_levels, reinterpret_cast<const void* const*>(x), conv_bias, gamma, beta,
+                                 level_tokens, batch, channels, num_groups, eps, stats, out, false);
 }
 
 extern "C" int egtr_input_proj_groupnorm_flatten_f32(egtr_stream_t stream, int num_levels, const float* const* x,
@@ -1156,6 +1197,39 @@ extern "C" int egtr_bias_act_nchw_bf16(egtr_stream_t stream, const uint16_t* x, 
     const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(bias_act_nchw_scalar_bf16, dim3(blocks), dim3(256), 0, st, x, bias, residual, y, n, C, HW, relu);
   }
+  return egtr_check_launch();
+}
+
+namespace {
+// fp32 twin: 4 consecutive channels per lane (C % 4 == 0)
+__global__ __launch_bounds__(256) void bias_act_nhwc_flat4_f32(const float* __restrict__ x, const float* __restrict__ bias,
+                                                               const float* __restrict__ res, float* __restrict__ y,
+                                                               long long n4, int C, int relu) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 b = *reinterpret_cast<const float4*>(bias + (int)((i * 4) % C));
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (res != nullptr) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (relu) v = make_float4(egtr_relu(v.x), egtr_relu(v.y), egtr_relu(v.z), egtr_relu(v.w));
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int egtr_bias_act_nhwc_f32(egtr_stream_t stream, const float* x, const float* bias, const float* residual, float* y,
+                                      long long rows, int C, int relu) {
+  if (!x || !bias || !y) return EGTR_E_ARG;
+  if (rows <= 0 || C <= 0) return EGTR_E_ARG;
+  if (C % 4 != 0 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+                      reinterpret_cast<uintptr_t>(bias)) & 15))
+    return EGTR_E_UNSUPPORTED;
+  const long long n4 = rows * C / 4;
+  const int blocks = (int)std::min<long long>((n4 + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(bias_act_nhwc_flat4_f32, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias, residual, y,
+                     n4, C, relu);
   return egtr_check_launch();
 }
 

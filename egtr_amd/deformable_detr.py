@@ -1296,15 +1296,15 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             else:  # a user-supplied feature extractor: keep its (feature, mask) interface, drop its masks
                 feature_maps = [fm for fm, _ in conv_encoder(pixel_values, pixel_mask)]
             n_extra = self.config.num_feature_levels - len(feature_maps)
-            channels_last = all(fm.dim() == 4 and fm.dtype == torch.bfloat16 and not fm.is_contiguous()
+            channels_last = all(fm.dim() == 4 and fm.dtype == pixel_values.dtype and not fm.is_contiguous()
                                 and fm.is_contiguous(memory_format=torch.channels_last) for fm in feature_maps)
             if (channels_last and n_extra <= 1 and self.config.d_model == 256
-                    and self.input_proj[0][0].weight.dtype == torch.bfloat16
+                    and self.input_proj[0][0].weight.dtype == pixel_values.dtype
                     and all(isinstance(p[1], nn.GroupNorm) and p[1].num_groups == 32 and p[0].bias is not None
                             and p[0].groups == 1 for p in self.input_proj)
                     and all(tuple(self.input_proj[l][0].kernel_size) == (1, 1) and tuple(self.input_proj[l][0].stride) == (1, 1)
                             and tuple(self.input_proj[l][0].padding) == (0, 0) for l in range(len(feature_maps)))):
-                # channels-last bf16 backbone: a feature map IS its [B*H*W, C] token matrix, the 1x1 projection a plain GEMM
+                # channels-last backbone: a feature map IS its [B*H*W, C] token matrix, the 1x1 projection a plain GEMM
                 # whose output is already `flatten(2).transpose(1, 2)`; GroupNorm + concatenation without a transpose
                 toks, spatial_shapes_list = [], []
                 for level, fm in enumerate(feature_maps):

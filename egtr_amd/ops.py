@@ -1580,20 +1580,23 @@ def scale_rows_multi(tensors, scales):
 
 
 def bias_act_rows_(x2d, bias, residual=None, relu=True):
-    """In-place y = act(x + bias[c] (+ residual)) on a channels-last bf16 activation given as its [rows, C] matrix
-    (egtr_bias_act_nhwc_bf16; fp32 bias).  Inference only."""
+    """In-place y = act(x + bias[c] (+ residual)) on a channels-last activation given as its [rows, C] matrix (bf16 or fp32
+    activations, fp32 bias: egtr_bias_act_nhwc_bf16 / _f32).  Inference only."""
     lib = _lib.lib()
-    _chk(x2d, "x", torch.bfloat16)
+    dt = x2d.dtype
+    if dt not in (torch.bfloat16, torch.float32):
+        raise TypeError("bias_act_rows_: bf16 or fp32 activations")
+    _chk(x2d, "x", dt)
     _chk(bias, "bias", torch.float32)
     if residual is not None:
-        _chk(residual, "residual", torch.bfloat16)
+        _chk(residual, "residual", dt)
         if residual.shape != x2d.shape:
             raise ValueError("bias_act_rows_: residual must have the shape of x")
     rows, C = x2d.shape
-    st = lib.egtr_bias_act_nhwc_bf16(_stream(), x2d.data_ptr(), bias.data_ptr(),
-                                     residual.data_ptr() if residual is not None else None, x2d.data_ptr(), rows, C,
-                                     1 if relu else 0)
-    _lib.check(st, "egtr_bias_act_nhwc_bf16")
+    entry = "egtr_bias_act_nhwc_bf16" if dt == torch.bfloat16 else "egtr_bias_act_nhwc_f32"
+    st = getattr(lib, entry)(_stream(), x2d.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                             x2d.data_ptr(), rows, C, 1 if relu else 0)
+    _lib.check(st, entry)
     return x2d
 
 
@@ -1712,15 +1715,18 @@ def input_proj_groupnorm_flatten(conv_outputs, input_projs):
 
 
 def input_proj_groupnorm_tokens(token_outputs, input_projs):
-    """The same for TOKEN-MAJOR bf16 projections [B, H_l*W_l, 256] (the channels-last backbone: the level's 1x1 convolution run as
-    a plain GEMM, bias-free): conv bias + GroupNorm(32) + concatenation in two launches, no transpose
-    (egtr_input_proj_groupnorm_tokens_bf16).  Returns [B, S, 256] bf16.  Inference only."""
+    """The same for TOKEN-MAJOR projections [B, H_l*W_l, 256] (the channels-last backbone: the level's 1x1 convolution run as a
+    plain GEMM, bias-free; bf16 or fp32): conv bias + GroupNorm(32) + concatenation in two launches, no transpose
+    (egtr_input_proj_groupnorm_tokens_bf16 / _f32).  Returns [B, S, 256].  Inference only."""
     import ctypes
     lib = _lib.lib()
     L = len(token_outputs)
     B = token_outputs[0].shape[0]
     gn0 = input_projs[0][1]
-    xs = [_chk(x.contiguous(), "token-major projection", torch.bfloat16) for x in token_outputs]
+    dt = token_outputs[0].dtype
+    if dt not in (torch.bfloat16, torch.float32):
+        raise TypeError("input_proj_groupnorm_tokens: bf16 or fp32 projections")
+    xs = [_chk(x.contiguous(), "token-major projection", dt) for x in token_outputs]
     for proj, x in zip(input_projs[:L], xs):
         conv, gn = proj[0], proj[1]
         if gn.num_groups != 32 or gn.eps != gn0.eps or conv.bias is None or x.shape[-1] != 256 or x.shape[0] != B:
@@ -1730,14 +1736,15 @@ def input_proj_groupnorm_tokens(token_outputs, input_projs):
     keep = [tuple(flat[3 * l:3 * l + 3]) for l in range(L)]
     toks = [int(x.shape[1]) for x in xs]
     S = sum(toks)
-    out = torch.empty(B, S, 256, dtype=torch.bfloat16, device=xs[0].device)
+    out = torch.empty(B, S, 256, dtype=dt, device=xs[0].device)
     stats = torch.empty(L * B * 32 * 2, dtype=torch.float32, device=xs[0].device)
     PA, IA = ctypes.c_void_p * L, ctypes.c_int * L
-    st = lib.egtr_input_proj_groupnorm_tokens_bf16(
+    entry = "egtr_input_proj_groupnorm_tokens_bf16" if dt == torch.bfloat16 else "egtr_input_proj_groupnorm_tokens_f32"
+    st = getattr(lib, entry)(
         _stream(), L, PA(*[x.data_ptr() for x in xs]), PA(*[k[0].data_ptr() for k in keep]),
         PA(*[k[1].data_ptr() for k in keep]), PA(*[k[2].data_ptr() for k in keep]), IA(*toks), B, 256, 32, float(gn0.eps),
         stats.data_ptr(), out.data_ptr())
-    _lib.check(st, "egtr_input_proj_groupnorm_tokens_bf16")
+    _lib.check(st, entry)
     return out
 
 

@@ -368,6 +368,8 @@ int egtr_add_layernorm_bf16(egtr_stream_t stream, const uint16_t* x, const uint1
  * plain GEMMs). */
 int egtr_bias_act_nhwc_bf16(egtr_stream_t stream, const uint16_t* x, const float* bias, const uint16_t* residual, uint16_t* y,
                             long long rows, int C, int relu);
+int egtr_bias_act_nhwc_f32(egtr_stream_t stream, const float* x, const float* bias, const float* residual, float* y,
+                           long long rows, int C, int relu);   /* fp32 twin (C % 4 == 0) */
 /* ... and y_plus_pos = bf16(y + pos[row % pos_rows]) from the SAME launch: the next encoder layer's `hidden + pos`
  * (deformable_detr.py:1041), rounded like the reference's bf16 add of the already rounded y.  rows % pos_rows == 0. */
 int egtr_add_layernorm_pos_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* residual, const uint16_t* gamma,
@@ -504,6 +506,10 @@ int egtr_input_proj_groupnorm_tokens_bf16(egtr_stream_t stream, int num_levels, 
                                           const float* const* conv_bias, const float* const* gamma,
                                           const float* const* beta, const int* level_tokens, int batch, int channels,
                                           int num_groups, float eps, float* stats, uint16_t* out);
+int egtr_input_proj_groupnorm_tokens_f32(egtr_stream_t stream, int num_levels, const float* const* x,
+                                         const float* const* conv_bias, const float* const* gamma, const float* const* beta,
+                                         const int* level_tokens, int batch, int channels, int num_groups, float eps,
+                                         float* stats, float* out);   /* fp32 twin */
 
 /* ---- EGTR relation head ---------------------------------------------------------------------------------- */
 /* Inputs are the separable pieces of egtr.py:366-401 (see DESIGN.md "relation head algebra"):
