@@ -60,6 +60,7 @@ SIGNATURES = {
     "egtr_input_proj_groupnorm_flatten_bf16": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_input_proj_groupnorm_tokens_bf16": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
     "egtr_input_proj_groupnorm_tokens_f32": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _P, _P],
+    "egtr_input_proj_groupnorm_tokens_workspace_floats": [_I, _P, _I],
     "egtr_bbox_overlaps_f64": [_P, _P, _P, _I, _I, _I, _P],
     "egtr_hungarian_match_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float,
                                  ctypes.c_float, _I, ctypes.c_float, ctypes.c_float, _P, _P, _P, _P, _P, _P, _P],
@@ -116,6 +117,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"egtr_status_string": ctypes.c_char_p, "egtr_last_hip_error": ctypes.c_char_p,
              "egtr_ffn_packed_weights_bytes": ctypes.c_longlong,
+             "egtr_input_proj_groupnorm_tokens_workspace_floats": ctypes.c_longlong,
              "egtr_msda_backward_bf16_workspace_floats": ctypes.c_longlong,
              "egtr_hungarian_match_scratch_doubles": ctypes.c_longlong,
              "egtr_relation_loss_workspace_bytes": ctypes.c_longlong,

@@ -862,7 +862,8 @@ struct GnTokLevels {
   const float* gamma[4];
   const float* beta[4];
   int hw[4], start[4];
-  long long chunk0[5];   // first 16-byte chunk of a level in the flat apply grid (per image)
+  long long chunk0[5];   // first (token, group) chunk of a level in the flat apply grid (per image)
+  int cchunk0[5];        // first 256-token statistics chunk of a level
 };
 
 namespace {
@@ -874,30 +875,39 @@ __device__ __forceinline__ void load_group8(const float* x, size_t idx, float (&
   const float4 a = reinterpret_cast<const float4*>(x)[2 * idx], b = reinterpret_cast<const float4*>(x)[2 * idx + 1];
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
-// stats[(l * B + b) * 32 + g] = (mean, rstd) of (x + conv_bias) over the 8 channels x H_l W_l tokens of group g: one workgroup
-// per (image, level), thread = (group t & 31, token phase t >> 5)
+// Statistics in two small launches (one workgroup per (image, level) took 103 us at bs 1: 293 dependent loads deep):
+// (1) a workgroup sums 256 tokens of one level: thread = (group t & 31, token phase t >> 5), partial (sum, sum of squares) per
+//     group in double; (2) one wave per (image, level) adds the level's partials in order and writes (mean, rstd).
+constexpr int kGnTokChunk = 256;
 template <typename T>
-__global__ __launch_bounds__(1024) void gn_stats_tokens(GnTokLevels P, float eps, float2* __restrict__ stats) {
-  __shared__ double s_red[2][32][33];
-  const int b = blockIdx.x, l = blockIdx.y, B = gridDim.x;
-  const int g = threadIdx.x & 31, ph = threadIdx.x >> 5, hw = P.hw[l];
+__global__ __launch_bounds__(256) void gn_partial_tokens(GnTokLevels P, int L, int chunks_total, double2* __restrict__ partial) {
+  __shared__ double s_red[2][32][9];
+  const int b = blockIdx.y;
+  int l = 0;
+  while (l + 1 < L && (int)blockIdx.x >= P.cchunk0[l + 1]) ++l;
+  const int t_begin = ((int)blockIdx.x - P.cchunk0[l]) * kGnTokChunk, hw = P.hw[l];
+  const int g = threadIdx.x & 31, ph = threadIdx.x >> 5;
   const T* x = static_cast<const T*>(P.x[l]) + (size_t)b * hw * 256;
   const float4 ba = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g), bb = *reinterpret_cast<const float4*>(P.conv_bias[l] + 8 * g + 4);
   const float cb[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
   float s1 = 0.f, s2 = 0.f;
-  for (int t0 = ph; t0 < hw; t0 += 32 * 4) {
-    float f[4][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (t0 + 32 * u < hw) load_group8(x, (size_t)(t0 + 32 * u) * 32 + g, f[u]);
+  for (int u0 = 0; u0 < kGnTokChunk / 8; u0 += 8) {
+    float f[8][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (t0 + 32 * u < hw) {
+    for (int u = 0; u < 8; ++u) {
+      const int t = t_begin + ph + 8 * (u0 + u);
+      if (t < hw) load_group8(x, (size_t)t * 32 + g, f[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = t_begin + ph + 8 * (u0 + u);
+      if (t < hw) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-          const float t = f[u][k] + cb[k];
-          s1 += t;
-          s2 += t * t;
+          const float v = f[u][k] + cb[k];
+          s1 += v;
+          s2 += v * v;
         }
       }
     }
@@ -907,14 +917,26 @@ __global__ __launch_bounds__(1024) void gn_stats_tokens(GnTokLevels P, float eps
   __syncthreads();
   if (threadIdx.x < 32) {
     double t1 = 0.0, t2 = 0.0;
-    for (int w = 0; w < 32; ++w) {
+    for (int w = 0; w < 8; ++w) {
       t1 += s_red[0][threadIdx.x][w];
       t2 += s_red[1][threadIdx.x][w];
     }
-    const double n = 8.0 * hw, mean = t1 / n;
-    const double var = fmax(t2 / n - mean * mean, 0.0);  // biased, as nn.GroupNorm
-    stats[((size_t)l * B + b) * 32 + threadIdx.x] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    partial[((size_t)b * chunks_total + blockIdx.x) * 32 + threadIdx.x] = make_double2(t1, t2);
   }
+}
+
+__global__ __launch_bounds__(32) void gn_finalize_tokens(GnTokLevels P, int chunks_total, float eps,
+                                                         const double2* __restrict__ partial, float2* __restrict__ stats) {
+  const int b = blockIdx.x, l = blockIdx.y, B = gridDim.x, g = threadIdx.x;
+  double t1 = 0.0, t2 = 0.0;
+  for (int c = P.cchunk0[l]; c < P.cchunk0[l + 1]; ++c) {
+    const double2 p = partial[((size_t)b * chunks_total + c) * 32 + g];
+    t1 += p.x;
+    t2 += p.y;
+  }
+  const double n = 8.0 * P.hw[l], mean = t1 / n;
+  const double var = fmax(t2 / n - mean * mean, 0.0);  // biased, as nn.GroupNorm
+  stats[((size_t)l * B + b) * 32 + g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
 }
 
 template <typename T>
@@ -958,6 +980,18 @@ __global__ __launch_bounds__(256) void gn_apply_tokens(GnTokLevels P, int L, int
 }
 }  // namespace
 
+static int gn_tokens_chunks(int num_levels, const int* level_tokens) {
+  int c = 0;
+  for (int l = 0; l < num_levels; ++l) c += (level_tokens[l] + kGnTokChunk - 1) / kGnTokChunk;
+  return c;
+}
+
+extern "C" long long egtr_input_proj_groupnorm_tokens_workspace_floats(int num_levels, const int* level_tokens, int batch) {
+  if (!level_tokens || num_levels < 1 || num_levels > 4 || batch <= 0) return 0;
+  // (mean, rstd) per (level, image, group) + the double2 partials per (image, chunk, group), 16-byte aligned behind them
+  return (long long)num_levels * batch * 64 + (long long)batch * gn_tokens_chunks(num_levels, level_tokens) * 128;
+}
+
 static int groupnorm_tokens_launch(egtr_stream_t stream, int num_levels, const void* const* x, const float* const* conv_bias,
                                    const float* const* gamma, const float* const* beta, const int* level_tokens, int batch,
                                    int channels, int num_groups, float eps, float* stats, void* out, bool bf16) {
@@ -965,7 +999,7 @@ static int groupnorm_tokens_launch(egtr_stream_t stream, int num_levels, const v
   if (num_levels < 1 || num_levels > 4 || batch <= 0) return EGTR_E_ARG;
   if (channels != 256 || num_groups != 32) return EGTR_E_UNSUPPORTED;
   GnTokLevels P;
-  int S = 0;
+  int S = 0, cc = 0;
   for (int l = 0; l < 4; ++l) {
     const int s = l < num_levels ? l : 0;
     if (!x[s] || !conv_bias[s] || !gamma[s] || !beta[s] || level_tokens[s] <= 0) return EGTR_E_ARG;
@@ -977,24 +1011,33 @@ static int groupnorm_tokens_launch(egtr_stream_t stream, int num_levels, const v
     P.hw[l] = level_tokens[s];
     P.start[l] = S;
     P.chunk0[l] = (long long)S * 32;
-    if (l < num_levels) S += P.hw[l];
+    P.cchunk0[l] = cc;
+    if (l < num_levels) {
+      S += P.hw[l];
+      cc += (P.hw[l] + kGnTokChunk - 1) / kGnTokChunk;
+    }
   }
   P.chunk0[4] = (long long)S * 32;
-  for (int l = num_levels; l < 4; ++l) P.chunk0[l] = (long long)S * 32;
-  if (reinterpret_cast<uintptr_t>(out) & 15) return EGTR_E_UNSUPPORTED;
+  P.cchunk0[4] = cc;
+  for (int l = num_levels; l < 4; ++l) {
+    P.chunk0[l] = (long long)S * 32;
+    P.cchunk0[l] = cc;
+  }
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(stats)) & 15) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  float2* st2 = reinterpret_cast<float2*>(stats);
+  double2* partial = reinterpret_cast<double2*>(stats + (size_t)num_levels * batch * 64);
   const long long chunks = (long long)S * 32;
   const dim3 agrid((unsigned)((chunks + 255) / 256), batch);
   if (bf16) {
-    hipLaunchKernelGGL(gn_stats_tokens<unsigned short>, dim3(batch, num_levels), dim3(1024), 0, st, P, eps,
-                       reinterpret_cast<float2*>(stats));
-    hipLaunchKernelGGL(gn_apply_tokens<unsigned short>, agrid, dim3(256), 0, st, P, num_levels, S,
-                       reinterpret_cast<const float2*>(stats), static_cast<unsigned short*>(out));
+    hipLaunchKernelGGL(gn_partial_tokens<unsigned short>, dim3(cc, batch), dim3(256), 0, st, P, num_levels, cc, partial);
+    hipLaunchKernelGGL(gn_finalize_tokens, dim3(batch, num_levels), dim3(32), 0, st, P, cc, eps, partial, st2);
+    hipLaunchKernelGGL(gn_apply_tokens<unsigned short>, agrid, dim3(256), 0, st, P, num_levels, S, st2,
+                       static_cast<unsigned short*>(out));
   } else {
-    hipLaunchKernelGGL(gn_stats_tokens<float>, dim3(batch, num_levels), dim3(1024), 0, st, P, eps,
-                       reinterpret_cast<float2*>(stats));
-    hipLaunchKernelGGL(gn_apply_tokens<float>, agrid, dim3(256), 0, st, P, num_levels, S,
-                       reinterpret_cast<const float2*>(stats), static_cast<float*>(out));
+    hipLaunchKernelGGL(gn_partial_tokens<float>, dim3(cc, batch), dim3(256), 0, st, P, num_levels, cc, partial);
+    hipLaunchKernelGGL(gn_finalize_tokens, dim3(batch, num_levels), dim3(32), 0, st, P, cc, eps, partial, st2);
+    hipLaunchKernelGGL(gn_apply_tokens<float>, agrid, dim3(256), 0, st, P, num_levels, S, st2, static_cast<float*>(out));
   }
   return egtr_check_launch();
 }

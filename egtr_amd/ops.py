@@ -1737,8 +1737,9 @@ def input_proj_groupnorm_tokens(token_outputs, input_projs):
     toks = [int(x.shape[1]) for x in xs]
     S = sum(toks)
     out = torch.empty(B, S, 256, dtype=dt, device=xs[0].device)
-    stats = torch.empty(L * B * 32 * 2, dtype=torch.float32, device=xs[0].device)
     PA, IA = ctypes.c_void_p * L, ctypes.c_int * L
+    stats = torch.empty(int(lib.egtr_input_proj_groupnorm_tokens_workspace_floats(L, IA(*toks), B)), dtype=torch.float32,
+                        device=xs[0].device)
     entry = "egtr_input_proj_groupnorm_tokens_bf16" if dt == torch.bfloat16 else "egtr_input_proj_groupnorm_tokens_f32"
     st = getattr(lib, entry)(
         _stream(), L, PA(*[x.data_ptr() for x in xs]), PA(*[k[0].data_ptr() for k in keep]),

@@ -501,7 +501,10 @@ int egtr_input_proj_groupnorm_flatten_bf16(egtr_stream_t stream, int num_levels,
 
 /* The same epilogue for TOKEN-MAJOR bf16 projections (the channels-last backbone): x[l] is [B, level_tokens[l], 256], the
  * bias-free output of the level's 1x1 convolution run as a plain GEMM on the channels-last feature map; 32 groups of 8 channels
- * (a 16-byte chunk = one token's group).  stats: num_levels * B * 32 * 2 floats; out: [B, S, 256] bf16. */
+ * (8 consecutive channels of a token = one group).  Three small launches (partial sums per 256 tokens, their ordered reduction,
+ * the normalisation).  stats: device scratch of egtr_input_proj_groupnorm_tokens_workspace_floats(...) floats, 16-byte aligned
+ * (level_tokens is a HOST array); out: [B, S, 256]. */
+long long egtr_input_proj_groupnorm_tokens_workspace_floats(int num_levels, const int* level_tokens, int batch);
 int egtr_input_proj_groupnorm_tokens_bf16(egtr_stream_t stream, int num_levels, const uint16_t* const* x,
                                           const float* const* conv_bias, const float* const* gamma,
                                           const float* const* beta, const int* level_tokens, int batch, int channels,

@@ -1039,6 +1039,14 @@ def test_input_proj_groupnorm_tokens_bf16_matches_torch_and_the_nchw_kernel():
     err = (got.cpu().double() - want).abs()
     assert float((err / want.abs().clamp_min(1.0)).max()) < 2.0 ** -8
     assert float(((got.float() - nchw.float()).abs() / nchw.float().abs().clamp_min(1.0)).max()) <= 2.0 ** -7
+    # fp32 twin: against the fp64 GroupNorm and the NCHW fp32 entry
+    projs32 = projs.float()
+    xs32 = [x.float() for x in xs]
+    with torch.no_grad():
+        got32 = ops.input_proj_groupnorm_tokens([x.flatten(2).transpose(1, 2).contiguous().to(DEV) for x in xs32], projs32.to(DEV))
+        nchw32 = ops.input_proj_groupnorm_flatten([x.to(DEV) for x in xs32], projs32.to(DEV))
+    assert got32.dtype == torch.float32
+    assert float((got32.cpu().double() - want).abs().max()) < 2e-5 and float((got32 - nchw32).abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("rows,C", [(1, 8), (33, 64), (16 * 1000, 256), (977, 2048)])
@@ -1055,6 +1063,10 @@ def test_bias_act_rows_bf16_channels_last(rows, C):
         want = (want.relu() if relu else want).bfloat16()
         got = ops.bias_act_rows_(x.clone(), b, res, relu)
         assert torch.equal(got, want), (res is not None, relu)
+        if C % 4 == 0:   # fp32 twin (the same sums in the same order)
+            x32, r32 = x.float(), (res.float() if res is not None else None)
+            w32 = x32 + b + (r32 if r32 is not None else 0.0)
+            assert torch.equal(ops.bias_act_rows_(x32.clone(), b, r32, relu), w32.relu() if relu else w32)
 
 
 @pytest.mark.parametrize("N,C,H,Wd", [(2, 64, 25, 42), (1, 256, 100, 167), (3, 8, 3, 3), (1, 5, 1, 7), (2, 16, 50, 84)])
