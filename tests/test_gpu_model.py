@@ -541,6 +541,36 @@ def test_triplet_candidates_on_device_match_reference_postprocessing():
         assert np.abs(got[b]["pred_boxes"].cpu().numpy() - want["pred_boxes"]).max() < 1e-3
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_backbone_channels_last_path_matches_nchw_path(dtype, monkeypatch):
+    """The channels-last inference path of the backbone (MIOpen NHWC convolutions, 1x1 convolutions as GEMMs with bias / ReLU
+    epilogues, egtr_bias_act_nhwc_*) against the NCHW folded path (EGTR_BACKBONE_NHWC_*=0): the same three feature maps, returned
+    as channels-last tensors; fp32 to convolution-algorithm rounding, bf16 to a few bf16 ulps of the map's scale.  Odd sizes."""
+    import egtr_amd.backbone as bb
+    torch.manual_seed(2)
+    net = bb.ResNet50Features().to(DEV).eval()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.1)
+    net = net.to(dtype)
+    x = torch.randn(2, 3, 101, 135, device=DEV).to(dtype)
+    with torch.no_grad():
+        cl = net(x)
+        monkeypatch.setattr(bb, "NHWC_BF16", False)
+        monkeypatch.setattr(bb, "NHWC_F32", False)
+        net._folded = None
+        ref = net(x)
+    assert len(cl) == len(ref) == 3
+    for a, b in zip(cl, ref):
+        assert a.shape == b.shape and a.dtype == dtype
+        assert a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous()
+        scale = max(1.0, float(b.float().abs().max()))
+        assert float((a.float() - b.float()).abs().max()) < (2e-4 if dtype == torch.float32 else 0.06) * scale
+
+
 def test_backbone_folded_path_bf16_matches_unfolded_bf16():
     """bf16 model: frozen-BN folding (fp32 arithmetic, bf16 weights) + the bf16 bias/residual/ReLU epilogue vs the
     plain bf16 module path and vs the fp32 backbone (bf16 tolerance)."""
