@@ -70,6 +70,7 @@ class MsdaProbe:
     def __init__(self):
         self.args = None
         self.fused = False
+        self.keep_bits = None      # the bit-packed padding mask the model handed to the fused entry (explicit argument)
         from egtr_amd import ops
         self._ops = ops
         self._orig = ops.MultiScaleDeformableAttentionFunction.forward
@@ -87,6 +88,7 @@ class MsdaProbe:
         def fwd_fused(value, shapes, lsi, off, logits, ref, want_weights=False, keep_mask=None, **kw):
             if off.shape[1] == value.shape[1]:
                 probe.args, probe.fused = (value, shapes, lsi, off, logits, ref, False, keep_mask), True
+                probe.keep_bits = kw.get("keep_bits")
             return orig_fused(value, shapes, lsi, off, logits, ref, want_weights, keep_mask, **kw)
 
         self._ops.MultiScaleDeformableAttentionFunction.forward = staticmethod(fwd)
@@ -210,16 +212,17 @@ def time_split_gemm(dev, iters=100):
     return e0.elapsed_time(e1) * 1e3 / iters, 2.0 * M * K * (256 + 384)
 
 
-def time_msda_kernel(args, fused, iters=200):
+def time_msda_kernel(args, fused, iters=200, keep_bits=None):
     """Average duration of the encoder MSDA kernel: `iters` back-to-back launches through the C ABI on torch's
     current stream, bracketed by HIP events recorded on that same stream."""
     from egtr_amd.load_custom import load_hip_kernels
     k = load_hip_kernels()
     value, loc = args[0], args[3]
     if fused and value.dtype == torch.bfloat16:
-        fn = lambda: k.ms_deform_attn_forward_fused_bf16(*args[:6], args[7])  # noqa: E731
+        fn = lambda: k.ms_deform_attn_forward_fused_bf16(*args[:6], args[7], keep_bits=keep_bits)  # noqa: E731
     else:
-        fn = (lambda: k.ms_deform_attn_forward_fused(*args)) if fused else (lambda: k.ms_deform_attn_forward(*args))
+        fn = ((lambda: k.ms_deform_attn_forward_fused(*args, keep_bits=keep_bits)) if fused
+              else (lambda: k.ms_deform_attn_forward(*args)))
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
@@ -556,7 +559,7 @@ def stress_bench(dev, steps, warmup, batch=16):
     with MsdaProbe() as probe, torch.no_grad():
         model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
               output_hidden_states=True)
-        msda_args, fused = probe.args, probe.fused
+        msda_args, fused, msda_bits = probe.args, probe.fused, probe.keep_bits
     with torch.no_grad():
         for _ in range(warmup):
             fwd(pv, pm)
@@ -572,7 +575,7 @@ def stress_bench(dev, steps, warmup, batch=16):
            "config": {"workload": f"Stress: ResNet-50, 800x1333, N=300, 6 enc/8 dec, bf16, bs={batch}/GPU "
                                   "(BASELINE configs[4] shape on one GPU)", "hip_graph": bool(fwd.graphed)}}
     if msda_args is not None:
-        us, alg = time_msda_kernel(msda_args, fused, iters=50)
+        us, alg = time_msda_kernel(msda_args, fused, iters=50, keep_bits=msda_bits)
         ach = alg / (us * 1e-6) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "msda_fwd_q32_bf16<fused prologue>" if fused else "msda_fwd_q32_bf16",
                            "launch": f"encoder layer, B={batch}, Lq = S = 22223, bf16 values",
@@ -617,7 +620,7 @@ def stress_bench(dev, steps, warmup, batch=16):
                  "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
                  "algorithmic_flops_per_launch": flops, "avg_launch_us": round(us, 1)}
             b = busy.get("kernels", {}).get(kname) if isinstance(busy, dict) else None
-            if isinstance(b, dict):
+            if isinstance(b, dict) and b.get("source_sha256") is not None and b.get("source_sha256") == _source_hash(kname):
                 e["mfma_busy"] = b.get("mfma_busy")
                 e["mfma_busy_source"] = busy.get("_src")
             kernels.append(e)
@@ -628,12 +631,25 @@ def stress_bench(dev, steps, warmup, batch=16):
     return out
 
 
+def _source_hash(kernel):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from kernel_source_hash import source_hash
+        return source_hash(kernel)
+    except Exception:
+        return None
+
+
 def newest_pmc(pattern, kernel):
     """The most recent profiles/<pattern> (rocprofv3 --pmc passes over this command, tools/pmc_passes.sh + tools/*_pmc.py)
-    whose `kernel` field names the kernel that was just timed; (dict, "file name (mtime)") or ({}, None).  Counters are
-    collected in separate profiler runs, never inside the timed run, so the line says which file they come from."""
+    whose `kernel` field names the kernel that was just timed AND whose `source_sha256` equals the hash of that kernel's
+    source files as they are in the tree now (tools/kernel_source_hash.py): a profile taken from an older version of the
+    kernel is refused, whatever its label or file time says.  (dict, "file name (mtime, sources verified)") or ({}, None).
+    Counters are collected in separate profiler runs, never inside the timed run, so the line says which file they come
+    from."""
     import glob
     best = None
+    want = _source_hash(kernel)
     for path in glob.glob(os.path.join(ROOT, "profiles", pattern)):
         try:
             d = json.load(open(path))
@@ -641,12 +657,162 @@ def newest_pmc(pattern, kernel):
             continue
         if d.get("kernel") != kernel:
             continue
+        if want is None or d.get("source_sha256") != want:
+            continue    # stale (or pre-round-6, unhashed) profile: not quoted
         m = os.path.getmtime(path)
         if best is None or m > best[0]:
             best = (m, path, d)
     if best is None:
         return {}, None
-    return best[2], f"profiles/{os.path.basename(best[1])} (mtime {time.strftime('%Y-%m-%d %H:%M', time.gmtime(best[0]))} UTC)"
+    return best[2], (f"profiles/{os.path.basename(best[1])} (mtime {time.strftime('%Y-%m-%d %H:%M', time.gmtime(best[0]))} UTC, "
+                     f"kernel sources sha256 {want[:12]} verified)")
+
+
+def mixed_shape_set(n_shapes=12, seed=0, min_size=600, max_size=1000):
+    """Image shapes (H, W) as the reference's evaluation resize produces them (evaluate_egtr.py:165-175 ``--min_size 600
+    --max_size 1000``: short side -> 600 unless the long side would exceed 1000, then long side = 1000): aspect ratios
+    drawn with a fixed seed from U(1, 2), a quarter of them portrait; the bench's own 600x1000 is always in the set."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    shapes = [(H_IMG, W_IMG)]
+    while len(shapes) < n_shapes:
+        r = float(rng.uniform(1.0, 2.0))
+        short, long_ = min_size, int(round(min_size * r))
+        if long_ > max_size:
+            short, long_ = int(round(max_size / r)), max_size
+        hw = (long_, short) if rng.uniform() < 0.25 else (short, long_)
+        if hw not in shapes:
+            shapes.append(hw)
+    return shapes
+
+
+def mixed_shapes_leg(model, dev, fixed_value, n_shapes=12, stream=96, seed=0):
+    """The reference's FPS loop on a stream of differently sized images (evaluate_egtr.py:26-36 over a dataloader), bs = 1:
+    every distinct shape is captured once into its own HIP graph (egtr_amd.runtime.GraphedForward, LRU of 16) in an untimed
+    first pass, then `stream` images (shapes drawn with a fixed seed, inputs resident in HBM) are timed as one region.
+    MIOpen find mode and TunableOp tuning are OFF for the new shapes (an evaluation run meets a new shape without a tuning
+    pause; the 600x1000 shape keeps what the headline run tuned), so smaller images are not faster for free."""
+    import numpy as np
+    from egtr_amd.runtime import GraphedForward
+    shapes = mixed_shape_set(n_shapes, seed)
+    rng = np.random.RandomState(seed + 1)
+    order = [int(i) for i in rng.randint(0, len(shapes), stream)]
+    g = torch.Generator(device="cpu").manual_seed(seed + 2)
+    inputs = [(torch.randn(1, 3, h, w, generator=g).to(dev), torch.ones(1, h, w, dtype=torch.long, device=dev))
+              for (h, w) in shapes]
+    bench_find = torch.backends.cudnn.benchmark
+    tun = None
+    try:
+        import torch.cuda.tunable as tun
+        tuning_was = tun.tuning_is_enabled()
+        tun.tuning_enable(False)
+    except Exception:
+        tun = None
+    torch.backends.cudnn.benchmark = False
+    try:
+        fwd = GraphedForward(model, enabled=True, strict=True, max_graphs=16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for pv, pm in inputs:          # first pass: two eager warm-up runs + capture per shape
+                fwd(pv, pm)
+        torch.cuda.synchronize()
+        first_pass_s = time.perf_counter() - t0
+        captures = fwd.captures
+        with torch.no_grad():
+            for i in order[:8]:
+                fwd(*inputs[i])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in order:
+                fwd(*inputs[i])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        torch.backends.cudnn.benchmark = bench_find
+        if tun is not None:
+            tun.tuning_enable(tuning_was)
+    pixels = sum(shapes[i][0] * shapes[i][1] for i in order) / len(order)
+    value = len(order) / dt
+    return {"metric": "images/sec end-to-end SGG, bs=1, stream of differently sized images (HIP graph per shape)",
+            "value": round(value, 2), "unit": "images/sec", "ms_per_image": round(dt / len(order) * 1e3, 4),
+            "images": len(order), "distinct_shapes": len(shapes), "shapes_hw": [list(hw) for hw in shapes],
+            "graphs_captured": captures, "recaptures_in_timed_region": fwd.captures - captures,
+            "first_pass_s": round(first_pass_s, 3), "mean_pixels_vs_600x1000": round(pixels / (H_IMG * W_IMG), 4),
+            "vs_fixed_shape": round(value / fixed_value, 4) if fixed_value else None,
+            "tuning": "MIOpen find / TunableOp tuning off for the new shapes"}
+
+
+def eager_leg(model, pv, pm, iters=30):
+    """The same bs = 1 forward WITHOUT graph replay (what a caller gets from a plain ``model(...)`` call, and what every new
+    shape costs before its graph exists): eager launches, synchronised at both ends."""
+    with torch.no_grad():
+        for _ in range(5):
+            model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
+                  output_hidden_states=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
+                  output_hidden_states=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"value": round(pv.shape[0] * iters / dt, 2), "unit": "images/sec", "ms_per_step": round(dt / iters * 1e3, 4),
+            "iters": iters, "launch": "eager (no HIP graph), 600x1000, bs=%d" % pv.shape[0]}
+
+
+GRAD_BYTES_FP32 = 165 * 1000 * 1000   # SURVEY 8(d): ~165 MB of fp32 gradients per optimizer step (42.5 M parameters)
+
+
+def time_allreduce(dist, dev, nbytes=GRAD_BYTES_FP32, iters=10):
+    """A bare all-reduce of `nbytes` of fp32 over the process group (RCCL over xGMI on GPUs; gloo in the CPU launch test),
+    average ms per call -- device events on the GPU, wall clock on the CPU.  The per-link floor for 165 MB on an 8-GPU ring
+    is ~1.9 ms; DDP overlaps its buckets with backward, so the step pays less than this."""
+    t = torch.ones(nbytes // 4, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        dist.all_reduce(t)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        e0.record()
+        for _ in range(iters):
+            dist.all_reduce(t)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(t)
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def ddp_train_leg(args, world, rank, dev, dist):
+    """world > 1: a short DDP train loop (BASELINE configs[2]: bs 4 per GPU, accumulate 1 so that EVERY step carries the
+    bucketed gradient all-reduce over RCCL) on all ranks, plus the bare 165 MB all-reduce beside it.  Rank 0 gets the dict
+    that goes into the JSON line as `train_step_ddp` (schema: DESIGN.md 5); the other ranks get None."""
+    import copy
+    targs = copy.copy(args)
+    targs.mode, targs.batch, targs.steps, targs.warmup = "train", 4, max(2, args.extra_steps), 5
+    targs.no_cpu_baseline, targs.no_kernel_probes = True, True
+    find_was = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False      # MIOpen find mode: no gain for the train step (DESIGN 4.7)
+    try:
+        leg = train_bench(targs, world, rank, dev, dist, emit=False)
+    finally:
+        torch.backends.cudnn.benchmark = find_was
+    ar_ms = time_allreduce(dist, dev)
+    if rank != 0 or leg is None:
+        return None
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "final_loss",
+            "rccl_ranks", "rank_ms_per_step")
+    out = {k: leg[k] for k in keep if k in leg}
+    out["config"] = leg.get("config")
+    out["allreduce_ms"] = round(ar_ms, 4)
+    out["allreduce_bytes"] = GRAD_BYTES_FP32
+    out["allreduce_busbw_GBs"] = round(2 * (world - 1) / world * GRAD_BYTES_FP32 / (ar_ms * 1e-3) / 1e9, 2)
+    return out
 
 
 def rank_times(dt, steps, dist, dev, world):
@@ -678,7 +844,8 @@ def newest_mfma_busy():
             best = (m, path, d)
     if best is None:
         return {}, None
-    return ({k: v.get("mfma_busy") for k, v in best[2].get("kernels", {}).items()},
+    return ({k: v.get("mfma_busy") for k, v in best[2].get("kernels", {}).items()
+             if v.get("source_sha256") is not None and v.get("source_sha256") == _source_hash(k)},   # stale entries dropped
             f"profiles/{os.path.basename(best[1])} (mtime {time.strftime('%Y-%m-%d %H:%M', time.gmtime(best[0]))} UTC)")
 
 
@@ -730,9 +897,14 @@ def launch_check(args):
         dist.init_process_group("gloo")
     ranks = rccl_world_check(dist, dev)
     dist.barrier()
+    # the bare all-reduce timer of the world > 1 DDP leg (`train_step_ddp.allreduce_ms`), on a small buffer under gloo
+    nbytes = GRAD_BYTES_FP32 if backend == "nccl" else 4 * 1000 * 1000
+    ar_ms = time_allreduce(dist, dev, nbytes=nbytes, iters=3)
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": dist.get_world_size(), "rccl_ranks": ranks,
-                          "backend": backend, "requested_gpus": args.gpus}))
+                          "backend": backend, "requested_gpus": args.gpus,
+                          "train_step_ddp": {"allreduce_ms": round(ar_ms, 4), "allreduce_bytes": nbytes,
+                                             "note": "launch check: collective only, no model"}}))
     dist.destroy_process_group()
 
 
@@ -838,7 +1010,7 @@ def main():
     if args.graph and not fwd.graphed:
         raise SystemExit("[bench] HIP-graph capture did not happen (pass --graph 0 to time eager launches)")
 
-    msda_us, alg_bytes = time_msda_kernel(msda_args, probe.fused)
+    msda_us, alg_bytes = time_msda_kernel(msda_args, probe.fused, keep_bits=probe.keep_bits)
     achieved = alg_bytes / (msda_us * 1e-6) / 1e9
     rel_us, rel_flops = time_rel_head_kernel(rel_args)
     rel_tflops = rel_flops / (rel_us * 1e-6) / 1e12
@@ -942,7 +1114,22 @@ def main():
         if dp:
             d_entry.update(traffic=dp.get("hbm_bytes_per_launch"), l2_hit=dp.get("l2_hit"), traffic_source=dp_src)
         result["roofline_kernels"].append(d_entry)
+    if rank == 0 and world == 1 and args.extras:
+        # the FPS loop as the reference runs it (evaluate_egtr.py:26-36): differently sized images, and the eager number
+        try:
+            result["eager"] = eager_leg(model, pv, pm)
+            result["mixed_shapes"] = mixed_shapes_leg(model, dev, value)
+        except Exception as e:  # the headline stays valid; the failure is visible
+            result["mixed_shapes"] = {"error": f"{type(e).__name__}: {e}"}
     result["config"]["fast_path"] = {"strict": bool(_ops.STRICT_FAST_PATH), "fallbacks": dict(_ops.FALLBACKS)}
+    if world > 1 and args.extras:
+        # BASELINE configs[2] ("RCCL grad all-reduce over xGMI"): every rank takes part; rank 0 reports
+        try:
+            ddp = ddp_train_leg(args, world, rank, dev, dist)
+        except Exception as e:
+            ddp = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            result["train_step_ddp"] = ddp
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ncores = usable_cores()
         torch.set_num_threads(ncores)

@@ -13,9 +13,13 @@ Layout:
 """
 import os as _os
 
-# The bf16 backbone runs channels-last (egtr_amd.backbone, NHWC_BF16): PyTorch-ROCm hands channels-last tensors to MIOpen's NHWC
-# convolutions only with this switch, read ONCE at the process's first convolution -- so it is set at import, before any.  fp32
-# tensors stay contiguous NCHW and are not affected.
+# The inference backbone runs channels-last in bf16 AND fp32 (egtr_amd.backbone, NHWC_BF16 / NHWC_F32): PyTorch-ROCm hands
+# channels-last tensors to MIOpen's NHWC convolutions only with this switch, read ONCE at the process's first convolution -- so
+# it is set at import, before any.
+# SIDE EFFECT, process-wide: every other model in this process that feeds channels-last tensors to a convolution gets MIOpen's
+# NHWC kernels too (contiguous NCHW tensors are not affected); export PYTORCH_MIOPEN_SUGGEST_NHWC=0 before the import to keep
+# PyTorch's default -- the backbone then announces the slower route once (ops.note_fallback "backbone_nhwc"), as it does when a
+# convolution already ran before this import and the switch therefore came too late.
 _os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
 
 __version__ = "0.1.0"

@@ -203,6 +203,12 @@ class Bottleneck(nn.Module):
         y = torch._addmm_activation(q["b1"], x2, q["w1"].t(), use_gelu=False)
         y = y.view(B, H, W_, -1).permute(0, 3, 1, 2)                   # channels-last view of the GEMM's output
         y = F.conv2d(y, q["w2"], None, stride=self.conv2.stride, padding=1)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            # PYTORCH_MIOPEN_SUGGEST_NHWC was not in effect when this process ran its FIRST convolution (it is read once; the
+            # package sets it at import, see egtr_amd/__init__.py): the convolution ran NCHW between two layout transposes
+            # and the reshape below copies.  Correct, slower -- and never silent.
+            ops.note_fallback("backbone_nhwc", "a channels-last convolution returned an NCHW tensor: "
+                              "PYTORCH_MIOPEN_SUGGEST_NHWC=1 was not set before the process's first convolution")
         Ho, Wo = y.shape[-2:]
         y2 = y.permute(0, 2, 3, 1).reshape(-1, y.shape[1])
         ops.bias_act_rows_(y2, q["b2"])

@@ -86,15 +86,18 @@ __device__ __forceinline__ void barrier_arrive(unsigned* ctr, int lane) {
     asm volatile("global_atomic_add %0, %1, off" ::"v"(ctr), "v"(one) : "memory");
   }
 }
-__device__ __forceinline__ void barrier_wait(const unsigned* ctr, unsigned target, unsigned* status, int lane) {
+// Returns true when the wave gave up (the caller's `bad` flag: everything this wave derives from the partials it was
+// waiting for is void, and reduce_ln NaN-poisons it so that the failure reaches the outputs -- a wave that passed its barriers
+// has complete partials in front of it, so "timed out" and "void" coincide wave by wave).
+__device__ __forceinline__ bool barrier_wait(const unsigned* ctr, unsigned target, unsigned* status, int lane) {
   int spins = 0;
   while (true) {
     unsigned cur;
     asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(cur) : "s"(ctr) : "memory");
-    if ((int)(cur - target) >= 0) break;
+    if ((int)(cur - target) >= 0) return false;
     if (++spins > kMaxSpins) {
       if (lane == 0) atomicOr(status, 1u);
-      break;
+      return true;
     }
     __builtin_amdgcn_s_sleep(1);
   }
@@ -162,6 +165,7 @@ __device__ unsigned long long g_dec_stamps[kH * 32];
 
 struct Args {
   EgtrDecoderLayer p;
+  int drop_arrival;   // test hook (egtr_test_decoder_drop_arrival): cluster 0's last wave skips its second arrival
 };
 
 // A fragments of an 8-row panel for the broadcast form: lane (b = lane >> 2, i = lane & 3) holds x[rg * 4 + i][64 q + 4 b + t]
@@ -246,8 +250,8 @@ __device__ __forceinline__ RowParams load_params(const float* __restrict__ bias,
 // deterministic).  Never hangs: after kMaxSpins rounds bit 0 of *status is raised and the sum is taken as it is.
 template <bool TAGGED>
 __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of this cluster */, int r, int j, const RowParams& q,
-                                          f32x4 res0, f32x4 res1, float eps, unsigned tag, unsigned* status, f32x4& o0,
-                                          f32x4& o1) {
+                                          f32x4 res0, f32x4 res1, float eps, unsigned tag, unsigned* status, bool& bad_wave,
+                                          f32x4& o0, f32x4& o1) {
   f32x4 p0[kH], p1[kH];
   int spins = 0;
   while (true) {
@@ -272,6 +276,7 @@ __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of th
     if (__builtin_amdgcn_readfirstlane(__any((int)bad)) == 0) break;   // the whole wave retries together
     if (++spins > kMaxSpins) {
       atomicOr(status, 1u);
+      bad_wave = true;
       break;
     }
     __builtin_amdgcn_s_sleep(1);
@@ -294,6 +299,11 @@ __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of th
   const float rstd = rsqrtf(var + eps);
   o0 = y0 * rstd * q.g0 + q.e0;
   o1 = y1 * rstd * q.g1 + q.e1;
+  if (bad_wave) {   // a hand-over this wave waited for never completed: poison instead of handing out a plausible-looking row
+    const float nan = __builtin_nanf("");
+    o0 = f32x4{nan, nan, nan, nan};
+    o1 = f32x4{nan, nan, nan, nan};
+  }
 }
 
 // Store the 8 x 64 tile held by a wave (lane = column) as rows of the cluster's partial buffer.
@@ -343,6 +353,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
   LevelGeom G;
   load_geom(P.spatial_shapes, P.level_start_index, 4, G);
   unsigned my_xcc = 0, bar_base = 0, nbar = 0;
+  bool bad_wave = false;   // this wave gave up on a hand-over: what it hands out from then on is NaN (reduce_ln)
   const unsigned tag = TAGGED ? ((unsigned)P.generation & 3u) : 0u;   // 0: barrier mode
   bool have_base = false;
   if (tid == 0) {
@@ -509,11 +520,11 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     f32x4 w_ol[16], w_c[8];   // phase 2's streams land while the cluster gathers: offsets / logits (K quarter), cross projection
     w_issue<16, true>(w_ol, reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64, lane_bytes);
     w_issue<8, true>(w_c, reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
-    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
+    bad_wave |= barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(5);
     // ================================================================= phase 2: LayerNorm 1, cross-attention of head h ==
     f32x4 x1a, x1b;
-    reduce_ln<TAGGED>(part1, r, j, rp, xin0, xin1, P.ln_eps, tag, P.status, x1a, x1b);
+    reduce_ln<TAGGED>(part1, r, j, rp, xin0, xin1, P.ln_eps, tag, P.status, bad_wave, x1a, x1b);
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x1a;
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x1b;
     *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x1a + pos0;
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       store_partial(part2 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi, tag);
     }
     STAMP(10);
-    barrier_arrive<!TAGGED>(ctr, lane);
+    if (!(A.drop_arrival != 0 && c == 0 && h == kH - 1 && wave == 3)) barrier_arrive<!TAGGED>(ctr, lane);
     // fc1's stream (tile 2h + (wave & 1), K half wave >> 1) into AGPRs -- reused for the next layer's q / k / v -- and fc2's
     // (tile = wave, this head's 32 k groups) into VGPRs: both land while the cluster gathers and LayerNorm 2 runs
     f32x4 w_f[32];
@@ -630,12 +641,12 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
 #ifdef EGTR_DEC_FC2_EARLY
     w_issue<32>(w_g, reinterpret_cast<const float4*>(P.w_fc2) + ((size_t)wave * 256 + 32 * h) * 64, lane_bytes);
 #endif
-    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
+    bad_wave |= barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(11);
 
     // ================================================================= phase 3: LayerNorm 2, 128 hidden units ==========
     f32x4 x2a, x2b;
-    reduce_ln<TAGGED>(part2, r, j, rp, x1a, x1b, P.ln_eps, tag, P.status, x2a, x2b);
+    reduce_ln<TAGGED>(part2, r, j, rp, x1a, x1b, P.ln_eps, tag, P.status, bad_wave, x2a, x2b);
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x2a;
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x2b;
     rp = load_params(P.b_fc2, P.ln3_gamma, P.ln3_beta, j);
@@ -689,12 +700,12 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       w_issue<32, true>(w_f, reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
                         lane_bytes);
 #endif
-    barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
+    bad_wave |= barrier_wait(ctr, bar_base + (++nbar) * kArrivals, P.status, lane);
     STAMP(16);
 
     // ================================================================= phase 4: LayerNorm 3, next layer's q / k / v ====
     f32x4 x3a, x3b;
-    reduce_ln<TAGGED>(part3, r, j, rp, x2a, x2b, P.ln_eps, tag, P.status, x3a, x3b);
+    reduce_ln<TAGGED>(part3, r, j, rp, x2a, x2b, P.ln_eps, tag, P.status, bad_wave, x3a, x3b);
     STAMP(17);
     if (h == 0 && r < nvalid) {
       *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 4 * j) = x3a;
@@ -740,6 +751,14 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
 
 }  // namespace
 
+// TEST-ONLY (include/egtr_hip_test.h): while on, one wave of cluster 0 skips an arrival, so the cluster's second barrier times
+// out in every launch -- the only way to exercise the time-out path (status bit 0, NaN-poisoned states) on an idle GPU.
+static int g_drop_arrival = 0;
+extern "C" int egtr_test_decoder_drop_arrival(int on) {
+  g_drop_arrival = on != 0;
+  return EGTR_OK;
+}
+
 extern "C" int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLayer* layer) {
   if (layer == nullptr) return EGTR_E_ARG;
   const EgtrDecoderLayer& p = *layer;
@@ -762,6 +781,7 @@ extern "C" int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLay
     return EGTR_E_ARG;
   Args a;
   a.p = p;
+  a.drop_arrival = g_drop_arrival;
   if (p.generation != 0)
     hipLaunchKernelGGL(decoder_layer_cluster_f32<true>, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   else

@@ -4,7 +4,10 @@ Reference: model/deformable_detr.py:1774-1968 (the loop), :1390-1489 (the layer)
 eight workgroups that meet in the L2 of one XCD; it relies on workgroup ids being dealt round-robin to the XCDs and CHECKS
 that on every launch (status word, bit 1).  ``run`` reads the status after the first eager call on a device and raises
 ``DecoderClusterError`` if a cluster timed out or was spread over XCDs -- the caller then uses the per-operation path and
-says so once (``ops.note_fallback``).
+says so once (``ops.note_fallback``).  After that the status words stay STICKY and are polled without a synchronisation
+(``poll_status``: every 64 eager forwards here, every ``status_every`` replays in ``runtime.GraphedForward``, at the end of
+``runtime.calculate_fps``); the words of workspaces baked into captured graphs are included.  A wave that gives up on a
+barrier NaN-poisons what it hands out (csrc/dec_layer.hip ``reduce_ln``), so a time-out can not yield plausible states.
 """
 import ctypes
 import os
@@ -112,6 +115,8 @@ _WORKSPACES = {}   # (device index, stream handle, shape key) -> persistent buff
 _POOL = {}         # (device index, shape key) -> zeroed buffer sets, one per captured graph
 _GRAPH_WORKSPACES = []   # buffer sets baked into captured graphs, kept alive for the life of the process
 _CHECKED = set()   # device indices whose first eager run was verified
+_EAGER_CALLS = {}  # device index -> eager forwards since import (status poll every POLL_EVERY)
+POLL_EVERY = 64
 
 
 def _new_workspace(dev, shape_key):
@@ -169,25 +174,14 @@ def _rows(t, n_rows_per_image):
     return t2, t2.shape[0]
 
 
-def _keep_bits(mask, B, S):
-    """One bit per token (1 = real): the copy the level-geometry kernel left on the mask tensor, or packed here."""
-    kb = getattr(mask, "_egtr_bits", None)
-    if kb is not None and kb.dtype == torch.int32 and tuple(kb.shape) == (B, (S + 31) // 32) and kb.is_cuda:
-        return kb
-    words = (S + 31) // 32
-    m = torch.zeros(B, words * 32, dtype=torch.int64, device=mask.device)
-    m[:, :S] = mask.reshape(B, S).to(torch.int64)
-    w = (m.view(B, words, 32) << torch.arange(32, device=mask.device, dtype=torch.int64)).sum(-1)
-    return ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32).contiguous()
-
-
 def run(decoder, hidden_states, position_embeddings, reference_input, values, value_bias, keep_mask, spatial_shapes,
-        level_start_index, first_with_pos=None, valid_ratios=None):
+        level_start_index, first_with_pos=None, valid_ratios=None, keep_bits=None):
     """All layers of ``decoder``.  hidden_states / position_embeddings [B, N, 256] (stride-0 batch expansions are read in
     place), reference_input [B, N, 4, 2] (reference points x valid ratios; with ``valid_ratios`` [B, 4, 2]: the plain points [B, N, 2],
     multiplied in the kernel), values [Ld, B, S, 256] bias-free value
     projections, value_bias [Ld, 256].  Returns (states [Ld, B, N, 256], q [Ld, B, N, 256] scaled, k [Ld, B, N, 256];
-    q[0] / k[0] may be stride-0 expansions over the batch)."""
+    q[0] / k[0] may be stride-0 expansions over the batch).  ``keep_bits``: the bit-packed copy of ``keep_mask``
+    (``ops.level_geometry``'s fifth result), handed down explicitly; packed here when absent."""
     from . import ops
     lib = _lib.lib()
     dev = hidden_states.device
@@ -214,11 +208,16 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
             dict(x=x0, w=lay0.v_proj.weight, b=lay0.v_proj.bias)])
         return q.contiguous(), k.contiguous(), v.contiguous()
 
-    if x_rows == N and pos_rows == N:
+    def base(t):
+        return t._base if t._base is not None else t
+
+    def is_weight(t):   # a view of a module parameter (the learned query table), not a per-call activation
+        return isinstance(base(t), torch.nn.Parameter)
+
+    if x_rows == N and pos_rows == N and is_weight(hidden_states) and is_weight(position_embeddings):
         # both operands are rows of the query table (batch expansions): the projections are derived constants, keyed on the
-        # tensors the views were cut from and on the views' geometry
-        def base(t):
-            return t._base if t._base is not None else t
+        # tensors the views were cut from and on the views' geometry.  Fresh ``inputs_embeds`` at B == 1 also have N rows but
+        # are not parameters: caching those would pin one never-hit entry per call -- they take qkv0() directly
         srcs = [lay0.q_proj.weight, lay0.q_proj.bias, lay0.k_proj.weight, lay0.k_proj.bias, lay0.v_proj.weight,
                 lay0.v_proj.bias, base(hidden_states), base(position_embeddings)]
         name = f"decoder_cluster_qkv0:{x0.data_ptr()}:{pos.data_ptr()}:{with_pos0 is not None}"
@@ -237,7 +236,10 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
         vr = valid_ratios.contiguous()
     else:
         ref, ref_rows, vr = reference_input.contiguous(), 0, None
-    kbits = _keep_bits(keep_mask, B, S) if keep_mask is not None else None
+    kbits = None
+    if keep_mask is not None:
+        from .load_custom import _check_keep_bits, pack_keep_bits
+        kbits = _check_keep_bits(keep_bits, B, S) if keep_bits is not None else pack_keep_bits(keep_mask, B, S)
     vals = values if values.is_contiguous() else values.contiguous()
     vb = value_bias.contiguous() if value_bias is not None else None
     stream = _stream()
@@ -280,17 +282,20 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
         a.batch, a.num_query, a.spatial_size, a.num_clusters = B, N, S, nclusters
         a.generation = tags[i] if tags is not None else 0
         _lib.check(lib.egtr_decoder_layer_f32(stream, ctypes.byref(a)), "egtr_decoder_layer_f32")
-    if dev.index not in _CHECKED and not torch.cuda.is_current_stream_capturing():
-        st = int(status.item())   # one synchronisation, on the first eager run per device
-        if st != 0:
-            status.zero_()
-            barriers.zero_()
-            partials.zero_()
-            raise DecoderClusterError(
-                "egtr_decoder_layer_f32: " + ("a cluster barrier timed out; " if st & 1 else "")
-                + ("the workgroups of a cluster were spread over several XCDs; " if st & 2 else "")
-                + "the per-operation decoder is used instead")
-        _CHECKED.add(dev.index)
+    if not torch.cuda.is_current_stream_capturing():
+        if dev.index not in _CHECKED:
+            st = int(status.item())   # one synchronisation, on the first eager run per device
+            if st != 0:
+                _reset(dev)
+                raise DecoderClusterError(_describe(st) + "the per-operation decoder is used instead")
+            _CHECKED.add(dev.index)
+        else:
+            # later runs: the sticky status words (this workspace's and every captured graph's) are polled without a
+            # synchronisation every POLL_EVERY eager forwards; a time-out raises DecoderClusterError one poll late (the
+            # kernel has NaN-poisoned the states it handed out in the meantime, so nothing plausible-looking leaks)
+            _EAGER_CALLS[dev.index] = _EAGER_CALLS.get(dev.index, 0) + 1
+            if _EAGER_CALLS[dev.index] % POLL_EVERY == 0:
+                poll_status(dev)
     states = states.view(nl, B, N, 256)
     if qkv_rows0 == N:   # layer 0's projections are the same rows for every image
         q_all, k_all = [q0.unsqueeze(0).expand(B, N, 256)], [k0.unsqueeze(0).expand(B, N, 256)]
@@ -302,10 +307,80 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
     return states, q_all, k_all
 
 
+def _workspaces_on(dev):
+    """Every buffer set on ``dev``: eager workspaces AND the sets baked into captured graphs."""
+    return ([ws for (d, _, _), ws in _WORKSPACES.items() if d == dev.index]
+            + [ws for ws in _GRAPH_WORKSPACES if ws[1].device == dev])
+
+
+def _status_words(dev):
+    return [ws[1] for ws in _workspaces_on(dev)]
+
+
+def _reset(dev):
+    """After a reported failure: status, barrier counters and partial sums back to zero (stream-ordered), so that the next
+    launch starts from a whole state (a barrier that lost an arrival would otherwise release early for ever after)."""
+    for barriers, status, partials, _ in _workspaces_on(dev):
+        status.zero_()
+        barriers.zero_()
+        partials.zero_()
+
+
+def _describe(st):
+    return ("egtr_decoder_layer_f32: " + ("a cluster barrier timed out (the decoder states of that launch are NaN-poisoned); "
+                                          if st & 1 else "")
+            + ("the workgroups of a cluster were spread over several XCDs; " if st & 2 else ""))
+
+
 def read_status(dev):
-    """The sticky status words of this device's eager workspaces OR-ed together: 0 = every launch so far was sound."""
+    """The sticky status words of this device's workspaces -- eager ones and those of captured graphs -- OR-ed together
+    (one synchronising copy each): 0 = every launch so far was sound."""
     st = 0
-    for (d, _, _), ws in _WORKSPACES.items():
-        if d == dev.index:
-            st |= int(ws[1].item())
+    for w in _status_words(dev):
+        st |= int(w.item())
     return st
+
+
+_PENDING_STATUS = {}   # device index -> (pinned int32 host word, event) of the last asynchronous poll
+
+
+def poll_status(dev, wait=False):
+    """Check the status words WITHOUT stalling the stream: the verdict of the PREVIOUS poll is read if its copy
+    has completed (``wait=True``: is waited for), then a new asynchronous copy of the OR of all status words -- eager and
+    captured-graph workspaces -- is queued on the current stream.  A non-zero word raises ``DecoderClusterError`` (bit 0: a
+    cluster barrier timed out, e.g. because another stream or process held the CUs longer than the spin limit -- the kernel
+    has NaN-poisoned the decoder states it handed out; bit 1: a cluster was spread over XCDs).  Callers: ``GraphedForward``
+    every ``status_every`` replays, ``runtime.calculate_fps`` at the end of a run, ``runtime.triplet_candidates`` never
+    (it does not synchronise either)."""
+    if not isinstance(dev, torch.device):
+        dev = torch.device(dev)
+    if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+        return 0
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    verdict = 0
+    pend = _PENDING_STATUS.get(dev.index)
+    if pend is not None:
+        host, event = pend
+        if wait:
+            event.synchronize()
+        if event.query():
+            verdict = int(host.item())
+            _PENDING_STATUS.pop(dev.index, None)
+    words = _status_words(dev)
+    if words and dev.index not in _PENDING_STATUS:
+        if len(words) == 1:
+            acc = words[0]
+        else:   # OR of the two-bit masks, bit by bit (a plain max would lose bit 0 next to a 2)
+            stacked = torch.stack([w.reshape(()) for w in words])
+            acc = ((stacked & 1).max() | (stacked & 2).max()).to(torch.int32)
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(acc.reshape(1), non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        _PENDING_STATUS[dev.index] = (host, event)
+    if verdict:
+        _reset(dev)
+        _PENDING_STATUS.pop(dev.index, None)
+        raise DecoderClusterError(_describe(verdict) + "results since the previous poll are void")
+    return verdict

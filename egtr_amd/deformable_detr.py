@@ -355,7 +355,9 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                 encoder_hidden_states=None, encoder_attention_mask=None,
                 position_embeddings: Optional[torch.Tensor] = None, reference_points=None, spatial_shapes=None,
                 level_start_index=None, output_attentions: bool = False, spatial_shapes_list=None,
-                hidden_with_pos=None, precomputed_value=None, residual_ln=None):
+                hidden_with_pos=None, precomputed_value=None, residual_ln=None, mask_bits=None):
+        # mask_bits: ``attention_mask`` packed one bit per token (ops.level_geometry's fifth result), handed down explicitly
+        # by DeformableDetrModel.forward for the fused inference kernel; None: the kernel reads / packs the byte mask.
         # hidden_with_pos / precomputed_value: inference-only hand-ins that save launches (the previous LayerNorm
         # kernel also wrote hidden + pos; the decoder projects the values of all its layers in one batched GEMM)
         deferred = hidden_states if isinstance(hidden_states, ops.DeferredLayerNorm) else None
@@ -473,7 +475,8 @@ class DeformableDetrMultiscaleDeformableAttention(nn.Module):
                 value.contiguous(), spatial_shapes, level_start_index, sampling_offsets, attention_weights,
                 reference_points.contiguous(), want_weights=output_attentions,
                 keep_mask=None if value_is_masked else attention_mask,
-                value_bias=value_bias if value.dtype == torch.float32 else None)
+                value_bias=value_bias if value.dtype == torch.float32 else None,
+                keep_bits=None if value_is_masked else mask_bits)
         else:
             if value_bias is not None:
                 value = value + value_bias
@@ -635,9 +638,10 @@ class DeformableDetrEncoderLayer(nn.Module):
 
     def forward(self, hidden_states, attention_mask, position_embeddings=None, reference_points=None,
                 spatial_shapes=None, level_start_index=None, output_attentions: bool = False,
-                spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False):
+                spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False, mask_bits=None):
         """``hidden_with_pos`` / ``return_with_pos`` (inference plumbing): hidden + position embeddings handed in by
-        the previous layer / appended to the outputs for the next one (written by the final LayerNorm kernel)."""
+        the previous layer / appended to the outputs for the next one (written by the final LayerNorm kernel).
+        ``mask_bits``: the bit-packed ``attention_mask`` for the fused MSDA kernel."""
         if ops.encoder_layer_train_supported(self, hidden_states, position_embeddings, reference_points, attention_mask,
                                              output_attentions):
             # training: the whole layer as ONE autograd node (ops.EncoderLayerTrainFunction) -- the same kernels as the
@@ -656,7 +660,7 @@ class DeformableDetrEncoderLayer(nn.Module):
             encoder_attention_mask=attention_mask, position_embeddings=position_embeddings,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
-            hidden_with_pos=hidden_with_pos,
+            hidden_with_pos=hidden_with_pos, mask_bits=mask_bits,
             residual_ln=(residual, self.self_attn_layer_norm, tail) if fuse else None)
         if fuse and res[2] == "tail":      # the attention module ran the layer's whole tail (one launch)
             out = res[0]
@@ -757,7 +761,7 @@ class DeformableDetrDecoderLayer(nn.Module):
                 spatial_shapes=None, level_start_index=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, output_attentions=False, output_attention_states=False,
                 spatial_shapes_list=None, hidden_with_pos=None, return_with_pos=False, precomputed_value=None,
-                out=None, dropout_masks=None):
+                out=None, dropout_masks=None, mask_bits=None):
         """``hidden_with_pos`` / ``return_with_pos`` / ``precomputed_value`` / ``out`` (destination of the layer's output
         states): inference plumbing, see the encoder layer and DeformableDetrDecoder.forward.  ``dropout_masks`` (training):
         the byte masks [3, rows, 256] of the layer's three dropouts, drawn by the decoder for all its layers at once."""
@@ -771,7 +775,7 @@ class DeformableDetrDecoderLayer(nn.Module):
             return self._forward_deferred(hidden_states, position_embeddings, reference_points, spatial_shapes,
                                           level_start_index, encoder_hidden_states, encoder_attention_mask,
                                           output_attention_states, spatial_shapes_list, hidden_with_pos, return_with_pos,
-                                          precomputed_value, out)
+                                          precomputed_value, out, mask_bits)
         if incoming is not None:
             hidden_states = incoming.materialize()
         residual = hidden_states
@@ -794,7 +798,7 @@ class DeformableDetrDecoderLayer(nn.Module):
             position_embeddings=position_embeddings, reference_points=reference_points,
             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
             output_attentions=output_attentions, spatial_shapes_list=spatial_shapes_list,
-            hidden_with_pos=cross_with_pos, precomputed_value=precomputed_value)
+            hidden_with_pos=cross_with_pos, precomputed_value=precomputed_value, mask_bits=mask_bits)
         hidden_states = ops.dropout_add_layer_norm(hidden_states, second_residual, self.encoder_attn_layer_norm,
                                                    self.dropout, self.training,
                                                    keep=dropout_masks[1] if dropout_masks is not None else None)
@@ -825,7 +829,7 @@ class DeformableDetrDecoderLayer(nn.Module):
 
     def _forward_deferred(self, hidden_states, position_embeddings, reference_points, spatial_shapes, level_start_index,
                           encoder_hidden_states, encoder_attention_mask, output_attention_states, spatial_shapes_list,
-                          hidden_with_pos, return_with_pos, precomputed_value, out):
+                          hidden_with_pos, return_with_pos, precomputed_value, out, mask_bits=None):
         """The layer at inference (fp32, <= SKINNY_MAX_ROWS query rows) without stand-alone LayerNorm launches: each of the
         three residual-add + LayerNorm steps (dd:1437-1438, 1456-1457, 1466-1468) is an ``ops.DeferredLayerNorm`` that the
         next skinny linear evaluates as its prologue -- the sampling-offset / attention-weight projections, fc1, and the next
@@ -841,7 +845,7 @@ class DeformableDetrDecoderLayer(nn.Module):
             hidden_states=d1, attention_mask=encoder_attention_mask, encoder_hidden_states=encoder_hidden_states,
             encoder_attention_mask=encoder_attention_mask, position_embeddings=position_embeddings,
             reference_points=reference_points, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-            spatial_shapes_list=spatial_shapes_list, precomputed_value=precomputed_value)
+            spatial_shapes_list=spatial_shapes_list, precomputed_value=precomputed_value, mask_bits=mask_bits)
         d2 = ops.DeferredLayerNorm(cross_out, d1.out, self.encoder_attn_layer_norm)
         hidden = ops.linear_grouped([dict(x=d2, w=self.fc1.weight, b=self.fc1.bias, relu=True)])[0]
         hidden = ops.module_linear(self.fc2, hidden)
@@ -908,7 +912,8 @@ class DeformableDetrEncoder(DeformableDetrPreTrainedModel):
 
     def forward(self, inputs_embeds=None, attention_mask=None, position_embeddings=None, spatial_shapes=None,
                 level_start_index=None, valid_ratios=None, output_attentions=None, output_hidden_states=None,
-                return_dict=None, spatial_shapes_list=None, reference_points=None):
+                return_dict=None, spatial_shapes_list=None, reference_points=None, mask_bits=None):
+        # mask_bits: ``attention_mask`` packed one bit per token (ops.level_geometry), for the fused MSDA kernel
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_hidden_states = (output_hidden_states if output_hidden_states is not None
                                 else self.config.output_hidden_states)
@@ -932,7 +937,8 @@ class DeformableDetrEncoder(DeformableDetrPreTrainedModel):
                 hidden_states, attention_mask, position_embeddings=position_embeddings,
                 reference_points=reference_points, spatial_shapes=spatial_shapes,
                 level_start_index=level_start_index, output_attentions=output_attentions,
-                spatial_shapes_list=spatial_shapes_list, hidden_with_pos=with_pos, return_with_pos=want_pos)
+                spatial_shapes_list=spatial_shapes_list, hidden_with_pos=with_pos, return_with_pos=want_pos,
+                mask_bits=mask_bits)
             hidden_states = layer_outputs[0]
             with_pos = layer_outputs[-1] if want_pos else None
             if output_attentions:
@@ -960,9 +966,10 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
     def forward(self, inputs_embeds=None, encoder_hidden_states=None, encoder_attention_mask=None,
                 position_embeddings=None, reference_points=None, spatial_shapes=None, level_start_index=None,
                 valid_ratios=None, output_attentions=None, output_hidden_states=None, output_attention_states=None,
-                return_dict=None, spatial_shapes_list=None, first_with_pos=None):
+                return_dict=None, spatial_shapes_list=None, first_with_pos=None, mask_bits=None):
         """``first_with_pos`` (inference plumbing): inputs_embeds + position_embeddings, when the caller has it as a
-        derived constant of the query table."""
+        derived constant of the query table.  ``mask_bits``: ``encoder_attention_mask`` packed one bit per token
+        (ops.level_geometry), for the fused cross-attention kernels."""
         output_attentions = output_attentions if output_attentions is not None else self.config.output_attentions
         output_attention_states = (output_attention_states if output_attention_states is not None
                                    else self.config.output_attention_states)
@@ -1041,7 +1048,7 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 states, q_all, k_all = decoder_fused.run(
                     self, hidden_states, position_embeddings, reference_points, values_all, b_all,
                     encoder_attention_mask, spatial_shapes, level_start_index, first_with_pos=first_with_pos,
-                    valid_ratios=valid_ratios)
+                    valid_ratios=valid_ratios, keep_bits=mask_bits)
             except decoder_fused.DecoderClusterError as exc:
                 ops.note_fallback("decoder_cluster", str(exc))
                 decoder_fused.ENABLED = False
@@ -1087,7 +1094,7 @@ class DeformableDetrDecoder(DeformableDetrPreTrainedModel):
                 hidden_with_pos=with_pos, return_with_pos=True,
                 precomputed_value=values[idx] if values is not None else None,
                 out=inter_buf[idx] if inter_buf is not None else None,
-                dropout_masks=layer_masks[idx] if layer_masks is not None else None)
+                dropout_masks=layer_masks[idx] if layer_masks is not None else None, mask_bits=mask_bits)
             hidden_states = layer_outputs[0]
             with_pos = layer_outputs[-1]
             if isinstance(hidden_states, ops.DeferredLayerNorm):
@@ -1287,6 +1294,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                           and not (torch.is_grad_enabled() and self.level_embed.requires_grad))
         query_embeds = None if self.config.two_stage else self.query_position_embeddings.weight   # dd:2245-2247
         encoder_reference_points = None
+        mask_bits = None   # mask_flatten packed one bit per token: left by the level-geometry kernel, handed down explicitly
         if fused_geometry:
             # inference: masks, position embeddings (+ level_embed), valid ratios and the encoder reference points of
             # all levels come from ONE HIP kernel instead of ~100 tiny launches (dd:2195-2278, 1616-1648, 850-876)
@@ -1349,7 +1357,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                                                           else sources[-1]))
                 spatial_shapes_list = [tuple(src.shape[-2:]) for src in sources]
                 source_flatten = torch.cat([src.flatten(2).transpose(1, 2) for src in sources], 1)
-            mask_flatten, lvl_pos_embed_flatten, valid_ratios, encoder_reference_points = ops.level_geometry(
+            mask_flatten, lvl_pos_embed_flatten, valid_ratios, encoder_reference_points, mask_bits = ops.level_geometry(
                 pixel_mask, spatial_shapes_list, self.level_embed, pos_mod.embedding_dim, pos_mod.temperature,
                 pos_mod.scale)
         elif (ops.ENCODER_TRAIN_FUSED and pixel_mask.is_cuda and pixel_values.dtype == torch.float32
@@ -1419,7 +1427,7 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
                 level_start_index=level_start_index, valid_ratios=valid_ratios,
                 output_attentions=output_attentions, output_hidden_states=output_hidden_states,
                 return_dict=return_dict, spatial_shapes_list=spatial_shapes_list,
-                reference_points=encoder_reference_points)
+                reference_points=encoder_reference_points, mask_bits=mask_bits)
         elif return_dict and not isinstance(encoder_outputs, BaseModelOutput):
             encoder_outputs = BaseModelOutput(
                 last_hidden_state=encoder_outputs[0],
@@ -1469,7 +1477,8 @@ class DeformableDetrModel(DeformableDetrPreTrainedModel):
             encoder_attention_mask=mask_flatten, reference_points=reference_points, spatial_shapes=spatial_shapes,
             level_start_index=level_start_index, valid_ratios=valid_ratios, output_attentions=output_attentions,
             output_attention_states=output_attention_states, output_hidden_states=output_hidden_states,
-            return_dict=return_dict, spatial_shapes_list=spatial_shapes_list, first_with_pos=first_with_pos)
+            return_dict=return_dict, spatial_shapes_list=spatial_shapes_list, first_with_pos=first_with_pos,
+            mask_bits=mask_bits)
 
         if not return_dict:
             enc_outputs = tuple(v for v in (enc_outputs_class, enc_outputs_coord_logits) if v is not None)

@@ -244,20 +244,26 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
             class_cost=self.config.ce_loss_coefficient, bbox_cost=self.config.bbox_cost,
             giou_cost=self.config.giou_cost, smoothing=self.config.smoothing)
 
-    def _heads(self, outputs, want_gate_mean, labels=None, sigmoid=False):
+    def _heads(self, outputs, want_gate_mean, labels=None, sigmoid=False, last_level_only=None):
         """Detection heads + relation head on the base model's outputs (egtr:283-418).  Returns
         (logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, pending_match); the
         relation / connectivity logits are PRE-sigmoid unless ``sigmoid`` (inference: applied in the relation-head
         kernel's epilogue).  With ``labels`` on the GPU the Hungarian cost matrix and its
         copy to the host are enqueued BEFORE the relation head is launched (the matcher needs only logits and boxes), so
-        that the host-side assignment overlaps the relation-head kernel instead of idling the GPU."""
+        that the host-side assignment overlaps the relation-head kernel instead of idling the GPU.
+        ``last_level_only``: run the detection heads on the last decoder level only -- legal when nothing reads the other
+        levels (no auxiliary losses downstream).  None = decide here: only ``forward`` without labels qualifies;
+        ``forward_tensors`` (whose result feeds ``loss_from_tensors``, auxiliary terms included) always asks for every level
+        (under ``torch.no_grad()`` -- a validation loss -- the old rule silently dropped every ``*_i`` term)."""
+        if last_level_only is None:
+            last_level_only = labels is None
         sequence_output = outputs["last_hidden_state"]
         hidden_states = outputs.intermediate_hidden_states
         init_reference = outputs.init_reference_points
         inter_references = outputs.intermediate_reference_points
 
-        if (labels is None and ops.inference_fast_path(hidden_states) and not self.config.with_box_refine
-                and hidden_states.shape[1] > 1):
+        if (last_level_only and labels is None and ops.inference_fast_path(hidden_states)
+                and not self.config.with_box_refine and hidden_states.shape[1] > 1):
             # inference: nothing reads the intermediate levels' logits / boxes (they feed the auxiliary losses only,
             # egtr:307-316) -- the heads run on the last level's 200 rows instead of all Ld x 200 (the reference computes
             # every level and drops them)
@@ -294,7 +300,7 @@ class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):
         outputs = self.model(pixel_values, pixel_mask=pixel_mask, output_attentions=False, output_hidden_states=True,
                              output_attention_states=True, return_dict=True)
         logits, pred_boxes, outputs_class, outputs_coord, pred_rel, pred_connectivity, gate_mean, _ = \
-            self._heads(outputs, want_gate_mean=True)
+            self._heads(outputs, want_gate_mean=True, last_level_only=not self.config.auxiliary_loss)
         res = (logits, pred_boxes, pred_rel, pred_connectivity, gate_mean)
         if self.config.auxiliary_loss:
             res += (outputs_class, outputs_coord)

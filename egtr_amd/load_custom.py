@@ -31,6 +31,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def pack_keep_bits(mask, B, S):
+    """[B, S] padding mask (any dtype; non-zero = real token) -> [B, ceil(S/32)] int32, bit t%32 of word t/32 = token t."""
+    words = (S + 31) // 32
+    m = torch.zeros(B, words * 32, dtype=torch.int64, device=mask.device)
+    m[:, :S] = (mask.reshape(B, S) != 0).to(torch.int64)
+    w = (m.view(B, words, 32) << torch.arange(32, device=mask.device, dtype=torch.int64)).sum(-1)
+    return ((w + 2 ** 31) % 2 ** 32 - 2 ** 31).to(torch.int32).contiguous()
+
+
+def _check_keep_bits(bits, B, S):
+    if (not torch.is_tensor(bits) or not bits.is_cuda or bits.dtype != torch.int32
+            or tuple(bits.shape) != (B, (S + 31) // 32) or not bits.is_contiguous()):
+        raise RuntimeError(f"keep_bits must be a contiguous int32 CUDA/HIP tensor of shape {(B, (S + 31) // 32)}")
+    return bits
+
+
 class _MultiScaleDeformableAttention:
     """Module-like object bound to the global ``MultiScaleDeformableAttention`` (deformable_detr.py:392)."""
 
@@ -72,12 +88,15 @@ class _MultiScaleDeformableAttention:
 
     @staticmethod
     def ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                     reference_points, want_weights=False, keep_mask=None, value_bias=None):
+                                     reference_points, want_weights=False, keep_mask=None, value_bias=None, keep_bits=None):
         """Forward with the softmax over the L*P logits and ``loc = ref + offset / (W, H)`` (2-d reference points) or
         ``loc = box.xy + offset / P * box.wh * 0.5`` (4-d reference boxes) computed in the kernel
         (deformable_detr.py:1055-1081).  fp32, M = 8, D = 32, L*P = 16; no autograd.
         sampling_offsets [B,Lq,M,L,P,2] / attn_logits [B,Lq,M,L*P] may be column blocks of one wider Linear output
         (any row stride, unit inner strides); keep_mask [B,S] bool: padded tokens are skipped (== zeroed value rows).
+        keep_bits [B, ceil(S/32)] int32: the same mask packed one bit per token (bit t%32 of word t/32; what
+        ``ops.level_geometry`` returns as its fifth value) -- an EXPLICIT argument: the caller that owns the mask hands the
+        packed copy down; without it the byte mask is read by the kernel.
         value_bias [M*D]: ``value`` is the bias-free value projection and the bias is applied inside the kernel (times the
         sum of the in-range, unpadded corner weights).
         Returns (out [B,Lq,M*D], attention weights [B,Lq,M,L,P] or None)."""
@@ -107,16 +126,12 @@ class _MultiScaleDeformableAttention:
         off2, ld_off = rows(sampling_offsets, M * L * P * 2, "sampling_offsets")
         log2, ld_log = rows(attn_logits, M * L * P, "attn_logits")
         km = kbits = None
-        if keep_mask is not None:
-            # a bit-packed copy written by the level-geometry kernel travels as an attribute of the mask tensor
-            kbits = getattr(keep_mask, "_egtr_bits", None)
-            if kbits is not None and (kbits.dtype != torch.int32 or tuple(kbits.shape) != (B, (S + 31) // 32)
-                                      or not kbits.is_cuda):
-                kbits = None
-            if kbits is None:
-                km = keep_mask.reshape(B, S).contiguous()
-                km = km.view(torch.uint8) if km.dtype == torch.bool else km.to(torch.uint8)
-                _chk(km, "keep_mask")
+        if keep_bits is not None:
+            kbits = _check_keep_bits(keep_bits, B, S)
+        elif keep_mask is not None:
+            km = keep_mask.reshape(B, S).contiguous()
+            km = km.view(torch.uint8) if km.dtype == torch.bool else (km != 0).to(torch.uint8)
+            _chk(km, "keep_mask")
         out = torch.empty(B, Lq, M * D, dtype=value.dtype, device=value.device)
         wts = torch.empty(B, Lq, M, L, P, dtype=value.dtype, device=value.device) if want_weights else None
         vb = None
@@ -134,7 +149,7 @@ class _MultiScaleDeformableAttention:
 
     @staticmethod
     def ms_deform_attn_forward_fused_bf16(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                          reference_points, keep_mask=None):
+                                          reference_points, keep_mask=None, keep_bits=None):
         """bf16 counterpart of ``ms_deform_attn_forward_fused`` (M = 8, D = 32, L*P = 16): every tensor bf16, softmax and
         sampling locations formed in fp32 inside the kernel.  Returns out [B, Lq, M*D] bf16."""
         lib = _lib.lib()
@@ -160,17 +175,10 @@ class _MultiScaleDeformableAttention:
         off2, ld_off = rows(sampling_offsets, M * L * P * 2, "sampling_offsets")
         log2, ld_log = rows(attn_logits, M * L * P, "attn_logits")
         kbits = None
-        if keep_mask is not None:
-            # one bit per token: the copy the level-geometry kernel left on the mask, or packed here ONCE per mask tensor (the
-            # six encoder layers of a forward share it) -- the kernel keeps the bits of its image in LDS
-            kbits = getattr(keep_mask, "_egtr_bits", None)
-            if kbits is None or kbits.dtype != torch.int32 or tuple(kbits.shape) != (B, (S + 31) // 32) or not kbits.is_cuda:
-                from .decoder_fused import _keep_bits
-                kbits = _keep_bits(keep_mask, B, S)
-                try:
-                    keep_mask._egtr_bits = kbits
-                except Exception:   # pragma: no cover - a tensor subclass without attributes
-                    pass
+        if keep_bits is not None:   # one bit per token, handed down explicitly by the owner of the mask (ops.level_geometry)
+            kbits = _check_keep_bits(keep_bits, B, S)
+        elif keep_mask is not None:  # packed here, per call (the kernel keeps the bits of its image in LDS)
+            kbits = pack_keep_bits(keep_mask, B, S)
         out = torch.empty(B, Lq, M * D, dtype=bf, device=value.device)
         st = lib.egtr_msda_forward_fused_bf16(_stream(), value.data_ptr(), spatial_shapes.data_ptr(),
                                               level_start_index.data_ptr(), off2.data_ptr(), log2.data_ptr(),

@@ -134,18 +134,20 @@ def msda_fused_supported(num_heads, channels, num_levels, num_points):
 
 
 def msda_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits, reference_points,
-                       want_weights=False, keep_mask=None, value_bias=None):
+                       want_weights=False, keep_mask=None, value_bias=None, keep_bits=None):
     """MSDA forward with its softmax / sampling-location prologue fused in (no autograd: inference path).  With
-    ``value_bias`` (fp32 only) ``value`` is the bias-free value projection and the kernel applies the bias."""
+    ``value_bias`` (fp32 only) ``value`` is the bias-free value projection and the kernel applies the bias.
+    ``keep_bits``: the bit-packed copy of ``keep_mask`` (``level_geometry``'s fifth result), passed down explicitly."""
     from .load_custom import load_hip_kernels
     k = load_hip_kernels()
     if value.dtype == torch.bfloat16:
         if want_weights or value_bias is not None:
             raise NotImplementedError("the bf16 fused MSDA forward returns no attention weights and takes no value_bias")
         return k.ms_deform_attn_forward_fused_bf16(value, spatial_shapes, level_start_index, sampling_offsets,
-                                                   attn_logits, reference_points, keep_mask), None
+                                                   attn_logits, reference_points, keep_mask, keep_bits=keep_bits), None
     return k.ms_deform_attn_forward_fused(value, spatial_shapes, level_start_index, sampling_offsets, attn_logits,
-                                          reference_points, want_weights, keep_mask, value_bias=value_bias)
+                                          reference_points, want_weights, keep_mask, value_bias=value_bias,
+                                          keep_bits=keep_bits)
 
 
 class DecoderSelfAttentionFunction(Function):
@@ -1755,7 +1757,8 @@ _DIM_T = {}
 def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale, eps=1e-6):
     """Everything DeformableDetrModel.forward derives from ``pixel_mask`` alone, in one HIP kernel
     (egtr_level_geometry_f32): returns (mask_flatten [B,S] bool, lvl_pos_embed_flatten [B,S,2E] incl. level_embed,
-    valid_ratios [B,L,2], encoder reference_points [B,S,L,2]).  A bf16 ``level_embed`` (bf16 model) gives bf16 position rows
+    valid_ratios [B,L,2], encoder reference_points [B,S,L,2], mask bits [B, ceil(S/32)] int32 -- the mask packed one bit per
+    token, which the model hands to the fused MSDA kernels as ``mask_bits``).  A bf16 ``level_embed`` (bf16 model) gives bf16 position rows
     rounded like the reference's composition (egtr_level_geometry_bf16); everything else stays fp32.  Inference only (no
     autograd through level_embed)."""
     import ctypes
@@ -1790,9 +1793,9 @@ def level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, 
                              L, B, H, W_, embedding_dim, float(scale), float(eps), mask_u8.data_ptr(),
                              pos.data_ptr(), vr.data_ptr(), ref.data_ptr(), bits.data_ptr())
     _lib.check(st, entry)
-    mask = mask_u8.view(torch.bool)
-    mask._egtr_bits = bits  # one bit per token, consumed by the fused MSDA kernel (kept in LDS there)
-    return mask, pos, vr, ref
+    # `bits`: one bit per token, consumed by the fused MSDA kernels (kept in LDS there) -- returned, and handed down by the
+    # model as an explicit `mask_bits` argument (until round 5 it travelled as a Python attribute on the mask tensor)
+    return mask_u8.view(torch.bool), pos, vr, ref, bits
 
 
 class LevelGeometryTrainFunction(Function):
@@ -1805,7 +1808,7 @@ class LevelGeometryTrainFunction(Function):
 
     @staticmethod
     def forward(ctx, level_embed, pixel_mask, spatial_shapes_list, embedding_dim, temperature, scale):
-        mask, pos, vr, ref = level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale)
+        mask, pos, vr, ref, _ = level_geometry(pixel_mask, spatial_shapes_list, level_embed, embedding_dim, temperature, scale)
         ctx.shapes = (tuple(spatial_shapes_list), pos.shape[0])
         ctx.mark_non_differentiable(mask, vr, ref)
         return pos, mask, vr, ref

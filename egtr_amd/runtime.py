@@ -5,6 +5,7 @@ The reference drives training through pytorch-lightning (train_egtr.py:770-783: 
 clip 0.1) and measures FPS with a bare loop (evaluate_egtr.py:26-36).  Lightning is not part of the hot path and
 is absent on the GPU box; these helpers reproduce exactly the pieces that touch it.
 """
+import collections
 import contextlib
 import os
 
@@ -12,75 +13,198 @@ import torch
 import torch.distributed as dist
 
 
+class _GraphEntry:
+    """One captured forward: the graph, its static input buffers and static outputs, and the weight epoch it was captured at."""
+    __slots__ = ("graph", "static_in", "static_out", "epoch", "replays")
+
+    def __init__(self, graph, static_in, static_out, epoch):
+        self.graph, self.static_in, self.static_out, self.epoch, self.replays = graph, static_in, static_out, epoch, 0
+
+
 class GraphedForward:
-    """Replay ``model(pixel_values, pixel_mask, output_attention_states=True, output_hidden_states=True)`` from a
-    captured HIP graph.  At bs = 1 the forward is ~700 short kernels, i.e. launch-bound when issued eagerly
+    """Replay ``model(pixel_values, pixel_mask, output_attention_states=True, output_hidden_states=True)`` from captured
+    HIP graphs.  At bs = 1 the forward is ~150 short kernels, i.e. launch-bound when issued eagerly
     (MI355X_MICROARCH.md: eager launch ~3.3-3.8 us host time each); a graph replay issues them back-to-back.
     Inputs are copied into static buffers; outputs are the graph's static tensors (valid until the next call).
 
-    The captured graph bakes in pointers to DERIVED tensors built at capture time (folded-BN backbone weights, stacked /
-    concatenated projection weights, query tables), so the capture key holds a fingerprint of the model's parameters and
-    buffers (storage pointer + version counter of each): after an optimizer step, ``load_state_dict`` or a dtype /
-    device move the next call re-captures instead of replaying stale constants.  Edits through ``.data`` bypass the
-    version counter -- call ``invalidate()`` after those.
+    **Variable image sizes** (the reference's FPS loop runs over a dataloader whose images are resized to a short side of
+    ``--min_size`` / long side <= ``--max_size``, evaluate_egtr.py:26-36, 165-175, so almost every batch has its own shape):
+    the object keeps an LRU of up to ``max_graphs`` captured graphs keyed by (pixel shape, mask shape, dtypes, device).  A
+    shape seen before replays its own graph -- own static inputs, own outputs, own private memory pool (a 600x1000 fp32
+    forward holds < 0.5 GB; sixteen of them are noise in 288 GB of HBM) -- and only a NEW shape pays the two eager
+    warm-up runs + capture (the warm-up runs are also what lets MIOpen / TunableOp pick their kernels for the new
+    convolution / GEMM shapes outside the capture).  The least recently used graph is dropped when the table is full.
+
+    **Weights.**  A captured graph bakes in pointers to DERIVED tensors built at capture time (folded-BN backbone weights,
+    stacked / concatenated projection weights, query tables).  The table is therefore tagged with a weight EPOCH: the full
+    fingerprint of the model's parameters and buffers (storage pointer + version counter of each, ~140 us of host time for
+    the 589 tensors of EGTR) is taken once per epoch, not per call.  What starts a new epoch: ``load_state_dict`` (a hook
+    on the model), an explicit ``invalidate()``, and -- as the per-call O(1) check -- a change of the version counter or
+    storage of any of a few SENTINEL tensors (the first and last parameter of the backbone, encoder, decoder and heads: an
+    optimizer step, ``.to()`` / ``.half()`` / ``.cuda()`` or an in-place edit of the whole model moves all of them).  Every ``verify_every`` calls the full fingerprint is compared again as a backstop for edits that touch
+    only non-sentinel tensors.  On a new epoch every graph is dropped (they all hold stale constants).  Edits through
+    ``.data`` bypass the version counter -- call ``invalidate()`` after those.
 
     ``strict=True`` (what bench.py uses): a failed capture raises.  ``strict=False``: falls back to eager launches
-    (``self.graphed = False``, reason in ``capture_error``) -- same kernels either way, about 2x slower at bs = 1."""
+    (``self.graphed = False``, reason in ``capture_error``) -- same kernels either way, about 2x slower at bs = 1.
 
-    def __init__(self, model, enabled=True, warmup=2, strict=False):
+    Every ``status_every`` calls the sticky status words of the one-launch decoder layers are polled without a
+    synchronisation (``decoder_fused.poll_status``: asynchronous copy now, verdict at the next poll); a cluster barrier
+    that timed out raises ``DecoderClusterError`` instead of handing out void decoder states."""
+
+    def __init__(self, model, enabled=True, warmup=2, strict=False, max_graphs=16, verify_every=256, status_every=64):
         self.model = model
         self.enabled = enabled
         self.warmup = warmup
         self.strict = strict
+        self.max_graphs = max(1, int(max_graphs))
+        self.verify_every = max(1, int(verify_every))
+        self.status_every = max(1, int(status_every))
+        self._entries = collections.OrderedDict()   # key -> _GraphEntry, least recently used first
         self._tensors = None
+        self._sentinels = None
+        self._sentinel_key = None
+        self._fingerprint_key = None
+        self._epoch = 0
+        self._calls = 0
         self.graphed = False
-        self._graph = None
-        self._key = None
-        self._static_in = None
-        self._static_out = None
+        self.captures = 0          # graphs captured so far (a shape that comes back after eviction counts again)
+        self.evictions = 0
         self.capture_error = None
+        self._hooks = []
+        self._install_hooks()
 
+    # ---- weight epochs -------------------------------------------------------------------------------------------
+    def _install_hooks(self):
+        """load_state_dict starts a new epoch at once (it also bumps every version counter, which the sentinels see);
+        ``.to()`` / ``.cuda()`` / ``.half()`` replace every parameter's storage, which the sentinels see as well."""
+        bump = self._bump
+        try:
+            self._hooks.append(self.model.register_load_state_dict_post_hook(lambda module, incompatible: bump()))
+        except Exception:  # pragma: no cover - torch without the hook: the sentinels / verify pass still catch it
+            pass
+
+    def _bump(self):
+        self._epoch += 1
+        self._tensors = None
+        self._sentinels = None
+
+    def _all_tensors(self):
+        if self._tensors is None:
+            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
+        return self._tensors
+
+    def _fingerprint(self):
+        return [(t.data_ptr(), t._version) for t in self._all_tensors()]
+
+    def _sentinel_fingerprint(self):
+        if self._sentinels is None:
+            picks = []
+            for child in self.model.children():
+                ps = list(child.parameters())
+                if ps:
+                    picks += [ps[0], ps[-1]]
+                for grand in child.children():
+                    gs = list(grand.parameters())
+                    if gs:
+                        picks += [gs[0], gs[-1]]
+            own = list(self.model.parameters())
+            picks += own[:1] + own[-1:]
+            seen, uniq = set(), []
+            for t in picks:
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    uniq.append(t)
+            self._sentinels = uniq[:24]
+        return tuple((t.data_ptr(), t._version) for t in self._sentinels)
+
+    def _weights_changed(self):
+        """O(1) per call; the full fingerprint only when an epoch was announced, a sentinel moved, or on the periodic verify."""
+        full = self._fingerprint_key is None or self._calls % self.verify_every == 0
+        epoch_now = self._epoch
+        if self._sentinels is None or self._sentinel_fingerprint() != self._sentinel_key:
+            full = True
+        if getattr(self, "_seen_epoch", None) != epoch_now:
+            full = True
+        if not full:
+            return False
+        self._seen_epoch = epoch_now
+        self._tensors = self._sentinels = None     # re-enumerate: a parameter OBJECT may have been replaced
+        self._sentinel_key = self._sentinel_fingerprint()
+        fp = self._fingerprint()
+        if fp == self._fingerprint_key:
+            return False
+        changed = self._fingerprint_key is not None
+        self._fingerprint_key = fp
+        return changed
+
+    def invalidate(self):
+        """Forget every captured graph and every derived constant (after weights were edited through ``.data``)."""
+        from . import ops
+        ops.invalidate_derived(self.model)
+        self._drop_all()
+        self._bump()
+        self._fingerprint_key = None
+
+    def _drop_all(self):
+        self._entries.clear()
+
+    # ---- capture / replay ----------------------------------------------------------------------------------------
     def _eager(self, pv, pm):
         return self.model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
                           output_hidden_states=True)
 
+    @staticmethod
+    def _key(pv, pm):
+        return (tuple(pv.shape), pv.dtype, tuple(pm.shape), pm.dtype, pv.device)
+
     def _capture(self, pv, pm):
-        self._static_in = (pv.clone(), pm.clone())
+        static_in = (pv.clone(), pm.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.warmup):
-                self._eager(*self._static_in)
+                self._eager(*static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._static_out = self._eager(*self._static_in)
-        self._graph = g
-        self._key = (tuple(pv.shape), tuple(pm.shape), pv.device)
-        self._fingerprint_key = self._fingerprint()
+            static_out = self._eager(*static_in)
+        self.captures += 1
         self.graphed = True
+        return _GraphEntry(g, static_in, static_out, self._epoch)
 
-    def _fingerprint(self):
-        if self._tensors is None:
-            self._tensors = list(self.model.parameters()) + list(self.model.buffers())
-        return [(t.data_ptr(), t._version) for t in self._tensors]
+    @property
+    def cached_shapes(self):
+        """(pixel shape, ...) keys of the graphs held now, least recently used first."""
+        return [k[0] for k in self._entries]
 
-    def invalidate(self):
-        """Forget the captured graph and every derived constant (after weights were edited through ``.data``)."""
-        from . import ops
-        ops.invalidate_derived(self.model)
-        self._graph, self._key, self._tensors = None, None, None
+    def prime(self, shapes, dtype=torch.float32, device=None):
+        """Capture a graph for every (B, 3, H, W) in ``shapes`` ahead of time (zeros as pixels, all-ones masks) -- what an
+        evaluation run does once for the resize buckets of its dataloader; returns the number of new captures."""
+        device = device if device is not None else next(self.model.parameters()).device
+        before = self.captures
+        for shp in shapes:
+            b, _, h, w = shp
+            self(torch.zeros(*shp, dtype=dtype, device=device), torch.ones(b, h, w, dtype=torch.long, device=device))
+        return self.captures - before
+
+    def _poll_decoder_status(self, device):
+        from . import decoder_fused
+        decoder_fused.poll_status(device)
 
     @torch.no_grad()
     def __call__(self, pv, pm):
         if not self.enabled:
             return self._eager(pv, pm)
-        key = (tuple(pv.shape), tuple(pm.shape), pv.device)
-        if self._graph is None or key != self._key or self._fingerprint() != self._fingerprint_key:
+        self._calls += 1
+        if self._weights_changed():
+            self._drop_all()      # every graph holds constants derived from the old weights
+        key = self._key(pv, pm)
+        entry = self._entries.get(key)
+        if entry is None:
             try:
-                self._tensors = None  # parameters may have been replaced (e.g. .to(dtype)): re-enumerate
-                self._capture(pv, pm)
+                entry = self._capture(pv, pm)
             except Exception as e:  # capture unsupported by some library call: run eagerly, same kernels
                 if self.strict:
                     raise
@@ -89,10 +213,19 @@ class GraphedForward:
                 self.graphed = False
                 torch.cuda.synchronize()
                 return self._eager(pv, pm)
-        self._static_in[0].copy_(pv)
-        self._static_in[1].copy_(pm)
-        self._graph.replay()
-        return self._static_out
+            self._entries[key] = entry
+            while len(self._entries) > self.max_graphs:
+                self._entries.popitem(last=False)
+                self.evictions += 1
+        else:
+            self._entries.move_to_end(key)
+        entry.static_in[0].copy_(pv)
+        entry.static_in[1].copy_(pm)
+        entry.graph.replay()
+        entry.replays += 1
+        if self._calls % self.status_every == 0:
+            self._poll_decoder_status(pv.device)
+        return entry.static_out
 
 
 def configure_optimizers(model, lr=2e-6, lr_backbone=2e-7, lr_initialized=2e-4, weight_decay=1e-4,
@@ -199,16 +332,18 @@ class DataParallelTrainer:
         statuses = DeformableDetrHungarianMatcher.take_step_statuses()
         if not statuses:
             return None
-        # 0-dim float32, the shape torch's GradScaler hands to the fused optimizers as `found_inf`
-        flag = torch.cat([s.reshape(-1) for s in statuses]).ne(0).any().to(torch.float32).reshape(())
+        # the worst solver status code of the window (0 = assigned, 1 = NaN / -inf entries, 2 = infeasible) ...
+        worst = torch.cat([s.reshape(-1) for s in statuses]).max().to(torch.float32).reshape(())
         if self.world > 1:
-            # replicas must skip together (4 bytes) -- and RAISE together: the reduced flag is queued for raise_if_invalid on
-            # every rank, otherwise only the refusing rank would stop at its next step and the others would block in the
-            # next gradient all-reduce
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if flag.is_cuda:
-                DeformableDetrHungarianMatcher.defer_status(flag)
-        return flag
+            # replicas must skip together (4 bytes) -- and RAISE together, with the RIGHT message: the MAX of the status CODES
+            # is queued for raise_if_invalid on every rank (a 0 / 1 flag made every remote refusal read "invalid numeric
+            # entries"); otherwise only the refusing rank would stop at its next step and the others would block
+            # in the next gradient all-reduce
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            if worst.is_cuda:
+                DeformableDetrHungarianMatcher.defer_status(worst)
+        # ... and the 0 / 1 flag torch's GradScaler hands to the fused optimizers as `found_inf` (0-dim float32)
+        return worst.ne(0).to(torch.float32).reshape(())
 
     def training_step(self, batch):
         """One micro-batch; returns (loss, loss_dict, stepped).
@@ -303,18 +438,42 @@ def private_miopen_db():
 
 
 @torch.no_grad()
-def calculate_fps(model, batches, warmup=3):
-    """evaluate_egtr.py:26-36 with warm-up and synchronisation (the reference's loop has neither)."""
+def calculate_fps(model, batches, warmup=3, graphed=True, max_graphs=16, forward=None):
+    """evaluate_egtr.py:26-36 with warm-up and synchronisation (the reference's loop has neither).
+
+    ``graphed=True`` (GPU): every batch goes through a ``GraphedForward`` -- one captured HIP graph per distinct image
+    shape, LRU of ``max_graphs`` -- so a dataloader of differently sized images (evaluate_egtr.py:165-175: short side
+    ``--min_size``, long side <= ``--max_size``) runs at graph-replay speed once each shape has been seen.  When ``batches``
+    is a sequence its distinct shapes are captured BEFORE the clock starts (their two eager warm-up runs + capture are the
+    analogue of the reference's cudnn autotuning on a new shape); for a plain iterator the first occurrence of a shape is
+    inside the timed region.  ``forward``: an existing ``GraphedForward`` to reuse.  ``graphed=False``: eager launches."""
     import time
     model.eval()
+    fwd = forward
+    if fwd is None and graphed and torch.cuda.is_available():
+        fwd = GraphedForward(model, enabled=True, strict=False, max_graphs=max_graphs)
+
+    def run(batch):
+        pv, pm = batch["pixel_values"].cuda(non_blocking=True), batch["pixel_mask"].cuda(non_blocking=True)
+        if fwd is not None:
+            return fwd(pv, pm)
+        return model(pixel_values=pv, pixel_mask=pm, output_attentions=False, output_attention_states=True,
+                     output_hidden_states=True)
+
+    if fwd is not None and isinstance(batches, (list, tuple)):
+        seen = set()
+        for batch in batches:
+            key = (tuple(batch["pixel_values"].shape), tuple(batch["pixel_mask"].shape))
+            if key not in seen and len(seen) < fwd.max_graphs:
+                seen.add(key)
+                run(batch)
     n = 0
     t0 = None
     for i, batch in enumerate(batches):
         if i == warmup:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-        model(pixel_values=batch["pixel_values"].cuda(), pixel_mask=batch["pixel_mask"].cuda(),
-              output_attentions=False, output_attention_states=True, output_hidden_states=True)
+        run(batch)
         if i >= warmup:
             n += batch["pixel_values"].shape[0]
     torch.cuda.synchronize()

@@ -29,6 +29,12 @@ int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, 
                                    int num_heads, int channels, int num_levels, int num_query, int num_point,
                                    float* grad_value, float* grad_sampling_loc, float* grad_attn_weight, int variant);
 
+/* Fault injection for egtr_decoder_layer_f32 (tests/test_gpu_decoder_cluster.py): while `on` != 0, one wave of cluster 0
+ * skips its second barrier arrival in every launch, so that barrier times out (status bit 0; the waves that gave up
+ * NaN-poison the rows they hand out).  The barrier counters of the workspace are left short by one per launch: zero them
+ * (the host binding does when it reports the status) before the next healthy launch. */
+int egtr_test_decoder_drop_arrival(int on);
+
 #ifdef __cplusplus
 }
 #endif

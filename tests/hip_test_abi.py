@@ -12,6 +12,7 @@ _P, _I = ctypes.c_void_p, ctypes.c_int
 SIGNATURES = {
     "egtr_msda_forward_f32_variant": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I],
     "egtr_msda_backward_f32_variant": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I],
+    "egtr_test_decoder_drop_arrival": [_I],
 }
 
 
@@ -57,3 +58,8 @@ def msda_backward_variant(value, spatial_shapes, level_start_index, sampling_loc
                                           grad_attn.data_ptr(), variant)
     _lib.check(st, f"ms_deform_attn_backward(variant={variant})")
     return grad_value, grad_loc, grad_attn
+
+
+def decoder_drop_arrival(on):
+    """Fault injection for egtr_decoder_layer_f32: while on, one wave of cluster 0 skips its second barrier arrival."""
+    _lib.check(_handle().egtr_test_decoder_drop_arrival(1 if on else 0), "egtr_test_decoder_drop_arrival")

@@ -190,3 +190,56 @@ def test_a_refusing_device_falls_back_to_the_per_operation_decoder_and_says_so(m
     monkeypatch.setattr(decoder_fused, "_workspace", orig)
     for ws in decoder_fused._WORKSPACES.values():         # leave clean status words behind
         ws[1].zero_()
+
+
+def test_a_barrier_time_out_poisons_the_states_and_is_reported_late_without_a_sync():
+    """after the first verified run a time-out used to go unnoticed and hand out plausible-looking
+    decoder states.  Fault injection (include/egtr_hip_test.h ``egtr_test_decoder_drop_arrival``): one wave of cluster 0
+    skips an arrival, its cluster's second barrier times out.  Then (1) the waves that gave up NaN-poison what they hand
+    out -- the final states of the affected query rows are NaN, never plausible numbers; (2) the sticky status word is
+    picked up by the NEXT ``poll_status`` without a synchronisation in between, for eager workspaces and for the workspaces
+    baked into captured graphs alike; (3) after the report the workspace is whole again and results are right."""
+    import hip_test_abi
+    from egtr_amd import decoder_fused
+    from egtr_amd.runtime import GraphedForward
+    dev = torch.device(DEV)
+    model = _model(24, 2)
+    pv, pm = _inputs(1, 96, 128)
+    good = _run(model, pv, pm, fused=True, base=True).intermediate_hidden_states.clone()   # [B, Ld, N, 256]; first, verified run
+    assert decoder_fused.read_status(dev) == 0 and torch.isfinite(good).all()
+    decoder_fused.poll_status(dev, wait=True)            # drain a pending poll of earlier tests
+    try:
+        hip_test_abi.decoder_drop_arrival(True)
+        bad = _run(model, pv, pm, fused=True, base=True).intermediate_hidden_states
+        torch.cuda.synchronize()
+    finally:
+        hip_test_abi.decoder_drop_arrival(False)
+    assert torch.isnan(bad[0, 0, :8]).all(), "layer 0, cluster 0 (query rows 0-7) must be NaN-poisoned"
+    assert torch.equal(bad[0, 0, 8:], good[0, 0, 8:]), "layer 0: the other clusters passed their barriers, untouched"
+    assert torch.isnan(bad[0, 1]).all(), "layer 1 attends over the poisoned keys / values: every row is NaN"
+    assert decoder_fused.read_status(dev) & 1
+    assert decoder_fused.poll_status(dev) == 0           # queues the copy; nothing to report yet
+    with pytest.raises(decoder_fused.DecoderClusterError, match="timed out"):
+        decoder_fused.poll_status(dev, wait=True)        # the verdict of the previous poll
+    assert decoder_fused.read_status(dev) == 0           # reported once, workspace reset
+    again = _run(model, pv, pm, fused=True, base=True).intermediate_hidden_states
+    assert torch.equal(again, good)
+    # the same through a captured graph: its workspace is not an eager one, GraphedForward polls it every status_every calls
+    g = GraphedForward(model, enabled=True, strict=True, status_every=2)
+    ok = g(pv, pm).pred_rel.clone()                      # call 1: capture + replay
+    try:
+        hip_test_abi.decoder_drop_arrival(True)            # (a launch-time argument: replays carry what was captured --
+        g.invalidate()                                   #  so re-capture with the fault on)
+        r2 = g(pv, pm)                                   # call 2: capture with the fault; poll queued
+        torch.cuda.synchronize()
+        assert torch.isnan(r2.pred_rel).any()
+    finally:
+        hip_test_abi.decoder_drop_arrival(False)
+    g(pv, pm)                                            # call 3: no poll (status_every = 2)
+    with pytest.raises(decoder_fused.DecoderClusterError):
+        torch.cuda.synchronize()
+        g(pv, pm)                                        # call 4: reads the verdict of call 2's poll
+    g.invalidate()
+    fine = g(pv, pm).pred_rel
+    assert (fine - ok).abs().max() < 1e-5
+    assert decoder_fused.read_status(dev) == 0

@@ -771,10 +771,10 @@ def test_level_geometry_matches_reference_composition(mask_dtype, geom):
     vr = torch.stack([torch.stack([m[:, 0, :].sum(1).float() / m.shape[2], m[:, :, 0].sum(1).float() / m.shape[1]], -1)
                       for m in masks], 1)
     want_ref = DeformableDetrEncoder.get_reference_points(shapes, vr, "cpu")
-    mask, posf, vrf, ref = ops.level_geometry(pm.to(mask_dtype).to(DEV), shapes, level_embed.to(DEV), 128, 10000,
+    mask, posf, vrf, ref, _bits = ops.level_geometry(pm.to(mask_dtype).to(DEV), shapes, level_embed.to(DEV), 128, 10000,
                                               2 * math.pi)
     assert torch.equal(mask.cpu(), want_mask)
-    bits = mask._egtr_bits.cpu().long() & 0xFFFFFFFF
+    bits = _bits.cpu().long() & 0xFFFFFFFF
     S_ = want_mask.shape[1]
     unpacked = ((bits[:, torch.arange(S_) // 32] >> (torch.arange(S_) % 32)) & 1).bool()
     assert torch.equal(unpacked, want_mask)
@@ -883,10 +883,11 @@ def test_msda_fused_strided_inputs_and_keep_mask():
     for bi in range(B):
         words[bi].index_add_(0, idx // 32, keep[bi].long() << (idx % 32))
     bits = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).to(DEV)
-    km = d[5].clone()
-    km._egtr_bits = bits
-    out_b, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, km)
+    out_b, _ = k.ms_deform_attn_forward_fused(d[0], d[1], d[2], off, logits, d[4], False, d[5], keep_bits=bits)
     assert torch.equal(out_b, out)
+    # a mask that is not 0 / 1 (255 for "real") packs like its != 0 image
+    from egtr_amd.load_custom import pack_keep_bits
+    assert torch.equal(pack_keep_bits((d[5].to(torch.uint8) * 255), B, S), bits)
 
 
 @pytest.mark.parametrize("Lq", [50, 300, 1400])
@@ -975,14 +976,14 @@ def test_level_geometry_bf16_rounds_like_the_reference_composition(geom):
     g = torch.Generator().manual_seed(5)
     le16 = torch.randn(4, 256, generator=g).bfloat16().to(DEV)
     two_pi = 2 * 3.141592653589793
-    m0, sine, vr0, ref0 = ops.level_geometry(pm, shapes, torch.zeros(4, 256, device=DEV), 128, 10000, two_pi)
-    m1, pos16, vr1, ref1 = ops.level_geometry(pm, shapes, le16, 128, 10000, two_pi)
+    m0, sine, vr0, ref0, bits0 = ops.level_geometry(pm, shapes, torch.zeros(4, 256, device=DEV), 128, 10000, two_pi)
+    m1, pos16, vr1, ref1, bits1 = ops.level_geometry(pm, shapes, le16, 128, 10000, two_pi)
     assert pos16.dtype == torch.bfloat16 and pos16.shape == sine.shape
     sizes = [h * w for h, w in shapes]
     per_tok = torch.cat([le16[l].view(1, 1, -1).expand(B, n, -1) for l, n in enumerate(sizes)], 1)
     assert torch.equal(pos16, sine.bfloat16() + per_tok)
     assert torch.equal(m0, m1) and torch.equal(vr0, vr1) and torch.equal(ref0, ref1)
-    assert torch.equal(m0._egtr_bits, m1._egtr_bits)
+    assert torch.equal(bits0, bits1)
 
 
 def test_input_proj_groupnorm_flatten_bf16_matches_torch():

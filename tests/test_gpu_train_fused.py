@@ -351,7 +351,7 @@ def test_level_geometry_train_function_gradient_of_level_embed():
     le = torch.randn(4, 256, generator=g).to(DEV).requires_grad_(True)
     mask, pos, vr, ref = ops.level_geometry_train(pm, shapes, le, 128, 10000, 2 * 3.141592653589793)
     with torch.no_grad():
-        m0, p0, v0, r0 = ops.level_geometry(pm, shapes, le.detach(), 128, 10000, 2 * 3.141592653589793)
+        m0, p0, v0, r0, _bits = ops.level_geometry(pm, shapes, le.detach(), 128, 10000, 2 * 3.141592653589793)
     assert torch.equal(mask, m0) and torch.equal(pos.detach(), p0) and torch.equal(vr, v0) and torch.equal(ref, r0)
     assert pos.requires_grad and not vr.requires_grad and not ref.requires_grad
     gy = torch.randn(pos.shape, generator=g).to(DEV)

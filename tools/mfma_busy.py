@@ -69,11 +69,16 @@ def main():
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     raw = from_text(a.from_text) if a.from_text else from_dbs(a.paths)
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kernel_source_hash import source_hash
     kernels = {}
     for k, d in raw.items():
         if "SQ_VALU_MFMA_BUSY_CYCLES" in d and d.get("SQ_BUSY_CU_CYCLES"):
             kernels[k] = {"mfma_busy": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * d["SQ_BUSY_CU_CYCLES"]), 4),
-                          "counters": {c: v for c, v in d.items() if c != "launches"}, "launches": d.get("launches")}
+                          "counters": {c: v for c, v in d.items() if c != "launches"}, "launches": d.get("launches"),
+                          "source_sha256": source_hash(k)}   # bench.py quotes the entry only while this still matches
     out = {"definition": "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES), per-launch averages",
            "source": a.from_text or " ".join(a.paths), "kernels": kernels}
     json.dump(out, open(a.out, "w"), indent=1)

@@ -67,8 +67,14 @@ def main():
     for k, (n, v) in sorted(avg.items()):
         print(f"  {k:40s} n={n:6d} avg={v:16.1f}")
     g = lambda k: avg[k][1] if k in avg else None  # noqa: E731
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kernel_source_hash import files_for, source_hash
     res = {"kernel": a.name, "launches_averaged": {k: n for k, (n, _) in avg.items()},
-           "algorithmic_bytes_per_launch": a.alg_bytes or None}
+           "algorithmic_bytes_per_launch": a.alg_bytes or None,
+           # provenance: bench.py quotes this file only while the kernel's sources still hash to this value
+           "source_files": files_for(a.name), "source_sha256": source_hash(a.name)}
     if g("FETCH_SIZE") is not None:
         res["fetch_size_kb_raw"] = g("FETCH_SIZE")
         res["fetch_bytes_corrected"] = int(g("FETCH_SIZE") * 1024 * 2)

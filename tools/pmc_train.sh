@@ -19,6 +19,7 @@ b = json.load(open(f"gpurun_out/{tag}_msda_bwd_q64_pmc.json"))
 def add(k):
     return (a.get(k) or 0) + (b.get(k) or 0) if (a.get(k) is not None and b.get(k) is not None) else None
 out = {"kernel": "msda_bwd_q64_f32<no atomics> + msda_bwd_value_tile_f32",
+       "source_files": a.get("source_files"), "source_sha256": a.get("source_sha256"),
        "launch": "encoder layer backward, B = 4, Lq = S = 12537 (sum of the two kernels' per-launch averages)",
        "hbm_bytes_per_launch": add("hbm_bytes_per_launch"), "fetch_bytes_corrected": add("fetch_bytes_corrected"), "write_bytes": add("write_bytes"),
        "l1_gather_bytes": add("l1_gather_bytes"), "l2_hit": {"value_tile": a.get("l2_hit"), "q64": b.get("l2_hit")},
