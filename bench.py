@@ -311,6 +311,35 @@ def time_lib_entries(names, run, forwards=3):
     return out
 
 
+def time_l1_gather_ceiling(iters=2000, reps=3):
+    """The vector-L1 gather ceiling of THIS GPU in THIS run (GB/s): csrc/probe_l1.hip through the test ABI
+    (include/egtr_hip_test.h) -- 512 workgroups, every 8-lane group of a wave reading a different L1-resident 128-byte line
+    with 16 B per lane, i.e. the MSDA gather's access shape with every miss removed; HIP events on the launch stream."""
+    import ctypes
+    from egtr_amd import _lib
+    from egtr_amd.load_custom import _stream
+    h = _lib.lib()
+    h.egtr_test_l1_gather_buffer_bytes.argtypes, h.egtr_test_l1_gather_buffer_bytes.restype = [ctypes.c_int], ctypes.c_longlong
+    h.egtr_test_l1_gather_bandwidth.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_void_p]
+    h.egtr_test_l1_gather_bandwidth.restype = ctypes.c_int
+    blocks = 512
+    buf = torch.zeros(h.egtr_test_l1_gather_buffer_bytes(blocks) // 4, dtype=torch.float32, device="cuda")
+    out = torch.zeros(256, dtype=torch.float32, device="cuda")
+    moved = ctypes.c_longlong(0)
+    best = None
+    for _ in range(reps + 1):     # first launch: warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(h.egtr_test_l1_gather_bandwidth(_stream(), buf.data_ptr(), out.data_ptr(), iters, blocks,
+                                                   ctypes.byref(moved)), "egtr_test_l1_gather_bandwidth")
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    return moved.value / (best * 1e-3) / 1e9
+
+
 def msda_kernel_name(fused):
     from egtr_amd import ops
     name = getattr(ops, "MSDA_ENCODER_KERNEL", "msda_fwd_q64_f32")
@@ -686,12 +715,13 @@ def mixed_shape_set(n_shapes=12, seed=0, min_size=600, max_size=1000):
     return shapes
 
 
-def mixed_shapes_leg(model, dev, fixed_value, n_shapes=12, stream=96, seed=0):
+def mixed_shapes_leg(model, dev, fixed_value, n_shapes=12, stream=96, seed=0, tune_first_pass=True):
     """The reference's FPS loop on a stream of differently sized images (evaluate_egtr.py:26-36 over a dataloader), bs = 1:
     every distinct shape is captured once into its own HIP graph (egtr_amd.runtime.GraphedForward, LRU of 16) in an untimed
     first pass, then `stream` images (shapes drawn with a fixed seed, inputs resident in HBM) are timed as one region.
-    MIOpen find mode and TunableOp tuning are OFF for the new shapes (an evaluation run meets a new shape without a tuning
-    pause; the 600x1000 shape keeps what the headline run tuned), so smaller images are not faster for free."""
+    ``tune_first_pass``: MIOpen find mode / TunableOp tuning stay as the headline run set them during the (untimed) first
+    pass -- a new shape gets its convolution solvers and GEMM solutions picked once, like cudnn.benchmark does in the
+    reference's loop -- and are switched off for the timed stream; False: off for the first pass too (heuristic picks)."""
     import numpy as np
     from egtr_amd.runtime import GraphedForward
     shapes = mixed_shape_set(n_shapes, seed)
@@ -708,7 +738,17 @@ def mixed_shapes_leg(model, dev, fixed_value, n_shapes=12, stream=96, seed=0):
         tun.tuning_enable(False)
     except Exception:
         tun = None
-    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.benchmark = bench_find and tune_first_pass
+    budget = None
+    if tun is not None and tune_first_pass:
+        tun.tuning_enable(tuning_was)
+        try:    # a third of TunableOp's default budget per candidate (30 ms / 100 iterations): eleven new image shapes x ~25
+            # GEMM shapes each are tuned in this pass, and the default bench run has to stay within minutes
+            budget = (tun.get_max_tuning_duration(), tun.get_max_tuning_iterations())
+            tun.set_max_tuning_duration(10)
+            tun.set_max_tuning_iterations(20)
+        except Exception:
+            budget = None
     try:
         fwd = GraphedForward(model, enabled=True, strict=True, max_graphs=16)
         torch.cuda.synchronize()
@@ -718,6 +758,12 @@ def mixed_shapes_leg(model, dev, fixed_value, n_shapes=12, stream=96, seed=0):
                 fwd(pv, pm)
         torch.cuda.synchronize()
         first_pass_s = time.perf_counter() - t0
+        torch.backends.cudnn.benchmark = False
+        if tun is not None:
+            tun.tuning_enable(False)
+            if budget is not None:
+                tun.set_max_tuning_duration(budget[0])
+                tun.set_max_tuning_iterations(budget[1])
         captures = fwd.captures
         with torch.no_grad():
             for i in order[:8]:
@@ -740,7 +786,8 @@ def mixed_shapes_leg(model, dev, fixed_value, n_shapes=12, stream=96, seed=0):
             "graphs_captured": captures, "recaptures_in_timed_region": fwd.captures - captures,
             "first_pass_s": round(first_pass_s, 3), "mean_pixels_vs_600x1000": round(pixels / (H_IMG * W_IMG), 4),
             "vs_fixed_shape": round(value / fixed_value, 4) if fixed_value else None,
-            "tuning": "MIOpen find / TunableOp tuning off for the new shapes"}
+            "tuning": ("first pass: MIOpen find / TunableOp as in the headline run; timed stream: off" if tune_first_pass
+                       else "MIOpen find / TunableOp tuning off for the new shapes")}
 
 
 def eager_leg(model, pv, pm, iters=30):
@@ -936,6 +983,9 @@ def main():
                     help="--mode infer on one GPU: after the timed region also run a short bs = 4 train loop and the bf16 "
                          "stress forward and append them to the JSON line as `train_step` / `stress_bf16` (0 = skip)")
     ap.add_argument("--extra-steps", type=int, default=8, help="timed steps of each extra workload")
+    ap.add_argument("--mixed-tune", type=int, default=1,
+                    help="mixed_shapes leg: 1 = the untimed first pass keeps MIOpen find / TunableOp tuning on for the new "
+                         "shapes (what the reference's cudnn autotuning does on a new shape), 0 = heuristic picks")
     ap.add_argument("--strict-fast-path", type=int, default=1,
                     help="1: raise when a call falls off a HIP fast path (egtr_amd.ops.FALLBACKS); 0: count and warn")
     ap.add_argument("--launch-check", action="store_true",
@@ -1015,6 +1065,7 @@ def main():
     rel_us, rel_flops = time_rel_head_kernel(rel_args)
     rel_tflops = rel_flops / (rel_us * 1e-6) / 1e12
     msda_kernel = msda_kernel_name(probe.fused)
+    l1_ceiling_gbs = time_l1_gather_ceiling()
     # HBM bytes / cache behaviour per launch come from separate rocprofv3 --pmc passes over THIS command
     # (tools/pmc_passes.sh + tools/msda_pmc.py -> profiles/r02_msda_pmc.json); used only if they were collected for
     # the kernel that was just timed, otherwise null.
@@ -1037,8 +1088,14 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(msda_us, 3),
                      "traffic_source": pmc_src,
                      "l2_hit": pmc.get("l2_hit"), "l1_gather_bytes": pmc.get("l1_gather_bytes"),
-                     "frac_of_l1_gather_ceiling": (round(pmc["l1_gather_bytes"] / (msda_us * 1e-6) / 30.5e12, 3)
-                                                   if pmc.get("l1_gather_bytes") else None)},
+                     # the vector-L1 return path is what bounds this kernel: its ceiling is MEASURED in this
+                     # run (csrc/probe_l1.hip); the gathered bytes per launch are 4 corners x 16 samples x 128 B per (query,
+                     # head) by construction, the counter figure (incl. the prologue's reads) comes from the PMC file
+                     "l1_gather_ceiling_gbs": round(l1_ceiling_gbs, 1),
+                     "l1_gather_bytes_by_construction": int(msda_args[0].shape[0] * msda_args[3].shape[1] * 8 * 64 * 128),
+                     "frac_of_l1_gather_ceiling": round(
+                         (pmc.get("l1_gather_bytes") or msda_args[0].shape[0] * msda_args[3].shape[1] * 8 * 64 * 128)
+                         / (msda_us * 1e-6) / 1e9 / l1_ceiling_gbs, 3)},
         "rccl_ranks": args.rccl_ranks, "rank_ms_per_step": spread,
     }
     from egtr_amd import ops as _ops
@@ -1118,7 +1175,7 @@ def main():
         # the FPS loop as the reference runs it (evaluate_egtr.py:26-36): differently sized images, and the eager number
         try:
             result["eager"] = eager_leg(model, pv, pm)
-            result["mixed_shapes"] = mixed_shapes_leg(model, dev, value)
+            result["mixed_shapes"] = mixed_shapes_leg(model, dev, value, tune_first_pass=bool(args.mixed_tune))
         except Exception as e:  # the headline stays valid; the failure is visible
             result["mixed_shapes"] = {"error": f"{type(e).__name__}: {e}"}
     result["config"]["fast_path"] = {"strict": bool(_ops.STRICT_FAST_PATH), "fallbacks": dict(_ops.FALLBACKS)}

@@ -265,15 +265,21 @@ class DataParallelTrainer:
     once per optimizer step -- micro-steps before the accumulation boundary run under ``no_sync`` -- then
     clip-grad-norm 0.1 and AdamW.  ``num_boxes`` stays per-rank (model/egtr.py:976-980)."""
 
-    def __init__(self, model, optimizer=None, accumulate=2, clip=0.1, bucket_cap_mb=25, graph=False, force_ddp=False):
+    def __init__(self, model, optimizer=None, accumulate=2, clip=0.1, bucket_cap_mb=25, graph=False, force_ddp=False,
+                 grad_compression=None):
         """graph=True (single process, GPU, fixed image size): the static-shape part of the step -- backbone, encoder,
         decoder, detection + relation heads, forward AND backward -- is captured once into two HIP graphs
         (torch.cuda.make_graphed_callables over ``model.forward_tensors``) and replayed; the Hungarian matcher and the
         loss stay eager in between (they have data-dependent shapes).  Measured SLOWER than the eager step: the
         untraced eager step is GPU-bound with the host 25-40 ms ahead of the device, so a replay has no launch gaps to close,
         and it adds copies out of the graphs' static buffers (forward 15.1 vs 14.2 ms, backward 35.4 vs 29.9 ms).  Opt-in."""
+        """``grad_compression``: None (fp32 all-reduce, the reference's DDP), "bf16" or "fp16" -- DDP's communication hook that
+        casts every gradient bucket to 16 bits for the all-reduce and back (torch's ``bf16_compress_hook`` / ``fp16_compress_hook``):
+        half the bytes per link for the bandwidth-bound stress configuration (SURVEY 2b; 165 MB fp32 per step otherwise).  The
+        averaged gradient is then rounded to 8 / 11 significant bits before clipping -- opt-in, not the parity configuration."""
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.raw = model
+        self.grad_compression = None
         self._graph_wanted = bool(graph) and self.world == 1
         self._graphed = None
         self._graph_key = None
@@ -284,6 +290,13 @@ class DataParallelTrainer:
             self.model = torch.nn.parallel.DistributedDataParallel(
                 model, device_ids=ids, find_unused_parameters=False, bucket_cap_mb=bucket_cap_mb,
                 gradient_as_bucket_view=True)
+            if grad_compression is not None:
+                from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+                hooks = {"bf16": default_hooks.bf16_compress_hook, "fp16": default_hooks.fp16_compress_hook}
+                if grad_compression not in hooks:
+                    raise ValueError(f"grad_compression must be None, 'bf16' or 'fp16', got {grad_compression!r}")
+                self.model.register_comm_hook(state=None, hook=hooks[grad_compression])
+                self.grad_compression = grad_compression
         else:
             self.model = model
         self.opt = optimizer if optimizer is not None else configure_optimizers(model)

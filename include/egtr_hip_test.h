@@ -35,6 +35,15 @@ int egtr_msda_backward_f32_variant(egtr_stream_t stream, const float* grad_out, 
  * (the host binding does when it reports the status) before the next healthy launch. */
 int egtr_test_decoder_drop_arrival(int on);
 
+/* Measurement probe (csrc/probe_l1.hip): `blocks` workgroups of 256 threads, each gathering `iters` x 16 x 16 bytes per lane
+ * from its own L1-resident 12 KiB region, every 8-lane group a different 128-byte line -- the MSDA gather's access shape
+ * without misses.  `buf`: egtr_test_l1_gather_buffer_bytes(blocks) bytes of zeros; `out`: >= 256 floats (never written on a
+ * zero buffer); *bytes_moved: bytes returned to registers by the launch.  bench.py times it next to the MSDA kernel
+ * (roofline.l1_gather_ceiling_gbs). */
+long long egtr_test_l1_gather_buffer_bytes(int blocks);
+int egtr_test_l1_gather_bandwidth(egtr_stream_t stream, const void* buf, float* out, int iters, int blocks,
+                                  long long* bytes_moved);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,8 @@ SIGNATURES = {
     "egtr_msda_forward_f32_variant": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I],
     "egtr_msda_backward_f32_variant": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I],
     "egtr_test_decoder_drop_arrival": [_I],
+    "egtr_test_l1_gather_buffer_bytes": [_I],
+    "egtr_test_l1_gather_bandwidth": [_P, _P, _P, _I, _I, _P],
 }
 
 
@@ -20,7 +22,7 @@ def _handle():
     h = _lib.lib()
     for name, argtypes in SIGNATURES.items():
         fn = getattr(h, name)
-        fn.argtypes, fn.restype = argtypes, ctypes.c_int
+        fn.argtypes, fn.restype = argtypes, (ctypes.c_longlong if name.endswith("_bytes") else ctypes.c_int)
     return h
 
 

@@ -241,3 +241,52 @@ def test_bench_world_gt_one_line_schema_has_the_ddp_leg():
     assert out["allreduce_ms"] == 2.5 and "roofline" not in out
     # 165 MB over 8 ranks in 2.5 ms: bus bandwidth 2 (n - 1) / n x bytes / time
     assert abs(out["allreduce_busbw_GBs"] - 2 * 7 / 8 * 165e6 / 2.5e-3 / 1e9) < 0.01
+
+
+def _compression_worker(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from egtr_amd.runtime import DataParallelTrainer, init_distributed
+    res = {}
+    for mode in (None, "bf16"):
+        model = _build()
+        if mode is None:
+            assert init_distributed() == world
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        tr = DataParallelTrainer(model, optimizer=opt, accumulate=1, clip=1e9, grad_compression=mode)
+        assert tr.grad_compression == mode
+        captured = {}
+        orig_step = opt.step
+
+        def step(*a, _m=model, _c=captured, _o=orig_step, **k):
+            _c.update({n: p.grad.clone() for n, p in _m.named_parameters() if p.grad is not None})
+            return _o(*a, **k)
+
+        opt.step = step
+        tr.training_step(_batch(100 + rank))
+        res[str(mode)] = {n: g for n, g in captured.items()}
+    a, b = res["None"], res["bf16"]
+    worst = 0.0
+    for n in a:
+        scale = float(a[n].abs().max()) + 1e-30
+        worst = max(worst, float((a[n] - b[n]).abs().max()) / scale)
+    differs = any(not torch.equal(a[n], b[n]) for n in a)
+    with open(f"{out_path}.{rank}", "w") as f:
+        json.dump({"worst_rel": worst, "differs": differs}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bf16_gradient_compression_hook_two_ranks(tmp_path):
+    """SURVEY 2b (optional, for the bandwidth-bound stress configuration): DataParallelTrainer(grad_compression="bf16")
+    all-reduces 16-bit buckets.  The synchronised gradient equals the fp32 all-reduce's up to bf16 rounding of the buckets
+    (8 significant bits: <= 2^-8 of each tensor's largest entry after averaging two ranks) -- and is NOT identical, i.e. the
+    hook really ran."""
+    world, port = 2, _free_port()
+    out = str(tmp_path / "cmp")
+    mp.spawn(_compression_worker, args=(world, port, out), nprocs=world, join=True)
+    r = [json.load(open(f"{out}.{i}")) for i in range(world)]
+    for k in range(world):
+        assert r[k]["differs"] and r[k]["worst_rel"] < 2 ** -7, r[k]

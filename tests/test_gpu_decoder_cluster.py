@@ -215,7 +215,8 @@ def test_a_barrier_time_out_poisons_the_states_and_is_reported_late_without_a_sy
     finally:
         hip_test_abi.decoder_drop_arrival(False)
     assert torch.isnan(bad[0, 0, :8]).all(), "layer 0, cluster 0 (query rows 0-7) must be NaN-poisoned"
-    assert torch.equal(bad[0, 0, 8:], good[0, 0, 8:]), "layer 0: the other clusters passed their barriers, untouched"
+    # (close, not equal: the MIOpen convolutions in front of the encoder are not bit-reproducible run to run)
+    assert (bad[0, 0, 8:] - good[0, 0, 8:]).abs().max() < 1e-4, "layer 0: the other clusters passed their barriers, untouched"
     assert torch.isnan(bad[0, 1]).all(), "layer 1 attends over the poisoned keys / values: every row is NaN"
     assert decoder_fused.read_status(dev) & 1
     assert decoder_fused.poll_status(dev) == 0           # queues the copy; nothing to report yet
@@ -223,7 +224,7 @@ def test_a_barrier_time_out_poisons_the_states_and_is_reported_late_without_a_sy
         decoder_fused.poll_status(dev, wait=True)        # the verdict of the previous poll
     assert decoder_fused.read_status(dev) == 0           # reported once, workspace reset
     again = _run(model, pv, pm, fused=True, base=True).intermediate_hidden_states
-    assert torch.equal(again, good)
+    assert (again - good).abs().max() < 1e-4
     # the same through a captured graph: its workspace is not an eager one, GraphedForward polls it every status_every calls
     g = GraphedForward(model, enabled=True, strict=True, status_every=2)
     ok = g(pv, pm).pred_rel.clone()                      # call 1: capture + replay
