@@ -24,9 +24,6 @@
 #include <hip/hip_bf16.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <stdio.h>
-
-#include <algorithm>
 
 #include "common.h"
 #include "msda_common.h"
@@ -61,52 +58,18 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
     int Lq, int S, int L, int P, int nblk, const float* __restrict__ ref, float* __restrict__ attn_out, int ld_off,
     int ld_logit, const unsigned char* __restrict__ keep, const unsigned* __restrict__ keep_bits,
-    const float* __restrict__ vbias, int band) {
+    const float* __restrict__ vbias) {
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * kWaveEntries];
   __shared__ unsigned s_bits[FUSED ? kMaxBitWords : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int blk = xcd_remap(blockIdx.x, nblk);
-  int q = SPLIT ? blk : blk * kWaves + wave;
-  if (!SPLIT && band) {
-    // BAND mapping (encoder-shaped calls: the queries are the pixels of the levels, back to back): XCD x = blockIdx % 8 serves
-    // the x-th horizontal eighth of EVERY level -- the samples of its queries then fall into one band of the value tensor at
-    // all four levels (its L2's working set), and every XCD gets the same mix of fine- and coarse-level queries.  `nblk` =
-    // workgroups per band (the host sizes it for the largest band); position p of the band -> (image, level, pixel).
-    LevelGeom Gb;
-    load_geom(shapes, lsi, L, Gb);
-    const int x = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int r00 = Gb.H0 * x / 8, r01 = Gb.H0 * (x + 1) / 8, r10 = Gb.H1 * x / 8, r11 = Gb.H1 * (x + 1) / 8;
-    const int r20 = Gb.H2 * x / 8, r21 = Gb.H2 * (x + 1) / 8, r30 = Gb.H3 * x / 8, r31 = Gb.H3 * (x + 1) / 8;
-    const int c0 = (r01 - r00) * Gb.W0, c1 = L > 1 ? (r11 - r10) * Gb.W1 : 0, c2 = L > 2 ? (r21 - r20) * Gb.W2 : 0,
-              c3 = L > 3 ? (r31 - r30) * Gb.W3 : 0;
-    const int per_img = c0 + c1 + c2 + c3;
-    if ((long long)idx * kWaves >= (long long)per_img * (nq_total / Lq)) return;   // workgroup-uniform: beyond this band
-    int p = idx * kWaves + wave;
-    const int img = per_img > 0 ? p / per_img : 0;
-    p -= img * per_img;
-    int ql;
-    if (p < c0) ql = Gb.s0 + r00 * Gb.W0 + p;
-    else if (p < c0 + c1) ql = Gb.s1 + r10 * Gb.W1 + (p - c0);
-    else if (p < c0 + c1 + c2) ql = Gb.s2 + r20 * Gb.W2 + (p - c0 - c1);
-    else ql = Gb.s3 + r30 * Gb.W3 + (p - c0 - c1 - c2);
-    q = (per_img > 0 && img * Lq < nq_total) ? img * Lq + ql : nq_total;   // beyond the band: nothing to do
-    blk = q / kWaves;   // (only used for the image of the staged mask bits below)
-  }
+  const int blk = xcd_remap(blockIdx.x, nblk);
+  const int q = SPLIT ? blk : blk * kWaves + wave;
   const int nwords = (S + 31) >> 5;
   bool bits_in_lds = false;
   if (FUSED && keep_bits != nullptr && nwords <= kMaxBitWords) {
     // padding mask of the image of this workgroup's first query, one bit per token (1.5 KB at 600x1000), in LDS
-    // (band mode: the image of the workgroup's FIRST position; a workgroup whose four positions straddle two images reads the
-    // second image's bits from global memory)
-    int first_q = SPLIT ? blk : blk * kWaves;
-    if (!SPLIT && band) {
-      __shared__ int s_first;
-      if (threadIdx.x == 0) s_first = q;
-      __syncthreads();
-      first_q = s_first;
-    }
-    const int b0 = min(first_q, nq_total - 1) / Lq;
+    const int b0 = min(SPLIT ? blk : blk * kWaves, nq_total - 1) / Lq;
     for (int i = threadIdx.x; i < nwords; i += kWaves * 64) s_bits[i] = keep_bits[(size_t)b0 * nwords + i];
     __syncthreads();
     bits_in_lds = q < nq_total && q / Lq == b0;
@@ -264,216 +227,6 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     acc.w += vb.w * wsum;
   }
   reinterpret_cast<float4*>(out + (size_t)q * 256)[lane] = acc;
-}
-
-// ------------------------------------------------------------------------------- forward, persistent workgroups
-// The same wave-per-query arithmetic (identical operation order: results are bit-identical to msda_fwd_q64_f32) for long
-// query lists (encoder: 12 537 queries per image), restructured around what the 4-query workgroups paid per query:
-//   * a workgroup is NW waves and owns a CONTIGUOUS run of queries (nq / nwg of them: neighbours in a level row, so the
-//     corners one query pulled into the CU's L1 serve the next); its waves take queries from an LDS counter, so a CU is
-//     busy until its run is empty -- the 4-query workgroups left every CU with 12 or 13 workgroups (+6 % for the slowest)
-//     and a partly empty last round;
-//   * kernel arguments, level geometry and the padding-mask bits of the image (1.5 KB + a workgroup barrier) are set up
-//     ONCE per workgroup instead of once per four queries;
-//   * the raw offsets / logits / reference points of a wave's NEXT query are requested before the 64 gathers of the current
-//     one are issued (they are older in the in-order vmcnt queue, i.e. they have landed when the gathers have): the
-//     load -> geometry -> records chain at the head of every query no longer starts from a cold load.
-template <bool FUSED, bool BOX, int NW>
-__global__ __launch_bounds__(NW * 64) void msda_fwd_pers_f32(
-    const float* __restrict__ value, const int64_t* __restrict__ shapes, const int64_t* __restrict__ lsi,
-    const float* __restrict__ loc, const float* __restrict__ attn, float* __restrict__ out, int nq_total,
-    int Lq, int S, int L, int P, int nwg, const float* __restrict__ ref, float* __restrict__ attn_out, int ld_off,
-    int ld_logit, const unsigned char* __restrict__ keep, const unsigned* __restrict__ keep_bits,
-    const float* __restrict__ vbias, unsigned* __restrict__ ctr /* [8 chunk heads, exit tickets], zero between launches */) {
-  __shared__ __attribute__((aligned(16))) int4 s_off[NW * kWaveEntries];
-  __shared__ __attribute__((aligned(16))) float4 s_w[NW * kWaveEntries];
-  __shared__ unsigned s_bits[FUSED ? kMaxBitWords : 1];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // Work distribution: the query list is cut into 8 contiguous chunks, chunk x served first by the workgroups of XCD x (their
-  // L2 then holds one stripe of the value tensor); every WAVE draws its next query from its chunk's head word (one returning
-  // device-scope atomic per query, requested a whole query ahead) and, when the chunk is empty, from the next chunk -- so no
-  // wave idles while any query is left, whatever the regions cost.  The last wave to leave resets the words.
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const int home = (int)(xcc & 7u);
-  auto chunk_lo = [&](int c) { return (int)((long long)nq_total * c / 8); };
-  int chunk = home, steps = 0;   // steps: chunks visited so far (8 = everything is drained)
-  int q_end = chunk_lo(chunk + 1);
-  auto draw = [&]() -> int {      // lane 0's value is the one that counts
-    return chunk_lo(chunk) + (int)atomicAdd(&ctr[chunk], 1u);
-  };
-  const int nwords = (S + 31) >> 5;
-  const int b0 = chunk_lo(home) / Lq;
-  bool bits_staged = false;
-  if (FUSED && keep_bits != nullptr && nwords <= kMaxBitWords) {
-    for (int i = threadIdx.x; i < nwords; i += NW * 64) s_bits[i] = keep_bits[(size_t)b0 * nwords + i];
-    bits_staged = true;
-  }
-  __syncthreads();
-  LevelGeom G;
-  load_geom(shapes, lsi, L, G);
-  const int head_s = lane >> 3, s0 = (lane & 7) * 2;
-  const int lvl_s = s0 / P;   // both samples of the lane lie in one level (P is even)
-  int4* my_off = s_off + wave * kWaveEntries;
-  float4* my_w = s_w + wave * kWaveEntries;
-  const int head = lane >> 3;
-  const int4* ro = my_off + head * kHeadStride;
-  const float4* rw = my_w + head * kHeadStride;
-
-  // next valid query of this wave, moving on to the following chunk(s) when the current one is exhausted; -1 = all drained
-  auto advance = [&](int cand) -> int {
-    while (cand >= q_end) {
-      if (++steps >= 8) return -1;
-      chunk = (chunk + 1) & 7;
-      q_end = chunk_lo(chunk + 1);
-      // look before drawing: an exhausted chunk costs a load, not an atomic on a word every leaving wave would hammer
-      const unsigned seen = __hip_atomic_load(&ctr[chunk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((int)seen >= q_end - chunk_lo(chunk)) {
-        cand = q_end;
-        continue;
-      }
-      int d = 0;
-      if (lane == 0) d = draw();
-      cand = __builtin_amdgcn_readfirstlane(d);
-    }
-    return cand;
-  };
-  int q;
-  {
-    int d = 0;
-    if (lane == 0) d = draw();
-    q = advance(__builtin_amdgcn_readfirstlane(d));
-  }
-  float4 lc = make_float4(0.f, 0.f, 0.f, 0.f), rf = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 aw = make_float2(0.f, 0.f);
-  auto request = [&](int qq, float4& lc_, float2& aw_, float4& rf_) {
-    lc_ = reinterpret_cast<const float4*>(loc + (size_t)qq * (FUSED ? ld_off : 256))[lane];
-    aw_ = reinterpret_cast<const float2*>(attn + (size_t)qq * (FUSED ? ld_logit : 128))[lane];
-    if (FUSED) {
-      if (BOX) {
-        rf_ = *reinterpret_cast<const float4*>(ref + ((size_t)qq * L + lvl_s) * 4);
-      } else {
-        const float2 r = *reinterpret_cast<const float2*>(ref + ((size_t)qq * L + lvl_s) * 2);
-        rf_ = make_float4(r.x, r.y, 0.f, 0.f);
-      }
-    }
-  };
-  if (q >= 0) request(q, lc, aw, rf);
-  while (q >= 0) {
-    // the next query of this wave: requested now, read after the records are written
-    int qn_lane = 0;
-    if (lane == 0) qn_lane = draw();
-    const int b = q / Lq;
-    const char* vbase = reinterpret_cast<const char*>(value) + (size_t)b * S * (256 * 4);
-    const bool bits_in_lds = bits_staged && b == b0;
-    if (FUSED) {
-      if (BOX) {
-        const float fp = (float)P;  // same operation order as the reference: ((offset / P) * wh) * 0.5
-        lc = make_float4(rf.x + lc.x / fp * rf.z * 0.5f, rf.y + lc.y / fp * rf.w * 0.5f, rf.x + lc.z / fp * rf.z * 0.5f,
-                         rf.y + lc.w / fp * rf.w * 0.5f);
-      } else {
-        const float fw = (float)SEL_W(G, lvl_s), fh = (float)SEL_H(G, lvl_s);
-        lc = make_float4(rf.x + lc.x / fw, rf.y + lc.y / fh, rf.x + lc.z / fw, rf.y + lc.w / fh);
-      }
-      float m = fmaxf(aw.x, aw.y);
-      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
-      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
-      m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, false)));
-      const float e0 = expf(aw.x - m), e1 = expf(aw.y - m);
-      float sum = e0 + e1;
-      sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
-      sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
-      sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
-      aw = make_float2(e0 / sum, e1 / sum);
-      if (attn_out != nullptr) reinterpret_cast<float2*>(attn_out + (size_t)q * 128)[lane] = aw;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int s = s0 + j;
-      const SampleGeom g = sample_geom<1024, 128>(j ? lc.z : lc.x, j ? lc.w : lc.y, SEL_H(G, lvl_s), SEL_W(G, lvl_s),
-                                                  SEL_S(G, lvl_s), head_s);
-      const float a = j ? aw.y : aw.x;
-      bool k0 = g.ok[0], k1 = g.ok[1], k2 = g.ok[2], k3 = g.ok[3];
-      if (FUSED && keep_bits != nullptr) {
-        const int p0 = g.off[0] >> 10, p1 = g.off[1] >> 10, p2 = g.off[2] >> 10, p3 = g.off[3] >> 10;
-        if (bits_in_lds) {
-          k0 = k0 && ((s_bits[p0 >> 5] >> (p0 & 31)) & 1u);
-          k1 = k1 && ((s_bits[p1 >> 5] >> (p1 & 31)) & 1u);
-          k2 = k2 && ((s_bits[p2 >> 5] >> (p2 & 31)) & 1u);
-          k3 = k3 && ((s_bits[p3 >> 5] >> (p3 & 31)) & 1u);
-        } else {
-          const unsigned* kb = keep_bits + (size_t)b * nwords;
-          k0 = k0 && ((kb[p0 >> 5] >> (p0 & 31)) & 1u);
-          k1 = k1 && ((kb[p1 >> 5] >> (p1 & 31)) & 1u);
-          k2 = k2 && ((kb[p2 >> 5] >> (p2 & 31)) & 1u);
-          k3 = k3 && ((kb[p3 >> 5] >> (p3 & 31)) & 1u);
-        }
-      } else if (FUSED && keep != nullptr) {
-        const unsigned char* kp = keep + (size_t)b * S;
-        k0 = k0 && kp[g.off[0] >> 10];
-        k1 = k1 && kp[g.off[1] >> 10];
-        k2 = k2 && kp[g.off[2] >> 10];
-        k3 = k3 && kp[g.off[3] >> 10];
-      }
-      my_off[head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
-      my_w[head_s * kHeadStride + s] = make_float4(k0 ? g.w[0] * a : 0.f, k1 ? g.w[1] * a : 0.f,
-                                                   k2 ? g.w[2] * a : 0.f, k3 ? g.w[3] * a : 0.f);
-    }
-    // LDS ops of one wave execute in order; the fences only stop the compiler from reordering across lanes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // the next query's operands: requested BEFORE this query's gathers, so they are ahead of them in the return queue
-    const int qn = advance(__builtin_amdgcn_readfirstlane(qn_lane));
-    float4 lc_n = lc, rf_n = rf;
-    float2 aw_n = aw;
-    if (qn >= 0) request(qn, lc_n, aw_n, rf_n);
-
-    const char* vlane = vbase + (lane & 7) * 16;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
-      const int4 o = ro[s];
-      const float4 w = rw[s];
-      const float4 v0 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.x);
-      const float4 v1 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.y);
-      const float4 v2 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.z);
-      const float4 v3 = *reinterpret_cast<const float4*>(vlane + (unsigned)o.w);
-      acc.x += w.x * v0.x + w.y * v1.x + w.z * v2.x + w.w * v3.x;
-      acc.y += w.x * v0.y + w.y * v1.y + w.z * v2.y + w.w * v3.y;
-      acc.z += w.x * v0.z + w.y * v1.z + w.z * v2.z + w.w * v3.z;
-      acc.w += w.x * v0.w + w.y * v1.w + w.z * v2.w + w.w * v3.w;
-    }
-    if (vbias != nullptr) {
-      float wsum = 0.f;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float4 w = rw[s];
-        wsum += (w.x + w.y) + (w.z + w.w);
-      }
-      const float4 vb = reinterpret_cast<const float4*>(vbias)[lane];
-      acc.x += vb.x * wsum;
-      acc.y += vb.y * wsum;
-      acc.z += vb.z * wsum;
-      acc.w += vb.w * wsum;
-    }
-    reinterpret_cast<float4*>(out + (size_t)q * 256)[lane] = acc;
-    // (the records of this wave are rewritten at the top of the next round: its own LDS reads above have returned -- their
-    // results fed the loads -- and LDS operations of one wave execute in order)
-    q = qn;
-    lc = lc_n;
-    aw = aw_n;
-    rf = rf_n;
-  }
-  // exit ticket, one per workgroup: the last workgroup of the launch leaves the words zero for the next launch on this slot
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(&ctr[8], 1u);
-    if (t == (unsigned)nwg - 1u) {
-#pragma unroll
-      for (int i = 0; i < 9; ++i) ctr[i] = 0u;
-    }
-  }
 }
 
 // bf16 storage, fp32 accumulate; M = 8, D = 32, L*P = 16: a head row is 64 bytes = 4 lanes x 16 B, so one wave
@@ -943,82 +696,6 @@ __global__ void msda_bwd_generic(const T* __restrict__ grad_out, const T* __rest
 
 bool fast_shape(int M, int D, int L, int P) { return M == 8 && D == 32 && L >= 1 && L <= 4 && L * P == 16; }
 
-// Persistent forward (msda_fwd_pers_f32): waves per workgroup and workgroups per CU.  EGTR_MSDA_PERS = "0" turns it off,
-// "<waves>x<workgroups per CU>" (waves 8 or 16) overrides the default -- a measurement switch (tools/msda_bench.py), read once.
-struct PersCfg {
-  int nw, per_cu;
-};
-PersCfg pers_cfg() {
-  static PersCfg cfg = [] {
-    PersCfg c{16, 2};
-    if (const char* e = getenv("EGTR_MSDA_PERS")) {
-      int a = 0, b = 0;
-      if (sscanf(e, "%dx%d", &a, &b) == 2 && (a == 8 || a == 16) && b >= 1 && b <= 8) c = PersCfg{a, b};
-      else if (e[0] == '0') c = PersCfg{0, 0};
-    }
-    return c;
-  }();
-  return cfg;
-}
-int cu_count() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    return v;
-  }();
-  return n;
-}
-constexpr long long kPersMinQueries = 4096;   // below this the 4-query workgroups (or the split form) fill the chip better
-// chunk heads + exit tickets of the persistent forward: 16 words per launch slot, a ring of 64 slots so that launches that
-// may overlap (different streams) do not share words; zero at load, every launch leaves its slot zero again.
-__device__ unsigned g_pers_ctr[64 * 16];
-unsigned* pers_counters() {
-  static unsigned* base = [] {
-    void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pers_ctr)) != hipSuccess) p = nullptr;
-    return static_cast<unsigned*>(p);
-  }();
-  static int next = 0;
-  if (base == nullptr) return nullptr;
-  unsigned* slot = base + 16 * next;
-  next = (next + 1) & 63;
-  return slot;
-}
-
-// EXPERIMENT (EGTR_MSDA_BAND=1): band mapping of encoder-shaped calls (msda_fwd_q64_f32, `band`).  The level shapes live in
-// device memory, so the grid is sized from an upper bound of a band's size: S / 8 + 1024 positions (an eighth of every level,
-// rounded up by at most one row per level; surplus workgroups leave at once).
-int band_mode(int num_query, int spatial_size, int batch, int* grid) {
-  static const int on = [] {
-    const char* e = getenv("EGTR_MSDA_BAND");
-    return (e != nullptr && e[0] == '1') ? 1 : 0;
-  }();
-  if (!on || num_query != spatial_size) return 0;
-  const long long per_band = ((long long)spatial_size / 8 + 1024) * batch;
-  *grid = (int)(8 * ((per_band + kWaves - 1) / kWaves));
-  return 1;
-}
-
-template <bool FUSED, bool BOX>
-bool launch_pers(hipStream_t st, long long nq, const float* value, const int64_t* shapes, const int64_t* lsi, const float* loc,
-                 const float* attn, float* out, int Lq, int S, int L, int P, const float* ref, float* attn_out, int ld_off,
-                 int ld_logit, const unsigned char* keep, const unsigned* keep_bits, const float* vbias) {
-  const PersCfg c = pers_cfg();
-  if (c.nw == 0 || nq < kPersMinQueries) return false;
-  unsigned* ctr = pers_counters();
-  if (ctr == nullptr) return false;
-  int nwg = cu_count() * c.per_cu;
-  nwg = (int)std::min<long long>(nwg, std::max<long long>(1, nq / c.nw));
-  if (c.nw == 8)
-    hipLaunchKernelGGL((msda_fwd_pers_f32<FUSED, BOX, 8>), dim3(nwg), dim3(8 * 64), 0, st, value, shapes, lsi, loc, attn, out,
-                       (int)nq, Lq, S, L, P, nwg, ref, attn_out, ld_off, ld_logit, keep, keep_bits, vbias, ctr);
-  else
-    hipLaunchKernelGGL((msda_fwd_pers_f32<FUSED, BOX, 16>), dim3(nwg), dim3(16 * 64), 0, st, value, shapes, lsi, loc, attn, out,
-                       (int)nq, Lq, S, L, P, nwg, ref, attn_out, ld_off, ld_logit, keep, keep_bits, vbias, ctr);
-  return true;
-}
-
 }  // namespace
 
 // variant: 0 = automatic (wave-per-query when M = 8, D = 32, L*P = 16, else generic), 1 = wave-per-query,
@@ -1044,18 +721,13 @@ extern "C" int egtr_msda_forward_f32_variant(egtr_stream_t stream, const float* 
     hipLaunchKernelGGL((msda_fwd_q64_f32<false, true>), dim3((int)nq), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
                        num_levels, num_point, (int)nq, (const float*)nullptr, (float*)nullptr, 256, 128,
-                       (const unsigned char*)nullptr, (const unsigned*)nullptr, (const float*)nullptr, 0);
-  } else if (variant == 1 && launch_pers<false, false>(st, nq, value, spatial_shapes, level_start_index, sampling_loc, attn_weight,
-                                                       out, num_query, spatial_size, num_levels, num_point, nullptr,
-                                                       nullptr, 256, 128, nullptr, nullptr, nullptr)) {
-    // long query lists: persistent workgroups (same arithmetic, bit-identical results)
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
   } else if (variant == 1) {
-    int nblk = (int)((nq + kWaves - 1) / kWaves), grid = nblk;
-    const int band = band_mode(num_query, spatial_size, batch, &grid);
-    hipLaunchKernelGGL(msda_fwd_q64_f32<false>, dim3(grid), dim3(kWaves * 64), 0, st, value, spatial_shapes,
+    const int nblk = (int)((nq + kWaves - 1) / kWaves);
+    hipLaunchKernelGGL(msda_fwd_q64_f32<false>, dim3(nblk), dim3(kWaves * 64), 0, st, value, spatial_shapes,
                        level_start_index, sampling_loc, attn_weight, out, (int)nq, num_query, spatial_size,
                        num_levels, num_point, nblk, (const float*)nullptr, (float*)nullptr, 256, 128,
-                       (const unsigned char*)nullptr, (const unsigned*)nullptr, (const float*)nullptr, band);
+                       (const unsigned char*)nullptr, (const unsigned*)nullptr, (const float*)nullptr);
   } else {
     const long long n = nq * num_heads * channels;
     const int threads = 256;
@@ -1088,19 +760,14 @@ int launch_fused_f32(egtr_stream_t stream, const float* value, const int64_t* sp
     hipLaunchKernelGGL((msda_fwd_q64_f32<true, true, BOX>), dim3((int)nq), dim3(kWaves * 64), 0,
                        static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index, sampling_offsets,
                        attn_logits, out, (int)nq, num_query, spatial_size, num_levels, num_point, (int)nq,
-                       reference_points, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias, 0);
+                       reference_points, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias);
     return egtr_check_launch();
   }
-  if (launch_pers<true, BOX>(static_cast<hipStream_t>(stream), nq, value, spatial_shapes, level_start_index, sampling_offsets,
-                             attn_logits, out, num_query, spatial_size, num_levels, num_point, reference_points,
-                             attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias))
-    return egtr_check_launch();
-  int nblk = (int)((nq + kWaves - 1) / kWaves), grid = nblk;
-  const int band = band_mode(num_query, spatial_size, batch, &grid);
-  hipLaunchKernelGGL((msda_fwd_q64_f32<true, false, BOX>), dim3(grid), dim3(kWaves * 64), 0,
+  const int nblk = (int)((nq + kWaves - 1) / kWaves);
+  hipLaunchKernelGGL((msda_fwd_q64_f32<true, false, BOX>), dim3(nblk), dim3(kWaves * 64), 0,
                      static_cast<hipStream_t>(stream), value, spatial_shapes, level_start_index, sampling_offsets,
                      attn_logits, out, (int)nq, num_query, spatial_size, num_levels, num_point, nblk,
-                     reference_points, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias, band);
+                     reference_points, attn_weight_out, ld_offsets, ld_logits, keep_mask, keep_bits, value_bias);
   return egtr_check_launch();
 }
 }  // namespace
