@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("EGTR_HIP_LIBRARY") or os.path.join(_HERE, "libegtr_hi
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
-ABI_VERSION = 3   # include/egtr_hip.h: EGTR_ABI_VERSION of the header these signatures were written against
+ABI_VERSION = 4   # include/egtr_hip.h: EGTR_ABI_VERSION of the header these signatures were written against
 
 # name -> argtypes (restype is always int status unless listed in _RESTYPES)
 SIGNATURES = {
@@ -36,6 +36,7 @@ SIGNATURES = {
     "egtr_msda_forward_fused_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     "egtr_self_attn_forward_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "egtr_self_attn_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
+    "egtr_self_attn_backward_acc_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "egtr_linear_f32": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I],
     "egtr_linear_grouped_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I],
     "egtr_linear_grouped_ln_f32": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -70,6 +71,7 @@ SIGNATURES = {
     "egtr_msda_geometry_forward_f32": [_P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, _I, _P, _P, _P, ctypes.c_longlong, _I, _I, _I],
     "egtr_msda_geometry_backward_f32": [_P, _P, _P, _P, _P, ctypes.c_longlong, _P, _I, _P, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _P, ctypes.c_longlong, _I, _I, _I],
     "egtr_linear_backward_f32": [_P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _I, _I, _I],
+    "egtr_linear_backward_acc_f32": [_P, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _I, _I, _I, _P, _P],
     "egtr_weighted_column_sum_f32": [_P, _P, _P, _P, _P, _I, _I],
     "egtr_column_sum_f32": [_P, _P, _P, _P, _P, _P, _I, _I],
     "egtr_column_sum_workspace_floats": [_I, _I],

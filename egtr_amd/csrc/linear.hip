@@ -316,6 +316,8 @@ struct SkinnyBwdArgs {
   float* gb;        // nullable (needs gw tiles: computed by the k0 == 0 column of gw workgroups)
   int M, N, K, x_tiles;
   float alpha;
+  const float* add1;   // nullable, [M, K]: added to gx in the epilogue (gradient branches that meet at x: no add launches)
+  const float* add2;   // nullable, [M, K]
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -405,9 +407,19 @@ __global__ __launch_bounds__(64 * kBwdWaves) void linear_skinny_bwd_f32(SkinnyBw
       o[e] = s_red[((0 * 4 + e) * 64 + ln) * 4 + r] + s_red[((1 * 4 + e) * 64 + ln) * 4 + r] +
              s_red[((2 * 4 + e) * 64 + ln) * 4 + r] + s_red[((3 * 4 + e) * 64 + ln) * 4 + r];
     const int orow = m0 + (ln >> 4) * 4 + r;
-    if (orow < M)
-      *reinterpret_cast<float4*>(P.gx + (size_t)orow * K + k0 + 4 * (ln & 15)) =
-          make_float4(o[0] * P.alpha, o[1] * P.alpha, o[2] * P.alpha, o[3] * P.alpha);
+    if (orow < M) {
+      const size_t at = (size_t)orow * K + k0 + 4 * (ln & 15);
+      float4 r = make_float4(o[0] * P.alpha, o[1] * P.alpha, o[2] * P.alpha, o[3] * P.alpha);
+      if (P.add1 != nullptr) {
+        const float4 a = *reinterpret_cast<const float4*>(P.add1 + at);
+        r = make_float4(r.x + a.x, r.y + a.y, r.z + a.z, r.w + a.w);
+      }
+      if (P.add2 != nullptr) {
+        const float4 a = *reinterpret_cast<const float4*>(P.add2 + at);
+        r = make_float4(r.x + a.x, r.y + a.y, r.z + a.z, r.w + a.w);
+      }
+      *reinterpret_cast<float4*>(P.gx + at) = r;
+    }
     return;
   }
   if (GW32) {
@@ -639,19 +651,22 @@ extern "C" int egtr_linear_f32(egtr_stream_t stream, const float* x, const float
   return egtr_check_launch();
 }
 
-extern "C" int egtr_linear_backward_f32(egtr_stream_t stream, const float* grad_y, const float* relu_output,
-                                        const float* x, const float* w, float alpha, float* grad_x, float* grad_w,
-                                        float* grad_bias, int M, int K, int N) {
+extern "C" int egtr_linear_backward_acc_f32(egtr_stream_t stream, const float* grad_y, const float* relu_output,
+                                            const float* x, const float* w, float alpha, float* grad_x, float* grad_w,
+                                            float* grad_bias, int M, int K, int N, const float* grad_x_add1,
+                                            const float* grad_x_add2) {
   if (!grad_y || !x || !w || M <= 0 || K <= 0 || N <= 0) return EGTR_E_ARG;
   if (!grad_x && !grad_w && !grad_bias) return EGTR_E_ARG;
+  if ((grad_x_add1 || grad_x_add2) && !grad_x) return EGTR_E_ARG;
   if (K % 64 != 0 || N % 64 != 0) return EGTR_E_UNSUPPORTED;
   const uintptr_t al = reinterpret_cast<uintptr_t>(grad_y) | reinterpret_cast<uintptr_t>(relu_output) |
                        reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
-                       reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(grad_w);
+                       reinterpret_cast<uintptr_t>(grad_x) | reinterpret_cast<uintptr_t>(grad_w) |
+                       reinterpret_cast<uintptr_t>(grad_x_add1) | reinterpret_cast<uintptr_t>(grad_x_add2);
   if (al & 15) return EGTR_E_UNSUPPORTED;
   SkinnyBwdArgs P;
   P.g = grad_y; P.y = relu_output; P.x = x; P.w = w; P.gx = grad_x; P.gw = grad_w; P.gb = grad_bias;
-  P.M = M; P.N = N; P.K = K; P.alpha = alpha;
+  P.M = M; P.N = N; P.K = K; P.alpha = alpha; P.add1 = grad_x_add1; P.add2 = grad_x_add2;
   P.x_tiles = grad_x ? ((M + 15) / 16) * (K / 64) : 0;
   // gw tiles: 16 x 16 while that is at most two workgroups per CU, 32 x 32 (four accumulators per wave) for the wide layers
   const bool gw32 = (N / 16) * (K / 16) > 512;
@@ -661,4 +676,11 @@ extern "C" int egtr_linear_backward_f32(egtr_stream_t stream, const float* grad_
   else
     launch_skinny_bwd<false>(static_cast<hipStream_t>(stream), P, P.x_tiles + w_tiles, gw32);
   return egtr_check_launch();
+}
+
+extern "C" int egtr_linear_backward_f32(egtr_stream_t stream, const float* grad_y, const float* relu_output,
+                                        const float* x, const float* w, float alpha, float* grad_x, float* grad_w,
+                                        float* grad_bias, int M, int K, int N) {
+  return egtr_linear_backward_acc_f32(stream, grad_y, relu_output, x, w, alpha, grad_x, grad_w, grad_bias, M, K, N, nullptr,
+                                      nullptr);
 }

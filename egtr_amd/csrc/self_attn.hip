@@ -172,7 +172,8 @@ __global__ __launch_bounds__(64 * kBwdSplit) void self_attn_bwd_f32(const float*
                                                         const float* __restrict__ lse,
                                                         const float* __restrict__ grad_out,
                                                         float* __restrict__ grad_q, float* __restrict__ grad_k,
-                                                        float* __restrict__ grad_v, int B, int N, int M) {
+                                                        float* __restrict__ grad_v, int B, int N, int M,
+                                                        const float* __restrict__ add_q, const float* __restrict__ add_k) {
   __shared__ f32x4 s_acc[kBwdSplit][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int ntile = (N + 15) >> 4;
@@ -234,7 +235,13 @@ __global__ __launch_bounds__(64 * kBwdSplit) void self_attn_bwd_f32(const float*
         dq0 += s_acc[w][0][lane];
         dq1 += s_acc[w][1][lane];
       }
-      float* p = grad_q + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
+      const size_t at = ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
+      float* p = grad_q + at;
+      if (add_q != nullptr) {   // gradient that reaches q by another route (the retained maps): added here, not in a launch
+        const float4 a0 = *reinterpret_cast<const float4*>(add_q + at), a1 = *reinterpret_cast<const float4*>(add_q + at + 16);
+        dq0 += f32x4{a0.x, a0.y, a0.z, a0.w};
+        dq1 += f32x4{a1.x, a1.y, a1.z, a1.w};
+      }
       *reinterpret_cast<float4*>(p) = make_float4(dq0[0], dq0[1], dq0[2], dq0[3]);
       *reinterpret_cast<float4*>(p + 16) = make_float4(dq1[0], dq1[1], dq1[2], dq1[3]);
     }
@@ -297,8 +304,14 @@ __global__ __launch_bounds__(64 * kBwdSplit) void self_attn_bwd_f32(const float*
         dv0 += s_acc[w][2][lane];
         dv1 += s_acc[w][3][lane];
       }
-      float* pk = grad_k + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
-      float* pv = grad_v + ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
+      const size_t at = ((size_t)b * N + r0 + c) * MD + h * 32 + g * 4;
+      float* pk = grad_k + at;
+      float* pv = grad_v + at;
+      if (add_k != nullptr) {
+        const float4 a0 = *reinterpret_cast<const float4*>(add_k + at), a1 = *reinterpret_cast<const float4*>(add_k + at + 16);
+        dk0 += f32x4{a0.x, a0.y, a0.z, a0.w};
+        dk1 += f32x4{a1.x, a1.y, a1.z, a1.w};
+      }
       *reinterpret_cast<float4*>(pk) = make_float4(dk0[0], dk0[1], dk0[2], dk0[3]);
       *reinterpret_cast<float4*>(pk + 16) = make_float4(dk1[0], dk1[1], dk1[2], dk1[3]);
       *reinterpret_cast<float4*>(pv) = make_float4(dv0[0], dv0[1], dv0[2], dv0[3]);
@@ -328,16 +341,25 @@ extern "C" int egtr_self_attn_forward_f32(egtr_stream_t stream, const float* q, 
   return egtr_check_launch();
 }
 
-extern "C" int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
-                                           const float* out, const float* lse, const float* grad_out, int batch,
-                                           int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
-                                           float* grad_v) {
+extern "C" int egtr_self_attn_backward_acc_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
+                                               const float* out, const float* lse, const float* grad_out, int batch,
+                                               int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
+                                               float* grad_v, const float* grad_q_add, const float* grad_k_add) {
   if (!q || !k || !v || !out || !lse || !grad_out || !grad_q || !grad_k || !grad_v) return EGTR_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(grad_q_add) | reinterpret_cast<uintptr_t>(grad_k_add)) & 15) return EGTR_E_UNSUPPORTED;
   if (batch <= 0 || num_query <= 0 || num_heads <= 0) return EGTR_E_ARG;
   if (head_dim != 32) return EGTR_E_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntile = (num_query + 15) / 16;
   hipLaunchKernelGGL(self_attn_bwd_f32, dim3(batch * num_heads * ntile, 2), dim3(64 * kBwdSplit), 0, st, q, k, v, out, lse, grad_out,
-                     grad_q, grad_k, grad_v, batch, num_query, num_heads);
+                     grad_q, grad_k, grad_v, batch, num_query, num_heads, grad_q_add, grad_k_add);
   return egtr_check_launch();
+}
+
+extern "C" int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
+                                           const float* out, const float* lse, const float* grad_out, int batch,
+                                           int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
+                                           float* grad_v) {
+  return egtr_self_attn_backward_acc_f32(stream, q, k, v, out, lse, grad_out, batch, num_query, num_heads, head_dim, grad_q,
+                                         grad_k, grad_v, nullptr, nullptr);
 }

@@ -783,6 +783,22 @@ class DeformableDetrDecoderLayer(nn.Module):
                                           level_start_index, encoder_hidden_states, encoder_attention_mask,
                                           output_attention_states, spatial_shapes_list, hidden_with_pos, return_with_pos,
                                           precomputed_value, out, mask_bits)
+        if (incoming is None and torch.is_tensor(precomputed_value) and position_embeddings is not None
+                and ops.decoder_layer_train_supported(self, hidden_states, position_embeddings, reference_points,
+                                                      precomputed_value, attention_mask, output_attentions)):
+            # training: the whole layer as ONE autograd node (ops.DecoderLayerTrainFunction) -- the kernels of the composition
+            # below, with the gradient-accumulation adds at the meeting points of its branches folded into their epilogues
+            y3, qs, ks = ops.decoder_layer_train(self, hidden_states, position_embeddings, reference_points,
+                                                 precomputed_value, spatial_shapes, level_start_index, masks=dropout_masks)
+            outputs = (y3,)
+            if output_attention_states:   # the retained maps [B, M, N, D] (dd:1179-1185) as transposed views
+                b_, n_, _ = qs.shape
+                sa_ = self.self_attn
+                outputs += (qs.view(b_, n_, sa_.num_heads, sa_.head_dim).transpose(1, 2),
+                            ks.view(b_, n_, sa_.num_heads, sa_.head_dim).transpose(1, 2))
+            if return_with_pos:
+                outputs += (None,)
+            return outputs
         if incoming is not None:
             hidden_states = incoming.materialize()
         residual = hidden_states

@@ -852,6 +852,210 @@ def encoder_layer_train(layer, x, attention_mask, pos, ref, spatial_shapes, leve
         layer.fc2.weight, layer.fc2.bias, layer.final_layer_norm.weight, layer.final_layer_norm.bias)
 
 
+# ---- decoder layer as ONE autograd node (training) ---------------------------------------------------------------------------
+DECODER_TRAIN_FUSED = True   # module attribute, not an environment switch: tests patch it for the switch-off twin
+
+
+def _skinny_fwd(x2, w, b, alpha=1.0, relu=False):
+    """act((x W^T + b) * alpha) for object-query rows (egtr_linear_f32), plain tensors, no autograd."""
+    lib = _lib.lib()
+    M, K = x2.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+    _lib.check(lib.egtr_linear_f32(_stream(), x2.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None,
+                                   y.data_ptr(), M, K, N, float(alpha), 1 if relu else 0), "egtr_linear_f32")
+    return y
+
+
+def _skinny_bwd(g, x2, w, alpha=1.0, relu_out=None, want_gb=True, add1=None, add2=None, out=None):
+    """(grad_x [+ add1 + add2], grad_w, grad_b) of ``_skinny_fwd`` in one launch (egtr_linear_backward_acc_f32)."""
+    lib = _lib.lib()
+    M, N = g.shape
+    K = w.shape[1]
+    gx = out if out is not None else torch.empty(M, K, dtype=torch.float32, device=g.device)
+    gw = torch.empty(N, K, dtype=torch.float32, device=g.device)
+    gb = torch.empty(N, dtype=torch.float32, device=g.device) if want_gb else None
+    _lib.check(lib.egtr_linear_backward_acc_f32(
+        _stream(), g.data_ptr(), relu_out.data_ptr() if relu_out is not None else None, x2.data_ptr(), w.data_ptr(),
+        float(alpha), gx.data_ptr(), gw.data_ptr(), gb.data_ptr() if gb is not None else None, M, K, N,
+        add1.data_ptr() if add1 is not None else None, add2.data_ptr() if add2 is not None else None),
+        "egtr_linear_backward_acc_f32")
+    return gx, gw, gb
+
+
+class DecoderLayerTrainFunction(Function):
+    """One Deformable-DETR decoder layer in TRAINING as a single autograd node (reference:
+    DeformableDetrDecoderLayer.forward, model/deformable_detr.py:1390-1489; self-attention with the retained scaled-q / k maps
+    :1107-1262; cross-attention :1026-1104 on the value projection handed in by ``DecoderValueProjTrainFunction``):
+
+        q = s (x + pos) Wq^T + s bq,  k = (x + pos) Wk^T + bk,  v = x Wv^T + bv;   a = out_proj(softmax(q k^T) v)
+        y1 = LN1(x + drop(a));   [off | logits] of (y1 + pos);   c = output_proj(MSDA(value, loc, softmax(logits)))
+        y2 = LN2(y1 + drop(c));  y3 = LN3(y2 + drop(fc2(relu(fc1(y2)))))            returns (y3, q, k)
+
+    The per-operation composition ran the same kernels as ~14 autograd nodes per layer; what autograd added around them -- per
+    layer and step, on [B N, 256] tensors of 0.8 MB -- were the gradient-accumulation adds where branches meet (x feeds q / k, v
+    and the residual; y1 feeds the offset / logit projections and the residual; y2 feeds fc1 and the residual; q and k also feed
+    the relation head through the retained maps), ``x + pos`` / ``y1 + pos`` and their backward, and contiguous copies of views:
+    ~18 launches of ~4 us each per layer (profiles/r06_train_ops_by_shape_before.txt: 55 add + 24 add_ + 14 copy_ + 12 mul
+    launches of that shape per step).  Here every meeting point is the epilogue of the product that arrives last
+    (egtr_linear_backward_acc_f32: up to two addends on grad_x; egtr_self_attn_backward_acc_f32: the maps' gradients on grad_q /
+    grad_k); three ATen adds per layer remain (x + pos, y1 + pos, the two pos gradients).  Arithmetic: exactly the kernels of the
+    composition (exact-f32 MFMA), so values agree to rounding of the changed summation order at the meeting points."""
+
+    @staticmethod
+    def forward(ctx, x, pos, ref, value, shapes, lsi, p_drop, masks, eps3, scaling, wq, bq, wk, bk, wv, bv, wo, bo, ln1w, ln1b,
+                wso, bso, waw, baw, wop, bop, ln2w, ln2b, w1, b1, w2, b2, ln3w, ln3b):
+        lib = _lib.lib()
+        B, N, D = x.shape
+        M = B * N
+        dev = x.device
+        x2 = _rows256(x.detach())
+        pos2 = _rows256(pos.detach().expand(B, N, D)) if tuple(pos.shape) != (B, N, D) else _rows256(pos.detach())
+        heads = 8
+        d = [t.detach() for t in (wq, bq, wk, bk, wv, bv, wo, bo, ln1w, ln1b, wso, bso, waw, baw, wop, bop, ln2w, ln2b, w1, b1,
+                                  w2, b2, ln3w, ln3b)]
+        (wq_, bq_, wk_, bk_, wv_, bv_, wo_, bo_, g1, be1, wso_, bso_, waw_, baw_, wop_, bop_, g2, be2, w1_, b1_, w2_, b2_, g3,
+         be3) = [t if t.is_contiguous() else t.contiguous() for t in d]
+        p = float(p_drop)
+        scale = 1.0 / (1.0 - p) if p > 0.0 else 1.0
+        if masks is not None:
+            m1, m2, m3 = masks[0], masks[1], masks[2]
+        elif p > 0.0:
+            mm = torch.empty(3, M, D, dtype=torch.uint8, device=dev).bernoulli_(1.0 - p)
+            m1, m2, m3 = mm[0], mm[1], mm[2]
+        else:
+            m1 = m2 = m3 = None
+        e1, e2, e3 = (float(v) for v in eps3)
+        # ---- self-attention
+        xp = x2 + pos2
+        q = _skinny_fwd(xp, wq_, bq_, alpha=scaling)
+        k = _skinny_fwd(xp, wk_, bk_)
+        v = _skinny_fwd(x2, wv_, bv_)
+        sa = torch.empty(M, D, dtype=torch.float32, device=dev)
+        lse = torch.empty(B, heads, N, dtype=torch.float32, device=dev)
+        _lib.check(lib.egtr_self_attn_forward_f32(_stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), B, N, heads, D // heads,
+                                                  sa.data_ptr(), None, None, lse.data_ptr()), "egtr_self_attn_forward_f32")
+        a = _skinny_fwd(sa, wo_, bo_)
+        y1 = dropout_add_layernorm(a, x2, m1, scale, g1, be1, e1)
+        # ---- cross-attention (MSDA over the encoder's value projection)
+        y1p = y1 + pos2
+        off = _skinny_fwd(y1p, wso_, bso_)
+        lg = _skinny_fwd(y1p, waw_, baw_)
+        L = shapes.shape[0]
+        P_ = wso_.shape[0] // (heads * L * 2)
+        refc = _chk(ref.detach().contiguous(), "reference_points", torch.float32)
+        shp = _chk(shapes.contiguous(), "spatial_shapes", torch.int64)
+        loc = torch.empty(B, N, heads, L, P_, 2, dtype=torch.float32, device=dev)
+        attn = torch.empty(B, N, heads, L, P_, dtype=torch.float32, device=dev)
+        _lib.check(lib.egtr_msda_geometry_forward_f32(_stream(), off.data_ptr(), off.stride(0), lg.data_ptr(), lg.stride(0),
+                                                      refc.data_ptr(), refc.shape[-1], shp.data_ptr(), loc.data_ptr(),
+                                                      attn.data_ptr(), M, heads, L, P_), "egtr_msda_geometry_forward_f32")
+        val = value.detach()
+        S = val.shape[1]
+        val4 = (val if val.is_contiguous() else val.contiguous()).view(B, S, heads, D // heads)
+        ca = _msda().ms_deform_attn_forward(val4, shp, lsi, loc, attn, 64).view(M, D)
+        c = _skinny_fwd(ca, wop_, bop_)
+        y2 = dropout_add_layernorm(c, y1, m2, scale, g2, be2, e2)
+        # ---- feed-forward block
+        h = _skinny_fwd(y2, w1_, b1_, relu=True)
+        f = _skinny_fwd(h, w2_, b2_)
+        y3 = dropout_add_layernorm(f, y2, m3, scale, g3, be3, e3)
+        ctx.save_for_backward(x2, xp, q, k, v, sa, lse, a, m1, y1, y1p, off, refc, shp, lsi, loc, attn, val4, ca, c, m2, y2, h,
+                              f, m3, wq_, wk_, wv_, wo_, g1, wso_, waw_, wop_, g2, w1_, w2_, g3)
+        ctx.dims = (B, N, D, heads, L, P_, scale, e1, e2, e3, float(scaling))
+        ctx.pos_shape = tuple(pos.shape)
+        ctx.value_shape = tuple(value.shape)
+        ctx.ref_needs_grad = bool(ref.requires_grad)
+        return y3.view(B, N, D), q.view(B, N, D), k.view(B, N, D)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_y3, g_q_ext, g_k_ext):
+        lib = _lib.lib()
+        (x2, xp, q, k, v, sa, lse, a, m1, y1, y1p, off, refc, shp, lsi, loc, attn, val4, ca, c, m2, y2, h, f, m3, wq_, wk_, wv_,
+         wo_, g1, wso_, waw_, wop_, g2, w1_, w2_, g3) = ctx.saved_tensors
+        B, N, D, heads, L, P_, scale, e1, e2, e3, scaling = ctx.dims
+        M = B * N
+        dev = x2.device
+        g3y = _rows256(g_y3)
+        # ---- feed-forward block: LN3 <- fc2 <- ReLU <- fc1, the residual's gradient joins in fc1's data gradient
+        gs3, gf, gbb3 = dropout_add_layernorm_backward(f, y2, m3, scale, g3, e3, g3y)
+        g_h, d_w2, _ = _skinny_bwd(gf, h, w2_, want_gb=False)
+        g_y2, d_w1, d_b1 = _skinny_bwd(g_h, y2, w1_, relu_out=h, add1=gs3)
+        # ---- cross-attention
+        gs2, gc, gbb2 = dropout_add_layernorm_backward(c, y1, m2, scale, g2, e2, g_y2)
+        g_ca, d_wop, _ = _skinny_bwd(gc, ca, wop_, want_gb=False)
+        g_value, g_loc, g_attn = _msda().ms_deform_attn_backward(val4, shp, lsi, loc, attn, g_ca.view(B, N, D), 64)
+        g_off = torch.empty(M, off.shape[1], dtype=torch.float32, device=dev)
+        g_lg = torch.empty(M, attn.numel() // M, dtype=torch.float32, device=dev)
+        g_ref = torch.empty_like(refc) if ctx.ref_needs_grad else None
+        _lib.check(lib.egtr_msda_geometry_backward_f32(
+            _stream(), g_loc.data_ptr(), g_attn.data_ptr(), attn.data_ptr(), off.data_ptr(), off.stride(0), refc.data_ptr(),
+            refc.shape[-1], shp.data_ptr(), g_off.data_ptr(), g_off.shape[1], g_lg.data_ptr(), g_lg.shape[1],
+            g_ref.data_ptr() if g_ref is not None else None, M, heads, L, P_), "egtr_msda_geometry_backward_f32")
+        t_so, d_wso, d_bso = _skinny_bwd(g_off, y1p, wso_)
+        g_y1p, d_waw, d_baw = _skinny_bwd(g_lg, y1p, waw_, add1=t_so, out=t_so)          # d loss / d (y1 + pos)
+        g_y1 = gs2.add_(g_y1p)
+        # ---- self-attention
+        gs1, ga, gbb1 = dropout_add_layernorm_backward(a, x2, m1, scale, g1, e1, g_y1)
+        g_sa, d_wo, _ = _skinny_bwd(ga, sa, wo_, want_gb=False)
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        gqe = _rows256(g_q_ext) if g_q_ext is not None else None
+        gke = _rows256(g_k_ext) if g_k_ext is not None else None
+        _lib.check(lib.egtr_self_attn_backward_acc_f32(
+            _stream(), q.data_ptr(), k.data_ptr(), v.data_ptr(), sa.data_ptr(), lse.data_ptr(), g_sa.data_ptr(), B, N, heads,
+            D // heads, gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), gqe.data_ptr() if gqe is not None else None,
+            gke.data_ptr() if gke is not None else None), "egtr_self_attn_backward_acc_f32")
+        u_q, d_wq, d_bq = _skinny_bwd(gq, xp, wq_, alpha=scaling)
+        g_xp, d_wk, d_bk = _skinny_bwd(gk, xp, wk_, add1=u_q, out=u_q)                  # d loss / d (x + pos)
+        g_x, d_wv, d_bv = _skinny_bwd(gv, x2, wv_, add1=g_xp, add2=gs1, out=gs1)
+        g_pos = (g_y1p + g_xp).view(B, N, D)
+        if ctx.pos_shape != (B, N, D):
+            g_pos = g_pos.sum_to_size(ctx.pos_shape)
+        g_val = g_value.view(ctx.value_shape)
+        return (g_x.view(B, N, D), g_pos, g_ref, g_val, None, None, None, None, None, None,
+                d_wq, d_bq, d_wk, d_bk, d_wv, d_bv, d_wo, gbb1[512:768], gbb1[0:256], gbb1[256:512],
+                d_wso, d_bso, d_waw, d_baw, d_wop, gbb2[512:768], gbb2[0:256], gbb2[256:512],
+                d_w1, d_b1, d_w2, gbb3[512:768], gbb3[0:256], gbb3[256:512])
+
+
+def decoder_layer_train_supported(layer, x, pos, ref, value, attention_mask, output_attentions):
+    """The decoder-layer training node serves the reference's training configuration: fp32 on the GPU, object-query rows,
+    d_model 256, 8 heads, 4 levels x 4 points, 2-d reference points (no box refinement), ReLU FFN, no attention maps / masks /
+    attention dropout, a precomputed (already masked) value projection."""
+    sa, ca = layer.self_attn, layer.encoder_attn
+    eligible = (DECODER_TRAIN_FUSED and ENCODER_TRAIN_FUSED and SKINNY_BACKWARD_FUSED and torch.is_grad_enabled()
+                and layer.training and not output_attentions and attention_mask is None and torch.is_tensor(x) and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] * x.shape[1] <= SKINNY_MAX_ROWS
+                and torch.is_tensor(value))
+    ok = (eligible and x.shape[-1] == 256 and pos is not None and pos.dtype == torch.float32 and pos.shape[-1] == 256
+          and ref is not None and ref.dim() == 4 and ref.shape[-1] == 2 and ref.shape[2] == 4
+          and value.dim() == 3 and value.shape[-1] == 256 and value.dtype == torch.float32
+          and sa.num_heads == 8 and sa.embed_dim == 256 and sa.dropout == 0.0 and sa.q_proj.bias is not None
+          and ca.n_heads == 8 and ca.n_levels == 4 and ca.n_points == 4 and ca.d_model == 256
+          and layer.activation_fn is torch.nn.functional.relu and layer.activation_dropout == 0.0
+          and layer.fc1.weight.shape[0] % 64 == 0 and tuple(layer.fc2.weight.shape) == (256, layer.fc1.weight.shape[0])
+          and x.shape[1] <= 640 and 0.0 <= layer.dropout < 1.0)
+    return _gate("decoder_layer_train", eligible, ok,
+                 lambda: f"states {tuple(x.shape)}: the training node serves d_model 256, 8 heads, 4 x 4 sampling points, ReLU, "
+                         "2-d reference points, <= 640 queries, no attention dropout")
+
+
+def decoder_layer_train(layer, x, pos, ref, value, spatial_shapes, level_start_index, masks=None):
+    """(y3, scaled q, k) of one decoder layer through DecoderLayerTrainFunction."""
+    sa, ca = layer.self_attn, layer.encoder_attn
+    return DecoderLayerTrainFunction.apply(
+        x, pos, ref, value, spatial_shapes, level_start_index, layer.dropout, masks,
+        (layer.self_attn_layer_norm.eps, layer.encoder_attn_layer_norm.eps, layer.final_layer_norm.eps), float(sa.scaling),
+        sa.q_proj.weight, sa.q_proj.bias, sa.k_proj.weight, sa.k_proj.bias, sa.v_proj.weight, sa.v_proj.bias,
+        sa.out_proj.weight, sa.out_proj.bias, layer.self_attn_layer_norm.weight, layer.self_attn_layer_norm.bias,
+        ca.sampling_offsets.weight, ca.sampling_offsets.bias, ca.attention_weights.weight, ca.attention_weights.bias,
+        ca.output_proj.weight, ca.output_proj.bias, layer.encoder_attn_layer_norm.weight, layer.encoder_attn_layer_norm.bias,
+        layer.fc1.weight, layer.fc1.bias, layer.fc2.weight, layer.fc2.bias, layer.final_layer_norm.weight,
+        layer.final_layer_norm.bias)
+
+
+
 def cached_weights(owner, name, tensors, builder):
     """Derived constants of module weights (stacks, slices, concatenations), built once and rebuilt when a source tensor
     is replaced, moved or modified in place.  The cache lives ON the owning module (``owner._egtr_derived``), and an

@@ -46,7 +46,7 @@ enum {
 
 /* Bumped whenever an entry point is added / removed or the meaning of an argument changes; egtr_amd/_lib.py refuses a
  * library whose number differs from the one it was written against. */
-#define EGTR_ABI_VERSION 3
+#define EGTR_ABI_VERSION 4
 int egtr_abi_version(void);
 const char* egtr_status_string(int status);
 /* last HIP error string seen by this thread (for EGTR_E_LAUNCH) */
@@ -173,6 +173,14 @@ int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const floa
                                 int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
                                 float* grad_v);
 
+/* The same with gradients that reach q / k by another route added in the epilogue (optional, [B, N, M*D] each): the retained
+ * scaled-q / k maps of dd:1179-1185 feed the relation head, whose gradient meets the attention's at q and k (training node
+ * of a decoder layer, egtr_amd.ops.DecoderLayerTrainFunction). */
+int egtr_self_attn_backward_acc_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
+                                    const float* out, const float* lse, const float* grad_out, int batch,
+                                    int num_query, int num_heads, int head_dim, float* grad_q, float* grad_k,
+                                    float* grad_v, const float* grad_q_add, const float* grad_k_add);
+
 /* ---- skinny linear layer (object-query rows) --------------------------------------------------------------- */
 /* y[M,N] = act((x[M,K] . w[N,K]^T + bias[N]) * alpha); bias may be NULL; relu != 0 applies max(.,0) last.
  * Replaces the nn.Linear calls of the decoder layers (model/deformable_detr.py:1132-1135, 990-995, 1386-1387),
@@ -189,6 +197,13 @@ int egtr_linear_f32(egtr_stream_t stream, const float* x, const float* w, const 
 int egtr_linear_backward_f32(egtr_stream_t stream, const float* grad_y, const float* relu_output, const float* x,
                              const float* w, float alpha, float* grad_x, float* grad_w, float* grad_bias, int M, int K,
                              int N);
+
+/* The same with up to two [M, K] tensors added to grad_x in the epilogue (NULL = none; may alias grad_x): where the gradient
+ * branches of a layer meet (x feeds q / k / v projections AND the residual), the sum is formed by the product that
+ * arrives last instead of by add launches (training node of a decoder layer). */
+int egtr_linear_backward_acc_f32(egtr_stream_t stream, const float* grad_y, const float* relu_output, const float* x,
+                                 const float* w, float alpha, float* grad_x, float* grad_w, float* grad_bias, int M,
+                                 int K, int N, const float* grad_x_add1, const float* grad_x_add2);
 
 /* Up to 16 independent skinny linears in ONE launch (every launch costs ~5 us in a graph-replayed forward):
  *   y_g[M_g, N_g] (row stride ldy_g floats) = act((alpha_x_g * X_g W_g^T + b_g) * alpha_g),  X_g [M_g, K], W_g [N_g, K].

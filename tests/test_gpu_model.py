@@ -25,7 +25,7 @@ def small(golden_dir):
 def test_native_library_is_the_one_loaded():
     from egtr_amd import _lib
     h = _lib.lib()
-    assert h.egtr_abi_version() == _lib.ABI_VERSION == 3
+    assert h.egtr_abi_version() == _lib.ABI_VERSION == 4
     maps = open("/proc/self/maps").read()
     assert "libegtr_hip.so" in maps
 
