@@ -14,16 +14,16 @@ import torch.nn.functional as F
 from torch import nn
 
 
-TRAIN_FUSED_EPILOGUE = os.environ.get("EGTR_BACKBONE_TRAIN_FUSED", "1") != "0"
+TRAIN_FUSED_EPILOGUE = True   # module attribute (tests patch it); no environment switch since round 6
 # bf16 inference: the backbone behind the stem runs channels-last -- MIOpen's NHWC 3x3 convolutions on the tensors as they lie
 # (on NCHW tensors the same kernels run between two layout transposes: 418 vs 176 us for a layer-1 convolution at bs 16,
 # tools/nhwc_probe.py) and the 1x1 convolutions as plain [N*H*W, Cin] x [Cin, Cout] GEMMs with bias (+ ReLU) in the epilogue.
-# "0": NCHW throughout.
-NHWC_BF16 = os.environ.get("EGTR_BACKBONE_NHWC_BF16", "1") != "0"
+# EGTR_BACKBONE_NHWC=0 (one switch for both dtypes since round 6): NCHW throughout.
+NHWC_BF16 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 # fp32 inference: the same layout behind the (NCHW, fused pool) stem -- MIOpen's NHWC 3x3 kernels measure 10-30 % faster than
 # its NCHW choices at bs 1 (tools/nhwc_probe.py --fp32: 786 -> 660 us over the 16 convolutions) and the conv1 epilogue
-# launches disappear into the GEMMs.  "0": NCHW throughout.
-NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC_F32", "1") != "0"
+# launches disappear into the GEMMs.
+NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 
 
 def _fold(conv, bn):
@@ -90,7 +90,7 @@ class ScaleWeightsFunction(torch.autograd.Function):
         return (None, *out)
 
 
-SCALE_WEIGHTS_FUSED = os.environ.get("EGTR_BACKBONE_SCALE_FUSED", "1") != "0"
+SCALE_WEIGHTS_FUSED = True   # module attribute (tests patch it); no environment switch since round 6
 
 
 class Bottleneck(nn.Module):

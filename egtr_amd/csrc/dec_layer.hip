@@ -76,11 +76,9 @@ __device__ __forceinline__ unsigned barrier_base(const unsigned* ctr) {
   asm volatile("s_nop 4\n\ts_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
   return v / kArrivals * kArrivals;
 }
-template <bool WAIT_ACK = true>
 __device__ __forceinline__ void barrier_arrive(unsigned* ctr, int lane) {
-  // this wave's partial stores have reached the L2 -- or (tagged mode) are merely on their way: the readers then verify the
-  // launch tag of what they load and re-load the rare chunk that has not landed yet
-  if constexpr (WAIT_ACK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // this wave's partial stores have reached the L2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (lane == 0) {
     const unsigned one = 1u;
     asm volatile("global_atomic_add %0, %1, off" ::"v"(ctr), "v"(one) : "memory");
@@ -242,45 +240,21 @@ __device__ __forceinline__ RowParams load_params(const float* __restrict__ bias,
 
 // Thread (r = tid >> 5, j = tid & 31) owns columns 4j .. 4j+3 and 128 + 4j .. of row r of the cluster's panel:
 // y = sum of the 8 partials (head order) + bias + residual, then LayerNorm over the row (32 lanes).
-// tag != 0 (dataflow mode): every word of a partial carries the launch's 2-bit tag in its two lowest mantissa bits, written
-// by store_partial; the words the buffer held before carry another tag (the host hands consecutive launches on a buffer
-// different tags, a fresh buffer is zero = tag 0).  The reader therefore needs no barrier: it loads, and re-loads while a
-// word still shows the old tag -- the hand-over costs one store -> L2 -> load trip instead of store -> acknowledge ->
-// atomic -> poll -> load.  The tag bits are cleared before the sum (a perturbation of <= 3 ulp of each partial,
-// deterministic).  Never hangs: after kMaxSpins rounds bit 0 of *status is raised and the sum is taken as it is.
-template <bool TAGGED>
+// (Round 5 also had a barrier-free hand-over -- every word of a partial carried a 2-bit launch tag and the readers re-loaded
+// until they saw it: 34 vs 29 us per layer, the re-loads compete with the stores they wait for; removed in round 6,
+// DESIGN.md 4.13, code in the history: commit 46d9c2f and before.)
 __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of this cluster */, int r, int j, const RowParams& q,
-                                          f32x4 res0, f32x4 res1, float eps, unsigned tag, unsigned* status, bool& bad_wave,
-                                          f32x4& o0, f32x4& o1) {
+                                          f32x4 res0, f32x4 res1, float eps, bool bad_wave, f32x4& o0, f32x4& o1) {
   f32x4 p0[kH], p1[kH];
-  int spins = 0;
-  while (true) {
 #pragma unroll
-    for (int hh = 0; hh < kH; ++hh) {
-      p0[hh] = ld_l2(part + (hh * kR + r) * 256 + 4 * j);
-      p1[hh] = ld_l2(part + (hh * kR + r) * 256 + 128 + 4 * j);
-    }
-    wait_loads(p0[0], p0[1], p0[2], p0[3]);
-    wait_loads(p0[4], p0[5], p0[6], p0[7]);
-    wait_loads(p1[0], p1[1], p1[2], p1[3]);
-    wait_loads(p1[4], p1[5], p1[6], p1[7]);
-    if constexpr (!TAGGED) break;
-    // one word per 16-byte chunk: the four words of a chunk are neighbours in ONE 128-byte line written by one store
-    // instruction of one wave
-    unsigned bad = 0;
-#pragma unroll
-    for (int hh = 0; hh < kH; ++hh) {
-      bad |= (__float_as_uint(p0[hh][0]) ^ tag) & 3u;
-      bad |= (__float_as_uint(p1[hh][0]) ^ tag) & 3u;
-    }
-    if (__builtin_amdgcn_readfirstlane(__any((int)bad)) == 0) break;   // the whole wave retries together
-    if (++spins > kMaxSpins) {
-      atomicOr(status, 1u);
-      bad_wave = true;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(1);
+  for (int hh = 0; hh < kH; ++hh) {
+    p0[hh] = ld_l2(part + (hh * kR + r) * 256 + 4 * j);
+    p1[hh] = ld_l2(part + (hh * kR + r) * 256 + 128 + 4 * j);
   }
+  wait_loads(p0[0], p0[1], p0[2], p0[3]);
+  wait_loads(p0[4], p0[5], p0[6], p0[7]);
+  wait_loads(p1[0], p1[1], p1[2], p1[3]);
+  wait_loads(p1[4], p1[5], p1[6], p1[7]);
   f32x4 y0 = p0[0], y1 = p1[0];
 #pragma unroll
   for (int hh = 1; hh < kH; ++hh) {
@@ -307,15 +281,11 @@ __device__ __forceinline__ void reduce_ln(const float* part /* [8][8][256] of th
 }
 
 // Store the 8 x 64 tile held by a wave (lane = column) as rows of the cluster's partial buffer.
-__device__ __forceinline__ float tagged(float v, unsigned tag) {   // tag == 0 (barrier mode): v & ~0 | 0 = v
-  return __uint_as_float((__float_as_uint(v) & ~(tag ? 3u : 0u)) | tag);
-}
-__device__ __forceinline__ void store_partial(float* part_h /* [8][256] of this head */, int col, const f32x4& lo, const f32x4& hi,
-                                              unsigned tag) {
+__device__ __forceinline__ void store_partial(float* part_h /* [8][256] of this head */, int col, const f32x4& lo, const f32x4& hi) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    part_h[i * 256 + col] = tagged(lo[i], tag);
-    part_h[(4 + i) * 256 + col] = tagged(hi[i], tag);
+    part_h[i * 256 + col] = lo[i];
+    part_h[(4 + i) * 256 + col] = hi[i];
   }
 }
 __device__ __forceinline__ void stash_tile(float* s_red, int wave, int lane, const f32x4& lo, const f32x4& hi) {
@@ -326,7 +296,6 @@ __device__ __forceinline__ void stash_tile(float* s_red, int wave, int lane, con
   }
 }
 
-template <bool TAGGED>
 __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
   const EgtrDecoderLayer& P = A.p;
   __shared__ __attribute__((aligned(16))) float s_x[kR * kLdx];     // the panel (LayerNorm output)
@@ -354,7 +323,6 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
   load_geom(P.spatial_shapes, P.level_start_index, 4, G);
   unsigned my_xcc = 0, bar_base = 0, nbar = 0;
   bool bad_wave = false;   // this wave gave up on a hand-over: what it hands out from then on is NaN (reduce_ln)
-  const unsigned tag = TAGGED ? ((unsigned)P.generation & 3u) : 0u;   // 0: barrier mode
   bool have_base = false;
   if (tid == 0) {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(my_xcc));
@@ -513,10 +481,10 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       load_a<1>(s_a + ai * kLda + 4 * (ab & 7), kLda, a0, a1);
       w_wait<8, true>(w_o);
       mma_steps<0, 8, 1>(w_o, a0, a1, lo, hi);
-      store_partial(part1 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi, tag);
+      store_partial(part1 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
     STAMP(4);
-    barrier_arrive<!TAGGED>(ctr, lane);
+    barrier_arrive(ctr, lane);
     f32x4 w_ol[16], w_c[8];   // phase 2's streams land while the cluster gathers: offsets / logits (K quarter), cross projection
     w_issue<16, true>(w_ol, reinterpret_cast<const float4*>(P.w_off_logit) + ((size_t)h * 64 + 16 * wave) * 64, lane_bytes);
     w_issue<8, true>(w_c, reinterpret_cast<const float4*>(P.w_cross_out) + ((size_t)wave * 64 + 8 * h) * 64, lane_bytes);
@@ -524,7 +492,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
     STAMP(5);
     // ================================================================= phase 2: LayerNorm 1, cross-attention of head h ==
     f32x4 x1a, x1b;
-    reduce_ln<TAGGED>(part1, r, j, rp, xin0, xin1, P.ln_eps, tag, P.status, bad_wave, x1a, x1b);
+    reduce_ln(part1, r, j, rp, xin0, xin1, P.ln_eps, bad_wave, x1a, x1b);
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x1a;
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x1b;
     *reinterpret_cast<f32x4*>(s_xp + r * kLdx + 4 * j) = x1a + pos0;
@@ -624,10 +592,10 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       load_a<1>(s_a + ai * kLda + 4 * (ab & 7), kLda, a0, a1);
       w_wait<8, true>(w_c);
       mma_steps<0, 8, 1>(w_c, a0, a1, lo, hi);
-      store_partial(part2 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi, tag);
+      store_partial(part2 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
     STAMP(10);
-    if (!(A.drop_arrival != 0 && c == 0 && h == kH - 1 && wave == 3)) barrier_arrive<!TAGGED>(ctr, lane);
+    if (!(A.drop_arrival != 0 && c == 0 && h == kH - 1 && wave == 3)) barrier_arrive(ctr, lane);
     // fc1's stream (tile 2h + (wave & 1), K half wave >> 1) into AGPRs -- reused for the next layer's q / k / v -- and fc2's
     // (tile = wave, this head's 32 k groups) into VGPRs: both land while the cluster gathers and LayerNorm 2 runs
     f32x4 w_f[32];
@@ -646,7 +614,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
 
     // ================================================================= phase 3: LayerNorm 2, 128 hidden units ==========
     f32x4 x2a, x2b;
-    reduce_ln<TAGGED>(part2, r, j, rp, x1a, x1b, P.ln_eps, tag, P.status, bad_wave, x2a, x2b);
+    reduce_ln(part2, r, j, rp, x1a, x1b, P.ln_eps, bad_wave, x2a, x2b);
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 4 * j) = x2a;
     *reinterpret_cast<f32x4*>(s_x + r * kLdx + 128 + 4 * j) = x2b;
     rp = load_params(P.b_fc2, P.ln3_gamma, P.ln3_beta, j);
@@ -691,10 +659,10 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
       w_wait<32, true>(w_f);
 #endif
       mma_steps<0, 32, 2>(w_g, a0, a1, lo, hi);
-      store_partial(part3 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi, tag);
+      store_partial(part3 + (size_t)h * kR * 256, wave * 64 + lane, lo, hi);
     }
     STAMP(15);
-    barrier_arrive<!TAGGED>(ctr, lane);
+    barrier_arrive(ctr, lane);
 #ifndef EGTR_DEC_FC2_EARLY
     if (P.q_next != nullptr)
       w_issue<32, true>(w_f, reinterpret_cast<const float4*>(P.w_qkv_next) + ((size_t)(2 * h + (wave & 1)) * 64 + 32 * (wave >> 1)) * 64,
@@ -705,7 +673,7 @@ __global__ __launch_bounds__(256) void decoder_layer_cluster_f32(Args A) {
 
     // ================================================================= phase 4: LayerNorm 3, next layer's q / k / v ====
     f32x4 x3a, x3b;
-    reduce_ln<TAGGED>(part3, r, j, rp, x2a, x2b, P.ln_eps, tag, P.status, bad_wave, x3a, x3b);
+    reduce_ln(part3, r, j, rp, x2a, x2b, P.ln_eps, bad_wave, x3a, x3b);
     STAMP(17);
     if (h == 0 && r < nvalid) {
       *reinterpret_cast<f32x4*>(P.x_out + grow * 256 + 4 * j) = x3a;
@@ -767,7 +735,7 @@ extern "C" int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLay
   // rows shared by the images of a batch come as ONE image's rows
   if ((p.qkv_rows != p.num_query && p.qkv_rows != p.batch * p.num_query) || p.x_rows % p.num_query || p.pos_rows % p.num_query)
     return EGTR_E_ARG;
-  if (p.generation < 0 || p.generation > 3) return EGTR_E_ARG;
+  if (p.generation != 0) return EGTR_E_ARG;   // (1..3 selected the tagged hand-over of round 5: removed)
   if (p.valid_ratios != nullptr && p.ref_rows <= 0) return EGTR_E_ARG;
   if (p.num_query > kMaxKeys) return EGTR_E_UNSUPPORTED;
   if (p.num_clusters != p.batch * ((p.num_query + kR - 1) / kR)) return EGTR_E_ARG;
@@ -782,10 +750,7 @@ extern "C" int egtr_decoder_layer_f32(egtr_stream_t stream, const EgtrDecoderLay
   Args a;
   a.p = p;
   a.drop_arrival = g_drop_arrival;
-  if (p.generation != 0)
-    hipLaunchKernelGGL(decoder_layer_cluster_f32<true>, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
-  else
-    hipLaunchKernelGGL(decoder_layer_cluster_f32<false>, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(decoder_layer_cluster_f32, dim3(256), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   return egtr_check_launch();
 }
 

@@ -94,11 +94,11 @@ struct GemmProblems {
   GemmProblem p[kMaxProblems];
 };
 
-// DB (round 5 experiment): TWO LDS stage buffers -- the split-on-load of stage s + 1 goes into the other
-// buffer while the MFMAs of stage s issue, ONE barrier per stage instead of two.  120 KiB of (dynamic) LDS at BM = 128: one
-// workgroup of eight waves per CU instead of two.
-template <int BM, bool DB = false>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DB ? 2 : 4, DB ? 2 : 4))) void gemm_split_bf16_f32(
+// (A double-buffered form of this loop -- two LDS stage buffers, one barrier per stage, 120 KiB of LDS = one workgroup per CU --
+// and a ping-pong schedule on it were measured 7-15 % slower in round 5 and removed in round 6: DESIGN.md 4.12,
+// profiles/r05_gemm_double_buffer_ab.txt; the code is in the history, commit 46d9c2f and before.)
+template <int BM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_split_bf16_f32(
     GemmProblems P, int nprob, int M, int K) {
   // tile -> (problem, n block, m block): n blocks of one m block are neighbours (they read the same activation rows)
   const int mblocks = (M + BM - 1) / BM;
@@ -122,9 +122,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DB ? 2 : 4,
   constexpr int NT = 4 / WAVES_N;             // 32-column MFMA tiles per wave: 2 or 1
   constexpr int AQ = BM / 64;                 // float4 of A per thread and stage (BM rows x 8 float4 / 512 threads)
   constexpr int kStageElems = 3 * BM * kPitch + 3 * kBN * kPitch;
-  extern __shared__ __attribute__((aligned(16))) __bf16 smem_dyn[];
-  __shared__ __attribute__((aligned(16))) __bf16 smem_static[DB ? 8 : kStageElems];
-  __bf16* sbase = DB ? smem_dyn : smem_static;
+  __shared__ __attribute__((aligned(16))) __bf16 sbase[kStageElems];
   __bf16* sA = sbase;
   __bf16* sW = sbase + 3 * BM * kPitch;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,8 +162,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DB ? 2 : 4,
 #pragma unroll
     for (int q = 0; q < 3; ++q) rw[q] = gload(wp + q * 8192);
   };
-  auto stash = [&](int buf) {
-    __bf16* sA = sbase + buf * kStageElems;
+  auto stash = [&]() {
+    __bf16* sA = sbase;
     __bf16* sW = sA + 3 * BM * kPitch;
 #pragma unroll
     for (int q = 0; q < AQ; ++q) vm_wait0(ra[q]);
@@ -203,13 +201,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DB ? 2 : 4,
     for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
 
   issue(0);
-  stash(0);
+  stash();
   __syncthreads();
   const __bf16* pa0 = sA + (wm * 32 + li) * kPitch + 8 * hf;
   const __bf16* pw0 = sW + (wn * (32 * NT) + li) * kPitch + 8 * hf;
-  auto compute = [&](int buf) {
-    const __bf16* pa = pa0 + buf * kStageElems;
-    const __bf16* pw = pw0 + buf * kStageElems;
+  auto compute = [&]() {
+    const __bf16* pa = pa0;
+    const __bf16* pw = pw0;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[3], w[NT][3];
@@ -235,28 +233,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DB ? 2 : 4,
   };
   // every iteration issues the loads of the NEXT stage, multiplies the current one out of LDS and stores the next one
   // (issue and stash unconditionally paired: no path leaves a load in flight); the last stage is peeled
-  if constexpr (DB) {
-    // stage s is read from buffer s & 1 while stage s + 1 is split into the other one: the barrier at the end of the
-    // iteration says both "stage s + 1 is complete" and "nobody reads stage s any more" (its buffer is refilled next)
 #pragma unroll 1
-    for (int s = 0; s + 1 < nk; ++s) {
-      issue(s + 1);
-      compute(s & 1);
-      stash((s + 1) & 1);
-      __syncthreads();
-    }
-    compute((nk - 1) & 1);
-  } else {
-#pragma unroll 1
-    for (int s = 0; s + 1 < nk; ++s) {
-      issue(s + 1);
-      compute(0);
-      __syncthreads();   // every wave has read stage s out of LDS
-      stash(0);
-      __syncthreads();
-    }
-    compute(0);
+  for (int s = 0; s + 1 < nk; ++s) {
+    issue(s + 1);
+    compute();
+    __syncthreads();   // every wave has read stage s out of LDS
+    stash();
+    __syncthreads();
   }
+  compute();
 
   // epilogue: D[i = n][j = m]; accumulator r <-> column n = (r & 3) + 8 (r >> 2) + 4 hf of the 32-wide n tile, row m =
   // lane & 31: one float4 (4 consecutive columns) per accumulator quad
@@ -324,17 +309,7 @@ int launch_grouped(hipStream_t st, const GemmProblems& P, int nprob, int M, int 
   // (value 256 -> 256 + offsets / weights 256 -> 384, M = 12 537) has 490 128-row tiles = 980 64-row tiles: one nearly full round
   // of the larger tiles beats 1.91 rounds of the smaller ones -- 42.9 -> 37.2 us per launch, 281.9 -> 284.7 images/s end to end
   // (three alternations on one box, abl/infer_ab.sh).
-  static const int db_min_tiles = [] {   // EGTR_GEMM_DB=<tiles>: double-buffered kernel from that many 128-row tiles on (0 = never)
-    const char* e = getenv("EGTR_GEMM_DB");
-    return e ? atoi(e) : 0;
-  }();
-  if (db_min_tiles > 0 && tiles128 >= db_min_tiles) {
-    constexpr int kDbBytes = 2 * (3 * 128 * kPitch + 3 * kBN * kPitch) * 2;
-    static unsigned long long done = 0;
-    const int rs = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(&gemm_split_bf16_f32<128, true>), kDbBytes, &done);
-    if (rs != EGTR_OK) return rs;
-    hipLaunchKernelGGL((gemm_split_bf16_f32<128, true>), dim3((unsigned)tiles128), dim3(512), kDbBytes, st, P, nprob, M, K);
-  } else if (tiles128 >= 480)
+  if (tiles128 >= 480)
     hipLaunchKernelGGL(gemm_split_bf16_f32<128>, dim3((unsigned)tiles128), dim3(512), 0, st, P, nprob, M, K);
   else
     hipLaunchKernelGGL(gemm_split_bf16_f32<64>, dim3((unsigned)tiles64), dim3(512), 0, st, P, nprob, M, K);

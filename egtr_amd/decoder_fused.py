@@ -20,10 +20,8 @@ from .load_custom import _stream
 # "0": the per-operation decoder (eight launches per layer) -- the A/B switch of tools/forward_breakdown.py
 ENABLED = os.environ.get("EGTR_DECODER_CLUSTER", "1") != "0"
 MAX_QUERIES = 320
-# "0" (default): the workgroups of a cluster meet at L2 barriers.  "1": they hand their partial results over as tagged data
-# (every word carries a 2-bit launch tag, the readers re-load until they see it) -- measured SLOWER (34 vs 29 us per layer:
-# the re-loads of the 64 KiB of partials compete with the stores they wait for); kept as the tested alternative.
-DATAFLOW = os.environ.get("EGTR_DECODER_DATAFLOW", "0") != "0"
+# (Round 5 also carried a barrier-free hand-over of the cluster's partial results, EGTR_DECODER_DATAFLOW: 34 vs 29 us per
+# layer -- removed in round 6 together with its switch)
 
 
 class DecoderClusterError(RuntimeError):
@@ -120,8 +118,7 @@ POLL_EVERY = 64
 
 
 def _new_workspace(dev, shape_key):
-    """(barriers, status, partials): zeroed ONCE.  The barrier counters only grow; the partials' zero words carry tag 0, which
-    no launch uses (dataflow mode)."""
+    """(barriers, status, partials, xcc ids): zeroed ONCE.  The barrier counters only grow."""
     B, N, _ = shape_key
     lib = _lib.lib()
     pf, bw, iw = ctypes.c_longlong(0), ctypes.c_int(0), ctypes.c_int(0)
@@ -132,8 +129,8 @@ def _new_workspace(dev, shape_key):
 
 
 def _workspace(dev, shape_key):
-    """Launches that share a buffer set must be stream-ordered and of one shape (batch, queries, layers): then consecutive
-    launches on it carry different tags (``_tags``) and the barrier counters stay whole.  Eager launches: one set per
+    """Launches that share a buffer set must be stream-ordered and of one shape (batch, queries, layers): then the barrier
+    counters stay whole.  Eager launches: one set per
     (device, stream, shape).  Under stream capture: a set of its own for the graph being captured, taken from a pool that
     the first eager run of that shape filled (an allocation inside the capture would put memset nodes into the graph; it
     still works and is what happens when the pool is empty)."""
@@ -152,17 +149,6 @@ def _workspace(dev, shape_key):
         if (dev.index, shape_key) not in _POOL:
             _POOL[(dev.index, shape_key)] = [_new_workspace(dev, shape_key) for _ in range(4)]
     return ws
-
-
-def _tags(nl):
-    """Tags 1..3 of the nl launches of one forward such that neighbours differ, also across the seam between two forwards
-    (the last launch of one and the first of the next use the same buffers); None when that is impossible (nl == 1)."""
-    if nl < 2:
-        return None
-    t = [1 + (l % 3) for l in range(nl)]
-    if t[-1] == t[0]:
-        t[-1] = next(v for v in (1, 2, 3) if v != t[0] and v != t[-2])
-    return t
 
 
 def _rows(t, n_rows_per_image):
@@ -228,9 +214,7 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
 
     states = torch.empty(nl, B * N, 256, dtype=torch.float32, device=dev)
     qkv = torch.empty(max(nl - 1, 1), 3, B * N, 256, dtype=torch.float32, device=dev)
-    tags = _tags(nl) if DATAFLOW else None
-    # (the mode is part of the key: words written in barrier mode carry no tag and must never meet a dataflow reader)
-    barriers, status, partials, ids = _workspace(dev, (B, N, nl if tags is not None else -nl))
+    barriers, status, partials, ids = _workspace(dev, (B, N, nl))
     if valid_ratios is not None:   # plain [B, N, 2] points (possibly one image's rows expanded) + [B, 4, 2] ratios
         ref, ref_rows = _rows(reference_input, N)
         vr = valid_ratios.contiguous()
@@ -280,7 +264,7 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
                                                        ids.data_ptr())
         a.q_scale, a.ln_eps = scale, float(layer.self_attn_layer_norm.eps)
         a.batch, a.num_query, a.spatial_size, a.num_clusters = B, N, S, nclusters
-        a.generation = tags[i] if tags is not None else 0
+        a.generation = 0
         _lib.check(lib.egtr_decoder_layer_f32(stream, ctypes.byref(a)), "egtr_decoder_layer_f32")
     if not torch.cuda.is_current_stream_capturing():
         if dev.index not in _CHECKED:

@@ -49,9 +49,9 @@ def _get_clones(module, N):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
 
 
-# "0": slot projections, first MLP layer and gate logits of the relation head as three launches (the A/B switch of the merged
-# preparation below)
-REL_PREP_MERGED = os.environ.get("EGTR_REL_PREP_MERGED", "1") != "0"
+# False: slot projections, first MLP layer and gate logits of the relation head as three launches (the A/B twin of the merged
+# preparation below; a module attribute that tests patch -- no environment switch since round 6)
+REL_PREP_MERGED = True
 
 
 class DetrForSceneGraphGeneration(DeformableDetrPreTrainedModel):

@@ -124,7 +124,7 @@ def msda_geometry_supported(offsets, logits, reference_points, M, L, P):
             and rows_ok(offsets) and rows_ok(logits))
 
 
-MSDA_GEOMETRY = os.environ.get("EGTR_MSDA_GEOMETRY", "1") != "0"
+MSDA_GEOMETRY = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 
 
 def msda_fused_supported(num_heads, channels, num_levels, num_points):
@@ -208,7 +208,7 @@ def decoder_self_attention(q, k, v, num_heads, want_maps=True):
     return DecoderSelfAttentionFunction.apply(q.contiguous(), k.contiguous(), v.contiguous(), num_heads, want_maps)
 
 
-SKINNY_BACKWARD_FUSED = os.environ.get("EGTR_SKINNY_BACKWARD", "1") != "0"
+SKINNY_BACKWARD_FUSED = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 # token-sized linears under autograd through TokenLinearFunction (split-bf16 forward / data / weight gradients); "0": plain autograd
 TOKEN_LINEAR = os.environ.get("EGTR_TOKEN_LINEAR", "1") != "0"
 SKINNY_MAX_ROWS = 4096  # above this the vendor GEMM (rocBLAS / hipBLASLt) fills the chip and is the right tool
@@ -304,7 +304,7 @@ def linear(x, weight, bias=None, alpha=1.0, relu=False):
 
 # bf16 models: the encoder layer's feed-forward block + residual + LayerNorm (+ position rows) in one launch
 # (csrc/ffn_bf16.hip).  "0": two vendor GEMMs + the LayerNorm launch.
-FFN_BF16_FUSED = os.environ.get("EGTR_FFN_BF16_FUSED", "1") != "0"
+FFN_BF16_FUSED = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 
 
 def ffn_bf16_supported(x, fc1, fc2, ln):
@@ -353,7 +353,7 @@ def ffn_layernorm_bf16(x, fc1, fc2, ln, pos=None):
 
 # bf16 models, object-query-sized rows (the decoder of the stress configuration: 4800 rows): csrc/linear_bf16.hip instead of the
 # vendor library, whose choice for these shapes takes 20 us per layer.  "0": F.linear.
-LINEAR_BF16 = os.environ.get("EGTR_LINEAR_BF16", "1") != "0"
+LINEAR_BF16 = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 LINEAR_BF16_MAX_ROWS = 16384
 
 
@@ -479,7 +479,7 @@ class TokenLinearFunction(Function):
 # "0": the per-op composition of rounds 2 / 3 (TokenLinearFunction + F.dropout + AddLayerNormFunction + clamp_nonfinite_ ...)
 ENCODER_TRAIN_FUSED = os.environ.get("EGTR_ENCODER_TRAIN_FUSED", "1") != "0"
 # training forward of the relation head on the split-bf16 arithmetic (rel_head_fwd_x6 with the activation stores); 0: exact-f32 kernel
-REL_HEAD_TRAIN_X6 = os.environ.get("EGTR_REL_HEAD_TRAIN_X6", "1") != "0"
+REL_HEAD_TRAIN_X6 = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 
 
 def _host_array(ctype, vals):
@@ -1088,6 +1088,23 @@ def invalidate_derived(model):
             m.__dict__["_folded"] = None
 
 
+# ---- the environment switches of the package (round 6: seven route switches, down from twenty-four) ----------------------------
+# Each selects between two SHIPPED routes that both have a use; everything else that used to be switchable from the environment
+# is either gone (the decoder's tagged hand-over, the double-buffered split GEMM: measured slower) or a plain module attribute
+# that only the switch-off twin tests patch (the route it turns off is the generic composition that CPU tensors and unsupported
+# shapes take anyway).  tests/test_gpu_model.py::test_full_size_with_every_kept_switch_off_at_once_vs_reference runs the
+# combination of all of them.
+#   EGTR_DECODER_CLUSTER=0      decoder_fused.ENABLED       decoder layer: one launch per layer  ->  per-operation launches
+#   EGTR_GEMM_SPLIT_BF16=0      ops.GEMM_SPLIT_BF16         token-sized linears: split-bf16 matrix cores  ->  vendor fp32 GEMM
+#   EGTR_REL_HEAD_SPLIT_BF16=0  ops.REL_HEAD_SPLIT_BF16     relation head at inference: split-bf16  ->  exact-f32 MFMA kernel
+#   EGTR_FFN_FUSED=0            ops.FFN_FUSED               encoder FFN / layer tail row-panel kernels  ->  separate launches
+#   EGTR_BACKBONE_NHWC=0        backbone.NHWC_F32 / _BF16   inference backbone channels-last  ->  NCHW
+#   EGTR_ENCODER_TRAIN_FUSED=0  ops.ENCODER_TRAIN_FUSED     training nodes (encoder / decoder layer, values, LayerNorm)  ->  per-op autograd
+#   EGTR_TOKEN_LINEAR=0         ops.TOKEN_LINEAR            token-sized linears under autograd: TokenLinearFunction  ->  F.linear
+# Not route switches: EGTR_HIP_LIBRARY (another build of the library), EGTR_STRICT_FAST_PATH (below), EGTR_TRUST_CHECKPOINT_PICKLE.
+ENV_ROUTE_SWITCHES = ("EGTR_DECODER_CLUSTER", "EGTR_GEMM_SPLIT_BF16", "EGTR_REL_HEAD_SPLIT_BF16", "EGTR_FFN_FUSED",
+                      "EGTR_BACKBONE_NHWC", "EGTR_ENCODER_TRAIN_FUSED", "EGTR_TOKEN_LINEAR")
+
 # ---- leaving a HIP fast path is never silent ------------------------------------------------------------------------------
 # Every route from a hand-written kernel to an ATen composition (unsupported shape, misaligned operand, a device that
 # refuses the cluster kernel) is counted here and announced ONCE per reason; EGTR_STRICT_FAST_PATH=1 (bench.py sets it)
@@ -1127,7 +1144,7 @@ def inference_fast_path(x):
 
 # Decoder at inference: the residual-add + LayerNorm steps run as prologues of the skinny linears that consume them
 # (DeferredLayerNorm below) instead of in launches of their own.  "0": stand-alone add_layernorm_256 launches.
-DEFER_LAYERNORM = os.environ.get("EGTR_DEFER_LAYERNORM", "1") != "0"
+DEFER_LAYERNORM = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 
 
 class DeferredLayerNorm:
@@ -1366,9 +1383,9 @@ def add_layer_norm_pos(x, residual, ln, pos, out=None):
 GEMM_SPLIT_BF16 = os.environ.get("EGTR_GEMM_SPLIT_BF16", "1") != "0"
 # encoder at inference: the offsets / weights projection adds the position embeddings while loading its operand instead of
 # reading a materialised `hidden + pos` written by the previous layer's epilogue ("0": materialise)
-LAZY_POS = os.environ.get("EGTR_LAZY_POS", "1") != "0"
+LAZY_POS = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 GEMM_SPLIT_MIN_ROWS = 4096
-GEMM_SPLIT_WGRAD = os.environ.get("EGTR_GEMM_SPLIT_WGRAD", "1") != "0"
+GEMM_SPLIT_WGRAD = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 
 
 def gemm_split_weights(weight):
@@ -1627,7 +1644,7 @@ def ffn_fused(x, fc1, fc2, ln=None, pos=None):
 
 # The whole tail of an encoder layer (output projection + LayerNorm + FFN block + LayerNorm) as ONE launch
 # (egtr_encoder_tail_x6_f32); "0": projection + LayerNorm and the FFN block as two launches.
-ENCODER_TAIL_FUSED = os.environ.get("EGTR_ENCODER_TAIL_FUSED", "1") != "0"
+ENCODER_TAIL_FUSED = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 
 
 def encoder_tail_fused_supported(context, out_proj, ln1, fc1, fc2, ln2):
@@ -2204,14 +2221,14 @@ class RelationHeadFunction(Function):
 
 # bf16 model: layer 1 of the relation head (gated sum over the slots) on the matrix cores as well, tables pre-packed in
 # operand order, W2 resident in LDS (csrc/rel_head_bf16.hip).  "0": the VALU layer 1 of rel_head_fwd_bf16w.
-REL_HEAD_BF16_PACKED = os.environ.get("EGTR_REL_HEAD_BF16_PACKED", "1") != "0"
+REL_HEAD_BF16_PACKED = True   # module attribute (tests patch it for the switch-off twin); no environment switch since round 6
 
 
 def relation_head_bf16w(gate_q, gate_k, uq, uk, b1, w2r, b2r, w3r, b3r, w2c, b2c, w3c, b3c, triplet_dist=None,
                         node_cls=None, want_gate_mean=False):
     """Inference forward of a bf16 model: the matrix products on the bf16 matrix cores with the bf16 parameters as they are
     (egtr_rel_head_forward_bf16p: all three layers, per-query tables uq / uk rounded to bf16 -- a bf16 model produces them
-    in bf16 -- and packed in operand order by egtr_rel_head_pack_tables_bf16; or, EGTR_REL_HEAD_BF16_PACKED=0,
+    in bf16 -- and packed in operand order by egtr_rel_head_pack_tables_bf16; or, with ops.REL_HEAD_BF16_PACKED = False,
     egtr_rel_head_forward_bf16w with an fp32 VALU layer 1); gates, biases and the outputs are fp32.  No autograd."""
     lib = _lib.lib()
     B, N, T = gate_q.shape

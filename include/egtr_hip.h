@@ -244,7 +244,7 @@ int egtr_linear_grouped_ln_f32(egtr_stream_t stream, int num_groups, const float
  * kernel times the sum of the in-range, unpadded corner weights; keep_bits (may be NULL): one bit per token, 0 = padded
  * (== the zeroed value rows of :1050-1052).  reference_points: either [B * N, 4, 2] with the valid ratios applied
  * (:1874-1880), or the plain [ref_rows, 2] points together with valid_ratios [B, 4, 2] -- the kernel multiplies.
- * q_next == NULL (last layer): no projections.  Workspace (egtr_decoder_layer_workspace): `partials` floats (zeroed once for the dataflow mode, see `generation`), `barriers`
+ * q_next == NULL (last layer): no projections.  Workspace (egtr_decoder_layer_workspace): `partials` floats, `barriers`
  * 32-bit words (ZEROED ONCE when allocated, never again), `xcc_ids` ints, `status` one word zeroed by the caller: after
  * the launch bit 0 = a cluster barrier timed out, bit 1 = the workgroups of a cluster did not share one XCD -- the
  * results are void in both cases and the caller must use the per-operation entries instead.
@@ -292,10 +292,8 @@ typedef struct EgtrDecoderLayer {
   float ln_eps;
   /* x_rows / pos_rows / qkv_rows: B * N, or N when the rows are the same for every image (layer 0: query table) */
   int batch, num_query, spatial_size, x_rows, pos_rows, qkv_rows, num_clusters; /* num_clusters = batch * ceil(num_query / 8) */
-  /* 0: the cluster's workgroups meet at L2 barriers.  1..3: DATAFLOW mode -- every word of a partial result carries this
-   * 2-bit tag in its two lowest mantissa bits and the readers re-load until they see it (no barrier at all).  The caller
-   * must hand CONSECUTIVE launches on the same `partials` buffer different tags and zero the buffer once when it is
-   * allocated (zero = tag 0). */
+  /* must be 0 (the cluster's workgroups meet at L2 barriers).  Until ABI version 3 the values 1..3 selected a barrier-free
+   * tagged-data hand-over; it was slower and is gone -- the field keeps the struct layout. */
   int generation;
   int ref_rows;                   /* rows of reference_points when valid_ratios != NULL (N: the same points for every image) */
 } EgtrDecoderLayer;

@@ -58,13 +58,10 @@ def _run(model, pv, pm, fused, base=False):
         decoder_fused.ENABLED = old
 
 
-@pytest.mark.parametrize("dataflow", [True, False])
 @pytest.mark.parametrize("num_queries,batch,hw", [(200, 1, (160, 224)), (37, 2, (128, 160)), (300, 2, (96, 128)),
                                                   (8, 3, (96, 128))])
-def test_cluster_decoder_matches_the_per_operation_decoder(num_queries, batch, hw, dataflow, monkeypatch):
-    """Both hand-over modes of the cluster's partial results: tagged data (default) and L2 barriers."""
+def test_cluster_decoder_matches_the_per_operation_decoder(num_queries, batch, hw, monkeypatch):
     from egtr_amd import decoder_fused, ops
-    monkeypatch.setattr(decoder_fused, "DATAFLOW", dataflow)
     model = _model(num_queries, 3)
     pv, pm = _inputs(batch, *hw)
     ref, ref_base = _run(model, pv, pm, fused=False), _run(model, pv, pm, fused=False, base=True)

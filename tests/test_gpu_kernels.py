@@ -531,7 +531,7 @@ def test_relation_head_streams_kernel_equals_torch_composition():
 
 @pytest.mark.parametrize("B,N,T,R", [(2, 24, 4, 7), (1, 37, 7, 50)])
 def test_relation_head_training_forward_on_split_arithmetic_vs_exact(B, N, T, R, monkeypatch):
-    """ops.RelationHeadFunction with its forward on the split-bf16 kernel (EGTR_REL_HEAD_TRAIN_X6, the default) against the
+    """ops.RelationHeadFunction with its forward on the split-bf16 kernel (ops.REL_HEAD_TRAIN_X6, the default) against the
     exact-f32 kernel: logits to fp32 rounding, every gradient within 1e-4 of its scale (a hidden-2 unit within rounding
     of zero may take the other side of its ReLU)."""
     from egtr_amd import ops

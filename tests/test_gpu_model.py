@@ -211,8 +211,8 @@ def test_full_size_600x1000_vs_reference(golden_dir, fixture):
 @pytest.mark.parametrize("switch", ["FFN_FUSED", "ENCODER_TAIL_FUSED", "LAZY_POS", "DEFER_LAYERNORM", "GEMM_SPLIT_BF16",
                                     "REL_HEAD_SPLIT_BF16"])
 def test_full_size_with_each_fusion_switched_off_vs_reference(golden_dir, switch, monkeypatch):
-    """Every inference fusion of round 2 / 3 has an environment switch that restores the composition it replaced
-    (EGTR_<switch>=0).  Those routes are product code too: the 600x1000 / N = 200 fixture of the reference must hold at the
+    """Every inference fusion of round 2 / 3 has a module attribute that restores the composition it replaced (three of them
+    are also environment switches, ops.ENV_ROUTE_SWITCHES).  Those routes are product code too: the 600x1000 / N = 200 fixture of the reference must hold at the
     same 1e-3 with each switch off, and the outputs must stay within fp32 rounding of the default route's."""
     from egtr_amd import ops
     g = Hh.load_golden(golden_dir, "sgg_full.npz")
@@ -234,6 +234,43 @@ def test_full_size_with_each_fusion_switched_off_vs_reference(golden_dir, switch
     assert (h["enc"].cpu()[:, ::37] - _t(g["enc_strided"])).abs().max() < tol
     assert (h["conn_logits"].cpu()[..., 0] - _t(g["conn_logits"])).abs().max() < tol
     for key in ("logits", "pred_boxes", "last_hidden", "enc", "conn_logits"):
+        assert (h[key] - base[key]).abs().max() < 2e-4, key
+    rm = lambda x: Hh.rel_mlp_from_logits(x["rel_logits"], x["logits"], model.triplet_dist)  # noqa: E731
+    assert (rm(h) - rm(base)).abs().max() < 2e-4
+
+
+def test_full_size_with_every_kept_switch_off_at_once_vs_reference(golden_dir, monkeypatch):
+    """Round 6: seven environment route switches are left (egtr_amd.ops.ENV_ROUTE_SWITCHES).  Their COMBINATION -- every
+    inference-side switch off at once: per-operation decoder, vendor fp32 GEMMs for the token linears, exact-f32 relation
+    head, separate FFN / LayerNorm launches, NCHW backbone -- is a route a user can select, so it must hold the reference's
+    600x1000 fixture at the same 1e-3, and the names in the table must be the switches the modules actually read."""
+    import inspect
+    from egtr_amd import backbone, decoder_fused, ops
+    import egtr_amd
+    src = "".join(inspect.getsource(m) for m in (ops, backbone, decoder_fused, egtr_amd.egtr))
+    import re
+    read = set(re.findall(r'os\.environ\.get\("(EGTR_[A-Z0-9_]+)"', src))
+    assert read - {"EGTR_STRICT_FAST_PATH"} == set(ops.ENV_ROUTE_SWITCHES), read
+    g = Hh.load_golden(golden_dir, "sgg_full.npz")
+    cfg_dict, shapes = json.loads(str(g["cfg"])), json.loads(str(g["shapes"]))
+    model, cfg, sd = Hh.build_product_model(cfg_dict, shapes, int(g["seed"]))
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    rng = W.rng_inputs(int(g["input_seed"]))
+    pv = torch.from_numpy(rng.standard_normal((1, 3, 600, 1000))).float().to(DEV)
+    pm = torch.ones(1, 600, 1000, dtype=torch.long, device=DEV)
+    base = Hh.product_heads(model, pv, pm)
+    for mod, name in ((decoder_fused, "ENABLED"), (ops, "GEMM_SPLIT_BF16"), (ops, "REL_HEAD_SPLIT_BF16"), (ops, "FFN_FUSED"),
+                      (backbone, "NHWC_F32"), (backbone, "NHWC_BF16")):
+        assert getattr(mod, name) is True, name
+        monkeypatch.setattr(mod, name, False)
+    h = Hh.product_heads(model, pv, pm)
+    tol = 1e-3
+    assert (h["logits"].cpu() - _t(g["logits"])).abs().max() < tol
+    assert (h["pred_boxes"].cpu() - _t(g["pred_boxes"])).abs().max() < tol
+    assert (h["last_hidden"].cpu() - _t(g["last_hidden"])).abs().max() < tol
+    assert (h["conn_logits"].cpu()[..., 0] - _t(g["conn_logits"])).abs().max() < tol
+    for key in ("logits", "pred_boxes", "last_hidden", "conn_logits"):
         assert (h[key] - base[key]).abs().max() < 2e-4, key
     rm = lambda x: Hh.rel_mlp_from_logits(x["rel_logits"], x["logits"], model.triplet_dist)  # noqa: E731
     assert (rm(h) - rm(base)).abs().max() < 2e-4
@@ -367,7 +404,7 @@ def test_train_step_with_each_training_fusion_switched_off_vs_reference(golden_d
     """The training twin of test_full_size_with_each_fusion_switched_off_vs_reference: every training-path fusion has a switch
     (EGTR_<...>=0) that restores the composition it replaced, and that route must hold the reference's 600x1000 train
     fixture too.  ENCODER_TRAIN_FUSED off exposes the per-op route of rounds 2 / 3, on which the other switches act -- so each
-    of them is flipped together with it.  (EGTR_BACKBONE_TRAIN_FUSED has its own two-route test:
+    of them is flipped together with it.  (backbone.TRAIN_FUSED_EPILOGUE has its own two-route test:
     test_bottleneck_training_fused_epilogue_matches_reference_order; the fixture's backbone is the stub.)"""
     import egtr_amd.backbone as backbone
     from egtr_amd import ops
@@ -544,7 +581,7 @@ def test_triplet_candidates_on_device_match_reference_postprocessing():
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_backbone_channels_last_path_matches_nchw_path(dtype, monkeypatch):
     """The channels-last inference path of the backbone (MIOpen NHWC convolutions, 1x1 convolutions as GEMMs with bias / ReLU
-    epilogues, egtr_bias_act_nhwc_*) against the NCHW folded path (EGTR_BACKBONE_NHWC_*=0): the same three feature maps, returned
+    epilogues, egtr_bias_act_nhwc_*) against the NCHW folded path (EGTR_BACKBONE_NHWC=0): the same three feature maps, returned
     as channels-last tensors; fp32 to convolution-algorithm rounding, bf16 to a few bf16 ulps of the map's scale.  Odd sizes."""
     import egtr_amd.backbone as bb
     torch.manual_seed(2)
@@ -820,7 +857,7 @@ def test_bottleneck_training_fused_epilogue_matches_reference_order(downsample, 
 def test_backbone_training_scales_all_weights_in_one_launch():
     """ResNet50Features in training: the frozen-BN scale of every trainable convolution applied to its weight by ONE multi-tensor
     launch (backbone.ScaleWeightsFunction over egtr_scale_rows_multi_f32), the weight gradients scaled back by one more --
-    outputs, input gradient and every parameter gradient equal the per-weight `w * scale` route (EGTR_BACKBONE_SCALE_FUSED=0)
+    outputs, input gradient and every parameter gradient equal the per-weight `w * scale` route (backbone.SCALE_WEIGHTS_FUSED = False)
     bit for bit (the same fp32 products), and the kernel against torch on ragged tensor lists (65 tensors: two launches)."""
     import egtr_amd.backbone as bb
     from egtr_amd import ops
