@@ -35,6 +35,7 @@ SIGNATURES = {
     "egtr_msda_forward_bf16": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "egtr_msda_forward_fused_bf16": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     "egtr_self_attn_forward_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "egtr_self_attn_forward_bf16": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "egtr_self_attn_backward_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "egtr_self_attn_backward_acc_f32": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "egtr_linear_f32": [_P, _P, _P, _P, _P, _I, _I, _I, ctypes.c_float, _I],

@@ -54,16 +54,57 @@ __device__ __forceinline__ void load_frag8(const float* __restrict__ base, int N
   f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
 }
 
+// bf16 storage (the bf16 model's decoder, inference): the same kernel reads / writes raw bfloat16 and computes in fp32 -- widening
+// is exact, the output is rounded to nearest even once, the retained maps are bit copies of the inputs.  (Round 5 ran the fp32
+// kernel between three widening and three narrowing cast launches per layer: ~0.5 ms of a 24.8 ms stress forward.)
+__device__ __forceinline__ float bf16_up(uint16_t u) { return __uint_as_float((unsigned)u << 16); }
+__device__ __forceinline__ uint16_t bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ void load_frag8(const uint16_t* __restrict__ base, int N, int MD, int b, int row, int h, int g,
+                                           float (&f)[8]) {
+  const int r = min(row, N - 1);
+  const uint4 a = *reinterpret_cast<const uint4*>(base + ((size_t)b * N + r) * MD + h * 32 + g * 8);
+  f[0] = __uint_as_float(a.x << 16); f[1] = __uint_as_float(a.x & 0xffff0000u);
+  f[2] = __uint_as_float(a.y << 16); f[3] = __uint_as_float(a.y & 0xffff0000u);
+  f[4] = __uint_as_float(a.z << 16); f[5] = __uint_as_float(a.z & 0xffff0000u);
+  f[6] = __uint_as_float(a.w << 16); f[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const uint16_t* p) { return bf16_up(*p); }
+__device__ __forceinline__ void store8(float* p, const float (&f)[8]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+__device__ __forceinline__ void store8(uint16_t* p, const float (&f)[8]) {   // (values that came from bf16: exact)
+  uint4 o;
+  o.x = (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);
+  o.y = (__float_as_uint(f[2]) >> 16) | (__float_as_uint(f[3]) & 0xffff0000u);
+  o.z = (__float_as_uint(f[4]) >> 16) | (__float_as_uint(f[5]) & 0xffff0000u);
+  o.w = (__float_as_uint(f[6]) >> 16) | (__float_as_uint(f[7]) & 0xffff0000u);
+  *reinterpret_cast<uint4*>(p) = o;
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store4(uint16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)bf16_rne(a) | ((unsigned)bf16_rne(b) << 16),
+                                            (unsigned)bf16_rne(c) | ((unsigned)bf16_rne(d) << 16));
+}
+
 // Forward.  The keys are split over KS waves of one workgroup (wave w takes key tiles w, w + KS, ...; NTW = tiles per
 // wave held in registers): with ONE wave per (b, head, 16-query tile) the kernel was a single dependent chain of
 // 13 x (K-tile load -> 8 MFMAs) + 104 x (V load -> MFMA) -- 15.4 us per launch for 41 MFLOP with only 104 waves on the
 // chip; split four ways 11 us (226.9 vs 225.6 images/s end to end).  Each wave keeps its own running
 // maximum / sum / unnormalised output and the partial results are merged lane by lane through LDS
 // (O = sum_w O_w e^{m_w - M} / sum_w s_w e^{m_w - M}); the softmax is exact as before, only the summation order differs.
-template <int NTW, int KS>
+template <int NTW, int KS, typename T = float>
 __global__ __launch_bounds__(64 * KS) void self_attn_fwd_split_f32(
-    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ out,
-    float* __restrict__ q_heads, float* __restrict__ k_heads, float* __restrict__ lse, int B, int N, int M) {
+    const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
+    T* __restrict__ q_heads, T* __restrict__ k_heads, float* __restrict__ lse, int B, int N, int M) {
   __shared__ float s_part[KS][10][64];  // [wave][o0[0..3], o1[0..3], max, sum][lane]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
   const int ntile = (N + 15) >> 4;
@@ -78,15 +119,11 @@ __global__ __launch_bounds__(64 * KS) void self_attn_fwd_split_f32(
   load_frag8(q, N, MD, b, q0 + c, h, g, qf);
   if (wave == 0 && (q_heads != nullptr || k_heads != nullptr) && q0 + c < N) {
     const size_t o = (((size_t)b * M + h) * N + q0 + c) * 32 + g * 8;
-    if (q_heads) {
-      reinterpret_cast<float4*>(q_heads + o)[0] = make_float4(qf[0], qf[1], qf[2], qf[3]);
-      reinterpret_cast<float4*>(q_heads + o)[1] = make_float4(qf[4], qf[5], qf[6], qf[7]);
-    }
+    if (q_heads) store8(q_heads + o, qf);
     if (k_heads) {
       float kf0[8];
       load_frag8(k, N, MD, b, q0 + c, h, g, kf0);
-      reinterpret_cast<float4*>(k_heads + o)[0] = make_float4(kf0[0], kf0[1], kf0[2], kf0[3]);
-      reinterpret_cast<float4*>(k_heads + o)[1] = make_float4(kf0[4], kf0[5], kf0[6], kf0[7]);
+      store8(k_heads + o, kf0);
     }
   }
 
@@ -131,9 +168,9 @@ __global__ __launch_bounds__(64 * KS) void self_attn_fwd_split_f32(
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int key = min(k0 + g * 4 + t, N - 1);
-        const float* vp = v + ((size_t)b * N + key) * MD + h * 32 + c;
-        o0 = mfma16(vp[0], s[i][t], o0);
-        o1 = mfma16(vp[16], s[i][t], o1);
+        const T* vp = v + ((size_t)b * N + key) * MD + h * 32 + c;
+        o0 = mfma16(ld1(vp), s[i][t], o0);
+        o1 = mfma16(ld1(vp + 16), s[i][t], o1);
       }
     }
   }
@@ -159,9 +196,9 @@ __global__ __launch_bounds__(64 * KS) void self_attn_fwd_split_f32(
     for (int r = 0; r < 8; ++r) o[r] += s_part[w][r][lane] * f;
   }
   const float inv = 1.f / tot;
-  float* op = out + ((size_t)b * N + q0 + c) * MD + h * 32 + g * 4;
-  *reinterpret_cast<float4*>(op) = make_float4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-  *reinterpret_cast<float4*>(op + 16) = make_float4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
+  T* op = out + ((size_t)b * N + q0 + c) * MD + h * 32 + g * 4;
+  store4(op, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+  store4(op + 16, o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv);
   if (lse != nullptr && g == 0) lse[((size_t)b * M + h) * N + q0 + c] = mall + __logf(tot);
 }
 
@@ -338,6 +375,27 @@ extern "C" int egtr_self_attn_forward_f32(egtr_stream_t stream, const float* q, 
   else
     hipLaunchKernelGGL((self_attn_fwd_split_f32<10, 4>), grid, block, 0, st, q, k, v, out, q_heads, k_heads, lse, batch,
                        num_query, num_heads);
+  return egtr_check_launch();
+}
+
+extern "C" int egtr_self_attn_forward_bf16(egtr_stream_t stream, const uint16_t* q, const uint16_t* k, const uint16_t* v,
+                                           int batch, int num_query, int num_heads, int head_dim, uint16_t* out,
+                                           uint16_t* q_heads, uint16_t* k_heads) {
+  if (!q || !k || !v || !out) return EGTR_E_ARG;
+  if (batch <= 0 || num_query <= 0 || num_heads <= 0) return EGTR_E_ARG;
+  if (head_dim != 32 || num_query > 16 * 40) return EGTR_E_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) |
+       reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(q_heads) | reinterpret_cast<uintptr_t>(k_heads)) & 15)
+    return EGTR_E_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nt = (num_query + 15) / 16;
+  const dim3 grid(batch * num_heads * nt), block(256);
+  if (nt <= 16)
+    hipLaunchKernelGGL((self_attn_fwd_split_f32<4, 4, uint16_t>), grid, block, 0, st, q, k, v, out, q_heads, k_heads,
+                       (float*)nullptr, batch, num_query, num_heads);
+  else
+    hipLaunchKernelGGL((self_attn_fwd_split_f32<10, 4, uint16_t>), grid, block, 0, st, q, k, v, out, q_heads, k_heads,
+                       (float*)nullptr, batch, num_query, num_heads);
   return egtr_check_launch();
 }
 

@@ -200,10 +200,14 @@ def run(decoder, hidden_states, position_embeddings, reference_input, values, va
     def is_weight(t):   # a view of a module parameter (the learned query table), not a per-call activation
         return isinstance(base(t), torch.nn.Parameter)
 
-    if x_rows == N and pos_rows == N and is_weight(hidden_states) and is_weight(position_embeddings):
+    # ``first_with_pos`` is handed in by DeformableDetrModel.forward exactly when its inputs are DERIVED CONSTANTS of the query
+    # table (ops.cached_weights "query_tables": tensors that live as long as the weights do)
+    constant_inputs = first_with_pos is not None or (is_weight(hidden_states) and is_weight(position_embeddings))
+    if x_rows == N and pos_rows == N and constant_inputs:
         # both operands are rows of the query table (batch expansions): the projections are derived constants, keyed on the
         # tensors the views were cut from and on the views' geometry.  Fresh ``inputs_embeds`` at B == 1 also have N rows but
-        # are not parameters: caching those would pin one never-hit entry per call -- they take qkv0() directly
+        # are neither parameters nor the model's cached tables: caching those would pin one never-hit entry per call
+        #  -- they take qkv0() directly
         srcs = [lay0.q_proj.weight, lay0.q_proj.bias, lay0.k_proj.weight, lay0.k_proj.bias, lay0.v_proj.weight,
                 lay0.v_proj.bias, base(hidden_states), base(position_embeddings)]
         name = f"decoder_cluster_qkv0:{x0.data_ptr()}:{pos.data_ptr()}:{with_pos0 is not None}"

@@ -201,7 +201,20 @@ class DecoderSelfAttentionFunction(Function):
 
 
 def decoder_self_attention(q, k, v, num_heads, want_maps=True):
-    if q.dtype != torch.float32:  # bf16 / fp16 models: the kernel computes in fp32, results go back to the model dtype
+    if (q.dtype == torch.bfloat16 and q.is_cuda and k.dtype == v.dtype == torch.bfloat16 and q.shape[-1] == 32 * num_heads
+            and q.shape[1] <= 640 and not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad))):
+        # bf16 model at inference: the kernel reads and writes bf16 itself (fp32 arithmetic) -- no cast launches around it
+        lib = _lib.lib()
+        B, N, MD = q.shape
+        q2, k2, v2 = (t if (t.is_contiguous() and t.data_ptr() % 16 == 0) else t.contiguous() for t in (q, k, v))
+        out = torch.empty_like(q2)
+        qh = torch.empty(B, num_heads, N, 32, dtype=q.dtype, device=q.device) if want_maps else None
+        kh = torch.empty_like(qh) if want_maps else None
+        _lib.check(lib.egtr_self_attn_forward_bf16(_stream(), q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), B, N, num_heads, 32,
+                                                   out.data_ptr(), qh.data_ptr() if want_maps else None,
+                                                   kh.data_ptr() if want_maps else None), "egtr_self_attn_forward_bf16")
+        return out, qh, kh
+    if q.dtype != torch.float32:  # fp16 models / bf16 under autograd: the kernel computes in fp32, results go back to the model dtype
         o, qm, km = DecoderSelfAttentionFunction.apply(q.float().contiguous(), k.float().contiguous(),
                                                        v.float().contiguous(), num_heads, want_maps)
         return o.to(q.dtype), (qm.to(q.dtype) if qm is not None else None), (km.to(q.dtype) if km is not None else None)
@@ -910,7 +923,7 @@ class DecoderLayerTrainFunction(Function):
         M = B * N
         dev = x.device
         x2 = _rows256(x.detach())
-        pos2 = _rows256(pos.detach().expand(B, N, D)) if tuple(pos.shape) != (B, N, D) else _rows256(pos.detach())
+        pos3 = pos.detach()          # [B, N, D], usually a stride-0 batch expansion of the query table: added as it is (no copy)
         heads = 8
         d = [t.detach() for t in (wq, bq, wk, bk, wv, bv, wo, bo, ln1w, ln1b, wso, bso, waw, baw, wop, bop, ln2w, ln2b, w1, b1,
                                   w2, b2, ln3w, ln3b)]
@@ -927,7 +940,7 @@ class DecoderLayerTrainFunction(Function):
             m1 = m2 = m3 = None
         e1, e2, e3 = (float(v) for v in eps3)
         # ---- self-attention
-        xp = x2 + pos2
+        xp = _rows256(x2.view(B, N, D) + pos3)
         q = _skinny_fwd(xp, wq_, bq_, alpha=scaling)
         k = _skinny_fwd(xp, wk_, bk_)
         v = _skinny_fwd(x2, wv_, bv_)
@@ -938,7 +951,7 @@ class DecoderLayerTrainFunction(Function):
         a = _skinny_fwd(sa, wo_, bo_)
         y1 = dropout_add_layernorm(a, x2, m1, scale, g1, be1, e1)
         # ---- cross-attention (MSDA over the encoder's value projection)
-        y1p = y1 + pos2
+        y1p = _rows256(y1.view(B, N, D) + pos3)
         off = _skinny_fwd(y1p, wso_, bso_)
         lg = _skinny_fwd(y1p, waw_, baw_)
         L = shapes.shape[0]

@@ -167,6 +167,12 @@ int egtr_self_attn_forward_f32(egtr_stream_t stream, const float* q, const float
                                int num_query, int num_heads, int head_dim, float* out, float* q_heads,
                                float* k_heads, float* lse);
 
+/* The same on raw bfloat16 tensors (the bf16 model's decoder at inference): fp32 arithmetic, out rounded to nearest even, the
+ * retained maps bit copies of q / k.  16-byte aligned operands. */
+int egtr_self_attn_forward_bf16(egtr_stream_t stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, int batch,
+                                int num_query, int num_heads, int head_dim, uint16_t* out, uint16_t* q_heads,
+                                uint16_t* k_heads);
+
 /* grads wrt q, k, v ([B, N, M*D] each, fully overwritten) from grad_out [B,N,M*D], the forward's out and lse. */
 int egtr_self_attn_backward_f32(egtr_stream_t stream, const float* q, const float* k, const float* v,
                                 const float* out, const float* lse, const float* grad_out, int batch,

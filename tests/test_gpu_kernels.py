@@ -1726,3 +1726,21 @@ def test_ffn_layernorm_bf16_fused(M, F, prow):
     assert float(((y.double() - w64).abs() / w64.abs().clamp_min(1.0)).max()) < 3e-2
     if prow:
         assert torch.equal(yp, y + pos.repeat(M // prow, 1).view(1, M, 256))
+
+
+@pytest.mark.parametrize("B,N", [(2, 300), (16, 300), (1, 37), (3, 200)])
+def test_self_attention_bf16_entry_equals_the_fp32_kernel_on_widened_operands(B, N):
+    """egtr_self_attn_forward_bf16 (round 6: the bf16 model's decoder without cast launches around the fp32 kernel; reference
+    math dd:1170-1253): the SAME arithmetic in the same order on the exactly widened operands, so the output is the fp32
+    kernel's output rounded to bf16 once (bit-identical), and the retained maps are bit copies of q / k in [B, M, N, D]."""
+    from egtr_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    q, k, v = ((torch.randn(B, N, 256, generator=g) * s).bfloat16().to(DEV) for s in (0.4, 1.0, 1.0))
+    out, qh, kh = ops.decoder_self_attention(q, k, v, 8, want_maps=True)
+    assert out.dtype == qh.dtype == kh.dtype == torch.bfloat16
+    ref, rq, rk = ops.DecoderSelfAttentionFunction.apply(q.float(), k.float(), v.float(), 8, True)
+    assert torch.equal(out, ref.bfloat16())
+    assert torch.equal(qh, rq.bfloat16()) and torch.equal(kh, rk.bfloat16())
+    assert torch.equal(qh, q.view(B, N, 8, 32).transpose(1, 2))
+    out2, none_q, none_k = ops.decoder_self_attention(q, k, v, 8, want_maps=False)
+    assert torch.equal(out2, out) and none_q is None and none_k is None
