@@ -33,7 +33,8 @@ class GraphedForward:
     shape seen before replays its own graph -- own static inputs, own outputs, own private memory pool (a 600x1000 fp32
     forward holds < 0.5 GB; sixteen of them are noise in 288 GB of HBM) -- and only a NEW shape pays the two eager
     warm-up runs + capture (the warm-up runs are also what lets MIOpen / TunableOp pick their kernels for the new
-    convolution / GEMM shapes outside the capture).  The least recently used graph is dropped when the table is full.
+    convolution / GEMM shapes outside the capture).  The least recently used graph is dropped when the table is full;
+    ``capture_after = k`` defers a shape's capture until it is seen for the k-th time (eager launches before that).
 
     **Weights.**  A captured graph bakes in pointers to DERIVED tensors built at capture time (folded-BN backbone weights,
     stacked / concatenated projection weights, query tables).  The table is therefore tagged with a weight EPOCH: the full
@@ -52,7 +53,8 @@ class GraphedForward:
     synchronisation (``decoder_fused.poll_status``: asynchronous copy now, verdict at the next poll); a cluster barrier
     that timed out raises ``DecoderClusterError`` instead of handing out void decoder states."""
 
-    def __init__(self, model, enabled=True, warmup=2, strict=False, max_graphs=16, verify_every=256, status_every=64):
+    def __init__(self, model, enabled=True, warmup=2, strict=False, max_graphs=16, verify_every=256, status_every=64,
+                 capture_after=1):
         self.model = model
         self.enabled = enabled
         self.warmup = warmup
@@ -60,6 +62,12 @@ class GraphedForward:
         self.max_graphs = max(1, int(max_graphs))
         self.verify_every = max(1, int(verify_every))
         self.status_every = max(1, int(status_every))
+        # a shape is captured when it is seen for the `capture_after`-th time and runs eagerly before that: a dataloader with
+        # hundreds of distinct shapes (every long side between 600 and 1000) should not pay ~1.5 s of warm-up + capture for
+        # a shape it meets once -- raise it (and `max_graphs`: sixteen graphs are ~6 GB of the 288) for such streams
+        self.capture_after = max(1, int(capture_after))
+        self._seen = collections.Counter()
+        self.eager_calls = 0
         self._entries = collections.OrderedDict()   # key -> _GraphEntry, least recently used first
         self._tensors = None
         self._sentinels = None
@@ -202,6 +210,11 @@ class GraphedForward:
             self._drop_all()      # every graph holds constants derived from the old weights
         key = self._key(pv, pm)
         entry = self._entries.get(key)
+        if entry is None and self.capture_after > 1:
+            self._seen[key] += 1
+            if self._seen[key] < self.capture_after:
+                self.eager_calls += 1
+                return self._eager(pv, pm)
         if entry is None:
             try:
                 entry = self._capture(pv, pm)
@@ -451,7 +464,7 @@ def private_miopen_db():
 
 
 @torch.no_grad()
-def calculate_fps(model, batches, warmup=3, graphed=True, max_graphs=16, forward=None):
+def calculate_fps(model, batches, warmup=3, graphed=True, max_graphs=16, forward=None, capture_after=1):
     """evaluate_egtr.py:26-36 with warm-up and synchronisation (the reference's loop has neither).
 
     ``graphed=True`` (GPU): every batch goes through a ``GraphedForward`` -- one captured HIP graph per distinct image
@@ -459,12 +472,14 @@ def calculate_fps(model, batches, warmup=3, graphed=True, max_graphs=16, forward
     ``--min_size``, long side <= ``--max_size``) runs at graph-replay speed once each shape has been seen.  When ``batches``
     is a sequence its distinct shapes are captured BEFORE the clock starts (their two eager warm-up runs + capture are the
     analogue of the reference's cudnn autotuning on a new shape); for a plain iterator the first occurrence of a shape is
-    inside the timed region.  ``forward``: an existing ``GraphedForward`` to reuse.  ``graphed=False``: eager launches."""
+    inside the timed region.  ``forward``: an existing ``GraphedForward`` to reuse.  ``graphed=False``: eager launches.
+    A real evaluation set has hundreds of distinct shapes: raise ``max_graphs`` (a 600x1000 graph holds < 0.5 GB of the 288 GB)
+    and / or ``capture_after`` (eager until a shape comes back) accordingly."""
     import time
     model.eval()
     fwd = forward
     if fwd is None and graphed and torch.cuda.is_available():
-        fwd = GraphedForward(model, enabled=True, strict=False, max_graphs=max_graphs)
+        fwd = GraphedForward(model, enabled=True, strict=False, max_graphs=max_graphs, capture_after=capture_after)
 
     def run(batch):
         pv, pm = batch["pixel_values"].cuda(non_blocking=True), batch["pixel_mask"].cuda(non_blocking=True)

@@ -789,6 +789,16 @@ def test_graph_cache_replays_across_shape_changes_equal_eager():
     fps = calculate_fps(model, batches, warmup=1, forward=fwd)
     assert fps > 0 and fwd.captures == 3 and fwd.evictions == 0
     assert calculate_fps(model, batches, warmup=1, graphed=False) > 0
+    # capture_after = 2: a shape runs eagerly the first time it is seen and is captured on its second visit
+    lazy = GraphedForward(model, enabled=True, strict=True, capture_after=2)
+    for i, (h, w) in enumerate([(160, 224), (128, 256), (160, 224), (160, 224)]):
+        pv = torch.randn(1, 3, h, w, device=DEV)
+        pm = torch.ones(1, h, w, dtype=torch.long, device=DEV)
+        with torch.no_grad():
+            e = model(pixel_values=pv, pixel_mask=pm, output_attention_states=True)
+        r = lazy(pv, pm)
+        assert (r.pred_rel - e.pred_rel).abs().max() < 1e-5
+        assert (lazy.captures, lazy.eager_calls) == [(0, 1), (0, 2), (1, 2), (1, 2)][i]
 
 
 def test_postprocessing_on_device_vs_reference_fixture(golden_dir):
