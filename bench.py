@@ -1009,13 +1009,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # EGTR_BENCH_BACKEND=gloo: the whole world > 1 code path (replica inference, DDP train leg, all-reduce timer) on a box with
+    # FEWER GPUs than ranks -- ranks share devices (local_rank % device_count) and the collectives go through gloo.  A
+    # self-test of the bench's own plumbing (this pool hands out one-GPU boxes), never a performance number: the line says so.
+    backend = os.environ.get("EGTR_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     if rank == 0 and world != args.gpus:
         print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE = {world}: reporting n_gpus = {world}",
               file=sys.stderr)
@@ -1098,6 +1106,8 @@ def main():
                          / (msda_us * 1e-6) / 1e9 / l1_ceiling_gbs, 3)},
         "rccl_ranks": args.rccl_ranks, "rank_ms_per_step": spread,
     }
+    if world > 1 and backend != "nccl":
+        result["config"]["collective_backend"] = f"{backend} (plumbing self-test: ranks share GPUs; not a performance number)"
     from egtr_amd import ops as _ops
     split = bool(_ops.REL_HEAD_SPLIT_BF16) and rel_args[1].get("owner") is not None
     busy, busy_src = newest_mfma_busy()
