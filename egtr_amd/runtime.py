@@ -54,7 +54,7 @@ class GraphedForward:
     that timed out raises ``DecoderClusterError`` instead of handing out void decoder states."""
 
     def __init__(self, model, enabled=True, warmup=2, strict=False, max_graphs=16, verify_every=256, status_every=64,
-                 capture_after=1):
+                 capture_after=1, bucket=None):
         self.model = model
         self.enabled = enabled
         self.warmup = warmup
@@ -66,6 +66,13 @@ class GraphedForward:
         # hundreds of distinct shapes (every long side between 600 and 1000) should not pay ~1.5 s of warm-up + capture for
         # a shape it meets once -- raise it (and `max_graphs`: sixteen graphs are ~6 GB of the 288) for such streams
         self.capture_after = max(1, int(capture_after))
+        # bucket = k (opt-in): images are placed in the top-left corner of a zero canvas whose height and width are rounded up
+        # to multiples of k, the rest masked out in pixel_mask -- exactly what the reference's collate does to the smaller
+        # images of a BATCH (DetrFeatureExtractor.pad_and_create_pixel_mask) -- so that a dataset with hundreds of distinct
+        # sizes needs a few dozen graphs (k = 32: <= 14 long sides for short side 600 / long side 600..1000, x 2
+        # orientations).  Outputs are those of the padded forward (normalised boxes refer to the VALID region through the
+        # valid ratios, as in batched inference), not bit-identical to the unpadded one.
+        self.bucket = int(bucket) if bucket else None
         self._seen = collections.Counter()
         self.eager_calls = 0
         self._entries = collections.OrderedDict()   # key -> _GraphEntry, least recently used first
@@ -197,6 +204,18 @@ class GraphedForward:
             self(torch.zeros(*shp, dtype=dtype, device=device), torch.ones(b, h, w, dtype=torch.long, device=device))
         return self.captures - before
 
+    def _to_bucket(self, pv, pm):
+        k = self.bucket
+        h, w = pv.shape[-2:]
+        hb, wb = -(-h // k) * k, -(-w // k) * k
+        if (hb, wb) == (h, w):
+            return pv, pm
+        cpv = pv.new_zeros(*pv.shape[:-2], hb, wb)
+        cpv[..., :h, :w] = pv
+        cpm = pm.new_zeros(*pm.shape[:-2], hb, wb)
+        cpm[..., :h, :w] = pm
+        return cpv, cpm
+
     def _poll_decoder_status(self, device):
         from . import decoder_fused
         decoder_fused.poll_status(device)
@@ -205,6 +224,8 @@ class GraphedForward:
     def __call__(self, pv, pm):
         if not self.enabled:
             return self._eager(pv, pm)
+        if self.bucket:
+            pv, pm = self._to_bucket(pv, pm)
         self._calls += 1
         if self._weights_changed():
             self._drop_all()      # every graph holds constants derived from the old weights

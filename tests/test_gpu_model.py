@@ -789,6 +789,19 @@ def test_graph_cache_replays_across_shape_changes_equal_eager():
     fps = calculate_fps(model, batches, warmup=1, forward=fwd)
     assert fps > 0 and fwd.captures == 3 and fwd.evictions == 0
     assert calculate_fps(model, batches, warmup=1, graphed=False) > 0
+    # bucket = 32: sizes are rounded up on a zero canvas with the rest masked out (the reference's batch collate); three
+    # different sizes share ONE graph and every replay equals the eager forward of the explicitly padded input
+    bk = GraphedForward(model, enabled=True, strict=True, bucket=32)
+    for (h, w) in [(150, 200), (160, 224), (131, 193)]:
+        pv = torch.randn(1, 3, h, w, device=DEV)
+        pm = torch.ones(1, h, w, dtype=torch.long, device=DEV)
+        cpv, cpm = torch.zeros(1, 3, 160, 224, device=DEV), torch.zeros(1, 160, 224, dtype=torch.long, device=DEV)
+        cpv[..., :h, :w], cpm[:, :h, :w] = pv, pm
+        with torch.no_grad():
+            e = model(pixel_values=cpv, pixel_mask=cpm, output_attention_states=True)
+        r = bk(pv, pm)
+        assert (r.pred_rel - e.pred_rel).abs().max() < 1e-5 and (r.pred_boxes - e.pred_boxes).abs().max() < 1e-5
+    assert bk.captures == 1
     # capture_after = 2: a shape runs eagerly the first time it is seen and is captured on its second visit
     lazy = GraphedForward(model, enabled=True, strict=True, capture_after=2)
     for i, (h, w) in enumerate([(160, 224), (128, 256), (160, 224), (160, 224)]):
