@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench -- python3 bench.py > gpurun_out/${tag}_bench_rocprofv3.log 2>&1
 grep -E '^\{"metric"' gpurun_out/${tag}_bench_rocprofv3.log > gpurun_out/${tag}_bench_under_rocprofv3.json
-python3 tools/rocpd_stats.py gpurun_out/prof_bench/bench_results.db --top 60 --split-grid msda_fwd_q64:1000 > gpurun_out/${tag}_bench_kernel_stats.txt 2>&1
+python3 tools/rocpd_stats.py gpurun_out/prof_bench/bench_results.db --top 60 --split-grid msda_fwd_q64:1000 --exact-grid msda_fwd_q64:3135 > gpurun_out/${tag}_bench_kernel_stats.txt 2>&1
 rm -rf gpurun_out/prof_bench
 bash tools/train_gaps.sh ${tag} > /dev/null 2>&1
 bash tools/pmc_bench.sh ${tag} > /dev/null 2>&1

@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--split-grid", default=None,
                     help="NAME:THRESHOLD -- report kernels whose name contains NAME separately for launches with at "
                          "least THRESHOLD workgroups (e.g. msda_fwd_q64:1000 = the encoder-shaped MSDA launches)")
+    ap.add_argument("--exact-grid", default=None,
+                    help="NAME:WORKGROUPS -- the launches of kernels whose name contains NAME with EXACTLY that many workgroups "
+                         "(msda_fwd_q64:3135 = the encoder launch of the bench workload, 12 537 queries / 4 per workgroup; the "
+                         "default bench command also launches the kernel at the training batch and at the mixed image shapes)")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
     rows = c.execute("select name, start, end from kernels").fetchall()
@@ -45,6 +49,18 @@ def main():
                 if v:
                     print(f"{nm} launches with {lab}: n = {len(v)}, average {sum(v) / len(v) / 1e3:.2f} us, "
                           f"min {min(v) / 1e3:.2f} us, max {max(v) / 1e3:.2f} us")
+    if a.exact_grid:
+        nm, want = a.exact_grid.rsplit(":", 1)
+        cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+        gx = next((x for x in ("grid_x", "grid_size_x", "grid_size") if x in cols), None)
+        wx = next((x for x in ("workgroup_x", "workgroup_size_x", "workgroup_size") if x in cols), None)
+        if gx is not None:
+            q = f"select name, start, end, {gx}, {wx if wx else 1} from kernels"
+            v = [(e - s_) for n, s_, e, g, w in c.execute(q) if nm in n and (g // max(int(w), 1)) == int(want)]
+            if v:
+                v.sort()
+                print(f"{nm} launches with exactly {want} workgroups: n = {len(v)}, average {sum(v) / len(v) / 1e3:.2f} us, "
+                      f"median {v[len(v) // 2] / 1e3:.2f} us, min {v[0] / 1e3:.2f} us, max {v[-1] / 1e3:.2f} us")
     if a.last_ms > 0 and rows:
         t_end = max(r[2] for r in rows)
         rows = [r for r in rows if r[1] >= t_end - a.last_ms * 1e6]
