@@ -27,7 +27,15 @@ def _chk(t, name, dtype=None):
     return t
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The raw handle of torch's current stream on the current device.  Every launch through the C ABI asks for it (~60 per
+    eager forward): the private raw accessor answers in ~0.3 us, ``torch.cuda.current_stream().cuda_stream`` builds a Stream
+    object first (~6 us: 0.4 ms of host time per forward, and the eager forward is host-bound)."""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

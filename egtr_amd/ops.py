@@ -1099,6 +1099,7 @@ def invalidate_derived(model):
             m.__dict__["_egtr_derived"].clear()
         if "_folded" in m.__dict__:
             m.__dict__["_folded"] = None
+        m.__dict__.pop("_fold_full", None)
 
 
 # ---- the environment switches of the package (round 6: seven route switches, down from twenty-four) ----------------------------
