@@ -62,7 +62,8 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
   __shared__ __attribute__((aligned(16))) int4 s_off[kWaves * kWaveEntries];
   __shared__ __attribute__((aligned(16))) float4 s_w[kWaves * kWaveEntries];
   __shared__ unsigned s_bits[FUSED ? kMaxBitWords : 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a scalar: the query, its image, its mask row and the branches on them become wave-uniform)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int blk = xcd_remap(blockIdx.x, nblk);
   const int q = SPLIT ? blk : blk * kWaves + wave;
   const int nwords = (S + 31) >> 5;
@@ -94,20 +95,25 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
                        r.y + lc.w / fp * r.w * 0.5f);
     } else {
       const float2 r = *reinterpret_cast<const float2*>(ref + ((size_t)q * L + lvl) * 2);
-      const float fw = (float)SEL_W(G, lvl), fh = (float)SEL_H(G, lvl);
-      lc = make_float4(r.x + lc.x / fw, r.y + lc.y / fh, r.x + lc.z / fw, r.y + lc.w / fh);
+      // round 6: reciprocal multiplies and the hardware exponential below (as the bf16 kernel since round 5).  The counters
+      // (profiles/r06_sq_pmc.txt) put this kernel at 809 VALU instructions per query of which the gather loop is 180: four
+      // IEEE divisions, two expf and two more divisions per lane were ~150 of the rest.  1-2 ulp of fp32 against the
+      // reference's `offset / normalizer` and softmax: 1e-7 pixels / 1e-7 of a weight.
+      const float iw = __frcp_rn((float)SEL_W(G, lvl)), ih = __frcp_rn((float)SEL_H(G, lvl));
+      lc = make_float4(r.x + lc.x * iw, r.y + lc.y * ih, r.x + lc.z * iw, r.y + lc.w * ih);
     }
     // softmax over the 16 logits of the head: 8 lanes x 2
     float m = fmaxf(aw.x, aw.y);
     m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xf, 0xf, false)));
     m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xf, 0xf, false)));
     m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xf, 0xf, false)));
-    const float e0 = expf(aw.x - m), e1 = expf(aw.y - m);
+    const float e0 = __expf(aw.x - m), e1 = __expf(aw.y - m);
     float sum = e0 + e1;
     sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0xB1, 0xf, 0xf, false));
     sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x4E, 0xf, 0xf, false));
     sum += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum), 0x141, 0xf, 0xf, false));
-    aw = make_float2(e0 / sum, e1 / sum);
+    const float inv_sum = __frcp_rn(sum);
+    aw = make_float2(e0 * inv_sum, e1 * inv_sum);
     if (attn_out != nullptr && (!SPLIT || wave == 0)) reinterpret_cast<float2*>(attn_out + (size_t)q * 128)[lane] = aw;
   }
   int4* my_off = s_off + wave * kWaveEntries;
@@ -124,24 +130,27 @@ __global__ __launch_bounds__(kWaves * 64) void msda_fwd_q64_f32(
     // is the same sum and saves a pass over the value tensor)
     if (FUSED && keep_bits != nullptr) {
       const int p0 = g.off[0] >> 10, p1 = g.off[1] >> 10, p2 = g.off[2] >> 10, p3 = g.off[3] >> 10;
+      // (bitwise, not short-circuit: the clamped offsets are always readable, and four independent reads beat four branches)
+      unsigned w0, w1, w2, w3;
       if (bits_in_lds) {
-        k0 = k0 && ((s_bits[p0 >> 5] >> (p0 & 31)) & 1u);
-        k1 = k1 && ((s_bits[p1 >> 5] >> (p1 & 31)) & 1u);
-        k2 = k2 && ((s_bits[p2 >> 5] >> (p2 & 31)) & 1u);
-        k3 = k3 && ((s_bits[p3 >> 5] >> (p3 & 31)) & 1u);
+        w0 = s_bits[p0 >> 5]; w1 = s_bits[p1 >> 5]; w2 = s_bits[p2 >> 5]; w3 = s_bits[p3 >> 5];
+        // (keeps the optimiser from sinking the two branches' reads into one FLAT load of a selected pointer)
+        asm volatile("" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3));
       } else {
         const unsigned* kb = keep_bits + (size_t)b * nwords;
-        k0 = k0 && ((kb[p0 >> 5] >> (p0 & 31)) & 1u);
-        k1 = k1 && ((kb[p1 >> 5] >> (p1 & 31)) & 1u);
-        k2 = k2 && ((kb[p2 >> 5] >> (p2 & 31)) & 1u);
-        k3 = k3 && ((kb[p3 >> 5] >> (p3 & 31)) & 1u);
+        w0 = kb[p0 >> 5]; w1 = kb[p1 >> 5]; w2 = kb[p2 >> 5]; w3 = kb[p3 >> 5];
       }
+      k0 = k0 & (bool)((w0 >> (p0 & 31)) & 1u);
+      k1 = k1 & (bool)((w1 >> (p1 & 31)) & 1u);
+      k2 = k2 & (bool)((w2 >> (p2 & 31)) & 1u);
+      k3 = k3 & (bool)((w3 >> (p3 & 31)) & 1u);
     } else if (FUSED && keep != nullptr) {
       const unsigned char* kp = keep + (size_t)b * S;
-      k0 = k0 && kp[g.off[0] >> 10];
-      k1 = k1 && kp[g.off[1] >> 10];
-      k2 = k2 && kp[g.off[2] >> 10];
-      k3 = k3 && kp[g.off[3] >> 10];
+      const unsigned char c0 = kp[g.off[0] >> 10], c1 = kp[g.off[1] >> 10], c2 = kp[g.off[2] >> 10], c3 = kp[g.off[3] >> 10];
+      k0 = k0 & (c0 != 0);
+      k1 = k1 & (c1 != 0);
+      k2 = k2 & (c2 != 0);
+      k3 = k3 & (c3 != 0);
     }
     my_off[head_s * kHeadStride + s] = make_int4(g.off[0], g.off[1], g.off[2], g.off[3]);
     my_w[head_s * kHeadStride + s] = make_float4(k0 ? g.w[0] * a : 0.f, k1 ? g.w[1] * a : 0.f,
