@@ -817,18 +817,34 @@ def batched_leg(model, dev, batch=8, steps=10, warmup=3):
     pv = torch.randn(batch, 3, H_IMG, W_IMG, device=dev)
     pm = torch.ones(batch, H_IMG, W_IMG, dtype=torch.long, device=dev)
     fwd = GraphedForward(model, enabled=True, strict=True)
-    with torch.no_grad():
-        for _ in range(warmup):
-            fwd(pv, pm)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fwd(pv, pm)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+    # heuristic solver / GEMM picks for the batched shapes (MIOpen find + TunableOp tuning of them cost ~75 s of the default run)
+    find_was = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    tun = None
+    try:
+        import torch.cuda.tunable as tun
+        tuning_was = tun.tuning_is_enabled()
+        tun.tuning_enable(False)
+    except Exception:
+        tun = None
+    try:
+        with torch.no_grad():
+            for _ in range(warmup):
+                fwd(pv, pm)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fwd(pv, pm)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        torch.backends.cudnn.benchmark = find_was
+        if tun is not None:
+            tun.tuning_enable(tuning_was)
     return {"metric": "images/sec end-to-end SGG, 600x1000, fp32, throughput mode", "value": round(batch * steps / dt, 2),
             "unit": "images/sec", "images_per_step": batch, "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "warmup": warmup, "note": "extra information; the headline stays bs = 1 (the reference's FPS path)"}
+            "warmup": warmup, "note": "extra information; the headline stays bs = 1 (the reference's FPS path); heuristic MIOpen / GEMM picks "
+                                           "(tuned: 443 images/s)"}
 
 
 GRAD_BYTES_FP32 = 165 * 1000 * 1000   # ~165 MB of fp32 gradients per optimizer step (42.5 M parameters)
