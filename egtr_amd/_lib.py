@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("EGTR_HIP_LIBRARY") or os.path.join(_HERE, "libegtr_hi
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
-ABI_VERSION = 4   # include/egtr_hip.h: EGTR_ABI_VERSION of the header these signatures were written against
+ABI_VERSION = 5   # include/egtr_hip.h: EGTR_ABI_VERSION of the header these signatures were written against
 
 # name -> argtypes (restype is always int status unless listed in _RESTYPES)
 SIGNATURES = {
@@ -103,6 +103,7 @@ SIGNATURES = {
     "egtr_dropout_add_layernorm_backward_f32": [_P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P,
                                                 _P, _I, _I, ctypes.c_float],
     "egtr_pad_batch_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "egtr_conv1x1_tail_x6_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I],
     "egtr_ffn_x6_f32": [_P, _P, _I, _P, _P, _P, _P, _P, _P, ctypes.c_float, _P, _I, _P, _P, _I, _I, _I],
     "egtr_encoder_tail_x6_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _P, ctypes.c_float, _P, _P, _P, _P, _P, _P, ctypes.c_float,
                                  _P, _I, _P, _P, _I, _I, _I],

@@ -24,6 +24,10 @@ NHWC_BF16 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 # its NCHW choices at bs 1 (tools/nhwc_probe.py --fp32: 786 -> 660 us over the 16 convolutions) and the conv1 epilogue
 # launches disappear into the GEMMs.
 NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
+# fp32 channels-last bottleneck: shift + ReLU of conv2, conv3, shift + shortcut + ReLU as one launch of the bottleneck-tail
+# kernel (Bottleneck.forward_folded_nhwc, csrc/conv_tail_x6.hip).  EGTR_GEMM_SPLIT_BF16=0 turns this off together with the other
+# split-bf16 routes.
+CONV3_FUSED = True   # module attribute (tests patch it for the switch-off twin)
 
 
 def _fold(conv, bn):
@@ -195,8 +199,9 @@ class Bottleneck(nn.Module):
         return out
 
     def forward_folded_nhwc(self, x, q):
-        """Inference, bf16, x a channels-last [B, C, H, W] tensor: conv1 = GEMM + bias + ReLU in its epilogue (no pass of its
-        own), conv2 = MIOpen NHWC + one epilogue pass, conv3 = GEMM, then shift + shortcut + ReLU in one pass."""
+        """Inference, x a channels-last [B, C, H, W] tensor: conv1 = GEMM + bias + ReLU in its epilogue (no pass of its own),
+        conv2 = MIOpen NHWC; then fp32: the tail kernel (conv2's shift + ReLU, conv3, shift + shortcut + ReLU in one launch);
+        bf16: one epilogue pass, conv3 = GEMM, shift + shortcut + ReLU in one pass."""
         from . import ops
         B, C, H, W_ = x.shape
         x2 = x.permute(0, 2, 3, 1).reshape(-1, C)                      # a view: channels-last IS [B*H*W, C]
@@ -211,14 +216,24 @@ class Bottleneck(nn.Module):
                               "PYTORCH_MIOPEN_SUGGEST_NHWC=1 was not set before the process's first convolution")
         Ho, Wo = y.shape[-2:]
         y2 = y.permute(0, 2, 3, 1).reshape(-1, y.shape[1])
-        ops.bias_act_rows_(y2, q["b2"])
-        z = torch.mm(y2, q["w3"].t())
+        N3 = q["w3"].shape[0]
         if self.downsample is None:
             idt = x2
         elif q["wd"].dim() == 2:
             idt = torch.mm(x2, q["wd"].t())
         else:
-            idt = F.conv2d(x, q["wd"], None, stride=self.downsample[0].stride).permute(0, 2, 3, 1).reshape(-1, z.shape[1])
+            idt = F.conv2d(x, q["wd"], None, stride=self.downsample[0].stride).permute(0, 2, 3, 1).reshape(-1, N3)
+        if (CONV3_FUSED and ops.GEMM_SPLIT_BF16 and ops.conv1x1_tail_supported(y2, N3) and idt.dtype == torch.float32
+                and idt.stride(1) == 1 and idt.stride(0) % 4 == 0 and idt.data_ptr() % 16 == 0):
+            # fp32: the block's tail as ONE launch (csrc/conv_tail_x6.hip, fp32-accurate split-bf16 products): conv2's shift +
+            # ReLU applied to the rows on their way into LDS, conv3's shift + shortcut + ReLU in the epilogue -- instead of
+            # pass, vendor GEMM, pass (two round trips of the activation through memory and two launches less per block)
+            if "w3xs" not in q:
+                q["w3xs"] = ops.xs_split(q["w3"], weights=True)
+            z = ops.conv1x1_tail(y2, q["b2"], q["w3xs"], q["b3"], idt, N3)
+            return z.view(B, Ho, Wo, -1).permute(0, 3, 1, 2)
+        ops.bias_act_rows_(y2, q["b2"])
+        z = torch.mm(y2, q["w3"].t())
         ops.bias_act_rows_(z, q["b3"], idt)
         return z.view(B, Ho, Wo, -1).permute(0, 3, 1, 2)
 

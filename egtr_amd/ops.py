@@ -1604,6 +1604,34 @@ def xs_split(x, pos=None, weights=False, plain=True):
     return out if pos is None else (out, out_pos)
 
 
+def conv1x1_tail_supported(a, N):
+    """Shapes the bottleneck-tail kernel serves (csrc/conv_tail_x6.hip): fp32 pixel rows with unit inner stride, K = planes in
+    {64, 128, 256, 512}, N a multiple of 128."""
+    return (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and a.stride(0) % 4 == 0
+            and a.data_ptr() % 16 == 0 and a.shape[1] in (64, 128, 256, 512) and N % 128 == 0)
+
+
+def conv1x1_tail(a, a_shift, w_xs, bias, shortcut, N, relu_in=True, relu_out=True, tile=(0, 0)):
+    """relu(relu(a + a_shift) W^T + bias + shortcut) in ONE HIP launch (egtr_conv1x1_tail_x6_f32): the last 1x1 convolution of
+    a ResNet bottleneck on channels-last fp32 rows together with the shift + ReLU in front of it and the shift + shortcut +
+    ReLU behind it (reference: model/deformable_detr.py:735-760, the timm ResNet-50 backbone with frozen batch norm).
+    ``a`` [M, K] raw 3x3-convolution output, ``w_xs`` = ``xs_split(W [N, K], weights=True)``, ``shortcut`` [M, N] or None.
+    fp32-level accuracy (six-term split-bf16 products).  Inference only."""
+    lib = _lib.lib()
+    M, K = a.shape
+    for name, t in (("a_shift", a_shift), ("bias", bias), ("shortcut", shortcut)):
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32 or t.stride(-1) != 1):
+            raise RuntimeError(f"conv1x1_tail: {name} must be a float32 device tensor with unit inner stride")
+    y = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    st = lib.egtr_conv1x1_tail_x6_f32(
+        _stream(), a.data_ptr(), a.stride(0), a_shift.data_ptr() if a_shift is not None else None, 1 if relu_in else 0,
+        w_xs.data_ptr(), bias.data_ptr() if bias is not None else None,
+        shortcut.data_ptr() if shortcut is not None else None, shortcut.stride(0) if shortcut is not None else 0,
+        1 if relu_out else 0, y.data_ptr(), y.stride(0), M, K, N, int(tile[0]), int(tile[1]))
+    _lib.check(st, "egtr_conv1x1_tail_x6_f32")
+    return y
+
+
 FFN_FUSED = os.environ.get("EGTR_FFN_FUSED", "1") != "0"
 
 

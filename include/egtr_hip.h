@@ -46,7 +46,7 @@ enum {
 
 /* Bumped whenever an entry point is added / removed or the meaning of an argument changes; egtr_amd/_lib.py refuses a
  * library whose number differs from the one it was written against. */
-#define EGTR_ABI_VERSION 4
+#define EGTR_ABI_VERSION 5
 int egtr_abi_version(void);
 const char* egtr_status_string(int status);
 /* last HIP error string seen by this thread (for EGTR_E_LAUNCH) */
@@ -675,6 +675,21 @@ long long egtr_xs_bytes(int rows, int K);
  * mid = lo = 0. */
 int egtr_xs_split_f32(egtr_stream_t stream, const float* x, int ldx, const float* pos, int pos_rows, int rows, int K,
                       void* xs_out, void* xs_pos_out, int round_to_nearest);
+
+/* The tail of a ResNet bottleneck on channels-last fp32 data as one launch (inference, frozen batch norm folded):
+ *     y = act_out( act_in(a + a_shift) . W^T + bias + shortcut )
+ * a [M, lda] = the raw output of the 3x3 convolution (M = B H W pixel rows, K = planes), a_shift [K] its folded batch-norm
+ * shift (NULL: none), relu_in != 0: ReLU behind it; W [N, K] the 1x1 convolution as XS(W) (egtr_xs_split_f32 with
+ * round_to_nearest = 1); bias [N] (NULL: none); shortcut [M, ld_shortcut] (NULL: none); relu_out != 0: closing ReLU.
+ * Replaces, per block: an in-place shift + ReLU pass, a vendor fp32 GEMM and a shift + shortcut + ReLU pass
+ * (egtr_amd/backbone.py::Bottleneck.forward_folded_nhwc; reference: model/deformable_detr.py:735-760, the timm ResNet-50
+ * backbone with frozen batch norm -- conv3 -> bn3 -> += shortcut -> relu).  Six-term split-bf16 arithmetic: the error of an
+ * fp32 GEMM.  K in {64, 128, 256, 512}, N % 128 == 0, 16-byte aligned pointers, row strides % 4 == 0 (EGTR_E_UNSUPPORTED
+ * otherwise).  tile_rows (0 | 32 | 64) / tile_cols (0 | 128 | 256): 0 = the library's choice; other values pin the workgroup
+ * tile (tools/conv3_fused_ab.py sweeps them). */
+int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, int lda, const float* a_shift, int relu_in,
+                             const void* w_xs, const float* bias, const float* shortcut, int ld_shortcut, int relu_out,
+                             float* y, int ldy, int M, int K, int N, int tile_rows, int tile_cols);
 
 /* The encoder layer's feed-forward block in ONE launch (csrc/ffn_x6.hip; reference: two nn.Linear + ReLU + dropout(eval) +
  * residual + LayerNorm, model/deformable_detr.py:1335-1345): out = fc2(relu(fc1(x))), or with ln_gamma / ln_beta

@@ -47,7 +47,7 @@ def test_library_exports_every_declared_symbol(lib_path):
     for n in _declared():
         assert hasattr(h, n), f"{n} declared in include/egtr_hip.h but not exported"
     h.egtr_abi_version.restype = ctypes.c_int
-    assert h.egtr_abi_version() == 4
+    assert h.egtr_abi_version() == 5
     h.egtr_status_string.restype = ctypes.c_char_p
     assert b"ok" == h.egtr_status_string(0)
 

@@ -1744,3 +1744,91 @@ def test_self_attention_bf16_entry_equals_the_fp32_kernel_on_widened_operands(B,
     assert torch.equal(qh, q.view(B, N, 8, 32).transpose(1, 2))
     out2, none_q, none_k = ops.decoder_self_attention(q, k, v, 8, want_maps=False)
     assert torch.equal(out2, out) and none_q is None and none_k is None
+
+
+# ---- the bottleneck-tail kernel (csrc/conv_tail_x6.hip, egtr_conv1x1_tail_x6_f32) ------------------------------------------
+def _tail_ref(a, sh, w, b, sc, relu_in, relu_out):
+    x = a.double()
+    if sh is not None:
+        x = x + sh.double()
+    if relu_in:
+        x = torch.relu(x)
+    y = x @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if sc is not None:
+        y = y + sc.double()
+    return torch.relu(y) if relu_out else y
+
+
+@pytest.mark.parametrize("K,N", [(64, 256), (128, 512), (256, 1024), (512, 2048), (64, 128), (256, 384)])
+@pytest.mark.parametrize("M", [1, 37, 608, 2399])
+def test_conv1x1_tail_matches_fp64_product(K, N, M):
+    """relu(relu(a + shift2) W3^T + shift3 + shortcut) in one launch against the fp64 product of the same fp32 operands: the
+    six-term split-bf16 arithmetic has the error of an fp32 GEMM (1e-5 of the row's scale here); ragged row counts (the last
+    panel is partial), every tile the dispatcher can pick, N that is a multiple of 128 but not of 256."""
+    from egtr_amd import ops
+    torch.manual_seed(K + N + M)
+    a = torch.randn(M, K, device=DEV)
+    sh = torch.randn(K, device=DEV) * 0.3
+    w = torch.randn(N, K, device=DEV) / K ** 0.5
+    b = torch.randn(N, device=DEV) * 0.3
+    sc = torch.randn(M, N, device=DEV)
+    wxs = ops.xs_split(w, weights=True)
+    ref = _tail_ref(a, sh, w, b, sc, True, True)
+    tiles = [(0, 0), (32, 128)] + ([(32, 256)] if N % 256 == 0 else []) + ([(64, 128)] if K <= 256 else []) \
+        + ([(64, 256)] if K <= 256 and N % 256 == 0 else [])
+    outs = []
+    for tile in tiles:
+        y = ops.conv1x1_tail(a, sh, wxs, b, sc, N, tile=tile)
+        assert y.shape == (M, N) and y.dtype == torch.float32
+        assert float((y.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), tile
+        outs.append(y)
+    # the tile only changes who computes an element, not how: same k order, same six terms
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert torch.equal(outs[0], ops.conv1x1_tail(a, sh, wxs, b, sc, N))   # run-to-run bit-identical (no atomics)
+
+
+def test_conv1x1_tail_optional_operands_and_strides():
+    """Every optional operand absent / present, both ReLUs off, and row strides larger than the row (a column block of a wider
+    buffer as input, shortcut and -- through the view the caller makes -- output)."""
+    from egtr_amd import ops
+    torch.manual_seed(5)
+    M, K, N = 333, 128, 256
+    wide_a = torch.randn(M, K + 64, device=DEV)
+    wide_s = torch.randn(M, N + 128, device=DEV)
+    a, sc = wide_a[:, 32:32 + K], wide_s[:, 64:64 + N]
+    assert a.data_ptr() % 16 == 0 and sc.data_ptr() % 16 == 0
+    w = torch.randn(N, K, device=DEV) / K ** 0.5
+    wxs = ops.xs_split(w, weights=True)
+    sh, b = torch.randn(K, device=DEV), torch.randn(N, device=DEV)
+    for use_sh, use_b, use_sc, r_in, r_out in [(0, 0, 0, 0, 0), (1, 0, 0, 1, 0), (0, 1, 0, 0, 1), (0, 0, 1, 1, 1), (1, 1, 1, 0, 0),
+                                               (1, 1, 1, 1, 1)]:
+        y = ops.conv1x1_tail(a, sh if use_sh else None, wxs, b if use_b else None, sc if use_sc else None, N,
+                             relu_in=bool(r_in), relu_out=bool(r_out))
+        ref = _tail_ref(a, sh if use_sh else None, w, b if use_b else None, sc if use_sc else None, r_in, r_out)
+        assert float((y.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), (use_sh, use_b, use_sc, r_in, r_out)
+
+
+def test_conv1x1_tail_non_finite_rows_stay_in_their_rows_and_bad_shapes_are_refused():
+    from egtr_amd import ops
+    from egtr_amd._lib import EgtrHipError
+    torch.manual_seed(6)
+    M, K, N = 100, 64, 256
+    a = torch.randn(M, K, device=DEV)
+    a[7, 3] = float("nan")
+    a[50, 0] = float("inf")
+    w = torch.randn(N, K, device=DEV) / 8
+    wxs = ops.xs_split(w, weights=True)
+    y = ops.conv1x1_tail(a, None, wxs, None, None, N, relu_in=False, relu_out=False)
+    bad = ~torch.isfinite(y).all(dim=1)
+    assert bad[7] and bad[50] and int(bad.sum()) == 2          # nothing leaks into the other rows of the panel
+    # ReLU as torch computes it: relu(NaN) = NaN
+    y2 = ops.conv1x1_tail(a, None, wxs, None, None, N, relu_in=True, relu_out=True)
+    assert torch.isnan(y2[7]).all() and torch.isfinite(y2[6]).all()
+    assert not ops.conv1x1_tail_supported(torch.randn(M, 96, device=DEV), 256)     # K not a bottleneck width
+    assert not ops.conv1x1_tail_supported(a, 192)                                   # N not a multiple of 128
+    with pytest.raises(EgtrHipError):
+        ops.conv1x1_tail(torch.randn(M, 96, device=DEV), None, wxs, None, None, 256)
+    with pytest.raises(EgtrHipError):
+        ops.conv1x1_tail(a, None, wxs, None, None, N, tile=(64, 512))

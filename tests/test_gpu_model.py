@@ -25,7 +25,7 @@ def small(golden_dir):
 def test_native_library_is_the_one_loaded():
     from egtr_amd import _lib
     h = _lib.lib()
-    assert h.egtr_abi_version() == _lib.ABI_VERSION == 4
+    assert h.egtr_abi_version() == _lib.ABI_VERSION == 5
     maps = open("/proc/self/maps").read()
     assert "libegtr_hip.so" in maps
 
@@ -606,6 +606,43 @@ def test_backbone_channels_last_path_matches_nchw_path(dtype, monkeypatch):
         assert a.is_contiguous(memory_format=torch.channels_last) and b.is_contiguous()
         scale = max(1.0, float(b.float().abs().max()))
         assert float((a.float() - b.float()).abs().max()) < (2e-4 if dtype == torch.float32 else 0.06) * scale
+
+
+def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch):
+    """fp32 channels-last backbone: every bottleneck's tail (shift + ReLU, conv3, shift + shortcut + ReLU) runs as ONE launch of
+    csrc/conv_tail_x6.hip -- 16 calls per ResNet-50 forward, identity and downsample shortcuts, stride-2 blocks -- and matches
+    the three-launch composition it replaces (backbone.CONV3_FUSED = False) to fp32 GEMM rounding.  Odd sizes: ragged panels."""
+    import egtr_amd.backbone as bb
+    from egtr_amd import ops
+    torch.manual_seed(3)
+    net = bb.ResNet50Features().to(DEV).eval()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.1)
+    x = torch.randn(2, 3, 117, 203, device=DEV)
+    calls = []
+    real = ops.conv1x1_tail
+    monkeypatch.setattr(ops, "conv1x1_tail", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    assert bb.CONV3_FUSED is True
+    with torch.no_grad():
+        fused = net(x)
+        assert len(calls) == 16 and sorted({c[1] for c in calls}) == [64, 128, 256, 512]
+        monkeypatch.setattr(bb, "CONV3_FUSED", False)
+        plain = net(x)
+        assert len(calls) == 16
+    for a, b in zip(fused, plain):
+        assert a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) < 2e-5 * scale
+    # with the split-bf16 routes switched off as a group the kernel is not used either
+    monkeypatch.setattr(bb, "CONV3_FUSED", True)
+    monkeypatch.setattr(ops, "GEMM_SPLIT_BF16", False)
+    with torch.no_grad():
+        net(x)
+    assert len(calls) == 16
 
 
 def test_backbone_folded_path_bf16_matches_unfolded_bf16():
