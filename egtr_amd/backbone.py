@@ -27,7 +27,8 @@ NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 # fp32 channels-last bottleneck: shift + ReLU of conv2, conv3, shift + shortcut + ReLU as one launch of the bottleneck-tail
 # kernel (Bottleneck.forward_folded_nhwc, csrc/conv_tail_x6.hip).  EGTR_GEMM_SPLIT_BF16=0 turns this off together with the other
 # split-bf16 routes.
-CONV3_FUSED = True   # module attribute (tests patch it for the switch-off twin)
+CONV3_FUSED = True        # module attributes (tests patch them for the switch-off twins)
+CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
 
 
 def _fold(conv, bn):
@@ -231,6 +232,13 @@ class Bottleneck(nn.Module):
             if "w3xs" not in q:
                 q["w3xs"] = ops.xs_split(q["w3"], weights=True)
             z = ops.conv1x1_tail(y2, q["b2"], q["w3xs"], q["b3"], idt, N3)
+            return z.view(B, Ho, Wo, -1).permute(0, 3, 1, 2)
+        if (CONV3_FUSED_BF16 and ops.conv1x1_tail_bf16_supported(y2, N3) and idt.dtype == torch.bfloat16 and idt.stride(1) == 1
+                and idt.stride(0) % 8 == 0 and idt.data_ptr() % 16 == 0):
+            # bf16: the same as one launch of csrc/conv_tail_bf16.hip, with the rounding points of the composition below
+            if "w3pk" not in q:
+                q["w3pk"] = ops.conv_tail_pack_bf16(q["w3"])
+            z = ops.conv1x1_tail_bf16(y2, q["b2"], q["w3pk"], q["b3"], idt, N3)
             return z.view(B, Ho, Wo, -1).permute(0, 3, 1, 2)
         ops.bias_act_rows_(y2, q["b2"])
         z = torch.mm(y2, q["w3"].t())

@@ -1632,6 +1632,45 @@ def conv1x1_tail(a, a_shift, w_xs, bias, shortcut, N, relu_in=True, relu_out=Tru
     return y
 
 
+def conv1x1_tail_bf16_supported(a, N):
+    """Shapes the bf16 bottleneck-tail kernel serves (csrc/conv_tail_bf16.hip): bf16 pixel rows with unit inner stride, K = planes
+    in {64, 128, 256, 512}, N a multiple of 256."""
+    return (a.is_cuda and a.dtype == torch.bfloat16 and a.dim() == 2 and a.stride(1) == 1 and a.stride(0) % 8 == 0
+            and a.data_ptr() % 16 == 0 and a.shape[1] in (64, 128, 256, 512) and N % 256 == 0)
+
+
+def conv_tail_pack_bf16(w):
+    """W [N, K] bf16 -> the MFMA-operand stream of the bf16 bottleneck-tail kernel (egtr_conv1x1_tail_pack_weights_bf16)."""
+    lib = _lib.lib()
+    w = w.detach()
+    if not w.is_cuda or w.dtype != torch.bfloat16 or w.dim() != 2 or w.stride(1) != 1:
+        raise RuntimeError("conv_tail_pack_bf16: a 2-d bfloat16 device tensor with unit inner stride expected")
+    N, K = w.shape
+    out = torch.empty(N * K, dtype=torch.bfloat16, device=w.device)
+    st = lib.egtr_conv1x1_tail_pack_weights_bf16(_stream(), w.data_ptr(), w.stride(0), N, K, out.data_ptr())
+    _lib.check(st, "egtr_conv1x1_tail_pack_weights_bf16")
+    return out
+
+
+def conv1x1_tail_bf16(a, a_shift, w_packed, bias, shortcut, N, relu_in=True, relu_out=True):
+    """relu(bf16(relu(a + a_shift) W^T) + bias + shortcut) in ONE HIP launch (egtr_conv1x1_tail_bf16): the bf16 twin of
+    ``conv1x1_tail`` with the rounding points of the pass / GEMM / pass composition it replaces.  ``a`` [M, K] and ``shortcut``
+    [M, N] bf16, shifts fp32, ``w_packed`` from ``conv_tail_pack_bf16``.  Inference only."""
+    lib = _lib.lib()
+    M, K = a.shape
+    for name, t, dt in (("a_shift", a_shift, torch.float32), ("bias", bias, torch.float32), ("shortcut", shortcut, torch.bfloat16)):
+        if t is not None and (not t.is_cuda or t.dtype != dt or t.stride(-1) != 1):
+            raise RuntimeError(f"conv1x1_tail_bf16: {name} must be a {dt} device tensor with unit inner stride")
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    st = lib.egtr_conv1x1_tail_bf16(
+        _stream(), a.data_ptr(), a.stride(0), a_shift.data_ptr() if a_shift is not None else None, 1 if relu_in else 0,
+        w_packed.data_ptr(), bias.data_ptr() if bias is not None else None,
+        shortcut.data_ptr() if shortcut is not None else None, shortcut.stride(0) if shortcut is not None else 0,
+        1 if relu_out else 0, y.data_ptr(), y.stride(0), M, K, N)
+    _lib.check(st, "egtr_conv1x1_tail_bf16")
+    return y
+
+
 FFN_FUSED = os.environ.get("EGTR_FFN_FUSED", "1") != "0"
 
 

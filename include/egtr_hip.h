@@ -691,6 +691,17 @@ int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, int lda, cons
                              const void* w_xs, const float* bias, const float* shortcut, int ld_shortcut, int relu_out,
                              float* y, int ldy, int M, int K, int N, int tile_rows, int tile_cols);
 
+/* The bf16 twin (the bf16 model of the stress configuration): a, shortcut, y bf16 (raw bits), shifts fp32, fp32 accumulation;
+ *     y = act_out( bf16( act_in(a + a_shift) . W^T ) + bias + shortcut )
+ * with the rounding points of the composition it replaces (the shifted + rectified input rounded to bf16, the product rounded
+ * to bf16, the sum rounded once more): egtr_bias_act_nhwc_bf16, a vendor bf16 GEMM, egtr_bias_act_nhwc_bf16.  w_packed: W [N, K]
+ * in MFMA operand order from egtr_conv1x1_tail_pack_weights_bf16 (N * K elements; a derived constant of the weights).
+ * K in {64, 128, 256, 512}, N % 256 == 0, 16-byte aligned pointers, row strides % 8 == 0 (EGTR_E_UNSUPPORTED otherwise). */
+int egtr_conv1x1_tail_pack_weights_bf16(egtr_stream_t stream, const uint16_t* w, int ldw, int N, int K, uint16_t* w_packed);
+int egtr_conv1x1_tail_bf16(egtr_stream_t stream, const uint16_t* a, int lda, const float* a_shift, int relu_in,
+                           const uint16_t* w_packed, const float* bias, const uint16_t* shortcut, int ld_shortcut, int relu_out,
+                           uint16_t* y, int ldy, int M, int K, int N);
+
 /* The encoder layer's feed-forward block in ONE launch (csrc/ffn_x6.hip; reference: two nn.Linear + ReLU + dropout(eval) +
  * residual + LayerNorm, model/deformable_detr.py:1335-1345): out = fc2(relu(fc1(x))), or with ln_gamma / ln_beta
  * out = LayerNorm(x + fc2(relu(fc1(x)))) and optionally out_pos = out + pos[row % pos_rows].  x [M, ldx] fp32;

@@ -1832,3 +1832,64 @@ def test_conv1x1_tail_non_finite_rows_stay_in_their_rows_and_bad_shapes_are_refu
         ops.conv1x1_tail(torch.randn(M, 96, device=DEV), None, wxs, None, None, 256)
     with pytest.raises(EgtrHipError):
         ops.conv1x1_tail(a, None, wxs, None, None, N, tile=(64, 512))
+
+
+@pytest.mark.parametrize("K,N", [(64, 256), (128, 512), (256, 1024), (512, 2048)])
+@pytest.mark.parametrize("M", [1, 70, 2399])
+def test_conv1x1_tail_bf16_matches_pass_gemm_pass(K, N, M):
+    """The bf16 twin (csrc/conv_tail_bf16.hip) against the composition it replaces, with the same rounding points: shift + ReLU
+    pass (bf16 out), bf16 GEMM with fp32 accumulation (bf16 out), shift + shortcut + ReLU pass.  Only the accumulation order of
+    the product differs, so outputs agree except where a product lands within rounding distance of a bf16 tie: at most one
+    bf16 ulp there, on a small fraction of the elements.  Also against the fp64 product with the same rounding points."""
+    from egtr_amd import ops
+    torch.manual_seed(K + M)
+    a = torch.randn(M, K, device=DEV).bfloat16()
+    sh = torch.randn(K, device=DEV) * 0.3
+    w = (torch.randn(N, K, device=DEV) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device=DEV) * 0.3
+    sc = torch.randn(M, N, device=DEV).bfloat16()
+    y = ops.conv1x1_tail_bf16(a, sh, ops.conv_tail_pack_bf16(w), b, sc, N)
+    assert y.shape == (M, N) and y.dtype == torch.bfloat16
+    a2 = a.clone()
+    ops.bias_act_rows_(a2, sh)
+    z = torch.mm(a2, w.t())
+    ops.bias_act_rows_(z, b, sc)
+    diff = (y.float() - z.float()).abs()
+    ulp = torch.maximum(z.float().abs(), torch.tensor(1.0, device=DEV)) * 2.0 ** -7
+    assert bool((diff <= ulp).all())
+    assert float((diff > 0).float().mean()) < 0.02
+    # fp64 product, same rounding points
+    a64 = torch.relu(a.double() + sh.double()).bfloat16().double()
+    z64 = (a64 @ w.double().t()).bfloat16().double()
+    ref = torch.relu(z64 + b.double() + sc.double())
+    assert float((y.double() - ref).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(y, ops.conv1x1_tail_bf16(a, sh, ops.conv_tail_pack_bf16(w), b, sc, N))
+
+
+def test_conv1x1_tail_bf16_optional_operands_strides_and_refusals():
+    from egtr_amd import ops
+    from egtr_amd._lib import EgtrHipError
+    torch.manual_seed(8)
+    M, K, N = 333, 128, 256
+    wide_a = torch.randn(M, K + 64, device=DEV).bfloat16()
+    wide_s = torch.randn(M, N + 128, device=DEV).bfloat16()
+    a, sc = wide_a[:, 32:32 + K], wide_s[:, 64:64 + N]
+    w = (torch.randn(N, K, device=DEV) / K ** 0.5).bfloat16()
+    wp = ops.conv_tail_pack_bf16(w)
+    sh, b = torch.randn(K, device=DEV), torch.randn(N, device=DEV)
+    for use_sh, use_b, use_sc, r_in, r_out in [(0, 0, 0, 0, 0), (1, 0, 0, 1, 0), (0, 1, 1, 0, 1), (1, 1, 1, 1, 1)]:
+        y = ops.conv1x1_tail_bf16(a, sh if use_sh else None, wp, b if use_b else None, sc if use_sc else None, N,
+                                  relu_in=bool(r_in), relu_out=bool(r_out))
+        x = a.double() + (sh.double() if use_sh else 0.0)
+        x = (torch.relu(x) if r_in else x).bfloat16().double()
+        z = (x @ w.double().t()).bfloat16().double() + (b.double() if use_b else 0.0) + (sc.double() if use_sc else 0.0)
+        ref = torch.relu(z) if r_out else z
+        assert float((y.double() - ref).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref.abs().max())), (use_sh, use_b, use_sc)
+    an = a.clone()
+    an[5, 1] = float("nan")
+    yn = ops.conv1x1_tail_bf16(an, None, wp, None, None, N, relu_in=True, relu_out=True)
+    bad = ~torch.isfinite(yn.float()).all(dim=1)
+    assert bad[5] and int(bad.sum()) == 1
+    assert not ops.conv1x1_tail_bf16_supported(a, 128)
+    with pytest.raises(EgtrHipError):
+        ops.conv1x1_tail_bf16(a, None, wp, None, None, 128)

@@ -645,6 +645,38 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
     assert len(calls) == 16
 
 
+def test_backbone_bf16_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch):
+    """bf16 channels-last backbone: the tails run as one launch of csrc/conv_tail_bf16.hip each (16 per forward) and the feature
+    maps match the pass / GEMM / pass route (backbone.CONV3_FUSED_BF16 = False) to a few bf16 ulps of the map's scale -- the
+    rounding points are the same, ties in the product flip single ulps that later layers carry along."""
+    import egtr_amd.backbone as bb
+    from egtr_amd import ops
+    torch.manual_seed(4)
+    net = bb.ResNet50Features().to(DEV).eval()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.1)
+    net = net.to(torch.bfloat16)
+    x = torch.randn(2, 3, 117, 203, device=DEV).bfloat16()
+    calls = []
+    real = ops.conv1x1_tail_bf16
+    monkeypatch.setattr(ops, "conv1x1_tail_bf16", lambda *a, **k: (calls.append(a[0].shape), real(*a, **k))[1])
+    assert bb.CONV3_FUSED_BF16 is True
+    with torch.no_grad():
+        fused = net(x)
+        assert len(calls) == 16
+        monkeypatch.setattr(bb, "CONV3_FUSED_BF16", False)
+        plain = net(x)
+        assert len(calls) == 16
+    for a, b in zip(fused, plain):
+        assert a.shape == b.shape and a.dtype == torch.bfloat16 and a.is_contiguous(memory_format=torch.channels_last)
+        scale = max(1.0, float(b.float().abs().max()))
+        assert float((a.float() - b.float()).abs().max()) < 0.03 * scale
+
+
 def test_backbone_folded_path_bf16_matches_unfolded_bf16():
     """bf16 model: frozen-BN folding (fp32 arithmetic, bf16 weights) + the bf16 bias/residual/ReLU epilogue vs the
     plain bf16 module path and vs the fp32 backbone (bf16 tolerance)."""
