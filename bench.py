@@ -602,7 +602,8 @@ def stress_bench(dev, steps, warmup, batch=16):
            "unit": "images/sec", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
            "dtype": "bf16", "n_gpus": 1,
            "config": {"workload": f"Stress: ResNet-50, 800x1333, N=300, 6 enc/8 dec, bf16, bs={batch}/GPU "
-                                  "(BASELINE configs[4] shape on one GPU)", "hip_graph": bool(fwd.graphed)}}
+                                  "(BASELINE configs[4] shape on one GPU)", "hip_graph": bool(fwd.graphed),
+                      "miopen_find": bool(torch.backends.cudnn.benchmark)}}
     if msda_args is not None:
         us, alg = time_msda_kernel(msda_args, fused, iters=50, keep_bits=msda_bits)
         ach = alg / (us * 1e-6) / 1e9
@@ -808,7 +809,7 @@ def eager_leg(model, pv, pm, iters=30):
             "iters": iters, "launch": "eager (no HIP graph), 600x1000, bs=%d" % pv.shape[0]}
 
 
-def batched_leg(model, dev, batch=8, steps=10, warmup=3):
+def batched_leg(model, dev, batch=8, steps=10, warmup=3, find=True):
     """The same fp32 model in THROUGHPUT mode: `batch` 600x1000 images per forward (HIP-graph replay).  Not the headline -- the
     reference's FPS path is bs = 1 (evaluate_egtr.py:26-36, BASELINE configs[1]) -- but what one GPU delivers when latency is
     not the constraint: the MSDA launch is long enough to sit at its L1 floor, the token GEMMs fill their last tile round."""
@@ -817,9 +818,11 @@ def batched_leg(model, dev, batch=8, steps=10, warmup=3):
     pv = torch.randn(batch, 3, H_IMG, W_IMG, device=dev)
     pm = torch.ones(batch, H_IMG, W_IMG, dtype=torch.long, device=dev)
     fwd = GraphedForward(model, enabled=True, strict=True)
-    # heuristic solver / GEMM picks for the batched shapes (MIOpen find + TunableOp tuning of them cost ~75 s of the default run)
+    # MIOpen find mode for the batched convolution shapes (`find`; the heuristic picks vary from run to run and cost up to 3 ms
+    # of the 17.4: profiles/r06_batched_bs8_breakdown_find{0,1}.txt), heuristic GEMM picks (TunableOp tuning of the batched shapes
+    # cost ~60 s of the default run for 3 %)
     find_was = torch.backends.cudnn.benchmark
-    torch.backends.cudnn.benchmark = False
+    torch.backends.cudnn.benchmark = bool(find)
     tun = None
     try:
         import torch.cuda.tunable as tun
@@ -843,8 +846,8 @@ def batched_leg(model, dev, batch=8, steps=10, warmup=3):
             tun.tuning_enable(tuning_was)
     return {"metric": "images/sec end-to-end SGG, 600x1000, fp32, throughput mode", "value": round(batch * steps / dt, 2),
             "unit": "images/sec", "images_per_step": batch, "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "warmup": warmup, "note": "extra information; the headline stays bs = 1 (the reference's FPS path); heuristic MIOpen / GEMM picks "
-                                           "(tuned: 443 images/s)"}
+            "warmup": warmup, "miopen_find": bool(find),
+            "note": "extra information; the headline stays bs = 1 (the reference's FPS path); heuristic GEMM picks"}
 
 
 GRAD_BYTES_FP32 = 165 * 1000 * 1000   # ~165 MB of fp32 gradients per optimizer step (42.5 M parameters)
@@ -1264,12 +1267,17 @@ def main():
         # 10 warm-up steps as in `--mode train`: TunableOp picks and the caching allocator's pool settle over the first steps
         targs.mode, targs.batch, targs.steps, targs.warmup = "train", 4, 2 * args.extra_steps, 10
         targs.no_cpu_baseline, targs.no_kernel_probes = True, False
+        find_was = torch.backends.cudnn.benchmark
         torch.backends.cudnn.benchmark = False      # MIOpen find mode: no gain for the train step
         try:
             result["train_step"] = train_bench(targs, 1, 0, dev, None, emit=False)
         except Exception as e:  # the headline stays valid; the failure is visible
             result["train_step"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
+        # ... and a large one for the bf16 stress forward: MIOpen's heuristic pick for the layer-1 3x3 convolutions at bs 16 is a
+        # 400 us kernel where the search finds a 147 us one (tools/miopen_solver_ab.sh: 690 -> 771 images/s).  Until round 6
+        # this leg inherited the train leg's "off".
+        torch.backends.cudnn.benchmark = find_was
         try:
             result["stress_bf16"] = stress_bench(dev, steps=args.extra_steps, warmup=3)
         except Exception as e:

@@ -10,9 +10,9 @@
 // rounded to bf16 (the GEMM wrote it), the sum rounded once more.
 //
 // HBM-bound (layer 1: 1152 bytes per pixel row for 32 K flop): a workgroup of 4 waves owns 64 rows x 256 columns;
-//   * the 64 x K panel is shifted, rectified, rounded and parked in LDS as [row][K + 8] bf16;
+//   * the 64 x K panel is shifted, rectified, rounded and parked in LDS as [row][K + 8] bf16 (K = 512: in two halves);
 //   * a wave owns 64 columns; its weight fragments come straight from global memory in MFMA operand order (a derived constant
-//     of the weights: egtr_amd/ops.py::conv_tail_pack_bf16), four k-steps ahead;
+//     of the weights: egtr_amd/ops.py::conv_tail_pack_bf16), three k-steps ahead;
 //   * MFMA roles as in the other bf16 kernels (A = weights, i = column; B = activations, j = row): a lane ends up with one row and
 //     4 consecutive columns per accumulator quad.  The wave rounds its 32 x 64 tile to bf16 into a private LDS patch and reads
 //     it back row-major, 16 bytes = 8 columns per lane: shortcut loads (requested at kernel start) and stores are whole 128-byte
@@ -40,6 +40,7 @@ struct TailArgs {
   unsigned short* y;               // [M, ldy] bf16
   int M, N, lda, ldsc, ldy;
   int relu_in, relu_out;
+  int row_major;   // tile order: 1 = the column blocks of a row panel are neighbours, 0 = the row panels of a column block
 };
 
 __device__ __forceinline__ float lo_bf(unsigned u) { return __uint_as_float(u << 16); }
@@ -57,12 +58,15 @@ __device__ __forceinline__ int xcd_tile(int bid, int total) {
 }
 
 template <int KS>
-__global__ __launch_bounds__(256) void conv_tail_bf16_kernel(TailArgs A) {
-  constexpr int K = 16 * KS;
-  constexpr int kPitch = K + 8;          // bf16 elements per panel row
-  constexpr int C8 = K / 8;              // 16-byte chunks per panel row
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 16 ? 2 : 3))) void conv_tail_bf16_kernel(TailArgs A) {
+  constexpr int PH = KS > 16 ? 2 : 1;    // K = 512: the panel is built in two halves (34 instead of 67 KiB: three workgroups
+  constexpr int KSP = KS / PH;           // per CU instead of one); the accumulators carry over
+  constexpr int KP = 16 * KSP;           // panel columns per phase
+  constexpr int kPitch = KP + 8;         // bf16 elements per panel row
+  constexpr int C8 = KP / 8;             // 16-byte chunks per panel row
   constexpr int NQ = kBM * C8 / 256;     // chunks per thread
-  constexpr int PF = KS < 4 ? KS : 4;    // weight fragments are requested PF k-steps ahead
+  constexpr int PF = 3;                  // weight fragments are requested PF k-steps ahead
+  constexpr int CH = NQ < 4 ? NQ : 4;    // panel chunks in flight per thread (<= 170 registers: three waves per SIMD)
   static_assert(256 % C8 == 0 && NQ >= 1, "a thread keeps one column group of the panel");
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
   unsigned short* const sA = reinterpret_cast<unsigned short*>(s_raw);                      // [64][kPitch]
@@ -72,7 +76,12 @@ __global__ __launch_bounds__(256) void conv_tail_bf16_kernel(TailArgs A) {
 
   const int mblocks = (A.M + kBM - 1) / kBM;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int nb = tile / mblocks, m0 = (tile - nb * mblocks) * kBM;
+  // neighbours in the tile order run side by side on one XCD and share its L2: whichever operand is larger is the one
+  // that must not be fetched once per partner (the host decides: panel bytes M K against weight bytes N K)
+  constexpr int nblocks_unit = kBN;
+  const int nblocks = A.N / nblocks_unit;
+  const int nb = A.row_major ? tile % nblocks : tile / mblocks;
+  const int m0 = (A.row_major ? tile / nblocks : tile - nb * mblocks) * kBM;
   const int nt0 = nb * (kBN / 32) + wave * kNTW;   // first 32-column tile of this wave
   const int col0 = nt0 * 32;
 
@@ -104,39 +113,41 @@ __global__ __launch_bounds__(256) void conv_tail_bf16_kernel(TailArgs A) {
   __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the requests to their first use)
 
   // the panel: thread t owns chunk c8 = t % C8 of rows t / C8 + (256 / C8) q
-  {
+  auto build_panel = [&](int ph) {
     const int c8 = tid % C8, r0 = tid / C8;
     float sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (A.a_shift != nullptr) {
-      const float4 s0 = *reinterpret_cast<const float4*>(A.a_shift + 8 * c8);
-      const float4 s1 = *reinterpret_cast<const float4*>(A.a_shift + 8 * c8 + 4);
+      const float4 s0 = *reinterpret_cast<const float4*>(A.a_shift + ph * KP + 8 * c8);
+      const float4 s1 = *reinterpret_cast<const float4*>(A.a_shift + ph * KP + 8 * c8 + 4);
       sh[0] = s0.x; sh[1] = s0.y; sh[2] = s0.z; sh[3] = s0.w;
       sh[4] = s1.x; sh[5] = s1.y; sh[6] = s1.z; sh[7] = s1.w;
     }
     const bool relu_in = A.relu_in != 0;
-    uint4 v[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int row = min(m0 + r0 + (256 / C8) * q, A.M - 1);
-      v[q] = *reinterpret_cast<const uint4*>(A.a + (size_t)row * A.lda + 8 * c8);
-    }
+    for (int q0 = 0; q0 < NQ; q0 += CH) {
+      uint4 v[CH];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const unsigned u[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-      unsigned o[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float lo = lo_bf(u[k]) + sh[2 * k], hi = hi_bf(u[k]) + sh[2 * k + 1];
-        if (relu_in) {
-          lo = egtr_relu(lo);
-          hi = egtr_relu(hi);
-        }
-        o[k] = pk_bf16(lo, hi);
+      for (int q = 0; q < CH; ++q) {
+        const int row = min(m0 + r0 + (256 / C8) * (q0 + q), A.M - 1);
+        v[q] = *reinterpret_cast<const uint4*>(A.a + (size_t)row * A.lda + ph * KP + 8 * c8);
       }
-      *reinterpret_cast<uint4*>(sA + (r0 + (256 / C8) * q) * kPitch + 8 * c8) = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const unsigned u[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float lo = lo_bf(u[k]) + sh[2 * k], hi = hi_bf(u[k]) + sh[2 * k + 1];
+          if (relu_in) {
+            lo = egtr_relu(lo);
+            hi = egtr_relu(hi);
+          }
+          o[k] = pk_bf16(lo, hi);
+        }
+        *reinterpret_cast<uint4*>(sA + (r0 + (256 / C8) * (q0 + q)) * kPitch + 8 * c8) = make_uint4(o[0], o[1], o[2], o[3]);
+      }
     }
-  }
-  __syncthreads();
+  };
 
   f32x16 acc[kMT][kNTW];
 #pragma unroll
@@ -148,22 +159,28 @@ __global__ __launch_bounds__(256) void conv_tail_bf16_kernel(TailArgs A) {
 
   const unsigned short* const pa0 = sA + li * kPitch + 8 * hf;
   bf16x8 a[2][kMT];
-  auto read_a = [&](int ks, bf16x8 (&dst)[kMT]) {
+  auto read_a = [&](int j, bf16x8 (&dst)[kMT]) {
 #pragma unroll
-    for (int m = 0; m < kMT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(pa0 + m * 32 * kPitch + 16 * ks);
+    for (int m = 0; m < kMT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(pa0 + m * 32 * kPitch + 16 * j);
   };
-  read_a(0, a[0]);
-  static_for<KS>([&](auto ks_) {
-    constexpr int ks = decltype(ks_)::value;
-    if constexpr (ks + PF < KS) load_w(ks + PF, w[(ks + PF) % (PF + 1)]);
-    if constexpr (ks + 1 < KS) read_a(ks + 1, a[(ks + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
+  static_for<PH>([&](auto ph_) {
+    constexpr int ph = decltype(ph_)::value;
+    if constexpr (ph > 0) __syncthreads();   // every wave has read the previous half out of LDS
+    build_panel(ph);
+    __syncthreads();
+    read_a(0, a[0]);
+    static_for<KSP>([&](auto j_) {
+      constexpr int j = decltype(j_)::value, ks = ph * KSP + j;
+      if constexpr (ks + PF < KS) load_w(ks + PF, w[(ks + PF) % (PF + 1)]);
+      if constexpr (j + 1 < KSP) read_a(j + 1, a[(j + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int m = 0; m < kMT; ++m)
+      for (int m = 0; m < kMT; ++m)
 #pragma unroll
-      for (int t = 0; t < kNTW; ++t)
-        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks % (PF + 1)][t], a[ks & 1][m], acc[m][t], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t < kNTW; ++t)
+          acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks % (PF + 1)][t], a[j & 1][m], acc[m][t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   });
 
   // epilogue, one 32 x 64 tile at a time: D[i = n][j = m] -- lane l holds row l & 31, accumulator quad q columns 8 q + 4 (l >> 5)
@@ -208,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_tail_bf16_kernel(TailArgs A) {
 template <int KS>
 int launch(hipStream_t st, const TailArgs& A) {
   static unsigned long long raised = 0;
-  constexpr int lds = (kBM * (16 * KS + 8) + 4 * 32 * kPatchPitch) * 2;
+  constexpr int lds = (kBM * (16 * (KS > 16 ? KS / 2 : KS) + 8) + 4 * 32 * kPatchPitch) * 2;
   auto kern = conv_tail_bf16_kernel<KS>;
   if (lds > 64 * 1024) {
     const int rc = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &raised);
@@ -253,7 +270,8 @@ extern "C" int egtr_conv1x1_tail_bf16(egtr_stream_t stream, const uint16_t* a, i
       (reinterpret_cast<uintptr_t>(w_packed) & 15) || (reinterpret_cast<uintptr_t>(a_shift) & 15) ||
       (reinterpret_cast<uintptr_t>(bias) & 15) || (reinterpret_cast<uintptr_t>(shortcut) & 15))
     return EGTR_E_UNSUPPORTED;
-  TailArgs A{a, a_shift, w_packed, bias, shortcut, y, M, N, lda, ld_shortcut, ldy, relu_in, relu_out};
+  TailArgs A{a, a_shift, w_packed, bias, shortcut, y, M, N, lda, ld_shortcut, ldy, relu_in, relu_out,
+             (long long)M * K * 2 >= (long long)N * K * 2 ? 1 : 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (K) {
     case 64: return launch<4>(st, A);

@@ -17,8 +17,10 @@
 //   * a wave owns 32 NTW output columns for all BM rows.  Its weight fragments never touch LDS: W3 arrives pre-split in the XS
 //     format (xs_format.h: 1 KiB MFMA-operand fragments, fragment (n / 32, k / 16, piece)), one 16-byte load per lane and
 //     fragment straight into registers, two k-steps ahead of the products that consume them (plain loads: the compiler
-//     counts vmcnt).  All workgroups of a column block read the same K x BN x 6 bytes: L2 hits; workgroup -> tile order keeps a
-//     column block on one XCD (xcd_tile), so that at N = 2048, K = 512 (12 MiB of split weights) an XCD's L2 holds its eighth;
+//     counts vmcnt).  All workgroups of a column block read the same K x BN x 6 bytes: L2 hits.  The workgroup -> tile order
+//     (xcd_tile: every XCD gets a contiguous range) is chosen on the host: column blocks of a row panel side by side when the
+//     activation (4 M K bytes) is the larger operand, row panels of a column block side by side when the split weights
+//     (6 N K bytes: 6 MiB at N = 2048, K = 512 -- more than an XCD's L2) are;
 //   * MFMA roles: A operand = activation piece (i = row), B operand = weight piece (j = column) -- the other way round than in
 //     gemm_split / ffn_x6 -- so that a lane holds ONE output column and the 32 lanes of a half wave 128 consecutive bytes of a
 //     row: the shortcut reads and the stores of the epilogue (+ shift3 + shortcut, ReLU) are whole cache lines per
@@ -42,6 +44,7 @@ struct TailArgs {
   float* y;               // [M, ldy]
   int M, N, lda, ldsc, ldy;
   int relu_in, relu_out;
+  int row_major;   // tile order: 1 = the column blocks of a row panel are neighbours, 0 = the row panels of a column block
 };
 
 __device__ __forceinline__ int xcd_tile(int bid, int total) {
@@ -69,7 +72,11 @@ __global__ __launch_bounds__(256) void conv_tail_x6_kernel(TailArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mblocks = (A.M + BM - 1) / BM;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int nb = tile / mblocks, m0 = (tile - nb * mblocks) * BM;
+  // neighbours in the tile order run side by side on one XCD and share its L2: whichever operand is larger is the one
+  // that must not be fetched once per partner (the host decides: panel bytes 4 M K against weight bytes 6 N K)
+  const int nblocks = A.N / BN;
+  const int nb = A.row_major ? tile % nblocks : tile / mblocks;
+  const int m0 = (A.row_major ? tile / nblocks : tile - nb * mblocks) * BM;
   const int nt0 = nb * (BN / 32) + wave * NTW;           // first 32-column tile of this wave
 
   // weight fragment (n tile, k-step, piece) of this lane
@@ -237,7 +244,8 @@ extern "C" int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, in
       (reinterpret_cast<uintptr_t>(a_shift) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) ||
       (reinterpret_cast<uintptr_t>(shortcut) & 15))
     return EGTR_E_UNSUPPORTED;
-  TailArgs A{a, a_shift, static_cast<const char*>(w_xs), bias, shortcut, y, M, N, lda, ld_shortcut, ldy, relu_in, relu_out};
+  TailArgs A{a, a_shift, static_cast<const char*>(w_xs), bias, shortcut, y, M, N, lda, ld_shortcut, ldy, relu_in, relu_out,
+             (long long)M * K * 4 >= (long long)N * K * 6 ? 1 : 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int fn = tile_cols / 128;
   switch (K) {

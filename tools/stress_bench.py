@@ -17,9 +17,13 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--find", type=int, default=1, help="1 = MIOpen find mode (torch.backends.cudnn.benchmark), as bench.py's leg")
     a = ap.parse_args()
     from egtr_amd.runtime import GraphedForward, enable_gemm_tuning
     enable_gemm_tuning()
+    if a.find:
+        from egtr_amd.runtime import enable_conv_tuning
+        enable_conv_tuning()
     dev = torch.device("cuda:0")
     model, cfg, _ = bench.build_model(dev, {"num_queries": 300, "decoder_layers": 8})
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
