@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 16 ? 2
   constexpr int kPitch = KP + 8;         // bf16 elements per panel row
   constexpr int C8 = KP / 8;             // 16-byte chunks per panel row
   constexpr int NQ = kBM * C8 / 256;     // chunks per thread
-  constexpr int PF = 3;                  // weight fragments are requested PF k-steps ahead
+  constexpr int PF = KS == 16 ? 2 : 3;   // weight fragments are requested PF k-steps ahead (K = 256: 2, or 8 registers spill)
   constexpr int CH = NQ < 4 ? NQ : 4;    // panel chunks in flight per thread (<= 170 registers: three waves per SIMD)
   static_assert(256 % C8 == 0 && NQ >= 1, "a thread keeps one column group of the panel");
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
@@ -85,6 +85,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 16 ? 2
   const int nt0 = nb * (kBN / 32) + wave * kNTW;   // first 32-column tile of this wave
   const int col0 = nt0 * 32;
 
+  // Requests in the order the data is needed (a wave's loads return in order): the first chunk of the panel (thread t owns chunk
+  // c8 = t % C8 of rows t / C8 + (256 / C8) q), the weight fragments of the first k-steps, then shift3 and the shortcut values.
+  const int c8 = tid % C8, r0 = tid / C8;
+  uint4 v[CH];
+  auto request_panel = [&](int ph, int q0) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int row = min(m0 + r0 + (256 / C8) * (q0 + q), A.M - 1);
+      v[q] = *reinterpret_cast<const uint4*>(A.a + (size_t)row * A.lda + ph * KP + 8 * c8);
+    }
+  };
+  request_panel(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+
   const unsigned short* const wlane = A.w + ((size_t)nt0 * KS * 64 + lane) * 8;
   bf16x8 w[PF + 1][kNTW];
   auto load_w = [&](int ks, bf16x8 (&dst)[kNTW]) {
@@ -101,20 +115,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 16 ? 2
   // 32-row tile, columns 8 (lane % 8) .. + 7 of the wave's 64), requested now
   const int prow = lane >> 3, pcg = lane & 7;
   uint4 sc[kMT][4];
+  auto request_shortcut = [&]() {
 #pragma unroll
-  for (int m = 0; m < kMT; ++m)
+    for (int m = 0; m < kMT; ++m)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = min(m0 + m * 32 + prow + 8 * i, A.M - 1);
-      sc[m][i] = A.shortcut != nullptr
-                     ? *reinterpret_cast<const uint4*>(A.shortcut + (size_t)row * A.ldsc + col0 + 8 * pcg)
-                     : make_uint4(0u, 0u, 0u, 0u);
-    }
+      for (int i = 0; i < 4; ++i) {
+        const int row = min(m0 + m * 32 + prow + 8 * i, A.M - 1);
+        sc[m][i] = A.shortcut != nullptr
+                       ? *reinterpret_cast<const uint4*>(A.shortcut + (size_t)row * A.ldsc + col0 + 8 * pcg)
+                       : make_uint4(0u, 0u, 0u, 0u);
+      }
+  };
+  // K <= 64: at kernel start (the product loop is too short to cover them); longer K: behind the first panel chunk, whose
+  // registers they take over (<= 170 registers = three waves per SIMD)
+  constexpr bool kShortcutFirst = KS <= 4;
+  if constexpr (kShortcutFirst) request_shortcut();
   __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the requests to their first use)
 
-  // the panel: thread t owns chunk c8 = t % C8 of rows t / C8 + (256 / C8) q
+  // the panel: shift, ReLU, round, park
   auto build_panel = [&](int ph) {
-    const int c8 = tid % C8, r0 = tid / C8;
     float sh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (A.a_shift != nullptr) {
       const float4 s0 = *reinterpret_cast<const float4*>(A.a_shift + ph * KP + 8 * c8);
@@ -125,12 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 16 ? 2
     const bool relu_in = A.relu_in != 0;
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += CH) {
-      uint4 v[CH];
-#pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        const int row = min(m0 + r0 + (256 / C8) * (q0 + q), A.M - 1);
-        v[q] = *reinterpret_cast<const uint4*>(A.a + (size_t)row * A.lda + ph * KP + 8 * c8);
-      }
+      if (ph > 0 || q0 > 0) request_panel(ph, q0);
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
         const unsigned u[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
@@ -163,10 +177,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 16 ? 2
 #pragma unroll
     for (int m = 0; m < kMT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(pa0 + m * 32 * kPitch + 16 * j);
   };
+  float bz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto load_bias = [&]() {
+    if (A.bias != nullptr) {
+      const float4 b0 = *reinterpret_cast<const float4*>(A.bias + col0 + 8 * pcg);
+      const float4 b1 = *reinterpret_cast<const float4*>(A.bias + col0 + 8 * pcg + 4);
+      bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w;
+      bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
+    }
+  };
   static_for<PH>([&](auto ph_) {
     constexpr int ph = decltype(ph_)::value;
     if constexpr (ph > 0) __syncthreads();   // every wave has read the previous half out of LDS
     build_panel(ph);
+    if constexpr (ph == 0 && !kShortcutFirst) request_shortcut();
+    if constexpr (ph == PH - 1) load_bias();   // (requested here, not at kernel start: the panel chunks need those registers)
     __syncthreads();
     read_a(0, a[0]);
     static_for<KSP>([&](auto j_) {
@@ -186,13 +211,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KS > 16 ? 2
   // epilogue, one 32 x 64 tile at a time: D[i = n][j = m] -- lane l holds row l & 31, accumulator quad q columns 8 q + 4 (l >> 5)
   // .. + 3 of a 32-wide tile.  Rounded to bf16 (the product as the GEMM stored it) into the wave's patch, read back row-major.
   const bool relu_out = A.relu_out != 0;
-  float bz[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (A.bias != nullptr) {
-    const float4 b0 = *reinterpret_cast<const float4*>(A.bias + col0 + 8 * pcg);
-    const float4 b1 = *reinterpret_cast<const float4*>(A.bias + col0 + 8 * pcg + 4);
-    bz[0] = b0.x; bz[1] = b0.y; bz[2] = b0.z; bz[3] = b0.w;
-    bz[4] = b1.x; bz[5] = b1.y; bz[6] = b1.z; bz[7] = b1.w;
-  }
 #pragma unroll
   for (int m = 0; m < kMT; ++m) {
 #pragma unroll

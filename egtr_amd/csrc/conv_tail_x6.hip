@@ -34,6 +34,7 @@
 
 namespace {
 using namespace x6;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 struct TailArgs {
   const float* a;         // [M, lda]
@@ -52,24 +53,42 @@ __device__ __forceinline__ int xcd_tile(int bid, int total) {
   return x * q + min(x, r) + (bid >> 3);
 }
 
-template <int BM, int NTW, int KS>
-__global__ __launch_bounds__(256) void conv_tail_x6_kernel(TailArgs A) {
+#ifdef EGTR_TAIL_TIMING
+// debugging aid (tools/tail_timing.py): per workgroup of the LAST launch (no atomics: they would be the bottleneck), the
+// real-time counter (100 MHz) at entry and exit and the shader-clock stamps of wave 0 between the phases
+constexpr int kTailRecWg = 4096;
+__device__ unsigned long long g_tail_rec[kTailRecWg][8];
+#define TAIL_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define TAIL_T(v) do { } while (0)
+#endif
+
+template <int BM, int NTW, int KS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv_tail_x6_kernel(TailArgs A) {
   constexpr int K = 16 * KS;
   constexpr int MT = BM / 32;            // 32-row MFMA tiles of the panel
-  constexpr int BN = 128 * NTW;          // output columns per workgroup
+  constexpr int BN = 32 * NTW * NW;      // output columns per workgroup
+  constexpr int NT = 64 * NW;            // threads
   constexpr int kPitch = K + 8;          // bf16 elements per LDS row
   constexpr int C4 = K / 4;              // float4 per panel row
-  constexpr int NQ = BM * C4 / 256;      // float4 per thread
+  constexpr int NQ = BM * C4 / NT;       // float4 per thread
   // weight fragments are requested PF k-steps ahead (K = 64: all of them up front).  Measured and not kept (600 x 1000, inside
   // the forward): PF = 6-8 for K >= 256 together with one LDS-DMA touch per 128-byte line of the wave's weight block at kernel
   // start (all first-touch misses in flight at once): 16.5 -> 19.6 us (K = 256), 20.4 -> 28.3 us (K = 512) per launch.
-  constexpr int PF = KS <= 4 ? 4 : 3;
-  static_assert(256 % C4 == 0 && NQ >= 1, "a thread keeps one column group of the panel");
+#ifndef EGTR_TAIL_PF_LONG
+#define EGTR_TAIL_PF_LONG 3
+#endif
+  constexpr int PF = KS <= 4 ? 4 : EGTR_TAIL_PF_LONG;
+  static_assert(NT % C4 == 0 && NQ >= 1, "a thread keeps one column group of the panel");
   extern __shared__ __attribute__((aligned(16))) char s_raw[];
   __bf16* const sA = reinterpret_cast<__bf16*>(s_raw);   // [3][BM][kPitch]
 
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef EGTR_TAIL_TIMING
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  TAIL_T(t0);
   const int mblocks = (A.M + BM - 1) / BM;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   // neighbours in the tile order run side by side on one XCD and share its L2: whichever operand is larger is the one
@@ -78,6 +97,24 @@ __global__ __launch_bounds__(256) void conv_tail_x6_kernel(TailArgs A) {
   const int nb = A.row_major ? tile % nblocks : tile / mblocks;
   const int m0 = (A.row_major ? tile / nblocks : tile - nb * mblocks) * BM;
   const int nt0 = nb * (BN / 32) + wave * NTW;           // first 32-column tile of this wave
+
+  // Requests in the order the data is needed -- a wave's loads return in order, so whatever is requested first is what the
+  // first wait waits for: the panel rows (thread t owns column group c4 = t % C4 of rows t / C4 + (NT / C4) q), then the weight
+  // fragments of the first k-steps, then shift3 and the shortcut values (needed last, after the products).
+  const int c4 = tid % C4, r0 = tid / C4;
+  constexpr int CH = NQ < 8 ? NQ : 8;   // panel loads in flight per thread
+  f32x4v v[CH];
+  auto request_panel = [&](int q0) {
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+      const int row = min(m0 + r0 + (NT / C4) * (q0 + q), A.M - 1);
+      v[q] = *reinterpret_cast<const f32x4v*>(A.a + (size_t)row * A.lda + 4 * c4);
+    }
+  };
+  request_panel(0);
+  f32x4v sh = {0.f, 0.f, 0.f, 0.f};
+  if (A.a_shift != nullptr) sh = *reinterpret_cast<const f32x4v*>(A.a_shift + 4 * c4);
+  __builtin_amdgcn_sched_barrier(0);   // (keeps this order: the scheduler would sort the requests by address readiness)
 
   // weight fragment (n tile, k-step, piece) of this lane
   const char* const wlane = A.w + (size_t)nt0 * KS * (3 * xs::kFragBytes) + lane * 16;
@@ -93,6 +130,9 @@ __global__ __launch_bounds__(256) void conv_tail_x6_kernel(TailArgs A) {
     constexpr int i = decltype(i_)::value;
     if constexpr (i < KS) load_w(i, w[i]);
   });
+  float bz[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) bz[t] = A.bias != nullptr ? A.bias[(nt0 + t) * 32 + li] : 0.f;
   // the shortcut values of this lane's outputs, requested now (D[i = m][j = n]: lane l holds column n = l & 31 of a 32-wide
   // tile, accumulator r row (r & 3) + 8 (r >> 2) + 4 (l >> 5)): they arrive under the panel build and the products
   float sc[MT][NTW][16];
@@ -116,35 +156,28 @@ __global__ __launch_bounds__(256) void conv_tail_x6_kernel(TailArgs A) {
   }
   __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks the requests to their first use: no prefetch left)
 
-  // the panel: thread t owns column group c4 = t % C4 of rows t / C4 + (256 / C4) q
+  // the panel: shift, ReLU, split, park
   {
-    const int c4 = tid % C4, r0 = tid / C4;
-    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (A.a_shift != nullptr) sh = *reinterpret_cast<const float4*>(A.a_shift + 4 * c4);
     const bool relu_in = A.relu_in != 0;
-    constexpr int CH = NQ < 8 ? NQ : 8;   // loads in flight per thread
 #pragma unroll
     for (int q0 = 0; q0 < NQ; q0 += CH) {
-      float4 v[CH];
+      if (q0 > 0) request_panel(q0);
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
-        const int row = min(m0 + r0 + (256 / C4) * (q0 + q), A.M - 1);
-        v[q] = *reinterpret_cast<const float4*>(A.a + (size_t)row * A.lda + 4 * c4);
-      }
-#pragma unroll
-      for (int q = 0; q < CH; ++q) {
-        float4 t = make_float4(v[q].x + sh.x, v[q].y + sh.y, v[q].z + sh.z, v[q].w + sh.w);
-        if (relu_in) t = make_float4(egtr_relu(t.x), egtr_relu(t.y), egtr_relu(t.z), egtr_relu(t.w));
+        f32x4v t = v[q] + sh;
+        if (relu_in) t = f32x4v{egtr_relu(t.x), egtr_relu(t.y), egtr_relu(t.z), egtr_relu(t.w)};
         const xs::Split3 s0 = xs::split3_fast(t.x), s1 = xs::split3_fast(t.y), s2 = xs::split3_fast(t.z),
                          s3 = xs::split3_fast(t.w);
-        __bf16* p = sA + (r0 + (256 / C4) * (q0 + q)) * kPitch + 4 * c4;
+        __bf16* p = sA + (r0 + (NT / C4) * (q0 + q)) * kPitch + 4 * c4;
         *reinterpret_cast<uint2*>(p) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
         *reinterpret_cast<uint2*>(p + BM * kPitch) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
         *reinterpret_cast<uint2*>(p + 2 * BM * kPitch) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
       }
     }
   }
+  TAIL_T(t1);
   __syncthreads();
+  TAIL_T(t2);
 
   f32x16 acc[MT][NTW];
 #pragma unroll
@@ -178,12 +211,13 @@ __global__ __launch_bounds__(256) void conv_tail_x6_kernel(TailArgs A) {
     __builtin_amdgcn_sched_barrier(0);
   });
 
+  TAIL_T(t3);
   // epilogue: the 32 lanes of a half wave write 128 CONSECUTIVE bytes of one row per instruction
   const bool relu_out = A.relu_out != 0;
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     const int col = (nt0 + t) * 32 + li;
-    const float b = A.bias != nullptr ? A.bias[col] : 0.f;
+    const float b = bz[t];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -195,20 +229,36 @@ __global__ __launch_bounds__(256) void conv_tail_x6_kernel(TailArgs A) {
       }
     }
   }
+#ifdef EGTR_TAIL_TIMING
+  TAIL_T(t4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TAIL_T(t5);
+  if (tid == 0 && blockIdx.x < kTailRecWg) {
+    unsigned long long* r = g_tail_rec[blockIdx.x];
+    r[0] = rt0;
+    r[1] = __builtin_amdgcn_s_memrealtime();
+    r[2] = t1 - t0;   // requests + panel build (the loads' latency is waited for here)
+    r[3] = t2 - t1;   // barrier
+    r[4] = t3 - t2;   // products
+    r[5] = t4 - t3;   // epilogue up to the last store instruction
+    r[6] = t5 - t4;   // the stores' completion
+    r[7] = 1;
+  }
+#endif
 }
 
-template <int BM, int NTW, int KS>
+template <int BM, int NTW, int KS, int NW = 4>
 int launch(hipStream_t st, const TailArgs& A) {
   static unsigned long long raised = 0;
   constexpr int lds = 3 * BM * (16 * KS + 8) * 2;
-  auto kern = conv_tail_x6_kernel<BM, NTW, KS>;
+  auto kern = conv_tail_x6_kernel<BM, NTW, KS, NW>;
   if (lds > 64 * 1024) {
     const int rc = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &raised);
     if (rc != EGTR_OK) return rc;
   }
-  const long long tiles = (long long)((A.M + BM - 1) / BM) * (A.N / (128 * NTW));
+  const long long tiles = (long long)((A.M + BM - 1) / BM) * (A.N / (32 * NTW * NW));
   if (tiles >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), lds, st, A);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(64 * NW), lds, st, A);
   return egtr_check_launch();
 }
 
@@ -227,11 +277,30 @@ int dispatch(hipStream_t st, const TailArgs& A, int force_bm, int force_ntw) {
   if constexpr (KS <= 16) {
     if (bm == 64) return ntw == 2 ? launch<64, 2, KS>(st, A) : launch<64, 1, KS>(st, A);
   }
+  if constexpr (KS >= 32) {
+    // K = 512: the panel fills the LDS (one workgroup per CU), so the 256-column block is 8 waves x 32 columns -- twice the
+    // waves streaming weight fragments and building the panel (16.6 -> 14.5 us per launch at M = 608)
+    if (bm == 32 && ntw == 2) return launch<32, 1, KS, 8>(st, A);
+  }
   if (bm == 32) return ntw == 2 ? launch<32, 2, KS>(st, A) : launch<32, 1, KS>(st, A);
   return EGTR_E_ARG;
 }
 
 }  // namespace
+
+#ifdef EGTR_TAIL_TIMING
+extern "C" int egtr_conv_tail_stamps(unsigned long long* host_out, int reset) {   // host_out: kTailRecWg x 8
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tail_rec), sizeof(unsigned long long) * kTailRecWg * 8) != hipSuccess)
+    return EGTR_E_LAUNCH;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tail_rec)) != hipSuccess ||
+        hipMemset(p, 0, sizeof(unsigned long long) * kTailRecWg * 8) != hipSuccess)
+      return EGTR_E_LAUNCH;
+  }
+  return EGTR_OK;
+}
+#endif
 
 extern "C" int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, int lda, const float* a_shift, int relu_in,
                                         const void* w_xs, const float* bias, const float* shortcut, int ld_shortcut,
