@@ -1,0 +1,212 @@
+// 3x3 convolution (stride 1, padding 1, no bias) on channels-last fp32 data with fp32-level accuracy on the bf16 matrix cores:
+// the middle convolution of a ResNet bottleneck in inference (reference: model/deformable_detr.py:735-760, the timm ResNet-50
+// backbone; frozen batch norm folded into the weights, its shift + ReLU applied by the consumer, conv_tail_x6.hip).
+//     y[b, h, w, n] = sum_{dy, dx, c} x[b, h + dy - 1, w + dx - 1, c] * W[n, c, dy, dx]
+// MIOpen serves these with fp32-MFMA implicit-GEMM kernels at 65-75 TFLOP/s (37-42 us per convolution at 600 x 1000, bs 1).
+// Here: the six-term split-bf16 product of the x6 kernels (x6_common.h) as an implicit GEMM whose activation operand never leaves
+// the CU once loaded:
+//   * a workgroup (4 waves) owns TH x TW output pixels x all BN output channels of its column block.  The (TH + 2) x (TW + 2)
+//     input halo tile is loaded once, split into its three bf16 pieces and parked in LDS as [piece][halo pixel][C + 8]; pixels
+//     outside the image are zeros (the padding);
+//   * the product loop walks the 9 taps x C / 16 k-steps: the activation fragment of a tap is the SAME LDS tile read at a shifted
+//     pixel -- per lane one base address, tap / k-step / piece are immediate offsets; the weight fragments stream from global
+//     memory in the XS operand format of the [N, 9 C] matrix W[n][dy][dx][c] (egtr_xs_split_f32), straight into registers,
+//     PF k-steps ahead;
+//   * MFMA roles as in conv_tail_x6 (A = activation pixels, B = weight columns): a lane holds one output channel and a half wave
+//     128 consecutive bytes of a pixel: whole-line stores.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+#include "x6_common.h"
+#include "xs_format.h"
+
+namespace {
+using namespace x6;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* x;   // [B, H, W, C] channels-last
+  const char* w;    // XS(Wm [N, 9 C]), Wm[n][(dy * 3 + dx) * C + c]
+  float* y;         // [B, H, W, N]
+  int B, H, W, N;
+  int tiles_x, tiles_y;
+};
+
+// TH x TW output pixels per workgroup; an MFMA row tile is 4 rows x 8 pixels (TW == 8), MT = TH / 4 of them, split over WM
+// wave rows; WN = 4 / WM waves side by side over the 32-column tiles.
+template <int C, int TH, int WM, int NTW>
+__global__ __launch_bounds__(256) void conv3x3_x6_kernel(ConvArgs A) {
+  constexpr int TW = 8;
+  constexpr int HW_ = TW + 2, HH = TH + 2, HP = HH * HW_;   // halo tile
+  constexpr int KC = C / 16;                                // k-steps per tap
+  constexpr int KS = 9 * KC;
+  constexpr int kPitch = C + 8;                             // bf16 elements per halo pixel in LDS
+  constexpr int MTW = (TH / 4) / WM;                        // row tiles per wave
+  constexpr int WN = 4 / WM;
+  constexpr int BN = 32 * NTW * WN;                         // output channels per workgroup
+  constexpr int PF = 3;
+  constexpr int C4 = C / 4;
+  static_assert(TH % (4 * WM) == 0 && 4 % WM == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  __bf16* const sA = reinterpret_cast<__bf16*>(s_raw);   // [3][HP][kPitch]
+
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nblocks = A.N / BN;
+  int t = blockIdx.x;
+  const int nb = t % nblocks;
+  t /= nblocks;
+  const int tx = t % A.tiles_x;
+  t /= A.tiles_x;
+  const int ty = t % A.tiles_y, b = t / A.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int nt0 = nb * (BN / 32) + wn * NTW;
+
+  // weight fragments of the first k-steps
+  const char* const wlane = A.w + (size_t)nt0 * KS * (3 * xs::kFragBytes) + lane * 16;
+  bf16x8 w[PF + 1][NTW][3];
+  auto load_w = [&](int ks, bf16x8 (&dst)[NTW][3]) {
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dst[tt][p] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)(tt * KS + ks) * 3 + p) * xs::kFragBytes);
+  };
+
+  // the halo tile: chunk idx = halo pixel * C4 + c4; pixels outside the image are zeros
+  {
+    constexpr int CHUNKS = HP * C4;
+    constexpr int NQ = (CHUNKS + 255) / 256;
+    constexpr int CH = 6;
+    const float* const xb = A.x + (size_t)b * A.H * A.W * C;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += CH) {
+      f32x4v v[CH];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int idx = tid + 256 * (q0 + q);
+        const int hp = idx / C4, c4 = idx % C4;
+        const int gy = y0 - 1 + hp / HW_, gx = x0 - 1 + hp % HW_;
+        const bool in = (q0 + q < NQ) && idx < CHUNKS && gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
+        v[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        if (in) v[q] = *reinterpret_cast<const f32x4v*>(xb + ((size_t)gy * A.W + gx) * C + 4 * c4);
+      }
+      if (q0 == 0) {
+        static_for<PF>([&](auto i_) {
+          constexpr int i = decltype(i_)::value;
+          load_w(i, w[i]);
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int idx = tid + 256 * (q0 + q);
+        if (q0 + q < NQ && idx < CHUNKS) {
+          const int hp = idx / C4, c4 = idx % C4;
+          const xs::Split3 s0 = xs::split3_fast(v[q].x), s1 = xs::split3_fast(v[q].y), s2 = xs::split3_fast(v[q].z),
+                           s3 = xs::split3_fast(v[q].w);
+          __bf16* p = sA + hp * kPitch + 4 * c4;
+          *reinterpret_cast<uint2*>(p) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
+          *reinterpret_cast<uint2*>(p + HP * kPitch) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
+          *reinterpret_cast<uint2*>(p + 2 * HP * kPitch) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][tt][r] = 0.f;
+
+  // lane -> pixel (li / 8, li % 8) of a 4 x 8 row tile; row tile m of this wave starts at tile row 4 (wm MTW + m)
+  const __bf16* pa[MTW];
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+    pa[m] = sA + ((4 * (wm * MTW + m) + (li >> 3)) * HW_ + (li & 7)) * kPitch + 8 * hf;
+  bf16x8 a[2][MTW][3];
+  auto read_a = [&](auto ks_, bf16x8 (&dst)[MTW][3]) {
+    constexpr int ks = decltype(ks_)::value;
+    constexpr int tap = ks / KC, kc = ks % KC;
+    constexpr int off = ((tap / 3) * HW_ + (tap % 3)) * kPitch + 16 * kc;   // halo origin is (-1, -1): tap (dy, dx) reads (py + dy, px + dx)
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[m][p] = *reinterpret_cast<const bf16x8*>(pa[m] + p * HP * kPitch + off);
+  };
+  read_a(std::integral_constant<int, 0>{}, a[0]);
+  static_for<KS>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    if constexpr (ks + PF < KS) load_w(ks + PF, w[(ks + PF) % (PF + 1)]);
+    if constexpr (ks + 1 < KS) read_a(std::integral_constant<int, ks + 1>{}, a[(ks + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) acc[m][tt] = mfma6(a[ks & 1][m], w[ks % (PF + 1)][tt], acc[m][tt]);
+    __builtin_amdgcn_sched_barrier(0);
+  });
+
+  // epilogue: D[i = pixel][j = channel]: lane l holds channel l & 31 of a 32-wide tile, accumulator r pixel (r & 3) + 8 (r >> 2)
+  // + 4 (l >> 5) of the 4 x 8 row tile
+  float* const yb = A.y + (size_t)b * A.H * A.W * A.N;
+#pragma unroll
+  for (int m = 0; m < MTW; ++m)
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) {
+      const int col = (nt0 + tt) * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const int gy = y0 + 4 * (wm * MTW + m) + (p >> 3), gx = x0 + (p & 7);
+        if (gy < A.H && gx < A.W) yb[((size_t)gy * A.W + gx) * A.N + col] = acc[m][tt][r];
+      }
+    }
+}
+
+template <int C, int TH, int WM, int NTW>
+int launch(hipStream_t st, ConvArgs A) {
+  static unsigned long long raised = 0;
+  constexpr int lds = 3 * (TH + 2) * 10 * (C + 8) * 2;
+  constexpr int BN = 32 * NTW * (4 / WM);
+  auto kern = conv3x3_x6_kernel<C, TH, WM, NTW>;
+  if (lds > 64 * 1024) {
+    const int rc = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &raised);
+    if (rc != EGTR_OK) return rc;
+  }
+  A.tiles_x = (A.W + 7) / 8;
+  A.tiles_y = (A.H + TH - 1) / TH;
+  const long long wgs = (long long)A.B * A.tiles_x * A.tiles_y * (A.N / BN);
+  if (wgs >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, st, A);
+  return egtr_check_launch();
+}
+
+}  // namespace
+
+extern "C" int egtr_conv3x3_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, float* y, int B, int H, int W, int C,
+                                   int N, int variant) {
+  if (!x || !w_xs || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return EGTR_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(w_xs) & 15))
+    return EGTR_E_UNSUPPORTED;
+  ConvArgs A{x, static_cast<const char*>(w_xs), y, B, H, W, N, 0, 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (C == 64 && N == 64) {
+    // 16 x 8 pixels x 64 channels: waves = 2 (pixel halves) x 2 (32-channel tiles); or 8 x 8 pixels
+    if (variant == 1) return launch<64, 8, 2, 1>(st, A);
+    return launch<64, 16, 2, 1>(st, A);
+  }
+  if (C == 128 && N == 128) {
+    // 4 x 8 pixels x 128 channels (4 waves x 32 channels); or 8 x 8 pixels x 64 channels
+    if (variant == 1) return launch<128, 8, 2, 1>(st, A);
+    return launch<128, 4, 1, 1>(st, A);
+  }
+  if (C == 256 && N == 256) return launch<256, 4, 1, 1>(st, A);   // 4 x 8 pixels x 128 channels, two column blocks
+  return EGTR_E_UNSUPPORTED;
+}

@@ -1632,6 +1632,34 @@ def conv1x1_tail(a, a_shift, w_xs, bias, shortcut, N, relu_in=True, relu_out=Tru
     return y
 
 
+def conv3x3_supported(x, N):
+    """Shapes the split-bf16 3x3 convolution serves (csrc/conv3x3_x6.hip): channels-last fp32 [B, C, H, W] tensors (dense NHWC
+    memory), stride 1 / padding 1, (C, N) one of the pairs below."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and (x.shape[1], N) in CONV3X3_SHAPES and x.data_ptr() % 16 == 0)
+
+
+CONV3X3_SHAPES = ((64, 64), (128, 128), (256, 256))
+
+
+def conv3x3_weights(w):
+    """W [N, C, 3, 3] fp32 -> the XS operand stream of the [N, 9 C] matrix W[n][dy][dx][c] (csrc/conv3x3_x6.hip)."""
+    N, C = w.shape[:2]
+    return xs_split(w.detach().permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), weights=True)
+
+
+def conv3x3(x, w_xs, N, variant=0):
+    """3x3 convolution, stride 1, padding 1, no bias, on a channels-last fp32 tensor in ONE HIP launch with fp32-level accuracy on
+    the bf16 matrix cores (egtr_conv3x3_x6_f32; reference: the timm ResNet-50 bottleneck's conv2, model/deformable_detr.py:735-760).
+    Returns a channels-last [B, N, H, W] tensor.  Inference only."""
+    lib = _lib.lib()
+    B, C, H, W = x.shape
+    y = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    st = lib.egtr_conv3x3_x6_f32(_stream(), x.data_ptr(), w_xs.data_ptr(), y.data_ptr(), B, H, W, C, N, int(variant))
+    _lib.check(st, "egtr_conv3x3_x6_f32")
+    return y
+
+
 def conv1x1_tail_bf16_supported(a, N):
     """Shapes the bf16 bottleneck-tail kernel serves (csrc/conv_tail_bf16.hip): bf16 pixel rows with unit inner stride, K = planes
     in {64, 128, 256, 512}, N a multiple of 256."""

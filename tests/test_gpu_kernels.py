@@ -1893,3 +1893,50 @@ def test_conv1x1_tail_bf16_optional_operands_strides_and_refusals():
     assert not ops.conv1x1_tail_bf16_supported(a, 128)
     with pytest.raises(EgtrHipError):
         ops.conv1x1_tail_bf16(a, None, wp, None, None, 128)
+
+
+# ---- the split-bf16 3x3 convolution (csrc/conv3x3_x6.hip, egtr_conv3x3_x6_f32) ---------------------------------------------
+@pytest.mark.parametrize("C", [64, 128, 256])
+@pytest.mark.parametrize("B,H,W", [(1, 38, 63), (2, 7, 9), (1, 1, 1), (1, 4, 8), (3, 17, 33)])
+def test_conv3x3_x6_matches_fp64_convolution(C, B, H, W):
+    """3x3 / stride 1 / padding 1 on channels-last fp32 tensors against torch's fp64 convolution of the same fp32 operands: the
+    six-term split-bf16 arithmetic has the error of an fp32 convolution (K = 9 C products per output: 2e-5 of the output scale
+    here; MIOpen's fp32 kernels measure 2-4e-6, this kernel 4-9e-6).  Sizes that are not multiples of the 4 x 8 / 8 x 8 / 16 x 8
+    pixel tiles, images smaller than a tile, batches; every tile variant; the padding is zeros."""
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    torch.manual_seed(C + H + W)
+    x = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(C, C, 3, 3, device=DEV) / (9 * C) ** 0.5
+    assert ops.conv3x3_supported(x, C)
+    ref = F.conv2d(x.double(), w.double(), None, stride=1, padding=1)
+    wxs = ops.conv3x3_weights(w)
+    outs = []
+    for variant in (0, 1):
+        y = ops.conv3x3(x, wxs, C, variant=variant)
+        assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+        assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), variant
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])                        # the tile decides who computes an element, not how
+    assert torch.equal(outs[0], ops.conv3x3(x, wxs, C))         # no atomics: run-to-run bit-identical
+
+
+def test_conv3x3_x6_non_finite_inputs_and_refusals():
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    from egtr_amd._lib import EgtrHipError
+    torch.manual_seed(9)
+    x = torch.randn(1, 64, 12, 20, device=DEV).contiguous(memory_format=torch.channels_last)
+    x[0, 5, 6, 7] = float("nan")
+    w = torch.randn(64, 64, 3, 3, device=DEV) / 24
+    y = ops.conv3x3(x, ops.conv3x3_weights(w), 64)
+    bad = ~torch.isfinite(y).all(dim=1)[0]                      # [H, W]: pixels with a non-finite channel
+    want = torch.zeros(12, 20, dtype=torch.bool, device=DEV)
+    want[5:8, 6:9] = True                                       # exactly the 3 x 3 neighbourhood that reads the NaN
+    assert torch.equal(bad, want)
+    ref = F.conv2d(torch.nan_to_num(x), w, None, padding=1)
+    assert float((y - ref)[0, :, ~want].abs().max()) < 1e-4
+    assert not ops.conv3x3_supported(x.contiguous(), 64)                                   # NCHW memory
+    assert not ops.conv3x3_supported(torch.randn(1, 96, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last), 96)
+    with pytest.raises(EgtrHipError):
+        ops.conv3x3(torch.randn(1, 96, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last), ops.conv3x3_weights(w), 96)

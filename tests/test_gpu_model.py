@@ -637,12 +637,28 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
         assert a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) < 2e-5 * scale
-    # with the split-bf16 routes switched off as a group the kernel is not used either
+    # the same for the 3x3 convolutions of our own (backbone.CONV2_X6: every stride-1 conv2 whose width the kernel serves)
+    calls2 = []
+    real2 = ops.conv3x3
+    monkeypatch.setattr(ops, "conv3x3", lambda *a, **k: (calls2.append(a[0].shape[1]), real2(*a, **k))[1])
+    monkeypatch.setattr(bb, "CONV3_FUSED", True)
+    with torch.no_grad():
+        on = net(x)
+        assert sorted(calls2) == [64] * 3 + [128] * 3 + [256] * 5
+        monkeypatch.setattr(bb, "CONV2_X6", False)
+        off = net(x)
+        assert len(calls2) == 11
+    for a, b in zip(on, off):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) < 5e-5 * scale
+    monkeypatch.setattr(bb, "CONV2_X6", True)
+    # with the split-bf16 routes switched off as a group the kernels are not used either
     monkeypatch.setattr(bb, "CONV3_FUSED", True)
     monkeypatch.setattr(ops, "GEMM_SPLIT_BF16", False)
+    n_tail, n_conv = len(calls), len(calls2)
     with torch.no_grad():
         net(x)
-    assert len(calls) == 16
+    assert len(calls) == n_tail and len(calls2) == n_conv
 
 
 def test_backbone_bf16_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch):

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 run_bench() {   # $1 = 0 | 1, rest = bench.py arguments
   local f=$1; shift
-  python3 -c "import sys, runpy; import egtr_amd.backbone as b; b.CONV3_FUSED = b.CONV3_FUSED and bool($f); \
+  python3 -c "import sys, runpy; import egtr_amd.backbone as b; b.CONV3_FUSED = b.CONV3_FUSED and bool($f); b.CONV2_X6 = b.CONV2_X6 and bool(int('${CONV2:-1}')); \
 b.CONV3_FUSED_BF16 = getattr(b, 'CONV3_FUSED_BF16', False) and bool($f); sys.argv = ['bench.py'] + sys.argv[1:]; \
 runpy.run_path('bench.py', run_name='__main__')" "$@"
 }
