@@ -29,7 +29,8 @@ NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 # split-bf16 routes.
 CONV3_FUSED = True        # module attributes (tests patch them for the switch-off twins)
 CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
-CONV2_X6 = True           # fp32 3x3 convolutions (stride 1) as csrc/conv3x3_x6.hip
+CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
+CONV2_X6_MAX_WIDTH = 256  # ... up to this width (at 512 channels a wave walks K = 4608 alone: 38-50 us, MIOpen 40)
 
 
 def _fold(conv, bn):
@@ -209,12 +210,14 @@ class Bottleneck(nn.Module):
         x2 = x.permute(0, 2, 3, 1).reshape(-1, C)                      # a view: channels-last IS [B*H*W, C]
         y = torch._addmm_activation(q["b1"], x2, q["w1"].t(), use_gelu=False)
         y = y.view(B, H, W_, -1).permute(0, 3, 1, 2)                   # channels-last view of the GEMM's output
-        if (CONV2_X6 and ops.GEMM_SPLIT_BF16 and tuple(self.conv2.stride) == (1, 1) and ops.conv3x3_supported(y, q["w2"].shape[0])):
+        st2 = tuple(self.conv2.stride)
+        if (CONV2_X6 and ops.GEMM_SPLIT_BF16 and st2 in ((1, 1), (2, 2)) and q["w2"].shape[0] <= CONV2_X6_MAX_WIDTH
+                and ops.conv3x3_supported(y, q["w2"].shape[0], st2[0])):
             # fp32: the 3x3 convolution as a split-bf16 implicit GEMM of our own (csrc/conv3x3_x6.hip) -- 22 us where MIOpen's
             # fp32-MFMA kernels take 41 at 600 x 1000
             if "w2xs" not in q:
-                q["w2xs"] = ops.conv3x3_weights(q["w2"])
-            y = ops.conv3x3(y, q["w2xs"], q["w2"].shape[0])
+                q["w2xs"] = ops.conv3x3_weights(q["w2"], st2[0])
+            y = ops.conv3x3(y, q["w2xs"], q["w2"].shape[0], st2[0])
         else:
             y = F.conv2d(y, q["w2"], None, stride=self.conv2.stride, padding=1)
         if not y.is_contiguous(memory_format=torch.channels_last):

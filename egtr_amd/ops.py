@@ -1632,30 +1632,35 @@ def conv1x1_tail(a, a_shift, w_xs, bias, shortcut, N, relu_in=True, relu_out=Tru
     return y
 
 
-def conv3x3_supported(x, N):
+def conv3x3_supported(x, N, stride=1, variant=0):
     """Shapes the split-bf16 3x3 convolution serves (csrc/conv3x3_x6.hip): channels-last fp32 [B, C, H, W] tensors (dense NHWC
-    memory), stride 1 / padding 1, (C, N) one of the pairs below."""
+    memory), padding 1, C == N in {64, 128, 256, 512} at stride 1 and {128, 256, 512} at stride 2."""
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
-            and (x.shape[1], N) in CONV3X3_SHAPES and x.data_ptr() % 16 == 0)
+            and x.data_ptr() % 16 == 0
+            and int(_lib.lib().egtr_conv3x3_phase_channels(int(x.shape[1]), int(N), int(stride), int(variant))) > 0)
 
 
-CONV3X3_SHAPES = ((64, 64), (128, 128), (256, 256))
-
-
-def conv3x3_weights(w):
-    """W [N, C, 3, 3] fp32 -> the XS operand stream of the [N, 9 C] matrix W[n][dy][dx][c] (csrc/conv3x3_x6.hip)."""
+def conv3x3_weights(w, stride=1, variant=0):
+    """W [N, C, 3, 3] fp32 -> the XS operand stream of the [N, 9 C] matrix the kernel for (C, N, stride, variant) walks: channels
+    in phases of CP (egtr_conv3x3_phase_channels), within a phase W[n][dy][dx][c'] (csrc/conv3x3_x6.hip)."""
     N, C = w.shape[:2]
-    return xs_split(w.detach().permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous(), weights=True)
+    cp = int(_lib.lib().egtr_conv3x3_phase_channels(int(C), int(N), int(stride), int(variant)))
+    if cp <= 0:
+        raise RuntimeError(f"conv3x3_weights: C = {C}, N = {N}, stride {stride} is not served")
+    wm = w.detach().reshape(N, C // cp, cp, 3, 3).permute(0, 1, 3, 4, 2).reshape(N, 9 * C).contiguous()
+    return xs_split(wm, weights=True)
 
 
-def conv3x3(x, w_xs, N, variant=0):
-    """3x3 convolution, stride 1, padding 1, no bias, on a channels-last fp32 tensor in ONE HIP launch with fp32-level accuracy on
-    the bf16 matrix cores (egtr_conv3x3_x6_f32; reference: the timm ResNet-50 bottleneck's conv2, model/deformable_detr.py:735-760).
-    Returns a channels-last [B, N, H, W] tensor.  Inference only."""
+def conv3x3(x, w_xs, N, stride=1, variant=0):
+    """3x3 convolution, stride 1 or 2, padding 1, no bias, on a channels-last fp32 tensor in ONE HIP launch with fp32-level
+    accuracy on the bf16 matrix cores (egtr_conv3x3_x6_f32; reference: the timm ResNet-50 bottleneck's conv2,
+    model/deformable_detr.py:735-760).  ``w_xs`` from ``conv3x3_weights`` with the same stride / variant.  Returns a channels-last
+    [B, N, Ho, Wo] tensor.  Inference only."""
     lib = _lib.lib()
     B, C, H, W = x.shape
-    y = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    st = lib.egtr_conv3x3_x6_f32(_stream(), x.data_ptr(), w_xs.data_ptr(), y.data_ptr(), B, H, W, C, N, int(variant))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, N, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    st = lib.egtr_conv3x3_x6_f32(_stream(), x.data_ptr(), w_xs.data_ptr(), y.data_ptr(), B, H, W, C, N, int(stride), int(variant))
     _lib.check(st, "egtr_conv3x3_x6_f32")
     return y
 

@@ -691,14 +691,17 @@ int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, int lda, cons
                              const void* w_xs, const float* bias, const float* shortcut, int ld_shortcut, int relu_out,
                              float* y, int ldy, int M, int K, int N, int tile_rows, int tile_cols);
 
-/* 3x3 convolution, stride 1, padding 1, no bias, channels-last fp32 (x [B, H, W, C] -> y [B, H, W, N]) with the six-term
- * split-bf16 arithmetic (error of an fp32 convolution): the middle convolution of a ResNet bottleneck in inference
- * (model/deformable_detr.py:735-760, timm ResNet-50; the folded batch norm's shift + ReLU is applied by the consumer,
- * egtr_conv1x1_tail_x6_f32).  w_xs = XS(Wm [N, 9 C]) with Wm[n][(dy * 3 + dx) * C + c] = W[n][c][dy][dx]
- * (egtr_xs_split_f32, round_to_nearest = 1).  Shapes served: see egtr_amd/ops.py::conv3x3_supported (EGTR_E_UNSUPPORTED
- * otherwise).  variant: 0 = the library's tile, other values pin a tile (tools/conv3x3_ab.py). */
+/* 3x3 convolution, stride 1 or 2, padding 1, no bias, channels-last fp32 (x [B, H, W, C] -> y [B, Ho, Wo, N], Ho = (H - 1) /
+ * stride + 1) with the six-term split-bf16 arithmetic (error of an fp32 convolution): the middle convolution of a ResNet
+ * bottleneck in inference (model/deformable_detr.py:735-760, timm ResNet-50; the folded batch norm's shift + ReLU is applied by
+ * the consumer, egtr_conv1x1_tail_x6_f32).  w_xs = XS(Wm [N, 9 C]) (egtr_xs_split_f32, round_to_nearest = 1) with the
+ * channels in phases of CP = egtr_conv3x3_phase_channels(C, N, stride, variant):
+ *     Wm[n][((ph * 3 + dy) * 3 + dx) * CP + c'] = W[n][ph * CP + c'][dy][dx]        (CP == C: Wm[n][(dy * 3 + dx) * C + c])
+ * Served: C == N in {64, 128, 256, 512} at stride 1, {128, 256, 512} at stride 2 (phase_channels returns 0 and the
+ * convolution EGTR_E_UNSUPPORTED otherwise).  variant: 0 = the library's tile, other values pin a tile (tools/conv3x3_ab.py). */
+int egtr_conv3x3_phase_channels(int C, int N, int stride, int variant);
 int egtr_conv3x3_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, float* y, int B, int H, int W, int C, int N,
-                        int variant);
+                        int stride, int variant);
 
 /* The bf16 twin (the bf16 model of the stress configuration): a, shortcut, y bf16 (raw bits), shifts fp32, fp32 accumulation;
  *     y = act_out( bf16( act_in(a + a_shift) . W^T ) + bias + shortcut )

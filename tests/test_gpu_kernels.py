@@ -1896,29 +1896,31 @@ def test_conv1x1_tail_bf16_optional_operands_strides_and_refusals():
 
 
 # ---- the split-bf16 3x3 convolution (csrc/conv3x3_x6.hip, egtr_conv3x3_x6_f32) ---------------------------------------------
-@pytest.mark.parametrize("C", [64, 128, 256])
-@pytest.mark.parametrize("B,H,W", [(1, 38, 63), (2, 7, 9), (1, 1, 1), (1, 4, 8), (3, 17, 33)])
-def test_conv3x3_x6_matches_fp64_convolution(C, B, H, W):
-    """3x3 / stride 1 / padding 1 on channels-last fp32 tensors against torch's fp64 convolution of the same fp32 operands: the
-    six-term split-bf16 arithmetic has the error of an fp32 convolution (K = 9 C products per output: 2e-5 of the output scale
-    here; MIOpen's fp32 kernels measure 2-4e-6, this kernel 4-9e-6).  Sizes that are not multiples of the 4 x 8 / 8 x 8 / 16 x 8
-    pixel tiles, images smaller than a tile, batches; every tile variant; the padding is zeros."""
+@pytest.mark.parametrize("C,stride", [(64, 1), (128, 1), (256, 1), (512, 1), (128, 2), (256, 2), (512, 2)])
+@pytest.mark.parametrize("B,H,W", [(1, 38, 63), (2, 7, 9), (1, 1, 1), (1, 4, 8), (3, 17, 33), (1, 8, 16)])
+def test_conv3x3_x6_matches_fp64_convolution(C, stride, B, H, W):
+    """3x3 / stride 1 or 2 / padding 1 on channels-last fp32 tensors against torch's fp64 convolution of the same fp32 operands:
+    the six-term split-bf16 arithmetic has the error of an fp32 convolution (K = 9 C products per output: 2e-5 of the output
+    scale here; MIOpen's fp32 kernels measure 2-4e-6, this kernel 4-9e-6).  Sizes that are not multiples of the pixel tiles, odd
+    sizes at stride 2, images smaller than a tile, batches; every tile / phase variant; the padding is zeros."""
     import torch.nn.functional as F
     from egtr_amd import ops
     torch.manual_seed(C + H + W)
     x = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
     w = torch.randn(C, C, 3, 3, device=DEV) / (9 * C) ** 0.5
-    assert ops.conv3x3_supported(x, C)
-    ref = F.conv2d(x.double(), w.double(), None, stride=1, padding=1)
-    wxs = ops.conv3x3_weights(w)
+    assert ops.conv3x3_supported(x, C, stride)
+    ref = F.conv2d(x.double(), w.double(), None, stride=stride, padding=1)
     outs = []
-    for variant in (0, 1):
-        y = ops.conv3x3(x, wxs, C, variant=variant)
+    for variant in (0, 1, 2, 3, 4):
+        if variant and not (stride == 1 and variant in {64: (1, 2, 3), 128: (1, 3, 4), 256: (1,)}.get(C, ())):
+            continue
+        y = ops.conv3x3(x, ops.conv3x3_weights(w, stride, variant), C, stride, variant)
         assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
         assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), variant
-        outs.append(y)
-    assert torch.equal(outs[0], outs[1])                        # the tile decides who computes an element, not how
-    assert torch.equal(outs[0], ops.conv3x3(x, wxs, C))         # no atomics: run-to-run bit-identical
+        outs.append((variant, y))
+    # a tile decides who computes an element, not how (C = 256: the phased default sums the channels in another order)
+    assert all(torch.equal(outs[0][1], o) for v, o in outs[1:] if C != 256)
+    assert torch.equal(outs[0][1], ops.conv3x3(x, ops.conv3x3_weights(w, stride), C, stride))   # run-to-run bit-identical
 
 
 def test_conv3x3_x6_non_finite_inputs_and_refusals():
@@ -1930,6 +1932,8 @@ def test_conv3x3_x6_non_finite_inputs_and_refusals():
     x[0, 5, 6, 7] = float("nan")
     w = torch.randn(64, 64, 3, 3, device=DEV) / 24
     y = ops.conv3x3(x, ops.conv3x3_weights(w), 64)
+    y2 = ops.conv3x3(x, ops.conv3x3_weights(torch.randn(128, 128, 3, 3, device=DEV)[:64, :64].contiguous(), 1), 64)
+    assert y2.shape == y.shape
     bad = ~torch.isfinite(y).all(dim=1)[0]                      # [H, W]: pixels with a non-finite channel
     want = torch.zeros(12, 20, dtype=torch.bool, device=DEV)
     want[5:8, 6:9] = True                                       # exactly the 3 x 3 neighbourhood that reads the NaN
