@@ -1194,6 +1194,11 @@ def main():
             "encoder layer: value (256->256) + offsets/weights (256->384, + position rows on load), M=12537, one launch",
             g_us, g_flops, 6 * g_flops, "gemm_split_bf16_f32"))
         result["config"]["encoder_linears"] = "fp32 via bf16x6 operand split, fp32 accumulate"
+        import egtr_amd.backbone as _bb
+        result["config"]["backbone"] = ("ResNet-50, frozen BN folded, channels-last; 3x3 convolutions of layers 1-3 "
+                                        + ("own split-bf16 implicit GEMM (fp32 accumulate)" if _bb.CONV2_X6 else "MIOpen")
+                                        + ", bottleneck tails " + ("own fused kernel" if _bb.CONV3_FUSED else "vendor GEMM + passes")
+                                        + ", the rest MIOpen / hipBLASLt")
         t_us, t_flops = time_encoder_tail(dev)
         if t_us is not None:
             tail_entry = x6_entry(
