@@ -30,7 +30,7 @@ NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 CONV3_FUSED = True        # module attributes (tests patch them for the switch-off twins)
 CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
 CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
-CONV2_X6_MAX_WIDTH = 256  # ... up to this width (at 512 channels a wave walks K = 4608 alone: 38-50 us, MIOpen 40)
+CONV2_X6_MAX_WIDTH = 512  # ... up to this width (all 16 of ResNet-50)
 
 
 def _fold(conv, bn):

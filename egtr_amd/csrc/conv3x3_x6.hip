@@ -325,6 +325,161 @@ __global__ __launch_bounds__(256) void conv3x3_x6_phased_kernel(ConvArgs A) {
   }
 }
 
+// The phased kernel with K split over the waves (C = 512: one wave walking K = 4608 alone takes 24 us of matrix time).  A workgroup
+// owns 4 x 8 output pixels x ONE 32-channel tile; within every phase wave q multiplies the q-th quarter of the phase's channels
+// (all 9 taps), so a wave walks K / 4; the four partial tiles meet in LDS at the end (fixed order: wave 0 + 1 + 2 + 3), each wave
+// finishing and storing a quarter of the rows.
+template <int C, int CP, int STRIDE>
+__global__ __launch_bounds__(256) void conv3x3_x6_ksplit_kernel(ConvArgs A) {
+  constexpr int TH = 4, TW = 8;
+  constexpr int HH = STRIDE * (TH - 1) + 3, HW_ = STRIDE * (TW - 1) + 3, HP = HH * HW_;
+  constexpr int PH = C / CP;
+  constexpr int KCP = CP / 16;            // k-steps per tap and phase
+  constexpr int KSP = 9 * KCP;            // k-steps per phase (all waves)
+  constexpr int KCW = KCP / 4;            // k-steps per tap, phase and wave
+  constexpr int JS = 9 * KCW;             // k-steps per phase and wave
+  constexpr int kPitch = CP + 8;
+  constexpr int PF = (JS % 6 == 0) ? 5 : 2;
+  constexpr int C4 = CP / 4;
+  static_assert(KCP % 4 == 0 && JS % (PF + 1) == 0, "phase shape");
+  extern __shared__ __attribute__((aligned(16))) char s_raw[];
+  __bf16* const sA = reinterpret_cast<__bf16*>(s_raw);   // [3][HP][kPitch]; afterwards the partial tiles [4][16][64] floats
+
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ntiles = A.N / 32;
+  int t = blockIdx.x;
+  const int nt = t % ntiles;
+  t /= ntiles;
+  const int tx = t % A.tiles_x;
+  t /= A.tiles_x;
+  const int ty = t % A.tiles_y, b = t / A.tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int iy0 = STRIDE * y0 - 1, ix0 = STRIDE * x0 - 1;
+
+  // k-step (phase ph, local step j) of this wave: tap j / KCW, channel step wave * KCW + j % KCW of the phase
+  const char* const wlane = A.w + (size_t)nt * (PH * KSP) * (3 * xs::kFragBytes) + lane * 16;
+  auto wptr = [&](int ph, int j) {
+    const int ks = ph * KSP + (j / KCW) * KCP + wave * KCW + (j % KCW);
+    return wlane + (size_t)ks * 3 * xs::kFragBytes;
+  };
+  bf16x8 w[PF + 1][3];
+  auto load_w = [&](int ph, int j, bf16x8 (&dst)[3]) {
+    const char* p0 = wptr(ph, j);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8*>(p0 + p * xs::kFragBytes);
+  };
+  static_for<PF>([&](auto i_) {
+    constexpr int i = decltype(i_)::value;
+    load_w(0, i, w[i]);
+  });
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* const xb = A.x + (size_t)b * A.H * A.W * C;
+  const __bf16* const pa = sA + (STRIDE * (li >> 3) * HW_ + STRIDE * (li & 7)) * kPitch + 8 * hf + 16 * KCW * wave;
+
+#pragma unroll 1
+  for (int ph = 0; ph < PH; ++ph) {
+    if (ph > 0) __syncthreads();
+    {
+      constexpr int CHUNKS = HP * C4;
+      constexpr int NQ = (CHUNKS + 255) / 256;
+      constexpr int CH = NQ < 8 ? NQ : 8;
+#pragma unroll
+      for (int q0 = 0; q0 < NQ; q0 += CH) {
+        f32x4v v[CH];
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          const int idx = tid + 256 * (q0 + q);
+          const int hp = idx / C4, c4 = idx % C4;
+          const int gy = iy0 + hp / HW_, gx = ix0 + hp % HW_;
+          const bool in = (q0 + q < NQ) && idx < CHUNKS && gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
+          v[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
+          if (in) v[q] = *reinterpret_cast<const f32x4v*>(xb + ((size_t)gy * A.W + gx) * C + ph * CP + 4 * c4);
+        }
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          const int idx = tid + 256 * (q0 + q);
+          if (q0 + q < NQ && idx < CHUNKS) {
+            const int hp = idx / C4, c4 = idx % C4;
+            const xs::Split3 s0 = xs::split3_fast(v[q].x), s1 = xs::split3_fast(v[q].y), s2 = xs::split3_fast(v[q].z),
+                             s3 = xs::split3_fast(v[q].w);
+            __bf16* p = sA + hp * kPitch + 4 * c4;
+            *reinterpret_cast<uint2*>(p) = make_uint2(xs::pack_hi16(s0.hi, s1.hi), xs::pack_hi16(s2.hi, s3.hi));
+            *reinterpret_cast<uint2*>(p + HP * kPitch) = make_uint2(xs::pack_hi16(s0.mid, s1.mid), xs::pack_hi16(s2.mid, s3.mid));
+            *reinterpret_cast<uint2*>(p + 2 * HP * kPitch) = make_uint2(xs::pack_hi16(s0.lo, s1.lo), xs::pack_hi16(s2.lo, s3.lo));
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    bf16x8 a[2][3];
+    auto read_a = [&](auto j_, bf16x8 (&dst)[3]) {
+      constexpr int j = decltype(j_)::value;
+      constexpr int tap = j / KCW, kcl = j % KCW;
+      constexpr int off = ((tap / 3) * HW_ + (tap % 3)) * kPitch + 16 * kcl;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8*>(pa + p * HP * kPitch + off);
+    };
+    read_a(std::integral_constant<int, 0>{}, a[0]);
+    static_for<JS>([&](auto j_) {
+      constexpr int j = decltype(j_)::value;
+      if constexpr (j + PF < JS) {
+        load_w(ph, j + PF, w[(j + PF) % (PF + 1)]);
+      } else {
+        if (ph + 1 < PH) load_w(ph + 1, j + PF - JS, w[(j + PF) % (PF + 1)]);   // (uniform)
+      }
+      if constexpr (j + 1 < JS) read_a(std::integral_constant<int, j + 1>{}, a[(j + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = mfma6(a[j & 1], w[j % (PF + 1)], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+
+  // the four partial tiles: [wave][accumulator r][lane] floats in LDS, then wave q sums and stores rows r = 4 q .. 4 q + 3
+  __syncthreads();
+  float* const part = reinterpret_cast<float*>(s_raw);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const int Ho = (A.H - 1) / STRIDE + 1, Wo = (A.W - 1) / STRIDE + 1;
+  float* const yb = A.y + (size_t)b * Ho * Wo * A.N;
+  const int col = nt * 32 + li;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = 4 * wave + rr;
+    const float v = ((part[(0 * 16 + r) * 64 + lane] + part[(1 * 16 + r) * 64 + lane]) + part[(2 * 16 + r) * 64 + lane]) +
+                    part[(3 * 16 + r) * 64 + lane];
+    const int p = (r & 3) + 8 * (r >> 2) + 4 * hf;
+    const int gy = y0 + (p >> 3), gx = x0 + (p & 7);
+    if (gy < Ho && gx < Wo) yb[((size_t)gy * Wo + gx) * A.N + col] = v;
+  }
+}
+
+template <int C, int CP, int STRIDE>
+int launch_ksplit(hipStream_t st, ConvArgs A) {
+  static unsigned long long raised = 0;
+  constexpr int HP = (STRIDE * 3 + 3) * (STRIDE * 7 + 3);
+  constexpr int lds = 3 * HP * (CP + 8) * 2;
+  static_assert(lds >= 4 * 16 * 64 * 4, "the partial tiles reuse the halo tile's LDS");
+  auto kern = conv3x3_x6_ksplit_kernel<C, CP, STRIDE>;
+  if (lds > 64 * 1024) {
+    const int rc = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &raised);
+    if (rc != EGTR_OK) return rc;
+  }
+  const int Ho = (A.H - 1) / STRIDE + 1, Wo = (A.W - 1) / STRIDE + 1;
+  A.tiles_x = (Wo + 7) / 8;
+  A.tiles_y = (Ho + 3) / 4;
+  const long long wgs = (long long)A.B * A.tiles_x * A.tiles_y * (A.N / 32);
+  if (wgs >= (1ll << 31)) return EGTR_E_UNSUPPORTED;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), lds, st, A);
+  return egtr_check_launch();
+}
+
 template <int C, int CP, int STRIDE>
 int launch_phased(hipStream_t st, ConvArgs A) {
   static unsigned long long raised = 0;
@@ -385,7 +540,7 @@ extern "C" int egtr_conv3x3_phase_channels(int C, int N, int stride, int variant
   if (C != N) return 0;
   if (stride == 1) {
     if (C == 64 || C == 128) return C;   // (every variant)
-    if (C == 256) return variant == 1 ? 128 : 256;
+    if (C == 256) return variant == 3 ? 256 : 128;
     if (C == 512) return 128;
     return 0;
   }
@@ -402,28 +557,35 @@ extern "C" int egtr_conv3x3_x6_f32(egtr_stream_t stream, const float* x, const v
   ConvArgs A{x, static_cast<const char*>(w_xs), y, B, H, W, N, 0, 0};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stride == 2) {
-    if (C == 128) return launch_phased<128, 64, 2>(st, A);
-    if (C == 256) return launch_phased<256, 64, 2>(st, A);
-    return launch_phased<512, 64, 2>(st, A);
+    // (inside the forward: C = 128 phased 27.1 us, K split 33.8; C = 256 phased 37.4, K split 39.6; C = 512 phased 49, K split 37)
+    if (C == 128) return variant == 1 ? launch_ksplit<128, 64, 2>(st, A) : launch_phased<128, 64, 2>(st, A);
+    if (C == 256) return variant == 1 ? launch_ksplit<256, 64, 2>(st, A) : launch_phased<256, 64, 2>(st, A);
+    if (variant == 1) return launch_phased<512, 64, 2>(st, A);
+    return launch_ksplit<512, 64, 2>(st, A);
   }
-  // variant 0 = the library's tile (tools/conv3x3_ab.py, tools/conv3x3_timing.sh: the kernels are bound by the matrix pipes during
-  // their product phase and by the halo-tile latency before it -- many small workgroups balance the CUs best); the other
-  // variants pin a tile for the tests and the sweeps
+  // variant 0 = the library's choice, by the kernels' times INSIDE the forward (tools/conv2_ab.sh; stand-alone the variants are
+  // within 10 % of each other): the kernels are bound by the matrix pipes during their product phase and by the halo-tile
+  // latency before it (tools/conv3x3_timing.sh) -- many small workgroups balance the CUs best, and from C = 128 on splitting K
+  // over the waves of a workgroup shortens the longest wave.  The other variants pin a kernel for the tests and the sweeps.
   if (C == 64) {
     if (variant == 1) return launch<64, 8, 2, 1>(st, A);     // 8 x 8 pixels x 64 channels: 2 (pixel halves) x 2 (channel tiles)
     if (variant == 2) return launch<64, 16, 2, 1>(st, A);    // 16 x 8 pixels
     if (variant == 3) return launch<64, 16, 4, 1>(st, A);    // 16 x 8 pixels x 32 channels: the four waves share a weight stream
-    return launch<64, 4, 1, 1, 2>(st, A);                    // 4 x 8 pixels x 64 channels, two waves
+    if (variant == 4) return launch_ksplit<64, 64, 1>(st, A);   // K split over the waves: 24.7 us inside the forward
+    return launch<64, 4, 1, 1, 2>(st, A);                       // 4 x 8 pixels x 64 channels, two waves: 20.4 us
   }
   if (C == 128) {
     if (variant == 1) return launch<128, 8, 2, 1>(st, A);    // 8 x 8 pixels x 64 channels
     if (variant == 3) return launch<128, 16, 4, 1>(st, A);   // 16 x 8 pixels x 32 channels
     if (variant == 4) return launch<128, 4, 1, 1, 2>(st, A); // 4 x 8 pixels x 64 channels, two waves
-    return launch<128, 4, 1, 1>(st, A);                      // 4 x 8 pixels x 128 channels (4 waves x 32)
+    if (variant == 2) return launch<128, 4, 1, 1>(st, A);    // 4 x 8 pixels x 128 channels (4 waves x 32)
+    return launch_ksplit<128, 128, 1>(st, A);
   }
   if (C == 256) {
     if (variant == 1) return launch_phased<256, 128, 1>(st, A);   // two phases of 128 channels, three workgroups per CU: 31.4 us
-    return launch<256, 4, 1, 1>(st, A);                           // inside the forward, the whole halo tile resident (95 KiB): 29.6
+    if (variant == 3) return launch<256, 4, 1, 1>(st, A);
+    return launch_ksplit<256, 128, 1>(st, A);   // K split over the waves                           // inside the forward, the whole halo tile resident (95 KiB): 29.6
   }
-  return launch_phased<512, 128, 1>(st, A);
+  if (variant == 1) return launch_phased<512, 128, 1>(st, A);
+  return launch_ksplit<512, 128, 1>(st, A);
 }

@@ -1912,14 +1912,17 @@ def test_conv3x3_x6_matches_fp64_convolution(C, stride, B, H, W):
     ref = F.conv2d(x.double(), w.double(), None, stride=stride, padding=1)
     outs = []
     for variant in (0, 1, 2, 3, 4):
-        if variant and not (stride == 1 and variant in {64: (1, 2, 3), 128: (1, 3, 4), 256: (1,)}.get(C, ())):
+        if variant and not (variant in ({64: (1, 2, 3, 4), 128: (1, 2, 3, 4), 256: (1, 3), 512: (1,)} if stride == 1 else {128: (1,), 256: (1,), 512: (1,)}).get(C, ())):
             continue
         y = ops.conv3x3(x, ops.conv3x3_weights(w, stride, variant), C, stride, variant)
         assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
         assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), variant
         outs.append((variant, y))
-    # a tile decides who computes an element, not how (C = 256: the phased default sums the channels in another order)
-    assert all(torch.equal(outs[0][1], o) for v, o in outs[1:] if C != 256)
+    # a tile decides who computes an element, not how: the variants that walk K in one piece agree bit for bit (the ones that
+    # split K over the waves or walk channel phases sum in another order)
+    whole_k = {64: (0, 1, 2, 3), 128: (1, 2, 3, 4)}.get(C, ()) if stride == 1 else ()
+    same = [o for v, o in outs if v in whole_k]
+    assert all(torch.equal(same[0], o) for o in same[1:])
     assert torch.equal(outs[0][1], ops.conv3x3(x, ops.conv3x3_weights(w, stride), C, stride))   # run-to-run bit-identical
 
 

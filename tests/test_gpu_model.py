@@ -637,17 +637,17 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
         assert a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) < 2e-5 * scale
-    # the same for the 3x3 convolutions of our own (backbone.CONV2_X6: every conv2 of layers 1-3)
+    # the same for the 3x3 convolutions of our own (backbone.CONV2_X6: every conv2 of the network)
     calls2 = []
     real2 = ops.conv3x3
     monkeypatch.setattr(ops, "conv3x3", lambda *a, **k: (calls2.append(a[0].shape[1]), real2(*a, **k))[1])
     monkeypatch.setattr(bb, "CONV3_FUSED", True)
     with torch.no_grad():
         on = net(x)
-        assert sorted(calls2) == [64] * 3 + [128] * 4 + [256] * 6     # stride 1 and stride 2; layer 4 (512) stays on MIOpen
+        assert sorted(calls2) == [64] * 3 + [128] * 4 + [256] * 6 + [512] * 3     # all 16: stride 1 and stride 2
         monkeypatch.setattr(bb, "CONV2_X6", False)
         off = net(x)
-        assert len(calls2) == 13
+        assert len(calls2) == 16
     for a, b in zip(on, off):
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) < 5e-5 * scale

@@ -15,7 +15,7 @@ from conv3_fused_ab import graph_time  # noqa: E402
 
 
 def variant_exists(C, stride, variant):
-    return stride == 1 and variant in {64: (1, 2, 3), 128: (1, 3, 4), 256: (1,)}.get(C, ())
+    return variant in ({64: (1, 2, 3, 4), 128: (1, 2, 3, 4), 256: (1, 3), 512: (1,)} if stride == 1 else {128: (1,), 256: (1,), 512: (1,)}).get(C, ())
 
 
 def main():
