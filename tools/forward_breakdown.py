@@ -14,8 +14,9 @@ c = sqlite3.connect(db)
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
 idx = [i for i, r in enumerate(rows) if "rel_head_fwd" in r[0]]
 # a bench run also holds eager forwards (warm-up, parity pass) and the stand-alone roofline probes: take the whole
-# forwards (>= 100 kernels between two relation-head launches) and of those the one with the shortest span = a graph replay
-cands = [rows[idx[k - 1] + 1: idx[k] + 1] for k in range(1, len(idx)) if idx[k] - idx[k - 1] >= 100]
+# forwards (>= 80 kernels between two relation-head launches; a replay has ~100 since the backbone kernels of late round 6)
+# and of those the one with the shortest span = a graph replay
+cands = [rows[idx[k - 1] + 1: idx[k] + 1] for k in range(1, len(idx)) if idx[k] - idx[k - 1] >= 80]
 seg = min(cands, key=lambda s_: s_[-1][2] - s_[0][1])
 names = [r[0] for r in seg]
 print(f"one forward: {len(seg)} kernels, span {(seg[-1][2] - seg[0][1]) / 1e6:.3f} ms, busy {sum(r[2] - r[1] for r in seg) / 1e6:.3f} ms")
