@@ -29,6 +29,7 @@ NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 # split-bf16 routes.
 CONV3_FUSED = True        # module attributes (tests patch them for the switch-off twins)
 CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
+STEM_FUSED = True         # fp32 stem: 7x7 convolution + shift + ReLU + max-pool as csrc/stem_x6.hip
 CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
 CONV2_X6_MAX_WIDTH = 512  # ... up to this width (all 16 of ResNet-50)
 
@@ -388,7 +389,16 @@ class ResNet50Features(nn.Module):
                     ops.bias_act_rows_(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]), b)
                 else:
                     # fp32: the stem keeps its one-pass pool + shift + ReLU kernel (NCHW); the pooled map changes layout once
-                    x = self._stem_folded(x, w, b).contiguous(memory_format=torch.channels_last)
+                    mp = self.maxpool
+                    if (STEM_FUSED and ops.GEMM_SPLIT_BF16 and ops.stem_fused_supported(x, w) and tuple(self.conv1.stride) == (2, 2)
+                            and tuple(self.conv1.padding) == (3, 3) and mp.kernel_size == 3 and mp.stride == 2 and mp.padding == 1
+                            and mp.dilation == 1 and not mp.ceil_mode):
+                        # convolution + shift + ReLU + pool in one launch, channels-last out (csrc/stem_x6.hip)
+                        if "stem_xs" not in self._folded["nhwc"]:
+                            self._folded["nhwc"]["stem_xs"] = ops.stem_weights(w)
+                        x = ops.stem_fused(x, self._folded["nhwc"]["stem_xs"], b)
+                    else:
+                        x = self._stem_folded(x, w, b).contiguous(memory_format=torch.channels_last)
                 for li in range(1, 5):
                     for blk, q in zip(getattr(self, f"layer{li}"), self._folded["nhwc"][li]):
                         x = blk.forward_folded_nhwc(x, q)

@@ -1632,6 +1632,33 @@ def conv1x1_tail(a, a_shift, w_xs, bias, shortcut, N, relu_in=True, relu_out=Tru
     return y
 
 
+def stem_weights(w):
+    """W [64, 3, 7, 7] fp32 (frozen BN scale folded in) -> the XS operand stream of the [64, 224] matrix the stem kernel walks:
+    per kernel row 8 taps x 4 channels, the padded tap / channel zeros (csrc/stem_x6.hip)."""
+    wm = torch.zeros(64, 7, 8, 4, dtype=torch.float32, device=w.device)
+    wm[:, :, :7, :3] = w.detach().permute(0, 2, 3, 1)
+    return xs_split(wm.reshape(64, 224), weights=True)
+
+
+def stem_fused_supported(x, w):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous()
+            and tuple(w.shape) == (64, 3, 7, 7))
+
+
+def stem_fused(x, w_xs, bias):
+    """maxpool3x3/2(relu(conv7x7/2(x) + bias)) of the ResNet stem in ONE HIP launch (egtr_stem_conv7x7_pool_x6_f32; reference:
+    timm ResNet-50 conv1 -> bn1 -> act1 -> maxpool, model/deformable_detr.py:735-760).  x [B, 3, H, W] NCHW fp32 -> a
+    channels-last [B, 64, Hp, Wp] tensor.  fp32-level accuracy (six-term split-bf16 products).  Inference only."""
+    lib = _lib.lib()
+    B, _, H, W = x.shape
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    y = torch.empty((B, 64, Hp, Wp), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    st = lib.egtr_stem_conv7x7_pool_x6_f32(_stream(), x.data_ptr(), w_xs.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W)
+    _lib.check(st, "egtr_stem_conv7x7_pool_x6_f32")
+    return y
+
+
 def conv3x3_supported(x, N, stride=1, variant=0):
     """Shapes the split-bf16 3x3 convolution serves (csrc/conv3x3_x6.hip): channels-last fp32 [B, C, H, W] tensors (dense NHWC
     memory), padding 1, C == N in {64, 128, 256, 512} at stride 1 and {128, 256, 512} at stride 2."""

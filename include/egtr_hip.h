@@ -691,6 +691,14 @@ int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, int lda, cons
                              const void* w_xs, const float* bias, const float* shortcut, int ld_shortcut, int relu_out,
                              float* y, int ldy, int M, int K, int N, int tile_rows, int tile_cols);
 
+/* The ResNet stem in inference as one launch: 7x7 convolution (stride 2, padding 3, 3 -> 64 channels) + folded batch-norm shift
+ * + ReLU + 3x3 max-pool (stride 2, padding 1); x [B, 3, H, W] NCHW fp32 -> y [B, Hp, Wp, 64] channels-last fp32 with
+ * Hc = (H - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1 (model/deformable_detr.py:735-760: timm ResNet-50 conv1 -> bn1 -> act1 -> maxpool).
+ * Six-term split-bf16 products (error of an fp32 convolution).  w_xs = XS(Wm [64, 224]) (egtr_xs_split_f32, round_to_nearest = 1)
+ * with Wm[n][ky * 32 + kx * 4 + c] = W[n][c][ky][kx] and zeros at kx == 7 / c == 3 (egtr_amd.ops.stem_weights). */
+int egtr_stem_conv7x7_pool_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, const float* bias, float* y, int B,
+                                  int H, int W);
+
 /* 3x3 convolution, stride 1 or 2, padding 1, no bias, channels-last fp32 (x [B, H, W, C] -> y [B, Ho, Wo, N], Ho = (H - 1) /
  * stride + 1) with the six-term split-bf16 arithmetic (error of an fp32 convolution): the middle convolution of a ResNet
  * bottleneck in inference (model/deformable_detr.py:735-760, timm ResNet-50; the folded batch norm's shift + ReLU is applied by

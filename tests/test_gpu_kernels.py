@@ -1947,3 +1947,40 @@ def test_conv3x3_x6_non_finite_inputs_and_refusals():
     assert not ops.conv3x3_supported(torch.randn(1, 96, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last), 96)
     with pytest.raises(EgtrHipError):
         ops.conv3x3(torch.randn(1, 96, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last), ops.conv3x3_weights(w), 96)
+
+
+# ---- the fused stem (csrc/stem_x6.hip, egtr_stem_conv7x7_pool_x6_f32) -------------------------------------------------------
+@pytest.mark.parametrize("B,H,W", [(1, 224, 320), (2, 61, 83), (1, 7, 9), (1, 1, 1), (1, 64, 128), (3, 33, 37)])
+def test_stem_fused_matches_fp64_conv_relu_pool(B, H, W):
+    """7x7/2 convolution + shift + ReLU + 3x3/2 max-pool in one launch, channels-last out, against the fp64 composition of the
+    same fp32 operands (six-term split-bf16 products: 1e-5 of the output scale); odd sizes, images smaller than a tile (the
+    zero padding of both the convolution and the pool is exercised everywhere at the borders), batches."""
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    torch.manual_seed(H + W)
+    x = torch.randn(B, 3, H, W, device=DEV)
+    w = torch.randn(64, 3, 7, 7, device=DEV) / 147 ** 0.5
+    b = torch.randn(64, device=DEV) * 0.3
+    assert ops.stem_fused_supported(x, w)
+    y = ops.stem_fused(x, ops.stem_weights(w), b)
+    ref = F.max_pool2d(torch.relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=3) + b.double().view(1, -1, 1, 1)), 3, 2, 1)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert float((y.double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(y, ops.stem_fused(x, ops.stem_weights(w), b))
+
+
+def test_stem_fused_nan_pixel_reaches_exactly_its_pool_windows():
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    torch.manual_seed(11)
+    x = torch.randn(1, 3, 40, 56, device=DEV)
+    x[0, 1, 20, 30] = float("nan")
+    w = torch.randn(64, 3, 7, 7, device=DEV) / 12
+    b = torch.zeros(64, device=DEV)
+    y = ops.stem_fused(x, ops.stem_weights(w), b)
+    # (fp64 reference: a direct convolution -- MIOpen's fp32 Winograd kernel spreads a NaN over its whole transform tile)
+    ref = F.max_pool2d(torch.relu(F.conv2d(x.double(), w.double(), None, stride=2, padding=3)), 3, 2, 1)
+    assert torch.equal(torch.isnan(y), torch.isnan(ref))          # exactly the windows that contain the pixel, all 64 channels
+    assert int(torch.isnan(ref).any(dim=1).sum()) in (4, 6, 9)   # a 7 x 7 window / stride 2, pooled 3 x 3 / stride 2
+    ok = ~torch.isnan(ref)
+    assert float((y[ok].double() - ref[ok]).abs().max()) < 1e-4

@@ -652,13 +652,27 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) < 5e-5 * scale
     monkeypatch.setattr(bb, "CONV2_X6", True)
+    # ... and for the stem (backbone.STEM_FUSED: convolution + shift + ReLU + pool in one launch)
+    calls3 = []
+    real3 = ops.stem_fused
+    monkeypatch.setattr(ops, "stem_fused", lambda *a, **k: (calls3.append(1), real3(*a, **k))[1])
+    with torch.no_grad():
+        on = net(x)
+        assert len(calls3) == 1
+        monkeypatch.setattr(bb, "STEM_FUSED", False)
+        off = net(x)
+        assert len(calls3) == 1
+    for a, b in zip(on, off):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) < 5e-5 * scale
+    monkeypatch.setattr(bb, "STEM_FUSED", True)
     # with the split-bf16 routes switched off as a group the kernels are not used either
     monkeypatch.setattr(bb, "CONV3_FUSED", True)
     monkeypatch.setattr(ops, "GEMM_SPLIT_BF16", False)
-    n_tail, n_conv = len(calls), len(calls2)
+    n_tail, n_conv, n_stem = len(calls), len(calls2), len(calls3)
     with torch.no_grad():
         net(x)
-    assert len(calls) == n_tail and len(calls2) == n_conv
+    assert len(calls) == n_tail and len(calls2) == n_conv and len(calls3) == n_stem
 
 
 def test_backbone_bf16_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch):
