@@ -29,6 +29,9 @@ NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 # split-bf16 routes.
 CONV3_FUSED = True        # module attributes (tests patch them for the switch-off twins)
 CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
+CONV1_X6 = True           # fp32 first 1x1 convolution of a block through the tail kernel ...
+CONV1_X6_WIDTHS = (64,)   # ... for these input widths: 7.3 us against the vendor GEMM's 16 at 64 -> 64 (layer 1, block 0); at
+                          # 256 / 512 input channels the two are level inside the forward (tools/conv2_ab.sh, SWITCH=CONV1_X6)
 STEM_FUSED = True         # fp32 stem: 7x7 convolution + shift + ReLU + max-pool as csrc/stem_x6.hip
 CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
 CONV2_X6_MAX_WIDTH = 512  # ... up to this width (all 16 of ResNet-50)
@@ -209,7 +212,16 @@ class Bottleneck(nn.Module):
         from . import ops
         B, C, H, W_ = x.shape
         x2 = x.permute(0, 2, 3, 1).reshape(-1, C)                      # a view: channels-last IS [B*H*W, C]
-        y = torch._addmm_activation(q["b1"], x2, q["w1"].t(), use_gelu=False)
+        N1 = q["w1"].shape[0]
+        if (CONV1_X6 and ops.GEMM_SPLIT_BF16 and C in CONV1_X6_WIDTHS and ops.conv1x1_tail_supported(x2, N1)):
+            # fp32, block inputs of up to 512 channels: the panel-resident split-bf16 kernel of the tail, here without input
+            # shift and shortcut (csrc/conv_tail_x6.hip), instead of the vendor GEMM with its bias + ReLU epilogue
+            if "w1xs" not in q:
+                q["w1xs"] = ops.xs_split(q["w1"], weights=True)
+                q["b1f"] = q["b1"].float().contiguous()
+            y = ops.conv1x1_tail(x2, None, q["w1xs"], q["b1f"], None, N1, relu_in=False, relu_out=True)
+        else:
+            y = torch._addmm_activation(q["b1"], x2, q["w1"].t(), use_gelu=False)
         y = y.view(B, H, W_, -1).permute(0, 3, 1, 2)                   # channels-last view of the GEMM's output
         st2 = tuple(self.conv2.stride)
         if (CONV2_X6 and ops.GEMM_SPLIT_BF16 and st2 in ((1, 1), (2, 2)) and q["w2"].shape[0] <= CONV2_X6_MAX_WIDTH

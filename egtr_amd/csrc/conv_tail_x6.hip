@@ -267,6 +267,10 @@ int launch(hipStream_t st, const TailArgs& A) {
 // but the last, where K = 512 leaves one workgroup per CU (100 KiB of panel) and the wider block halves the panel builds
 template <int KS>
 int dispatch(hipStream_t st, const TailArgs& A, int force_bm, int force_ntw) {
+  if (A.N % 128 != 0) {   // N % 64 == 0 (a bottleneck's first 1x1 convolution at 64 planes): two waves x 32 columns
+    if (force_bm == 64 || force_ntw == 2) return EGTR_E_UNSUPPORTED;
+    return launch<32, 1, KS, 2>(st, A);
+  }
   const bool n256 = A.N % 256 == 0;
   int bm = 32;
   int ntw = (KS >= 32 && n256) ? 2 : 1;
@@ -308,7 +312,7 @@ extern "C" int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, in
   if (!a || !w_xs || !y || M <= 0 || K <= 0 || N <= 0 || lda < K || ldy < N || (shortcut && ld_shortcut < N)) return EGTR_E_ARG;
   if ((tile_rows != 0 && tile_rows != 32 && tile_rows != 64) || (tile_cols != 0 && tile_cols != 128 && tile_cols != 256))
     return EGTR_E_ARG;
-  if ((K != 64 && K != 128 && K != 256 && K != 512) || N % 128 || (lda & 3) || (ldy & 3) || (shortcut && (ld_shortcut & 3)) ||
+  if ((K != 64 && K != 128 && K != 256 && K != 512) || N % 64 || (lda & 3) || (ldy & 3) || (shortcut && (ld_shortcut & 3)) ||
       (reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(w_xs) & 15) ||
       (reinterpret_cast<uintptr_t>(a_shift) & 15) || (reinterpret_cast<uintptr_t>(bias) & 15) ||
       (reinterpret_cast<uintptr_t>(shortcut) & 15))

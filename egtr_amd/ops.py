@@ -1606,9 +1606,9 @@ def xs_split(x, pos=None, weights=False, plain=True):
 
 def conv1x1_tail_supported(a, N):
     """Shapes the bottleneck-tail kernel serves (csrc/conv_tail_x6.hip): fp32 pixel rows with unit inner stride, K = planes in
-    {64, 128, 256, 512}, N a multiple of 128."""
+    {64, 128, 256, 512}, N a multiple of 64."""
     return (a.is_cuda and a.dtype == torch.float32 and a.dim() == 2 and a.stride(1) == 1 and a.stride(0) % 4 == 0
-            and a.data_ptr() % 16 == 0 and a.shape[1] in (64, 128, 256, 512) and N % 128 == 0)
+            and a.data_ptr() % 16 == 0 and a.shape[1] in (64, 128, 256, 512) and N % 64 == 0)
 
 
 def conv1x1_tail(a, a_shift, w_xs, bias, shortcut, N, relu_in=True, relu_out=True, tile=(0, 0)):

@@ -684,7 +684,7 @@ int egtr_xs_split_f32(egtr_stream_t stream, const float* x, int ldx, const float
  * Replaces, per block: an in-place shift + ReLU pass, a vendor fp32 GEMM and a shift + shortcut + ReLU pass
  * (egtr_amd/backbone.py::Bottleneck.forward_folded_nhwc; reference: model/deformable_detr.py:735-760, the timm ResNet-50
  * backbone with frozen batch norm -- conv3 -> bn3 -> += shortcut -> relu).  Six-term split-bf16 arithmetic: the error of an
- * fp32 GEMM.  K in {64, 128, 256, 512}, N % 128 == 0, 16-byte aligned pointers, row strides % 4 == 0 (EGTR_E_UNSUPPORTED
+ * fp32 GEMM.  K in {64, 128, 256, 512}, N % 64 == 0, 16-byte aligned pointers, row strides % 4 == 0 (EGTR_E_UNSUPPORTED
  * otherwise).  tile_rows (0 | 32 | 64) / tile_cols (0 | 128 | 256): 0 = the library's choice; other values pin the workgroup
  * tile (tools/conv3_fused_ab.py sweeps them). */
 int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, int lda, const float* a_shift, int relu_in,

@@ -1761,12 +1761,12 @@ def _tail_ref(a, sh, w, b, sc, relu_in, relu_out):
     return torch.relu(y) if relu_out else y
 
 
-@pytest.mark.parametrize("K,N", [(64, 256), (128, 512), (256, 1024), (512, 2048), (64, 128), (256, 384)])
+@pytest.mark.parametrize("K,N", [(64, 256), (128, 512), (256, 1024), (512, 2048), (64, 128), (256, 384), (64, 64), (256, 192)])
 @pytest.mark.parametrize("M", [1, 37, 608, 2399])
 def test_conv1x1_tail_matches_fp64_product(K, N, M):
     """relu(relu(a + shift2) W3^T + shift3 + shortcut) in one launch against the fp64 product of the same fp32 operands: the
     six-term split-bf16 arithmetic has the error of an fp32 GEMM (1e-5 of the row's scale here); ragged row counts (the last
-    panel is partial), every tile the dispatcher can pick, N that is a multiple of 128 but not of 256."""
+    panel is partial), every tile the dispatcher can pick, N that is a multiple of 128 but not of 256, and of 64 but not of 128 (two waves)."""
     from egtr_amd import ops
     torch.manual_seed(K + N + M)
     a = torch.randn(M, K, device=DEV)
@@ -1776,8 +1776,8 @@ def test_conv1x1_tail_matches_fp64_product(K, N, M):
     sc = torch.randn(M, N, device=DEV)
     wxs = ops.xs_split(w, weights=True)
     ref = _tail_ref(a, sh, w, b, sc, True, True)
-    tiles = [(0, 0), (32, 128)] + ([(32, 256)] if N % 256 == 0 else []) + ([(64, 128)] if K <= 256 else []) \
-        + ([(64, 256)] if K <= 256 and N % 256 == 0 else [])
+    tiles = [(0, 0)] + ([(32, 128)] if N % 128 == 0 else []) + ([(32, 256)] if N % 256 == 0 else []) \
+        + ([(64, 128)] if K <= 256 and N % 128 == 0 else []) + ([(64, 256)] if K <= 256 and N % 256 == 0 else [])
     outs = []
     for tile in tiles:
         y = ops.conv1x1_tail(a, sh, wxs, b, sc, N, tile=tile)
@@ -1827,7 +1827,7 @@ def test_conv1x1_tail_non_finite_rows_stay_in_their_rows_and_bad_shapes_are_refu
     y2 = ops.conv1x1_tail(a, None, wxs, None, None, N, relu_in=True, relu_out=True)
     assert torch.isnan(y2[7]).all() and torch.isfinite(y2[6]).all()
     assert not ops.conv1x1_tail_supported(torch.randn(M, 96, device=DEV), 256)     # K not a bottleneck width
-    assert not ops.conv1x1_tail_supported(a, 192)                                   # N not a multiple of 128
+    assert not ops.conv1x1_tail_supported(a, 96)                                    # N not a multiple of 64
     with pytest.raises(EgtrHipError):
         ops.conv1x1_tail(torch.randn(M, 96, device=DEV), None, wxs, None, None, 256)
     with pytest.raises(EgtrHipError):

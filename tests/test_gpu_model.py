@@ -629,10 +629,11 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
     assert bb.CONV3_FUSED is True
     with torch.no_grad():
         fused = net(x)
-        assert len(calls) == 16 and sorted({c[1] for c in calls}) == [64, 128, 256, 512]
+        assert len(calls) == 17 and sorted({c[1] for c in calls}) == [64, 128, 256, 512]   # 16 tails + layer 1's first conv1
         monkeypatch.setattr(bb, "CONV3_FUSED", False)
+        monkeypatch.setattr(bb, "CONV1_X6", False)
         plain = net(x)
-        assert len(calls) == 16
+        assert len(calls) == 17
     for a, b in zip(fused, plain):
         assert a.shape == b.shape and a.is_contiguous(memory_format=torch.channels_last)
         scale = max(1.0, float(b.abs().max()))
@@ -642,6 +643,7 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
     real2 = ops.conv3x3
     monkeypatch.setattr(ops, "conv3x3", lambda *a, **k: (calls2.append(a[0].shape[1]), real2(*a, **k))[1])
     monkeypatch.setattr(bb, "CONV3_FUSED", True)
+    monkeypatch.setattr(bb, "CONV1_X6", True)
     with torch.no_grad():
         on = net(x)
         assert sorted(calls2) == [64] * 3 + [128] * 4 + [256] * 6 + [512] * 3     # all 16: stride 1 and stride 2

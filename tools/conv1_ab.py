@@ -43,7 +43,7 @@ def main():
         line = f"M={M:6d} K={K:4d} N={N:3d} (x{cnt}): vendor {tv:6.1f} us"
         if ops.conv1x1_tail_supported(x, N):
             wxs = ops.xs_split(w, weights=True)
-            for tile in ((0, 0), (32, 128), (64, 128)) + (((32, 256),) if N % 256 == 0 else ()):
+            for tile in ((0, 0),) + (((32, 128), (64, 128)) if N % 128 == 0 else ()) + (((32, 256),) if N % 256 == 0 else ()):
                 if tile[0] == 64 and K > 256:
                     continue
                 tt, yt = graph_time(lambda: ops.conv1x1_tail(x, None, wxs, b, None, N, relu_in=False, relu_out=True, tile=tile))
