@@ -925,14 +925,28 @@ __global__ __launch_bounds__(256) void gn_partial_tokens(GnTokLevels P, int L, i
   }
 }
 
-__global__ __launch_bounds__(32) void gn_finalize_tokens(GnTokLevels P, int chunks_total, float eps,
-                                                         const double2* __restrict__ partial, float2* __restrict__ stats) {
-  const int b = blockIdx.x, l = blockIdx.y, B = gridDim.x, g = threadIdx.x;
+// 256 threads per (image, level): group g = thread & 31 is summed by the 8 threads thread >> 5 = 0 .. 7, each over every 8th
+// chunk, then over the 8 in a fixed order through LDS (a single thread per group walked up to 37 dependent 16-byte loads: 10 us
+// of pure latency for the bench's level 0).
+__global__ __launch_bounds__(256) void gn_finalize_tokens(GnTokLevels P, int chunks_total, float eps,
+                                                          const double2* __restrict__ partial, float2* __restrict__ stats) {
+  __shared__ double2 s_part[8][32];
+  const int b = blockIdx.x, l = blockIdx.y, B = gridDim.x, g = threadIdx.x & 31, part = threadIdx.x >> 5;
   double t1 = 0.0, t2 = 0.0;
-  for (int c = P.cchunk0[l]; c < P.cchunk0[l + 1]; ++c) {
+  for (int c = P.cchunk0[l] + part; c < P.cchunk0[l + 1]; c += 8) {
     const double2 p = partial[((size_t)b * chunks_total + c) * 32 + g];
     t1 += p.x;
     t2 += p.y;
+  }
+  s_part[part][g] = make_double2(t1, t2);
+  __syncthreads();
+  if (part != 0) return;
+  t1 = 0.0;
+  t2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    t1 += s_part[k][g].x;
+    t2 += s_part[k][g].y;
   }
   const double n = 8.0 * P.hw[l], mean = t1 / n;
   const double var = fmax(t2 / n - mean * mean, 0.0);  // biased, as nn.GroupNorm
@@ -1031,12 +1045,12 @@ static int groupnorm_tokens_launch(egtr_stream_t stream, int num_levels, const v
   const dim3 agrid((unsigned)((chunks + 255) / 256), batch);
   if (bf16) {
     hipLaunchKernelGGL(gn_partial_tokens<unsigned short>, dim3(cc, batch), dim3(256), 0, st, P, num_levels, cc, partial);
-    hipLaunchKernelGGL(gn_finalize_tokens, dim3(batch, num_levels), dim3(32), 0, st, P, cc, eps, partial, st2);
+    hipLaunchKernelGGL(gn_finalize_tokens, dim3(batch, num_levels), dim3(256), 0, st, P, cc, eps, partial, st2);
     hipLaunchKernelGGL(gn_apply_tokens<unsigned short>, agrid, dim3(256), 0, st, P, num_levels, S, st2,
                        static_cast<unsigned short*>(out));
   } else {
     hipLaunchKernelGGL(gn_partial_tokens<float>, dim3(cc, batch), dim3(256), 0, st, P, num_levels, cc, partial);
-    hipLaunchKernelGGL(gn_finalize_tokens, dim3(batch, num_levels), dim3(32), 0, st, P, cc, eps, partial, st2);
+    hipLaunchKernelGGL(gn_finalize_tokens, dim3(batch, num_levels), dim3(256), 0, st, P, cc, eps, partial, st2);
     hipLaunchKernelGGL(gn_apply_tokens<float>, agrid, dim3(256), 0, st, P, num_levels, S, st2, static_cast<float*>(out));
   }
   return egtr_check_launch();
