@@ -32,6 +32,7 @@ CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
 CONV1_X6 = True           # fp32 first 1x1 convolution of a block through the tail kernel ...
 CONV1_X6_WIDTHS = (64,)   # ... for these input widths: 7.3 us against the vendor GEMM's 16 at 64 -> 64 (layer 1, block 0); at
                           # 256 / 512 input channels the two are level inside the forward (tools/conv2_ab.sh, SWITCH=CONV1_X6)
+FROZEN_PREFIX_NHWC = True  # training: the frozen stem + layer 1 through the channels-last inference kernels
 STEM_FUSED = True         # fp32 stem: 7x7 convolution + shift + ReLU + max-pool as csrc/stem_x6.hip
 CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
 CONV2_X6_MAX_WIDTH = 512  # ... up to this width (all 16 of ResNet-50)
@@ -334,6 +335,20 @@ class ResNet50Features(nn.Module):
                                        1: [blk.folded_params() for blk in self.layer1]}
                 self._frozen_key = key
             w, b = self._frozen_folded["stem"]
+            mp = self.maxpool
+            if (FROZEN_PREFIX_NHWC and NHWC_F32 and STEM_FUSED and ops.GEMM_SPLIT_BF16 and x.dtype == torch.float32
+                    and ops.stem_fused_supported(x, w) and hasattr(torch, "_addmm_activation")
+                    and tuple(self.conv1.stride) == (2, 2) and tuple(self.conv1.padding) == (3, 3) and mp.kernel_size == 3
+                    and mp.stride == 2 and mp.padding == 1 and mp.dilation == 1 and not mp.ceil_mode):
+                # the inference kernels of the channels-last route (fused stem, own 3x3 convolutions, bottleneck tails) for the
+                # part of the network that never takes gradients; the trainable layers behind it run NCHW: one layout change
+                if "nhwc" not in self._frozen_folded:
+                    self._frozen_folded["nhwc"] = [blk.folded_params_nhwc() for blk in self.layer1]
+                    self._frozen_folded["stem_xs"] = ops.stem_weights(w)
+                x = ops.stem_fused(x, self._frozen_folded["stem_xs"], b)
+                for blk, q in zip(self.layer1, self._frozen_folded["nhwc"]):
+                    x = blk.forward_folded_nhwc(x, q)
+                return x.contiguous()
             x = self._stem_folded(x, w, b)
             for blk, p in zip(self.layer1, self._frozen_folded[1]):
                 x = blk.forward_folded(x, p)

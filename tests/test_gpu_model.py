@@ -677,6 +677,36 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
     assert len(calls) == n_tail and len(calls2) == n_conv and len(calls3) == n_stem
 
 
+def test_training_frozen_prefix_through_the_channels_last_kernels_matches_the_nchw_route(monkeypatch):
+    """Training: stem + layer 1 take no gradients (the reference freezes them, model/deformable_detr.py:763-770), so they run
+    under no_grad -- through the channels-last inference kernels (fused stem, own 3x3 convolutions, bottleneck tails) and one
+    layout change (backbone.FROZEN_PREFIX_NHWC) or through the NCHW folded route: the same NCHW-contiguous map."""
+    import egtr_amd.backbone as bb
+    torch.manual_seed(5)
+    net = bb.ResNet50Features().to(DEV).train()
+    for m in net.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 1.5)
+            m.running_mean.normal_(0, 0.1)
+    for p in list(net.conv1.parameters()) + list(net.layer1.parameters()):
+        p.requires_grad_(False)
+    x = torch.randn(2, 3, 93, 121, device=DEV)
+    params = net._frozen_prefix()
+    assert params is not None and bb.FROZEN_PREFIX_NHWC is True
+    a = net._forward_frozen_prefix(x, params)
+    monkeypatch.setattr(bb, "FROZEN_PREFIX_NHWC", False)
+    net._frozen_folded = None
+    b = net._forward_frozen_prefix(x, params)
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous() and not a.requires_grad
+    assert float((a - b).abs().max()) < 5e-5 * max(1.0, float(b.abs().max()))
+    # and the whole training forward + backward still runs behind it
+    monkeypatch.setattr(bb, "FROZEN_PREFIX_NHWC", True)
+    net._frozen_folded = None
+    feats = net(x)
+    sum(f.sum() for f in feats).backward()
+    assert net.layer2[0].conv1.weight.grad is not None and net.conv1.weight.grad is None
+
+
 def test_backbone_bf16_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch):
     """bf16 channels-last backbone: the tails run as one launch of csrc/conv_tail_bf16.hip each (16 per forward) and the feature
     maps match the pass / GEMM / pass route (backbone.CONV3_FUSED_BF16 = False) to a few bf16 ulps of the map's scale -- the
