@@ -182,6 +182,62 @@ def time_encoder_tail(dev, iters=100):
     return best, 2.0 * M * (D * D + 2 * D * F)
 
 
+def _time_us(fn, iters=60):
+    """Median of three event-timed batches of `fn` on the current stream (us per call)."""
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(max(1, iters // 3)):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e3 / max(1, iters // 3))
+    return sorted(times)[1]
+
+
+def time_backbone_kernels(dev):
+    """The hand-written backbone kernels of the fp32 channels-last route at the bench shapes (600x1000, bs 1), stand-alone:
+    [(kernel, launch description, us, algorithmic flops, algorithmic bytes)] -- the 3x3 convolution of a layer-3 bottleneck
+    (38x63, C = 256; csrc/conv3x3_x6.hip), the tail of a layer-1 bottleneck (37 500 rows, 64 -> 256; csrc/conv_tail_x6.hip)
+    and the fused stem (csrc/stem_x6.hip)."""
+    from egtr_amd import ops
+    out = []
+    with torch.no_grad():
+        g = torch.Generator(device="cpu").manual_seed(0)
+        x = torch.randn(1, 256, 38, 63, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(256, 256, 3, 3, generator=g) / 48.0).to(dev)
+        if ops.conv3x3_supported(x, 256):
+            wxs = ops.conv3x3_weights(w)
+            us = _time_us(lambda: ops.conv3x3(x, wxs, 256))
+            out.append(("conv3x3_x6_ksplit_kernel<256, 128, 1>", "3x3 convolution of a layer-3 bottleneck: 38x63 pixels, 256 -> 256 "
+                        "channels (5 such launches per forward; 16 own 3x3 convolutions in all)", us,
+                        2.0 * 38 * 63 * 9 * 256 * 256, 4.0 * (2 * 38 * 63 * 256 + 9 * 256 * 256)))
+        M, K, N = 37500, 64, 256
+        a, sc = torch.randn(M, K, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+        w3 = (torch.randn(N, K, generator=g) / 8.0).to(dev)
+        b2, b3 = torch.randn(K, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+        if ops.conv1x1_tail_supported(a, N):
+            w3xs = ops.xs_split(w3, weights=True)
+            us = _time_us(lambda: ops.conv1x1_tail(a, b2, w3xs, b3, sc, N))
+            out.append(("conv_tail_x6_kernel<32, 1, 4, 4>", "tail of a layer-1 bottleneck: shift + ReLU, 1x1 convolution 64 -> 256, "
+                        "shift + shortcut + ReLU over 37 500 pixel rows (3 such launches per forward; 16 tails in all)", us,
+                        2.0 * M * K * N, 4.0 * M * (K + 2 * N)))
+        xs_ = torch.randn(1, 3, H_IMG, W_IMG, generator=g).to(dev)
+        ws = (torch.randn(64, 3, 7, 7, generator=g) / 12.0).to(dev)
+        bs = torch.randn(64, generator=g).to(dev)
+        if ops.stem_fused_supported(xs_, ws):
+            wsx = ops.stem_weights(ws)
+            us = _time_us(lambda: ops.stem_fused(xs_, wsx, bs))
+            out.append(("stem_x6_kernel", "stem: 7x7/2 convolution 3 -> 64 + shift + ReLU + 3x3/2 max-pool, 600x1000 -> 150x250x64 "
+                        "channels-last (1 launch per forward)", us, 2.0 * 300 * 500 * 147 * 64,
+                        4.0 * (3 * H_IMG * W_IMG + 150 * 250 * 64)))
+    return out
+
+
 def time_split_gemm(dev, iters=100):
     """The split-bf16 tile GEMM as the encoder layer launches it since round 3 (csrc/gemm_split.hip, one grouped launch):
     value projection 256 -> 256 of the layer input and sampling-offset / attention-weight projection 256 -> 384 of
@@ -1228,6 +1284,20 @@ def main():
         if dp:
             d_entry.update(traffic=dp.get("hbm_bytes_per_launch"), l2_hit=dp.get("l2_hit"), traffic_source=dp_src)
         result["roofline_kernels"].append(d_entry)
+    try:
+        for kname, launch, us, flops, nbytes in time_backbone_kernels(dev):
+            e = x6_entry(kname, launch, us, flops, 6 * flops, kname.split("<")[0])
+            # (the stem executes more than 6x its algorithmic flops: K padded 147 -> 224, overlapping pool windows)
+            e["algorithmic_bytes_per_launch"] = int(nbytes)
+            e["frac_of_hbm_roofline"] = round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            pat = {"conv_tail_x6_kernel": "r*_conv_tail_x6_pmc.json", "conv3x3_x6_ksplit_kernel": "r*_conv3x3_x6_pmc.json",
+                   "stem_x6_kernel": "r*_stem_x6_pmc.json"}.get(kname.split("<")[0])
+            tp, tp_src = newest_pmc(pat, kname) if pat else ({}, None)
+            if tp:
+                e.update(traffic=tp.get("hbm_bytes_per_launch"), l2_hit=tp.get("l2_hit"), traffic_source=tp_src)
+            result["roofline_kernels"].append(e)
+    except Exception as exc:  # the headline stays valid
+        result["roofline_kernels"].append({"kernel": "backbone kernels", "error": f"{type(exc).__name__}: {exc}"})
     if rank == 0 and world == 1 and args.extras:
         # the FPS loop as the reference runs it (evaluate_egtr.py:26-36): differently sized images, and the eager number
         try:

@@ -17,6 +17,8 @@ SOURCES = [
     ("msda_fwd", ["msda.hip", "msda_common.h"]),
     ("rel_head_fwd_bf16", ["rel_head_bf16.hip"]),
     ("rel_head", ["rel_head.hip", "xs_format.h", "x6_common.h"]),
+    ("conv3x3_x6", ["conv3x3_x6.hip", "xs_format.h", "x6_common.h"]),
+    ("stem_x6", ["stem_x6.hip", "xs_format.h", "x6_common.h"]),
     ("conv_tail_bf16", ["conv_tail_bf16.hip", "x6_common.h"]),
     ("conv_tail_x6", ["conv_tail_x6.hip", "xs_format.h", "x6_common.h"]),
     ("ffn_bf16", ["ffn_bf16.hip"]),

@@ -16,6 +16,9 @@ import sqlite3
 KERNELS = {"ffn_x6_kernel": "ffn_x6_kernel<true", "proj_x6_kernel": "proj_x6_kernel",
            "gemm_split_bf16_f32": "gemm_split_bf16_f32", "rel_head_fwd_x6": "rel_head_fwd_x6",
            "wgrad_split_bf16_f32": "wgrad_split_bf16_f32", "enc_bwd_x6": "enc_bwd",
+           # backbone kernels of late round 6 (the layer-3 convolution, all tails, the stem)
+           "conv3x3_x6_ksplit_kernel": "conv3x3_x6_ksplit_kernel<256", "conv_tail_x6_kernel": "conv_tail_x6_kernel",
+           "stem_x6_kernel": "stem_x6_kernel",
            # bf16 model (stress workload, tools/profile_r05_stress.sh)
            "rel_head_fwd_bf16p": "rel_head_fwd_bf16p", "ffn_bf16_kernel": "ffn_bf16_kernel",
            "linear_bf16_rows32": "linear_bf16_rows32"}
