@@ -30,8 +30,8 @@ NHWC_F32 = os.environ.get("EGTR_BACKBONE_NHWC", "1") != "0"
 CONV3_FUSED = True        # module attributes (tests patch them for the switch-off twins)
 CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
 CONV1_X6 = True           # fp32 first 1x1 convolution of a block through the tail kernel ...
-CONV1_X6_WIDTHS = (64,)   # ... for these input widths: 7.3 us against the vendor GEMM's 16 at 64 -> 64 (layer 1, block 0); at
-                          # 256 / 512 input channels the two are level inside the forward (tools/conv2_ab.sh, SWITCH=CONV1_X6)
+CONV1_X6_SHAPES = ((64, 64),)   # ... for these (input channels, planes): 7 us against the vendor GEMM's 16 at 64 -> 64 (layer 1,
+                          # block 0); at 256 -> 64 and wider the two are level inside the forward (tools/conv2_ab.sh, SWITCH=CONV1_X6)
 FROZEN_PREFIX_NHWC = True  # training: the frozen stem + layer 1 through the channels-last inference kernels
 STEM_FUSED = True         # fp32 stem: 7x7 convolution + shift + ReLU + max-pool as csrc/stem_x6.hip
 CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
@@ -214,7 +214,7 @@ class Bottleneck(nn.Module):
         B, C, H, W_ = x.shape
         x2 = x.permute(0, 2, 3, 1).reshape(-1, C)                      # a view: channels-last IS [B*H*W, C]
         N1 = q["w1"].shape[0]
-        if (CONV1_X6 and ops.GEMM_SPLIT_BF16 and C in CONV1_X6_WIDTHS and ops.conv1x1_tail_supported(x2, N1)):
+        if (CONV1_X6 and ops.GEMM_SPLIT_BF16 and (C, N1) in CONV1_X6_SHAPES and ops.conv1x1_tail_supported(x2, N1)):
             # fp32, block inputs of up to 512 channels: the panel-resident split-bf16 kernel of the tail, here without input
             # shift and shortcut (csrc/conv_tail_x6.hip), instead of the vendor GEMM with its bias + ReLU epilogue
             if "w1xs" not in q:
