@@ -1109,7 +1109,10 @@ def invalidate_derived(model):
 # shapes take anyway).  tests/test_gpu_model.py::test_full_size_with_every_kept_switch_off_at_once_vs_reference runs the
 # combination of all of them.
 #   EGTR_DECODER_CLUSTER=0      decoder_fused.ENABLED       decoder layer: one launch per layer  ->  per-operation launches
-#   EGTR_GEMM_SPLIT_BF16=0      ops.GEMM_SPLIT_BF16         token-sized linears: split-bf16 matrix cores  ->  vendor fp32 GEMM
+#   EGTR_GEMM_SPLIT_BF16=0      ops.GEMM_SPLIT_BF16         token-sized linears: split-bf16 matrix cores  ->  vendor fp32 GEMM; also the
+#                                                           fp32 backbone's own split-bf16 kernels (stem, 3x3 convolutions, bottleneck
+#                                                           tails: backbone.STEM_FUSED / CONV2_X6 / CONV3_FUSED / CONV1_X6)  ->  MIOpen /
+#                                                           vendor GEMM + passes
 #   EGTR_REL_HEAD_SPLIT_BF16=0  ops.REL_HEAD_SPLIT_BF16     relation head at inference: split-bf16  ->  exact-f32 MFMA kernel
 #   EGTR_FFN_FUSED=0            ops.FFN_FUSED               encoder FFN / layer tail row-panel kernels  ->  separate launches
 #   EGTR_BACKBONE_NHWC=0        backbone.NHWC_F32 / _BF16   inference backbone channels-last  ->  NCHW
