@@ -31,9 +31,13 @@ struct StemArgs {
   int B, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y;
 };
 
-constexpr int kPH = 4, kPW = 8;                 // pooled pixels per workgroup
+#ifndef EGTR_STEM_PH
+#define EGTR_STEM_PH 4
+#endif
+constexpr int kPH = EGTR_STEM_PH, kPW = 8;      // pooled pixels per workgroup
 constexpr int kCH = 2 * kPH + 1, kCW = 2 * kPW + 1;   // convolution outputs per workgroup: 9 x 17
 constexpr int kCP = kCH * kCW;                  // 153
+constexpr int kMT = (kCP + 31) / 32;            // row tiles of 32 convolution pixels
 constexpr int kIH = 2 * kCH + 5, kIW = 40;      // input tile: 23 rows x 40 columns (2 * 17 + 5 = 39, + the padded tap)
 constexpr int kKS = 14;                         // k-steps: 7 kernel rows x 2
 constexpr int kPieceBytes = kIH * kIW * 4 * 2;  // one bf16 piece of the input tile: 7360 bytes
@@ -41,7 +45,7 @@ constexpr int kConvPitch = 64;                  // floats per convolution pixel 
 
 __global__ __launch_bounds__(256) void stem_x6_kernel(StemArgs A) {
   __shared__ __attribute__((aligned(16))) char s_in[3 * kPieceBytes];           // [piece][row][col][4] bf16
-  __shared__ __attribute__((aligned(16))) float s_conv[160 * kConvPitch];       // [conv pixel slot][64]
+  __shared__ __attribute__((aligned(16))) float s_conv[32 * kMT * kConvPitch];  // [conv pixel slot][64]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = blockIdx.x;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void stem_x6_kernel(StemArgs A) {
   // row tiles m = wave >> 1, + 2, + 4 (waves 0, 1: three of the five; waves 2, 3: two); lane -> convolution pixel slot 32 m + li
   const float bz = A.bias[nt * 32 + li];
 #pragma unroll 1
-  for (int m = wave >> 1; m < 5; m += 2) {
+  for (int m = wave >> 1; m < kMT; m += 2) {
     const int slot = 32 * m + li;
     const int cyl = min(slot, kCP - 1) / kCW, cxl = min(slot, kCP - 1) % kCW;   // (slots 153 .. 159 repeat the last pixel)
     const char* const pa = s_in + ((2 * cyl) * kIW + 2 * cxl) * 8 + hf * 16;
