@@ -32,6 +32,7 @@ CONV3_FUSED_BF16 = True   # the bf16 twin (csrc/conv_tail_bf16.hip)
 CONV1_X6 = True           # fp32 first 1x1 convolution of a block through the tail kernel ...
 CONV1_X6_SHAPES = ((64, 64),)   # ... for these (input channels, planes): 7 us against the vendor GEMM's 16 at 64 -> 64 (layer 1,
                           # block 0); at 256 -> 64 and wider the two are level inside the forward (tools/conv2_ab.sh, SWITCH=CONV1_X6)
+SHORTCUT_X6 = True        # fp32 stride-2 shortcut projections as the one-tap form of csrc/conv3x3_x6.hip
 FROZEN_PREFIX_NHWC = True  # training: the frozen stem + layer 1 through the channels-last inference kernels
 STEM_FUSED = True         # fp32 stem: 7x7 convolution + shift + ReLU + max-pool as csrc/stem_x6.hip
 CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
@@ -247,6 +248,12 @@ class Bottleneck(nn.Module):
             idt = x2
         elif q["wd"].dim() == 2:
             idt = torch.mm(x2, q["wd"].t())
+        elif (SHORTCUT_X6 and ops.GEMM_SPLIT_BF16 and tuple(self.downsample[0].stride) == (2, 2)
+              and ops.conv1x1_strided_supported(x, N3, 2)):
+            # fp32: the stride-2 shortcut projection through the one-tap form of the own convolution kernel (csrc/conv3x3_x6.hip)
+            if "wdxs" not in q:
+                q["wdxs"] = ops.xs_split(q["wd"].reshape(N3, C).contiguous(), weights=True)
+            idt = ops.conv1x1_strided(x, q["wdxs"], N3, 2)
         else:
             idt = F.conv2d(x, q["wd"], None, stride=self.downsample[0].stride).permute(0, 2, 3, 1).reshape(-1, N3)
         if (CONV3_FUSED and ops.GEMM_SPLIT_BF16 and ops.conv1x1_tail_supported(y2, N3) and idt.dtype == torch.float32

@@ -212,13 +212,16 @@ __global__ __launch_bounds__(64 * NWV) void conv3x3_x6_kernel(ConvArgs A) {
 // tile of CP channels is built, the 9 taps x CP / 16 k-steps of that phase are multiplied, the accumulators carry over.  The
 // weight stream is ordered to match: Wm[n][((ph * 3 + dy) * 3 + dx) * CP + c'] = W[n][ph * CP + c'][dy][dx]
 // (egtr_amd/ops.py::conv3x3_weights with `phase`).  One phase of k-steps is unrolled; the phases are a loop.
-template <int C, int CP, int STRIDE>
+// TAPS == 1: the same machinery as a 1x1 convolution with stride (a bottleneck's shortcut projection: no padding, the tile is
+// the 4 x 8 input pixels the outputs read, gathered with the stride; weights XS(W [N, C]) as they are).
+template <int C, int CP, int STRIDE, int TAPS = 9>
 __global__ __launch_bounds__(256) void conv3x3_x6_phased_kernel(ConvArgs A) {
   constexpr int TH = 4, TW = 8;
-  constexpr int HH = STRIDE * (TH - 1) + 3, HW_ = STRIDE * (TW - 1) + 3, HP = HH * HW_;
+  static_assert(TAPS == 9 || TAPS == 1, "3x3 or 1x1");
+  constexpr int HH = TAPS == 9 ? STRIDE * (TH - 1) + 3 : TH, HW_ = TAPS == 9 ? STRIDE * (TW - 1) + 3 : TW, HP = HH * HW_;
   constexpr int PH = C / CP;
   constexpr int KCP = CP / 16;            // k-steps per tap and phase
-  constexpr int KSP = 9 * KCP;            // k-steps per phase
+  constexpr int KSP = TAPS * KCP;         // k-steps per phase
   constexpr int KS = PH * KSP;
   constexpr int kPitch = CP + 8;
   constexpr int PF = EGTR_CONV_PF;
@@ -256,7 +259,8 @@ __global__ __launch_bounds__(256) void conv3x3_x6_phased_kernel(ConvArgs A) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const float* const xb = A.x + (size_t)b * A.H * A.W * C;
-  const __bf16* const pa = sA + (STRIDE * (li >> 3) * HW_ + STRIDE * (li & 7)) * kPitch + 8 * hf;
+  constexpr int PS = TAPS == 9 ? STRIDE : 1;   // pixel spacing of the outputs inside the tile
+  const __bf16* const pa = sA + (PS * (li >> 3) * HW_ + PS * (li & 7)) * kPitch + 8 * hf;
 
 #pragma unroll 1
   for (int ph = 0; ph < PH; ++ph) {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(256) void conv3x3_x6_phased_kernel(ConvArgs A) {
         for (int q = 0; q < CH; ++q) {
           const int idx = tid + 256 * (q0 + q);
           const int hp = idx / C4, c4 = idx % C4;
-          const int gy = iy0 + hp / HW_, gx = ix0 + hp % HW_;
+          const int gy = TAPS == 9 ? iy0 + hp / HW_ : STRIDE * (y0 + hp / HW_), gx = TAPS == 9 ? ix0 + hp % HW_ : STRIDE * (x0 + hp % HW_);
           const bool in = (q0 + q < NQ) && idx < CHUNKS && gy >= 0 && gy < A.H && gx >= 0 && gx < A.W;
           v[q] = f32x4v{0.f, 0.f, 0.f, 0.f};
           if (in) v[q] = *reinterpret_cast<const f32x4v*>(xb + ((size_t)gy * A.W + gx) * C + ph * CP + 4 * c4);
@@ -480,12 +484,12 @@ int launch_ksplit(hipStream_t st, ConvArgs A) {
   return egtr_check_launch();
 }
 
-template <int C, int CP, int STRIDE>
+template <int C, int CP, int STRIDE, int TAPS = 9>
 int launch_phased(hipStream_t st, ConvArgs A) {
   static unsigned long long raised = 0;
-  constexpr int HP = (STRIDE * 3 + 3) * (STRIDE * 7 + 3);
+  constexpr int HP = TAPS == 9 ? (STRIDE * 3 + 3) * (STRIDE * 7 + 3) : 32;
   constexpr int lds = 3 * HP * (CP + 8) * 2;
-  auto kern = conv3x3_x6_phased_kernel<C, CP, STRIDE>;
+  auto kern = conv3x3_x6_phased_kernel<C, CP, STRIDE, TAPS>;
   if (lds > 64 * 1024) {
     const int rc = egtr_raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, &raised);
     if (rc != EGTR_OK) return rc;
@@ -588,4 +592,24 @@ extern "C" int egtr_conv3x3_x6_f32(egtr_stream_t stream, const float* x, const v
   }
   if (variant == 1) return launch_phased<512, 128, 1>(st, A);
   return launch_ksplit<512, 128, 1>(st, A);
+}
+
+extern "C" int egtr_conv1x1_strided_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, float* y, int B, int H, int W,
+                                           int C, int N, int stride) {
+  if (!x || !w_xs || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return EGTR_E_ARG;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(w_xs) & 15) ||
+      N % 128 || (stride != 1 && stride != 2))
+    return EGTR_E_UNSUPPORTED;
+  ConvArgs A{x, static_cast<const char*>(w_xs), y, B, H, W, N, 0, 0};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stride == 2) {
+    if (C == 256) return launch_phased<256, 256, 2, 1>(st, A);
+    if (C == 512) return launch_phased<512, 256, 2, 1>(st, A);
+    if (C == 1024) return launch_phased<1024, 256, 2, 1>(st, A);
+    return EGTR_E_UNSUPPORTED;
+  }
+  if (C == 256) return launch_phased<256, 256, 1, 1>(st, A);
+  if (C == 512) return launch_phased<512, 256, 1, 1>(st, A);
+  if (C == 1024) return launch_phased<1024, 256, 1, 1>(st, A);
+  return EGTR_E_UNSUPPORTED;
 }

@@ -1695,6 +1695,26 @@ def conv3x3(x, w_xs, N, stride=1, variant=0):
     return y
 
 
+def conv1x1_strided_supported(x, N, stride):
+    """Shapes the strided 1x1 convolution serves (csrc/conv3x3_x6.hip, one tap): channels-last fp32 [B, C, H, W] with C in
+    {256, 512, 1024}, N a multiple of 128, stride 1 or 2."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and x.data_ptr() % 16 == 0 and x.shape[1] in (256, 512, 1024) and N % 128 == 0 and stride in (1, 2))
+
+
+def conv1x1_strided(x, w_xs, N, stride):
+    """1x1 convolution with stride (no padding, no bias) on a channels-last fp32 tensor in ONE HIP launch
+    (egtr_conv1x1_strided_x6_f32): a bottleneck's shortcut projection; ``w_xs`` = ``xs_split(W [N, C], weights=True)``.  Returns
+    the rows [B Ho Wo, N].  fp32-level accuracy.  Inference only."""
+    lib = _lib.lib()
+    B, C, H, W = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(B * Ho * Wo, N, dtype=torch.float32, device=x.device)
+    st = lib.egtr_conv1x1_strided_x6_f32(_stream(), x.data_ptr(), w_xs.data_ptr(), y.data_ptr(), B, H, W, C, N, int(stride))
+    _lib.check(st, "egtr_conv1x1_strided_x6_f32")
+    return y
+
+
 def conv1x1_tail_bf16_supported(a, N):
     """Shapes the bf16 bottleneck-tail kernel serves (csrc/conv_tail_bf16.hip): bf16 pixel rows with unit inner stride, K = planes
     in {64, 128, 256, 512}, N a multiple of 256."""

@@ -711,6 +711,14 @@ int egtr_conv3x3_phase_channels(int C, int N, int stride, int variant);
 int egtr_conv3x3_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, float* y, int B, int H, int W, int C, int N,
                         int stride, int variant);
 
+/* 1x1 convolution with stride 1 or 2 (no padding, no bias) on channels-last fp32 data: x [B, H, W, C] -> y [B, Ho, Wo, N],
+ * Ho = (H - 1) / stride + 1 -- the shortcut projection of a bottleneck that changes resolution (model/deformable_detr.py:735-760:
+ * timm ResNet-50 `downsample.0`; its folded batch-norm shift rides on the tail's shift3).  The machinery of egtr_conv3x3_x6_f32
+ * with one tap: the 4 x 8 input pixels a tile reads are gathered with the stride, channels in phases of 256; w_xs = XS(W [N, C])
+ * (egtr_xs_split_f32, round_to_nearest = 1).  C in {256, 512, 1024}, N % 128 == 0 (EGTR_E_UNSUPPORTED otherwise). */
+int egtr_conv1x1_strided_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, float* y, int B, int H, int W, int C, int N,
+                                int stride);
+
 /* The bf16 twin (the bf16 model of the stress configuration): a, shortcut, y bf16 (raw bits), shifts fp32, fp32 accumulation;
  *     y = act_out( bf16( act_in(a + a_shift) . W^T ) + bias + shortcut )
  * with the rounding points of the composition it replaces (the shifted + rectified input rounded to bf16, the product rounded

@@ -1984,3 +1984,22 @@ def test_stem_fused_nan_pixel_reaches_exactly_its_pool_windows():
     assert int(torch.isnan(ref).any(dim=1).sum()) in (4, 6, 9)   # a 7 x 7 window / stride 2, pooled 3 x 3 / stride 2
     ok = ~torch.isnan(ref)
     assert float((y[ok].double() - ref[ok]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("C,N", [(256, 512), (512, 1024), (1024, 2048), (256, 128)])
+@pytest.mark.parametrize("B,H,W,stride", [(1, 38, 63, 2), (2, 7, 9, 2), (1, 1, 1, 2), (1, 8, 16, 1), (2, 17, 33, 1)])
+def test_conv1x1_strided_matches_fp64_convolution(C, N, B, H, W, stride):
+    """The shortcut projection of a resolution-changing bottleneck (1x1 convolution, stride 2; stride 1 served as well) through
+    the one-tap form of the own convolution kernel against torch's fp64 convolution: odd sizes (the last row / column is read
+    or not), sizes below a tile, batches, every channel-phase count."""
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    torch.manual_seed(C + H + W)
+    x = torch.randn(B, C, H, W, device=DEV).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(N, C, 1, 1, device=DEV) / C ** 0.5
+    assert ops.conv1x1_strided_supported(x, N, stride)
+    y = ops.conv1x1_strided(x, ops.xs_split(w.reshape(N, C).contiguous(), weights=True), N, stride)
+    ref = F.conv2d(x.double(), w.double(), None, stride=stride).permute(0, 2, 3, 1).reshape(-1, N)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(y, ops.conv1x1_strided(x, ops.xs_split(w.reshape(N, C).contiguous(), weights=True), N, stride))

@@ -668,13 +668,27 @@ def test_backbone_fp32_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
         scale = max(1.0, float(b.abs().max()))
         assert float((a - b).abs().max()) < 5e-5 * scale
     monkeypatch.setattr(bb, "STEM_FUSED", True)
+    # ... and for the stride-2 shortcut projections of layers 2-4 (backbone.SHORTCUT_X6)
+    calls4 = []
+    real4 = ops.conv1x1_strided
+    monkeypatch.setattr(ops, "conv1x1_strided", lambda *a, **k: (calls4.append(a[0].shape[1]), real4(*a, **k))[1])
+    with torch.no_grad():
+        on = net(x)
+        assert calls4 == [256, 512, 1024]
+        monkeypatch.setattr(bb, "SHORTCUT_X6", False)
+        off = net(x)
+        assert len(calls4) == 3
+    for a, b in zip(on, off):
+        scale = max(1.0, float(b.abs().max()))
+        assert float((a - b).abs().max()) < 5e-5 * scale
+    monkeypatch.setattr(bb, "SHORTCUT_X6", True)
     # with the split-bf16 routes switched off as a group the kernels are not used either
     monkeypatch.setattr(bb, "CONV3_FUSED", True)
     monkeypatch.setattr(ops, "GEMM_SPLIT_BF16", False)
-    n_tail, n_conv, n_stem = len(calls), len(calls2), len(calls3)
+    n_tail, n_conv, n_stem, n_sc = len(calls), len(calls2), len(calls3), len(calls4)
     with torch.no_grad():
         net(x)
-    assert len(calls) == n_tail and len(calls2) == n_conv and len(calls3) == n_stem
+    assert len(calls) == n_tail and len(calls2) == n_conv and len(calls3) == n_stem and len(calls4) == n_sc
 
 
 def test_training_frozen_prefix_through_the_channels_last_kernels_matches_the_nchw_route(monkeypatch):
