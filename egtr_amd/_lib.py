@@ -104,6 +104,7 @@ SIGNATURES = {
                                                 _P, _I, _I, ctypes.c_float],
     "egtr_pad_batch_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "egtr_conv1x1_tail_x6_f32": [_P, _P, _I, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I],
+    "egtr_stem_conv7x7_pool_bf16": [_P, _P, _P, _P, _P, _I, _I, _I],
     "egtr_stem_conv7x7_pool_x6_f32": [_P, _P, _P, _P, _P, _I, _I, _I],
     "egtr_conv1x1_strided_x6_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I],
     "egtr_conv3x3_phase_channels": [_I, _I, _I, _I],

@@ -34,6 +34,7 @@ CONV1_X6_SHAPES = ((64, 64),)   # ... for these (input channels, planes): 7 us a
                           # block 0); at 256 -> 64 and wider the two are level inside the forward (tools/conv2_ab.sh, SWITCH=CONV1_X6)
 SHORTCUT_X6 = True        # fp32 stride-2 shortcut projections as the one-tap form of csrc/conv3x3_x6.hip
 FROZEN_PREFIX_NHWC = True  # training: the frozen stem + layer 1 through the channels-last inference kernels
+STEM_FUSED_BF16 = True    # the bf16 twin (csrc/stem_bf16.hip)
 STEM_FUSED = True         # fp32 stem: 7x7 convolution + shift + ReLU + max-pool as csrc/stem_x6.hip
 CONV2_X6 = True           # fp32 3x3 convolutions as csrc/conv3x3_x6.hip ...
 CONV2_X6_MAX_WIDTH = 512  # ... up to this width (all 16 of ResNet-50)
@@ -414,7 +415,15 @@ class ResNet50Features(nn.Module):
                         self._folded["nhwc"] = {li: [blk.folded_params_nhwc() for blk in getattr(self, f"layer{li}")]
                                                 for li in range(1, 5)}
                         self._folded["nhwc"]["stem"] = w.contiguous(memory_format=torch.channels_last)
-                if x.dtype == torch.bfloat16:
+                mp0 = self.maxpool
+                stem_std = (tuple(self.conv1.stride) == (2, 2) and tuple(self.conv1.padding) == (3, 3) and mp0.kernel_size == 3
+                            and mp0.stride == 2 and mp0.padding == 1 and mp0.dilation == 1 and not mp0.ceil_mode)
+                if x.dtype == torch.bfloat16 and STEM_FUSED_BF16 and stem_std and ops.stem_fused_bf16_supported(x, w):
+                    # bf16: convolution + shift + ReLU + pool in one launch, channels-last out (csrc/stem_bf16.hip)
+                    if "stem_pk" not in self._folded["nhwc"]:
+                        self._folded["nhwc"]["stem_pk"] = ops.stem_weights_bf16(w)
+                    x = ops.stem_fused_bf16(x, self._folded["nhwc"]["stem_pk"], b)
+                elif x.dtype == torch.bfloat16:
                     # channels-last from the pixels on: the stem convolution and the pool on channels-last tensors as well (the
                     # stem ran MIOpen's NHWC kernel between two layout transposes anyway), shift + ReLU on the pooled tensor
                     x = F.conv2d(x.contiguous(memory_format=torch.channels_last), self._folded["nhwc"]["stem"], None, stride=2,

@@ -1643,6 +1643,32 @@ def stem_weights(w):
     return xs_split(wm.reshape(64, 224), weights=True)
 
 
+def stem_weights_bf16(w):
+    """W [64, 3, 7, 7] bf16 (frozen BN scale folded in) -> the packed MFMA-operand stream of the bf16 stem kernel
+    (csrc/stem_bf16.hip): per kernel row 8 taps x 4 channels, the padded tap / channel zeros."""
+    wm = torch.zeros(64, 7, 8, 4, dtype=torch.bfloat16, device=w.device)
+    wm[:, :, :7, :3] = w.detach().permute(0, 2, 3, 1)
+    return conv_tail_pack_bf16(wm.reshape(64, 224).contiguous())
+
+
+def stem_fused_bf16_supported(x, w):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous()
+            and tuple(w.shape) == (64, 3, 7, 7) and w.dtype == torch.bfloat16)
+
+
+def stem_fused_bf16(x, w_packed, bias):
+    """The bf16 twin of ``stem_fused`` (egtr_stem_conv7x7_pool_bf16): x [B, 3, H, W] NCHW bf16 -> channels-last bf16
+    [B, 64, Hp, Wp]; ``bias`` fp32.  Inference only."""
+    lib = _lib.lib()
+    B, _, H, W = x.shape
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    y = torch.empty((B, 64, Hp, Wp), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    st = lib.egtr_stem_conv7x7_pool_bf16(_stream(), x.data_ptr(), w_packed.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W)
+    _lib.check(st, "egtr_stem_conv7x7_pool_bf16")
+    return y
+
+
 def stem_fused_supported(x, w):
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous()
             and tuple(w.shape) == (64, 3, 7, 7))

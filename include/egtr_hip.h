@@ -699,6 +699,13 @@ int egtr_conv1x1_tail_x6_f32(egtr_stream_t stream, const float* a, int lda, cons
 int egtr_stem_conv7x7_pool_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, const float* bias, float* y, int B,
                                   int H, int W);
 
+/* The bf16 twin of egtr_stem_conv7x7_pool_x6_f32 (the bf16 model of the stress configuration): x [B, 3, H, W] NCHW bf16 ->
+ * y [B, Hp, Wp, 64] channels-last bf16, fp32 accumulation, shift fp32; rounding points of the composition it replaces (bf16
+ * convolution output, shift + ReLU in fp32, one more rounding; the pool commutes).  w_packed = egtr_conv1x1_tail_pack_weights_bf16
+ * of Wm [64, 224] with Wm[n][ky * 32 + kx * 4 + c] = W[n][c][ky][kx], zeros at kx == 7 / c == 3 (egtr_amd.ops.stem_weights_bf16). */
+int egtr_stem_conv7x7_pool_bf16(egtr_stream_t stream, const uint16_t* x, const uint16_t* w_packed, const float* bias, uint16_t* y,
+                                int B, int H, int W);
+
 /* 3x3 convolution, stride 1 or 2, padding 1, no bias, channels-last fp32 (x [B, H, W, C] -> y [B, Ho, Wo, N], Ho = (H - 1) /
  * stride + 1) with the six-term split-bf16 arithmetic (error of an fp32 convolution): the middle convolution of a ResNet
  * bottleneck in inference (model/deformable_detr.py:735-760, timm ResNet-50; the folded batch norm's shift + ReLU is applied by

@@ -2003,3 +2003,31 @@ def test_conv1x1_strided_matches_fp64_convolution(C, N, B, H, W, stride):
     assert y.shape == ref.shape
     assert float((y.double() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert torch.equal(y, ops.conv1x1_strided(x, ops.xs_split(w.reshape(N, C).contiguous(), weights=True), N, stride))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 224, 320), (2, 61, 83), (1, 7, 9), (1, 1, 1), (3, 33, 37)])
+def test_stem_fused_bf16_matches_the_composition_it_replaces(B, H, W):
+    """The bf16 stem kernel (csrc/stem_bf16.hip) against fp64 arithmetic with its rounding points -- bf16 inputs / weights, the
+    convolution output rounded to bf16, shift + ReLU in fp32, max-pool, rounded once more -- to one bf16 ulp of the output scale
+    (the accumulation order differs, so a product on a rounding tie may flip), and against torch's bf16 convolution + pool +
+    the shift / ReLU pass it replaces."""
+    import torch.nn.functional as F
+    from egtr_amd import ops
+    torch.manual_seed(H + W)
+    x = torch.randn(B, 3, H, W, device=DEV).bfloat16()
+    w = (torch.randn(64, 3, 7, 7, device=DEV) / 147 ** 0.5).bfloat16()
+    b = torch.randn(64, device=DEV) * 0.3
+    assert ops.stem_fused_bf16_supported(x, w)
+    y = ops.stem_fused_bf16(x, ops.stem_weights_bf16(w), b)
+    conv = F.conv2d(x.double(), w.double(), None, stride=2, padding=3).bfloat16().double()
+    ref = F.max_pool2d(torch.relu(conv + b.double().view(1, -1, 1, 1)), 3, 2, 1).bfloat16()
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    scale = max(1.0, float(ref.float().abs().max()))
+    assert float((y.double() - ref.double()).abs().max()) <= 2.0 ** -7 * scale
+    assert float((y != ref).float().mean()) < 0.02
+    # the route it replaces
+    t = F.max_pool2d(F.conv2d(x.contiguous(memory_format=torch.channels_last), w.contiguous(memory_format=torch.channels_last),
+                              None, stride=2, padding=3), 3, 2, 1).contiguous(memory_format=torch.channels_last)
+    ops.bias_act_rows_(t.permute(0, 2, 3, 1).reshape(-1, 64), b)
+    assert float((y.float() - t.float()).abs().max()) <= 2.0 ** -6 * scale
+    assert torch.equal(y, ops.stem_fused_bf16(x, ops.stem_weights_bf16(w), b))

@@ -751,6 +751,20 @@ def test_backbone_bf16_bottleneck_tail_kernel_matches_pass_gemm_pass(monkeypatch
         assert a.shape == b.shape and a.dtype == torch.bfloat16 and a.is_contiguous(memory_format=torch.channels_last)
         scale = max(1.0, float(b.float().abs().max()))
         assert float((a.float() - b.float()).abs().max()) < 0.03 * scale
+    # the fused bf16 stem (backbone.STEM_FUSED_BF16) against torch's convolution + pool + the shift / ReLU pass
+    monkeypatch.setattr(bb, "CONV3_FUSED_BF16", True)
+    calls2 = []
+    real2 = ops.stem_fused_bf16
+    monkeypatch.setattr(ops, "stem_fused_bf16", lambda *a, **k: (calls2.append(1), real2(*a, **k))[1])
+    with torch.no_grad():
+        on = net(x)
+        assert len(calls2) == 1
+        monkeypatch.setattr(bb, "STEM_FUSED_BF16", False)
+        off = net(x)
+        assert len(calls2) == 1
+    for a, b in zip(on, off):
+        scale = max(1.0, float(b.float().abs().max()))
+        assert float((a.float() - b.float()).abs().max()) < 0.03 * scale
 
 
 def test_backbone_folded_path_bf16_matches_unfolded_bf16():

@@ -28,8 +28,8 @@ for i in 1 2; do
 done
 for i in 1 2; do
   for f in 0 1; do
-    echo "== CONV3_FUSED_BF16=$f run $i: stress forward (800x1333, N=300, 8 decoder layers, bf16, bs 16)"
-    python3 -c "import sys, runpy; import egtr_amd.backbone as b; b.CONV3_FUSED_BF16 = bool($f); sys.argv = ['stress_bench.py', '--iters', '10']; runpy.run_path('tools/stress_bench.py', run_name='__main__')" 2>&1 | grep -v amdgpu.ids | tail -2
+    echo "== ${BF16_SWITCH:-CONV3_FUSED_BF16}=$f run $i: stress forward (800x1333, N=300, 8 decoder layers, bf16, bs 16)"
+    python3 -c "import sys, runpy; import egtr_amd.backbone as b; b.${BF16_SWITCH:-CONV3_FUSED_BF16} = bool($f); sys.argv = ['stress_bench.py', '--iters', '10']; runpy.run_path('tools/stress_bench.py', run_name='__main__')" 2>&1 | grep -v amdgpu.ids | tail -2
   done
 done
 } > gpurun_out/conv3_ab.txt 2>&1
