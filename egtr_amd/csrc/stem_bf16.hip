@@ -32,13 +32,17 @@ struct StemArgs {
   int B, H, W, Hc, Wc, Hp, Wp, tiles_x, tiles_y;
 };
 
-constexpr int kPH = 4, kPW = 8;                       // pooled pixels per workgroup
+#ifndef EGTR_STEM_BF16_PH
+#define EGTR_STEM_BF16_PH 4
+#endif
+constexpr int kPH = EGTR_STEM_BF16_PH, kPW = 8;       // pooled pixels per workgroup
 constexpr int kCH = 2 * kPH + 1, kCW = 2 * kPW + 1;   // convolution outputs per workgroup: 9 x 17
 constexpr int kCP = kCH * kCW;                        // 153
 constexpr int kMT = (kCP + 31) / 32;                  // row tiles of 32 convolution pixels
 constexpr int kIH = 2 * kCH + 5, kIW = 40;            // input tile: 23 rows x 40 columns (2 * 17 + 5 = 39, + the padded tap)
 constexpr int kKS = 14;                               // k-steps: 7 kernel rows x 2
-constexpr int kConvPitch = 64;                        // floats per convolution pixel in LDS
+constexpr int kConvPitch = 64;                        // bf16 elements per convolution pixel in LDS (rounding is monotone: the
+                                                      // pool of the rounded values is the rounded pool)
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float(((unsigned)u) << 16); }
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
@@ -52,7 +56,7 @@ __device__ __forceinline__ float rbf(float a) { return __uint_as_float(pk_bf16(a
 
 __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs A) {
   __shared__ __attribute__((aligned(16))) unsigned short s_in[kIH * kIW * 4];       // [row][col][4] bf16
-  __shared__ __attribute__((aligned(16))) float s_conv[32 * kMT * kConvPitch];      // [conv pixel slot][64]
+  __shared__ __attribute__((aligned(16))) unsigned short s_conv[32 * kMT * kConvPitch];   // [conv pixel slot][64] bf16
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int t = blockIdx.x;
@@ -65,61 +69,89 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs A) {
   const int nt = wave & 1;
   const unsigned short* const wlane = A.w + ((size_t)nt * kKS * 64 + lane) * 8;
 
-  // input tile: item = (channel c, row r, column quad q); the fourth channel of every pixel is a zero
-  for (int it = tid; it < 3 * kIH * (kIW / 4); it += 256) {
-    const int q = it % (kIW / 4), r = (it / (kIW / 4)) % kIH, c = it / ((kIW / 4) * kIH);
-    const int gy = iy0 + r;
+  // input tile: item = one element (channel c, row r, column x), consecutive threads on consecutive columns of a row (a wave's
+  // load covers 1.6 rows of 80 bytes); all requests of a thread first, then the LDS stores; the fourth channel is a zero
+  {
+    constexpr int NE = 3 * kIH * kIW, NQ = (NE + 255) / 256;
+    unsigned short v[NQ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int gx = ix0 + 4 * q + j;
-      const unsigned short v = (gy >= 0 && gy < A.H && gx >= 0 && gx < A.W) ? A.x[((size_t)(b * 3 + c) * A.H + gy) * A.W + gx]
-                                                                             : (unsigned short)0;
-      s_in[(r * kIW + 4 * q + j) * 4 + c] = v;
+    for (int k = 0; k < NQ; ++k) {
+      const int it = tid + 256 * k;
+      const int xx = it % kIW, r = (it / kIW) % kIH, c = it / (kIW * kIH);
+      const int gy = iy0 + r, gx = ix0 + xx;
+      v[k] = (it < NE && gy >= 0 && gy < A.H && gx >= 0 && gx < A.W) ? A.x[((size_t)(b * 3 + c) * A.H + gy) * A.W + gx]
+                                                                     : (unsigned short)0;
+    }
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int it = tid + 256 * k;
+      if (it < NE) {
+        const int xx = it % kIW, r = (it / kIW) % kIH, c = it / (kIW * kIH);
+        s_in[(r * kIW + xx) * 4 + c] = v[k];
+      }
     }
   }
   for (int it = tid; it < kIH * kIW; it += 256) s_in[it * 4 + 3] = 0;
   __syncthreads();
 
+  // k-steps outside, this wave's row tiles (m = wave >> 1, + 2, ...) inside: a weight fragment is loaded ONCE per wave (all 14
+  // up front: 56 registers) and feeds every row tile; the row tiles' accumulators are independent MFMA chains
   const float bz = A.bias[nt * 32 + li];
-#pragma unroll 1
-  for (int m = wave >> 1; m < kMT; m += 2) {
-    const int slot = 32 * m + li;
-    const int cyl = min(slot, kCP - 1) / kCW, cxl = min(slot, kCP - 1) % kCW;
-    const char* const pa = reinterpret_cast<const char*>(s_in) + ((2 * cyl) * kIW + 2 * cxl) * 8 + hf * 16;
-    f32x16 acc;
+  constexpr int MW = (kMT + 1) / 2;                   // row tiles per wave (the odd group may have one less)
+  bf16x8 w[kKS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    static_for<kKS>([&](auto ks_) {
-      constexpr int ks = decltype(ks_)::value;
-      constexpr int ky = ks >> 1, h = ks & 1;
-      // k = ky * 32 + 16 h + 8 hf + (0 .. 7) = taps kx = 4 h + 2 hf, + 1 (4 channels each) of kernel row ky
-      bf16x8 a = *reinterpret_cast<const bf16x8*>(pa + (ky * kIW + 4 * h) * 8);
-      const bf16x8 w = *reinterpret_cast<const bf16x8*>(wlane + (size_t)ks * (64 * 8));
-      if constexpr (h == 1) {
-        // lanes of the upper k-group hold taps 6 and 7: the padded tap's weights are zeros, but 0 x (a non-finite neighbour
-        // pixel) would be NaN -- a pixel must reach exactly the windows that contain it: blank those four elements
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 u = __builtin_bit_cast(u32x4, a);
-        u.z = hf ? 0u : u.z;
-        u.w = hf ? 0u : u.w;
-        a = __builtin_bit_cast(bf16x8, u);
+  for (int ks = 0; ks < kKS; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(wlane + (size_t)ks * (64 * 8));
+  const char* pa[MW];
+  f32x16 acc[MW];
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int slot = min(32 * ((wave >> 1) + 2 * i) + li, kCP - 1);
+    pa[i] = reinterpret_cast<const char*>(s_in) + ((2 * (slot / kCW)) * kIW + 2 * (slot % kCW)) * 8 + hf * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  }
+  static_for<kKS>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    constexpr int ky = ks >> 1, h = ks & 1;
+    // k = ky * 32 + 16 h + 8 hf + (0 .. 7) = taps kx = 4 h + 2 hf, + 1 (4 channels each) of kernel row ky
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      if ((wave >> 1) + 2 * i < kMT) {                // (wave-uniform)
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(pa[i] + (ky * kIW + 4 * h) * 8);
+        if constexpr (h == 1) {
+          // lanes of the upper k-group hold taps 6 and 7: the padded tap's weights are zeros, but 0 x (a non-finite neighbour
+          // pixel) would be NaN -- a pixel must reach exactly the windows that contain it: blank those four elements
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          u32x4 u = __builtin_bit_cast(u32x4, a);
+          u.z = hf ? 0u : u.z;
+          u.w = hf ? 0u : u.w;
+          a = __builtin_bit_cast(bf16x8, u);
+        }
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w[ks], acc[i], 0, 0, 0);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc, 0, 0, 0);
-    });
-    // D[i = pixel slot][j = channel]: lane l holds channel l & 31, accumulator r slot (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    }
+  });
+  // D[i = pixel slot][j = channel]: lane l holds channel l & 31, accumulator r slot (r & 3) + 8 (r >> 2) + 4 (l >> 5)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int s2 = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hf;
-      const int cy = cy0 + s2 / kCW, cx = cx0 + s2 % kCW;
-      const bool valid = s2 < kCP && cy >= 0 && cy < A.Hc && cx >= 0 && cx < A.Wc;
-      s_conv[s2 * kConvPitch + nt * 32 + li] = valid ? egtr_relu(rbf(acc[r]) + bz) : 0.f;   // (the convolution as bf16 stored it)
+  for (int i = 0; i < MW; ++i) {
+    const int m = (wave >> 1) + 2 * i;
+    if (m < kMT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int s2 = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const int cy = cy0 + s2 / kCW, cx = cx0 + s2 % kCW;
+        const bool valid = s2 < kCP && cy >= 0 && cy < A.Hc && cx >= 0 && cx < A.Wc;
+        // (the convolution as bf16 stored it, then shift + ReLU in fp32, rounded)
+        s_conv[s2 * kConvPitch + nt * 32 + li] =
+            valid ? (unsigned short)(pk_bf16(egtr_relu(rbf(acc[i][r]) + bz), 0.f) & 0xffffu) : (unsigned short)0;
+      }
     }
   }
   __syncthreads();
 
   // pool: item = (pooled pixel, channel octet): 32 x 8 = one per thread
-  {
-    const int c8 = tid & 7, pp = tid >> 3;
+  for (int it = tid; it < kPH * kPW * 8; it += 256) {
+    const int c8 = it & 7, pp = it >> 3;
     const int pyl = pp / kPW, pxl = pp % kPW;
     const int py = py0 + pyl, px = px0 + pxl;
     if (py < A.Hp && px < A.Wp) {
@@ -128,9 +160,10 @@ __global__ __launch_bounds__(256) void stem_bf16_kernel(StemArgs A) {
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-          const float* p = &s_conv[((2 * pyl + dy) * kCW + 2 * pxl + dx) * kConvPitch + 8 * c8];
-          const float4 v0 = *reinterpret_cast<const float4*>(p), v1 = *reinterpret_cast<const float4*>(p + 4);
-          const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const uint4 u = *reinterpret_cast<const uint4*>(&s_conv[((2 * pyl + dy) * kCW + 2 * pxl + dx) * kConvPitch + 8 * c8]);
+          const float v[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                              __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                              __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
 #pragma unroll
           for (int k = 0; k < 8; ++k) mx[k] = (v[k] > mx[k] || v[k] != v[k]) ? v[k] : mx[k];   // NaN propagates as in torch
         }

@@ -10,8 +10,9 @@
 // tile parked in LDS as [row][column][4 channels] bf16, the 8 consecutive k of an MFMA operand are two neighbouring input pixels:
 // one aligned 16-byte read at a per-lane base plus an immediate.
 //
-// A workgroup (4 waves) owns 4 x 8 POOLED pixels x 64 channels: the 9 x 17 convolution outputs they cover (160 slots = 5 row
-// tiles of 32 x 2 channel tiles, dealt to the waves), from a 23 x 40 input tile.  Convolution outputs + shift, ReLU -> LDS (fp32,
+// A workgroup (4 waves) owns 3 x 8 POOLED pixels x 64 channels: the 7 x 17 convolution outputs they cover (128 slots = 4 row
+// tiles of 32 x 2 channel tiles: two per wave), from a 19 x 40 input tile (4 pooled rows = 5 row tiles deal 3 : 2 over the waves
+// and measure 47 us against 44.5; tools/stem_variants.sh).  Convolution outputs + shift, ReLU -> LDS (fp32,
 // zeros outside the image: a pool window always holds a valid value >= 0), then the pool reads 3 x 3 of them per output.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,22 +33,35 @@ struct StemArgs {
 };
 
 #ifndef EGTR_STEM_PH
-#define EGTR_STEM_PH 4
+#define EGTR_STEM_PH 3
 #endif
 constexpr int kPH = EGTR_STEM_PH, kPW = 8;      // pooled pixels per workgroup
-constexpr int kCH = 2 * kPH + 1, kCW = 2 * kPW + 1;   // convolution outputs per workgroup: 9 x 17
-constexpr int kCP = kCH * kCW;                  // 153
+constexpr int kCH = 2 * kPH + 1, kCW = 2 * kPW + 1;   // convolution outputs per workgroup: 7 x 17
+constexpr int kCP = kCH * kCW;                  // 119
 constexpr int kMT = (kCP + 31) / 32;            // row tiles of 32 convolution pixels
-constexpr int kIH = 2 * kCH + 5, kIW = 40;      // input tile: 23 rows x 40 columns (2 * 17 + 5 = 39, + the padded tap)
+constexpr int kIH = 2 * kCH + 5, kIW = 40;      // input tile: 19 rows x 40 columns (2 * 17 + 5 = 39, + the padded tap)
 constexpr int kKS = 14;                         // k-steps: 7 kernel rows x 2
 constexpr int kPieceBytes = kIH * kIW * 4 * 2;  // one bf16 piece of the input tile: 7360 bytes
 constexpr int kConvPitch = 64;                  // floats per convolution pixel in LDS
+
+#ifdef EGTR_STEM_TIMING
+// debugging aid (tools/stem_timing.sh): per workgroup of the last launch, real-time counter at entry / exit and shader-clock stamps
+constexpr int kRecWg = 4096;
+__device__ unsigned long long g_stem_rec[kRecWg][8];
+#define STEM_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define STEM_T(v) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256) void stem_x6_kernel(StemArgs A) {
   __shared__ __attribute__((aligned(16))) char s_in[3 * kPieceBytes];           // [piece][row][col][4] bf16
   __shared__ __attribute__((aligned(16))) float s_conv[32 * kMT * kConvPitch];  // [conv pixel slot][64]
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef EGTR_STEM_TIMING
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  STEM_T(t0);
   int t = blockIdx.x;
   const int tx = t % A.tiles_x;
   t /= A.tiles_x;
@@ -85,52 +99,80 @@ __global__ __launch_bounds__(256) void stem_x6_kernel(StemArgs A) {
     const int piece = it / (kIH * kIW), px = it % (kIH * kIW);
     reinterpret_cast<unsigned short*>(s_in)[piece * (kPieceBytes / 2) + px * 4 + 3] = 0;
   }
+  STEM_T(t1);
   __syncthreads();
+  STEM_T(t2);
 
-  // row tiles m = wave >> 1, + 2, + 4 (waves 0, 1: three of the five; waves 2, 3: two); lane -> convolution pixel slot 32 m + li
+  // k-steps outside, this wave's row tiles (m = wave >> 1, + 2, + 4: waves 0, 1 three of the five, waves 2, 3 two) inside: a
+  // weight fragment is loaded once per wave and k-step (not once per row tile), PF k-steps ahead; the row tiles' accumulators are
+  // independent MFMA chains.  (Row tiles outside, fragments loaded where used: 11.7 of a workgroup's 17.3 us were this loop.)
   const float bz = A.bias[nt * 32 + li];
-#pragma unroll 1
-  for (int m = wave >> 1; m < kMT; m += 2) {
-    const int slot = 32 * m + li;
-    const int cyl = min(slot, kCP - 1) / kCW, cxl = min(slot, kCP - 1) % kCW;   // (slots 153 .. 159 repeat the last pixel)
-    const char* const pa = s_in + ((2 * cyl) * kIW + 2 * cxl) * 8 + hf * 16;
-    f32x16 acc;
+  constexpr int MW = (kMT + 1) / 2, PF = 3;
+  bf16x8 w[PF + 1][3];
+  auto load_w = [&](int ks, bf16x8 (&dst)[3]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    static_for<kKS>([&](auto ks_) {
-      constexpr int ks = decltype(ks_)::value;
-      constexpr int ky = ks >> 1, h = ks & 1;
-      // k = ky * 32 + 16 h + 8 hf + (0 .. 7) = taps kx = 4 h + 2 hf, + 1 (4 channels each) of kernel row ky
-      bf16x8 a[3], w[3];
+    for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)ks * 3 + p) * xs::kFragBytes);
+  };
+  static_for<PF>([&](auto i_) {
+    constexpr int i = decltype(i_)::value;
+    load_w(i, w[i]);
+  });
+  const char* pa[MW];
+  f32x16 acc[MW];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        a[p] = *reinterpret_cast<const bf16x8*>(pa + p * kPieceBytes + (ky * kIW + 4 * h) * 8);
-        w[p] = *reinterpret_cast<const bf16x8*>(wlane + ((size_t)ks * 3 + p) * xs::kFragBytes);
-      }
-      if constexpr (h == 1) {
-        // lanes of the upper k-group hold taps 6 and 7: the padded tap's weights are zeros, but 0 x (a non-finite neighbour
-        // pixel) would be NaN -- a pixel must reach exactly the windows that contain it: blank those four elements
+  for (int i = 0; i < MW; ++i) {
+    const int slot = min(32 * ((wave >> 1) + 2 * i) + li, kCP - 1);   // (slots 153 .. 159 repeat the last pixel)
+    pa[i] = s_in + ((2 * (slot / kCW)) * kIW + 2 * (slot % kCW)) * 8 + hf * 16;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          u32x4 u = __builtin_bit_cast(u32x4, a[p]);
-          u.z = hf ? 0u : u.z;
-          u.w = hf ? 0u : u.w;
-          a[p] = __builtin_bit_cast(bf16x8, u);
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  }
+  static_for<kKS>([&](auto ks_) {
+    constexpr int ks = decltype(ks_)::value;
+    constexpr int ky = ks >> 1, h = ks & 1;
+    if constexpr (ks + PF < kKS) {
+      load_w(ks + PF, w[(ks + PF) % (PF + 1)]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // k = ky * 32 + 16 h + 8 hf + (0 .. 7) = taps kx = 4 h + 2 hf, + 1 (4 channels each) of kernel row ky
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      if ((wave >> 1) + 2 * i < kMT) {                // (wave-uniform)
+        bf16x8 a[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(pa[i] + p * kPieceBytes + (ky * kIW + 4 * h) * 8);
+        if constexpr (h == 1) {
+          // lanes of the upper k-group hold taps 6 and 7: the padded tap's weights are zeros, but 0 x (a non-finite neighbour
+          // pixel) would be NaN -- a pixel must reach exactly the windows that contain it: blank those four elements
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 u = __builtin_bit_cast(u32x4, a[p]);
+            u.z = hf ? 0u : u.z;
+            u.w = hf ? 0u : u.w;
+            a[p] = __builtin_bit_cast(bf16x8, u);
+          }
         }
+        acc[i] = mfma6(a, w[ks % (PF + 1)], acc[i]);
       }
-      acc = mfma6(a, w, acc);
-    });
-    // D[i = pixel slot][j = channel]: lane l holds channel l & 31, accumulator r slot (r & 3) + 8 (r >> 2) + 4 (l >> 5)
+    }
+  });
+  // D[i = pixel slot][j = channel]: lane l holds channel l & 31, accumulator r slot (r & 3) + 8 (r >> 2) + 4 (l >> 5)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int s2 = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hf;
-      const int cy = cy0 + s2 / kCW, cx = cx0 + s2 % kCW;
-      const bool valid = s2 < kCP && cy >= 0 && cy < A.Hc && cx >= 0 && cx < A.Wc;
-      s_conv[s2 * kConvPitch + nt * 32 + li] = valid ? egtr_relu(acc[r] + bz) : 0.f;
+  for (int i = 0; i < MW; ++i) {
+    const int m = (wave >> 1) + 2 * i;
+    if (m < kMT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int s2 = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        const int cy = cy0 + s2 / kCW, cx = cx0 + s2 % kCW;
+        const bool valid = s2 < kCP && cy >= 0 && cy < A.Hc && cx >= 0 && cx < A.Wc;
+        s_conv[s2 * kConvPitch + nt * 32 + li] = valid ? egtr_relu(acc[i][r] + bz) : 0.f;
+      }
     }
   }
+  STEM_T(t3);
   __syncthreads();
+  STEM_T(t4);
 
   // pool: item = (pooled pixel, channel quad): 32 x 16
   for (int it = tid; it < kPH * kPW * 16; it += 256) {
@@ -152,9 +194,30 @@ __global__ __launch_bounds__(256) void stem_x6_kernel(StemArgs A) {
       }
     *reinterpret_cast<float4*>(A.y + (((size_t)b * A.Hp + py) * A.Wp + px) * 64 + 4 * c4) = mx;
   }
+#ifdef EGTR_STEM_TIMING
+  STEM_T(t5);
+  if (tid == 0 && blockIdx.x < kRecWg) {
+    unsigned long long* r = g_stem_rec[blockIdx.x];
+    r[0] = rt0;
+    r[1] = __builtin_amdgcn_s_memrealtime();
+    r[2] = t1 - t0;   // input tile
+    r[3] = t2 - t1;   // barrier
+    r[4] = t3 - t2;   // products + outputs to LDS
+    r[5] = t4 - t3;   // barrier
+    r[6] = t5 - t4;   // pool + stores
+    r[7] = 1;
+  }
+#endif
 }
 
 }  // namespace
+
+#ifdef EGTR_STEM_TIMING
+extern "C" int egtr_stem_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stem_rec), sizeof(unsigned long long) * kRecWg * 8) == hipSuccess ? EGTR_OK
+                                                                                                                  : EGTR_E_LAUNCH;
+}
+#endif
 
 extern "C" int egtr_stem_conv7x7_pool_x6_f32(egtr_stream_t stream, const float* x, const void* w_xs, const float* bias, float* y,
                                              int B, int H, int W) {
